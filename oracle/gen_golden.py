@@ -1,0 +1,161 @@
+"""Generates tests/golden/*.json|npz by RUNNING THE REFERENCE (dev container only).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Imports the reference's Dataset / Sampler /
+Evaluation code through the recipe of oracle/ref_import.py (TensorFlow stubbed — none of the code
+exercised here touches TensorFlow) and records inputs + the reference's outputs.  The fixtures are
+data only; no reference source is copied.  Run:  python oracle/gen_golden.py
+
+What is pinned:
+  idmap.json ............ assign_internal_ids            (mem_dataset.py:309-330)
+  point_sampler.json .... PointSampler.sample streams    (point_sampler.py:44-61), plus the reference's own
+                          known answers null_interaction_pair_generator(seed=23) -> (1,0),(0,2),(1,3),(0,1)
+                          (tests/Dataset/test_mem_dataset.py:678-697)
+  list_sampler.json ..... ListSampler.sample_group_records as Caser configures it (caser.py:72-75)
+  interaction_vecs.json . select_user_interaction_vec / select_item_interaction_vec rows
+  frames.npz ............ the seeded synthetic input frames used above
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+RES = '/root/reference/tests/Dataset/resources'
+
+
+def _py(x):
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.floating,)):
+        return float(x)
+    if isinstance(x, (list, tuple)):
+        return [_py(v) for v in x]
+    return x
+
+
+def synth_frame(seed, n_users, n_items, n_rows, string_users, gapped_items, with_ts, dup_frac=0.0):
+    r = np.random.RandomState(seed)
+    u = r.randint(0, n_users, size=n_rows)
+    pop = 1.0 / np.arange(1, n_items + 1)
+    pop /= pop.sum()
+    i = r.choice(n_items, size=n_rows, p=pop)
+    if dup_frac == 0.0:                      # unique (u,i) pairs, like MovieLens
+        _, first = np.unique(u.astype(np.int64) * n_items + i, return_index=True)
+        first.sort()
+        u, i = u[first], i[first]
+    val = r.randint(0, 6, size=len(u)).astype(np.int64)      # 0..5, zeros exercise the threshold
+    users = np.array([f'user_{x:04d}' for x in u]) if string_users else (u + 1).astype(np.int64)
+    items = (i * 3 + 7).astype(np.int64) if gapped_items else (i + 1).astype(np.int64)
+    f = {'user': users, 'item': items, 'interaction': val}
+    if with_ts:
+        f['timestamp'] = r.randint(0, 10 ** 6, size=len(u)).astype(np.int64)
+    return f
+
+
+def main():
+    warnings.filterwarnings('ignore')
+    from ref_import import import_reference
+    import_reference()
+    import pandas as pd
+    from DRecPy.Dataset import InteractionDataset
+    from DRecPy.Sampler import PointSampler, ListSampler
+
+    os.makedirs(OUT, exist_ok=True)
+    frames = {
+        'pt_str_gapped': synth_frame(1, 300, 500, 9000, True, True, False),
+        'pt_int_dense': synth_frame(2, 64, 40, 1500, False, False, False),     # dense: many rejections
+        'ls_int_ts': synth_frame(3, 120, 400, 7000, False, True, True),
+    }
+    np.savez_compressed(os.path.join(OUT, 'frames.npz'),
+                        **{f'{k}__{c}': v for k, f in frames.items() for c, v in f.items()})
+
+    def ds_of(frame):
+        ds = InteractionDataset.read_df(pd.DataFrame(frame), verbose=False)
+        ds.assign_internal_ids()
+        return ds
+
+    # ---- id maps --------------------------------------------------------------------------
+    idmap = {}
+    for name in ('test.csv', 'test_floats.csv', 'test_int_ids.csv'):
+        ds = InteractionDataset(os.path.join(RES, name), columns=['user', 'item', 'interaction'],
+                                has_header=True, verbose=False)
+        ds.assign_internal_ids()
+        rows = ds.values_list(['user', 'item', 'interaction', 'uid', 'iid'], to_list=True)
+        idmap[name] = {'user': [_py(r[0]) for r in rows], 'item': [_py(r[1]) for r in rows],
+                       'interaction': [_py(r[2]) for r in rows],
+                       'uid': [_py(r[3]) for r in rows], 'iid': [_py(r[4]) for r in rows],
+                       'user_to_uid': {str(k): _py(v) for k, v in ds._user_mapping.items()},
+                       'item_to_iid': {str(k): _py(v) for k, v in ds._item_mapping.items()}}
+    for k, f in frames.items():
+        ds = ds_of(f)
+        idmap[k] = {'uid': [int(x) for x in ds._df['uid'].values],
+                    'iid': [int(x) for x in ds._df['iid'].values],
+                    'n_users': int(ds.count_unique('uid')), 'n_items': int(ds.count_unique('iid')),
+                    'probe_user_to_uid': [[_py(u), _py(ds.user_to_uid(u))] for u in f['user'][:20].tolist()]
+                    + [['no_such_user' if f['user'].dtype.kind == 'U' else -5,
+                        _py(ds.user_to_uid('no_such_user' if f['user'].dtype.kind == 'U' else -5))]],
+                    'probe_iid_to_item': [[i, _py(ds.iid_to_item(i))] for i in range(10)]}
+    json.dump(idmap, open(os.path.join(OUT, 'idmap.json'), 'w'))
+
+    # ---- PointSampler streams ----------------------------------------------------------------
+    ps = {}
+    ds = InteractionDataset(os.path.join(RES, 'test.csv'), columns=['user', 'item', 'interaction'],
+                            has_header=True, verbose=False)
+    ds.assign_internal_ids()
+    ps['test.csv|5|0.001|10'] = [_py(list(t)) for t in PointSampler(ds, 5, 0.001, 10).sample(64)]
+    g = ds.null_interaction_pair_generator(seed=23)
+    ps['test.csv|null_pair_gen|seed23'] = [_py(list(next(g))) for _ in range(16)]
+    g = ds.select_random_generator(seed=23)
+    ps['test.csv|select_random_gen|seed23'] = [[_py(r['uid']), _py(r['iid']), _py(r['interaction'])]
+                                               for r in (next(g) for _ in range(16))]
+    for k, cfgs in (('pt_str_gapped', [(5, 0.001, 10, 600), (1, 3, 7, 300), (5, None, 123, 300)]),
+                    ('pt_int_dense', [(5, 0.001, 10, 400), (2, 4, 0, 300)])):
+        ds = ds_of(frames[k])
+        for neg, thr, seed, n in cfgs:
+            s = PointSampler(ds, neg, thr, seed)
+            a = s.sample(n // 2)
+            a += s.sample(n - n // 2)            # two calls: generators keep their state
+            ps[f'{k}|{neg}|{thr}|{seed}'] = [_py(list(t)) for t in a]
+    json.dump(ps, open(os.path.join(OUT, 'point_sampler.json'), 'w'))
+
+    # ---- ListSampler streams (Caser configuration, caser.py:72-75) --------------------------------
+    ls = {}
+    ds = ds_of(frames['ls_int_ts'])
+    for (L, T, neg, thr, seed, n) in ((5, 3, 2, 0.001, 10, 150), (3, 2, 3, 2, 5, 100)):
+        s = ListSampler(ds, ['uid'], neg_ratio=neg, n_targets=T, interaction_threshold=thr,
+                        negative_ids_col='iid', min_positive_records=L, max_positive_records=L,
+                        sort_column='timestamp', seed=seed)
+        recs = s.sample_group_records(n)
+        ls[f'{L}|{T}|{neg}|{thr}|{seed}'] = [
+            {'uid': _py(b[0]['uid']), 'before': [_py(r['iid']) for r in b], 'after': [_py(r['iid']) for r in a],
+             'before_rid': [_py(r['rid']) for r in b], 'after_rid': [_py(r['rid']) for r in a],
+             'neg': [_py(x) for x in ng]}
+            for b, a, ng in recs]
+    json.dump(ls, open(os.path.join(OUT, 'list_sampler.json'), 'w'))
+
+    # ---- interaction vectors -------------------------------------------------------------------
+    iv = {}
+    for k in ('pt_str_gapped', 'pt_int_dense'):
+        ds = ds_of(frames[k])
+        iv[k] = {'user': {}, 'item': {}}
+        for uid in (0, 1, 5, 17, 63):
+            v = ds.select_user_interaction_vec(uid)
+            iv[k]['user'][str(uid)] = {'idx': [int(x) for x in v.indices.tolist()],
+                                       'val': [float(x) for x in v.data.tolist()], 'n': int(v.shape[1])}
+        for iid in (0, 2, 11, 39):
+            v = ds.select_item_interaction_vec(iid).tocsr()
+            v.sort_indices()
+            iv[k]['item'][str(iid)] = {'idx': [int(x) for x in v.indices.tolist()],
+                                       'val': [float(x) for x in v.data.tolist()], 'n': int(v.shape[1])}
+    json.dump(iv, open(os.path.join(OUT, 'interaction_vecs.json'), 'w'))
+    print('golden fixtures written to', OUT)
+    for fn in sorted(os.listdir(OUT)):
+        print(' ', fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == '__main__':
+    main()
