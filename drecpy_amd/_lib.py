@@ -1,0 +1,110 @@
+"""ctypes binding of libdrx.so (the C ABI declared in include/drx.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+PyTorch tensors are only the device-memory container — their `data_ptr()`s are what crosses the ABI.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdrx.so')
+
+LOSS_BCE, LOSS_MSE = 0, 1
+TARGETS_REFERENCE, TARGETS_PER_ROW = 0, 1
+OPT_ADAM, OPT_ADAGRAD = 0, 1
+KEY_NONE = 0xFFFFFFFF
+
+
+class DrxError(RuntimeError):
+    pass
+
+
+class CdaeParams(C.Structure):
+    _fields_ = [('n_users', C.c_int32), ('n_items', C.c_int32), ('k', C.c_int32), ('ld', C.c_int32),
+                ('W', C.c_void_p), ('W2T', C.c_void_p), ('V', C.c_void_p), ('b', C.c_void_p), ('b2', C.c_void_p)]
+
+
+class History(C.Structure):
+    _fields_ = [('indptr', C.c_void_p), ('indices', C.c_void_p)]
+
+
+class Batch(C.Structure):
+    _fields_ = [('B', C.c_int32), ('uid', C.c_void_p), ('iid', C.c_void_p), ('y', C.c_void_p),
+                ('keep_off', C.c_void_p), ('keep', C.c_void_p), ('mask_seed', C.c_uint64), ('q', C.c_float),
+                ('n_touch_slots', C.c_int32)]
+
+
+class Optim(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('lr', C.c_float), ('reg_rate', C.c_float), ('beta1', C.c_float),
+                ('beta2', C.c_float), ('eps', C.c_float), ('alpha', C.c_float * 5),
+                ('s1', C.c_void_p * 5), ('s2', C.c_void_p * 5)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol declared in include/drx.h
+SIGNATURES = {
+    'drx_version': (C.c_int, []),
+    'drx_strerror': (C.c_char_p, [C.c_int]),
+    'drx_hash_u32': (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32]),
+    'drx_cdae_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    'drx_cdae_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32]),
+    'drx_cdae_step_dense': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch),
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    'drx_cdae_step_sparse': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch),
+                                       C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                           C.c_void_p]),
+    'drx_idmap_scratch_bytes': (C.c_size_t, [C.c_int64]),
+    'drx_idmap_build': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
+    'drx_sampler_create': (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_double, C.c_int64]),
+    'drx_sampler_sample': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'drx_sampler_destroy': (None, [C.c_void_p]),
+    'drx_rng_create': (C.c_void_p, [C.c_int64]),
+    'drx_rng_destroy': (None, [C.c_void_p]),
+    'drx_rng_random': (C.c_double, [C.c_void_p]),
+    'drx_rng_randint': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64]),
+    'drx_rng_corruption_keep': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                          C.c_double, C.c_void_p, C.c_void_p, C.c_int64]),
+}
+
+
+def lib():
+    """Loads libdrx.so once.  Raises DrxError when it has not been built (run `python -m drecpy_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DrxError(f'{LIB_PATH} not found: the HIP engine is not built (python -m drecpy_amd.build). '
+                           'drecpy_amd has no CPU fallback.')
+        # torch ships its own libamdhip64 (SONAME libamdhip64.so.7); it must be in the process BEFORE
+        # libdrx.so so that both share ONE HIP runtime (otherwise torch's stream handles and device
+        # pointers would belong to a different runtime instance than the one launching our kernels).
+        import torch  # noqa: F401
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)            # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.drx_version() != 100:
+            raise DrxError('libdrx.so version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().drx_strerror(rc).decode()
+        raise DrxError(f'{what} failed: {msg} (code {rc})')
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream (0 = default stream)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

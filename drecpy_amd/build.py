@@ -1,0 +1,59 @@
+"""Builds drecpy_amd/libdrx.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m drecpy_amd.build            # incremental
+    python -m drecpy_amd.build --force
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'csrc', 'build')
+LIB = os.path.join(HERE, 'libdrx.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_host.cpp']
+COMMON = ['-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(ROOT, 'include', 'drx.h'), os.path.join(CSRC, 'drx_common.hpp')]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src + '.o')
+        objs.append(op)
+        if not force and _newer(op, [sp] + headers):
+            continue
+        cmd = [HIPCC] + COMMON + ['-c', sp, '-o', op]
+        if src.endswith('.hip'):
+            cmd[1:1] = [f'--offload-arch={ARCH}']
+        else:
+            cmd[1:1] = ['-x', 'c++'] if False else []
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'hipcc failed on {src}')
+    if force or procs or not _newer(LIB, objs):
+        cmd = [HIPCC, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,125 @@
+// Internal helpers shared by the libdrx.so translation units (gfx950 only).
+#pragma once
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "drx.h"
+
+#define DRX_HIP(expr)                                  \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) return (int)e_;              \
+  } while (0)
+
+#define DRX_LAUNCH_CHECK()                             \
+  do {                                                 \
+    hipError_t e_ = hipGetLastError();                 \
+    if (e_ != hipSuccess) return (int)e_;              \
+  } while (0)
+
+namespace drx {
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kBlock = 256;          // 4 waves, one per SIMD
+
+// splitmix64-style mix of (seed, a, b) -> 32 bits.  Same function on host and device.
+__host__ __device__ inline uint32_t hash_u32(uint64_t seed, uint32_t a, uint32_t b) {
+  uint64_t x = seed + (uint64_t)a * 0x9E3779B97F4A7C15ull + (uint64_t)b * 0xD1B54A32D192ED03ull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+__host__ inline uint32_t q_threshold(float q) {
+  double t = (double)q * 4294967296.0;
+  if (t <= 0.0) return 0u;
+  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  return (uint32_t)t;
+}
+
+// Sum over an aligned group of G lanes (G power of two <= 64); every lane gets the total.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4_fma(float4 &a, float s, const float4 &x) {
+  a.x = fmaf(s, x.x, a.x); a.y = fmaf(s, x.y, a.y); a.z = fmaf(s, x.z, a.z); a.w = fmaf(s, x.w, a.w);
+}
+__device__ __forceinline__ void f4_add(float4 &a, const float4 &x) {
+  a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+}
+__device__ __forceinline__ float f4_dot(const float4 &a, const float4 &b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+// Plain-division sigmoid (matches 1/(1+exp(-x)) of the oracle to ~1 ulp; no fast-math).
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Keras binary_crossentropy element and its derivative wrt p.
+__device__ __forceinline__ float bce_elem(float t, float p) {
+  const float eps = 1e-7f;
+  float pc = fminf(fmaxf(p, eps), 1.0f - eps);
+  return -(t * logf(pc + eps) + (1.0f - t) * logf(1.0f - pc + eps));
+}
+__device__ __forceinline__ float bce_grad(float t, float p) {
+  const float eps = 1e-7f;
+  float pc = fminf(fmaxf(p, eps), 1.0f - eps);
+  float g = -(t / (pc + eps) - (1.0f - t) / (1.0f - pc + eps));
+  return (p >= eps && p <= 1.0f - eps) ? g : 0.0f;
+}
+
+// Row-group geometry: G lanes cooperate on one table row, each lane owns J float4 (cols
+// 4*(lane + j*G) .. +3).  ld <= 4*G*J.
+struct Geom { int G, J; };
+inline Geom pick_geom(int ld) {
+  if (ld <= 32) return {8, 1};
+  if (ld <= 64) return {16, 1};
+  if (ld <= 128) return {32, 1};
+  if (ld <= 256) return {64, 1};
+  if (ld <= 512) return {64, 2};
+  return {64, 4};
+}
+
+#define DRX_DISPATCH_GEOM(ld, CALL)                        \
+  do {                                                     \
+    drx::Geom g_ = drx::pick_geom(ld);                     \
+    if (g_.G == 8) { CALL(8, 1); }                         \
+    else if (g_.G == 16) { CALL(16, 1); }                  \
+    else if (g_.G == 32) { CALL(32, 1); }                  \
+    else if (g_.J == 1) { CALL(64, 1); }                   \
+    else if (g_.J == 2) { CALL(64, 2); }                   \
+    else { CALL(64, 4); }                                  \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's scratch buffer.
+struct Carver {
+  char *base; size_t off; size_t cap;
+  Carver(void *p, size_t c) : base((char *)p), off(0), cap(c) {}
+  template <typename T> T *take(size_t n) {
+    off = align_up(off, 256);
+    T *r = (T *)(base ? base + off : nullptr);
+    off += n * sizeof(T);
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+
+// Internal: radix sort of (key, val) pairs, implemented in drx_sort.hip.
+size_t sort_pairs_temp_bytes(size_t n, int end_bit);
+int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+               uint32_t *vout, size_t n, int end_bit, hipStream_t stream);
+
+inline int bits_for(uint64_t max_key_exclusive) {
+  int b = 1;
+  while (b < 32 && (1ull << b) < max_key_exclusive) ++b;
+  return b;
+}
+
+}  // namespace drx

@@ -1,0 +1,227 @@
+"""Device-side state of one CDAE model and the calls into libdrx.so.
+
+Holds the parameter tables, optimizer slots, the positives-CSR of the training set and the scratch
+arena as torch tensors on one MI355X (torch is the allocator/stream provider only) and forwards
+every computation to the hand-written HIP kernels through the C ABI of include/drx.h.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Batch, CdaeParams, History, Optim, check, lib, ptr, stream_ptr
+
+VAR_ORDER = ('W', 'W2T', 'V', 'b', 'b2')      # registration order W, W_, V, b, b_ (cdae.py:43)
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7  # tf.keras.optimizers.Adam defaults
+ADAGRAD_INIT, ADAGRAD_EPS = 0.1, 1e-7         # tf.keras.optimizers.Adagrad defaults
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class CdaeEngine:
+    def __init__(self, n_users, n_items, k, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise _lib.DrxError('drecpy_amd needs a ROCm GPU (MI355X); there is no CPU fallback.')
+        lib()
+        self.device = torch.device(device)
+        self.n_users, self.n_items, self.k = int(n_users), int(n_items), int(k)
+        self.ld = _round_up(self.k, 4)
+        z = dict(dtype=torch.float32, device=self.device)
+        self.W = torch.zeros(self.n_items, self.ld, **z)
+        self.W2T = torch.zeros(self.n_items, self.ld, **z)
+        self.V = torch.zeros(self.n_users, self.ld, **z)
+        self.b = torch.zeros(self.ld, **z)
+        self.b2 = torch.zeros(self.n_items, **z)
+        self._params = CdaeParams(self.n_users, self.n_items, self.k, self.ld, *[ptr(t) for t in self.tables()])
+        self.opt = None
+        self.s1 = self.s2 = None
+        self.hist_indptr = self.hist_indices = None
+        self._hist = None
+        self._scratch = None
+        self._loss = torch.zeros(2, **z)
+
+    # ---- parameters -------------------------------------------------------------------------
+    def tables(self):
+        return [self.W, self.W2T, self.V, self.b, self.b2]
+
+    def init_glorot(self, seed):
+        """GlorotUniform for all five variables, biases included (cdae.py:35-41; App. A.1).
+        TF's generator cannot be reproduced, so the stream is numpy's PCG64 seeded with `seed`."""
+        rng = np.random.default_rng(seed)
+
+        def glorot(shape):
+            fi, fo = (shape[0], shape[0]) if len(shape) == 1 else (shape[0], shape[1])
+            lim = math.sqrt(6.0 / (fi + fo))
+            return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+        self.set_params(W=glorot((self.n_items, self.k)), W_=glorot((self.k, self.n_items)),
+                        V=glorot((self.n_users, self.k)), b=glorot((self.k,)), b_=glorot((self.n_items,)))
+
+    def set_params(self, W, W_, V, b, b_):
+        """Weights in the reference's orientation: W [N,K], W_ [K,N], V [U,K], b [K], b_ [N]."""
+        k = self.k
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
+        self.W.zero_(); self.W2T.zero_(); self.V.zero_(); self.b.zero_()
+        self.W[:, :k] = t(W)
+        self.W2T[:, :k] = t(W_).t()
+        self.V[:, :k] = t(V)
+        self.b[:k] = t(b)
+        self.b2.copy_(t(b_))
+
+    def get_params(self):
+        k = self.k
+        c = lambda x: x.detach().cpu().numpy().copy()
+        return {'W': c(self.W[:, :k]), 'W_': c(self.W2T[:, :k].t()), 'V': c(self.V[:, :k]), 'b': c(self.b[:k]),
+                'b_': c(self.b2)}
+
+    def snapshot(self):
+        """Device copies of parameters and optimizer slots (used by _store_epoch_weights/_revert_weights)."""
+        snap = {'p': [t.clone() for t in self.tables()]}
+        if self.s1 is not None:
+            snap['s1'] = [t.clone() for t in self.s1]
+            snap['s2'] = [t.clone() for t in self.s2] if self.s2 is not None else None
+        return snap
+
+    def restore(self, snap, with_optimizer=False):
+        for dst, src in zip(self.tables(), snap['p']):
+            dst.copy_(src)
+        if with_optimizer and 's1' in snap:
+            for dst, src in zip(self.s1, snap['s1']):
+                dst.copy_(src)
+            if snap['s2'] is not None:
+                for dst, src in zip(self.s2, snap['s2']):
+                    dst.copy_(src)
+
+    # ---- training-set positives (CSR) ---------------------------------------------------------
+    def set_history(self, indptr, indices):
+        self.hist_indptr = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device) \
+            if not torch.is_tensor(indptr) else indptr.to(self.device, torch.int64)
+        self.hist_indices = torch.as_tensor(np.asarray(indices, dtype=np.int32)).to(self.device) \
+            if not torch.is_tensor(indices) else indices.to(self.device, torch.int32)
+        if self.hist_indices.numel() == 0:
+            self.hist_indices = torch.zeros(1, dtype=torch.int32, device=self.device)
+        assert self.hist_indptr.numel() == self.n_users + 1
+        self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices))
+
+    # ---- optimizer --------------------------------------------------------------------------
+    def init_optimizer(self, kind, lr, reg_rate):
+        """kind: 'adam' (Keras Adam, reference default recommender_abc.py:153) or 'adagrad'."""
+        self.opt_kind = _lib.OPT_ADAM if kind == 'adam' else _lib.OPT_ADAGRAD
+        self.lr, self.reg_rate = float(lr), float(reg_rate)
+        if kind == 'adam':
+            self.s1 = [torch.zeros_like(t) for t in self.tables()]
+            self.s2 = [torch.zeros_like(t) for t in self.tables()]
+        else:
+            self.s1 = [torch.full_like(t, ADAGRAD_INIT) for t in self.tables()]
+            self.s2 = None
+
+    def _optim(self, alphas):
+        o = Optim()
+        o.kind = self.opt_kind
+        o.lr, o.reg_rate = self.lr, self.reg_rate
+        o.beta1, o.beta2 = ADAM_B1, ADAM_B2
+        o.eps = ADAM_EPS if self.opt_kind == _lib.OPT_ADAM else ADAGRAD_EPS
+        for j in range(5):
+            o.alpha[j] = alphas[j]
+            o.s1[j] = self.s1[j].data_ptr()
+            o.s2[j] = self.s2[j].data_ptr() if self.s2 is not None else 0
+        return o
+
+    @staticmethod
+    def adam_alpha(lr, t):
+        """Keras-Adam lr_t for the 1-based step t, in fp32 like optimizer_v2/adam.py."""
+        f = np.float32
+        return float(f(lr) * np.sqrt(f(1.0) - np.power(f(ADAM_B2), f(t))) / (f(1.0) - np.power(f(ADAM_B1), f(t))))
+
+    # ---- batches ----------------------------------------------------------------------------
+    def _dev(self, a, dtype):
+        if a is None:
+            return None
+        if torch.is_tensor(a):
+            return a.to(self.device, dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a)).to(self.device, dtype)
+
+    def make_batch(self, uid, iid=None, y=None, keep_off=None, keep=None, q=0.0, mask_seed=0, n_touch_slots=None):
+        """Uploads (if needed) one batch and returns (Batch struct, keep-alive tensors)."""
+        uid = self._dev(uid, torch.int32)
+        B = int(uid.numel())
+        if keep_off is None:
+            deg = (self.hist_indptr[uid.long() + 1] - self.hist_indptr[uid.long()])
+            keep_off = torch.zeros(B + 1, dtype=torch.int32, device=self.device)
+            keep_off[1:] = torch.cumsum(deg, 0).to(torch.int32)
+        else:
+            keep_off = self._dev(keep_off, torch.int32)
+        if n_touch_slots is None:
+            n_touch_slots = int(keep_off[-1].item())
+        iid = self._dev(iid, torch.int32)
+        y = self._dev(y, torch.float32)
+        keep = self._dev(keep, torch.uint8)
+        if keep is not None and keep.numel() == 0:
+            keep = torch.zeros(1, dtype=torch.uint8, device=self.device)
+        bt = Batch(B, ptr(uid), ptr(iid), ptr(y), ptr(keep_off), ptr(keep), int(mask_seed) & (2 ** 64 - 1), float(q),
+                   int(n_touch_slots))
+        return bt, (uid, iid, y, keep_off, keep)
+
+    def _ensure_scratch(self, B, n_touch_slots):
+        need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, n_touch_slots)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    # ---- calls ------------------------------------------------------------------------------
+    def forward(self, uid, keep_off=None, keep=None, q=0.0, mask_seed=0, want_pred=True):
+        """h [B,K], pred [B,N] for the given users (cdae.py:73-76).  q == 0 and keep is None gives the
+        inference path of cdae.py:67-71 (uncorrupted, unscaled)."""
+        bt, alive = self.make_batch(uid, keep_off=keep_off, keep=keep, q=q, mask_seed=mask_seed, n_touch_slots=0)
+        h = torch.empty(bt.B, self.ld, dtype=torch.float32, device=self.device)
+        pred = torch.empty(bt.B, self.n_items, dtype=torch.float32, device=self.device) if want_pred else None
+        check(lib().drx_cdae_forward(C.byref(self._params), C.byref(self._hist), C.byref(bt), ptr(h), ptr(pred),
+                                     stream_ptr(self.device)), 'drx_cdae_forward')
+        return h[:, :self.k], pred
+
+    def step_dense(self, step, bt, loss='bce', targets='reference', want_loss=False):
+        """One reference-mode fit() iteration; `step` is the 0-based batch index (Adam t = 5*step+j+1)."""
+        alphas = [self.adam_alpha(self.lr, 5 * step + j + 1) for j in range(5)]
+        o = self._optim(alphas)
+        sc = self._ensure_scratch(bt.B, max(bt.n_touch_slots, 0))
+        check(lib().drx_cdae_step_dense(
+            C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
+            _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE,
+            _lib.TARGETS_REFERENCE if targets == 'reference' else _lib.TARGETS_PER_ROW,
+            ptr(sc), sc.numel(), ptr(self._loss) if want_loss else None, stream_ptr(self.device)),
+            'drx_cdae_step_dense')
+        return self._loss if want_loss else None
+
+    def step_sparse(self, step, bt, loss='bce', want_loss=False):
+        """One sampled-output step (sparse Adagrad / lazy Adam on touched rows)."""
+        a = self.adam_alpha(self.lr, step + 1)
+        o = self._optim([a] * 5)
+        sc = self._ensure_scratch(bt.B, bt.n_touch_slots)
+        check(lib().drx_cdae_step_sparse(
+            C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
+            _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE,
+            ptr(sc), sc.numel(), ptr(self._loss) if want_loss else None, stream_ptr(self.device)),
+            'drx_cdae_step_sparse')
+        return self._loss if want_loss else None
+
+    def topk(self, scores, k, cand_mask=None):
+        """Row-wise top-k with heapq.nlargest((score, iid)) ordering (cdae.py:103)."""
+        scores = scores.contiguous()
+        R, n = scores.shape
+        out_idx = torch.empty(R, k, dtype=torch.int32, device=self.device)
+        out_val = torch.empty(R, k, dtype=torch.float32, device=self.device)
+        check(lib().drx_topk(ptr(scores), ptr(cand_mask), R, n, k, ptr(out_idx), ptr(out_val),
+                             stream_ptr(self.device)), 'drx_topk')
+        return out_idx, out_val
+
+
+def pack_mask_bits(mask_bool):
+    """bool [R,n] (numpy) -> uint32 words; bit (i & 31) of word (i >> 5) is flat element i."""
+    flat = np.asarray(mask_bool, dtype=bool).ravel()
+    pad = (-len(flat)) % 32
+    if pad:
+        flat = np.concatenate([flat, np.zeros(pad, bool)])
+    return np.packbits(flat, bitorder='little').view(np.uint32).copy()

@@ -1,0 +1,165 @@
+/* drx.h — C ABI of libdrx.so, the MI355X (gfx950) engine behind the DRecPy-compatible Python surface.
+ *
+ * The reference (fabioiuri/DRecPy) is pure Python and has no FFI of its own: its device boundary is
+ * "whatever TensorFlow eager op the hook calls" (DRecPy/Recommender/recommender_abc.py:191-205).  This
+ * header is therefore the boundary a maintainer would bind with ctypes; each entry point names the
+ * reference lines whose work it replaces.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - plain C types only; every pointer whose name is not prefixed `h_` is DEVICE memory owned by the
+ *     caller (torch-allocated in the Python host); the library never allocates or frees device memory,
+ *     never synchronises the device, and keeps no global state.  Work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream).
+ *   - return value: 0 on success, <0 = DRX_E* below, >0 = a hipError_t.  Never throws.
+ *   - parameter tables are fp32, row-major, row stride `ld` floats (ld % 4 == 0, ld >= k, the
+ *     padding columns are zero and stay zero).
+ *   - W2T is the reference's W_ [K,N] stored transposed [N,ld] so that an output unit is one row.
+ */
+#ifndef DRX_H_
+#define DRX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRX_VERSION 100
+
+enum {
+  DRX_OK = 0,
+  DRX_EINVAL = -1,     /* bad argument (null pointer, k > DRX_MAX_K, ld % 4, ...) */
+  DRX_ESCRATCH = -2,   /* scratch buffer too small */
+  DRX_ENOTIMPL = -3
+};
+
+#define DRX_MAX_K 1024
+#define DRX_KEY_NONE 0xFFFFFFFFu
+
+enum { DRX_LOSS_BCE = 0, DRX_LOSS_MSE = 1 };           /* cdae.py:30-31 */
+enum { DRX_TARGETS_REFERENCE = 0, DRX_TARGETS_PER_ROW = 1 };   /* (B,B,N) broadcast == batch-mean target, cdae.py:78-79 */
+enum { DRX_OPT_ADAM = 0, DRX_OPT_ADAGRAD = 1 };
+
+/* CDAE parameters (cdae.py:34-41) and optimizer slots of the same shapes.
+ * Adam uses s1 = m, s2 = v; Adagrad uses s1 = accumulator (s2 unused, may be NULL). */
+typedef struct DrxCdaeParams {
+  int32_t n_users, n_items, k, ld;
+  float *W;    /* [n_items, ld]  cdae.py:36 */
+  float *W2T;  /* [n_items, ld]  cdae.py:37 (transposed) */
+  float *V;    /* [n_users, ld]  cdae.py:38 */
+  float *b;    /* [ld]           cdae.py:40 */
+  float *b2;   /* [n_items]      cdae.py:41 */
+} DrxCdaeParams;
+
+/* The training set as the hot loop needs it: CSR of each user's POSITIVE items
+ * (interaction >= threshold, duplicates merged, columns ascending) — the non-zeros of
+ * `select_user_interaction_vec(uid)` after the binarisation of cdae.py:61. */
+typedef struct DrxHistory {
+  const int64_t *indptr;   /* [n_users + 1] */
+  const int32_t *indices;  /* [indptr[n_users]] */
+} DrxHistory;
+
+/* One mini-batch (one fit() "epoch", recommender_abc.py:189-205).
+ * uid  : the sampled users (PointSampler triples' first field, cdae.py:52).
+ * iid,y: sampled output unit and its {0,1} target — used by the sampled-output mode only.
+ * Corruption (cdae.py:63): entry j of user uid[b]'s history survives iff
+ *     keep != NULL ?  keep[keep_off[b] + j] != 0            (host MT19937 stream, parity mode)
+ *                  :  drx_hash(mask_seed, b, j) >= q * 2^32  (counter-based, throughput mode)
+ * keep_off[b] = sum_{b' < b} deg(uid[b'])  (exclusive prefix sum, keep_off[B] = total). */
+typedef struct DrxBatch {
+  int32_t B;
+  const int32_t *uid;       /* [B] */
+  const int32_t *iid;       /* [B] or NULL */
+  const float   *y;         /* [B] or NULL */
+  const int32_t *keep_off;  /* [B + 1] */
+  const uint8_t *keep;      /* [keep_off[B]] or NULL */
+  uint64_t mask_seed;
+  float q;                  /* corruption level; survivors are scaled by 1/(1-q) */
+  int32_t n_touch_slots;    /* host-known upper bound of keep_off[B] (sizes the sort) */
+} DrxBatch;
+
+typedef struct DrxOptim {
+  int32_t kind;             /* DRX_OPT_* */
+  float lr, reg_rate;       /* reg is applied as reg_rate / B (cdae.py:82) */
+  float beta1, beta2, eps;  /* Adam: .9 .999 1e-7 (Keras); Adagrad: eps 1e-7 */
+  /* Keras-Adam lr_t = lr*sqrt(1-b2^t)/(1-b1^t) per variable in registration order W, W_, V, b, b_
+   * (recommender_abc.py:328-334 advances the counter once per variable: t = 5*step + j + 1). */
+  float alpha[5];
+  float *s1[5];             /* slots in the order W, W2T, V, b, b2 */
+  float *s2[5];
+} DrxOptim;
+
+int drx_version(void);
+const char *drx_strerror(int code);
+
+/* 64-bit mix used for the counter-based corruption mask; exported so hosts/tests can reproduce it. */
+uint32_t drx_hash_u32(uint64_t seed, uint32_t a, uint32_t b);
+
+/* ---- inference ------------------------------------------------------------------------------
+ * h[B,ld] = sigmoid(scale * sum_{kept} W[n] + V[uid] + b);  p[B,n_items] = sigmoid(h W_ + b_).
+ * Replaces CDAE._reconstruct (cdae.py:73-76) as used by _predict/_rank (cdae.py:67-71,84-103:
+ * keep == NULL && q == 0 -> uncorrupted, unscaled) and by _predict_batch (cdae.py:50-65).
+ * p may be NULL (hidden layer only). */
+int drx_cdae_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt,
+                     float *h, float *pred, void *stream);
+
+/* ---- scratch sizing ---------------------------------------------------------------------- */
+size_t drx_cdae_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots);
+
+/* ---- one reference-mode training step ------------------------------------------------------
+ * forward + Keras BCE/MSE against the batch-mean (or per-row) target over ALL output units +
+ * L2/B on W, W_, V + backward + dense Adam on every parameter: replaces the body of the fit() loop
+ * recommender_abc.py:190-204 for CDAE (cdae.py:50-82).  loss_out (device, 2 floats: prediction
+ * loss, regularisation loss) may be NULL. */
+int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist,
+                        const DrxBatch *bt, int32_t loss_kind, int32_t targets_kind,
+                        void *scratch, size_t scratch_bytes, float *loss_out, void *stream);
+
+/* ---- one sampled-output training step (engine mode) ----------------------------
+ * per triple (uid, iid, y): one output unit, loss mean over B, L2/B on touched rows, sparse
+ * Adagrad / lazy Adam on touched rows of W, W2T, V, b2 and dense update of b.
+ * alpha[0] is used as the Adam lr_t for every table. */
+int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist,
+                         const DrxBatch *bt, int32_t loss_kind,
+                         void *scratch, size_t scratch_bytes, float *loss_out, void *stream);
+
+/* ---- ranking (cdae.py:90-103, recommender_abc.py:454-461) --------------------------------
+ * For each of R rows of `scores` [R, n] select the top `k` entries among those with
+ * cand_mask == NULL || bit (r*n + i) set; order = descending score, ties by larger index
+ * (heapq.nlargest over (score, iid) tuples).  out_idx/out_val [R,k]; missing = -1 / -inf. */
+int drx_topk(const float *scores, const uint32_t *cand_mask, int32_t R, int32_t n, int32_t k,
+             int32_t *out_idx, float *out_val, void *stream);
+
+/* ---- raw -> internal id map (mem_dataset.py:309-330) --------------------------------------
+ * codes[r] = rank of first appearance of raw[r] (int64 raw ids), bit-exact.
+ * n_unique (device int32) receives the number of categories; uniques[c] the raw id of code c.
+ * scratch: >= drx_idmap_scratch_bytes(n). */
+size_t drx_idmap_scratch_bytes(int64_t n);
+int drx_idmap_build(const int64_t *raw, int64_t n, int32_t *codes, int64_t *uniques,
+                    int32_t *n_unique, void *scratch, size_t scratch_bytes, void *stream);
+
+/* ---- host-side sampler (point_sampler.py:44-61; mem_dataset.py:111-163) ---------------------
+ * CPython-exact MT19937 streams (random.Random(seed): init_by_array, 53-bit random(),
+ * getrandbits-rejection randint).  All pointers here are HOST memory. */
+typedef struct DrxSampler DrxSampler;
+DrxSampler *drx_sampler_create(const int32_t *h_uid, const int32_t *h_iid, const double *h_val, int64_t n_rows,
+                               int32_t neg_ratio, int32_t has_threshold, double threshold, int64_t seed);
+int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out);
+void drx_sampler_destroy(DrxSampler *s);
+
+/* CDAE corruption stream (cdae.py:63, RecommenderABC._rng of recommender_abc.py:74): draws
+ * n_items uniforms per row, in batch order, and writes keep flags for the positives of each row. */
+typedef struct DrxRng DrxRng;
+DrxRng *drx_rng_create(int64_t seed);
+void drx_rng_destroy(DrxRng *r);
+double drx_rng_random(DrxRng *r);
+int64_t drx_rng_randint(DrxRng *r, int64_t a, int64_t b);
+int drx_rng_corruption_keep(DrxRng *r, const int64_t *h_indptr, const int32_t *h_indices, int32_t n_items,
+                            const int32_t *h_uid, int32_t B, double q,
+                            int32_t *h_keep_off, uint8_t *h_keep, int64_t keep_capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRX_H_ */

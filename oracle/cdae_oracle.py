@@ -23,8 +23,14 @@ HIP path can be checked against a CPU statement of exactly that mode.
 import numpy as np
 
 KERAS_EPS = 1e-7           # tf.keras.backend.epsilon()
-ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7       # tf.keras.optimizers.Adam defaults (App. A.5)
-ADAGRAD_INIT, ADAGRAD_EPS = 0.1, 1e-7               # tf.keras.optimizers.Adagrad defaults
+# tf.keras.optimizers.Adam defaults (App. A.5).  TF casts the hyper-parameters to the variable dtype (fp32) and
+# its ApplyAdam kernel forms (1 - beta) IN fp32:  m += (g - m) * (1 - b1);  v += (g*g - v) * (1 - b2);
+# var -= (m * lr_t) / (sqrt(v) + eps).  1.0f - 0.999f = 0.00099998713 (not 0.001): the constants below are those
+# fp32 values, used as-is by both the float32 and the float64 restatement.
+ADAM_B1, ADAM_B2, ADAM_EPS = float(np.float32(0.9)), float(np.float32(0.999)), float(np.float32(1e-7))
+ADAM_OMB1 = float(np.float32(1.0) - np.float32(0.9))
+ADAM_OMB2 = float(np.float32(1.0) - np.float32(0.999))
+ADAGRAD_INIT, ADAGRAD_EPS = float(np.float32(0.1)), float(np.float32(1e-7))   # tf.keras.optimizers.Adagrad defaults
 
 
 def glorot_uniform(rng, shape, dtype=np.float32):
@@ -145,8 +151,12 @@ VAR_ORDER = ('W', 'W_', 'V', 'b', 'b_')      # registration order, cdae.py:43
 
 
 def adam_alpha(lr, t):
-    """lr_t of Keras Adam for 1-based step t (App. A.5), in double."""
-    return lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+    """lr_t of Keras Adam for the 1-based step t (App. A.5), evaluated in fp32 like optimizer_v2/adam.py does
+    (beta powers via pow on the fp32-cast hyper-parameters)."""
+    f = np.float32
+    b1p = np.power(f(0.9), f(t))
+    b2p = np.power(f(0.999), f(t))
+    return float(f(lr) * np.sqrt(f(1.0) - b2p) / (f(1.0) - b1p))
 
 
 def dense_step(params, state, step, uids, x_tilde, t, lr, reg_rate, loss='bce', targets='reference'):
@@ -158,9 +168,9 @@ def dense_step(params, state, step, uids, x_tilde, t, lr, reg_rate, loss='bce', 
         tt = 5 * step + j + 1
         a = dt.type(adam_alpha(lr, tt))
         m, v = state[name]
-        m[...] = dt.type(ADAM_B1) * m + dt.type(1 - ADAM_B1) * g[name]
-        v[...] = dt.type(ADAM_B2) * v + dt.type(1 - ADAM_B2) * g[name] * g[name]
-        params[name][...] = params[name] - a * m / (np.sqrt(v) + dt.type(ADAM_EPS))
+        m[...] = m + (g[name] - m) * dt.type(ADAM_OMB1)
+        v[...] = v + (g[name] * g[name] - v) * dt.type(ADAM_OMB2)
+        params[name][...] = params[name] - (m * a) / (np.sqrt(v) + dt.type(ADAM_EPS))
     return lval
 
 
@@ -233,13 +243,13 @@ def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss=
         if optimizer == 'adagrad':
             acc = state[name]
             acc[index] = acc[index] + g * g
-            params[name][index] = params[name][index] - dt.type(lr) * g / (np.sqrt(acc[index]) + dt.type(ADAGRAD_EPS))
+            params[name][index] = params[name][index] - dt.type(np.float32(lr)) * g / (np.sqrt(acc[index]) + dt.type(ADAGRAD_EPS))
         else:
             m, v = state[name]
             a = dt.type(adam_alpha(lr, step + 1))
-            m[index] = dt.type(ADAM_B1) * m[index] + dt.type(1 - ADAM_B1) * g
-            v[index] = dt.type(ADAM_B2) * v[index] + dt.type(1 - ADAM_B2) * g * g
-            params[name][index] = params[name][index] - a * m[index] / (np.sqrt(v[index]) + dt.type(ADAM_EPS))
+            m[index] = m[index] + (g - m[index]) * dt.type(ADAM_OMB1)
+            v[index] = v[index] + (g * g - v[index]) * dt.type(ADAM_OMB2)
+            params[name][index] = params[name][index] - (m[index] * a) / (np.sqrt(v[index]) + dt.type(ADAM_EPS))
 
     # gradients are all taken at the pre-update parameters
     regW_ = {i: rb * W_[:, i].copy() for i in gW_}

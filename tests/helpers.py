@@ -20,3 +20,59 @@ def load_frames():
         k, c = key.split('__')
         frames.setdefault(k, {})[c] = z[key]
     return frames
+
+
+# ---- synthetic CDAE problems shared by the GPU parity tests -------------------------------------
+def hash_u32(seed, a, b):
+    """numpy restatement of drx_hash_u32 (include/drx.h) for uint32 arrays a, b."""
+    M = (1 << 64) - 1
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        x = (np.uint64(seed & M) + a * np.uint64(0x9E3779B97F4A7C15) + b * np.uint64(0xD1B54A32D192ED03))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return (x >> np.uint64(32)).astype(np.uint32)
+
+
+def q_threshold(q):
+    t = float(np.float32(q)) * 4294967296.0
+    return 0 if t <= 0 else min(int(t), 0xFFFFFFFF)
+
+
+def synth_history(rng, n_users, n_items, mean_deg, zipf=1.0, min_deg=0):
+    """Random positives CSR (sorted, unique columns per row)."""
+    pop = 1.0 / np.arange(1, n_items + 1) ** zipf
+    pop /= pop.sum()
+    indptr = [0]
+    idx = []
+    for u in range(n_users):
+        d = min(n_items, max(min_deg, int(rng.poisson(mean_deg))))
+        cols = np.sort(rng.choice(n_items, size=d, replace=False, p=pop)) if d else np.zeros(0, np.int64)
+        idx.append(cols)
+        indptr.append(indptr[-1] + d)
+    return np.asarray(indptr, np.int64), (np.concatenate(idx) if idx else np.zeros(0)).astype(np.int32)
+
+
+def batch_rows(indptr, indices, uids, n_items, keep_flat=None):
+    """Dense targets t [B,N], keep offsets and (optionally) the kept-item lists per row."""
+    B = len(uids)
+    t = np.zeros((B, n_items), dtype=bool)
+    keep_off = np.zeros(B + 1, dtype=np.int32)
+    kept = []
+    for b, u in enumerate(uids):
+        s, e = indptr[u], indptr[u + 1]
+        t[b, indices[s:e]] = True
+        keep_off[b + 1] = keep_off[b] + (e - s)
+        if keep_flat is not None:
+            kf = keep_flat[keep_off[b]:keep_off[b + 1]].astype(bool)
+            kept.append(indices[s:e][kf].tolist())
+    return t, keep_off, kept
+
+
+def x_tilde(t, kept, q, dtype):
+    x = np.zeros(t.shape, dtype=dtype)
+    for b, k in enumerate(kept):
+        x[b, k] = 1.0 / (1.0 - q)
+    return x

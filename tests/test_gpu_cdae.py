@@ -1,0 +1,158 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Gates: predictions within 1e-5 relative of the fp64 oracle after 0, 1, 10 and 50 steps
+from injected weights / masks; integer outputs bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import cdae_oracle as co
+from helpers import batch_rows, hash_u32, q_threshold, synth_history, x_tilde
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def _engine(U, N, K, seed=0):
+    from drecpy_amd.engine import CdaeEngine
+    rng = np.random.default_rng(seed)
+    p = co.init_params(rng, U, N, K, np.float64)
+    eng = CdaeEngine(U, N, K)
+    eng.set_params(**{k: v for k, v in p.items()})
+    return eng, p, rng
+
+
+def _relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
+
+
+@pytest.mark.parametrize('K', [8, 50, 128, 200, 300])
+def test_forward_matches_oracle(K):
+    U, N = 57, 211
+    eng, p, rng = _engine(U, N, K)
+    indptr, indices = synth_history(rng, U, N, 12)
+    eng.set_history(indptr, indices)
+    uids = rng.integers(0, U, size=37)
+    # inference path (cdae.py:67-71): uncorrupted, unscaled
+    h, pred = eng.forward(uids)
+    t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+    ho, po = co.forward(p, uids, t.astype(np.float64))
+    assert _relerr(h.cpu().numpy(), ho) < REL
+    assert _relerr(pred.cpu().numpy(), po) < REL
+    # training forward with an explicit keep stream
+    keep = (rng.random(keep_off[-1]) >= 0.2).astype(np.uint8)
+    _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+    h, pred = eng.forward(uids, keep_off=keep_off, keep=keep, q=0.2)
+    ho, po = co.forward(p, uids, x_tilde(t, kept, 0.2, np.float64))
+    assert _relerr(pred.cpu().numpy(), po) < REL
+    # counter-based mask
+    seed = 0x1234ABCD5678
+    h, pred = eng.forward(uids, q=0.3, mask_seed=seed)
+    thr = q_threshold(0.3)
+    keep2 = np.concatenate([hash_u32(seed, np.full(keep_off[b + 1] - keep_off[b], b), np.arange(keep_off[b + 1] - keep_off[b])) >= thr
+                            for b in range(len(uids))]).astype(np.uint8)
+    _, _, kept2 = batch_rows(indptr, indices, uids, N, keep2)
+    ho, po = co.forward(p, uids, x_tilde(t, kept2, float(np.float32(0.3)), np.float64))
+    assert _relerr(pred.cpu().numpy(), po) < REL
+
+
+@pytest.mark.parametrize('K,B,loss,targets', [(50, 64, 'bce', 'reference'), (128, 64, 'bce', 'reference'),
+                                              (8, 33, 'mse', 'reference'), (50, 40, 'bce', 'per_row'),
+                                              (300, 16, 'mse', 'per_row'), (128, 700, 'bce', 'reference')])
+def test_dense_steps_match_oracle(K, B, loss, targets):
+    U, N = 90, 173
+    eng, p, rng = _engine(U, N, K, seed=1)
+    indptr, indices = synth_history(rng, U, N, 15)
+    eng.set_history(indptr, indices)
+    eng.init_optimizer('adam', 1e-3, 1e-3)
+    st = co.adam_state(p)
+    p32 = {k: v.astype(np.float32) for k, v in p.items()}     # fp32 oracle: what TF itself computes in
+    st32 = co.adam_state(p32)
+    q = 0.2
+    checks = (1, 10, 50) if B <= 64 else (1, 3)
+    probe = rng.integers(0, U, size=20)
+    tp, _, _ = batch_rows(indptr, indices, probe, N)
+    for step in range(max(checks)):
+        uids = rng.integers(0, U, size=B)
+        t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        keep = (rng.random(keep_off[-1]) >= q).astype(np.uint8)
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        bt, alive = eng.make_batch(uids, keep_off=keep_off, keep=keep, q=q)
+        lo = co.dense_step(p, st, step, uids, x_tilde(t, kept, float(np.float32(q)), np.float64), t, 1e-3, 1e-3, loss, targets)
+        co.dense_step(p32, st32, step, uids, x_tilde(t, kept, float(np.float32(q)), np.float32), t, 1e-3, 1e-3, loss, targets)
+        lg = eng.step_dense(step, bt, loss, targets, want_loss=True).cpu().numpy()
+        assert abs(lg.sum() - lo) / abs(lo) < 1e-4, (step, lg, lo)
+        if step + 1 in checks:
+            _, pred = eng.forward(probe)
+            _, po = co.forward(p, probe, tp.astype(np.float64))
+            _, po32 = co.forward(p32, probe, tp.astype(np.float32))
+            err, drift32 = _relerr(pred.cpu().numpy(), po), _relerr(po32, po)
+            # gate: 1e-5 vs the fp64 oracle; after many Adam steps fp32 rounding (TF's own included) is amplified by
+            # m/(sqrt(v)+eps), so the budget there is twice the fp32 oracle's own drift from fp64
+            assert err < max(REL, 2.0 * drift32), (step, err, drift32)
+            assert err < 5e-5
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize('K,B,opt,loss,explicit', [(128, 256, 'adagrad', 'bce', True), (50, 64, 'adagrad', 'bce', False),
+                                                   (8, 100, 'adam', 'mse', True), (128, 4096, 'adagrad', 'bce', False),
+                                                   (300, 50, 'adam', 'bce', False)])
+def test_sparse_steps_match_oracle(K, B, opt, loss, explicit):
+    U, N = 120, 260
+    eng, p, rng = _engine(U, N, K, seed=2)
+    indptr, indices = synth_history(rng, U, N, 14, zipf=1.1)
+    eng.set_history(indptr, indices)
+    lr = 0.05 if opt == 'adagrad' else 1e-3
+    eng.init_optimizer(opt, lr, 1e-3)
+    st = co.sparse_state(p, opt)
+    q = 0.2
+    qf = float(np.float32(q))
+    probe = np.arange(U)
+    tp, _, _ = batch_rows(indptr, indices, probe, N)
+    n_steps = 10 if B <= 256 else 3
+    for step in range(n_steps):
+        uids = rng.integers(0, U, size=B)
+        iids = rng.integers(0, N, size=B)
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        seed = 977 + step * 7919
+        if explicit:
+            keep = (rng.random(keep_off[-1]) >= q).astype(np.uint8)
+            bt, alive = eng.make_batch(uids, iids, y, keep_off=keep_off, keep=keep, q=q)
+        else:
+            thr = q_threshold(q)
+            keep = np.concatenate([hash_u32(seed, np.full(keep_off[b + 1] - keep_off[b], b), np.arange(keep_off[b + 1] - keep_off[b])) >= thr
+                                   for b in range(B)]).astype(np.uint8)
+            bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, lr, 1e-3, loss, opt)
+        lg = eng.step_sparse(step, bt, loss, want_loss=True).cpu().numpy()
+        assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    _, pred = eng.forward(probe)
+    _, po = co.forward(p, probe, tp.astype(np.float64))
+    assert _relerr(pred.cpu().numpy(), po) < REL
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5)
+
+
+def test_sparse_step_is_deterministic():
+    import torch
+    U, N, K, B = 200, 300, 128, 2048
+    outs = []
+    for rep in range(2):
+        eng, p, rng = _engine(U, N, K, seed=5)
+        indptr, indices = synth_history(rng, U, N, 20, zipf=1.2)
+        eng.set_history(indptr, indices)
+        eng.init_optimizer('adagrad', 0.05, 1e-3)
+        for step in range(3):
+            uids = rng.integers(0, U, size=B); iids = rng.integers(0, N, size=B)
+            y = (rng.random(B) < 0.3).astype(np.float32)
+            bt, alive = eng.make_batch(uids, iids, y, q=0.2, mask_seed=step)
+            eng.step_sparse(step, bt)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in eng.tables()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -76,8 +76,10 @@ def test_adam_counter_is_per_variable():
     for j, k in enumerate(co.VAR_ORDER):
         tt = j + 1
         a = co.adam_alpha(1e-3, tt)
-        want = before[k] - a * (0.1 * g[k]) / (np.sqrt(0.001 * g[k] ** 2) + 1e-7)
+        want = before[k] - a * (co.ADAM_OMB1 * g[k]) / (np.sqrt(co.ADAM_OMB2 * g[k] ** 2) + co.ADAM_EPS)
         np.testing.assert_allclose(p[k], want, rtol=1e-12)
+    # TF forms (1 - beta) in fp32: 1.0f - 0.999f is NOT 0.001
+    assert co.ADAM_OMB2 == 0.0009999871253967285 and co.ADAM_OMB1 == 0.10000002384185791
 
 
 def test_sparse_step_matches_autograd():
@@ -111,8 +113,8 @@ def test_sparse_step_matches_autograd():
     g['W_'][:, ti] += rb * p['W_'][:, ti]
     want = {}
     for k in p:
-        acc = np.full_like(p[k], 0.1) + g[k] ** 2
-        want[k] = p[k] - 0.05 * g[k] / (np.sqrt(acc) + 1e-7)
+        acc = np.full_like(p[k], co.ADAGRAD_INIT) + g[k] ** 2
+        want[k] = p[k] - float(np.float32(0.05)) * g[k] / (np.sqrt(acc) + co.ADAGRAD_EPS)
     st = co.sparse_state(p, 'adagrad')
     lval, _ = co.sparse_step(p, st, 0, uids, iids, y, kept, q, 0.05, 1e-3, 'bce', 'adagrad')
     assert abs(lval - L.item()) < 1e-12
