@@ -1,0 +1,230 @@
+"""bench.py — training samples/s of the CDAE hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synth-10m|ml-1m|ml-100k] [--batch B]
+
+A "step" is one pass of the hot path over one batch of B (u, i, y) triples per GPU: counter-based point sampling is done
+ahead of time (batches resident in HBM), the timed region runs gather + hidden layer + sampled output unit + BCE +
+backward + sparse-Adagrad update (drx_cdae_step_sparse).  One process per GPU; for N > 1 launch with
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RCCL over xGMI, user-sharded tables).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+K = 128
+Q = 0.2
+NEG_RATIO = 5
+LR, REG = 0.05, 1e-3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='synth-10m', choices=['synth-10m', 'ml-1m', 'ml-100k'])
+    ap.add_argument('--batch', type=int, default=65536, help='triples per GPU per step')
+    ap.add_argument('--n-batches', type=int, default=8, help='distinct pre-sampled batches cycled through')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
+    return ap.parse_args()
+
+
+def hash_u32_torch(seed, a, b):
+    """drx_hash_u32 restated with wrapping int64 torch ops (to count surviving inputs of a batch exactly)."""
+    def c(v):
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def srl(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+    x = a * c(0x9E3779B97F4A7C15) + b * c(0xD1B54A32D192ED03) + c(seed)
+    x = (x ^ srl(x, 30)) * c(0xBF58476D1CE4E5B9)
+    x = (x ^ srl(x, 27)) * c(0x94D049BB133111EB)
+    x = x ^ srl(x, 31)
+    return srl(x, 32)
+
+
+def q_threshold(q):
+    t = float(np.float32(q)) * 4294967296.0
+    return 0 if t <= 0 else min(int(t), 0xFFFFFFFF)
+
+
+def kept_count(keep_off, seed, q):
+    B = keep_off.numel() - 1
+    deg = (keep_off[1:] - keep_off[:-1]).long()
+    row = torch.repeat_interleave(torch.arange(B, device=keep_off.device), deg)
+    j = torch.arange(int(keep_off[-1].item()), device=keep_off.device) - keep_off[:-1].long()[row]
+    return int((hash_u32_torch(seed, row, j) >= q_threshold(q)).sum().item())
+
+
+def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_cpu=1024):
+    """Times the CPU oracle (oracle/cdae_oracle.py sparse_step: the NumPy restatement, 'port') on the first n_cpu triples
+    of one bench batch.  The tables are compacted to the rows that sample touches (same arithmetic per sample; the
+    CPU sees a cache-friendlier table than the GPU does)."""
+    from oracle import cdae_oracle as co
+    n_cpu = min(n_cpu, batch[0].numel())
+    uid, iid, y = [t[:n_cpu].cpu().numpy() for t in batch[:3]]
+    ip = hist_indptr.cpu().numpy() if hist_indptr.numel() < 50_000_000 else None
+    thr = q_threshold(Q)
+    kept, users, items = [], {}, {}
+    for b in range(n_cpu):
+        u = int(uid[b])
+        s, e = (int(hist_indptr[u].item()), int(hist_indptr[u + 1].item())) if ip is None else (int(ip[u]), int(ip[u + 1]))
+        row = hist_indices[s:e].cpu().numpy()
+        kf = co.drx_hash_u32(seed, np.full(e - s, b), np.arange(e - s)) >= thr
+        users.setdefault(u, len(users))
+        for n in row[kf].tolist() + [int(iid[b])]:
+            items.setdefault(n, len(items))
+        kept.append([items[n] for n in row[kf].tolist()])
+    ul = torch.tensor(list(users.keys()), device=eng.device)
+    il = torch.tensor(list(items.keys()), device=eng.device)
+    k = eng.k
+    p = {'W': eng.W[il, :k].cpu().numpy().copy(), 'W_': eng.W2T[il, :k].t().cpu().numpy().copy(),
+         'V': eng.V[ul, :k].cpu().numpy().copy(), 'b': eng.b[:k].cpu().numpy().copy(), 'b_': eng.b2[il].cpu().numpy().copy()}
+    st = co.sparse_state(p, 'adagrad')
+    cu = np.array([users[int(u)] for u in uid])
+    ci = np.array([items[int(i)] for i in iid])
+    t0 = time.perf_counter()
+    n_done = 0
+    while time.perf_counter() - t0 < budget_s:
+        co.sparse_step(p, st, n_done, cu, ci, y, kept, float(np.float32(Q)), LR, REG, 'bce', 'adagrad')
+        n_done += 1
+    dt = time.perf_counter() - t0
+    return {'value': n_cpu * n_done / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n_done} steps of the first {n_cpu} triples of one bench batch (same tables, compacted to touched '
+                      f'rows), NumPy restatement oracle/cdae_oracle.py:sparse_step, {dt:.1f} s, host has {os.cpu_count()} cpus'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from drecpy_amd import synth
+    from drecpy_amd.engine import CdaeEngine
+    U, N, md, mn, alpha = synth.SHAPES[args.workload]
+    if args.users:
+        U = args.users
+    B = args.batch
+    lo, hi = U * rank // world, U * (rank + 1) // world
+    t_setup = time.time()
+    indptr, indices = synth.synth_history(U, N, md, mn, alpha, seed=0, device=dev, user_lo=lo, user_hi=hi)
+    nnz_local = int(indptr[-1].item())
+
+    if world == 1:
+        eng = CdaeEngine(hi - lo, N, K, device=dev)
+        eng.init_glorot_device(10)
+        eng.set_history(indptr, indices)
+        eng.init_optimizer('adagrad', LR, REG)
+        stepper = None
+    else:
+        from drecpy_amd.dist import ShardedCdae
+        stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG)
+        eng = stepper.engine
+
+    # ---- pre-sampled batches, resident in HBM -------------------------------------------------------------
+    batches, structs, kept_tot = [], [], 0
+    for i in range(args.n_batches):
+        seed = 1000 + 7919 * i + 104729 * rank
+        uid, iid, y, keep_off = eng.sample_device(B, NEG_RATIO, seed)
+        torch.cuda.synchronize()
+        n_slots = int(keep_off[-1].item())
+        kept_tot += kept_count(keep_off, seed, Q)
+        bt, alive = eng.make_batch(uid, iid, y, keep_off=keep_off, q=Q, mask_seed=seed, n_touch_slots=n_slots)
+        batches.append((uid, iid, y, keep_off, seed))
+        structs.append((bt, alive))
+    rows_per_sample = kept_tot / (args.n_batches * B) + 2.0          # R: kept W rows + V row + W2T row
+    setup_s = time.time() - t_setup
+
+    def run_step(s, events=None):
+        bt, _ = structs[s % len(structs)]
+        if stepper is None:
+            eng.step_sparse(s, bt, 'bce', events=events)
+        else:
+            stepper.step(s, bt, events=events)
+
+    for s in range(args.warmup):
+        run_step(s)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+    for es in evs:
+        for e in es:
+            e.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        run_step(args.warmup + s, events=evs[s])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    phases = np.array([[es[i].elapsed_time(es[i + 1]) for i in range(5)] for es in evs])     # ms
+    ph = phases.mean(axis=0)
+    names = ['k_sampled_fwd_bwd', 'touch_sort', 'k_seg_reduce', 'k_span_fixup', 'bias_update']
+    # algorithmic bytes per launch: forward reads 4K*R per sample; the update reads and
+    # writes parameter + S optimizer slots per touched-row occurrence: 4K*R*(2+2S), S = 1 for Adagrad.
+    alg = {'k_sampled_fwd_bwd': B * 4.0 * K * rows_per_sample,
+           'k_seg_reduce': B * 4.0 * K * rows_per_sample * 4.0}
+    dom = 'k_seg_reduce' if ph[2] >= ph[0] else 'k_sampled_fwd_bwd'
+    dom_ms = ph[2] if dom == 'k_seg_reduce' else ph[0]
+    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+    step_alg = B * 4.0 * K * rows_per_sample * 5.0
+
+    if rank == 0:
+        out = {
+            'metric': 'training samples/sec (user-item pairs)', 'value': world * B * args.steps / dt, 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-Adagrad on {args.workload}-shaped synthetic '
+                                   f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
+                                   f'corruption {Q}, neg_ratio {NEG_RATIO}',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
+                       'sharding': 'single GPU' if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': float(dom_ms),
+                         'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
+                         'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+            'phases_ms': {n: float(v) for n, v in zip(names, ph)},
+            'setup_s': round(setup_s, 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            uid, iid, y, keep_off, seed = batches[0]
+            out['cpu_baseline'] = cpu_baseline(eng, indptr, indices, (uid, iid, y, keep_off), seed)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

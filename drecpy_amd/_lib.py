@@ -54,6 +54,12 @@ SIGNATURES = {
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     'drx_cdae_step_sparse': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch),
                                        C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    'drx_cdae_step_sparse_timed': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History),
+                                             C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.POINTER(C.c_void_p), C.c_void_p]),
+    'drx_point_sample_scratch_bytes': (C.c_size_t, [C.c_int32]),
+    'drx_point_sample': (C.c_int, [C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                            C.c_void_p]),
     'drx_idmap_scratch_bytes': (C.c_size_t, [C.c_int64]),

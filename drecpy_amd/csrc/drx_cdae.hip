@@ -816,7 +816,8 @@ static int check_params(const DrxCdaeParams *p) {
 }
 
 static int check_batch(const DrxHistory *h, const DrxBatch *bt) {
-  if (!h || !h->indptr || !h->indices || !bt || !bt->uid || !bt->keep_off) return DRX_EINVAL;
+  if (!h || !h->indptr || !h->indices || !bt || !bt->uid) return DRX_EINVAL;
+  if (bt->keep && !bt->keep_off) return DRX_EINVAL;
   if (bt->B < 1 || bt->q < 0.f || bt->q >= 1.f) return DRX_EINVAL;
   return DRX_OK;
 }
@@ -927,12 +928,13 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
   return DRX_OK;
 }
 
-int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
-                         int32_t loss_kind, void *scratch, size_t scratch_bytes, float *loss_out, void *stream) {
+static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
+                            int32_t loss_kind, void *scratch, size_t scratch_bytes, float *loss_out, void *const *events,
+                            void *stream) {
   int rc = check_params(p);
   if (rc) return rc;
   rc = check_batch(hist, bt);
-  if (rc || !opt || !scratch || !bt->iid || !bt->y) return DRX_EINVAL;
+  if (rc || !opt || !scratch || !bt->iid || !bt->y || !bt->keep_off) return DRX_EINVAL;
   if (opt->kind != DRX_OPT_ADAM && opt->kind != DRX_OPT_ADAGRAD) return DRX_EINVAL;
   for (int i = 0; i < 5; ++i)
     if (!opt->s1[i] || (opt->kind == DRX_OPT_ADAM && !opt->s2[i])) return DRX_EINVAL;
@@ -945,31 +947,51 @@ int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxH
   const float scale = 1.0f / (1.0f - bt->q);
   const uint32_t qthr = q_threshold(bt->q);
   const int bits = bits_for((uint64_t)2 * p->n_items + p->n_users + 1);
-  DRX_HIP(hipMemsetAsync(S.n_span, 0, sizeof(uint32_t), st));
-  // slots beyond keep_off[B] (when n_touch_slots is only an upper bound) must be padding
-  DRX_HIP(hipMemsetAsync(S.keys, 0xFF, (size_t)S.T * sizeof(uint32_t), st));
   const int rows_per_block = (bt->B + S.n_bpart - 1) / S.n_bpart;
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
+#define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
+    DRX_HIP(hipMemsetAsync(S.n_span, 0, sizeof(uint32_t), st));                                                        \
+    /* slots beyond keep_off[B] (n_touch_slots may be an upper bound) must read as padding */                          \
+    DRX_HIP(hipMemsetAsync(S.keys, 0xFF, (size_t)S.T * sizeof(uint32_t), st));                                         \
+    EV(0);                                                                                                             \
     hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt,  \
                        scale, qthr, loss_kind, S);                                                                     \
+    EV(1);                                                                                                             \
     rc = sort_pairs(sort_temp, sort_bytes, S.keys, S.keys_s, S.vals, S.vals_s, (size_t)S.T, bits, st);                 \
     if (rc) return rc;                                                                                                 \
+    EV(2);                                                                                                             \
     hipLaunchKernelGGL((k_seg_reduce<G, J>), dim3((S.n_chunks + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, bt->B, \
                        scale, S);                                                                                      \
+    EV(3);                                                                                                             \
     hipLaunchKernelGGL((k_span_fixup<G, J>), dim3(1024), dim3(kBlock), ((size_t)gpb * p->ld + gpb) * 4, st, *p, *opt,  \
                        bt->B, S);                                                                                      \
+    EV(4);                                                                                                             \
     hipLaunchKernelGGL((k_bias_partial<G, J>), dim3(n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B, \
                        S.dz1, S.bpart, rows_per_block);                                                                \
     hipLaunchKernelGGL((k_bias_final<G, J>), dim3(1), dim3(kBlock), 0, st, *p, *opt, bt->B, S.bpart, n_bpart, S.lossb, \
                        loss_out);                                                                                      \
+    EV(5);                                                                                                             \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL
+#undef EV
   DRX_LAUNCH_CHECK();
   return DRX_OK;
+}
+
+int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
+                         int32_t loss_kind, void *scratch, size_t scratch_bytes, float *loss_out, void *stream) {
+  return step_sparse_impl(p, opt, hist, bt, loss_kind, scratch, scratch_bytes, loss_out, nullptr, stream);
+}
+
+int drx_cdae_step_sparse_timed(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
+                               int32_t loss_kind, void *scratch, size_t scratch_bytes, float *loss_out, void *const *events,
+                               void *stream) {
+  if (!events) return DRX_EINVAL;
+  return step_sparse_impl(p, opt, hist, bt, loss_kind, scratch, scratch_bytes, loss_out, events, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,76 @@
+// Device-side PointSampler for the throughput mode (counter-based draws instead of the MT19937 streams of
+// DRecPy/Sampler/point_sampler.py:44-61 — same distribution, different stream; the bit-exact stream is the host
+// sampler in drx_host.cpp):
+//   with probability neg_ratio/(neg_ratio+1) a negative: uniform (u, i) with i NOT among u's rows (mem_dataset.py:154-163;
+//   membership here = the positives CSR), else a positive: uniform user with >= 1 positive, then a uniform positive of
+//   that user (mem_dataset.py:119-129).  Also emits keep_off = exclusive scan of deg(uid[b]) for the step kernels.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+#include "drx_common.hpp"
+
+namespace drx {
+
+__device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
+
+__global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_users, int n_items, int B, int neg_ratio,
+                                                         uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *deg) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t r0 = hash_u32(seed, (uint32_t)b, 0u);
+  const bool null_pair = ((double)r0 * (1.0 / 4294967296.0)) * (double)(neg_ratio + 1) > 1.0;
+  int u = 0, i = 0;
+  uint32_t c = 1;
+  for (int tries = 0; tries < 4096; ++tries) {
+    u = (int)bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)n_users);
+    const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+    if (null_pair) {
+      i = (int)bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)n_items);
+      int64_t lo = s, hi = e;                  // lower_bound in the sorted row
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (H.indices[mid] < i) lo = mid + 1; else hi = mid;
+      }
+      if (lo == e || H.indices[lo] != i) break;
+    } else {
+      if (e == s) continue;
+      i = H.indices[s + bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)(e - s))];
+      break;
+    }
+  }
+  uid[b] = u;
+  iid[b] = i;
+  y[b] = null_pair ? 0.0f : 1.0f;
+  deg[b] = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
+}
+
+}  // namespace drx
+
+extern "C" size_t drx_point_sample_scratch_bytes(int32_t B) {
+  if (B < 1) return 0;
+  size_t tb = 0;
+  int *d = nullptr;
+  (void)rocprim::inclusive_scan(nullptr, tb, d, d, (size_t)B, rocprim::plus<int>(), (hipStream_t)0);
+  return drx::align_up((size_t)B * 4, 256) + drx::align_up(tb, 256) + 256;
+}
+
+extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
+                                uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off, void *scratch,
+                                size_t scratch_bytes, void *stream) {
+  using namespace drx;
+  if (!hist || !hist->indptr || !hist->indices || !uid || !iid || !y || !keep_off || !scratch || B < 1 || n_users < 1 ||
+      n_items < 1 || neg_ratio < 0)
+    return DRX_EINVAL;
+  if (scratch_bytes < drx_point_sample_scratch_bytes(B)) return DRX_ESCRATCH;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *deg = (int32_t *)scratch;
+  void *tmp = (char *)scratch + align_up((size_t)B * 4, 256);
+  size_t tb = scratch_bytes - align_up((size_t)B * 4, 256);
+  hipLaunchKernelGGL(k_point_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, *hist, n_users, n_items, B,
+                     neg_ratio, seed, uid, iid, y, deg);
+  DRX_HIP(hipMemsetAsync(keep_off, 0, sizeof(int32_t), st));
+  hipError_t e = rocprim::inclusive_scan(tmp, tb, deg, keep_off + 1, (size_t)B, rocprim::plus<int>(), st);
+  if (e != hipSuccess) return (int)e;
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}

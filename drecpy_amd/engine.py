@@ -60,6 +60,23 @@ class CdaeEngine:
         self.set_params(W=glorot((self.n_items, self.k)), W_=glorot((self.k, self.n_items)),
                         V=glorot((self.n_users, self.k)), b=glorot((self.k,)), b_=glorot((self.n_items,)))
 
+    def init_glorot_device(self, seed):
+        """Same distribution as init_glorot, drawn on the GPU (benchmark-sized tables: no 5 GB host copy)."""
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(int(seed))
+        k = self.k
+
+        def fill(t, rows, fi, fo):
+            lim = math.sqrt(6.0 / (fi + fo))
+            t.zero_()
+            view = t[:, :k] if t.dim() == 2 else t[:rows]
+            view.copy_((torch.rand(view.shape, generator=gen, device=self.device, dtype=torch.float32) * 2 - 1) * lim)
+        fill(self.W, self.n_items, self.n_items, k)
+        fill(self.W2T, self.n_items, k, self.n_items)
+        fill(self.V, self.n_users, self.n_users, k)
+        fill(self.b, k, k, k)
+        fill(self.b2, self.n_items, self.n_items, self.n_items)
+
     def set_params(self, W, W_, V, b, b_):
         """Weights in the reference's orientation: W [N,K], W_ [K,N], V [U,K], b [K], b_ [N]."""
         k = self.k
@@ -195,17 +212,39 @@ class CdaeEngine:
             'drx_cdae_step_dense')
         return self._loss if want_loss else None
 
-    def step_sparse(self, step, bt, loss='bce', want_loss=False):
-        """One sampled-output step (sparse Adagrad / lazy Adam on touched rows)."""
+    def step_sparse(self, step, bt, loss='bce', want_loss=False, events=None):
+        """One sampled-output step (sparse Adagrad / lazy Adam on touched rows).
+        events: optional list of 6 recorded-once torch.cuda.Event(enable_timing=True); their raw hipEvent_t are
+        re-recorded by the library around each phase (include/drx.h, drx_cdae_step_sparse_timed)."""
         a = self.adam_alpha(self.lr, step + 1)
         o = self._optim([a] * 5)
         sc = self._ensure_scratch(bt.B, bt.n_touch_slots)
-        check(lib().drx_cdae_step_sparse(
-            C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
-            _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE,
-            ptr(sc), sc.numel(), ptr(self._loss) if want_loss else None, stream_ptr(self.device)),
-            'drx_cdae_step_sparse')
+        lk = _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE
+        lo = ptr(self._loss) if want_loss else None
+        if events is None:
+            check(lib().drx_cdae_step_sparse(C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt), lk,
+                                             ptr(sc), sc.numel(), lo, stream_ptr(self.device)), 'drx_cdae_step_sparse')
+        else:
+            arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events])
+            check(lib().drx_cdae_step_sparse_timed(C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
+                                                   lk, ptr(sc), sc.numel(), lo, arr, stream_ptr(self.device)),
+                  'drx_cdae_step_sparse_timed')
         return self._loss if want_loss else None
+
+    def sample_device(self, B, neg_ratio, seed):
+        """Throughput-mode PointSampler on the GPU: returns device tensors (uid, iid, y, keep_off)."""
+        uid = torch.empty(B, dtype=torch.int32, device=self.device)
+        iid = torch.empty(B, dtype=torch.int32, device=self.device)
+        y = torch.empty(B, dtype=torch.float32, device=self.device)
+        keep_off = torch.empty(B + 1, dtype=torch.int32, device=self.device)
+        need = lib().drx_point_sample_scratch_bytes(B)
+        if getattr(self, '_sscratch', None) is None or self._sscratch.numel() < need:
+            self._sscratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        check(lib().drx_point_sample(C.byref(self._hist), self.n_users, self.n_items, B, neg_ratio,
+                                     int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y), ptr(keep_off),
+                                     ptr(self._sscratch), self._sscratch.numel(), stream_ptr(self.device)),
+              'drx_point_sample')
+        return uid, iid, y, keep_off
 
     def topk(self, scores, k, cand_mask=None):
         """Row-wise top-k with heapq.nlargest((score, iid)) ordering (cdae.py:103)."""

@@ -124,6 +124,23 @@ int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxH
                          const DrxBatch *bt, int32_t loss_kind,
                          void *scratch, size_t scratch_bytes, float *loss_out, void *stream);
 
+/* Same step with per-phase timing: `events` holds DRX_SPARSE_PHASES + 1 caller-created hipEvent_t; event i is recorded
+ * on `stream` before phase i, the last one after the final phase.  Phases: 0 gather+forward+backward (k_sampled_fwd_bwd),
+ * 1 touch sort, 2 segmented reduce + row update (k_seg_reduce), 3 cross-chunk fix-up, 4 hidden-bias update. */
+#define DRX_SPARSE_PHASES 5
+int drx_cdae_step_sparse_timed(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist,
+                               const DrxBatch *bt, int32_t loss_kind, void *scratch, size_t scratch_bytes,
+                               float *loss_out, void *const *events, void *stream);
+
+/* ---- device-side point sampler (throughput mode; distribution of point_sampler.py:44-61) ------------
+ * Draws B triples with a counter-based generator keyed by (seed, b): negatives with probability
+ * neg_ratio/(neg_ratio+1) = uniform (u,i) outside u's positives, positives = uniform user then uniform positive.
+ * Also writes keep_off[B+1] (exclusive prefix sum of deg(uid[b])). */
+size_t drx_point_sample_scratch_bytes(int32_t B);
+int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
+                     uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
+                     void *scratch, size_t scratch_bytes, void *stream);
+
 /* ---- ranking (cdae.py:90-103, recommender_abc.py:454-461) --------------------------------
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with
  * cand_mask == NULL || bit (r*n + i) set; order = descending score, ties by larger index

@@ -266,6 +266,25 @@ def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss=
     return lval, (h, p)
 
 
+def drx_hash_u32(seed, a, b):
+    """numpy restatement of drx_hash_u32 (include/drx.h): the counter-based corruption mask of the throughput mode.
+    Entry j of batch row b survives iff drx_hash_u32(mask_seed, b, j) >= floor(float32(q) * 2^32)."""
+    M = (1 << 64) - 1
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        x = np.uint64(seed & M) + a * np.uint64(0x9E3779B97F4A7C15) + b * np.uint64(0xD1B54A32D192ED03)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return (x >> np.uint64(32)).astype(np.uint32)
+
+
+def q_threshold(q):
+    t = float(np.float32(q)) * 4294967296.0
+    return 0 if t <= 0 else min(int(t), 0xFFFFFFFF)
+
+
 # ----------------------------------------------------------------------------------------------
 # ranking (cdae.py:90-103): heapq.nlargest over (prediction, iid) => ties broken by larger iid
 # ----------------------------------------------------------------------------------------------
