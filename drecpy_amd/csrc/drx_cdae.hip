@@ -486,8 +486,8 @@ struct SparseBufs {
   uint32_t *keys, *vals, *keys_s, *vals_s;    // [T]
   float *phead, *ptail;                       // [n_chunks, ld]
   float *phs, *pts;                           // [n_chunks] scalar (b2) partials
-  uint32_t *span_list;                        // [n_chunks]
-  uint32_t *n_span;                           // [1]
+  uint32_t *span_list, *long_list;            // [n_chunks] each
+  uint32_t *n_span;                           // [0] crossing segments, [1] long ones
   float *bpart;                               // [n_bpart, ld]
   int T, n_chunks, n_bpart;
 };
@@ -562,19 +562,39 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
 // Segmented reduction over the sorted touch list in fixed chunks of kChunk touches per group.
 // Segments that lie inside one chunk are updated here; segments crossing chunk borders leave
 // partial rows that k_span_fixup combines in chunk order (deterministic).
+// The chunk's (key, sample) pairs are fetched with one coalesced load per lane and broadcast by shuffles; the
+// contribution rows are then loaded LB at a time (independent loads in flight) before they are folded in order.
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_seg_reduce(DrxCdaeParams P, DrxOptim opt, int B, float scale, SparseBufs S) {
   const int lane = threadIdx.x % G;
   const int g = blockIdx.x * (kBlock / G) + threadIdx.x / G;
   if (g >= S.n_chunks) return;
   const int start = g * kChunk, end = min(S.T, start + kChunk);
+  const int n = end - start;
   const uint32_t N = (uint32_t)P.n_items;
   const uint32_t prev_key = start > 0 ? S.keys_s[start - 1] : DRX_KEY_NONE;
   const uint32_t next_key = end < S.T ? S.keys_s[end] : DRX_KEY_NONE;
-  // lane l preloads touch start+l (kChunk <= 64; for G < kChunk loop)
+  constexpr int KPL = (kChunk + G - 1) / G;          // (key, val) registers per lane
+  constexpr int LB = J == 1 ? 8 : (J == 2 ? 4 : 2);  // rows in flight per group
+  uint32_t kreg[KPL], vreg[KPL];
+#pragma unroll
+  for (int r = 0; r < KPL; ++r) {
+    const int t = r * G + lane;
+    const bool ok = t < n && t < kChunk;
+    kreg[r] = ok ? S.keys_s[start + t] : DRX_KEY_NONE;
+    vreg[r] = ok ? S.vals_s[start + t] : 0u;
+  }
+  auto bcast = [&](const uint32_t (&reg)[KPL], int t) -> uint32_t {
+    uint32_t sel = reg[0];
+#pragma unroll
+    for (int r = 1; r < KPL; ++r) sel = (t / G == r) ? reg[r] : sel;
+    return (uint32_t)__shfl((int)sel, t % G, G);
+  };
   float4 acc[J];
+#pragma unroll
+  for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
   float accs = 0.f;
-  uint32_t cur = DRX_KEY_NONE;
+  uint32_t cur = DRX_KEY_NONE, last_key = DRX_KEY_NONE;
   bool cur_from_start = false;
   auto flush = [&](bool at_end) {
     if (cur == DRX_KEY_NONE) return;
@@ -594,59 +614,117 @@ __global__ __launch_bounds__(kBlock) void k_seg_reduce(DrxCdaeParams P, DrxOptim
       }
     }
   };
-  for (int j = start; j < end; ++j) {
-    const uint32_t key = S.keys_s[j];
-    if (key == DRX_KEY_NONE) break;        // padding (dropped inputs) sorts last
-    if (key != cur) {
-      flush(false);
-      cur = key;
-      cur_from_start = (j == start);
+  for (int t0 = 0; t0 < n; t0 += LB) {
+    uint32_t k8[LB];
+    float s8[LB];
+    float4 rows[LB][J];
 #pragma unroll
-      for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
-      accs = 0.f;
+    for (int u = 0; u < LB; ++u) {
+      const int t = t0 + u;
+      k8[u] = t < n ? bcast(kreg, t) : DRX_KEY_NONE;    // padding (dropped inputs) sorts last
+      const uint32_t b = bcast(vreg, t < n ? t : 0);
+      s8[u] = 0.f;
+#pragma unroll
+      for (int jx = 0; jx < J; ++jx) rows[u][jx] = f4_zero();
+      if (k8[u] != DRX_KEY_NONE) {
+        const bool is_out = k8[u] >= N && k8[u] < 2 * N;
+        load_row<G, J>(is_out ? S.g2 : S.dz1, (size_t)b, P.ld, lane, rows[u]);
+        if (is_out) s8[u] = S.dz2[b];
+      }
     }
-    const uint32_t b = S.vals_s[j];
-    float4 v[J];
-    if (key >= N && key < 2 * N) {
-      load_row<G, J>(S.g2, (size_t)b, P.ld, lane, v);
-      accs += S.dz2[b];
 #pragma unroll
-      for (int jx = 0; jx < J; ++jx) f4_add(acc[jx], v[jx]);
-    } else {
-      load_row<G, J>(S.dz1, (size_t)b, P.ld, lane, v);
-      const float c = key < N ? scale : 1.0f;
+    for (int u = 0; u < LB; ++u) {
+      const uint32_t key = k8[u];
+      if (key != DRX_KEY_NONE) {
+        if (key != cur) {
+          flush(false);
+          cur = key;
+          cur_from_start = (t0 + u == 0);
 #pragma unroll
-      for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c, v[jx]);
+          for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+          accs = 0.f;
+        }
+        const float c = key < N ? scale : 1.0f;
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c, rows[u][jx]);
+        accs += s8[u];
+        last_key = key;
+      }
     }
   }
-  // the last segment ends at the chunk border iff the loop ran to `end` without hitting padding
-  const bool ran_to_end = (end > start) && (S.keys_s[end - 1] != DRX_KEY_NONE);
+  // the last segment ends at the chunk border iff the final touch of the chunk is a real key
+  const bool ran_to_end = n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE;
+  (void)last_key;
   flush(ran_to_end);
 }
 
-// One workgroup per chunk-crossing segment: tail partial of its first chunk + head partials of the
-// following chunks whose first key equals the segment key, summed in chunk order.
+// Fix-up of chunk-crossing segments, two tiers.
+//   k_span_short : one GROUP per crossing segment: tail partial of its first chunk + head partials of the next chunks
+//                  whose first key equals the segment key, in chunk order.  Segments that cross more than
+//                  kShortSpan chunk borders (hot items) are queued for
+//   k_span_long  : one 1024-thread workgroup per such segment; its R = 1024/G groups stride over the chunks and the
+//                  R partial sums are combined in a fixed order.  Both tiers are deterministic.
+constexpr int kShortSpan = 6;
+constexpr int kFixBlock = 1024;
+
 template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_span_fixup(DrxCdaeParams P, DrxOptim opt, int B, SparseBufs S) {
+__global__ __launch_bounds__(kBlock) void k_span_short(DrxCdaeParams P, DrxOptim opt, int B, SparseBufs S) {
+  const int lane = threadIdx.x % G;
+  const uint32_t n_span = S.n_span[0];
+  const int gpb = kBlock / G;
+  for (uint32_t si = blockIdx.x * gpb + threadIdx.x / G; si < n_span; si += gridDim.x * gpb) {
+    const int g0 = (int)S.span_list[si];
+    const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
+    // number of following chunks that continue this segment (bounded look-ahead)
+    int m = 0;
+    while (m <= kShortSpan && g0 + 1 + m < S.n_chunks && S.keys_s[(g0 + 1 + m) * kChunk] == key) ++m;
+    if (m > kShortSpan) {
+      if (lane == 0) S.long_list[atomicAdd(&S.n_span[1], 1u)] = (uint32_t)g0;
+      continue;
+    }
+    float4 t[J];
+    load_row<G, J>(S.ptail, (size_t)g0, P.ld, lane, t);
+    float ts = S.pts[g0];
+    for (int c = g0 + 1; c <= g0 + m; ++c) {
+      float4 v[J];
+      load_row<G, J>(S.phead, (size_t)c, P.ld, lane, v);
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
+      ts += S.phs[c];
+    }
+    sparse_apply<G, J>(P, opt, B, key, lane, t, ts);
+  }
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kFixBlock) void k_span_long(DrxCdaeParams P, DrxOptim opt, int B, SparseBufs S) {
   extern __shared__ __align__(16) float lds[];   // [R, ld] + [R]
-  constexpr int R = kBlock / G;
+  constexpr int R = kFixBlock / G;
   float *sc = lds + (size_t)R * P.ld;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  const uint32_t n_span = *S.n_span;
-  for (uint32_t si = blockIdx.x; si < n_span; si += gridDim.x) {
-    const int g0 = (int)S.span_list[si];
+  const uint32_t n_long = S.n_span[1];
+  for (uint32_t si = blockIdx.x; si < n_long; si += gridDim.x) {
+    const int g0 = (int)S.long_list[si];
     const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
     float4 acc[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = f4_zero();
     float accs = 0.f;
-    for (int c = g0 + 1 + r; c < S.n_chunks; c += R) {
+    for (int c = g0 + 1 + r; c < S.n_chunks; c += 2 * R) {
       if (S.keys_s[c * kChunk] != key) break;
-      float4 v[J];
+      const int c2 = c + R;
+      const bool two = c2 < S.n_chunks && S.keys_s[c2 * kChunk] == key;
+      float4 v[J], v2[J];
       load_row<G, J>(S.phead, (size_t)c, P.ld, lane, v);
 #pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+      for (int j = 0; j < J; ++j) v2[j] = f4_zero();
+      float s2 = 0.f;
+      if (two) { load_row<G, J>(S.phead, (size_t)c2, P.ld, lane, v2); s2 = S.phs[c2]; }
+#pragma unroll
+      for (int j = 0; j < J; ++j) { f4_add(acc[j], v[j]); f4_add(acc[j], v2[j]); }
       accs += S.phs[c];
+      accs += s2;
+      if (!two) break;
     }
     __syncthreads();
     store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
@@ -704,15 +782,28 @@ __global__ __launch_bounds__(kBlock) void k_bias_partial(int ld, int B, const fl
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_bias_final(DrxCdaeParams P, DrxOptim opt, int B, const float *__restrict__ part,
                                                        int n_part, const float *__restrict__ lossb, float *loss_out) {
+  extern __shared__ __align__(16) float lds[];   // [R, ld]
   __shared__ float red[kBlock / 64];
-  const int lane = threadIdx.x % G;
-  if (threadIdx.x < G) {
+  constexpr int R = kBlock / G;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  float4 acc[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+  for (int i = r; i < n_part; i += R) {
+    float4 v[J];
+    load_row<G, J>(part, (size_t)i, P.ld, lane, v);
+#pragma unroll
+    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+  }
+  store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
+  __syncthreads();
+  if (r == 0) {
     float4 g[J], w[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) g[j] = f4_zero();
-    for (int i = 0; i < n_part; ++i) {
+    for (int rr = 0; rr < R; ++rr) {
       float4 v[J];
-      load_row<G, J>(part, (size_t)i, P.ld, lane, v);
+      load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
 #pragma unroll
       for (int j = 0; j < J; ++j) f4_add(g[j], v[j]);
     }
@@ -786,7 +877,7 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   SparseBufs S{};
   S.T = n_touch_slots + 2 * B;
   S.n_chunks = (S.T + kChunk - 1) / kChunk;
-  S.n_bpart = 512;
+  S.n_bpart = 256;
   S.dz1 = cv.take<float>((size_t)B * P.ld);
   S.g2 = cv.take<float>((size_t)B * P.ld);
   S.dz2 = cv.take<float>(B);
@@ -800,6 +891,7 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.phs = cv.take<float>(S.n_chunks);
   S.pts = cv.take<float>(S.n_chunks);
   S.span_list = cv.take<uint32_t>(S.n_chunks);
+  S.long_list = cv.take<uint32_t>(S.n_chunks);
   S.n_span = cv.take<uint32_t>(64);
   S.bpart = cv.take<float>((size_t)S.n_bpart * P.ld);
   const int bits = bits_for((uint64_t)2 * P.n_items + P.n_users + 1);
@@ -953,7 +1045,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
-    DRX_HIP(hipMemsetAsync(S.n_span, 0, sizeof(uint32_t), st));                                                        \
+    DRX_HIP(hipMemsetAsync(S.n_span, 0, 2 * sizeof(uint32_t), st));                                                        \
     /* slots beyond keep_off[B] (n_touch_slots may be an upper bound) must read as padding */                          \
     DRX_HIP(hipMemsetAsync(S.keys, 0xFF, (size_t)S.T * sizeof(uint32_t), st));                                         \
     EV(0);                                                                                                             \
@@ -966,13 +1058,17 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     hipLaunchKernelGGL((k_seg_reduce<G, J>), dim3((S.n_chunks + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, bt->B, \
                        scale, S);                                                                                      \
     EV(3);                                                                                                             \
-    hipLaunchKernelGGL((k_span_fixup<G, J>), dim3(1024), dim3(kBlock), ((size_t)gpb * p->ld + gpb) * 4, st, *p, *opt,  \
-                       bt->B, S);                                                                                      \
+    hipLaunchKernelGGL((k_span_short<G, J>), dim3(1024), dim3(kBlock), 0, st, *p, *opt, bt->B, S);                     \
+    if (((size_t)(kFixBlock / G) * (p->ld + 1)) * 4 > 48 * 1024)                                                       \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_span_long<G, J>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                  (int)(((size_t)(kFixBlock / G) * (p->ld + 1)) * 4)));                                \
+    hipLaunchKernelGGL((k_span_long<G, J>), dim3(256), dim3(kFixBlock), ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4,   \
+                       st, *p, *opt, bt->B, S);                                                                        \
     EV(4);                                                                                                             \
     hipLaunchKernelGGL((k_bias_partial<G, J>), dim3(n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B, \
                        S.dz1, S.bpart, rows_per_block);                                                                \
-    hipLaunchKernelGGL((k_bias_final<G, J>), dim3(1), dim3(kBlock), 0, st, *p, *opt, bt->B, S.bpart, n_bpart, S.lossb, \
-                       loss_out);                                                                                      \
+    hipLaunchKernelGGL((k_bias_final<G, J>), dim3(1), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, bt->B,      \
+                       S.bpart, n_bpart, S.lossb, loss_out);                                                           \
     EV(5);                                                                                                             \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
