@@ -1,0 +1,469 @@
+"""Column-store interaction dataset with the DRecPy `InteractionDataset` API that the fit()/rank()/evaluation
+path uses (reference: DRecPy/Dataset/dataset_abc.py, mem_dataset.py, dataset_factory.py — the sqlite backend,
+db_dataset.py, is out of scope).
+
+Layout: one numpy array per column plus a `rid` index; the positives CSR (and its transpose) is built once with
+sort-based numpy calls instead of the reference's per-user Python loop (mem_dataset.py:480-498).  Internal ids are the
+rank of first appearance (mem_dataset.py:309-330): for integer raw ids the map is built on the GPU by
+`drx_idmap_build` whenever a GPU is present (bit-exact integer work); string ids — which cannot travel to the device —
+and CPU-only hosts use the host statement in `_first_appearance_host`.
+"""
+import random
+
+import numpy as np
+
+ID_COLS = ('uid', 'iid', 'rid')
+
+
+def _first_appearance_host(raw):
+    """codes (int64) and categories in first-appearance order; host logic for string ids / CPU-only hosts."""
+    arr = np.asarray(raw)
+    uniq, first, inv = np.unique(arr, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind='stable')              # unique values ordered by first appearance
+    rank = np.empty(len(uniq), dtype=np.int64)
+    rank[order] = np.arange(len(uniq))
+    return rank[inv], uniq[order]
+
+
+def _first_appearance_device(raw):
+    """int64 raw ids -> codes via the HIP kernel drx_idmap_build (include/drx.h)."""
+    import ctypes as C
+    import torch
+    from .. import _lib
+    L = _lib.lib()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    r = torch.as_tensor(np.ascontiguousarray(raw, dtype=np.int64)).to(dev)
+    n = r.numel()
+    codes = torch.empty(n, dtype=torch.int32, device=dev)
+    uniq = torch.empty(n, dtype=torch.int64, device=dev)
+    n_u = torch.zeros(1, dtype=torch.int32, device=dev)
+    sb = L.drx_idmap_scratch_bytes(n)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    _lib.check(L.drx_idmap_build(_lib.ptr(r), n, _lib.ptr(codes), _lib.ptr(uniq), _lib.ptr(n_u), _lib.ptr(scratch), sb,
+                                 _lib.stream_ptr(dev)), 'drx_idmap_build')
+    k = int(n_u.item())
+    return codes.cpu().numpy().astype(np.int64), uniq[:k].cpu().numpy()
+
+
+def first_appearance_codes(raw):
+    arr = np.asarray(raw)
+    if arr.dtype.kind in 'iu' and len(arr):
+        import torch
+        if torch.cuda.is_available():
+            return _first_appearance_device(arr.astype(np.int64))
+    return _first_appearance_host(arr)
+
+
+def _code_dtype(n):
+    """pd.Categorical.codes dtype by cardinality (int8/int16/int32), as the reference's uid/iid columns have."""
+    return np.int8 if n <= 127 else np.int16 if n <= 32767 else np.int32
+
+
+class InteractionDatasetABC:
+    """Marker base class (the samplers of the reference assert on it, point_sampler.py:23)."""
+
+
+class MemoryInteractionDataset(InteractionDatasetABC):
+    def __init__(self, path='', columns=None, delimiter=',', has_header=False, df=None, user_label='user',
+                 item_label='item', interaction_label='interaction', verbose=True, encoding=None, **kwds):
+        self.verbose = verbose
+        self.in_memory = True
+        self.path = path
+        self.has_internal_ids = False
+        self._user_mapping = self._user_mapping_inv = self._item_mapping = self._item_mapping_inv = None
+        self._csr = self._csc = None
+        if df is None:
+            import pandas as pd
+            names = [c for c in columns if c != 'rid']
+            use = [i for i, c in enumerate(names) if c is not None]
+            frame = pd.read_csv(path, delimiter=delimiter, names=names, encoding=encoding,
+                                skiprows=1 if has_header else 0, usecols=use)
+            cols = {c: frame[c].values for c in names if c is not None}
+            self.columns = [c for c in columns if c is not None]
+        else:
+            cols = {str(c): np.asarray(df[c]) for c in (df.columns if hasattr(df, 'columns') else df.keys())}
+            try:
+                cols['user'] = cols[user_label]
+                cols['item'] = cols[item_label]
+                cols['interaction'] = cols[interaction_label]
+            except KeyError as e:
+                raise Exception('An error occurred when converting the main columns. Required columns: "user", "item" '
+                                f'and "interaction". More details: {e}')
+            for lab, std in ((user_label, 'user'), (item_label, 'item'), (interaction_label, 'interaction')):
+                if lab != std:
+                    cols.pop(lab, None)
+            self.columns = list(cols.keys()) + ['rid'] if columns is None else list(columns)
+        for c in list(cols):
+            if c not in self.columns:
+                del cols[c]
+            elif cols[c].dtype.kind == 'O':
+                cols[c] = np.array(['' if (x is None or x != x) else x for x in cols[c]], dtype=object)
+        for req in ('user', 'item', 'interaction'):
+            if req not in cols:
+                raise Exception(f'Missing required column "{req}".')
+        self._cols = cols
+        n = len(cols['user'])
+        self._rid = np.arange(n, dtype=np.int64)
+
+    # ---- basics -------------------------------------------------------------------------------------
+    def __len__(self):
+        return len(self._rid)
+
+    def __str__(self):
+        return f'[MemoryInteractionDataset with shape {(len(self), len(self.columns))}]'
+
+    __repr__ = __str__
+
+    def _log(self, msg):
+        if self.verbose:
+            print(f'[{self.__class__.__name__}] {msg}')
+
+    def _validate_column(self, column):
+        assert column is not None, 'No column was given.'
+        assert type(column) is str, f'Unexpected column type "{type(column)}".'
+        assert column in self.columns, f'Unexpected column "{column}".'
+
+    def _handle_columns(self, columns):
+        if columns is None:
+            columns = list(self.columns)
+        if type(columns) is not list:
+            columns = [columns]
+        for c in columns:
+            assert c in self.columns, f'Unexpected column "{c}".'
+        return columns
+
+    def _col(self, c):
+        return self._rid if c == 'rid' else self._cols[c]
+
+    def copy(self):
+        new = MemoryInteractionDataset.__new__(MemoryInteractionDataset)
+        new.__dict__.update(self.__dict__)
+        new.columns = list(self.columns)
+        new._cols = dict(self._cols)          # arrays are shared, never modified in place
+        new._csr = new._csc = None
+        return new
+
+    __copy__ = copy       # recommender_abc.py:137 calls __copy__ (absent in the reference -> crash); provided here
+
+    def _filtered(self, mask):
+        new = self.copy()
+        new._cols = {c: v[mask] for c, v in self._cols.items()}
+        new._rid = self._rid[mask]
+        return new
+
+    # ---- query language (mem_dataset.py:385-478) ----------------------------------------------------------
+    def _query_mask(self, query):
+        mask = None
+        for seg in str(query).split(','):
+            seg = seg.strip()
+            try:
+                column, op, value = seg.split(' ')
+            except ValueError:
+                raise Exception('Query segment failed to be parsed. Check if there are no missing spaces or invalid '
+                                f'characters. Query segment: "{seg}"')
+            assert column in self.columns, f'Unexpected column "{column}".'
+            vals = self._col(column)
+            kind = vals.dtype.kind
+            if column not in ID_COLS:
+                try:
+                    if kind in 'fiu':
+                        value = float(value)
+                    elif kind in 'OUS':
+                        value = eval(value)
+                except ValueError:
+                    raise Exception(f'Query "{query}" was failed to be parsed: check if no invalid comparisons are '
+                                    'being made (column of type int being compared to a str, or vice versa).')
+            else:
+                value = int(value)
+            if column == 'user' and self.has_internal_ids and kind not in 'iu':
+                vals, value = self._cols['uid'], self.user_to_uid(value)
+            elif column == 'item' and self.has_internal_ids and kind not in 'iu':
+                vals, value = self._cols['iid'], self.item_to_iid(value)
+            if value is None:
+                m = np.zeros(len(vals), dtype=bool) if op != '!=' else np.ones(len(vals), dtype=bool)
+            elif op == '>': m = vals > value
+            elif op == '>=': m = vals >= value
+            elif op == '<=': m = vals <= value
+            elif op == '<': m = vals < value
+            elif op == '==': m = vals == value
+            elif op == '!=': m = vals != value
+            else:
+                raise Exception(f'Unexpected operator "{op}".')
+            mask = m if mask is None else (mask & m)
+        return mask
+
+    def select(self, query, copy=True):
+        mask = self._query_mask(query)
+        new = self._filtered(mask)
+        if not copy:
+            self.__dict__.update(new.__dict__)
+            return self
+        return new
+
+    def _record(self, i, columns, to_list):
+        if to_list:
+            rec = [self._col(c)[i] for c in columns]
+            return rec[0] if len(rec) == 1 else rec
+        return {c: self._col(c)[i] for c in columns}
+
+    def select_one(self, query, columns=None, to_list=False):
+        columns = self._handle_columns(columns)
+        idx = np.flatnonzero(self._query_mask(query))
+        if len(idx) == 0:
+            return None
+        return self._record(idx[0], columns, to_list)
+
+    def exists(self, query):
+        return bool(self._query_mask(query).any())
+
+    def unique(self, columns=None, copy=True):
+        columns = list(self._handle_columns(columns))
+        if 'rid' not in columns:
+            columns.append('rid')
+        data_cols = [c for c in columns if c != 'rid']
+        if len(self):
+            keys = [first_appearance_codes_host_safe(self._cols[c]) for c in data_cols]
+            comb = keys[0]
+            for k in keys[1:]:
+                comb = comb * (int(k.max()) + 1) + k
+            _, first = np.unique(comb, return_index=True)
+            first.sort()
+        else:
+            first = np.zeros(0, dtype=np.int64)
+        new = self.copy() if copy else self
+        new._cols = {c: self._cols[c][first] for c in data_cols}
+        new._rid = self._rid[first]
+        new.columns = columns
+        new._csr = new._csc = None
+        return new
+
+    def count_unique(self, columns=None):
+        return len(self.unique(columns))
+
+    def max(self, column=None):
+        self._validate_column(column)
+        return self._col(column).max()
+
+    def min(self, column=None):
+        self._validate_column(column)
+        return self._col(column).min()
+
+    def values(self, columns=None, to_list=False):
+        columns = self._handle_columns(columns)
+        for i in range(len(self)):
+            yield self._record(i, columns, to_list)
+
+    def values_list(self, columns=None, to_list=False):
+        columns = self._handle_columns(columns)
+        if to_list and len(columns) == 1:
+            return list(self._col(columns[0]))
+        return [self._record(i, columns, to_list) for i in range(len(self))]
+
+    def drop(self, record_ids, copy=True, keep=False):
+        m = np.isin(self._rid, np.asarray(list(record_ids)))
+        new = self._filtered(m if keep else ~m)
+        if not copy:
+            self.__dict__.update(new.__dict__)
+            return self
+        return new
+
+    def apply(self, column, function):
+        self._validate_column(column)
+        if column in ('rid', 'uid', 'iid', 'user', 'item'):
+            raise Exception(f'Column "{column}" is read-only.')
+        try:
+            out = [function(x) for x in self._cols[column]]
+            t = type(out[0].item() if hasattr(out[0], 'item') else out[0])
+            assert t in (int, float, str), f'New column type "{t}" is not supported.'
+            self._cols = dict(self._cols)
+            self._cols[column] = np.array(out, dtype=object if t is str else None)
+            self._csr = self._csc = None
+        except Exception as e:
+            raise Exception(f'Failed to apply operation on column "{column}". Details: {e}')
+
+    def save(self, path='', columns=None, write_header=False):
+        if len(path) == 0 and len(self.path) == 0:
+            raise Exception('No save path was specified.')
+        path = path or self.path
+        cols = [c for c in self.columns if c not in ID_COLS]
+        import csv
+        with open(path, 'w', newline='') as f:
+            w = csv.writer(f)
+            if write_header:
+                w.writerow(cols)
+            for i in range(len(self)):
+                w.writerow([self._cols[c][i] for c in cols])
+
+    # ---- internal ids (mem_dataset.py:264-330) -----------------------------------------------------------
+    def assign_internal_ids(self):
+        ucodes, ucats = first_appearance_codes(self._cols['user'])
+        icodes, icats = first_appearance_codes(self._cols['item'])
+        self._cols = dict(self._cols)
+        self._cols['uid'] = ucodes.astype(_code_dtype(len(ucats)))
+        self._cols['iid'] = icodes.astype(_code_dtype(len(icats)))
+        py = lambda x: x.item() if hasattr(x, 'item') else x
+        self._user_mapping = {py(c): k for k, c in enumerate(ucats)}
+        self._user_mapping_inv = {k: py(c) for k, c in enumerate(ucats)}
+        self._item_mapping = {py(c): k for k, c in enumerate(icats)}
+        self._item_mapping_inv = {k: py(c) for k, c in enumerate(icats)}
+        for c in ('uid', 'iid'):
+            if c not in self.columns:
+                self.columns.append(c)
+        self.has_internal_ids = True
+        self._csr = self._csc = None
+
+    def remove_internal_ids(self):
+        self.has_internal_ids = False
+        if 'uid' in self.columns:
+            self._cols = {c: v for c, v in self._cols.items() if c not in ('uid', 'iid')}
+            self.columns.remove('uid')
+            self.columns.remove('iid')
+
+    def _raw_key(self, col, x):
+        if self._cols[col].dtype.kind in 'iu':
+            try:
+                return int(x)
+            except ValueError:
+                raise Exception(f'The provided {col} type does not match the inferred type (expected: int, found: {type(x)}')
+        return str(x)
+
+    def user_to_uid(self, user):
+        assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        return self._user_mapping.get(self._raw_key('user', user))
+
+    def uid_to_user(self, uid):
+        assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        return self._user_mapping_inv.get(int(uid)) if uid is not None else None
+
+    def item_to_iid(self, item):
+        assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        return self._item_mapping.get(self._raw_key('item', item))
+
+    def iid_to_item(self, iid):
+        assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        return self._item_mapping_inv.get(int(iid)) if iid is not None else None
+
+    # ---- interaction matrix (mem_dataset.py:165-218, 480-498) ------------------------------------------------
+    def interaction_csr(self, transpose=False):
+        """(indptr int64, indices int64, values float64) of the [U,N] interaction matrix, duplicates summed,
+        columns ascending; transpose=True gives the [N,U] matrix."""
+        assert self.has_internal_ids is True, 'Cannot retrieve user interaction vector without assigned internal ids.'
+        if self._csr is None:
+            U, N = len(self._user_mapping), len(self._item_mapping)
+            self._csr = _build_csr(self._cols['uid'], self._cols['iid'], self._cols['interaction'], U, N)
+            self._csc = _build_csr(self._cols['iid'], self._cols['uid'], self._cols['interaction'], N, U)
+        return self._csc if transpose else self._csr
+
+    def positives_csr(self, interaction_threshold):
+        """CSR of the entries with (summed) interaction >= threshold: the non-zeros of cdae.py:61."""
+        indptr, cols, vals = self.interaction_csr()
+        keep = vals >= interaction_threshold
+        rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))[keep]
+        ip = np.zeros(len(indptr), dtype=np.int64)
+        np.add.at(ip, rows + 1, 1)
+        return np.cumsum(ip), cols[keep].astype(np.int32)
+
+    def _vec(self, csr, i, n):
+        from scipy.sparse import csr_matrix
+        indptr, cols, vals = csr
+        s, e = indptr[i], indptr[i + 1]
+        return csr_matrix((vals[s:e], cols[s:e], np.array([0, e - s])), shape=(1, n))
+
+    def select_user_interaction_vec(self, uid):
+        assert self.has_internal_ids is True, 'Cannot retrieve user interaction vector without assigned internal ids.'
+        assert self.uid_to_user(uid) is not None, f'User internal id {uid} was not found.'
+        return self._vec(self.interaction_csr(), uid, len(self._item_mapping))
+
+    def select_item_interaction_vec(self, iid):
+        assert self.has_internal_ids is True, 'Cannot retrieve user interaction vector without assigned internal ids.'
+        assert self.iid_to_item(iid) is not None, f'Item internal id {iid} was not found.'
+        return self._vec(self.interaction_csr(transpose=True), iid, len(self._user_mapping))
+
+    # ---- random generators (mem_dataset.py:104-163), host streams via libdrx --------------------------------------
+    def _sampler(self, neg_ratio, threshold, seed):
+        from ..Sampler.point_sampler import _HostSampler
+        return _HostSampler(self, neg_ratio, threshold, seed)
+
+    def select_random_generator(self, query=None, seed=None):
+        assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        assert len(self) > 0, 'No records were found.'
+        src = self if query is None else self.select(query)
+        assert len(src) > 0, 'No records were found to sample from.'
+        rng = random.Random(seed) if seed is not None else random
+        max_uid = int(self.max('uid'))
+        rows_of = {}
+        for r, u in enumerate(src._cols['uid'].tolist()):
+            rows_of.setdefault(u, []).append(r)
+        cols = [c for c in self.columns if c != 'rid']
+        while True:
+            u = rng.randint(0, max_uid)
+            rows = rows_of.get(u)
+            if not rows:
+                continue
+            r = rows[rng.randint(0, len(rows) - 1)]
+            rec = {c: src._cols[c][r] for c in cols}
+            rec['rid'] = src._rid[r]
+            rec['uid'], rec['iid'] = int(rec['uid']), int(rec['iid'])
+            yield rec
+
+    def null_interaction_pair_generator(self, interaction_threshold=None, seed=None):
+        assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        assert len(self) > 0, 'No records were found to sample from.'
+        rng = random.Random(seed) if seed is not None else random
+        max_uid, max_iid = int(self.max('uid')), int(self.max('iid'))
+        pairs = set(zip(self._cols['uid'].tolist(), self._cols['iid'].tolist()))
+        while True:      # the "existing null pair" branch is dead for the in-memory backend (mem_dataset.py:141-146)
+            u = rng.randint(0, max_uid)
+            i = rng.randint(0, max_iid)
+            if (u, i) not in pairs:
+                yield u, i
+
+
+def first_appearance_codes_host_safe(col):
+    return _first_appearance_host(col)[0]
+
+
+def _build_csr(rows, cols, vals, n_rows, n_cols):
+    rows = np.asarray(rows, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    vals = np.asarray(vals, dtype=np.float64)
+    key = rows * n_cols + cols
+    order = np.argsort(key, kind='stable')
+    ks = key[order]
+    if len(ks):
+        uniq, start = np.unique(ks, return_index=True)
+        sums = np.add.reduceat(vals[order], start)
+    else:
+        uniq, sums = ks, vals
+    r = uniq // n_cols
+    indptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(indptr, r + 1, 1)
+    return np.cumsum(indptr), (uniq - r * n_cols), sums
+
+
+class InteractionDataset:
+    """Factory with the reference's signature (dataset_factory.py:18-54); in-memory backend only."""
+
+    def __new__(cls, path='', columns=None, delimiter=',', has_header=False, in_memory=True, **kwds):
+        if path.endswith('.sqlite') or not in_memory:
+            raise NotImplementedError('the sqlite out-of-core backend (db_dataset.py) is out of scope for drecpy_amd')
+        if columns is None:
+            raise Exception('Missing the "columns" argument.')
+        if 'uid' in columns:
+            raise Exception('Cannot import column "uid".')
+        if 'iid' in columns:
+            raise Exception('Cannot import column "iid".')
+        return MemoryInteractionDataset(path=path, columns=columns + ['rid'], delimiter=delimiter,
+                                        has_header=has_header, **kwds)
+
+    @staticmethod
+    def read_df(df, user_label='user', item_label='item', interaction_label='interaction', **kwds):
+        return MemoryInteractionDataset(df=df, user_label=user_label, item_label=item_label,
+                                        interaction_label=interaction_label, **kwds)
+
+    @staticmethod
+    def from_arrays(user, item, interaction, **extra):
+        """Convenience constructor from numpy arrays (no pandas)."""
+        d = {'user': np.asarray(user), 'item': np.asarray(item), 'interaction': np.asarray(interaction)}
+        d.update({k: np.asarray(v) for k, v in extra.items()})
+        return MemoryInteractionDataset(df=d, verbose=False)

@@ -1,0 +1,173 @@
+"""CDAE (Collaborative Denoising Auto-Encoder) on the MI355X engine — constructor, hooks and semantics of the reference
+model (DRecPy/Recommender/cdae.py), arithmetic in hand-written HIP kernels behind the C ABI of include/drx.h.
+
+mode='reference' (default) reproduces the reference step exactly: every sampled triple contributes its USER only
+(cdae.py:52), the loss runs over ALL output units against the batch-mean target ((B,B,N) Keras broadcast,
+cdae.py:78-79), L2/B over the full W, W_, V (cdae.py:81-82), dense Keras Adam with one apply per variable
+(recommender_abc.py:328-334), corruption drawn from MT19937 seeded like RecommenderABC._rng, N draws per row
+(cdae.py:63) — the stream is generated in C++ (drx_rng_corruption_keep) and is bit-identical to `random.Random(seed)`.
+
+mode='sampled' is the engine's throughput mode (CDAE paper's negative sampling, which the reference skips, cdae.py:5):
+the sampled (uid, iid, value) triple selects ONE output unit with target 1[value >= threshold]; sparse Adagrad (or lazy
+Adam) touches only the rows involved; corruption comes from a counter-based mask evaluated on the device.
+"""
+import numpy as np
+
+from .recommender_abc import RecommenderABC
+from ..Sampler import PointSampler
+
+
+class CDAE(RecommenderABC):
+    def __init__(self, hidden_factors=50, corruption_level=0.2, loss='bce', mode='reference', loss_targets='reference',
+                 sparse_optimizer='adagrad', device='cuda:0', **kwds):
+        super().__init__(**kwds)
+        self.hidden_factors = hidden_factors
+        self.corruption_level = corruption_level
+        if loss not in ('mse', 'bce'):
+            raise Exception(f'Loss function "{loss}" is not supported. Supported losses: "mse", "bce".')
+        if mode not in ('reference', 'sampled'):
+            raise Exception(f'Unknown mode "{mode}" (supported: "reference", "sampled").')
+        self._loss_name = loss
+        self.mode = mode
+        self.loss_targets = loss_targets
+        self.sparse_optimizer = sparse_optimizer
+        self.device = device
+
+    # ---- cdae.py:34-45 ---------------------------------------------------------------------------
+    def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):
+        from .. import _lib
+        from ..engine import CdaeEngine
+        ds = self.interaction_dataset
+        self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
+        weights = kwds.get('initial_weights')
+        if weights is not None:                      # injected weights (TF's GlorotUniform stream is not reproducible)
+            self._engine.set_params(**weights)
+        else:
+            self._engine.init_glorot(self.seed if self.seed is not None else np.random.SeedSequence().entropy % (2 ** 32))
+        self._hist_indptr, self._hist_indices = ds.positives_csr(self.interaction_threshold)
+        self._engine.set_history(self._hist_indptr, self._hist_indices)
+        if self.mode == 'reference':
+            self._engine.init_optimizer('adam', learning_rate, reg_rate)
+        else:
+            self._engine.init_optimizer(self.sparse_optimizer, learning_rate, reg_rate)
+        self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
+        L = _lib.lib()
+        seed = self.seed if self.seed is not None else self._rng.getrandbits(62)
+        self._mask_rng = L.drx_rng_create(int(seed))    # same MT19937 stream as self._rng = random.Random(seed)
+        self._mask_seed = int(seed)
+
+    def _restore_engine(self, params):
+        from ..engine import CdaeEngine
+        self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
+        self._engine.set_params(**params)
+        ip, idx = self.interaction_dataset.positives_csr(self.interaction_threshold)
+        self._hist_indptr, self._hist_indices = ip, idx
+        self._engine.set_history(ip, idx)
+
+    def _sample_batch(self, batch_size, **kwds):       # cdae.py:47
+        if self.mode == 'sampled' and kwds.get('as_arrays', True):
+            return self._sampler.sample_arrays(batch_size)      # (uid, iid, value, is_negative) numpy arrays
+        return self._sampler.sample(batch_size)                  # list of (uid, iid, value) like the reference
+
+    # ---- fused training step (replaces recommender_abc.py:190-204 for this model) ------------------------------------
+    def _batch_arrays(self, batch_samples):
+        if isinstance(batch_samples, tuple) and len(batch_samples) == 4 and hasattr(batch_samples[0], 'dtype'):
+            return batch_samples[0], batch_samples[1], batch_samples[2]
+        u = np.array([s[0] for s in batch_samples], dtype=np.int32)
+        i = np.array([s[1] for s in batch_samples], dtype=np.int32)
+        v = np.array([float(s[2]) for s in batch_samples], dtype=np.float64)
+        return u, i, v
+
+    def _corruption_keep(self, uid):
+        """MT19937 corruption stream of cdae.py:63 for the batch rows (C++ host, N draws per row, batch order)."""
+        from .. import _lib
+        B = len(uid)
+        deg = self._hist_indptr[uid.astype(np.int64) + 1] - self._hist_indptr[uid.astype(np.int64)]
+        keep_off = np.zeros(B + 1, dtype=np.int32)
+        keep = np.zeros(max(int(deg.sum()), 1), dtype=np.uint8)
+        uid32 = np.ascontiguousarray(uid, dtype=np.int32)
+        _lib.check(_lib.lib().drx_rng_corruption_keep(
+            self._mask_rng, self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items,
+            uid32.ctypes.data, B, float(self.corruption_level), keep_off.ctypes.data, keep.ctypes.data, len(keep)),
+            'drx_rng_corruption_keep')
+        return keep_off, keep
+
+    def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
+        uid, iid, val = self._batch_arrays(batch_samples)
+        eng = self._engine
+        if self.mode == 'reference':
+            keep_off, keep = self._corruption_keep(uid)
+            bt, alive = eng.make_batch(uid, keep_off=keep_off, keep=keep, q=self.corruption_level,
+                                       n_touch_slots=int(keep_off[-1]))
+            loss = eng.step_dense(step, bt, self._loss_name, self.loss_targets, want_loss=want_loss)
+            return float(loss.sum().item()) if want_loss else None
+        y = (val >= self.interaction_threshold).astype(np.float32)
+        bt, alive = eng.make_batch(uid, iid, y, q=self.corruption_level, mask_seed=self._mask_seed + 0x9E3779B9 * (step + 1))
+        loss = eng.step_sparse(step, bt, self._loss_name, want_loss=want_loss)
+        return float(loss[0].item()) if want_loss else None
+
+    # ---- hooks kept for API compatibility (cdae.py:50-82) ---------------------------------------------------
+    def _predict_batch(self, batch_samples, **kwds):
+        """Training-mode reconstructions of the batch users: (predictions [B,N] device tensor, desired [B,N] uint8)."""
+        uid, _, _ = self._batch_arrays(batch_samples)
+        keep_off, keep = self._corruption_keep(uid)
+        with self._device_lock:
+            _, pred = self._engine.forward(uid, keep_off=keep_off, keep=keep, q=self.corruption_level)
+        desired = np.zeros((len(uid), self.n_items), dtype=np.uint8)
+        for b, u in enumerate(uid):
+            desired[b, self._hist_indices[self._hist_indptr[u]:self._hist_indptr[u + 1]]] = 1
+        return pred, desired
+
+    def _compute_batch_loss(self, predictions, desired_values, **kwds):
+        """Keras BCE / MSE of the reference on the (B,B,N) broadcast == against the batch-mean target (cdae.py:78-79)."""
+        import torch
+        p = predictions.double()
+        t = torch.as_tensor(np.asarray(desired_values), dtype=torch.float64, device=p.device)
+        tbar = t.mean(dim=0, keepdim=True)
+        if self._loss_name == 'bce':
+            eps = 1e-7
+            pc = p.clamp(eps, 1 - eps)
+            return float((-(tbar * torch.log(pc + eps) + (1 - tbar) * torch.log(1 - pc + eps))).mean().item())
+        return float((((p - tbar) ** 2) + tbar * (1 - tbar)).mean().item())
+
+    def _compute_reg_loss(self, reg_rate, batch_size, trainable_models=None, trainable_layers=None, trainable_weights=None, **kwds):
+        e = self._engine                                   # cdae.py:81-82
+        return float(sum((t.double() ** 2).sum().item() for t in (e.W, e.W2T, e.V)) * 0.5 * reg_rate / batch_size)
+
+    # ---- inference (cdae.py:67-71, 84-103) -----------------------------------------------------------------
+    def _predict(self, uid, iid=None, **kwds):
+        if uid is None:
+            return None
+        with self._device_lock:
+            _, pred = self._engine.forward(np.array([uid], dtype=np.int32))
+            row = pred[0].cpu().numpy()
+        return row if iid is None else row[iid]
+
+    def _rank(self, uid, iids, n, novelty):
+        """Top-n of the candidates by (prediction, iid) — heapq.nlargest order (cdae.py:90-103) — on the device."""
+        import torch
+        from ..engine import pack_mask_bits
+        cand = np.zeros(self.n_items, dtype=bool)
+        cand[np.fromiter((int(i) for i in iids), dtype=np.int64)] = True
+        if novelty:
+            cand[self._all_user_items(uid)] = False        # every (uid, iid) row of the frame, whatever its value
+        n_cand = int(cand.sum())
+        k = min(int(n), n_cand)
+        if k <= 0:
+            return []
+        with self._device_lock:
+            eng = self._engine
+            _, pred = eng.forward(np.array([uid], dtype=np.int32))
+            mask = torch.as_tensor(pack_mask_bits(cand).view(np.int32)).to(eng.device)
+            idx, val = eng.topk(pred, k, mask)
+            idx, val = idx[0].cpu().numpy(), val[0].cpu().numpy()
+        return [(float(v), int(i)) for v, i in zip(val, idx) if i >= 0]
+
+    def _all_user_items(self, uid):
+        if not hasattr(self, '_user_items'):
+            ds = self.interaction_dataset
+            order = np.argsort(ds._cols['uid'], kind='stable')
+            self._ui_sorted = ds._cols['iid'][order].astype(np.int64)
+            self._ui_ptr = np.searchsorted(ds._cols['uid'][order], np.arange(self.n_users + 1))
+            self._user_items = True
+        return self._ui_sorted[self._ui_ptr[uid]:self._ui_ptr[uid + 1]]

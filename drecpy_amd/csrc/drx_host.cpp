@@ -165,10 +165,14 @@ DrxSampler *drx_sampler_create(const int32_t *h_uid, const int32_t *h_iid, const
   return s;
 }
 
-int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out) {
-  if (!s || n < 0 || !h_uid_out || !h_iid_out || !h_val_out) return DRX_EINVAL;
+int drx_sampler_draw(DrxSampler *s, int32_t kind, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out,
+                     uint8_t *h_neg_out) {
+  if (!s || n < 0 || kind < 0 || kind > 2 || !h_uid_out || !h_iid_out || !h_val_out) return DRX_EINVAL;
   for (int32_t k = 0; k < n; ++k) {
-    const bool null_pair = s->r_sel.uniform(0.0, (double)(s->neg_ratio + 1)) > 1.0;   // point_sampler.py:58
+    bool null_pair;
+    if (kind == DRX_DRAW_MIXED) null_pair = s->r_sel.uniform(0.0, (double)(s->neg_ratio + 1)) > 1.0;   // point_sampler.py:58
+    else null_pair = (kind == DRX_DRAW_NEGATIVE);
+    if (h_neg_out) h_neg_out[k] = null_pair ? 1 : 0;
     if (null_pair) {                                                                   // mem_dataset.py:154-163
       for (;;) {
         const int64_t u = s->r_neg.randint(0, s->max_uid);
@@ -180,6 +184,7 @@ int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_
         }
       }
     } else {                                                                           // mem_dataset.py:119-129
+      if (s->pos_rows.empty()) return DRX_EINVAL;    // no eligible positive at all: the reference would spin forever
       for (;;) {
         const int64_t u = s->r_pos.randint(0, s->max_uid);
         const int64_t lo = s->pos_ptr[(size_t)u], hi = s->pos_ptr[(size_t)u + 1];
@@ -191,6 +196,10 @@ int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_
     }
   }
   return DRX_OK;
+}
+
+int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out) {
+  return drx_sampler_draw(s, DRX_DRAW_MIXED, n, h_uid_out, h_iid_out, h_val_out, nullptr);
 }
 
 void drx_sampler_destroy(DrxSampler *s) { delete s; }

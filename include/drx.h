@@ -65,7 +65,7 @@ typedef struct DrxHistory {
  * iid,y: sampled output unit and its {0,1} target — used by the sampled-output mode only.
  * Corruption (cdae.py:63): entry j of user uid[b]'s history survives iff
  *     keep != NULL ?  keep[keep_off[b] + j] != 0            (host MT19937 stream, parity mode)
- *                  :  drx_hash(mask_seed, b, j) >= q * 2^32  (counter-based, throughput mode)
+ *                  :  drx_hash_u32(mask_seed, b, j) >= q * 2^32  (counter-based, throughput mode)
  * keep_off[b] = sum_{b' < b} deg(uid[b'])  (exclusive prefix sum, keep_off[B] = total). */
 typedef struct DrxBatch {
   int32_t B;
@@ -163,6 +163,12 @@ typedef struct DrxSampler DrxSampler;
 DrxSampler *drx_sampler_create(const int32_t *h_uid, const int32_t *h_iid, const double *h_val, int64_t n_rows,
                                int32_t neg_ratio, int32_t has_threshold, double threshold, int64_t seed);
 int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out);
+/* kind: DRX_DRAW_MIXED = PointSampler.sample, DRX_DRAW_NEGATIVE = sample_negative, DRX_DRAW_POSITIVE = sample_positive
+ * (point_sampler.py:74-96); each advances only the stream(s) the reference method advances.
+ * h_neg_out (optional): 1 where the draw is a negative (a pair absent from the frame, value 0). */
+enum { DRX_DRAW_MIXED = 0, DRX_DRAW_NEGATIVE = 1, DRX_DRAW_POSITIVE = 2 };
+int drx_sampler_draw(DrxSampler *s, int32_t kind, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out,
+                     uint8_t *h_neg_out);
 void drx_sampler_destroy(DrxSampler *s);
 
 /* CDAE corruption stream (cdae.py:63, RecommenderABC._rng of recommender_abc.py:74): draws

@@ -1,0 +1,119 @@
+"""End-to-end drop-in test: CDAE(...).fit() on the GPU against the CPU oracle driven by the SAME seeded inputs
+(injected initial weights, bit-exact PointSampler stream, MT19937 corruption stream) — SURVEY.md §8d parity gates."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cdae_oracle as co
+from oracle import data_oracle as do
+from helpers import load_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame():
+    f = load_frames()['pt_int_dense']          # 64 users x 40 items, values 0..5 (zeros exercise the threshold)
+    return {k: v.copy() for k, v in f.items()}
+
+
+def _oracle_fit(frame, K, epochs, B, seed, weights, loss='bce', q=0.2, lr=1e-3, reg=1e-3, thr=1e-3, neg_ratio=5):
+    uid, _ = do.first_appearance_codes(frame['user'].tolist())
+    iid, _ = do.first_appearance_codes(frame['item'].tolist())
+    U, N = int(uid.max()) + 1, int(iid.max()) + 1
+    indptr, cols, vals = do.interaction_csr(uid, iid, frame['interaction'], U, N)
+    sampler = do.PointSamplerOracle(uid, iid, frame['interaction'], neg_ratio, thr, seed)
+    rng = random.Random(seed)                    # RecommenderABC._rng (recommender_abc.py:74)
+    p = {k: np.asarray(v, np.float64).copy() for k, v in weights.items()}
+    st = co.adam_state(p)
+    tmat = np.zeros((U, N), dtype=bool)
+    for u in range(U):
+        s, e = indptr[u], indptr[u + 1]
+        tmat[u, cols[s:e][vals[s:e] >= thr]] = True
+    losses = []
+    for step in range(epochs):
+        batch = sampler.sample(B)
+        uids = np.array([b[0] for b in batch])
+        t = tmat[uids]
+        keep = do.corruption_keep_mask(rng, B, N, q)                     # N draws per row (cdae.py:63)
+        xt = (t & keep).astype(np.float64) / (1.0 - q)
+        losses.append(co.dense_step(p, st, step, uids, xt, t, lr, reg, loss))
+    return p, tmat, losses
+
+
+@pytest.mark.parametrize('K,loss', [(50, 'bce'), (16, 'mse')])
+def test_cdae_fit_matches_oracle(K, loss):
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    frame = _frame()
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    rng = np.random.default_rng(7)
+    U, N = 64, 40
+    w = co.init_params(rng, U, N, K, np.float32)
+    epochs, B, seed = 12, 32, 10
+    model = CDAE(hidden_factors=K, corruption_level=0.2, loss=loss, seed=seed, verbose=False)
+    model.fit(ds, epochs=epochs, batch_size=B, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5, initial_weights=w)
+    assert model.n_users == U and model.n_items == N
+    p, tmat, _ = _oracle_fit(frame, K, epochs, B, seed, w, loss)
+    # predict(): raw ids in, full-precision match on every (user, item)
+    worst = 0.0
+    for u in range(U):
+        row = model._predict(u)
+        want = co.predict_row(p, u, tmat[u])
+        worst = max(worst, float(np.max(np.abs(row - want) / np.abs(want))))
+    assert worst < 1e-5, worst
+    raw_u, raw_i = frame['user'][0], frame['item'][3]
+    uid, iid = ds.user_to_uid(raw_u), ds.item_to_iid(raw_i)
+    assert abs(model.predict(raw_u, raw_i) - co.predict_row(p, uid, tmat[uid])[iid]) < 1e-6
+    # rank(): heapq.nlargest over (prediction, iid), novelty removes every item the user has a row for
+    cand_raw = [ds.iid_to_item(i) for i in range(0, N, 2)] + [10 ** 9]            # one unknown item is skipped
+    got = model.rank(raw_u, cand_raw, novelty=True, n=5)
+    rows = np.flatnonzero(ds._cols['uid'] == uid)
+    seen = set(ds._cols['iid'][rows].tolist())
+    want = co.rank_row(co.predict_row(p, uid, tmat[uid]).astype(np.float32), range(0, N, 2), 5, exclude=seen)
+    assert [ds.item_to_iid(i) for _, i in got] == [i for _, i in want]
+    rec = model.recommend(raw_u, n=7, novelty=False)
+    want = co.rank_row(co.predict_row(p, uid, tmat[uid]).astype(np.float32), range(N), 7)
+    assert [ds.item_to_iid(i) for _, i in rec] == [i for _, i in want]
+
+
+def test_cdae_loss_tracking_and_hooks():
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE, MaxValidationValueRule
+    frame = _frame()
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    w = co.init_params(np.random.default_rng(3), 64, 40, 8, np.float32)
+    calls = []
+
+    def cb(m):
+        calls.append(len(calls))
+        return {'val': -abs(len(calls) - 2)}          # best at the 2nd callback (epoch 4)
+    model = CDAE(hidden_factors=8, seed=10, verbose=False)
+    model.fit(ds, epochs=8, batch_size=16, initial_weights=w, epoch_callback_fn=cb, epoch_callback_freq=2,
+              early_stopping_rule=MaxValidationValueRule('val'), early_stopping_freq=2)
+    _, _, losses = _oracle_fit(frame, 8, 8, 16, 10, w)
+    got = model._loss_tracker.epoch_losses
+    assert len(got) == 8 and max(abs(a - b) / b for a, b in zip(got, losses)) < 1e-4
+    # weights were reverted to the rule's best epoch (4)
+    p4, tmat, _ = _oracle_fit(frame, 8, 4, 16, 10, w)
+    row = model._predict(5)
+    want = co.predict_row(p4, 5, tmat[5])
+    assert float(np.max(np.abs(row - want) / np.abs(want))) < 1e-5
+    # API-compat hooks
+    batch = model._sampler.sample(4)
+    preds, desired = model._predict_batch(batch)
+    assert tuple(preds.shape) == (4, 40) and desired.shape == (4, 40)
+    assert model._compute_batch_loss(preds, desired) > 0 and model._compute_reg_loss(1e-3, 4) > 0
+
+
+def test_cdae_sampled_mode_learns():
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    ds = InteractionDataset.read_df(_frame(), verbose=False)
+    model = CDAE(hidden_factors=16, mode='sampled', seed=3, verbose=False)
+    model.fit(ds, epochs=1, batch_size=256, learning_rate=0.05)
+    l0 = model._do_batch(model._sample_batch(256), step=1, want_loss=True)
+    for s in range(2, 60):
+        model._do_batch(model._sample_batch(256), step=s)
+    l1 = model._do_batch(model._sample_batch(256), step=60, want_loss=True)
+    assert l1 < l0

@@ -1,0 +1,64 @@
+"""GPU parity for the integer kernels: id map (bit-exact vs the reference-generated golden codes) and top-k."""
+import numpy as np
+import pytest
+
+from oracle import cdae_oracle as co
+from oracle import data_oracle as do
+from helpers import load_frames, load_json
+
+pytestmark = pytest.mark.gpu
+
+
+def test_idmap_device_matches_reference_codes():
+    from drecpy_amd.Dataset.interaction_dataset import _first_appearance_device
+    g = load_json('idmap.json')
+    frames = load_frames()
+    for k in ('pt_str_gapped', 'pt_int_dense', 'ls_int_ts'):
+        codes, cats = _first_appearance_device(frames[k]['item'].astype(np.int64))     # int raw ids
+        assert codes.tolist() == g[k]['iid']
+        assert len(cats) == g[k]['n_items']
+        want_codes, want_cats = do.first_appearance_codes(frames[k]['item'].tolist())
+        assert cats.tolist() == list(want_cats)
+    # reference resource file with int ids (tests/Dataset/resources/test_int_ids.csv)
+    e = g['test_int_ids.csv']
+    codes, _ = _first_appearance_device(np.array(e['user'], dtype=np.int64))
+    assert codes.tolist() == e['uid']
+    # large random case with heavy duplication and negative ids
+    rng = np.random.default_rng(0)
+    raw = rng.integers(-5000, 5000, size=300_000).astype(np.int64) * 1_000_003
+    codes, cats = _first_appearance_device(raw)
+    want, wcats = do.first_appearance_codes(raw.tolist())
+    assert np.array_equal(codes, want) and cats.tolist() == wcats
+
+
+def test_dataset_assign_ids_on_gpu_matches_golden():
+    from drecpy_amd.Dataset import InteractionDataset
+    g = load_json('idmap.json')
+    for k, f in load_frames().items():
+        ds = InteractionDataset.read_df(dict(f), verbose=False)
+        ds.assign_internal_ids()
+        assert ds._cols['uid'].tolist() == g[k]['uid'] and ds._cols['iid'].tolist() == g[k]['iid']
+        for raw, want in g[k]['probe_user_to_uid']:
+            assert ds.user_to_uid(raw) == want
+        for iid, want in g[k]['probe_iid_to_item']:
+            assert ds.iid_to_item(iid) == want
+
+
+@pytest.mark.parametrize('n,k', [(40, 5), (1682, 10), (3706, 100), (5000, 5000), (16384, 7)])
+def test_topk_matches_heapq(n, k):
+    import torch
+    from drecpy_amd.engine import CdaeEngine, pack_mask_bits
+    eng = CdaeEngine(4, 8, 4)
+    rng = np.random.default_rng(n)
+    R = 5
+    scores = rng.random((R, n)).astype(np.float32)
+    scores[:, ::7] = scores[:, 3:4]                    # many exact ties -> larger index must win
+    mask = rng.random((R, n)) < 0.7
+    mask[0] = True
+    idx, val = eng.topk(torch.as_tensor(scores).cuda(), k, torch.as_tensor(pack_mask_bits(mask).view(np.int32)).cuda())
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    for r in range(R):
+        want = co.rank_row(scores[r], np.flatnonzero(mask[r]), k)
+        got = [(float(v), int(i)) for v, i in zip(val[r], idx[r]) if i >= 0]
+        assert got == [(float(np.float32(v)), i) for v, i in want]
+        assert (idx[r] >= 0).sum() == min(k, int(mask[r].sum()))

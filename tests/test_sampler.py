@@ -1,0 +1,112 @@
+"""Host-side sampler / RNG of libdrx.so against stdlib random (CPython's MT19937) and the golden streams recorded
+from the reference (tests/golden/point_sampler.json).  No GPU needed: these entry points are host code."""
+import ctypes as C
+import random
+
+import numpy as np
+
+from helpers import load_frames, load_json
+
+
+def _ds(frame):
+    from drecpy_amd.Dataset import InteractionDataset
+    ds = InteractionDataset.read_df({k: v for k, v in frame.items()}, verbose=False)
+    ds.assign_internal_ids()
+    return ds
+
+
+def test_rng_matches_cpython():
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    for seed in (0, 1, 10, 23, 2 ** 31, 2 ** 40 + 17, -5):
+        r = L.drx_rng_create(seed)
+        py = random.Random(seed)
+        for _ in range(700):                       # crosses the 624-word regeneration boundary
+            assert L.drx_rng_random(r) == py.random()
+        for hi in (0, 1, 2, 5, 942, 1681, 10 ** 6, 2 ** 31 - 1, 2 ** 32, 2 ** 40 + 3):
+            for _ in range(20):
+                assert L.drx_rng_randint(r, 0, hi) == py.randint(0, hi)
+        L.drx_rng_destroy(r)
+
+
+def test_point_sampler_streams_match_reference():
+    from drecpy_amd.Sampler import PointSampler
+    ps = load_json('point_sampler.json')
+    frames = load_frames()
+    checked = 0
+    for key, want in ps.items():
+        k = key.split('|')[0]
+        if k not in frames:
+            continue
+        _, neg, thr, seed = key.split('|')
+        thr = None if thr == 'None' else float(thr)
+        s = PointSampler(_ds(frames[k]), int(neg), thr, int(seed))
+        got = s.sample(len(want) // 2) + s.sample(len(want) - len(want) // 2)
+        assert [[int(a), int(b), int(c)] for a, b, c in got] == want, key
+        checked += len(want)
+    assert checked >= 1500
+
+
+def test_point_sampler_resource_csv_stream():
+    # stream captured from the reference on tests/Dataset/resources/test.csv
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Sampler import PointSampler
+    g = load_json('idmap.json')['test.csv']
+    ds = InteractionDataset.read_df({'user': np.array(g['user'], dtype=object), 'item': np.array(g['item'], dtype=object),
+                                     'interaction': np.array(g['interaction'])}, verbose=False)
+    ds.assign_internal_ids()
+    assert ds._cols['uid'].tolist() == g['uid'] and ds._cols['iid'].tolist() == g['iid']
+    s = PointSampler(ds, 5, 0.001, 10)
+    got = [[int(a), int(b), int(c)] for a, b, c in s.sample(64)]
+    assert got == load_json('point_sampler.json')['test.csv|5|0.001|10']
+    # reference known answers (tests/Dataset/test_mem_dataset.py:678-697): seed 23 -> (1,0),(0,2),(1,3),(0,1)
+    s = PointSampler(ds, 5, None, 23)
+    assert [s.sample_negative()[:2] for _ in range(4)] == [(1, 0), (0, 2), (1, 3), (0, 1)]
+    gen = ds.null_interaction_pair_generator(seed=23)
+    assert [next(gen) for _ in range(4)] == [(1, 0), (0, 2), (1, 3), (0, 1)]
+    s = PointSampler(ds, 5, None, 23)
+    want = load_json('point_sampler.json')['test.csv|select_random_gen|seed23']
+    assert [[int(x) for x in s.sample_positive()] for _ in range(16)] == want
+    gen = ds.select_random_generator(seed=23)
+    assert [[r['uid'], r['iid'], int(r['interaction'])] for r in (next(gen) for _ in range(16))] == want
+
+
+def test_corruption_stream_matches_python_rng():
+    from drecpy_amd import _lib
+    from oracle import data_oracle as do
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    U, N, B, q = 30, 47, 12, 0.2
+    indptr = np.zeros(U + 1, dtype=np.int64)
+    idx = []
+    for u in range(U):
+        c = np.sort(rng.choice(N, size=rng.integers(0, 9), replace=False))
+        idx.append(c); indptr[u + 1] = indptr[u] + len(c)
+    indices = np.concatenate(idx).astype(np.int32)
+    uids = rng.integers(0, U, size=B).astype(np.int32)
+    r = L.drx_rng_create(10)
+    keep_off = np.zeros(B + 1, dtype=np.int32)
+    keep = np.zeros(int(indptr[-1]) * 2 + 8, dtype=np.uint8)
+    assert L.drx_rng_corruption_keep(r, indptr.ctypes.data, indices.ctypes.data, N, uids.ctypes.data, B, q,
+                                     keep_off.ctypes.data, keep.ctypes.data, len(keep)) == 0
+    want = do.corruption_keep_mask(random.Random(10), B, N, q)       # cdae.py:63 stream, N draws per row
+    for b, u in enumerate(uids):
+        cols = indices[indptr[u]:indptr[u + 1]]
+        assert keep[keep_off[b]:keep_off[b + 1]].astype(bool).tolist() == want[b, cols].tolist()
+    # the next draw continues the same MT stream
+    py = random.Random(10)
+    for _ in range(B * N):
+        py.random()
+    assert L.drx_rng_random(r) == py.random()
+    L.drx_rng_destroy(r)
+
+
+def test_library_exports_every_declared_symbol():
+    import re, os
+    from drecpy_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'drx.h')).read()
+    declared = set(re.findall(r'\b(drx_[a-z0-9_]+)\s*\(', hdr))
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
