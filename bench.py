@@ -113,12 +113,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    debug_gloo = os.environ.get('DRX_BENCH_BACKEND') == 'gloo'     # debugging aid: N ranks sharing ONE GPU, host-staged exchange
+    dev_index = local_rank % torch.cuda.device_count() if debug_gloo else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if debug_gloo:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from drecpy_amd import synth
     from drecpy_amd.engine import CdaeEngine
@@ -139,14 +144,15 @@ def main():
         stepper = None
     else:
         from drecpy_amd.dist import ShardedCdae
-        stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG)
+        stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
+                              cpu_staging=debug_gloo)
         eng = stepper.engine
 
     # ---- pre-sampled batches, resident in HBM -------------------------------------------------------------
     batches, structs, kept_tot = [], [], 0
     for i in range(args.n_batches):
         seed = 1000 + 7919 * i + 104729 * rank
-        uid, iid, y, keep_off = eng.sample_device(B, NEG_RATIO, seed)
+        uid, iid, y, keep_off = eng.sample_device(B, NEG_RATIO, seed, n_items=N)
         torch.cuda.synchronize()
         n_slots = int(keep_off[-1].item())
         kept_tot += kept_count(keep_off, seed, Q)
@@ -188,14 +194,17 @@ def main():
 
     phases = np.array([[es[i].elapsed_time(es[i + 1]) for i in range(5)] for es in evs])     # ms
     ph = phases.mean(axis=0)
-    names = ['k_sampled_fwd_bwd', 'touch_sort', 'k_seg_reduce', 'k_span_fixup', 'bias_update']
-    # algorithmic bytes per launch (SURVEY.md §8d, DESIGN.md): forward reads 4K*R per sample; the update reads and
+    # algorithmic bytes per launch (SURVEY.md §8d, DESIGN.md §3): forward reads 4K*R per sample; the update reads and
     # writes parameter + S optimizer slots per touched-row occurrence: 4K*R*(2+2S), S = 1 for Adagrad.
-    alg = {'k_sampled_fwd_bwd': B * 4.0 * K * rows_per_sample,
-           'k_seg_reduce': B * 4.0 * K * rows_per_sample * 4.0}
-    dom = 'k_seg_reduce' if ph[2] >= ph[0] else 'k_sampled_fwd_bwd'
-    dom_ms = ph[2] if dom == 'k_seg_reduce' else ph[0]
-    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+    alg_fwd = B * 4.0 * K * rows_per_sample
+    alg_upd = B * 4.0 * K * rows_per_sample * 4.0
+    if world == 1:
+        names = ['k_sampled_fwd_bwd', 'touch_sort', 'k_seg_reduce', 'k_span_fixup', 'bias_update']
+        dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
+    else:
+        names = ['touches+index+row_exchange', 'k_shard_fwd_bwd', 'local_reduce+grad_exchange', 'owner_apply', 'bias_allreduce']
+        dom, dom_ms, dom_alg = 'k_shard_fwd_bwd', ph[1], alg_fwd
+    achieved = dom_alg / (dom_ms * 1e-3) / 1e9
     step_alg = B * 4.0 * K * rows_per_sample * 5.0
 
     if rank == 0:
@@ -210,7 +219,7 @@ def main():
                        'sharding': 'single GPU' if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': float(dom_ms),
+                         'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms),
                          'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
                          'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             'phases_ms': {n: float(v) for n, v in zip(names, ph)},

@@ -34,6 +34,11 @@ class Batch(C.Structure):
                 ('n_touch_slots', C.c_int32)]
 
 
+class Shard(C.Structure):
+    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('n_items', C.c_int32), ('items_per_rank', C.c_int32),
+                ('n_users_local', C.c_int32)]
+
+
 class Optim(C.Structure):
     _fields_ = [('kind', C.c_int32), ('lr', C.c_float), ('reg_rate', C.c_float), ('beta1', C.c_float),
                 ('beta2', C.c_float), ('eps', C.c_float), ('alpha', C.c_float * 5),
@@ -60,6 +65,25 @@ SIGNATURES = {
     'drx_point_sample_scratch_bytes': (C.c_size_t, [C.c_int32]),
     'drx_point_sample': (C.c_int, [C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_shard_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32]),
+    'drx_shard_touches': (C.c_int, [C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    'drx_shard_index': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_void_p]),
+    'drx_shard_gather_rows': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    'drx_shard_fwd_bwd': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    'drx_shard_reduce': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_float,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_shard_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_shard_bias_grad': (C.c_int, [C.POINTER(CdaeParams), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    'drx_shard_bias_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.c_int32, C.c_void_p, C.c_void_p]),
     'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                            C.c_void_p]),
     'drx_idmap_scratch_bytes': (C.c_size_t, [C.c_int64]),

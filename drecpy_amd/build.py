@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libdrx.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
-SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_sampler.hip', 'drx_host.cpp']
+SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_sampler.hip', 'drx_shard.hip', 'drx_host.cpp']
 COMMON = ['-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
 
@@ -27,7 +27,8 @@ def _newer(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(ROOT, 'include', 'drx.h'), os.path.join(CSRC, 'drx_common.hpp')]
+    headers = [os.path.join(ROOT, 'include', 'drx.h')] + [os.path.join(CSRC, h) for h in
+               ('drx_common.hpp', 'drx_rows.hpp', 'drx_segreduce.hpp')]
     objs = []
     procs = []
     for src in SOURCES:

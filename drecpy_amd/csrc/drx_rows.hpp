@@ -1,0 +1,115 @@
+// Row-group device helpers shared by the libdrx.so kernels (gfx950): coalesced float4 row access for a group of G
+// lanes, the hidden-layer activation, Keras optimizer updates, deterministic block reduction.
+#pragma once
+#include "drx_common.hpp"
+
+namespace drx {
+
+template <int G, int J>
+__device__ __forceinline__ void load_row(const float *base, size_t row, int ld, int lane, float4 (&v)[J]) {
+  const float4 *r = reinterpret_cast<const float4 *>(base + row * (size_t)ld);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    int c = lane + j * G;
+    v[j] = (4 * c < ld) ? r[c] : f4_zero();
+  }
+}
+
+template <int G, int J>
+__device__ __forceinline__ void store_row(float *base, size_t row, int ld, int lane, const float4 (&v)[J]) {
+  float4 *r = reinterpret_cast<float4 *>(base + row * (size_t)ld);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    int c = lane + j * G;
+    if (4 * c < ld) r[c] = v[j];
+  }
+}
+
+__device__ __forceinline__ float colmask(int col, int k, float v) { return col < k ? v : 0.0f; }
+
+// h = sigmoid(scale*bag + V[u] + b), zero in the padding columns.
+template <int G, int J>
+__device__ __forceinline__ void hidden_act(const DrxCdaeParams &P, int u, float scale, int lane,
+                                           const float4 (&acc)[J], float4 (&h)[J]) {
+  float4 v[J], bb[J];
+  load_row<G, J>(P.V, (size_t)u, P.ld, lane, v);
+  load_row<G, J>(P.b, 0, P.ld, lane, bb);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int col = 4 * (lane + j * G);
+    h[j].x = colmask(col + 0, P.k, sigmoidf_(fmaf(scale, acc[j].x, v[j].x + bb[j].x)));
+    h[j].y = colmask(col + 1, P.k, sigmoidf_(fmaf(scale, acc[j].y, v[j].y + bb[j].y)));
+    h[j].z = colmask(col + 2, P.k, sigmoidf_(fmaf(scale, acc[j].z, v[j].z + bb[j].z)));
+    h[j].w = colmask(col + 3, P.k, sigmoidf_(fmaf(scale, acc[j].w, v[j].w + bb[j].w)));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer row updates (fp32, Keras formulas)
+// ------------------------------------------------------------------------------------------------
+struct OptScalars {
+  int kind;
+  float lr, rb;              // rb = reg_rate / B
+  float b1, b2, eps, alpha;  // alpha = Keras-Adam lr_t of the variable being updated
+};
+
+__device__ __forceinline__ void opt_update1(const OptScalars &o, float g, float &p, float &s1, float &s2) {
+  if (o.kind == DRX_OPT_ADAM) {
+    // TF's ApplyAdam functor, operation for operation (1 - beta is formed in fp32 there too)
+    s1 = s1 + (g - s1) * (1.0f - o.b1);
+    s2 = s2 + (g * g - s2) * (1.0f - o.b2);
+    p = p - (s1 * o.alpha) / (sqrtf(s2) + o.eps);
+  } else {
+    s1 = s1 + g * g;
+    p = p - o.lr * g / (sqrtf(s1) + o.eps);
+  }
+}
+
+// Applies g (data gradient, already complete) + rb*p to one row of `tab` with slots s1/s2.
+template <int G, int J>
+__device__ __forceinline__ float row_update(const OptScalars &o, float *tab, float *s1, float *s2, size_t row, int ld,
+                                            int lane, const float4 (&w)[J], const float4 (&g)[J]) {
+  float sq = 0.f;
+  float4 *pr = reinterpret_cast<float4 *>(tab + row * (size_t)ld);
+  float4 *a1 = reinterpret_cast<float4 *>(s1 + row * (size_t)ld);
+  float4 *a2 = (o.kind == DRX_OPT_ADAM) ? reinterpret_cast<float4 *>(s2 + row * (size_t)ld) : nullptr;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = lane + j * G;
+    if (4 * c < ld) {
+      float4 p = w[j];
+      float4 m = a1[c];
+      float4 v = a2 ? a2[c] : f4_zero();
+      sq += f4_dot(p, p);
+      opt_update1(o, fmaf(o.rb, p.x, g[j].x), p.x, m.x, v.x);
+      opt_update1(o, fmaf(o.rb, p.y, g[j].y), p.y, m.y, v.y);
+      opt_update1(o, fmaf(o.rb, p.z, g[j].z), p.z, m.z, v.z);
+      opt_update1(o, fmaf(o.rb, p.w, g[j].w), p.w, m.w, v.w);
+      pr[c] = p;
+      a1[c] = m;
+      if (a2) a2[c] = v;
+    }
+  }
+  return sq;   // partial |row|^2 of this lane (pre-update), for the L2 loss value
+}
+
+__device__ __forceinline__ OptScalars opt_for(const DrxOptim &opt, int var, int B) {
+  OptScalars o;
+  o.kind = opt.kind; o.lr = opt.lr; o.rb = opt.reg_rate / (float)B;
+  o.b1 = opt.beta1; o.b2 = opt.beta2; o.eps = opt.eps; o.alpha = opt.alpha[var];
+  return o;
+}
+
+// Deterministic block reduction of one float per thread -> thread 0 holds the sum.
+__device__ __forceinline__ float block_sum(float v, float *red /* [kBlock/64] in LDS */) {
+  v = group_sum<64>(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kBlock / 64; ++i) t += red[i];
+  return t;
+}
+
+}  // namespace drx

@@ -1,0 +1,278 @@
+"""Row-sharded CDAE across the GPUs of one node: one process per GPU, `torch.distributed` over
+RCCL/xGMI (backend "nccl"); the same orchestration runs over gloo on CPU tensors in the world-size-2 tests, with the
+per-rank device work swapped for a NumPy statement (tests/dist_ops_numpy.py).
+
+Sharding
+  * users (V rows + optimizer state, their positives CSR, and the triples sampled for them): contiguous uid ranges —
+    the 5 GB table of the 10M-user configuration never leaves its GPU and needs no exchange;
+  * item rows (W, W2T, b2 + state): contiguous item ranges of `ipr = ceil(N / world)` rows.
+  * hidden bias b (K floats): replicated, its gradient all-reduced.
+
+One step (every rank, its own B triples; losses/L2 are normalised by the GLOBAL batch so the step equals a single-GPU
+step on the concatenated batch):
+  1. touches of the local batch -> stable sort -> DISTINCT row keys (owner-major key space: a rank's distinct keys are
+     contiguous per owner) -> per-owner counts                                       [drx_shard_touches / _index]
+  2. all-to-all counts, all-to-all(v) of the requested keys                          [xGMI, 4 B per distinct row]
+  3. owners gather the requested rows; all-to-all(v) of rows (+ output biases)       [xGMI, 4K B per distinct row]
+  4. forward/backward against the row cache                                          [drx_shard_fwd_bwd]
+  5. local segmented reduction: ONE gradient row per distinct item row (hot Zipf rows are merged before they travel);
+     V rows are updated in place                                                     [drx_shard_reduce]
+  6. all-to-all(v) of the gradient rows back to the owners                           [xGMI, 4K B per distinct row]
+  7. owners sum duplicates across ranks in rank order and apply sparse Adagrad/Adam  [drx_shard_apply]
+  8. all-reduce of the K-float bias gradient (+ loss), dense update of b.
+Direct all-to-all drives all 7 xGMI links of a GPU at once (ring all-reduce would be bound by one link), and only
+distinct rows travel.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def items_per_rank(n_items, world):
+    return (n_items + world - 1) // world
+
+
+def item_key(n, ipr, is_out):
+    """owner-major row key of item n (numpy / python ints)"""
+    o = n // ipr
+    return o * 2 * ipr + (ipr if is_out else 0) + (n - o * ipr)
+
+
+class HipShardOps:
+    """Per-rank device work through the C ABI (include/drx.h, drx_shard_*)."""
+
+    def __init__(self, n_users_local, n_items, k, rank, world, device, optimizer, lr, reg):
+        from . import _lib
+        from .engine import CdaeEngine
+        self._lib = _lib
+        self.L = _lib.lib()
+        self.ipr = items_per_rank(n_items, world)
+        self.rank, self.world = rank, world
+        self.engine = CdaeEngine(n_users_local, self.ipr, k, device=device)
+        self.engine.init_optimizer(optimizer, lr, reg)
+        self.device = self.engine.device
+        self.ld = self.engine.ld
+        self.shard = _lib.Shard(world, rank, n_items, self.ipr, n_users_local)
+        self._scratch = None
+
+    # -- helpers
+    def _sc(self, n):
+        need = self.L.drx_shard_scratch_bytes(C.byref(self.engine._params), C.byref(self.shard), int(n))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(int(need * 1.3) + 4096, dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    def _e(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def _stream(self):
+        return self._lib.stream_ptr(self.device)
+
+    # -- ops
+    def touches(self, bt):
+        T = bt.n_touch_slots + 2 * bt.B
+        keys, vals, bpos = (self._e(T, dtype=torch.int32) for _ in range(3))
+        p = self._lib.ptr
+        self._lib.check(self.L.drx_shard_touches(C.byref(self.shard), C.byref(self.engine._hist), C.byref(bt), p(keys), p(vals),
+                                                 p(bpos), self._stream()), 'drx_shard_touches')
+        return keys, vals, bpos
+
+    def index(self, keys, vals):
+        T = keys.numel()
+        ks, vs, ss, sp, uk = (self._e(T, dtype=torch.int32) for _ in range(5))
+        bounds = self._e(self.world + 2, dtype=torch.int32)
+        sc = self._sc(T)
+        p = self._lib.ptr
+        self._lib.check(self.L.drx_shard_index(C.byref(self.engine._params), C.byref(self.shard), p(keys), p(vals), T, p(ks),
+                                               p(vs), p(ss), p(sp), p(uk), p(bounds), p(sc), sc.numel(), self._stream()),
+                        'drx_shard_index')
+        return {'keys_s': ks, 'vals_s': vs, 'slot_sorted': ss, 'slot_of_pos': sp, 'uniq_keys': uk,
+                'bounds': bounds.cpu().tolist()}
+
+    def gather_rows(self, req):
+        n = req.numel()
+        rows, b2v = self._e(max(n, 1), self.ld), self._e(max(n, 1))
+        p = self._lib.ptr
+        self._lib.check(self.L.drx_shard_gather_rows(C.byref(self.engine._params), C.byref(self.shard), p(req), n, p(rows),
+                                                     p(b2v), self._stream()), 'drx_shard_gather_rows')
+        return rows[:n], b2v[:n]
+
+    def fwd_bwd(self, bt, slot_of_pos, rows_cache, b2_cache, b_norm, loss_kind):
+        B = bt.B
+        self.dz1, self.g2 = self._e(B, self.ld), self._e(B, self.ld)
+        self.dz2, self.lossb = self._e(B), self._e(B)
+        if rows_cache.numel() == 0:
+            rows_cache, b2_cache = self._e(1, self.ld), self._e(1)
+        p = self._lib.ptr
+        self._lib.check(self.L.drx_shard_fwd_bwd(C.byref(self.engine._params), C.byref(self.engine._hist), C.byref(bt),
+                                                 p(slot_of_pos), p(rows_cache), p(b2_cache), b_norm, loss_kind, p(self.dz1),
+                                                 p(self.g2), p(self.dz2), p(self.lossb), self._stream()), 'drx_shard_fwd_bwd')
+
+    def reduce(self, idx, bpos, q_item, b_norm, q, opt):
+        T = idx['keys_s'].numel()
+        gc, gb2c = self._e(max(q_item, 1), self.ld), self._e(max(q_item, 1))
+        sc = self._sc(T)
+        p = self._lib.ptr
+        self._lib.check(self.L.drx_shard_reduce(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), b_norm,
+                                                float(q), p(idx['keys_s']), p(idx['vals_s']), p(idx['slot_sorted']), p(bpos),
+                                                T, p(self.dz1), p(self.g2), p(self.dz2), p(gc), p(gb2c), p(sc), sc.numel(),
+                                                self._stream()), 'drx_shard_reduce')
+        return gc[:q_item], gb2c[:q_item]
+
+    def apply(self, recv_keys, recv_rows, recv_b2, b_norm, opt):
+        n = recv_keys.numel()
+        if n == 0:
+            return
+        sc = self._sc(n)
+        p = self._lib.ptr
+        self._lib.check(self.L.drx_shard_apply(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), b_norm,
+                                               p(recv_keys), p(recv_rows.contiguous()), p(recv_b2.contiguous()), n, p(sc),
+                                               sc.numel(), self._stream()), 'drx_shard_apply')
+
+    def bias_grad(self, B):
+        out = self._e(self.ld + 1)
+        sc = self._sc(1)
+        p = self._lib.ptr
+        self._lib.check(self.L.drx_shard_bias_grad(C.byref(self.engine._params), p(self.dz1), p(self.lossb), B, p(out), p(sc),
+                                                   sc.numel(), self._stream()), 'drx_shard_bias_grad')
+        return out
+
+    def bias_apply(self, grad, b_norm, opt):
+        g = grad[:self.ld].contiguous()
+        self._lib.check(self.L.drx_shard_bias_apply(C.byref(self.engine._params), C.byref(opt), b_norm, self._lib.ptr(g),
+                                                    self._stream()), 'drx_shard_bias_apply')
+
+    def optim(self, step):
+        a = self.engine.adam_alpha(self.engine.lr, step + 1)
+        return self.engine._optim([a] * 5)
+
+    def make_batch(self, *a, **k):
+        return self.engine.make_batch(*a, **k)
+
+    def set_params(self, W, W_, V, b, b_):
+        self.engine.set_params(W=W, W_=W_, V=V, b=b, b_=b_)
+
+    def get_params(self):
+        return self.engine.get_params()
+
+
+class ShardedCdae:
+    """One rank of the row-sharded sampled-mode CDAE.  `ops` = per-rank compute backend (HipShardOps on a GPU)."""
+
+    def __init__(self, n_users_total, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
+                 optimizer='adagrad', ops=None, group=None, loss='bce', q=0.2, cpu_staging=False):
+        self.rank, self.world, self.group = rank, world, group
+        self.cpu_staging = cpu_staging        # tests: gloo has no device all-to-all; stage the exchange through the host
+        self.n_items, self.k = n_items, k
+        self.ipr = items_per_rank(n_items, world)
+        self.user_lo = n_users_total * rank // world
+        self.user_hi = n_users_total * (rank + 1) // world
+        self.n_users_total = n_users_total
+        n_local = self.user_hi - self.user_lo
+        self.ops = ops if ops is not None else HipShardOps(n_local, n_items, k, rank, world, device, optimizer, lr, reg)
+        self.engine = getattr(self.ops, 'engine', None)
+        self.loss_kind = 0 if loss == 'bce' else 1
+        self.q = q
+        if self.engine is not None:
+            self.engine.set_history(hist_indptr, hist_indices)
+            self._init_random(seed)
+        self.last_loss = None
+
+    def _init_random(self, seed):
+        """GlorotUniform of the GLOBAL shapes, drawn per shard on the device (cdae.py:35-41)."""
+        e = self.engine
+        gen = torch.Generator(device=e.device)
+        gen.manual_seed(int(seed) * 1000003 + self.rank)
+        k = self.k
+
+        def fill(t, fi, fo):
+            lim = math.sqrt(6.0 / (fi + fo))
+            t.zero_()
+            view = t[:, :k] if t.dim() == 2 else t
+            view.copy_((torch.rand(view.shape, generator=gen, device=e.device, dtype=torch.float32) * 2 - 1) * lim)
+        fill(e.W, self.n_items, k)
+        fill(e.W2T, k, self.n_items)
+        fill(e.V, self.n_users_total, k)
+        fill(e.b2, self.n_items, self.n_items)
+        gb = torch.Generator(device=e.device)
+        gb.manual_seed(int(seed))                     # b is replicated: same draw on every rank
+        e.b.zero_()
+        e.b[:k] = (torch.rand(k, generator=gb, device=e.device) * 2 - 1) * math.sqrt(3.0 / k)
+
+    def set_params_global(self, W, W_, V, b, b_):
+        """Slices global (reference-orientation) weights into this rank's shards."""
+        ipr, r = self.ipr, self.rank
+        lo, hi = r * ipr, min(self.n_items, (r + 1) * ipr)
+        dt = np.asarray(W).dtype
+        Wl = np.zeros((ipr, self.k), dt); Wl[:hi - lo] = W[lo:hi]
+        W_l = np.zeros((self.k, ipr), dt); W_l[:, :hi - lo] = W_[:, lo:hi]
+        b_l = np.zeros(ipr, dt); b_l[:hi - lo] = b_[lo:hi]
+        self.ops.set_params(Wl, W_l, np.asarray(V[self.user_lo:self.user_hi], dt), np.asarray(b, dt), b_l)
+
+    # ---- exchanges ---------------------------------------------------------------------------------------
+    def _a2a(self, send, send_counts, recv_counts):
+        shape = (int(sum(recv_counts)),) + tuple(send.shape[1:])
+        out = torch.empty(shape, dtype=send.dtype, device=send.device)
+        if self.world == 1:
+            out.copy_(send[:shape[0]])
+            return out
+        if self.cpu_staging and send.is_cuda:
+            o = torch.empty(shape, dtype=send.dtype)
+            dist.all_to_all_single(o, send.contiguous().cpu(), output_split_sizes=list(recv_counts),
+                                   input_split_sizes=list(send_counts), group=self.group)
+            return o.to(send.device)
+        dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
+                               input_split_sizes=list(send_counts), group=self.group)
+        return out
+
+    def _counts(self, send_counts, device):
+        if self.world == 1:
+            return list(send_counts)
+        s = torch.tensor(send_counts, dtype=torch.int64, device='cpu' if self.cpu_staging else device)
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=self.group)
+        return r.cpu().tolist()
+
+    # ---- one step ------------------------------------------------------------------------------------------
+    def step(self, step, bt, events=None, want_loss=False):
+        ops, W = self.ops, self.world
+        b_norm = bt.B * W
+        opt = ops.optim(step)
+        rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
+        rec(0)
+        keys, vals, bpos = ops.touches(bt)
+        idx = ops.index(keys, vals)
+        bounds = idx['bounds']
+        send_counts = [bounds[o + 1] - bounds[o] for o in range(W)]
+        q_item = bounds[W]
+        recv_counts = self._counts(send_counts, keys.device)
+        req = self._a2a(idx['uniq_keys'][:q_item], send_counts, recv_counts)
+        rows, b2v = ops.gather_rows(req)
+        rows_cache = self._a2a(rows, recv_counts, send_counts)
+        b2_cache = self._a2a(b2v, recv_counts, send_counts)
+        rec(1)        # [0,1): touches, index, row request/response exchange
+        ops.fwd_bwd(bt, idx['slot_of_pos'], rows_cache, b2_cache, b_norm, self.loss_kind)
+        rec(2)        # [1,2): forward/backward
+        gc, gb2c = ops.reduce(idx, bpos, q_item, b_norm, bt.q, opt)
+        rg = self._a2a(gc, send_counts, recv_counts)
+        rb2 = self._a2a(gb2c, send_counts, recv_counts)
+        rec(3)        # [2,3): local reduce + gradient exchange
+        ops.apply(req, rg, rb2, b_norm, opt)
+        rec(4)        # [3,4): owner apply
+        gb = ops.bias_grad(bt.B)
+        if W > 1:
+            if self.cpu_staging and gb.is_cuda:
+                g = gb.cpu()
+                dist.all_reduce(g, group=self.group)
+                gb = g.to(gb.device)
+            else:
+                dist.all_reduce(gb, group=self.group)
+        ops.bias_apply(gb, b_norm, opt)
+        rec(5)
+        if want_loss:
+            self.last_loss = float(gb[-1].item()) / b_norm
+            return self.last_loss
+        return None

@@ -231,7 +231,7 @@ class CdaeEngine:
                   'drx_cdae_step_sparse_timed')
         return self._loss if want_loss else None
 
-    def sample_device(self, B, neg_ratio, seed):
+    def sample_device(self, B, neg_ratio, seed, n_items=None):
         """Throughput-mode PointSampler on the GPU: returns device tensors (uid, iid, y, keep_off)."""
         uid = torch.empty(B, dtype=torch.int32, device=self.device)
         iid = torch.empty(B, dtype=torch.int32, device=self.device)
@@ -240,7 +240,7 @@ class CdaeEngine:
         need = lib().drx_point_sample_scratch_bytes(B)
         if getattr(self, '_sscratch', None) is None or self._sscratch.numel() < need:
             self._sscratch = torch.empty(need, dtype=torch.uint8, device=self.device)
-        check(lib().drx_point_sample(C.byref(self._hist), self.n_users, self.n_items, B, neg_ratio,
+        check(lib().drx_point_sample(C.byref(self._hist), self.n_users, n_items or self.n_items, B, neg_ratio,
                                      int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y), ptr(keep_off),
                                      ptr(self._sscratch), self._sscratch.numel(), stream_ptr(self.device)),
               'drx_point_sample')

@@ -141,6 +141,51 @@ int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, i
                      uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
                      void *scratch, size_t scratch_bytes, void *stream);
 
+/* ---- row-sharded multi-GPU step (no reference equivalent — DRecPy is single-process) ---------------
+ * Per-rank, collective-free pieces of the sampled step; the host (drecpy_amd/dist.py) runs the RCCL all-to-all
+ * exchanges between them.  Users (V, histories, samples) are sharded by uid range; item rows (W, W2T, b2) by item range
+ * of `items_per_rank` rows; in this mode DrxCdaeParams describes the LOCAL tables (n_users = local users,
+ * n_items = items_per_rank).  Row keys are owner-major: item n of owner o = n / ipr -> o*2*ipr + (n - o*ipr) for its W
+ * row, + ipr for its W2T row; local user u -> world*2*ipr + u. */
+typedef struct DrxShard {
+  int32_t world, rank;
+  int32_t n_items;          /* global number of items */
+  int32_t items_per_rank;   /* ceil(n_items / world) */
+  int32_t n_users_local;
+} DrxShard;
+
+size_t drx_shard_scratch_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32_t n_touches);
+/* keys/vals/b_of_pos [n_touch_slots + 2B]: row key (or DRX_KEY_NONE for dropped inputs), position, sample of each touch */
+int drx_shard_touches(const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt, uint32_t *keys, uint32_t *vals,
+                      uint32_t *b_of_pos, void *stream);
+/* stable sort by key; slot_sorted[j] / slot_of_pos[p] = index of the touch's key among the DISTINCT keys (ascending);
+ * uniq_keys[slot]; bounds[o] = #distinct keys owned by ranks < o (o = 0..world; bounds[world] = first user key),
+ * bounds[world+1] = #distinct keys. */
+int drx_shard_index(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *keys, const uint32_t *vals, int32_t T,
+                    uint32_t *keys_s, uint32_t *vals_s, int32_t *slot_sorted, uint32_t *slot_of_pos, uint32_t *uniq_keys,
+                    int32_t *bounds, void *scratch, size_t scratch_bytes, void *stream);
+/* owner side: rows[i] = the W / W2T row named by req_keys[i], b2_out[i] = its output bias (0 for W rows) */
+int drx_shard_gather_rows(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *req_keys, int32_t n, float *rows,
+                          float *b2_out, void *stream);
+/* forward + backward of the local triples against the fetched rows (rows_cache[slot]); losses are scaled by 1/b_norm
+ * (the GLOBAL batch size) */
+int drx_shard_fwd_bwd(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const uint32_t *slot_of_pos,
+                      const float *rows_cache, const float *b2_cache, int32_t b_norm, int32_t loss_kind, float *dz1, float *g2,
+                      float *dz2, float *lossb, void *stream);
+/* one summed gradient row per distinct item row -> gc[slot] / gb2c[slot]; V rows are updated in place */
+int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, float q,
+                     const uint32_t *keys_s, const uint32_t *vals_s, const int32_t *slot_sorted, const uint32_t *b_of_pos,
+                     int32_t T, const float *dz1, const float *g2, const float *dz2, float *gc, float *gb2c, void *scratch,
+                     size_t scratch_bytes, void *stream);
+/* owner side: sum the received gradient rows per owned row (arrival = source-rank order) and apply the optimizer */
+int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
+                    const float *recv_rows, const float *recv_b2, int32_t n, void *scratch, size_t scratch_bytes,
+                    void *stream);
+/* out[0..ld) = column sums of dz1 (gradient of the hidden bias), out[ld] = sum of the per-sample losses */
+int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *lossb, int32_t B, float *out, void *scratch,
+                        size_t scratch_bytes, void *stream);
+int drx_shard_bias_apply(const DrxCdaeParams *p, const DrxOptim *opt, int32_t b_norm, const float *grad, void *stream);
+
 /* ---- ranking (cdae.py:90-103, recommender_abc.py:454-461) --------------------------------
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with
  * cand_mask == NULL || bit (r*n + i) set; order = descending score, ties by larger index

@@ -1,0 +1,93 @@
+"""World-size-2 tests of the row-sharded step (drecpy_amd/dist.py) over gloo on CPU: two processes, each holding half of
+the users and half of the item rows, exchange distinct rows / gradient rows by all-to-all; the result must equal the
+single-process oracle step on the concatenated batch (SURVEY.md §8e parity caveat: same bucketing)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+U, N, K, B, STEPS, Q = 40, 57, 6, 24, 3, 0.2
+
+
+def _problem():
+    from oracle import cdae_oracle as co
+    from helpers import synth_history
+    rng = np.random.default_rng(11)
+    p = co.init_params(rng, U, N, K, np.float64)
+    indptr, indices = synth_history(rng, U, N, 7, zipf=1.1)
+    batches = []
+    for s in range(STEPS):
+        per_rank = []
+        for r in range(2):
+            lo, hi = U * r // 2, U * (r + 1) // 2
+            per_rank.append((rng.integers(lo, hi, size=B), rng.integers(0, N, size=B), (rng.random(B) < 0.3).astype(np.float64),
+                             1000 + 17 * s + r))
+        batches.append(per_rank)
+    return p, indptr, indices, batches
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from drecpy_amd.dist import ShardedCdae
+    from dist_ops_numpy import NumpyShardOps, np_batch
+    p, indptr, indices, batches = _problem()
+    lo, hi = U * rank // world, U * (rank + 1) // world
+    lip = indptr[lo:hi + 1] - indptr[lo]
+    lidx = indices[indptr[lo]:indptr[hi]]
+    ops = NumpyShardOps(hi - lo, N, K, rank, world, lip, lidx, 0.05, 1e-3)
+    m = ShardedCdae(U, N, K, rank, world, 'cpu', lip, lidx, ops=ops, q=Q)
+    m.set_params_global(**p)
+    losses = []
+    for s in range(STEPS):
+        uid, iid, y, seed = batches[s][rank]
+        bt = np_batch(uid - lo, iid, y, lip, Q, mask_seed=seed)
+        losses.append(m.step(s, bt, want_loss=True))
+    got = ops.get_params()
+    torch.save({'params': {k: np.asarray(v) for k, v in got.items()}, 'losses': losses}, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_equals_single_process_oracle(tmp_path):
+    from oracle import cdae_oracle as co
+    out = str(tmp_path / 'shard')
+    port = 29600 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    p, indptr, indices, batches = _problem()
+    st = co.sparse_state(p, 'adagrad')
+    want_losses = []
+    for s in range(STEPS):
+        uid = np.concatenate([batches[s][r][0] for r in range(2)])
+        iid = np.concatenate([batches[s][r][1] for r in range(2)])
+        y = np.concatenate([batches[s][r][2] for r in range(2)])
+        kept = []
+        for r in range(2):
+            u_r, _, _, seed = batches[s][r]
+            for b, u in enumerate(u_r):
+                row = indices[indptr[u]:indptr[u + 1]]
+                kf = co.drx_hash_u32(seed, np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
+                kept.append(row[kf].tolist())
+        lval, _ = co.sparse_step(p, st, s, uid, iid, y, kept, float(np.float32(Q)), 0.05, 1e-3, 'bce', 'adagrad')
+        want_losses.append(lval)
+    res = [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)]
+    ipr = (N + 1) // 2
+    for r in range(2):
+        g = res[r]['params']
+        lo, hi = r * ipr, min(N, (r + 1) * ipr)
+        np.testing.assert_allclose(g['W'][:hi - lo], p['W'][lo:hi], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g['W_'][:, :hi - lo], p['W_'][:, lo:hi], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g['b_'][:hi - lo], p['b_'][lo:hi], rtol=1e-9, atol=1e-12)
+        ulo, uhi = U * r // 2, U * (r + 1) // 2
+        np.testing.assert_allclose(g['V'], p['V'][ulo:uhi], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g['b'], p['b'], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res[r]['losses'], want_losses, rtol=1e-9)

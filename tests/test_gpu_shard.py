@@ -1,0 +1,109 @@
+"""GPU parity of the row-sharded step's HIP kernels (drx_shard_*): world 1 in-process, and world 2 as two processes
+sharing the one GPU of the box (gloo + host-staged exchange stand in for RCCL) — against the single-process oracle step
+on the concatenated batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+pytestmark = pytest.mark.gpu
+U, N, K, B, STEPS, Q = 300, 411, 50, 512, 4, 0.2
+
+
+def _problem(world):
+    from oracle import cdae_oracle as co
+    from helpers import synth_history
+    rng = np.random.default_rng(5)
+    p = co.init_params(rng, U, N, K, np.float32)
+    indptr, indices = synth_history(rng, U, N, 12, zipf=1.2)
+    batches = []
+    for s in range(STEPS):
+        per_rank = []
+        for r in range(world):
+            lo, hi = U * r // world, U * (r + 1) // world
+            per_rank.append((rng.integers(lo, hi, size=B), rng.integers(0, N, size=B), (rng.random(B) < 0.3).astype(np.float32),
+                             500 + 31 * s + r))
+        batches.append(per_rank)
+    return p, indptr, indices, batches
+
+
+def _oracle(world):
+    from oracle import cdae_oracle as co
+    p, indptr, indices, batches = _problem(world)
+    p = {k: v.astype(np.float64) for k, v in p.items()}
+    st = co.sparse_state(p, 'adagrad')
+    losses = []
+    for s in range(STEPS):
+        uid = np.concatenate([batches[s][r][0] for r in range(world)])
+        iid = np.concatenate([batches[s][r][1] for r in range(world)])
+        y = np.concatenate([batches[s][r][2] for r in range(world)])
+        kept = []
+        for r in range(world):
+            u_r, _, _, seed = batches[s][r]
+            for b, u in enumerate(u_r):
+                row = indices[indptr[u]:indptr[u + 1]]
+                kf = co.drx_hash_u32(seed, np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
+                kept.append(row[kf].tolist())
+        lval, _ = co.sparse_step(p, st, s, uid, iid, y, kept, float(np.float32(Q)), 0.05, 1e-3, 'bce', 'adagrad')
+        losses.append(lval)
+    return p, losses
+
+
+def _run_rank(rank, world, staged):
+    from drecpy_amd.dist import ShardedCdae
+    p, indptr, indices, batches = _problem(world)
+    lo, hi = U * rank // world, U * (rank + 1) // world
+    lip = indptr[lo:hi + 1] - indptr[lo]
+    lidx = indices[indptr[lo]:indptr[hi]]
+    m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged)
+    m.set_params_global(**p)
+    losses = []
+    for s in range(STEPS):
+        uid, iid, y, seed = batches[s][rank]
+        bt, alive = m.ops.make_batch(uid - lo, iid, y, q=Q, mask_seed=seed)
+        losses.append(m.step(s, bt, want_loss=True))
+    torch.cuda.synchronize()
+    return m.ops.get_params(), losses, (lo, hi)
+
+
+def _check(world, results):
+    p, want_losses = _oracle(world)
+    ipr = (N + world - 1) // world
+    for r, (g, losses, (ulo, uhi)) in enumerate(results):
+        lo, hi = r * ipr, min(N, (r + 1) * ipr)
+        tol = dict(rtol=0, atol=3e-6)
+        np.testing.assert_allclose(g['W'][:hi - lo], p['W'][lo:hi], **tol)
+        np.testing.assert_allclose(g['W_'][:, :hi - lo], p['W_'][:, lo:hi], **tol)
+        np.testing.assert_allclose(g['b_'][:hi - lo], p['b_'][lo:hi], **tol)
+        np.testing.assert_allclose(g['V'], p['V'][ulo:uhi], **tol)
+        np.testing.assert_allclose(g['b'], p['b'], **tol)
+        np.testing.assert_allclose(losses, want_losses, rtol=1e-5)
+
+
+def test_sharded_world1_matches_oracle():
+    _check(1, [_run_rank(0, 1, False)])
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    res = _run_rank(rank, world, True)
+    torch.save(res, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path):
+    out = str(tmp_path / 'shard')
+    port = 29700 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    _check(2, [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)])
