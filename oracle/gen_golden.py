@@ -152,6 +152,79 @@ def main():
             iv[k]['item'][str(iid)] = {'idx': [int(x) for x in v.indices.tolist()],
                                        'val': [float(x) for x in v.data.tolist()], 'n': int(v.shape[1])}
     json.dump(iv, open(os.path.join(OUT, 'interaction_vecs.json'), 'w'))
+    # ---- ranking_evaluation protocol + metrics ---------------------------------------------
+    import random as _random
+    from heapq import nlargest
+    from DRecPy.Evaluation.Processes import ranking_evaluation
+    from DRecPy.Evaluation.Metrics import HitRatio, NDCG, Precision, Recall, ReciprocalRank, AveragePrecision, FScore, DCG
+
+    r0 = _random.Random(0)       # same construction as the reference's own fixture (test_ranking_evaluation.py:12-19)
+    rows = [[u, i, r0.randint(-1, 5)] for u in range(50) for i in range(200) if r0.randint(0, 4) == 0]
+    rows = np.array(rows, dtype=np.int64)
+    # deterministic hold-out: the last 5 rows of every user go to the test frame
+    test_mask = np.zeros(len(rows), bool)
+    for u in range(50):
+        idx = np.flatnonzero(rows[:, 0] == u)
+        test_mask[idx[-5:]] = True
+    tr, te = rows[~test_mask], rows[test_mask]
+    scores = np.random.RandomState(4).rand(50, 200)
+
+    class FakeModel:
+        # ranks by a fixed score matrix; only the attributes ranking_evaluation reads
+        def __init__(self, ds):
+            self.interaction_dataset = ds
+            self.n_items = ds.count_unique('iid')
+            self.interaction_threshold = 0.001
+            self.fitted = True
+
+        def rank(self, user_id, item_ids, novelty=True, skip_invalid_items=True, **kw):
+            ds = self.interaction_dataset
+            uid = ds.user_to_uid(user_id)
+            iids = [ds.item_to_iid(i) for i in item_ids]
+            iids = [i for i in iids if i is not None]
+            if novelty:
+                seen = set(ds.select(f'uid == {uid}').values_list('iid', to_list=True))
+                iids = [i for i in iids if i not in seen]
+            raw_u = int(ds.uid_to_user(uid))
+            lst = nlargest(len(iids), [(scores[raw_u, int(ds.iid_to_item(i))], i) for i in set(iids)])
+            return [(s, ds.iid_to_item(i)) for s, i in lst]
+
+    ds_tr = InteractionDataset.read_df(pd.DataFrame(tr, columns=['user', 'item', 'interaction']), verbose=False)
+    ds_te = InteractionDataset.read_df(pd.DataFrame(te, columns=['user', 'item', 'interaction']), verbose=False)
+    ds_tr.assign_internal_ids()
+    fm = FakeModel(ds_tr)
+    cfgs = [dict(k=2), dict(k=2, n_neg_interactions=20, generate_negative_pairs=True), dict(k=2, n_neg_interactions=1),
+            dict(k=[1, 5, 10]), dict(k=2, novelty=True), dict(k=2, n_pos_interactions=1),
+            dict(k=[1, 5, 10], novelty=True, n_test_users=30, n_pos_interactions=1, n_neg_interactions=100,
+                 generate_negative_pairs=True, seed=10),                                  # examples/cdae.py:15-17 protocol
+            dict(k=3, n_neg_interactions=0.5, seed=3)]
+    re_out = []
+    for c in cfgs:
+        res = ranking_evaluation(fm, ds_te, verbose=False, **c)
+        re_out.append({'cfg': c, 'result': res})
+    res_train = ranking_evaluation(fm, None, k=[1, 3], n_pos_interactions=2, n_neg_interactions=10,
+                                   generate_negative_pairs=True, seed=5, verbose=False)
+    mrng = np.random.RandomState(9)
+    mcases = []
+    for _ in range(40):
+        n = int(mrng.randint(1, 12))
+        recs = [int(x) for x in mrng.permutation(30)[:n]]
+        rel = [int(x) for x in mrng.permutation(30)[:int(mrng.randint(1, 8))]]
+        relv = {int(i): float(mrng.randint(0, 6)) for i in set(recs) | set(rel)}
+        if all(v == 0 for v in relv.values()):
+            relv[recs[0]] = 3.0
+        kk = [None, 1, 3, 10][int(mrng.randint(0, 4))]
+        vals = {'HitRatio': HitRatio()(recs, k=kk, relevant_recommendations=rel),
+                'Recall': Recall()(recs, k=kk, relevant_recommendations=rel),
+                'Precision': Precision()(recs, k=kk, relevant_recommendations=rel),
+                'AveragePrecision': AveragePrecision()(recs, k=kk, relevant_recommendations=rel),
+                'ReciprocalRank': ReciprocalRank()(recs, k=kk, relevant_recommendation=rel[0]),
+                'NDCG': NDCG()(recs, k=kk, relevancies=relv), 'DCG_weak': DCG(strong_relevancy=False)(recs, k=kk, relevancies=relv)}
+        p_, r_ = vals['Precision'], vals['Recall']
+        vals['FScore'] = FScore()(recs, k=kk, relevant_recommendations=rel) if (p_ + r_) > 0 else None
+        mcases.append({'recs': recs, 'rel': rel, 'relv': {str(a): b for a, b in relv.items()}, 'k': kk, 'vals': vals})
+    json.dump({'train': tr.tolist(), 'test': te.tolist(), 'scores_seed': 4, 'evals': re_out, 'train_eval': res_train,
+               'metric_cases': mcases}, open(os.path.join(OUT, 'ranking_eval.json'), 'w'))
     print('golden fixtures written to', OUT)
     for fn in sorted(os.listdir(OUT)):
         print(' ', fn, os.path.getsize(os.path.join(OUT, fn)))
