@@ -206,6 +206,17 @@ def main():
         dom, dom_ms, dom_alg = 'k_shard_fwd_bwd', ph[1], alg_fwd
     achieved = dom_alg / (dom_ms * 1e-3) / 1e9
     step_alg = B * 4.0 * K * rows_per_sample * 5.0
+    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json), only when that
+    # profile was taken on this very configuration; rocprofv3 cannot run inside the bench itself.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            pmc = json.load(f)
+        m = pmc['_meta']
+        if m['workload'] == args.workload and m['batch_per_gpu'] == B and m['n_gpus'] == world and not args.users:
+            traffic = pmc['kernels'].get('drx::' + dom, {}).get('hbm_bytes_per_launch')
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         out = {
@@ -218,7 +229,7 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
                        'sharding': 'single GPU' if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms),
                          'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
                          'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
