@@ -17,8 +17,16 @@
 
 namespace drx {
 
-constexpr int kChunk = 32;      // touches per group in the segmented reduction
-constexpr int kShortSpan = 6;
+#ifndef DRX_CHUNK
+#define DRX_CHUNK 32
+#endif
+constexpr int kChunk = DRX_CHUNK;      // touches per group in the segmented reduction
+#ifdef DRX_SEG_WAVE_PER_CHUNK
+#define SEG_GPB(G) (drx::kBlock / 64)
+#else
+#define SEG_GPB(G) (drx::kBlock / (G))
+#endif
+constexpr int kShortSpan = 64;     // chunk borders a segment may cross and still be combined by one group
 constexpr int kFixBlock = 1024;
 
 struct SegBufs {
@@ -37,8 +45,15 @@ struct SegBufs {
 // contribution rows are then loaded LB at a time (independent loads in flight) before they are folded in order.
 template <int G, int J, class Policy>
 __global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
+#ifdef DRX_SEG_WAVE_PER_CHUNK
+  // experiment: one chunk per WAVE (lanes >= G idle) so that a group's flush never stalls a sibling group
+  const int lane = threadIdx.x % 64;
+  if (lane >= G) return;
+  const int g = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+#else
   const int lane = threadIdx.x % G;
   const int g = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+#endif
   if (g >= S.n_chunks) return;
   const int start = g * kChunk, end = min(S.T, start + kChunk);
   const int n = end - start;
@@ -134,27 +149,49 @@ __global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
 template <int G, int J, class Policy>
 __global__ __launch_bounds__(kBlock) void k_span_short(SegBufs S, Policy pol) {
   const int lane = threadIdx.x % G;
+  const int gshift = (threadIdx.x & 63) / G * G;          // position of this group's lanes in the wave's ballot
+  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
   const uint32_t n_span = S.n_span[0];
   const int gpb = kBlock / G;
+  constexpr int UL = J == 1 ? 8 : 2;                       // partial rows in flight
   for (uint32_t si = blockIdx.x * gpb + threadIdx.x / G; si < n_span; si += gridDim.x * gpb) {
     const int g0 = (int)S.span_list[si];
     const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
-    // number of following chunks that continue this segment (bounded look-ahead)
+    // m = number of following chunks that continue this segment; the lanes probe G chunk heads at a time
     int m = 0;
-    while (m <= kShortSpan && g0 + 1 + m < S.n_chunks && S.keys_s[(g0 + 1 + m) * kChunk] == key) ++m;
-    if (m > kShortSpan) {
+    bool is_long = false;
+    for (int base = g0 + 1;; base += G) {
+      const int c = base + lane;
+      const bool cont = c < S.n_chunks && S.keys_s[c * kChunk] == key;
+      const unsigned long long bits = (__ballot(cont) >> gshift) & gmask;
+      const int run = bits == gmask ? G : __builtin_ctzll(~bits);     // leading run of continuing chunks
+      m += run;
+      if (run < G) break;
+      if (m >= kShortSpan) { is_long = true; break; }
+    }
+    if (is_long || m > kShortSpan) {
       if (lane == 0) S.long_list[atomicAdd(&S.n_span[1], 1u)] = (uint32_t)g0;
       continue;
     }
     float4 t[J];
     load_row<G, J>(S.ptail, (size_t)g0, S.ld, lane, t);
     float ts = S.pts[g0];
-    for (int c = g0 + 1; c <= g0 + m; ++c) {
-      float4 v[J];
-      load_row<G, J>(S.phead, (size_t)c, S.ld, lane, v);
+    for (int c0 = g0 + 1; c0 <= g0 + m; c0 += UL) {
+      float4 v[UL][J];
+      float sv[UL];
 #pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
-      ts += S.phs[c];
+      for (int u = 0; u < UL; ++u) {
+        sv[u] = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) v[u][j] = f4_zero();
+        if (c0 + u <= g0 + m) { load_row<G, J>(S.phead, (size_t)(c0 + u), S.ld, lane, v[u]); sv[u] = S.phs[c0 + u]; }
+      }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {           // chunk order
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(t[j], v[u][j]);
+        ts += sv[u];
+      }
     }
     pol.template finish<G, J>(key, min(S.T, (g0 + 1) * kChunk) - 1, lane, t, ts);
   }
@@ -174,21 +211,28 @@ __global__ __launch_bounds__(kFixBlock) void k_span_long(SegBufs S, Policy pol) 
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = f4_zero();
     float accs = 0.f;
-    for (int c = g0 + 1 + r; c < S.n_chunks; c += 2 * R) {
+    constexpr int UL = J == 1 ? 8 : 2;        // partial rows in flight per group
+    for (int c = g0 + 1 + r; c < S.n_chunks; c += UL * R) {
       if (S.keys_s[c * kChunk] != key) break;
-      const int c2 = c + R;
-      const bool two = c2 < S.n_chunks && S.keys_s[c2 * kChunk] == key;
-      float4 v[J], v2[J];
-      load_row<G, J>(S.phead, (size_t)c, S.ld, lane, v);
+      float4 v[UL][J];
+      float sv[UL];
+      bool ok[UL];
 #pragma unroll
-      for (int j = 0; j < J; ++j) v2[j] = f4_zero();
-      float s2 = 0.f;
-      if (two) { load_row<G, J>(S.phead, (size_t)c2, S.ld, lane, v2); s2 = S.phs[c2]; }
+      for (int u = 0; u < UL; ++u) {
+        const int cu = c + u * R;
+        ok[u] = cu < S.n_chunks && S.keys_s[cu * kChunk] == key;     // contiguous run: false once, false after
+        sv[u] = 0.f;
 #pragma unroll
-      for (int j = 0; j < J; ++j) { f4_add(acc[j], v[j]); f4_add(acc[j], v2[j]); }
-      accs += S.phs[c];
-      accs += s2;
-      if (!two) break;
+        for (int j = 0; j < J; ++j) v[u][j] = f4_zero();
+        if (ok[u]) { load_row<G, J>(S.phead, (size_t)cu, S.ld, lane, v[u]); sv[u] = S.phs[cu]; }
+      }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(acc[j], v[u][j]);
+        accs += sv[u];
+      }
+      if (!ok[UL - 1]) break;
     }
     __syncthreads();
     store_row<G, J>(lds, (size_t)r, S.ld, lane, acc);

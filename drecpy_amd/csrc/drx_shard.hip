@@ -182,7 +182,9 @@ struct LocalPolicy {
   DrxShard sh;
   int b_norm;
   float scale;
-  const float *dz1, *g2, *dz2;
+  const float *dz1;              // g2 = dz1 + g2_off (value select, see DirectPolicy in drx_cdae.hip)
+  long long g2_off;
+  const float *dz2;
   const uint32_t *b_of_pos;
   const int *slot_sorted;
   float *gc, *gb2c;              // [Q_item, ld], [Q_item]
@@ -192,7 +194,7 @@ struct LocalPolicy {
     const uint32_t uk0 = user_key0(sh);
     const bool is_user = key >= uk0;
     const bool is_out = !is_user && (key % (2u * sh.items_per_rank)) >= (uint32_t)sh.items_per_rank;
-    load_row<G, J>(is_out ? g2 : dz1, (size_t)b, P.ld, lane, row);
+    load_row<G, J>(dz1 + (is_out ? g2_off : 0ll), (size_t)b, P.ld, lane, row);
     if (is_out) sc = dz2[b];
     coef = (!is_user && !is_out) ? scale : 1.0f;
   }
@@ -233,9 +235,10 @@ struct OwnerPolicy {
     const size_t row = is_out ? t - sh.items_per_rank : t;
     OptScalars o = opt_for(opt, 0, b_norm);
     float4 w[J];
-    float *tab = is_out ? P.W2T : P.W;
+    float *wt = P.W, *w2 = P.W2T, *a0 = opt.s1[0], *a1 = opt.s1[1], *c0 = opt.s2[0], *c1 = opt.s2[1];   // scalar loads first
+    float *tab = is_out ? w2 : wt;
     load_row<G, J>(tab, row, P.ld, lane, w);
-    row_update<G, J>(o, tab, opt.s1[is_out ? 1 : 0], opt.s2[is_out ? 1 : 0], row, P.ld, lane, w, g);
+    row_update<G, J>(o, tab, is_out ? a1 : a0, is_out ? c1 : c0, row, P.ld, lane, w, g);
     if (is_out && lane == 0) {
       float pb = P.b2[row], m = opt.s1[4][row], v = o.kind == DRX_OPT_ADAM ? opt.s2[4][row] : 0.f;
       o.rb = 0.f;
@@ -388,7 +391,7 @@ static int run_segreduce(const DrxCdaeParams &P, const SegBufs &sb, const Policy
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
-    hipLaunchKernelGGL((k_seg_reduce<G, J, Policy>), dim3((sb.n_chunks + gpb - 1) / gpb), dim3(kBlock), 0, st, sb, pol); \
+    hipLaunchKernelGGL((k_seg_reduce<G, J, Policy>), dim3((sb.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, sb, pol); \
     hipLaunchKernelGGL((k_span_short<G, J, Policy>), dim3(1024), dim3(kBlock), 0, st, sb, pol);                        \
     const size_t lds = ((size_t)(kFixBlock / G) * (P.ld + 1)) * 4;                                                     \
     if (lds > 48 * 1024)                                                                                               \
@@ -503,7 +506,7 @@ int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard
   SegLayout L = seg_layout(cv, p->ld, T, key_bits(*sh));
   if (!cv.ok()) return DRX_ESCRATCH;
   L.sb.keys_s = keys_s; L.sb.vals_s = vals_s;
-  LocalPolicy pol{*p, *opt, *sh, b_norm, 1.0f / (1.0f - q), dz1, g2, dz2, b_of_pos, slot_sorted, gc, gb2c};
+  LocalPolicy pol{*p, *opt, *sh, b_norm, 1.0f / (1.0f - q), dz1, (long long)(g2 - dz1), dz2, b_of_pos, slot_sorted, gc, gb2c};
   return run_segreduce(*p, L.sb, pol, (hipStream_t)stream);
 }
 

@@ -8,8 +8,6 @@
 // sub-wave), each lane holding J float4 -> one coalesced 16 B/lane access per row; K=128 is a half-wave
 // (two rows per wave64), K=50 (ld 52) a 16-lane group (four rows per wave).
 #include "drx_common.hpp"
-#include "drx_rows.hpp"
-#include "drx_segreduce.hpp"
 
 namespace drx {
 
@@ -23,6 +21,32 @@ struct DenseAux {
   uint32_t *tb;    // [B, Nw]   per-row target bits (DRX_TARGETS_PER_ROW) or nullptr
   int32_t Bw, Nw;
 };
+
+struct RowRef {
+  const float4 *p;
+};
+
+template <int G, int J>
+__device__ __forceinline__ void load_row(const float *base, size_t row, int ld, int lane, float4 (&v)[J]) {
+  const float4 *r = reinterpret_cast<const float4 *>(base + row * (size_t)ld);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    int c = lane + j * G;
+    v[j] = (4 * c < ld) ? r[c] : f4_zero();
+  }
+}
+
+template <int G, int J>
+__device__ __forceinline__ void store_row(float *base, size_t row, int ld, int lane, const float4 (&v)[J]) {
+  float4 *r = reinterpret_cast<float4 *>(base + row * (size_t)ld);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    int c = lane + j * G;
+    if (4 * c < ld) r[c] = v[j];
+  }
+}
+
+__device__ __forceinline__ float colmask(int col, int k, float v) { return col < k ? v : 0.0f; }
 
 // Gathers scale * sum_{kept} W[n] for one batch row.  MODE 0: plain; 1: also builds DenseAux;
 // 2: also emits the (key,val) touch list of the sampled mode.
@@ -75,6 +99,23 @@ __device__ __forceinline__ void gather_bag(const DrxCdaeParams &P, const DrxHist
   }
 }
 
+// h = sigmoid(scale*bag + V[u] + b), zero in the padding columns.
+template <int G, int J>
+__device__ __forceinline__ void hidden_act(const DrxCdaeParams &P, int u, float scale, int lane,
+                                           const float4 (&acc)[J], float4 (&h)[J]) {
+  float4 v[J], bb[J];
+  load_row<G, J>(P.V, (size_t)u, P.ld, lane, v);
+  load_row<G, J>(P.b, 0, P.ld, lane, bb);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int col = 4 * (lane + j * G);
+    h[j].x = colmask(col + 0, P.k, sigmoidf_(fmaf(scale, acc[j].x, v[j].x + bb[j].x)));
+    h[j].y = colmask(col + 1, P.k, sigmoidf_(fmaf(scale, acc[j].y, v[j].y + bb[j].y)));
+    h[j].z = colmask(col + 2, P.k, sigmoidf_(fmaf(scale, acc[j].z, v[j].z + bb[j].z)));
+    h[j].w = colmask(col + 3, P.k, sigmoidf_(fmaf(scale, acc[j].w, v[j].w + bb[j].w)));
+  }
+}
+
 template <int G, int J, int MODE>
 __global__ __launch_bounds__(kBlock) void k_hidden_fwd(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
                                                        uint32_t qthr, float *__restrict__ hout, DenseAux aux) {
@@ -109,6 +150,74 @@ __global__ __launch_bounds__(kBlock) void k_out_fwd(DrxCdaeParams P, const float
       if (lane == 0) pred[(size_t)b * P.n_items + n] = sigmoidf_(d + bias);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer row updates (fp32, Keras formulas)
+// ------------------------------------------------------------------------------------------------
+struct OptScalars {
+  int kind;
+  float lr, rb;              // rb = reg_rate / B
+  float b1, b2, eps, alpha;  // alpha = Keras-Adam lr_t of the variable being updated
+};
+
+__device__ __forceinline__ void opt_update1(const OptScalars &o, float g, float &p, float &s1, float &s2) {
+  if (o.kind == DRX_OPT_ADAM) {
+    // TF's ApplyAdam functor, operation for operation (1 - beta is formed in fp32 there too)
+    s1 = s1 + (g - s1) * (1.0f - o.b1);
+    s2 = s2 + (g * g - s2) * (1.0f - o.b2);
+    p = p - (s1 * o.alpha) / (sqrtf(s2) + o.eps);
+  } else {
+    s1 = s1 + g * g;
+    p = p - o.lr * g / (sqrtf(s1) + o.eps);
+  }
+}
+
+// Applies g (data gradient, already complete) + rb*p to one row of `tab` with slots s1/s2.
+template <int G, int J>
+__device__ __forceinline__ float row_update(const OptScalars &o, float *tab, float *s1, float *s2, size_t row, int ld,
+                                            int lane, const float4 (&w)[J], const float4 (&g)[J]) {
+  float sq = 0.f;
+  float4 *pr = reinterpret_cast<float4 *>(tab + row * (size_t)ld);
+  float4 *a1 = reinterpret_cast<float4 *>(s1 + row * (size_t)ld);
+  float4 *a2 = (o.kind == DRX_OPT_ADAM) ? reinterpret_cast<float4 *>(s2 + row * (size_t)ld) : nullptr;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = lane + j * G;
+    if (4 * c < ld) {
+      float4 p = w[j];
+      float4 m = a1[c];
+      float4 v = a2 ? a2[c] : f4_zero();
+      sq += f4_dot(p, p);
+      opt_update1(o, fmaf(o.rb, p.x, g[j].x), p.x, m.x, v.x);
+      opt_update1(o, fmaf(o.rb, p.y, g[j].y), p.y, m.y, v.y);
+      opt_update1(o, fmaf(o.rb, p.z, g[j].z), p.z, m.z, v.z);
+      opt_update1(o, fmaf(o.rb, p.w, g[j].w), p.w, m.w, v.w);
+      pr[c] = p;
+      a1[c] = m;
+      if (a2) a2[c] = v;
+    }
+  }
+  return sq;   // partial |row|^2 of this lane (pre-update), for the L2 loss value
+}
+
+__device__ __forceinline__ OptScalars opt_for(const DrxOptim &opt, int var, int B) {
+  OptScalars o;
+  o.kind = opt.kind; o.lr = opt.lr; o.rb = opt.reg_rate / (float)B;
+  o.b1 = opt.beta1; o.b2 = opt.beta2; o.eps = opt.eps; o.alpha = opt.alpha[var];
+  return o;
+}
+
+// Deterministic block reduction of one float per thread -> thread 0 holds the sum.
+__device__ __forceinline__ float block_sum(float v, float *red /* [kBlock/64] in LDS */) {
+  v = group_sum<64>(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kBlock / 64; ++i) t += red[i];
+  return t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,6 +492,8 @@ struct SparseBufs {
   int T, n_chunks, n_bpart;
 };
 
+constexpr int kChunk = 32;      // touches per group in the segmented reduction
+
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
                                                             uint32_t qthr, int loss_kind, SparseBufs S) {
@@ -428,16 +539,13 @@ template <int G, int J>
 __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOptim &opt, int B, uint32_t key, int lane,
                                              const float4 (&g)[J], float gs) {
   const uint32_t N = (uint32_t)P.n_items;
-  // read every candidate pointer as a scalar first, then select VALUES (a dynamic index into the kernarg pointer
-  // arrays would become a vector load + s_waitcnt vmcnt(0))
-  float *const tW = P.W, *const tO = P.W2T, *const tV = P.V;
-  float *const a0 = opt.s1[0], *const a1 = opt.s1[1], *const a2 = opt.s1[2];
-  float *const c0 = opt.s2[0], *const c1 = opt.s2[1], *const c2 = opt.s2[2];
-  const int var = key < N ? 0 : (key < 2 * N ? 1 : 2);
-  const size_t row = key - (uint32_t)var * N;
-  float *const tab = var == 0 ? tW : (var == 1 ? tO : tV);
-  float *const s1 = var == 0 ? a0 : (var == 1 ? a1 : a2);
-  float *const s2 = var == 0 ? c0 : (var == 1 ? c1 : c2);
+  float *tab, *s1, *s2;
+  size_t row;
+  int var;
+  if (key < N) { tab = P.W; var = 0; row = key; }
+  else if (key < 2 * N) { tab = P.W2T; var = 1; row = key - N; }
+  else { tab = P.V; var = 2; row = key - 2 * N; }
+  s1 = opt.s1[var]; s2 = opt.s2[var];
   OptScalars o = opt_for(opt, 0, B);
   float4 w[J];
   load_row<G, J>(tab, row, P.ld, lane, w);
@@ -451,32 +559,192 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
   }
 }
 
-// Policy of the single-GPU sparse step for the generic segmented reduction (drx_segreduce.hpp):
-// key space [0,N) W rows (contribution dz1[b] * 1/(1-q)), [N,2N) W2T rows (g2[b], scalar dz2[b] for b2), [2N,2N+U) V rows.
-struct DirectPolicy {
-  DrxCdaeParams P;
-  DrxOptim opt;
-  int B;
-  float scale;
-  // contribution rows: dz1 [B,ld] and g2 [B,ld]; g2 is addressed as dz1 + g2_off so that the choice between them is
-  // a VALUE select (a select between the two kernarg pointer FIELDS makes hipcc fetch the pointer with a vector load
-  // and an s_waitcnt vmcnt(0) in front of every row load, which serialises the loads: measured 0.26 -> 0.33 ms)
-  const float *dz1;
-  long long g2_off;
-  const float *dz2;
-  template <int G, int J>
-  __device__ __forceinline__ void load(uint32_t key, uint32_t b, int lane, float4 (&row)[J], float &sc, float &coef) const {
-    const uint32_t N = (uint32_t)P.n_items;
-    const bool is_out = key >= N && key < 2 * N;
-    load_row<G, J>(dz1 + (is_out ? g2_off : 0ll), (size_t)b, P.ld, lane, row);
-    if (is_out) sc = dz2[b];
-    coef = key < N ? scale : 1.0f;
+// Segmented reduction over the sorted touch list in fixed chunks of kChunk touches per group.
+// Segments that lie inside one chunk are updated here; segments crossing chunk borders leave
+// partial rows that k_span_fixup combines in chunk order (deterministic).
+// The chunk's (key, sample) pairs are fetched with one coalesced load per lane and broadcast by shuffles; the
+// contribution rows are then loaded LB at a time (independent loads in flight) before they are folded in order.
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_seg_reduce(DrxCdaeParams P, DrxOptim opt, int B, float scale, SparseBufs S) {
+  const int lane = threadIdx.x % G;
+  const int g = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (g >= S.n_chunks) return;
+  const int start = g * kChunk, end = min(S.T, start + kChunk);
+  const int n = end - start;
+  const uint32_t N = (uint32_t)P.n_items;
+  const uint32_t prev_key = start > 0 ? S.keys_s[start - 1] : DRX_KEY_NONE;
+  const uint32_t next_key = end < S.T ? S.keys_s[end] : DRX_KEY_NONE;
+  constexpr int KPL = (kChunk + G - 1) / G;          // (key, val) registers per lane
+  constexpr int LB = J == 1 ? 8 : (J == 2 ? 4 : 2);  // rows in flight per group
+  uint32_t kreg[KPL], vreg[KPL];
+#pragma unroll
+  for (int r = 0; r < KPL; ++r) {
+    const int t = r * G + lane;
+    const bool ok = t < n && t < kChunk;
+    kreg[r] = ok ? S.keys_s[start + t] : DRX_KEY_NONE;
+    vreg[r] = ok ? S.vals_s[start + t] : 0u;
   }
-  template <int G, int J>
-  __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
-    sparse_apply<G, J>(P, opt, B, key, lane, g, gs);
+  auto bcast = [&](const uint32_t (&reg)[KPL], int t) -> uint32_t {
+    uint32_t sel = reg[0];
+#pragma unroll
+    for (int r = 1; r < KPL; ++r) sel = (t / G == r) ? reg[r] : sel;
+    return (uint32_t)__shfl((int)sel, t % G, G);
+  };
+  float4 acc[J];
+#pragma unroll
+  for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+  float accs = 0.f;
+  uint32_t cur = DRX_KEY_NONE, last_key = DRX_KEY_NONE;
+  bool cur_from_start = false;
+  auto flush = [&](bool at_end) {
+    if (cur == DRX_KEY_NONE) return;
+    const bool cont_left = cur_from_start && prev_key == cur;
+    const bool cont_right = at_end && next_key == cur;
+    if (!cont_left && !cont_right) {
+      sparse_apply<G, J>(P, opt, B, cur, lane, acc, accs);
+    } else if (cont_left) {
+      store_row<G, J>(S.phead, (size_t)g, P.ld, lane, acc);
+      if (lane == 0) S.phs[g] = accs;
+    } else {
+      store_row<G, J>(S.ptail, (size_t)g, P.ld, lane, acc);
+      if (lane == 0) {
+        S.pts[g] = accs;
+        const uint32_t slot = atomicAdd(S.n_span, 1u);
+        S.span_list[slot] = (uint32_t)g;
+      }
+    }
+  };
+  for (int t0 = 0; t0 < n; t0 += LB) {
+    uint32_t k8[LB];
+    float s8[LB];
+    float4 rows[LB][J];
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      const int t = t0 + u;
+      k8[u] = t < n ? bcast(kreg, t) : DRX_KEY_NONE;    // padding (dropped inputs) sorts last
+      const uint32_t b = bcast(vreg, t < n ? t : 0);
+      s8[u] = 0.f;
+#pragma unroll
+      for (int jx = 0; jx < J; ++jx) rows[u][jx] = f4_zero();
+      if (k8[u] != DRX_KEY_NONE) {
+        const bool is_out = k8[u] >= N && k8[u] < 2 * N;
+        load_row<G, J>(is_out ? S.g2 : S.dz1, (size_t)b, P.ld, lane, rows[u]);
+        if (is_out) s8[u] = S.dz2[b];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      const uint32_t key = k8[u];
+      if (key != DRX_KEY_NONE) {
+        if (key != cur) {
+          flush(false);
+          cur = key;
+          cur_from_start = (t0 + u == 0);
+#pragma unroll
+          for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+          accs = 0.f;
+        }
+        const float c = key < N ? scale : 1.0f;
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c, rows[u][jx]);
+        accs += s8[u];
+        last_key = key;
+      }
+    }
   }
-};
+  // the last segment ends at the chunk border iff the final touch of the chunk is a real key
+  const bool ran_to_end = n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE;
+  (void)last_key;
+  flush(ran_to_end);
+}
+
+// Fix-up of chunk-crossing segments, two tiers.
+//   k_span_short : one GROUP per crossing segment: tail partial of its first chunk + head partials of the next chunks
+//                  whose first key equals the segment key, in chunk order.  Segments that cross more than
+//                  kShortSpan chunk borders (hot items) are queued for
+//   k_span_long  : one 1024-thread workgroup per such segment; its R = 1024/G groups stride over the chunks and the
+//                  R partial sums are combined in a fixed order.  Both tiers are deterministic.
+constexpr int kShortSpan = 6;
+constexpr int kFixBlock = 1024;
+
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_span_short(DrxCdaeParams P, DrxOptim opt, int B, SparseBufs S) {
+  const int lane = threadIdx.x % G;
+  const uint32_t n_span = S.n_span[0];
+  const int gpb = kBlock / G;
+  for (uint32_t si = blockIdx.x * gpb + threadIdx.x / G; si < n_span; si += gridDim.x * gpb) {
+    const int g0 = (int)S.span_list[si];
+    const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
+    // number of following chunks that continue this segment (bounded look-ahead)
+    int m = 0;
+    while (m <= kShortSpan && g0 + 1 + m < S.n_chunks && S.keys_s[(g0 + 1 + m) * kChunk] == key) ++m;
+    if (m > kShortSpan) {
+      if (lane == 0) S.long_list[atomicAdd(&S.n_span[1], 1u)] = (uint32_t)g0;
+      continue;
+    }
+    float4 t[J];
+    load_row<G, J>(S.ptail, (size_t)g0, P.ld, lane, t);
+    float ts = S.pts[g0];
+    for (int c = g0 + 1; c <= g0 + m; ++c) {
+      float4 v[J];
+      load_row<G, J>(S.phead, (size_t)c, P.ld, lane, v);
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
+      ts += S.phs[c];
+    }
+    sparse_apply<G, J>(P, opt, B, key, lane, t, ts);
+  }
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kFixBlock) void k_span_long(DrxCdaeParams P, DrxOptim opt, int B, SparseBufs S) {
+  extern __shared__ __align__(16) float lds[];   // [R, ld] + [R]
+  constexpr int R = kFixBlock / G;
+  float *sc = lds + (size_t)R * P.ld;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const uint32_t n_long = S.n_span[1];
+  for (uint32_t si = blockIdx.x; si < n_long; si += gridDim.x) {
+    const int g0 = (int)S.long_list[si];
+    const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
+    float4 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+    float accs = 0.f;
+    for (int c = g0 + 1 + r; c < S.n_chunks; c += 2 * R) {
+      if (S.keys_s[c * kChunk] != key) break;
+      const int c2 = c + R;
+      const bool two = c2 < S.n_chunks && S.keys_s[c2 * kChunk] == key;
+      float4 v[J], v2[J];
+      load_row<G, J>(S.phead, (size_t)c, P.ld, lane, v);
+#pragma unroll
+      for (int j = 0; j < J; ++j) v2[j] = f4_zero();
+      float s2 = 0.f;
+      if (two) { load_row<G, J>(S.phead, (size_t)c2, P.ld, lane, v2); s2 = S.phs[c2]; }
+#pragma unroll
+      for (int j = 0; j < J; ++j) { f4_add(acc[j], v[j]); f4_add(acc[j], v2[j]); }
+      accs += S.phs[c];
+      accs += s2;
+      if (!two) break;
+    }
+    __syncthreads();
+    store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
+    if (lane == 0) sc[r] = accs;
+    __syncthreads();
+    if (r == 0) {
+      float4 t[J];
+      load_row<G, J>(S.ptail, (size_t)g0, P.ld, lane, t);
+      float ts = S.pts[g0];
+      for (int rr = 0; rr < R; ++rr) {
+        float4 v[J];
+        load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
+        ts += sc[rr];
+      }
+      sparse_apply<G, J>(P, opt, B, key, lane, t, ts);
+    }
+  }
+}
 
 // hidden bias b: column sums of dz1 in two deterministic stages, then a dense optimizer update.
 template <int G, int J>
@@ -773,8 +1041,6 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const int bits = bits_for((uint64_t)2 * p->n_items + p->n_users + 1);
   const int rows_per_block = (bt->B + S.n_bpart - 1) / S.n_bpart;
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
-  SegBufs SB{S.keys_s, S.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.T, S.n_chunks, p->ld};
-  DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
@@ -789,16 +1055,15 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     rc = sort_pairs(sort_temp, sort_bytes, S.keys, S.keys_s, S.vals, S.vals_s, (size_t)S.T, bits, st);                 \
     if (rc) return rc;                                                                                                 \
     EV(2);                                                                                                             \
-    hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
-                       pol);                                                                                           \
+    hipLaunchKernelGGL((k_seg_reduce<G, J>), dim3((S.n_chunks + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, bt->B, \
+                       scale, S);                                                                                      \
     EV(3);                                                                                                             \
-    hipLaunchKernelGGL((k_span_short<G, J, DirectPolicy>), dim3(1024), dim3(kBlock), 0, st, SB, pol);                  \
+    hipLaunchKernelGGL((k_span_short<G, J>), dim3(1024), dim3(kBlock), 0, st, *p, *opt, bt->B, S);                     \
     if (((size_t)(kFixBlock / G) * (p->ld + 1)) * 4 > 48 * 1024)                                                       \
-      DRX_HIP(hipFuncSetAttribute((const void *)k_span_long<G, J, DirectPolicy>,                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,                                         \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_span_long<G, J>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                   (int)(((size_t)(kFixBlock / G) * (p->ld + 1)) * 4)));                                \
-    hipLaunchKernelGGL((k_span_long<G, J, DirectPolicy>), dim3(256), dim3(kFixBlock),                                  \
-                       ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4, st, SB, pol);                                      \
+    hipLaunchKernelGGL((k_span_long<G, J>), dim3(256), dim3(kFixBlock), ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4,   \
+                       st, *p, *opt, bt->B, S);                                                                        \
     EV(4);                                                                                                             \
     hipLaunchKernelGGL((k_bias_partial<G, J>), dim3(n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B, \
                        S.dz1, S.bpart, rows_per_block);                                                                \
