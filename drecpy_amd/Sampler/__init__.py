@@ -1,3 +1,4 @@
 from .point_sampler import PointSampler
+from .list_sampler import ListSampler
 
-__all__ = ['PointSampler']
+__all__ = ['PointSampler', 'ListSampler']

@@ -110,3 +110,20 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_list_sampler_streams_match_reference():
+    """Caser's configuration of ListSampler (caser.py:72-75) against streams recorded from the reference."""
+    from drecpy_amd.Sampler import ListSampler
+    ls = load_json('list_sampler.json')
+    ds = _ds(load_frames()['ls_int_ts'])
+    for key, want in ls.items():
+        L, T, neg, thr, seed = key.split('|')
+        s = ListSampler(ds, ['uid'], neg_ratio=int(neg), n_targets=int(T), interaction_threshold=float(thr),
+                        negative_ids_col='iid', min_positive_records=int(L), max_positive_records=int(L),
+                        sort_column='timestamp', seed=int(seed))
+        got = s.sample_group_records(len(want))
+        for (b, a, ng), w in zip(got, want):
+            assert [int(r['rid']) for r in b] == w['before_rid'] and [int(r['rid']) for r in a] == w['after_rid']
+            assert [int(r['iid']) for r in b] == w['before'] and [int(r['iid']) for r in a] == w['after']
+            assert int(b[0]['uid']) == w['uid'] and [int(x) for x in ng] == w['neg'], key
