@@ -45,6 +45,13 @@ def glorot_uniform(rng, shape, dtype=np.float32):
     return rng.uniform(-lim, lim, size=shape).astype(dtype)
 
 
+def glorot_uniform_conv(rng, shape, dtype=np.float32):
+    """Keras glorot_uniform for a Conv1D kernel [k, in, out]: fan_in = k*in, fan_out = k*out."""
+    k, cin, cout = shape
+    lim = np.sqrt(6.0 / (k * cin + k * cout))
+    return rng.uniform(-lim, lim, size=shape).astype(dtype)
+
+
 def init_params(rng, n_users, n_items, k, dtype=np.float32):
     """cdae.py:34-41.  W_ is kept in the reference's [K,N] orientation here."""
     return {
