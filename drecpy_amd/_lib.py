@@ -39,6 +39,22 @@ class Shard(C.Structure):
                 ('n_users_local', C.c_int32)]
 
 
+class AdamSegments(C.Structure):
+    _fields_ = [('n', C.c_int32), ('start', C.c_int32 * 16), ('len', C.c_int32 * 16), ('alpha', C.c_float * 16),
+                ('l2_coef', C.c_float * 16)]
+
+
+class CaserDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('L', 'T', 'Tp', 'd', 'ld', 'ld2', 'n_v', 'n_h', 'n_small', 'off_kv', 'off_bv')] + \
+               [('off_kh', C.c_int32 * 8), ('off_bh', C.c_int32 * 8), ('off_wd', C.c_int32), ('off_bd', C.c_int32)]
+
+
+class CaserArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('item_emb', 'user_emb', 'W1', 'b1', 'sw', 'uid', 'before', 'after', 'keep')] + \
+               [('rate', C.c_float), ('B', C.c_int32)] + \
+               [(n, C.c_void_p) for n in ('dE', 'dW1', 'db1', 'dPu', 'gsw_part', 'loss_part', 'cat_out')]
+
+
 class Optim(C.Structure):
     _fields_ = [('kind', C.c_int32), ('lr', C.c_float), ('reg_rate', C.c_float), ('beta1', C.c_float),
                 ('beta2', C.c_float), ('eps', C.c_float), ('alpha', C.c_float * 5),
@@ -84,6 +100,18 @@ SIGNATURES = {
     'drx_shard_bias_grad': (C.c_int, [C.POINTER(CdaeParams), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
     'drx_shard_bias_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.c_int32, C.c_void_p, C.c_void_p]),
+    'drx_adam_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_void_p]),
+    'drx_scatter_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'drx_scatter_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_rows_dot': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+    'drx_adam_segments': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamSegments), C.c_float,
+                                    C.c_float, C.c_float, C.c_void_p]),
+    'drx_caser_grid': (C.c_int, [C.POINTER(CaserDims), C.c_int32]),
+    'drx_caser_fwd_bwd': (C.c_int, [C.POINTER(CaserDims), C.POINTER(CaserArgs), C.c_void_p, C.c_void_p]),
+    'drx_caser_hidden': (C.c_int, [C.POINTER(CaserDims), C.POINTER(CaserArgs), C.c_void_p]),
     'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                            C.c_void_p]),
     'drx_idmap_scratch_bytes': (C.c_size_t, [C.c_int64]),

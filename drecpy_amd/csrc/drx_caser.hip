@@ -1,0 +1,256 @@
+// Caser (DRecPy/Recommender/caser.py) forward / backward on gfx950.
+//
+// One wavefront per sample, lane c = embedding channel (d <= 64): the L item rows and the user row are single
+// coalesced row reads; the vertical conv (caser.py:53,103 — kernel [L,d,n_v], it sums over d), the L horizontal convs
+// with relu + max over time (caser.py:55-58,106-108), dense_0 (caser.py:63,114) and the T' target dots
+// (caser.py:115-120) are channel-parallel FMAs followed by wave reductions.  The gradients of the small weights are
+// accumulated per workgroup in LDS by their owning lane (no atomics, fixed sample order) and reduced over workgroups
+// in a second, ordered pass; the gradients of the embedding lookups leave as one row per lookup for
+// drx_scatter_rows.  Small weights are stored channel-fastest ([s][f][c]) so that every lane reads its own column.
+#include "drx_common.hpp"
+#include "drx_rows.hpp"
+
+namespace drx {
+
+constexpr int kCaserMaxL = 8;
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+struct CaserLds {
+  float *gsw;     // [n_small] gradient accumulators of the small weights
+  float *E;       // [L][64] item rows of the current sample
+  float *dE;      // [L][64]
+  float *x;       // [nx] concat(out_v, out_h) before dropout
+  float *xd;      // [nx] after dropout
+  float *pre;     // [nx] pre-activation at the arg-max step (horizontal convs)
+  float *dx;      // [nx]
+  int *arg;       // [nx]
+};
+
+template <bool TRAIN>
+__global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  const int c = threadIdx.x;
+  const int L = D.L, d = D.d, nx = D.n_v + D.L * D.n_h;
+  CaserLds S;
+  float *q = lds;
+  S.gsw = q; q += TRAIN ? D.n_small : 0;
+  S.E = q; q += L * 64;
+  S.dE = q; q += L * 64;
+  S.x = q; q += nx;
+  S.xd = q; q += nx;
+  S.pre = q; q += nx;
+  S.dx = q; q += nx;
+  S.arg = reinterpret_cast<int *>(q);
+  const float *sw = A.sw;
+  if (TRAIN)
+    for (int i = c; i < D.n_small; i += 64) S.gsw[i] = 0.f;
+  float loss_acc = 0.f;
+  const bool live = c < d;
+  const float inv_bt = 1.0f / ((float)A.B * (float)D.Tp);
+  const float inv_keep = 1.0f / (1.0f - A.rate);
+
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    __syncthreads();
+    // ---- 1. embeddings ---------------------------------------------------------------------------------------------
+    for (int t = 0; t < L; ++t) {
+      const int n = A.before[b * L + t];
+      S.E[t * 64 + c] = live ? A.item_emb[(size_t)n * D.ld + c] : 0.f;
+      S.dE[t * 64 + c] = 0.f;
+    }
+    const int u = A.uid[b];
+    const float pu = live ? A.user_emb[(size_t)u * D.ld + c] : 0.f;
+    __syncthreads();
+    // ---- 2. vertical conv ------------------------------------------------------------------------------------------
+    for (int f = 0; f < D.n_v; ++f) {
+      float part = 0.f;
+      for (int t = 0; t < L; ++t) part = fmaf(S.E[t * 64 + c], live ? sw[D.off_kv + (t * D.n_v + f) * D.ld + c] : 0.f, part);
+      const float v = wave_sum(part) + sw[D.off_bv + f];
+      if (c == 0) { S.x[f] = v; S.pre[f] = v; S.arg[f] = 0; }
+    }
+    // ---- 3. horizontal convs + relu + max over time -------------------------------------------------------------------
+    for (int i = 0; i < L; ++i) {
+      for (int f = 0; f < D.n_h; ++f) {
+        float best = -1.f, bpre = 0.f;
+        int bt = 0;
+        for (int t = 0; t + i < L; ++t) {
+          float part = 0.f;
+          for (int s = 0; s <= i; ++s)
+            part = fmaf(S.E[(t + s) * 64 + c], live ? sw[D.off_kh[i] + (s * D.n_h + f) * D.ld + c] : 0.f, part);
+          const float v = wave_sum(part) + sw[D.off_bh[i] + f];
+          const float r = fmaxf(v, 0.f);
+          if (r > best) { best = r; bt = t; bpre = v; }        // first maximum wins, like the max-pool gradient
+        }
+        if (c == 0) {
+          const int j = D.n_v + i * D.n_h + f;
+          S.x[j] = best; S.pre[j] = bpre; S.arg[j] = bt;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 4. dropout (mask injected by the host; caser.py:61,114) -------------------------------------------------------
+    for (int j = c; j < nx; j += 64) {
+      float v = S.x[j];
+      if (TRAIN && A.keep) v = A.keep[(size_t)b * nx + j] ? v * inv_keep : 0.f;
+      S.xd[j] = v;
+    }
+    __syncthreads();
+    // ---- 5. dense_0 (relu) ---------------------------------------------------------------------------------------------
+    float z0 = live ? sw[D.off_bd + c] : 0.f;
+    if (live)
+      for (int j = 0; j < nx; ++j) z0 = fmaf(S.xd[j], sw[D.off_wd + j * D.ld + c], z0);
+    const float z = fmaxf(z0, 0.f);
+    if (!TRAIN) {
+      if (live) { A.cat_out[(size_t)b * D.ld2 + c] = z; A.cat_out[(size_t)b * D.ld2 + d + c] = pu; }
+      continue;
+    }
+    // ---- 6. targets: score, sigmoid, Keras BCE, backward to the lookups -------------------------------------------------
+    float dz = 0.f, dpu = 0.f;
+    for (int j = 0; j < D.Tp; ++j) {
+      const int n = A.after[b * D.Tp + j];
+      const float wa = live ? A.W1[(size_t)n * D.ld2 + c] : 0.f;
+      const float wb = live ? A.W1[(size_t)n * D.ld2 + d + c] : 0.f;
+      const float sc = wave_sum(fmaf(z, wa, pu * wb)) + A.b1[n];
+      const float p = sigmoidf_(sc);
+      const float y = j < D.T ? 1.f : 0.f;
+      loss_acc += bce_elem(y, p);
+      const float ds = bce_grad(y, p) * inv_bt * p * (1.f - p);
+      const size_t row = (size_t)b * D.Tp + j;
+      if (live) { A.dW1[row * D.ld2 + c] = ds * z; A.dW1[row * D.ld2 + d + c] = ds * pu; }
+      if (c == 0) A.db1[row] = ds;
+      dz = fmaf(ds, wa, dz);
+      dpu = fmaf(ds, wb, dpu);
+    }
+    if (live) A.dPu[(size_t)b * D.ld + c] = dpu;
+    const float dz0 = z0 > 0.f ? dz : 0.f;
+    // ---- 7. dense_0 backward ---------------------------------------------------------------------------------------------
+    if (live) S.gsw[D.off_bd + c] += dz0;
+    for (int j = 0; j < nx; ++j) {
+      const float w = live ? sw[D.off_wd + j * D.ld + c] : 0.f;
+      if (live) S.gsw[D.off_wd + j * D.ld + c] = fmaf(S.xd[j], dz0, S.gsw[D.off_wd + j * D.ld + c]);
+      float g = wave_sum(dz0 * w);
+      if (A.keep) g = A.keep[(size_t)b * nx + j] ? g * inv_keep : 0.f;
+      if (c == 0) S.dx[j] = g;
+    }
+    __syncthreads();
+    // ---- 8. vertical conv backward ---------------------------------------------------------------------------------------
+    for (int f = 0; f < D.n_v; ++f) {
+      const float dv = S.dx[f];
+      if (c == 0) S.gsw[D.off_bv + f] += dv;
+      if (live)
+        for (int t = 0; t < L; ++t) {
+          const int k = D.off_kv + (t * D.n_v + f) * D.ld + c;
+          S.gsw[k] = fmaf(S.E[t * 64 + c], dv, S.gsw[k]);
+          S.dE[t * 64 + c] = fmaf(dv, sw[k], S.dE[t * 64 + c]);
+        }
+    }
+    // ---- 9. horizontal convs backward (through relu at the arg-max step) -------------------------------------------------
+    for (int i = 0; i < L; ++i)
+      for (int f = 0; f < D.n_h; ++f) {
+        const int j = D.n_v + i * D.n_h + f;
+        const float dc = S.pre[j] > 0.f ? S.dx[j] : 0.f;
+        if (dc == 0.f) continue;
+        const int t = S.arg[j];
+        if (c == 0) S.gsw[D.off_bh[i] + f] += dc;
+        if (live)
+          for (int s = 0; s <= i; ++s) {
+            const int k = D.off_kh[i] + (s * D.n_h + f) * D.ld + c;
+            S.gsw[k] = fmaf(S.E[(t + s) * 64 + c], dc, S.gsw[k]);
+            S.dE[(t + s) * 64 + c] = fmaf(dc, sw[k], S.dE[(t + s) * 64 + c]);
+          }
+      }
+    // ---- 10. gradient rows of the item lookups ------------------------------------------------------------------------------
+    if (live)
+      for (int t = 0; t < L; ++t) A.dE[((size_t)b * L + t) * D.ld + c] = S.dE[t * 64 + c];
+  }
+  if (TRAIN) {
+    __syncthreads();
+    for (int i = c; i < D.n_small; i += 64) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = S.gsw[i];
+    if (c == 0) A.loss_part[blockIdx.x] = loss_acc * inv_bt;
+  }
+}
+
+// out[j] = sum_r part[r][j] (fixed order); out[n] = sum_r tail[r]
+__global__ __launch_bounds__(kBlock) void k_sum_partials(const float *__restrict__ part, int n_rows, int n, const float *__restrict__ tail,
+                                                         float *__restrict__ out) {
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j <= n; j += gridDim.x * kBlock) {
+    float a = 0.f;
+    if (j < n) for (int r = 0; r < n_rows; ++r) a += part[(size_t)r * n + j];
+    else for (int r = 0; r < n_rows; ++r) a += tail[r];
+    out[j] = a;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_adam_segments(float *p, float *m, float *v, const float *g, DrxAdamSegments sg, float b1,
+                                                          float b2, float eps) {
+  for (int s = 0; s < sg.n; ++s) {
+    OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, sg.alpha[s]};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < sg.len[s]; i += gridDim.x * kBlock) {
+      const int k = sg.start[s] + i;
+      float pp = p[k], mm = m[k], vv = v[k];
+      opt_update1(o, fmaf(sg.l2_coef[s], pp, g[k]), pp, mm, vv);
+      p[k] = pp; m[k] = mm; v[k] = vv;
+    }
+  }
+}
+
+static size_t caser_lds_bytes(const DrxCaserDims &D, bool train) {
+  const int nx = D.n_v + D.L * D.n_h;
+  return ((size_t)(train ? D.n_small : 0) + 2 * (size_t)D.L * 64 + 5 * (size_t)nx) * 4 + 64;
+}
+
+static int check_dims(const DrxCaserDims *D) {
+  if (!D || D->L < 1 || D->L > kCaserMaxL || D->d < 1 || D->d > 64 || D->ld < D->d || (D->ld & 3) || D->ld2 < 2 * D->d ||
+      (D->ld2 & 3) || D->n_v < 1 || D->n_h < 1 || D->T < 1 || D->Tp < D->T || D->n_small < 1)
+    return DRX_EINVAL;
+  return caser_lds_bytes(*D, true) <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
+}
+
+}  // namespace drx
+
+using namespace drx;
+
+extern "C" {
+
+int drx_caser_grid(const DrxCaserDims *D, int32_t B) {
+  (void)D;
+  return B < 512 ? B : 512;
+}
+
+int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, void *stream) {
+  int rc = check_dims(D);
+  if (rc) return rc;
+  if (!A || !A->item_emb || !A->user_emb || !A->W1 || !A->b1 || !A->sw || !A->uid || !A->before || !A->after || !A->dE ||
+      !A->dW1 || !A->db1 || !A->dPu || !A->gsw_part || !A->loss_part || !gsw_out || A->B < 1 || A->rate < 0.f || A->rate >= 1.f)
+    return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = drx_caser_grid(D, A->B);
+  const size_t lds = caser_lds_bytes(*D, true);
+  DRX_HIP(hipFuncSetAttribute((const void *)k_caser<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_caser<true>, dim3(grid), dim3(64), lds, st, *D, *A);
+  hipLaunchKernelGGL(k_sum_partials, dim3((D->n_small + kBlock) / kBlock), dim3(kBlock), 0, st, A->gsw_part, grid, D->n_small,
+                     A->loss_part, gsw_out);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_caser_hidden(const DrxCaserDims *D, const DrxCaserArgs *A, void *stream) {
+  int rc = check_dims(D);
+  if (rc) return rc;
+  if (!A || !A->item_emb || !A->user_emb || !A->sw || !A->uid || !A->before || !A->cat_out || A->B < 1) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = caser_lds_bytes(*D, false);
+  hipLaunchKernelGGL(k_caser<false>, dim3(A->B < 2048 ? A->B : 2048), dim3(64), lds, st, *D, *A);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_adam_segments(float *p, float *m, float *v, const float *g, const DrxAdamSegments *sg, float beta1, float beta2, float eps,
+                      void *stream) {
+  if (!p || !m || !v || !g || !sg || sg->n < 1 || sg->n > DRX_MAX_SEGMENTS) return DRX_EINVAL;
+  hipLaunchKernelGGL(k_adam_segments, dim3(64), dim3(kBlock), 0, (hipStream_t)stream, p, m, v, g, *sg, beta1, beta2, eps);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+}  // extern "C"

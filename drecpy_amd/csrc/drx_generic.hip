@@ -1,0 +1,183 @@
+// Model-independent pieces of the reference-mode ("dense Keras Adam") steps of DMF and Caser:
+//   drx_adam_dense   : fused L2 + Keras-Adam sweep over a flat parameter array (replaces one
+//                      optimizer.apply_gradients of recommender_abc.py:328-334): p, m, v read once / written once
+//   drx_scatter_rows : deterministic scatter-add of per-touch gradient rows into a dense gradient table
+//                      (what tape.gradient does for tf.nn.embedding_lookup / Keras Embedding inputs): stable sort of
+//                      the touches by destination row + the segmented reduction of drx_segreduce.hpp
+//   drx_rows_dot     : scores[b, n] = x_b . T[n] (+ bias[n]) for all rows n (all-item scoring of _rank)
+#include "drx_common.hpp"
+#include "drx_rows.hpp"
+#include "drx_segreduce.hpp"
+
+namespace drx {
+
+__global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
+                                                       const float *__restrict__ g, size_t n, float alpha, float l2c, float b1,
+                                                       float b2, float eps) {
+  const size_t n4 = n / 4;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+    float4 pp = reinterpret_cast<float4 *>(p)[i], mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+    float4 gg = g ? reinterpret_cast<const float4 *>(g)[i] : f4_zero();
+    OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, alpha};
+    opt_update1(o, fmaf(l2c, pp.x, gg.x), pp.x, mm.x, vv.x);
+    opt_update1(o, fmaf(l2c, pp.y, gg.y), pp.y, mm.y, vv.y);
+    opt_update1(o, fmaf(l2c, pp.z, gg.z), pp.z, mm.z, vv.z);
+    opt_update1(o, fmaf(l2c, pp.w, gg.w), pp.w, mm.w, vv.w);
+    reinterpret_cast<float4 *>(p)[i] = pp; reinterpret_cast<float4 *>(m)[i] = mm; reinterpret_cast<float4 *>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    float pp = p[i], mm = m[i], vv = v[i];
+    OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, alpha};
+    opt_update1(o, fmaf(l2c, pp, g ? g[i] : 0.f), pp, mm, vv);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+struct ScatterPolicy {
+  const float *src;          // [n_src, ld]
+  const uint32_t *src_index; // [T] row of src contributed by touch `pos` (nullptr: pos itself)
+  const float *coef;         // [T] multiplier (nullptr: 1)
+  const float *src_s;        // [n_src] scalar side channel (nullptr: none)
+  float *out;                // [n_rows, ld]
+  float *out_s;              // [n_rows] or nullptr
+  int ld;
+  template <int G, int J>
+  __device__ __forceinline__ void load(uint32_t, uint32_t pos, int lane, float4 (&row)[J], float &sc, float &c) const {
+    const uint32_t r = src_index ? src_index[pos] : pos;
+    load_row<G, J>(src, (size_t)r, ld, lane, row);
+    c = coef ? coef[pos] : 1.0f;
+    if (src_s) sc = src_s[r] * c;
+  }
+  template <int G, int J>
+  __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
+    store_row<G, J>(out, (size_t)key, ld, lane, g);
+    if (out_s && lane == 0) out_s[key] = gs;
+  }
+};
+
+__global__ void k_iota2(uint32_t *v, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_rows_dot(const float *__restrict__ x, int B, const float *__restrict__ tab, int n_rows,
+                                                     int ld, const float *__restrict__ bias, float *__restrict__ out) {
+  const int lane = threadIdx.x % G;
+  const int gpb = kBlock / G;
+  for (int n = blockIdx.x * gpb + threadIdx.x / G; n < n_rows; n += gridDim.x * gpb) {
+    float4 w[J];
+    load_row<G, J>(tab, (size_t)n, ld, lane, w);
+    const float bb = bias ? bias[n] : 0.f;
+    for (int b = 0; b < B; ++b) {
+      float4 xv[J];
+      load_row<G, J>(x, (size_t)b, ld, lane, xv);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) d += f4_dot(w[j], xv[j]);
+      d = group_sum<G>(d);
+      if (lane == 0) out[(size_t)b * n_rows + n] = d + bb;
+    }
+  }
+}
+
+struct ScatterLayout {
+  SegBufs sb;
+  uint32_t *idx, *keys_s, *vals_s;
+  void *sort_temp;
+  size_t sort_bytes;
+};
+
+static ScatterLayout scatter_layout(Carver &cv, int ld, int T, int bits) {
+  ScatterLayout L{};
+  const int n_chunks = (T + kChunk - 1) / kChunk;
+  L.sb.T = T; L.sb.n_chunks = n_chunks; L.sb.ld = ld;
+  L.sb.phead = cv.take<float>((size_t)n_chunks * ld);
+  L.sb.ptail = cv.take<float>((size_t)n_chunks * ld);
+  L.sb.phs = cv.take<float>(n_chunks);
+  L.sb.pts = cv.take<float>(n_chunks);
+  L.sb.span_list = cv.take<uint32_t>(n_chunks);
+  L.sb.long_list = cv.take<uint32_t>(n_chunks);
+  L.sb.n_span = cv.take<uint32_t>(64);
+  L.idx = cv.take<uint32_t>(T);
+  L.keys_s = cv.take<uint32_t>(T);
+  L.vals_s = cv.take<uint32_t>(T);
+  L.sort_bytes = sort_pairs_temp_bytes((size_t)T, bits);
+  L.sort_temp = cv.take<char>(L.sort_bytes);
+  return L;
+}
+
+}  // namespace drx
+
+using namespace drx;
+
+extern "C" {
+
+int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, float alpha, float l2_coef, float beta1, float beta2,
+                   float eps, void *stream) {
+  if (!p || !m || !v || n < 1) return DRX_EINVAL;
+  if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return DRX_EINVAL;
+  int blocks = (int)std::min<int64_t>((n / 4 + kBlock - 1) / kBlock + 1, 4096);
+  hipLaunchKernelGGL(k_adam_dense, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, p, m, v, g, (size_t)n, alpha, l2_coef,
+                     beta1, beta2, eps);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows) {
+  if (ld < 4 || (ld & 3) || n_touches < 1 || n_rows < 1) return 0;
+  Carver cv(nullptr, 0);
+  (void)scatter_layout(cv, ld, n_touches, bits_for((uint64_t)n_rows + 1));
+  return align_up(cv.off, 256) + 256;
+}
+
+int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const uint32_t *src_index, const float *coef,
+                     const float *src_s, int32_t ld, int32_t n_rows, float *out, float *out_s, void *scratch,
+                     size_t scratch_bytes, void *stream) {
+  if (!keys || !src || !out || !scratch || T < 1 || n_rows < 1 || ld < 4 || (ld & 3) || ld > DRX_MAX_K) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int bits = bits_for((uint64_t)n_rows + 1);
+  Carver cv(scratch, scratch_bytes);
+  ScatterLayout L = scatter_layout(cv, ld, T, bits);
+  if (!cv.ok()) return DRX_ESCRATCH;
+  hipLaunchKernelGGL(k_iota2, dim3(1024), dim3(256), 0, st, L.idx, T);
+  int rc = sort_pairs(L.sort_temp, L.sort_bytes, keys, L.keys_s, L.idx, L.vals_s, (size_t)T, bits, st);
+  if (rc) return rc;
+  L.sb.keys_s = L.keys_s; L.sb.vals_s = L.vals_s;
+  ScatterPolicy pol{src, src_index, coef, src_s, out, out_s, ld};
+  DRX_HIP(hipMemsetAsync(L.sb.n_span, 0, 2 * sizeof(uint32_t), st));
+#define CALL(G, J)                                                                                                      \
+  {                                                                                                                     \
+    hipLaunchKernelGGL((k_seg_reduce<G, J, ScatterPolicy>), dim3((L.sb.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)),        \
+                       dim3(kBlock), 0, st, L.sb, pol);                                                                 \
+    hipLaunchKernelGGL((k_span_short<G, J, ScatterPolicy>), dim3(256), dim3(kBlock), 0, st, L.sb, pol);                 \
+    const size_t lds = ((size_t)(kFixBlock / G) * (ld + 1)) * 4;                                                        \
+    if (lds > 48 * 1024)                                                                                                \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_span_long<G, J, ScatterPolicy>,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+    hipLaunchKernelGGL((k_span_long<G, J, ScatterPolicy>), dim3(64), dim3(kFixBlock), lds, st, L.sb, pol);              \
+  }
+  DRX_DISPATCH_GEOM(ld, CALL);
+#undef CALL
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_rows_dot(const float *x, int32_t B, const float *table, int32_t n_rows, int32_t ld, const float *bias, float *out,
+                 void *stream) {
+  if (!x || !table || !out || B < 1 || n_rows < 1 || ld < 4 || (ld & 3) || ld > DRX_MAX_K) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(G, J)                                                                                       \
+  {                                                                                                      \
+    const int gpb = kBlock / G;                                                                          \
+    int blocks = (n_rows + gpb - 1) / gpb;                                                               \
+    if (blocks > 2048) blocks = 2048;                                                                    \
+    hipLaunchKernelGGL((k_rows_dot<G, J>), dim3(blocks), dim3(kBlock), 0, st, x, B, table, n_rows, ld, bias, out); \
+  }
+  DRX_DISPATCH_GEOM(ld, CALL);
+#undef CALL
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""Device-side state of one Caser model and the calls into libdrx.so (drx_caser_*, drx_scatter_rows, drx_adam_*).
+
+One training step = the body of the reference fit() loop for Caser (recommender_abc.py:190-204 over caser.py:86-120):
+  drx_caser_fwd_bwd     forward, Keras BCE, backward -> one gradient row per embedding lookup + small-weight gradients
+  drx_scatter_rows x3   lookups' rows -> dense gradient tables (item_emb, dense_1_W (+dense_1_b), user_emb)
+  drx_adam_dense x4     fused L2 (Keras l2(reg): 2*reg*w) + Keras Adam on the four tables, one lr_t per registered layer
+  drx_adam_segments     the conv / dense_0 kernels and biases
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AdamSegments, CaserArgs, CaserDims, check, lib, ptr, stream_ptr
+from .engine import ADAM_B1, ADAM_B2, ADAM_EPS, CdaeEngine, _round_up
+
+
+class CaserEngine:
+    def __init__(self, n_users, n_items, L=5, T=3, neg_ratio=3, d=50, n_v=4, n_h=16, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise _lib.DrxError('drecpy_amd needs a ROCm GPU (MI355X); there is no CPU fallback.')
+        lib()
+        assert L <= 8 and d <= 64, 'Caser engine supports L <= 8 and d <= 64'
+        self.device = torch.device(device)
+        self.U, self.N, self.L, self.T, self.d, self.n_v, self.n_h = n_users, n_items, L, T, d, n_v, n_h
+        self.Tp = T + T * neg_ratio
+        self.ld, self.ld2 = _round_up(d, 4), _round_up(2 * d, 4)
+        self.nx = n_v + L * n_h
+        ld = self.ld
+        off = 0
+        D = CaserDims()
+        D.L, D.T, D.Tp, D.d, D.ld, D.ld2, D.n_v, D.n_h = L, T, self.Tp, d, ld, self.ld2, n_v, n_h
+        self.seg = []                    # (name, start, len, regularised, layer index)
+        D.off_kv = off; self.seg.append(('conv_v_k', off, L * n_v * ld, True, 2)); off += L * n_v * ld
+        D.off_bv = off; self.seg.append(('conv_v_b', off, n_v, False, 2)); off += _round_up(n_v, 4)
+        for i in range(L):
+            D.off_kh[i] = off; self.seg.append((f'conv_h{i}_k', off, (i + 1) * n_h * ld, True, 3 + i)); off += (i + 1) * n_h * ld
+            D.off_bh[i] = off; self.seg.append((f'conv_h{i}_b', off, n_h, False, 3 + i)); off += _round_up(n_h, 4)
+        D.off_wd = off; self.seg.append(('dense0_k', off, self.nx * ld, True, 3 + L)); off += self.nx * ld
+        D.off_bd = off; self.seg.append(('dense0_b', off, ld, False, 3 + L)); off += ld
+        D.n_small = off
+        self.D = D
+        self.n_layers = 6 + L
+        z = dict(dtype=torch.float32, device=self.device)
+        self.item_emb = torch.zeros(n_items, ld, **z)
+        self.user_emb = torch.zeros(n_users, ld, **z)
+        self.W1 = torch.zeros(n_items, self.ld2, **z)
+        self.b1 = torch.zeros(n_items, **z)
+        self.sw = torch.zeros(off, **z)
+        self.state = {n: (torch.zeros_like(t), torch.zeros_like(t)) for n, t in self.tensors().items()}
+        self._grads = {n: torch.zeros_like(t) for n, t in self.tensors().items()}
+        self._scratch = None
+        self.lr, self.reg = 1e-3, 1e-3
+
+    def tensors(self):
+        return {'user_emb': self.user_emb, 'item_emb': self.item_emb, 'W1': self.W1, 'b1': self.b1, 'sw': self.sw}
+
+    # ---- parameters in the reference's layout (oracle/caser_oracle.py:init_params) -----------------------------
+    def set_params(self, p):
+        d, ld = self.d, self.ld
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
+        for x in self.tensors().values():
+            x.zero_()
+        self.user_emb[:, :d] = t(p['user_emb'])
+        self.item_emb[:, :d] = t(p['item_emb'])
+        self.W1[:, :2 * d] = t(p['W1'])
+        self.b1.copy_(t(p['b1']).reshape(-1))
+        for name, start, n, _, _ in self.seg:
+            if name.endswith('_k') and name.startswith('conv'):
+                k = t(p[name]).permute(0, 2, 1).contiguous()            # [s, d, f] -> [s, f, d]
+                view = self.sw[start:start + n].view(k.shape[0], k.shape[1], ld)
+                view[:, :, :d] = k
+            elif name == 'dense0_k':
+                self.sw[start:start + n].view(self.nx, ld)[:, :d] = t(p[name])
+            elif name == 'dense0_b':
+                self.sw[start:start + d] = t(p[name])
+            else:
+                self.sw[start:start + n] = t(p[name])
+
+    def get_params(self):
+        d, ld = self.d, self.ld
+        c = lambda x: x.detach().cpu().numpy().copy()
+        p = {'user_emb': c(self.user_emb[:, :d]), 'item_emb': c(self.item_emb[:, :d]), 'W1': c(self.W1[:, :2 * d]),
+             'b1': c(self.b1).reshape(-1, 1)}
+        for name, start, n, _, _ in self.seg:
+            if name.endswith('_k') and name.startswith('conv'):
+                s_ = n // (ld * (self.n_v if name == 'conv_v_k' else self.n_h))
+                f = self.n_v if name == 'conv_v_k' else self.n_h
+                p[name] = c(self.sw[start:start + n].view(s_, f, ld)[:, :, :d].permute(0, 2, 1))
+            elif name == 'dense0_k':
+                p[name] = c(self.sw[start:start + n].view(self.nx, ld)[:, :d])
+            elif name == 'dense0_b':
+                p[name] = c(self.sw[start:start + d])
+            else:
+                p[name] = c(self.sw[start:start + n])
+        return p
+
+    def snapshot(self):
+        return {'p': {n: t.clone() for n, t in self.tensors().items()}}
+
+    def restore(self, snap, with_optimizer=False):
+        for n, t in self.tensors().items():
+            t.copy_(snap['p'][n])
+
+    # ---- helpers --------------------------------------------------------------------------------------------------
+    def _dev_i32(self, a):
+        if torch.is_tensor(a):
+            return a.to(self.device, torch.int32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    def _scatter(self, keys, src, ld, n_rows, out, src_s=None, out_s=None):
+        T = keys.numel()
+        need = lib().drx_scatter_scratch_bytes(ld, T, n_rows)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(int(need * 1.2) + 1024, dtype=torch.uint8, device=self.device)
+        out.zero_()
+        if out_s is not None:
+            out_s.zero_()
+        check(lib().drx_scatter_rows(ptr(keys), T, ptr(src), None, None, ptr(src_s), ld, n_rows, ptr(out), ptr(out_s),
+                                     ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
+
+    def _adam(self, name, grad, alpha, l2c):
+        p = self.tensors()[name]
+        m, v = self.state[name]
+        check(lib().drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(grad), p.numel(), alpha, l2c, ADAM_B1, ADAM_B2, ADAM_EPS,
+                                   stream_ptr(self.device)), 'drx_adam_dense')
+
+    def _args(self, uid, before, after=None, keep=None, rate=0.0):
+        A = CaserArgs()
+        A.item_emb, A.user_emb, A.W1, A.b1, A.sw = (t.data_ptr() for t in (self.item_emb, self.user_emb, self.W1, self.b1, self.sw))
+        A.uid, A.before = uid.data_ptr(), before.data_ptr()
+        A.after = after.data_ptr() if after is not None else None
+        A.keep = keep.data_ptr() if keep is not None else None
+        A.rate, A.B = float(rate), int(uid.numel())
+        return A
+
+    # ---- one training step ---------------------------------------------------------------------------------------
+    def step(self, step_idx, uids, before, after, keep=None, rate=0.0, want_loss=False):
+        L_ = lib()
+        uid, bef, aft = self._dev_i32(uids), self._dev_i32(before), self._dev_i32(after)
+        B = uid.numel()
+        assert bef.shape == (B, self.L) and aft.shape == (B, self.Tp)
+        kp = None
+        if keep is not None:
+            kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
+                else keep.to(self.device, torch.uint8).contiguous()
+        z = dict(dtype=torch.float32, device=self.device)
+        grid = L_.drx_caser_grid(C.byref(self.D), B)
+        dE = torch.empty(B * self.L, self.ld, **z)
+        dW1 = torch.empty(B * self.Tp, self.ld2, **z)
+        db1 = torch.empty(B * self.Tp, **z)
+        dPu = torch.empty(B, self.ld, **z)
+        gpart = torch.empty(grid, self.D.n_small, **z)
+        lpart = torch.empty(grid, **z)
+        gsw = torch.empty(self.D.n_small + 1, **z)
+        dE.zero_(); dW1.zero_(); dPu.zero_()          # padding columns of the gradient rows
+        A = self._args(uid, bef, aft, kp, rate)
+        A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = (t.data_ptr() for t in (dE, dW1, db1, dPu, gpart, lpart))
+        reg_loss = None
+        if want_loss:                                   # Keras l2(reg) on the pre-update weights
+            sq = (self.user_emb ** 2).sum() + (self.item_emb ** 2).sum() + (self.W1 ** 2).sum()
+            for name, start, n, regd, _ in self.seg:
+                if regd:
+                    sq = sq + (self.sw[start:start + n] ** 2).sum()
+            reg_loss = self.reg * sq
+        check(L_.drx_caser_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream_ptr(self.device)), 'drx_caser_fwd_bwd')
+        g = self._grads
+        self._scatter(bef.reshape(-1), dE, self.ld, self.N, g['item_emb'])
+        self._scatter(aft.reshape(-1), dW1, self.ld2, self.N, g['W1'], src_s=db1, out_s=g['b1'])
+        self._scatter(uid, dPu, self.ld, self.U, g['user_emb'])
+        alpha = lambda j: CdaeEngine.adam_alpha(self.lr, self.n_layers * step_idx + j + 1)
+        l2c = 2.0 * self.reg
+        self._adam('user_emb', g['user_emb'], alpha(0), l2c)
+        self._adam('item_emb', g['item_emb'], alpha(1), l2c)
+        self._adam('W1', g['W1'], alpha(4 + self.L), l2c)
+        self._adam('b1', g['b1'], alpha(5 + self.L), 0.0)
+        sg = AdamSegments()
+        sg.n = len(self.seg)
+        for i, (_, start, n, regd, layer) in enumerate(self.seg):
+            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha(layer), (l2c if regd else 0.0)
+        m, v = self.state['sw']
+        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), ADAM_B1, ADAM_B2, ADAM_EPS,
+                                   stream_ptr(self.device)), 'drx_adam_segments')
+        if want_loss:
+            return float((gsw[-1] + reg_loss).item())
+        return None
+
+    # ---- inference: scores of ALL items for each (user, last-L-items) row (caser.py:128-137) --------------------
+    def scores_all(self, uids, before):
+        uid, bef = self._dev_i32(uids), self._dev_i32(before)
+        B = uid.numel()
+        cat = torch.zeros(B, self.ld2, dtype=torch.float32, device=self.device)
+        A = self._args(uid, bef)
+        A.cat_out = cat.data_ptr()
+        check(lib().drx_caser_hidden(C.byref(self.D), C.byref(A), stream_ptr(self.device)), 'drx_caser_hidden')
+        out = torch.empty(B, self.N, dtype=torch.float32, device=self.device)
+        check(lib().drx_rows_dot(ptr(cat), B, ptr(self.W1), self.N, self.ld2, ptr(self.b1), ptr(out),
+                                 stream_ptr(self.device)), 'drx_rows_dot')
+        return out

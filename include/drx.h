@@ -186,6 +186,67 @@ int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *l
                         size_t scratch_bytes, void *stream);
 int drx_shard_bias_apply(const DrxCdaeParams *p, const DrxOptim *opt, int32_t b_norm, const float *grad, void *stream);
 
+/* ---- model-independent pieces of the dense (Keras-Adam) steps of DMF / Caser ------------------------------------
+ * drx_adam_dense: p, m, v [n] (16-B aligned): g_total = g + l2_coef * p (g may be NULL); TF ApplyAdam update with the
+ *   given lr_t `alpha`.  One call = one optimizer.apply_gradients on one variable (recommender_abc.py:328-334). */
+int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, float alpha, float l2_coef, float beta1, float beta2,
+                   float eps, void *stream);
+/* drx_scatter_rows: out[key] = sum over touches t with keys[t] == key of coef[t] * src[src_index[t]]  (and
+ *   out_s[key] = sum coef[t] * src_s[src_index[t]]), summed in touch order (deterministic).  Rows of `out` that no
+ *   touch names are left untouched (zero them first).  keys may hold DRX_KEY_NONE (ignored).  This is the gradient
+ *   of an embedding lookup (tf.nn.embedding_lookup / Keras Embedding, caser.py:99-100,117-118; dmf.py:89-90 first layer). */
+size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows);
+int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const uint32_t *src_index, const float *coef,
+                     const float *src_s, int32_t ld, int32_t n_rows, float *out, float *out_s, void *scratch,
+                     size_t scratch_bytes, void *stream);
+/* drx_rows_dot: out[b, n] = x[b, :] . table[n, :] + bias[n]   (all-item scoring, caser.py:137) */
+int drx_rows_dot(const float *x, int32_t B, const float *table, int32_t n_rows, int32_t ld, const float *bias, float *out,
+                 void *stream);
+
+/* Adam over up to DRX_MAX_SEGMENTS slices of one flat array, each with its own Keras lr_t and L2 coefficient: the
+ * small conv/dense weights of a model, one slice per registered layer kernel / bias (recommender_abc.py:328-334). */
+#define DRX_MAX_SEGMENTS 16
+typedef struct DrxAdamSegments {
+  int32_t n;
+  int32_t start[DRX_MAX_SEGMENTS], len[DRX_MAX_SEGMENTS];
+  float alpha[DRX_MAX_SEGMENTS], l2_coef[DRX_MAX_SEGMENTS];
+} DrxAdamSegments;
+int drx_adam_segments(float *p, float *m, float *v, const float *g, const DrxAdamSegments *sg, float beta1, float beta2, float eps,
+                      void *stream);
+
+/* ---- Caser (DRecPy/Recommender/caser.py) ------------------------------------------------------------------------
+ * Tables: item_emb [N, ld], user_emb [U, ld] (caser.py:47-50), W1 [N, ld2] = dense_1_W rows (first d columns meet
+ * dense_0's output, the next d the user embedding, caser.py:66,115-120), b1 [N] (caser.py:69).  Small weights `sw`
+ * (one flat array, channel-fastest): conv_v kernel [L][n_v][ld] at off_kv + bias [n_v] at off_bv (caser.py:53);
+ * convs_h[i] kernel [i+1][n_h][ld] at off_kh[i] + bias [n_h] at off_bh[i] (caser.py:55-58); dense_0 kernel
+ * [n_v + L*n_h][ld] at off_wd + bias [ld] at off_bd (caser.py:63). */
+typedef struct DrxCaserDims {
+  int32_t L, T, Tp, d, ld, ld2, n_v, n_h, n_small;   /* Tp = T + T*neg_ratio targets per sample */
+  int32_t off_kv, off_bv, off_kh[8], off_bh[8], off_wd, off_bd;
+} DrxCaserDims;
+typedef struct DrxCaserArgs {
+  const float *item_emb, *user_emb, *W1, *b1, *sw;
+  const int32_t *uid;      /* [B] */
+  const int32_t *before;   /* [B, L]  last L items (caser.py:79-83) */
+  const int32_t *after;    /* [B, Tp] T targets then T*neg negatives */
+  const uint8_t *keep;     /* [B, n_v + L*n_h] dropout keep mask (TF's RNG cannot be reproduced) or NULL = no dropout */
+  float rate;
+  int32_t B;
+  float *dE;               /* [B*L, ld]   gradient row of every item lookup */
+  float *dW1;              /* [B*Tp, ld2] gradient row of every dense_1_W lookup */
+  float *db1;              /* [B*Tp] */
+  float *dPu;              /* [B, ld]     gradient row of every user lookup */
+  float *gsw_part;         /* [drx_caser_grid(), n_small] */
+  float *loss_part;        /* [drx_caser_grid()] */
+  float *cat_out;          /* [B, ld2] (drx_caser_hidden only) */
+} DrxCaserArgs;
+int drx_caser_grid(const DrxCaserDims *D, int32_t B);
+/* forward + Keras BCE + backward (caser.py:86-120 under the tape of recommender_abc.py:191-203): fills the lookup
+ * gradient rows above and gsw_out[0..n_small) = gradient of the small weights, gsw_out[n_small] = prediction loss. */
+int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, void *stream);
+/* inference hidden state cat_out[b] = [dense_0 output | user embedding] (caser.py:97-115 with training=False) */
+int drx_caser_hidden(const DrxCaserDims *D, const DrxCaserArgs *A, void *stream);
+
 /* ---- ranking (cdae.py:90-103, recommender_abc.py:454-461) --------------------------------
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with
  * cand_mask == NULL || bit (r*n + i) set; order = descending score, ties by larger index
