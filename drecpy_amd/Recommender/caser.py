@@ -1,0 +1,137 @@
+"""Caser (Convolutional Sequence Embedding Recommendation) on the MI355X engine — constructor, hooks and semantics of
+DRecPy/Recommender/caser.py; arithmetic in drx_caser.hip / drx_generic.hip behind include/drx.h.
+
+Reference behaviour kept: ListSampler configured as caser.py:72-75 (window of L inputs + T targets + T*neg_ratio
+negative ids, sorted by `sort_column`), vertical conv that sums over the embedding dimension (caser.py:53 — not the
+paper's per-dimension conv), max over time of the horizontal convs, dense Keras Adam with one apply per registered layer
+(6 + L per step), l2(reg_rate) on embeddings and kernels.  TF's dropout RNG cannot be reproduced: the keep mask comes
+from a numpy Generator seeded with the model seed (or is injected with `dropout_mask_fn` for tests); relu is the only
+supported activation (the reference's default for both act_h and act_mlp).
+"""
+import numpy as np
+
+from .recommender_abc import RecommenderABC
+from ..Sampler import ListSampler
+
+
+class Caser(RecommenderABC):
+    def __init__(self, L=5, T=3, d=50, n_v=4, n_h=16, act_h='relu', act_mlp='relu', dropout_rate=0.5,
+                 sort_column='timestamp', device='cuda:0', **kwds):
+        super().__init__(**kwds)
+        if act_h != 'relu' or act_mlp != 'relu':
+            raise Exception('drecpy_amd.Caser supports relu activations only (the reference defaults).')
+        self.L, self.T, self.d, self.n_v, self.n_h = L, T, d, n_v, n_h
+        self.dropout_rate = dropout_rate
+        self.sort_column = sort_column
+        self.device = device
+
+    def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):          # caser.py:45-75
+        from ..engine_caser import CaserEngine
+        self.neg_ratio = neg_ratio
+        self._engine = CaserEngine(self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v, self.n_h,
+                                   device=self.device)
+        self._engine.lr, self._engine.reg = float(learning_rate), float(reg_rate)
+        weights = kwds.get('initial_weights')
+        if weights is None:
+            weights = self._keras_init(np.random.default_rng(self.seed))
+        self._engine.set_params(weights)
+        self._sampler = ListSampler(self.interaction_dataset, ['uid'], neg_ratio=neg_ratio, n_targets=self.T,
+                                    interaction_threshold=self.interaction_threshold, negative_ids_col='iid',
+                                    min_positive_records=self.L, max_positive_records=self.L,
+                                    sort_column=self.sort_column, seed=self.seed)
+        self._drop_rng = np.random.default_rng(self.seed)
+        self._dropout_mask_fn = kwds.get('dropout_mask_fn')
+
+    def _keras_init(self, rng):
+        """Keras defaults: Embedding uniform(-0.05, 0.05); Conv1D / Dense glorot_uniform kernels, zero biases."""
+        f32 = np.float32
+        u = lambda *s: rng.uniform(-0.05, 0.05, size=s).astype(f32)
+
+        def glorot(shape, fan_in, fan_out):
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            return rng.uniform(-lim, lim, size=shape).astype(f32)
+        L, d, n_v, n_h = self.L, self.d, self.n_v, self.n_h
+        p = {'user_emb': u(self.n_users, d), 'item_emb': u(self.n_items, d),
+             'conv_v_k': glorot((L, d, n_v), L * d, L * n_v), 'conv_v_b': np.zeros(n_v, f32)}
+        for i in range(L):
+            p[f'conv_h{i}_k'] = glorot((i + 1, d, n_h), (i + 1) * d, (i + 1) * n_h)
+            p[f'conv_h{i}_b'] = np.zeros(n_h, f32)
+        nx = n_v + L * n_h
+        p['dense0_k'] = glorot((nx, d), nx, d)
+        p['dense0_b'] = np.zeros(d, f32)
+        p['W1'] = u(self.n_items, 2 * d)
+        p['b1'] = u(self.n_items, 1)
+        return p
+
+    def _sample_batch(self, batch_size, **kwds):                          # caser.py:77-84
+        uids, before, after = [], [], []
+        for pos, targets, negs in self._sampler.sample_group_records(batch_size):
+            uids.append(int(pos[0]['uid']))
+            before.append([int(r['iid']) for r in pos])
+            after.append([int(r['iid']) for r in targets] + [int(x) for x in negs])
+        return uids, before, after
+
+    def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
+        uids, before, after = batch_samples
+        B = len(uids)
+        keep, rate = None, 0.0
+        if self.dropout_rate and self.dropout_rate > 0:
+            rate = float(self.dropout_rate)
+            nx = self.n_v + self.L * self.n_h
+            keep = self._dropout_mask_fn(step, B, nx) if self._dropout_mask_fn is not None \
+                else (self._drop_rng.random((B, nx)) >= rate)
+        return self._engine.step(step, np.asarray(uids), np.asarray(before), np.asarray(after), keep, rate,
+                                 want_loss=want_loss)
+
+    def _predict_batch(self, batch_samples, **kwds):
+        """Sigmoid scores of the batch's targets (caser.py:86-95, evaluation mode: no dropout)."""
+        import torch
+        uids, before, after = batch_samples
+        with self._device_lock:
+            sc = self._engine.scores_all(np.asarray(uids), np.asarray(before))
+        idx = torch.as_tensor(np.asarray(after), device=sc.device, dtype=torch.long)
+        preds = torch.sigmoid(torch.gather(sc, 1, idx))
+        desired = np.tile(np.array([1.] * self.T + [0.] * (self.T * self.neg_ratio), dtype=np.float32), (len(uids), 1))
+        return preds, desired
+
+    def _compute_batch_loss(self, predictions, desired_values, **kwds):
+        import torch
+        p = predictions.double()
+        t = torch.as_tensor(np.asarray(desired_values), dtype=torch.float64, device=p.device)
+        eps = 1e-7
+        pc = p.clamp(eps, 1 - eps)
+        return float((-(t * torch.log(pc + eps) + (1 - t) * torch.log(1 - pc + eps))).mean().item())
+
+    def _predict(self, uid, iid, **kwds):
+        raise NotImplementedError('This model does not support point-based predictions.')
+
+    def _user_sequence(self, uid):
+        if not hasattr(self, '_seq_ptr'):
+            ds = self.interaction_dataset
+            u = ds._cols['uid'].astype(np.int64)
+            key = ds._cols[self.sort_column] if self.sort_column in ds.columns else np.arange(len(u))
+            order = np.lexsort((np.arange(len(u)), key, u))           # by user, then sort column (stable)
+            self._seq_items = ds._cols['iid'][order].astype(np.int64)
+            self._seq_ptr = np.searchsorted(u[order], np.arange(self.n_users + 1))
+        return self._seq_items[self._seq_ptr[uid]:self._seq_ptr[uid + 1]]
+
+    def _rank(self, uid, iids, n, novelty):                               # caser.py:128-146
+        import torch
+        from ..engine import CdaeEngine, pack_mask_bits
+        seq = self._user_sequence(uid)
+        cand = np.zeros(self.n_items, dtype=bool)
+        cand[np.fromiter((int(i) for i in iids), dtype=np.int64)] = True
+        if novelty:
+            cand[seq] = False
+        k = min(int(n), int(cand.sum()))
+        if k <= 0:
+            return []
+        with self._device_lock:
+            sc = self._engine.scores_all(np.array([uid]), seq[-self.L:][None, :])
+            if not hasattr(self, '_topk_helper'):
+                self._topk_helper = CdaeEngine.__new__(CdaeEngine)
+                self._topk_helper.device = self._engine.device
+            mask = torch.as_tensor(pack_mask_bits(cand).view(np.int32)).to(sc.device)
+            idx, val = CdaeEngine.topk(self._topk_helper, sc, k, mask)
+            idx, val = idx[0].cpu().numpy(), val[0].cpu().numpy()
+        return [(float(v), int(i)) for v, i in zip(val, idx) if i >= 0]

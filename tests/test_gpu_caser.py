@@ -45,3 +45,49 @@ def test_caser_steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop):
     for r in range(5):
         want = ca.rank_scores(p, uids[r], before[r])
         assert np.max(np.abs(sc[r] - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))
+
+
+def test_caser_fit_matches_oracle_end_to_end():
+    """Caser.fit() with the reference-exact ListSampler stream and injected weights / dropout masks vs the oracle."""
+    from helpers import load_frames
+    from oracle import data_oracle as do
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import Caser
+    frame = {k: v.copy() for k, v in load_frames()['ls_int_ts'].items()}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    L, T, d, n_v, n_h, neg, B, epochs, seed = 5, 3, 16, 2, 4, 2, 24, 5, 10
+    uid, _ = do.first_appearance_codes(frame['user'].tolist())
+    iid, _ = do.first_appearance_codes(frame['item'].tolist())
+    U, N = int(uid.max()) + 1, int(iid.max()) + 1
+    p = ca.init_params(np.random.default_rng(1), U, N, L, d, n_v, n_h, np.float32)
+    nx = n_v + L * n_h
+    masks = [np.random.default_rng(100 + s).random((B, nx)) >= 0.5 for s in range(epochs)]
+    model = Caser(L=L, T=T, d=d, n_v=n_v, n_h=n_h, dropout_rate=0.5, seed=seed, verbose=False)
+    model.fit(ds, epochs=epochs, batch_size=B, learning_rate=5e-3, reg_rate=1e-5, neg_ratio=neg, initial_weights=p,
+              dropout_mask_fn=lambda s, b, n: masks[s])
+    # oracle side: reference ListSampler semantics restated on stdlib random
+    f = dict(frame)
+    f['uid'], f['iid'] = uid.astype(np.int16), iid.astype(np.int16)
+    smp = do.ListSamplerOracle(f, 'uid', neg_ratio=neg, n_targets=T, interaction_threshold=1e-3, sort_column='timestamp',
+                               min_positive_records=L, max_positive_records=L, seed=seed)
+    po = {k: v.astype(np.float64) for k, v in p.items()}
+    st = ca.adam_state(po)
+    for s in range(epochs):
+        recs = smp.sample_group_records(B)
+        uids = np.array([int(f['uid'][b[0]]) for b, _, _ in recs])
+        before = np.array([[int(f['iid'][r]) for r in b] for b, _, _ in recs])
+        after = np.array([[int(f['iid'][r]) for r in a] + ng for _, a, ng in recs])
+        ca.step(po, st, s, uids, before, after, T, 5e-3, 1e-5, masks[s], 0.5)
+    g = model._engine.get_params()
+    for k in po:
+        np.testing.assert_allclose(g[k], po[k], rtol=0, atol=3e-5, err_msg=k)
+    # rank(): all-item scores from the user's last L items, novelty removes the user's own items
+    u0 = 3
+    rows = np.flatnonzero(uid == u0)
+    seq = iid[rows][np.argsort(frame['timestamp'][rows], kind='stable')]
+    want_sc = ca.rank_scores(po, u0, seq[-L:])
+    raw_items = [ds.iid_to_item(i) for i in range(0, N, 3)]
+    got = model.rank(ds.uid_to_user(u0), raw_items, novelty=True, n=8)
+    from oracle import cdae_oracle as co
+    want = co.rank_row(want_sc.astype(np.float32), range(0, N, 3), 8, exclude=set(seq.tolist()))
+    assert [ds.item_to_iid(i) for _, i in got] == [i for _, i in want]
