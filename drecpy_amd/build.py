@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libdrx.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
-SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_sampler.hip', 'drx_shard.hip', 'drx_generic.hip', 'drx_caser.hip', 'drx_host.cpp']
+SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_sampler.hip', 'drx_shard.hip', 'drx_generic.hip', 'drx_caser.hip', 'drx_dmf.hip', 'drx_host.cpp']
 COMMON = ['-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
 

@@ -1,0 +1,263 @@
+// DMF (DRecPy/Recommender/dmf.py) forward / backward on gfx950, plus the bf16-MFMA all-pairs cosine scorer.
+//
+// One wavefront per (user, item, target) triple, lane k = hidden unit (layer widths <= 64).  The first Dense layer of
+// each tower acts on an l2-normalised sparse interaction row / column (dmf.py:75-86): it is an embedding bag over the
+// first-layer kernel rows (one coalesced row read per non-zero), not a [1,N]x[N,f] product.  Deeper layers are tiny
+// (64x32): activations are broadcast with wave shuffles, kernels read straight from L2.  Small-weight gradients are
+// accumulated per workgroup in LDS by their owning lane (fixed order, no atomics); the first-layer kernel gradient
+// leaves as (row key, sample, coefficient) touches + one dz0 row per sample for drx_scatter_rows.
+#include "drx_common.hpp"
+#include "drx_rows.hpp"
+
+namespace drx {
+
+constexpr float kL2NEps = 1e-12f;
+constexpr int kDmfMaxLayers = 4;
+
+struct TowerIO {
+  const float *K0;            // [rows, ld0] first-layer kernel
+  int ld0;
+  const int64_t *indptr;      // CSR (user tower) / CSC (item tower) of the interaction matrix, raw values
+  const int32_t *indices;
+  const float *values;
+  const int32_t *ids;         // [B] uid / iid
+  const int32_t *off;         // [B+1] touch offsets
+  float *dz0;                 // [B, ld0]
+  uint32_t *tkeys, *tsrc;     // [T] touches: first-layer row, sample
+  float *tcoef;               // [T] normalised input value
+};
+
+// Forward of one tower for sample b; returns the final activation of lane k.  z[l], a[l] keep pre/post activations.
+template <bool TRAIN>
+__device__ __forceinline__ float tower_fwd(const DrxDmfDims &D, int tw, const TowerIO &T, const float *sw, int b, int k,
+                                           float (&zs)[kDmfMaxLayers], float (&as)[kDmfMaxLayers], float &rho_in) {
+  const int nl = D.n_layers[tw];
+  const int id = T.ids[b];
+  const int64_t s = T.indptr[id], e = T.indptr[id + 1];
+  float q = 0.f;
+  for (int64_t j = s + k; j < e; j += 64) { const float v = T.values[j]; q = fmaf(v, v, q); }
+  q = group_sum<64>(q);
+  rho_in = D.l2_norm_vectors ? rsqrtf(fmaxf(q, kL2NEps)) : 1.0f;
+  const int f0 = D.f[tw][0];
+  float acc = 0.f;
+  const int base = TRAIN ? T.off[b] : 0;
+  for (int64_t c = s; c < e; c += 64) {            // lanes fetch 64 (index, value) pairs, then broadcast them
+    const int64_t j = c + k;
+    int idx = 0;
+    float v = 0.f;
+    if (j < e) {
+      idx = T.indices[j];
+      v = T.values[j] * rho_in;
+      if (TRAIN) { T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v; }
+    }
+    const int n_here = (int)((e - c) < 64 ? (e - c) : 64);
+    for (int t = 0; t < n_here; t += 4) {
+      const int i0 = __shfl(idx, t), i1 = __shfl(idx, t + 1), i2 = __shfl(idx, t + 2), i3 = __shfl(idx, t + 3);
+      const float v0 = __shfl(v, t), v1 = __shfl(v, t + 1), v2 = __shfl(v, t + 2), v3 = __shfl(v, t + 3);
+      const bool ok = k < f0;
+      const float r0 = ok ? T.K0[(size_t)i0 * T.ld0 + k] : 0.f;
+      const float r1 = (ok && t + 1 < n_here) ? T.K0[(size_t)i1 * T.ld0 + k] : 0.f;
+      const float r2 = (ok && t + 2 < n_here) ? T.K0[(size_t)i2 * T.ld0 + k] : 0.f;
+      const float r3 = (ok && t + 3 < n_here) ? T.K0[(size_t)i3 * T.ld0 + k] : 0.f;
+      acc = fmaf(v0, r0, acc);
+      acc = fmaf(t + 1 < n_here ? v1 : 0.f, r1, acc);
+      acc = fmaf(t + 2 < n_here ? v2 : 0.f, r2, acc);
+      acc = fmaf(t + 3 < n_here ? v3 : 0.f, r3, acc);
+    }
+  }
+  float z = k < f0 ? acc + sw[D.off_b[tw][0] + k] : 0.f;
+  float a = fmaxf(z, 0.f);
+  zs[0] = z; as[0] = a;
+#pragma unroll
+  for (int l = 1; l < kDmfMaxLayers; ++l) {
+    if (l >= nl) break;
+    const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
+    float zz = k < fo ? sw[D.off_b[tw][l] + k] : 0.f;
+    for (int j = 0; j < fin; ++j) {
+      const float aj = __shfl(a, j);
+      if (k < fo) zz = fmaf(aj, sw[D.off_k[tw][l] + j * fo + k], zz);
+    }
+    z = zz; a = fmaxf(zz, 0.f);
+    zs[l] = z; as[l] = a;
+  }
+  return a;
+}
+
+// Backward of one tower given dr = dL/d(final activation) on lane k; accumulates small-weight gradients in LDS.
+__device__ __forceinline__ void tower_bwd(const DrxDmfDims &D, int tw, const TowerIO &T, const float *sw, float *gsw, int b, int k,
+                                          const float (&zs)[kDmfMaxLayers], const float (&as)[kDmfMaxLayers], float da) {
+  const int nl = D.n_layers[tw];
+#pragma unroll
+  for (int l = kDmfMaxLayers - 1; l >= 1; --l) {
+    if (l >= nl) continue;
+    const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
+    const float dz = (k < fo && zs[l] > 0.f) ? da : 0.f;
+    if (k < fo) gsw[D.off_b[tw][l] + k] += dz;
+    float dprev = 0.f;
+    for (int j = 0; j < fin; ++j) {
+      const float aj = __shfl(as[l - 1], j);
+      if (k < fo) { const int w = D.off_k[tw][l] + j * fo + k; gsw[w] = fmaf(aj, dz, gsw[w]); }
+    }
+    // da_{l-1}[j] = sum_k dz[k] * K[j][k] : lane j walks its kernel row
+    for (int kk = 0; kk < fo; ++kk) {
+      const float dzk = __shfl(dz, kk);
+      if (k < fin) dprev = fmaf(dzk, sw[D.off_k[tw][l] + k * fo + kk], dprev);
+    }
+    da = dprev;
+  }
+  const int f0 = D.f[tw][0];
+  const float dz0 = (k < f0 && zs[0] > 0.f) ? da : 0.f;
+  if (k < f0) gsw[D.off_b[tw][0] + k] += dz0;
+  if (k < T.ld0) T.dz0[(size_t)b * T.ld0 + k] = k < f0 ? dz0 : 0.f;
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(64) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
+  extern __shared__ __align__(16) float gsw[];       // [n_small] (TRAIN)
+  const int k = threadIdx.x;
+  if (TRAIN)
+    for (int i = k; i < D.n_small; i += 64) gsw[i] = 0.f;
+  TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
+  TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
+  float loss_acc = 0.f;
+  const float inv_b = 1.0f / (float)A.B;
+  __syncthreads();
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
+    float zu[kDmfMaxLayers], au[kDmfMaxLayers], zi[kDmfMaxLayers], ai[kDmfMaxLayers];
+    float rin_u, rin_i;
+    const float ru = tower_fwd<TRAIN>(D, 0, Tu, A.sw, b, k, zu, au, rin_u);
+    const float ri = tower_fwd<TRAIN>(D, 1, Ti, A.sw, b, k, zi, ai, rin_i);
+    const float qu = group_sum<64>(ru * ru), qi = group_sum<64>(ri * ri);
+    const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
+    const float nu = ru * rhou, ni = ri * rhoi;
+    const float s = group_sum<64>(nu * ni);
+    const float pred = fmaxf(1e-6f, s);
+    if (!TRAIN) {
+      if (k == 0 && A.pred_out) A.pred_out[b] = pred;
+      if (A.rep_u_out) A.rep_u_out[(size_t)b * 64 + k] = nu;       // l2-normalised representations (zero beyond f_last)
+      if (A.rep_i_out) A.rep_i_out[(size_t)b * 64 + k] = ni;
+      continue;
+    }
+    const float y = A.y[b];
+    loss_acc += bce_elem(y, pred);
+    const float ds = s > 1e-6f ? bce_grad(y, pred) * inv_b : 0.f;
+    // l2_normalize backward (tf.nn.l2_normalize: x * rsqrt(max(sum x^2, eps)))
+    const float dnu = ds * ni, dni = ds * nu;
+    const float du = group_sum<64>(nu * dnu), di = group_sum<64>(ni * dni);
+    const float dru = qu > kL2NEps ? rhou * (dnu - nu * du) : rhou * dnu;
+    const float dri = qi > kL2NEps ? rhoi * (dni - ni * di) : rhoi * dni;
+    tower_bwd(D, 0, Tu, A.sw, gsw, b, k, zu, au, dru);
+    tower_bwd(D, 1, Ti, A.sw, gsw, b, k, zi, ai, dri);
+  }
+  if (TRAIN) {
+    __syncthreads();
+    for (int i = k; i < D.n_small; i += 64) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = gsw[i];
+    if (k == 0) A.loss_part[blockIdx.x] = loss_acc * inv_b;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_partials2(const float *__restrict__ part, int n_rows, int n, const float *__restrict__ tail,
+                                                          float *__restrict__ out) {
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j <= n; j += gridDim.x * kBlock) {
+    float a = 0.f;
+    if (j < n) for (int r = 0; r < n_rows; ++r) a += part[(size_t)r * n + j];
+    else for (int r = 0; r < n_rows; ++r) a += tail[r];
+    out[j] = a;
+  }
+}
+
+// ---- bf16 MFMA all-pairs cosine scorer: out[u, n] = max(1e-6, ru[u] . ri[n]) for l2-normalised fp32 rows of width 32 -------
+// One wave per 32x32 tile, two v_mfma_f32_32x32x16_bf16 (K = 32).  A = users (row r = lane & 31, k = 8*(lane >> 5) + j),
+// B = items (col r, same k); C/D: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ short f2bf(float x) {
+  union { float f; uint32_t u; } c; c.f = x;
+  return (short)((c.u + 0x7FFFu + ((c.u >> 16) & 1u)) >> 16);      // round-to-nearest-even (inputs are finite, |x| <= 1)
+}
+
+__global__ __launch_bounds__(64) void k_score_pairs_bf16(const float *__restrict__ ru, int n_u, const float *__restrict__ ri, int n_i,
+                                                         int ld, int kdim, float *__restrict__ out) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int u0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int ks = 0; ks < kdim / 16; ++ks) {
+    bf16x8 a, bb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = ks * 16 + 8 * h + j;
+      a[j] = (u0 + r < n_u) ? f2bf(ru[(size_t)(u0 + r) * ld + kk]) : (short)0;
+      bb[j] = (i0 + r < n_i) ? f2bf(ri[(size_t)(i0 + r) * ld + kk]) : (short)0;
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (u0 + row < n_u && i0 + r < n_i) out[(size_t)(u0 + row) * n_i + i0 + r] = fmaxf(1e-6f, acc[reg]);
+  }
+}
+
+static int check_dims(const DrxDmfDims *D) {
+  if (!D || D->n_small < 1) return DRX_EINVAL;
+  for (int tw = 0; tw < 2; ++tw) {
+    if (D->n_layers[tw] < 1 || D->n_layers[tw] > kDmfMaxLayers) return DRX_EINVAL;
+    for (int l = 0; l < D->n_layers[tw]; ++l)
+      if (D->f[tw][l] < 1 || D->f[tw][l] > 64) return DRX_EINVAL;
+    if (D->ld0[tw] < D->f[tw][0] || (D->ld0[tw] & 3) || D->ld0[tw] > 64) return DRX_EINVAL;
+  }
+  return (size_t)D->n_small * 4 <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
+}
+
+}  // namespace drx
+
+using namespace drx;
+
+extern "C" {
+
+int drx_dmf_grid(int32_t B) { return B < 1024 ? B : 1024; }
+
+int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream) {
+  int rc = check_dims(D);
+  if (rc) return rc;
+  if (!A || !A->K0u || !A->K0i || !A->sw || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices ||
+      !A->i_values || !A->uid || !A->iid || !A->y || !A->off_u || !A->off_i || !A->dz0u || !A->dz0i || !A->tkeys_u ||
+      !A->tsrc_u || !A->tcoef_u || !A->tkeys_i || !A->tsrc_i || !A->tcoef_i || !A->gsw_part || !A->loss_part || !gsw_out ||
+      A->B < 1)
+    return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = drx_dmf_grid(A->B);
+  const size_t lds = (size_t)D->n_small * 4;
+  if (lds > 48 * 1024)
+    DRX_HIP(hipFuncSetAttribute((const void *)k_dmf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_dmf<true>, dim3(grid), dim3(64), lds, st, *D, *A);
+  hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + kBlock) / kBlock), dim3(kBlock), 0, st, A->gsw_part, grid, D->n_small,
+                     A->loss_part, gsw_out);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream) {
+  int rc = check_dims(D);
+  if (rc) return rc;
+  if (!A || !A->K0u || !A->K0i || !A->sw || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices ||
+      !A->i_values || !A->uid || !A->iid || A->B < 1 || (!A->pred_out && !A->rep_u_out && !A->rep_i_out))
+    return DRX_EINVAL;
+  hipLaunchKernelGGL(k_dmf<false>, dim3(A->B < 4096 ? A->B : 4096), dim3(64), 0, (hipStream_t)stream, *D, *A);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim, float *out,
+                         void *stream) {
+  if (!ru || !ri || !out || n_u < 1 || n_i < 1 || kdim < 16 || (kdim & 15) || ld < kdim) return DRX_EINVAL;
+  hipLaunchKernelGGL(k_score_pairs_bf16, dim3((n_i + 31) / 32, (n_u + 31) / 32), dim3(64), 0, (hipStream_t)stream, ru, n_u, ri, n_i,
+                     ld, kdim, out);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""Device-side state of one DMF model and the calls into libdrx.so (drx_dmf_*, drx_scatter_rows, drx_adam_*,
+drx_score_pairs_bf16).
+
+One training step = the body of the reference fit() loop for DMF (recommender_abc.py:190-204 over dmf.py:64-99):
+  drx_dmf_fwd_bwd       both towers, cosine, clip, Keras BCE, backward -> dz0 rows + first-layer touches + small grads
+  drx_scatter_rows x2   first-layer kernel gradients (embedding-bag backward), deterministic
+  drx_adam_dense x2     Keras l2 + Adam on the two first-layer kernels (user_nn t = 2s+1, item_nn t = 2s+2)
+  drx_adam_segments     deeper kernels and all biases
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AdamSegments, DmfArgs, DmfDims, check, lib, ptr, stream_ptr
+from .engine import ADAM_B1, ADAM_B2, ADAM_EPS, CdaeEngine, _round_up
+
+
+class DmfEngine:
+    def __init__(self, n_users, n_items, user_factors=(64, 32), item_factors=(64, 32), l2_norm_vectors=True, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise _lib.DrxError('drecpy_amd needs a ROCm GPU (MI355X); there is no CPU fallback.')
+        lib()
+        self.device = torch.device(device)
+        self.U, self.N = n_users, n_items
+        self.factors = [list(user_factors), list(item_factors)]
+        assert all(1 <= len(f) <= 4 and max(f) <= 64 for f in self.factors), 'DMF engine: <= 4 layers of width <= 64'
+        D = DmfDims()
+        self.seg = []                      # (name, start, len, regularised, tower)
+        off = 0
+        for tw, pre in ((0, 'u'), (1, 'i')):
+            f = self.factors[tw]
+            D.n_layers[tw] = len(f)
+            D.ld0[tw] = _round_up(f[0], 4)
+            for l, fl in enumerate(f):
+                D.f[tw][l] = fl
+                if l >= 1:
+                    D.off_k[tw][l] = off
+                    self.seg.append((f'{pre}{l}_k', off, f[l - 1] * fl, True, tw)); off += _round_up(f[l - 1] * fl, 4)
+                D.off_b[tw][l] = off
+                self.seg.append((f'{pre}{l}_b', off, fl, False, tw)); off += _round_up(fl, 4)
+        D.n_small = off
+        D.l2_norm_vectors = 1 if l2_norm_vectors else 0
+        self.D = D
+        z = dict(dtype=torch.float32, device=self.device)
+        self.K0u = torch.zeros(n_items, D.ld0[0], **z)
+        self.K0i = torch.zeros(n_users, D.ld0[1], **z)
+        self.sw = torch.zeros(off, **z)
+        self.state = {n: (torch.zeros_like(t), torch.zeros_like(t)) for n, t in self.tensors().items()}
+        self._g = {'K0u': torch.zeros_like(self.K0u), 'K0i': torch.zeros_like(self.K0i)}
+        self._scratch = None
+        self.lr, self.reg = 1e-3, 1e-3
+
+    def tensors(self):
+        return {'K0u': self.K0u, 'K0i': self.K0i, 'sw': self.sw}
+
+    def set_interactions(self, csr, csc):
+        """csr / csc = (indptr int64, indices, values) of the [U,N] interaction matrix and of its transpose, raw values."""
+        d = self.device
+        mk = lambda t: (torch.as_tensor(np.asarray(t[0], np.int64)).to(d), torch.as_tensor(np.asarray(t[1], np.int32)).to(d),
+                        torch.as_tensor(np.asarray(t[2], np.float32)).to(d))
+        self.csr, self.csc = mk(csr), mk(csc)
+
+    def set_params(self, p):
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
+        for x in self.tensors().values():
+            x.zero_()
+        self.K0u[:, :self.factors[0][0]] = t(p['u0_k'])
+        self.K0i[:, :self.factors[1][0]] = t(p['i0_k'])
+        for name, start, n, _, _ in self.seg:
+            self.sw[start:start + n] = t(p[name]).reshape(-1)
+
+    def get_params(self):
+        c = lambda x: x.detach().cpu().numpy().copy()
+        p = {'u0_k': c(self.K0u[:, :self.factors[0][0]]), 'i0_k': c(self.K0i[:, :self.factors[1][0]])}
+        for name, start, n, _, tw in self.seg:
+            v = c(self.sw[start:start + n])
+            if name.endswith('_k'):
+                l = int(name[1])
+                v = v.reshape(self.factors[tw][l - 1], self.factors[tw][l])
+            p[name] = v
+        return p
+
+    def snapshot(self):
+        return {'p': {n: t.clone() for n, t in self.tensors().items()}}
+
+    def restore(self, snap, with_optimizer=False):
+        for n, t in self.tensors().items():
+            t.copy_(snap['p'][n])
+
+    def _i32(self, a):
+        if torch.is_tensor(a):
+            return a.to(self.device, torch.int32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    def _base_args(self, uid, iid):
+        A = DmfArgs()
+        A.K0u, A.K0i, A.sw = self.K0u.data_ptr(), self.K0i.data_ptr(), self.sw.data_ptr()
+        A.u_indptr, A.u_indices, A.u_values = (t.data_ptr() for t in self.csr)
+        A.i_indptr, A.i_indices, A.i_values = (t.data_ptr() for t in self.csc)
+        A.uid, A.iid, A.B = uid.data_ptr(), iid.data_ptr(), int(uid.numel())
+        return A
+
+    def _offsets(self, ids, indptr):
+        deg = indptr[ids.long() + 1] - indptr[ids.long()]
+        off = torch.zeros(ids.numel() + 1, dtype=torch.int32, device=self.device)
+        off[1:] = torch.cumsum(deg, 0).to(torch.int32)
+        return off, int(off[-1].item())
+
+    def _scatter(self, keys, T, src, src_index, coef, ld, n_rows, out):
+        out.zero_()
+        if T == 0:
+            return
+        need = lib().drx_scatter_scratch_bytes(ld, T, n_rows)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(int(need * 1.2) + 1024, dtype=torch.uint8, device=self.device)
+        check(lib().drx_scatter_rows(ptr(keys), T, ptr(src), ptr(src_index), ptr(coef), None, ld, n_rows, ptr(out), None,
+                                     ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
+
+    def step(self, step_idx, uids, iids, y, want_loss=False):
+        L_ = lib()
+        uid, iid = self._i32(uids), self._i32(iids)
+        yv = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(self.device)
+        B = uid.numel()
+        z = dict(dtype=torch.float32, device=self.device)
+        off_u, Tu = self._offsets(uid, self.csr[0])
+        off_i, Ti = self._offsets(iid, self.csc[0])
+        ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
+        dz0u, dz0i = torch.empty(B, ld0u, **z), torch.empty(B, ld0i, **z)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        tk_u, ts_u, tc_u = torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **z)
+        tk_i, ts_i, tc_i = torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **z)
+        grid = L_.drx_dmf_grid(B)
+        gpart, lpart = torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z)
+        gsw = torch.empty(self.D.n_small + 1, **z)
+        A = self._base_args(uid, iid)
+        A.y, A.off_u, A.off_i = yv.data_ptr(), off_u.data_ptr(), off_i.data_ptr()
+        A.dz0u, A.dz0i = dz0u.data_ptr(), dz0i.data_ptr()
+        A.tkeys_u, A.tsrc_u, A.tcoef_u = tk_u.data_ptr(), ts_u.data_ptr(), tc_u.data_ptr()
+        A.tkeys_i, A.tsrc_i, A.tcoef_i = tk_i.data_ptr(), ts_i.data_ptr(), tc_i.data_ptr()
+        A.gsw_part, A.loss_part = gpart.data_ptr(), lpart.data_ptr()
+        reg_loss = None
+        if want_loss:
+            sq = (self.K0u ** 2).sum() + (self.K0i ** 2).sum()
+            for _, start, n, regd, _ in self.seg:
+                if regd:
+                    sq = sq + (self.sw[start:start + n] ** 2).sum()
+            reg_loss = self.reg * sq
+        check(L_.drx_dmf_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream_ptr(self.device)), 'drx_dmf_fwd_bwd')
+        self._scatter(tk_u, Tu, dz0u, ts_u, tc_u, ld0u, self.N, self._g['K0u'])
+        self._scatter(tk_i, Ti, dz0i, ts_i, tc_i, ld0i, self.U, self._g['K0i'])
+        alpha = [CdaeEngine.adam_alpha(self.lr, 2 * step_idx + j + 1) for j in range(2)]
+        l2c = 2.0 * self.reg
+        for name, tw in (('K0u', 0), ('K0i', 1)):
+            p = self.tensors()[name]
+            m, v = self.state[name]
+            check(L_.drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(self._g[name]), p.numel(), alpha[tw], l2c, ADAM_B1, ADAM_B2,
+                                    ADAM_EPS, stream_ptr(self.device)), 'drx_adam_dense')
+        sg = AdamSegments()
+        sg.n = len(self.seg)
+        for i, (_, start, n, regd, tw) in enumerate(self.seg):
+            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[tw], (l2c if regd else 0.0)
+        m, v = self.state['sw']
+        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), ADAM_B1, ADAM_B2, ADAM_EPS,
+                                   stream_ptr(self.device)), 'drx_adam_segments')
+        if want_loss:
+            return float((gsw[-1] + reg_loss).item())
+        return None
+
+    def predict(self, uids, iids, want_reps=False):
+        """max(1e-6, cosine) for each (uid, iid) pair (dmf.py:88-96); optionally the normalised tower outputs [B,64]."""
+        uid, iid = self._i32(uids), self._i32(iids)
+        B = uid.numel()
+        pred = torch.empty(B, dtype=torch.float32, device=self.device)
+        A = self._base_args(uid, iid)
+        A.pred_out = pred.data_ptr()
+        ru = ri = None
+        if want_reps:
+            ru = torch.empty(B, 64, dtype=torch.float32, device=self.device)
+            ri = torch.empty(B, 64, dtype=torch.float32, device=self.device)
+            A.rep_u_out, A.rep_i_out = ru.data_ptr(), ri.data_ptr()
+        check(lib().drx_dmf_predict(C.byref(self.D), C.byref(A), stream_ptr(self.device)), 'drx_dmf_predict')
+        return (pred, ru, ri) if want_reps else pred
+
+    def score_matrix_bf16(self, uids):
+        """[len(uids), N] cosine scores of the given users against ALL items on the matrix cores (bf16 operands)."""
+        uid = self._i32(uids)
+        n_u = uid.numel()
+        all_items = torch.arange(self.N, dtype=torch.int32, device=self.device)
+        _, _, ri = self.predict(torch.zeros(self.N, dtype=torch.int32, device=self.device), all_items, want_reps=True)
+        _, ru, _ = self.predict(uid, torch.zeros(n_u, dtype=torch.int32, device=self.device), want_reps=True)
+        out = torch.empty(n_u, self.N, dtype=torch.float32, device=self.device)
+        kdim = _round_up(self.factors[0][-1], 16)
+        check(lib().drx_score_pairs_bf16(ptr(ru), n_u, ptr(ri), self.N, 64, kdim, ptr(out), stream_ptr(self.device)),
+              'drx_score_pairs_bf16')
+        return out

@@ -247,6 +247,45 @@ int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_o
 /* inference hidden state cat_out[b] = [dense_0 output | user embedding] (caser.py:97-115 with training=False) */
 int drx_caser_hidden(const DrxCaserDims *D, const DrxCaserArgs *A, void *stream);
 
+/* ---- DMF (DRecPy/Recommender/dmf.py) ---------------------------------------------------------------------------
+ * Tower 0 = user_nn (input: the user's interaction ROW over items), tower 1 = item_nn (input: the item's COLUMN over
+ * users), both l2-normalised when l2_norm_vectors (dmf.py:75-86).  First-layer kernels K0u [n_items, ld0[0]] and
+ * K0i [n_users, ld0[1]] are tables; every other weight lives in one flat array `sw`: layer l >= 1 kernel [f[l-1]][f[l]]
+ * at off_k[tw][l], layer l >= 0 bias [f[l]] at off_b[tw][l].  Layer widths <= 64, <= 4 layers per tower. */
+typedef struct DrxDmfDims {
+  int32_t n_layers[2];
+  int32_t f[2][4];
+  int32_t ld0[2];
+  int32_t off_k[2][4], off_b[2][4];
+  int32_t n_small;
+  int32_t l2_norm_vectors;
+} DrxDmfDims;
+typedef struct DrxDmfArgs {
+  const float *K0u, *K0i, *sw;
+  const int64_t *u_indptr; const int32_t *u_indices; const float *u_values;   /* CSR [U, N], raw interaction values */
+  const int64_t *i_indptr; const int32_t *i_indices; const float *i_values;   /* CSC (= CSR of the transpose) [N, U] */
+  const int32_t *uid, *iid;  /* [B] */
+  const float *y;            /* [B] targets (standardised when use_nce, dmf.py:69) */
+  const int32_t *off_u, *off_i;   /* [B+1] prefix sums of the row / column lengths of the batch */
+  int32_t B;
+  float *dz0u, *dz0i;        /* [B, ld0] gradient wrt the first-layer pre-activation */
+  uint32_t *tkeys_u, *tsrc_u; float *tcoef_u;   /* [off_u[B]] first-layer touches: kernel row, sample, input value */
+  uint32_t *tkeys_i, *tsrc_i; float *tcoef_i;   /* [off_i[B]] */
+  float *gsw_part, *loss_part;                  /* [drx_dmf_grid(B), n_small], [drx_dmf_grid(B)] */
+  float *pred_out;           /* [B]      (drx_dmf_predict) max(1e-6, cosine) */
+  float *rep_u_out, *rep_i_out;   /* [B, 64] (drx_dmf_predict, optional) l2-normalised tower outputs */
+} DrxDmfArgs;
+int drx_dmf_grid(int32_t B);
+/* forward + Keras BCE + backward (dmf.py:88-99 under the tape): dz0 rows + touches for drx_scatter_rows,
+ * gsw_out[0..n_small) small-weight gradients, gsw_out[n_small] = prediction loss */
+int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream);
+int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream);
+/* all-pairs cosine scores on the matrix cores: out[u, n] = max(1e-6, ru[u,:kdim] . ri[n,:kdim]) with bf16 operands /
+ * fp32 accumulation (v_mfma_f32_32x32x16_bf16); ru, ri = l2-normalised tower outputs, kdim % 16 == 0 (dmf.py:92-95
+ * evaluated for a block of users against all items instead of one _predict per pair, recommender_abc.py:460). */
+int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim, float *out,
+                         void *stream);
+
 /* ---- ranking (cdae.py:90-103, recommender_abc.py:454-461) --------------------------------
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with
  * cand_mask == NULL || bit (r*n + i) set; order = descending score, ties by larger index
