@@ -1,6 +1,7 @@
 from .recommender_abc import RecommenderABC
 from .cdae import CDAE
 from .caser import Caser
+from .dmf import DMF
 from .early_stopping import EarlyStoppingRuleABC, MaxValidationValueRule
 
-__all__ = ['RecommenderABC', 'CDAE', 'Caser', 'EarlyStoppingRuleABC', 'MaxValidationValueRule']
+__all__ = ['RecommenderABC', 'CDAE', 'Caser', 'DMF', 'EarlyStoppingRuleABC', 'MaxValidationValueRule']

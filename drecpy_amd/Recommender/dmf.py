@@ -1,0 +1,100 @@
+"""DMF (Deep Matrix Factorization) on the MI355X engine — constructor, hooks and semantics of
+DRecPy/Recommender/dmf.py; arithmetic in drx_dmf.hip / drx_generic.hip behind include/drx.h.
+
+Reference behaviour kept: PointSampler triples, inputs = RAW interaction row / column l2-normalised (dmf.py:75-86),
+targets standardised to [0,1] when use_nce with min_interaction forced to 0 when the data minimum is 1
+(recommender_abc.py:141,463-465), cosine clipped at 1e-6, Keras BCE, l2(reg_rate) on the Dense kernels, dense Keras Adam
+with one apply per tower per step, `_predict` rescaled to the interaction range (dmf.py:101-106).
+Additions: `_rank` scores all candidates of a user in ONE launch instead of one `_predict` per item
+(recommender_abc.py:460), and `score_matrix(user_ids)` scores users against all items on the matrix cores (bf16).
+"""
+from heapq import nlargest
+
+import numpy as np
+
+from .recommender_abc import RecommenderABC
+from ..Sampler import PointSampler
+
+
+class DMF(RecommenderABC):
+    def __init__(self, user_factors=None, item_factors=None, use_nce=True, l2_norm_vectors=True, device='cuda:0', **kwds):
+        super().__init__(**kwds)
+        self.user_factors = [64, 32] if user_factors is None else user_factors
+        assert type(self.user_factors) is list, 'The "user_factors" argument must be of type list (ex: [64, 32]).'
+        assert len(self.user_factors) > 0, 'The "user_factors" argument must have at least 1 element.'
+        self.item_factors = [64, 32] if item_factors is None else item_factors
+        assert type(self.item_factors) is list, 'The "item_factors" argument must be of type list (ex: [64, 32]).'
+        assert len(self.item_factors) > 0, 'The "item_factors" argument must have at least 1 element.'
+        assert self.user_factors[-1] == self.item_factors[-1], \
+            f'The last user and item factors dimension must be equal ({self.user_factors[-1]} != {self.item_factors[-1]})'
+        self.use_nce = use_nce
+        self.l2_norm_vectors = l2_norm_vectors
+        self.device = device
+
+    def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):          # dmf.py:46-62
+        from ..engine_dmf import DmfEngine
+        ds = self.interaction_dataset
+        self._engine = DmfEngine(self.n_users, self.n_items, self.user_factors, self.item_factors, self.l2_norm_vectors,
+                                 device=self.device)
+        self._engine.lr, self._engine.reg = float(learning_rate), float(reg_rate)
+        self._engine.set_interactions(ds.interaction_csr(), ds.interaction_csr(transpose=True))
+        weights = kwds.get('initial_weights')
+        if weights is None:
+            weights = self._keras_init(np.random.default_rng(self.seed))
+        self._engine.set_params(weights)
+        self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
+
+    def _keras_init(self, rng):
+        p = {}
+        for tower, n_in, factors in (('u', self.n_items, self.user_factors), ('i', self.n_users, self.item_factors)):
+            prev = n_in
+            for l, f in enumerate(factors):
+                lim = np.sqrt(6.0 / (prev + f))
+                p[f'{tower}{l}_k'] = rng.uniform(-lim, lim, size=(prev, f)).astype(np.float32)
+                p[f'{tower}{l}_b'] = np.zeros(f, np.float32)
+                prev = f
+        return p
+
+    def _sample_batch(self, batch_size, **kwds):                          # dmf.py:64-73
+        u, i, v, _ = self._sampler.sample_arrays(batch_size)
+        y = self._standardize_value(v) if self.use_nce else v
+        return u, i, np.asarray(y, dtype=np.float32)
+
+    def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
+        u, i, y = batch_samples
+        return self._engine.step(step, u, i, y, want_loss=want_loss)
+
+    def _predict_batch(self, batch_samples, **kwds):
+        u, i, y = batch_samples
+        with self._device_lock:
+            return self._engine.predict(u, i), y
+
+    def _compute_batch_loss(self, predictions, desired_values, **kwds):
+        import torch
+        p = predictions.double()
+        t = torch.as_tensor(np.asarray(desired_values), dtype=torch.float64, device=p.device)
+        eps = 1e-7
+        pc = p.clamp(eps, 1 - eps)
+        return float((-(t * torch.log(pc + eps) + (1 - t) * torch.log(1 - pc + eps))).mean().item())
+
+    def _predict(self, uid, iid, **kwds):                                 # dmf.py:101-106
+        with self._device_lock:
+            p = float(self._engine.predict(np.array([uid]), np.array([iid]))[0].item())
+        return self._rescale_value(p)
+
+    def _rank(self, uid, iids, n, novelty):
+        if novelty:
+            rated = self.interaction_dataset.select(f'uid == {uid}').values_list('iid', to_list=True)
+            iids = set(iids).difference(set(rated))
+        iids = sorted(set(int(i) for i in iids))
+        if not iids:
+            return []
+        with self._device_lock:
+            preds = self._engine.predict(np.full(len(iids), uid), np.asarray(iids)).cpu().numpy()
+        return nlargest(n, [(self._rescale_value(float(p)), i) for p, i in zip(preds, iids)])
+
+    def score_matrix(self, user_ids):
+        """[len(user_ids), n_items] clipped cosine scores via the bf16 MFMA scorer (raw user ids in)."""
+        uids = [self.interaction_dataset.user_to_uid(u) for u in user_ids]
+        with self._device_lock:
+            return self._engine.score_matrix_bf16(np.asarray(uids))

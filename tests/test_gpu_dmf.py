@@ -79,3 +79,43 @@ def test_mfma_bf16_all_pairs_scorer():
     _lib.check(_lib.lib().drx_score_pairs_bf16(_lib.ptr(a), 70, _lib.ptr(b), 45, 64, 32, _lib.ptr(out), _lib.stream_ptr()), 'score')
     want = torch.clamp(a[:, :32] @ b[:, :32].t(), min=1e-6)
     assert torch.equal(out, want)
+
+
+def test_dmf_fit_matches_oracle_end_to_end():
+    """DMF.fit() with the reference-exact PointSampler stream and injected weights vs the oracle."""
+    from helpers import load_frames
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import DMF
+    frame = {k: v.copy() for k, v in load_frames()['pt_int_dense'].items()}     # 64 users x 40 items, values 0..5
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    uid, _ = do.first_appearance_codes(frame['user'].tolist())
+    iid, _ = do.first_appearance_codes(frame['item'].tolist())
+    U, N = int(uid.max()) + 1, int(iid.max()) + 1
+    p = dm.init_params(np.random.default_rng(2), U, N, (16, 8), (16, 8), np.float32)
+    epochs, B, seed = 8, 32, 10
+    model = DMF(user_factors=[16, 8], item_factors=[16, 8], seed=seed, verbose=False)
+    model.fit(ds, epochs=epochs, batch_size=B, learning_rate=2e-3, reg_rate=1e-3, neg_ratio=3, initial_weights=p)
+    # oracle: same sampler stream (stdlib random restatement), standardised targets (min 0, max 5)
+    dense = np.zeros((U, N))
+    np.add.at(dense, (uid, iid), frame['interaction'].astype(np.float64))
+    smp = do.PointSamplerOracle(uid, iid, frame['interaction'], 3, 1e-3, seed)
+    po = {k: v.astype(np.float64) for k, v in p.items()}
+    st = dm.adam_state(po)
+    mn, mx = float(frame['interaction'].min()), float(frame['interaction'].max())
+    mn = 0.0 if mn == 1 else mn
+    for s in range(epochs):
+        batch = smp.sample(B)
+        u = np.array([t[0] for t in batch]); i = np.array([t[1] for t in batch])
+        y = (np.array([float(t[2]) for t in batch]) - mn) / (mx - mn)
+        dm.step(po, st, s, dense[u], dense[:, i].T.copy(), y.astype(np.float32).astype(np.float64), 2e-3, 1e-3, 2, 2)
+    g = model._engine.get_params()
+    for k in po:
+        np.testing.assert_allclose(g[k], po[k], rtol=0, atol=3e-5, err_msg=k)
+    raw_u, raw_i = frame['user'][0], frame['item'][5]
+    u0, i0 = ds.user_to_uid(raw_u), ds.item_to_iid(raw_i)
+    want, _ = dm.forward(po, dense[u0:u0 + 1], dense[:, i0:i0 + 1].T.copy(), 2, 2)
+    assert abs(model.predict(raw_u, raw_i) - (mn + (mx - mn) * want[0])) < 1e-4
+    ranked = model.rank(raw_u, [ds.iid_to_item(j) for j in range(N)], novelty=True, n=5)
+    assert len(ranked) == 5 and all(ranked[j][0] >= ranked[j + 1][0] for j in range(4))
+    sm = model.score_matrix([raw_u]).cpu().numpy()
+    assert sm.shape == (1, N)
