@@ -223,8 +223,38 @@ def main():
         p_, r_ = vals['Precision'], vals['Recall']
         vals['FScore'] = FScore()(recs, k=kk, relevant_recommendations=rel) if (p_ + r_) > 0 else None
         mcases.append({'recs': recs, 'rel': rel, 'relv': {str(a): b for a, b in relv.items()}, 'k': kk, 'vals': vals})
+    # recommendation_evaluation (examples/caser.py:17-18 protocol) with a recommend()-capable fake model
+    from DRecPy.Evaluation.Processes import recommendation_evaluation
+
+    class FakeRec(FakeModel):
+        def recommend(self, user_id, n=None, novelty=True, interaction_threshold=None, **kw):
+            ds = self.interaction_dataset
+            items = [ds.iid_to_item(i) for i in range(self.n_items)]
+            ranked = self.rank(user_id, items, novelty=novelty)
+            if interaction_threshold is not None:
+                ranked = [x for x in ranked if x[0] >= interaction_threshold]
+            return ranked[:n]
+    fr = FakeRec(ds_tr)
+    rec_out = []
+    for c in (dict(k=[1, 5, 10], novelty=True, seed=10), dict(k=3, n_pos_interactions=2, seed=1),
+              dict(k=[2, 4], novelty=False, ignore_low_predictions_threshold=0.5, n_test_users=20)):
+        mets = [AveragePrecision(), Precision(), Recall()] if 'novelty' in c and c.get('seed') == 10 else None
+        kw = dict(c)
+        if mets is not None:
+            kw['metrics'] = mets
+        rec_out.append({'cfg': c, 'caser_metrics': mets is not None, 'result': recommendation_evaluation(fr, ds_te, verbose=False, **kw)})
+    # leave_k_out on a frame with timestamps
+    from DRecPy.Evaluation.Splits import leave_k_out
+    lko = []
+    fr3 = frames['ls_int_ts']
+    for c in (dict(k=2, seed=10), dict(k=0.2, last_timestamps=True, seed=0), dict(k=3, min_user_interactions=40, seed=5),
+              dict(k=0.1, seed=3)):
+        d_tr, d_te = leave_k_out(InteractionDataset.read_df(pd.DataFrame(fr3), verbose=False), verbose=False, **c)
+        lko.append({'cfg': c, 'train_rids': sorted(int(x) for x in d_tr.values_list('rid', to_list=True)),
+                    'test_rids': sorted(int(x) for x in d_te.values_list('rid', to_list=True))})
     json.dump({'train': tr.tolist(), 'test': te.tolist(), 'scores_seed': 4, 'evals': re_out, 'train_eval': res_train,
-               'metric_cases': mcases}, open(os.path.join(OUT, 'ranking_eval.json'), 'w'))
+               'metric_cases': mcases, 'rec_evals': rec_out, 'leave_k_out': lko},
+              open(os.path.join(OUT, 'ranking_eval.json'), 'w'))
     print('golden fixtures written to', OUT)
     for fn in sorted(os.listdir(OUT)):
         print(' ', fn, os.path.getsize(os.path.join(OUT, fn)))
