@@ -130,8 +130,9 @@ SIGNATURES = {
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
     'drx_score_pairs_bf16': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p]),
+    'drx_topk_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                           C.c_void_p]),
+                           C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_idmap_scratch_bytes': (C.c_size_t, [C.c_int64]),
     'drx_idmap_build': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),

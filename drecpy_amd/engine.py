@@ -252,7 +252,9 @@ class CdaeEngine:
         R, n = scores.shape
         out_idx = torch.empty(R, k, dtype=torch.int32, device=self.device)
         out_val = torch.empty(R, k, dtype=torch.float32, device=self.device)
-        check(lib().drx_topk(ptr(scores), ptr(cand_mask), R, n, k, ptr(out_idx), ptr(out_val),
+        sb = lib().drx_topk_scratch_bytes(R, n)
+        sc = torch.empty(sb, dtype=torch.uint8, device=self.device) if sb else None
+        check(lib().drx_topk(ptr(scores), ptr(cand_mask), R, n, k, ptr(out_idx), ptr(out_val), ptr(sc), sb,
                              stream_ptr(self.device)), 'drx_topk')
         return out_idx, out_val
 

@@ -290,8 +290,9 @@ int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t 
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with
  * cand_mask == NULL || bit (r*n + i) set; order = descending score, ties by larger index
  * (heapq.nlargest over (score, iid) tuples).  out_idx/out_val [R,k]; missing = -1 / -inf. */
+size_t drx_topk_scratch_bytes(int32_t R, int32_t n);   /* 0 for n <= 16384 (LDS bitonic path, scratch may be NULL) */
 int drx_topk(const float *scores, const uint32_t *cand_mask, int32_t R, int32_t n, int32_t k,
-             int32_t *out_idx, float *out_val, void *stream);
+             int32_t *out_idx, float *out_val, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- raw -> internal id map (mem_dataset.py:309-330) --------------------------------------
  * codes[r] = rank of first appearance of raw[r] (int64 raw ids), bit-exact.
