@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=65536, help='triples per GPU per step')
     ap.add_argument('--n-batches', type=int, default=8, help='distinct pre-sampled batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     return ap.parse_args()
 
@@ -162,13 +163,40 @@ def main():
     rows_per_sample = kept_tot / (args.n_batches * B) + 2.0          # R: kept W rows + V row + W2T row
     setup_s = time.time() - t_setup
 
-    def run_step(s, events=None):
-        bt, _ = structs[s % len(structs)]
-        if stepper is None:
-            eng.step_sparse(s, bt, 'bce', events=events)
-        else:
-            stepper.step(s, bt, events=events)
+    # The touch list of a batch (sorted row keys) does not depend on the parameters: it is prepared for batch t+1 on a
+    # side stream while batch t trains (single GPU; the sharded path prepares inline).
+    overlap = stepper is None and not args.no_overlap
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream() if overlap else None
+    prep_bufs = [None, None]
+    prep_done = [torch.cuda.Event(), torch.cuda.Event()]
+    step_done = [torch.cuda.Event(), torch.cuda.Event()]
 
+    def prepare(s):
+        bt, _ = structs[s % len(structs)]
+        side.wait_event(step_done[s % 2])            # the buffer's previous user (step s-2) must be finished
+        with torch.cuda.stream(side):
+            prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])
+            prep_done[s % 2].record(side)
+
+    def run_step(s, events=None, last=False):
+        bt, _ = structs[s % len(structs)]
+        if stepper is not None:
+            stepper.step(s, bt, events=events)
+            return
+        if not overlap:
+            eng.step_sparse(s, bt, 'bce', events=events)
+            return
+        if not last:
+            prepare(s + 1)
+        main.wait_event(prep_done[s % 2])
+        eng.step_sparse(s, bt, 'bce', events=events, prepared=prep_bufs[s % 2])
+        step_done[s % 2].record(main)
+
+    for e in step_done:
+        e.record(main)
+    if overlap:
+        prepare(0)
     for s in range(args.warmup):
         run_step(s)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
@@ -181,7 +209,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        run_step(args.warmup + s, events=evs[s])
+        run_step(args.warmup + s, events=evs[s], last=(s == args.steps - 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,7 +227,8 @@ def main():
     alg_fwd = B * 4.0 * K * rows_per_sample
     alg_upd = B * 4.0 * K * rows_per_sample * 4.0
     if world == 1:
-        names = ['k_sampled_fwd_bwd', 'touch_sort', 'k_seg_reduce', 'k_span_fixup', 'bias_update']
+        names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce',
+                 'k_span_fixup', 'bias_update']
         dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
         names = ['touches+index+row_exchange', 'k_shard_fwd_bwd', 'local_reduce+grad_exchange', 'owner_apply', 'bias_allreduce']
@@ -227,6 +256,7 @@ def main():
                                    f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
                                    f'corruption {Q}, neg_ratio {NEG_RATIO}',
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
+                       'touch_list': 'prepared one batch ahead on a side stream' if overlap else 'inline',
                        'sharding': 'single GPU' if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

@@ -91,6 +91,12 @@ SIGNATURES = {
     'drx_cdae_step_sparse_timed': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History),
                                              C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.c_void_p]),
+    'drx_cdae_prep_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32]),
+    'drx_cdae_sparse_prepare': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
+    'drx_cdae_step_sparse_prepared': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History),
+                                                C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     'drx_point_sample_scratch_bytes': (C.c_size_t, [C.c_int32]),
     'drx_point_sample': (C.c_int, [C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

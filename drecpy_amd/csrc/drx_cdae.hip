@@ -374,7 +374,6 @@ struct SparseBufs {
   float *g2;        // [B, ld]  dz2_b * h_b
   float *dz2;       // [B]
   float *lossb;     // [B]
-  uint32_t *keys, *vals, *keys_s, *vals_s;    // [T]
   float *phead, *ptail;                       // [n_chunks, ld]
   float *phs, *pts;                           // [n_chunks] scalar (b2) partials
   uint32_t *span_list, *long_list;            // [n_chunks] each
@@ -382,6 +381,31 @@ struct SparseBufs {
   float *bpart;                               // [n_bpart, ld]
   int T, n_chunks, n_bpart;
 };
+
+// Touch list of one batch (row key, sample): depends only on the batch, never on the parameters, so it can be built
+// and sorted for batch t+1 while batch t trains (drx_cdae_sparse_prepare on a second stream).
+__global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
+                                                           uint32_t *vals) {
+  constexpr int G = 16;
+  const int lane = threadIdx.x % G;
+  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (b >= bt.B) return;
+  const int u = bt.uid[b];
+  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+  const int base = bt.keep_off[b] + 2 * b;
+  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
+  for (int64_t j = s + lane; j < e; j += G) {
+    const uint32_t jj = (uint32_t)(j - s);
+    const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
+    keys[base + jj] = kf ? (uint32_t)H.indices[j] : DRX_KEY_NONE;
+    vals[base + jj] = (uint32_t)b;
+  }
+  if (lane == 0) {
+    const int deg = (int)(e - s);
+    keys[base + deg] = (uint32_t)(n_items + bt.iid[b]);       vals[base + deg] = (uint32_t)b;
+    keys[base + deg + 1] = (uint32_t)(2 * n_items + u);       vals[base + deg + 1] = (uint32_t)b;
+  }
+}
 
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
@@ -391,15 +415,9 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
   if (b >= bt.B) return;
   const int u = bt.uid[b], i = bt.iid[b];
   const float y = bt.y[b];
-  const int base = bt.keep_off[b] + 2 * b;
-  const int deg = bt.keep_off[b + 1] - bt.keep_off[b];
   float4 acc[J], h[J], w2[J];
   DenseAux none{};
-  gather_bag<G, J, 2>(P, H, bt, qthr, b, lane, acc, none, S.keys, S.vals, base);
-  if (lane == 0) {
-    S.keys[base + deg] = (uint32_t)(P.n_items + i);       S.vals[base + deg] = (uint32_t)b;
-    S.keys[base + deg + 1] = (uint32_t)(2 * P.n_items + u); S.vals[base + deg + 1] = (uint32_t)b;
-  }
+  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
   hidden_act<G, J>(P, u, scale, lane, acc, h);
   load_row<G, J>(P.W2T, (size_t)i, P.ld, lane, w2);
   float d = 0.f;
@@ -604,8 +622,27 @@ static DenseLayout dense_layout(Carver &cv, const DrxCdaeParams &P, int B, bool 
   return L;
 }
 
-static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots, size_t *sort_bytes,
-                                void **sort_temp) {
+struct PrepBufs {
+  uint32_t *keys_s, *vals_s, *keys, *vals;
+  void *sort_temp;
+  size_t sort_bytes;
+  int T, bits;
+};
+
+static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots) {
+  PrepBufs R{};
+  R.T = n_touch_slots + 2 * B;
+  R.bits = bits_for((uint64_t)2 * P.n_items + P.n_users + 1);
+  R.keys_s = cv.take<uint32_t>(R.T);
+  R.vals_s = cv.take<uint32_t>(R.T);
+  R.keys = cv.take<uint32_t>(R.T);
+  R.vals = cv.take<uint32_t>(R.T);
+  R.sort_bytes = sort_pairs_temp_bytes(R.T, R.bits);
+  R.sort_temp = cv.take<char>(R.sort_bytes);
+  return R;
+}
+
+static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots) {
   SparseBufs S{};
   S.T = n_touch_slots + 2 * B;
   S.n_chunks = (S.T + kChunk - 1) / kChunk;
@@ -614,10 +651,6 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.g2 = cv.take<float>((size_t)B * P.ld);
   S.dz2 = cv.take<float>(B);
   S.lossb = cv.take<float>(B);
-  S.keys = cv.take<uint32_t>(S.T);
-  S.vals = cv.take<uint32_t>(S.T);
-  S.keys_s = cv.take<uint32_t>(S.T);
-  S.vals_s = cv.take<uint32_t>(S.T);
   S.phead = cv.take<float>((size_t)S.n_chunks * P.ld);
   S.ptail = cv.take<float>((size_t)S.n_chunks * P.ld);
   S.phs = cv.take<float>(S.n_chunks);
@@ -626,9 +659,6 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.long_list = cv.take<uint32_t>(S.n_chunks);
   S.n_span = cv.take<uint32_t>(64);
   S.bpart = cv.take<float>((size_t)S.n_bpart * P.ld);
-  const int bits = bits_for((uint64_t)2 * P.n_items + P.n_users + 1);
-  *sort_bytes = sort_pairs_temp_bytes(S.T, bits);
-  *sort_temp = cv.take<char>(*sort_bytes);
   return S;
 }
 
@@ -698,8 +728,8 @@ size_t drx_cdae_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch
   Carver c1(nullptr, 0);
   (void)dense_layout(c1, *p, B, true);
   Carver c2(nullptr, 0);
-  size_t sb; void *stmp;
-  (void)sparse_layout(c2, *p, B, n_touch_slots, &sb, &stmp);
+  (void)sparse_layout(c2, *p, B, n_touch_slots);
+  (void)prep_layout(c2, *p, B, n_touch_slots);
   size_t m = c1.off > c2.off ? c1.off : c2.off;
   return align_up(m, 256) + 256;
 }
@@ -752,9 +782,18 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
   return DRX_OK;
 }
 
+static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
+  // slots beyond keep_off[B] (n_touch_slots may be an upper bound) must read as padding
+  DRX_HIP(hipMemsetAsync(R.keys, 0xFF, (size_t)R.T * sizeof(uint32_t), st));
+  const int gpb = kBlock / 16;
+  hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
+                     q_threshold(bt->q), R.keys, R.vals);
+  return sort_pairs(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, st);
+}
+
 static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
-                            int32_t loss_kind, void *scratch, size_t scratch_bytes, float *loss_out, void *const *events,
-                            void *stream) {
+                            int32_t loss_kind, const void *prepared, size_t prepared_bytes, void *scratch, size_t scratch_bytes,
+                            float *loss_out, void *const *events, void *stream) {
   int rc = check_params(p);
   if (rc) return rc;
   rc = check_batch(hist, bt);
@@ -765,29 +804,35 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   if ((uint64_t)2 * p->n_items + p->n_users + 1 >= 0xFFFFFFFFull) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   Carver cv(scratch, scratch_bytes);
-  size_t sort_bytes; void *sort_temp;
-  SparseBufs S = sparse_layout(cv, *p, bt->B, bt->n_touch_slots, &sort_bytes, &sort_temp);
+  SparseBufs S = sparse_layout(cv, *p, bt->B, bt->n_touch_slots);
+  PrepBufs R{};
+  if (prepared) {
+    Carver cp(const_cast<void *>(prepared), prepared_bytes);
+    R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
+    if (!cp.ok()) return DRX_ESCRATCH;
+  } else {
+    R = prep_layout(cv, *p, bt->B, bt->n_touch_slots);
+  }
   if (!cv.ok()) return DRX_ESCRATCH;
   const float scale = 1.0f / (1.0f - bt->q);
   const uint32_t qthr = q_threshold(bt->q);
-  const int bits = bits_for((uint64_t)2 * p->n_items + p->n_users + 1);
   const int rows_per_block = (bt->B + S.n_bpart - 1) / S.n_bpart;
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
-  SegBufs SB{S.keys_s, S.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.T, S.n_chunks, p->ld};
+  SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.T, S.n_chunks, p->ld};
   DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
-    DRX_HIP(hipMemsetAsync(S.n_span, 0, 2 * sizeof(uint32_t), st));                                                        \
-    /* slots beyond keep_off[B] (n_touch_slots may be an upper bound) must read as padding */                          \
-    DRX_HIP(hipMemsetAsync(S.keys, 0xFF, (size_t)S.T * sizeof(uint32_t), st));                                         \
+    DRX_HIP(hipMemsetAsync(S.n_span, 0, 2 * sizeof(uint32_t), st));                                                    \
     EV(0);                                                                                                             \
     hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt,  \
                        scale, qthr, loss_kind, S);                                                                     \
     EV(1);                                                                                                             \
-    rc = sort_pairs(sort_temp, sort_bytes, S.keys, S.keys_s, S.vals, S.vals_s, (size_t)S.T, bits, st);                 \
-    if (rc) return rc;                                                                                                 \
+    if (!prepared) {                                                                                                   \
+      rc = prepare_impl(p, hist, bt, R, st);                                                                           \
+      if (rc) return rc;                                                                                               \
+    }                                                                                                                  \
     EV(2);                                                                                                             \
     hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
                        pol);                                                                                           \
@@ -813,16 +858,45 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   return DRX_OK;
 }
 
+size_t drx_cdae_prep_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots) {
+  if (!p || B < 1 || n_touch_slots < 0) return 0;
+  Carver c(nullptr, 0);
+  (void)prep_layout(c, *p, B, n_touch_slots);
+  return align_up(c.off, 256) + 256;
+}
+
+int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, void *prepared,
+                            size_t prepared_bytes, void *stream) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  rc = check_batch(hist, bt);
+  if (rc || !prepared || !bt->iid || !bt->keep_off) return DRX_EINVAL;
+  Carver cp(prepared, prepared_bytes);
+  PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
+  if (!cp.ok()) return DRX_ESCRATCH;
+  rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream);
+  if (rc) return rc;
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_cdae_step_sparse_prepared(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
+                                  int32_t loss_kind, const void *prepared, size_t prepared_bytes, void *scratch,
+                                  size_t scratch_bytes, float *loss_out, void *const *events, void *stream) {
+  if (!prepared) return DRX_EINVAL;
+  return step_sparse_impl(p, opt, hist, bt, loss_kind, prepared, prepared_bytes, scratch, scratch_bytes, loss_out, events, stream);
+}
+
 int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
                          int32_t loss_kind, void *scratch, size_t scratch_bytes, float *loss_out, void *stream) {
-  return step_sparse_impl(p, opt, hist, bt, loss_kind, scratch, scratch_bytes, loss_out, nullptr, stream);
+  return step_sparse_impl(p, opt, hist, bt, loss_kind, nullptr, 0, scratch, scratch_bytes, loss_out, nullptr, stream);
 }
 
 int drx_cdae_step_sparse_timed(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
                                int32_t loss_kind, void *scratch, size_t scratch_bytes, float *loss_out, void *const *events,
                                void *stream) {
   if (!events) return DRX_EINVAL;
-  return step_sparse_impl(p, opt, hist, bt, loss_kind, scratch, scratch_bytes, loss_out, events, stream);
+  return step_sparse_impl(p, opt, hist, bt, loss_kind, nullptr, 0, scratch, scratch_bytes, loss_out, events, stream);
 }
 
 }  // extern "C"

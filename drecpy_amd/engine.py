@@ -212,20 +212,35 @@ class CdaeEngine:
             'drx_cdae_step_dense')
         return self._loss if want_loss else None
 
-    def step_sparse(self, step, bt, loss='bce', want_loss=False, events=None):
+    def prepare_sparse(self, bt, out=None):
+        """Builds and sorts the touch list of a batch (drx_cdae_sparse_prepare) on the CURRENT stream.  The list does not
+        depend on the parameters, so this may run on a side stream for batch t+1 while batch t trains."""
+        need = lib().drx_cdae_prep_bytes(C.byref(self._params), bt.B, bt.n_touch_slots)
+        if out is None or out.numel() < need:
+            out = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        check(lib().drx_cdae_sparse_prepare(C.byref(self._params), C.byref(self._hist), C.byref(bt), ptr(out), out.numel(),
+                                            stream_ptr(self.device)), 'drx_cdae_sparse_prepare')
+        return out
+
+    def step_sparse(self, step, bt, loss='bce', want_loss=False, events=None, prepared=None):
         """One sampled-output step (sparse Adagrad / lazy Adam on touched rows).
         events: optional list of 6 recorded-once torch.cuda.Event(enable_timing=True); their raw hipEvent_t are
-        re-recorded by the library around each phase (include/drx.h, drx_cdae_step_sparse_timed)."""
+        re-recorded by the library around each phase (include/drx.h, drx_cdae_step_sparse_timed).
+        prepared: buffer returned by prepare_sparse() for this batch (else the touch list is built inline)."""
         a = self.adam_alpha(self.lr, step + 1)
         o = self._optim([a] * 5)
         sc = self._ensure_scratch(bt.B, bt.n_touch_slots)
         lk = _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE
         lo = ptr(self._loss) if want_loss else None
-        if events is None:
+        arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events]) if events is not None else None
+        if prepared is not None:
+            check(lib().drx_cdae_step_sparse_prepared(C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
+                                                      lk, ptr(prepared), prepared.numel(), ptr(sc), sc.numel(), lo, arr,
+                                                      stream_ptr(self.device)), 'drx_cdae_step_sparse_prepared')
+        elif events is None:
             check(lib().drx_cdae_step_sparse(C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt), lk,
                                              ptr(sc), sc.numel(), lo, stream_ptr(self.device)), 'drx_cdae_step_sparse')
         else:
-            arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events])
             check(lib().drx_cdae_step_sparse_timed(C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
                                                    lk, ptr(sc), sc.numel(), lo, arr, stream_ptr(self.device)),
                   'drx_cdae_step_sparse_timed')

@@ -132,6 +132,17 @@ int drx_cdae_step_sparse_timed(const DrxCdaeParams *p, const DrxOptim *opt, cons
                                const DrxBatch *bt, int32_t loss_kind, void *scratch, size_t scratch_bytes,
                                float *loss_out, void *const *events, void *stream);
 
+/* The touch list of a batch (row keys sorted, with the contributing sample) depends only on the batch, not on the
+ * parameters: it can be prepared for batch t+1 on another stream while batch t trains.  `prepared` is an opaque
+ * device buffer of drx_cdae_prep_bytes() bytes; events may be NULL (else as in drx_cdae_step_sparse_timed; phase 1 is
+ * then empty). */
+size_t drx_cdae_prep_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots);
+int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, void *prepared,
+                            size_t prepared_bytes, void *stream);
+int drx_cdae_step_sparse_prepared(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
+                                  int32_t loss_kind, const void *prepared, size_t prepared_bytes, void *scratch,
+                                  size_t scratch_bytes, float *loss_out, void *const *events, void *stream);
+
 /* ---- device-side point sampler (throughput mode; distribution of point_sampler.py:44-61) ------------
  * Draws B triples with a counter-based generator keyed by (seed, b): negatives with probability
  * neg_ratio/(neg_ratio+1) = uniform (u,i) outside u's positives, positives = uniform user then uniform positive.
