@@ -30,13 +30,13 @@ template <int G, int J, int MODE>
 __device__ __forceinline__ void gather_bag(const DrxCdaeParams &P, const DrxHistory &H, const DrxBatch &bt,
                                            uint32_t qthr, int b, int lane, float4 (&acc)[J],
                                            const DenseAux &aux, uint32_t *tkeys, uint32_t *tvals,
-                                           int touch_base) {
+                                           int touch_base, int part = 0, int nparts = 1) {
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
   const int u = bt.uid[b];
   const int64_t s = H.indptr[u], e = H.indptr[u + 1];
   const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
-  for (int64_t c = s; c < e; c += G) {
+  for (int64_t c = s + (int64_t)part * G; c < e; c += (int64_t)nparts * G) {
     const int64_t j = c + lane;
     int idx = -1, kf = 0;
     if (j < e) {
@@ -89,6 +89,36 @@ __global__ __launch_bounds__(kBlock) void k_hidden_fwd(DrxCdaeParams P, DrxHisto
   store_row<G, J>(hout, (size_t)b, P.ld, lane, h);
 }
 
+// Small batches (the reference's own B = 32..64): one WORKGROUP per batch row — its 256/G groups split the user's history,
+// each keeps 4 row loads in flight, and the partial bags are combined in LDS in group order.  With one group per row a
+// 155-item history is a chain of ~40 dependent load batches on 8 workgroups of the whole chip (measured 94 us at ml-1m).
+template <int G, int J, int MODE>
+__global__ __launch_bounds__(kBlock) void k_hidden_fwd_wg(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
+                                                          uint32_t qthr, float *__restrict__ hout, DenseAux aux) {
+  extern __shared__ __align__(16) float lds[];   // [R, ld]
+  constexpr int R = kBlock / G;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const int b = blockIdx.x;
+  float4 acc[J], h[J];
+  gather_bag<G, J, MODE>(P, H, bt, qthr, b, lane, acc, aux, nullptr, nullptr, 0, r, R);
+  store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
+  __syncthreads();
+  if (r == 0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+    for (int rr = 0; rr < R; ++rr) {
+      float4 v[J];
+      load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+    }
+    const int u = bt.uid[b];
+    if (MODE == 1 && lane == 0) atomicOr(&aux.vm[(size_t)u * aux.Bw + (b >> 5)], 1u << (b & 31));
+    hidden_act<G, J>(P, u, scale, lane, acc, h);
+    store_row<G, J>(hout, (size_t)b, P.ld, lane, h);
+  }
+}
+
 // pred[b,n] = sigmoid(h_b . W2T[n] + b2[n]) for all b, n  (inference; cdae.py:76)
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_out_fwd(DrxCdaeParams P, const float *__restrict__ h, int B,
@@ -131,7 +161,7 @@ struct OutDenseArgs {
   int loss_kind;
 };
 
-template <int G, int J>
+template <int G, int J, bool WANT_LOSS>
 __global__ __launch_bounds__(kBlock) void k_out_dense(DrxCdaeParams P, DrxOptim opt, OutDenseArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int R = kBlock / G;
@@ -170,6 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_out_dense(DrxCdaeParams P, DrxOptim 
         tbar = (float)A.cnt[n] * invB;
       }
       store_row<G, J>(w_s, (size_t)r, ld, lane, w);
+#pragma unroll 4
       for (int b = 0; b < nb; ++b) {
         float d = 0.f;
 #pragma unroll
@@ -185,12 +216,12 @@ __global__ __launch_bounds__(kBlock) void k_out_dense(DrxCdaeParams P, DrxOptim 
           if (A.tb) t = (A.tb[(size_t)(b0 + b) * A.Nw + (n >> 5)] >> (n & 31)) & 1u ? 1.0f : 0.0f;
           float dp;
           if (A.loss_kind == DRX_LOSS_BCE) {
-            loss_acc += bce_elem(t, p);
+            if (WANT_LOSS) loss_acc += bce_elem(t, p);
             dp = bce_grad(t, p) * invBN;
           } else {
             const float df = p - t;
             // (B,B,N) broadcast of squared error: (p - tbar)^2 + var(t) for binary targets
-            loss_acc += df * df + (A.tb ? 0.f : t * (1.0f - t));
+            if (WANT_LOSS) loss_acc += df * df + (A.tb ? 0.f : t * (1.0f - t));
             dp = 2.0f * df * invBN;
           }
           dz = dp * p * (1.0f - p);
@@ -261,11 +292,18 @@ __global__ __launch_bounds__(kBlock) void k_hidden_bwd(int ld, int B, int n_slab
   float4 acc[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  for (int s = r; s < n_slabs; s += R) {
-    float4 v[J];
-    load_row<G, J>(slab, (size_t)s * B + b, ld, lane, v);
+  for (int s = r; s < n_slabs; s += 4 * R) {            // 4 independent slab rows in flight, folded in slab order
+    float4 v[4][J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[u][j] = f4_zero();
+      if (s + u * R < n_slabs) load_row<G, J>(slab, (size_t)(s + u * R) * B + b, ld, lane, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(acc[j], v[u][j]);
   }
   store_row<G, J>(lds, (size_t)r, ld, lane, acc);
   __syncthreads();
@@ -573,7 +611,8 @@ __global__ __launch_bounds__(kBlock) void k_bias_final(DrxCdaeParams P, DrxOptim
 // ------------------------------------------------------------------------------------------------
 // scratch layouts (shared by the sizing entry point and the step functions)
 // ------------------------------------------------------------------------------------------------
-constexpr int kOutGrid = 256;        // persistent workgroups of k_out_dense (one per CU)
+constexpr int kSmallBatch = 1024;    // at or below: one workgroup per batch row in the hidden-layer gather
+constexpr int kOutGrid = 512;        // persistent workgroups of k_out_dense (two per CU when LDS allows)
 constexpr int kSweepGrid = 1024;
 constexpr size_t kLdsBudget = 144 * 1024;
 
@@ -709,8 +748,12 @@ int drx_cdae_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBa
 #define CALL(G, J)                                                                                        \
   {                                                                                                       \
     const int gpb = kBlock / G;                                                                           \
-    hipLaunchKernelGGL((k_hidden_fwd<G, J, 0>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, \
-                       scale, qthr, h, none);                                                             \
+    if (bt->B <= kSmallBatch)                                                                             \
+      hipLaunchKernelGGL((k_hidden_fwd_wg<G, J, 0>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *hist, *bt, \
+                         scale, qthr, h, none);                                                           \
+    else                                                                                                  \
+      hipLaunchKernelGGL((k_hidden_fwd<G, J, 0>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, \
+                         scale, qthr, h, none);                                                           \
     if (pred) {                                                                                           \
       int blocks = (p->n_items + gpb - 1) / gpb;                                                          \
       if (blocks > 2048) blocks = 2048;                                                                   \
@@ -761,11 +804,21 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
 #define CALL(G, J)                                                                                                   \
   {                                                                                                                  \
     const int gpb = kBlock / G;                                                                                      \
-    hipLaunchKernelGGL((k_hidden_fwd<G, J, 1>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt,  \
-                       scale, qthr, L.h, aux);                                                                       \
-    DRX_HIP(hipFuncSetAttribute((const void *)k_out_dense<G, J>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                (int)L.lds_bytes));                                                                  \
-    hipLaunchKernelGGL((k_out_dense<G, J>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A);           \
+    if (bt->B <= kSmallBatch)                                                                                        \
+      hipLaunchKernelGGL((k_hidden_fwd_wg<G, J, 1>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *hist, *bt, \
+                         scale, qthr, L.h, aux);                                                                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_hidden_fwd<G, J, 1>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, \
+                         scale, qthr, L.h, aux);                                                                     \
+    if (loss_out) {                                                                                                  \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_out_dense<G, J, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)L.lds_bytes));                                                                \
+      hipLaunchKernelGGL((k_out_dense<G, J, true>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A);   \
+    } else {                                                                                                         \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_out_dense<G, J, false>, hipFuncAttributeMaxDynamicSharedMemorySize,\
+                                  (int)L.lds_bytes));                                                                \
+      hipLaunchKernelGGL((k_out_dense<G, J, false>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A);  \
+    }                                                                                                                \
     hipLaunchKernelGGL((k_hidden_bwd<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B,   \
                        L.out_grid, L.dh_slab, L.h, L.dz1);                                                           \
     int sweep = (total_rows + gpb - 1) / gpb;                                                                        \

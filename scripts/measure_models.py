@@ -1,0 +1,116 @@
+"""Secondary measurements on one MI355X (not the driver's bench line): reference-mode CDAE at the reference's own
+configuration, DMF and Caser steps at ml-1m-shaped synthetic data, each with the CPU oracle timed beside it.
+    python scripts/measure_models.py > profiles/r01_models.json
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from drecpy_amd import synth                                         # noqa: E402
+from drecpy_amd.Dataset import InteractionDataset                    # noqa: E402
+
+
+def frame_of(shape, seed=0):
+    U, N, md, mn, a = synth.SHAPES[shape]
+    ip, idx = synth.synth_history(U, N, md, mn, a, seed=seed)
+    ip, idx = ip.numpy(), idx.numpy()
+    rng = np.random.RandomState(seed)
+    user = np.repeat(np.arange(U), np.diff(ip)) + 1
+    item = idx.astype(np.int64) + 1
+    perm = rng.permutation(len(user))                                   # shuffled row order, like a ratings file
+    return {'user': user[perm], 'item': item[perm], 'interaction': rng.randint(1, 6, size=len(user))[perm],
+            'timestamp': rng.randint(0, 10 ** 9, size=len(user))[perm]}
+
+
+def timed(fn, n, sync=True):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    if sync:
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def main():
+    out = {}
+    from drecpy_amd.Recommender import CDAE, DMF, Caser
+    from oracle import cdae_oracle as co
+    for shape, K, B in (('ml-100k', 50, 64), ('ml-1m', 128, 64)):
+        ds = InteractionDataset.read_df(frame_of(shape), verbose=False)
+        m = CDAE(hidden_factors=K, corruption_level=0.2, seed=10, verbose=False)
+        t0 = time.perf_counter()
+        m.fit(ds, epochs=1, batch_size=B, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
+        setup = time.perf_counter() - t0
+        state = {'s': 1}
+
+        def full_step():
+            batch = m._sample_batch(B)
+            m._do_batch(batch, step=state['s'])
+            state['s'] += 1
+        e2e = timed(full_step, 200)
+        batch = m._sample_batch(B)
+        uid, _, _ = m._batch_arrays(batch)
+        keep_off, keep = m._corruption_keep(uid)
+        bt, alive = m._engine.make_batch(uid, keep_off=keep_off, keep=keep, q=0.2, n_touch_slots=int(keep_off[-1]))
+        dev = timed(lambda: m._engine.step_dense(5, bt), 200)
+        # CPU oracle on the same batch (fp32 NumPy restatement of the reference step; BLAS threads as configured)
+        p = {k: v.astype(np.float32) for k, v in m._engine.get_params().items()}
+        st = co.adam_state(p)
+        N = m.n_items
+        t = np.zeros((B, N), bool)
+        for b, u in enumerate(uid):
+            t[b, m._hist_indices[m._hist_indptr[u]:m._hist_indptr[u + 1]]] = True
+        xt = (t * (np.random.default_rng(0).random((B, N)) >= 0.2)).astype(np.float32) / np.float32(0.8)
+        tc = time.perf_counter(); n_cpu = 0
+        while time.perf_counter() - tc < 5.0:
+            co.dense_step(p, st, n_cpu, uid, xt, t, 1e-3, 1e-3); n_cpu += 1
+        cpu = (time.perf_counter() - tc) / n_cpu
+        P = 2 * N * K + m.n_users * K + N + K
+        out[f'cdae_reference_{shape}_K{K}_B{B}'] = {
+            'n_users': m.n_users, 'n_items': N, 'nnz': m.n_rows, 'setup_s': round(setup, 2),
+            'fit_loop_ms_per_step (C++ sampler + MT19937 corruption stream + H2D + dense step)': e2e * 1e3,
+            'fit_loop_samples_per_s': B / e2e, 'device_step_ms': dev * 1e3, 'device_samples_per_s': B / dev,
+            'algorithmic_bytes_per_step (24P + 4NK)': 24 * P + 4 * N * K, 'achieved_GBs_device_only': (24 * P + 4 * N * K) / dev / 1e9,
+            'cpu_oracle_ms_per_step (numpy fp32 math only, no sampler)': cpu * 1e3, 'cpu_oracle_samples_per_s': B / cpu}
+    # ---- DMF / Caser at ml-1m shape -----------------------------------------------------------------------------------
+    fr = frame_of('ml-1m')
+    ds = InteractionDataset.read_df(dict(fr), verbose=False)
+    for B in (256, 4096):
+        m = DMF(seed=10, verbose=False)
+        m.fit(ds, epochs=1, batch_size=B, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
+        batch = m._sample_batch(B)
+        state = {'s': 1}
+
+        def dstep():
+            m._engine.step(state['s'], *batch); state['s'] += 1
+        dev = timed(dstep, 30)
+        out[f'dmf_ml-1m_64x32_B{B}'] = {'device_step_ms': dev * 1e3, 'samples_per_s': B / dev}
+    ue = torch.arange(0, 2048, device='cuda')
+    t_sc = timed(lambda: m._engine.score_matrix_bf16(ue), 10)
+    out['dmf_mfma_score_matrix_2048users_x_3706items'] = {'ms (incl. both tower forwards over all items/users)': t_sc * 1e3}
+    for B in (512, 4096):
+        m = Caser(seed=10, verbose=False, dropout_rate=0.5)
+        m.fit(ds, epochs=1, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3)
+        t0 = time.perf_counter(); batch = m._sample_batch(B); t_s = time.perf_counter() - t0
+        state = {'s': 1}
+
+        def cstep():
+            m._do_batch(batch, step=state['s']); state['s'] += 1
+        dev = timed(cstep, 20)
+        out[f'caser_ml-1m_L5_T3_d50_B{B}'] = {'device_step_ms (incl. dropout-mask upload)': dev * 1e3, 'samples_per_s': B / dev,
+                                             'list_sampler_host_ms_per_batch': t_s * 1e3}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
