@@ -19,7 +19,7 @@ from ..Sampler import PointSampler
 
 class CDAE(RecommenderABC):
     def __init__(self, hidden_factors=50, corruption_level=0.2, loss='bce', mode='reference', loss_targets='reference',
-                 sparse_optimizer='adagrad', device='cuda:0', **kwds):
+                 sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', **kwds):
         super().__init__(**kwds)
         self.hidden_factors = hidden_factors
         self.corruption_level = corruption_level
@@ -31,6 +31,7 @@ class CDAE(RecommenderABC):
         self.mode = mode
         self.loss_targets = loss_targets
         self.sparse_optimizer = sparse_optimizer
+        self.device_sampler = device_sampler      # sampled mode: draw the triples on the GPU (counter-based stream)
         self.device = device
 
     # ---- cdae.py:34-45 ---------------------------------------------------------------------------
@@ -65,6 +66,9 @@ class CDAE(RecommenderABC):
         self._engine.set_history(ip, idx)
 
     def _sample_batch(self, batch_size, **kwds):       # cdae.py:47
+        if self.mode == 'sampled' and self.device_sampler:
+            self._dev_draws = getattr(self, '_dev_draws', 0) + 1
+            return self._engine.sample_device(batch_size, self._sampler.neg_ratio, self._mask_seed * 7919 + self._dev_draws)
         if self.mode == 'sampled' and kwds.get('as_arrays', True):
             return self._sampler.sample_arrays(batch_size)      # (uid, iid, value, is_negative) numpy arrays
         return self._sampler.sample(batch_size)                  # list of (uid, iid, value) like the reference
@@ -93,8 +97,14 @@ class CDAE(RecommenderABC):
         return keep_off, keep
 
     def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
-        uid, iid, val = self._batch_arrays(batch_samples)
         eng = self._engine
+        if self.mode == 'sampled' and self.device_sampler:       # (uid, iid, y, keep_off) device tensors from drx_point_sample
+            uid, iid, y, keep_off = batch_samples
+            bt, alive = eng.make_batch(uid, iid, y, keep_off=keep_off, q=self.corruption_level,
+                                       mask_seed=self._mask_seed + 0x9E3779B9 * (step + 1))
+            loss = eng.step_sparse(step, bt, self._loss_name, want_loss=want_loss)
+            return float(loss[0].item()) if want_loss else None
+        uid, iid, val = self._batch_arrays(batch_samples)
         if self.mode == 'reference':
             keep_off, keep = self._corruption_keep(uid)
             bt, alive = eng.make_batch(uid, keep_off=keep_off, keep=keep, q=self.corruption_level,

@@ -117,3 +117,24 @@ def test_cdae_sampled_mode_learns():
         model._do_batch(model._sample_batch(256), step=s)
     l1 = model._do_batch(model._sample_batch(256), step=60, want_loss=True)
     assert l1 < l0
+
+
+def test_cdae_sampled_mode_with_device_sampler_learns():
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    ds = InteractionDataset.read_df(_frame(), verbose=False)
+    model = CDAE(hidden_factors=16, mode='sampled', device_sampler=True, seed=3, verbose=False)
+    model.fit(ds, epochs=1, batch_size=512, learning_rate=0.05)
+    l0 = model._do_batch(model._sample_batch(512), step=1, want_loss=True)
+    for s in range(2, 80):
+        model._do_batch(model._sample_batch(512), step=s)
+    l1 = model._do_batch(model._sample_batch(512), step=80, want_loss=True)
+    assert l1 < l0
+    u, i, y, ko = model._sample_batch(2048)
+    u, i, y = u.cpu().numpy(), i.cpu().numpy(), y.cpu().numpy()
+    pairs = set(zip(ds._cols['uid'].tolist(), ds._cols['iid'].tolist()))
+    pos = set((a, b) for a, b, v in zip(ds._cols['uid'].tolist(), ds._cols['iid'].tolist(), ds._cols['interaction'].tolist()) if v >= 1e-3)
+    # negatives are outside the user's positives, positives inside; roughly neg_ratio/(neg_ratio+1) negatives
+    for a, b, t in zip(u.tolist(), i.tolist(), y.tolist()):
+        assert ((a, b) in pos) == (t == 1.0)
+    assert 0.75 < (y == 0).mean() < 0.9
