@@ -10,50 +10,44 @@ import random
 
 import numpy as np
 
-from .metrics import HitRatio, NDCG, Precision, RankingMetricABC, Recall
+from ._protocol import MetricTable, as_k_list, resolve_metrics, sample_positives
 
 
 def _user_lists(model, user, ds_test, thr, n_pos, n_neg, train_evaluation, generate_negative_pairs, rng):
-    """Candidate construction for one user (ranking_evaluation.py:163-219); returns None when the user is skipped."""
+    """Candidate construction for one user (ranking_evaluation.py:163-219); returns None when the user is skipped.
+    RNG call order: sample positives, sample test negatives, generate extra negatives, shuffle."""
     user_ds = ds_test.select(f'user == {user}')
-    pos_ds = user_ds.select(f'interaction >= {thr}')
-    if n_pos is None:
-        interacted = pos_ds.values_list(['item', 'interaction'])
-    else:
-        if len(pos_ds) < n_pos:
-            return None
-        interacted = rng.sample(pos_ds.values_list(['item', 'interaction']), n_pos)
-    best_item = None if len(interacted) == 0 else max(interacted, key=lambda p: -p['interaction'])['item']
-    interacted = [p['item'] for p in interacted]
+    drawn = sample_positives(user_ds, thr, n_pos, rng)
+    if drawn is None:
+        return None
+    relevant, best_item, pos_ds = drawn
 
-    neg_ds = user_ds.select(f'interaction < {thr}')
-    if n_neg is None:
-        non_interacted = neg_ds.values_list(['item'], to_list=True)
-    else:
+    neg_items = user_ds.select(f'interaction < {thr}').values_list(['item'], to_list=True)
+    if n_neg is not None:
         if isinstance(n_neg, float):
-            n_neg = int(n_neg * len(interacted))
-        non_interacted = rng.sample(neg_ds.values_list(['item'], to_list=True), min(n_neg, len(neg_ds)))
-        if len(non_interacted) < n_neg and generate_negative_pairs:
-            if train_evaluation:
-                train_pos = pos_ds
-            else:
-                train_pos = model.interaction_dataset.select(f'user == {user}, interaction >= {thr}')
+            n_neg = int(n_neg * len(relevant))
+        n_from_test = min(n_neg, len(neg_items))
+        neg_items = rng.sample(neg_items, n_from_test)
+        if generate_negative_pairs and len(neg_items) < n_neg:
+            train_pos = pos_ds if train_evaluation else \
+                model.interaction_dataset.select(f'user == {user}, interaction >= {thr}')
             blacklist = set(train_pos.unique('item').values_list('item', to_list=True))
             if not train_evaluation:
-                blacklist = blacklist.union(set(pos_ds.unique('item').values_list('item', to_list=True)))
+                blacklist |= set(pos_ds.unique('item').values_list('item', to_list=True))
             if model.n_items - len(blacklist) < n_neg:
-                logging.warning(f'Skipping user {user} due to not having enough negative eligible items to be sampled.')
+                logging.warning(f'Skipping user {user}: only {model.n_items - len(blacklist)} eligible negative items for '
+                                f'{n_neg} requested (decrease n_neg_interactions).')
                 return None
-            while len(non_interacted) < n_neg:
-                new_item = rng.randint(0, model.n_items - 1)      # internal-range integer used as a raw id (quirk kept)
-                if new_item not in blacklist and new_item not in non_interacted:
-                    non_interacted.append(new_item)
-    all_items = interacted + non_interacted
-    if len(all_items) == 0:
+            while len(neg_items) < n_neg:
+                candidate = rng.randint(0, model.n_items - 1)     # internal-range integer used as a RAW id (quirk kept)
+                if candidate not in blacklist and candidate not in neg_items:
+                    neg_items.append(candidate)
+    candidates = relevant + neg_items
+    if not candidates:
         return None
-    rng.shuffle(all_items)
-    relevancies = {item: (user_ds.select_one(f'item == {item}', ['interaction'], to_list=True) or 0) for item in all_items}
-    return {'user': user, 'items': all_items, 'relevant': interacted, 'best': best_item, 'relevancies': relevancies}
+    rng.shuffle(candidates)
+    relevancies = {item: (user_ds.select_one(f'item == {item}', ['interaction'], to_list=True) or 0) for item in candidates}
+    return {'user': user, 'items': candidates, 'relevant': relevant, 'best': best_item, 'relevancies': relevancies}
 
 
 def _batched_rank(model, tasks, novelty):
@@ -96,19 +90,11 @@ def ranking_evaluation(model, ds_test=None, n_test_users=None, k=10, n_pos_inter
                         'is not defined. Either set generate_negative_pairs=False or define the n_neg_interactions '
                         'parameter.')
     thr = kwds.get('interaction_threshold', model.interaction_threshold)
-    if type(k) is not list:
-        k = [k]
-    for k_ in k:
-        assert k_ > 0, f'k ({k_}) should be > 0.'
-    train_evaluation = False
-    if ds_test is None or ds_test is model.interaction_dataset:
-        train_evaluation = True
+    ks = as_k_list(k)
+    train_evaluation = ds_test is None or ds_test is model.interaction_dataset
+    if train_evaluation:
         ds_test = model.interaction_dataset
-    metrics = kwds.get('metrics', [Precision(), Recall(), HitRatio(), NDCG()])
-    assert isinstance(metrics, list), f'Expected "metrics" argument to be a list and found {type(metrics)}.'
-    for m in metrics:
-        assert isinstance(m, RankingMetricABC), f'Expected metric {m} to be an instance of type RankingMetricABC.'
-    metric_sums = {(m.name, k_): [0, 0] for m in metrics for k_ in k}
+    table = MetricTable(resolve_metrics(kwds), ks)
 
     users = ds_test.unique('user').values_list('user', to_list=True)
     n_test_users = len(users) if n_test_users is None else min(n_test_users, len(users))
@@ -132,20 +118,5 @@ def ranking_evaluation(model, ds_test=None, n_test_users=None, k=10, n_pos_inter
                   for t in tasks]
 
     for t, recommendations in zip(tasks, ranked):
-        for m in metrics:
-            names = m.__call__.__code__.co_varnames
-            for k_ in k:
-                params = {}
-                for pn in names:
-                    if pn == 'recommendations': params[pn] = recommendations
-                    elif pn == 'relevant_recommendations': params[pn] = t['relevant']
-                    elif pn == 'relevant_recommendation': params[pn] = t['best']
-                    elif pn == 'relevancies': params[pn] = t['relevancies']
-                    elif pn == 'k': params[pn] = k_
-                try:
-                    metric_sums[(m.name, k_)][0] += m(**params)
-                    metric_sums[(m.name, k_)][1] += 1
-                except Exception:                     # e.g. empty recommendation list (ranking_evaluation.py:243-246)
-                    pass
-    return {m + f'@{k_}': round(metric_sums[(m, k_)][0] / metric_sums[(m, k_)][1], 4) if metric_sums[(m, k_)][1] > 0 else 0
-            for m, k_ in metric_sums}
+        table.add(recommendations, t['relevant'], t['best'], t['relevancies'])
+    return table.result()

@@ -1,10 +1,10 @@
-"""Top-N recommendation evaluation with the protocol of DRecPy/Evaluation/Processes/recommendation_evaluation.py:18-192
-(used by examples/caser.py:17-18): per test user, `model.recommend(user, n=max(k), novelty)` against the user's sampled
-positives; same per-user `random.Random(seed + i)` streams, metric plumbing and rounding."""
+"""Top-N recommendation evaluation with the protocol of DRecPy/Evaluation/Processes/recommendation_evaluation.py (used by
+examples/caser.py:17-18): per test user `model.recommend(user, n=max(k), novelty)` against the user's (sampled) test
+positives; user i draws from `random.Random(seed + i)`; result keys `metric@k`, rounded to 4 decimals."""
 import logging
 import random
 
-from .metrics import HitRatio, NDCG, Precision, RankingMetricABC, Recall
+from ._protocol import MetricTable, as_k_list, resolve_metrics, sample_positives
 
 
 def recommendation_evaluation(model, ds_test=None, n_test_users=None, k=10, n_pos_interactions=None, novelty=False,
@@ -12,57 +12,28 @@ def recommendation_evaluation(model, ds_test=None, n_test_users=None, k=10, n_po
     assert n_test_users is None or n_test_users > 0, f'The number of test users ({n_test_users}) should be > 0.'
     assert n_pos_interactions is None or n_pos_interactions > 0, \
         f'The number of positive interactions ({n_pos_interactions}) should be None or an integer > 0.'
-    thr = kwds.get('interaction_threshold', model.interaction_threshold)
-    if type(k) is not list:
-        k = [k]
-    for k_ in k:
-        assert k_ > 0, f'k ({k_}) should be > 0.'
-    if ds_test is None:
-        ds_test = model.interaction_dataset
-    metrics = kwds.get('metrics', [Precision(), Recall(), HitRatio(), NDCG()])
-    assert isinstance(metrics, list), f'Expected "metrics" argument to be a list and found {type(metrics)}.'
-    for m in metrics:
-        assert isinstance(m, RankingMetricABC), f'Expected metric {m} to be an instance of type RankingMetricABC.'
-    metric_sums = {(m.name, k_): [0, 0] for m in metrics for k_ in k}
+    threshold = kwds.get('interaction_threshold', model.interaction_threshold)
+    ks = as_k_list(k)
+    table = MetricTable(resolve_metrics(kwds), ks)
+    ds_test = model.interaction_dataset if ds_test is None else ds_test
     users = ds_test.unique('user').values_list('user', to_list=True)
-    n_test_users = len(users) if n_test_users is None else min(n_test_users, len(users))
-    for i, user in enumerate(users[:n_test_users]):
+    if n_test_users is not None:
+        users = users[:n_test_users]
+    for offset, user in enumerate(users):
         user = user.item() if hasattr(user, 'item') else user
-        rng = random.Random(seed + i)
         try:
             user_ds = ds_test.select(f'user == {user}')
-            pos_ds = user_ds.select(f'interaction >= {thr}')
-            if n_pos_interactions is None:
-                interacted = pos_ds.values_list(['item', 'interaction'])
-            else:
-                if len(pos_ds) < n_pos_interactions:
-                    continue
-                interacted = rng.sample(pos_ds.values_list(['item', 'interaction']), n_pos_interactions)
-            best_item = None if len(interacted) == 0 else max(interacted, key=lambda p: -p['interaction'])['item']
-            interacted = [p['item'] for p in interacted]
-            if len(interacted) == 0:
+            drawn = sample_positives(user_ds, threshold, n_pos_interactions, random.Random(seed + offset))
+            if drawn is None or not drawn[0]:
                 continue
-            recommendations = [item for _, item in model.recommend(user, n=max(k), novelty=novelty, skip_invalid_items=True,
-                                                                   interaction_threshold=ignore_low_predictions_threshold)]
+            relevant, best, _ = drawn
+            ranked = model.recommend(user, n=max(ks), novelty=novelty, skip_invalid_items=True,
+                                     interaction_threshold=ignore_low_predictions_threshold)
+            recommendations = [item for _, item in ranked]
             relevancies = {item: (user_ds.select_one(f'item == {item}', ['interaction'], to_list=True) or 0)
-                           for item in set(interacted).union(set(recommendations))}
-        except Exception as e:
-            logging.error(e)
+                           for item in set(relevant) | set(recommendations)}
+        except Exception as err:          # the reference logs and skips the user
+            logging.error(err)
             continue
-        for m in metrics:
-            names = m.__call__.__code__.co_varnames
-            for k_ in k:
-                params = {}
-                for pn in names:
-                    if pn == 'recommendations': params[pn] = recommendations
-                    elif pn == 'relevant_recommendations': params[pn] = interacted
-                    elif pn == 'relevant_recommendation': params[pn] = best_item
-                    elif pn == 'relevancies': params[pn] = relevancies
-                    elif pn == 'k': params[pn] = k_
-                try:
-                    metric_sums[(m.name, k_)][0] += m(**params)
-                    metric_sums[(m.name, k_)][1] += 1
-                except Exception:
-                    pass
-    return {m + f'@{k_}': round(metric_sums[(m, k_)][0] / metric_sums[(m, k_)][1], 4) if metric_sums[(m, k_)][1] > 0 else 0
-            for m, k_ in metric_sums}
+        table.add(recommendations, relevant, best, relevancies)
+    return table.result()

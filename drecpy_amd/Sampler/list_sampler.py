@@ -1,17 +1,24 @@
-"""ListSampler with the reference's API and stream (DRecPy/Sampler/list_sampler.py:5-151): grouped, sorted, windowed
-record sequences with targets and sampled negative ids, as Caser consumes them (caser.py:72-84).
+"""ListSampler with the reference's API and stream (DRecPy/Sampler/list_sampler.py): grouped, sorted, windowed record
+sequences with targets and sampled negative ids, as Caser consumes them (caser.py:72-84).
 
-Host logic on stdlib `random.Random` (one MT19937 stream, list_sampler.py:69) over the column store: per-group row
-lists are built once (no `select()` scan per draw).  `rng.sample(set, k)` (list_sampler.py:147) depends on CPython's
-iteration order of a set of numpy integer scalars; the same objects are inserted in the same order here, so the stream
-is identical (checked against vectors recorded from the reference, tests/test_sampler.py).  Python >= 3.11 removed
-sampling from a set: the set is then materialised with `tuple()` exactly as 3.10's `random.sample` did.
+Host logic on stdlib `random.Random` (one MT19937 stream) over the column store.  The rows of every group are indexed
+once, so a draw costs O(group size) instead of a dataset scan.  `rng.sample(set, k)` in the reference depends on CPython's
+iteration order of a set of numpy integer scalars; `_eligible_negatives` builds the same set objects in the same order, and
+`tuple(set)` is what Python <= 3.10 did internally (3.11 removed sampling from sets).  The stream is checked against
+vectors recorded from the reference (tests/test_sampler.py::test_list_sampler_streams_match_reference).
+
+RNG call order per attempt: choice(group) -> [randint(window start)] -> [sample(negatives)]; an attempt that fails a
+size check is retried up to 20 times after the first (then raises).
 """
 import random
 
-import numpy as np
-
 from ..Dataset import InteractionDatasetABC
+
+
+class _Retry(Exception):
+    def __init__(self, hint):
+        super().__init__(hint)
+        self.hint = hint
 
 
 class ListSampler:
@@ -26,88 +33,86 @@ class ListSampler:
         assert interaction_dataset.has_internal_ids, \
             'The provided interaction dataset instance does not have internal ids assigned.'
         assert neg_ratio is not None, 'A neg_ratio value is required.'
-        assert isinstance(group_columns, list) and len(group_columns) > 0, 'group_columns must be a non-empty list.'
-        ds = interaction_dataset
-        self.interaction_dataset = ds
-        self.group_columns = group_columns
-        self.neg_ratio = neg_ratio
-        self.n_targets = n_targets
-        self.interaction_threshold = interaction_threshold
-        self.sort_column = sort_column
-        self.min_positive_records = min_positive_records
-        self.max_positive_records = max_positive_records
-        self.negative_ids_col = negative_ids_col
+        assert isinstance(group_columns, list) and group_columns, 'group_columns must be a non-empty list.'
+        self.interaction_dataset = ds = interaction_dataset
+        self.group_columns, self.negative_ids_col = group_columns, negative_ids_col
+        self.neg_ratio, self.n_targets = neg_ratio, n_targets
+        self.interaction_threshold, self.sort_column = interaction_threshold, sort_column
+        self.min_positive_records, self.max_positive_records = min_positive_records, max_positive_records
         self.rng = random.Random(seed)
-        self._cols = [c for c in ds.columns if c != 'rid']
-        # first-appearance-ordered unique groups / negative ids (dataset.unique keeps the first occurrence)
-        ug = ds.unique(group_columns)
-        if len(group_columns) == 1:
-            self.unique_groups = list(ug._cols[group_columns[0]])
-        else:
-            self.unique_groups = [[ug._cols[c][r] for c in group_columns] for r in range(len(ug))]
-        self.unique_negative_ids = set(ds.unique(negative_ids_col)._cols[negative_ids_col])
-        self._group_rows = {}
-        keys = zip(*[ds._cols[c].tolist() for c in group_columns])
-        for r, k in enumerate(keys):
-            self._group_rows.setdefault(k, []).append(r)
+        self._record_cols = [c for c in ds.columns if c != 'rid']
 
-    def _record(self, r):
+        # groups and negative ids in first-appearance order (Dataset.unique keeps first occurrences)
+        firsts = ds.unique(group_columns)
+        cols = [firsts._cols[c] for c in group_columns]
+        self.unique_groups = list(cols[0]) if len(cols) == 1 else [list(vals) for vals in zip(*cols)]
+        self.unique_negative_ids = set(ds.unique(negative_ids_col)._cols[negative_ids_col])
+        self._rows_of_group = {}
+        for row, key in enumerate(zip(*[ds._cols[c].tolist() for c in group_columns])):
+            self._rows_of_group.setdefault(key, []).append(row)
+
+    # ---- pieces of one draw -----------------------------------------------------------------------------------
+    def _as_record(self, row):
         ds = self.interaction_dataset
-        rec = {c: ds._cols[c][r] for c in self._cols}
-        rec['rid'] = ds._rid[r]
-        return rec
+        record = {c: ds._cols[c][row] for c in self._record_cols}
+        record['rid'] = ds._rid[row]
+        return record
+
+    def _positive_rows(self, group):
+        parts = group if isinstance(group, list) else [group]
+        rows = self._rows_of_group[tuple(p.item() if hasattr(p, 'item') else p for p in parts)]
+        if self.interaction_threshold is not None:
+            values = self.interaction_dataset._cols['interaction']
+            rows = [r for r in rows if values[r] >= self.interaction_threshold]
+        needed = self.min_positive_records + (self.n_targets or 0)
+        if len(rows) < self.min_positive_records or len(rows) < needed:
+            raise _Retry(f'consider reducing the min_group_records ({self.min_positive_records}).')
+        if self.sort_column is not None:
+            keys = self.interaction_dataset._cols[self.sort_column]
+            rows = sorted(rows, key=lambda r: keys[r])           # stable, like list.sort in the reference
+        return list(rows)
+
+    def _window_start(self, n_rows):
+        """Random start of the window of max_positive_records inputs (None when the group is not longer than that)."""
+        limit = self.max_positive_records
+        if limit is None or n_rows <= limit:
+            return None
+        return self.rng.randint(0, n_rows - limit - (self.n_targets or 0))
+
+    def _eligible_negatives(self, all_rows):
+        ids = self.interaction_dataset._cols[self.negative_ids_col]
+        return self.unique_negative_ids.difference(set([ids[r] for r in all_rows]))
+
+    def _draw_once(self):
+        rows = self._positive_rows(self.rng.choice(self.unique_groups))
+        start = self._window_start(len(rows))
+        inputs = rows if start is None else rows[start:start + self.max_positive_records]
+        if self.n_targets is None:
+            return [self._as_record(r) for r in inputs]
+        if start is None:        # reference quirk: without a window the split is inputs = first T, targets = the rest
+            inputs, targets = rows[:self.n_targets], rows[self.n_targets:]
+        else:
+            stop = start + self.max_positive_records
+            targets = rows[stop:stop + self.n_targets]
+        eligible = self._eligible_negatives(rows)
+        n_negatives = self.neg_ratio * len(targets)
+        if len(eligible) < n_negatives:
+            raise _Retry(f'consider reducing the neg_ratio ({self.neg_ratio}) or the n_targets ({self.n_targets}).')
+        negatives = self.rng.sample(tuple(eligible), n_negatives)
+        return [self._as_record(r) for r in inputs], [self._as_record(r) for r in targets], negatives
 
     def sample_group_records(self, n=16):
-        ds = self.interaction_dataset
-        inter = ds._cols['interaction']
+        """n draws: lists of input records (n_targets None) or (input records, target records, negative ids) triples."""
         out = []
-        for _ in range(n):
-            tries = 0
+        while len(out) < n:
+            failures = 0
             while True:
-                tries += 1
-                grp = self.rng.choice(self.unique_groups)
-                key = tuple(x.item() if hasattr(x, 'item') else x for x in (grp if isinstance(grp, list) else [grp]))
-                rows = self._group_rows[key]
-                pos = rows if self.interaction_threshold is None else \
-                    [r for r in rows if inter[r] >= self.interaction_threshold]
-                if len(pos) < self.min_positive_records or \
-                        (self.n_targets is not None and len(pos) < self.min_positive_records + self.n_targets):
-                    if tries > self.max_consecutive_tries:
-                        raise Exception(f'Failed to sample group records, max consecutive tries reached '
-                                        f'({self.max_consecutive_tries}): consider reducing the min_group_records '
-                                        f'({self.min_positive_records}).')
-                    continue
-                pos = list(pos)
-                if self.sort_column is not None:
-                    sc = ds._cols[self.sort_column]
-                    pos.sort(key=lambda r: sc[r])
-                all_pos = pos
-                padding = None
-                if self.max_positive_records is not None and len(pos) > self.max_positive_records:
-                    if self.n_targets is None:
-                        padding = self.rng.randint(0, len(pos) - self.max_positive_records)
-                    else:
-                        padding = self.rng.randint(0, len(pos) - self.max_positive_records - self.n_targets)
-                    pos = pos[padding:padding + self.max_positive_records]
-                if self.n_targets is None:
-                    out.append([self._record(r) for r in pos])
+                try:
+                    out.append(self._draw_once())
                     break
-                nid = ds._cols[self.negative_ids_col]
-                eligible = self.unique_negative_ids.difference(set([nid[r] for r in all_pos]))
-                if padding is None:
-                    targets = pos[self.n_targets:]
-                    pos = pos[:self.n_targets]
-                else:
-                    targets = all_pos[padding + self.max_positive_records:
-                                      padding + self.max_positive_records + self.n_targets]
-                k = self.neg_ratio * len(targets)
-                if len(eligible) < k:
-                    if tries > self.max_consecutive_tries:
-                        raise Exception(f'Failed to sample group records, max consecutive tries reached '
-                                        f'({self.max_consecutive_tries}): consider reducing the neg_ratio '
-                                        f'({self.neg_ratio}) or the n_targets ({self.n_targets}).')
-                    continue
-                negatives = self.rng.sample(tuple(eligible), k)      # == random.sample(set, k) of CPython <= 3.10
-                out.append(([self._record(r) for r in pos], [self._record(r) for r in targets], negatives))
-                break
+                except _Retry as retry:
+                    failures += 1
+                    if failures > self.max_consecutive_tries:
+                        raise Exception('Failed to sample group records, max consecutive tries reached '
+                                        f'({self.max_consecutive_tries}): {retry.hint}')
         return out
