@@ -83,7 +83,7 @@ SIGNATURES = {
     'drx_hash_u32': (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32]),
     'drx_cdae_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
-    'drx_cdae_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32]),
+    'drx_cdae_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32, C.c_int32]),
     'drx_cdae_step_dense': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch),
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     'drx_cdae_step_sparse': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch),

@@ -766,15 +766,16 @@ int drx_cdae_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBa
   return DRX_OK;
 }
 
-size_t drx_cdae_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots) {
+size_t drx_cdae_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t dense_mode) {
   if (!p || B < 1 || n_touch_slots < 0) return 0;
-  Carver c1(nullptr, 0);
-  (void)dense_layout(c1, *p, B, true);
-  Carver c2(nullptr, 0);
-  (void)sparse_layout(c2, *p, B, n_touch_slots);
-  (void)prep_layout(c2, *p, B, n_touch_slots);
-  size_t m = c1.off > c2.off ? c1.off : c2.off;
-  return align_up(m, 256) + 256;
+  Carver c(nullptr, 0);
+  if (dense_mode) {
+    (void)dense_layout(c, *p, B, true);
+  } else {
+    (void)sparse_layout(c, *p, B, n_touch_slots);
+    (void)prep_layout(c, *p, B, n_touch_slots);
+  }
+  return align_up(c.off, 256) + 256;
 }
 
 int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,

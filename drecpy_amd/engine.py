@@ -182,10 +182,11 @@ class CdaeEngine:
                    int(n_touch_slots))
         return bt, (uid, iid, y, keep_off, keep)
 
-    def _ensure_scratch(self, B, n_touch_slots):
-        need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, n_touch_slots)
+    def _ensure_scratch(self, B, n_touch_slots, dense=False):
+        need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, n_touch_slots, 1 if dense else 0)
         if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+            self._scratch = None
+            self._scratch = torch.empty(int(need * 1.1) + 1024, dtype=torch.uint8, device=self.device)
         return self._scratch
 
     # ---- calls ------------------------------------------------------------------------------
@@ -203,7 +204,7 @@ class CdaeEngine:
         """One reference-mode fit() iteration; `step` is the 0-based batch index (Adam t = 5*step+j+1)."""
         alphas = [self.adam_alpha(self.lr, 5 * step + j + 1) for j in range(5)]
         o = self._optim(alphas)
-        sc = self._ensure_scratch(bt.B, max(bt.n_touch_slots, 0))
+        sc = self._ensure_scratch(bt.B, max(bt.n_touch_slots, 0), dense=True)
         check(lib().drx_cdae_step_dense(
             C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
             _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE,

@@ -105,7 +105,9 @@ int drx_cdae_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBa
                      float *h, float *pred, void *stream);
 
 /* ---- scratch sizing ---------------------------------------------------------------------- */
-size_t drx_cdae_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots);
+/* dense_mode != 0: drx_cdae_step_dense (per-row batch bitmasks: grows with B * (n_users + n_items) / 8 bytes);
+ * dense_mode == 0: drx_cdae_step_sparse* (grows with the number of touches). */
+size_t drx_cdae_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t dense_mode);
 
 /* ---- one reference-mode training step ------------------------------------------------------
  * forward + Keras BCE/MSE against the batch-mean (or per-row) target over ALL output units +
