@@ -11,6 +11,10 @@
 #include "drx_rows.hpp"
 #include "drx_segreduce.hpp"
 
+#ifndef DRX_GATHER_ROWS
+#define DRX_GATHER_ROWS 8
+#endif
+
 namespace drx {
 
 // ------------------------------------------------------------------------------------------------
@@ -54,23 +58,21 @@ __device__ __forceinline__ void gather_bag(const DrxCdaeParams &P, const DrxHist
       }
     }
     const int n_here = (int)((e - c) < (int64_t)G ? (e - c) : (int64_t)G);
-    for (int t = 0; t < n_here; t += 4) {
-      int i0 = __shfl(idx, t, G), i1 = __shfl(idx, t + 1, G), i2 = __shfl(idx, t + 2, G), i3 = __shfl(idx, t + 3, G);
-      int k0 = __shfl(kf, t, G), k1 = __shfl(kf, t + 1, G), k2 = __shfl(kf, t + 2, G), k3 = __shfl(kf, t + 3, G);
-      k1 = (t + 1 < n_here) ? k1 : 0;
-      k2 = (t + 2 < n_here) ? k2 : 0;
-      k3 = (t + 3 < n_here) ? k3 : 0;
-      float4 r0[J], r1[J], r2[J], r3[J];
+    constexpr int NF = J == 1 ? DRX_GATHER_ROWS : 4;       // rows in flight per group
+    for (int t = 0; t < n_here; t += NF) {
+      float4 r[NF][J];
 #pragma unroll
-      for (int jx = 0; jx < J; ++jx) r0[jx] = r1[jx] = r2[jx] = r3[jx] = f4_zero();
-      if (k0) load_row<G, J>(P.W, (size_t)i0, P.ld, lane, r0);
-      if (k1) load_row<G, J>(P.W, (size_t)i1, P.ld, lane, r1);
-      if (k2) load_row<G, J>(P.W, (size_t)i2, P.ld, lane, r2);
-      if (k3) load_row<G, J>(P.W, (size_t)i3, P.ld, lane, r3);
+      for (int q = 0; q < NF; ++q) {
+        const int iq = __shfl(idx, t + q, G);
+        const int kq = (t + q < n_here) ? __shfl(kf, t + q, G) : 0;
 #pragma unroll
-      for (int jx = 0; jx < J; ++jx) {
-        f4_add(acc[jx], r0[jx]); f4_add(acc[jx], r1[jx]); f4_add(acc[jx], r2[jx]); f4_add(acc[jx], r3[jx]);
+        for (int jx = 0; jx < J; ++jx) r[q][jx] = f4_zero();
+        if (kq) load_row<G, J>(P.W, (size_t)iq, P.ld, lane, r[q]);
       }
+#pragma unroll
+      for (int q = 0; q < NF; ++q)
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) f4_add(acc[jx], r[q][jx]);
     }
   }
 }

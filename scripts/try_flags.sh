@@ -2,7 +2,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 for F in "$@"; do
-  for src in drx_cdae drx_shard; do
+  for src in drx_cdae drx_shard drx_generic; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $F -I include -I drecpy_amd/csrc -c drecpy_amd/csrc/$src.hip -o drecpy_amd/csrc/build/$src.hip.o
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o drecpy_amd/libdrx.so drecpy_amd/csrc/build/*.o
