@@ -202,7 +202,6 @@ __global__ __launch_bounds__(kBlock) void k_out_dense(DrxCdaeParams P, DrxOptim 
         tbar = (float)A.cnt[n] * invB;
       }
       store_row<G, J>(w_s, (size_t)r, ld, lane, w);
-#pragma unroll 4
       for (int b = 0; b < nb; ++b) {
         float d = 0.f;
 #pragma unroll
