@@ -138,3 +138,32 @@ def test_cdae_sampled_mode_with_device_sampler_learns():
     for a, b, t in zip(u.tolist(), i.tolist(), y.tolist()):
         assert ((a, b) in pos) == (t == 1.0)
     assert 0.75 < (y == 0).mean() < 0.9
+
+
+def test_save_load_and_predict_error_semantics(tmp_path):
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE, RecommenderABC
+    frame = _frame()
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    model = CDAE(hidden_factors=8, seed=10, verbose=False)
+    with pytest.raises(AssertionError):
+        model.predict(frame['user'][0], frame['item'][0])                  # not fitted yet
+    model.fit(ds, epochs=5, batch_size=16)
+    raw_u, raw_i = frame['user'][0], frame['item'][0]
+    p0 = model.predict(raw_u, raw_i)
+    with pytest.raises(AssertionError):
+        model.predict(10 ** 9, raw_i)                                       # unknown user
+    assert model.predict(10 ** 9, raw_i, skip_errors=True) is None
+    # reference quirk kept: an unknown ITEM with skip_errors=True reaches _predict(uid, None) = the whole row (cdae.py:88)
+    assert len(model.predict(raw_u, 10 ** 9, skip_errors=True)) == model.n_items
+    with pytest.raises(Exception):
+        model.rank(raw_u, [10 ** 9], skip_invalid_items=False)
+    with pytest.raises(AssertionError):
+        model.rank(raw_u, [raw_i], n=5)                                     # n larger than the candidate list
+    path = str(tmp_path / 'cdae.bin')
+    model.save(path)
+    again = RecommenderABC.load(path)
+    assert abs(again.predict(raw_u, raw_i) - p0) < 1e-7
+    a = model.recommend(raw_u, n=6, novelty=True)
+    b = again.recommend(raw_u, n=6, novelty=True)
+    assert [i for _, i in a] == [i for _, i in b]
