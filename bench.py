@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
+    ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
     return ap.parse_args()
 
 
@@ -137,7 +138,7 @@ def main():
     indptr, indices = synth.synth_history(U, N, md, mn, alpha, seed=0, device=dev, user_lo=lo, user_hi=hi)
     nnz_local = int(indptr[-1].item())
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         eng = CdaeEngine(hi - lo, N, K, device=dev)
         eng.init_glorot_device(10)
         eng.set_history(indptr, indices)
@@ -165,7 +166,7 @@ def main():
 
     # The touch list of a batch (sorted row keys) does not depend on the parameters: it is prepared for batch t+1 on a
     # side stream while batch t trains (single GPU; the sharded path prepares inline).
-    overlap = stepper is None and not args.no_overlap
+    overlap = not args.no_overlap
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream() if overlap else None
     prep_bufs = [None, None]
@@ -176,21 +177,27 @@ def main():
         bt, _ = structs[s % len(structs)]
         side.wait_event(step_done[s % 2])            # the buffer's previous user (step s-2) must be finished
         with torch.cuda.stream(side):
-            prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])
+            if stepper is not None:                  # local, collective-free part of the sharded step
+                prep_bufs[s % 2] = stepper.prepare(bt, consumer_stream=main)
+            else:
+                prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])
             prep_done[s % 2].record(side)
 
     def run_step(s, events=None, last=False):
         bt, _ = structs[s % len(structs)]
-        if stepper is not None:
-            stepper.step(s, bt, events=events)
-            return
         if not overlap:
-            eng.step_sparse(s, bt, 'bce', events=events)
+            if stepper is not None:
+                stepper.step(s, bt, events=events)
+            else:
+                eng.step_sparse(s, bt, 'bce', events=events)
             return
         if not last:
             prepare(s + 1)
         main.wait_event(prep_done[s % 2])
-        eng.step_sparse(s, bt, 'bce', events=events, prepared=prep_bufs[s % 2])
+        if stepper is not None:
+            stepper.step(s, bt, events=events, prepared=prep_bufs[s % 2])
+        else:
+            eng.step_sparse(s, bt, 'bce', events=events, prepared=prep_bufs[s % 2])
         step_done[s % 2].record(main)
 
     for e in step_done:
@@ -226,7 +233,7 @@ def main():
     # writes parameter + S optimizer slots per touched-row occurrence: 4K*R*(2+2S), S = 1 for Adagrad.
     alg_fwd = B * 4.0 * K * rows_per_sample
     alg_upd = B * 4.0 * K * rows_per_sample * 4.0
-    if world == 1:
+    if stepper is None:
         names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce',
                  'k_span_fixup', 'bias_update']
         dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)

@@ -538,8 +538,10 @@ struct DirectPolicy {
 // hidden bias b: column sums of dz1 in two deterministic stages, then a dense optimizer update.
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_bias_partial(int ld, int B, const float *__restrict__ dz1, float *__restrict__ part,
-                                                         int rows_per_block) {
+                                                         int rows_per_block, const float *__restrict__ lossb,
+                                                         float *__restrict__ loss_part) {
   extern __shared__ __align__(16) float lds[];   // [R, ld]
+  __shared__ float red[kBlock / 64];
   constexpr int R = kBlock / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
@@ -565,6 +567,12 @@ __global__ __launch_bounds__(kBlock) void k_bias_partial(int ld, int B, const fl
       for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
     }
     store_row<G, J>(part, (size_t)blockIdx.x, ld, lane, t);
+  }
+  if (loss_part) {                                 // this block's slice of the per-sample losses
+    float a = 0.f;
+    for (int b = b0 + (int)threadIdx.x; b < b1; b += kBlock) a += lossb[b];
+    const float tl = block_sum(a, red);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = tl;
   }
 }
 
@@ -601,9 +609,9 @@ __global__ __launch_bounds__(kBlock) void k_bias_final(DrxCdaeParams P, DrxOptim
     o.rb = 0.f;
     row_update<G, J>(o, P.b, opt.s1[3], opt.s2[3], 0, P.ld, lane, w, g);
   }
-  if (loss_out) {   // mean of the per-sample losses, fixed order
+  if (loss_out) {   // mean of the per-sample losses from the per-block partials, fixed order
     float a = 0.f;
-    for (int b = threadIdx.x; b < B; b += kBlock) a += lossb[b];
+    for (int b = threadIdx.x; b < n_part; b += kBlock) a += lossb[b];
     float t = block_sum(a, red);
     if (threadIdx.x == 0) { loss_out[0] = t / (float)B; loss_out[1] = 0.f; }
   }
@@ -698,7 +706,7 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.span_list = cv.take<uint32_t>(S.n_chunks);
   S.long_list = cv.take<uint32_t>(S.n_chunks);
   S.n_span = cv.take<uint32_t>(64);
-  S.bpart = cv.take<float>((size_t)S.n_bpart * P.ld);
+  S.bpart = cv.take<float>((size_t)S.n_bpart * (P.ld + 1));     // partial rows + per-block loss partials
   return S;
 }
 
@@ -901,9 +909,9 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
                        ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4, st, SB, pol);                                      \
     EV(4);                                                                                                             \
     hipLaunchKernelGGL((k_bias_partial<G, J>), dim3(n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B, \
-                       S.dz1, S.bpart, rows_per_block);                                                                \
+                       S.dz1, S.bpart, rows_per_block, S.lossb, loss_out ? S.bpart + (size_t)S.n_bpart * p->ld : nullptr);     \
     hipLaunchKernelGGL((k_bias_final<G, J>), dim3(1), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, bt->B,      \
-                       S.bpart, n_bpart, S.lossb, loss_out);                                                           \
+                       S.bpart, n_bpart, S.bpart + (size_t)S.n_bpart * p->ld, loss_out);                               \
     EV(5);                                                                                                             \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);

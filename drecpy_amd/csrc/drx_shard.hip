@@ -256,8 +256,10 @@ __global__ void k_iota(uint32_t *v, int n) {
 // ---- 7. hidden bias --------------------------------------------------------------------------------------------
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_colsum_partial(int ld, int B, const float *__restrict__ x, float *__restrict__ part,
-                                                           int rows_per_block) {
+                                                           int rows_per_block, const float *__restrict__ lossb,
+                                                           float *__restrict__ loss_part) {
   extern __shared__ __align__(16) float lds[];
+  __shared__ float red[kBlock / 64];
   constexpr int R = kBlock / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
@@ -284,9 +286,13 @@ __global__ __launch_bounds__(kBlock) void k_colsum_partial(int ld, int B, const 
     }
     store_row<G, J>(part, (size_t)blockIdx.x, ld, lane, t);
   }
+  float a = 0.f;                                   // this block's slice of the per-sample losses
+  for (int b = b0 + (int)threadIdx.x; b < b1; b += kBlock) a += lossb[b];
+  const float tl = block_sum(a, red);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = tl;
 }
 
-// out[0..ld) = sum of the n_part partial rows; out[ld] = sum(lossb)   (one workgroup, fixed order)
+// out[0..ld) = sum of the n_part partial rows; out[ld] = sum of the n_part loss partials   (one workgroup, fixed order)
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_colsum_final(int ld, const float *__restrict__ part, int n_part,
                                                          const float *__restrict__ lossb, int B, float *__restrict__ out) {
@@ -318,9 +324,10 @@ __global__ __launch_bounds__(kBlock) void k_colsum_final(int ld, const float *__
     store_row<G, J>(out, 0, ld, lane, t);
   }
   float a = 0.f;
-  for (int b = threadIdx.x; b < B; b += kBlock) a += lossb[b];
+  for (int i = threadIdx.x; i < n_part; i += kBlock) a += lossb[i];      // lossb = per-block loss partials here
   const float tl = block_sum(a, red);
   if (threadIdx.x == 0) out[ld] = tl;
+  (void)B;
 }
 
 template <int G, int J>
@@ -532,18 +539,19 @@ int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard 
 int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *lossb, int32_t B, float *out, void *scratch,
                         size_t scratch_bytes, void *stream) {
   if (!p || !dz1 || !lossb || !out || !scratch || B < 1) return DRX_EINVAL;
-  if (scratch_bytes < (size_t)256 * p->ld * 4) return DRX_ESCRATCH;
+  if (scratch_bytes < (size_t)256 * (p->ld + 1) * 4) return DRX_ESCRATCH;
   hipStream_t st = (hipStream_t)stream;
   float *part = (float *)scratch;
+  float *loss_part = part + (size_t)256 * p->ld;
   const int rows_per_block = (B + 255) / 256;
   const int n_part = (B + rows_per_block - 1) / rows_per_block;
 #define CALL(G, J)                                                                                                  \
   {                                                                                                                 \
     const int gpb = kBlock / G;                                                                                     \
     hipLaunchKernelGGL((k_colsum_partial<G, J>), dim3(n_part), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, B, dz1, \
-                       part, rows_per_block);                                                                       \
+                       part, rows_per_block, lossb, loss_part);                                                     \
     hipLaunchKernelGGL((k_colsum_final<G, J>), dim3(1), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, part, n_part,  \
-                       lossb, B, out);                                                                              \
+                       loss_part, B, out);                                                                          \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL

@@ -89,8 +89,17 @@ class HipShardOps:
         self._lib.check(self.L.drx_shard_index(C.byref(self.engine._params), C.byref(self.shard), p(keys), p(vals), T, p(ks),
                                                p(vs), p(ss), p(sp), p(uk), p(bounds), p(sc), sc.numel(), self._stream()),
                         'drx_shard_index')
-        return {'keys_s': ks, 'vals_s': vs, 'slot_sorted': ss, 'slot_of_pos': sp, 'uniq_keys': uk,
-                'bounds': bounds.cpu().tolist()}
+        host = torch.empty(self.world + 2, dtype=torch.int32, pin_memory=True)
+        host.copy_(bounds, non_blocking=True)          # read by bounds_of() after the stream (or its event) is reached
+        return {'keys_s': ks, 'vals_s': vs, 'slot_sorted': ss, 'slot_of_pos': sp, 'uniq_keys': uk, 'bounds_dev': bounds,
+                'bounds_host': host}
+
+    @staticmethod
+    def bounds_of(idx, event=None):
+        if 'bounds' not in idx:
+            (event.synchronize() if event is not None else torch.cuda.current_stream().synchronize())
+            idx['bounds'] = idx['bounds_host'].tolist()
+        return idx['bounds']
 
     def gather_rows(self, req):
         n = req.numel()
@@ -237,23 +246,41 @@ class ShardedCdae:
         return r.cpu().tolist()
 
     # ---- one step ------------------------------------------------------------------------------------------
-    def step(self, step, bt, events=None, want_loss=False):
+    def prepare(self, bt, consumer_stream=None):
+        """Parameter-independent, collective-free part of a step: touches of the local batch, stable sort, distinct
+        keys, slots, per-owner bounds.  May run on a side stream for batch t+1 while batch t trains; `consumer_stream`
+        is the stream that will later read the result (allocator bookkeeping)."""
+        keys, vals, bpos = self.ops.touches(bt)
+        idx = self.ops.index(keys, vals)
+        ev = None
+        if torch.is_tensor(keys) and keys.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            if consumer_stream is not None:
+                for t in [bpos] + [v for v in idx.values() if torch.is_tensor(v) and v.is_cuda]:
+                    t.record_stream(consumer_stream)
+        return {'idx': idx, 'bpos': bpos, 'event': ev, 'keys': keys, 'vals': vals}
+
+    def step(self, step, bt, events=None, want_loss=False, prepared=None):
         ops, W = self.ops, self.world
         b_norm = bt.B * W
         opt = ops.optim(step)
         rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
         rec(0)
-        keys, vals, bpos = ops.touches(bt)
-        idx = ops.index(keys, vals)
-        bounds = idx['bounds']
+        if prepared is None:
+            prepared = self.prepare(bt)
+        elif prepared['event'] is not None:
+            torch.cuda.current_stream().wait_event(prepared['event'])
+        idx, bpos = prepared['idx'], prepared['bpos']
+        bounds = ops.bounds_of(idx, prepared['event']) if hasattr(ops, 'bounds_of') else idx['bounds']
         send_counts = [bounds[o + 1] - bounds[o] for o in range(W)]
         q_item = bounds[W]
-        recv_counts = self._counts(send_counts, keys.device)
+        recv_counts = self._counts(send_counts, idx['uniq_keys'].device)
         req = self._a2a(idx['uniq_keys'][:q_item], send_counts, recv_counts)
         rows, b2v = ops.gather_rows(req)
         rows_cache = self._a2a(rows, recv_counts, send_counts)
         b2_cache = self._a2a(b2v, recv_counts, send_counts)
-        rec(1)        # [0,1): touches, index, row request/response exchange
+        rec(1)        # [0,1): (touches, index,) row request/response exchange
         ops.fwd_bwd(bt, idx['slot_of_pos'], rows_cache, b2_cache, b_norm, self.loss_kind)
         rec(2)        # [1,2): forward/backward
         gc, gb2c = ops.reduce(idx, bpos, q_item, b_norm, bt.q, opt)
