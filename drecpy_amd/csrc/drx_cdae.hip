@@ -416,6 +416,7 @@ struct SparseBufs {
   float *phead, *ptail;                       // [n_chunks, ld]
   float *phs, *pts;                           // [n_chunks] scalar (b2) partials
   uint32_t *span_list, *long_list;            // [n_chunks] each
+  uint8_t *cflag;                             // [n_chunks]
   uint32_t *n_span;                           // [0] crossing segments, [1] long ones
   float *bpart;                               // [n_bpart, ld]
   int T, n_chunks, n_bpart;
@@ -706,6 +707,7 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.span_list = cv.take<uint32_t>(S.n_chunks);
   S.long_list = cv.take<uint32_t>(S.n_chunks);
   S.n_span = cv.take<uint32_t>(64);
+  S.cflag = cv.take<uint8_t>(S.n_chunks);
   S.bpart = cv.take<float>((size_t)S.n_bpart * (P.ld + 1));     // partial rows + per-block loss partials
   return S;
 }
@@ -881,7 +883,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const uint32_t qthr = q_threshold(bt->q);
   const int rows_per_block = (bt->B + S.n_bpart - 1) / S.n_bpart;
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
-  SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.T, S.n_chunks, p->ld};
+  SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
   DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
 #define CALL(G, J)                                                                                                     \

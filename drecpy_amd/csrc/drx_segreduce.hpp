@@ -35,6 +35,8 @@ struct SegBufs {
   float *phs, *pts;                           // [n_chunks] scalar partials
   uint32_t *span_list, *long_list;            // [n_chunks] each
   uint32_t *n_span;                           // [0] crossing segments, [1] long ones (zeroed by the caller)
+  uint8_t *cflag;                             // [n_chunks] 0: chunk's first segment starts here; 2: the whole chunk is the
+                                              //   middle of one crossing segment; 1: it starts with the END of one
   int T, n_chunks, ld;
 };
 
@@ -137,6 +139,12 @@ __global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
   // the last segment ends at the chunk border iff the final touch of the chunk is a real key
   const bool ran_to_end = n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE;
   flush(ran_to_end);
+  if (lane == 0) {
+    const uint32_t first = n > 0 ? S.keys_s[start] : DRX_KEY_NONE, last = n > 0 ? S.keys_s[end - 1] : DRX_KEY_NONE;
+    const bool cont = first != DRX_KEY_NONE && first == prev_key;
+    const bool middle = cont && last == first && next_key == first;
+    S.cflag[g] = middle ? 2 : (cont ? 1 : 0);
+  }
 }
 
 // Fix-up of chunk-crossing segments, two tiers.
@@ -157,16 +165,20 @@ __global__ __launch_bounds__(kBlock) void k_span_short(SegBufs S, Policy pol) {
   for (uint32_t si = blockIdx.x * gpb + threadIdx.x / G; si < n_span; si += gridDim.x * gpb) {
     const int g0 = (int)S.span_list[si];
     const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
-    // m = number of following chunks that continue this segment; the lanes probe G chunk heads at a time
+    // m = number of following chunks that continue this segment: a run of "middle" chunks (flag 2), closed by an
+    // optional "end" chunk (flag 1); the lanes probe G one-byte chunk flags at a time
     int m = 0;
     bool is_long = false;
     for (int base = g0 + 1;; base += G) {
       const int c = base + lane;
-      const bool cont = c < S.n_chunks && S.keys_s[c * kChunk] == key;
-      const unsigned long long bits = (__ballot(cont) >> gshift) & gmask;
-      const int run = bits == gmask ? G : __builtin_ctzll(~bits);     // leading run of continuing chunks
+      const int fl = c < S.n_chunks ? (int)S.cflag[c] : 0;
+      const unsigned long long mid = (__ballot(fl == 2) >> gshift) & gmask;
+      const int run = mid == gmask ? G : __builtin_ctzll(~mid);       // leading run of middle chunks
       m += run;
-      if (run < G) break;
+      if (run < G) {
+        m += (__shfl(fl, run, G) == 1) ? 1 : 0;
+        break;
+      }
       if (m >= kShortSpan) { is_long = true; break; }
     }
     if (is_long || m > kShortSpan) {
@@ -211,20 +223,38 @@ __global__ __launch_bounds__(kFixBlock) void k_span_long(SegBufs S, Policy pol) 
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = f4_zero();
     float accs = 0.f;
+    // span length: all threads probe one-byte chunk flags, kFixBlock at a time (a run of "middle" chunks, closed by
+    // an optional "end" chunk); positions beyond the last chunk read as 0, so the loop always terminates
+    __shared__ int s_stop, s_len;
+    int len = 0;
+    for (int base = g0 + 1;; base += kFixBlock) {
+      if (threadIdx.x == 0) s_stop = kFixBlock;
+      __syncthreads();
+      const int c = base + (int)threadIdx.x;
+      const int fl = c < S.n_chunks ? (int)S.cflag[c] : 0;
+      if (fl != 2) atomicMin(&s_stop, (int)threadIdx.x);
+      __syncthreads();
+      const int stop = s_stop;
+      if (stop < kFixBlock) {
+        if ((int)threadIdx.x == stop) s_len = len + stop + (fl == 1 ? 1 : 0);
+        __syncthreads();
+        break;
+      }
+      len += kFixBlock;
+      __syncthreads();
+    }
+    const int m = s_len;
     constexpr int UL = J == 1 ? 8 : 2;        // partial rows in flight per group
-    for (int c = g0 + 1 + r; c < S.n_chunks; c += UL * R) {
-      if (S.keys_s[c * kChunk] != key) break;
+    for (int c = g0 + 1 + r; c <= g0 + m; c += UL * R) {
       float4 v[UL][J];
       float sv[UL];
-      bool ok[UL];
 #pragma unroll
       for (int u = 0; u < UL; ++u) {
         const int cu = c + u * R;
-        ok[u] = cu < S.n_chunks && S.keys_s[cu * kChunk] == key;     // contiguous run: false once, false after
         sv[u] = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) v[u][j] = f4_zero();
-        if (ok[u]) { load_row<G, J>(S.phead, (size_t)cu, S.ld, lane, v[u]); sv[u] = S.phs[cu]; }
+        if (cu <= g0 + m) { load_row<G, J>(S.phead, (size_t)cu, S.ld, lane, v[u]); sv[u] = S.phs[cu]; }
       }
 #pragma unroll
       for (int u = 0; u < UL; ++u) {
@@ -232,7 +262,6 @@ __global__ __launch_bounds__(kFixBlock) void k_span_long(SegBufs S, Policy pol) 
         for (int j = 0; j < J; ++j) f4_add(acc[j], v[u][j]);
         accs += sv[u];
       }
-      if (!ok[UL - 1]) break;
     }
     __syncthreads();
     store_row<G, J>(lds, (size_t)r, S.ld, lane, acc);

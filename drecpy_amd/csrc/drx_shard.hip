@@ -365,6 +365,7 @@ static SegLayout seg_layout(Carver &cv, int ld, int T, int sort_bits) {
   L.sb.span_list = cv.take<uint32_t>(n_chunks);
   L.sb.long_list = cv.take<uint32_t>(n_chunks);
   L.sb.n_span = cv.take<uint32_t>(64);
+  L.sb.cflag = cv.take<uint8_t>(n_chunks);
   L.idx = cv.take<uint32_t>(T);
   L.keys_s = cv.take<uint32_t>(T);
   L.vals_s = cv.take<uint32_t>(T);

@@ -167,3 +167,20 @@ def test_save_load_and_predict_error_semantics(tmp_path):
     a = model.recommend(raw_u, n=6, novelty=True)
     b = again.recommend(raw_u, n=6, novelty=True)
     assert [i for _, i in a] == [i for _, i in b]
+
+
+def test_rank_is_thread_safe():
+    """The reference evaluators call model.rank() from a 4-thread pool (ranking_evaluation.py:107-113)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    frame = _frame()
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    model = CDAE(hidden_factors=16, seed=1, verbose=False)
+    model.fit(ds, epochs=10, batch_size=32)
+    users = [ds.uid_to_user(u) for u in range(model.n_users)]
+    items = [ds.iid_to_item(i) for i in range(model.n_items)]
+    serial = [model.rank(u, items, novelty=True, n=7) for u in users]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        threaded = list(pool.map(lambda u: model.rank(u, items, novelty=True, n=7), users * 3))
+    assert threaded == serial * 3
