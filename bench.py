@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=65536, help='triples per GPU per step')
     ap.add_argument('--n-batches', type=int, default=8, help='distinct pre-sampled batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hr', action='store_true', help='skip the HR@10 sanity run (ml-100k-shaped set, reference mode)')
     ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
@@ -107,6 +108,36 @@ def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_c
     return {'value': n_cpu * n_done / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
             'sample': f'{n_done} steps of the first {n_cpu} triples of one bench batch (same tables, compacted to touched '
                       f'rows), NumPy restatement oracle/cdae_oracle.py:sparse_step, {dt:.1f} s, host has {os.cpu_count()} cpus'}
+
+
+def hr_at_10(dev):
+    """The HR@10 half of BASELINE.json's metric: CDAE in REFERENCE mode with the README configuration (K=50, q=0.2, BCE,
+    100 one-batch epochs of 64, lr 1e-3, reg 1e-3, neg_ratio 5, seed 10) on the ml-100k-shaped synthetic set, leave-10-out,
+    evaluated with the protocol of examples/cdae.py:15-17.  No MovieLens files exist offline: not comparable with
+    README.md:140-141 (0.5536 on the real ml-100k); an untrained model scores ~10/101."""
+    from drecpy_amd import synth
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Evaluation import leave_k_out, ranking_evaluation
+    from drecpy_amd.Recommender import CDAE
+    U, N, md, mn, a = synth.SHAPES['ml-100k']
+    ip, idx = synth.synth_history(U, N, md + 12, mn, a, seed=0)
+    ip, idx = ip.numpy(), idx.numpy()
+    rng = np.random.RandomState(0)
+    user = np.repeat(np.arange(U), np.diff(ip)) + 1
+    perm = rng.permutation(len(user))
+    ds = InteractionDataset.read_df({'user': user[perm], 'item': (idx.astype(np.int64) + 1)[perm],
+                                     'interaction': rng.randint(1, 6, size=len(user))[perm]}, verbose=False)
+    tr, te = leave_k_out(ds, k=10, min_user_interactions=10, seed=10, verbose=False)
+    m = CDAE(hidden_factors=50, corruption_level=0.2, loss='bce', seed=10, verbose=False, device=str(dev))
+    t0 = time.perf_counter()
+    m.fit(tr, epochs=100, batch_size=64, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
+    fit_s = time.perf_counter() - t0
+    res = ranking_evaluation(m, te, k=[1, 5, 10], novelty=True, n_test_users=100, n_pos_interactions=1, n_neg_interactions=100,
+                             generate_negative_pairs=True, seed=10, verbose=False)
+    return {'value': res['HitRatio@10'], 'ndcg_at_10': res['NDCG@10'], 'fit_seconds_100_steps_of_64': round(fit_s, 3),
+            'fit_samples_per_s_incl_host': round(6400 / fit_s, 1),
+            'setup': 'CDAE reference mode (dense Keras Adam), README.md:106-114 configuration, ml-100k-shaped synthetic '
+                     f'({len(tr)} train / {len(te)} test rows), protocol examples/cdae.py:15-17'}
 
 
 def main():
@@ -278,6 +309,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(eng, indptr, indices, (uid, iid, y, keep_off), seed)
         else:
             out['cpu_baseline'] = None
+        out['hr_at_10'] = hr_at_10(dev) if (world == 1 and not args.no_hr and not args.users) else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
