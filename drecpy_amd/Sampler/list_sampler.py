@@ -50,6 +50,10 @@ class ListSampler:
         self._rows_of_group = {}
         for row, key in enumerate(zip(*[ds._cols[c].tolist() for c in group_columns])):
             self._rows_of_group.setdefault(key, []).append(row)
+        # per-group results that do not depend on the RNG (sorted positive rows, eligible-negative tuple) are memoised:
+        # a group is drawn many times over a fit (4096 draws per step over a few thousand users in examples/caser.py)
+        self._memo_rows, self._memo_negs = {}, {}
+        self._memo_budget = 60_000_000          # cached tuple slots (about 0.5 GB of references) before caching stops
 
     # ---- pieces of one draw -----------------------------------------------------------------------------------
     def _as_record(self, row):
@@ -58,9 +62,25 @@ class ListSampler:
         record['rid'] = ds._rid[row]
         return record
 
-    def _positive_rows(self, group):
+    def _group_key(self, group):
         parts = group if isinstance(group, list) else [group]
-        rows = self._rows_of_group[tuple(p.item() if hasattr(p, 'item') else p for p in parts)]
+        return tuple(p.item() if hasattr(p, 'item') else p for p in parts)
+
+    def _positive_rows(self, group):
+        key = self._group_key(group)
+        hit = self._memo_rows.get(key)
+        if hit is None:
+            try:
+                hit = self._positive_rows_uncached(key)
+            except _Retry as retry:
+                hit = retry
+            self._memo_rows[key] = hit
+        if isinstance(hit, _Retry):
+            raise hit
+        return hit
+
+    def _positive_rows_uncached(self, key):
+        rows = self._rows_of_group[key]
         if self.interaction_threshold is not None:
             values = self.interaction_dataset._cols['interaction']
             rows = [r for r in rows if values[r] >= self.interaction_threshold]
@@ -79,12 +99,21 @@ class ListSampler:
             return None
         return self.rng.randint(0, n_rows - limit - (self.n_targets or 0))
 
-    def _eligible_negatives(self, all_rows):
-        ids = self.interaction_dataset._cols[self.negative_ids_col]
-        return self.unique_negative_ids.difference(set([ids[r] for r in all_rows]))
+    def _eligible_negatives(self, group, all_rows):
+        """tuple(set) of the candidate negative ids of a group, in CPython's set iteration order."""
+        key = self._group_key(group)
+        hit = self._memo_negs.get(key)
+        if hit is None:
+            ids = self.interaction_dataset._cols[self.negative_ids_col]
+            hit = tuple(self.unique_negative_ids.difference(set([ids[r] for r in all_rows])))
+            if self._memo_budget >= len(hit):
+                self._memo_budget -= len(hit)
+                self._memo_negs[key] = hit
+        return hit
 
     def _draw_once(self):
-        rows = self._positive_rows(self.rng.choice(self.unique_groups))
+        group = self.rng.choice(self.unique_groups)
+        rows = self._positive_rows(group)
         start = self._window_start(len(rows))
         inputs = rows if start is None else rows[start:start + self.max_positive_records]
         if self.n_targets is None:
@@ -94,11 +123,11 @@ class ListSampler:
         else:
             stop = start + self.max_positive_records
             targets = rows[stop:stop + self.n_targets]
-        eligible = self._eligible_negatives(rows)
+        eligible = self._eligible_negatives(group, rows)
         n_negatives = self.neg_ratio * len(targets)
         if len(eligible) < n_negatives:
             raise _Retry(f'consider reducing the neg_ratio ({self.neg_ratio}) or the n_targets ({self.n_targets}).')
-        negatives = self.rng.sample(tuple(eligible), n_negatives)
+        negatives = self.rng.sample(eligible, n_negatives)
         return [self._as_record(r) for r in inputs], [self._as_record(r) for r in targets], negatives
 
     def sample_group_records(self, n=16):
