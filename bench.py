@@ -2,12 +2,17 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synth-10m|ml-1m|ml-100k] [--batch B]
 
-A "step" is one pass of the hot path over one batch of B (u, i, y) triples per GPU: counter-based point sampling is done
-ahead of time (batches resident in HBM), the timed region runs gather + hidden layer + sampled output unit + BCE +
-backward + sparse-Adagrad update (drx_cdae_step_sparse).  One process per GPU; for N > 1 launch with
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RCCL over xGMI, user-sharded tables).
+A "step" is one pass of the hot path over one batch of B (u, i, y) triples per GPU: gather + hidden layer + sampled
+output unit + BCE + backward + sparse-Adagrad update (drx_cdae_step_sparse_prepared).  At 1 GPU every step trains on a
+FRESH batch drawn by the device PointSampler (drx_point_sample) two steps ahead on a side stream, and the batch's sorted
+touch list (drx_cdae_sparse_prepare) is built one step ahead on the same side stream — both depend only on the data,
+never on the parameters — so the timed region is the whole training loop including sampling (`--presampled` cycles
+through batches sampled at setup instead: +2.5 %).  All inputs live in HBM; nothing crosses PCIe in the timed region
+except one 4-byte touch count per step.  One process per GPU; for N > 1 launch with
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RCCL over xGMI, user-sharded tables,
+pre-sampled batches).
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline).
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline / hr_at_10).
 """
 import argparse
 import json
@@ -35,7 +40,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='synth-10m', choices=['synth-10m', 'ml-1m', 'ml-100k'])
     ap.add_argument('--batch', type=int, default=65536, help='triples per GPU per step')
-    ap.add_argument('--n-batches', type=int, default=8, help='distinct pre-sampled batches cycled through')
+    ap.add_argument('--n-batches', type=int, default=8, help='batches sampled at setup (R estimate, CPU baseline; cycled with --presampled)')
+    ap.add_argument('--presampled', action='store_true', help='cycle through the setup batches instead of sampling a fresh batch every step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hr', action='store_true', help='skip the HR@10 sanity run (ml-100k-shaped set, reference mode)')
     ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
@@ -204,8 +210,39 @@ def main():
     prep_done = [torch.cuda.Event(), torch.cuda.Event()]
     step_done = [torch.cuda.Event(), torch.cuda.Event()]
 
+    fresh = overlap and stepper is None and not args.presampled
+    # fresh mode: the device PointSampler draws a NEW batch for every step, two steps ahead on the side stream; its touch
+    # count comes back through pinned memory (event-synchronised, off the critical path) and sizes the sort of `prepare`.
+    ring = [eng.sample_device(B, NEG_RATIO, 1, n_items=N) for _ in range(3)] if fresh else None
+    ring_T = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(3)] if fresh else None
+    ring_ev = [torch.cuda.Event() for _ in range(3)]
+    ring_free = [torch.cuda.Event() for _ in range(3)]
+    ring_bt = [None, None, None]
+
+    def seed_of(s):
+        return 5000 + 7919 * s + 104729 * rank
+
+    def sample(s):
+        k = s % 3
+        side.wait_event(ring_free[k])                # the slot's previous batch (step s-3) has been consumed
+        with torch.cuda.stream(side):
+            eng.sample_device(B, NEG_RATIO, seed_of(s), n_items=N, out=ring[k])
+            ring_T[k].copy_(ring[k][3][-1:], non_blocking=True)
+            ring_ev[k].record(side)
+
+    def batch_of(s):
+        if not fresh:
+            return structs[s % len(structs)][0]
+        k = s % 3
+        if ring_bt[k] is None or ring_bt[k][0] != s:
+            ring_ev[k].synchronize()                 # host wait on the tiny D2H issued two steps ago
+            uid, iid, y, keep_off = ring[k]
+            bt, alive = eng.make_batch(uid, iid, y, keep_off=keep_off, q=Q, mask_seed=seed_of(s), n_touch_slots=int(ring_T[k][0]))
+            ring_bt[k] = (s, bt, alive)
+        return ring_bt[k][1]
+
     def prepare(s):
-        bt, _ = structs[s % len(structs)]
+        bt = batch_of(s)
         side.wait_event(step_done[s % 2])            # the buffer's previous user (step s-2) must be finished
         with torch.cuda.stream(side):
             if stepper is not None:                  # local, collective-free part of the sharded step
@@ -215,24 +252,32 @@ def main():
             prep_done[s % 2].record(side)
 
     def run_step(s, events=None, last=False):
-        bt, _ = structs[s % len(structs)]
         if not overlap:
+            bt = batch_of(s)
             if stepper is not None:
                 stepper.step(s, bt, events=events)
             else:
                 eng.step_sparse(s, bt, 'bce', events=events)
             return
+        if fresh and not last:
+            sample(s + 2)
         if not last:
             prepare(s + 1)
+        bt = batch_of(s)
         main.wait_event(prep_done[s % 2])
         if stepper is not None:
             stepper.step(s, bt, events=events, prepared=prep_bufs[s % 2])
         else:
             eng.step_sparse(s, bt, 'bce', events=events, prepared=prep_bufs[s % 2])
         step_done[s % 2].record(main)
+        if fresh:
+            ring_free[s % 3].record(main)
 
-    for e in step_done:
+    for e in step_done + ring_free:
         e.record(main)
+    if fresh:
+        sample(0)
+        sample(1)
     if overlap:
         prepare(0)
     for s in range(args.warmup):
@@ -295,6 +340,8 @@ def main():
                                    f'corruption {Q}, neg_ratio {NEG_RATIO}',
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
                        'touch_list': 'prepared one batch ahead on a side stream' if overlap else 'inline',
+                       'batches': 'fresh device-sampled batch every step (sampler two steps ahead on the side stream)' if fresh
+                       else f'{args.n_batches} pre-sampled batches cycled',
                        'sharding': 'single GPU' if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

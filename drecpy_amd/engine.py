@@ -247,12 +247,12 @@ class CdaeEngine:
                   'drx_cdae_step_sparse_timed')
         return self._loss if want_loss else None
 
-    def sample_device(self, B, neg_ratio, seed, n_items=None):
-        """Throughput-mode PointSampler on the GPU: returns device tensors (uid, iid, y, keep_off)."""
-        uid = torch.empty(B, dtype=torch.int32, device=self.device)
-        iid = torch.empty(B, dtype=torch.int32, device=self.device)
-        y = torch.empty(B, dtype=torch.float32, device=self.device)
-        keep_off = torch.empty(B + 1, dtype=torch.int32, device=self.device)
+    def sample_device(self, B, neg_ratio, seed, n_items=None, out=None):
+        """Throughput-mode PointSampler on the GPU: returns device tensors (uid, iid, y, keep_off); `out` reuses them."""
+        if out is None:
+            out = (torch.empty(B, dtype=torch.int32, device=self.device), torch.empty(B, dtype=torch.int32, device=self.device),
+                   torch.empty(B, dtype=torch.float32, device=self.device), torch.empty(B + 1, dtype=torch.int32, device=self.device))
+        uid, iid, y, keep_off = out
         need = lib().drx_point_sample_scratch_bytes(B)
         if getattr(self, '_sscratch', None) is None or self._sscratch.numel() < need:
             self._sscratch = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -260,7 +260,7 @@ class CdaeEngine:
                                      int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y), ptr(keep_off),
                                      ptr(self._sscratch), self._sscratch.numel(), stream_ptr(self.device)),
               'drx_point_sample')
-        return uid, iid, y, keep_off
+        return out
 
     def topk(self, scores, k, cand_mask=None):
         """Row-wise top-k with heapq.nlargest((score, iid)) ordering (cdae.py:103)."""
