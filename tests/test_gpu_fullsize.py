@@ -1,0 +1,87 @@
+"""Size-independent properties of the sampled step at BASELINE sizes (no oracle can follow at this scale):
+  * ml-1m-shaped (config 1 of BASELINE.json: U=6040, N=3706, K=128) and a 1M-user x 1M-item slice of the 10M x 1M set
+  * bit-reproducibility of a step sequence, `prepared` (side-stream) == inline touch lists bit for bit,
+    rows no triple touches keep their bits (parameters AND optimizer slots), the row-sharded path at world 1 agrees with
+    the direct path, the forward of a user is the same whether it is computed alone or inside a large batch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(shape, users=None, K=128):
+    from drecpy_amd import synth
+    from drecpy_amd.engine import CdaeEngine
+    U, N, md, mn, a = synth.SHAPES[shape]
+    U = users or U
+    ip, idx = synth.synth_history(U, N, md, mn, a, seed=0, device='cuda', user_hi=U)
+    eng = CdaeEngine(U, N, K)
+    eng.init_glorot_device(10)
+    eng.set_history(ip, idx)
+    eng.init_optimizer('adagrad', 0.05, 1e-3)
+    return eng, U, N, ip, idx
+
+
+def _run(eng, N, B, steps, prepared):
+    for s in range(steps):
+        uid, iid, y, ko = eng.sample_device(B, 5, 100 + s, n_items=N)
+        bt, alive = eng.make_batch(uid, iid, y, keep_off=ko, q=0.2, mask_seed=7 + s)
+        prep = eng.prepare_sparse(bt) if prepared else None
+        eng.step_sparse(s, bt, prepared=prep)
+    torch.cuda.synchronize()
+    return [t.clone() for t in eng.tables()] + [t.clone() for t in eng.s1]
+
+
+@pytest.mark.parametrize('shape,users,B', [('ml-1m', None, 16384), ('synth-10m', 1_000_000, 65536)])
+def test_full_size_properties(shape, users, B):
+    eng, U, N, ip, idx = _setup(shape, users)
+    a = _run(eng, N, B, 3, prepared=False)
+    eng2, _, _, _, _ = _setup(shape, users)
+    b = _run(eng2, N, B, 3, prepared=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)                       # deterministic, and prepared == inline bit for bit
+    # rows that no triple of a further step touches keep their bits (parameters and Adagrad accumulators)
+    before = [t.clone() for t in eng.tables()] + [t.clone() for t in eng.s1]
+    uid, iid, y, ko = eng.sample_device(B, 5, 999, n_items=N)
+    bt, alive = eng.make_batch(uid, iid, y, keep_off=ko, q=0.0, mask_seed=1)       # q = 0: every history item is touched
+    eng.step_sparse(3, bt)
+    torch.cuda.synchronize()
+    after = [t.clone() for t in eng.tables()] + [t.clone() for t in eng.s1]
+    touched_u = torch.zeros(U, dtype=torch.bool, device='cuda'); touched_u[uid.long()] = True
+    touched_o = torch.zeros(N, dtype=torch.bool, device='cuda'); touched_o[iid.long()] = True
+    touched_w = torch.zeros(N, dtype=torch.bool, device='cuda')
+    deg = (ip[uid.long() + 1] - ip[uid.long()])
+    rows = torch.repeat_interleave(ip[uid.long()], deg) + (torch.arange(int(deg.sum()), device='cuda') - torch.repeat_interleave(torch.cumsum(deg, 0) - deg, deg))
+    touched_w[idx[rows].long()] = True
+    for off in (0, 5):                                    # parameters, then optimizer slots
+        W0, O0, V0, _, b20 = before[off:off + 5]
+        W1, O1, V1, _, b21 = after[off:off + 5]
+        assert torch.equal(W0[~touched_w], W1[~touched_w]) and torch.equal(O0[~touched_o], O1[~touched_o])
+        assert torch.equal(V0[~touched_u], V1[~touched_u]) and torch.equal(b20[~touched_o], b21[~touched_o])
+        if off == 0:        # (g^2 of a single user's row can vanish against the 0.1 accumulator in fp32: parameters only)
+            assert not torch.equal(W0[touched_w], W1[touched_w]) and not torch.equal(V0[touched_u], V1[touched_u])
+    # a user's forward does not depend on its batch neighbours
+    probe = torch.randint(0, U, (4096,), device='cuda', dtype=torch.int32)
+    h_big, _ = eng.forward(probe, want_pred=False)
+    h_one, _ = eng.forward(probe[17:18], want_pred=False)
+    assert torch.equal(h_big[17], h_one[0]) or float((h_big[17] - h_one[0]).abs().max()) < 1e-6
+
+
+def test_sharded_world1_agrees_with_direct_at_scale():
+    from drecpy_amd import synth
+    from drecpy_amd.dist import ShardedCdae
+    eng, U, N, ip, idx = _setup('synth-10m', 500_000)
+    m = ShardedCdae(U, N, 128, 0, 1, 'cuda:0', ip, idx, q=0.2)
+    for dst, src in zip(m.engine.tables(), eng.tables()):
+        dst.copy_(src)
+    B = 32768
+    for s in range(2):
+        uid, iid, y, ko = eng.sample_device(B, 5, 50 + s, n_items=N)
+        bt, alive = eng.make_batch(uid, iid, y, keep_off=ko, q=0.2, mask_seed=3 + s)
+        eng.step_sparse(s, bt)
+        bt2, alive2 = m.engine.make_batch(uid, iid, y, keep_off=ko, q=0.2, mask_seed=3 + s)
+        m.step(s, bt2)
+    torch.cuda.synchronize()
+    for name, x, y in zip(('W', 'W2T', 'V', 'b', 'b2'), eng.tables(), m.engine.tables()):
+        assert float((x - y).abs().max()) < 2e-6, name        # same sums, different chunking of the sorted touches
