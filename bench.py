@@ -346,6 +346,10 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms),
+                         # DRAM rate actually sustained = PMC bytes / measured duration (duplicate rows of a batch are
+                         # reduced before the read-modify-write and gradient rows re-read from L2, so traffic < algorithmic)
+                         'traffic_rate': (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+                         'traffic_frac': (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
                          'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             'phases_ms': {n: float(v) for n, v in zip(names, ph)},

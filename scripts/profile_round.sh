@@ -1,0 +1,23 @@
+#!/bin/bash
+# One GPU-box call: bench line + kernel-trace stats + the two PMC passes (separate runs, per the microarch guide).
+# Usage (through gpurun): bash scripts/profile_round.sh <tag>
+set -u
+TAG=${1:-r01f}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-hr > $OUT/kt_bench.json 2> $OUT/kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hr > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hr > /dev/null 2> $OUT/pmc_write.err
+cd $ROOT
+find $OUT -name '*.csv' | head -20
+python profiles/pmc_summary.py $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) $OUT/pmc_traffic_raw.json
+# keep only the small summaries
+find $OUT -name '*kernel_trace.csv' -delete
+find $OUT -size +4M -delete
+tail -5 $OUT/kt.err
+du -sh $ROOT/gpurun_out
+ls -la $OUT
