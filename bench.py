@@ -157,6 +157,11 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     import torch.distributed as dist
+    rccl1 = world == 1 and os.environ.get('DRX_BENCH_RCCL1') == '1'     # debugging aid: 1-rank RCCL communicator, real collectives
+    if rccl1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29455')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        dist.init_process_group('nccl', device_id=dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if debug_gloo:
@@ -184,7 +189,7 @@ def main():
     else:
         from drecpy_amd.dist import ShardedCdae
         stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
-                              cpu_staging=debug_gloo)
+                              cpu_staging=debug_gloo, force_collectives=(world == 1 and os.environ.get('DRX_BENCH_RCCL1') == '1'))
         eng = stepper.engine
 
     # ---- pre-sampled batches, resident in HBM -------------------------------------------------------------
@@ -362,7 +367,7 @@ def main():
             out['cpu_baseline'] = None
         out['hr_at_10'] = hr_at_10(dev) if (world == 1 and not args.no_hr and not args.users) else None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rccl1:
         dist.destroy_process_group()
 
 

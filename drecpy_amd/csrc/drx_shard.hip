@@ -249,6 +249,75 @@ struct OwnerPolicy {
   }
 };
 
+// The rows a rank receives are W segments (one per source rank, in rank order), each with ascending DISTINCT keys.  Instead
+// of sorting them again, every received row is entered in a direct-address table tab[local key][source] = row index
+// (no two writers per entry); then the row of the LOWEST source holding a key sums all holders in source order and
+// applies the optimizer — one pass, fixed summation order, no sort, no atomics.
+struct SegOff { int off[DRX_MAX_WORLD + 1]; };
+
+__device__ __forceinline__ int source_of(const SegOff &so, int world, int j) {
+  int s = 0;
+  while (s + 1 < world && j >= so.off[s + 1]) ++s;
+  return s;
+}
+
+__global__ void k_owner_scatter(DrxShard sh, SegOff so, const uint32_t *__restrict__ recv_keys, int n, uint32_t *tab) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t lk = recv_keys[j] - (uint32_t)(sh.rank * 2 * sh.items_per_rank);
+    tab[(size_t)lk * sh.world + source_of(so, sh.world, j)] = (uint32_t)j;
+  }
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_owner_apply(OwnerPolicy pol, SegOff so, const uint32_t *__restrict__ recv_keys, int n,
+                                                        const uint32_t *__restrict__ tab) {
+  const int lane = threadIdx.x % G;
+  const int gpb = kBlock / G;
+  const int W = pol.sh.world;
+  for (int j = blockIdx.x * gpb + threadIdx.x / G; j < n; j += gridDim.x * gpb) {
+    const uint32_t key = recv_keys[j];
+    const uint32_t lk = key - (uint32_t)(pol.sh.rank * 2 * pol.sh.items_per_rank);
+    const uint32_t *row_tab = tab + (size_t)lk * W;
+    float4 g[J];
+#pragma unroll
+    for (int jx = 0; jx < J; ++jx) g[jx] = f4_zero();
+    float gs = 0.f;
+    bool leader = true, first = true;
+    for (int s0 = 0; s0 < W && leader; s0 += G) {                 // G sources at a time, one table entry per lane
+      const uint32_t e = (s0 + lane < W) ? row_tab[s0 + lane] : DRX_KEY_NONE;
+      const int n_here = min(G, W - s0);
+      for (int t = 0; t < n_here; t += 4) {
+        uint32_t r[4];
+        float4 v[4][J];
+        float sc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          r[q] = (t + q < n_here) ? (uint32_t)__shfl((int)e, t + q, G) : DRX_KEY_NONE;
+          sc[q] = 0.f;
+#pragma unroll
+          for (int jx = 0; jx < J; ++jx) v[q][jx] = f4_zero();
+        }
+        if (first) {                                               // the first holder must be this very row
+          uint32_t r0 = DRX_KEY_NONE;
+#pragma unroll
+          for (int q = 3; q >= 0; --q) if (r[q] != DRX_KEY_NONE) r0 = r[q];
+          if (r0 != DRX_KEY_NONE) { first = false; if (r0 != (uint32_t)j) { leader = false; break; } }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (r[q] != DRX_KEY_NONE) { load_row<G, J>(pol.recv_rows, (size_t)r[q], pol.P.ld, lane, v[q]); sc[q] = pol.recv_b2[r[q]]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int jx = 0; jx < J; ++jx) f4_add(g[jx], v[q][jx]);
+          gs += sc[q];
+        }
+      }
+    }
+    if (leader && !first) pol.template finish<G, J>(key, 0, lane, g, gs);
+  }
+}
+
 __global__ void k_iota(uint32_t *v, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = (uint32_t)i;
 }
@@ -380,12 +449,16 @@ static SegLayout seg_layout(Carver &cv, int ld, int T, int sort_bits) {
   return L;
 }
 
+static uint32_t *owner_table(Carver &cv, const DrxShard &sh) {
+  return cv.take<uint32_t>((size_t)2 * sh.items_per_rank * sh.world);
+}
+
 static int key_bits(const DrxShard &sh) {
   return bits_for((uint64_t)sh.world * 2 * sh.items_per_rank + (uint64_t)sh.n_users_local + 1);
 }
 
 static int check_shard(const DrxShard *sh) {
-  if (!sh || sh->world < 1 || sh->rank < 0 || sh->rank >= sh->world || sh->items_per_rank < 1 || sh->n_items < 1 ||
+  if (!sh || sh->world < 1 || sh->world > DRX_MAX_WORLD || sh->rank < 0 || sh->rank >= sh->world || sh->items_per_rank < 1 || sh->n_items < 1 ||
       sh->n_users_local < 1)
     return DRX_EINVAL;
   if ((uint64_t)sh->world * 2 * sh->items_per_rank + (uint64_t)sh->n_users_local + 1 >= 0xFFFFFFFFull) return DRX_EINVAL;
@@ -423,6 +496,7 @@ size_t drx_shard_scratch_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32
   if (!p || check_shard(sh) || n_touches < 0) return 0;
   Carver cv(nullptr, 0);
   (void)seg_layout(cv, p->ld, n_touches, key_bits(*sh));
+  (void)owner_table(cv, *sh);
   return align_up(cv.off, 256) + 256;
 }
 
@@ -519,22 +593,35 @@ int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard
 }
 
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *recv_rows, const float *recv_b2, int32_t n, void *scratch, size_t scratch_bytes,
-                    void *stream) {
-  if (!p || !opt || check_shard(sh) || n < 0 || b_norm < 1 || !scratch) return DRX_EINVAL;
+                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, void *scratch,
+                    size_t scratch_bytes, void *stream) {
+  if (!p || !opt || check_shard(sh) || n < 0 || b_norm < 1 || !scratch || !recv_counts) return DRX_EINVAL;
   if (n == 0) return DRX_OK;
   if (!recv_keys || !recv_rows || !recv_b2) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  SegOff so{};
+  for (int s = 0; s < sh->world; ++s) {
+    if (recv_counts[s] < 0) return DRX_EINVAL;
+    so.off[s + 1] = so.off[s] + recv_counts[s];
+  }
+  if (so.off[sh->world] != n) return DRX_EINVAL;
   Carver cv(scratch, scratch_bytes);
-  SegLayout L = seg_layout(cv, p->ld, n, key_bits(*sh));
+  uint32_t *tab = owner_table(cv, *sh);
   if (!cv.ok()) return DRX_ESCRATCH;
-  hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, st, L.idx, n);
-  // stable sort: duplicates of one row keep their arrival (= source rank) order -> fixed summation order
-  int rc = sort_pairs(L.sort_temp, L.sort_bytes, recv_keys, L.keys_s, L.idx, L.vals_s, (size_t)n, key_bits(*sh), st);
-  if (rc) return rc;
-  L.sb.keys_s = L.keys_s; L.sb.vals_s = L.vals_s;
+  DRX_HIP(hipMemsetAsync(tab, 0xFF, (size_t)2 * sh->items_per_rank * sh->world * 4, st));
+  hipLaunchKernelGGL(k_owner_scatter, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, *sh, so, recv_keys, n, tab);
   OwnerPolicy pol{*p, *opt, *sh, b_norm, recv_rows, recv_b2};
-  return run_segreduce(*p, L.sb, pol, st);
+#define CALL(G, J)                                                                                                     \
+  {                                                                                                                    \
+    const int gpb = kBlock / G;                                                                                        \
+    int blocks = (n + gpb - 1) / gpb;                                                                                  \
+    if (blocks > 8192) blocks = 8192;                                                                                  \
+    hipLaunchKernelGGL((k_owner_apply<G, J>), dim3(blocks), dim3(kBlock), 0, st, pol, so, recv_keys, n, tab);          \
+  }
+  DRX_DISPATCH_GEOM(p->ld, CALL);
+#undef CALL
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
 }
 
 int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *lossb, int32_t B, float *out, void *scratch,

@@ -131,15 +131,16 @@ class HipShardOps:
                                                 self._stream()), 'drx_shard_reduce')
         return gc[:q_item], gb2c[:q_item]
 
-    def apply(self, recv_keys, recv_rows, recv_b2, b_norm, opt):
+    def apply(self, recv_keys, recv_rows, recv_b2, b_norm, opt, recv_counts):
         n = recv_keys.numel()
         if n == 0:
             return
         sc = self._sc(n)
         p = self._lib.ptr
+        counts = (C.c_int32 * self.world)(*[int(c) for c in recv_counts])
         self._lib.check(self.L.drx_shard_apply(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), b_norm,
-                                               p(recv_keys), p(recv_rows.contiguous()), p(recv_b2.contiguous()), n, p(sc),
-                                               sc.numel(), self._stream()), 'drx_shard_apply')
+                                               p(recv_keys), p(recv_rows.contiguous()), p(recv_b2.contiguous()), n, counts,
+                                               p(sc), sc.numel(), self._stream()), 'drx_shard_apply')
 
     def bias_grad(self, B):
         out = self._e(self.ld + 1)
@@ -172,8 +173,11 @@ class ShardedCdae:
     """One rank of the row-sharded sampled-mode CDAE.  `ops` = per-rank compute backend (HipShardOps on a GPU)."""
 
     def __init__(self, n_users_total, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
-                 optimizer='adagrad', ops=None, group=None, loss='bce', q=0.2, cpu_staging=False):
+                 optimizer='adagrad', ops=None, group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False):
         self.rank, self.world, self.group = rank, world, group
+        # world 1 normally bypasses torch.distributed; `force_collectives` sends every exchange through the process group
+        # anyway (a 1-rank RCCL communicator exercises the exact call sequence of the N-rank step on one GPU)
+        self.collectives = world > 1 or force_collectives
         self.cpu_staging = cpu_staging        # tests: gloo has no device all-to-all; stage the exchange through the host
         self.n_items, self.k = n_items, k
         self.ipr = items_per_rank(n_items, world)
@@ -225,7 +229,7 @@ class ShardedCdae:
     def _a2a(self, send, send_counts, recv_counts):
         shape = (int(sum(recv_counts)),) + tuple(send.shape[1:])
         out = torch.empty(shape, dtype=send.dtype, device=send.device)
-        if self.world == 1:
+        if not self.collectives:
             out.copy_(send[:shape[0]])
             return out
         if self.cpu_staging and send.is_cuda:
@@ -238,7 +242,7 @@ class ShardedCdae:
         return out
 
     def _counts(self, send_counts, device):
-        if self.world == 1:
+        if not self.collectives:
             return list(send_counts)
         s = torch.tensor(send_counts, dtype=torch.int64, device='cpu' if self.cpu_staging else device)
         r = torch.empty_like(s)
@@ -287,10 +291,10 @@ class ShardedCdae:
         rg = self._a2a(gc, send_counts, recv_counts)
         rb2 = self._a2a(gb2c, send_counts, recv_counts)
         rec(3)        # [2,3): local reduce + gradient exchange
-        ops.apply(req, rg, rb2, b_norm, opt)
+        ops.apply(req, rg, rb2, b_norm, opt, recv_counts)
         rec(4)        # [3,4): owner apply
         gb = ops.bias_grad(bt.B)
-        if W > 1:
+        if self.collectives:
             if self.cpu_staging and gb.is_cuda:
                 g = gb.cpu()
                 dist.all_reduce(g, group=self.group)

@@ -160,6 +160,7 @@ int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, i
  * of `items_per_rank` rows; in this mode DrxCdaeParams describes the LOCAL tables (n_users = local users,
  * n_items = items_per_rank).  Row keys are owner-major: item n of owner o = n / ipr -> o*2*ipr + (n - o*ipr) for its W
  * row, + ipr for its W2T row; local user u -> world*2*ipr + u. */
+#define DRX_MAX_WORLD 64                /* ranks of one sharded job (per-source offsets travel as a kernel argument) */
 typedef struct DrxShard {
   int32_t world, rank;
   int32_t n_items;          /* global number of items */
@@ -190,10 +191,12 @@ int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard
                      const uint32_t *keys_s, const uint32_t *vals_s, const int32_t *slot_sorted, const uint32_t *b_of_pos,
                      int32_t T, const float *dz1, const float *g2, const float *dz2, float *gc, float *gb2c, void *scratch,
                      size_t scratch_bytes, void *stream);
-/* owner side: sum the received gradient rows per owned row (arrival = source-rank order) and apply the optimizer */
+/* owner side: sum the received gradient rows per owned row in source-rank order and apply the optimizer.  The n received
+ * rows are `world` segments in source-rank order, recv_counts[s] (HOST array, world entries) rows from rank s, each segment
+ * holding ascending distinct keys (what drx_shard_index produces on the sender). */
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *recv_rows, const float *recv_b2, int32_t n, void *scratch, size_t scratch_bytes,
-                    void *stream);
+                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, void *scratch,
+                    size_t scratch_bytes, void *stream);
 /* out[0..ld) = column sums of dz1 (gradient of the hidden bias), out[ld] = sum of the per-sample losses */
 int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *lossb, int32_t B, float *out, void *scratch,
                         size_t scratch_bytes, void *stream);

@@ -153,7 +153,7 @@ class NumpyShardOps:
             self._update('V', u, g, b_norm)
         return torch.from_numpy(gc), torch.from_numpy(gb2c)
 
-    def apply(self, recv_keys, recv_rows, recv_b2, b_norm, opt):
+    def apply(self, recv_keys, recv_rows, recv_b2, b_norm, opt, recv_counts=None):
         k, r, s = recv_keys.numpy(), recv_rows.numpy(), recv_b2.numpy()
         tot, tots = {}, {}
         for i, key in enumerate(k):              # arrival order = source-rank order

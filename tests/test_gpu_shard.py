@@ -57,13 +57,13 @@ def _oracle(world):
     return p, losses
 
 
-def _run_rank(rank, world, staged):
+def _run_rank(rank, world, staged, force=False):
     from drecpy_amd.dist import ShardedCdae
     p, indptr, indices, batches = _problem(world)
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
-    m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged)
+    m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force)
     m.set_params_global(**p)
     losses = []
     for s in range(STEPS):
@@ -107,3 +107,23 @@ def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path):
     port = 29700 + (os.getpid() % 200)
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     _check(2, [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)])
+
+
+def _worker_rccl(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    res = _run_rank(0, 1, False, force=True)
+    torch.save(res, f'{out}.0')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_through_rccl_world1(tmp_path):
+    """The N-rank call sequence (count / key / row / gradient all-to-all(v), bias all-reduce) on a real 1-rank RCCL
+    communicator: device int32 and float32 buffers, uneven-split API, stream ordering with the drx kernels."""
+    out = str(tmp_path / 'rccl')
+    port = 29400 + (os.getpid() % 200)
+    mp.spawn(_worker_rccl, args=(port, out), nprocs=1, join=True)
+    _check(1, [torch.load(f'{out}.0', weights_only=False)])
