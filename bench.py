@@ -210,7 +210,7 @@ def main():
     # side stream while batch t trains (single GPU; the sharded path prepares inline).
     overlap = not args.no_overlap
     main = torch.cuda.current_stream()
-    side = torch.cuda.Stream() if overlap else None
+    side = torch.cuda.Stream(priority=-1) if overlap else None
     prep_bufs = [None, None]
     prep_done = [torch.cuda.Event(), torch.cuda.Event()]
     step_done = [torch.cuda.Event(), torch.cuda.Event()]
@@ -256,7 +256,15 @@ def main():
                 prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])
             prep_done[s % 2].record(side)
 
+    pipe = None
+    if stepper is not None and overlap:
+        from drecpy_amd.dist import ShardedPipeline
+        pipe = ShardedPipeline(stepper, lambda s: structs[s % len(structs)][0], args.warmup + args.steps)
+
     def run_step(s, events=None, last=False):
+        if pipe is not None:           # keys of batch s+1 and counts of batch s+2 travel ahead of step s (dist.ShardedPipeline)
+            pipe.run_step(events=events)
+            return
         if not overlap:
             bt = batch_of(s)
             if stepper is not None:
@@ -283,7 +291,7 @@ def main():
     if fresh:
         sample(0)
         sample(1)
-    if overlap:
+    if overlap and pipe is None:
         prepare(0)
     for s in range(args.warmup):
         run_step(s)
@@ -319,7 +327,7 @@ def main():
                  'k_span_fixup', 'bias_update']
         dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
-        names = ['touches+index+row_exchange', 'k_shard_fwd_bwd', 'local_reduce+grad_exchange', 'owner_apply', 'bias_allreduce']
+        names = ['row_gather+row_exchange', 'k_shard_fwd_bwd', 'local_reduce+grad_exchange', 'owner_apply', 'bias_allreduce']
         dom, dom_ms, dom_alg = 'k_shard_fwd_bwd', ph[1], alg_fwd
     achieved = dom_alg / (dom_ms * 1e-3) / 1e9
     step_alg = B * 4.0 * K * rows_per_sample * 5.0
@@ -344,10 +352,10 @@ def main():
                                    f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
                                    f'corruption {Q}, neg_ratio {NEG_RATIO}',
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
-                       'touch_list': 'prepared one batch ahead on a side stream' if overlap else 'inline',
+                       'touch_list': ('keys exchanged one batch ahead, counts two (dist.ShardedPipeline)' if pipe is not None else 'prepared one batch ahead on a side stream') if overlap else 'inline',
                        'batches': 'fresh device-sampled batch every step (sampler two steps ahead on the side stream)' if fresh
                        else f'{args.n_batches} pre-sampled batches cycled',
-                       'sharding': 'single GPU' if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
+                       'sharding': ('single GPU' if stepper is None else 'row-sharded code path at world 1') if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms),
@@ -359,6 +367,7 @@ def main():
                          'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             'phases_ms': {n: float(v) for n, v in zip(names, ph)},
             'setup_s': round(setup_s, 1),
+            'host_issue_ms_per_step': ([round(1e3 * t / (args.warmup + args.steps), 4) for t in pipe.host_s + [stepper.wait_s]] if pipe is not None else None),
         }
         if world == 1 and not args.no_cpu_baseline:
             uid, iid, y, keep_off, seed = batches[0]

@@ -25,6 +25,7 @@ distinct rows travel.
 """
 import ctypes as C
 import math
+import time
 
 import numpy as np
 import torch
@@ -56,14 +57,17 @@ class HipShardOps:
         self.device = self.engine.device
         self.ld = self.engine.ld
         self.shard = _lib.Shard(world, rank, n_items, self.ipr, n_users_local)
-        self._scratch = None
+        self._scratch = {}
 
     # -- helpers
-    def _sc(self, n):
+    def _sc(self, n, stage='step'):
+        """Scratch of one stage: `index` may run ahead on a side stream while reduce/apply of an earlier batch run on the
+        training stream, so the two never share a buffer."""
         need = self.L.drx_shard_scratch_bytes(C.byref(self.engine._params), C.byref(self.shard), int(n))
-        if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(int(need * 1.3) + 4096, dtype=torch.uint8, device=self.device)
-        return self._scratch
+        cur = self._scratch.get(stage)
+        if cur is None or cur.numel() < need:
+            cur = self._scratch[stage] = torch.empty(int(need * 1.3) + 4096, dtype=torch.uint8, device=self.device)
+        return cur
 
     def _e(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
@@ -84,7 +88,7 @@ class HipShardOps:
         T = keys.numel()
         ks, vs, ss, sp, uk = (self._e(T, dtype=torch.int32) for _ in range(5))
         bounds = self._e(self.world + 2, dtype=torch.int32)
-        sc = self._sc(T)
+        sc = self._sc(T, 'prepare')
         p = self._lib.ptr
         self._lib.check(self.L.drx_shard_index(C.byref(self.engine._params), C.byref(self.shard), p(keys), p(vals), T, p(ks),
                                                p(vs), p(ss), p(sp), p(uk), p(bounds), p(sc), sc.numel(), self._stream()),
@@ -193,6 +197,7 @@ class ShardedCdae:
             self.engine.set_history(hist_indptr, hist_indices)
             self._init_random(seed)
         self.last_loss = None
+        self.wait_s = 0.0                     # host time spent waiting for count exchanges (should stay ~0 when pipelined)
 
     def _init_random(self, seed):
         """GlorotUniform of the GLOBAL shapes, drawn per shard on the device (cdae.py:35-41)."""
@@ -250,10 +255,16 @@ class ShardedCdae:
         return r.cpu().tolist()
 
     # ---- one step ------------------------------------------------------------------------------------------
+    # A step has three parameter-independent stages that may run ahead of the training stream (ShardedPipeline below):
+    #   prepare(bt)            local: touches, stable sort, distinct keys, slots, per-owner bounds      [no collective]
+    #   exchange_counts(P)     all-to-all of the per-owner distinct-key counts; the result goes to pinned host memory
+    #   exchange_keys(P)       all-to-all(v) of the distinct keys each owner is asked for (needs the counts on the host)
+    # and the parameter-dependent rest in step().  Every rank must call the stages in the same program order: they all
+    # run on one communicator.
     def prepare(self, bt, consumer_stream=None):
         """Parameter-independent, collective-free part of a step: touches of the local batch, stable sort, distinct
-        keys, slots, per-owner bounds.  May run on a side stream for batch t+1 while batch t trains; `consumer_stream`
-        is the stream that will later read the result (allocator bookkeeping)."""
+        keys, slots, per-owner bounds.  May run on a side stream for a later batch while the current one trains;
+        `consumer_stream` is the stream that will later read the result (allocator bookkeeping)."""
         keys, vals, bpos = self.ops.touches(bt)
         idx = self.ops.index(keys, vals)
         ev = None
@@ -263,28 +274,73 @@ class ShardedCdae:
             if consumer_stream is not None:
                 for t in [bpos] + [v for v in idx.values() if torch.is_tensor(v) and v.is_cuda]:
                     t.record_stream(consumer_stream)
-        return {'idx': idx, 'bpos': bpos, 'event': ev, 'keys': keys, 'vals': vals}
+        return {'idx': idx, 'bpos': bpos, 'event': ev, 'keys': keys, 'vals': vals, 'consumer': consumer_stream}
+
+    def exchange_counts(self, P):
+        """Stage 2: how many distinct keys every rank asks of every owner.  On the device path nothing here waits on the
+        host: the send counts are differences of the device-side bounds, the received counts land in pinned memory."""
+        idx, W = P['idx'], self.world
+        if 'bounds_dev' in idx and not self.cpu_staging:
+            bd = idx['bounds_dev']
+            send = (bd[1:W + 1] - bd[0:W]).to(torch.int64)
+            recv = torch.empty_like(send)
+            if self.collectives:
+                dist.all_to_all_single(recv, send, group=self.group)
+            else:
+                recv.copy_(send)
+            host = torch.empty(2, W, dtype=torch.int64, pin_memory=True)
+            host[0].copy_(send, non_blocking=True)
+            host[1].copy_(recv, non_blocking=True)
+            P['counts_host'] = host
+            P['event'] = torch.cuda.Event()
+            P['event'].record()
+            if P.get('consumer') is not None:
+                send.record_stream(P['consumer']); recv.record_stream(P['consumer'])
+        else:
+            bounds = self.ops.bounds_of(idx, P['event']) if hasattr(self.ops, 'bounds_of') else idx['bounds']
+            send_counts = [bounds[o + 1] - bounds[o] for o in range(W)]
+            P['send_counts'] = send_counts
+            P['recv_counts'] = self._counts(send_counts, idx['uniq_keys'].device)
+        return P
+
+    def exchange_keys(self, P):
+        """Stage 3: every owner learns which of its rows each rank wants (4 B per distinct row)."""
+        if 'send_counts' not in P:
+            if 'counts_host' not in P:
+                self.exchange_counts(P)
+            if 'counts_host' in P:
+                t0 = time.perf_counter()
+                P['event'].synchronize()                # the tiny count exchange, issued at least one step earlier
+                self.wait_s += time.perf_counter() - t0
+                P['send_counts'] = P['counts_host'][0].tolist()
+                P['recv_counts'] = P['counts_host'][1].tolist()
+        q_item = int(sum(P['send_counts']))
+        P['q_item'] = q_item
+        P['req'] = self._a2a(P['idx']['uniq_keys'][:q_item], P['send_counts'], P['recv_counts'])
+        if torch.is_tensor(P['req']) and P['req'].is_cuda:
+            P['event'] = torch.cuda.Event()
+            P['event'].record()
+            if P.get('consumer') is not None:
+                P['req'].record_stream(P['consumer'])
+        return P
 
     def step(self, step, bt, events=None, want_loss=False, prepared=None):
-        ops, W = self.ops, self.world
-        b_norm = bt.B * W
+        ops = self.ops
+        b_norm = bt.B * self.world
         opt = ops.optim(step)
         rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
         rec(0)
-        if prepared is None:
-            prepared = self.prepare(bt)
-        elif prepared['event'] is not None:
-            torch.cuda.current_stream().wait_event(prepared['event'])
-        idx, bpos = prepared['idx'], prepared['bpos']
-        bounds = ops.bounds_of(idx, prepared['event']) if hasattr(ops, 'bounds_of') else idx['bounds']
-        send_counts = [bounds[o + 1] - bounds[o] for o in range(W)]
-        q_item = bounds[W]
-        recv_counts = self._counts(send_counts, idx['uniq_keys'].device)
-        req = self._a2a(idx['uniq_keys'][:q_item], send_counts, recv_counts)
+        P = prepared if prepared is not None else self.prepare(bt)
+        if 'req' not in P:
+            self.exchange_keys(P)
+        elif P['event'] is not None:
+            torch.cuda.current_stream().wait_event(P['event'])
+        idx, bpos, req = P['idx'], P['bpos'], P['req']
+        send_counts, recv_counts, q_item = P['send_counts'], P['recv_counts'], P['q_item']
         rows, b2v = ops.gather_rows(req)
         rows_cache = self._a2a(rows, recv_counts, send_counts)
         b2_cache = self._a2a(b2v, recv_counts, send_counts)
-        rec(1)        # [0,1): (touches, index,) row request/response exchange
+        rec(1)        # [0,1): (stages not run ahead,) row gather + row exchange
         ops.fwd_bwd(bt, idx['slot_of_pos'], rows_cache, b2_cache, b_norm, self.loss_kind)
         rec(2)        # [1,2): forward/backward
         gc, gb2c = ops.reduce(idx, bpos, q_item, b_norm, bt.q, opt)
@@ -307,3 +363,74 @@ class ShardedCdae:
             self.last_loss = float(gb[-1].item()) / b_norm
             return self.last_loss
         return None
+
+
+class ShardedPipeline:
+    """Drives ShardedCdae so that no step waits on the host or on a parameter-independent exchange.
+
+    Iteration s issues, in this program order (identical on every rank — one communicator):
+        exchange_keys(batch s+1)  ·  prepare + exchange_counts(batch s+2)  ·  step(batch s)
+    The count exchange of batch s+2 is queued ahead of step s's collectives, so its host-side result (read when
+    iteration s+1 issues exchange_keys) is ready without stalling; keys and counts travel while the owner gathers the
+    rows of step s.  On a GPU the run-ahead stages use a side stream; on CPU (gloo tests) everything runs inline in the
+    same order.  `batch_of(s)` must return the DrxBatch of step s and be callable two steps ahead."""
+
+    LOOKAHEAD = 2
+
+    def __init__(self, model, batch_of, n_steps, use_side_stream=None):
+        self.m, self.batch_of, self.n = model, batch_of, n_steps
+        eng = model.engine
+        self.cuda = eng is not None and torch.device(eng.device).type == 'cuda'
+        if use_side_stream is None:
+            use_side_stream = self.cuda
+        self.main = torch.cuda.current_stream(eng.device) if self.cuda else None
+        # High priority: ROCm multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and a stream that
+        # lands on the queue of the training or the RCCL stream inherits their barriers (measured: the count exchange then
+        # completes only when the GPU drains, +0.2 ms/step); priority streams get queues of their own.
+        self.side = torch.cuda.Stream(eng.device, priority=-1) if (self.cuda and use_side_stream) else None
+        self.P = {}
+        self.next = 0
+        self.host_s = [0.0, 0.0, 0.0]
+        if self.side is not None:
+            self.side.wait_stream(self.main)            # histories / batches set up on the training stream
+        self._ahead(0, keys=True)
+        if n_steps > 1:
+            self._ahead(1, keys=False)
+
+    def _on_side(self):
+        return torch.cuda.stream(self.side) if self.side is not None else _Null()
+
+    def _ahead(self, s, keys):
+        """prepare + count exchange of batch s (and its key exchange when `keys`)"""
+        bt = self.batch_of(s)
+        with self._on_side():
+            P = self.m.prepare(bt, consumer_stream=self.main if self.side is not None else None)
+            self.m.exchange_counts(P)
+            if keys:
+                self.m.exchange_keys(P)
+        self.P[s] = P
+
+    def run_step(self, events=None, want_loss=False):
+        s = self.next
+        assert s < self.n
+        t0 = time.perf_counter()
+        if s + 1 < self.n:
+            with self._on_side():
+                self.m.exchange_keys(self.P[s + 1])
+        t1 = time.perf_counter()
+        if s + 2 < self.n:
+            self._ahead(s + 2, keys=False)
+        t2 = time.perf_counter()
+        out = self.m.step(s, self.batch_of(s), events=events, want_loss=want_loss, prepared=self.P.pop(s))
+        t3 = time.perf_counter()
+        self.host_s[0] += t1 - t0; self.host_s[1] += t2 - t1; self.host_s[2] += t3 - t2     # host time issuing each stage
+        self.next = s + 1
+        return out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

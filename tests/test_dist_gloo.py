@@ -34,7 +34,7 @@ def _problem():
     return p, indptr, indices, batches
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, pipelined=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -48,21 +48,29 @@ def _worker(rank, world, port, out):
     m = ShardedCdae(U, N, K, rank, world, 'cpu', lip, lidx, ops=ops, q=Q)
     m.set_params_global(**p)
     losses = []
-    for s in range(STEPS):
+
+    def batch_of(s):
         uid, iid, y, seed = batches[s][rank]
-        bt = np_batch(uid - lo, iid, y, lip, Q, mask_seed=seed)
-        losses.append(m.step(s, bt, want_loss=True))
+        return np_batch(uid - lo, iid, y, lip, Q, mask_seed=seed)
+    if pipelined:                      # run-ahead stage order of the multi-GPU bench (keys s+1, counts s+2, step s)
+        from drecpy_amd.dist import ShardedPipeline
+        pipe = ShardedPipeline(m, batch_of, STEPS)
+        losses = [pipe.run_step(want_loss=True) for _ in range(STEPS)]
+    else:
+        for s in range(STEPS):
+            losses.append(m.step(s, batch_of(s), want_loss=True))
     got = ops.get_params()
     torch.save({'params': {k: np.asarray(v) for k, v in got.items()}, 'losses': losses}, f'{out}.{rank}')
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_step_equals_single_process_oracle(tmp_path):
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined):
     from oracle import cdae_oracle as co
     out = str(tmp_path / 'shard')
-    port = 29600 + (os.getpid() % 200)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29600 + (os.getpid() % 200) + (200 if pipelined else 0)
+    mp.spawn(_worker, args=(2, port, out, pipelined), nprocs=2, join=True)
     p, indptr, indices, batches = _problem()
     st = co.sparse_state(p, 'adagrad')
     want_losses = []

@@ -57,7 +57,7 @@ def _oracle(world):
     return p, losses
 
 
-def _run_rank(rank, world, staged, force=False):
+def _run_rank(rank, world, staged, force=False, pipelined=False):
     from drecpy_amd.dist import ShardedCdae
     p, indptr, indices, batches = _problem(world)
     lo, hi = U * rank // world, U * (rank + 1) // world
@@ -65,11 +65,20 @@ def _run_rank(rank, world, staged, force=False):
     lidx = indices[indptr[lo]:indptr[hi]]
     m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force)
     m.set_params_global(**p)
-    losses = []
-    for s in range(STEPS):
-        uid, iid, y, seed = batches[s][rank]
-        bt, alive = m.ops.make_batch(uid - lo, iid, y, q=Q, mask_seed=seed)
-        losses.append(m.step(s, bt, want_loss=True))
+    losses, made = [], {}
+
+    def batch_of(s):
+        if s not in made:
+            uid, iid, y, seed = batches[s][rank]
+            made[s] = m.ops.make_batch(uid - lo, iid, y, q=Q, mask_seed=seed)
+        return made[s][0]
+    if pipelined:
+        from drecpy_amd.dist import ShardedPipeline
+        pipe = ShardedPipeline(m, batch_of, STEPS)
+        losses = [pipe.run_step(want_loss=True) for _ in range(STEPS)]
+    else:
+        for s in range(STEPS):
+            losses.append(m.step(s, batch_of(s), want_loss=True))
     torch.cuda.synchronize()
     return m.ops.get_params(), losses, (lo, hi)
 
@@ -88,42 +97,45 @@ def _check(world, results):
         np.testing.assert_allclose(losses, want_losses, rtol=1e-5)
 
 
-def test_sharded_world1_matches_oracle():
-    _check(1, [_run_rank(0, 1, False)])
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_sharded_world1_matches_oracle(pipelined):
+    _check(1, [_run_rank(0, 1, False, pipelined=pipelined)])
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, pipelined=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _run_rank(rank, world, True)
+    res = _run_rank(rank, world, True, pipelined=pipelined)
     torch.save(res, f'{out}.{rank}')
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path):
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined):
     out = str(tmp_path / 'shard')
-    port = 29700 + (os.getpid() % 200)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29700 + (os.getpid() % 200) + (200 if pipelined else 0)
+    mp.spawn(_worker, args=(2, port, out, pipelined), nprocs=2, join=True)
     _check(2, [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)])
 
 
-def _worker_rccl(rank, port, out):
+def _worker_rccl(rank, port, out, pipelined):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    res = _run_rank(0, 1, False, force=True)
+    res = _run_rank(0, 1, False, force=True, pipelined=pipelined)
     torch.save(res, f'{out}.0')
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_step_through_rccl_world1(tmp_path):
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_sharded_step_through_rccl_world1(tmp_path, pipelined):
     """The N-rank call sequence (count / key / row / gradient all-to-all(v), bias all-reduce) on a real 1-rank RCCL
     communicator: device int32 and float32 buffers, uneven-split API, stream ordering with the drx kernels."""
     out = str(tmp_path / 'rccl')
-    port = 29400 + (os.getpid() % 200)
-    mp.spawn(_worker_rccl, args=(port, out), nprocs=1, join=True)
+    port = 29400 + (os.getpid() % 200) + (200 if pipelined else 0)
+    mp.spawn(_worker_rccl, args=(port, out, pipelined), nprocs=1, join=True)
     _check(1, [torch.load(f'{out}.0', weights_only=False)])
