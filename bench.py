@@ -216,44 +216,23 @@ def main():
     step_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     fresh = overlap and stepper is None and not args.presampled
-    # fresh mode: the device PointSampler draws a NEW batch for every step, two steps ahead on the side stream; its touch
-    # count comes back through pinned memory (event-synchronised, off the critical path) and sizes the sort of `prepare`.
-    ring = [eng.sample_device(B, NEG_RATIO, 1, n_items=N) for _ in range(3)] if fresh else None
-    ring_T = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(3)] if fresh else None
-    ring_ev = [torch.cuda.Event() for _ in range(3)]
-    ring_free = [torch.cuda.Event() for _ in range(3)]
-    ring_bt = [None, None, None]
-
-    def seed_of(s):
-        return 5000 + 7919 * s + 104729 * rank
-
-    def sample(s):
-        k = s % 3
-        side.wait_event(ring_free[k])                # the slot's previous batch (step s-3) has been consumed
-        with torch.cuda.stream(side):
-            eng.sample_device(B, NEG_RATIO, seed_of(s), n_items=N, out=ring[k])
-            ring_T[k].copy_(ring[k][3][-1:], non_blocking=True)
-            ring_ev[k].record(side)
+    # fresh mode: the device PointSampler draws a NEW batch for every step, two steps ahead on a side stream, and the batch's
+    # touch list is sorted one step ahead — drecpy_amd.engine.SampledPipeline, the code path of
+    # CDAE.fit(mode='sampled', device_sampler=True).
+    spipe = None
+    if fresh:
+        from drecpy_amd.engine import SampledPipeline
+        spipe = SampledPipeline(eng, B, NEG_RATIO, Q, lambda s: 5000 + 7919 * s + 104729 * rank,
+                                lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N)
 
     def batch_of(s):
-        if not fresh:
-            return structs[s % len(structs)][0]
-        k = s % 3
-        if ring_bt[k] is None or ring_bt[k][0] != s:
-            ring_ev[k].synchronize()                 # host wait on the tiny D2H issued two steps ago
-            uid, iid, y, keep_off = ring[k]
-            bt, alive = eng.make_batch(uid, iid, y, keep_off=keep_off, q=Q, mask_seed=seed_of(s), n_touch_slots=int(ring_T[k][0]))
-            ring_bt[k] = (s, bt, alive)
-        return ring_bt[k][1]
+        return structs[s % len(structs)][0]
 
     def prepare(s):
         bt = batch_of(s)
         side.wait_event(step_done[s % 2])            # the buffer's previous user (step s-2) must be finished
         with torch.cuda.stream(side):
-            if stepper is not None:                  # local, collective-free part of the sharded step
-                prep_bufs[s % 2] = stepper.prepare(bt, consumer_stream=main)
-            else:
-                prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])
+            prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])
             prep_done[s % 2].record(side)
 
     pipe = None
@@ -265,6 +244,9 @@ def main():
         if pipe is not None:           # keys of batch s+1 and counts of batch s+2 travel ahead of step s (dist.ShardedPipeline)
             pipe.run_step(events=events)
             return
+        if spipe is not None:
+            spipe.run_step(events=events)
+            return
         if not overlap:
             bt = batch_of(s)
             if stepper is not None:
@@ -272,26 +254,16 @@ def main():
             else:
                 eng.step_sparse(s, bt, 'bce', events=events)
             return
-        if fresh and not last:
-            sample(s + 2)
         if not last:
             prepare(s + 1)
         bt = batch_of(s)
         main.wait_event(prep_done[s % 2])
-        if stepper is not None:
-            stepper.step(s, bt, events=events, prepared=prep_bufs[s % 2])
-        else:
-            eng.step_sparse(s, bt, 'bce', events=events, prepared=prep_bufs[s % 2])
+        eng.step_sparse(s, bt, 'bce', events=events, prepared=prep_bufs[s % 2])
         step_done[s % 2].record(main)
-        if fresh:
-            ring_free[s % 3].record(main)
 
-    for e in step_done + ring_free:
+    for e in step_done:
         e.record(main)
-    if fresh:
-        sample(0)
-        sample(1)
-    if overlap and pipe is None:
+    if overlap and pipe is None and spipe is None:
         prepare(0)
     for s in range(args.warmup):
         run_step(s)

@@ -40,6 +40,7 @@ class CDAE(RecommenderABC):
         from ..engine import CdaeEngine
         ds = self.interaction_dataset
         self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
+        self._pipeline = None
         weights = kwds.get('initial_weights')
         if weights is not None:                      # injected weights (TF's GlorotUniform stream is not reproducible)
             self._engine.set_params(**weights)
@@ -67,8 +68,17 @@ class CDAE(RecommenderABC):
 
     def _sample_batch(self, batch_size, **kwds):       # cdae.py:47
         if self.mode == 'sampled' and self.device_sampler:
-            self._dev_draws = getattr(self, '_dev_draws', 0) + 1
-            return self._engine.sample_device(batch_size, self._sampler.neg_ratio, self._mask_seed * 7919 + self._dev_draws)
+            # the device sampler runs two batches ahead of the training stream inside SampledPipeline; this hook only
+            # makes sure the pipeline exists for this batch size and hands _do_batch a token
+            pipe = getattr(self, '_pipeline', None)
+            if pipe is None or pipe.B != batch_size:
+                from ..engine import SampledPipeline
+                first = 0 if pipe is None else pipe.next
+                ms = self._mask_seed
+                pipe = self._pipeline = SampledPipeline(
+                    self._engine, batch_size, self._sampler.neg_ratio, self.corruption_level,
+                    lambda s: ms * 7919 + first + s + 1, lambda s: ms + 0x9E3779B9 * (first + s + 1), loss=self._loss_name)
+            return ('device-batch', pipe.next)
         if self.mode == 'sampled' and kwds.get('as_arrays', True):
             return self._sampler.sample_arrays(batch_size)      # (uid, iid, value, is_negative) numpy arrays
         return self._sampler.sample(batch_size)                  # list of (uid, iid, value) like the reference
@@ -98,11 +108,8 @@ class CDAE(RecommenderABC):
 
     def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
         eng = self._engine
-        if self.mode == 'sampled' and self.device_sampler:       # (uid, iid, y, keep_off) device tensors from drx_point_sample
-            uid, iid, y, keep_off = batch_samples
-            bt, alive = eng.make_batch(uid, iid, y, keep_off=keep_off, q=self.corruption_level,
-                                       mask_seed=self._mask_seed + 0x9E3779B9 * (step + 1))
-            loss = eng.step_sparse(step, bt, self._loss_name, want_loss=want_loss)
+        if self.mode == 'sampled' and self.device_sampler:       # batch drawn and indexed ahead of time on the device
+            loss = self._pipeline.run_step(want_loss=want_loss)
             return float(loss[0].item()) if want_loss else None
         uid, iid, val = self._batch_arrays(batch_samples)
         if self.mode == 'reference':

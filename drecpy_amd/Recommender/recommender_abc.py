@@ -25,7 +25,7 @@ from .early_stopping import InvalidEpochValidationResultsException
 from .loss_tracker import LossTracker
 
 _LOG_FORMAT = '[%(asctime)s] (%(levelname)s) %(name)s: %(message)s'
-_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', 'epoch_weights')
+_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', 'epoch_weights', '_pipeline')
 
 
 def _make_logger(name, handler):

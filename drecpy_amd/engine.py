@@ -282,3 +282,75 @@ def pack_mask_bits(mask_bool):
     if pad:
         flat = np.concatenate([flat, np.zeros(pad, bool)])
     return np.packbits(flat, bitorder='little').view(np.uint32).copy()
+
+
+class SampledPipeline:
+    """Keeps the training stream of the sampled-output mode free of everything that does not depend on the parameters.
+
+    Step s trains on a batch the device PointSampler (drx_point_sample) drew two steps earlier and whose sorted touch
+    list (drx_cdae_sparse_prepare) was built one step earlier, both on a high-priority side stream; the touch count of a
+    batch reaches the host through pinned memory two steps before it is needed, so nothing waits.  Used by
+    `CDAE.fit(mode='sampled', device_sampler=True)` and by bench.py — the same code path.
+
+    sample_seed_of(s) / mask_seed_of(s): seeds of step s's triple draw and of its corruption mask."""
+
+    def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce'):
+        self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
+        self.sample_seed_of, self.mask_seed_of = sample_seed_of, mask_seed_of
+        self.n_items = n_items
+        dev = eng.device
+        self.main = torch.cuda.current_stream(dev)
+        # high priority: a normal stream may share a hardware queue with the training stream and inherit its barriers
+        self.side = torch.cuda.Stream(dev, priority=-1)
+        self.ring = [eng.sample_device(self.B, self.neg_ratio, 1, n_items=n_items) for _ in range(3)]
+        self.ring_T = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(3)]
+        self.ring_ev = [torch.cuda.Event() for _ in range(3)]
+        self.ring_free = [torch.cuda.Event() for _ in range(3)]
+        self.ring_bt = [None, None, None]
+        self.prep = [None, None]
+        self.prep_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.step_done = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in self.step_done + self.ring_free:
+            e.record(self.main)
+        self.next = 0
+        self._sample(0)
+        self._sample(1)
+        self._prepare(0)
+
+    def _sample(self, s):
+        k = s % 3
+        self.side.wait_event(self.ring_free[k])              # the slot's previous batch (step s-3) has been consumed
+        with torch.cuda.stream(self.side):
+            self.eng.sample_device(self.B, self.neg_ratio, self.sample_seed_of(s), n_items=self.n_items, out=self.ring[k])
+            self.ring_T[k].copy_(self.ring[k][3][-1:], non_blocking=True)
+            self.ring_ev[k].record(self.side)
+
+    def batch_of(self, s):
+        k = s % 3
+        if self.ring_bt[k] is None or self.ring_bt[k][0] != s:
+            self.ring_ev[k].synchronize()                    # the 4-byte count copied two steps ago
+            uid, iid, y, keep_off = self.ring[k]
+            bt, alive = self.eng.make_batch(uid, iid, y, keep_off=keep_off, q=self.q, mask_seed=self.mask_seed_of(s),
+                                            n_touch_slots=int(self.ring_T[k][0]))
+            self.ring_bt[k] = (s, bt, alive)
+        return self.ring_bt[k][1]
+
+    def _prepare(self, s):
+        bt = self.batch_of(s)
+        self.side.wait_event(self.step_done[s % 2])          # the buffer's previous user (step s-2) has finished
+        with torch.cuda.stream(self.side):
+            self.prep[s % 2] = self.eng.prepare_sparse(bt, self.prep[s % 2])
+            self.prep_done[s % 2].record(self.side)
+
+    def run_step(self, events=None, want_loss=False):
+        """Queues step `self.next` (and the run-ahead work of the two following steps); returns the loss tensor or None."""
+        s = self.next
+        self._sample(s + 2)
+        self._prepare(s + 1)
+        bt = self.batch_of(s)
+        self.main.wait_event(self.prep_done[s % 2])
+        out = self.eng.step_sparse(s, bt, self.loss, want_loss=want_loss, events=events, prepared=self.prep[s % 2])
+        self.step_done[s % 2].record(self.main)
+        self.ring_free[s % 3].record(self.main)
+        self.next = s + 1
+        return out

@@ -130,7 +130,7 @@ def test_cdae_sampled_mode_with_device_sampler_learns():
         model._do_batch(model._sample_batch(512), step=s)
     l1 = model._do_batch(model._sample_batch(512), step=80, want_loss=True)
     assert l1 < l0
-    u, i, y, ko = model._sample_batch(2048)
+    u, i, y, ko = model._engine.sample_device(2048, 5, 12345)
     u, i, y = u.cpu().numpy(), i.cpu().numpy(), y.cpu().numpy()
     pairs = set(zip(ds._cols['uid'].tolist(), ds._cols['iid'].tolist()))
     pos = set((a, b) for a, b, v in zip(ds._cols['uid'].tolist(), ds._cols['iid'].tolist(), ds._cols['interaction'].tolist()) if v >= 1e-3)
@@ -184,3 +184,29 @@ def test_rank_is_thread_safe():
     with ThreadPoolExecutor(max_workers=4) as pool:
         threaded = list(pool.map(lambda u: model.rank(u, items, novelty=True, n=7), users * 3))
     assert threaded == serial * 3
+
+
+def test_pipelined_sampled_fit_equals_the_inline_sequence():
+    """CDAE.fit(mode='sampled', device_sampler=True) runs through SampledPipeline (sampler two batches ahead, touch list one
+    ahead, side stream); the parameters must be bit-identical to sampling, indexing and stepping inline with the same seeds."""
+    import torch
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    from drecpy_amd.engine import CdaeEngine
+    ds = InteractionDataset.read_df(_frame(), verbose=False)
+    model = CDAE(hidden_factors=16, mode='sampled', device_sampler=True, seed=3, verbose=False)
+    model.fit(ds, epochs=25, batch_size=384, learning_rate=0.05, reg_rate=1e-3, neg_ratio=5)
+    torch.cuda.synchronize()
+    got = [t.clone() for t in model._engine.tables()]
+    eng = CdaeEngine(model.n_users, model.n_items, 16)
+    eng.init_glorot(3)
+    eng.set_history(model._hist_indptr, model._hist_indices)
+    eng.init_optimizer('adagrad', 0.05, 1e-3)
+    ms = model._mask_seed
+    for s in range(25):
+        uid, iid, y, ko = eng.sample_device(384, 5, ms * 7919 + s + 1)
+        bt, alive = eng.make_batch(uid, iid, y, keep_off=ko, q=0.2, mask_seed=ms + 0x9E3779B9 * (s + 1))
+        eng.step_sparse(s, bt, 'bce')
+    torch.cuda.synchronize()
+    for a, b in zip(got, eng.tables()):
+        assert torch.equal(a, b)
