@@ -70,7 +70,8 @@ class MemoryInteractionDataset(InteractionDatasetABC):
         self.in_memory = True
         self.path = path
         self.has_internal_ids = False
-        self._user_mapping = self._user_mapping_inv = self._item_mapping = self._item_mapping_inv = None
+        self._user_mapping = self._item_mapping = None
+        self._user_cats = self._item_cats = None
         self._csr = self._csc = None
         if df is None:
             import pandas as pd
@@ -238,6 +239,12 @@ class MemoryInteractionDataset(InteractionDatasetABC):
         return new
 
     def count_unique(self, columns=None):
+        cols = [c for c in self._handle_columns(columns) if c != 'rid']
+        if len(cols) == 1 and len(self):
+            if self.has_internal_ids and cols[0] in ('uid', 'iid', 'user', 'item'):
+                c = self._cols['uid' if cols[0] in ('uid', 'user') else 'iid']
+                return int(np.count_nonzero(np.bincount(c)))           # codes are dense small ints: no sort
+            return len(np.unique(self._cols[cols[0]]))
         return len(self.unique(columns))
 
     def max(self, column=None):
@@ -301,11 +308,10 @@ class MemoryInteractionDataset(InteractionDatasetABC):
         self._cols = dict(self._cols)
         self._cols['uid'] = ucodes.astype(_code_dtype(len(ucats)))
         self._cols['iid'] = icodes.astype(_code_dtype(len(icats)))
-        py = lambda x: x.item() if hasattr(x, 'item') else x
-        self._user_mapping = {py(c): k for k, c in enumerate(ucats)}
-        self._user_mapping_inv = {k: py(c) for k, c in enumerate(ucats)}
-        self._item_mapping = {py(c): k for k, c in enumerate(icats)}
-        self._item_mapping_inv = {k: py(c) for k, c in enumerate(icats)}
+        # the raw<->internal maps (mem_dataset.py:318-329 keeps four dicts) are held as the category arrays; the raw->internal
+        # dict of a side is built on its first lookup, internal->raw is an array index
+        self._user_cats, self._item_cats = ucats, icats
+        self._user_mapping = self._item_mapping = None
         for c in ('uid', 'iid'):
             if c not in self.columns:
                 self.columns.append(c)
@@ -327,21 +333,47 @@ class MemoryInteractionDataset(InteractionDatasetABC):
                 raise Exception(f'The provided {col} type does not match the inferred type (expected: int, found: {type(x)}')
         return str(x)
 
+    @staticmethod
+    def _forward_map(cats):
+        return {(c.item() if hasattr(c, 'item') else c): k for k, c in enumerate(cats)}
+
+    @staticmethod
+    def _inverse(cats, k):
+        if k is None:
+            return None
+        k = int(k)
+        if not 0 <= k < len(cats):
+            return None
+        c = cats[k]
+        return c.item() if hasattr(c, 'item') else c
+
+    @property
+    def n_users(self):
+        return len(self._user_cats)
+
+    @property
+    def n_items(self):
+        return len(self._item_cats)
+
     def user_to_uid(self, user):
         assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        if self._user_mapping is None:
+            self._user_mapping = self._forward_map(self._user_cats)
         return self._user_mapping.get(self._raw_key('user', user))
 
     def uid_to_user(self, uid):
         assert self.has_internal_ids is True, 'No internal ids assigned yet.'
-        return self._user_mapping_inv.get(int(uid)) if uid is not None else None
+        return self._inverse(self._user_cats, uid)
 
     def item_to_iid(self, item):
         assert self.has_internal_ids is True, 'No internal ids assigned yet.'
+        if self._item_mapping is None:
+            self._item_mapping = self._forward_map(self._item_cats)
         return self._item_mapping.get(self._raw_key('item', item))
 
     def iid_to_item(self, iid):
         assert self.has_internal_ids is True, 'No internal ids assigned yet.'
-        return self._item_mapping_inv.get(int(iid)) if iid is not None else None
+        return self._inverse(self._item_cats, iid)
 
     # ---- interaction matrix (mem_dataset.py:165-218, 480-498) ------------------------------------------------
     def interaction_csr(self, transpose=False):
@@ -349,7 +381,7 @@ class MemoryInteractionDataset(InteractionDatasetABC):
         columns ascending; transpose=True gives the [N,U] matrix."""
         assert self.has_internal_ids is True, 'Cannot retrieve user interaction vector without assigned internal ids.'
         if self._csr is None:
-            U, N = len(self._user_mapping), len(self._item_mapping)
+            U, N = self.n_users, self.n_items
             self._csr = _build_csr(self._cols['uid'], self._cols['iid'], self._cols['interaction'], U, N)
             self._csc = _build_csr(self._cols['iid'], self._cols['uid'], self._cols['interaction'], N, U)
         return self._csc if transpose else self._csr
@@ -360,7 +392,7 @@ class MemoryInteractionDataset(InteractionDatasetABC):
         keep = vals >= interaction_threshold
         rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))[keep]
         ip = np.zeros(len(indptr), dtype=np.int64)
-        np.add.at(ip, rows + 1, 1)
+        ip[1:] = np.bincount(rows, minlength=len(indptr) - 1)
         return np.cumsum(ip), cols[keep].astype(np.int32)
 
     def _vec(self, csr, i, n):
@@ -372,12 +404,12 @@ class MemoryInteractionDataset(InteractionDatasetABC):
     def select_user_interaction_vec(self, uid):
         assert self.has_internal_ids is True, 'Cannot retrieve user interaction vector without assigned internal ids.'
         assert self.uid_to_user(uid) is not None, f'User internal id {uid} was not found.'
-        return self._vec(self.interaction_csr(), uid, len(self._item_mapping))
+        return self._vec(self.interaction_csr(), uid, self.n_items)
 
     def select_item_interaction_vec(self, iid):
         assert self.has_internal_ids is True, 'Cannot retrieve user interaction vector without assigned internal ids.'
         assert self.iid_to_item(iid) is not None, f'Item internal id {iid} was not found.'
-        return self._vec(self.interaction_csr(transpose=True), iid, len(self._user_mapping))
+        return self._vec(self.interaction_csr(transpose=True), iid, self.n_users)
 
     # ---- random generators (mem_dataset.py:104-163), host streams via libdrx --------------------------------------
     def _sampler(self, neg_ratio, threshold, seed):
@@ -424,21 +456,14 @@ def first_appearance_codes_host_safe(col):
 
 
 def _build_csr(rows, cols, vals, n_rows, n_cols):
-    rows = np.asarray(rows, dtype=np.int64)
-    cols = np.asarray(cols, dtype=np.int64)
-    vals = np.asarray(vals, dtype=np.float64)
-    key = rows * n_cols + cols
-    order = np.argsort(key, kind='stable')
-    ks = key[order]
-    if len(ks):
-        uniq, start = np.unique(ks, return_index=True)
-        sums = np.add.reduceat(vals[order], start)
-    else:
-        uniq, sums = ks, vals
-    r = uniq // n_cols
-    indptr = np.zeros(n_rows + 1, dtype=np.int64)
-    np.add.at(indptr, r + 1, 1)
-    return np.cumsum(indptr), (uniq - r * n_cols), sums
+    """Duplicates summed (in record order), columns ascending: what csr_matrix((v, (r, c))) gives the reference
+    (mem_dataset.py:480-498).  scipy's coo->csr is a counting sort in C; duplicates are added in their stored order."""
+    from scipy.sparse import coo_matrix
+    m = coo_matrix((np.asarray(vals, dtype=np.float64), (np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64))),
+                   shape=(n_rows, n_cols)).tocsr()
+    m.sum_duplicates()
+    m.sort_indices()
+    return m.indptr.astype(np.int64), m.indices.astype(np.int64), m.data
 
 
 class InteractionDataset:

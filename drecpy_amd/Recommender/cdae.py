@@ -45,7 +45,10 @@ class CDAE(RecommenderABC):
         if weights is not None:                      # injected weights (TF's GlorotUniform stream is not reproducible)
             self._engine.set_params(**weights)
         else:
-            self._engine.init_glorot(self.seed if self.seed is not None else np.random.SeedSequence().entropy % (2 ** 32))
+            seed = self.seed if self.seed is not None else np.random.SeedSequence().entropy % (2 ** 32)
+            n_params = (2 * self.n_items + self.n_users) * self.hidden_factors
+            # large tables are drawn on the device (same distribution, torch's generator instead of numpy's)
+            (self._engine.init_glorot_device if n_params > (1 << 26) else self._engine.init_glorot)(seed)
         self._hist_indptr, self._hist_indices = ds.positives_csr(self.interaction_threshold)
         self._engine.set_history(self._hist_indptr, self._hist_indices)
         if self.mode == 'reference':
