@@ -296,7 +296,7 @@ def main():
     alg_upd = B * 4.0 * K * rows_per_sample * 4.0
     if stepper is None:
         names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce',
-                 'k_span_fixup', 'bias_update']
+                 'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
         dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
         names = ['row_gather+row_exchange', 'k_shard_fwd_bwd', 'local_reduce+grad_exchange', 'owner_apply', 'bias_allreduce']

@@ -452,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
                                                             uint32_t qthr, int loss_kind, SparseBufs S) {
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;     // counters of the segmented reduction that follows
   if (b >= bt.B) return;
   const int u = bt.uid[b], i = bt.iid[b];
   const float y = bt.y[b];
@@ -536,22 +537,28 @@ struct DirectPolicy {
   }
 };
 
-// hidden bias b: column sums of dz1 in two deterministic stages, then a dense optimizer update.
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_bias_partial(int ld, int B, const float *__restrict__ dz1, float *__restrict__ part,
-                                                         int rows_per_block, const float *__restrict__ lossb,
-                                                         float *__restrict__ loss_part) {
-  extern __shared__ __align__(16) float lds[];   // [R, ld]
-  __shared__ float red[kBlock / 64];
-  constexpr int R = kBlock / G;
+// hidden bias b: column sums of dz1 in two deterministic stages, then a dense optimizer update.  Both stages are ROLES of
+// the two tail launches of the sparse step (k_sparse_tail_a / _b below): they share a launch with the span fix-ups, which
+// they do not depend on.
+struct BiasArgs {
+  const float *dz1;       // [B, ld]
+  float *part;            // [n_part, ld] column-sum partials, then [n_part] loss partials
+  const float *lossb;     // [B]
+  float *loss_out;        // nullptr: no loss wanted
+  int B, n_part, rows_per_block;
+};
+
+template <int G, int J, int NT>
+__device__ __forceinline__ void bias_partial_body(int ld, const BiasArgs &A, int block_id, float *lds /* [NT/G, ld] */, float *red) {
+  constexpr int R = NT / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
+  const int b0 = block_id * A.rows_per_block, b1 = min(A.B, b0 + A.rows_per_block);
   float4 acc[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
   for (int b = b0 + r; b < b1; b += R) {
     float4 v[J];
-    load_row<G, J>(dz1, (size_t)b, ld, lane, v);
+    load_row<G, J>(A.dz1, (size_t)b, ld, lane, v);
 #pragma unroll
     for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
   }
@@ -567,29 +574,27 @@ __global__ __launch_bounds__(kBlock) void k_bias_partial(int ld, int B, const fl
 #pragma unroll
       for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
     }
-    store_row<G, J>(part, (size_t)blockIdx.x, ld, lane, t);
+    store_row<G, J>(A.part, (size_t)block_id, ld, lane, t);
   }
-  if (loss_part) {                                 // this block's slice of the per-sample losses
+  if (A.loss_out) {                                // this block's slice of the per-sample losses
     float a = 0.f;
-    for (int b = b0 + (int)threadIdx.x; b < b1; b += kBlock) a += lossb[b];
+    for (int b = b0 + (int)threadIdx.x; b < b1; b += NT) a += A.lossb[b];
     const float tl = block_sum(a, red);
-    if (threadIdx.x == 0) loss_part[blockIdx.x] = tl;
+    if (threadIdx.x == 0) A.part[(size_t)A.n_part * ld + block_id] = tl;
   }
 }
 
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_bias_final(DrxCdaeParams P, DrxOptim opt, int B, const float *__restrict__ part,
-                                                       int n_part, const float *__restrict__ lossb, float *loss_out) {
-  extern __shared__ __align__(16) float lds[];   // [R, ld]
-  __shared__ float red[kBlock / 64];
-  constexpr int R = kBlock / G;
+template <int G, int J, int NT>
+__device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const DrxOptim &opt, const BiasArgs &A,
+                                                float *lds /* [NT/G, ld] */, float *red) {
+  constexpr int R = NT / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   float4 acc[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  for (int i = r; i < n_part; i += R) {
+  for (int i = r; i < A.n_part; i += R) {
     float4 v[J];
-    load_row<G, J>(part, (size_t)i, P.ld, lane, v);
+    load_row<G, J>(A.part, (size_t)i, P.ld, lane, v);
 #pragma unroll
     for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
   }
@@ -606,16 +611,36 @@ __global__ __launch_bounds__(kBlock) void k_bias_final(DrxCdaeParams P, DrxOptim
       for (int j = 0; j < J; ++j) f4_add(g[j], v[j]);
     }
     load_row<G, J>(P.b, 0, P.ld, lane, w);
-    OptScalars o = opt_for(opt, 0, B);
+    OptScalars o = opt_for(opt, 0, A.B);
     o.rb = 0.f;
     row_update<G, J>(o, P.b, opt.s1[3], opt.s2[3], 0, P.ld, lane, w, g);
   }
-  if (loss_out) {   // mean of the per-sample losses from the per-block partials, fixed order
+  if (A.loss_out) {   // mean of the per-sample losses from the per-block partials, fixed order
+    const float *lp = A.part + (size_t)A.n_part * P.ld;
     float a = 0.f;
-    for (int b = threadIdx.x; b < n_part; b += kBlock) a += lossb[b];
+    for (int b = threadIdx.x; b < A.n_part; b += NT) a += lp[b];
     float t = block_sum(a, red);
-    if (threadIdx.x == 0) { loss_out[0] = t / (float)B; loss_out[1] = 0.f; }
+    if (threadIdx.x == 0) { A.loss_out[0] = t / (float)A.B; A.loss_out[1] = 0.f; }
   }
+}
+
+// Tail of the sparse step in two launches instead of four:
+//   A (kBlock threads):    blocks [0, n_fix)  combine the SHORT chunk-crossing segments; the rest are the bias partials
+//   B (kFixBlock threads): blocks [0, n_fix)  combine the LONG ones (queued by A); one more block finishes the bias
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_sparse_tail_a(SegBufs S, DirectPolicy pol, BiasArgs A, int n_fix) {
+  extern __shared__ __align__(16) float lds[];   // [kBlock/G, ld]
+  __shared__ float red[kBlock / 64];
+  if ((int)blockIdx.x < n_fix) span_short_body<G, J, DirectPolicy>(S, pol, (int)blockIdx.x, n_fix);
+  else bias_partial_body<G, J, kBlock>(S.ld, A, (int)blockIdx.x - n_fix, lds, red);
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kFixBlock) void k_sparse_tail_b(SegBufs S, DirectPolicy pol, BiasArgs A, int n_fix) {
+  extern __shared__ __align__(16) float lds[];   // [kFixBlock/G, ld] + [kFixBlock/G]
+  __shared__ float red[kFixBlock / 64];
+  if ((int)blockIdx.x < n_fix) span_long_body<G, J, DirectPolicy>(S, pol, (int)blockIdx.x, n_fix, lds);
+  else bias_final_body<G, J, kFixBlock>(pol.P, pol.opt, A, lds, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -886,10 +911,11 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
   DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
+  BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
-    DRX_HIP(hipMemsetAsync(S.n_span, 0, 2 * sizeof(uint32_t), st));                                                    \
+    const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
     EV(0);                                                                                                             \
     hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt,  \
                        scale, qthr, loss_kind, S);                                                                     \
@@ -902,18 +928,13 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
                        pol);                                                                                           \
     EV(3);                                                                                                             \
-    hipLaunchKernelGGL((k_span_short<G, J, DirectPolicy>), dim3(1024), dim3(kBlock), 0, st, SB, pol);                  \
-    if (((size_t)(kFixBlock / G) * (p->ld + 1)) * 4 > 48 * 1024)                                                       \
-      DRX_HIP(hipFuncSetAttribute((const void *)k_span_long<G, J, DirectPolicy>,                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,                                         \
-                                  (int)(((size_t)(kFixBlock / G) * (p->ld + 1)) * 4)));                                \
-    hipLaunchKernelGGL((k_span_long<G, J, DirectPolicy>), dim3(256), dim3(kFixBlock),                                  \
-                       ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4, st, SB, pol);                                      \
+    hipLaunchKernelGGL((k_sparse_tail_a<G, J>), dim3(1024 + n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, SB, pol, BA, \
+                       1024);                                                                                          \
     EV(4);                                                                                                             \
-    hipLaunchKernelGGL((k_bias_partial<G, J>), dim3(n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B, \
-                       S.dz1, S.bpart, rows_per_block, S.lossb, loss_out ? S.bpart + (size_t)S.n_bpart * p->ld : nullptr);     \
-    hipLaunchKernelGGL((k_bias_final<G, J>), dim3(1), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, bt->B,      \
-                       S.bpart, n_bpart, S.bpart + (size_t)S.n_bpart * p->ld, loss_out);                               \
+    if (lds_b > 48 * 1024)                                                                                             \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_sparse_tail_b<G, J>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                  (int)lds_b));                                                                        \
+    hipLaunchKernelGGL((k_sparse_tail_b<G, J>), dim3(256 + 1), dim3(kFixBlock), lds_b, st, SB, pol, BA, 256);          \
     EV(5);                                                                                                             \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);

@@ -101,14 +101,14 @@ __device__ __forceinline__ OptScalars opt_for(const DrxOptim &opt, int var, int 
 }
 
 // Deterministic block reduction of one float per thread -> thread 0 holds the sum.
-__device__ __forceinline__ float block_sum(float v, float *red /* [kBlock/64] in LDS */) {
+__device__ __forceinline__ float block_sum(float v, float *red /* [blockDim.x/64] in LDS */) {
   v = group_sum<64>(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   float t = 0.f;
   if (threadIdx.x == 0)
-    for (int i = 0; i < kBlock / 64; ++i) t += red[i];
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
   return t;
 }
 

@@ -155,14 +155,14 @@ __global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
 //                  R partial sums are combined in a fixed order.  Both tiers are deterministic.
 
 template <int G, int J, class Policy>
-__global__ __launch_bounds__(kBlock) void k_span_short(SegBufs S, Policy pol) {
+__device__ __forceinline__ void span_short_body(const SegBufs &S, const Policy &pol, int block_id, int n_blocks) {
   const int lane = threadIdx.x % G;
   const int gshift = (threadIdx.x & 63) / G * G;          // position of this group's lanes in the wave's ballot
   const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
   const uint32_t n_span = S.n_span[0];
   const int gpb = kBlock / G;
   constexpr int UL = J == 1 ? 8 : 2;                       // partial rows in flight
-  for (uint32_t si = blockIdx.x * gpb + threadIdx.x / G; si < n_span; si += gridDim.x * gpb) {
+  for (uint32_t si = block_id * gpb + threadIdx.x / G; si < n_span; si += n_blocks * gpb) {
     const int g0 = (int)S.span_list[si];
     const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
     // m = number of following chunks that continue this segment: a run of "middle" chunks (flag 2), closed by an
@@ -210,13 +210,18 @@ __global__ __launch_bounds__(kBlock) void k_span_short(SegBufs S, Policy pol) {
 }
 
 template <int G, int J, class Policy>
-__global__ __launch_bounds__(kFixBlock) void k_span_long(SegBufs S, Policy pol) {
-  extern __shared__ __align__(16) float lds[];   // [R, ld] + [R]
+__global__ __launch_bounds__(kBlock) void k_span_short(SegBufs S, Policy pol) {
+  span_short_body<G, J, Policy>(S, pol, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// lds: [R, ld] + [R] floats, R = kFixBlock / G
+template <int G, int J, class Policy>
+__device__ __forceinline__ void span_long_body(const SegBufs &S, const Policy &pol, int block_id, int n_blocks, float *lds) {
   constexpr int R = kFixBlock / G;
   float *sc = lds + (size_t)R * S.ld;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const uint32_t n_long = S.n_span[1];
-  for (uint32_t si = blockIdx.x; si < n_long; si += gridDim.x) {
+  for (uint32_t si = block_id; si < n_long; si += n_blocks) {
     const int g0 = (int)S.long_list[si];
     const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
     float4 acc[J];
@@ -281,6 +286,12 @@ __global__ __launch_bounds__(kFixBlock) void k_span_long(SegBufs S, Policy pol) 
       pol.template finish<G, J>(key, min(S.T, (g0 + 1) * kChunk) - 1, lane, t, ts);
     }
   }
+}
+
+template <int G, int J, class Policy>
+__global__ __launch_bounds__(kFixBlock) void k_span_long(SegBufs S, Policy pol) {
+  extern __shared__ __align__(16) float lds[];   // [R, ld] + [R]
+  span_long_body<G, J, Policy>(S, pol, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 
 }  // namespace drx

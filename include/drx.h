@@ -128,7 +128,8 @@ int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxH
 
 /* Same step with per-phase timing: `events` holds DRX_SPARSE_PHASES + 1 caller-created hipEvent_t; event i is recorded
  * on `stream` before phase i, the last one after the final phase.  Phases: 0 gather+forward+backward (k_sampled_fwd_bwd),
- * 1 touch sort, 2 segmented reduce + row update (k_seg_reduce), 3 cross-chunk fix-up, 4 hidden-bias update. */
+ * 1 touch sort, 2 segmented reduce + row update (k_seg_reduce), 3 tail launch A (short chunk-crossing segments, and beside
+ * them the column-sum partials of the hidden-bias gradient), 4 tail launch B (long segments, and the hidden-bias update). */
 #define DRX_SPARSE_PHASES 5
 int drx_cdae_step_sparse_timed(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist,
                                const DrxBatch *bt, int32_t loss_kind, void *scratch, size_t scratch_bytes,
