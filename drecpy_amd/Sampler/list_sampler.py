@@ -12,6 +12,8 @@ size check is retried up to 20 times after the first (then raises).
 """
 import random
 
+import numpy as np
+
 from ..Dataset import InteractionDatasetABC
 
 
@@ -47,9 +49,24 @@ class ListSampler:
         cols = [firsts._cols[c] for c in group_columns]
         self.unique_groups = list(cols[0]) if len(cols) == 1 else [list(vals) for vals in zip(*cols)]
         self.unique_negative_ids = set(ds.unique(negative_ids_col)._cols[negative_ids_col])
+        # rows of every group, already in their final order: record order, or (stable) sort_column order — one vectorised
+        # stable sort over the whole dataset instead of a Python sort per group on its first draw
         self._rows_of_group = {}
-        for row, key in enumerate(zip(*[ds._cols[c].tolist() for c in group_columns])):
-            self._rows_of_group.setdefault(key, []).append(row)
+        self._presorted = False
+        if len(group_columns) == 1 and len(ds):
+            gcol = ds._cols[group_columns[0]]
+            if sort_column is not None:
+                order = np.lexsort((ds._cols[sort_column], gcol))        # by group, then sort key; ties keep record order
+            else:
+                order = np.argsort(gcol, kind='stable')
+            gs = gcol[order]
+            cuts = np.flatnonzero(gs[1:] != gs[:-1]) + 1
+            for key, rows in zip(gs[np.concatenate([[0], cuts])].tolist(), np.split(order, cuts)):
+                self._rows_of_group[(key,)] = rows.tolist()
+            self._presorted = True
+        else:
+            for row, key in enumerate(zip(*[ds._cols[c].tolist() for c in group_columns])):
+                self._rows_of_group.setdefault(key, []).append(row)
         # per-group results that do not depend on the RNG (sorted positive rows, eligible-negative tuple) are memoised:
         # a group is drawn many times over a fit (4096 draws per step over a few thousand users in examples/caser.py)
         self._memo_rows, self._memo_negs = {}, {}
@@ -87,7 +104,7 @@ class ListSampler:
         needed = self.min_positive_records + (self.n_targets or 0)
         if len(rows) < self.min_positive_records or len(rows) < needed:
             raise _Retry(f'consider reducing the min_group_records ({self.min_positive_records}).')
-        if self.sort_column is not None:
+        if self.sort_column is not None and not self._presorted:
             keys = self.interaction_dataset._cols[self.sort_column]
             rows = sorted(rows, key=lambda r: keys[r])           # stable, like list.sort in the reference
         return list(rows)
@@ -105,7 +122,7 @@ class ListSampler:
         hit = self._memo_negs.get(key)
         if hit is None:
             ids = self.interaction_dataset._cols[self.negative_ids_col]
-            hit = tuple(self.unique_negative_ids.difference(set([ids[r] for r in all_rows])))
+            hit = tuple(self.unique_negative_ids.difference(ids[np.asarray(all_rows, dtype=np.int64)].tolist()))
             if self._memo_budget >= len(hit):
                 self._memo_budget -= len(hit)
                 self._memo_negs[key] = hit
