@@ -419,6 +419,7 @@ struct SparseBufs {
   uint8_t *cflag;                             // [n_chunks]
   uint32_t *n_span;                           // [0] crossing segments, [1] long ones
   float *bpart;                               // [n_bpart, ld]
+  const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row
   int T, n_chunks, n_bpart;
 };
 
@@ -448,7 +449,52 @@ __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHisto
 }
 
 template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
+__device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOptim &opt, int B, uint32_t key, int lane,
+                                             const float4 (&g)[J], float gs) {
+  const uint32_t N = (uint32_t)P.n_items;
+  // read every candidate pointer as a scalar first, then select VALUES (a dynamic index into the kernarg pointer
+  // arrays would become a vector load + s_waitcnt vmcnt(0))
+  float *const tW = P.W, *const tO = P.W2T, *const tV = P.V;
+  float *const a0 = opt.s1[0], *const a1 = opt.s1[1], *const a2 = opt.s1[2];
+  float *const c0 = opt.s2[0], *const c1 = opt.s2[1], *const c2 = opt.s2[2];
+  const int var = key < N ? 0 : (key < 2 * N ? 1 : 2);
+  const size_t row = key - (uint32_t)var * N;
+  float *const tab = var == 0 ? tW : (var == 1 ? tO : tV);
+  float *const s1 = var == 0 ? a0 : (var == 1 ? a1 : a2);
+  float *const s2 = var == 0 ? c0 : (var == 1 ? c1 : c2);
+  OptScalars o = opt_for(opt, 0, B);
+  float4 w[J];
+  load_row<G, J>(tab, row, P.ld, lane, w);
+  row_update<G, J>(o, tab, s1, s2, row, P.ld, lane, w, g);
+  if (var == 1 && lane == 0) {
+    float pb = P.b2[row], m = opt.s1[4][row], v = o.kind == DRX_OPT_ADAM ? opt.s2[4][row] : 0.f;
+    o.rb = 0.f;
+    opt_update1(o, gs, pb, m, v);
+    P.b2[row] = pb; opt.s1[4][row] = m;
+    if (o.kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
+  }
+}
+
+// V and W2T rows are mostly touched by ONE sample of the batch (a user is drawn once, output items are uniform).  When the
+// touch list is prepared ahead of the step, such rows are marked here: the forward/backward kernel, which holds the
+// sample's gradient rows in registers, then applies their update itself (no g2 row written, no re-read of the gradient
+// and of the parameter row later), and the touch is blanked (DRX_KEY_NONE) so that the segmented reduction passes over
+// it.  A sole toucher cannot race: no other sample of the batch reads or writes that V / W2T row.
+__global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, uint32_t n_items, uint8_t *solo_v,
+                            uint8_t *solo_o) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
+    const uint32_t k = keys_s[j];
+    if (k == DRX_KEY_NONE || k < n_items) continue;
+    const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
+    if (k == prev || k == next) continue;            // (a neighbour blanked concurrently was a different key anyway)
+    const uint32_t b = vals_s[j];
+    if (k < 2 * n_items) solo_o[b] = 1; else solo_v[b] = 1;
+    keys_s[j] = DRX_KEY_NONE;
+  }
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
                                                             uint32_t qthr, int loss_kind, SparseBufs S) {
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
@@ -479,35 +525,16 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
     g2[j].x = dz2 * h[j].x; g2[j].y = dz2 * h[j].y; g2[j].z = dz2 * h[j].z; g2[j].w = dz2 * h[j].w;
   }
   store_row<G, J>(S.dz1, (size_t)b, P.ld, lane, dz1);
-  store_row<G, J>(S.g2, (size_t)b, P.ld, lane, g2);
-  if (lane == 0) { S.dz2[b] = dz2; S.lossb[b] = lval; }
-}
-
-template <int G, int J>
-__device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOptim &opt, int B, uint32_t key, int lane,
-                                             const float4 (&g)[J], float gs) {
-  const uint32_t N = (uint32_t)P.n_items;
-  // read every candidate pointer as a scalar first, then select VALUES (a dynamic index into the kernarg pointer
-  // arrays would become a vector load + s_waitcnt vmcnt(0))
-  float *const tW = P.W, *const tO = P.W2T, *const tV = P.V;
-  float *const a0 = opt.s1[0], *const a1 = opt.s1[1], *const a2 = opt.s1[2];
-  float *const c0 = opt.s2[0], *const c1 = opt.s2[1], *const c2 = opt.s2[2];
-  const int var = key < N ? 0 : (key < 2 * N ? 1 : 2);
-  const size_t row = key - (uint32_t)var * N;
-  float *const tab = var == 0 ? tW : (var == 1 ? tO : tV);
-  float *const s1 = var == 0 ? a0 : (var == 1 ? a1 : a2);
-  float *const s2 = var == 0 ? c0 : (var == 1 ? c1 : c2);
-  OptScalars o = opt_for(opt, 0, B);
-  float4 w[J];
-  load_row<G, J>(tab, row, P.ld, lane, w);
-  row_update<G, J>(o, tab, s1, s2, row, P.ld, lane, w, g);
-  if (var == 1 && lane == 0) {
-    float pb = P.b2[row], m = opt.s1[4][row], v = o.kind == DRX_OPT_ADAM ? opt.s2[4][row] : 0.f;
-    o.rb = 0.f;
-    opt_update1(o, gs, pb, m, v);
-    P.b2[row] = pb; opt.s1[4][row] = m;
-    if (o.kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
+  if (lane == 0) S.lossb[b] = lval;
+  const uint8_t *const pv = S.solo_v, *const po = S.solo_o;
+  const bool solo_v = pv && pv[b], solo_o = po && po[b];
+  if (solo_o) {      // this sample alone touches W2T[i] and b2[i]: update them here (same arithmetic as the segment path)
+    sparse_apply<G, J>(P, opt, bt.B, (uint32_t)P.n_items + (uint32_t)i, lane, g2, dz2);
+  } else {
+    store_row<G, J>(S.g2, (size_t)b, P.ld, lane, g2);
+    if (lane == 0) S.dz2[b] = dz2;
   }
+  if (solo_v) sparse_apply<G, J>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
 }
 
 // Policy of the single-GPU sparse step for the generic segmented reduction (drx_segreduce.hpp):
@@ -700,6 +727,7 @@ struct PrepBufs {
   uint32_t *keys_s, *vals_s, *keys, *vals;
   void *sort_temp;
   size_t sort_bytes;
+  uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo)
   int T, bits;
 };
 
@@ -713,6 +741,8 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.vals = cv.take<uint32_t>(R.T);
   R.sort_bytes = sort_pairs_temp_bytes(R.T, R.bits);
   R.sort_temp = cv.take<char>(R.sort_bytes);
+  R.solo_v = cv.take<uint8_t>((size_t)2 * B);
+  R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
   return R;
 }
 
@@ -881,6 +911,14 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
   return sort_pairs(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, st);
 }
 
+// Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
+static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
+  DRX_HIP(hipMemsetAsync(R.solo_v, 0, (size_t)bt->B * 2, st));       // solo_v and solo_o are adjacent
+  hipLaunchKernelGGL(k_mark_solo, dim3(2048), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, (uint32_t)p->n_items, R.solo_v,
+                     R.solo_o);
+  return DRX_OK;
+}
+
 static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
                             int32_t loss_kind, const void *prepared, size_t prepared_bytes, void *scratch, size_t scratch_bytes,
                             float *loss_out, void *const *events, void *stream) {
@@ -908,6 +946,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const uint32_t qthr = q_threshold(bt->q);
   const int rows_per_block = (bt->B + S.n_bpart - 1) / S.n_bpart;
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
+  S.solo_v = prepared ? R.solo_v : nullptr;
+  S.solo_o = prepared ? R.solo_o : nullptr;
   SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
   DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
@@ -917,7 +957,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     const int gpb = kBlock / G;                                                                                        \
     const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
     EV(0);                                                                                                             \
-    hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt,  \
+    hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt,  \
                        scale, qthr, loss_kind, S);                                                                     \
     EV(1);                                                                                                             \
     if (!prepared) {                                                                                                   \
@@ -961,6 +1001,8 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
   if (!cp.ok()) return DRX_ESCRATCH;
   rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = mark_solo(p, bt, R, (hipStream_t)stream);
   if (rc) return rc;
   DRX_LAUNCH_CHECK();
   return DRX_OK;
