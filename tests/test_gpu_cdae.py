@@ -99,7 +99,11 @@ def test_dense_steps_match_oracle(K, B, loss, targets):
 @pytest.mark.parametrize('K,B,opt,loss,explicit', [(128, 256, 'adagrad', 'bce', True), (50, 64, 'adagrad', 'bce', False),
                                                    (8, 100, 'adam', 'mse', True), (128, 4096, 'adagrad', 'bce', False),
                                                    (300, 50, 'adam', 'bce', False)])
-def test_sparse_steps_match_oracle(K, B, opt, loss, explicit):
+@pytest.mark.parametrize('prepared', [False, True])
+def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
+    """prepared=True: the touch list is built ahead by drx_cdae_sparse_prepare, which also marks the V / W2T rows a single
+    sample touches; those are then updated by the forward kernel (batches of 50-100 over 120 users and 260 items mix sole
+    and shared rows)."""
     U, N = 120, 260
     eng, p, rng = _engine(U, N, K, seed=2)
     indptr, indices = synth_history(rng, U, N, 14, zipf=1.1)
@@ -128,7 +132,7 @@ def test_sparse_steps_match_oracle(K, B, opt, loss, explicit):
             bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
         _, _, kept = batch_rows(indptr, indices, uids, N, keep)
         lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, lr, 1e-3, loss, opt)
-        lg = eng.step_sparse(step, bt, loss, want_loss=True).cpu().numpy()
+        lg = eng.step_sparse(step, bt, loss, want_loss=True, prepared=eng.prepare_sparse(bt) if prepared else None).cpu().numpy()
         assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
     _, pred = eng.forward(probe)
     _, po = co.forward(p, probe, tp.astype(np.float64))

@@ -50,7 +50,9 @@ def _run(U, N, K, indptr, indices, batches, q, mode, opt='adagrad', explicit=Tru
         else:
             bt, alive = eng.make_batch(uids, np.asarray(iids), np.asarray(y, np.float32), q=q, **kw)
             lo, _ = co.sparse_step(p, st, step, uids, np.asarray(iids), np.asarray(y, np.float64), kept, qf, lr, 1e-3, 'bce', opt)
-            lg = float(eng.step_sparse(step, bt, want_loss=True)[0].item())
+            # odd steps go through the prepared path (touch list built ahead, sole-toucher rows updated by the forward kernel)
+            prep = eng.prepare_sparse(bt) if step % 2 else None
+            lg = float(eng.step_sparse(step, bt, want_loss=True, prepared=prep)[0].item())
         assert abs(lg - lo) <= 1e-4 * abs(lo) + 1e-7, (step, lg, lo)
     g = eng.get_params()
     for k in p:
