@@ -104,3 +104,19 @@ SHAPES = {
     'ml-1m': (6040, 3706, 300, 20, 1.0),        # ~940k positives (ml-1m train: 939 809)
     'synth-10m': (10_000_000, 1_000_000, 23.4, 5, 1.05),   # ~200M positives
 }
+
+
+def dataset(shape='ml-100k', seed=0, extra_per_user=0, with_timestamp=True):
+    """InteractionDataset shaped like a MovieLens set (users, items, ratings 1..5, shuffled rows, timestamps): the
+    offline stand-in for DRecPy's get_train_dataset('ml-100k') etc. (integrated_datasets.py:111), which download."""
+    from .Dataset import InteractionDataset
+    U, N, md, mn, a = SHAPES[shape]
+    ip, idx = synth_history(U, N, md + extra_per_user, mn, a, seed=seed)
+    ip, idx = ip.numpy(), idx.numpy()
+    rng = np.random.RandomState(seed)
+    user = np.repeat(np.arange(U, dtype=np.int64), np.diff(ip)) + 1
+    perm = rng.permutation(len(user))
+    cols = {'user': user[perm], 'item': (idx.astype(np.int64) + 1)[perm], 'interaction': rng.randint(1, 6, size=len(user))[perm]}
+    if with_timestamp:
+        cols['timestamp'] = rng.randint(0, 10 ** 9, size=len(user))[perm]
+    return InteractionDataset.read_df(cols, verbose=False)
