@@ -50,6 +50,21 @@ def parse():
     return ap.parse_args()
 
 
+def hbm_copy_gbs(dev, gib=2, reps=8):
+    """Achievable HBM rate on this box: a device-to-device copy of `gib` GiB (read + write counted), GB/s."""
+    n = gib * (1 << 30) // 4
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        dst.copy_(src)
+    ev[1].record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+
+
 def hash_u32_torch(seed, a, b):
     """drx_hash_u32 restated with wrapping int64 torch ops (to count surviving inputs of a batch exactly)."""
     def c(v):
@@ -295,8 +310,16 @@ def main():
     ph = phases.mean(axis=0)
     # algorithmic bytes per launch: forward reads 4K*R per sample; the update reads and
     # writes parameter + S optimizer slots per touched-row occurrence: 4K*R*(2+2S), S = 1 for Adagrad.
-    alg_fwd = B * 4.0 * K * rows_per_sample
-    alg_upd = B * 4.0 * K * rows_per_sample * 4.0
+    # With a touch list prepared ahead, V / W2T rows touched by a single triple of the batch are updated by the forward kernel
+    # (k_mark_solo): their (2+2S) update bytes are charged to it instead of the segmented reduction.
+    f_solo = 0.0
+    if stepper is None and overlap:
+        uid0, iid0 = batches[0][0].long(), batches[0][1].long()
+        for col in (uid0, iid0):
+            _, inv, cnt = torch.unique(col, return_inverse=True, return_counts=True)
+            f_solo += float((cnt[inv] == 1).float().mean().item())
+    alg_fwd = B * 4.0 * K * (rows_per_sample + f_solo * 4.0)
+    alg_upd = B * 4.0 * K * (rows_per_sample - f_solo) * 4.0
     if stepper is None:
         names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce',
                  'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
@@ -318,6 +341,7 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    copy_gbs = hbm_copy_gbs(dev) if rank == 0 else None
     if rank == 0:
         out = {
             'metric': 'training samples/sec (user-item pairs)', 'value': world * B * args.steps / dt, 'unit': 'samples/s',
@@ -327,6 +351,7 @@ def main():
                                    f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
                                    f'corruption {Q}, neg_ratio {NEG_RATIO}',
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
+                       'sole_toucher_rows_per_sample': round(f_solo, 3),
                        'touch_list': ('keys exchanged one batch ahead, counts two (dist.ShardedPipeline)' if pipe is not None else 'prepared one batch ahead on a side stream') if overlap else 'inline',
                        'batches': 'fresh device-sampled batch every step (sampler two steps ahead on the side stream)' if fresh
                        else f'{args.n_batches} pre-sampled batches cycled',
@@ -340,7 +365,8 @@ def main():
                          'traffic_rate': (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                          'traffic_frac': (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
-                         'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         'hbm_copy_achievable': copy_gbs},     # read+write rate of a 2 GiB device copy on this box, GB/s
             'phases_ms': {n: float(v) for n, v in zip(names, ph)},
             'setup_s': round(setup_s, 1),
             'host_issue_ms_per_step': ([round(1e3 * t / (args.warmup + args.steps), 4) for t in pipe.host_s + [stepper.wait_s]] if pipe is not None else None),
