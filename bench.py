@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
+    ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     return ap.parse_args()
 
 
@@ -207,6 +208,7 @@ def main():
                               cpu_staging=debug_gloo, force_collectives=(world == 1 and os.environ.get('DRX_BENCH_RCCL1') == '1'))
         eng = stepper.engine
 
+    micro = max(1, args.micro)       # > 1: micro-batches whose exchanges overlap each other's compute (measured at world 1: the split costs more than it hides)
     # ---- pre-sampled batches, resident in HBM -------------------------------------------------------------
     batches, structs, kept_tot = [], [], 0
     for i in range(args.n_batches):
@@ -215,9 +217,22 @@ def main():
         torch.cuda.synchronize()
         n_slots = int(keep_off[-1].item())
         kept_tot += kept_count(keep_off, seed, Q)
-        bt, alive = eng.make_batch(uid, iid, y, keep_off=keep_off, q=Q, mask_seed=seed, n_touch_slots=n_slots)
         batches.append((uid, iid, y, keep_off, seed))
-        structs.append((bt, alive))
+        if stepper is not None and micro > 1:
+            # micro-batches of a sharded step: the triples split by uid so that no user is in two of them
+            parts = []
+            for m in range(micro):
+                ix = torch.nonzero(uid % micro == m).squeeze(1)
+                um = uid[ix].contiguous()
+                deg = (indptr[um.long() + 1] - indptr[um.long()]).to(torch.int32)
+                ko = torch.zeros(um.numel() + 1, dtype=torch.int32, device=dev)
+                ko[1:] = torch.cumsum(deg, 0)
+                parts.append(eng.make_batch(um, iid[ix].contiguous(), y[ix].contiguous(), keep_off=ko, q=Q, mask_seed=seed + 1000003 * m,
+                                            n_touch_slots=int(ko[-1].item())))
+            structs.append(([p_[0] for p_ in parts], parts))
+        else:
+            bt, alive = eng.make_batch(uid, iid, y, keep_off=keep_off, q=Q, mask_seed=seed, n_touch_slots=n_slots)
+            structs.append((bt, alive))
     rows_per_sample = kept_tot / (args.n_batches * B) + 2.0          # R: kept W rows + V row + W2T row
     setup_s = time.time() - t_setup
 
@@ -325,8 +340,9 @@ def main():
                  'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
         dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
-        names = ['row_gather+row_exchange', 'k_shard_fwd_bwd', 'local_reduce+grad_exchange', 'owner_apply', 'bias_allreduce']
-        dom, dom_ms, dom_alg = 'k_shard_fwd_bwd', ph[1], alg_fwd
+        names = ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce(+overlapped exchanges)', 'rest_of_grad_exchange', 'owner_apply', 'bias_allreduce']
+        # forward reads one row per occurrence, the local reduce one gradient row per occurrence
+        dom, dom_ms, dom_alg = 'k_shard_fwd_bwd+k_seg_reduce<LocalPolicy>', ph[1], 2.0 * B * 4.0 * K * rows_per_sample
     achieved = dom_alg / (dom_ms * 1e-3) / 1e9
     step_alg = B * 4.0 * K * rows_per_sample * 5.0
     # HBM traffic of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json), only when that
@@ -355,6 +371,7 @@ def main():
                        'touch_list': ('keys exchanged one batch ahead, counts two (dist.ShardedPipeline)' if pipe is not None else 'prepared one batch ahead on a side stream') if overlap else 'inline',
                        'batches': 'fresh device-sampled batch every step (sampler two steps ahead on the side stream)' if fresh
                        else f'{args.n_batches} pre-sampled batches cycled',
+                       'micro_batches': (micro if stepper is not None else None),
                        'sharding': ('single GPU' if stepper is None else 'row-sharded code path at world 1') if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

@@ -115,7 +115,7 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_shard_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_size_t,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
     'drx_shard_bias_grad': (C.c_int, [C.POINTER(CdaeParams), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),

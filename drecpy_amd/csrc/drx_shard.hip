@@ -253,18 +253,18 @@ struct OwnerPolicy {
 // of sorting them again, every received row is entered in a direct-address table tab[local key][source] = row index
 // (no two writers per entry); then the row of the LOWEST source holding a key sums all holders in source order and
 // applies the optimizer — one pass, fixed summation order, no sort, no atomics.
-struct SegOff { int off[DRX_MAX_WORLD + 1]; };
+struct SegOff { int off[DRX_MAX_WORLD * DRX_MAX_MICRO + 1]; int n_seg; };   // segments: micro-batch-major, then source rank
 
-__device__ __forceinline__ int source_of(const SegOff &so, int world, int j) {
+__device__ __forceinline__ int source_of(const SegOff &so, int j) {
   int s = 0;
-  while (s + 1 < world && j >= so.off[s + 1]) ++s;
+  while (s + 1 < so.n_seg && j >= so.off[s + 1]) ++s;
   return s;
 }
 
 __global__ void k_owner_scatter(DrxShard sh, SegOff so, const uint32_t *__restrict__ recv_keys, int n, uint32_t *tab) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const uint32_t lk = recv_keys[j] - (uint32_t)(sh.rank * 2 * sh.items_per_rank);
-    tab[(size_t)lk * sh.world + source_of(so, sh.world, j)] = (uint32_t)j;
+    tab[(size_t)lk * so.n_seg + source_of(so, j)] = (uint32_t)j;
   }
 }
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_apply(OwnerPolicy pol, SegOff 
                                                         const uint32_t *__restrict__ tab) {
   const int lane = threadIdx.x % G;
   const int gpb = kBlock / G;
-  const int W = pol.sh.world;
+  const int W = so.n_seg;                          // holders of a key are looked up per (micro-batch, source rank) segment
   for (int j = blockIdx.x * gpb + threadIdx.x / G; j < n; j += gridDim.x * gpb) {
     const uint32_t key = recv_keys[j];
     const uint32_t lk = key - (uint32_t)(pol.sh.rank * 2 * pol.sh.items_per_rank);
@@ -450,7 +450,7 @@ static SegLayout seg_layout(Carver &cv, int ld, int T, int sort_bits) {
 }
 
 static uint32_t *owner_table(Carver &cv, const DrxShard &sh) {
-  return cv.take<uint32_t>((size_t)2 * sh.items_per_rank * sh.world);
+  return cv.take<uint32_t>((size_t)2 * sh.items_per_rank * sh.world * DRX_MAX_MICRO);
 }
 
 static int key_bits(const DrxShard &sh) {
@@ -593,22 +593,24 @@ int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard
 }
 
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, void *scratch,
-                    size_t scratch_bytes, void *stream) {
+                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, int32_t n_segments,
+                    void *scratch, size_t scratch_bytes, void *stream) {
   if (!p || !opt || check_shard(sh) || n < 0 || b_norm < 1 || !scratch || !recv_counts) return DRX_EINVAL;
+  if (n_segments < sh->world || n_segments % sh->world || n_segments > sh->world * DRX_MAX_MICRO) return DRX_EINVAL;
   if (n == 0) return DRX_OK;
   if (!recv_keys || !recv_rows || !recv_b2) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   SegOff so{};
-  for (int s = 0; s < sh->world; ++s) {
+  so.n_seg = n_segments;
+  for (int s = 0; s < n_segments; ++s) {
     if (recv_counts[s] < 0) return DRX_EINVAL;
     so.off[s + 1] = so.off[s] + recv_counts[s];
   }
-  if (so.off[sh->world] != n) return DRX_EINVAL;
+  if (so.off[n_segments] != n) return DRX_EINVAL;
   Carver cv(scratch, scratch_bytes);
   uint32_t *tab = owner_table(cv, *sh);
   if (!cv.ok()) return DRX_ESCRATCH;
-  DRX_HIP(hipMemsetAsync(tab, 0xFF, (size_t)2 * sh->items_per_rank * sh->world * 4, st));
+  DRX_HIP(hipMemsetAsync(tab, 0xFF, (size_t)2 * sh->items_per_rank * n_segments * 4, st));
   hipLaunchKernelGGL(k_owner_scatter, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, *sh, so, recv_keys, n, tab);
   OwnerPolicy pol{*p, *opt, *sh, b_norm, recv_rows, recv_b2};
 #define CALL(G, J)                                                                                                     \

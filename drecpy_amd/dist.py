@@ -114,24 +114,25 @@ class HipShardOps:
         return rows[:n], b2v[:n]
 
     def fwd_bwd(self, bt, slot_of_pos, rows_cache, b2_cache, b_norm, loss_kind):
+        """Returns the per-sample gradient buffers of this (micro-)batch: the context reduce() and bias_grad() consume."""
         B = bt.B
-        self.dz1, self.g2 = self._e(B, self.ld), self._e(B, self.ld)
-        self.dz2, self.lossb = self._e(B), self._e(B)
+        ctx = {'dz1': self._e(B, self.ld), 'g2': self._e(B, self.ld), 'dz2': self._e(B), 'lossb': self._e(B)}
         if rows_cache.numel() == 0:
             rows_cache, b2_cache = self._e(1, self.ld), self._e(1)
         p = self._lib.ptr
         self._lib.check(self.L.drx_shard_fwd_bwd(C.byref(self.engine._params), C.byref(self.engine._hist), C.byref(bt),
-                                                 p(slot_of_pos), p(rows_cache), p(b2_cache), b_norm, loss_kind, p(self.dz1),
-                                                 p(self.g2), p(self.dz2), p(self.lossb), self._stream()), 'drx_shard_fwd_bwd')
+                                                 p(slot_of_pos), p(rows_cache), p(b2_cache), b_norm, loss_kind, p(ctx['dz1']),
+                                                 p(ctx['g2']), p(ctx['dz2']), p(ctx['lossb']), self._stream()), 'drx_shard_fwd_bwd')
+        return ctx
 
-    def reduce(self, idx, bpos, q_item, b_norm, q, opt):
+    def reduce(self, idx, bpos, q_item, b_norm, q, opt, ctx):
         T = idx['keys_s'].numel()
         gc, gb2c = self._e(max(q_item, 1), self.ld), self._e(max(q_item, 1))
         sc = self._sc(T)
         p = self._lib.ptr
         self._lib.check(self.L.drx_shard_reduce(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), b_norm,
                                                 float(q), p(idx['keys_s']), p(idx['vals_s']), p(idx['slot_sorted']), p(bpos),
-                                                T, p(self.dz1), p(self.g2), p(self.dz2), p(gc), p(gb2c), p(sc), sc.numel(),
+                                                T, p(ctx['dz1']), p(ctx['g2']), p(ctx['dz2']), p(gc), p(gb2c), p(sc), sc.numel(),
                                                 self._stream()), 'drx_shard_reduce')
         return gc[:q_item], gb2c[:q_item]
 
@@ -141,16 +142,16 @@ class HipShardOps:
             return
         sc = self._sc(n)
         p = self._lib.ptr
-        counts = (C.c_int32 * self.world)(*[int(c) for c in recv_counts])
+        counts = (C.c_int32 * len(recv_counts))(*[int(c) for c in recv_counts])      # world x micro-batches segments
         self._lib.check(self.L.drx_shard_apply(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), b_norm,
                                                p(recv_keys), p(recv_rows.contiguous()), p(recv_b2.contiguous()), n, counts,
-                                               p(sc), sc.numel(), self._stream()), 'drx_shard_apply')
+                                               len(recv_counts), p(sc), sc.numel(), self._stream()), 'drx_shard_apply')
 
-    def bias_grad(self, B):
+    def bias_grad(self, B, ctx):
         out = self._e(self.ld + 1)
         sc = self._sc(1)
         p = self._lib.ptr
-        self._lib.check(self.L.drx_shard_bias_grad(C.byref(self.engine._params), p(self.dz1), p(self.lossb), B, p(out), p(sc),
+        self._lib.check(self.L.drx_shard_bias_grad(C.byref(self.engine._params), p(ctx['dz1']), p(ctx['lossb']), B, p(out), p(sc),
                                                    sc.numel(), self._stream()), 'drx_shard_bias_grad')
         return out
 
@@ -246,6 +247,24 @@ class ShardedCdae:
                                input_split_sizes=list(send_counts), group=self.group)
         return out
 
+    def _a2a_start(self, send, send_counts, recv_counts, out=None, overlap=False):
+        """all-to-all(v) that the caller waits for later: returns (received tensor, wait()-able or None).  The training stream
+        keeps running kernels of another micro-batch while the rows travel."""
+        n = int(sum(recv_counts))
+        if out is None:
+            out = torch.empty((n,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if not self.collectives:
+            out.copy_(send[:n])
+            return out, None
+        if (self.cpu_staging and send.is_cuda) or not send.is_cuda:
+            out.copy_(self._a2a(send, send_counts, recv_counts))
+            return out, None
+        # async_op only when there is another micro-batch to compute meanwhile: on one micro-batch the asynchronous form was
+        # measured slower (1-rank RCCL: 1.15 vs 1.05 ms/step)
+        work = dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
+                                      input_split_sizes=list(send_counts), group=self.group, async_op=overlap)
+        return out, (work if overlap else None)
+
     def _counts(self, send_counts, device):
         if not self.collectives:
             return list(send_counts)
@@ -324,32 +343,67 @@ class ShardedCdae:
                 P['req'].record_stream(P['consumer'])
         return P
 
-    def step(self, step, bt, events=None, want_loss=False, prepared=None):
+    def step(self, step, bt, events=None, want_loss=False, prepared=None, after_row_requests=None):
+        """One training step of this rank.  `bt` is a DrxBatch or a list of up to DRX_MAX_MICRO micro-batches with pairwise
+        DISJOINT users (then `prepared` is the matching list): all micro-batches read the pre-step parameters and every
+        owned row is updated once with the sum of their gradients — the step still equals the single-process step on the
+        concatenated batch — but the row exchange of micro-batch m+1 and the gradient exchange of micro-batch m travel while
+        the other one computes.
+        Event slots (bench): [0,1) row gather + the first row exchange, [1,2) forward/backward + local reduce of all
+        micro-batches (later row / earlier gradient exchanges hidden behind them), [2,3) rest of the gradient exchange,
+        [3,4) owner apply, [4,5) bias.
+        after_row_requests: called once the row exchanges of this step are queued — ShardedPipeline queues the run-ahead
+        count / key exchanges of later batches there, so that on the communicator they sit behind this step's row exchange
+        (and travel while it computes) instead of in front of it."""
         ops = self.ops
-        b_norm = bt.B * self.world
+        bts = list(bt) if isinstance(bt, (list, tuple)) else [bt]
+        Ps = (list(prepared) if isinstance(prepared, (list, tuple)) else [prepared]) if prepared is not None else [None] * len(bts)
+        b_norm = sum(b.B for b in bts) * self.world
         opt = ops.optim(step)
         rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
+        wait = lambda w: w.wait() if w is not None else None
         rec(0)
-        P = prepared if prepared is not None else self.prepare(bt)
-        if 'req' not in P:
-            self.exchange_keys(P)
-        elif P['event'] is not None:
-            torch.cuda.current_stream().wait_event(P['event'])
-        idx, bpos, req = P['idx'], P['bpos'], P['req']
-        send_counts, recv_counts, q_item = P['send_counts'], P['recv_counts'], P['q_item']
-        rows, b2v = ops.gather_rows(req)
-        rows_cache = self._a2a(rows, recv_counts, send_counts)
-        b2_cache = self._a2a(b2v, recv_counts, send_counts)
-        rec(1)        # [0,1): (stages not run ahead,) row gather + row exchange
-        ops.fwd_bwd(bt, idx['slot_of_pos'], rows_cache, b2_cache, b_norm, self.loss_kind)
-        rec(2)        # [1,2): forward/backward
-        gc, gb2c = ops.reduce(idx, bpos, q_item, b_norm, bt.q, opt)
-        rg = self._a2a(gc, send_counts, recv_counts)
-        rb2 = self._a2a(gb2c, send_counts, recv_counts)
-        rec(3)        # [2,3): local reduce + gradient exchange
-        ops.apply(req, rg, rb2, b_norm, opt, recv_counts)
-        rec(4)        # [3,4): owner apply
-        gb = ops.bias_grad(bt.B)
+        for m, b in enumerate(bts):
+            P = Ps[m] = Ps[m] if Ps[m] is not None else self.prepare(b)
+            if 'req' not in P:
+                self.exchange_keys(P)
+            elif P['event'] is not None:
+                torch.cuda.current_stream().wait_event(P['event'])
+        fetched = []
+        for P in Ps:                                   # owners answer every micro-batch's request from the pre-step tables
+            rows, b2v = ops.gather_rows(P['req'])
+            fetched.append((self._a2a_start(rows, P['recv_counts'], P['send_counts'], overlap=len(Ps) > 1),
+                            self._a2a_start(b2v, P['recv_counts'], P['send_counts'], overlap=len(Ps) > 1)))
+        if after_row_requests is not None:
+            after_row_requests()
+        wait(fetched[0][0][1]); wait(fetched[0][1][1])
+        rec(1)
+        n_recv = [int(sum(P['recv_counts'])) for P in Ps]
+        rg = rb2 = None
+        pushed, ctxs, off = [], [], 0
+        for m, (b, P) in enumerate(zip(bts, Ps)):
+            (rows_cache, w1), (b2_cache, w2) = fetched[m]
+            wait(w1); wait(w2)
+            ctx = ops.fwd_bwd(b, P['idx']['slot_of_pos'], rows_cache, b2_cache, b_norm, self.loss_kind)
+            gc, gb2c = ops.reduce(P['idx'], P['bpos'], P['q_item'], b_norm, b.q, opt, ctx)
+            if rg is None:                             # one receive buffer for all micro-batches: segments stay adjacent
+                rg = torch.empty((sum(n_recv),) + tuple(gc.shape[1:]), dtype=gc.dtype, device=gc.device)
+                rb2 = torch.empty(sum(n_recv), dtype=gb2c.dtype, device=gb2c.device)
+            ov = len(Ps) > 1
+            pushed.append((self._a2a_start(gc, P['send_counts'], P['recv_counts'], out=rg[off:off + n_recv[m]], overlap=ov)[1],
+                           self._a2a_start(gb2c, P['send_counts'], P['recv_counts'], out=rb2[off:off + n_recv[m]], overlap=ov)[1], gc, gb2c))
+            ctxs.append(ctx)
+            off += n_recv[m]
+        rec(2)
+        for w1, w2, _, _ in pushed:
+            wait(w1); wait(w2)
+        rec(3)
+        req = Ps[0]['req'] if len(Ps) == 1 else torch.cat([P['req'] for P in Ps])
+        ops.apply(req, rg, rb2, b_norm, opt, [c for P in Ps for c in P['recv_counts']])
+        rec(4)
+        gb = ops.bias_grad(bts[0].B, ctxs[0])
+        for b, ctx in zip(bts[1:], ctxs[1:]):
+            gb = gb + ops.bias_grad(b.B, ctx)
         if self.collectives:
             if self.cpu_staging and gb.is_cuda:
                 g = gb.cpu()
@@ -369,13 +423,14 @@ class ShardedPipeline:
     """Drives ShardedCdae so that no step waits on the host or on a parameter-independent exchange.
 
     Iteration s issues, in this program order (identical on every rank — one communicator):
-        exchange_keys(batch s+1)  ·  prepare + exchange_counts(batch s+2)  ·  step(batch s)
-    The count exchange of batch s+2 is queued ahead of step s's collectives, so its host-side result (read when
-    iteration s+1 issues exchange_keys) is ready without stalling; keys and counts travel while the owner gathers the
-    rows of step s.  On a GPU the run-ahead stages use a side stream; on CPU (gloo tests) everything runs inline in the
-    same order.  `batch_of(s)` must return the DrxBatch of step s and be callable two steps ahead."""
+        step(batch s) up to its row exchange  ·  exchange_keys(batch s+1)  ·  exchange_counts(batch s+2)  ·
+        prepare(batch s+3)  ·  rest of step(batch s)
+    The run-ahead exchanges sit behind step s's row exchange on the communicator and travel while step s computes; the
+    count exchange of batch s+2 has long finished when iteration s+1 reads its host-side result.  On a GPU the run-ahead stages use a side stream; on CPU (gloo tests) everything runs inline in the
+    same order.  `batch_of(s)` must return the DrxBatch (or the list of micro-batches) of step s and be callable three
+    steps ahead."""
 
-    LOOKAHEAD = 2
+    LOOKAHEAD = 3
 
     def __init__(self, model, batch_of, n_steps, use_side_stream=None):
         self.m, self.batch_of, self.n = model, batch_of, n_steps
@@ -393,37 +448,55 @@ class ShardedPipeline:
         self.host_s = [0.0, 0.0, 0.0]
         if self.side is not None:
             self.side.wait_stream(self.main)            # histories / batches set up on the training stream
-        self._ahead(0, keys=True)
-        if n_steps > 1:
-            self._ahead(1, keys=False)
+        # Staggered run-ahead: a collective queued on the communicator must only depend on work that finished long ago —
+        # it sits in FRONT of the current step's gradient exchange there, and would hold it up while, say, a sort that was
+        # queued a moment ago is still running.  So batch s+3 is indexed, batch s+2 exchanges counts, batch s+1 keys.
+        for s in range(min(3, n_steps)):
+            self._prepare(s)
+        for s in range(min(2, n_steps)):
+            self._counts(s)
+        self._keys(0)
 
     def _on_side(self):
         return torch.cuda.stream(self.side) if self.side is not None else _Null()
 
-    def _ahead(self, s, keys):
-        """prepare + count exchange of batch s (and its key exchange when `keys`)"""
+    def _micro(self, s):
         bt = self.batch_of(s)
+        return list(bt) if isinstance(bt, (list, tuple)) else [bt]
+
+    def _prepare(self, s):
         with self._on_side():
-            P = self.m.prepare(bt, consumer_stream=self.main if self.side is not None else None)
-            self.m.exchange_counts(P)
-            if keys:
+            self.P[s] = [self.m.prepare(bt, consumer_stream=self.main if self.side is not None else None) for bt in self._micro(s)]
+
+    def _counts(self, s):
+        with self._on_side():
+            for P in self.P[s]:
+                self.m.exchange_counts(P)
+
+    def _keys(self, s):
+        with self._on_side():
+            for P in self.P[s]:
                 self.m.exchange_keys(P)
-        self.P[s] = P
 
     def run_step(self, events=None, want_loss=False):
         s = self.next
         assert s < self.n
         t0 = time.perf_counter()
-        if s + 1 < self.n:
-            with self._on_side():
-                self.m.exchange_keys(self.P[s + 1])
-        t1 = time.perf_counter()
-        if s + 2 < self.n:
-            self._ahead(s + 2, keys=False)
-        t2 = time.perf_counter()
-        out = self.m.step(s, self.batch_of(s), events=events, want_loss=want_loss, prepared=self.P.pop(s))
+        ahead_s = [0.0]
+
+        def run_ahead():                       # queued behind this step's row exchange on the communicator
+            ta = time.perf_counter()
+            if s + 1 < self.n:
+                self._keys(s + 1)
+            if s + 2 < self.n:
+                self._counts(s + 2)
+            if s + 3 < self.n:
+                self._prepare(s + 3)
+            ahead_s[0] = time.perf_counter() - ta
+        out = self.m.step(s, self._micro(s), events=events, want_loss=want_loss, prepared=self.P.pop(s),
+                          after_row_requests=run_ahead)
         t3 = time.perf_counter()
-        self.host_s[0] += t1 - t0; self.host_s[1] += t2 - t1; self.host_s[2] += t3 - t2     # host time issuing each stage
+        self.host_s[1] += ahead_s[0]; self.host_s[2] += t3 - t0 - ahead_s[0]                 # host time issuing each part
         self.next = s + 1
         return out
 

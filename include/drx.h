@@ -192,12 +192,14 @@ int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard
                      const uint32_t *keys_s, const uint32_t *vals_s, const int32_t *slot_sorted, const uint32_t *b_of_pos,
                      int32_t T, const float *dz1, const float *g2, const float *dz2, float *gc, float *gb2c, void *scratch,
                      size_t scratch_bytes, void *stream);
-/* owner side: sum the received gradient rows per owned row in source-rank order and apply the optimizer.  The n received
- * rows are `world` segments in source-rank order, recv_counts[s] (HOST array, world entries) rows from rank s, each segment
- * holding ascending distinct keys (what drx_shard_index produces on the sender). */
+/* owner side: sum the received gradient rows per owned row in segment order and apply the optimizer ONCE per row.  The n
+ * received rows are `n_segments` = world x (micro-batches of the step, <= DRX_MAX_MICRO) segments, micro-batch-major then
+ * source rank, recv_counts[s] (HOST array) rows in segment s, each segment holding ascending distinct keys (what
+ * drx_shard_index produces on the sender). */
+#define DRX_MAX_MICRO 4
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, void *scratch,
-                    size_t scratch_bytes, void *stream);
+                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, int32_t n_segments,
+                    void *scratch, size_t scratch_bytes, void *stream);
 /* out[0..ld) = column sums of dz1 (gradient of the hidden bias), out[ld] = sum of the per-sample losses */
 int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *lossb, int32_t B, float *out, void *scratch,
                         size_t scratch_bytes, void *stream);

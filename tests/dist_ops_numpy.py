@@ -101,7 +101,7 @@ class NumpyShardOps:
         sp, rc, bc = slot_of_pos.numpy(), rows_cache.numpy(), b2_cache.numpy()
         B, K = bt.B, self.k
         dt = np.dtype(np.float64)
-        self.dz1, self.g2, self.dz2, self.lossb = np.zeros((B, K)), np.zeros((B, K)), np.zeros(B), np.zeros(B)
+        ctx = {'dz1': np.zeros((B, K)), 'g2': np.zeros((B, K)), 'dz2': np.zeros(B), 'lossb': np.zeros(B)}
         s = 1.0 / (1.0 - bt.q)
         for b in range(B):
             base = bt.keep_off[b] + 2 * b
@@ -116,15 +116,16 @@ class NumpyShardOps:
             p = co.sigmoid(h @ w2 + bc[so])
             y = bt.y[b]
             if loss_kind == 0:
-                self.lossb[b] = co.bce_elem(np.float64(y), p, dt)
+                ctx['lossb'][b] = co.bce_elem(np.float64(y), p, dt)
                 dp = co.bce_grad(np.float64(y), p, dt) / b_norm
             else:
-                self.lossb[b] = (p - y) ** 2
+                ctx['lossb'][b] = (p - y) ** 2
                 dp = 2 * (p - y) / b_norm
             dz2 = dp * p * (1 - p)
-            self.dz2[b] = dz2
-            self.g2[b] = dz2 * h
-            self.dz1[b] = dz2 * w2 * h * (1 - h)
+            ctx['dz2'][b] = dz2
+            ctx['g2'][b] = dz2 * h
+            ctx['dz1'][b] = dz2 * w2 * h * (1 - h)
+        return ctx
 
     def _update(self, name, row, g, b_norm, reg=True):
         p = getattr(self, name)
@@ -133,7 +134,7 @@ class NumpyShardOps:
         self.acc[name][row] = self.acc[name][row] + g * g
         p[row] = p[row] - float(np.float32(self.lr)) * g / (np.sqrt(self.acc[name][row]) + co.ADAGRAD_EPS)
 
-    def reduce(self, idx, bpos, q_item, b_norm, q, opt):
+    def reduce(self, idx, bpos, q_item, b_norm, q, opt, ctx):
         ks, vs, ss, bp = idx['keys_s'].numpy(), idx['vals_s'].numpy(), idx['slot_sorted'].numpy(), bpos.numpy()
         gc, gb2c = np.zeros((q_item, self.k)), np.zeros(q_item)
         s = 1.0 / (1.0 - q)
@@ -143,12 +144,12 @@ class NumpyShardOps:
                 continue
             b = bp[pos]
             if key >= self.uk0:
-                gv[key - self.uk0] = gv.get(key - self.uk0, 0) + self.dz1[b]
+                gv[key - self.uk0] = gv.get(key - self.uk0, 0) + ctx['dz1'][b]
             elif (key % (2 * self.ipr)) >= self.ipr:
-                gc[slot] += self.g2[b]
-                gb2c[slot] += self.dz2[b]
+                gc[slot] += ctx['g2'][b]
+                gb2c[slot] += ctx['dz2'][b]
             else:
-                gc[slot] += s * self.dz1[b]
+                gc[slot] += s * ctx['dz1'][b]
         for u, g in gv.items():
             self._update('V', u, g, b_norm)
         return torch.from_numpy(gc), torch.from_numpy(gb2c)
@@ -165,8 +166,8 @@ class NumpyShardOps:
             if is_out:
                 self._update('b2', row, tots[key], b_norm, reg=False)
 
-    def bias_grad(self, B):
-        return torch.from_numpy(np.concatenate([self.dz1.sum(axis=0), [self.lossb.sum()]]))
+    def bias_grad(self, B, ctx):
+        return torch.from_numpy(np.concatenate([ctx['dz1'].sum(axis=0), [ctx['lossb'].sum()]]))
 
     def bias_apply(self, grad, b_norm, opt):
         self._update('b', slice(None), grad.numpy()[:self.k], b_norm, reg=False)

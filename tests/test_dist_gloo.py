@@ -34,7 +34,7 @@ def _problem():
     return p, indptr, indices, batches
 
 
-def _worker(rank, world, port, out, pipelined=False):
+def _worker(rank, world, port, out, pipelined=False, micro=1):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -51,7 +51,10 @@ def _worker(rank, world, port, out, pipelined=False):
 
     def batch_of(s):
         uid, iid, y, seed = batches[s][rank]
-        return np_batch(uid - lo, iid, y, lip, Q, mask_seed=seed)
+        if micro == 1:
+            return np_batch(uid - lo, iid, y, lip, Q, mask_seed=seed)
+        parts = [np.flatnonzero(uid % micro == m) for m in range(micro)]          # micro-batches with disjoint users
+        return [np_batch(uid[ix] - lo, iid[ix], y[ix], lip, Q, mask_seed=seed + 100 * m) for m, ix in enumerate(parts)]
     if pipelined:                      # run-ahead stage order of the multi-GPU bench (keys s+1, counts s+2, step s)
         from drecpy_amd.dist import ShardedPipeline
         pipe = ShardedPipeline(m, batch_of, STEPS)
@@ -65,12 +68,14 @@ def _worker(rank, world, port, out, pipelined=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined', [False, True])
-def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined):
+@pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2), (False, 3)])
+def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro):
+    """micro > 1: every rank's batch is split into micro-batches with disjoint users whose exchanges overlap each other's
+    compute; the step must still equal the single-process step on the concatenated batch."""
     from oracle import cdae_oracle as co
     out = str(tmp_path / 'shard')
-    port = 29600 + (os.getpid() % 200) + (200 if pipelined else 0)
-    mp.spawn(_worker, args=(2, port, out, pipelined), nprocs=2, join=True)
+    port = 29600 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0))
+    mp.spawn(_worker, args=(2, port, out, pipelined, micro), nprocs=2, join=True)
     p, indptr, indices, batches = _problem()
     st = co.sparse_state(p, 'adagrad')
     want_losses = []
@@ -78,13 +83,16 @@ def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined):
         uid = np.concatenate([batches[s][r][0] for r in range(2)])
         iid = np.concatenate([batches[s][r][1] for r in range(2)])
         y = np.concatenate([batches[s][r][2] for r in range(2)])
-        kept = []
+        kept = [None] * len(uid)
+        base = 0
         for r in range(2):
             u_r, _, _, seed = batches[s][r]
-            for b, u in enumerate(u_r):
-                row = indices[indptr[u]:indptr[u + 1]]
-                kf = co.drx_hash_u32(seed, np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
-                kept.append(row[kf].tolist())
+            for m in range(micro):                      # the corruption mask of a sample is keyed by its micro-batch position
+                for b, j in enumerate(np.flatnonzero(u_r % micro == m)):
+                    row = indices[indptr[u_r[j]]:indptr[u_r[j] + 1]]
+                    kf = co.drx_hash_u32(seed + (100 * m if micro > 1 else 0), np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
+                    kept[base + j] = row[kf].tolist()
+            base += len(u_r)
         lval, _ = co.sparse_step(p, st, s, uid, iid, y, kept, float(np.float32(Q)), 0.05, 1e-3, 'bce', 'adagrad')
         want_losses.append(lval)
     res = [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)]

@@ -35,7 +35,7 @@ def _problem(world):
     return p, indptr, indices, batches
 
 
-def _oracle(world):
+def _oracle(world, micro=1):
     from oracle import cdae_oracle as co
     p, indptr, indices, batches = _problem(world)
     p = {k: v.astype(np.float64) for k, v in p.items()}
@@ -45,19 +45,22 @@ def _oracle(world):
         uid = np.concatenate([batches[s][r][0] for r in range(world)])
         iid = np.concatenate([batches[s][r][1] for r in range(world)])
         y = np.concatenate([batches[s][r][2] for r in range(world)])
-        kept = []
+        kept = [None] * len(uid)
+        base = 0
         for r in range(world):
             u_r, _, _, seed = batches[s][r]
-            for b, u in enumerate(u_r):
-                row = indices[indptr[u]:indptr[u + 1]]
-                kf = co.drx_hash_u32(seed, np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
-                kept.append(row[kf].tolist())
+            for m in range(micro):                      # a sample's corruption mask is keyed by its micro-batch position
+                for b, j in enumerate(np.flatnonzero(u_r % micro == m)):
+                    row = indices[indptr[u_r[j]]:indptr[u_r[j] + 1]]
+                    kf = co.drx_hash_u32(seed + (100 * m if micro > 1 else 0), np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
+                    kept[base + j] = row[kf].tolist()
+            base += len(u_r)
         lval, _ = co.sparse_step(p, st, s, uid, iid, y, kept, float(np.float32(Q)), 0.05, 1e-3, 'bce', 'adagrad')
         losses.append(lval)
     return p, losses
 
 
-def _run_rank(rank, world, staged, force=False, pipelined=False):
+def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1):
     from drecpy_amd.dist import ShardedCdae
     p, indptr, indices, batches = _problem(world)
     lo, hi = U * rank // world, U * (rank + 1) // world
@@ -70,8 +73,12 @@ def _run_rank(rank, world, staged, force=False, pipelined=False):
     def batch_of(s):
         if s not in made:
             uid, iid, y, seed = batches[s][rank]
-            made[s] = m.ops.make_batch(uid - lo, iid, y, q=Q, mask_seed=seed)
-        return made[s][0]
+            if micro == 1:
+                made[s] = [m.ops.make_batch(uid - lo, iid, y, q=Q, mask_seed=seed)]
+            else:                                       # micro-batches with disjoint users
+                made[s] = [m.ops.make_batch(uid[ix] - lo, iid[ix], y[ix], q=Q, mask_seed=seed + 100 * k)
+                           for k, ix in enumerate(np.flatnonzero(uid % micro == k) for k in range(micro))]
+        return made[s][0][0] if micro == 1 else [bt for bt, _ in made[s]]
     if pipelined:
         from drecpy_amd.dist import ShardedPipeline
         pipe = ShardedPipeline(m, batch_of, STEPS)
@@ -83,8 +90,8 @@ def _run_rank(rank, world, staged, force=False, pipelined=False):
     return m.ops.get_params(), losses, (lo, hi)
 
 
-def _check(world, results):
-    p, want_losses = _oracle(world)
+def _check(world, results, micro=1):
+    p, want_losses = _oracle(world, micro)
     ipr = (N + world - 1) // world
     for r, (g, losses, (ulo, uhi)) in enumerate(results):
         lo, hi = r * ipr, min(N, (r + 1) * ipr)
@@ -97,45 +104,45 @@ def _check(world, results):
         np.testing.assert_allclose(losses, want_losses, rtol=1e-5)
 
 
-@pytest.mark.parametrize('pipelined', [False, True])
-def test_sharded_world1_matches_oracle(pipelined):
-    _check(1, [_run_rank(0, 1, False, pipelined=pipelined)])
+@pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2)])
+def test_sharded_world1_matches_oracle(pipelined, micro):
+    _check(1, [_run_rank(0, 1, False, pipelined=pipelined, micro=micro)], micro)
 
 
-def _worker(rank, world, port, out, pipelined=False):
+def _worker(rank, world, port, out, pipelined=False, micro=1):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _run_rank(rank, world, True, pipelined=pipelined)
+    res = _run_rank(rank, world, True, pipelined=pipelined, micro=micro)
     torch.save(res, f'{out}.{rank}')
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined', [False, True])
-def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined):
+@pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2)])
+def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro):
     out = str(tmp_path / 'shard')
-    port = 29700 + (os.getpid() % 200) + (200 if pipelined else 0)
-    mp.spawn(_worker, args=(2, port, out, pipelined), nprocs=2, join=True)
-    _check(2, [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)])
+    port = 29700 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0))
+    mp.spawn(_worker, args=(2, port, out, pipelined, micro), nprocs=2, join=True)
+    _check(2, [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)], micro)
 
 
-def _worker_rccl(rank, port, out, pipelined):
+def _worker_rccl(rank, port, out, pipelined, micro):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    res = _run_rank(0, 1, False, force=True, pipelined=pipelined)
+    res = _run_rank(0, 1, False, force=True, pipelined=pipelined, micro=micro)
     torch.save(res, f'{out}.0')
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined', [False, True])
-def test_sharded_step_through_rccl_world1(tmp_path, pipelined):
+@pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2)])
+def test_sharded_step_through_rccl_world1(tmp_path, pipelined, micro):
     """The N-rank call sequence (count / key / row / gradient all-to-all(v), bias all-reduce) on a real 1-rank RCCL
     communicator: device int32 and float32 buffers, uneven-split API, stream ordering with the drx kernels."""
     out = str(tmp_path / 'rccl')
-    port = 29400 + (os.getpid() % 200) + (200 if pipelined else 0)
-    mp.spawn(_worker_rccl, args=(port, out, pipelined), nprocs=1, join=True)
-    _check(1, [torch.load(f'{out}.0', weights_only=False)])
+    port = 29400 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0))
+    mp.spawn(_worker_rccl, args=(port, out, pipelined, micro), nprocs=1, join=True)
+    _check(1, [torch.load(f'{out}.0', weights_only=False)], micro)
