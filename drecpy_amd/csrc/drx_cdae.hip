@@ -493,18 +493,14 @@ __global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_
   }
 }
 
+// Everything of one triple after its input bag is known: hidden layer, sampled output unit, loss, backward, gradient rows
+// (and the in-place update of rows only this triple touches).
 template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
-                                                            uint32_t qthr, int loss_kind, SparseBufs S) {
-  const int lane = threadIdx.x % G;
-  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;     // counters of the segmented reduction that follows
-  if (b >= bt.B) return;
+__device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, float scale,
+                                               int loss_kind, const SparseBufs &S, int b, int lane, const float4 (&acc)[J]) {
   const int u = bt.uid[b], i = bt.iid[b];
   const float y = bt.y[b];
-  float4 acc[J], h[J], w2[J];
-  DenseAux none{};
-  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
+  float4 h[J], w2[J];
   hidden_act<G, J>(P, u, scale, lane, acc, h);
   load_row<G, J>(P.W2T, (size_t)i, P.ld, lane, w2);
   float d = 0.f;
@@ -535,6 +531,47 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
     if (lane == 0) S.dz2[b] = dz2;
   }
   if (solo_v) sparse_apply<G, J>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+                                                            uint32_t qthr, int loss_kind, SparseBufs S) {
+  const int lane = threadIdx.x % G;
+  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;     // counters of the segmented reduction that follows
+  if (b >= bt.B) return;
+  float4 acc[J];
+  DenseAux none{};
+  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
+  sampled_finish<G, J>(P, opt, bt, scale, loss_kind, S, b, lane, acc);
+}
+
+// Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
+// a chain of ~20 dependent load rounds on a chip that is mostly idle (measured 143 us at B = 4096).  Here one WORKGROUP
+// takes a triple: its 256/G groups split the history, the partial bags are summed in LDS in group order.
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_wg(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+                                                               uint32_t qthr, int loss_kind, SparseBufs S) {
+  extern __shared__ __align__(16) float lds[];   // [R, ld]
+  constexpr int R = kBlock / G;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const int b = blockIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;
+  float4 acc[J];
+  DenseAux none{};
+  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0, r, R);
+  store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
+  __syncthreads();
+  if (r != 0) return;
+#pragma unroll
+  for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+  for (int rr = 0; rr < R; ++rr) {
+    float4 v[J];
+    load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
+#pragma unroll
+    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+  }
+  sampled_finish<G, J>(P, opt, bt, scale, loss_kind, S, b, lane, acc);
 }
 
 // Policy of the single-GPU sparse step for the generic segmented reduction (drx_segreduce.hpp):
@@ -951,14 +988,23 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
   DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
+  // One workgroup per triple (its groups split the history) instead of one group per triple: when a group would walk many
+  // dependent load rounds.  Short histories (mean <= 64 items): only while the batch cannot fill the chip anyway.
+  static const int wg_long = getenv("DRX_WG_LONG") ? atoi(getenv("DRX_WG_LONG")) : 64;
+  const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
+  const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
     const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
     EV(0);                                                                                                             \
-    hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt,  \
-                       scale, qthr, loss_kind, S);                                                                     \
+    if (per_wg)                                                                                                        \
+      hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
+                         *bt, scale, qthr, loss_kind, S);                                                              \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt,  \
+                         scale, qthr, loss_kind, S);                                                                   \
     EV(1);                                                                                                             \
     if (!prepared) {                                                                                                   \
       rc = prepare_impl(p, hist, bt, R, st);                                                                           \

@@ -142,6 +142,38 @@ def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
         np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize('prepared', [False, True])
+def test_sparse_long_histories_take_the_workgroup_path(prepared):
+    """Mean history of ~60 items, 48 triples: the forward/backward runs one WORKGROUP per triple (k_sampled_fwd_bwd_wg: its
+    groups split the history, partial bags summed in LDS) — same oracle, same tolerance."""
+    U, N, K, B = 40, 400, 128, 48
+    eng, p, rng = _engine(U, N, K, seed=9)
+    indptr, indices = synth_history(rng, U, N, 60, zipf=1.05)
+    assert (indptr[-1] / U) > 40
+    eng.set_history(indptr, indices)
+    eng.init_optimizer('adagrad', 0.05, 1e-3)
+    st = co.sparse_state(p, 'adagrad')
+    q = 0.2
+    qf = float(np.float32(q))
+    for step in range(6):
+        uids = rng.integers(0, U, size=B)
+        iids = rng.integers(0, N, size=B)
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        seed = 31 + step
+        keep = np.concatenate([hash_u32(seed, np.full(keep_off[b + 1] - keep_off[b], b), np.arange(keep_off[b + 1] - keep_off[b])) >= q_threshold(q)
+                               for b in range(B)]).astype(np.uint8)
+        bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, 0.05, 1e-3, 'bce', 'adagrad')
+        lg = eng.step_sparse(step, bt, 'bce', want_loss=True, prepared=eng.prepare_sparse(bt) if prepared else None).cpu().numpy()
+        assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=5e-5)
+
+
+
 def test_sparse_step_is_deterministic():
     import torch
     U, N, K, B = 200, 300, 128, 2048
