@@ -120,3 +120,22 @@ def test_bad_arguments_are_rejected():
     assert rc == -1                                  # DRX_EINVAL
     with pytest.raises(_lib.DrxError):
         _lib.check(rc, 'drx_cdae_step_sparse')
+
+
+@pytest.mark.parametrize('K', [1, 3, 20, 33, 64, 65, 129, 200, 256, 260, 512, 600, 1000])
+@pytest.mark.parametrize('mode,opt', [('sparse', 'adagrad'), ('sparse', 'adam'), ('dense', 'adam')])
+def test_every_row_geometry(K, mode, opt):
+    """One K per lane-group geometry and both of its borders — (8,1) ld<=32, (16,1) <=64, (32,1) <=128, (64,1) <=256,
+    (64,2) <=512, (64,4) <=1024 — incl. K with padding columns and the > 48 KB LDS of the long-span tier at K = 1000;
+    hot rows that cross many chunks, sole-toucher rows (odd steps go through the prepared path), ragged batch."""
+    rng = np.random.default_rng(K)
+    U, N = 23, 61
+    rows = {u: rng.choice(N, size=rng.integers(0, 14), replace=False).tolist() for u in range(U)}
+    rows[3] = list(range(N))                                                 # one user with every item
+    indptr, indices = _hist(U, N, rows)
+    B = 150                                                                  # 150 triples over 61 items: every W row is hot
+    batches = []
+    for _ in range(3):
+        u = rng.integers(0, U, size=B); u[:40] = 3
+        batches.append((u, rng.integers(0, N, size=B), (rng.random(B) < 0.4)))
+    _run(U, N, K, indptr, indices, batches, 0.25, mode, opt=opt, explicit=(mode == 'dense'))

@@ -146,3 +146,11 @@ def test_sharded_step_through_rccl_world1(tmp_path, pipelined, micro):
     port = 29400 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0))
     mp.spawn(_worker_rccl, args=(port, out, pipelined, micro), nprocs=1, join=True)
     _check(1, [torch.load(f'{out}.0', weights_only=False)], micro)
+
+
+@pytest.mark.parametrize('k', [7, 130, 600])
+def test_sharded_world1_other_row_geometries(k, monkeypatch):
+    """The shard kernels in the (8,1), (64,1) and (64,4) lane-group geometries (the tests above run K = 50: (16,1))."""
+    import sys as _sys
+    monkeypatch.setattr(_sys.modules[__name__], 'K', k)
+    _check(1, [_run_rank(0, 1, False, pipelined=True)])
