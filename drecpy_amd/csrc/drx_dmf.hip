@@ -27,11 +27,14 @@ struct TowerIO {
   float *tcoef;               // [T] normalised input value
 };
 
-// Forward of one tower for sample b; returns the final activation of lane k.  z[l], a[l] keep pre/post activations.
+constexpr int kDmfWaves = 4;      // waves of a workgroup that share the sparse first layer of one sample
+
+// First (sparse) layer of one tower for sample b: the l2-normalised rating row / column against the kernel rows it names —
+// an embedding bag.  The workgroup's waves take every kDmfWaves-th block of 64 non-zeros, 8 kernel rows in flight each;
+// returns this wave's partial pre-activation of lane k (popular items have thousands of non-zeros: with one wave and
+// 4 loads in flight this loop was 60 % of a DMF step).
 template <bool TRAIN>
-__device__ __forceinline__ float tower_fwd(const DrxDmfDims &D, int tw, const TowerIO &T, const float *sw, int b, int k,
-                                           float (&zs)[kDmfMaxLayers], float (&as)[kDmfMaxLayers], float &rho_in) {
-  const int nl = D.n_layers[tw];
+__device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float &rho_in) {
   const int id = T.ids[b];
   const int64_t s = T.indptr[id], e = T.indptr[id + 1];
   float q = 0.f;
@@ -39,9 +42,10 @@ __device__ __forceinline__ float tower_fwd(const DrxDmfDims &D, int tw, const To
   q = group_sum<64>(q);
   rho_in = D.l2_norm_vectors ? rsqrtf(fmaxf(q, kL2NEps)) : 1.0f;
   const int f0 = D.f[tw][0];
+  const bool ok = k < f0;
   float acc = 0.f;
   const int base = TRAIN ? T.off[b] : 0;
-  for (int64_t c = s; c < e; c += 64) {            // lanes fetch 64 (index, value) pairs, then broadcast them
+  for (int64_t c = s + 64 * (int64_t)w; c < e; c += 64 * kDmfWaves) {   // lanes fetch 64 (index, value) pairs, then broadcast them
     const int64_t j = c + k;
     int idx = 0;
     float v = 0.f;
@@ -51,20 +55,27 @@ __device__ __forceinline__ float tower_fwd(const DrxDmfDims &D, int tw, const To
       if (TRAIN) { T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v; }
     }
     const int n_here = (int)((e - c) < 64 ? (e - c) : 64);
-    for (int t = 0; t < n_here; t += 4) {
-      const int i0 = __shfl(idx, t), i1 = __shfl(idx, t + 1), i2 = __shfl(idx, t + 2), i3 = __shfl(idx, t + 3);
-      const float v0 = __shfl(v, t), v1 = __shfl(v, t + 1), v2 = __shfl(v, t + 2), v3 = __shfl(v, t + 3);
-      const bool ok = k < f0;
-      const float r0 = ok ? T.K0[(size_t)i0 * T.ld0 + k] : 0.f;
-      const float r1 = (ok && t + 1 < n_here) ? T.K0[(size_t)i1 * T.ld0 + k] : 0.f;
-      const float r2 = (ok && t + 2 < n_here) ? T.K0[(size_t)i2 * T.ld0 + k] : 0.f;
-      const float r3 = (ok && t + 3 < n_here) ? T.K0[(size_t)i3 * T.ld0 + k] : 0.f;
-      acc = fmaf(v0, r0, acc);
-      acc = fmaf(t + 1 < n_here ? v1 : 0.f, r1, acc);
-      acc = fmaf(t + 2 < n_here ? v2 : 0.f, r2, acc);
-      acc = fmaf(t + 3 < n_here ? v3 : 0.f, r3, acc);
+    for (int t = 0; t < n_here; t += 8) {
+      float r[8], vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int iu = __shfl(idx, t + u);
+        vv[u] = (t + u < n_here) ? __shfl(v, t + u) : 0.f;
+        r[u] = (ok && t + u < n_here) ? T.K0[(size_t)iu * T.ld0 + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(vv[u], r[u], acc);
     }
   }
+  return acc;
+}
+
+// Dense layers of one tower from the summed first-layer pre-activation; returns the final activation of lane k.  z[l], a[l]
+// keep pre/post activations.
+__device__ __forceinline__ float tower_dense(const DrxDmfDims &D, int tw, const float *sw, int k, float acc,
+                                             float (&zs)[kDmfMaxLayers], float (&as)[kDmfMaxLayers]) {
+  const int nl = D.n_layers[tw];
+  const int f0 = D.f[tw][0];
   float z = k < f0 ? acc + sw[D.off_b[tw][0] + k] : 0.f;
   float a = fmaxf(z, 0.f);
   zs[0] = z; as[0] = a;
@@ -112,57 +123,77 @@ __device__ __forceinline__ void tower_bwd(const DrxDmfDims &D, int tw, const Tow
 }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(64) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
-  extern __shared__ __align__(16) float gsw[];       // [n_small] (TRAIN)
-  const int k = threadIdx.x;
+__global__ __launch_bounds__(64 * kDmfWaves) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
+  extern __shared__ __align__(16) float lds[];       // [2][kDmfWaves][64] first-layer partials, then gsw [n_small] (TRAIN)
+  float *part = lds;
+  float *gsw = lds + 2 * kDmfWaves * 64;
+  const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (TRAIN)
-    for (int i = k; i < D.n_small; i += 64) gsw[i] = 0.f;
+    for (int i = threadIdx.x; i < D.n_small; i += 64 * kDmfWaves) gsw[i] = 0.f;
   TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
   float loss_acc = 0.f;
   const float inv_b = 1.0f / (float)A.B;
   __syncthreads();
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
-    float zu[kDmfMaxLayers], au[kDmfMaxLayers], zi[kDmfMaxLayers], ai[kDmfMaxLayers];
     float rin_u, rin_i;
-    const float ru = tower_fwd<TRAIN>(D, 0, Tu, A.sw, b, k, zu, au, rin_u);
-    const float ri = tower_fwd<TRAIN>(D, 1, Ti, A.sw, b, k, zi, ai, rin_i);
-    const float qu = group_sum<64>(ru * ru), qi = group_sum<64>(ri * ri);
-    const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
-    const float nu = ru * rhou, ni = ri * rhoi;
-    const float s = group_sum<64>(nu * ni);
-    const float pred = fmaxf(1e-6f, s);
-    if (!TRAIN) {
-      if (k == 0 && A.pred_out) A.pred_out[b] = pred;
-      if (A.rep_u_out) A.rep_u_out[(size_t)b * 64 + k] = nu;       // l2-normalised representations (zero beyond f_last)
-      if (A.rep_i_out) A.rep_i_out[(size_t)b * 64 + k] = ni;
-      continue;
+    part[(0 * kDmfWaves + w) * 64 + k] = tower_gather<TRAIN>(D, 0, Tu, b, k, w, rin_u);
+    part[(1 * kDmfWaves + w) * 64 + k] = tower_gather<TRAIN>(D, 1, Ti, b, k, w, rin_i);
+    __syncthreads();
+    if (w == 0) {                                    // one wave finishes the sample: dense layers, loss, backward
+      float pu = 0.f, pi = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < kDmfWaves; ++ww) { pu += part[(0 * kDmfWaves + ww) * 64 + k]; pi += part[(1 * kDmfWaves + ww) * 64 + k]; }
+      float zu[kDmfMaxLayers], au[kDmfMaxLayers], zi[kDmfMaxLayers], ai[kDmfMaxLayers];
+      const float ru = tower_dense(D, 0, A.sw, k, pu, zu, au);
+      const float ri = tower_dense(D, 1, A.sw, k, pi, zi, ai);
+      const float qu = group_sum<64>(ru * ru), qi = group_sum<64>(ri * ri);
+      const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
+      const float nu = ru * rhou, ni = ri * rhoi;
+      const float s = group_sum<64>(nu * ni);
+      const float pred = fmaxf(1e-6f, s);
+      if (!TRAIN) {
+        if (k == 0 && A.pred_out) A.pred_out[b] = pred;
+        if (A.rep_u_out) A.rep_u_out[(size_t)b * 64 + k] = nu;       // l2-normalised representations (zero beyond f_last)
+        if (A.rep_i_out) A.rep_i_out[(size_t)b * 64 + k] = ni;
+      } else {
+        const float y = A.y[b];
+        loss_acc += bce_elem(y, pred);
+        const float ds = s > 1e-6f ? bce_grad(y, pred) * inv_b : 0.f;
+        // l2_normalize backward (tf.nn.l2_normalize: x * rsqrt(max(sum x^2, eps)))
+        const float dnu = ds * ni, dni = ds * nu;
+        const float du = group_sum<64>(nu * dnu), di = group_sum<64>(ni * dni);
+        const float dru = qu > kL2NEps ? rhou * (dnu - nu * du) : rhou * dnu;
+        const float dri = qi > kL2NEps ? rhoi * (dni - ni * di) : rhoi * dni;
+        tower_bwd(D, 0, Tu, A.sw, gsw, b, k, zu, au, dru);
+        tower_bwd(D, 1, Ti, A.sw, gsw, b, k, zi, ai, dri);
+      }
     }
-    const float y = A.y[b];
-    loss_acc += bce_elem(y, pred);
-    const float ds = s > 1e-6f ? bce_grad(y, pred) * inv_b : 0.f;
-    // l2_normalize backward (tf.nn.l2_normalize: x * rsqrt(max(sum x^2, eps)))
-    const float dnu = ds * ni, dni = ds * nu;
-    const float du = group_sum<64>(nu * dnu), di = group_sum<64>(ni * dni);
-    const float dru = qu > kL2NEps ? rhou * (dnu - nu * du) : rhou * dnu;
-    const float dri = qi > kL2NEps ? rhoi * (dni - ni * di) : rhoi * dni;
-    tower_bwd(D, 0, Tu, A.sw, gsw, b, k, zu, au, dru);
-    tower_bwd(D, 1, Ti, A.sw, gsw, b, k, zi, ai, dri);
+    __syncthreads();                                 // the partials are free for the next sample
   }
   if (TRAIN) {
-    __syncthreads();
-    for (int i = k; i < D.n_small; i += 64) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = gsw[i];
-    if (k == 0) A.loss_part[blockIdx.x] = loss_acc * inv_b;
+    for (int i = threadIdx.x; i < D.n_small; i += 64 * kDmfWaves) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = gsw[i];
+    if (threadIdx.x == 0) A.loss_part[blockIdx.x] = loss_acc * inv_b;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_sum_partials2(const float *__restrict__ part, int n_rows, int n, const float *__restrict__ tail,
-                                                          float *__restrict__ out) {
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j <= n; j += gridDim.x * kBlock) {
-    float a = 0.f;
-    if (j < n) for (int r = 0; r < n_rows; ++r) a += part[(size_t)r * n + j];
-    else for (int r = 0; r < n_rows; ++r) a += tail[r];
-    out[j] = a;
+// out[j] = sum_r part[r][j] for j < n, out[n] = sum_r tail[r]: 64 columns per workgroup, its 16 waves take every 16th row,
+// their partial sums are combined in wave order (fixed order of additions).
+__global__ __launch_bounds__(1024) void k_sum_partials2(const float *__restrict__ part, int n_rows, int n, const float *__restrict__ tail,
+                                                        float *__restrict__ out) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float a = 0.f;
+  if (j < n) for (int r = q; r < n_rows; r += 16) a += part[(size_t)r * n + j];
+  else if (j == n) for (int r = q; r < n_rows; r += 16) a += tail[r];
+  red[q][c] = a;
+  __syncthreads();
+  if (q == 0 && j <= n) {
+    float t = 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) t += red[qq][c];
+    out[j] = t;
   }
 }
 
@@ -230,11 +261,11 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
     return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = drx_dmf_grid(A->B);
-  const size_t lds = (size_t)D->n_small * 4;
+  const size_t lds = ((size_t)D->n_small + 2 * kDmfWaves * 64) * 4;
   if (lds > 48 * 1024)
     DRX_HIP(hipFuncSetAttribute((const void *)k_dmf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_dmf<true>, dim3(grid), dim3(64), lds, st, *D, *A);
-  hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + kBlock) / kBlock), dim3(kBlock), 0, st, A->gsw_part, grid, D->n_small,
+  hipLaunchKernelGGL(k_dmf<true>, dim3(grid), dim3(64 * kDmfWaves), lds, st, *D, *A);
+  hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
                      A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
@@ -246,7 +277,8 @@ int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream) {
   if (!A || !A->K0u || !A->K0i || !A->sw || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices ||
       !A->i_values || !A->uid || !A->iid || A->B < 1 || (!A->pred_out && !A->rep_u_out && !A->rep_i_out))
     return DRX_EINVAL;
-  hipLaunchKernelGGL(k_dmf<false>, dim3(A->B < 4096 ? A->B : 4096), dim3(64), 0, (hipStream_t)stream, *D, *A);
+  hipLaunchKernelGGL(k_dmf<false>, dim3(A->B < 4096 ? A->B : 4096), dim3(64 * kDmfWaves), (size_t)2 * kDmfWaves * 64 * 4,
+                     (hipStream_t)stream, *D, *A);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
