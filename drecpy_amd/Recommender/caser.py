@@ -64,6 +64,16 @@ class Caser(RecommenderABC):
         return p
 
     def _sample_batch(self, batch_size, **kwds):                          # caser.py:77-84
+        if getattr(self._sampler, '_native', None) is not None:           # array form of the same draws (C++ loop)
+            ds = self.interaction_dataset
+            grp, in_off, in_rows, tg_off, tg_rows, ng_off, negs = self._sampler.sample_group_arrays(batch_size)
+            iid = ds._cols['iid']
+            L, T, Tn = self.L, self.T, self.T * self.neg_ratio
+            assert in_off[-1] == batch_size * L and tg_off[-1] == batch_size * T and ng_off[-1] == batch_size * Tn
+            before = np.asarray(iid[in_rows], dtype=np.int64).reshape(batch_size, L)
+            after = np.concatenate([np.asarray(iid[tg_rows], dtype=np.int64).reshape(batch_size, T),
+                                    negs.astype(np.int64).reshape(batch_size, Tn)], axis=1)
+            return np.asarray(grp, dtype=np.int64), before, after
         uids, before, after = [], [], []
         for pos, targets, negs in self._sampler.sample_group_records(batch_size):
             uids.append(int(pos[0]['uid']))

@@ -71,6 +71,79 @@ class ListSampler:
         # a group is drawn many times over a fit (4096 draws per step over a few thousand users in examples/caser.py)
         self._memo_rows, self._memo_negs = {}, {}
         self._memo_budget = 60_000_000          # cached tuple slots (about 0.5 GB of references) before caching stops
+        self._native = None
+        self._build_native(seed)
+
+    # ---- native draw loop (libdrx.so, csrc/drx_host.cpp: drx_list_sampler_*) ---------------------------------------------
+    def _build_native(self, seed):
+        """The whole draw loop in C++ with the same MT19937 stream and CPython's set iteration order, when the configuration
+        allows it: one group column, dense internal ids as negatives, an int seed.  Otherwise the Python loop below runs."""
+        ds = self.interaction_dataset
+        if not (self._presorted and self.negative_ids_col in ('iid', 'uid') and isinstance(seed, (int, np.integer))
+                and not isinstance(seed, bool) and abs(int(seed)) < 2 ** 63 and len(ds)):
+            return
+        ids = np.asarray(ds._cols[self.negative_ids_col])
+        n_ids = len(self.unique_negative_ids)
+        if ids.min() < 0 or int(ids.max()) + 1 != n_ids or n_ids >= 2 ** 31 or len(ds) >= 2 ** 62:
+            return
+        keep = None
+        if self.interaction_threshold is not None:
+            keep = np.asarray(ds._cols['interaction']) >= self.interaction_threshold
+        parts, lens = [], []
+        for g in self.unique_groups:                       # the order rng.choice indexes
+            rows = np.asarray(self._rows_of_group[self._group_key(g)], dtype=np.int64)
+            if keep is not None:
+                rows = rows[keep[rows]]
+            parts.append(rows)
+            lens.append(len(rows))
+        from .. import _lib
+        L = _lib.lib()
+        self._n_rows_flat = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        indptr = np.zeros(len(lens) + 1, dtype=np.int64)
+        indptr[1:] = np.cumsum(lens)
+        row_ids = np.ascontiguousarray(ids[self._n_rows_flat], dtype=np.int32)
+        handle = L.drx_list_sampler_create(indptr.ctypes.data, self._n_rows_flat.ctypes.data, row_ids.ctypes.data, len(lens), n_ids,
+                                           int(self.neg_ratio), -1 if self.n_targets is None else int(self.n_targets),
+                                           int(self.min_positive_records),
+                                           -1 if self.max_positive_records is None else int(self.max_positive_records), int(seed))
+        if not handle:
+            return
+        self._native = (L, handle)
+        self._max_group = max(lens) if lens else 0
+        self._group_values = np.asarray(self.unique_groups)
+
+    def __del__(self):
+        native = getattr(self, '_native', None)
+        if native is not None:
+            native[0].drx_list_sampler_destroy(native[1])
+            self._native = None
+
+    def sample_group_arrays(self, n=16):
+        """n draws as arrays (native loop only): group values [n], offsets + dataset rows of the inputs and of the targets,
+        offsets + ids of the negatives.  Same stream, same draws as sample_group_records."""
+        assert self._native is not None, 'the native draw loop is not available for this configuration'
+        from .. import _lib
+        L, handle = self._native
+        T = self.n_targets
+        # widest a draw can be: a window of max_positive_records inputs + T targets, or — the reference quirk for groups not
+        # longer than the window — the first T rows as inputs and ALL the others as targets
+        widest = self._max_group if self.max_positive_records is None else min(self._max_group, self.max_positive_records)
+        in_cap = n * max(widest, T or 0, 1)
+        tg_cap = 0 if T is None else n * max(widest, T, 1)
+        ng_cap = tg_cap * self.neg_ratio
+        grp = np.zeros(n, np.int32)
+        in_off, tg_off, ng_off = (np.zeros(n + 1, np.int64) for _ in range(3))
+        in_rows, tg_rows = np.zeros(max(in_cap, 1), np.int64), np.zeros(max(tg_cap, 1), np.int64)
+        negs = np.zeros(max(ng_cap, 1), np.int32)
+        rc = L.drx_list_sampler_sample(handle, n, grp.ctypes.data, in_off.ctypes.data, in_rows.ctypes.data, in_cap, tg_off.ctypes.data,
+                                       tg_rows.ctypes.data, tg_cap, ng_off.ctypes.data, negs.ctypes.data, ng_cap)
+        if rc == -4:                                       # DRX_ERETRY
+            hint = (f'consider reducing the min_group_records ({self.min_positive_records}).' if L.drx_list_sampler_last_hint(handle) == 1
+                    else f'consider reducing the neg_ratio ({self.neg_ratio}) or the n_targets ({self.n_targets}).')
+            raise Exception('Failed to sample group records, max consecutive tries reached '
+                            f'({self.max_consecutive_tries}): {hint}')
+        _lib.check(rc, 'drx_list_sampler_sample')
+        return (self._group_values[grp], in_off, in_rows[:in_off[-1]], tg_off, tg_rows[:tg_off[-1]], ng_off, negs[:ng_off[-1]])
 
     # ---- pieces of one draw -----------------------------------------------------------------------------------
     def _as_record(self, row):
@@ -122,7 +195,9 @@ class ListSampler:
         hit = self._memo_negs.get(key)
         if hit is None:
             ids = self.interaction_dataset._cols[self.negative_ids_col]
-            hit = tuple(self.unique_negative_ids.difference(ids[np.asarray(all_rows, dtype=np.int64)].tolist()))
+            # a SET argument, as list_sampler.py:130 passes: CPython's set.difference picks copy-and-discard or rebuild-by-adding
+            # from the argument's type and size, and the two can leave different table layouts (= iteration orders)
+            hit = tuple(self.unique_negative_ids.difference(set(ids[np.asarray(all_rows, dtype=np.int64)].tolist())))
             if self._memo_budget >= len(hit):
                 self._memo_budget -= len(hit)
                 self._memo_negs[key] = hit
@@ -149,6 +224,19 @@ class ListSampler:
 
     def sample_group_records(self, n=16):
         """n draws: lists of input records (n_targets None) or (input records, target records, negative ids) triples."""
+        if self._native is not None:
+            _, in_off, in_rows, tg_off, tg_rows, ng_off, negs = self.sample_group_arrays(n)
+            ids = self.interaction_dataset._cols[self.negative_ids_col]
+            out = []
+            for d in range(n):
+                inputs = [self._as_record(r) for r in in_rows[in_off[d]:in_off[d + 1]]]
+                if self.n_targets is None:
+                    out.append(inputs)
+                else:
+                    # negatives as elements of the id column, like the members of unique_negative_ids
+                    out.append((inputs, [self._as_record(r) for r in tg_rows[tg_off[d]:tg_off[d + 1]]],
+                                [ids.dtype.type(x) for x in negs[ng_off[d]:ng_off[d + 1]]]))
+            return out
         out = []
         while len(out) < n:
             failures = 0

@@ -148,6 +148,12 @@ SIGNATURES = {
     'drx_sampler_sample': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_sampler_draw': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_sampler_destroy': (None, [C.c_void_p]),
+    'drx_list_sampler_create': (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_int64]),
+    'drx_list_sampler_sample': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),
+    'drx_list_sampler_last_hint': (C.c_int32, [C.c_void_p]),
+    'drx_list_sampler_destroy': (None, [C.c_void_p]),
     'drx_rng_create': (C.c_void_p, [C.c_int64]),
     'drx_rng_destroy': (None, [C.c_void_p]),
     'drx_rng_random': (C.c_double, [C.c_void_p]),

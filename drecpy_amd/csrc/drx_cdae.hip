@@ -832,6 +832,7 @@ const char *drx_strerror(int code) {
     case DRX_EINVAL: return "invalid argument";
     case DRX_ESCRATCH: return "scratch buffer too small";
     case DRX_ENOTIMPL: return "not implemented";
+    case DRX_ERETRY: return "sampler gave up after its maximum number of consecutive failed attempts";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown drx error";
   }
 }

@@ -3,6 +3,7 @@
 // and the N-long Python list comprehensions of DRecPy/Recommender/cdae.py:61-63 while producing bit-identical
 // streams (checked against stdlib `random.Random` and the golden vectors generated from the reference).
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <new>
@@ -104,7 +105,208 @@ struct DrxSampler {
   std::vector<double> val;
 };
 
+// ---- ListSampler (DRecPy/Sampler/list_sampler.py:76-151) -------------------------------------------------------------------
+// One draw: rng.choice(unique_groups) -> the group's positive rows (already threshold-filtered and ordered) -> optional
+// window start rng.randint -> inputs / targets -> eligible negative ids = tuple(unique_negative_ids - ids of the rows), in
+// CPython's set iteration order -> rng.sample.  Ids are dense small ints whose hash is the id itself, so the order of the
+// eligible tuple is reproduced by following Objects/setobject.c (3.7 .. 3.12): see eligible_order().
+namespace {
+
+constexpr int kLinearProbes = 9, kPerturbShift = 5;
+
+struct PySetOfInts {            // a CPython set holding non-negative ints (hash(i) == i): open addressing, linear probes, perturb
+  std::vector<int64_t> tab;    // -1 = unused slot
+  size_t mask, fill;
+  PySetOfInts() : tab(8, -1), mask(7), fill(0) {}
+  static void insert_clean(std::vector<int64_t> &t, size_t mask, int64_t key) {      // set_insert_clean
+    size_t perturb = (size_t)key, i = (size_t)key & mask;
+    for (;;) {
+      if (t[i] < 0) { t[i] = key; return; }
+      if (i + kLinearProbes <= mask)
+        for (int j = 1; j <= kLinearProbes; ++j)
+          if (t[i + j] < 0) { t[i + j] = key; return; }
+      perturb >>= kPerturbShift;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+  }
+  void resize(size_t minused) {                                                      // set_table_resize
+    size_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    std::vector<int64_t> nt(newsize, -1);
+    for (int64_t k : tab)
+      if (k >= 0) insert_clean(nt, newsize - 1, k);
+    tab.swap(nt);
+    mask = newsize - 1;
+  }
+  void add(int64_t key) {                                                            // set_add_entry (key known to be absent)
+    size_t perturb = (size_t)key, i = (size_t)key & mask;
+    for (;;) {
+      const int probes = (i + kLinearProbes <= mask) ? kLinearProbes : 0;
+      bool placed = false;
+      for (int j = 0; j <= probes; ++j)
+        if (tab[i + j] < 0) { tab[i + j] = key; placed = true; break; }
+      if (placed) break;
+      perturb >>= kPerturbShift;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+    ++fill;
+    if (fill * 5 >= mask * 3) resize(fill > 50000 ? fill * 2 : fill * 4);
+  }
+};
+
+struct ListGroup {
+  int64_t begin, end;                 // rows [begin, end) in the flattened row arrays
+  std::vector<int32_t> held;          // ascending distinct negative-ids among the group's rows
+  std::vector<int32_t> order;         // eligible ids in set order, only when that order is not simply ascending
+  bool order_built = false;
+};
+
+}  // namespace
+
+struct DrxListSampler {
+  MT rng;
+  int32_t n_groups, n_ids, neg_ratio, n_targets, min_pos, max_pos;     // n_targets / max_pos < 0: None
+  std::vector<int64_t> rows;          // dataset row numbers, group by group
+  std::vector<int32_t> ids;           // negative_ids_col value of each of those rows
+  std::vector<ListGroup> groups;      // in unique_groups order
+  int32_t last_hint = 0;
+
+  // j-th (0-based) id of the ascending complement of `held` in [0, n_ids)
+  static int32_t complement_at(const std::vector<int32_t> &held, int64_t j) {
+    // smallest v with v - #(held <= v) == j  <=>  v = j + (number of held ids <= v); iterate to the fixed point
+    size_t lo = 0, hi = held.size();
+    while (lo < hi) {                       // count of held ids h with h - rank(h) <= j, rank = its index in held
+      const size_t mid = (lo + hi) / 2;
+      if ((int64_t)held[mid] - (int64_t)mid <= j) lo = mid + 1; else hi = mid;
+    }
+    return (int32_t)(j + (int64_t)lo);
+  }
+  int64_t eligible_count(const ListGroup &g) const { return (int64_t)n_ids - (int64_t)g.held.size(); }
+  // tuple(unique_negative_ids.difference(set(held))) [j]
+  int32_t eligible_at(ListGroup &g, int64_t j) {
+    // set_difference (setobject.c): when len(so) >> 2 > len(other) the result is a COPY of so with the held ids discarded;
+    // so's table (and the copy's, sized for 2 * len) is larger than every id, each id sits in slot == id: ascending order.
+    if (((int64_t)n_ids >> 2) > (int64_t)g.held.size()) return complement_at(g.held, j);
+    if (!g.order_built) {                   // otherwise a NEW set receives the surviving ids one by one (ascending), growing
+      PySetOfInts so;                       // as it fills: ids beyond the table size collide and the order is the table's
+      const int64_t n = eligible_count(g);
+      for (int64_t t = 0; t < n; ++t) so.add(complement_at(g.held, t));
+      g.order.reserve((size_t)n);
+      for (int64_t k : so.tab)
+        if (k >= 0) g.order.push_back((int32_t)k);
+      g.order_built = true;
+    }
+    return g.order[(size_t)j];
+  }
+};
+
 extern "C" {
+
+DrxListSampler *drx_list_sampler_create(const int64_t *grp_indptr, const int64_t *grp_rows, const int32_t *grp_ids, int32_t n_groups,
+                                        int32_t n_ids, int32_t neg_ratio, int32_t n_targets, int32_t min_positive,
+                                        int32_t max_positive, int64_t seed) {
+  if (!grp_indptr || n_groups < 1 || n_ids < 1 || neg_ratio < 0 || min_positive < 0) return nullptr;
+  const int64_t nnz = grp_indptr[n_groups];
+  if (nnz > 0 && (!grp_rows || !grp_ids)) return nullptr;
+  DrxListSampler *s = new (std::nothrow) DrxListSampler;
+  if (!s) return nullptr;
+  s->rng.seed_int(seed);
+  s->n_groups = n_groups; s->n_ids = n_ids; s->neg_ratio = neg_ratio; s->n_targets = n_targets;
+  s->min_pos = min_positive; s->max_pos = max_positive;
+  s->rows.assign(grp_rows, grp_rows + nnz);
+  s->ids.assign(grp_ids, grp_ids + nnz);
+  s->groups.resize((size_t)n_groups);
+  for (int32_t g = 0; g < n_groups; ++g) {
+    ListGroup &G = s->groups[(size_t)g];
+    G.begin = grp_indptr[g]; G.end = grp_indptr[g + 1];
+    G.held.assign(s->ids.begin() + G.begin, s->ids.begin() + G.end);
+    std::sort(G.held.begin(), G.held.end());
+    G.held.erase(std::unique(G.held.begin(), G.held.end()), G.held.end());
+    if (!G.held.empty() && (G.held.front() < 0 || G.held.back() >= n_ids)) { delete s; return nullptr; }
+  }
+  return s;
+}
+
+void drx_list_sampler_destroy(DrxListSampler *s) { delete s; }
+
+int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, int64_t *in_off, int64_t *in_rows, int64_t in_cap,
+                            int64_t *tg_off, int64_t *tg_rows, int64_t tg_cap, int64_t *ng_off, int32_t *neg_ids, int64_t ng_cap) {
+  if (!s || n < 0 || !group_out || !in_off || !in_rows || !tg_off || !ng_off) return DRX_EINVAL;
+  const bool has_targets = s->n_targets >= 0;
+  const int64_t T = has_targets ? s->n_targets : 0;
+  in_off[0] = tg_off[0] = ng_off[0] = 0;
+  std::vector<int32_t> pool;
+  std::vector<int64_t> picked;
+  for (int32_t d = 0; d < n; ++d) {
+    int failures = 0;
+    for (;;) {
+      // one attempt (list_sampler.py:92-148); a failed attempt has consumed the draws it made
+      const int32_t gi = (int32_t)s->rng.randbelow((uint64_t)s->n_groups);               // rng.choice(unique_groups)
+      ListGroup &G = s->groups[(size_t)gi];
+      const int64_t n_rows = G.end - G.begin;
+      bool ok = !(n_rows < s->min_pos || n_rows < (int64_t)s->min_pos + T);
+      if (!ok) s->last_hint = 1;
+      int64_t start = -1;
+      if (ok && s->max_pos >= 0 && n_rows > s->max_pos)
+        start = s->rng.randint(0, n_rows - s->max_pos - T);                              // rng.randint(0, ...)
+      int64_t i0 = 0, i1 = 0, t0 = 0, t1 = 0;
+      if (ok) {
+        if (!has_targets) {
+          if (start < 0) { i0 = 0; i1 = n_rows; } else { i0 = start; i1 = start + s->max_pos; }
+        } else if (start < 0) {               // reference quirk: without a window, inputs = first T rows, targets = the rest
+          i0 = 0; i1 = std::min<int64_t>(T, n_rows); t0 = i1; t1 = n_rows;
+        } else {
+          i0 = start; i1 = start + s->max_pos; t0 = i1; t1 = std::min<int64_t>(i1 + T, n_rows);
+        }
+      }
+      int64_t n_neg = 0;
+      if (ok && has_targets) {
+        n_neg = (int64_t)s->neg_ratio * (t1 - t0);
+        if (s->eligible_count(G) < n_neg) { ok = false; s->last_hint = 2; }
+      }
+      if (!ok) {
+        if (++failures > 20) return DRX_ERETRY;
+        continue;
+      }
+      if (in_off[d] + (i1 - i0) > in_cap || (has_targets && (!tg_rows || tg_off[d] + (t1 - t0) > tg_cap)) ||
+          (n_neg > 0 && (!neg_ids || ng_off[d] + n_neg > ng_cap)))
+        return DRX_ESCRATCH;
+      group_out[d] = gi;
+      for (int64_t r = i0; r < i1; ++r) in_rows[in_off[d] + (r - i0)] = s->rows[(size_t)(G.begin + r)];
+      in_off[d + 1] = in_off[d] + (i1 - i0);
+      for (int64_t r = t0; r < t1; ++r) tg_rows[tg_off[d] + (r - t0)] = s->rows[(size_t)(G.begin + r)];
+      tg_off[d + 1] = tg_off[d] + (t1 - t0);
+      if (n_neg > 0) {                                                                     // rng.sample(eligible, n_neg)
+        const int64_t n_pop = s->eligible_count(G), k = n_neg;
+        int64_t setsize = 21;
+        if (k > 5) setsize += (int64_t)std::pow(4.0, std::ceil(std::log((double)(k * 3)) / std::log(4.0)));
+        int32_t *out = neg_ids + ng_off[d];
+        if (n_pop <= setsize) {
+          pool.resize((size_t)n_pop);
+          for (int64_t j = 0; j < n_pop; ++j) pool[(size_t)j] = s->eligible_at(G, j);
+          for (int64_t i = 0; i < k; ++i) {
+            const int64_t j = (int64_t)s->rng.randbelow((uint64_t)(n_pop - i));
+            out[i] = pool[(size_t)j];
+            pool[(size_t)j] = pool[(size_t)(n_pop - i - 1)];
+          }
+        } else {
+          picked.clear();
+          for (int64_t i = 0; i < k; ++i) {
+            int64_t j = (int64_t)s->rng.randbelow((uint64_t)n_pop);
+            while (std::find(picked.begin(), picked.end(), j) != picked.end()) j = (int64_t)s->rng.randbelow((uint64_t)n_pop);
+            picked.push_back(j);
+            out[i] = s->eligible_at(G, j);
+          }
+        }
+      }
+      ng_off[d + 1] = ng_off[d] + n_neg;
+      break;
+    }
+  }
+  return DRX_OK;
+}
+
+int32_t drx_list_sampler_last_hint(const DrxListSampler *s) { return s ? s->last_hint : 0; }
 
 DrxRng *drx_rng_create(int64_t seed) {
   DrxRng *r = new (std::nothrow) DrxRng;

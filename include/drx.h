@@ -31,7 +31,8 @@ enum {
   DRX_OK = 0,
   DRX_EINVAL = -1,     /* bad argument (null pointer, k > DRX_MAX_K, ld % 4, ...) */
   DRX_ESCRATCH = -2,   /* scratch buffer too small */
-  DRX_ENOTIMPL = -3
+  DRX_ENOTIMPL = -3,
+  DRX_ERETRY = -4      /* a sampler gave up after its maximum number of consecutive failed attempts */
 };
 
 #define DRX_MAX_K 1024
@@ -335,6 +336,24 @@ enum { DRX_DRAW_MIXED = 0, DRX_DRAW_NEGATIVE = 1, DRX_DRAW_POSITIVE = 2 };
 int drx_sampler_draw(DrxSampler *s, int32_t kind, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out,
                      uint8_t *h_neg_out);
 void drx_sampler_destroy(DrxSampler *s);
+
+/* ---- host-side ListSampler (list_sampler.py:76-151) ---------------------------------------------------------------------
+ * The draw loop of ListSampler.sample_group_records with the stream of random.Random(seed): choice of a group, window start,
+ * inputs / targets, rng.sample over the eligible negative ids in CPython's set iteration order (the ids are dense ints in
+ * [0, n_ids), all present in the dataset).  Groups come in unique_groups order; group g owns the dataset rows
+ * grp_rows[grp_indptr[g] .. grp_indptr[g+1]) — already filtered by interaction_threshold and ordered by sort_column — whose
+ * negative_ids_col values are grp_ids[...].  n_targets < 0 / max_positive < 0 mean None.  All pointers are HOST memory. */
+typedef struct DrxListSampler DrxListSampler;
+DrxListSampler *drx_list_sampler_create(const int64_t *grp_indptr, const int64_t *grp_rows, const int32_t *grp_ids, int32_t n_groups,
+                                        int32_t n_ids, int32_t neg_ratio, int32_t n_targets, int32_t min_positive,
+                                        int32_t max_positive, int64_t seed);
+/* n draws: group_out[n]; in_off / tg_off / ng_off [n+1] prefix offsets into in_rows / tg_rows (dataset rows of the inputs /
+ * targets) and neg_ids.  DRX_ESCRATCH: a capacity is too small; DRX_ERETRY: more than 20 consecutive failed attempts
+ * (drx_list_sampler_last_hint: 1 = too few positive records, 2 = too few eligible negatives). */
+int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, int64_t *in_off, int64_t *in_rows, int64_t in_cap,
+                            int64_t *tg_off, int64_t *tg_rows, int64_t tg_cap, int64_t *ng_off, int32_t *neg_ids, int64_t ng_cap);
+int32_t drx_list_sampler_last_hint(const DrxListSampler *s);
+void drx_list_sampler_destroy(DrxListSampler *s);
 
 /* CDAE corruption stream (cdae.py:63, RecommenderABC._rng of recommender_abc.py:74): draws
  * n_items uniforms per row, in batch order, and writes keep flags for the positives of each row. */

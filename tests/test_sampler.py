@@ -4,6 +4,7 @@ import ctypes as C
 import random
 
 import numpy as np
+import pytest
 
 from helpers import load_frames, load_json
 
@@ -127,3 +128,55 @@ def test_list_sampler_streams_match_reference():
             assert [int(r['rid']) for r in b] == w['before_rid'] and [int(r['rid']) for r in a] == w['after_rid']
             assert [int(r['iid']) for r in b] == w['before'] and [int(r['iid']) for r in a] == w['after']
             assert int(b[0]['uid']) == w['uid'] and [int(x) for x in ng] == w['neg'], key
+
+
+@pytest.mark.parametrize('cfg', [dict(n_targets=3, min_positive_records=5, max_positive_records=5, neg_ratio=3, sort_column='timestamp'),
+                                 dict(n_targets=2, min_positive_records=1, max_positive_records=None, neg_ratio=2, sort_column=None),
+                                 dict(n_targets=None, min_positive_records=2, max_positive_records=4, neg_ratio=1, sort_column='timestamp'),
+                                 dict(n_targets=1, min_positive_records=3, max_positive_records=6, neg_ratio=9, sort_column='timestamp',
+                                      interaction_threshold=3)])
+def test_native_list_sampler_equals_the_python_loop(cfg):
+    """drx_list_sampler_* (C++: MT19937 stream + CPython's set iteration order for the eligible negatives) against the
+    Python loop on the same dataset and seed — including users who hold more than a quarter of all items, for whom
+    set.difference rebuilds the set by insertion and the tuple order is NOT ascending."""
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Sampler import ListSampler
+    rng = np.random.default_rng(3)
+    U, N = 60, 90
+    rows = []
+    for u in range(U):
+        deg = int(rng.integers(1, 12)) if u % 7 else int(rng.integers(30, 80))        # every 7th user is a heavy one
+        for i in rng.choice(N, size=deg, replace=False):
+            rows.append((u + 100, int(i) * 3 + 7, int(rng.integers(1, 6)), int(rng.integers(0, 10 ** 6))))
+    rows = [rows[j] for j in rng.permutation(len(rows))]
+    cols = list(zip(*rows))
+    ds = InteractionDataset.read_df({'user': np.array(cols[0]), 'item': np.array(cols[1]), 'interaction': np.array(cols[2]),
+                                     'timestamp': np.array(cols[3])}, verbose=False)
+    ds.assign_internal_ids()
+    a = ListSampler(ds, ['uid'], seed=41, **cfg)
+    b = ListSampler(ds, ['uid'], seed=41, **cfg)
+    assert a._native is not None
+    b._native = None                                                                  # force the Python loop
+    for n in (1, 7, 64, 200):
+        ra, rb = a.sample_group_records(n), b.sample_group_records(n)
+        assert len(ra) == len(rb) == n
+        for xa, xb in zip(ra, rb):
+            if cfg['n_targets'] is None:
+                assert [r['rid'] for r in xa] == [r['rid'] for r in xb]
+            else:
+                assert [r['rid'] for r in xa[0]] == [r['rid'] for r in xb[0]]
+                assert [r['rid'] for r in xa[1]] == [r['rid'] for r in xb[1]]
+                assert [int(v) for v in xa[2]] == [int(v) for v in xb[2]]
+                assert all(k == kb and va == vb for (k, va), (kb, vb) in zip(sorted(xa[0][0].items()), sorted(xb[0][0].items())))
+
+
+def test_native_list_sampler_gives_up_like_the_python_loop():
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Sampler import ListSampler
+    ds = InteractionDataset.read_df({'user': np.array([1, 1, 2]), 'item': np.array([5, 6, 5]), 'interaction': np.array([1, 1, 1])},
+                                    verbose=False)
+    ds.assign_internal_ids()
+    s = ListSampler(ds, ['uid'], n_targets=2, min_positive_records=4, seed=1)
+    assert s._native is not None
+    with pytest.raises(Exception, match='max consecutive tries reached'):
+        s.sample_group_records(3)
