@@ -16,6 +16,24 @@ constexpr int kCaserMaxL = 8;
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 
+// Sums 16 per-lane values across the 64 lanes with 17 shuffles instead of 16 full butterflies (96): each exchange halves
+// the number of values a lane carries.  Afterwards lane l holds the wave total of v[slot16(l)] (four lanes per value).
+__device__ __forceinline__ int slot16(int lane) { return ((lane >> 5) & 1) << 3 | ((lane >> 4) & 1) << 2 | ((lane >> 3) & 1) << 1 | ((lane >> 2) & 1); }
+__device__ __forceinline__ float reduce16(const float (&v)[16], int lane) {
+  float a[8], b[4], c[2];
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (h5 ? v[8 + k] : v[k]) + __shfl_xor(h5 ? v[k] : v[8 + k], 32);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = (h4 ? a[4 + k] : a[k]) + __shfl_xor(h4 ? a[k] : a[4 + k], 16);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) c[k] = (h3 ? b[2 + k] : b[k]) + __shfl_xor(h3 ? b[k] : b[2 + k], 8);
+  float d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4);
+  d += __shfl_xor(d, 2);
+  d += __shfl_xor(d, 1);
+  return d;
+}
+
 struct CaserLds {
   float *gsw;     // [n_small] gradient accumulators of the small weights
   float *E;       // [L][64] item rows of the current sample
@@ -69,20 +87,33 @@ __global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
       if (c == 0) { S.x[f] = v; S.pre[f] = v; S.arg[f] = 0; }
     }
     // ---- 3. horizontal convs + relu + max over time -------------------------------------------------------------------
+    // 16 filters at a time: their (i+1) x 16 kernel values of this channel are requested together, the 16 channel sums
+    // leave through one reduce16, and the lanes that end up holding filter f track its maximum over the window positions.
     for (int i = 0; i < L; ++i) {
-      for (int f = 0; f < D.n_h; ++f) {
+      for (int f0 = 0; f0 < D.n_h; f0 += 16) {
+        const int fm = slot16(c);                               // the filter (of this block) whose total this lane receives
         float best = -1.f, bpre = 0.f;
         int bt = 0;
         for (int t = 0; t + i < L; ++t) {
-          float part = 0.f;
-          for (int s = 0; s <= i; ++s)
-            part = fmaf(S.E[(t + s) * 64 + c], live ? sw[D.off_kh[i] + (s * D.n_h + f) * D.ld + c] : 0.f, part);
-          const float v = wave_sum(part) + sw[D.off_bh[i] + f];
+          float part[16];
+#pragma unroll
+          for (int ff = 0; ff < 16; ++ff) part[ff] = 0.f;
+          for (int s2 = 0; s2 <= i; ++s2) {
+            const float e = S.E[(t + s2) * 64 + c];
+            float w16[16];
+#pragma unroll
+            for (int ff = 0; ff < 16; ++ff)
+              w16[ff] = (live && f0 + ff < D.n_h) ? sw[D.off_kh[i] + (s2 * D.n_h + f0 + ff) * D.ld + c] : 0.f;
+#pragma unroll
+            for (int ff = 0; ff < 16; ++ff) part[ff] = fmaf(e, w16[ff], part[ff]);
+          }
+          const float tot = reduce16(part, c);
+          const float v = tot + ((f0 + fm < D.n_h) ? sw[D.off_bh[i] + f0 + fm] : 0.f);
           const float r = fmaxf(v, 0.f);
           if (r > best) { best = r; bt = t; bpre = v; }        // first maximum wins, like the max-pool gradient
         }
-        if (c == 0) {
-          const int j = D.n_v + i * D.n_h + f;
+        if ((c & 3) == 0 && f0 + fm < D.n_h) {                  // one of the four lanes that hold filter fm
+          const int j = D.n_v + i * D.n_h + f0 + fm;
           S.x[j] = best; S.pre[j] = bpre; S.arg[j] = bt;
         }
       }
@@ -125,12 +156,21 @@ __global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
     const float dz0 = z0 > 0.f ? dz : 0.f;
     // ---- 7. dense_0 backward ---------------------------------------------------------------------------------------------
     if (live) S.gsw[D.off_bd + c] += dz0;
-    for (int j = 0; j < nx; ++j) {
-      const float w = live ? sw[D.off_wd + j * D.ld + c] : 0.f;
-      if (live) S.gsw[D.off_wd + j * D.ld + c] = fmaf(S.xd[j], dz0, S.gsw[D.off_wd + j * D.ld + c]);
-      float g = wave_sum(dz0 * w);
-      if (A.keep) g = A.keep[(size_t)b * nx + j] ? g * inv_keep : 0.f;
-      if (c == 0) S.dx[j] = g;
+    for (int j0 = 0; j0 < nx; j0 += 16) {                       // dx[j] = sum_c dz0[c] * Wd[j][c], 16 rows of Wd per reduce16
+      float prod[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = j0 + jj;
+        const float w = (live && j < nx) ? sw[D.off_wd + j * D.ld + c] : 0.f;
+        if (live && j < nx) S.gsw[D.off_wd + j * D.ld + c] = fmaf(S.xd[j], dz0, S.gsw[D.off_wd + j * D.ld + c]);
+        prod[jj] = dz0 * w;
+      }
+      float g = reduce16(prod, c);
+      const int j = j0 + slot16(c);
+      if ((c & 3) == 0 && j < nx) {
+        if (A.keep) g = A.keep[(size_t)b * nx + j] ? g * inv_keep : 0.f;
+        S.dx[j] = g;
+      }
     }
     __syncthreads();
     // ---- 8. vertical conv backward ---------------------------------------------------------------------------------------
