@@ -94,7 +94,11 @@ def main():
         def dstep():
             m._engine.step(state['s'], *batch); state['s'] += 1
         dev = timed(dstep, 30)
-        out[f'dmf_ml-1m_64x32_B{B}'] = {'device_step_ms': dev * 1e3, 'samples_per_s': B / dev}
+        def dfull():
+            m._do_batch(m._sample_batch(B), step=state['s']); state['s'] += 1
+        e2e = timed(dfull, 30)
+        out[f'dmf_ml-1m_64x32_B{B}'] = {'device_step_ms': dev * 1e3, 'samples_per_s': B / dev,
+                                        'fit_loop_ms_per_step (C++ PointSampler + packing + step)': e2e * 1e3, 'fit_loop_samples_per_s': B / e2e}
     ue = torch.arange(0, 2048, device='cuda')
     t_sc = timed(lambda: m._engine.score_matrix_bf16(ue), 10)
     out['dmf_mfma_score_matrix_2048users_x_3706items'] = {'ms (incl. both tower forwards over all items/users)': t_sc * 1e3}
@@ -107,8 +111,13 @@ def main():
         def cstep():
             m._do_batch(batch, step=state['s']); state['s'] += 1
         dev = timed(cstep, 20)
+        def cfull():
+            m._do_batch(m._sample_batch(B), step=state['s']); state['s'] += 1
+        e2e = timed(cfull, 20)
         out[f'caser_ml-1m_L5_T3_d50_B{B}'] = {'device_step_ms (incl. dropout-mask upload)': dev * 1e3, 'samples_per_s': B / dev,
-                                             'list_sampler_host_ms_per_batch': t_s * 1e3}
+                                             'list_sampler_host_ms_per_batch (first call)': t_s * 1e3,
+                                             'fit_loop_ms_per_step (C++ ListSampler + packing + step)': e2e * 1e3,
+                                             'fit_loop_samples_per_s': B / e2e}
     print(json.dumps(out, indent=1))
 
 
