@@ -991,7 +991,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
   // One workgroup per triple (its groups split the history) instead of one group per triple: when a group would walk many
   // dependent load rounds.  Short histories (mean <= 64 items): only while the batch cannot fill the chip anyway.
-  static const int wg_long = getenv("DRX_WG_LONG") ? atoi(getenv("DRX_WG_LONG")) : 64;
+  constexpr int wg_long = 64;
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
