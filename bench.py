@@ -268,7 +268,14 @@ def main():
     pipe = None
     if stepper is not None and overlap:
         from drecpy_amd.dist import ShardedPipeline
-        pipe = ShardedPipeline(stepper, lambda s: structs[s % len(structs)][0], args.warmup + args.steps)
+        fresh_sharded = not args.presampled and micro == 1 and not debug_gloo
+        if fresh_sharded:      # a new device-sampled batch of this rank's users every step, drawn ahead on its own stream
+            from drecpy_amd.engine import DeviceBatchSource
+            source = DeviceBatchSource(eng, B, NEG_RATIO, Q, lambda s: 5000 + 7919 * s + 104729 * rank,
+                                       lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N)
+        else:
+            source = lambda s: structs[s % len(structs)][0]
+        pipe = ShardedPipeline(stepper, source, args.warmup + args.steps)
 
     def run_step(s, events=None, last=False):
         if pipe is not None:           # keys of batch s+1 and counts of batch s+2 travel ahead of step s (dist.ShardedPipeline)
@@ -369,7 +376,7 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
                        'sole_toucher_rows_per_sample': round(f_solo, 3),
                        'touch_list': ('keys exchanged one batch ahead, counts two (dist.ShardedPipeline)' if pipe is not None else 'prepared one batch ahead on a side stream') if overlap else 'inline',
-                       'batches': 'fresh device-sampled batch every step (sampler two steps ahead on the side stream)' if fresh
+                       'batches': 'fresh device-sampled batch every step (sampler two steps ahead on the side stream)' if (fresh or (pipe is not None and fresh_sharded))
                        else f'{args.n_batches} pre-sampled batches cycled',
                        'micro_batches': (micro if stepper is not None else None),
                        'sharding': ('single GPU' if stepper is None else 'row-sharded code path at world 1') if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},

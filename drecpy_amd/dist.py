@@ -497,6 +497,8 @@ class ShardedPipeline:
                           after_row_requests=run_ahead)
         t3 = time.perf_counter()
         self.host_s[1] += ahead_s[0]; self.host_s[2] += t3 - t0 - ahead_s[0]                 # host time issuing each part
+        if hasattr(self.batch_of, 'release'):
+            self.batch_of.release(s)                   # e.g. engine.DeviceBatchSource: the batch's buffers may be reused
         self.next = s + 1
         return out
 

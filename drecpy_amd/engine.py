@@ -284,6 +284,57 @@ def pack_mask_bits(mask_bool):
     return np.packbits(flat, bitorder='little').view(np.uint32).copy()
 
 
+class DeviceBatchSource:
+    """batch_of(s) for pipelines that index batches ahead of time: step s's triples are drawn by the device PointSampler on a
+    high-priority stream when batch s - AHEAD is requested, so that by the time batch s itself is asked for its touch count
+    is already in pinned memory and nothing waits.  Batches must be requested in increasing order (as the pipelines do)."""
+
+    AHEAD = 2
+
+    def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, slots=8):
+        self.eng, self.B, self.neg_ratio, self.q = eng, int(batch_size), int(neg_ratio), float(q)
+        self.sample_seed_of, self.mask_seed_of, self.n_items = sample_seed_of, mask_seed_of, n_items
+        self.stream = torch.cuda.Stream(eng.device, priority=-1)
+        self.stream.wait_stream(torch.cuda.current_stream(eng.device))
+        self.n_slots = slots                       # a slot is reused `slots` steps later: more than any pipeline looks ahead
+        self.ring = [None] * slots
+        self.count = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(slots)]
+        self.ready = [torch.cuda.Event() for _ in range(slots)]
+        self.free = [None] * slots                 # recorded by release(): the step that used the slot's batch is queued
+        self.made = {}
+        self.drawn = -1
+
+    def release(self, s):
+        """The consumer has queued step s on the current stream: its batch's slot may be overwritten once that point is reached."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.eng.device))
+        self.free[s % self.n_slots] = ev
+
+    def _draw_up_to(self, s):
+        while self.drawn < s:
+            self.drawn += 1
+            k = self.drawn % self.n_slots
+            if self.free[k] is not None:
+                self.stream.wait_event(self.free[k])
+            with torch.cuda.stream(self.stream):
+                self.ring[k] = self.eng.sample_device(self.B, self.neg_ratio, self.sample_seed_of(self.drawn), n_items=self.n_items,
+                                                      out=self.ring[k])
+                self.count[k].copy_(self.ring[k][3][-1:], non_blocking=True)
+                self.ready[k].record(self.stream)
+
+    def __call__(self, s):
+        if s not in self.made:
+            self._draw_up_to(s + self.AHEAD)
+            k = s % self.n_slots
+            self.ready[k].synchronize()             # drawn AHEAD requests ago
+            uid, iid, y, keep_off = self.ring[k]
+            torch.cuda.current_stream(self.eng.device).wait_event(self.ready[k])
+            self.made[s] = self.eng.make_batch(uid, iid, y, keep_off=keep_off, q=self.q, mask_seed=self.mask_seed_of(s),
+                                               n_touch_slots=int(self.count[k][0]))
+            self.made.pop(s - self.n_slots + self.AHEAD + 1, None)
+        return self.made[s][0]
+
+
 class SampledPipeline:
     """Keeps the training stream of the sampled-output mode free of everything that does not depend on the parameters.
 

@@ -25,17 +25,8 @@ indptr, indices = synth.synth_history(U, N, mean_deg, min_deg, alpha, seed=0, de
 model = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=0.05, reg=1e-3, q=Q)
 eng = model.engine
 
-batches = {}
-
-
-def batch_of(s):                                  # this rank's B triples of step s, drawn on the device
-    if s not in batches:
-        uid, iid, y, keep_off = eng.sample_device(B, 5, 1000 + 7919 * s + rank, n_items=N)
-        batches[s] = eng.make_batch(uid, iid, y, keep_off=keep_off, q=Q, mask_seed=s * 31 + rank)
-        batches.pop(s - 4, None)
-    return batches[s][0]
-
-
+from drecpy_amd.engine import DeviceBatchSource     # this rank's B triples of step s, drawn on the device two requests ahead
+batch_of = DeviceBatchSource(eng, B, 5, Q, lambda s: 1000 + 7919 * s + rank, lambda s: 31 * s + rank, n_items=N)
 pipe = ShardedPipeline(model, batch_of, STEPS)
 for s in range(10):
     pipe.run_step()
