@@ -390,7 +390,8 @@ def main():
                          'traffic_frac': (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
                          'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                         'hbm_copy_achievable': copy_gbs},     # read+write rate of a 2 GiB device copy on this box, GB/s
+                         'hbm_copy_achievable': copy_gbs,
+                         'note': 'algorithmic bytes (SURVEY 8d) charge a parameter read-modify-write per touched-row OCCURRENCE; the kernel merges the occurrences of a row first, so frac can exceed 1 - traffic / traffic_rate are the bytes it really moves (DESIGN.md section 3)'},     # read+write rate of a 2 GiB device copy on this box, GB/s
             'phases_ms': {n: float(v) for n, v in zip(names, ph)},
             'setup_s': round(setup_s, 1),
             'host_issue_ms_per_step': ([round(1e3 * t / (args.warmup + args.steps), 4) for t in pipe.host_s + [stepper.wait_s]] if pipe is not None else None),
