@@ -180,3 +180,30 @@ def test_native_list_sampler_gives_up_like_the_python_loop():
     assert s._native is not None
     with pytest.raises(Exception, match='max consecutive tries reached'):
         s.sample_group_records(3)
+
+
+def test_c_program_links_and_runs_against_the_abi(tmp_path):
+    """include/drx.h is a C header and libdrx.so a plain shared library: a C program (no Python, no torch, no GPU) builds with
+    gcc, links, and gets the CPython-exact random stream."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, 'drecpy_amd', 'libdrx.so')
+    if shutil.which('gcc') is None or not os.path.exists(lib):
+        pytest.skip('gcc or libdrx.so not available')
+    exe = str(tmp_path / 'abi_smoke')
+    subprocess.run(['gcc', '-std=c11', '-Wall', '-Werror', '-I', os.path.join(root, 'include'), os.path.join(root, 'tests', 'c', 'abi_smoke.c'),
+                    '-o', exe, '-L', os.path.dirname(lib), '-ldrx', '-Wl,-rpath,' + os.path.dirname(lib)], check=True)
+    env = dict(os.environ)
+    try:
+        import torch
+        env['LD_LIBRARY_PATH'] = os.path.join(os.path.dirname(torch.__file__), 'lib') + ':/opt/rocm/lib:' + env.get('LD_LIBRARY_PATH', '')
+    except ImportError:
+        pass
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, env=env).stdout.split('\n')
+    r = random.Random(10)
+    a, b, c = r.random(), r.random(), r.randint(0, 9)
+    got = out[0].split()
+    assert float(got[0]) == a and float(got[1]) == b and int(got[2]) == c          # %.17g round-trips a double exactly
+    assert out[1] == 'ok'
