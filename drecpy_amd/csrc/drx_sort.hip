@@ -2,6 +2,11 @@
 // touched embedding rows (stable, so contributions are summed in sample order => deterministic).
 // rocPRIM is the ROCm-native primitive library (not a CUDA shim); the sort is plumbing around the
 // hand-written gather / segmented-reduce kernels, which carry the HBM traffic.
+//
+// A sort of our own was written and measured for this size class (1.4 M pairs, 25 key bits: LSD passes of 9 bits, per-tile
+// histograms, a scan over tiles, wave-level match ranking with 9 ballots per round; stable, passed the same tests): 12 short
+// launches took ~140 us against rocPRIM's ~117 us (onesweep, 4-5 launches), and sharing the chip with it slowed the training
+// stream more (133 vs 146 M triples/s).  Beating onesweep here needs its decoupled look-back, i.e. rewriting it — not done.
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -25,3 +30,16 @@ int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kou
 }
 
 }  // namespace drx
+
+// C ABI (include/drx.h): the sort as a utility of its own
+extern "C" {
+size_t drx_sort_pairs_temp_bytes(int64_t n, int32_t key_bits) {
+  if (n < 0 || key_bits < 1 || key_bits > 32) return 0;
+  return drx::sort_pairs_temp_bytes((size_t)n, key_bits) + 256;
+}
+int drx_sort_pairs(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int32_t key_bits,
+                   void *temp, size_t temp_bytes, void *stream) {
+  if (n < 0 || key_bits < 1 || key_bits > 32 || (n > 0 && (!keys_in || !keys_out || !vals_in || !vals_out || !temp))) return DRX_EINVAL;
+  return drx::sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, key_bits, (hipStream_t)stream);
+}
+}

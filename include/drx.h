@@ -314,6 +314,13 @@ size_t drx_topk_scratch_bytes(int32_t R, int32_t n);   /* 0 for n <= 16384 (LDS 
 int drx_topk(const float *scores, const uint32_t *cand_mask, int32_t R, int32_t n, int32_t k,
              int32_t *out_idx, float *out_val, void *scratch, size_t scratch_bytes, void *stream);
 
+/* ---- stable device radix sort of (key, val) pairs on the low key_bits bits of the key (the inverted-index builder of the
+ * sparse steps; ties keep their input order).  keys_out / vals_out must not alias the inputs.  temp: >=
+ * drx_sort_pairs_temp_bytes(n, key_bits). */
+size_t drx_sort_pairs_temp_bytes(int64_t n, int32_t key_bits);
+int drx_sort_pairs(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int32_t key_bits,
+                   void *temp, size_t temp_bytes, void *stream);
+
 /* ---- raw -> internal id map (mem_dataset.py:309-330) --------------------------------------
  * codes[r] = rank of first appearance of raw[r] (int64 raw ids), bit-exact.
  * n_unique (device int32) receives the number of categories; uniques[c] the raw id of code c.

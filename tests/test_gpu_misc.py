@@ -62,3 +62,33 @@ def test_topk_matches_heapq(n, k):
         got = [(float(v), int(i)) for v, i in zip(val[r], idx[r]) if i >= 0]
         assert got == [(float(np.float32(v)), i) for v, i in want]
         assert (idx[r] >= 0).sum() == min(k, int(mask[r].sum()))
+
+
+@pytest.mark.parametrize('n,bits', [(1, 1), (63, 9), (64, 10), (4096, 18), (4097, 18), (100_003, 25), (1_440_000, 25), (300_000, 27), (70_000, 32)])
+def test_sort_pairs_is_a_stable_sort(n, bits):
+    """drx_sort_pairs (the inverted-index builder of the sparse steps) against torch's stable sort: heavy duplicates (Zipf-like
+    keys), padding keys 0xFFFFFFFF, sizes around tile and wave borders, only the low `bits` bits order the pairs."""
+    import ctypes as C
+    import torch
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device='cuda'); g.manual_seed(n + bits)
+    hi = (1 << bits) - 1
+    u = torch.rand(n, generator=g, device='cuda', dtype=torch.float64)
+    keys64 = (u ** 6 * hi).to(torch.int64)                                 # skewed: many duplicates of small keys
+    if bits == 25 or bits == 32:
+        pad = torch.rand(n, generator=g, device='cuda') < 0.15
+        keys64 = torch.where(pad, torch.full_like(keys64, 0xFFFFFFFF), keys64)
+    keys64 = keys64 & 0xFFFFFFFF
+    keys = (keys64 - ((keys64 >> 31) << 32)).to(torch.int32)               # uint32 bit pattern in an int32 tensor
+    vals = torch.arange(n, device='cuda', dtype=torch.int32)
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    need = L.drx_sort_pairs_temp_bytes(n, bits)
+    tmp = torch.empty(need, dtype=torch.uint8, device='cuda')
+    _lib.check(L.drx_sort_pairs(_lib.ptr(keys), _lib.ptr(ko), _lib.ptr(vals), _lib.ptr(vo), n, bits, _lib.ptr(tmp), need,
+                                _lib.stream_ptr(torch.device('cuda'))), 'drx_sort_pairs')
+    torch.cuda.synchronize()
+    low = keys64 & hi                                                       # only the low `bits` bits order the pairs
+    want = torch.sort(low, stable=True)
+    assert torch.equal(vo.long(), want.indices)
+    assert torch.equal(ko.long() & 0xFFFFFFFF, keys64[want.indices])
