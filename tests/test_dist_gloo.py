@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 U, N, K, B, STEPS, Q = 40, 57, 6, 24, 3, 0.2
 
 
-def _problem():
+def _problem(world=2):
     from oracle import cdae_oracle as co
     from helpers import synth_history
     rng = np.random.default_rng(11)
@@ -26,8 +26,8 @@ def _problem():
     batches = []
     for s in range(STEPS):
         per_rank = []
-        for r in range(2):
-            lo, hi = U * r // 2, U * (r + 1) // 2
+        for r in range(world):
+            lo, hi = U * r // world, U * (r + 1) // world
             per_rank.append((rng.integers(lo, hi, size=B), rng.integers(0, N, size=B), (rng.random(B) < 0.3).astype(np.float64),
                              1000 + 17 * s + r))
         batches.append(per_rank)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, out, pipelined=False, micro=1):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from drecpy_amd.dist import ShardedCdae
     from dist_ops_numpy import NumpyShardOps, np_batch
-    p, indptr, indices, batches = _problem()
+    p, indptr, indices, batches = _problem(world)
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
@@ -68,24 +68,24 @@ def _worker(rank, world, port, out, pipelined=False, micro=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2), (False, 3)])
-def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro):
+@pytest.mark.parametrize('pipelined,micro,world', [(False, 1, 2), (True, 1, 2), (True, 2, 2), (False, 3, 2), (True, 1, 3), (True, 2, 4)])
+def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, world):
     """micro > 1: every rank's batch is split into micro-batches with disjoint users whose exchanges overlap each other's
     compute; the step must still equal the single-process step on the concatenated batch."""
     from oracle import cdae_oracle as co
     out = str(tmp_path / 'shard')
-    port = 29600 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0))
-    mp.spawn(_worker, args=(2, port, out, pipelined, micro), nprocs=2, join=True)
-    p, indptr, indices, batches = _problem()
+    port = 29600 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0)) + 2000 * world
+    mp.spawn(_worker, args=(world, port, out, pipelined, micro), nprocs=world, join=True)
+    p, indptr, indices, batches = _problem(world)
     st = co.sparse_state(p, 'adagrad')
     want_losses = []
     for s in range(STEPS):
-        uid = np.concatenate([batches[s][r][0] for r in range(2)])
-        iid = np.concatenate([batches[s][r][1] for r in range(2)])
-        y = np.concatenate([batches[s][r][2] for r in range(2)])
+        uid = np.concatenate([batches[s][r][0] for r in range(world)])
+        iid = np.concatenate([batches[s][r][1] for r in range(world)])
+        y = np.concatenate([batches[s][r][2] for r in range(world)])
         kept = [None] * len(uid)
         base = 0
-        for r in range(2):
+        for r in range(world):
             u_r, _, _, seed = batches[s][r]
             for m in range(micro):                      # the corruption mask of a sample is keyed by its micro-batch position
                 for b, j in enumerate(np.flatnonzero(u_r % micro == m)):
@@ -95,15 +95,15 @@ def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro):
             base += len(u_r)
         lval, _ = co.sparse_step(p, st, s, uid, iid, y, kept, float(np.float32(Q)), 0.05, 1e-3, 'bce', 'adagrad')
         want_losses.append(lval)
-    res = [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)]
-    ipr = (N + 1) // 2
-    for r in range(2):
+    res = [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)]
+    ipr = (N + world - 1) // world
+    for r in range(world):
         g = res[r]['params']
         lo, hi = r * ipr, min(N, (r + 1) * ipr)
         np.testing.assert_allclose(g['W'][:hi - lo], p['W'][lo:hi], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g['W_'][:, :hi - lo], p['W_'][:, lo:hi], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g['b_'][:hi - lo], p['b_'][lo:hi], rtol=1e-9, atol=1e-12)
-        ulo, uhi = U * r // 2, U * (r + 1) // 2
+        ulo, uhi = U * r // world, U * (r + 1) // world
         np.testing.assert_allclose(g['V'], p['V'][ulo:uhi], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g['b'], p['b'], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(res[r]['losses'], want_losses, rtol=1e-9)

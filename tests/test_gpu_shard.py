@@ -119,12 +119,13 @@ def _worker(rank, world, port, out, pipelined=False, micro=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2)])
-def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro):
+@pytest.mark.parametrize('pipelined,micro,world', [(False, 1, 2), (True, 1, 2), (True, 2, 2), (True, 1, 3)])
+def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro, world):
+    """`world` processes share the one GPU of the box (gloo + host-staged exchanges); world 3 splits 411 items unevenly."""
     out = str(tmp_path / 'shard')
-    port = 29700 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0))
-    mp.spawn(_worker, args=(2, port, out, pipelined, micro), nprocs=2, join=True)
-    _check(2, [torch.load(f'{out}.{r}', weights_only=False) for r in range(2)], micro)
+    port = 29700 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0)) + 2000 * world
+    mp.spawn(_worker, args=(world, port, out, pipelined, micro), nprocs=world, join=True)
+    _check(world, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)], micro)
 
 
 def _worker_rccl(rank, port, out, pipelined, micro):
