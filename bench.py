@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
+    ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'adam'], help='sparse optimizer of the sampled mode (S = 1 / 2 slots per parameter; single-GPU path)')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     return ap.parse_args()
 
@@ -94,7 +95,7 @@ def kept_count(keep_off, seed, q):
     return int((hash_u32_torch(seed, row, j) >= q_threshold(q)).sum().item())
 
 
-def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_cpu=1024):
+def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_cpu=1024, optimizer='adagrad'):
     """Times the CPU oracle (oracle/cdae_oracle.py sparse_step: the NumPy restatement, 'port') on the first n_cpu triples
     of one bench batch.  The tables are compacted to the rows that sample touches (same arithmetic per sample; the
     CPU sees a cache-friendlier table than the GPU does)."""
@@ -118,13 +119,13 @@ def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_c
     k = eng.k
     p = {'W': eng.W[il, :k].cpu().numpy().copy(), 'W_': eng.W2T[il, :k].t().cpu().numpy().copy(),
          'V': eng.V[ul, :k].cpu().numpy().copy(), 'b': eng.b[:k].cpu().numpy().copy(), 'b_': eng.b2[il].cpu().numpy().copy()}
-    st = co.sparse_state(p, 'adagrad')
+    st = co.sparse_state(p, optimizer)
     cu = np.array([users[int(u)] for u in uid])
     ci = np.array([items[int(i)] for i in iid])
     t0 = time.perf_counter()
     n_done = 0
     while time.perf_counter() - t0 < budget_s:
-        co.sparse_step(p, st, n_done, cu, ci, y, kept, float(np.float32(Q)), LR, REG, 'bce', 'adagrad')
+        co.sparse_step(p, st, n_done, cu, ci, y, kept, float(np.float32(Q)), LR if optimizer == 'adagrad' else 1e-3, REG, 'bce', optimizer)
         n_done += 1
     dt = time.perf_counter() - t0
     return {'value': n_cpu * n_done / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
@@ -200,7 +201,7 @@ def main():
         eng = CdaeEngine(hi - lo, N, K, device=dev)
         eng.init_glorot_device(10)
         eng.set_history(indptr, indices)
-        eng.init_optimizer('adagrad', LR, REG)
+        eng.init_optimizer(args.optimizer, LR if args.optimizer == 'adagrad' else 1e-3, REG)
         stepper = None
     else:
         from drecpy_amd.dist import ShardedCdae
@@ -340,8 +341,9 @@ def main():
         for col in (uid0, iid0):
             _, inv, cnt = torch.unique(col, return_inverse=True, return_counts=True)
             f_solo += float((cnt[inv] == 1).float().mean().item())
-    alg_fwd = B * 4.0 * K * (rows_per_sample + f_solo * 4.0)
-    alg_upd = B * 4.0 * K * (rows_per_sample - f_solo) * 4.0
+    S_opt = 2.0 if (args.optimizer == 'adam' and stepper is None) else 1.0      # optimizer slots per parameter
+    alg_fwd = B * 4.0 * K * (rows_per_sample + f_solo * (2.0 + 2.0 * S_opt))
+    alg_upd = B * 4.0 * K * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)
     if stepper is None:
         names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce',
                  'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
@@ -351,7 +353,7 @@ def main():
         # forward reads one row per occurrence, the local reduce one gradient row per occurrence
         dom, dom_ms, dom_alg = 'k_shard_fwd_bwd+k_seg_reduce<LocalPolicy>', ph[1], 2.0 * B * 4.0 * K * rows_per_sample
     achieved = dom_alg / (dom_ms * 1e-3) / 1e9
-    step_alg = B * 4.0 * K * rows_per_sample * 5.0
+    step_alg = B * 4.0 * K * rows_per_sample * (3.0 + 2.0 * S_opt)
     # HBM traffic of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json), only when that
     # profile was taken on this very configuration; rocprofv3 cannot run inside the bench itself.
     traffic = None
@@ -370,7 +372,7 @@ def main():
             'metric': 'training samples/sec (user-item pairs)', 'value': world * B * args.steps / dt, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-Adagrad on {args.workload}-shaped synthetic '
+            'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{"Adam (lazy)" if S_opt == 2.0 else "Adagrad"} on {args.workload}-shaped synthetic '
                                    f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
                                    f'corruption {Q}, neg_ratio {NEG_RATIO}',
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
@@ -398,7 +400,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             uid, iid, y, keep_off, seed = batches[0]
-            out['cpu_baseline'] = cpu_baseline(eng, indptr, indices, (uid, iid, y, keep_off), seed)
+            out['cpu_baseline'] = cpu_baseline(eng, indptr, indices, (uid, iid, y, keep_off), seed, optimizer=args.optimizer)
         else:
             out['cpu_baseline'] = None
         out['hr_at_10'] = hr_at_10(dev) if (world == 1 and not args.no_hr and not args.users) else None
