@@ -47,7 +47,7 @@ def parse():
     ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
-    ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'adam'], help='sparse optimizer of the sampled mode (S = 1 / 2 slots per parameter; single-GPU path)')
+    ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'adam', 'rowwise_adagrad'], help='sparse optimizer of the sampled mode (S = 1 / 2 slots per parameter; single-GPU path)')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     return ap.parse_args()
 
@@ -125,7 +125,7 @@ def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_c
     t0 = time.perf_counter()
     n_done = 0
     while time.perf_counter() - t0 < budget_s:
-        co.sparse_step(p, st, n_done, cu, ci, y, kept, float(np.float32(Q)), LR if optimizer == 'adagrad' else 1e-3, REG, 'bce', optimizer)
+        co.sparse_step(p, st, n_done, cu, ci, y, kept, float(np.float32(Q)), 1e-3 if optimizer == 'adam' else LR, REG, 'bce', optimizer)
         n_done += 1
     dt = time.perf_counter() - t0
     return {'value': n_cpu * n_done / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
@@ -201,7 +201,7 @@ def main():
         eng = CdaeEngine(hi - lo, N, K, device=dev)
         eng.init_glorot_device(10)
         eng.set_history(indptr, indices)
-        eng.init_optimizer(args.optimizer, LR if args.optimizer == 'adagrad' else 1e-3, REG)
+        eng.init_optimizer(args.optimizer, 1e-3 if args.optimizer == 'adam' else LR, REG)
         stepper = None
     else:
         from drecpy_amd.dist import ShardedCdae
@@ -341,7 +341,8 @@ def main():
         for col in (uid0, iid0):
             _, inv, cnt = torch.unique(col, return_inverse=True, return_counts=True)
             f_solo += float((cnt[inv] == 1).float().mean().item())
-    S_opt = 2.0 if (args.optimizer == 'adam' and stepper is None) else 1.0      # optimizer slots per parameter
+    # optimizer slots per parameter (row-wise Adagrad keeps 1/K of a slot: one float per row)
+    S_opt = {'adam': 2.0, 'adagrad': 1.0, 'rowwise_adagrad': 1.0 / K}[args.optimizer] if stepper is None else 1.0
     alg_fwd = B * 4.0 * K * (rows_per_sample + f_solo * (2.0 + 2.0 * S_opt))
     alg_upd = B * 4.0 * K * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)
     if stepper is None:
@@ -372,7 +373,7 @@ def main():
             'metric': 'training samples/sec (user-item pairs)', 'value': world * B * args.steps / dt, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{"Adam (lazy)" if S_opt == 2.0 else "Adagrad"} on {args.workload}-shaped synthetic '
+            'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{dict(adam="Adam (lazy)", adagrad="Adagrad", rowwise_adagrad="row-wise Adagrad")[args.optimizer if stepper is None else "adagrad"]} on {args.workload}-shaped synthetic '
                                    f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
                                    f'corruption {Q}, neg_ratio {NEG_RATIO}',
                        'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),

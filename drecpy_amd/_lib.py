@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libdrx.so')
 
 LOSS_BCE, LOSS_MSE = 0, 1
 TARGETS_REFERENCE, TARGETS_PER_ROW = 0, 1
-OPT_ADAM, OPT_ADAGRAD = 0, 1
+OPT_ADAM, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
 KEY_NONE = 0xFFFFFFFF
 
 

@@ -463,6 +463,7 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
   float *const s1 = var == 0 ? a0 : (var == 1 ? a1 : a2);
   float *const s2 = var == 0 ? c0 : (var == 1 ? c1 : c2);
   OptScalars o = opt_for(opt, 0, B);
+  o.inv_k = 1.0f / (float)P.k;
   float4 w[J];
   load_row<G, J>(tab, row, P.ld, lane, w);
   row_update<G, J>(o, tab, s1, s2, row, P.ld, lane, w, g);
@@ -676,6 +677,7 @@ __device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const Dr
     }
     load_row<G, J>(P.b, 0, P.ld, lane, w);
     OptScalars o = opt_for(opt, 0, A.B);
+    if (o.kind == DRX_OPT_ROWWISE_ADAGRAD) o.kind = DRX_OPT_ADAGRAD;      // the bias vectors keep one accumulator per element
     o.rb = 0.f;
     row_update<G, J>(o, P.b, opt.s1[3], opt.s2[3], 0, P.ld, lane, w, g);
   }
@@ -964,7 +966,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   if (rc) return rc;
   rc = check_batch(hist, bt);
   if (rc || !opt || !scratch || !bt->iid || !bt->y || !bt->keep_off) return DRX_EINVAL;
-  if (opt->kind != DRX_OPT_ADAM && opt->kind != DRX_OPT_ADAGRAD) return DRX_EINVAL;
+  if (opt->kind != DRX_OPT_ADAM && opt->kind != DRX_OPT_ADAGRAD && opt->kind != DRX_OPT_ROWWISE_ADAGRAD) return DRX_EINVAL;
   for (int i = 0; i < 5; ++i)
     if (!opt->s1[i] || (opt->kind == DRX_OPT_ADAM && !opt->s2[i])) return DRX_EINVAL;
   if ((uint64_t)2 * p->n_items + p->n_users + 1 >= 0xFFFFFFFFull) return DRX_EINVAL;

@@ -51,6 +51,7 @@ struct OptScalars {
   int kind;
   float lr, rb;              // rb = reg_rate / B
   float b1, b2, eps, alpha;  // alpha = Keras-Adam lr_t of the variable being updated
+  float inv_k = 0.f;         // 1 / K (row-wise Adagrad: mean of the squared gradient over the K columns)
 };
 
 __device__ __forceinline__ void opt_update1(const OptScalars &o, float g, float &p, float &s1, float &s2) {
@@ -71,6 +72,33 @@ __device__ __forceinline__ float row_update(const OptScalars &o, float *tab, flo
                                             int lane, const float4 (&w)[J], const float4 (&g)[J]) {
   float sq = 0.f;
   float4 *pr = reinterpret_cast<float4 *>(tab + row * (size_t)ld);
+  if (o.kind == DRX_OPT_ROWWISE_ADAGRAD) {
+    // one accumulator per row (first float of the row's slot): the optimizer state costs 4 bytes of traffic per row, not 4K
+    float4 gg[J];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const float4 p = w[j];
+      gg[j].x = fmaf(o.rb, p.x, g[j].x); gg[j].y = fmaf(o.rb, p.y, g[j].y);
+      gg[j].z = fmaf(o.rb, p.z, g[j].z); gg[j].w = fmaf(o.rb, p.w, g[j].w);
+      q += f4_dot(gg[j], gg[j]);
+      sq += f4_dot(p, p);
+    }
+    q = group_sum<G>(q) * o.inv_k;
+    const float acc = s1[row * (size_t)ld] + q;
+    const float step = o.lr / (sqrtf(acc) + o.eps);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = lane + j * G;
+      if (4 * c < ld) {
+        float4 p = w[j];
+        p.x -= step * gg[j].x; p.y -= step * gg[j].y; p.z -= step * gg[j].z; p.w -= step * gg[j].w;
+        pr[c] = p;
+      }
+    }
+    if (lane == 0) s1[row * (size_t)ld] = acc;
+    return sq;
+  }
   float4 *a1 = reinterpret_cast<float4 *>(s1 + row * (size_t)ld);
   float4 *a2 = (o.kind == DRX_OPT_ADAM) ? reinterpret_cast<float4 *>(s2 + row * (size_t)ld) : nullptr;
 #pragma unroll

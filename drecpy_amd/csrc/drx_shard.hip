@@ -204,6 +204,7 @@ struct LocalPolicy {
     if (key >= uk0) {
       const size_t row = key - uk0;
       OptScalars o = opt_for(opt, 0, b_norm);
+      o.inv_k = 1.0f / (float)P.k;
       float4 w[J];
       load_row<G, J>(P.V, row, P.ld, lane, w);
       row_update<G, J>(o, P.V, opt.s1[2], opt.s2[2], row, P.ld, lane, w, g);
@@ -234,6 +235,7 @@ struct OwnerPolicy {
     const bool is_out = t >= (uint32_t)sh.items_per_rank;
     const size_t row = is_out ? t - sh.items_per_rank : t;
     OptScalars o = opt_for(opt, 0, b_norm);
+    o.inv_k = 1.0f / (float)P.k;
     float4 w[J];
     float *wt = P.W, *w2 = P.W2T, *a0 = opt.s1[0], *a1 = opt.s1[1], *c0 = opt.s2[0], *c1 = opt.s2[1];   // scalar loads first
     float *tab = is_out ? w2 : wt;
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_bias_apply(DrxCdaeParams P, DrxOptim
     load_row<G, J>(grad, 0, P.ld, lane, g);
     load_row<G, J>(P.b, 0, P.ld, lane, w);
     OptScalars o = opt_for(opt, 0, b_norm);
+    if (o.kind == DRX_OPT_ROWWISE_ADAGRAD) o.kind = DRX_OPT_ADAGRAD;
     o.rb = 0.f;
     row_update<G, J>(o, P.b, opt.s1[3], opt.s2[3], 0, P.ld, lane, w, g);
   }

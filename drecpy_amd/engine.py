@@ -125,8 +125,11 @@ class CdaeEngine:
 
     # ---- optimizer --------------------------------------------------------------------------
     def init_optimizer(self, kind, lr, reg_rate):
-        """kind: 'adam' (Keras Adam, reference default recommender_abc.py:153) or 'adagrad'."""
-        self.opt_kind = _lib.OPT_ADAM if kind == 'adam' else _lib.OPT_ADAGRAD
+        """kind: 'adam' (Keras Adam, reference default recommender_abc.py:153), 'adagrad', or — sampled mode only —
+        'rowwise_adagrad' (one accumulator per table row: acc += mean_k(g^2); an engine extension, oracle/cdae_oracle.py)."""
+        if kind not in ('adam', 'adagrad', 'rowwise_adagrad'):
+            raise _lib.DrxError(f'unknown optimizer "{kind}" (adam, adagrad, rowwise_adagrad)')
+        self.opt_kind = {'adam': _lib.OPT_ADAM, 'adagrad': _lib.OPT_ADAGRAD, 'rowwise_adagrad': _lib.OPT_ROWWISE_ADAGRAD}[kind]
         self.lr, self.reg_rate = float(lr), float(reg_rate)
         if kind == 'adam':
             self.s1 = [torch.zeros_like(t) for t in self.tables()]

@@ -40,7 +40,9 @@ enum {
 
 enum { DRX_LOSS_BCE = 0, DRX_LOSS_MSE = 1 };           /* cdae.py:30-31 */
 enum { DRX_TARGETS_REFERENCE = 0, DRX_TARGETS_PER_ROW = 1 };   /* (B,B,N) broadcast == batch-mean target, cdae.py:78-79 */
-enum { DRX_OPT_ADAM = 0, DRX_OPT_ADAGRAD = 1 };
+enum { DRX_OPT_ADAM = 0, DRX_OPT_ADAGRAD = 1,
+       DRX_OPT_ROWWISE_ADAGRAD = 2   /* sampled mode only: ONE accumulator per table row, kept in the first float of the row's slot
+                                        (s1[var][row * ld]): acc += mean_k(g^2), p -= lr * g / (sqrt(acc) + eps); b and b2 per element */ };
 
 /* CDAE parameters (cdae.py:34-41) and optimizer slots of the same shapes.
  * Adam uses s1 = m, s2 = v; Adagrad uses s1 = accumulator (s2 unused, may be NULL). */

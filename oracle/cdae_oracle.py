@@ -187,6 +187,12 @@ def dense_step(params, state, step, uids, x_tilde, t, lr, reg_rate, loss='bce', 
 def sparse_state(params, optimizer='adagrad'):
     if optimizer == 'adagrad':
         return {k: np.full_like(v, ADAGRAD_INIT) for k, v in params.items()}
+    if optimizer == 'rowwise_adagrad':
+        # one accumulator per table ROW (W rows, W_ columns, V rows); the bias vectors keep one per element
+        return {'W': np.full(params['W'].shape[0], ADAGRAD_INIT, params['W'].dtype),
+                'W_': np.full(params['W_'].shape[1], ADAGRAD_INIT, params['W_'].dtype),
+                'V': np.full(params['V'].shape[0], ADAGRAD_INIT, params['V'].dtype),
+                'b': np.full_like(params['b'], ADAGRAD_INIT), 'b_': np.full_like(params['b_'], ADAGRAD_INIT)}
     return {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in params.items()}
 
 
@@ -247,7 +253,14 @@ def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss=
     def upd(name, index, g):
         """index: tuple selecting the touched slice of params[name]."""
         g = np.asarray(g, dtype=dt)
-        if optimizer == 'adagrad':
+        if optimizer == 'rowwise_adagrad' and name in ('W', 'W_', 'V'):
+            # engine extension (no reference counterpart): acc_row += mean_k(g^2); p -= lr * g / (sqrt(acc_row) + eps)
+            r = index[1] if name == 'W_' else index[0]
+            acc = state[name]
+            acc[r] = acc[r] + (g * g).mean(dtype=dt)
+            params[name][index] = params[name][index] - dt.type(np.float32(lr)) * g / (np.sqrt(acc[r]) + dt.type(ADAGRAD_EPS))
+            return
+        if optimizer in ('adagrad', 'rowwise_adagrad'):
             acc = state[name]
             acc[index] = acc[index] + g * g
             params[name][index] = params[name][index] - dt.type(np.float32(lr)) * g / (np.sqrt(acc[index]) + dt.type(ADAGRAD_EPS))

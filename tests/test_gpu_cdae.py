@@ -98,7 +98,8 @@ def test_dense_steps_match_oracle(K, B, loss, targets):
 
 @pytest.mark.parametrize('K,B,opt,loss,explicit', [(128, 256, 'adagrad', 'bce', True), (50, 64, 'adagrad', 'bce', False),
                                                    (8, 100, 'adam', 'mse', True), (128, 4096, 'adagrad', 'bce', False),
-                                                   (300, 50, 'adam', 'bce', False)])
+                                                   (300, 50, 'adam', 'bce', False), (128, 300, 'rowwise_adagrad', 'bce', False),
+                                                   (50, 64, 'rowwise_adagrad', 'mse', True)])
 @pytest.mark.parametrize('prepared', [False, True])
 def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
     """prepared=True: the touch list is built ahead by drx_cdae_sparse_prepare, which also marks the V / W2T rows a single
@@ -108,7 +109,7 @@ def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
     eng, p, rng = _engine(U, N, K, seed=2)
     indptr, indices = synth_history(rng, U, N, 14, zipf=1.1)
     eng.set_history(indptr, indices)
-    lr = 0.05 if opt == 'adagrad' else 1e-3
+    lr = 1e-3 if opt == 'adam' else 0.05
     eng.init_optimizer(opt, lr, 1e-3)
     st = co.sparse_state(p, opt)
     q = 0.2
