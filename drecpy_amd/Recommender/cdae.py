@@ -41,6 +41,7 @@ class CDAE(RecommenderABC):
         ds = self.interaction_dataset
         self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
         self._pipeline = None
+        self._pending = None
         weights = kwds.get('initial_weights')
         if weights is not None:                      # injected weights (TF's GlorotUniform stream is not reproducible)
             self._engine.set_params(**weights)
@@ -84,7 +85,39 @@ class CDAE(RecommenderABC):
             return ('device-batch', pipe.next)
         if self.mode == 'sampled' and kwds.get('as_arrays', True):
             return self._sampler.sample_arrays(batch_size)      # (uid, iid, value, is_negative) numpy arrays
+        if self.mode == 'reference':
+            return self._reference_batch(batch_size, kwds.get('more_to_come', False))
         return self._sampler.sample(batch_size)                  # list of (uid, iid, value) like the reference
+
+    class _Batch(list):
+        """The reference's list of (uid, iid, value) triples, carrying what the fused step needs of it."""
+        uid = keep_off = keep = None
+
+    def _draw_reference(self, batch_size):
+        """Sampler draw + MT19937 corruption stream of one batch (host only; both streams advance batch by batch)."""
+        batch = CDAE._Batch(self._sampler.sample(batch_size))
+        batch.uid = np.array([s[0] for s in batch], dtype=np.int32)
+        batch.keep_off, batch.keep = self._corruption_keep(batch.uid)
+        return batch
+
+    def _reference_batch(self, batch_size, more_to_come):
+        """Inside fit() the host work of batch t+1 (sampler, N uniform draws per row) runs on a worker thread while batch t
+        trains — the C++ calls release the GIL; the streams still advance strictly batch by batch, and nothing is drawn
+        beyond the last epoch."""
+        pending = getattr(self, '_pending', None)
+        self._pending = None
+        if pending is not None and pending[0] == batch_size:
+            batch = pending[1].result()
+        else:
+            if pending is not None:
+                pending[1].result()                                # (a batch of another size was drawn: it is consumed, like a draw)
+            batch = self._draw_reference(batch_size)
+        if more_to_come:
+            if getattr(self, '_host_pool', None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._host_pool = ThreadPoolExecutor(max_workers=1)
+            self._pending = (batch_size, self._host_pool.submit(self._draw_reference, batch_size))
+        return batch
 
     # ---- fused training step (replaces recommender_abc.py:190-204 for this model) ------------------------------------
     def _batch_arrays(self, batch_samples):
@@ -114,6 +147,11 @@ class CDAE(RecommenderABC):
         if self.mode == 'sampled' and self.device_sampler:       # batch drawn and indexed ahead of time on the device
             loss = self._pipeline.run_step(want_loss=want_loss)
             return float(loss[0].item()) if want_loss else None
+        if self.mode == 'reference' and getattr(batch_samples, 'keep', None) is not None:
+            uid, keep_off, keep = batch_samples.uid, batch_samples.keep_off, batch_samples.keep      # prepared by _sample_batch
+            bt, alive = eng.make_batch(uid, keep_off=keep_off, keep=keep, q=self.corruption_level, n_touch_slots=int(keep_off[-1]))
+            loss = eng.step_dense(step, bt, self._loss_name, self.loss_targets, want_loss=want_loss)
+            return float(loss.sum().item()) if want_loss else None
         uid, iid, val = self._batch_arrays(batch_samples)
         if self.mode == 'reference':
             keep_off, keep = self._corruption_keep(uid)

@@ -25,7 +25,8 @@ from .early_stopping import InvalidEpochValidationResultsException
 from .loss_tracker import LossTracker
 
 _LOG_FORMAT = '[%(asctime)s] (%(levelname)s) %(name)s: %(message)s'
-_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', 'epoch_weights', '_pipeline')
+_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', 'epoch_weights', '_pipeline', '_pending',
+              '_host_pool')
 
 
 def _make_logger(name, handler):
@@ -153,7 +154,9 @@ class RecommenderABC(ABC):
         bar = self._progress_bar(epochs)
         epoch = 0
         for epoch in (bar if bar is not None else range(1, epochs + 1)):
-            batch = self._sample_batch(batch_size, **kwds)
+            # `more_to_come`: a model may start preparing the NEXT batch on the host while this one trains (never after the
+            # last epoch, so the sampler streams end exactly where the reference's do)
+            batch = self._sample_batch(batch_size, more_to_come=epoch < epochs, **kwds)
             with self._device_lock:
                 loss = self._do_batch(batch, step=epoch - 1, want_loss=monitor.needs_loss, **kwds)
             if monitor.rule is not None and monitor.callback_due(epoch):

@@ -44,8 +44,17 @@ struct MT {
     uint32_t key[2] = {(uint32_t)(a & 0xFFFFFFFFu), (uint32_t)(a >> 32)};
     init_by_array(key, key[1] ? 2 : 1);
   }
-  uint32_t next() {
-    if (idx >= 624) {
+  // discards k outputs: the state is regenerated block by block as usual, but nothing is tempered
+  void skip(uint64_t k) {
+    while (k) {
+      if (idx >= 624) regenerate();
+      const uint64_t step = k < (uint64_t)(624 - idx) ? k : (uint64_t)(624 - idx);
+      idx += (int)step;
+      k -= step;
+    }
+  }
+  void regenerate() {
+    {
       int kk;
       uint32_t y;
       for (kk = 0; kk < 624 - 397; ++kk) {
@@ -60,6 +69,9 @@ struct MT {
       s[623] = s[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
       idx = 0;
     }
+  }
+  uint32_t next() {
+    if (idx >= 624) regenerate();
     uint32_t y = s[idx++];
     y ^= y >> 11;
     y ^= (y << 7) & 0x9D2C5680u;
@@ -326,15 +338,18 @@ int drx_rng_corruption_keep(DrxRng *r, const int64_t *h_indptr, const int32_t *h
     h_keep_off[b] = (int32_t)off;
     const int64_t s = h_indptr[h_uid[b]], e = h_indptr[h_uid[b] + 1];
     if (off + (e - s) > keep_capacity) return DRX_ESCRATCH;
-    int64_t j = s;
-    // cdae.py:63 draws one uniform(0,1) for EVERY item n = 0..N-1 of the row, positives or not
-    for (int32_t n = 0; n < n_items; ++n) {
+    // cdae.py:63 draws one uniform(0,1) for EVERY item n = 0..N-1 of the row, positives or not; only the draws that fall on a
+    // positive are looked at, the others just advance the stream (two 32-bit outputs per uniform)
+    int32_t n = 0;
+    for (int64_t j = s; j < e; ++j) {
+      const int32_t col = h_indices[j];
+      if (col < n || col >= n_items) return DRX_EINVAL;      // columns must ascend within a row
+      r->mt.skip(2ull * (uint64_t)(col - n));
       const double x = r->mt.random();     // uniform(0, 1) == 0 + (1 - 0) * random()
-      if (j < e && h_indices[j] == n) {
-        h_keep[off + (j - s)] = (x < q) ? 0 : 1;
-        ++j;
-      }
+      h_keep[off + (j - s)] = (x < q) ? 0 : 1;
+      n = col + 1;
     }
+    r->mt.skip(2ull * (uint64_t)(n_items - n));
     off += e - s;
   }
   h_keep_off[B] = (int32_t)off;

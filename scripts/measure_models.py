@@ -57,7 +57,11 @@ def main():
             batch = m._sample_batch(B)
             m._do_batch(batch, step=state['s'])
             state['s'] += 1
-        e2e = timed(full_step, 200)
+        timed(full_step, 200)
+        t0 = time.perf_counter()           # the public call: second fit() of 2000 one-batch epochs (set-up included)
+        m.fit(ds, epochs=2000, batch_size=B, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
+        torch.cuda.synchronize()
+        e2e = (time.perf_counter() - t0) / 2000
         batch = m._sample_batch(B)
         uid, _, _ = m._batch_arrays(batch)
         keep_off, keep = m._corruption_keep(uid)
@@ -78,7 +82,7 @@ def main():
         P = 2 * N * K + m.n_users * K + N + K
         out[f'cdae_reference_{shape}_K{K}_B{B}'] = {
             'n_users': m.n_users, 'n_items': N, 'nnz': m.n_rows, 'setup_s': round(setup, 2),
-            'fit_loop_ms_per_step (C++ sampler + MT19937 corruption stream + H2D + dense step)': e2e * 1e3,
+            'fit_loop_ms_per_step (fit() of 2000 epochs incl. set-up: C++ sampler + MT19937 corruption stream on a worker thread, H2D, dense step)': e2e * 1e3,
             'fit_loop_samples_per_s': B / e2e, 'device_step_ms': dev * 1e3, 'device_samples_per_s': B / dev,
             'algorithmic_bytes_per_step (24P + 4NK)': 24 * P + 4 * N * K, 'achieved_GBs_device_only': (24 * P + 4 * N * K) / dev / 1e9,
             'cpu_oracle_ms_per_step (numpy fp32 math only, no sampler)': cpu * 1e3, 'cpu_oracle_samples_per_s': B / cpu}
