@@ -15,6 +15,8 @@ from ..Sampler import ListSampler
 
 
 class Caser(RecommenderABC):
+    _host_prefetch = True      # fit() draws batch t+1 on a worker thread while batch t trains (sampler-only, engine-free hook)
+
     def __init__(self, L=5, T=3, d=50, n_v=4, n_h=16, act_h='relu', act_mlp='relu', dropout_rate=0.5,
                  sort_column='timestamp', device='cuda:0', **kwds):
         super().__init__(**kwds)

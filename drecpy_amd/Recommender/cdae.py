@@ -113,10 +113,7 @@ class CDAE(RecommenderABC):
                 pending[1].result()                                # (a batch of another size was drawn: it is consumed, like a draw)
             batch = self._draw_reference(batch_size)
         if more_to_come:
-            if getattr(self, '_host_pool', None) is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._host_pool = ThreadPoolExecutor(max_workers=1)
-            self._pending = (batch_size, self._host_pool.submit(self._draw_reference, batch_size))
+            self._pending = (batch_size, self._prefetch_pool().submit(self._draw_reference, batch_size))
         return batch
 
     # ---- fused training step (replaces recommender_abc.py:190-204 for this model) ------------------------------------

@@ -17,6 +17,8 @@ from ..Sampler import PointSampler
 
 
 class DMF(RecommenderABC):
+    _host_prefetch = True      # fit() draws batch t+1 on a worker thread while batch t trains (sampler-only, engine-free hook)
+
     def __init__(self, user_factors=None, item_factors=None, use_nce=True, l2_norm_vectors=True, device='cuda:0', **kwds):
         super().__init__(**kwds)
         self.user_factors = [64, 32] if user_factors is None else user_factors

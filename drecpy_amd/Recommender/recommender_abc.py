@@ -152,11 +152,17 @@ class RecommenderABC(ABC):
         monitor = _FitMonitor(self, epochs, kwds)
         monitor.before_training()
         bar = self._progress_bar(epochs)
-        epoch = 0
+        epoch, ahead = 0, None
         for epoch in (bar if bar is not None else range(1, epochs + 1)):
-            # `more_to_come`: a model may start preparing the NEXT batch on the host while this one trains (never after the
-            # last epoch, so the sampler streams end exactly where the reference's do)
-            batch = self._sample_batch(batch_size, more_to_come=epoch < epochs, **kwds)
+            # The host work of the NEXT batch overlaps this batch's device step — never beyond the last epoch, so the sampler
+            # streams end exactly where the reference's do.  Models whose _sample_batch is independent of _do_batch opt in with
+            # `_host_prefetch` (the draw runs on a worker thread; ctypes calls release the GIL); CDAE handles `more_to_come`
+            # itself (its corruption stream belongs to the draw).
+            if getattr(self, '_host_prefetch', False):
+                batch = ahead.result() if ahead is not None else self._sample_batch(batch_size, **kwds)
+                ahead = self._prefetch_pool().submit(self._sample_batch, batch_size, **kwds) if epoch < epochs else None
+            else:
+                batch = self._sample_batch(batch_size, more_to_come=epoch < epochs, **kwds)
             with self._device_lock:
                 loss = self._do_batch(batch, step=epoch - 1, want_loss=monitor.needs_loss, **kwds)
             if monitor.rule is not None and monitor.callback_due(epoch):
@@ -166,6 +172,8 @@ class RecommenderABC(ABC):
                 bar.set_description(text)
             self._info(text, log_console=False)
             if stop:
+                if ahead is not None:
+                    ahead.result()                 # drawn but unused: an early stop leaves the sampler one batch further
                 break
         best = monitor.after_training(epoch)
         if best is not None and best != epochs:
@@ -192,6 +200,12 @@ class RecommenderABC(ABC):
     @abstractmethod
     def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):
         """Build the model state for `self.interaction_dataset` (tables on the device, sampler)."""
+
+    def _prefetch_pool(self):
+        if getattr(self, '_host_pool', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._host_pool = ThreadPoolExecutor(max_workers=1)
+        return self._host_pool
 
     @abstractmethod
     def _sample_batch(self, batch_size, **kwds):
