@@ -152,8 +152,10 @@ def hr_at_10(dev):
                                      'interaction': rng.randint(1, 6, size=len(user))[perm]}, verbose=False)
     tr, te = leave_k_out(ds, k=10, min_user_interactions=10, seed=10, verbose=False)
     m = CDAE(hidden_factors=50, corruption_level=0.2, loss='bce', seed=10, verbose=False, device=str(dev))
+    m.fit(tr, epochs=2, batch_size=64, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)       # loads the dense-mode kernels once
     t0 = time.perf_counter()
-    m.fit(tr, epochs=100, batch_size=64, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
+    m.fit(tr, epochs=100, batch_size=64, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)     # a fresh fit: new tables, new sampler
+    torch.cuda.synchronize()
     fit_s = time.perf_counter() - t0
     res = ranking_evaluation(m, te, k=[1, 5, 10], novelty=True, n_test_users=100, n_pos_interactions=1, n_neg_interactions=100,
                              generate_negative_pairs=True, seed=10, verbose=False)
