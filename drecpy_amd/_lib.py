@@ -148,6 +148,11 @@ SIGNATURES = {
     'drx_sampler_sample': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_sampler_draw': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_sampler_destroy': (None, [C.c_void_p]),
+    'drx_cdae_kshard_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    'drx_cdae_kshard_step': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch), C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     'drx_sort_pairs_temp_bytes': (C.c_size_t, [C.c_int64, C.c_int32]),
     'drx_sort_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_list_sampler_create': (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

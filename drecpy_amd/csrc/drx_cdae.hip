@@ -494,20 +494,27 @@ __global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_
   }
 }
 
-// Everything of one triple after its input bag is known: hidden layer, sampled output unit, loss, backward, gradient rows
-// (and the in-place update of rows only this triple touches).
+// One triple after its input bag is known, in two halves.  sampled_hidden: hidden layer and the dot product with the
+// sampled output row (on the columns this table holds).  sampled_rest: loss, backward, gradient rows (and the in-place update
+// of rows only this triple touches) from the COMPLETE dot product — the same value in the single-GPU step, the sum over ranks
+// of the partial dots in the column-sharded one.
 template <int G, int J>
-__device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, float scale,
-                                               int loss_kind, const SparseBufs &S, int b, int lane, const float4 (&acc)[J]) {
-  const int u = bt.uid[b], i = bt.iid[b];
-  const float y = bt.y[b];
-  float4 h[J], w2[J];
-  hidden_act<G, J>(P, u, scale, lane, acc, h);
-  load_row<G, J>(P.W2T, (size_t)i, P.ld, lane, w2);
+__device__ __forceinline__ float sampled_hidden(const DrxCdaeParams &P, const DrxBatch &bt, float scale, int b, int lane,
+                                                const float4 (&acc)[J], float4 (&h)[J], float4 (&w2)[J]) {
+  hidden_act<G, J>(P, bt.uid[b], scale, lane, acc, h);
+  load_row<G, J>(P.W2T, (size_t)bt.iid[b], P.ld, lane, w2);
   float d = 0.f;
 #pragma unroll
   for (int j = 0; j < J; ++j) d += f4_dot(w2[j], h[j]);
-  d = group_sum<G>(d);
+  return group_sum<G>(d);
+}
+
+template <int G, int J>
+__device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, int loss_kind,
+                                             const SparseBufs &S, int b, int lane, float d, const float4 (&h)[J],
+                                             const float4 (&w2)[J]) {
+  const int u = bt.uid[b], i = bt.iid[b];
+  const float y = bt.y[b];
   const float p = sigmoidf_(d + P.b2[i]);
   const float invB = 1.0f / (float)bt.B;
   float lval, dp;
@@ -532,6 +539,42 @@ __device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const Drx
     if (lane == 0) S.dz2[b] = dz2;
   }
   if (solo_v) sparse_apply<G, J>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
+}
+
+template <int G, int J>
+__device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, float scale,
+                                               int loss_kind, const SparseBufs &S, int b, int lane, const float4 (&acc)[J]) {
+  float4 h[J], w2[J];
+  const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
+  sampled_rest<G, J>(P, opt, bt, loss_kind, S, b, lane, d, h, w2);
+}
+
+// ---- column-sharded ("K-sharded") step: the two halves as kernels of their own, the all-reduce of dot[] between them ----------
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_kshard_fwd(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale, uint32_t qthr,
+                                                       float *__restrict__ h_out, float *__restrict__ dot_out) {
+  const int lane = threadIdx.x % G;
+  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (b >= bt.B) return;
+  float4 acc[J], h[J], w2[J];
+  DenseAux none{};
+  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
+  const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
+  store_row<G, J>(h_out, (size_t)b, P.ld, lane, h);
+  if (lane == 0) dot_out[b] = d;
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_kshard_rest(DrxCdaeParams P, DrxOptim opt, DrxBatch bt, int loss_kind, SparseBufs S,
+                                                        const float *__restrict__ h_in, const float *__restrict__ dot_total) {
+  const int lane = threadIdx.x % G;
+  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;     // counters of the segmented reduction that follows
+  if (b >= bt.B) return;
+  float4 h[J], w2[J];
+  load_row<G, J>(h_in, (size_t)b, P.ld, lane, h);
+  load_row<G, J>(P.W2T, (size_t)bt.iid[b], P.ld, lane, w2);
+  sampled_rest<G, J>(P, opt, bt, loss_kind, S, b, lane, dot_total[b], h, w2);
 }
 
 template <int G, int J>
@@ -961,7 +1004,8 @@ static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs 
 
 static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
                             int32_t loss_kind, const void *prepared, size_t prepared_bytes, void *scratch, size_t scratch_bytes,
-                            float *loss_out, void *const *events, void *stream) {
+                            float *loss_out, void *const *events, void *stream, const float *ks_h = nullptr,
+                            const float *ks_dot = nullptr) {
   int rc = check_params(p);
   if (rc) return rc;
   rc = check_batch(hist, bt);
@@ -1002,7 +1046,10 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     const int gpb = kBlock / G;                                                                                        \
     const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
     EV(0);                                                                                                             \
-    if (per_wg)                                                                                                        \
+    if (ks_h)                                                                                                          \
+      hipLaunchKernelGGL((k_kshard_rest<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *bt, loss_kind, S, \
+                         ks_h, ks_dot);                                                                                \
+    else if (per_wg)                                                                                                   \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
                          *bt, scale, qthr, loss_kind, S);                                                              \
     else                                                                                                               \
@@ -1062,6 +1109,36 @@ int drx_cdae_step_sparse_prepared(const DrxCdaeParams *p, const DrxOptim *opt, c
                                   size_t scratch_bytes, float *loss_out, void *const *events, void *stream) {
   if (!prepared) return DRX_EINVAL;
   return step_sparse_impl(p, opt, hist, bt, loss_kind, prepared, prepared_bytes, scratch, scratch_bytes, loss_out, events, stream);
+}
+
+int drx_cdae_kshard_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, float *h_out, float *dot_partial,
+                            void *stream) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  rc = check_batch(hist, bt);
+  if (rc || !bt->iid || !bt->keep_off || !h_out || !dot_partial) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = 1.0f / (1.0f - bt->q);
+  const uint32_t qthr = q_threshold(bt->q);
+#define CALL(G, J)                                                                                                     \
+  {                                                                                                                    \
+    const int gpb = kBlock / G;                                                                                        \
+    hipLaunchKernelGGL((k_kshard_fwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, scale, qthr, \
+                       h_out, dot_partial);                                                                            \
+  }
+  DRX_DISPATCH_GEOM(p->ld, CALL);
+#undef CALL
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_cdae_kshard_step(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt, int32_t loss_kind,
+                         const float *h, const float *dot_total, const void *prepared, size_t prepared_bytes, void *scratch,
+                         size_t scratch_bytes, float *loss_out, void *const *events, void *stream) {
+  if (!h || !dot_total) return DRX_EINVAL;
+  if (opt && opt->kind == DRX_OPT_ROWWISE_ADAGRAD) return DRX_EINVAL;      // its row statistic would cover the local columns only
+  return step_sparse_impl(p, opt, hist, bt, loss_kind, prepared, prepared_bytes, scratch, scratch_bytes, loss_out, events, stream,
+                          h, dot_total);
 }
 
 int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,

@@ -509,3 +509,67 @@ class _Null:
 
     def __exit__(self, *a):
         return False
+
+
+class ColumnShardedCdae:
+    """One rank of the COLUMN-sharded ("K-sharded") sampled-mode CDAE: every rank holds all rows but only the columns
+    [k_lo, k_hi) of W, W2T, V and b (b2 is replicated) and every rank trains on the SAME global batch (identical sampler and
+    mask seeds).  A step is the single-GPU step on K/N columns with ONE exchange: the all-reduce of the per-triple partial
+    dot products h_b . W2T[i_b] (B floats).  Nothing else travels, so unlike the row-sharded layout it does not depend on
+    the point-to-point xGMI bandwidth between a PAIR of GPUs (one link), which bounds row-sharding at 2 and 4 GPUs.
+    The result equals the single-process step on the global batch with all K columns (the dot product is summed in rank
+    order); histories (the positives CSR of ALL users) are replicated."""
+
+    def __init__(self, n_users, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
+                 optimizer='adagrad', group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False):
+        from .engine import CdaeEngine
+        self.rank, self.world, self.group = rank, world, group
+        self.cpu_staging = cpu_staging
+        self.collectives = world > 1 or force_collectives
+        self.k = k
+        kpr = -(-k // world)
+        self.k_lo, self.k_hi = min(k, rank * kpr), min(k, (rank + 1) * kpr)
+        assert self.k_hi > self.k_lo, 'more ranks than columns'
+        self.engine = e = CdaeEngine(n_users, n_items, self.k_hi - self.k_lo, device=device)
+        e.set_history(hist_indptr, hist_indices)
+        e.init_optimizer(optimizer, lr, reg)
+        self.loss, self.q = loss, q
+        # GlorotUniform of the GLOBAL shapes; this rank's columns from its own stream, the replicated b2 from a shared one
+        gen = torch.Generator(device=e.device); gen.manual_seed(int(seed) * 1000003 + rank)
+        kl = self.k_hi - self.k_lo
+        for t, lim in ((e.W, math.sqrt(6.0 / (n_items + k))), (e.W2T, math.sqrt(6.0 / (k + n_items))), (e.V, math.sqrt(6.0 / (n_users + k)))):
+            t.zero_()
+            t[:, :kl] = (torch.rand(t.shape[0], kl, generator=gen, device=e.device) * 2 - 1) * lim
+        e.b.zero_(); e.b[:kl] = (torch.rand(kl, generator=gen, device=e.device) * 2 - 1) * math.sqrt(3.0 / k)
+        gb = torch.Generator(device=e.device); gb.manual_seed(int(seed))
+        e.b2.copy_((torch.rand(n_items, generator=gb, device=e.device) * 2 - 1) * math.sqrt(3.0 / n_items))
+
+    def set_params_global(self, W, W_, V, b, b_):
+        """Slices global (reference-orientation) weights into this rank's columns."""
+        lo, hi = self.k_lo, self.k_hi
+        self.engine.set_params(W=np.asarray(W)[:, lo:hi], W_=np.asarray(W_)[lo:hi, :], V=np.asarray(V)[:, lo:hi], b=np.asarray(b)[lo:hi],
+                               b_=np.asarray(b_))
+
+    def get_params(self):
+        return self.engine.get_params()
+
+    def step(self, step, bt, prepared=None, events=None, want_loss=False):
+        e = self.engine
+        h, dot = e.kshard_forward(bt)
+        if self.collectives:
+            if self.cpu_staging:
+                d = dot.cpu()
+                dist.all_reduce(d, group=self.group)
+                dot = d.to(dot.device)
+            else:
+                dist.all_reduce(dot, group=self.group)
+        out = e.step_sparse(step, bt, self.loss, want_loss=want_loss, events=events, prepared=prepared, kshard=(h, dot))
+        return float(out[0].item()) if want_loss else None
+
+    def pipeline(self, batch_size, neg_ratio, sample_seed_of, mask_seed_of):
+        """SampledPipeline over this rank: the SAME seeds on every rank give every rank the same global batch."""
+        from .engine import SampledPipeline
+        return SampledPipeline(self.engine, batch_size, neg_ratio, self.q, sample_seed_of, mask_seed_of, n_items=self.engine.n_items,
+                               loss=self.loss, step_fn=lambda s, bt, prep, events, want_loss: self.step(s, bt, prepared=prep, events=events,
+                                                                                                         want_loss=want_loss))
+

@@ -226,7 +226,15 @@ class CdaeEngine:
                                             stream_ptr(self.device)), 'drx_cdae_sparse_prepare')
         return out
 
-    def step_sparse(self, step, bt, loss='bce', want_loss=False, events=None, prepared=None):
+    def kshard_forward(self, bt):
+        """Forward half of the column-sharded step on this engine's columns: (h [B, ld], partial dot products [B])."""
+        h = torch.empty(bt.B, self.ld, dtype=torch.float32, device=self.device)
+        d = torch.empty(bt.B, dtype=torch.float32, device=self.device)
+        check(lib().drx_cdae_kshard_forward(C.byref(self._params), C.byref(self._hist), C.byref(bt), ptr(h), ptr(d),
+                                            stream_ptr(self.device)), 'drx_cdae_kshard_forward')
+        return h, d
+
+    def step_sparse(self, step, bt, loss='bce', want_loss=False, events=None, prepared=None, kshard=None):
         """One sampled-output step (sparse Adagrad / lazy Adam on touched rows).
         events: optional list of 6 recorded-once torch.cuda.Event(enable_timing=True); their raw hipEvent_t are
         re-recorded by the library around each phase (include/drx.h, drx_cdae_step_sparse_timed).
@@ -237,6 +245,13 @@ class CdaeEngine:
         lk = _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE
         lo = ptr(self._loss) if want_loss else None
         arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events]) if events is not None else None
+        if kshard is not None:            # column-sharded step: (h, all-reduced dot products) replace the forward half
+            h, dot_total = kshard
+            check(lib().drx_cdae_kshard_step(C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt), lk, ptr(h),
+                                             ptr(dot_total), ptr(prepared) if prepared is not None else None,
+                                             prepared.numel() if prepared is not None else 0, ptr(sc), sc.numel(), lo, arr,
+                                             stream_ptr(self.device)), 'drx_cdae_kshard_step')
+            return self._loss if want_loss else None
         if prepared is not None:
             check(lib().drx_cdae_step_sparse_prepared(C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
                                                       lk, ptr(prepared), prepared.numel(), ptr(sc), sc.numel(), lo, arr,
@@ -348,8 +363,11 @@ class SampledPipeline:
 
     sample_seed_of(s) / mask_seed_of(s): seeds of step s's triple draw and of its corruption mask."""
 
-    def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce'):
+    def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None):
         self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
+        # step_fn(s, bt, prepared, events, want_loss): what trains on a prepared batch (default: this engine's sparse step;
+        # dist.ColumnShardedCdae.step for the column-sharded multi-GPU layout)
+        self.step_fn = step_fn
         self.sample_seed_of, self.mask_seed_of = sample_seed_of, mask_seed_of
         self.n_items = n_items
         dev = eng.device
@@ -403,7 +421,10 @@ class SampledPipeline:
         self._prepare(s + 1)
         bt = self.batch_of(s)
         self.main.wait_event(self.prep_done[s % 2])
-        out = self.eng.step_sparse(s, bt, self.loss, want_loss=want_loss, events=events, prepared=self.prep[s % 2])
+        if self.step_fn is not None:
+            out = self.step_fn(s, bt, self.prep[s % 2], events, want_loss)
+        else:
+            out = self.eng.step_sparse(s, bt, self.loss, want_loss=want_loss, events=events, prepared=self.prep[s % 2])
         self.step_done[s % 2].record(self.main)
         self.ring_free[s % 3].record(self.main)
         self.next = s + 1

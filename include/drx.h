@@ -158,6 +158,18 @@ int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, i
                      uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
                      void *scratch, size_t scratch_bytes, void *stream);
 
+/* ---- column-sharded ("K-sharded") multi-GPU step (no reference equivalent) ------------------------------------------------
+ * Every rank holds ALL rows but only its own columns of W, W2T, V and b (DrxCdaeParams describes that slice: k = local columns;
+ * b2 is replicated) and trains on the SAME global batch.  The one exchange of a step is the sum over ranks of the per-triple
+ * partial dot products: forward -> all-reduce(dot_partial) -> step.  Everything else (touch list, segmented reduction, updates)
+ * is the single-GPU step on K/N columns.  drx_cdae_kshard_step is drx_cdae_step_sparse(_prepared) with the forward half
+ * replaced by (h, dot_total); `prepared` may be NULL (touch list built inline), `events` as in drx_cdae_step_sparse_timed. */
+int drx_cdae_kshard_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, float *h_out /* [B, ld] */,
+                            float *dot_partial /* [B] */, void *stream);
+int drx_cdae_kshard_step(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt, int32_t loss_kind,
+                         const float *h, const float *dot_total, const void *prepared, size_t prepared_bytes, void *scratch,
+                         size_t scratch_bytes, float *loss_out, void *const *events, void *stream);
+
 /* ---- row-sharded multi-GPU step (no reference equivalent — DRecPy is single-process) ---------------
  * Per-rank, collective-free pieces of the sampled step; the host (drecpy_amd/dist.py) runs the RCCL all-to-all
  * exchanges between them.  Users (V, histories, samples) are sharded by uid range; item rows (W, W2T, b2) by item range

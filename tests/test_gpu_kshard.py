@@ -1,0 +1,139 @@
+"""GPU parity of the COLUMN-sharded step (dist.ColumnShardedCdae: every rank all rows x its columns, same global batch, one
+all-reduce of the partial dot products): world 1 in-process, world 2 / 3 as processes sharing the one GPU of the box (gloo,
+host-staged all-reduce), and through a 1-rank RCCL communicator — against the single-process oracle step on all K columns."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+pytestmark = pytest.mark.gpu
+U, N, B, STEPS, Q = 300, 411, 700, 4, 0.2
+
+
+def _problem(K):
+    from oracle import cdae_oracle as co
+    from helpers import synth_history
+    rng = np.random.default_rng(5)
+    p = co.init_params(rng, U, N, K, np.float32)
+    indptr, indices = synth_history(rng, U, N, 12, zipf=1.2)
+    batches = [(rng.integers(0, U, size=B), rng.integers(0, N, size=B), (rng.random(B) < 0.3).astype(np.float32), 500 + 31 * s)
+               for s in range(STEPS)]
+    return p, indptr, indices, batches
+
+
+def _oracle(K, opt):
+    from oracle import cdae_oracle as co
+    p, indptr, indices, batches = _problem(K)
+    p = {k: v.astype(np.float64) for k, v in p.items()}
+    st = co.sparse_state(p, opt)
+    lr = 0.05 if opt == 'adagrad' else 1e-3
+    losses = []
+    for s, (uid, iid, y, seed) in enumerate(batches):
+        kept = []
+        for b, u in enumerate(uid):
+            row = indices[indptr[u]:indptr[u + 1]]
+            kf = co.drx_hash_u32(seed, np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
+            kept.append(row[kf].tolist())
+        lval, _ = co.sparse_step(p, st, s, uid, iid, y, kept, float(np.float32(Q)), lr, 1e-3, 'bce', opt)
+        losses.append(lval)
+    return p, losses
+
+
+def _run_rank(rank, world, K, opt, staged, force=False, prepared=True):
+    from drecpy_amd.dist import ColumnShardedCdae
+    p, indptr, indices, batches = _problem(K)
+    m = ColumnShardedCdae(U, N, K, rank, world, 'cuda:0', indptr, indices, q=Q, optimizer=opt, lr=0.05 if opt == 'adagrad' else 1e-3,
+                          cpu_staging=staged, force_collectives=force)
+    m.set_params_global(**p)
+    losses = []
+    for s, (uid, iid, y, seed) in enumerate(batches):                      # the SAME batch on every rank
+        bt, alive = m.engine.make_batch(uid, iid, y, q=Q, mask_seed=seed)
+        prep = m.engine.prepare_sparse(bt) if (prepared and s % 2) else None
+        losses.append(m.step(s, bt, prepared=prep, want_loss=True))
+    torch.cuda.synchronize()
+    return m.get_params(), losses, (m.k_lo, m.k_hi)
+
+
+def _check(K, opt, results):
+    p, want_losses = _oracle(K, opt)
+    tol = dict(rtol=0, atol=3e-6)
+    for g, losses, (lo, hi) in results:
+        np.testing.assert_allclose(g['W'], p['W'][:, lo:hi], **tol)
+        np.testing.assert_allclose(g['W_'], p['W_'][lo:hi, :], **tol)
+        np.testing.assert_allclose(g['V'], p['V'][:, lo:hi], **tol)
+        np.testing.assert_allclose(g['b'], p['b'][lo:hi], **tol)
+        np.testing.assert_allclose(g['b_'], p['b_'], **tol)                 # replicated, updated identically everywhere
+        np.testing.assert_allclose(losses, want_losses, rtol=1e-5)
+
+
+@pytest.mark.parametrize('K,opt', [(50, 'adagrad'), (128, 'adam')])
+def test_column_sharded_world1_matches_oracle(K, opt):
+    _check(K, opt, [_run_rank(0, 1, K, opt, False)])
+
+
+def _worker(rank, world, port, out, K, opt):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    res = _run_rank(rank, world, K, opt, True)
+    torch.save(res, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adagrad'), (2, 64, 'adam')])
+def test_column_sharded_processes_on_one_gpu_match_oracle(tmp_path, world, K, opt):
+    """world 3 with K = 50: 17 + 17 + 16 columns (uneven, and lane-group geometries differ from the unsharded one)."""
+    out = str(tmp_path / 'ks')
+    port = 29800 + (os.getpid() % 200) + 300 * world + K
+    mp.spawn(_worker, args=(world, port, out, K, opt), nprocs=world, join=True)
+    _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
+
+
+def _worker_rccl(rank, port, out, K, opt):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    res = _run_rank(0, 1, K, opt, False, force=True)
+    torch.save(res, f'{out}.0')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_column_sharded_step_through_rccl_world1(tmp_path):
+    out = str(tmp_path / 'ksr')
+    port = 29300 + (os.getpid() % 200)
+    mp.spawn(_worker_rccl, args=(port, out, 128, 'adagrad'), nprocs=1, join=True)
+    _check(128, 'adagrad', [torch.load(f'{out}.0', weights_only=False)])
+
+
+def test_column_sharded_pipeline_equals_stepping_inline():
+    """ColumnShardedCdae.pipeline (device sampler two batches ahead, touch list one ahead) vs the same seeds stepped inline."""
+    from drecpy_amd.dist import ColumnShardedCdae
+    p, indptr, indices, _ = _problem(64)
+    outs = []
+    for piped in (True, False):
+        m = ColumnShardedCdae(U, N, 64, 0, 1, 'cuda:0', indptr, indices, q=Q)
+        m.set_params_global(**p)
+        if piped:
+            pipe = m.pipeline(512, 5, lambda s: 77 + s, lambda s: 1000 + s)
+            for _ in range(6):
+                pipe.run_step()
+        else:
+            for s in range(6):
+                uid, iid, y, ko = m.engine.sample_device(512, 5, 77 + s)
+                bt, alive = m.engine.make_batch(uid, iid, y, keep_off=ko, q=Q, mask_seed=1000 + s)
+                m.step(s, bt)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in m.engine.tables()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
