@@ -48,6 +48,10 @@ def parse():
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
     ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'adam', 'rowwise_adagrad'], help='sparse optimizer of the sampled mode (S = 1 / 2 slots per parameter; single-GPU path)')
+    ap.add_argument('--layout', default='columns', choices=['columns', 'rows'],
+                    help='multi-GPU layout: columns = every rank all rows x K/N columns, same global batch, one all-reduce of B scalars per step; '
+                         'rows = users and item rows sharded by range, rows and gradient rows travel by all-to-all')
+    ap.add_argument('--force-columns', action='store_true', help='run the column-sharded code path even at 1 GPU')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     return ap.parse_args()
 
@@ -165,6 +169,88 @@ def hr_at_10(dev):
                      f'({len(tr)} train / {len(te)} test rows), protocol examples/cdae.py:15-17'}
 
 
+def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
+    """Column-sharded layout (dist.ColumnShardedCdae): the job's global batch (B per GPU x N GPUs) is drawn identically on every
+    rank, each rank trains its K/N columns of every table on all of it; one all-reduce of B_global floats per step."""
+    from drecpy_amd import synth
+    from drecpy_amd.dist import ColumnShardedCdae
+    U, N, md, mn, alpha = synth.SHAPES[args.workload]
+    if args.users:
+        U = args.users
+    Bg = args.batch * world
+    t_setup = time.time()
+    indptr, indices = synth.synth_history(U, N, md, mn, alpha, seed=0, device=dev)          # every rank: all users
+    nnz = int(indptr[-1].item())
+    model = ColumnShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=1e-3 if args.optimizer == 'adam' else LR, reg=REG,
+                              optimizer=args.optimizer, q=Q, cpu_staging=debug_gloo, force_collectives=rccl1)
+    eng = model.engine
+    uid, iid, y, keep_off = eng.sample_device(Bg, NEG_RATIO, 1000, n_items=N)
+    rows_per_sample = kept_count(keep_off, 1000, Q) / Bg + 2.0
+    f_solo = 0.0
+    for col in (uid.long(), iid.long()):
+        _, inv, cnt = torch.unique(col, return_inverse=True, return_counts=True)
+        f_solo += float((cnt[inv] == 1).float().mean().item())
+    setup_s = time.time() - t_setup
+    pipe = model.pipeline(Bg, NEG_RATIO, lambda s: 5000 + 7919 * s, lambda s: 5000 + 7919 * s)    # same seeds on every rank
+    for _ in range(args.warmup):
+        pipe.run_step()
+    EVERY = max(1, int(os.environ.get('DRX_BENCH_EVENTS_EVERY', 4)))
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+    for es in evs:
+        for e in es:
+            e.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        if s % EVERY == 0:
+            evs[s][0].record()                        # [0,1): forward half + all-reduce of the partial dot products
+            pipe.run_step(events=evs[s][1:])
+        else:
+            pipe.run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ph = np.array([[es[i].elapsed_time(es[i + 1]) for i in range(6)] for es in evs[::EVERY]]).mean(axis=0)
+    names = ['k_kshard_fwd+allreduce(dot)', 'k_kshard_rest', 'touch_sort(overlapped on side stream)', 'k_seg_reduce',
+             'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
+    kl = model.k_hi - model.k_lo
+    S_opt = 2.0 if args.optimizer == 'adam' else 1.0
+    alg_upd = Bg * 4.0 * kl * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)      # this rank's columns of the global batch
+    alg_fwd = Bg * 4.0 * kl * rows_per_sample
+    dom, dom_ms, dom_alg = ('k_seg_reduce', ph[3], alg_upd) if ph[3] >= ph[0] else ('k_kshard_fwd+allreduce(dot)', ph[0], alg_fwd)
+    step_alg = Bg * 4.0 * kl * rows_per_sample * (3.0 + 2.0 * S_opt)
+    if rank == 0:
+        copy_gbs = hbm_copy_gbs(dev)
+        out = {'metric': 'training samples/sec (user-item pairs)', 'value': Bg * args.steps / dt, 'unit': 'samples/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{"Adam (lazy)" if S_opt == 2.0 else "Adagrad"} on '
+                                      f'{args.workload}-shaped synthetic ({U} users x {N} items, {nnz} positives), corruption {Q}, neg_ratio {NEG_RATIO}',
+                          'batch_per_gpu': args.batch, 'global_batch': Bg, 'rows_per_sample': round(rows_per_sample, 3),
+                          'sole_toucher_rows_per_sample': round(f_solo, 3),
+                          'batches': 'fresh device-sampled global batch every step, drawn identically on every rank (sampler two steps ahead)',
+                          'sharding': f'columns: every rank holds all rows x {kl} of {K} columns and trains on the whole global batch; '
+                                      f'one all-reduce of {Bg} floats per step'},
+               'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': dom_alg / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': dom_alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                            'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(evs[::EVERY])),
+                            'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
+                            'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 'hbm_copy_achievable': copy_gbs,
+                            'note': 'per-rank figures: this rank\'s K/N columns of the global batch; algorithmic bytes per SURVEY 8d charge a '
+                                    'read-modify-write per touched-row occurrence, the kernel merges occurrences first (DESIGN.md section 3)'},
+               'phases_ms': {n: float(v) for n, v in zip(names, ph)}, 'setup_s': round(setup_s, 1), 'cpu_baseline': None, 'hr_at_10': None}
+        print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -187,6 +273,12 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+
+    if (world > 1 and args.layout == 'columns' and not args.force_sharded) or args.force_columns:
+        run_columns(args, rank, world, dev, dist, debug_gloo, rccl1)
+        if world > 1 or rccl1:
+            dist.destroy_process_group()
+        return
 
     from drecpy_amd import synth
     from drecpy_amd.engine import CdaeEngine

@@ -77,6 +77,7 @@ __device__ __forceinline__ float bce_grad(float t, float p) {
 // 4*(lane + j*G) .. +3).  ld <= 4*G*J.
 struct Geom { int G, J; };
 inline Geom pick_geom(int ld) {
+  if (ld <= 16) return {4, 1};      // e.g. K = 128 columns sharded over 8 GPUs: 16 wave64 rows per load instruction
   if (ld <= 32) return {8, 1};
   if (ld <= 64) return {16, 1};
   if (ld <= 128) return {32, 1};
@@ -88,7 +89,8 @@ inline Geom pick_geom(int ld) {
 #define DRX_DISPATCH_GEOM(ld, CALL)                        \
   do {                                                     \
     drx::Geom g_ = drx::pick_geom(ld);                     \
-    if (g_.G == 8) { CALL(8, 1); }                         \
+    if (g_.G == 4) { CALL(4, 1); }                         \
+    else if (g_.G == 8) { CALL(8, 1); }                    \
     else if (g_.G == 16) { CALL(16, 1); }                  \
     else if (g_.G == 32) { CALL(32, 1); }                  \
     else if (g_.J == 1) { CALL(64, 1); }                   \

@@ -122,10 +122,10 @@ def test_bad_arguments_are_rejected():
         _lib.check(rc, 'drx_cdae_step_sparse')
 
 
-@pytest.mark.parametrize('K', [1, 3, 20, 33, 64, 65, 129, 200, 256, 260, 512, 600, 1000])
+@pytest.mark.parametrize('K', [1, 3, 13, 16, 17, 20, 33, 64, 65, 129, 200, 256, 260, 512, 600, 1000])
 @pytest.mark.parametrize('mode,opt', [('sparse', 'adagrad'), ('sparse', 'adam'), ('dense', 'adam')])
 def test_every_row_geometry(K, mode, opt):
-    """One K per lane-group geometry and both of its borders — (8,1) ld<=32, (16,1) <=64, (32,1) <=128, (64,1) <=256,
+    """One K per lane-group geometry and both of its borders — (4,1) ld<=16, (8,1) <=32, (16,1) <=64, (32,1) <=128, (64,1) <=256,
     (64,2) <=512, (64,4) <=1024 — incl. K with padding columns and the > 48 KB LDS of the long-span tier at K = 1000;
     hot rows that cross many chunks, sole-toucher rows (odd steps go through the prepared path), ragged batch."""
     rng = np.random.default_rng(K)
