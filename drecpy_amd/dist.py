@@ -521,8 +521,7 @@ class ColumnShardedCdae:
     order); histories (the positives CSR of ALL users) are replicated."""
 
     def __init__(self, n_users, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
-                 optimizer='adagrad', group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False):
-        from .engine import CdaeEngine
+                 optimizer='adagrad', group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False, engine=None):
         self.rank, self.world, self.group = rank, world, group
         self.cpu_staging = cpu_staging
         self.collectives = world > 1 or force_collectives
@@ -530,10 +529,14 @@ class ColumnShardedCdae:
         kpr = -(-k // world)
         self.k_lo, self.k_hi = min(k, rank * kpr), min(k, (rank + 1) * kpr)
         assert self.k_hi > self.k_lo, 'more ranks than columns'
+        self.loss, self.q = loss, q
+        if engine is not None:            # tests: a NumPy statement of the two per-rank halves (tests/test_dist_gloo.py)
+            self.engine = engine
+            return
+        from .engine import CdaeEngine
         self.engine = e = CdaeEngine(n_users, n_items, self.k_hi - self.k_lo, device=device)
         e.set_history(hist_indptr, hist_indices)
         e.init_optimizer(optimizer, lr, reg)
-        self.loss, self.q = loss, q
         # GlorotUniform of the GLOBAL shapes; this rank's columns from its own stream, the replicated b2 from a shared one
         gen = torch.Generator(device=e.device); gen.manual_seed(int(seed) * 1000003 + rank)
         kl = self.k_hi - self.k_lo
@@ -564,7 +567,7 @@ class ColumnShardedCdae:
             else:
                 dist.all_reduce(dot, group=self.group)
         out = e.step_sparse(step, bt, self.loss, want_loss=want_loss, events=events, prepared=prepared, kshard=(h, dot))
-        return float(out[0].item()) if want_loss else None
+        return float(out[0]) if want_loss else None
 
     def pipeline(self, batch_size, neg_ratio, sample_seed_of, mask_seed_of):
         """SampledPipeline over this rank: the SAME seeds on every rank give every rank the same global batch."""

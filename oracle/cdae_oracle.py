@@ -197,7 +197,7 @@ def sparse_state(params, optimizer='adagrad'):
 
 
 def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss='bce',
-                optimizer='adagrad'):
+                optimizer='adagrad', dot_reduce=None):
     """One step over B triples (u_b, i_b, y_b).  kept[b] = item ids of u_b's positives that
     survive corruption (cdae.py:61-63 restricted to the non-zero entries).
 
@@ -220,7 +220,10 @@ def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss=
     z1 = z1 + V[uids] + b
     h = sigmoid(z1)
     w2 = W_[:, iids].T                                   # [B,K]
-    p = sigmoid((h * w2).sum(axis=1) + b_[iids])
+    d = (h * w2).sum(axis=1)
+    if dot_reduce is not None:       # column-sharded layout: `params` holds a column slice, the dot products are summed over ranks
+        d = dot_reduce(d)
+    p = sigmoid(d + b_[iids])
     yy = np.asarray(y, dtype=dt)
     if loss == 'bce':
         lval = bce_elem(yy, p, dt).mean()

@@ -107,3 +107,87 @@ def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, w
         np.testing.assert_allclose(g['V'], p['V'][ulo:uhi], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g['b'], p['b'], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(res[r]['losses'], want_losses, rtol=1e-9)
+
+
+# ---- column-sharded layout (dist.ColumnShardedCdae) over gloo on CPU -------------------------------------------------------------
+class _NumpyColumnEngine:
+    """The two per-rank halves of the column-sharded step, stated with the oracle's arithmetic on a column slice: the forward
+    half yields the partial dot products, the step half is oracle.sparse_step fed the all-reduced ones."""
+
+    def __init__(self, p_slice, indptr, indices, lr, reg):
+        from oracle import cdae_oracle as co
+        self.co, self.p, self.indptr, self.indices, self.lr, self.reg = co, p_slice, indptr, indices, lr, reg
+        self.st = co.sparse_state(p_slice, 'adagrad')
+
+    def _kept(self, bt):
+        co = self.co
+        out = []
+        for b, u in enumerate(bt['uid']):
+            row = self.indices[self.indptr[u]:self.indptr[u + 1]]
+            kf = co.drx_hash_u32(bt['seed'], np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
+            out.append(row[kf].tolist())
+        return out
+
+    def kshard_forward(self, bt):
+        co, p = self.co, self.p
+        s = 1.0 / (1.0 - float(np.float32(Q)))
+        z1 = np.stack([p['W'][k].sum(axis=0) * s if len(k) else np.zeros(p['W'].shape[1]) for k in self._kept(bt)]) + p['V'][bt['uid']] + p['b']
+        h = co.sigmoid(z1)
+        return h, torch.from_numpy((h * p['W_'][:, bt['iid']].T).sum(axis=1))
+
+    def step_sparse(self, step, bt, loss, want_loss=False, events=None, prepared=None, kshard=None):
+        total = kshard[1].numpy()
+        lval, _ = self.co.sparse_step(self.p, self.st, step, bt['uid'], bt['iid'], bt['y'], self._kept(bt), float(np.float32(Q)), self.lr, self.reg,
+                                      'bce', 'adagrad', dot_reduce=lambda d: total)
+        return [lval]
+
+
+def _column_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from drecpy_amd.dist import ColumnShardedCdae
+    p, indptr, indices, batches = _problem(1)
+    m = ColumnShardedCdae(U, N, K, rank, world, 'cpu', indptr, indices, q=Q, engine=object())
+    lo, hi = m.k_lo, m.k_hi
+    m.engine = _NumpyColumnEngine({'W': p['W'][:, lo:hi].copy(), 'W_': p['W_'][lo:hi, :].copy(), 'V': p['V'][:, lo:hi].copy(),
+                                   'b': p['b'][lo:hi].copy(), 'b_': p['b_'].copy()}, indptr, indices, 0.05, 1e-3)
+    losses = []
+    for s in range(STEPS):
+        uid, iid, y, seed = batches[s][0]                       # the SAME global batch on every rank
+        losses.append(m.step(s, {'uid': uid, 'iid': iid, 'y': y, 'seed': seed}, want_loss=True))
+    torch.save({'params': m.engine.p, 'losses': losses, 'cols': (lo, hi)}, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_column_sharded_step_equals_single_process_oracle(tmp_path, world):
+    """Every rank holds all rows x its columns and the same batch; the only exchange is the all-reduce of the partial dot
+    products (dist.ColumnShardedCdae.step) — the result must equal the single-process step on all K columns (K = 6: 3 + 3, 2 + 2 + 2)."""
+    from oracle import cdae_oracle as co
+    out = str(tmp_path / 'cols')
+    port = 29100 + (os.getpid() % 200) + 300 * world
+    mp.spawn(_column_worker, args=(world, port, out), nprocs=world, join=True)
+    p, indptr, indices, batches = _problem(1)
+    st = co.sparse_state(p, 'adagrad')
+    want = []
+    for s in range(STEPS):
+        uid, iid, y, seed = batches[s][0]
+        kept = []
+        for b, u in enumerate(uid):
+            row = indices[indptr[u]:indptr[u + 1]]
+            kept.append(row[co.drx_hash_u32(seed, np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)].tolist())
+        lval, _ = co.sparse_step(p, st, s, uid, iid, y, kept, float(np.float32(Q)), 0.05, 1e-3, 'bce', 'adagrad')
+        want.append(lval)
+    for r in range(world):
+        res = torch.load(f'{out}.{r}', weights_only=False)
+        lo, hi = res['cols']
+        g = res['params']
+        tol = dict(rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g['W'], p['W'][:, lo:hi], **tol)
+        np.testing.assert_allclose(g['W_'], p['W_'][lo:hi, :], **tol)
+        np.testing.assert_allclose(g['V'], p['V'][:, lo:hi], **tol)
+        np.testing.assert_allclose(g['b'], p['b'][lo:hi], **tol)
+        np.testing.assert_allclose(g['b_'], p['b_'], **tol)
+        np.testing.assert_allclose(res['losses'], want, rtol=1e-9)
