@@ -556,6 +556,17 @@ class ColumnShardedCdae:
     def get_params(self):
         return self.engine.get_params()
 
+    def gather_params_global(self):
+        """All K columns on every rank (reference orientation: W [N,K], W_ [K,N], V [U,K], b [K], b_ [N]) — for evaluation or
+        export; an infrequent host-side gather, not part of a step."""
+        mine = self.get_params()
+        if not self.collectives:
+            return mine
+        parts = [None] * self.world
+        dist.all_gather_object(parts, mine, group=self.group)
+        return {'W': np.concatenate([p['W'] for p in parts], axis=1), 'W_': np.concatenate([p['W_'] for p in parts], axis=0),
+                'V': np.concatenate([p['V'] for p in parts], axis=1), 'b': np.concatenate([p['b'] for p in parts]), 'b_': parts[0]['b_']}
+
     def step(self, step, bt, prepared=None, events=None, want_loss=False):
         e = self.engine
         h, dot = e.kshard_forward(bt)

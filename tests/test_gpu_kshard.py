@@ -59,6 +59,10 @@ def _run_rank(rank, world, K, opt, staged, force=False, prepared=True):
         prep = m.engine.prepare_sparse(bt) if (prepared and s % 2) else None
         losses.append(m.step(s, bt, prepared=prep, want_loss=True))
     torch.cuda.synchronize()
+    if world > 1:                                                           # every rank can assemble the whole model
+        full = m.gather_params_global()
+        assert full['W'].shape == (N, K) and full['W_'].shape == (K, N) and full['V'].shape == (U, K) and full['b'].shape == (K,)
+        np.testing.assert_array_equal(full['W'][:, m.k_lo:m.k_hi], m.get_params()['W'])
     return m.get_params(), losses, (m.k_lo, m.k_hi)
 
 
