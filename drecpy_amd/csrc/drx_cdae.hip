@@ -40,31 +40,43 @@ __device__ __forceinline__ void gather_bag(const DrxCdaeParams &P, const DrxHist
   const int u = bt.uid[b];
   const int64_t s = H.indptr[u], e = H.indptr[u + 1];
   const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
-  for (int64_t c = s + (int64_t)part * G; c < e; c += (int64_t)nparts * G) {
-    const int64_t j = c + lane;
-    int idx = -1, kf = 0;
-    if (j < e) {
-      idx = H.indices[j];
-      const uint32_t jj = (uint32_t)(j - s);
-      kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
-      if (MODE == 1) {
-        atomicAdd(&aux.cnt[idx], 1);
-        if (aux.tb) atomicOr(&aux.tb[(size_t)b * aux.Nw + (idx >> 5)], 1u << (idx & 31));
-        if (kf) atomicOr(&aux.km[(size_t)idx * aux.Bw + (b >> 5)], 1u << (b & 31));
-      }
-      if (MODE == 2) {
-        tkeys[touch_base + jj] = kf ? (uint32_t)idx : DRX_KEY_NONE;
-        tvals[touch_base + jj] = (uint32_t)b;
+  // a group fetches CH history entries per round: its G lanes hold IPL each, so that narrow groups (rows of <= 32 floats:
+  // G = 4 or 8) do not walk the history in rounds of 4 or 8 dependent index loads
+  constexpr int IPL = G >= 16 ? 1 : 16 / G;
+  constexpr int CH = G * IPL;
+  for (int64_t c = s + (int64_t)part * CH; c < e; c += (int64_t)nparts * CH) {
+    int idx[IPL], kf[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int64_t j = c + r * G + lane;
+      idx[r] = -1; kf[r] = 0;
+      if (j < e) {
+        idx[r] = H.indices[j];
+        const uint32_t jj = (uint32_t)(j - s);
+        kf[r] = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
+        if (MODE == 1) {
+          atomicAdd(&aux.cnt[idx[r]], 1);
+          if (aux.tb) atomicOr(&aux.tb[(size_t)b * aux.Nw + (idx[r] >> 5)], 1u << (idx[r] & 31));
+          if (kf[r]) atomicOr(&aux.km[(size_t)idx[r] * aux.Bw + (b >> 5)], 1u << (b & 31));
+        }
+        if (MODE == 2) {
+          tkeys[touch_base + jj] = kf[r] ? (uint32_t)idx[r] : DRX_KEY_NONE;
+          tvals[touch_base + jj] = (uint32_t)b;
+        }
       }
     }
-    const int n_here = (int)((e - c) < (int64_t)G ? (e - c) : (int64_t)G);
+    const int n_here = (int)((e - c) < (int64_t)CH ? (e - c) : (int64_t)CH);
     constexpr int NF = J == 1 ? DRX_GATHER_ROWS : 4;       // rows in flight per group
     for (int t = 0; t < n_here; t += NF) {
       float4 r[NF][J];
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
-        const int iq = __shfl(idx, t + q, G);
-        const int kq = (t + q < n_here) ? __shfl(kf, t + q, G) : 0;
+        const int tt = t + q;
+        int si = idx[0], sk = kf[0];
+#pragma unroll
+        for (int rr = 1; rr < IPL; ++rr) { si = (tt / G == rr) ? idx[rr] : si; sk = (tt / G == rr) ? kf[rr] : sk; }
+        const int iq = __shfl(si, tt % G, G);
+        const int kq = (tt < n_here) ? __shfl(sk, tt % G, G) : 0;
 #pragma unroll
         for (int jx = 0; jx < J; ++jx) r[q][jx] = f4_zero();
         if (kq) load_row<G, J>(P.W, (size_t)iq, P.ld, lane, r[q]);
