@@ -277,6 +277,7 @@ def main():
     if (world > 1 and args.layout == 'columns' and not args.force_sharded) or args.force_columns:
         run_columns(args, rank, world, dev, dist, debug_gloo, rccl1)
         if world > 1 or rccl1:
+            dist.barrier()                      # rank 0 prints (and times a device copy) after the others are done
             dist.destroy_process_group()
         return
 
@@ -501,6 +502,7 @@ def main():
         out['hr_at_10'] = hr_at_10(dev) if (world == 1 and not args.no_hr and not args.users) else None
         print(json.dumps(out), flush=True)
     if world > 1 or rccl1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
