@@ -36,8 +36,8 @@ LR, REG = 0.05, 1e-3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='synth-10m', choices=['synth-10m', 'ml-1m', 'ml-100k'])
     ap.add_argument('--batch', type=int, default=65536, help='triples per GPU per step')
     ap.add_argument('--n-batches', type=int, default=8, help='batches sampled at setup (R estimate, CPU baseline; cycled with --presampled)')
