@@ -3,7 +3,6 @@
 import random
 from heapq import heappush, heapreplace
 
-import numpy as np
 
 
 def leave_k_out(interaction_dataset, k=1, min_user_interactions=0, last_timestamps=False, timestamp_label='timestamp',

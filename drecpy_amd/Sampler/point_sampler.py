@@ -4,7 +4,6 @@ The draws come from the C++ host sampler in libdrx.so (CPython-exact MT19937, th
 CSR / sorted-pair membership instead of the O(nnz) pandas scans of mem_dataset.py:121,161); the streams are
 bit-identical to the reference's (tests/test_sampler.py checks them against vectors recorded from the reference).
 """
-import ctypes as C
 import random
 
 import numpy as np

@@ -1,6 +1,5 @@
 """Host-side issue time vs device time of the row-sharded step at world 1 (where is the sharded path host-bound?)."""
 import os, sys, time
-import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
