@@ -27,7 +27,6 @@ def _first_appearance_host(raw):
 
 def _first_appearance_device(raw):
     """int64 raw ids -> codes via the HIP kernel drx_idmap_build (include/drx.h)."""
-    import ctypes as C
     import torch
     from .. import _lib
     L = _lib.lib()
