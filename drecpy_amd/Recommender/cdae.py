@@ -34,11 +34,70 @@ class CDAE(RecommenderABC):
         self.device_sampler = device_sampler      # sampled mode: draw the triples on the GPU (counter-based stream)
         self.device = device
 
+    # ---- multi-GPU: the same fit() under an initialised torch.distributed process group ------------------------------------
+    def _world(self):
+        """(rank, world) when this fit() is one process of a multi-GPU job, else None.  Sampled mode with the device sampler
+        trains column-sharded (drecpy_amd/dist.py, ColumnShardedCdae): every process is given the SAME dataset and seed,
+        holds K/N columns of every table and trains on the same batches; afterwards every process assembles all K columns
+        and predicts / ranks on its own like a single-GPU model."""
+        import torch.distributed as dist
+        if not (self.mode == 'sampled' and self.device_sampler and dist.is_available() and dist.is_initialized()):
+            return None
+        return (dist.get_rank(), dist.get_world_size()) if dist.get_world_size() > 1 else None
+
+    def fit(self, interaction_dataset, epochs=50, batch_size=32, learning_rate=0.001, neg_ratio=5, reg_rate=0.001,
+            copy_dataset=False, **kwds):
+        out = super().fit(interaction_dataset, epochs=epochs, batch_size=batch_size, learning_rate=learning_rate, neg_ratio=neg_ratio,
+                          reg_rate=reg_rate, copy_dataset=copy_dataset, **kwds)
+        if getattr(self, '_dist_model', None) is not None:      # training is over: every rank keeps the whole model
+            from ..engine import CdaeEngine
+            full = self._dist_model.gather_params_global()
+            self._dist_model = self._pipeline = None
+            self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
+            self._engine.set_params(**full)
+            self._engine.set_history(self._hist_indptr, self._hist_indices)
+        return out
+
+    def _pre_fit_distributed(self, rank, world, learning_rate, neg_ratio, reg_rate, **kwds):
+        import torch.distributed as dist
+        from ..dist import ColumnShardedCdae
+        if kwds.get('epoch_callback_fn') is not None or kwds.get('early_stopping_rule') is not None:
+            raise Exception('epoch callbacks / early stopping need the whole model at every call: not available while it is column-sharded')
+        ds = self.interaction_dataset
+        self._hist_indptr, self._hist_indices = ds.positives_csr(self.interaction_threshold)
+        seed = self.seed if self.seed is not None else 0
+        m = ColumnShardedCdae(self.n_users, self.n_items, self.hidden_factors, rank, world, self.device, self._hist_indptr,
+                              self._hist_indices, seed=seed, lr=learning_rate, reg=reg_rate, optimizer=self.sparse_optimizer,
+                              loss=self._loss_name, q=self.corruption_level, cpu_staging=(dist.get_backend() == 'gloo'))
+        weights = kwds.get('initial_weights')
+        n_params = (2 * self.n_items + self.n_users) * self.hidden_factors
+        if weights is None and n_params <= (1 << 26):                # the single-GPU initialisation, sliced
+            rng = np.random.default_rng(seed)
+
+            def glorot(shape):
+                fi, fo = (shape[0], shape[0]) if len(shape) == 1 else (shape[0], shape[1])
+                lim = np.sqrt(6.0 / (fi + fo))
+                return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            k = self.hidden_factors
+            weights = dict(W=glorot((self.n_items, k)), W_=glorot((k, self.n_items)), V=glorot((self.n_users, k)), b=glorot((k,)),
+                           b_=glorot((self.n_items,)))
+        if weights is not None:
+            m.set_params_global(**weights)
+        self._dist_model, self._engine = m, m.engine
+        self._pipeline = self._pending = None
+        self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
+        self._mask_seed = int(self.seed if self.seed is not None else 0)
+        self._mask_rng = None
+
     # ---- cdae.py:34-45 ---------------------------------------------------------------------------
     def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):
         from .. import _lib
         from ..engine import CdaeEngine
         ds = self.interaction_dataset
+        self._dist_model = None
+        world = self._world()
+        if world is not None:
+            return self._pre_fit_distributed(world[0], world[1], learning_rate, neg_ratio, reg_rate, **kwds)
         self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
         self._pipeline = None
         self._pending = None
@@ -79,9 +138,12 @@ class CDAE(RecommenderABC):
                 from ..engine import SampledPipeline
                 first = 0 if pipe is None else pipe.next
                 ms = self._mask_seed
-                pipe = self._pipeline = SampledPipeline(
-                    self._engine, batch_size, self._sampler.neg_ratio, self.corruption_level,
-                    lambda s: ms * 7919 + first + s + 1, lambda s: ms + 0x9E3779B9 * (first + s + 1), loss=self._loss_name)
+                seeds = (lambda s: ms * 7919 + first + s + 1, lambda s: ms + 0x9E3779B9 * (first + s + 1))
+                if getattr(self, '_dist_model', None) is not None:      # the same seeds on every rank: the same batches
+                    pipe = self._pipeline = self._dist_model.pipeline(batch_size, self._sampler.neg_ratio, *seeds)
+                else:
+                    pipe = self._pipeline = SampledPipeline(self._engine, batch_size, self._sampler.neg_ratio, self.corruption_level,
+                                                            *seeds, loss=self._loss_name)
             return ('device-batch', pipe.next)
         if self.mode == 'sampled' and kwds.get('as_arrays', True):
             return self._sampler.sample_arrays(batch_size)      # (uid, iid, value, is_negative) numpy arrays
@@ -143,7 +205,9 @@ class CDAE(RecommenderABC):
         eng = self._engine
         if self.mode == 'sampled' and self.device_sampler:       # batch drawn and indexed ahead of time on the device
             loss = self._pipeline.run_step(want_loss=want_loss)
-            return float(loss[0].item()) if want_loss else None
+            if not want_loss:
+                return None
+            return float(loss) if isinstance(loss, float) else float(loss[0].item())
         if self.mode == 'reference' and getattr(batch_samples, 'keep', None) is not None:
             uid, keep_off, keep = batch_samples.uid, batch_samples.keep_off, batch_samples.keep      # prepared by _sample_batch
             bt, alive = eng.make_batch(uid, keep_off=keep_off, keep=keep, q=self.corruption_level, n_touch_slots=int(keep_off[-1]))

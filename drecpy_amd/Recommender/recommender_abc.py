@@ -26,7 +26,7 @@ from .loss_tracker import LossTracker
 
 _LOG_FORMAT = '[%(asctime)s] (%(levelname)s) %(name)s: %(message)s'
 _UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', 'epoch_weights', '_pipeline', '_pending',
-              '_host_pool')
+              '_host_pool', '_dist_model')
 
 
 def _make_logger(name, handler):

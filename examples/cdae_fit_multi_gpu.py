@@ -1,0 +1,38 @@
+"""The ordinary CDAE.fit() as a multi-GPU job: start one process per GPU, give every process the SAME dataset and seed; training
+runs column-sharded (every rank K/N columns of every table, same batches, one all-reduce of B floats per step), and when fit()
+returns every rank holds the whole model and can predict / rank on its own.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/cdae_fit_multi_gpu.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from drecpy_amd import synth
+from drecpy_amd.Dataset import InteractionDataset
+from drecpy_amd.Recommender import CDAE
+
+rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
+torch.cuda.set_device(local)
+dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+users = 1_000_000
+_, n_items, mean_deg, min_deg, alpha = synth.SHAPES['synth-10m']
+indptr, indices = synth.synth_history(users, n_items, mean_deg, min_deg, alpha, seed=0, device=f'cuda:{local}', user_hi=users)
+indptr, indices = indptr.cpu().numpy(), indices.cpu().numpy()
+user = np.repeat(np.arange(users, dtype=np.int64), np.diff(indptr))
+ds = InteractionDataset.from_arrays(user, indices.astype(np.int64), np.ones(len(user)))        # identical on every rank
+
+model = CDAE(hidden_factors=128, corruption_level=0.2, mode='sampled', device_sampler=True, seed=10, verbose=False,
+             device=f'cuda:{local}')
+t0 = time.time()
+model.fit(ds, learning_rate=0.05, reg_rate=0.001, epochs=300, batch_size=65536 * world, neg_ratio=5)
+torch.cuda.synchronize()
+if rank == 0:
+    print(f'{world} GPUs: fit (set-up + 300 steps of {65536 * world}) {time.time() - t0:.2f} s; top-5 for user 0:', model.recommend(0, n=5))
+dist.barrier()
+dist.destroy_process_group()

@@ -141,3 +141,45 @@ def test_column_sharded_pipeline_equals_stepping_inline():
         outs.append([t.clone() for t in m.engine.tables()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def _fit_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_gpu_fit import _frame
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    ds = InteractionDataset.read_df(_frame(), verbose=False)
+    model = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False)
+    model.fit(ds, epochs=20, batch_size=384, learning_rate=0.05, reg_rate=1e-3, neg_ratio=5)
+    torch.cuda.synchronize()
+    frame = _frame()
+    torch.save({'params': model._engine.get_params(), 'pred': float(model.predict(frame['user'][0], frame['item'][1])),
+                'rank': model.rank(frame['user'][0], list(frame['item'][:30]), n=5)}, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path):
+    """CDAE.fit(mode='sampled', device_sampler=True) as two processes of one job (column-sharded training, then every rank
+    holds the whole model): parameters, a prediction and a ranking equal the single-process fit with the same seed."""
+    from test_gpu_fit import _frame
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    out = str(tmp_path / 'fit')
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_fit_worker, args=(2, port, out), nprocs=2, join=True)
+    frame = _frame()
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    single = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False)
+    single.fit(ds, epochs=20, batch_size=384, learning_rate=0.05, reg_rate=1e-3, neg_ratio=5)
+    want = single._engine.get_params()
+    want_pred = float(single.predict(frame['user'][0], frame['item'][1]))
+    want_rank = single.rank(frame['user'][0], list(frame['item'][:30]), n=5)
+    for r in range(2):
+        got = torch.load(f'{out}.{r}', weights_only=False)
+        for k in want:
+            np.testing.assert_allclose(got['params'][k], want[k], rtol=0, atol=2e-6, err_msg=k)
+        assert abs(got['pred'] - want_pred) < 1e-6
+        assert [i for _, i in got['rank']] == [i for _, i in want_rank]
