@@ -576,6 +576,33 @@ __global__ __launch_bounds__(kBlock) void k_kshard_fwd(DrxCdaeParams P, DrxHisto
   if (lane == 0) dot_out[b] = d;
 }
 
+// (long histories / small batches: one workgroup per triple, like k_sampled_fwd_bwd_wg)
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_kshard_fwd_wg(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale, uint32_t qthr,
+                                                          float *__restrict__ h_out, float *__restrict__ dot_out) {
+  extern __shared__ __align__(16) float lds[];   // [R, ld]
+  constexpr int R = kBlock / G;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const int b = blockIdx.x;
+  float4 acc[J], h[J], w2[J];
+  DenseAux none{};
+  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0, r, R);
+  store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
+  __syncthreads();
+  if (r != 0) return;
+#pragma unroll
+  for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+  for (int rr = 0; rr < R; ++rr) {
+    float4 v[J];
+    load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
+#pragma unroll
+    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+  }
+  const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
+  store_row<G, J>(h_out, (size_t)b, P.ld, lane, h);
+  if (lane == 0) dot_out[b] = d;
+}
+
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_kshard_rest(DrxCdaeParams P, DrxOptim opt, DrxBatch bt, int loss_kind, SparseBufs S,
                                                         const float *__restrict__ h_in, const float *__restrict__ dot_total) {
@@ -1135,11 +1162,17 @@ int drx_cdae_kshard_forward(const DrxCdaeParams *p, const DrxHistory *hist, cons
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / (1.0f - bt->q);
   const uint32_t qthr = q_threshold(bt->q);
+  const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
+  const bool per_wg = mean_hist > 64 || (bt->B <= 8192 && mean_hist > 16);      // as in step_sparse_impl
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
-    hipLaunchKernelGGL((k_kshard_fwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, scale, qthr, \
-                       h_out, dot_partial);                                                                            \
+    if (per_wg)                                                                                                        \
+      hipLaunchKernelGGL((k_kshard_fwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *hist, *bt, scale, \
+                         qthr, h_out, dot_partial);                                                                    \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_kshard_fwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, scale, qthr, \
+                         h_out, dot_partial);                                                                          \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL

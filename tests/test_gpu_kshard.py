@@ -183,3 +183,29 @@ def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path):
             np.testing.assert_allclose(got['params'][k], want[k], rtol=0, atol=2e-6, err_msg=k)
         assert abs(got['pred'] - want_pred) < 1e-6
         assert [i for _, i in got['rank']] == [i for _, i in want_rank]
+
+
+def test_column_sharded_long_histories_take_the_workgroup_forward():
+    """Mean history of ~60 items, 48 triples: k_kshard_fwd_wg (one workgroup per triple) — against the direct single-GPU step on
+    the same columns, which runs its own workgroup variant."""
+    from oracle import cdae_oracle as co
+    from helpers import synth_history
+    from drecpy_amd.dist import ColumnShardedCdae
+    from drecpy_amd.engine import CdaeEngine
+    rng = np.random.default_rng(9)
+    Ul, Nl, Kl, Bl = 40, 400, 64, 48
+    p = co.init_params(rng, Ul, Nl, Kl, np.float32)
+    indptr, indices = synth_history(rng, Ul, Nl, 60, zipf=1.05)
+    m = ColumnShardedCdae(Ul, Nl, Kl, 0, 1, 'cuda:0', indptr, indices, q=Q)
+    m.set_params_global(**p)
+    e = CdaeEngine(Ul, Nl, Kl); e.set_params(**p); e.set_history(indptr, indices); e.init_optimizer('adagrad', 0.05, 1e-3)
+    for s in range(4):
+        uid, iid, y = rng.integers(0, Ul, size=Bl), rng.integers(0, Nl, size=Bl), (rng.random(Bl) < 0.3).astype(np.float32)
+        bt, alive = m.engine.make_batch(uid, iid, y, q=Q, mask_seed=s)
+        assert bt.n_touch_slots > 16 * Bl
+        m.step(s, bt)
+        bt2, alive2 = e.make_batch(uid, iid, y, q=Q, mask_seed=s)
+        e.step_sparse(s, bt2)
+    torch.cuda.synchronize()
+    for a, b in zip(m.engine.tables(), e.tables()):
+        assert float((a - b).abs().max()) < 1e-6
