@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
     ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'adam', 'rowwise_adagrad'], help='sparse optimizer of the sampled mode (S = 1 / 2 slots per parameter; single-GPU path)')
+    ap.add_argument('--k', type=int, default=0, help='hidden factors (default 128); with --force-columns --k 128/N --batch 65536*N one GPU runs the '
+                                                      'shape of ONE rank of an N-GPU column-sharded job')
     ap.add_argument('--layout', default='columns', choices=['columns', 'rows'],
                     help='multi-GPU layout: columns = every rank all rows x K/N columns, same global batch, one all-reduce of B scalars per step; '
                          'rows = users and item rows sharded by range, rows and gradient rows travel by all-to-all')
@@ -252,7 +254,10 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
 
 
 def main():
+    global K
     args = parse()
+    if args.k:
+        K = args.k
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
