@@ -54,6 +54,7 @@ def parse():
                     help='multi-GPU layout: columns = every rank all rows x K/N columns, same global batch, one all-reduce of B scalars per step; '
                          'rows = users and item rows sharded by range, rows and gradient rows travel by all-to-all')
     ap.add_argument('--force-columns', action='store_true', help='run the column-sharded code path even at 1 GPU')
+    ap.add_argument('--parts-prepare', action='store_true', help='column layout: every rank sorts 1/N of the touch list, one all-gather on a side stream (default: every rank sorts all of it)')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     return ap.parse_args()
 
@@ -193,7 +194,32 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
         _, inv, cnt = torch.unique(col, return_inverse=True, return_counts=True)
         f_solo += float((cnt[inv] == 1).float().mean().item())
     setup_s = time.time() - t_setup
-    pipe = model.pipeline(Bg, NEG_RATIO, lambda s: 5000 + 7919 * s, lambda s: 5000 + 7919 * s)    # same seeds on every rank
+    seed_of = lambda s: 5000 + 7919 * s                                                              # same seeds on every rank
+    emu = int(os.environ.get('DRX_BENCH_EMULATE_PARTS', 0))
+    if args.parts_prepare:
+        model.distributed_prepare = True
+    if emu > 1 and world == 1:
+        # debugging aid (one GPU standing in for one rank of `emu`): the batches cycle, this process sorts only part 0 of every
+        # touch list afresh and takes the other parts, computed once, from a cache; a device copy stands in for the all-gather
+        seed_of = lambda s: 5000 + 7919 * (s % args.n_batches)
+        cache, recv = {}, [None, None]
+
+        def emulated_prepare(s, bt, out):
+            c = s % args.n_batches
+            if c not in cache:
+                cache[c] = torch.cat([eng.prepare_part(bt, r, emu).clone() for r in range(emu)])
+            part = eng.prepare_part(bt, 0, emu, slot=s % 2)
+            n = cache[c].numel()
+            if recv[s % 2] is None or recv[s % 2].numel() < n:
+                recv[s % 2] = torch.empty(int(n * 1.05), dtype=torch.uint8, device=dev)
+            got = recv[s % 2][:n]
+            got.copy_(cache[c])
+            got[:part.numel()].copy_(part)
+            out, model._oflow[s % 2] = eng.prepare_assemble(bt, got, emu, out, model._oflow[s % 2])
+            return out
+        model.distributed_prepare = True
+        model.prepare = emulated_prepare
+    pipe = model.pipeline(Bg, NEG_RATIO, seed_of, seed_of)
     for _ in range(args.warmup):
         pipe.run_step()
     EVERY = max(1, int(os.environ.get('DRX_BENCH_EVENTS_EVERY', 4)))
@@ -241,7 +267,9 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
                           'sole_toucher_rows_per_sample': round(f_solo, 3),
                           'batches': 'fresh device-sampled global batch every step, drawn identically on every rank (sampler two steps ahead)',
                           'sharding': f'columns: every rank holds all rows x {kl} of {K} columns and trains on the whole global batch; '
-                                      f'one all-reduce of {Bg} floats per step'},
+                                      f'one all-reduce of {Bg} floats per step; touch list '
+                                      + ('sorted in parts (1/N per rank) + one all-gather on a side stream' if model.distributed_prepare
+                                         else 'sorted whole on every rank')},
                'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': dom_alg / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': dom_alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                             'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(evs[::EVERY])),

@@ -10,6 +10,8 @@
 #include "drx_common.hpp"
 #include "drx_rows.hpp"
 #include "drx_segreduce.hpp"
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
 
 #ifndef DRX_GATHER_ROWS
 #define DRX_GATHER_ROWS 8
@@ -902,6 +904,167 @@ static int check_batch(const DrxHistory *h, const DrxBatch *bt) {
   return DRX_OK;
 }
 
+// ---- touch list prepared in PARTS (column-sharded multi-GPU: every rank needs the same list of the same global batch) ---------
+// Sorting it on every rank is the one cost of that layout that does not shrink with N (10 M pairs at 8 GPUs: 0.75 ms per step).
+// Any order that keeps equal keys adjacent (and their touches in sample order) serves the segmented reduction, so rank r sorts
+// only the touches whose row it "owns" — row id modulo the number of parts, which spreads rows evenly however ids were assigned — and
+// the global list is the concatenation of the parts in rank order.
+__device__ __forceinline__ int touch_owner(uint32_t key, uint32_t n_items, int parts) {
+  const uint32_t row = key < n_items ? key : key < 2 * n_items ? key - n_items : key - 2 * n_items;
+  return (int)(row % (uint32_t)parts);
+}
+
+// Two passes over the batch (count, then write at the scanned offsets) take the owned touches in sample order straight from the
+// histories: nothing of the size of the whole list is ever written.  WRITE = false: cnt[b] = owned touches of sample b;
+// WRITE = true: cnt[] holds the inclusive scan of those counts.
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_owned_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, int part, int parts,
+                                                          int *__restrict__ cnt, int cap, uint32_t *__restrict__ ck,
+                                                          uint32_t *__restrict__ cv, int32_t *__restrict__ header) {
+  constexpr int G = 16;
+  const int lane = threadIdx.x % G;
+  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (b >= bt.B) return;
+  const int gshift = ((threadIdx.x % 64) / G) * G;            // this group's 16 bits of the wave's ballot
+  const int u = bt.uid[b];
+  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+  const int deg = (int)(e - s);
+  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
+  int run = WRITE ? (b > 0 ? cnt[b - 1] : 0) : 0;
+  for (int j0 = 0; j0 < deg; j0 += G) {
+    const int jj = j0 + lane;
+    bool mine = false;
+    uint32_t key = 0;
+    if (jj < deg) {
+      const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, (uint32_t)jj) >= qthr);
+      key = (uint32_t)H.indices[s + jj];
+      mine = kf && (int)(key % (uint32_t)parts) == part;
+    }
+    const uint32_t m = (uint32_t)(__ballot(mine) >> gshift) & 0xFFFFu;
+    if (WRITE && mine) {
+      const int pos = run + __popc(m & ((1u << lane) - 1u));
+      if (pos < cap) { ck[pos] = key; cv[pos] = (uint32_t)b; }
+    }
+    run += __popc(m);
+  }
+  if (lane == 0) {
+    const uint32_t i = (uint32_t)bt.iid[b];
+    const bool own_o = (int)(i % (uint32_t)parts) == part, own_v = (int)((uint32_t)u % (uint32_t)parts) == part;
+    if (WRITE) {
+      if (own_o) { if (run < cap) { ck[run] = (uint32_t)n_items + i; cv[run] = (uint32_t)b; } ++run; }
+      if (own_v) { if (run < cap) { ck[run] = 2u * (uint32_t)n_items + (uint32_t)u; cv[run] = (uint32_t)b; } ++run; }
+      if (b == bt.B - 1) { header[0] = run < cap ? run : cap; header[2] = run > cap ? 1 : 0; }
+    } else {
+      cnt[b] = run + (own_o ? 1 : 0) + (own_v ? 1 : 0);
+    }
+  }
+}
+
+// A part travels as [header: 4 int32 = touches, runs, overflow, 0 | runs: (key << 32 | first position) per distinct key | the samples
+// of the touches, grouped by key]: 4 bytes per touch instead of 8, which is what the exchange costs.
+__global__ void k_run_flags(const uint32_t *__restrict__ ks, int n, int *__restrict__ flag) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t k = ks[j];
+    flag[j] = (k != DRX_KEY_NONE && (j == 0 || ks[j - 1] != k)) ? 1 : 0;
+  }
+}
+
+__global__ void k_take_runs(const uint32_t *__restrict__ ks, const int *__restrict__ scan, int n, int rcap,
+                            unsigned long long *__restrict__ runs, int32_t *__restrict__ header) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int incl = scan[j], prev = j > 0 ? scan[j - 1] : 0;
+    if (incl != prev && incl <= rcap) runs[incl - 1] = ((unsigned long long)ks[j] << 32) | (uint32_t)j;
+    if (j == n - 1) {
+      header[1] = incl < rcap ? incl : rcap;
+      if (incl > rcap) header[2] = 1;               // cannot happen (rcap bounds the distinct keys of a part); checked all the same
+      header[3] = 0;
+    }
+  }
+}
+
+struct PartView {               // one part inside the exchanged buffer
+  const int32_t *header;
+  const unsigned long long *runs;
+  const uint32_t *vals;
+};
+
+__device__ __forceinline__ PartView part_view(const char *all, size_t part_bytes, size_t runs_off, size_t vals_off, int r) {
+  const char *b = all + (size_t)r * part_bytes;
+  return PartView{(const int32_t *)b, (const unsigned long long *)(b + runs_off), (const uint32_t *)(b + vals_off)};
+}
+
+// parts in rank order -> keys_s / vals_s of the whole batch, padded with DRX_KEY_NONE.  One position per thread: neighbouring
+// positions walk the same path through a part's runs, so the binary search costs a cache line or two per step and wave.
+__global__ void k_assemble_parts(const char *__restrict__ all, size_t part_bytes, size_t runs_off, size_t vals_off, int parts, int T,
+                                 uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s, int32_t *__restrict__ flags_out) {
+  __shared__ int off[DRX_MAX_WORLD + 1];
+  if (threadIdx.x == 0) {
+    int run = 0, bad = 0;
+    for (int r = 0; r < parts; ++r) {
+      const int32_t *h = part_view(all, part_bytes, runs_off, vals_off, r).header;
+      off[r] = run; run += h[0]; bad |= h[2];
+    }
+    off[parts] = run;
+    if (blockIdx.x == 0) flags_out[0] = (bad || run > T) ? 1 : 0;
+  }
+  __syncthreads();
+  const int total = off[parts] < T ? off[parts] : T;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
+    if (j >= total) { keys_s[j] = DRX_KEY_NONE; vals_s[j] = 0; continue; }
+    int r = 0;
+    while (r + 1 < parts && j >= off[r + 1]) ++r;
+    const PartView pv = part_view(all, part_bytes, runs_off, vals_off, r);
+    const uint32_t local = (uint32_t)(j - off[r]);
+    int lo = 0, hi = pv.header[1] - 1;               // last run starting at or before `local`
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((uint32_t)pv.runs[mid] <= local) lo = mid; else hi = mid - 1;
+    }
+    keys_s[j] = (uint32_t)(pv.runs[lo] >> 32);
+    vals_s[j] = pv.vals[local];
+  }
+}
+
+struct PartOut {                 // layout of one exchanged part
+  size_t runs_off, vals_off, bytes;
+  int cap, rcap;
+};
+
+static PartOut part_out_layout(const DrxCdaeParams &P, int B, int n_touch_slots, int parts) {
+  PartOut o{};
+  const long long T = (long long)n_touch_slots + 2ll * B;
+  o.cap = (int)(T / parts + T / (4 * parts) + 16384);         // 1.25 x the even share + slack (ids are spread evenly)
+  if (parts == 1 || o.cap > T) o.cap = (int)T;
+  o.rcap = 2 * ((P.n_items + parts - 1) / parts + 1) + (P.n_users + parts - 1) / parts + 1;   // distinct rows a part can own
+  o.runs_off = 256;
+  o.vals_off = align_up(o.runs_off + (size_t)o.rcap * 8, 256);
+  o.bytes = align_up(o.vals_off + (size_t)o.cap * 4, 256);
+  return o;
+}
+
+struct PartBufs {
+  PrepBufs R;                    // full touch arrays (keys / vals) + sort temp of the full size
+  int *flag;
+  void *scan_temp;
+  size_t scan_bytes;
+  uint32_t *ck, *cv, *ck_s;
+  PartOut out;
+};
+
+static PartBufs part_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots, int parts) {
+  PartBufs L{};
+  L.R = prep_layout(cv, P, B, n_touch_slots);
+  L.out = part_out_layout(P, B, n_touch_slots, parts);
+  L.flag = cv.take<int>(L.R.T);                 // [B] counts of the samples, later [cap] run flags
+  L.scan_bytes = 0;
+  int *d = nullptr;
+  (void)rocprim::inclusive_scan(nullptr, L.scan_bytes, d, d, (size_t)(L.R.T > 0 ? L.R.T : 1), rocprim::plus<int>(), (hipStream_t)0);
+  L.scan_temp = cv.take<char>(L.scan_bytes);
+  L.ck = cv.take<uint32_t>(L.out.cap); L.cv = cv.take<uint32_t>(L.out.cap);
+  L.ck_s = cv.take<uint32_t>(L.out.cap);
+  return L;
+}
+
 }  // namespace drx
 
 using namespace drx;
@@ -1141,6 +1304,79 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream);
   if (rc) return rc;
   rc = mark_solo(p, bt, R, (hipStream_t)stream);
+  if (rc) return rc;
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+size_t drx_cdae_prep_part_out_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t parts) {
+  if (!p || B < 1 || n_touch_slots < 0 || parts < 1 || parts > DRX_MAX_WORLD) return 0;
+  return part_out_layout(*p, B, n_touch_slots, parts).bytes;
+}
+
+int drx_cdae_prep_part_layout(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t parts, size_t *out4) {
+  if (!p || !out4 || B < 1 || n_touch_slots < 0 || parts < 1 || parts > DRX_MAX_WORLD) return DRX_EINVAL;
+  const PartOut o = part_out_layout(*p, B, n_touch_slots, parts);
+  out4[0] = o.runs_off; out4[1] = o.vals_off; out4[2] = (size_t)o.rcap; out4[3] = (size_t)o.cap;
+  return DRX_OK;
+}
+
+size_t drx_cdae_prep_part_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t parts) {
+  if (!p || B < 1 || n_touch_slots < 0 || parts < 1 || parts > DRX_MAX_WORLD) return 0;
+  Carver c(nullptr, 0);
+  (void)part_layout(c, *p, B, n_touch_slots, parts);
+  return align_up(c.off, 256) + 256;
+}
+
+int drx_cdae_sparse_prepare_part(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, int32_t part, int32_t parts,
+                                 void *part_out, size_t part_out_bytes, void *scratch, size_t scratch_bytes, void *stream) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  rc = check_batch(hist, bt);
+  if (rc || !bt->iid || !bt->keep_off || !part_out || !scratch || parts < 1 || parts > DRX_MAX_WORLD || part < 0 || part >= parts)
+    return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(scratch, scratch_bytes);
+  PartBufs L = part_layout(cv, *p, bt->B, bt->n_touch_slots, parts);
+  if (!cv.ok() || part_out_bytes < L.out.bytes) return DRX_ESCRATCH;
+  const int T = L.R.T, cap = L.out.cap;
+  int32_t *header = (int32_t *)part_out;
+  unsigned long long *runs = (unsigned long long *)((char *)part_out + L.out.runs_off);
+  uint32_t *vals_out = (uint32_t *)((char *)part_out + L.out.vals_off);
+  const int gpb = kBlock / 16;
+  const dim3 grid((bt->B + gpb - 1) / gpb);
+  const uint32_t qthr = q_threshold(bt->q);
+  hipLaunchKernelGGL(k_owned_touches<false>, grid, dim3(kBlock), 0, st, p->n_items, *hist, *bt, qthr, part, parts, L.flag, cap, L.ck, L.cv,
+                     header);
+  hipError_t e = rocprim::inclusive_scan(L.scan_temp, L.scan_bytes, L.flag, L.flag, (size_t)bt->B, rocprim::plus<int>(), st);
+  if (e != hipSuccess) return (int)e;
+  DRX_HIP(hipMemsetAsync(L.ck, 0xFF, (size_t)cap * sizeof(uint32_t), st));
+  DRX_HIP(hipMemsetAsync(L.cv, 0, (size_t)cap * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_owned_touches<true>, grid, dim3(kBlock), 0, st, p->n_items, *hist, *bt, qthr, part, parts, L.flag, cap, L.ck, L.cv,
+                     header);
+  rc = sort_pairs(L.R.sort_temp, L.R.sort_bytes, L.ck, L.ck_s, L.cv, vals_out, (size_t)cap, L.R.bits, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_run_flags, dim3(1024), dim3(256), 0, st, L.ck_s, cap, L.flag);
+  e = rocprim::inclusive_scan(L.scan_temp, L.scan_bytes, L.flag, L.flag, (size_t)cap, rocprim::plus<int>(), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_take_runs, dim3(1024), dim3(256), 0, st, L.ck_s, L.flag, cap, L.out.rcap, runs, header);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt, const void *all_parts, int32_t parts, void *prepared,
+                                     size_t prepared_bytes, int32_t *overflow_out, void *stream) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!bt || bt->B < 1 || !all_parts || !prepared || !overflow_out || parts < 1 || parts > DRX_MAX_WORLD) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  Carver cp(prepared, prepared_bytes);
+  PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
+  if (!cp.ok()) return DRX_ESCRATCH;
+  const PartOut o = part_out_layout(*p, bt->B, bt->n_touch_slots, parts);
+  hipLaunchKernelGGL(k_assemble_parts, dim3(2048), dim3(256), 0, st, (const char *)all_parts, o.bytes, o.runs_off, o.vals_off, parts, R.T,
+                     R.keys_s, R.vals_s, overflow_out);
+  rc = mark_solo(p, bt, R, st);
   if (rc) return rc;
   DRX_LAUNCH_CHECK();
   return DRX_OK;

@@ -521,8 +521,15 @@ class ColumnShardedCdae:
     order); histories (the positives CSR of ALL users) are replicated."""
 
     def __init__(self, n_users, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
-                 optimizer='adagrad', group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False, engine=None):
+                 optimizer='adagrad', group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False, engine=None,
+                 distributed_prepare=None):
         self.rank, self.world, self.group = rank, world, group
+        # touch lists built in parts (prepare()) instead of whole on every rank.  Off by default: with one GPU standing in for a
+        # rank of 8 (bench.py, DRX_BENCH_EMULATE_PARTS) the extra passes cost what the smaller sort saves (DESIGN.md section 6.1)
+        self.distributed_prepare = bool(distributed_prepare)
+        self._all, self._oflow, self._oflow_ev = [None, None], [None, None], [None, None]
+        self._oflow_host = None
+        self._prep_group = None
         self.cpu_staging = cpu_staging
         self.collectives = world > 1 or force_collectives
         self.k = k
@@ -580,10 +587,52 @@ class ColumnShardedCdae:
         out = e.step_sparse(step, bt, self.loss, want_loss=want_loss, events=events, prepared=prepared, kshard=(h, dot))
         return float(out[0]) if want_loss else None
 
+    def prepare(self, s, bt, out=None):
+        """The sorted touch list of the (global) batch `bt`, built in PARTS: this rank sorts the touches of the rows it owns
+        (row id % world == rank), the parts travel in one all-gather on a communicator of their own (so that this long
+        exchange never queues in front of a step's all-reduce) and every rank assembles the same list.  Runs on the CURRENT
+        stream (the pipeline's side stream).  A part that does not fit its fixed capacity is reported two calls later."""
+        e = self.engine
+        k = s % 2
+        if self._oflow_host is None:
+            self._oflow_host = [torch.zeros(1, dtype=torch.int32, pin_memory=True) for _ in range(2)]
+        self._check_overflow(k)
+        part = e.prepare_part(bt, self.rank, self.world, slot=k)
+        if self.collectives:
+            need = part.numel() * self.world
+            if self._all[k] is None or self._all[k].numel() < need:
+                self._all[k] = None
+                self._all[k] = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=part.device)
+            allp = self._all[k][:need]
+            if self._prep_group is None:
+                self._prep_group = dist.new_group(ranks=dist.get_process_group_ranks(self.group) if self.group is not None else None)
+            if self.cpu_staging:
+                hp = part.cpu()
+                ha = torch.empty(part.numel() * self.world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(ha, hp, group=self._prep_group)
+                allp.copy_(ha)
+            else:
+                dist.all_gather_into_tensor(allp, part, group=self._prep_group)
+        else:
+            allp = part
+        out, self._oflow[k] = e.prepare_assemble(bt, allp, self.world, out, self._oflow[k])
+        self._oflow_host[k].copy_(self._oflow[k], non_blocking=True)
+        self._oflow_ev[k] = torch.cuda.Event()
+        self._oflow_ev[k].record(torch.cuda.current_stream(e.device))
+        return out
+
+    def _check_overflow(self, k):
+        if self._oflow_ev[k] is not None:
+            self._oflow_ev[k].synchronize()                  # recorded two preparations ago
+            if int(self._oflow_host[k][0]):
+                raise RuntimeError('a part of the touch list exceeded its capacity (row popularity too uneven for parts of 1.25x the '
+                                   'even share): train without distributed_prepare')
+
     def pipeline(self, batch_size, neg_ratio, sample_seed_of, mask_seed_of):
         """SampledPipeline over this rank: the SAME seeds on every rank give every rank the same global batch."""
         from .engine import SampledPipeline
         return SampledPipeline(self.engine, batch_size, neg_ratio, self.q, sample_seed_of, mask_seed_of, n_items=self.engine.n_items,
                                loss=self.loss, step_fn=lambda s, bt, prep, events, want_loss: self.step(s, bt, prepared=prep, events=events,
-                                                                                                         want_loss=want_loss))
+                                                                                                         want_loss=want_loss),
+                               prepare_fn=self.prepare if self.distributed_prepare else None)
 

@@ -226,6 +226,41 @@ class CdaeEngine:
                                             stream_ptr(self.device)), 'drx_cdae_sparse_prepare')
         return out
 
+    def prepare_part(self, bt, part, parts, slot=None):
+        """This rank's share of a batch's touch list (drx_cdae_sparse_prepare_part) on the CURRENT stream: a byte tensor that
+        the caller gathers from all ranks and hands to prepare_assemble().  slot: reuse the (grow-only) buffer of that name —
+        the result is then a view of it, valid until the slot's next use."""
+        P = C.byref(self._params)
+        nb = int(lib().drx_cdae_prep_part_out_bytes(P, bt.B, bt.n_touch_slots, parts))
+        if slot is None:
+            out = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        else:
+            bufs = self.__dict__.setdefault('_part_bufs', {})
+            if slot not in bufs or bufs[slot].numel() < nb:
+                bufs[slot] = None
+                bufs[slot] = torch.empty(int(nb * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+            out = bufs[slot][:nb]
+        need = lib().drx_cdae_prep_part_bytes(P, bt.B, bt.n_touch_slots, parts)
+        if getattr(self, '_pscratch', None) is None or self._pscratch.numel() < need:
+            self._pscratch = None
+            self._pscratch = torch.empty(int(need * 1.1) + 1024, dtype=torch.uint8, device=self.device)
+        check(lib().drx_cdae_sparse_prepare_part(P, C.byref(self._hist), C.byref(bt), part, parts, ptr(out), out.numel(),
+                                                 ptr(self._pscratch), self._pscratch.numel(), stream_ptr(self.device)),
+              'drx_cdae_sparse_prepare_part')
+        return out
+
+    def prepare_assemble(self, bt, all_parts, parts, out=None, overflow=None):
+        """The parts of all ranks (rank order, contiguous) -> a prepared buffer like prepare_sparse()'s.  Returns (buffer,
+        overflow flag tensor [1] int32 on the device: 1 = a part did not fit, the list is incomplete)."""
+        need = lib().drx_cdae_prep_bytes(C.byref(self._params), bt.B, bt.n_touch_slots)
+        if out is None or out.numel() < need:
+            out = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        if overflow is None:
+            overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(lib().drx_cdae_sparse_prepare_assemble(C.byref(self._params), C.byref(bt), ptr(all_parts), parts, ptr(out), out.numel(),
+                                                     ptr(overflow), stream_ptr(self.device)), 'drx_cdae_sparse_prepare_assemble')
+        return out, overflow
+
     def kshard_forward(self, bt):
         """Forward half of the column-sharded step on this engine's columns: (h [B, ld], partial dot products [B])."""
         h = torch.empty(bt.B, self.ld, dtype=torch.float32, device=self.device)
@@ -363,8 +398,11 @@ class SampledPipeline:
 
     sample_seed_of(s) / mask_seed_of(s): seeds of step s's triple draw and of its corruption mask."""
 
-    def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None):
+    def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None,
+                 prepare_fn=None):
         self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
+        # prepare_fn(s, bt, out) -> prepared buffer, called with the side stream current (default: eng.prepare_sparse)
+        self.prepare_fn = prepare_fn
         # step_fn(s, bt, prepared, events, want_loss): what trains on a prepared batch (default: this engine's sparse step;
         # dist.ColumnShardedCdae.step for the column-sharded multi-GPU layout)
         self.step_fn = step_fn
@@ -411,7 +449,10 @@ class SampledPipeline:
         bt = self.batch_of(s)
         self.side.wait_event(self.step_done[s % 2])          # the buffer's previous user (step s-2) has finished
         with torch.cuda.stream(self.side):
-            self.prep[s % 2] = self.eng.prepare_sparse(bt, self.prep[s % 2])
+            if self.prepare_fn is not None:
+                self.prep[s % 2] = self.prepare_fn(s, bt, self.prep[s % 2])
+            else:
+                self.prep[s % 2] = self.eng.prepare_sparse(bt, self.prep[s % 2])
             self.prep_done[s % 2].record(self.side)
 
     def run_step(self, events=None, want_loss=False):

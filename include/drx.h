@@ -170,6 +170,25 @@ int drx_cdae_kshard_step(const DrxCdaeParams *p, const DrxOptim *opt, const DrxH
                          const float *h, const float *dot_total, const void *prepared, size_t prepared_bytes, void *scratch,
                          size_t scratch_bytes, float *loss_out, void *const *events, void *stream);
 
+/* Touch list prepared in PARTS (column-sharded layout: all ranks need the same list of the same batch, and sorting it on every
+ * rank is the one cost that does not shrink with N).  Part r of `parts` = the touches of the rows with id % parts == r (item id for W
+ * and W2T keys, user id for V keys), taken in sample order and sorted by key; the list of the batch is the
+ * concatenation of the parts in order (equal keys adjacent, the touches of a key in sample order: all the segmented reduction needs).
+ *   drx_cdae_sparse_prepare_part     -> part_out [drx_cdae_prep_part_out_bytes]: 4 int32 (touches, distinct keys, overflow, 0), then per
+ *                                       distinct key (key << 32 | first position), then the samples of the touches — 4 bytes a touch
+ *   (the host gathers the parts of all ranks, in rank order, into all_parts [parts * part_out_bytes])
+ *   drx_cdae_sparse_prepare_assemble -> a `prepared` buffer like drx_cdae_sparse_prepare's; overflow_out[0] (device) = 1 when a part
+ *                                       did not fit its fixed capacity (1.25 x the even share): that list is incomplete and the
+ *                                       caller must prepare the batch with drx_cdae_sparse_prepare instead. */
+size_t drx_cdae_prep_part_out_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t parts);
+/* out4 = byte offset of the runs, byte offset of the samples, capacity in runs, capacity in touches (of one part) */
+int drx_cdae_prep_part_layout(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t parts, size_t *out4);
+size_t drx_cdae_prep_part_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t parts);
+int drx_cdae_sparse_prepare_part(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, int32_t part, int32_t parts,
+                                 void *part_out, size_t part_out_bytes, void *scratch, size_t scratch_bytes, void *stream);
+int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt, const void *all_parts, int32_t parts, void *prepared,
+                                     size_t prepared_bytes, int32_t *overflow_out, void *stream);
+
 /* ---- row-sharded multi-GPU step (no reference equivalent — DRecPy is single-process) ---------------
  * Per-rank, collective-free pieces of the sampled step; the host (drecpy_amd/dist.py) runs the RCCL all-to-all
  * exchanges between them.  Users (V, histories, samples) are sharded by uid range; item rows (W, W2T, b2) by item range

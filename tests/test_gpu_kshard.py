@@ -47,7 +47,7 @@ def _oracle(K, opt):
     return p, losses
 
 
-def _run_rank(rank, world, K, opt, staged, force=False, prepared=True):
+def _run_rank(rank, world, K, opt, staged, force=False, prepared=True, parts=False):
     from drecpy_amd.dist import ColumnShardedCdae
     p, indptr, indices, batches = _problem(K)
     m = ColumnShardedCdae(U, N, K, rank, world, 'cuda:0', indptr, indices, q=Q, optimizer=opt, lr=0.05 if opt == 'adagrad' else 1e-3,
@@ -56,7 +56,10 @@ def _run_rank(rank, world, K, opt, staged, force=False, prepared=True):
     losses = []
     for s, (uid, iid, y, seed) in enumerate(batches):                      # the SAME batch on every rank
         bt, alive = m.engine.make_batch(uid, iid, y, q=Q, mask_seed=seed)
-        prep = m.engine.prepare_sparse(bt) if (prepared and s % 2) else None
+        if parts:                                                           # touch list built in parts and gathered
+            prep = m.prepare(s, bt)
+        else:
+            prep = m.engine.prepare_sparse(bt) if (prepared and s % 2) else None
         losses.append(m.step(s, bt, prepared=prep, want_loss=True))
     torch.cuda.synchronize()
     if world > 1:                                                           # every rank can assemble the whole model
@@ -83,11 +86,11 @@ def test_column_sharded_world1_matches_oracle(K, opt):
     _check(K, opt, [_run_rank(0, 1, K, opt, False)])
 
 
-def _worker(rank, world, port, out, K, opt):
+def _worker(rank, world, port, out, K, opt, parts=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _run_rank(rank, world, K, opt, True)
+    res = _run_rank(rank, world, K, opt, True, parts=parts)
     torch.save(res, f'{out}.{rank}')
     dist.barrier()
     dist.destroy_process_group()
@@ -102,12 +105,12 @@ def test_column_sharded_processes_on_one_gpu_match_oracle(tmp_path, world, K, op
     _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
 
 
-def _worker_rccl(rank, port, out, K, opt):
+def _worker_rccl(rank, port, out, K, opt, parts=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    res = _run_rank(0, 1, K, opt, False, force=True)
+    res = _run_rank(0, 1, K, opt, False, force=True, parts=parts)
     torch.save(res, f'{out}.0')
     dist.barrier()
     dist.destroy_process_group()
@@ -120,13 +123,97 @@ def test_column_sharded_step_through_rccl_world1(tmp_path):
     _check(128, 'adagrad', [torch.load(f'{out}.0', weights_only=False)])
 
 
-def test_column_sharded_pipeline_equals_stepping_inline():
+@pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adam')])
+def test_touch_list_built_in_parts_across_processes(tmp_path, world, K, opt):
+    """ColumnShardedCdae.prepare: every rank sorts the touches of the rows it owns, one all-gather, every rank assembles."""
+    out = str(tmp_path / 'kp')
+    port = 28800 + (os.getpid() % 200) + 300 * world + K
+    mp.spawn(_worker, args=(world, port, out, K, opt, True), nprocs=world, join=True)
+    _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
+
+
+def test_touch_list_built_in_parts_through_rccl_world1(tmp_path):
+    out = str(tmp_path / 'kpr')
+    port = 28300 + (os.getpid() % 200)
+    mp.spawn(_worker_rccl, args=(port, out, 128, 'adagrad', True), nprocs=1, join=True)
+    _check(128, 'adagrad', [torch.load(f'{out}.0', weights_only=False)])
+
+
+@pytest.mark.parametrize('parts', [1, 2, 3, 8, 64])
+def test_parts_of_a_touch_list_hold_every_touch_once(parts):
+    """The exchanged format of include/drx.h (header | runs | samples), decoded on the host: the parts partition the touches
+    of the batch by row id % parts, keys ascend inside a part and the samples of a key keep their order; the list
+    assembled from them trains to the same result as the locally sorted one."""
+    import ctypes as C
+    from drecpy_amd import _lib
+    from drecpy_amd.engine import CdaeEngine
+    from oracle import cdae_oracle as co
+    p, indptr, indices, batches = _problem(32)
+    uid, iid, y, seed = batches[0]
+    e = CdaeEngine(U, N, 32); e.set_params(**p); e.set_history(indptr, indices); e.init_optimizer('adagrad', 0.05, 1e-3)
+    bt, alive = e.make_batch(uid, iid, y, q=Q, mask_seed=seed)
+    want = []                                                               # (key, sample) of every touch
+    for b, u in enumerate(uid):
+        row = indices[indptr[u]:indptr[u + 1]]
+        kf = co.drx_hash_u32(seed, np.full(len(row), b), np.arange(len(row))) >= co.q_threshold(Q)
+        want += [(int(n), b) for n in row[kf]] + [(N + int(iid[b]), b), (2 * N + int(u), b)]
+    lay = (C.c_size_t * 4)()
+    assert _lib.lib().drx_cdae_prep_part_layout(C.byref(e._params), bt.B, bt.n_touch_slots, parts, lay) == 0
+    runs_off, vals_off, rcap, cap = [int(v) for v in lay]
+    got, blobs = [], []
+    for r in range(parts):
+        blob = e.prepare_part(bt, r, parts).clone()
+        blobs.append(blob)
+        raw = blob.cpu().numpy()
+        n_touch, n_runs, overflow, _ = raw[:16].view(np.int32)
+        assert overflow == 0 and n_touch <= cap and n_runs <= rcap
+        runs = raw[runs_off:runs_off + 8 * n_runs].view(np.uint64)
+        vals = raw[vals_off:vals_off + 4 * n_touch].view(np.uint32)
+        keys, starts = (runs >> np.uint64(32)).astype(np.int64), (runs & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        assert np.all(np.diff(keys) > 0) and (n_runs == 0 or starts[0] == 0) and np.all(np.diff(starts) > 0)
+        ends = np.append(starts[1:], n_touch)
+        for k, a, z in zip(keys, starts, ends):
+            row = k if k < N else k - N if k < 2 * N else k - 2 * N
+            assert row % parts == r
+            assert np.all(np.diff(vals[a:z].astype(np.int64)) >= 0)         # sample order kept inside a key
+            got += [(int(k), int(v)) for v in vals[a:z]]
+    assert sorted(got) == sorted(want)
+    prep, overflow = e.prepare_assemble(bt, torch.cat(blobs), parts)
+    e.step_sparse(0, bt, prepared=prep)
+    e2 = CdaeEngine(U, N, 32); e2.set_params(**p); e2.set_history(indptr, indices); e2.init_optimizer('adagrad', 0.05, 1e-3)
+    bt2, alive2 = e2.make_batch(uid, iid, y, q=Q, mask_seed=seed)
+    e2.step_sparse(0, bt2, prepared=e2.prepare_sparse(bt2))
+    torch.cuda.synchronize()
+    assert int(overflow[0]) == 0
+    for a, b in zip(e.tables(), e2.tables()):
+        assert float((a - b).abs().max()) < 1e-6
+
+
+def test_a_part_that_does_not_fit_is_reported():
+    """All touches on one row of one part: 1.25 x the even share + 16384 cannot hold them, the flag must say so."""
+    from drecpy_amd.engine import CdaeEngine
+    rng = np.random.default_rng(1)
+    Ul, Nl, Bl = 8, 16, 60000
+    indptr = np.arange(Ul + 1, dtype=np.int64)
+    indices = np.zeros(Ul, np.int64)
+    e = CdaeEngine(Ul, Nl, 8); e.init_glorot(1); e.set_history(indptr, indices); e.init_optimizer('adagrad', 0.05, 1e-3)
+    uid, iid, y = np.zeros(Bl, np.int64), np.zeros(Bl, np.int64), np.ones(Bl, np.float32)     # every touch on row 0 of W, W2T, V
+    bt, alive = e.make_batch(uid, iid, y, q=0.0, mask_seed=0)
+    blobs = [e.prepare_part(bt, r, 4).clone() for r in range(4)]
+    prep, overflow = e.prepare_assemble(bt, torch.cat(blobs), 4)
+    torch.cuda.synchronize()
+    assert int(overflow[0]) == 1
+    assert int(blobs[0].cpu().numpy()[:16].view(np.int32)[2]) == 1
+
+
+@pytest.mark.parametrize('parts_prep', [False, True])
+def test_column_sharded_pipeline_equals_stepping_inline(parts_prep):
     """ColumnShardedCdae.pipeline (device sampler two batches ahead, touch list one ahead) vs the same seeds stepped inline."""
     from drecpy_amd.dist import ColumnShardedCdae
     p, indptr, indices, _ = _problem(64)
     outs = []
     for piped in (True, False):
-        m = ColumnShardedCdae(U, N, 64, 0, 1, 'cuda:0', indptr, indices, q=Q)
+        m = ColumnShardedCdae(U, N, 64, 0, 1, 'cuda:0', indptr, indices, q=Q, distributed_prepare=parts_prep)
         m.set_params_global(**p)
         if piped:
             pipe = m.pipeline(512, 5, lambda s: 77 + s, lambda s: 1000 + s)
