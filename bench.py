@@ -54,7 +54,8 @@ def parse():
                     help='multi-GPU layout: columns = every rank all rows x K/N columns, same global batch, one all-reduce of B scalars per step; '
                          'rows = users and item rows sharded by range, rows and gradient rows travel by all-to-all')
     ap.add_argument('--force-columns', action='store_true', help='run the column-sharded code path even at 1 GPU')
-    ap.add_argument('--parts-prepare', action='store_true', help='column layout: every rank sorts 1/N of the touch list, one all-gather on a side stream (default: every rank sorts all of it)')
+    ap.add_argument('--prepare', default='turns', choices=['local', 'turns', 'parts'],
+                    help='column layout, who sorts the touch list of a step: every rank all of it (local), rank s %% N for all (turns, default), every rank 1/N of it (parts)')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     return ap.parse_args()
 
@@ -195,16 +196,25 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
         f_solo += float((cnt[inv] == 1).float().mean().item())
     setup_s = time.time() - t_setup
     seed_of = lambda s: 5000 + 7919 * s                                                              # same seeds on every rank
-    emu = int(os.environ.get('DRX_BENCH_EMULATE_PARTS', 0))
-    if args.parts_prepare:
-        model.distributed_prepare = True
-    if emu > 1 and world == 1:
-        # debugging aid (one GPU standing in for one rank of `emu`): the batches cycle, this process sorts only part 0 of every
-        # touch list afresh and takes the other parts, computed once, from a cache; a device copy stands in for the all-gather
+    emu = int(os.environ.get('DRX_BENCH_EMULATE_RANKS', 0))
+    if emu > 1 and world == 1 and args.prepare != 'local':
+        # debugging aid (one GPU standing in for one rank of `emu`): the batches cycle and what the other ranks would send comes
+        # from a cache filled at the first encounter; a device copy stands in for the broadcast / all-gather
         seed_of = lambda s: 5000 + 7919 * (s % args.n_batches)
         cache, recv = {}, [None, None]
 
-        def emulated_prepare(s, bt, out):
+        def emulated_turns(s, bt, out):
+            c = s % args.n_batches
+            if c not in cache:
+                cache[c] = eng.prepare_sparse(bt).clone()
+            if s % emu == 0:
+                return eng.prepare_sparse(bt, out)
+            out = eng.prep_buffer(bt, out)
+            n = eng.prep_result_bytes(bt)
+            out[:n].copy_(cache[c][:n])
+            return out
+
+        def emulated_parts(s, bt, out):
             c = s % args.n_batches
             if c not in cache:
                 cache[c] = torch.cat([eng.prepare_part(bt, r, emu).clone() for r in range(emu)])
@@ -217,8 +227,10 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
             got[:part.numel()].copy_(part)
             out, model._oflow[s % 2] = eng.prepare_assemble(bt, got, emu, out, model._oflow[s % 2])
             return out
-        model.distributed_prepare = True
-        model.prepare = emulated_prepare
+        model.prepare_mode = args.prepare
+        model.prepare, model.prepare_in_turns = emulated_parts, emulated_turns
+    elif world > 1:
+        model.prepare_mode = args.prepare
     pipe = model.pipeline(Bg, NEG_RATIO, seed_of, seed_of)
     for _ in range(args.warmup):
         pipe.run_step()
@@ -268,8 +280,8 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
                           'batches': 'fresh device-sampled global batch every step, drawn identically on every rank (sampler two steps ahead)',
                           'sharding': f'columns: every rank holds all rows x {kl} of {K} columns and trains on the whole global batch; '
                                       f'one all-reduce of {Bg} floats per step; touch list '
-                                      + ('sorted in parts (1/N per rank) + one all-gather on a side stream' if model.distributed_prepare
-                                         else 'sorted whole on every rank')},
+                                      + {'local': 'sorted whole on every rank', 'turns': 'of step s sorted by rank s % N and broadcast on a side stream',
+                                         'parts': 'sorted in parts (1/N per rank) + one all-gather on a side stream'}[model.prepare_mode]},
                'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': dom_alg / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': dom_alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                             'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(evs[::EVERY])),

@@ -153,6 +153,7 @@ SIGNATURES = {
     'drx_cdae_kshard_step': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch), C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    'drx_cdae_prep_result_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32]),
     'drx_cdae_prep_part_out_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32, C.c_int32]),
     'drx_cdae_prep_part_layout': (C.c_int, [C.POINTER(CdaeParams), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     'drx_cdae_prep_part_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32, C.c_int32]),

@@ -851,6 +851,7 @@ struct PrepBufs {
   void *sort_temp;
   size_t sort_bytes;
   uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo)
+  size_t result_bytes;
   int T, bits;
 };
 
@@ -858,14 +859,17 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   PrepBufs R{};
   R.T = n_touch_slots + 2 * B;
   R.bits = bits_for((uint64_t)2 * P.n_items + P.n_users + 1);
+  // the RESULT first and contiguous (drx_cdae_prep_result_bytes: what a step reads, and all that has to travel when one rank
+  // prepares a list for the others), then what only the preparation itself needs
   R.keys_s = cv.take<uint32_t>(R.T);
   R.vals_s = cv.take<uint32_t>(R.T);
+  R.solo_v = cv.take<uint8_t>((size_t)2 * B);
+  R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
+  R.result_bytes = align_up(cv.off, 256);
   R.keys = cv.take<uint32_t>(R.T);
   R.vals = cv.take<uint32_t>(R.T);
   R.sort_bytes = sort_pairs_temp_bytes(R.T, R.bits);
   R.sort_temp = cv.take<char>(R.sort_bytes);
-  R.solo_v = cv.take<uint8_t>((size_t)2 * B);
-  R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
   return R;
 }
 
@@ -1307,6 +1311,12 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   if (rc) return rc;
   DRX_LAUNCH_CHECK();
   return DRX_OK;
+}
+
+size_t drx_cdae_prep_result_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots) {
+  if (!p || B < 1 || n_touch_slots < 0) return 0;
+  Carver c(nullptr, 0);
+  return prep_layout(c, *p, B, n_touch_slots).result_bytes;
 }
 
 size_t drx_cdae_prep_part_out_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots, int32_t parts) {

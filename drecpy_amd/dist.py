@@ -520,13 +520,17 @@ class ColumnShardedCdae:
     The result equals the single-process step on the global batch with all K columns (the dot product is summed in rank
     order); histories (the positives CSR of ALL users) are replicated."""
 
+    TURNS_AHEAD = 3       # prepare='turns': a list is started three steps before its step (a sort + a broadcast take about two)
+
     def __init__(self, n_users, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
                  optimizer='adagrad', group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False, engine=None,
-                 distributed_prepare=None):
+                 prepare='local'):
         self.rank, self.world, self.group = rank, world, group
-        # touch lists built in parts (prepare()) instead of whole on every rank.  Off by default: with one GPU standing in for a
-        # rank of 8 (bench.py, DRX_BENCH_EMULATE_PARTS) the extra passes cost what the smaller sort saves (DESIGN.md section 6.1)
-        self.distributed_prepare = bool(distributed_prepare)
+        # who builds the sorted touch list of a step (the same list on every rank; DESIGN.md section 6.1):
+        #   'local'  every rank builds all of it;   'turns'  rank s % N builds the list of step s and broadcasts it;
+        #   'parts'  every rank builds 1/N of every list, one all-gather
+        assert prepare in ('local', 'turns', 'parts')
+        self.prepare_mode = prepare
         self._all, self._oflow, self._oflow_ev = [None, None], [None, None], [None, None]
         self._oflow_host = None
         self._prep_group = None
@@ -587,6 +591,33 @@ class ColumnShardedCdae:
         out = e.step_sparse(step, bt, self.loss, want_loss=want_loss, events=events, prepared=prepared, kshard=(h, dot))
         return float(out[0]) if want_loss else None
 
+    def _prep_comm(self):
+        """A communicator of their own for the exchanges of prepared lists: they are long and run ahead, and must never queue in
+        front of a step's all-reduce."""
+        if self._prep_group is None:
+            self._prep_group = dist.new_group(ranks=dist.get_process_group_ranks(self.group) if self.group is not None else None)
+        return self._prep_group
+
+    def prepare_in_turns(self, s, bt, out=None):
+        """The sorted touch list of the (global) batch of step s: built by rank s % world only, then broadcast — a rank sorts one
+        list in `world` steps instead of one per step, and the received bytes land in the prepared buffer as they are
+        (drx_cdae_prep_result_bytes).  Runs on the CURRENT stream (the pipeline's side stream); needs a pipeline that prepares
+        several steps ahead (pipeline())."""
+        e = self.engine
+        owner = s % self.world
+        out = e.prepare_sparse(bt, out) if owner == self.rank else e.prep_buffer(bt, out)
+        if self.collectives:
+            res = out[:e.prep_result_bytes(bt)]
+            src = dist.get_global_rank(self.group, owner) if self.group is not None else owner
+            if self.cpu_staging:
+                h = res.cpu()
+                dist.broadcast(h, src=src, group=self._prep_comm())
+                if owner != self.rank:
+                    res.copy_(h)
+            else:
+                dist.broadcast(res, src=src, group=self._prep_comm())
+        return out
+
     def prepare(self, s, bt, out=None):
         """The sorted touch list of the (global) batch `bt`, built in PARTS: this rank sorts the touches of the rows it owns
         (row id % world == rank), the parts travel in one all-gather on a communicator of their own (so that this long
@@ -604,15 +635,13 @@ class ColumnShardedCdae:
                 self._all[k] = None
                 self._all[k] = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=part.device)
             allp = self._all[k][:need]
-            if self._prep_group is None:
-                self._prep_group = dist.new_group(ranks=dist.get_process_group_ranks(self.group) if self.group is not None else None)
             if self.cpu_staging:
                 hp = part.cpu()
                 ha = torch.empty(part.numel() * self.world, dtype=torch.uint8)
-                dist.all_gather_into_tensor(ha, hp, group=self._prep_group)
+                dist.all_gather_into_tensor(ha, hp, group=self._prep_comm())
                 allp.copy_(ha)
             else:
-                dist.all_gather_into_tensor(allp, part, group=self._prep_group)
+                dist.all_gather_into_tensor(allp, part, group=self._prep_comm())
         else:
             allp = part
         out, self._oflow[k] = e.prepare_assemble(bt, allp, self.world, out, self._oflow[k])
@@ -626,7 +655,7 @@ class ColumnShardedCdae:
             self._oflow_ev[k].synchronize()                  # recorded two preparations ago
             if int(self._oflow_host[k][0]):
                 raise RuntimeError('a part of the touch list exceeded its capacity (row popularity too uneven for parts of 1.25x the '
-                                   'even share): train without distributed_prepare')
+                                   "even share): train with prepare='local' or 'turns'")
 
     def pipeline(self, batch_size, neg_ratio, sample_seed_of, mask_seed_of):
         """SampledPipeline over this rank: the SAME seeds on every rank give every rank the same global batch."""
@@ -634,5 +663,6 @@ class ColumnShardedCdae:
         return SampledPipeline(self.engine, batch_size, neg_ratio, self.q, sample_seed_of, mask_seed_of, n_items=self.engine.n_items,
                                loss=self.loss, step_fn=lambda s, bt, prep, events, want_loss: self.step(s, bt, prepared=prep, events=events,
                                                                                                          want_loss=want_loss),
-                               prepare_fn=self.prepare if self.distributed_prepare else None)
+                               prepare_fn={'local': None, 'turns': self.prepare_in_turns, 'parts': self.prepare}[self.prepare_mode],
+                               prep_ahead=self.TURNS_AHEAD if self.prepare_mode == 'turns' else 1)
 

@@ -216,12 +216,22 @@ class CdaeEngine:
             'drx_cdae_step_dense')
         return self._loss if want_loss else None
 
+    def prep_buffer(self, bt, out=None):
+        """A buffer large enough for the prepared touch list of `bt` (`out` itself when it is)."""
+        need = lib().drx_cdae_prep_bytes(C.byref(self._params), bt.B, bt.n_touch_slots)
+        if out is None or out.numel() < need:
+            out = None
+            out = torch.empty(int(need * 1.03) + 4096, dtype=torch.uint8, device=self.device)
+        return out
+
+    def prep_result_bytes(self, bt):
+        """Leading bytes of a prepared buffer that a step reads (include/drx.h, drx_cdae_prep_result_bytes)."""
+        return int(lib().drx_cdae_prep_result_bytes(C.byref(self._params), bt.B, bt.n_touch_slots))
+
     def prepare_sparse(self, bt, out=None):
         """Builds and sorts the touch list of a batch (drx_cdae_sparse_prepare) on the CURRENT stream.  The list does not
         depend on the parameters, so this may run on a side stream for batch t+1 while batch t trains."""
-        need = lib().drx_cdae_prep_bytes(C.byref(self._params), bt.B, bt.n_touch_slots)
-        if out is None or out.numel() < need:
-            out = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        out = self.prep_buffer(bt, out)
         check(lib().drx_cdae_sparse_prepare(C.byref(self._params), C.byref(self._hist), C.byref(bt), ptr(out), out.numel(),
                                             stream_ptr(self.device)), 'drx_cdae_sparse_prepare')
         return out
@@ -396,49 +406,57 @@ class SampledPipeline:
     batch reaches the host through pinned memory two steps before it is needed, so nothing waits.  Used by
     `CDAE.fit(mode='sampled', device_sampler=True)` and by bench.py — the same code path.
 
-    sample_seed_of(s) / mask_seed_of(s): seeds of step s's triple draw and of its corruption mask."""
+    sample_seed_of(s) / mask_seed_of(s): seeds of step s's triple draw and of its corruption mask.
+    prep_ahead: how many steps ahead the touch list is prepared (1; more when preparing takes longer than a step, as when
+    the ranks of a column-sharded job take turns preparing the list for all — dist.ColumnShardedCdae)."""
 
     def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None,
-                 prepare_fn=None):
+                 prepare_fn=None, prep_ahead=1):
         self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
-        # prepare_fn(s, bt, out) -> prepared buffer, called with the side stream current (default: eng.prepare_sparse)
-        self.prepare_fn = prepare_fn
         # step_fn(s, bt, prepared, events, want_loss): what trains on a prepared batch (default: this engine's sparse step;
         # dist.ColumnShardedCdae.step for the column-sharded multi-GPU layout)
         self.step_fn = step_fn
+        # prepare_fn(s, bt, out) -> prepared buffer, called with the side stream current (default: eng.prepare_sparse)
+        self.prepare_fn = prepare_fn
         self.sample_seed_of, self.mask_seed_of = sample_seed_of, mask_seed_of
         self.n_items = n_items
         dev = eng.device
         self.main = torch.cuda.current_stream(dev)
         # high priority: a normal stream may share a hardware queue with the training stream and inherit its barriers
         self.side = torch.cuda.Stream(dev, priority=-1)
-        self.ring = [eng.sample_device(self.B, self.neg_ratio, 1, n_items=n_items) for _ in range(3)]
-        self.ring_T = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(3)]
-        self.ring_ev = [torch.cuda.Event() for _ in range(3)]
-        self.ring_free = [torch.cuda.Event() for _ in range(3)]
-        self.ring_bt = [None, None, None]
-        self.prep = [None, None]
-        self.prep_done = [torch.cuda.Event(), torch.cuda.Event()]
-        self.step_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.D = D = max(1, int(prep_ahead))
+        # batches are drawn one step before their list is prepared; two when lists are prepared far ahead (a draw then never
+        # queues right behind a long preparation whose count the host is about to wait for)
+        self.SA = D + 1 if D == 1 else D + 2
+        self.RS, self.RP = self.SA + 1, D + 1                 # ring sizes: drawn batches, prepared lists
+        self.ring = [eng.sample_device(self.B, self.neg_ratio, 1, n_items=n_items) for _ in range(self.RS)]
+        self.ring_T = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(self.RS)]
+        self.ring_ev = [torch.cuda.Event() for _ in range(self.RS)]
+        self.ring_free = [torch.cuda.Event() for _ in range(self.RS)]
+        self.ring_bt = [None] * self.RS
+        self.prep = [None] * self.RP
+        self.prep_done = [torch.cuda.Event() for _ in range(self.RP)]
+        self.step_done = [torch.cuda.Event() for _ in range(self.RP)]
         for e in self.step_done + self.ring_free:
             e.record(self.main)
         self.next = 0
-        self._sample(0)
-        self._sample(1)
-        self._prepare(0)
+        for i in range(self.SA):
+            self._sample(i)
+        for i in range(D):
+            self._prepare(i)
 
     def _sample(self, s):
-        k = s % 3
-        self.side.wait_event(self.ring_free[k])              # the slot's previous batch (step s-3) has been consumed
+        k = s % self.RS
+        self.side.wait_event(self.ring_free[k])              # the slot's previous batch (step s - RS) has been consumed
         with torch.cuda.stream(self.side):
             self.eng.sample_device(self.B, self.neg_ratio, self.sample_seed_of(s), n_items=self.n_items, out=self.ring[k])
             self.ring_T[k].copy_(self.ring[k][3][-1:], non_blocking=True)
             self.ring_ev[k].record(self.side)
 
     def batch_of(self, s):
-        k = s % 3
+        k = s % self.RS
         if self.ring_bt[k] is None or self.ring_bt[k][0] != s:
-            self.ring_ev[k].synchronize()                    # the 4-byte count copied two steps ago
+            self.ring_ev[k].synchronize()                    # the 4-byte count copied at least one step ago
             uid, iid, y, keep_off = self.ring[k]
             bt, alive = self.eng.make_batch(uid, iid, y, keep_off=keep_off, q=self.q, mask_seed=self.mask_seed_of(s),
                                             n_touch_slots=int(self.ring_T[k][0]))
@@ -447,26 +465,28 @@ class SampledPipeline:
 
     def _prepare(self, s):
         bt = self.batch_of(s)
-        self.side.wait_event(self.step_done[s % 2])          # the buffer's previous user (step s-2) has finished
+        k = s % self.RP
+        self.side.wait_event(self.step_done[k])              # the buffer's previous user (step s - RP) has finished
         with torch.cuda.stream(self.side):
             if self.prepare_fn is not None:
-                self.prep[s % 2] = self.prepare_fn(s, bt, self.prep[s % 2])
+                self.prep[k] = self.prepare_fn(s, bt, self.prep[k])
             else:
-                self.prep[s % 2] = self.eng.prepare_sparse(bt, self.prep[s % 2])
-            self.prep_done[s % 2].record(self.side)
+                self.prep[k] = self.eng.prepare_sparse(bt, self.prep[k])
+            self.prep_done[k].record(self.side)
 
     def run_step(self, events=None, want_loss=False):
-        """Queues step `self.next` (and the run-ahead work of the two following steps); returns the loss tensor or None."""
+        """Queues step `self.next` (and the run-ahead work of the following steps); returns the loss tensor or None."""
         s = self.next
-        self._sample(s + 2)
-        self._prepare(s + 1)
+        self._sample(s + self.SA)
+        self._prepare(s + self.D)
         bt = self.batch_of(s)
-        self.main.wait_event(self.prep_done[s % 2])
+        k = s % self.RP
+        self.main.wait_event(self.prep_done[k])
         if self.step_fn is not None:
-            out = self.step_fn(s, bt, self.prep[s % 2], events, want_loss)
+            out = self.step_fn(s, bt, self.prep[k], events, want_loss)
         else:
-            out = self.eng.step_sparse(s, bt, self.loss, want_loss=want_loss, events=events, prepared=self.prep[s % 2])
-        self.step_done[s % 2].record(self.main)
-        self.ring_free[s % 3].record(self.main)
+            out = self.eng.step_sparse(s, bt, self.loss, want_loss=want_loss, events=events, prepared=self.prep[k])
+        self.step_done[k].record(self.main)
+        self.ring_free[s % self.RS].record(self.main)
         self.next = s + 1
         return out

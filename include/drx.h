@@ -170,6 +170,12 @@ int drx_cdae_kshard_step(const DrxCdaeParams *p, const DrxOptim *opt, const DrxH
                          const float *h, const float *dot_total, const void *prepared, size_t prepared_bytes, void *scratch,
                          size_t scratch_bytes, float *loss_out, void *const *events, void *stream);
 
+/* The leading drx_cdae_prep_result_bytes of a `prepared` buffer are all that a step reads of it (the sorted list and the
+ * sole-toucher marks): a buffer whose leading bytes were copied from another device's drx_cdae_sparse_prepare of the SAME batch
+ * (same B, n_touch_slots, n_users, n_items) is a valid `prepared` argument — how one rank of a column-sharded job prepares the
+ * list of a step for all the others. */
+size_t drx_cdae_prep_result_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots);
+
 /* Touch list prepared in PARTS (column-sharded layout: all ranks need the same list of the same batch, and sorting it on every
  * rank is the one cost that does not shrink with N).  Part r of `parts` = the touches of the rows with id % parts == r (item id for W
  * and W2T keys, user id for V keys), taken in sample order and sorted by key; the list of the batch is the

@@ -47,7 +47,7 @@ def _oracle(K, opt):
     return p, losses
 
 
-def _run_rank(rank, world, K, opt, staged, force=False, prepared=True, parts=False):
+def _run_rank(rank, world, K, opt, staged, force=False, prepared=True, parts=False, turns=False):
     from drecpy_amd.dist import ColumnShardedCdae
     p, indptr, indices, batches = _problem(K)
     m = ColumnShardedCdae(U, N, K, rank, world, 'cuda:0', indptr, indices, q=Q, optimizer=opt, lr=0.05 if opt == 'adagrad' else 1e-3,
@@ -58,6 +58,8 @@ def _run_rank(rank, world, K, opt, staged, force=False, prepared=True, parts=Fal
         bt, alive = m.engine.make_batch(uid, iid, y, q=Q, mask_seed=seed)
         if parts:                                                           # touch list built in parts and gathered
             prep = m.prepare(s, bt)
+        elif turns:                                                         # built by rank s % world, broadcast
+            prep = m.prepare_in_turns(s, bt)
         else:
             prep = m.engine.prepare_sparse(bt) if (prepared and s % 2) else None
         losses.append(m.step(s, bt, prepared=prep, want_loss=True))
@@ -86,11 +88,11 @@ def test_column_sharded_world1_matches_oracle(K, opt):
     _check(K, opt, [_run_rank(0, 1, K, opt, False)])
 
 
-def _worker(rank, world, port, out, K, opt, parts=False):
+def _worker(rank, world, port, out, K, opt, parts=False, turns=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _run_rank(rank, world, K, opt, True, parts=parts)
+    res = _run_rank(rank, world, K, opt, True, parts=parts, turns=turns)
     torch.save(res, f'{out}.{rank}')
     dist.barrier()
     dist.destroy_process_group()
@@ -105,12 +107,12 @@ def test_column_sharded_processes_on_one_gpu_match_oracle(tmp_path, world, K, op
     _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
 
 
-def _worker_rccl(rank, port, out, K, opt, parts=False):
+def _worker_rccl(rank, port, out, K, opt, parts=False, turns=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    res = _run_rank(0, 1, K, opt, False, force=True, parts=parts)
+    res = _run_rank(0, 1, K, opt, False, force=True, parts=parts, turns=turns)
     torch.save(res, f'{out}.0')
     dist.barrier()
     dist.destroy_process_group()
@@ -130,6 +132,24 @@ def test_touch_list_built_in_parts_across_processes(tmp_path, world, K, opt):
     port = 28800 + (os.getpid() % 200) + 300 * world + K
     mp.spawn(_worker, args=(world, port, out, K, opt, True), nprocs=world, join=True)
     _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
+
+
+@pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adam')])
+def test_touch_list_built_in_turns_across_processes(tmp_path, world, K, opt):
+    """ColumnShardedCdae.prepare_in_turns: rank s % world sorts the list of step s and broadcasts the leading
+    drx_cdae_prep_result_bytes of its prepared buffer.  world 3, K = 50: the ranks' row widths differ (32, 32, 16 floats), so a
+    list marked for sole touchers by one geometry is consumed by another."""
+    out = str(tmp_path / 'kt')
+    port = 27800 + (os.getpid() % 200) + 300 * world + K
+    mp.spawn(_worker, args=(world, port, out, K, opt, False, True), nprocs=world, join=True)
+    _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
+
+
+def test_touch_list_built_in_turns_through_rccl_world1(tmp_path):
+    out = str(tmp_path / 'ktr')
+    port = 27300 + (os.getpid() % 200)
+    mp.spawn(_worker_rccl, args=(port, out, 128, 'adagrad', False, True), nprocs=1, join=True)
+    _check(128, 'adagrad', [torch.load(f'{out}.0', weights_only=False)])
 
 
 def test_touch_list_built_in_parts_through_rccl_world1(tmp_path):
@@ -206,14 +226,14 @@ def test_a_part_that_does_not_fit_is_reported():
     assert int(blobs[0].cpu().numpy()[:16].view(np.int32)[2]) == 1
 
 
-@pytest.mark.parametrize('parts_prep', [False, True])
-def test_column_sharded_pipeline_equals_stepping_inline(parts_prep):
+@pytest.mark.parametrize('prepare', ['local', 'turns', 'parts'])
+def test_column_sharded_pipeline_equals_stepping_inline(prepare):
     """ColumnShardedCdae.pipeline (device sampler two batches ahead, touch list one ahead) vs the same seeds stepped inline."""
     from drecpy_amd.dist import ColumnShardedCdae
     p, indptr, indices, _ = _problem(64)
     outs = []
     for piped in (True, False):
-        m = ColumnShardedCdae(U, N, 64, 0, 1, 'cuda:0', indptr, indices, q=Q, distributed_prepare=parts_prep)
+        m = ColumnShardedCdae(U, N, 64, 0, 1, 'cuda:0', indptr, indices, q=Q, prepare=prepare)
         m.set_params_global(**p)
         if piped:
             pipe = m.pipeline(512, 5, lambda s: 77 + s, lambda s: 1000 + s)
