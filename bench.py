@@ -203,16 +203,16 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
         seed_of = lambda s: 5000 + 7919 * (s % args.n_batches)
         cache, recv = {}, [None, None]
 
-        def emulated_turns(s, bt, out):
+        def emulated_build(s, bt, out):
             c = s % args.n_batches
             if c not in cache:
                 cache[c] = eng.prepare_sparse(bt).clone()
-            if s % emu == 0:
-                return eng.prepare_sparse(bt, out)
-            out = eng.prep_buffer(bt, out)
-            n = eng.prep_result_bytes(bt)
-            out[:n].copy_(cache[c][:n])
-            return out
+            return eng.prepare_sparse(bt, out) if s % emu == 0 else eng.prep_buffer(bt, out)
+
+        def emulated_deliver(s, bt, out):
+            if s % emu:
+                n = eng.prep_result_bytes(bt)
+                out[:n].copy_(cache[s % args.n_batches][:n])
 
         def emulated_parts(s, bt, out):
             c = s % args.n_batches
@@ -228,7 +228,7 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
             out, model._oflow[s % 2] = eng.prepare_assemble(bt, got, emu, out, model._oflow[s % 2])
             return out
         model.prepare_mode = args.prepare
-        model.prepare, model.prepare_in_turns = emulated_parts, emulated_turns
+        model.prepare, model.build_in_turns, model.deliver_in_turns = emulated_parts, emulated_build, emulated_deliver
     elif world > 1:
         model.prepare_mode = args.prepare
     pipe = model.pipeline(Bg, NEG_RATIO, seed_of, seed_of)

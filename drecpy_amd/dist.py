@@ -520,7 +520,7 @@ class ColumnShardedCdae:
     The result equals the single-process step on the global batch with all K columns (the dot product is summed in rank
     order); histories (the positives CSR of ALL users) are replicated."""
 
-    TURNS_AHEAD = 3       # prepare='turns': a list is started three steps before its step (a sort + a broadcast take about two)
+    TURNS_AHEAD = 3       # prepare='turns': a list is built three steps before its step and broadcast one step before it
 
     def __init__(self, n_users, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
                  optimizer='adagrad', group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False, engine=None,
@@ -598,24 +598,34 @@ class ColumnShardedCdae:
             self._prep_group = dist.new_group(ranks=dist.get_process_group_ranks(self.group) if self.group is not None else None)
         return self._prep_group
 
-    def prepare_in_turns(self, s, bt, out=None):
-        """The sorted touch list of the (global) batch of step s: built by rank s % world only, then broadcast — a rank sorts one
-        list in `world` steps instead of one per step, and the received bytes land in the prepared buffer as they are
-        (drx_cdae_prep_result_bytes).  Runs on the CURRENT stream (the pipeline's side stream); needs a pipeline that prepares
-        several steps ahead (pipeline())."""
+    def build_in_turns(self, s, bt, out=None):
+        """First half of prepare='turns': rank s % world builds the sorted touch list of step s (the others only make sure
+        they have a buffer for it).  A rank thus sorts one list in `world` steps instead of one per step."""
+        e = self.engine
+        return e.prepare_sparse(bt, out) if s % self.world == self.rank else e.prep_buffer(bt, out)
+
+    def deliver_in_turns(self, s, bt, out):
+        """Second half: the list of step s travels from its builder to everybody — the leading drx_cdae_prep_result_bytes of
+        the prepared buffer, broadcast as they are.  Issued a step before the list is used and long after it was built, so
+        that the collective never waits for a sort."""
+        if not self.collectives:
+            return
         e = self.engine
         owner = s % self.world
-        out = e.prepare_sparse(bt, out) if owner == self.rank else e.prep_buffer(bt, out)
-        if self.collectives:
-            res = out[:e.prep_result_bytes(bt)]
-            src = dist.get_global_rank(self.group, owner) if self.group is not None else owner
-            if self.cpu_staging:
-                h = res.cpu()
-                dist.broadcast(h, src=src, group=self._prep_comm())
-                if owner != self.rank:
-                    res.copy_(h)
-            else:
-                dist.broadcast(res, src=src, group=self._prep_comm())
+        res = out[:e.prep_result_bytes(bt)]
+        src = dist.get_global_rank(self.group, owner) if self.group is not None else owner
+        if self.cpu_staging:
+            h = res.cpu()
+            dist.broadcast(h, src=src, group=self._prep_comm())
+            if owner != self.rank:
+                res.copy_(h)
+        else:
+            dist.broadcast(res, src=src, group=self._prep_comm())
+
+    def prepare_in_turns(self, s, bt, out=None):
+        """Both halves at once, on the CURRENT stream (inline stepping; pipeline() issues them separately)."""
+        out = self.build_in_turns(s, bt, out)
+        self.deliver_in_turns(s, bt, out)
         return out
 
     def prepare(self, s, bt, out=None):
@@ -663,6 +673,7 @@ class ColumnShardedCdae:
         return SampledPipeline(self.engine, batch_size, neg_ratio, self.q, sample_seed_of, mask_seed_of, n_items=self.engine.n_items,
                                loss=self.loss, step_fn=lambda s, bt, prep, events, want_loss: self.step(s, bt, prepared=prep, events=events,
                                                                                                          want_loss=want_loss),
-                               prepare_fn={'local': None, 'turns': self.prepare_in_turns, 'parts': self.prepare}[self.prepare_mode],
+                               prepare_fn={'local': None, 'turns': self.build_in_turns, 'parts': self.prepare}[self.prepare_mode],
+                               deliver_fn=self.deliver_in_turns if self.prepare_mode == 'turns' else None,
                                prep_ahead=self.TURNS_AHEAD if self.prepare_mode == 'turns' else 1)
 

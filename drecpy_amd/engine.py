@@ -411,13 +411,17 @@ class SampledPipeline:
     the ranks of a column-sharded job take turns preparing the list for all — dist.ColumnShardedCdae)."""
 
     def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None,
-                 prepare_fn=None, prep_ahead=1):
+                 prepare_fn=None, prep_ahead=1, deliver_fn=None):
         self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
         # step_fn(s, bt, prepared, events, want_loss): what trains on a prepared batch (default: this engine's sparse step;
         # dist.ColumnShardedCdae.step for the column-sharded multi-GPU layout)
         self.step_fn = step_fn
         # prepare_fn(s, bt, out) -> prepared buffer, called with the side stream current (default: eng.prepare_sparse)
         self.prepare_fn = prepare_fn
+        # deliver_fn(s, bt, out): second stage of a preparation, issued ONE step before the list is used on a stream of its own
+        # (e.g. the broadcast of a list another rank built: issued late, so that no rank's collective waits for a sort)
+        self.deliver_fn = deliver_fn
+        self.comm = torch.cuda.Stream(eng.device, priority=-1) if deliver_fn is not None else None
         self.sample_seed_of, self.mask_seed_of = sample_seed_of, mask_seed_of
         self.n_items = n_items
         dev = eng.device
@@ -436,6 +440,7 @@ class SampledPipeline:
         self.ring_bt = [None] * self.RS
         self.prep = [None] * self.RP
         self.prep_done = [torch.cuda.Event() for _ in range(self.RP)]
+        self.built = [torch.cuda.Event() for _ in range(self.RP)]
         self.step_done = [torch.cuda.Event() for _ in range(self.RP)]
         for e in self.step_done + self.ring_free:
             e.record(self.main)
@@ -444,6 +449,8 @@ class SampledPipeline:
             self._sample(i)
         for i in range(D):
             self._prepare(i)
+        if deliver_fn is not None:
+            self._deliver(0)
 
     def _sample(self, s):
         k = s % self.RS
@@ -472,13 +479,23 @@ class SampledPipeline:
                 self.prep[k] = self.prepare_fn(s, bt, self.prep[k])
             else:
                 self.prep[k] = self.eng.prepare_sparse(bt, self.prep[k])
-            self.prep_done[k].record(self.side)
+            (self.prep_done if self.deliver_fn is None else self.built)[k].record(self.side)
+
+    def _deliver(self, s):
+        bt = self.batch_of(s)
+        k = s % self.RP
+        self.comm.wait_event(self.built[k])
+        with torch.cuda.stream(self.comm):
+            self.deliver_fn(s, bt, self.prep[k])
+            self.prep_done[k].record(self.comm)
 
     def run_step(self, events=None, want_loss=False):
         """Queues step `self.next` (and the run-ahead work of the following steps); returns the loss tensor or None."""
         s = self.next
         self._sample(s + self.SA)
         self._prepare(s + self.D)
+        if self.deliver_fn is not None:
+            self._deliver(s + 1)
         bt = self.batch_of(s)
         k = s % self.RP
         self.main.wait_event(self.prep_done[k])

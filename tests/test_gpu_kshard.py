@@ -250,6 +250,48 @@ def test_column_sharded_pipeline_equals_stepping_inline(prepare):
         assert torch.equal(a, b)
 
 
+def _pipe_worker(rank, world, port, out, prepare):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from drecpy_amd.dist import ColumnShardedCdae
+    p, indptr, indices, _ = _problem(64)
+    m = ColumnShardedCdae(U, N, 64, rank, world, 'cuda:0', indptr, indices, q=Q, cpu_staging=True, prepare=prepare)
+    m.set_params_global(**p)
+    pipe = m.pipeline(512, 5, lambda s: 77 + s, lambda s: 1000 + s)
+    for _ in range(9):
+        pipe.run_step()
+    torch.cuda.synchronize()
+    torch.save((m.get_params(), (m.k_lo, m.k_hi)), f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,prepare', [(2, 'turns'), (3, 'turns'), (2, 'parts')])
+def test_pipelines_of_several_processes_equal_the_single_process_run(tmp_path, world, prepare):
+    """The run-ahead pipeline with lists built in turns (built three steps ahead by rank s % world, broadcast one step ahead)
+    or in parts, as `world` processes sharing the GPU: every rank's columns equal those of one process stepping inline."""
+    from drecpy_amd.dist import ColumnShardedCdae
+    out = str(tmp_path / 'pp')
+    port = 26800 + (os.getpid() % 200) + 300 * world + (7 if prepare == 'parts' else 0)
+    mp.spawn(_pipe_worker, args=(world, port, out, prepare), nprocs=world, join=True)
+    p, indptr, indices, _ = _problem(64)
+    m = ColumnShardedCdae(U, N, 64, 0, 1, 'cuda:0', indptr, indices, q=Q)
+    m.set_params_global(**p)
+    for s in range(9):
+        uid, iid, y, ko = m.engine.sample_device(512, 5, 77 + s)
+        bt, alive = m.engine.make_batch(uid, iid, y, keep_off=ko, q=Q, mask_seed=1000 + s)
+        m.step(s, bt)
+    torch.cuda.synchronize()
+    want = m.get_params()
+    for r in range(world):
+        got, (lo, hi) = torch.load(f'{out}.{r}', weights_only=False)
+        np.testing.assert_allclose(got['W'], want['W'][:, lo:hi], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got['W_'], want['W_'][lo:hi, :], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got['V'], want['V'][:, lo:hi], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got['b_'], want['b_'], rtol=0, atol=2e-6)
+
+
 def _fit_worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
