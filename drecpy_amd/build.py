@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libdrx.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+HOSTCXX = os.environ.get('CXX', 'g++')
 ARCH = 'gfx950'
 SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_sampler.hip', 'drx_shard.hip', 'drx_generic.hip', 'drx_caser.hip', 'drx_dmf.hip', 'drx_host.cpp']
 COMMON = ['-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
@@ -37,11 +38,10 @@ def build(force=False, verbose=True):
         objs.append(op)
         if not force and _newer(op, [sp] + headers):
             continue
-        cmd = [HIPCC] + COMMON + ['-c', sp, '-o', op]
         if src.endswith('.hip'):
-            cmd[1:1] = [f'--offload-arch={ARCH}']
-        else:
-            cmd[1:1] = ['-x', 'c++'] if False else []
+            cmd = [HIPCC, f'--offload-arch={ARCH}'] + COMMON + ['-c', sp, '-o', op]
+        else:                   # host-only code (samplers, MT19937 streams): g++, so that function multiversioning is available
+            cmd = [HOSTCXX] + COMMON + ['-c', sp, '-o', op]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

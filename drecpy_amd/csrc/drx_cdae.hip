@@ -913,11 +913,6 @@ static int check_batch(const DrxHistory *h, const DrxBatch *bt) {
 // Any order that keeps equal keys adjacent (and their touches in sample order) serves the segmented reduction, so rank r sorts
 // only the touches whose row it "owns" — row id modulo the number of parts, which spreads rows evenly however ids were assigned — and
 // the global list is the concatenation of the parts in rank order.
-__device__ __forceinline__ int touch_owner(uint32_t key, uint32_t n_items, int parts) {
-  const uint32_t row = key < n_items ? key : key < 2 * n_items ? key - n_items : key - 2 * n_items;
-  return (int)(row % (uint32_t)parts);
-}
-
 // Two passes over the batch (count, then write at the scanned offsets) take the owned touches in sample order straight from the
 // histories: nothing of the size of the whole list is ever written.  WRITE = false: cnt[b] = owned touches of sample b;
 // WRITE = true: cnt[] holds the inclusive scan of those counts.

@@ -13,6 +13,27 @@
 namespace {
 
 // MT19937 exactly as CPython's Modules/_randommodule.c drives it (algorithm of Matsumoto & Nishimura).
+
+// One MT19937 state transition (624 words in place).  The corruption stream of reference mode is N uniform draws per batch row
+// (cdae.py:63), almost all of them skipped over: this loop IS that cost, so it is compiled for the widest vectors the host has
+// (runtime dispatch: the library is built on one machine and runs on another).
+__attribute__((target_clones("avx512f", "avx2", "default"))) void mt_twist(uint32_t *__restrict__ s) {
+  // word kk needs words kk + 1 (old) and kk + 397 mod 624 (old for kk < 227, else written 227 iterations earlier): in the three
+  // ranges below no iteration depends on another of the same range
+  auto range = [&](int lo, int hi, int off) {
+#pragma GCC ivdep
+    for (int kk = lo; kk < hi; ++kk) {
+      const uint32_t y = (s[kk] & 0x80000000u) | (s[kk + 1] & 0x7FFFFFFFu);
+      s[kk] = s[kk + off] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908B0DFu);
+    }
+  };
+  range(0, 227, 397);
+  range(227, 454, -227);
+  range(454, 623, -227);
+  const uint32_t y = (s[623] & 0x80000000u) | (s[0] & 0x7FFFFFFFu);
+  s[623] = s[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908B0DFu);
+}
+
 struct MT {
   uint32_t s[624];
   int idx;
@@ -54,21 +75,8 @@ struct MT {
     }
   }
   void regenerate() {
-    {
-      int kk;
-      uint32_t y;
-      for (kk = 0; kk < 624 - 397; ++kk) {
-        y = (s[kk] & 0x80000000u) | (s[kk + 1] & 0x7FFFFFFFu);
-        s[kk] = s[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
-      }
-      for (; kk < 623; ++kk) {
-        y = (s[kk] & 0x80000000u) | (s[kk + 1] & 0x7FFFFFFFu);
-        s[kk] = s[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
-      }
-      y = (s[623] & 0x80000000u) | (s[0] & 0x7FFFFFFFu);
-      s[623] = s[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
-      idx = 0;
-    }
+    mt_twist(s);
+    idx = 0;
   }
   uint32_t next() {
     if (idx >= 624) regenerate();

@@ -156,6 +156,20 @@ class CdaeEngine:
         f = np.float32
         return float(f(lr) * np.sqrt(f(1.0) - np.power(f(ADAM_B2), f(t))) / (f(1.0) - np.power(f(ADAM_B1), f(t))))
 
+    _ALPHA_CHUNK = 512
+
+    def _dense_alphas(self, step):
+        """The five lr_t of dense step `step` (t = 5 * step + j + 1), from a table computed 512 steps at a time with the same
+        fp32 arithmetic as adam_alpha (numpy scalar arithmetic per step costs more than launching the step)."""
+        c = getattr(self, '_alpha_tab', None)
+        base = step - step % self._ALPHA_CHUNK
+        if c is None or c[0] != base or c[1] != self.lr:
+            f = np.float32
+            t = (5 * base + 1 + np.arange(5 * self._ALPHA_CHUNK)).astype(np.float32)
+            tab = f(self.lr) * np.sqrt(f(1.0) - np.power(f(ADAM_B2), t)) / (f(1.0) - np.power(f(ADAM_B1), t))
+            c = self._alpha_tab = (base, self.lr, tab.astype(np.float32).reshape(-1, 5).tolist())
+        return c[2][step - base]
+
     # ---- batches ----------------------------------------------------------------------------
     def _dev(self, a, dtype):
         if a is None:
@@ -164,8 +178,50 @@ class CdaeEngine:
             return a.to(self.device, dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a)).to(self.device, dtype)
 
+    _STAGE_SLOTS = 4
+
+    def _make_batch_staged(self, uid, iid, y, keep_off, keep, q, mask_seed, n_touch_slots):
+        """Host (numpy) batch -> device in ONE asynchronous copy: the arrays are packed into a pinned staging buffer (a ring
+        of _STAGE_SLOTS, so the host can run ahead of the device) and land in one device buffer that the Batch points into."""
+        B = len(uid)
+        parts = [('uid', np.ascontiguousarray(uid, dtype=np.int32)), ('keep_off', np.ascontiguousarray(keep_off, dtype=np.int32))]
+        if iid is not None:
+            parts.append(('iid', np.ascontiguousarray(iid, dtype=np.int32)))
+        if y is not None:
+            parts.append(('y', np.ascontiguousarray(y, dtype=np.float32)))
+        if keep is not None:
+            k8 = np.ascontiguousarray(keep, dtype=np.uint8)
+            parts.append(('keep', k8 if k8.size else np.zeros(1, np.uint8)))
+        offs, total = {}, 0
+        for name, a in parts:
+            offs[name] = total
+            total += (a.nbytes + 15) & ~15
+        st = self.__dict__.setdefault('_stage', {'i': 0, 'host': [None] * self._STAGE_SLOTS, 'ev': [None] * self._STAGE_SLOTS})
+        k = st['i'] % self._STAGE_SLOTS
+        st['i'] += 1
+        if st['host'][k] is None or st['host'][k].numel() < total:
+            st['host'][k] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
+            st['ev'][k] = None
+        if st['ev'][k] is not None:
+            st['ev'][k].synchronize()                 # the copy that last read this pinned slot (4 batches ago) has finished
+        hv = st['host'][k].numpy()
+        for name, a in parts:
+            hv[offs[name]:offs[name] + a.nbytes] = a.view(np.uint8).reshape(-1)
+        dev = torch.empty(total, dtype=torch.uint8, device=self.device)      # owned by the batch (the keep-alive tuple)
+        dev.copy_(st['host'][k][:total], non_blocking=True)
+        st['ev'][k] = torch.cuda.Event()
+        st['ev'][k].record(torch.cuda.current_stream(self.device))
+        base = dev.data_ptr()
+        at = lambda name: (base + offs[name]) if name in offs else None
+        bt = Batch(B, at('uid'), at('iid'), at('y'), at('keep_off'), at('keep'), int(mask_seed) & (2 ** 64 - 1), float(q),
+                   int(n_touch_slots))
+        return bt, (dev,)
+
     def make_batch(self, uid, iid=None, y=None, keep_off=None, keep=None, q=0.0, mask_seed=0, n_touch_slots=None):
         """Uploads (if needed) one batch and returns (Batch struct, keep-alive tensors)."""
+        if (keep_off is not None and n_touch_slots is not None and self.device.type == 'cuda'
+                and not any(torch.is_tensor(a) for a in (uid, iid, y, keep_off, keep))):
+            return self._make_batch_staged(uid, iid, y, keep_off, keep, q, mask_seed, n_touch_slots)
         uid = self._dev(uid, torch.int32)
         B = int(uid.numel())
         if keep_off is None:
@@ -205,8 +261,7 @@ class CdaeEngine:
 
     def step_dense(self, step, bt, loss='bce', targets='reference', want_loss=False):
         """One reference-mode fit() iteration; `step` is the 0-based batch index (Adam t = 5*step+j+1)."""
-        alphas = [self.adam_alpha(self.lr, 5 * step + j + 1) for j in range(5)]
-        o = self._optim(alphas)
+        o = self._optim(self._dense_alphas(step))
         sc = self._ensure_scratch(bt.B, max(bt.n_touch_slots, 0), dense=True)
         check(lib().drx_cdae_step_dense(
             C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
