@@ -54,8 +54,9 @@ def parse():
                     help='multi-GPU layout: columns = every rank all rows x K/N columns, same global batch, one all-reduce of B scalars per step; '
                          'rows = users and item rows sharded by range, rows and gradient rows travel by all-to-all')
     ap.add_argument('--force-columns', action='store_true', help='run the column-sharded code path even at 1 GPU')
-    ap.add_argument('--prepare', default='turns', choices=['local', 'turns', 'parts'],
-                    help='column layout, who sorts the touch list of a step: every rank all of it (local), rank s %% N for all (turns, default), every rank 1/N of it (parts)')
+    ap.add_argument('--prepare', default='auto', choices=['auto', 'local', 'turns', 'parts'],
+                    help='column layout, who sorts the touch list of a step: every rank all of it (local), rank s %% N for all (turns), every rank '
+                         '1/N of it (parts); auto = turns from 4 GPUs on (at 2 it saves nothing), else local')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     return ap.parse_args()
 
@@ -197,6 +198,8 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
     setup_s = time.time() - t_setup
     seed_of = lambda s: 5000 + 7919 * s                                                              # same seeds on every rank
     emu = int(os.environ.get('DRX_BENCH_EMULATE_RANKS', 0))
+    if args.prepare == 'auto':
+        args.prepare = 'turns' if max(world, emu) >= 4 else 'local'
     if emu > 1 and world == 1 and args.prepare != 'local':
         # debugging aid (one GPU standing in for one rank of `emu`): the batches cycle and what the other ranks would send comes
         # from a cache filled at the first encounter; a device copy stands in for the broadcast / all-gather
@@ -277,7 +280,7 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
                                       f'{args.workload}-shaped synthetic ({U} users x {N} items, {nnz} positives), corruption {Q}, neg_ratio {NEG_RATIO}',
                           'batch_per_gpu': args.batch, 'global_batch': Bg, 'rows_per_sample': round(rows_per_sample, 3),
                           'sole_toucher_rows_per_sample': round(f_solo, 3),
-                          'batches': 'fresh device-sampled global batch every step, drawn identically on every rank (sampler two steps ahead)',
+                          'batches': 'fresh device-sampled global batch every step, drawn identically on every rank (sampler running ahead on a side stream)',
                           'sharding': f'columns: every rank holds all rows x {kl} of {K} columns and trains on the whole global batch; '
                                       f'one all-reduce of {Bg} floats per step; touch list '
                                       + {'local': 'sorted whole on every rank', 'turns': 'of step s sorted by rank s % N and broadcast on a side stream',
