@@ -11,6 +11,8 @@ mode='sampled' is the engine's throughput mode (CDAE paper's negative sampling, 
 the sampled (uid, iid, value) triple selects ONE output unit with target 1[value >= threshold]; sparse Adagrad (or lazy
 Adam) touches only the rows involved; corruption comes from a counter-based mask evaluated on the device.
 """
+import threading
+
 import numpy as np
 
 from .recommender_abc import RecommenderABC
@@ -100,7 +102,10 @@ class CDAE(RecommenderABC):
             return self._pre_fit_distributed(world[0], world[1], learning_rate, neg_ratio, reg_rate, **kwds)
         self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
         self._pipeline = None
+        for _, fut in (getattr(self, '_pending', None) or []):      # draws an early-stopped fit() left in flight
+            fut.result()
         self._pending = None
+        self._draw_cv = threading.Condition()
         weights = kwds.get('initial_weights')
         if weights is not None:                      # injected weights (TF's GlorotUniform stream is not reproducible)
             self._engine.set_params(**weights)
@@ -119,6 +124,13 @@ class CDAE(RecommenderABC):
         L = _lib.lib()
         seed = self.seed if self.seed is not None else self._rng.getrandbits(62)
         self._mask_rng = L.drx_rng_create(int(seed))    # same MT19937 stream as self._rng = random.Random(seed)
+        # a second generator on the same stream: inside fit() two worker threads draw batches t+1 and t+2 at once, each from
+        # its own generator advanced to where its batch begins (a batch always consumes 2·N·B words: cdae.py:63 draws for
+        # every item of every row), so the stream is still consumed strictly batch by batch
+        self._mask_rngs = [self._mask_rng, L.drx_rng_create(int(seed))]
+        self._mask_at = [0, 0]                          # words each generator has consumed
+        self._mask_pos = 0                              # where the next batch begins
+        self._draw_ticket = self._draw_turn = 0
         self._mask_seed = int(seed)
 
     def _restore_engine(self, params):
@@ -148,34 +160,53 @@ class CDAE(RecommenderABC):
         if self.mode == 'sampled' and kwds.get('as_arrays', True):
             return self._sampler.sample_arrays(batch_size)      # (uid, iid, value, is_negative) numpy arrays
         if self.mode == 'reference':
-            return self._reference_batch(batch_size, kwds.get('more_to_come', False))
+            return self._reference_batch(batch_size, kwds.get('batches_after', 1 if kwds.get('more_to_come', False) else 0))
         return self._sampler.sample(batch_size)                  # list of (uid, iid, value) like the reference
 
     class _Batch(list):
         """The reference's list of (uid, iid, value) triples, carrying what the fused step needs of it."""
         uid = keep_off = keep = None
 
-    def _draw_reference(self, batch_size):
-        """Sampler draw + MT19937 corruption stream of one batch (host only; both streams advance batch by batch)."""
-        batch = CDAE._Batch(self._sampler.sample(batch_size))
+    def _draw_reference(self, batch_size, ticket=None, gen=0, at=None):
+        """Sampler draw + MT19937 corruption stream of one batch (host only).  Inside fit() up to two of these run at once on
+        worker threads: the sampler draws happen in ticket order, the corruption streams on different generators (`gen`), each
+        advanced to the word `at` where its batch begins."""
+        if ticket is None:
+            batch = CDAE._Batch(self._sampler.sample(batch_size))
+        else:
+            with self._draw_cv:
+                while self._draw_turn != ticket:
+                    self._draw_cv.wait()
+                try:
+                    batch = CDAE._Batch(self._sampler.sample(batch_size))
+                finally:
+                    self._draw_turn += 1
+                    self._draw_cv.notify_all()
         batch.uid = np.array([s[0] for s in batch], dtype=np.int32)
-        batch.keep_off, batch.keep = self._corruption_keep(batch.uid)
+        batch.keep_off, batch.keep = self._corruption_keep(batch.uid, gen=gen, at=at)
         return batch
 
-    def _reference_batch(self, batch_size, more_to_come):
-        """Inside fit() the host work of batch t+1 (sampler, N uniform draws per row) runs on a worker thread while batch t
-        trains — the C++ calls release the GIL; the streams still advance strictly batch by batch, and nothing is drawn
-        beyond the last epoch."""
-        pending = getattr(self, '_pending', None)
+    def _submit_draw(self, batch_size):
+        ticket, self._draw_ticket = self._draw_ticket, self._draw_ticket + 1
+        at, self._mask_pos = self._mask_pos, self._mask_pos + 2 * self.n_items * batch_size
+        return batch_size, self._prefetch_pool().submit(self._draw_reference, batch_size, ticket, ticket % 2, at)
+
+    def _reference_batch(self, batch_size, batches_after):
+        """Inside fit() the host work of batches t+1 and t+2 (sampler, N uniform draws per row) runs on two worker threads
+        while batch t trains — the C++ calls release the GIL; the streams are still consumed strictly batch by batch, and
+        nothing is drawn beyond the last epoch."""
+        pending = getattr(self, '_pending', None) or []
         self._pending = None
-        if pending is not None and pending[0] == batch_size:
-            batch = pending[1].result()
+        if pending and pending[0][0] == batch_size:
+            batch = pending.pop(0)[1].result()
         else:
-            if pending is not None:
-                pending[1].result()                                # (a batch of another size was drawn: it is consumed, like a draw)
-            batch = self._draw_reference(batch_size)
-        if more_to_come:
-            self._pending = (batch_size, self._prefetch_pool().submit(self._draw_reference, batch_size))
+            for _, fut in pending:                                 # (batches of another size were drawn: consumed, like draws)
+                fut.result()
+            pending = []
+            batch = self._submit_draw(batch_size)[1].result()      # through the same bookkeeping, for the stream positions
+        while len(pending) < min(2, batches_after):
+            pending.append(self._submit_draw(batch_size))
+        self._pending = pending or None
         return batch
 
     # ---- fused training step (replaces recommender_abc.py:190-204 for this model) ------------------------------------
@@ -187,16 +218,26 @@ class CDAE(RecommenderABC):
         v = np.array([float(s[2]) for s in batch_samples], dtype=np.float64)
         return u, i, v
 
-    def _corruption_keep(self, uid):
-        """MT19937 corruption stream of cdae.py:63 for the batch rows (C++ host, N draws per row, batch order)."""
+    def _corruption_keep(self, uid, gen=0, at=None):
+        """MT19937 corruption stream of cdae.py:63 for the batch rows (C++ host, N draws per row, batch order).  gen / at: which
+        generator draws and the word of the stream where this batch begins (default: the next unclaimed one)."""
         from .. import _lib
         B = len(uid)
+        if at is None:                                   # a draw outside fit()'s run-ahead: after whatever is in flight
+            for _, fut in (getattr(self, '_pending', None) or []):
+                fut.result()
+            at, self._mask_pos = self._mask_pos, self._mask_pos + 2 * self.n_items * B
+        rng = self._mask_rngs[gen]
+        assert at >= self._mask_at[gen], 'corruption stream claimed out of order'
+        if at > self._mask_at[gen]:
+            _lib.lib().drx_rng_discard(rng, at - self._mask_at[gen])
+        self._mask_at[gen] = at + 2 * self.n_items * B
         deg = self._hist_indptr[uid.astype(np.int64) + 1] - self._hist_indptr[uid.astype(np.int64)]
         keep_off = np.zeros(B + 1, dtype=np.int32)
         keep = np.zeros(max(int(deg.sum()), 1), dtype=np.uint8)
         uid32 = np.ascontiguousarray(uid, dtype=np.int32)
         _lib.check(_lib.lib().drx_rng_corruption_keep(
-            self._mask_rng, self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items,
+            rng, self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items,
             uid32.ctypes.data, B, float(self.corruption_level), keep_off.ctypes.data, keep.ctypes.data, len(keep)),
             'drx_rng_corruption_keep')
         return keep_off, keep

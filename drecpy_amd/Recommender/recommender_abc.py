@@ -25,7 +25,7 @@ from .early_stopping import InvalidEpochValidationResultsException
 from .loss_tracker import LossTracker
 
 _LOG_FORMAT = '[%(asctime)s] (%(levelname)s) %(name)s: %(message)s'
-_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', 'epoch_weights', '_pipeline', '_pending',
+_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', '_mask_rngs', '_draw_cv', 'epoch_weights', '_pipeline', '_pending',
               '_host_pool', '_dist_model')
 
 
@@ -162,7 +162,7 @@ class RecommenderABC(ABC):
                 batch = ahead.result() if ahead is not None else self._sample_batch(batch_size, **kwds)
                 ahead = self._prefetch_pool().submit(self._sample_batch, batch_size, **kwds) if epoch < epochs else None
             else:
-                batch = self._sample_batch(batch_size, more_to_come=epoch < epochs, **kwds)
+                batch = self._sample_batch(batch_size, more_to_come=epoch < epochs, batches_after=epochs - epoch, **kwds)
             with self._device_lock:
                 loss = self._do_batch(batch, step=epoch - 1, want_loss=monitor.needs_loss, **kwds)
             if monitor.rule is not None and monitor.callback_due(epoch):
@@ -204,7 +204,7 @@ class RecommenderABC(ABC):
     def _prefetch_pool(self):
         if getattr(self, '_host_pool', None) is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._host_pool = ThreadPoolExecutor(max_workers=1)
+            self._host_pool = ThreadPoolExecutor(max_workers=2)
         return self._host_pool
 
     @abstractmethod

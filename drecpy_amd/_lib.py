@@ -173,6 +173,7 @@ SIGNATURES = {
     'drx_rng_destroy': (None, [C.c_void_p]),
     'drx_rng_random': (C.c_double, [C.c_void_p]),
     'drx_rng_randint': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64]),
+    'drx_rng_discard': (None, [C.c_void_p, C.c_uint64]),
     'drx_rng_corruption_keep': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                           C.c_double, C.c_void_p, C.c_void_p, C.c_int64]),
 }

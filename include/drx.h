@@ -408,6 +408,8 @@ DrxRng *drx_rng_create(int64_t seed);
 void drx_rng_destroy(DrxRng *r);
 double drx_rng_random(DrxRng *r);
 int64_t drx_rng_randint(DrxRng *r, int64_t a, int64_t b);
+/* advances the stream by n_words 32-bit outputs without producing them (a uniform(0,1) draw consumes two) */
+void drx_rng_discard(DrxRng *r, uint64_t n_words);
 int drx_rng_corruption_keep(DrxRng *r, const int64_t *h_indptr, const int32_t *h_indices, int32_t n_items,
                             const int32_t *h_uid, int32_t B, double q,
                             int32_t *h_keep_off, uint8_t *h_keep, int64_t keep_capacity);
