@@ -102,6 +102,45 @@ def test_corruption_stream_matches_python_rng():
     L.drx_rng_destroy(r)
 
 
+def test_two_generators_leapfrogging_the_corruption_stream_equal_one():
+    """What CDAE.fit() does on its two worker threads: batches drawn alternately from two generators of the same seed, each
+    advanced (drx_rng_discard) to the word where its batch begins — same masks as one generator drawing every batch, for a
+    stream long enough to cross many 624-word state blocks."""
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    U, N, B, q = 40, 1000, 16, 0.2
+    indptr = np.zeros(U + 1, dtype=np.int64)
+    idx = []
+    for u in range(U):
+        c = np.sort(rng.choice(N, size=rng.integers(1, 30), replace=False))
+        idx.append(c); indptr[u + 1] = indptr[u] + len(c)
+    indices = np.concatenate(idx).astype(np.int32)
+    batches = [rng.integers(0, U, size=B).astype(np.int32) for _ in range(7)]
+
+    def draw(r, uids):
+        keep_off = np.zeros(B + 1, dtype=np.int32)
+        keep = np.zeros(int(indptr[-1]) * 2 + 8, dtype=np.uint8)
+        assert L.drx_rng_corruption_keep(r, indptr.ctypes.data, indices.ctypes.data, N, uids.ctypes.data, B, q,
+                                         keep_off.ctypes.data, keep.ctypes.data, len(keep)) == 0
+        return keep[:keep_off[-1]].copy()
+
+    one = L.drx_rng_create(77)
+    want = [draw(one, u) for u in batches]
+    two, at = [L.drx_rng_create(77), L.drx_rng_create(77)], [0, 0]
+    for t, u in enumerate(batches):
+        g, begin = t % 2, t * 2 * N * B
+        L.drx_rng_discard(two[g], begin - at[g])
+        assert np.array_equal(draw(two[g], u), want[t])
+        at[g] = begin + 2 * N * B
+    py = random.Random(77)                                             # and both agree with CPython on where the stream is
+    for _ in range(len(batches) * N * B):
+        py.random()
+    assert L.drx_rng_random(one) == py.random()
+    for r in [one] + two:
+        L.drx_rng_destroy(r)
+
+
 def test_library_exports_every_declared_symbol():
     import re, os
     from drecpy_amd import _lib
