@@ -439,12 +439,17 @@ struct SparseBufs {
 
 // Touch list of one batch (row key, sample): depends only on the batch, never on the parameters, so it can be built
 // and sorted for batch t+1 while batch t trains (drx_cdae_sparse_prepare on a second stream).
+// Also clears the sole-toucher marks of the batch (solo: [2B] bytes or nullptr) and pads the slots beyond the last sample's up to
+// T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — two memsets the preparation would otherwise launch.
 __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
-                                                           uint32_t *vals) {
+                                                           uint32_t *vals, int T, uint8_t *solo) {
   constexpr int G = 16;
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
   if (b >= bt.B) return;
+  if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; }
+  if (b == bt.B - 1)
+    for (int j = bt.keep_off[bt.B] + 2 * bt.B + lane; j < T; j += G) { keys[j] = DRX_KEY_NONE; vals[j] = 0; }
   const int u = bt.uid[b];
   const int64_t s = H.indptr[u], e = H.indptr[u + 1];
   const int base = bt.keep_off[b] + 2 * b;
@@ -1187,17 +1192,15 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
 }
 
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
-  // slots beyond keep_off[B] (n_touch_slots may be an upper bound) must read as padding
-  DRX_HIP(hipMemsetAsync(R.keys, 0xFF, (size_t)R.T * sizeof(uint32_t), st));
   const int gpb = kBlock / 16;
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
-                     q_threshold(bt->q), R.keys, R.vals);
+                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v);
   return sort_pairs(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, st);
 }
 
 // Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
-static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
-  DRX_HIP(hipMemsetAsync(R.solo_v, 0, (size_t)bt->B * 2, st));
+static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
+  if (!cleared) DRX_HIP(hipMemsetAsync(R.solo_v, 0, (size_t)bt->B * 2, st));      // (prepare_impl's touch kernel clears them)
   // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
   // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
   if (p->ld <= 16) return DRX_OK;       // solo_v and solo_o are adjacent
@@ -1302,7 +1305,7 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   if (!cp.ok()) return DRX_ESCRATCH;
   rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream);
   if (rc) return rc;
-  rc = mark_solo(p, bt, R, (hipStream_t)stream);
+  rc = mark_solo(p, bt, R, (hipStream_t)stream, true);
   if (rc) return rc;
   DRX_LAUNCH_CHECK();
   return DRX_OK;
@@ -1381,7 +1384,7 @@ int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt,
   const PartOut o = part_out_layout(*p, bt->B, bt->n_touch_slots, parts);
   hipLaunchKernelGGL(k_assemble_parts, dim3(2048), dim3(256), 0, st, (const char *)all_parts, o.bytes, o.runs_off, o.vals_off, parts, R.T,
                      R.keys_s, R.vals_s, overflow_out);
-  rc = mark_solo(p, bt, R, st);
+  rc = mark_solo(p, bt, R, st, false);
   if (rc) return rc;
   DRX_LAUNCH_CHECK();
   return DRX_OK;

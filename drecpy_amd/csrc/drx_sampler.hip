@@ -14,9 +14,11 @@ namespace drx {
 __device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
 
 __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_users, int n_items, int B, int neg_ratio,
-                                                         uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *deg) {
+                                                         uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *deg,
+                                                         int32_t *keep_off) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
+  if (b == 0) keep_off[0] = 0;                 // the scan below fills keep_off[1..B]
   const uint32_t r0 = hash_u32(seed, (uint32_t)b, 0u);
   const bool null_pair = ((double)r0 * (1.0 / 4294967296.0)) * (double)(neg_ratio + 1) > 1.0;
   int u = 0, i = 0;
@@ -67,8 +69,7 @@ extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t
   void *tmp = (char *)scratch + align_up((size_t)B * 4, 256);
   size_t tb = scratch_bytes - align_up((size_t)B * 4, 256);
   hipLaunchKernelGGL(k_point_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, *hist, n_users, n_items, B,
-                     neg_ratio, seed, uid, iid, y, deg);
-  DRX_HIP(hipMemsetAsync(keep_off, 0, sizeof(int32_t), st));
+                     neg_ratio, seed, uid, iid, y, deg, keep_off);
   hipError_t e = rocprim::inclusive_scan(tmp, tb, deg, keep_off + 1, (size_t)B, rocprim::plus<int>(), st);
   if (e != hipSuccess) return (int)e;
   DRX_LAUNCH_CHECK();
