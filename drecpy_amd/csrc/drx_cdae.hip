@@ -296,6 +296,131 @@ __global__ __launch_bounds__(kBlock) void k_out_dense(DrxCdaeParams P, DrxOptim 
   if (threadIdx.x == 0) { A.loss_part[blockIdx.x] = lsum * invBN; A.reg_part[blockIdx.x] = rsum; }
 }
 
+// The same output-layer step for batches that fit LDS whole (the reference's own B = 64): k_out_dense walks the batch rows one
+// after the other with a cross-lane reduction per (row, unit) — a chain of B dependent shuffles that leaves the chip idle when
+// there are only N/R tiles to spread.  Here a tile of kTileR units is three small register-tiled products out of LDS:
+//   A  every thread owns (row, unit) pairs and forms their dot products serially over the columns -> p, loss, dz
+//   B  every thread owns one float4 of one unit's gradient row: sum_b dz[b] h[b,:] in batch order, then the optimizer update
+//   C  every thread owns (row, float4) cells of the tile's contribution to dh
+// h rows and W2T rows are padded by 4 floats in LDS so that 8 different rows read by a wave fall on different banks.
+constexpr int kTileR = 8;
+
+__host__ __device__ inline size_t out_tile_lds_floats(int B, int ld) {
+  return (size_t)B * (ld + 4) + (size_t)B * ld + (size_t)kTileR * (ld + 4) + (size_t)B * kTileR + 2 * kTileR;
+}
+
+template <bool WANT_LOSS>
+__global__ __launch_bounds__(kBlock) void k_out_dense_tile(DrxCdaeParams P, DrxOptim opt, OutDenseArgs A) {
+  constexpr int R = kTileR;
+  extern __shared__ __align__(16) float lds[];
+  const int ld = P.ld, ldp = ld + 4, B = A.B, c4n = ld / 4;
+  float *h_s = lds;                              // [B, ldp]
+  float *dh_s = h_s + (size_t)B * ldp;           // [B, ld]
+  float *w_s = dh_s + (size_t)B * ld;            // [R, ldp]
+  float *dz_s = w_s + (size_t)R * ldp;           // [B, R]
+  float *bias_s = dz_s + (size_t)B * R;          // [R]
+  float *tbar_s = bias_s + R;                    // [R]
+  __shared__ float red[kBlock / 64];
+  const int n_tiles = (P.n_items + R - 1) / R;
+  const OptScalars oW = opt_for(opt, 1, B), oB = opt_for(opt, 4, B);
+  const float invBN = 1.0f / ((float)B * (float)P.n_items);
+  const float invB = 1.0f / (float)B;
+  float loss_acc = 0.f, reg_acc = 0.f;
+
+  for (int i = threadIdx.x; i < B * c4n; i += kBlock) {
+    const int b = i / c4n, c = i % c4n;
+    reinterpret_cast<float4 *>(h_s + (size_t)b * ldp)[c] = reinterpret_cast<const float4 *>(A.h + (size_t)b * ld)[c];
+    reinterpret_cast<float4 *>(dh_s + (size_t)b * ld)[c] = f4_zero();
+  }
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();                             // previous tile's readers of w_s / dz_s are done (and h_s is loaded)
+    for (int i = threadIdx.x; i < R * c4n; i += kBlock) {
+      const int r = i / c4n, c = i % c4n, n = tile * R + r;
+      reinterpret_cast<float4 *>(w_s + (size_t)r * ldp)[c] =
+          n < P.n_items ? reinterpret_cast<const float4 *>(P.W2T + (size_t)n * ld)[c] : f4_zero();
+    }
+    if (threadIdx.x < R) {
+      const int n = tile * R + threadIdx.x;
+      bias_s[threadIdx.x] = n < P.n_items ? P.b2[n] : 0.f;
+      tbar_s[threadIdx.x] = n < P.n_items ? (float)A.cnt[n] * invB : 0.f;
+    }
+    __syncthreads();
+    // A: dot products, predictions, dz
+    for (int pair = threadIdx.x; pair < B * R; pair += kBlock) {
+      const int r = pair % R, b = pair / R, n = tile * R + r;
+      const float4 *wr = reinterpret_cast<const float4 *>(w_s + (size_t)r * ldp);
+      const float4 *hr = reinterpret_cast<const float4 *>(h_s + (size_t)b * ldp);
+      float d0 = 0.f, d1 = 0.f;
+      int c = 0;
+      for (; c + 1 < c4n; c += 2) { d0 += f4_dot(wr[c], hr[c]); d1 += f4_dot(wr[c + 1], hr[c + 1]); }
+      if (c < c4n) d0 += f4_dot(wr[c], hr[c]);
+      float dz = 0.f;
+      if (n < P.n_items) {
+        const float p = sigmoidf_((d0 + d1) + bias_s[r]);
+        float t = tbar_s[r];
+        if (A.tb) t = (A.tb[(size_t)b * A.Nw + (n >> 5)] >> (n & 31)) & 1u ? 1.0f : 0.0f;
+        float dp;
+        if (A.loss_kind == DRX_LOSS_BCE) {
+          if (WANT_LOSS) loss_acc += bce_elem(t, p);
+          dp = bce_grad(t, p) * invBN;
+        } else {
+          const float df = p - t;
+          if (WANT_LOSS) loss_acc += df * df + (A.tb ? 0.f : t * (1.0f - t));
+          dp = 2.0f * df * invBN;
+        }
+        dz = dp * p * (1.0f - p);
+      }
+      dz_s[b * R + r] = dz;
+    }
+    __syncthreads();
+    // C: dh_s[b,:] += sum_r dz[b,r] * w[r,:]
+    for (int i = threadIdx.x; i < B * c4n; i += kBlock) {
+      const int b = i / c4n, c = i % c4n;
+      float4 a = reinterpret_cast<float4 *>(dh_s + (size_t)b * ld)[c];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) f4_fma(a, dz_s[b * R + rr], reinterpret_cast<const float4 *>(w_s + (size_t)rr * ldp)[c]);
+      reinterpret_cast<float4 *>(dh_s + (size_t)b * ld)[c] = a;
+    }
+    // B: gradient row of each unit (batch order) and its update; one thread per (unit, float4)
+    for (int i = threadIdx.x; i < R * c4n; i += kBlock) {
+      const int r = i / c4n, c = i % c4n, n = tile * R + r;
+      if (n >= P.n_items) continue;
+      float4 g = f4_zero();
+      for (int b = 0; b < B; ++b) f4_fma(g, dz_s[b * R + r], reinterpret_cast<const float4 *>(h_s + (size_t)b * ldp)[c]);
+      float4 p = reinterpret_cast<const float4 *>(w_s + (size_t)r * ldp)[c];
+      float4 *pw = reinterpret_cast<float4 *>(P.W2T + (size_t)n * ld) + c;
+      float4 *p1 = reinterpret_cast<float4 *>(opt.s1[1] + (size_t)n * ld) + c;
+      float4 *p2 = oW.kind == DRX_OPT_ADAM ? reinterpret_cast<float4 *>(opt.s2[1] + (size_t)n * ld) + c : nullptr;
+      float4 m = *p1, v = p2 ? *p2 : f4_zero();
+      reg_acc += f4_dot(p, p);
+      opt_update1(oW, fmaf(oW.rb, p.x, g.x), p.x, m.x, v.x);
+      opt_update1(oW, fmaf(oW.rb, p.y, g.y), p.y, m.y, v.y);
+      opt_update1(oW, fmaf(oW.rb, p.z, g.z), p.z, m.z, v.z);
+      opt_update1(oW, fmaf(oW.rb, p.w, g.w), p.w, m.w, v.w);
+      *pw = p; *p1 = m;
+      if (p2) *p2 = v;
+    }
+    if (threadIdx.x >= kBlock - R) {             // the last R threads (idle in B for every supported width): the unit's bias
+      const int r = threadIdx.x - (kBlock - R), n = tile * R + r;
+      if (n < P.n_items) {
+        float gb2 = 0.f;
+        for (int b = 0; b < B; ++b) gb2 += dz_s[b * R + r];
+        float pb = bias_s[r], m = opt.s1[4][n], v = oB.kind == DRX_OPT_ADAM ? opt.s2[4][n] : 0.f;
+        OptScalars ob = oB; ob.rb = 0.f;
+        opt_update1(ob, gb2, pb, m, v);
+        P.b2[n] = pb; opt.s1[4][n] = m;
+        if (oB.kind == DRX_OPT_ADAM) opt.s2[4][n] = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B * c4n; i += kBlock)
+    reinterpret_cast<float4 *>(A.dh_slab + (size_t)blockIdx.x * B * ld)[i] = reinterpret_cast<float4 *>(dh_s)[i];
+  float lsum = block_sum(loss_acc, red);
+  float rsum = block_sum(reg_acc, red);
+  if (threadIdx.x == 0) { A.loss_part[blockIdx.x] = lsum * invBN; A.reg_part[blockIdx.x] = rsum; }
+}
+
 // dz1[b,:] = (sum_slabs dh) * h (1-h)      one workgroup per batch row, groups stride over slabs
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_hidden_bwd(int ld, int B, int n_slabs, const float *__restrict__ slab,
@@ -813,6 +938,7 @@ struct DenseLayout {
   size_t zero_begin, zero_end;
   int Bw, Nw, Bs, n_sub, out_grid;
   size_t lds_bytes;
+  bool tile_path;               // k_out_dense_tile: the whole batch in LDS
 };
 
 static DenseLayout dense_layout(Carver &cv, const DrxCdaeParams &P, int B, bool per_row) {
@@ -830,6 +956,13 @@ static DenseLayout dense_layout(Carver &cv, const DrxCdaeParams &P, int B, bool 
   L.Bs = Bs;
   L.n_sub = (B + Bs - 1) / Bs;
   L.lds_bytes = fixed + per_b * Bs;
+  L.tile_path = out_tile_lds_floats(B, P.ld) * 4 <= kLdsBudget / 2 && B <= 256;      // two workgroups per CU
+  if (L.tile_path) {
+    const int nt = (P.n_items + kTileR - 1) / kTileR;
+    L.out_grid = nt < kOutGrid ? nt : kOutGrid;
+    L.Bs = B; L.n_sub = 1;
+    L.lds_bytes = out_tile_lds_floats(B, P.ld) * 4;
+  }
   L.Bw = (B + 31) / 32;
   L.Nw = (P.n_items + 31) / 32;
   L.h = cv.take<float>((size_t)B * P.ld);
@@ -1166,7 +1299,17 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
     else                                                                                                             \
       hipLaunchKernelGGL((k_hidden_fwd<G, J, 1>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, \
                          scale, qthr, L.h, aux);                                                                     \
-    if (loss_out) {                                                                                                  \
+    if (L.tile_path) {                                                                                               \
+      if (loss_out) {                                                                                                \
+        DRX_HIP(hipFuncSetAttribute((const void *)k_out_dense_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)L.lds_bytes));                                                              \
+        hipLaunchKernelGGL((k_out_dense_tile<true>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A);  \
+      } else {                                                                                                       \
+        DRX_HIP(hipFuncSetAttribute((const void *)k_out_dense_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)L.lds_bytes));                                                              \
+        hipLaunchKernelGGL((k_out_dense_tile<false>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A); \
+      }                                                                                                              \
+    } else if (loss_out) {                                                                                           \
       DRX_HIP(hipFuncSetAttribute((const void *)k_out_dense<G, J, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)L.lds_bytes));                                                                \
       hipLaunchKernelGGL((k_out_dense<G, J, true>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A);   \
