@@ -352,6 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_out_dense_tile(DrxCdaeParams P, DrxO
       const float4 *hr = reinterpret_cast<const float4 *>(h_s + (size_t)b * ldp);
       float d0 = 0.f, d1 = 0.f;
       int c = 0;
+#pragma unroll 4
       for (; c + 1 < c4n; c += 2) { d0 += f4_dot(wr[c], hr[c]); d1 += f4_dot(wr[c + 1], hr[c + 1]); }
       if (c < c4n) d0 += f4_dot(wr[c], hr[c]);
       float dz = 0.f;
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_out_dense_tile(DrxCdaeParams P, DrxO
       const int r = i / c4n, c = i % c4n, n = tile * R + r;
       if (n >= P.n_items) continue;
       float4 g = f4_zero();
+#pragma unroll 8
       for (int b = 0; b < B; ++b) f4_fma(g, dz_s[b * R + r], reinterpret_cast<const float4 *>(h_s + (size_t)b * ldp)[c]);
       float4 p = reinterpret_cast<const float4 *>(w_s + (size_t)r * ldp)[c];
       float4 *pw = reinterpret_cast<float4 *>(P.W2T + (size_t)n * ld) + c;

@@ -22,8 +22,10 @@ bt, alive = m._engine.make_batch(uid, keep_off=keep_off, keep=keep, q=0.2, n_tou
 for s in range(5):
     m._engine.step_dense(s, bt)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for s in range(5, 305):
-    m._engine.step_dense(s, bt)
-torch.cuda.synchronize()
-print(shape, K, 'device ms/step', (time.perf_counter() - t0) / 300 * 1e3)
+n = int(os.environ.get('DRX_PROF_STEPS', 300))
+for rep in range(int(os.environ.get('DRX_PROF_REPS', 1))):
+    t0 = time.perf_counter()
+    for s in range(5, 5 + n):
+        m._engine.step_dense(s, bt)
+    torch.cuda.synchronize()
+    print(shape, K, 'device ms/step', (time.perf_counter() - t0) / n * 1e3)
