@@ -115,6 +115,7 @@ class CDAE(RecommenderABC):
             # large tables are drawn on the device (same distribution, torch's generator instead of numpy's)
             (self._engine.init_glorot_device if n_params > (1 << 26) else self._engine.init_glorot)(seed)
         self._hist_indptr, self._hist_indices = ds.positives_csr(self.interaction_threshold)
+        self._max_degree = int(np.diff(self._hist_indptr).max()) if len(self._hist_indptr) > 1 else 0
         self._engine.set_history(self._hist_indptr, self._hist_indices)
         if self.mode == 'reference':
             self._engine.init_optimizer('adam', learning_rate, reg_rate)
@@ -163,33 +164,64 @@ class CDAE(RecommenderABC):
             return self._reference_batch(batch_size, kwds.get('batches_after', 1 if kwds.get('more_to_come', False) else 0))
         return self._sampler.sample(batch_size)                  # list of (uid, iid, value) like the reference
 
-    class _Batch(list):
-        """The reference's list of (uid, iid, value) triples, carrying what the fused step needs of it."""
-        uid = keep_off = keep = None
+    class _Batch:
+        """What _sample_batch hands _do_batch in reference mode: the reference's list of (uid, iid, value) triples — built only
+        if somebody looks at it (len / iteration / indexing) — carrying what the fused step needs: the users and the
+        corruption stream's keep flags, already in a pinned staging slot of the engine."""
 
-    def _draw_reference(self, batch_size, ticket=None, gen=0, at=None):
+        def __init__(self, arrays, val_type):
+            self._arrays, self._val_type, self._list = arrays, val_type, None
+            self.uid = self.keep_off = self.keep = self.slot = None
+
+        def _triples(self):
+            if self._list is None:
+                u, i, v, neg = self._arrays
+                vt = self._val_type
+                self._list = [(a, b, 0) if ng else (a, b, vt(c)) for a, b, c, ng in zip(u.tolist(), i.tolist(), v.tolist(), neg.tolist())]
+            return self._list
+
+        def __len__(self):
+            return len(self._arrays[0])
+
+        def __iter__(self):
+            return iter(self._triples())
+
+        def __getitem__(self, k):
+            return self._triples()[k]
+
+    def _draw_reference(self, batch_size, ticket=None, gen=0, at=None, stage=None):
         """Sampler draw + MT19937 corruption stream of one batch (host only).  Inside fit() up to two of these run at once on
         worker threads: the sampler draws happen in ticket order, the corruption streams on different generators (`gen`), each
-        advanced to the word `at` where its batch begins."""
+        advanced to the word `at` where its batch begins; `stage` = a pinned staging slot of the engine to write into."""
         if ticket is None:
-            batch = CDAE._Batch(self._sampler.sample(batch_size))
+            arrays = self._sampler.sample_arrays(batch_size)
         else:
             with self._draw_cv:
                 while self._draw_turn != ticket:
                     self._draw_cv.wait()
                 try:
-                    batch = CDAE._Batch(self._sampler.sample(batch_size))
+                    arrays = self._sampler.sample_arrays(batch_size)
                 finally:
                     self._draw_turn += 1
                     self._draw_cv.notify_all()
-        batch.uid = np.array([s[0] for s in batch], dtype=np.int32)
-        batch.keep_off, batch.keep = self._corruption_keep(batch.uid, gen=gen, at=at)
+        batch = CDAE._Batch(arrays, self._sampler._val_type)
+        if stage is not None:
+            batch.slot, uid_v, ko_v, kp_v = stage
+            uid_v[:] = arrays[0]
+            batch.uid = uid_v
+            batch.keep_off, batch.keep = self._corruption_keep(uid_v, gen=gen, at=at, out=(ko_v, kp_v))
+        else:
+            batch.uid = np.ascontiguousarray(arrays[0], dtype=np.int32)
+            batch.keep_off, batch.keep = self._corruption_keep(batch.uid, gen=gen, at=at)
         return batch
 
     def _submit_draw(self, batch_size):
         ticket, self._draw_ticket = self._draw_ticket, self._draw_ticket + 1
         at, self._mask_pos = self._mask_pos, self._mask_pos + 2 * self.n_items * batch_size
-        return batch_size, self._prefetch_pool().submit(self._draw_reference, batch_size, ticket, ticket % 2, at)
+        stage = None
+        if getattr(self._engine, 'device', None) is not None and self._engine.device.type == 'cuda':
+            stage = self._engine.stage_acquire(batch_size, batch_size * self._max_degree)
+        return batch_size, self._prefetch_pool().submit(self._draw_reference, batch_size, ticket, ticket % 2, at, stage)
 
     def _reference_batch(self, batch_size, batches_after):
         """Inside fit() the host work of batches t+1 and t+2 (sampler, N uniform draws per row) runs on two worker threads
@@ -218,7 +250,7 @@ class CDAE(RecommenderABC):
         v = np.array([float(s[2]) for s in batch_samples], dtype=np.float64)
         return u, i, v
 
-    def _corruption_keep(self, uid, gen=0, at=None):
+    def _corruption_keep(self, uid, gen=0, at=None, out=None):
         """MT19937 corruption stream of cdae.py:63 for the batch rows (C++ host, N draws per row, batch order).  gen / at: which
         generator draws and the word of the stream where this batch begins (default: the next unclaimed one)."""
         from .. import _lib
@@ -232,15 +264,18 @@ class CDAE(RecommenderABC):
         if at > self._mask_at[gen]:
             _lib.lib().drx_rng_discard(rng, at - self._mask_at[gen])
         self._mask_at[gen] = at + 2 * self.n_items * B
-        deg = self._hist_indptr[uid.astype(np.int64) + 1] - self._hist_indptr[uid.astype(np.int64)]
-        keep_off = np.zeros(B + 1, dtype=np.int32)
-        keep = np.zeros(max(int(deg.sum()), 1), dtype=np.uint8)
         uid32 = np.ascontiguousarray(uid, dtype=np.int32)
+        if out is not None:                               # caller's buffers (a pinned staging slot): keep holds B * max degree
+            keep_off, keep = out
+        else:
+            u64 = uid32.astype(np.int64)
+            keep_off = np.zeros(B + 1, dtype=np.int32)
+            keep = np.zeros(max(int((self._hist_indptr[u64 + 1] - self._hist_indptr[u64]).sum()), 1), dtype=np.uint8)
         _lib.check(_lib.lib().drx_rng_corruption_keep(
             rng, self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items,
             uid32.ctypes.data, B, float(self.corruption_level), keep_off.ctypes.data, keep.ctypes.data, len(keep)),
             'drx_rng_corruption_keep')
-        return keep_off, keep
+        return keep_off, (keep if out is None else keep[:max(int(keep_off[B]), 1)])
 
     def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
         eng = self._engine
@@ -249,6 +284,11 @@ class CDAE(RecommenderABC):
             if not want_loss:
                 return None
             return float(loss) if isinstance(loss, float) else float(loss[0].item())
+        if self.mode == 'reference' and getattr(batch_samples, 'slot', None) is not None:     # already in pinned memory
+            bt, alive = eng.make_batch_staged(batch_samples.slot, len(batch_samples.uid), int(batch_samples.keep_off[-1]),
+                                              self.corruption_level)
+            loss = eng.step_dense(step, bt, self._loss_name, self.loss_targets, want_loss=want_loss)
+            return float(loss.sum().item()) if want_loss else None
         if self.mode == 'reference' and getattr(batch_samples, 'keep', None) is not None:
             uid, keep_off, keep = batch_samples.uid, batch_samples.keep_off, batch_samples.keep      # prepared by _sample_batch
             bt, alive = eng.make_batch(uid, keep_off=keep_off, keep=keep, q=self.corruption_level, n_touch_slots=int(keep_off[-1]))
