@@ -11,8 +11,6 @@ mode='sampled' is the engine's throughput mode (CDAE paper's negative sampling, 
 the sampled (uid, iid, value) triple selects ONE output unit with target 1[value >= threshold]; sparse Adagrad (or lazy
 Adam) touches only the rows involved; corruption comes from a counter-based mask evaluated on the device.
 """
-import threading
-
 import numpy as np
 
 from .recommender_abc import RecommenderABC
@@ -102,10 +100,8 @@ class CDAE(RecommenderABC):
             return self._pre_fit_distributed(world[0], world[1], learning_rate, neg_ratio, reg_rate, **kwds)
         self._engine = CdaeEngine(self.n_users, self.n_items, self.hidden_factors, device=self.device)
         self._pipeline = None
-        for _, fut in (getattr(self, '_pending', None) or []):      # draws an early-stopped fit() left in flight
-            fut.result()
+        self._close_drawahead()                                      # (draws an early-stopped fit() left in flight included)
         self._pending = None
-        self._draw_cv = threading.Condition()
         weights = kwds.get('initial_weights')
         if weights is not None:                      # injected weights (TF's GlorotUniform stream is not reproducible)
             self._engine.set_params(**weights)
@@ -131,8 +127,24 @@ class CDAE(RecommenderABC):
         self._mask_rngs = [self._mask_rng, L.drx_rng_create(int(seed))]
         self._mask_at = [0, 0]                          # words each generator has consumed
         self._mask_pos = 0                              # where the next batch begins
-        self._draw_ticket = self._draw_turn = 0
+        self._draw_ticket = 0
+        self._drawahead = L.drx_drawahead_create(self._sampler._host._h, self._mask_rngs[0], self._mask_rngs[1],
+                                                 self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items)
         self._mask_seed = int(seed)
+
+    def _close_drawahead(self):
+        if getattr(self, '_drawahead', None):
+            from .. import _lib
+            self._drain_draws()
+            _lib.lib().drx_drawahead_destroy(self._drawahead)
+        self._drawahead = None
+        self._pending = None
+
+    def __del__(self):
+        try:
+            self._close_drawahead()
+        except Exception:
+            pass
 
     def _restore_engine(self, params):
         from ..engine import CdaeEngine
@@ -189,54 +201,62 @@ class CDAE(RecommenderABC):
         def __getitem__(self, k):
             return self._triples()[k]
 
-    def _draw_reference(self, batch_size, ticket=None, gen=0, at=None, stage=None):
-        """Sampler draw + MT19937 corruption stream of one batch (host only).  Inside fit() up to two of these run at once on
-        worker threads: the sampler draws happen in ticket order, the corruption streams on different generators (`gen`), each
-        advanced to the word `at` where its batch begins; `stage` = a pinned staging slot of the engine to write into."""
-        if ticket is None:
-            arrays = self._sampler.sample_arrays(batch_size)
+    def _submit_draw(self, batch_size):
+        """Claims the next batch's place in both streams (sampler ticket, corruption words) and its buffers — a pinned staging
+        slot of the engine for users / offsets / keep flags — and hands the job to the native draw-ahead worker of its
+        generator (drx_drawahead_submit).  Returns what _finish_draw needs."""
+        from .. import _lib
+        B = int(batch_size)
+        ticket, self._draw_ticket = self._draw_ticket, self._draw_ticket + 1
+        gen = ticket % 2
+        at, self._mask_pos = self._mask_pos, self._mask_pos + 2 * self.n_items * B
+        discard, self._mask_at[gen] = at - self._mask_at[gen], at + 2 * self.n_items * B
+        cap = max(B * self._max_degree, 1)
+        if self._engine.device.type == 'cuda':
+            stage = self._engine.stage_acquire(B, cap)
         else:
-            with self._draw_cv:
-                while self._draw_turn != ticket:
-                    self._draw_cv.wait()
-                try:
-                    arrays = self._sampler.sample_arrays(batch_size)
-                finally:
-                    self._draw_turn += 1
-                    self._draw_cv.notify_all()
-        batch = CDAE._Batch(arrays, self._sampler._val_type)
-        if stage is not None:
-            batch.slot, uid_v, ko_v, kp_v = stage
-            uid_v[:] = arrays[0]
-            batch.uid = uid_v
-            batch.keep_off, batch.keep = self._corruption_keep(uid_v, gen=gen, at=at, out=(ko_v, kp_v))
-        else:
-            batch.uid = np.ascontiguousarray(arrays[0], dtype=np.int32)
-            batch.keep_off, batch.keep = self._corruption_keep(batch.uid, gen=gen, at=at)
+            stage = (None, np.empty(B, np.int32), np.empty(B + 1, np.int32), np.empty(cap, np.uint8))
+        extra = (np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8))
+        _, uid_v, ko_v, kp_v = stage
+        job = _lib.lib().drx_drawahead_submit(self._drawahead, gen, ticket, discard, B, float(self.corruption_level),
+                                              uid_v.ctypes.data, extra[0].ctypes.data, extra[1].ctypes.data, extra[2].ctypes.data,
+                                              ko_v.ctypes.data, kp_v.ctypes.data, len(kp_v))
+        if job < 0:
+            _lib.check(int(job), 'drx_drawahead_submit')
+        return B, gen, int(job), stage, extra
+
+    def _finish_draw(self, entry):
+        from .. import _lib
+        B, gen, job, stage, extra = entry
+        _lib.check(_lib.lib().drx_drawahead_wait(self._drawahead, gen, job), 'drx_cdae_reference_draw')
+        slot, uid_v, ko_v, kp_v = stage
+        batch = CDAE._Batch((uid_v,) + extra, self._sampler._val_type)
+        batch.slot, batch.uid, batch.keep_off = slot, uid_v, ko_v
+        batch.keep = kp_v[:max(int(ko_v[B]), 1)]
         return batch
 
-    def _submit_draw(self, batch_size):
-        ticket, self._draw_ticket = self._draw_ticket, self._draw_ticket + 1
-        at, self._mask_pos = self._mask_pos, self._mask_pos + 2 * self.n_items * batch_size
-        stage = None
-        if getattr(self._engine, 'device', None) is not None and self._engine.device.type == 'cuda':
-            stage = self._engine.stage_acquire(batch_size, batch_size * self._max_degree)
-        return batch_size, self._prefetch_pool().submit(self._draw_reference, batch_size, ticket, ticket % 2, at, stage)
+    def _drain_draws(self):
+        """Waits for (does not consume) the draws in flight: whoever touches the sampler or a generator directly comes after."""
+        from .. import _lib
+        for B, gen, job, _, _ in (getattr(self, '_pending', None) or []):
+            _lib.lib().drx_drawahead_wait(self._drawahead, gen, job)
+
+    _DRAW_AHEAD = 4        # batches in flight: two per worker
 
     def _reference_batch(self, batch_size, batches_after):
-        """Inside fit() the host work of batches t+1 and t+2 (sampler, N uniform draws per row) runs on two worker threads
-        while batch t trains — the C++ calls release the GIL; the streams are still consumed strictly batch by batch, and
-        nothing is drawn beyond the last epoch."""
+        """Inside fit() the host work of the next batches (sampler triples, N uniform draws per row) runs on the two native
+        draw-ahead threads of libdrx while batch t trains; the streams are still consumed strictly batch by batch, and nothing
+        is drawn beyond the last epoch."""
         pending = getattr(self, '_pending', None) or []
         self._pending = None
         if pending and pending[0][0] == batch_size:
-            batch = pending.pop(0)[1].result()
+            batch = self._finish_draw(pending.pop(0))
         else:
-            for _, fut in pending:                                 # (batches of another size were drawn: consumed, like draws)
-                fut.result()
+            for entry in pending:                                  # (batches of another size were drawn: consumed, like draws)
+                self._finish_draw(entry)
             pending = []
-            batch = self._submit_draw(batch_size)[1].result()      # through the same bookkeeping, for the stream positions
-        while len(pending) < min(2, batches_after):
+            batch = self._finish_draw(self._submit_draw(batch_size))
+        while len(pending) < min(self._DRAW_AHEAD, batches_after):
             pending.append(self._submit_draw(batch_size))
         self._pending = pending or None
         return batch
@@ -256,8 +276,7 @@ class CDAE(RecommenderABC):
         from .. import _lib
         B = len(uid)
         if at is None:                                   # a draw outside fit()'s run-ahead: after whatever is in flight
-            for _, fut in (getattr(self, '_pending', None) or []):
-                fut.result()
+            self._drain_draws()
             at, self._mask_pos = self._mask_pos, self._mask_pos + 2 * self.n_items * B
         rng = self._mask_rngs[gen]
         assert at >= self._mask_at[gen], 'corruption stream claimed out of order'
@@ -285,9 +304,9 @@ class CDAE(RecommenderABC):
                 return None
             return float(loss) if isinstance(loss, float) else float(loss[0].item())
         if self.mode == 'reference' and getattr(batch_samples, 'slot', None) is not None:     # already in pinned memory
-            bt, alive = eng.make_batch_staged(batch_samples.slot, len(batch_samples.uid), int(batch_samples.keep_off[-1]),
-                                              self.corruption_level)
+            bt = eng.batch_in_slot(batch_samples.slot, len(batch_samples.uid), int(batch_samples.keep_off[-1]), self.corruption_level)
             loss = eng.step_dense(step, bt, self._loss_name, self.loss_targets, want_loss=want_loss)
+            eng.stage_release(batch_samples.slot)
             return float(loss.sum().item()) if want_loss else None
         if self.mode == 'reference' and getattr(batch_samples, 'keep', None) is not None:
             uid, keep_off, keep = batch_samples.uid, batch_samples.keep_off, batch_samples.keep      # prepared by _sample_batch

@@ -146,6 +146,14 @@ SIGNATURES = {
     'drx_sampler_create': (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_double, C.c_int64]),
     'drx_sampler_sample': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'drx_cdae_reference_draw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int64]),
+    'drx_drawahead_create': (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    'drx_drawahead_submit': (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    'drx_drawahead_wait': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    'drx_drawahead_destroy': (None, [C.c_void_p]),
     'drx_sampler_draw': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_sampler_destroy': (None, [C.c_void_p]),
     'drx_cdae_kshard_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,

@@ -41,7 +41,7 @@ def build(force=False, verbose=True):
         if src.endswith('.hip'):
             cmd = [HIPCC, f'--offload-arch={ARCH}'] + COMMON + ['-c', sp, '-o', op]
         else:                   # host-only code (samplers, MT19937 streams): g++, so that function multiversioning is available
-            cmd = [HOSTCXX] + COMMON + ['-c', sp, '-o', op]
+            cmd = [HOSTCXX, '-pthread'] + COMMON + ['-c', sp, '-o', op]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError(f'hipcc failed on {src}')
     if force or procs or not _newer(LIB, objs):
-        cmd = [HIPCC, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [HIPCC, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-pthread', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

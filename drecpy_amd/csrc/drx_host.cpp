@@ -2,7 +2,13 @@
 // corruption stream.  These replace the O(nnz)-per-draw pandas scans of DRecPy/Dataset/mem_dataset.py:111-163
 // and the N-long Python list comprehensions of DRecPy/Recommender/cdae.py:61-63 while producing bit-identical
 // streams (checked against stdlib `random.Random` and the golden vectors generated from the reference).
+#include <sched.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -422,6 +428,137 @@ int drx_sampler_draw(DrxSampler *s, int32_t kind, int32_t n, int32_t *h_uid_out,
     }
   }
   return DRX_OK;
+}
+
+// One reference-mode batch in ONE call (so that a worker thread of fit() takes and drops the interpreter lock once): waits until the
+// shared counter *turn equals `ticket` (sampler draws of concurrent workers happen in submission order), draws the B triples,
+// passes the turn on, advances this worker's corruption generator by discard_words (the batches other workers draw) and
+// produces the keep flags of the rows.
+int drx_cdae_reference_draw(DrxSampler *smp, DrxRng *rng, int64_t *turn, int64_t ticket, uint64_t discard_words,
+                            const int64_t *h_indptr, const int32_t *h_indices, int32_t n_items, int32_t B, double q,
+                            int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out, uint8_t *h_neg_out, int32_t *h_keep_off,
+                            uint8_t *h_keep, int64_t keep_capacity) {
+  if (!smp || !rng || !turn) return DRX_EINVAL;
+  for (unsigned spins = 0; __atomic_load_n(turn, __ATOMIC_ACQUIRE) != ticket; ++spins)
+    if (spins > 64) sched_yield();
+  const int rc = drx_sampler_draw(smp, DRX_DRAW_MIXED, B, h_uid_out, h_iid_out, h_val_out, h_neg_out);
+  __atomic_store_n(turn, ticket + 1, __ATOMIC_RELEASE);
+  if (rc) return rc;
+  rng->mt.skip(discard_words);
+  return drx_rng_corruption_keep(rng, h_indptr, h_indices, n_items, h_uid_out, B, q, h_keep_off, h_keep, keep_capacity);
+}
+
+// ---- draw-ahead workers of reference-mode fit() ------------------------------------------------------------------------------
+// Two native threads, one per corruption generator, each fed through a small ring of jobs.  They poll for work for a few hundred
+// microseconds before going to sleep and the consumer polls for results the same way: during a fit a batch is needed every
+// 40-70 us, and handing work to a sleeping thread (futex wake-up on an idle core) costs about as much as the batch itself —
+// with Python futures the same loop ran anywhere between 65 and 180 us per step depending on where the threads happened to sit.
+struct DrawJob {
+  int64_t ticket;
+  uint64_t discard;
+  int32_t B;
+  double q;
+  int32_t *uid, *iid;
+  double *val;
+  uint8_t *neg;
+  int32_t *keep_off;
+  uint8_t *keep;
+  int64_t keep_cap;
+  int rc;
+};
+
+struct DrxDrawAhead {
+  static constexpr int kRing = 8;
+  static constexpr int kPollUs = 400;
+  DrxSampler *smp;
+  DrxRng *rng[2];
+  const int64_t *indptr;
+  const int32_t *indices;
+  int32_t n_items;
+  int64_t turn = 0;                      // whose sampler draw is next (tickets are handed out in submission order)
+  std::atomic<bool> stop{false};
+  struct Worker {
+    std::thread th;
+    DrawJob ring[kRing];
+    std::atomic<int64_t> submitted{0}, done{0};
+    std::atomic<bool> sleeping{false};
+    std::mutex mu;
+    std::condition_variable cv;
+  } w[2];
+
+  void run(int g) {
+    Worker &me = w[g];
+    for (int64_t next = 0;; ++next) {
+      auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0; me.submitted.load() <= next; ++spins) {
+        if (stop.load()) return;
+        __builtin_ia32_pause();
+        if ((spins & 255) == 255 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kPollUs) {
+          std::unique_lock<std::mutex> lk(me.mu);
+          me.sleeping.store(true);
+          me.cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return me.submitted.load() > next || stop.load(); });
+          me.sleeping.store(false);
+          t0 = std::chrono::steady_clock::now();
+        }
+      }
+      DrawJob &j = me.ring[next % kRing];
+      j.rc = drx_cdae_reference_draw(smp, rng[g], &turn, j.ticket, j.discard, indptr, indices, n_items, j.B, j.q, j.uid, j.iid,
+                                     j.val, j.neg, j.keep_off, j.keep, j.keep_cap);
+      me.done.store(next + 1);
+    }
+  }
+};
+
+DrxDrawAhead *drx_drawahead_create(DrxSampler *smp, DrxRng *rng0, DrxRng *rng1, const int64_t *h_indptr, const int32_t *h_indices,
+                                   int32_t n_items) {
+  if (!smp || !rng0 || !rng1 || !h_indptr || !h_indices) return nullptr;
+  DrxDrawAhead *d = new (std::nothrow) DrxDrawAhead;
+  if (!d) return nullptr;
+  d->smp = smp; d->rng[0] = rng0; d->rng[1] = rng1;
+  d->indptr = h_indptr; d->indices = h_indices; d->n_items = n_items;
+  for (int g = 0; g < 2; ++g) d->w[g].th = std::thread([d, g] { d->run(g); });
+  return d;
+}
+
+int64_t drx_drawahead_submit(DrxDrawAhead *d, int32_t gen, int64_t ticket, uint64_t discard_words, int32_t B, double q,
+                             int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out, uint8_t *h_neg_out, int32_t *h_keep_off,
+                             uint8_t *h_keep, int64_t keep_capacity) {
+  if (!d || gen < 0 || gen > 1 || B < 1 || !h_uid_out || !h_iid_out || !h_val_out || !h_keep_off || !h_keep) return DRX_EINVAL;
+  DrxDrawAhead::Worker &wk = d->w[gen];
+  const int64_t job = wk.submitted.load();
+  if (job - wk.done.load() >= DrxDrawAhead::kRing) return DRX_ERETRY;          // ring full: wait for an earlier job first
+  wk.ring[job % DrxDrawAhead::kRing] = DrawJob{ticket, discard_words, B, q, h_uid_out, h_iid_out, h_val_out, h_neg_out, h_keep_off,
+                                                h_keep, keep_capacity, 0};
+  wk.submitted.store(job + 1);
+  if (wk.sleeping.load()) {
+    std::lock_guard<std::mutex> lk(wk.mu);
+    wk.cv.notify_one();
+  }
+  return job;
+}
+
+int drx_drawahead_wait(DrxDrawAhead *d, int32_t gen, int64_t job) {
+  if (!d || gen < 0 || gen > 1 || job < 0 || job >= d->w[gen].submitted.load()) return DRX_EINVAL;
+  DrxDrawAhead::Worker &wk = d->w[gen];
+  auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; wk.done.load() <= job; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 255) == 255 &&
+        std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > DrxDrawAhead::kPollUs)
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  return wk.ring[job % DrxDrawAhead::kRing].rc;
+}
+
+void drx_drawahead_destroy(DrxDrawAhead *d) {
+  if (!d) return;
+  d->stop.store(true);
+  for (int g = 0; g < 2; ++g) {
+    { std::lock_guard<std::mutex> lk(d->w[g].mu); d->w[g].cv.notify_all(); }
+    if (d->w[g].th.joinable()) d->w[g].th.join();
+  }
+  delete d;
 }
 
 int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out) {

@@ -221,13 +221,13 @@ class CdaeEngine:
     def stage_acquire(self, B, keep_capacity):
         """A pinned staging slot for a user-only batch with explicit keep flags, laid out [uid int32 B | keep_off int32 B+1 |
         keep uint8 <= keep_capacity]: returns (slot, uid view, keep_off view, keep view) — numpy views a worker thread may fill
-        (e.g. through drx_rng_corruption_keep) while the main thread does something else.  The slot's previous upload has
-        finished when this returns."""
+        (e.g. through drx_rng_corruption_keep) while the main thread does something else.  The step that last read the slot
+        has finished when this returns."""
         off_ko = (4 * B + 15) & ~15
         off_kp = (off_ko + 4 * (B + 1) + 15) & ~15
         total = off_kp + max(int(keep_capacity), 1)
-        st = self.__dict__.setdefault('_slots', {'i': 0, 'host': [None] * 6, 'ev': [None] * 6})
-        k = st['i'] % 6
+        st = self.__dict__.setdefault('_slots', {'i': 0, 'host': [None] * 8, 'ev': [None] * 8})
+        k = st['i'] % 8
         st['i'] += 1
         if st['host'][k] is None or st['host'][k].numel() < total:
             st['host'][k] = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
@@ -239,18 +239,19 @@ class CdaeEngine:
         return ((k, off_ko, off_kp), hv[:4 * B].view(np.int32), hv[off_ko:off_ko + 4 * (B + 1)].view(np.int32),
                 hv[off_kp:off_kp + max(int(keep_capacity), 1)])
 
-    def make_batch_staged(self, slot, B, n_keep, q):
-        """Uploads a filled staging slot (ONE asynchronous copy of its used prefix) and returns (Batch, keep-alive)."""
+    def batch_in_slot(self, slot, B, n_keep, q):
+        """Batch struct over a filled staging slot, WITHOUT a copy: pinned host memory is addressable from the device, and a
+        batch of 64 users is a few KB that each workgroup of the gather kernel reads once — cheaper than an upload, which the
+        runtime performs only once the stream has drained.  Call stage_release(slot) after queueing the step that reads it."""
         k, off_ko, off_kp = slot
+        base = self._slots['host'][k].data_ptr()
+        return Batch(B, base, None, None, base + off_ko, base + off_kp, 0, float(q), int(n_keep))
+
+    def stage_release(self, slot):
+        """The work queued so far on the current stream is the last to read the slot (stage_acquire waits for it)."""
         st = self._slots
-        used = off_kp + max(int(n_keep), 1)
-        dev = torch.empty(used, dtype=torch.uint8, device=self.device)
-        dev.copy_(st['host'][k][:used], non_blocking=True)
-        st['ev'][k] = torch.cuda.Event()
-        st['ev'][k].record(torch.cuda.current_stream(self.device))
-        base = dev.data_ptr()
-        bt = Batch(B, base, None, None, base + off_ko, base + off_kp, 0, float(q), int(n_keep))
-        return bt, (dev,)
+        st['ev'][slot[0]] = torch.cuda.Event()
+        st['ev'][slot[0]].record(torch.cuda.current_stream(self.device))
 
     def make_batch(self, uid, iid=None, y=None, keep_off=None, keep=None, q=0.0, mask_seed=0, n_touch_slots=None):
         """Uploads (if needed) one batch and returns (Batch struct, keep-alive tensors)."""

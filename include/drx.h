@@ -414,6 +414,29 @@ int drx_rng_corruption_keep(DrxRng *r, const int64_t *h_indptr, const int32_t *h
                             const int32_t *h_uid, int32_t B, double q,
                             int32_t *h_keep_off, uint8_t *h_keep, int64_t keep_capacity);
 
+/* One reference-mode CDAE batch in one call, for worker threads drawing ahead of the training step (cdae.py:47-63: B sampler
+ * triples, then N uniform draws per batch row): waits until *turn == ticket, draws (DRX_DRAW_MIXED), stores ticket + 1 into
+ * *turn, advances `rng` by discard_words outputs (batches drawn by other workers from their own generator of the same seed)
+ * and fills keep_off / keep like drx_rng_corruption_keep. */
+int drx_cdae_reference_draw(DrxSampler *smp, DrxRng *rng, int64_t *turn, int64_t ticket, uint64_t discard_words,
+                            const int64_t *h_indptr, const int32_t *h_indices, int32_t n_items, int32_t B, double q,
+                            int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out, uint8_t *h_neg_out, int32_t *h_keep_off,
+                            uint8_t *h_keep, int64_t keep_capacity);
+
+/* Draw-ahead workers for the loop above: two native threads (one per corruption generator `gen`), each running the jobs submitted
+ * to it in order through drx_cdae_reference_draw with a turn counter of their own (tickets 0, 1, 2, ... in submission order
+ * across both).  They and drx_drawahead_wait poll for a few hundred microseconds before sleeping, so a fit() that needs a batch
+ * every 40-70 us never pays a thread wake-up.  The buffers of a job belong to the caller and must stay valid until its wait
+ * returns; at most 8 jobs per generator may be outstanding (DRX_ERETRY otherwise).  submit returns the job's index (>= 0). */
+typedef struct DrxDrawAhead DrxDrawAhead;
+DrxDrawAhead *drx_drawahead_create(DrxSampler *smp, DrxRng *rng0, DrxRng *rng1, const int64_t *h_indptr, const int32_t *h_indices,
+                                   int32_t n_items);
+int64_t drx_drawahead_submit(DrxDrawAhead *d, int32_t gen, int64_t ticket, uint64_t discard_words, int32_t B, double q,
+                             int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out, uint8_t *h_neg_out, int32_t *h_keep_off,
+                             uint8_t *h_keep, int64_t keep_capacity);
+int drx_drawahead_wait(DrxDrawAhead *d, int32_t gen, int64_t job);
+void drx_drawahead_destroy(DrxDrawAhead *d);
+
 #ifdef __cplusplus
 }
 #endif

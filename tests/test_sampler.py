@@ -141,6 +141,63 @@ def test_two_generators_leapfrogging_the_corruption_stream_equal_one():
         L.drx_rng_destroy(r)
 
 
+def test_native_draw_ahead_workers_reproduce_the_sequential_streams():
+    """drx_drawahead_*: the two native worker threads of reference-mode fit() (sampler triples in ticket order, each worker's
+    corruption generator advanced past the other's batches) against one sampler + one generator drawing batch after batch."""
+    from drecpy_amd import _lib
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Sampler import PointSampler
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    U, N, B, q, T = 60, 500, 32, 0.2, 11
+    rows = {(int(u), int(i)) for u, i in zip(rng.integers(0, U, 1500), rng.integers(0, N, 1500))}
+    frame = {'user': [r[0] for r in rows], 'item': [r[1] for r in rows], 'interaction': [1 + (r[0] + r[1]) % 5 for r in rows]}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    ds.assign_internal_ids()
+    indptr, indices = ds.positives_csr(1e-3)
+    n_items, max_deg = ds.count_unique('iid'), int(np.diff(indptr).max())
+
+    def buffers():
+        return (np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8), np.empty(B + 1, np.int32),
+                np.empty(B * max_deg, np.uint8))
+
+    # sequential statement: one sampler, one generator
+    s1, g1, want = PointSampler(ds, 5, 1e-3, 10), L.drx_rng_create(10), []
+    for t in range(T):
+        u, i, v, ng = s1.sample_arrays(B)
+        ko, kp = np.zeros(B + 1, np.int32), np.zeros(B * max_deg, np.uint8)
+        assert L.drx_rng_corruption_keep(g1, indptr.ctypes.data, indices.ctypes.data, n_items, u.ctypes.data, B, q, ko.ctypes.data,
+                                         kp.ctypes.data, len(kp)) == 0
+        want.append((u.copy(), i.copy(), v.copy(), ng.copy(), ko.copy(), kp[:ko[-1]].copy()))
+    # the workers: up to four jobs in flight, submitted in ticket order, finished in ticket order
+    s2, gens, at = PointSampler(ds, 5, 1e-3, 10), [L.drx_rng_create(10), L.drx_rng_create(10)], [0, 0]
+    h = L.drx_drawahead_create(s2._host._h, gens[0], gens[1], indptr.ctypes.data, indices.ctypes.data, n_items)
+    assert h
+    flight, got = [], []
+
+    def finish():
+        g, job, buf = flight.pop(0)
+        assert L.drx_drawahead_wait(h, g, job) == 0
+        got.append((buf[0].copy(), buf[1].copy(), buf[2].copy(), buf[3].copy(), buf[4].copy(), buf[5][:buf[4][-1]].copy()))
+
+    for t in range(T):
+        g, begin, buf = t % 2, t * 2 * n_items * B, buffers()
+        job = L.drx_drawahead_submit(h, g, t, begin - at[g], B, q, *[b.ctypes.data for b in buf], len(buf[5]))
+        assert job >= 0
+        at[g] = begin + 2 * n_items * B
+        flight.append((g, job, buf))
+        if len(flight) == 4:
+            finish()
+    while flight:
+        finish()
+    L.drx_drawahead_destroy(h)
+    for a, b in zip(want, got):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    for r in [g1] + gens:
+        L.drx_rng_destroy(r)
+
+
 def test_library_exports_every_declared_symbol():
     import re, os
     from drecpy_amd import _lib
