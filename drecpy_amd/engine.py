@@ -139,15 +139,19 @@ class CdaeEngine:
             self.s2 = None
 
     def _optim(self, alphas):
-        o = Optim()
-        o.kind = self.opt_kind
-        o.lr, o.reg_rate = self.lr, self.reg_rate
-        o.beta1, o.beta2 = ADAM_B1, ADAM_B2
-        o.eps = ADAM_EPS if self.opt_kind == _lib.OPT_ADAM else ADAGRAD_EPS
-        for j in range(5):
-            o.alpha[j] = alphas[j]
-            o.s1[j] = self.s1[j].data_ptr()
-            o.s2[j] = self.s2[j].data_ptr() if self.s2 is not None else 0
+        # the struct is kept between steps (the slot tensors live as long as the optimizer): only the five lr_t change
+        o = getattr(self, '_optim_struct', None)
+        if o is None or self._optim_for is not self.s1:
+            o = Optim()
+            o.kind = self.opt_kind
+            o.lr, o.reg_rate = self.lr, self.reg_rate
+            o.beta1, o.beta2 = ADAM_B1, ADAM_B2
+            o.eps = ADAM_EPS if self.opt_kind == _lib.OPT_ADAM else ADAGRAD_EPS
+            for j in range(5):
+                o.s1[j] = self.s1[j].data_ptr()
+                o.s2[j] = self.s2[j].data_ptr() if self.s2 is not None else 0
+            self._optim_struct, self._optim_for = o, self.s1
+        o.alpha[0], o.alpha[1], o.alpha[2], o.alpha[3], o.alpha[4] = alphas
         return o
 
     @staticmethod
@@ -278,6 +282,12 @@ class CdaeEngine:
         return bt, (uid, iid, y, keep_off, keep)
 
     def _ensure_scratch(self, B, n_touch_slots, dense=False):
+        if dense:                      # the dense step's scratch depends on B only
+            if getattr(self, '_dense_scratch_B', None) == B and self._scratch is not None:
+                return self._scratch
+            self._dense_scratch_B = B
+        else:
+            self._dense_scratch_B = None
         need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, n_touch_slots, 1 if dense else 0)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = None
