@@ -214,9 +214,10 @@ class CDAE(RecommenderABC):
         cap = max(B * self._max_degree, 1)
         if self._engine.device.type == 'cuda':
             stage = self._engine.stage_acquire(B, cap)
+            extra = self._engine.stage_extra(stage[0])
         else:
             stage = (None, np.empty(B, np.int32), np.empty(B + 1, np.int32), np.empty(cap, np.uint8))
-        extra = (np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8))
+            extra = (np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8))
         _, uid_v, ko_v, kp_v = stage
         job = _lib.lib().drx_drawahead_submit(self._drawahead, gen, ticket, discard, B, float(self.corruption_level),
                                               uid_v.ctypes.data, extra[0].ctypes.data, extra[1].ctypes.data, extra[2].ctypes.data,

@@ -230,18 +230,28 @@ class CdaeEngine:
         off_ko = (4 * B + 15) & ~15
         off_kp = (off_ko + 4 * (B + 1) + 15) & ~15
         total = off_kp + max(int(keep_capacity), 1)
-        st = self.__dict__.setdefault('_slots', {'i': 0, 'host': [None] * 8, 'ev': [None] * 8})
+        st = self.__dict__.setdefault('_slots', {'i': 0, 'host': [None] * 8, 'ev': [None] * 8, 'busy': [False] * 8, 'views': [None] * 8})
         k = st['i'] % 8
         st['i'] += 1
         if st['host'][k] is None or st['host'][k].numel() < total:
             st['host'][k] = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
-            st['ev'][k] = None
-        if st['ev'][k] is not None:
+            st['ev'][k] = torch.cuda.Event()
+            st['busy'][k] = False
+            st['views'][k] = None
+        if st['busy'][k]:
             st['ev'][k].synchronize()
-            st['ev'][k] = None
-        hv = st['host'][k].numpy()
-        return ((k, off_ko, off_kp), hv[:4 * B].view(np.int32), hv[off_ko:off_ko + 4 * (B + 1)].view(np.int32),
-                hv[off_kp:off_kp + max(int(keep_capacity), 1)])
+            st['busy'][k] = False
+        v = st['views'][k]
+        if v is None or v[0] != (B, int(keep_capacity)):      # the views of a slot are rebuilt only when the batch shape changes
+            hv = st['host'][k].numpy()
+            v = st['views'][k] = ((B, int(keep_capacity)), (k, off_ko, off_kp), hv[:4 * B].view(np.int32),
+                                  hv[off_ko:off_ko + 4 * (B + 1)].view(np.int32), hv[off_kp:off_kp + max(int(keep_capacity), 1)],
+                                  (np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8)))
+        return v[1], v[2], v[3], v[4]
+
+    def stage_extra(self, slot):
+        """Per-slot host arrays (iid int32 [B], value float64 [B], is_negative uint8 [B]) for what else a draw produces."""
+        return self._slots['views'][slot[0]][5]
 
     def batch_in_slot(self, slot, B, n_keep, q):
         """Batch struct over a filled staging slot, WITHOUT a copy: pinned host memory is addressable from the device, and a
@@ -254,8 +264,8 @@ class CdaeEngine:
     def stage_release(self, slot):
         """The work queued so far on the current stream is the last to read the slot (stage_acquire waits for it)."""
         st = self._slots
-        st['ev'][slot[0]] = torch.cuda.Event()
         st['ev'][slot[0]].record(torch.cuda.current_stream(self.device))
+        st['busy'][slot[0]] = True
 
     def make_batch(self, uid, iid=None, y=None, keep_off=None, keep=None, q=0.0, mask_seed=0, n_touch_slots=None):
         """Uploads (if needed) one batch and returns (Batch struct, keep-alive tensors)."""
