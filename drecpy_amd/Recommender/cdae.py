@@ -68,7 +68,8 @@ class CDAE(RecommenderABC):
         seed = self.seed if self.seed is not None else 0
         m = ColumnShardedCdae(self.n_users, self.n_items, self.hidden_factors, rank, world, self.device, self._hist_indptr,
                               self._hist_indices, seed=seed, lr=learning_rate, reg=reg_rate, optimizer=self.sparse_optimizer,
-                              loss=self._loss_name, q=self.corruption_level, cpu_staging=(dist.get_backend() == 'gloo'))
+                              loss=self._loss_name, q=self.corruption_level, cpu_staging=(dist.get_backend() == 'gloo'),
+                              prepare=kwds.get('prepare', 'turns' if world >= 4 else 'local'))     # who sorts the touch lists: dist.py
         weights = kwds.get('initial_weights')
         n_params = (2 * self.n_items + self.n_users) * self.hidden_factors
         if weights is None and n_params <= (1 << 26):                # the single-GPU initialisation, sliced

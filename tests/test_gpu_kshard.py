@@ -292,7 +292,7 @@ def test_pipelines_of_several_processes_equal_the_single_process_run(tmp_path, w
         np.testing.assert_allclose(got['b_'], want['b_'], rtol=0, atol=2e-6)
 
 
-def _fit_worker(rank, world, port, out):
+def _fit_worker(rank, world, port, out, prepare='local'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -301,7 +301,7 @@ def _fit_worker(rank, world, port, out):
     from drecpy_amd.Recommender import CDAE
     ds = InteractionDataset.read_df(_frame(), verbose=False)
     model = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False)
-    model.fit(ds, epochs=20, batch_size=384, learning_rate=0.05, reg_rate=1e-3, neg_ratio=5)
+    model.fit(ds, epochs=20, batch_size=384, learning_rate=0.05, reg_rate=1e-3, neg_ratio=5, prepare=prepare)
     torch.cuda.synchronize()
     frame = _frame()
     torch.save({'params': model._engine.get_params(), 'pred': float(model.predict(frame['user'][0], frame['item'][1])),
@@ -310,15 +310,16 @@ def _fit_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path):
+@pytest.mark.parametrize('prepare', ['local', 'turns'])
+def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path, prepare):
     """CDAE.fit(mode='sampled', device_sampler=True) as two processes of one job (column-sharded training, then every rank
     holds the whole model): parameters, a prediction and a ranking equal the single-process fit with the same seed."""
     from test_gpu_fit import _frame
     from drecpy_amd.Dataset import InteractionDataset
     from drecpy_amd.Recommender import CDAE
     out = str(tmp_path / 'fit')
-    port = 29900 + (os.getpid() % 90)
-    mp.spawn(_fit_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29900 + (os.getpid() % 90) + (5 if prepare == 'turns' else 0)
+    mp.spawn(_fit_worker, args=(2, port, out, prepare), nprocs=2, join=True)
     frame = _frame()
     ds = InteractionDataset.read_df(frame, verbose=False)
     single = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False)
