@@ -138,13 +138,25 @@ class CaserEngine:
     # ---- one training step ---------------------------------------------------------------------------------------
     def step(self, step_idx, uids, before, after, keep=None, rate=0.0, want_loss=False):
         L_ = lib()
-        uid, bef, aft = self._dev_i32(uids), self._dev_i32(before), self._dev_i32(after)
+        if any(torch.is_tensor(a) for a in (uids, before, after, keep)):
+            uid, bef, aft = self._dev_i32(uids), self._dev_i32(before), self._dev_i32(after)
+            kp = None
+            if keep is not None:
+                kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
+                    else keep.to(self.device, torch.uint8).contiguous()
+        else:                                          # host batch: one asynchronous copy for all of it
+            if getattr(self, '_stage', None) is None:
+                from ._staging import StagedUpload
+                self._stage = StagedUpload(self.device)
+            arrays = [np.ascontiguousarray(uids, dtype=np.int32), np.ascontiguousarray(before, dtype=np.int32),
+                      np.ascontiguousarray(after, dtype=np.int32)]
+            if keep is not None:
+                arrays.append(np.ascontiguousarray(keep, dtype=np.uint8))
+            _owner, views = self._stage(arrays)
+            uid, bef, aft = views[:3]
+            kp = views[3] if keep is not None else None
         B = uid.numel()
         assert bef.shape == (B, self.L) and aft.shape == (B, self.Tp)
-        kp = None
-        if keep is not None:
-            kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
-                else keep.to(self.device, torch.uint8).contiguous()
         z = dict(dtype=torch.float32, device=self.device)
         grid = L_.drx_caser_grid(C.byref(self.D), B)
         dE = torch.empty(B * self.L, self.ld, **z)

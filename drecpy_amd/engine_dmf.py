@@ -61,6 +61,7 @@ class DmfEngine:
         mk = lambda t: (torch.as_tensor(np.asarray(t[0], np.int64)).to(d), torch.as_tensor(np.asarray(t[1], np.int32)).to(d),
                         torch.as_tensor(np.asarray(t[2], np.float32)).to(d))
         self.csr, self.csc = mk(csr), mk(csc)
+        self._h_indptr = (np.asarray(csr[0], np.int64).copy(), np.asarray(csc[0], np.int64).copy())   # host copies: batch offsets
 
     def set_params(self, p):
         t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
@@ -118,24 +119,47 @@ class DmfEngine:
         check(lib().drx_scatter_rows(ptr(keys), T, ptr(src), ptr(src_index), ptr(coef), None, ld, n_rows, ptr(out), None,
                                      ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
 
+    def _upload_batch(self, uids, iids, y):
+        """Host batch -> device in one asynchronous copy (_staging.StagedUpload): uid, iid, y and the touch offsets, which are
+        computed on the host from the CSR / CSC row pointers — no device round trip for the counts."""
+        u64, i64 = np.asarray(uids, dtype=np.int64), np.asarray(iids, dtype=np.int64)
+        B = len(u64)
+        off_u, off_i = np.zeros(B + 1, np.int32), np.zeros(B + 1, np.int32)
+        np.cumsum(self._h_indptr[0][u64 + 1] - self._h_indptr[0][u64], out=off_u[1:])
+        np.cumsum(self._h_indptr[1][i64 + 1] - self._h_indptr[1][i64], out=off_i[1:])
+        if getattr(self, '_stage', None) is None:
+            from ._staging import StagedUpload
+            self._stage = StagedUpload(self.device)
+        dev, views = self._stage([u64.astype(np.int32), i64.astype(np.int32), np.ascontiguousarray(y, dtype=np.float32), off_u, off_i])
+        return (dev, views), [v.data_ptr() for v in views], B, int(off_u[-1]), int(off_i[-1])
+
     def step(self, step_idx, uids, iids, y, want_loss=False):
         L_ = lib()
-        uid, iid = self._i32(uids), self._i32(iids)
-        yv = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(self.device)
-        B = uid.numel()
         z = dict(dtype=torch.float32, device=self.device)
-        off_u, Tu = self._offsets(uid, self.csr[0])
-        off_i, Ti = self._offsets(iid, self.csc[0])
+        i32 = dict(dtype=torch.int32, device=self.device)
+        if torch.is_tensor(uids) or torch.is_tensor(iids):
+            uid, iid = self._i32(uids), self._i32(iids)
+            yv = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(self.device) if not torch.is_tensor(y) else y.to(self.device, torch.float32)
+            B = uid.numel()
+            off_u, Tu = self._offsets(uid, self.csr[0])
+            off_i, Ti = self._offsets(iid, self.csc[0])
+            alive = (uid, iid, yv, off_u, off_i)
+            p_uid, p_iid, p_y, p_offu, p_offi = (t.data_ptr() for t in alive)
+        else:
+            alive, (p_uid, p_iid, p_y, p_offu, p_offi), B, Tu, Ti = self._upload_batch(uids, iids, y)
         ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
         dz0u, dz0i = torch.empty(B, ld0u, **z), torch.empty(B, ld0i, **z)
-        i32 = dict(dtype=torch.int32, device=self.device)
         tk_u, ts_u, tc_u = torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **z)
         tk_i, ts_i, tc_i = torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **z)
         grid = L_.drx_dmf_grid(B)
         gpart, lpart = torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z)
         gsw = torch.empty(self.D.n_small + 1, **z)
-        A = self._base_args(uid, iid)
-        A.y, A.off_u, A.off_i = yv.data_ptr(), off_u.data_ptr(), off_i.data_ptr()
+        A = DmfArgs()
+        A.K0u, A.K0i, A.sw = self.K0u.data_ptr(), self.K0i.data_ptr(), self.sw.data_ptr()
+        A.u_indptr, A.u_indices, A.u_values = (t.data_ptr() for t in self.csr)
+        A.i_indptr, A.i_indices, A.i_values = (t.data_ptr() for t in self.csc)
+        A.uid, A.iid, A.B = p_uid, p_iid, int(B)
+        A.y, A.off_u, A.off_i = p_y, p_offu, p_offi
         A.dz0u, A.dz0i = dz0u.data_ptr(), dz0i.data_ptr()
         A.tkeys_u, A.tsrc_u, A.tcoef_u = tk_u.data_ptr(), ts_u.data_ptr(), tc_u.data_ptr()
         A.tkeys_i, A.tsrc_i, A.tcoef_i = tk_i.data_ptr(), ts_i.data_ptr(), tc_i.data_ptr()
