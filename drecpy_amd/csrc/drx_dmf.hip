@@ -27,13 +27,16 @@ struct TowerIO {
   float *tcoef;               // [T] normalised input value
 };
 
-constexpr int kDmfWaves = 4;      // waves of a workgroup that share the sparse first layer of one sample
+// waves of a workgroup that share the sparse first layer of one sample (WV below): 16 for batches that cannot fill the chip
+// otherwise (one workgroup per sample, the gather of ~150-250 rows is the sample's critical path: 0.37 -> 0.29 ms per step at
+// B = 256), 4 for large ones (more samples in flight per CU: 1.17 vs 1.48 ms at B = 4096)
+inline int dmf_waves(int B) { return B <= 512 ? 16 : (B <= 2048 ? 8 : 4); }
 
 // First (sparse) layer of one tower for sample b: the l2-normalised rating row / column against the kernel rows it names —
-// an embedding bag.  The workgroup's waves take every kDmfWaves-th block of 64 non-zeros, 8 kernel rows in flight each;
+// an embedding bag.  The workgroup's WV waves take every WV-th block of 64 non-zeros, 8 kernel rows in flight each;
 // returns this wave's partial pre-activation of lane k (popular items have thousands of non-zeros: with one wave and
 // 4 loads in flight this loop was 60 % of a DMF step).
-template <bool TRAIN>
+template <bool TRAIN, int WV>
 __device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float &rho_in) {
   const int id = T.ids[b];
   const int64_t s = T.indptr[id], e = T.indptr[id + 1];
@@ -45,7 +48,7 @@ __device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const
   const bool ok = k < f0;
   float acc = 0.f;
   const int base = TRAIN ? T.off[b] : 0;
-  for (int64_t c = s + 64 * (int64_t)w; c < e; c += 64 * kDmfWaves) {   // lanes fetch 64 (index, value) pairs, then broadcast them
+  for (int64_t c = s + 64 * (int64_t)w; c < e; c += 64 * WV) {   // lanes fetch 64 (index, value) pairs, then broadcast them
     const int64_t j = c + k;
     int idx = 0;
     float v = 0.f;
@@ -122,14 +125,14 @@ __device__ __forceinline__ void tower_bwd(const DrxDmfDims &D, int tw, const Tow
   if (k < T.ld0) T.dz0[(size_t)b * T.ld0 + k] = k < f0 ? dz0 : 0.f;
 }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(64 * kDmfWaves) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
-  extern __shared__ __align__(16) float lds[];       // [2][kDmfWaves][64] first-layer partials, then gsw [n_small] (TRAIN)
+template <bool TRAIN, int WV>
+__global__ __launch_bounds__(64 * WV) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
+  extern __shared__ __align__(16) float lds[];       // [2][WV][64] first-layer partials, then gsw [n_small] (TRAIN)
   float *part = lds;
-  float *gsw = lds + 2 * kDmfWaves * 64;
+  float *gsw = lds + 2 * WV * 64;
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (TRAIN)
-    for (int i = threadIdx.x; i < D.n_small; i += 64 * kDmfWaves) gsw[i] = 0.f;
+    for (int i = threadIdx.x; i < D.n_small; i += 64 * WV) gsw[i] = 0.f;
   TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
   float loss_acc = 0.f;
@@ -137,13 +140,13 @@ __global__ __launch_bounds__(64 * kDmfWaves) void k_dmf(DrxDmfDims D, DrxDmfArgs
   __syncthreads();
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     float rin_u, rin_i;
-    part[(0 * kDmfWaves + w) * 64 + k] = tower_gather<TRAIN>(D, 0, Tu, b, k, w, rin_u);
-    part[(1 * kDmfWaves + w) * 64 + k] = tower_gather<TRAIN>(D, 1, Ti, b, k, w, rin_i);
+    part[(0 * WV + w) * 64 + k] = tower_gather<TRAIN, WV>(D, 0, Tu, b, k, w, rin_u);
+    part[(1 * WV + w) * 64 + k] = tower_gather<TRAIN, WV>(D, 1, Ti, b, k, w, rin_i);
     __syncthreads();
     if (w == 0) {                                    // one wave finishes the sample: dense layers, loss, backward
       float pu = 0.f, pi = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < kDmfWaves; ++ww) { pu += part[(0 * kDmfWaves + ww) * 64 + k]; pi += part[(1 * kDmfWaves + ww) * 64 + k]; }
+      for (int ww = 0; ww < WV; ++ww) { pu += part[(0 * WV + ww) * 64 + k]; pi += part[(1 * WV + ww) * 64 + k]; }
       float zu[kDmfMaxLayers], au[kDmfMaxLayers], zi[kDmfMaxLayers], ai[kDmfMaxLayers];
       const float ru = tower_dense(D, 0, A.sw, k, pu, zu, au);
       const float ri = tower_dense(D, 1, A.sw, k, pi, zi, ai);
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64 * kDmfWaves) void k_dmf(DrxDmfDims D, DrxDmfArgs
     __syncthreads();                                 // the partials are free for the next sample
   }
   if (TRAIN) {
-    for (int i = threadIdx.x; i < D.n_small; i += 64 * kDmfWaves) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = gsw[i];
+    for (int i = threadIdx.x; i < D.n_small; i += 64 * WV) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = gsw[i];
     if (threadIdx.x == 0) A.loss_part[blockIdx.x] = loss_acc * inv_b;
   }
 }
@@ -261,10 +264,16 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
     return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = drx_dmf_grid(A->B);
-  const size_t lds = ((size_t)D->n_small + 2 * kDmfWaves * 64) * 4;
-  if (lds > 48 * 1024)
-    DRX_HIP(hipFuncSetAttribute((const void *)k_dmf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_dmf<true>, dim3(grid), dim3(64 * kDmfWaves), lds, st, *D, *A);
+  const int wv = dmf_waves(A->B);
+  const size_t lds = ((size_t)D->n_small + 2 * wv * 64) * 4;
+#define LAUNCH(WV)                                                                                                        \
+  {                                                                                                                       \
+    if (lds > 48 * 1024)                                                                                                  \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_dmf<true, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL((k_dmf<true, WV>), dim3(grid), dim3(64 * WV), lds, st, *D, *A);                                    \
+  }
+  if (wv == 16) LAUNCH(16) else if (wv == 8) LAUNCH(8) else LAUNCH(4)
+#undef LAUNCH
   hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
                      A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();
@@ -277,8 +286,11 @@ int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream) {
   if (!A || !A->K0u || !A->K0i || !A->sw || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices ||
       !A->i_values || !A->uid || !A->iid || A->B < 1 || (!A->pred_out && !A->rep_u_out && !A->rep_i_out))
     return DRX_EINVAL;
-  hipLaunchKernelGGL(k_dmf<false>, dim3(A->B < 4096 ? A->B : 4096), dim3(64 * kDmfWaves), (size_t)2 * kDmfWaves * 64 * 4,
-                     (hipStream_t)stream, *D, *A);
+  const int wv = dmf_waves(A->B);
+  const dim3 grid(A->B < 4096 ? A->B : 4096);
+  if (wv == 16) hipLaunchKernelGGL((k_dmf<false, 16>), grid, dim3(64 * 16), (size_t)2 * 16 * 64 * 4, (hipStream_t)stream, *D, *A);
+  else if (wv == 8) hipLaunchKernelGGL((k_dmf<false, 8>), grid, dim3(64 * 8), (size_t)2 * 8 * 64 * 4, (hipStream_t)stream, *D, *A);
+  else hipLaunchKernelGGL((k_dmf<false, 4>), grid, dim3(64 * 4), (size_t)2 * 4 * 64 * 4, (hipStream_t)stream, *D, *A);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
