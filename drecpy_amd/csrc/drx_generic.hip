@@ -81,6 +81,60 @@ __global__ __launch_bounds__(kBlock) void k_rows_dot(const float *__restrict__ x
   }
 }
 
+// ---- small problems: no sort ------------------------------------------------------------------------------------------------
+// A bit per (destination row, touch) — set with integer atomics, so deterministic — and one lane group per destination row that
+// walks its bits in ascending touch order (the order the stable sort would give).  The mask costs n_rows * T / 8 bytes to clear
+// and to read, so this is for small problems only: the three scatters of a Caser step of 512 windows (2.5 k / 6 k / 0.5 k touches
+// into 3.7 k - 6 k rows: masks of 0.4 - 2.8 MB) each cost a rocPRIM merge sort, the reduction and the span fix-ups — 8 - 10
+// launches, ~60 us; here it is 3 (step 0.35 -> 0.28 ms).  With masks of 18 + 48 MB (a DMF step of 256 pairs) it LOSES
+// (0.29 -> 0.42 ms): hence the budget.
+constexpr size_t kMaskBudget = (size_t)8 << 20;
+inline bool scatter_by_mask(int T, int n_rows) { return (size_t)n_rows * (size_t)((T + 31) / 32) * 4 <= kMaskBudget; }
+
+__global__ void k_mask_mark(const uint32_t *__restrict__ keys, int T, int W, int n_rows, uint32_t *__restrict__ mask) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+    const uint32_t key = keys[t];
+    if (key != DRX_KEY_NONE && key < (uint32_t)n_rows) atomicOr(&mask[(size_t)key * W + (t >> 5)], 1u << (t & 31));
+  }
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_mask_sweep(const uint32_t *__restrict__ mask, int W, int n_rows, ScatterPolicy pol) {
+  const int lane = threadIdx.x % G;
+  const int gshift = (G == 64) ? 0 : (((int)threadIdx.x % 64) / G) * G;
+  const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  const int gpb = kBlock / G;
+  for (int row = blockIdx.x * gpb + threadIdx.x / G; row < n_rows; row += gridDim.x * gpb) {
+    float4 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+    float accs = 0.f;
+    bool any = false;
+    const uint32_t *mr = mask + (size_t)row * W;
+    for (int w0 = 0; w0 < W; w0 += G) {
+      const uint32_t word = (w0 + lane < W) ? mr[w0 + lane] : 0u;
+      unsigned long long nz = (__ballot(word != 0u) >> gshift) & gmask;       // lanes of this group holding set bits
+      while (nz) {
+        const int l = __ffsll((long long)nz) - 1;
+        nz &= nz - 1;
+        uint32_t wv = (uint32_t)__shfl((int)word, l, G);
+        any = true;
+        while (wv) {
+          const uint32_t t = (uint32_t)(w0 + l) * 32u + (uint32_t)(__ffs((int)wv) - 1);
+          wv &= wv - 1;
+          float4 r[J];
+          float sc = 0.f, c = 1.f;
+          pol.template load<G, J>(0u, t, lane, r, sc, c);
+#pragma unroll
+          for (int j = 0; j < J; ++j) f4_fma(acc[j], c, r[j]);
+          accs += sc;
+        }
+      }
+    }
+    if (any) pol.template finish<G, J>((uint32_t)row, 0, lane, acc, accs);
+  }
+}
+
 struct ScatterLayout {
   SegBufs sb;
   uint32_t *idx, *keys_s, *vals_s;
@@ -129,7 +183,9 @@ size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows) 
   if (ld < 4 || (ld & 3) || n_touches < 1 || n_rows < 1) return 0;
   Carver cv(nullptr, 0);
   (void)scatter_layout(cv, ld, n_touches, bits_for((uint64_t)n_rows + 1));
-  return align_up(cv.off, 256) + 256;
+  size_t need = align_up(cv.off, 256) + 256;
+  if (scatter_by_mask(n_touches, n_rows)) need = std::max(need, (size_t)n_rows * (size_t)((n_touches + 31) / 32) * 4 + 512);
+  return need;
 }
 
 int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const uint32_t *src_index, const float *coef,
@@ -137,6 +193,26 @@ int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const ui
                      size_t scratch_bytes, void *stream) {
   if (!keys || !src || !out || !scratch || T < 1 || n_rows < 1 || ld < 4 || (ld & 3) || ld > DRX_MAX_K) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (scatter_by_mask(T, n_rows)) {
+    const int W = (T + 31) / 32;
+    const size_t mbytes = (size_t)n_rows * W * 4;
+    uint32_t *mask = (uint32_t *)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    if ((size_t)((char *)mask - (char *)scratch) + mbytes > scratch_bytes) return DRX_ESCRATCH;
+    DRX_HIP(hipMemsetAsync(mask, 0, mbytes, st));
+    hipLaunchKernelGGL(k_mask_mark, dim3((T + 255) / 256 < 2048 ? (T + 255) / 256 : 2048), dim3(256), 0, st, keys, T, W, n_rows, mask);
+    ScatterPolicy mpol{src, src_index, coef, src_s, out, out_s, ld};
+#define CALLM(G, J)                                                                                                     \
+  {                                                                                                                     \
+    const int gpb = kBlock / G;                                                                                         \
+    int blocks = (n_rows + gpb - 1) / gpb;                                                                              \
+    if (blocks > 8192) blocks = 8192;                                                                                   \
+    hipLaunchKernelGGL((k_mask_sweep<G, J>), dim3(blocks), dim3(kBlock), 0, st, mask, W, n_rows, mpol);                 \
+  }
+    DRX_DISPATCH_GEOM(ld, CALLM);
+#undef CALLM
+    DRX_LAUNCH_CHECK();
+    return DRX_OK;
+  }
   const int bits = bits_for((uint64_t)n_rows + 1);
   Carver cv(scratch, scratch_bytes);
   ScatterLayout L = scatter_layout(cv, ld, T, bits);

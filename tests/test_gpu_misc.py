@@ -92,3 +92,45 @@ def test_sort_pairs_is_a_stable_sort(n, bits):
     want = torch.sort(low, stable=True)
     assert torch.equal(vo.long(), want.indices)
     assert torch.equal(ko.long() & 0xFFFFFFFF, keys64[want.indices])
+
+
+@pytest.mark.parametrize('T,n_rows,ld,indexed', [(1, 5, 4, False), (700, 300, 52, False), (6144, 3706, 100, False),
+                                                  (2560, 3706, 52, True), (40_000, 3706, 64, True), (200_000, 50_000, 128, True),
+                                                  (70, 9, 300, True)])
+def test_scatter_rows_both_paths_against_numpy(T, n_rows, ld, indexed):
+    """drx_scatter_rows (the gradient of an embedding lookup) against a float64 statement: small problems take the bit-mask path
+    (a bit per destination row and touch, rows walk their bits in touch order), larger ones the stable sort + segmented
+    reduction; padding keys are ignored, rows nobody names keep what they held."""
+    import torch
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(T + n_rows)
+    n_src = max(T // 3, 1) if indexed else T
+    keys = rng.integers(0, n_rows, size=T).astype(np.int64)
+    keys[rng.random(T) < 0.5] = rng.integers(0, min(n_rows, 7))                 # a few hot rows
+    pad = rng.random(T) < 0.1
+    src = rng.standard_normal((n_src, ld)).astype(np.float32)
+    src_s = rng.standard_normal(n_src).astype(np.float32)
+    idx = rng.integers(0, n_src, size=T).astype(np.int64) if indexed else np.arange(T)
+    coef = rng.standard_normal(T).astype(np.float32) if indexed else np.ones(T, np.float32)
+    want, want_s = np.full((n_rows, ld), 7.0), np.full(n_rows, 7.0)             # 7 = "kept what it held"
+    named = np.unique(keys[~pad])
+    want[named], want_s[named] = 0.0, 0.0
+    np.add.at(want, keys[~pad], coef[~pad, None].astype(np.float64) * src[idx[~pad]])
+    np.add.at(want_s, keys[~pad], coef[~pad].astype(np.float64) * src_s[idx[~pad]])
+    dev = torch.device('cuda')
+    k32 = np.where(pad, 0xFFFFFFFF, keys).astype(np.uint32).view(np.int32)
+    t = lambda a: torch.as_tensor(a).to(dev)
+    d_keys, d_src, d_ss = t(k32), t(src), t(src_s)
+    d_idx = t(idx.astype(np.int32)) if indexed else None
+    d_coef = t(coef) if indexed else None
+    out = torch.full((n_rows, ld), 7.0, dtype=torch.float32, device=dev)
+    out_s = torch.full((n_rows,), 7.0, dtype=torch.float32, device=dev)
+    need = L.drx_scatter_scratch_bytes(ld, T, n_rows)
+    scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.check(L.drx_scatter_rows(_lib.ptr(d_keys), T, _lib.ptr(d_src), _lib.ptr(d_idx), _lib.ptr(d_coef), _lib.ptr(d_ss), ld, n_rows,
+                                  _lib.ptr(out), _lib.ptr(out_s), _lib.ptr(scratch), need, _lib.stream_ptr(dev)), 'drx_scatter_rows')
+    torch.cuda.synchronize()
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(out_s.cpu().numpy(), want_s, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want_s).max())))
