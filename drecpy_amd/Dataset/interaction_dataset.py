@@ -302,6 +302,12 @@ class MemoryInteractionDataset(InteractionDatasetABC):
 
     # ---- internal ids (mem_dataset.py:264-330) -----------------------------------------------------------
     def assign_internal_ids(self):
+        # fit() calls this every time (recommender_abc.py:140); the codes are a function of the two raw-id columns only, so a
+        # second call on the same column arrays keeps what the first one built (ids, category arrays, cached CSR / CSC)
+        src = (self._cols['user'], self._cols['item'])
+        done = getattr(self, '_ids_of', None)
+        if self.has_internal_ids and done is not None and done[0] is src[0] and done[1] is src[1] and 'uid' in self._cols:
+            return
         ucodes, ucats = first_appearance_codes(self._cols['user'])
         icodes, icats = first_appearance_codes(self._cols['item'])
         self._cols = dict(self._cols)
@@ -316,9 +322,11 @@ class MemoryInteractionDataset(InteractionDatasetABC):
                 self.columns.append(c)
         self.has_internal_ids = True
         self._csr = self._csc = None
+        self._ids_of = src
 
     def remove_internal_ids(self):
         self.has_internal_ids = False
+        self._ids_of = None
         if 'uid' in self.columns:
             self._cols = {c: v for c, v in self._cols.items() if c not in ('uid', 'iid')}
             self.columns.remove('uid')
