@@ -208,10 +208,10 @@ class CDAE(RecommenderABC):
         generator (drx_drawahead_submit).  Returns what _finish_draw needs."""
         from .. import _lib
         B = int(batch_size)
-        ticket, self._draw_ticket = self._draw_ticket, self._draw_ticket + 1
-        gen = ticket % 2
-        at, self._mask_pos = self._mask_pos, self._mask_pos + 2 * self.n_items * B
-        discard, self._mask_at[gen] = at - self._mask_at[gen], at + 2 * self.n_items * B
+        ticket = self._draw_ticket                      # (the counters move only once the job is really queued: a ticket that
+        gen = ticket % 2                                #  was handed out but never submitted would stall both workers)
+        at = self._mask_pos
+        discard = at - self._mask_at[gen]
         cap = max(B * self._max_degree, 1)
         if self._engine.device.type == 'cuda':
             stage = self._engine.stage_acquire(B, cap)
@@ -225,6 +225,8 @@ class CDAE(RecommenderABC):
                                               ko_v.ctypes.data, kp_v.ctypes.data, len(kp_v))
         if job < 0:
             _lib.check(int(job), 'drx_drawahead_submit')
+        self._draw_ticket = ticket + 1
+        self._mask_pos = self._mask_at[gen] = at + 2 * self.n_items * B
         return B, gen, int(job), stage, extra
 
     def _finish_draw(self, entry):

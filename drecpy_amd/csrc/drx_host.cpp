@@ -503,6 +503,10 @@ struct DrxDrawAhead {
         }
       }
       DrawJob &j = me.ring[next % kRing];
+      for (unsigned spins = 0; __atomic_load_n(&turn, __ATOMIC_ACQUIRE) != j.ticket; ++spins) {   // (so that destroy never hangs)
+        if (stop.load()) return;
+        if (spins > 64) sched_yield();
+      }
       j.rc = drx_cdae_reference_draw(smp, rng[g], &turn, j.ticket, j.discard, indptr, indices, n_items, j.B, j.q, j.uid, j.iid,
                                      j.val, j.neg, j.keep_off, j.keep, j.keep_cap);
       me.done.store(next + 1);
