@@ -49,7 +49,17 @@ class CaserEngine:
         self.b1 = torch.zeros(n_items, **z)
         self.sw = torch.zeros(off, **z)
         self.state = {n: (torch.zeros_like(t), torch.zeros_like(t)) for n, t in self.tensors().items()}
-        self._grads = {n: torch.zeros_like(t) for n, t in self.tensors().items()}
+        # the dense gradient tables of the scatters live in ONE buffer, zeroed by one kernel per step
+        scat = [n for n in ('item_emb', 'W1', 'b1', 'user_emb') if n in self.tensors()]
+        sizes = [(self.tensors()[n].numel() + 63) // 64 * 64 for n in scat]
+        self._grad_arena = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
+        self._grads, o = {}, 0
+        for n, sz in zip(scat, sizes):
+            self._grads[n] = self._grad_arena[o:o + self.tensors()[n].numel()].view(self.tensors()[n].shape)
+            o += sz
+        for n, t in self.tensors().items():
+            if n not in self._grads:
+                self._grads[n] = torch.zeros_like(t)
         self._scratch = None
         self.lr, self.reg = 1e-3, 1e-3
 
@@ -110,13 +120,11 @@ class CaserEngine:
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
 
     def _scatter(self, keys, src, ld, n_rows, out, src_s=None, out_s=None):
+        """`out` (and `out_s`) must already be zero: step() clears the whole gradient arena once."""
         T = keys.numel()
         need = lib().drx_scatter_scratch_bytes(ld, T, n_rows)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(int(need * 1.2) + 1024, dtype=torch.uint8, device=self.device)
-        out.zero_()
-        if out_s is not None:
-            out_s.zero_()
         check(lib().drx_scatter_rows(ptr(keys), T, ptr(src), None, None, ptr(src_s), ld, n_rows, ptr(out), ptr(out_s),
                                      ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
 
@@ -159,14 +167,14 @@ class CaserEngine:
         assert bef.shape == (B, self.L) and aft.shape == (B, self.Tp)
         z = dict(dtype=torch.float32, device=self.device)
         grid = L_.drx_caser_grid(C.byref(self.D), B)
-        dE = torch.empty(B * self.L, self.ld, **z)
-        dW1 = torch.empty(B * self.Tp, self.ld2, **z)
+        n_dE, n_dW1, n_dPu = B * self.L * self.ld, B * self.Tp * self.ld2, B * self.ld
+        rows = torch.zeros(n_dE + n_dW1 + n_dPu, **z)    # one buffer, one fill: the padding columns of the gradient rows are zero
+        dE, dW1, dPu = rows[:n_dE].view(B * self.L, self.ld), rows[n_dE:n_dE + n_dW1].view(B * self.Tp, self.ld2), rows[n_dE + n_dW1:].view(B, self.ld)
         db1 = torch.empty(B * self.Tp, **z)
-        dPu = torch.empty(B, self.ld, **z)
         gpart = torch.empty(grid, self.D.n_small, **z)
         lpart = torch.empty(grid, **z)
         gsw = torch.empty(self.D.n_small + 1, **z)
-        dE.zero_(); dW1.zero_(); dPu.zero_()          # padding columns of the gradient rows
+        self._grad_arena.zero_()
         A = self._args(uid, bef, aft, kp, rate)
         A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = (t.data_ptr() for t in (dE, dW1, db1, dPu, gpart, lpart))
         reg_loss = None

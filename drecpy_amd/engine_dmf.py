@@ -48,7 +48,9 @@ class DmfEngine:
         self.K0i = torch.zeros(n_users, D.ld0[1], **z)
         self.sw = torch.zeros(off, **z)
         self.state = {n: (torch.zeros_like(t), torch.zeros_like(t)) for n, t in self.tensors().items()}
-        self._g = {'K0u': torch.zeros_like(self.K0u), 'K0i': torch.zeros_like(self.K0i)}
+        nu, ni = self.K0u.numel(), self.K0i.numel()
+        self._g_arena = torch.zeros(nu + ni, **z)            # both dense gradient tables: one buffer, one fill per step
+        self._g = {'K0u': self._g_arena[:nu].view(self.K0u.shape), 'K0i': self._g_arena[nu:].view(self.K0i.shape)}
         self._scratch = None
         self.lr, self.reg = 1e-3, 1e-3
 
@@ -110,7 +112,7 @@ class DmfEngine:
         return off, int(off[-1].item())
 
     def _scatter(self, keys, T, src, src_index, coef, ld, n_rows, out):
-        out.zero_()
+        """`out` must already be zero (step() clears the gradient arena once)."""
         if T == 0:
             return
         need = lib().drx_scatter_scratch_bytes(ld, T, n_rows)
@@ -172,6 +174,7 @@ class DmfEngine:
                     sq = sq + (self.sw[start:start + n] ** 2).sum()
             reg_loss = self.reg * sq
         check(L_.drx_dmf_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream_ptr(self.device)), 'drx_dmf_fwd_bwd')
+        self._g_arena.zero_()
         self._scatter(tk_u, Tu, dz0u, ts_u, tc_u, ld0u, self.N, self._g['K0u'])
         self._scatter(tk_i, Ti, dz0i, ts_i, tc_i, ld0i, self.U, self._g['K0i'])
         alpha = [CdaeEngine.adam_alpha(self.lr, 2 * step_idx + j + 1) for j in range(2)]
