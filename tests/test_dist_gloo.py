@@ -191,3 +191,61 @@ def test_column_sharded_step_equals_single_process_oracle(tmp_path, world):
         np.testing.assert_allclose(g['b'], p['b'][lo:hi], **tol)
         np.testing.assert_allclose(g['b_'], p['b_'], **tol)
         np.testing.assert_allclose(res['losses'], want, rtol=1e-9)
+
+
+# ---- who builds the touch list of a step (ColumnShardedCdae prepare='turns') over gloo on CPU ----------------------------------
+class _FakePrepEngine:
+    """Stands in for CdaeEngine's preparation calls: a 'prepared list' is a byte buffer whose result part is a function of the
+    batch and of WHO built it, so the test can see whose list every rank ends up holding."""
+    RESULT, TOTAL = 96, 160
+
+    def __init__(self, rank):
+        self.rank, self.device = rank, torch.device('cpu')
+
+    def prep_buffer(self, bt, out=None):
+        return out if out is not None and out.numel() >= self.TOTAL else torch.full((self.TOTAL,), 255, dtype=torch.uint8)
+
+    def prep_result_bytes(self, bt):
+        return self.RESULT
+
+    def prepare_sparse(self, bt, out=None):
+        out = self.prep_buffer(bt, out)
+        out[:self.RESULT] = torch.arange(self.RESULT, dtype=torch.uint8) + bt['id']        # the list of this batch ...
+        out[self.RESULT:] = 100 + self.rank                                                # ... and the builder's private scratch
+        return out
+
+
+def _turns_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from drecpy_amd.dist import ColumnShardedCdae
+    p, indptr, indices, _ = _problem(1)
+    m = ColumnShardedCdae(U, N, K, rank, world, 'cpu', indptr, indices, q=Q, engine=_FakePrepEngine(rank), prepare='turns')
+    got, bufs = [], [None, None, None]
+    for s in range(7):
+        bt = {'id': 3 * s + 1}
+        if bufs[s % 3] is not None:
+            bufs[s % 3].fill_(255)                               # (forget who built the list this buffer held before)
+        buf = m.build_in_turns(s, bt, bufs[s % 3])               # rank s % world builds, the others only hold a buffer
+        built_here = bool((buf[_FakePrepEngine.RESULT:] == 100 + rank).all())
+        m.deliver_in_turns(s, bt, buf)
+        bufs[s % 3] = buf
+        got.append((built_here, buf[:_FakePrepEngine.RESULT].clone()))
+    torch.save(got, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_lists_built_in_turns_reach_every_rank(tmp_path, world):
+    """prepare='turns': the list of step s is built by rank s % world only and every rank ends up with exactly its result bytes
+    (the broadcast runs on a communicator of its own; the builder's scratch part never travels)."""
+    out = str(tmp_path / 'turns')
+    port = 29400 + (os.getpid() % 200) + 300 * world
+    mp.spawn(_turns_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(f'{out}.{r}', weights_only=False)
+        for s, (built_here, res) in enumerate(got):
+            assert built_here == (s % world == r)
+            assert torch.equal(res, torch.arange(_FakePrepEngine.RESULT, dtype=torch.uint8) + (3 * s + 1))
