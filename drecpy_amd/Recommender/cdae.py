@@ -129,6 +129,7 @@ class CDAE(RecommenderABC):
         self._mask_at = [0, 0]                          # words each generator has consumed
         self._mask_pos = 0                              # where the next batch begins
         self._draw_ticket = 0
+        self._L, self._q_float = L, float(self.corruption_level)
         self._drawahead = L.drx_drawahead_create(self._sampler._host._h, self._mask_rngs[0], self._mask_rngs[1],
                                                  self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items)
         self._mask_seed = int(seed)
@@ -216,13 +217,13 @@ class CDAE(RecommenderABC):
         if self._engine.device.type == 'cuda':
             stage = self._engine.stage_acquire(B, cap)
             extra = self._engine.stage_extra(stage[0])
+            ptrs = self._engine.stage_pointers(stage[0])
         else:
             stage = (None, np.empty(B, np.int32), np.empty(B + 1, np.int32), np.empty(cap, np.uint8))
             extra = (np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8))
-        _, uid_v, ko_v, kp_v = stage
-        job = _lib.lib().drx_drawahead_submit(self._drawahead, gen, ticket, discard, B, float(self.corruption_level),
-                                              uid_v.ctypes.data, extra[0].ctypes.data, extra[1].ctypes.data, extra[2].ctypes.data,
-                                              ko_v.ctypes.data, kp_v.ctypes.data, len(kp_v))
+            ptrs = (stage[1].ctypes.data, extra[0].ctypes.data, extra[1].ctypes.data, extra[2].ctypes.data, stage[2].ctypes.data,
+                    stage[3].ctypes.data, len(stage[3]))
+        job = self._L.drx_drawahead_submit(self._drawahead, gen, ticket, discard, B, self._q_float, *ptrs)
         if job < 0:
             _lib.check(int(job), 'drx_drawahead_submit')
         self._draw_ticket = ticket + 1
@@ -232,7 +233,9 @@ class CDAE(RecommenderABC):
     def _finish_draw(self, entry):
         from .. import _lib
         B, gen, job, stage, extra = entry
-        _lib.check(_lib.lib().drx_drawahead_wait(self._drawahead, gen, job), 'drx_cdae_reference_draw')
+        rc = self._L.drx_drawahead_wait(self._drawahead, gen, job)
+        if rc:
+            _lib.check(rc, 'drx_cdae_reference_draw')
         slot, uid_v, ko_v, kp_v = stage
         batch = CDAE._Batch((uid_v,) + extra, self._sampler._val_type)
         batch.slot, batch.uid, batch.keep_off = slot, uid_v, ko_v

@@ -25,7 +25,7 @@ from .early_stopping import InvalidEpochValidationResultsException
 from .loss_tracker import LossTracker
 
 _LOG_FORMAT = '[%(asctime)s] (%(levelname)s) %(name)s: %(message)s'
-_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', '_mask_rngs', '_drawahead', 'epoch_weights', '_pipeline', '_pending',
+_UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', '_mask_rngs', '_drawahead', '_L', 'epoch_weights', '_pipeline', '_pending',
               '_host_pool', '_dist_model')
 
 

@@ -244,14 +244,21 @@ class CdaeEngine:
         v = st['views'][k]
         if v is None or v[0] != (B, int(keep_capacity)):      # the views of a slot are rebuilt only when the batch shape changes
             hv = st['host'][k].numpy()
-            v = st['views'][k] = ((B, int(keep_capacity)), (k, off_ko, off_kp), hv[:4 * B].view(np.int32),
-                                  hv[off_ko:off_ko + 4 * (B + 1)].view(np.int32), hv[off_kp:off_kp + max(int(keep_capacity), 1)],
-                                  (np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8)))
+            extra = (np.empty(B, np.int32), np.empty(B, np.float64), np.empty(B, np.uint8))
+            uid_v, ko_v, kp_v = hv[:4 * B].view(np.int32), hv[off_ko:off_ko + 4 * (B + 1)].view(np.int32), hv[off_kp:off_kp + max(int(keep_capacity), 1)]
+            ptrs = (uid_v.ctypes.data, extra[0].ctypes.data, extra[1].ctypes.data, extra[2].ctypes.data, ko_v.ctypes.data, kp_v.ctypes.data,
+                    len(kp_v))
+            v = st['views'][k] = ((B, int(keep_capacity)), (k, off_ko, off_kp), uid_v, ko_v, kp_v, extra, ptrs)
         return v[1], v[2], v[3], v[4]
 
     def stage_extra(self, slot):
         """Per-slot host arrays (iid int32 [B], value float64 [B], is_negative uint8 [B]) for what else a draw produces."""
         return self._slots['views'][slot[0]][5]
+
+    def stage_pointers(self, slot):
+        """Addresses of the slot's arrays in the argument order of drx_drawahead_submit: uid, iid, value, is_negative, keep_off,
+        keep, keep capacity (numpy's .ctypes accessor costs a microsecond per array and call)."""
+        return self._slots['views'][slot[0]][6]
 
     def batch_in_slot(self, slot, B, n_keep, q):
         """Batch struct over a filled staging slot, WITHOUT a copy: pinned host memory is addressable from the device, and a
