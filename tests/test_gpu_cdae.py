@@ -56,6 +56,29 @@ def test_forward_matches_oracle(K):
     assert _relerr(pred.cpu().numpy(), po) < REL
 
 
+def test_dense_step_with_more_output_tiles_than_workgroups():
+    """N = 4500 output units = 563 tiles of 8 for the 512 persistent workgroups of k_out_dense_tile: some take two tiles (the dh
+    partial of a workgroup then sums both), against the oracle after two steps."""
+    U, N, K, B = 40, 4500, 16, 32
+    eng, p, rng = _engine(U, N, K, seed=3)
+    indptr, indices = synth_history(rng, U, N, 20)
+    eng.set_history(indptr, indices)
+    eng.init_optimizer('adam', 1e-3, 1e-3)
+    st = co.adam_state(p)
+    for step in range(2):
+        uids = rng.integers(0, U, size=B)
+        t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        keep = (rng.random(keep_off[-1]) >= 0.2).astype(np.uint8)
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        bt, alive = eng.make_batch(uids, keep_off=keep_off, keep=keep, q=0.2)
+        lo = co.dense_step(p, st, step, uids, x_tilde(t, kept, float(np.float32(0.2)), np.float64), t, 1e-3, 1e-3, 'bce', 'reference')
+        lg = eng.step_dense(step, bt, 'bce', 'reference', want_loss=True).cpu().numpy()
+        assert abs(lg.sum() - lo) / abs(lo) < 1e-4
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-6, err_msg=k)
+
+
 @pytest.mark.parametrize('K,B,loss,targets', [(50, 64, 'bce', 'reference'), (128, 64, 'bce', 'reference'),
                                               (8, 33, 'mse', 'reference'), (50, 40, 'bce', 'per_row'),
                                               (300, 16, 'mse', 'per_row'), (128, 700, 'bce', 'reference')])
