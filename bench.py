@@ -271,8 +271,8 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ph = np.array([[es[i].elapsed_time(es[i + 1]) for i in range(6)] for es in evs[::EVERY]]).mean(axis=0)
-    names = ['k_kshard_fwd+allreduce(dot)', 'k_kshard_rest', 'touch_sort(overlapped on side stream)', 'k_seg_reduce(+ bias partials)',
-             'k_sparse_tail(short spans | long spans | bias update)', '(second tail launch: none with a prepared touch list)']
+    names = ['k_kshard_fwd+allreduce(dot)', 'k_kshard_rest', 'touch_sort(overlapped on side stream)', 'k_seg_reduce',
+             'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
     kl = model.k_hi - model.k_lo
     S_opt = 2.0 if args.optimizer == 'adam' else 1.0
     alg_upd = Bg * 4.0 * kl * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)      # this rank's columns of the global batch
@@ -497,14 +497,9 @@ def main():
     alg_fwd = B * 4.0 * K * (rows_per_sample + f_solo * (2.0 + 2.0 * S_opt))
     alg_upd = B * 4.0 * K * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)
     if stepper is None:
-        # with a prepared touch list the reduction's launch also forms the bias partials (one more read of dz1: B*4K bytes) and
-        # the tail is one launch (include/drx.h, drx_cdae_step_sparse_timed)
-        seg = 'k_seg_reduce_bias' if overlap else 'k_seg_reduce'
-        names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', seg,
-                 'k_sparse_tail(short spans | long spans | bias update)' if overlap else 'k_sparse_tail_a(short spans | bias partials)',
-                 '(no second tail launch)' if overlap else 'k_sparse_tail_b(long spans | bias update)']
-        alg_seg = alg_upd + (B * 4.0 * K if overlap else 0.0)
-        dom, dom_ms, dom_alg = (seg, ph[2], alg_seg) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
+        names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce',
+                 'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
+        dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
         names = ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce(+overlapped exchanges)', 'rest_of_grad_exchange', 'owner_apply', 'bias_allreduce']
         # forward reads one row per occurrence, the local reduce one gradient row per occurrence

@@ -925,30 +925,6 @@ __global__ __launch_bounds__(kFixBlock) void k_sparse_tail_b(SegBufs S, DirectPo
   else bias_final_body<G, J, kFixBlock>(pol.P, pol.opt, A, lds, red);
 }
 
-// With a touch list prepared ahead the long segments are known before the step (PrepBufs::long_spans), and nothing in the tail
-// depends on anything else in it once the bias partials ride along with the reduction — three launches per step instead of four:
-//   k_seg_reduce_bias : blocks [0, n_seg) the segmented reduction; the rest the column-sum partials of dz1 and the loss partials
-//   k_sparse_tail     : kFixBlock threads; blocks [0, n_short) the SHORT chunk-crossing segments (its groups skip the long ones),
-//                       blocks [n_short, n_short + n_long_blocks) the LONG ones from the prepared list, one more block the bias
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_seg_reduce_bias(SegBufs S, DirectPolicy pol, BiasArgs A, int n_seg) {
-  extern __shared__ __align__(16) float lds[];   // [kBlock/G, ld] (bias role)
-  __shared__ float red[kBlock / 64];
-  if ((int)blockIdx.x < n_seg) seg_reduce_body<G, J, DirectPolicy>(S, pol, (int)blockIdx.x);
-  else bias_partial_body<G, J, kBlock>(S.ld, A, (int)blockIdx.x - n_seg, lds, red);
-}
-
-template <int G, int J>
-__global__ __launch_bounds__(kFixBlock) void k_sparse_tail(SegBufs S, DirectPolicy pol, BiasArgs A, int n_short, int n_long_blocks,
-                                                           const uint32_t *long_spans, const uint32_t *n_long) {
-  extern __shared__ __align__(16) float lds[];   // [kFixBlock/G, ld] + [kFixBlock/G]
-  __shared__ float red[kFixBlock / 64];
-  const int b = (int)blockIdx.x;
-  if (b < n_short) span_short_body<G, J, DirectPolicy>(S, pol, b, n_short, false);
-  else if (b < n_short + n_long_blocks) span_long_body<G, J, DirectPolicy>(S, pol, b - n_short, n_long_blocks, lds, long_spans, n_long);
-  else bias_final_body<G, J, kFixBlock>(pol.P, pol.opt, A, lds, red);
-}
-
 // ------------------------------------------------------------------------------------------------
 // scratch layouts (shared by the sizing entry point and the step functions)
 // ------------------------------------------------------------------------------------------------
@@ -1015,9 +991,6 @@ struct PrepBufs {
   void *sort_temp;
   size_t sort_bytes;
   uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo)
-  uint32_t *long_spans;         // [long_cap] first chunk of every segment that crosses more than kShortSpan chunk borders,
-  uint32_t *n_long;             //   [1] how many (see k_find_long): known from the sorted list alone
-  int long_cap;
   size_t result_bytes;
   int T, bits;
 };
@@ -1032,9 +1005,6 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.vals_s = cv.take<uint32_t>(R.T);
   R.solo_v = cv.take<uint8_t>((size_t)2 * B);
   R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
-  R.long_cap = R.T / ((kShortSpan + 1) * kChunk) + 4;
-  R.long_spans = cv.take<uint32_t>(R.long_cap);
-  R.n_long = cv.take<uint32_t>(4);
   R.result_bytes = align_up(cv.off, 256);
   R.keys = cv.take<uint32_t>(R.T);
   R.vals = cv.take<uint32_t>(R.T);
@@ -1234,34 +1204,6 @@ static PartBufs part_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   return L;
 }
 
-// The segments of the sorted list that cross more than kShortSpan chunk borders (hot rows: thousands of touches), by the first
-// chunk of each — the same segments span_short_body would classify as long by probing chunk flags after the reduction, found
-// here from the keys alone (a segment starting in chunk g is long iff the key of g's last touch is still the key 65 chunks on),
-// so that the step's tail needs one launch instead of two.  Must run on the fully sorted keys, BEFORE k_mark_solo blanks any.
-__global__ void k_find_long(const uint32_t *__restrict__ keys_s, int T, int n_chunks, uint32_t *__restrict__ long_spans, int cap,
-                            uint32_t *__restrict__ n_long) {
-  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_chunks; g += gridDim.x * blockDim.x) {
-    const int start = g * kChunk, end = min(T, start + kChunk);
-    const long long far = (long long)(g + kShortSpan + 1) * kChunk;
-    if (far >= T) continue;
-    const uint32_t key = keys_s[end - 1];
-    if (key == DRX_KEY_NONE || keys_s[far] != key) continue;
-    // the segment STARTS in this chunk unless the whole chunk continues it from the previous one
-    const bool from_left = keys_s[start] == key && start > 0 && keys_s[start - 1] == key;
-    if (from_left) continue;
-    const uint32_t slot = atomicAdd(n_long, 1u);
-    if ((int)slot < cap) long_spans[slot] = (uint32_t)g;
-  }
-}
-
-static int find_long_spans(const PrepBufs &R, hipStream_t st) {
-  DRX_HIP(hipMemsetAsync(R.n_long, 0, 4 * sizeof(uint32_t), st));
-  const int n_chunks = (R.T + kChunk - 1) / kChunk;
-  hipLaunchKernelGGL(k_find_long, dim3((n_chunks + 255) / 256 < 1024 ? (n_chunks + 255) / 256 : 1024), dim3(256), 0, st, R.keys_s, R.T,
-                     n_chunks, R.long_spans, R.long_cap, R.n_long);
-  return DRX_OK;
-}
-
 }  // namespace drx
 
 using namespace drx;
@@ -1451,7 +1393,6 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
-  constexpr int tail_ns = 128, tail_nl = 64;       // workgroups of the one-launch tail's short / long roles (swept: 32 .. 512 / 16 .. 256)
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
@@ -1472,19 +1413,6 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
       if (rc) return rc;                                                                                               \
     }                                                                                                                  \
     EV(2);                                                                                                             \
-    if (prepared) {       /* long segments known ahead: reduction + bias partials, then ONE tail launch */             \
-      const int n_seg = (S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G);                                                    \
-      hipLaunchKernelGGL((k_seg_reduce_bias<G, J>), dim3(n_seg + n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, SB, pol, BA, \
-                         n_seg);                                                                                       \
-      EV(3);                                                                                                           \
-      if (lds_b > 48 * 1024)                                                                                           \
-        DRX_HIP(hipFuncSetAttribute((const void *)k_sparse_tail<G, J>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                    (int)lds_b));                                                                      \
-      hipLaunchKernelGGL((k_sparse_tail<G, J>), dim3(tail_ns + tail_nl + 1), dim3(kFixBlock), lds_b, st, SB, pol, BA, tail_ns, tail_nl, \
-                         R.long_spans, R.n_long);                                                                      \
-      EV(4);                                                                                                           \
-      EV(5);                                                                                                           \
-    } else {                                                                                                           \
     hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
                        pol);                                                                                           \
     EV(3);                                                                                                             \
@@ -1496,7 +1424,6 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
                                   (int)lds_b));                                                                        \
     hipLaunchKernelGGL((k_sparse_tail_b<G, J>), dim3(256 + 1), dim3(kFixBlock), lds_b, st, SB, pol, BA, 256);          \
     EV(5);                                                                                                             \
-    }                                                                                                                  \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL
@@ -1522,8 +1449,6 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
   if (!cp.ok()) return DRX_ESCRATCH;
   rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream);
-  if (rc) return rc;
-  rc = find_long_spans(R, (hipStream_t)stream);
   if (rc) return rc;
   rc = mark_solo(p, bt, R, (hipStream_t)stream, true);
   if (rc) return rc;
@@ -1604,8 +1529,6 @@ int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt,
   const PartOut o = part_out_layout(*p, bt->B, bt->n_touch_slots, parts);
   hipLaunchKernelGGL(k_assemble_parts, dim3(2048), dim3(256), 0, st, (const char *)all_parts, o.bytes, o.runs_off, o.vals_off, parts, R.T,
                      R.keys_s, R.vals_s, overflow_out);
-  rc = find_long_spans(R, st);
-  if (rc) return rc;
   rc = mark_solo(p, bt, R, st, false);
   if (rc) return rc;
   DRX_LAUNCH_CHECK();

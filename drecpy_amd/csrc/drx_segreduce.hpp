@@ -46,15 +46,15 @@ struct SegBufs {
 // The chunk's (key, sample) pairs are fetched with one coalesced load per lane and broadcast by shuffles; the
 // contribution rows are then loaded LB at a time (independent loads in flight) before they are folded in order.
 template <int G, int J, class Policy>
-__device__ __forceinline__ void seg_reduce_body(const SegBufs &S, const Policy &pol, int block_id) {
+__global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
 #ifdef DRX_SEG_WAVE_PER_CHUNK
   // experiment: one chunk per WAVE (lanes >= G idle) so that a group's flush never stalls a sibling group
   const int lane = threadIdx.x % 64;
   if (lane >= G) return;
-  const int g = block_id * (kBlock / 64) + threadIdx.x / 64;
+  const int g = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
 #else
   const int lane = threadIdx.x % G;
-  const int g = block_id * (kBlock / G) + threadIdx.x / G;
+  const int g = blockIdx.x * (kBlock / G) + threadIdx.x / G;
 #endif
   if (g >= S.n_chunks) return;
   const int start = g * kChunk, end = min(S.T, start + kChunk);
@@ -147,11 +147,6 @@ __device__ __forceinline__ void seg_reduce_body(const SegBufs &S, const Policy &
   }
 }
 
-template <int G, int J, class Policy>
-__global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
-  seg_reduce_body<G, J, Policy>(S, pol, (int)blockIdx.x);
-}
-
 // Fix-up of chunk-crossing segments, two tiers.
 //   k_span_short : one GROUP per crossing segment: tail partial of its first chunk + head partials of the next chunks
 //                  whose first key equals the segment key, in chunk order.  Segments that cross more than
@@ -160,13 +155,12 @@ __global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
 //                  R partial sums are combined in a fixed order.  Both tiers are deterministic.
 
 template <int G, int J, class Policy>
-__device__ __forceinline__ void span_short_body(const SegBufs &S, const Policy &pol, int block_id, int n_blocks,
-                                                bool queue_long = true) {
+__device__ __forceinline__ void span_short_body(const SegBufs &S, const Policy &pol, int block_id, int n_blocks) {
   const int lane = threadIdx.x % G;
   const int gshift = (threadIdx.x & 63) / G * G;          // position of this group's lanes in the wave's ballot
   const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
   const uint32_t n_span = S.n_span[0];
-  const int gpb = (int)blockDim.x / G;
+  const int gpb = kBlock / G;
   constexpr int UL = J == 1 ? 8 : 2;                       // partial rows in flight
   for (uint32_t si = block_id * gpb + threadIdx.x / G; si < n_span; si += n_blocks * gpb) {
     const int g0 = (int)S.span_list[si];
@@ -187,8 +181,8 @@ __device__ __forceinline__ void span_short_body(const SegBufs &S, const Policy &
       }
       if (m >= kShortSpan) { is_long = true; break; }
     }
-    if (is_long || m > kShortSpan) {       // (when the caller found the long ones ahead of time they are somebody else's)
-      if (queue_long && lane == 0) S.long_list[atomicAdd(&S.n_span[1], 1u)] = (uint32_t)g0;
+    if (is_long || m > kShortSpan) {
+      if (lane == 0) S.long_list[atomicAdd(&S.n_span[1], 1u)] = (uint32_t)g0;
       continue;
     }
     float4 t[J];
@@ -222,15 +216,13 @@ __global__ __launch_bounds__(kBlock) void k_span_short(SegBufs S, Policy pol) {
 
 // lds: [R, ld] + [R] floats, R = kFixBlock / G
 template <int G, int J, class Policy>
-__device__ __forceinline__ void span_long_body(const SegBufs &S, const Policy &pol, int block_id, int n_blocks, float *lds,
-                                               const uint32_t *long_list = nullptr, const uint32_t *n_long_ptr = nullptr) {
+__device__ __forceinline__ void span_long_body(const SegBufs &S, const Policy &pol, int block_id, int n_blocks, float *lds) {
   constexpr int R = kFixBlock / G;
   float *sc = lds + (size_t)R * S.ld;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  if (!long_list) { long_list = S.long_list; n_long_ptr = S.n_span + 1; }
-  const uint32_t n_long = *n_long_ptr;
+  const uint32_t n_long = S.n_span[1];
   for (uint32_t si = block_id; si < n_long; si += n_blocks) {
-    const int g0 = (int)long_list[si];
+    const int g0 = (int)S.long_list[si];
     const uint32_t key = S.keys_s[min(S.T, (g0 + 1) * kChunk) - 1];
     float4 acc[J];
 #pragma unroll

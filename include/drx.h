@@ -132,10 +132,7 @@ int drx_cdae_step_sparse(const DrxCdaeParams *p, const DrxOptim *opt, const DrxH
 /* Same step with per-phase timing: `events` holds DRX_SPARSE_PHASES + 1 caller-created hipEvent_t; event i is recorded
  * on `stream` before phase i, the last one after the final phase.  Phases: 0 gather+forward+backward (k_sampled_fwd_bwd),
  * 1 touch sort, 2 segmented reduce + row update (k_seg_reduce), 3 tail launch A (short chunk-crossing segments, and beside
- * them the column-sum partials of the hidden-bias gradient), 4 tail launch B (long segments, and the hidden-bias update).
- * With a PREPARED touch list (drx_cdae_step_sparse_prepared, drx_cdae_kshard_step) the long segments are known ahead and the step
- * is three launches: phase 2 then also forms the bias partials, phase 3 is the whole tail (short | long | bias update) and
- * phase 4 is empty. */
+ * them the column-sum partials of the hidden-bias gradient), 4 tail launch B (long segments, and the hidden-bias update). */
 #define DRX_SPARSE_PHASES 5
 int drx_cdae_step_sparse_timed(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist,
                                const DrxBatch *bt, int32_t loss_kind, void *scratch, size_t scratch_bytes,
