@@ -58,12 +58,13 @@ class CaserArgs(C.Structure):
 class DmfDims(C.Structure):
     _fields_ = [('n_layers', C.c_int32 * 2), ('f', (C.c_int32 * 4) * 2), ('ld0', C.c_int32 * 2),
                 ('off_k', (C.c_int32 * 4) * 2), ('off_b', (C.c_int32 * 4) * 2), ('n_small', C.c_int32),
-                ('l2_norm_vectors', C.c_int32)]
+                ('l2_norm_vectors', C.c_int32), ('off_scale', C.c_int32)]
 
 
 class DmfArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('K0u', 'K0i', 'sw', 'u_indptr', 'u_indices', 'u_values', 'i_indptr', 'i_indices',
-                                          'i_values', 'uid', 'iid', 'y', 'off_u', 'off_i')] + [('B', C.c_int32)] + \
+                                          'i_values', 'uid', 'iid', 'y')] + [('target_mode', C.c_int32), ('y_mean', C.c_float)] + \
+               [(n, C.c_void_p) for n in ('off_u', 'off_i')] + [('B', C.c_int32)] + \
                [(n, C.c_void_p) for n in ('dz0u', 'dz0i', 'tkeys_u', 'tsrc_u', 'tcoef_u', 'tkeys_i', 'tsrc_i', 'tcoef_i',
                                           'gsw_part', 'loss_part', 'pred_out', 'rep_u_out', 'rep_i_out')]
 
@@ -135,7 +136,7 @@ SIGNATURES = {
     'drx_dmf_grid': (C.c_int, [C.c_int32]),
     'drx_dmf_fwd_bwd': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p]),
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
-    'drx_score_pairs_bf16': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+    'drx_score_pairs_bf16': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     'drx_topk_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -154,15 +154,22 @@ __global__ __launch_bounds__(64 * WV) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
       const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
       const float nu = ru * rhou, ni = ri * rhoi;
       const float s = group_sum<64>(nu * ni);
-      const float pred = fmaxf(1e-6f, s);
+      const float cosv = fmaxf(1e-6f, s);
+      // optional registered scalar multiplying every prediction (examples/extending_recommender_dmf.py:9-18)
+      const float wsc = D.off_scale >= 0 ? A.sw[D.off_scale] : 1.0f;
+      const float pred = wsc * cosv;
       if (!TRAIN) {
         if (k == 0 && A.pred_out) A.pred_out[b] = pred;
         if (A.rep_u_out) A.rep_u_out[(size_t)b * 64 + k] = nu;       // l2-normalised representations (zero beyond f_last)
         if (A.rep_i_out) A.rep_i_out[(size_t)b * 64 + k] = ni;
       } else {
-        const float y = A.y[b];
+        // target_mode 1: Keras BCE of (B,) targets against (B,1) predictions broadcasts to (B,B); its mean equals the BCE
+        // against the batch-mean target because the element is affine in t
+        const float y = A.target_mode == 1 ? A.y_mean : A.y[b];
         loss_acc += bce_elem(y, pred);
-        const float ds = s > 1e-6f ? bce_grad(y, pred) * inv_b : 0.f;
+        const float gp = bce_grad(y, pred) * inv_b;
+        if (D.off_scale >= 0 && k == 0) gsw[D.off_scale] = fmaf(gp, cosv, gsw[D.off_scale]);
+        const float ds = s > 1e-6f ? gp * wsc : 0.f;
         // l2_normalize backward (tf.nn.l2_normalize: x * rsqrt(max(sum x^2, eps)))
         const float dnu = ds * ni, dni = ds * nu;
         const float du = group_sum<64>(nu * dnu), di = group_sum<64>(ni * dni);
@@ -212,9 +219,10 @@ __device__ __forceinline__ short f2bf(float x) {
 }
 
 __global__ __launch_bounds__(64) void k_score_pairs_bf16(const float *__restrict__ ru, int n_u, const float *__restrict__ ri, int n_i,
-                                                         int ld, int kdim, float *__restrict__ out) {
+                                                         int ld, int kdim, const float *__restrict__ scale, float *__restrict__ out) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int u0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  const float wsc = scale ? *scale : 1.0f;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(64) void k_score_pairs_bf16(const float *__restrict
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    if (u0 + row < n_u && i0 + r < n_i) out[(size_t)(u0 + row) * n_i + i0 + r] = fmaxf(1e-6f, acc[reg]);
+    if (u0 + row < n_u && i0 + r < n_i) out[(size_t)(u0 + row) * n_i + i0 + r] = wsc * fmaxf(1e-6f, acc[reg]);
   }
 }
 
@@ -243,6 +251,7 @@ static int check_dims(const DrxDmfDims *D) {
       if (D->f[tw][l] < 1 || D->f[tw][l] > 64) return DRX_EINVAL;
     if (D->ld0[tw] < D->f[tw][0] || (D->ld0[tw] & 3) || D->ld0[tw] > 64) return DRX_EINVAL;
   }
+  if (D->off_scale < -1 || D->off_scale >= D->n_small) return DRX_EINVAL;
   return (size_t)D->n_small * 4 <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
 }
 
@@ -260,7 +269,7 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   if (!A || !A->K0u || !A->K0i || !A->sw || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices ||
       !A->i_values || !A->uid || !A->iid || !A->y || !A->off_u || !A->off_i || !A->dz0u || !A->dz0i || !A->tkeys_u ||
       !A->tsrc_u || !A->tcoef_u || !A->tkeys_i || !A->tsrc_i || !A->tcoef_i || !A->gsw_part || !A->loss_part || !gsw_out ||
-      A->B < 1)
+      A->B < 1 || (A->target_mode != 0 && A->target_mode != 1))
     return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = drx_dmf_grid(A->B);
@@ -295,11 +304,11 @@ int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream) {
   return DRX_OK;
 }
 
-int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim, float *out,
-                         void *stream) {
+int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim, const float *scale,
+                         float *out, void *stream) {
   if (!ru || !ri || !out || n_u < 1 || n_i < 1 || kdim < 16 || (kdim & 15) || ld < kdim) return DRX_EINVAL;
   hipLaunchKernelGGL(k_score_pairs_bf16, dim3((n_i + 31) / 32, (n_u + 31) / 32), dim3(64), 0, (hipStream_t)stream, ru, n_u, ri, n_i,
-                     ld, kdim, out);
+                     ld, kdim, scale, out);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

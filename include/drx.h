@@ -310,7 +310,8 @@ int drx_caser_hidden(const DrxCaserDims *D, const DrxCaserArgs *A, void *stream)
  * Tower 0 = user_nn (input: the user's interaction ROW over items), tower 1 = item_nn (input: the item's COLUMN over
  * users), both l2-normalised when l2_norm_vectors (dmf.py:75-86).  First-layer kernels K0u [n_items, ld0[0]] and
  * K0i [n_users, ld0[1]] are tables; every other weight lives in one flat array `sw`: layer l >= 1 kernel [f[l-1]][f[l]]
- * at off_k[tw][l], layer l >= 0 bias [f[l]] at off_b[tw][l].  Layer widths <= 64, <= 4 layers per tower. */
+ * at off_k[tw][l], layer l >= 0 bias [f[l]] at off_b[tw][l].  Layer widths <= 64, <= 4 layers per tower.
+ * gsw_out of drx_dmf_fwd_bwd holds the gradient of `sw` slot for slot (the scalar at off_scale included). */
 typedef struct DrxDmfDims {
   int32_t n_layers[2];
   int32_t f[2][4];
@@ -318,6 +319,8 @@ typedef struct DrxDmfDims {
   int32_t off_k[2][4], off_b[2][4];
   int32_t n_small;
   int32_t l2_norm_vectors;
+  int32_t off_scale;         /* offset in `sw` of a registered scalar that multiplies every prediction, or -1: the extra
+                              * tf.Variable of examples/extending_recommender_dmf.py:9-18 (ModifiedDMF, BASELINE config 3) */
 } DrxDmfDims;
 typedef struct DrxDmfArgs {
   const float *K0u, *K0i, *sw;
@@ -325,6 +328,9 @@ typedef struct DrxDmfArgs {
   const int64_t *i_indptr; const int32_t *i_indices; const float *i_values;   /* CSC (= CSR of the transpose) [N, U] */
   const int32_t *uid, *iid;  /* [B] */
   const float *y;            /* [B] targets (standardised when use_nce, dmf.py:69) */
+  int32_t target_mode;       /* 0: BCE(y[b], pred[b]) (dmf.py:98-99).  1: BCE(y_mean, pred[b]) = the mean of Keras' (B,B) broadcast of
+                              * (B,) targets against (B,1) predictions (ModifiedDMF's list of (1,)-tensors) */
+  float y_mean;              /* mean of y over the batch (target_mode 1) */
   const int32_t *off_u, *off_i;   /* [B+1] prefix sums of the row / column lengths of the batch */
   int32_t B;
   float *dz0u, *dz0i;        /* [B, ld0] gradient wrt the first-layer pre-activation */
@@ -342,8 +348,8 @@ int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream);
 /* all-pairs cosine scores on the matrix cores: out[u, n] = max(1e-6, ru[u,:kdim] . ri[n,:kdim]) with bf16 operands /
  * fp32 accumulation (v_mfma_f32_32x32x16_bf16); ru, ri = l2-normalised tower outputs, kdim % 16 == 0 (dmf.py:92-95
  * evaluated for a block of users against all items instead of one _predict per pair, recommender_abc.py:460). */
-int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim, float *out,
-                         void *stream);
+int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim,
+                         const float *scale /* device scalar multiplying every score, or NULL */, float *out, void *stream);
 
 /* ---- ranking (cdae.py:90-103, recommender_abc.py:454-461) --------------------------------
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with

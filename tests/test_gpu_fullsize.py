@@ -1,5 +1,6 @@
 """Size-independent properties of the sampled step at BASELINE sizes (no oracle can follow at this scale):
-  * ml-1m-shaped (config 1 of BASELINE.json: U=6040, N=3706, K=128) and a 1M-user x 1M-item slice of the 10M x 1M set
+  * ml-1m-shaped (config 2 of BASELINE.json: U=6040, N=3706, K=128), a 1M-user slice of the 10M x 1M set, and the
+    whole 10M-user x 1M-item x ~200M-interaction set of config 4 (one GPU holds all of it: 12.3 GB of tables + slots)
   * bit-reproducibility of a step sequence, `prepared` (side-stream) == inline touch lists bit for bit,
     rows no triple touches keep their bits (parameters AND optimizer slots), the row-sharded path at world 1 agrees with
     the direct path, the forward of a user is the same whether it is computed alone or inside a large batch."""
@@ -33,7 +34,7 @@ def _run(eng, N, B, steps, prepared):
     return [t.clone() for t in eng.tables()] + [t.clone() for t in eng.s1]
 
 
-@pytest.mark.parametrize('shape,users,B', [('ml-1m', None, 16384), ('synth-10m', 1_000_000, 65536)])
+@pytest.mark.parametrize('shape,users,B', [('ml-1m', None, 16384), ('synth-10m', 1_000_000, 65536), ('synth-10m', None, 65536)])
 def test_full_size_properties(shape, users, B):
     eng, U, N, ip, idx = _setup(shape, users)
     a = _run(eng, N, B, 3, prepared=False)
