@@ -50,8 +50,10 @@ def _user_lists(model, user, ds_test, thr, n_pos, n_neg, train_evaluation, gener
     return {'user': user, 'items': candidates, 'relevant': relevant, 'best': best_item, 'relevancies': relevancies}
 
 
-def _batched_rank(model, tasks, novelty):
-    """All users at once on the device: forward [R,N], candidate masks, top-k with heapq.nlargest order."""
+_RANK_CHUNK_BYTES = 1 << 30        # device bytes of one chunk's [R, N] prediction matrix
+
+
+def _rank_chunk(model, tasks, novelty):
     import torch
     from ..engine import pack_mask_bits
     ds = model.interaction_dataset
@@ -67,14 +69,34 @@ def _batched_rank(model, tasks, novelty):
         if novelty:
             cand[r, model._all_user_items(int(uids[r]))] = False
         kmax = max(kmax, int(cand[r].sum()))
-    out = []
     with model._device_lock:
         _, pred = eng.forward(uids)
         mask = torch.as_tensor(pack_mask_bits(cand).view(np.int32)).to(eng.device)
         idx, _ = eng.topk(pred, kmax, mask)
         idx = idx.cpu().numpy()
-    for r in range(R):
-        out.append([ds.iid_to_item(int(i)) for i in idx[r] if i >= 0])
+    return [[ds.iid_to_item(int(i)) for i in idx[r] if i >= 0] for r in range(R)]
+
+
+def _batched_rank(model, tasks, novelty):
+    """Users in chunks on the device: forward [R,N], candidate masks, top-k with heapq.nlargest order.  A chunk holds as many
+    users as keep its prediction matrix under _RANK_CHUNK_BYTES (and R*N under 2^31, the index range of drx_topk's long-row
+    path); a chunk that fails falls back to one model.rank() per user, and a user that still fails is logged and skipped like
+    the reference does (ranking_evaluation.py:152-156) — its entry is None."""
+    N = max(int(model.n_items), 1)
+    per = max(1, min(_RANK_CHUNK_BYTES // (4 * N), ((1 << 31) - 1) // N))
+    out = []
+    for lo in range(0, len(tasks), per):
+        chunk = tasks[lo:lo + per]
+        try:
+            out.extend(_rank_chunk(model, chunk, novelty))
+        except Exception as err:
+            logging.error(f'batched ranking of users {lo}..{lo + len(chunk) - 1} failed ({err}); ranking them one by one')
+            for t in chunk:
+                try:
+                    out.append([item for _, item in model.rank(t['user'], t['items'], novelty=novelty, skip_invalid_items=True)])
+                except Exception as e:
+                    logging.error(e)
+                    out.append(None)
     return out
 
 
@@ -118,5 +140,7 @@ def ranking_evaluation(model, ds_test=None, n_test_users=None, k=10, n_pos_inter
                   for t in tasks]
 
     for t, recommendations in zip(tasks, ranked):
+        if recommendations is None:                   # a user whose ranking failed: logged and skipped
+            continue
         table.add(recommendations, t['relevant'], t['best'], t['relevancies'])
     return table.result()

@@ -3,5 +3,7 @@ from .cdae import CDAE
 from .caser import Caser
 from .dmf import DMF
 from .early_stopping import EarlyStoppingRuleABC, MaxValidationValueRule
+from .trainables import TrainableLayer, TrainableModel, Variable
 
-__all__ = ['RecommenderABC', 'CDAE', 'Caser', 'DMF', 'EarlyStoppingRuleABC', 'MaxValidationValueRule']
+__all__ = ['RecommenderABC', 'CDAE', 'Caser', 'DMF', 'EarlyStoppingRuleABC', 'MaxValidationValueRule', 'Variable',
+           'TrainableLayer', 'TrainableModel']

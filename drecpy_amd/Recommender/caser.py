@@ -7,6 +7,9 @@ paper's per-dimension conv), max over time of the horizontal convs, dense Keras 
 (6 + L per step), l2(reg_rate) on embeddings and kernels.  TF's dropout RNG cannot be reproduced: the keep mask comes
 from a numpy Generator seeded with the model seed (or is injected with `dropout_mask_fn` for tests); relu is the only
 supported activation (the reference's default for both act_h and act_mlp).
+`_rank(novelty=False)` ignores the candidate list and ranks ALL items, exactly like caser.py:128-146 (only the novelty branch
+filters by `iids` there; ranking_evaluation defaults to novelty=False, so HR/NDCG@k are comparable with the reference's);
+`Caser(reference_rank=False)` restricts that branch to the candidates instead.
 """
 import numpy as np
 
@@ -18,8 +21,9 @@ class Caser(RecommenderABC):
     _host_prefetch = True      # fit() draws batch t+1 on a worker thread while batch t trains (sampler-only, engine-free hook)
 
     def __init__(self, L=5, T=3, d=50, n_v=4, n_h=16, act_h='relu', act_mlp='relu', dropout_rate=0.5,
-                 sort_column='timestamp', device='cuda:0', **kwds):
+                 sort_column='timestamp', device='cuda:0', reference_rank=True, **kwds):
         super().__init__(**kwds)
+        self.reference_rank = reference_rank
         if act_h != 'relu' or act_mlp != 'relu':
             raise Exception('drecpy_amd.Caser supports relu activations only (the reference defaults).')
         self.L, self.T, self.d, self.n_v, self.n_h = L, T, d, n_v, n_h
@@ -37,12 +41,24 @@ class Caser(RecommenderABC):
         if weights is None:
             weights = self._keras_init(np.random.default_rng(self.seed))
         self._engine.set_params(weights)
+        self._layers = self._engine.layers
+        self._register_trainables(self._layers)                              # caser.py:47-70, one Keras layer each
         self._sampler = ListSampler(self.interaction_dataset, ['uid'], neg_ratio=neg_ratio, n_targets=self.T,
                                     interaction_threshold=self.interaction_threshold, negative_ids_col='iid',
                                     min_positive_records=self.L, max_positive_records=self.L,
                                     sort_column=self.sort_column, seed=self.seed)
         self._drop_rng = np.random.default_rng(self.seed)
         self._dropout_mask_fn = kwds.get('dropout_mask_fn')
+
+    def _fused_trainables(self):
+        return self._engine.layers
+
+    def _configure_optimizer(self):
+        o = self.optimizer
+        if getattr(o, 'kind', None) != 'adam':
+            raise Exception(f'Caser trains with Keras Adam only (dense update of every registered layer); got {o!r}')
+        e = self._engine
+        e.lr, e.beta1, e.beta2, e.eps = o.learning_rate, o.beta_1, o.beta_2, o.epsilon
 
     def _keras_init(self, rng):
         """Keras defaults: Embedding uniform(-0.05, 0.05); Conv1D / Dense glorot_uniform kernels, zero biases."""
@@ -135,6 +151,8 @@ class Caser(RecommenderABC):
         cand[np.fromiter((int(i) for i in iids), dtype=np.int64)] = True
         if novelty:
             cand[seq] = False
+        elif getattr(self, 'reference_rank', True):
+            cand[:] = True                                                # caser.py:146: nlargest over every item
         k = min(int(n), int(cand.sum()))
         if k <= 0:
             return []

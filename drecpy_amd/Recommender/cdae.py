@@ -86,9 +86,44 @@ class CDAE(RecommenderABC):
             m.set_params_global(**weights)
         self._dist_model, self._engine = m, m.engine
         self._pipeline = self._pending = None
+        self._register_tables()
         self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
         self._mask_seed = int(self.seed if self.seed is not None else 0)
         self._mask_rng = None
+
+    def _register_tables(self):
+        """cdae.py:35-43: the five variables, registered in the order W, W_, V, b, b_ (their Adam counters: t = 5*step + j + 1).
+        The handles are views over the engine's tables (W_ is stored transposed, one output unit per row)."""
+        from .trainables import Variable
+        e = self._engine
+        self.W, self.W_, self.V, self.b, self.b_ = (Variable.over(t, n) for t, n in zip(e.tables(), ('W', 'W_', 'V', 'b', 'b_')))
+        self._register_trainables([self.W, self.W_, self.V, self.b, self.b_])
+
+    def _fused_trainables(self):
+        return [self.W, self.W_, self.V, self.b, self.b_]
+
+    def _configure_optimizer(self):
+        """Reference mode trains with Keras Adam (the default registered by fit(), or an optimizers.Adam passed as `optimizer=`);
+        sampled mode with the constructor's `sparse_optimizer` unless `optimizer=` forces another kind."""
+        o, e = self.optimizer, self._engine
+        if self.mode == 'reference':
+            if getattr(o, 'kind', None) != 'adam':
+                raise Exception(f'CDAE mode="reference" is the reference step: Keras Adam only (got {o!r}); Adagrad variants exist in mode="sampled"')
+            kind = 'adam'
+        else:
+            if not self._optimizer_forced:
+                return
+            kind = o.kind
+        if getattr(self, '_dist_model', None) is not None:
+            if self._optimizer_forced:
+                raise Exception('optimizer= cannot be forced on a column-sharded fit(): choose it with CDAE(sparse_optimizer=...)')
+            return
+        if kind == 'adam':
+            same = e.s2 is not None and (e.lr, e.beta1, e.beta2, e.opt_eps) == (o.learning_rate, o.beta_1, o.beta_2, o.epsilon)
+            if not same:                                   # (the slots _pre_fit allocated are kept when nothing differs)
+                e.init_optimizer('adam', o.learning_rate, e.reg_rate, o.beta_1, o.beta_2, o.epsilon)
+        else:
+            e.init_optimizer(kind, o.learning_rate, e.reg_rate, eps=o.epsilon, initial_accumulator=o.initial_accumulator_value)
 
     # ---- cdae.py:34-45 ---------------------------------------------------------------------------
     def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):
@@ -118,6 +153,7 @@ class CDAE(RecommenderABC):
             self._engine.init_optimizer('adam', learning_rate, reg_rate)
         else:
             self._engine.init_optimizer(self.sparse_optimizer, learning_rate, reg_rate)
+        self._register_tables()
         self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
         L = _lib.lib()
         seed = self.seed if self.seed is not None else self._rng.getrandbits(62)

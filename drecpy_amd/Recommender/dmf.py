@@ -44,7 +44,20 @@ class DMF(RecommenderABC):
         if weights is None:
             weights = self._keras_init(np.random.default_rng(self.seed))
         self._engine.set_params(weights)
+        self.user_nn, self.item_nn = self._engine.user_nn, self._engine.item_nn
+        self._register_trainables([self.user_nn, self.item_nn])               # dmf.py:60
         self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
+
+    def _fused_trainables(self):
+        e = self._engine
+        return [e.user_nn, e.item_nn] + ([e.scale_var] if e.scale_var is not None else [])
+
+    def _configure_optimizer(self):
+        o = self.optimizer
+        if getattr(o, 'kind', None) != 'adam':
+            raise Exception(f'DMF trains with Keras Adam only (dense update of both towers); got {o!r}')
+        e = self._engine
+        e.lr, e.beta1, e.beta2, e.eps = o.learning_rate, o.beta_1, o.beta_2, o.epsilon
 
     def _keras_init(self, rng):
         p = {}
@@ -64,12 +77,18 @@ class DMF(RecommenderABC):
 
     def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
         u, i, y = batch_samples
-        return self._engine.step(step, u, i, y, want_loss=want_loss)
+        e = self._engine
+        # one apply_gradients per registered item, in registration-list order (recommender_abc.py:194-196,328-334)
+        applies = (len(self._apply_order()), self._apply_position(e.user_nn), self._apply_position(e.item_nn),
+                   self._apply_position(e.scale_var) if e.scale_var is not None else None)
+        return e.step(step, u, i, y, want_loss=want_loss, applies=applies)
 
     def _predict_batch(self, batch_samples, **kwds):
+        """max(1e-6, cosine) of the batch pairs (dmf.py:88-96) as a device array [B] — WITHOUT any bound prediction scale: a
+        subclass that registered one multiplies here itself, like the reference's ModifiedDMF._predict_batch."""
         u, i, y = batch_samples
         with self._device_lock:
-            return self._engine.predict(u, i), y
+            return self._engine.predict(u, i, scaled=False), y
 
     def _compute_batch_loss(self, predictions, desired_values, **kwds):
         import torch
@@ -79,10 +98,17 @@ class DMF(RecommenderABC):
         pc = p.clamp(eps, 1 - eps)
         return float((-(t * torch.log(pc + eps) + (1 - t) * torch.log(1 - pc + eps))).mean().item())
 
-    def _predict(self, uid, iid, **kwds):                                 # dmf.py:101-106
-        with self._device_lock:
-            p = float(self._engine.predict(np.array([uid]), np.array([iid]))[0].item())
-        return self._rescale_value(p)
+    @staticmethod
+    def _as_array(preds):
+        """Predictions of _predict_batch -> numpy [B]: a device array, or (subclass overrides) a list of scalars / (1,)-arrays."""
+        import torch
+        if isinstance(preds, (list, tuple)):
+            preds = torch.stack([torch.as_tensor(p).reshape(-1)[0] for p in preds]) if len(preds) else torch.zeros(0)
+        return torch.as_tensor(preds).detach().reshape(-1).cpu().numpy()
+
+    def _predict(self, uid, iid, **kwds):                                 # dmf.py:101-106: through _predict_batch, like the reference
+        preds, _ = self._predict_batch((np.array([uid]), np.array([iid]), None))
+        return self._rescale_value(float(self._as_array(preds)[0]))
 
     def _rank(self, uid, iids, n, novelty):
         if novelty:
@@ -91,8 +117,7 @@ class DMF(RecommenderABC):
         iids = sorted(set(int(i) for i in iids))
         if not iids:
             return []
-        with self._device_lock:
-            preds = self._engine.predict(np.full(len(iids), uid), np.asarray(iids)).cpu().numpy()
+        preds = self._as_array(self._predict_batch((np.full(len(iids), uid), np.asarray(iids), None))[0])
         return nlargest(n, [(self._rescale_value(float(p)), i) for p, i in zip(preds, iids)])
 
     def score_matrix(self, user_ids):

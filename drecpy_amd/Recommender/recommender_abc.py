@@ -9,6 +9,14 @@ INTERNAL ids (recommender_abc.py:27).
 What changes underneath: a model provides `_do_batch(batch_samples, step, want_loss)` — one fused
 forward/loss/backward/update step on the GPU (BASELINE.json names this hook) — instead of being differentiated by a
 `tf.GradientTape` (recommender_abc.py:191-204).  One fit() "epoch" is still ONE mini-batch (recommender_abc.py:186-205).
+
+The registration half of the surface is kept too (recommender_abc.py:66-69, 266-285, 328-334): `_register_trainable(s)`
+fill `trainable_weights / trainable_layers / trainable_models` with HANDLES over device arrays (trainables.py) instead of
+TensorFlow objects; their concatenation, weights first (:194-196), is the order of the per-step optimizer applies and fixes
+each variable's Adam counter.  `_update_weights(gradients, trainable_weights)` applies gradients a model computed itself
+with the registered optimizer (optimizers.py) on the device.  What the engine does NOT have is the tape: a model whose
+trainables are only reachable through `_predict_batch` + `_compute_batch_loss` cannot be differentiated here and fit()
+says so (NotImplementedError) instead of returning an untrained model.
 Weights are snapshotted on the device only at epochs an early-stopping rule can choose (those where the epoch callback
 ran) instead of deep-copied every step (recommender_abc.py:336-341).  The loss is read back from the device only when it
 is logged or an early-stopping rule needs it.
@@ -26,7 +34,8 @@ from .loss_tracker import LossTracker
 
 _LOG_FORMAT = '[%(asctime)s] (%(levelname)s) %(name)s: %(message)s'
 _UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', '_mask_rngs', '_drawahead', '_L', 'epoch_weights', '_pipeline', '_pending',
-              '_host_pool', '_dist_model')
+              '_host_pool', '_dist_model', 'optimizer', 'trainable_vars', 'trainable_weights', 'trainable_layers', 'trainable_models',
+              '_extra_weight', 'W', 'W_', 'V', 'b', 'b_', 'user_nn', 'item_nn', '_layers')
 
 
 def _make_logger(name, handler):
@@ -110,6 +119,8 @@ class RecommenderABC(ABC):
         self.interaction_dataset = None
         self.fitted = False
         self.optimizer = None
+        self.trainable_vars = []                      # recommender_abc.py:66-69
+        self.trainable_weights, self.trainable_layers, self.trainable_models = [], [], []
         self.epoch_weights = {}                       # epoch -> device snapshot (only callback epochs)
         self._loss_tracker = None
         self._rng = random.Random(self.seed)          # recommender_abc.py:74
@@ -135,19 +146,53 @@ class RecommenderABC(ABC):
         self.max_interaction = ds.max('interaction')
         self.n_users, self.n_items, self.n_rows = ds.count_unique('uid'), ds.count_unique('iid'), len(ds)
 
+    def _reset_fit_state(self):
+        """A second fit() of the same object starts clean: per-dataset caches of the models (user -> items tables, sequences,
+        top-k helpers), snapshots of the previous run and the registration lists (the reference appends to them again on every
+        fit(), recommender_abc.py:66-69 are only initialised in __init__ — duplicates there, a fresh list here)."""
+        for name in ('_user_items', '_ui_sorted', '_ui_ptr', '_seq_ptr', '_seq_items', '_topk_helper'):
+            self.__dict__.pop(name, None)
+        self.epoch_weights = {}
+        self.trainable_vars = []
+        self.trainable_weights, self.trainable_layers, self.trainable_models = [], [], []
+
     def fit(self, interaction_dataset, epochs=50, batch_size=32, learning_rate=0.001, neg_ratio=5, reg_rate=0.001,
             copy_dataset=False, **kwds):
+        from .. import optimizers
+        self._reset_fit_state()
         self._bind_dataset(interaction_dataset, copy_dataset)
         self._loss_tracker = LossTracker()
         self._log_initial_info()
         self._info('Creating auxiliary structures...')
         self.learning_rate, self.reg_rate, self.batch_size = learning_rate, reg_rate, batch_size
-        self._register_optimizer(kwds.get('optimizer', 'adam'))      # default: Keras Adam(lr), recommender_abc.py:153
+        self._register_optimizer(optimizers.Adam(learning_rate=learning_rate))   # default optimizer, recommender_abc.py:153
         self._pre_fit(learning_rate, neg_ratio, reg_rate, **kwds)
-        self.fitted = True
+        self._optimizer_forced = kwds.get('optimizer', None) is not None
+        if self._optimizer_forced:                                   # allow forcing a custom optimizer (:155-156): AFTER _pre_fit
+            self._register_optimizer(optimizers.resolve(kwds.get('optimizer'), learning_rate))
+        self._configure_optimizer()
+        self.fitted = True  # should be able to make predictions after pre fit
+        registered = self.trainable_weights + self.trainable_layers + self.trainable_models
         if not hasattr(self, '_do_batch'):
-            self._info('No trainable step (_do_batch) defined: skipping further model training.')
-            return
+            if len(registered) == 0:
+                self._info('No trainable vars found: skipping further model training. If this is non-intentional, please '
+                           'use self._register_trainable or self._register_trainables to register variables that are '
+                           'subject to weight updates.')
+                return
+            raise NotImplementedError(
+                f'{type(self).__name__} registers {len(registered)} trainable variable(s) but defines no fused training step. This '
+                f'engine has no autodiff tape (recommender_abc.py:191-204 is replaced by hand-written HIP kernels), so a model '
+                f'defined only by _predict_batch / _compute_batch_loss cannot be trained: implement '
+                f'_do_batch(batch_samples, step, want_loss, **kwds) (see INTEGRATION.md), or derive from CDAE / DMF / Caser.')
+        fused = self._fused_trainables()
+        if fused is not None:
+            stray = [t for t in registered if not any(t is f for f in fused)]
+            if stray:
+                raise NotImplementedError(
+                    f'{type(self).__name__}: {stray} registered through _register_trainable(s) but the fused step of this model does '
+                    f'not update them (no autodiff tape here). Bind them to the engine (e.g. DmfEngine.bind_prediction_scale) or '
+                    f'update them in your own _do_batch with self._update_weights(gradients, variables).')
+        self._info(f'Number of registered trainable variables: {len(registered)}')
 
         monitor = _FitMonitor(self, epochs, kwds)
         monitor.before_training()
@@ -193,8 +238,61 @@ class RecommenderABC(ABC):
             return None
         return tqdm(range(1, epochs + 1), total=epochs, desc='Fitting model...', position=0, leave=True)
 
+    # ---- registration (recommender_abc.py:266-285) ----------------------------------------------------
+    def _register_trainable(self, variable):
+        from .trainables import TrainableLayer, TrainableModel, Variable
+        if variable is None:
+            raise Exception('Cannot register None as a trainable variable.')
+        if isinstance(variable, TrainableModel):
+            self.trainable_models.append(variable)
+        elif isinstance(variable, TrainableLayer):
+            self.trainable_layers.append(variable)
+        elif isinstance(variable, Variable):
+            self.trainable_weights.append(variable)
+        else:
+            raise Exception(f'Invalid trainable variable {variable}. The supported types are: drecpy_amd.Recommender.TrainableModel, '
+                            f'TrainableLayer and Variable (the device-side stand-ins for tf.keras.models.Model, '
+                            f'tf.keras.layers.Layer and tf.Variable; TensorFlow objects cannot be differentiated by this engine).')
+
+    def _register_trainables(self, variables):
+        for variable in variables:
+            self._register_trainable(variable)
+
     def _register_optimizer(self, optimizer):
         self.optimizer = optimizer
+
+    def _configure_optimizer(self):
+        """Called once per fit() after _pre_fit and the `optimizer=` override: models push the registered optimizer's kind and
+        hyper-parameters into their engine (and reject kinds their fused step does not implement)."""
+
+    def _fused_trainables(self):
+        """The handles a model's fused _do_batch updates, or None when the model manages its variables itself."""
+        return None
+
+    def _apply_order(self):
+        """Registered items in the order of the reference's per-step apply_gradients calls (recommender_abc.py:194-196)."""
+        return self.trainable_weights + self.trainable_layers + self.trainable_models
+
+    def _apply_position(self, handle):
+        for j, t in enumerate(self._apply_order()):
+            if t is handle:
+                return j
+        raise Exception(f'{handle} is not registered (self._register_trainable)')
+
+    def _update_weights(self, gradients, trainable_weights):
+        """One optimizer.apply_gradients per registered item (recommender_abc.py:328-334), on the device: `gradients[j]` is a
+        device array (or a list of them) matching `trainable_weights[j]` — a Variable, or the trainable_weights list of a
+        layer / model handle.  The fused steps of CDAE / DMF / Caser do this inside their kernels; this is for models that
+        compute gradients themselves in `_do_batch`."""
+        import torch
+        for gradient, trainable_var in zip(gradients, trainable_weights):
+            if torch.is_tensor(gradient):
+                gradient = [gradient]
+            if hasattr(trainable_var, 'trainable_weights'):             # a layer / model handle: its arrays
+                trainable_var = trainable_var.trainable_weights
+            elif not isinstance(trainable_var, (list, tuple)):           # a Variable (or a bare device array)
+                trainable_var = [trainable_var]
+            self.optimizer.apply_gradients(zip(gradient, trainable_var))
 
     # ---- hooks ------------------------------------------------------------------------------------
     @abstractmethod

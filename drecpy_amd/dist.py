@@ -161,7 +161,7 @@ class HipShardOps:
                                                     self._stream()), 'drx_shard_bias_apply')
 
     def optim(self, step):
-        a = self.engine.adam_alpha(self.engine.lr, step + 1)
+        a = self.engine.adam_alpha(self.engine.lr, step + 1, self.engine.beta1, self.engine.beta2)
         return self.engine._optim([a] * 5)
 
     def make_batch(self, *a, **k):

@@ -124,18 +124,22 @@ class CdaeEngine:
         self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices))
 
     # ---- optimizer --------------------------------------------------------------------------
-    def init_optimizer(self, kind, lr, reg_rate):
+    def init_optimizer(self, kind, lr, reg_rate, beta1=ADAM_B1, beta2=ADAM_B2, eps=None, initial_accumulator=ADAGRAD_INIT):
         """kind: 'adam' (Keras Adam, reference default recommender_abc.py:153), 'adagrad', or — sampled mode only —
-        'rowwise_adagrad' (one accumulator per table row: acc += mean_k(g^2); an engine extension, oracle/cdae_oracle.py)."""
+        'rowwise_adagrad' (one accumulator per table row: acc += mean_k(g^2); an engine extension, oracle/cdae_oracle.py).
+        The hyper-parameters default to tf.keras's; drecpy_amd.optimizers objects passed to fit(optimizer=...) set them."""
         if kind not in ('adam', 'adagrad', 'rowwise_adagrad'):
             raise _lib.DrxError(f'unknown optimizer "{kind}" (adam, adagrad, rowwise_adagrad)')
         self.opt_kind = {'adam': _lib.OPT_ADAM, 'adagrad': _lib.OPT_ADAGRAD, 'rowwise_adagrad': _lib.OPT_ROWWISE_ADAGRAD}[kind]
         self.lr, self.reg_rate = float(lr), float(reg_rate)
+        self.beta1, self.beta2 = float(beta1), float(beta2)
+        self.opt_eps = float(eps) if eps is not None else (ADAM_EPS if kind == 'adam' else ADAGRAD_EPS)
+        self._optim_struct = self._alpha_tab = None
         if kind == 'adam':
             self.s1 = [torch.zeros_like(t) for t in self.tables()]
             self.s2 = [torch.zeros_like(t) for t in self.tables()]
         else:
-            self.s1 = [torch.full_like(t, ADAGRAD_INIT) for t in self.tables()]
+            self.s1 = [torch.full_like(t, float(initial_accumulator)) for t in self.tables()]
             self.s2 = None
 
     def _optim(self, alphas):
@@ -145,8 +149,8 @@ class CdaeEngine:
             o = Optim()
             o.kind = self.opt_kind
             o.lr, o.reg_rate = self.lr, self.reg_rate
-            o.beta1, o.beta2 = ADAM_B1, ADAM_B2
-            o.eps = ADAM_EPS if self.opt_kind == _lib.OPT_ADAM else ADAGRAD_EPS
+            o.beta1, o.beta2 = self.beta1, self.beta2
+            o.eps = self.opt_eps
             for j in range(5):
                 o.s1[j] = self.s1[j].data_ptr()
                 o.s2[j] = self.s2[j].data_ptr() if self.s2 is not None else 0
@@ -155,10 +159,10 @@ class CdaeEngine:
         return o
 
     @staticmethod
-    def adam_alpha(lr, t):
+    def adam_alpha(lr, t, beta1=ADAM_B1, beta2=ADAM_B2):
         """Keras-Adam lr_t for the 1-based step t, in fp32 like optimizer_v2/adam.py."""
         f = np.float32
-        return float(f(lr) * np.sqrt(f(1.0) - np.power(f(ADAM_B2), f(t))) / (f(1.0) - np.power(f(ADAM_B1), f(t))))
+        return float(f(lr) * np.sqrt(f(1.0) - np.power(f(beta2), f(t))) / (f(1.0) - np.power(f(beta1), f(t))))
 
     _ALPHA_CHUNK = 512
 
@@ -170,7 +174,7 @@ class CdaeEngine:
         if c is None or c[0] != base or c[1] != self.lr:
             f = np.float32
             t = (5 * base + 1 + np.arange(5 * self._ALPHA_CHUNK)).astype(np.float32)
-            tab = f(self.lr) * np.sqrt(f(1.0) - np.power(f(ADAM_B2), t)) / (f(1.0) - np.power(f(ADAM_B1), t))
+            tab = f(self.lr) * np.sqrt(f(1.0) - np.power(f(self.beta2), t)) / (f(1.0) - np.power(f(self.beta1), t))
             c = self._alpha_tab = (base, self.lr, tab.astype(np.float32).reshape(-1, 5).tolist())
         return c[2][step - base]
 
@@ -402,7 +406,7 @@ class CdaeEngine:
         events: optional list of 6 recorded-once torch.cuda.Event(enable_timing=True); their raw hipEvent_t are
         re-recorded by the library around each phase (include/drx.h, drx_cdae_step_sparse_timed).
         prepared: buffer returned by prepare_sparse() for this batch (else the touch list is built inline)."""
-        a = self.adam_alpha(self.lr, step + 1)
+        a = self.adam_alpha(self.lr, step + 1, self.beta1, self.beta2)
         o = self._optim([a] * 5)
         sc = self._ensure_scratch(bt.B, bt.n_touch_slots)
         lk = _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE

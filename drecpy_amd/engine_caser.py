@@ -62,6 +62,15 @@ class CaserEngine:
                 self._grads[n] = torch.zeros_like(t)
         self._scratch = None
         self.lr, self.reg = 1e-3, 1e-3
+        self.beta1, self.beta2, self.eps = ADAM_B1, ADAM_B2, ADAM_EPS
+        from .Recommender.trainables import TrainableLayer
+        # the 6 + L Keras layers caser.py:47-70 registers, in that order (= the order of the per-step Adam applies)
+        seg_views = lambda j: [self.sw[st:st + n] for _, st, n, _, layer in self.seg if layer == j]
+        self.layers = [TrainableLayer('user_embeddings', lambda: [self.user_emb]), TrainableLayer('item_embeddings', lambda: [self.item_emb]),
+                       TrainableLayer('conv_v', lambda: seg_views(2))]
+        self.layers += [TrainableLayer(f'convs_h[{i}]', (lambda i=i: seg_views(3 + i))) for i in range(L)]
+        self.layers += [TrainableLayer('dense_0', lambda: seg_views(3 + L)), TrainableLayer('dense_1_W', lambda: [self.W1]),
+                        TrainableLayer('dense_1_b', lambda: [self.b1])]
 
     def tensors(self):
         return {'user_emb': self.user_emb, 'item_emb': self.item_emb, 'W1': self.W1, 'b1': self.b1, 'sw': self.sw}
@@ -131,7 +140,7 @@ class CaserEngine:
     def _adam(self, name, grad, alpha, l2c):
         p = self.tensors()[name]
         m, v = self.state[name]
-        check(lib().drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(grad), p.numel(), alpha, l2c, ADAM_B1, ADAM_B2, ADAM_EPS,
+        check(lib().drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(grad), p.numel(), alpha, l2c, self.beta1, self.beta2, self.eps,
                                    stream_ptr(self.device)), 'drx_adam_dense')
 
     def _args(self, uid, before, after=None, keep=None, rate=0.0):
@@ -189,7 +198,7 @@ class CaserEngine:
         self._scatter(bef.reshape(-1), dE, self.ld, self.N, g['item_emb'])
         self._scatter(aft.reshape(-1), dW1, self.ld2, self.N, g['W1'], src_s=db1, out_s=g['b1'])
         self._scatter(uid, dPu, self.ld, self.U, g['user_emb'])
-        alpha = lambda j: CdaeEngine.adam_alpha(self.lr, self.n_layers * step_idx + j + 1)
+        alpha = lambda j: CdaeEngine.adam_alpha(self.lr, self.n_layers * step_idx + j + 1, self.beta1, self.beta2)
         l2c = 2.0 * self.reg
         self._adam('user_emb', g['user_emb'], alpha(0), l2c)
         self._adam('item_emb', g['item_emb'], alpha(1), l2c)
@@ -200,7 +209,7 @@ class CaserEngine:
         for i, (_, start, n, regd, layer) in enumerate(self.seg):
             sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha(layer), (l2c if regd else 0.0)
         m, v = self.state['sw']
-        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), ADAM_B1, ADAM_B2, ADAM_EPS,
+        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), self.beta1, self.beta2, self.eps,
                                    stream_ptr(self.device)), 'drx_adam_segments')
         if want_loss:
             return float((gsw[-1] + reg_loss).item())

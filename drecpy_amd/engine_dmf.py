@@ -6,6 +6,10 @@ One training step = the body of the reference fit() loop for DMF (recommender_ab
   drx_scatter_rows x2   first-layer kernel gradients (embedding-bag backward), deterministic
   drx_adam_dense x2     Keras l2 + Adam on the two first-layer kernels (user_nn t = 2s+1, item_nn t = 2s+2)
   drx_adam_segments     deeper kernels and all biases
+
+`bind_prediction_scale(variable)` adds the ModifiedDMF extension of examples/extending_recommender_dmf.py:9-18 to the fused
+step: one registered scalar multiplies every prediction, the loss becomes Keras' (B,B) broadcast (= BCE against the batch-mean
+target) and the step makes three Adam applies, the scalar first (recommender_abc.py:194-196,328-334).
 """
 import ctypes as C
 
@@ -25,7 +29,9 @@ class DmfEngine:
         self.device = torch.device(device)
         self.U, self.N = n_users, n_items
         self.factors = [list(user_factors), list(item_factors)]
-        assert all(1 <= len(f) <= 4 and max(f) <= 64 for f in self.factors), 'DMF engine: <= 4 layers of width <= 64'
+        if not all(1 <= len(f) <= 4 and 1 <= min(f) and max(f) <= 64 for f in self.factors):
+            raise _lib.DrxError(f'DMF engine: towers of 1..4 layers of width 1..64 are supported (lane = hidden unit of one wavefront), got '
+                                f'user_factors={self.factors[0]}, item_factors={self.factors[1]}')
         D = DmfDims()
         self.seg = []                      # (name, start, len, regularised, tower)
         off = 0
@@ -40,9 +46,15 @@ class DmfEngine:
                     self.seg.append((f'{pre}{l}_k', off, f[l - 1] * fl, True, tw)); off += _round_up(f[l - 1] * fl, 4)
                 D.off_b[tw][l] = off
                 self.seg.append((f'{pre}{l}_b', off, fl, False, tw)); off += _round_up(fl, 4)
+        self._scale_slot = off                 # reserved for a registered prediction scale (bind_prediction_scale); unused: 1.0, no gradient
+        off += 4
         D.n_small = off
         D.l2_norm_vectors = 1 if l2_norm_vectors else 0
+        D.off_scale = -1
         self.D = D
+        self.scale_var = None
+        self.broadcast_targets = False
+        self.beta1, self.beta2, self.eps = ADAM_B1, ADAM_B2, ADAM_EPS
         z = dict(dtype=torch.float32, device=self.device)
         self.K0u = torch.zeros(n_items, D.ld0[0], **z)
         self.K0i = torch.zeros(n_users, D.ld0[1], **z)
@@ -53,6 +65,31 @@ class DmfEngine:
         self._g = {'K0u': self._g_arena[:nu].view(self.K0u.shape), 'K0i': self._g_arena[nu:].view(self.K0i.shape)}
         self._scratch = None
         self.lr, self.reg = 1e-3, 1e-3
+        from .Recommender.trainables import TrainableModel
+        # what DMF._pre_fit registers (dmf.py:60): the two Sequential towers, each one apply_gradients per step
+        self.user_nn = TrainableModel('user_nn', lambda: self._tower_weights(0))
+        self.item_nn = TrainableModel('item_nn', lambda: self._tower_weights(1))
+
+    def _tower_weights(self, tw):
+        out = [(self.K0u, self.K0i)[tw][:, :self.factors[tw][0]]]
+        for name, start, n, _, t in self.seg:
+            if t == tw:
+                out.append(self.sw[start:start + n])
+        return out
+
+    def bind_prediction_scale(self, variable, broadcast_targets=True):
+        """Every prediction of the fused step (and of predict / score_matrix_bf16) is multiplied by `variable` (a registered scalar
+        Variable), whose gradient and Adam update the step then also computes.  broadcast_targets: the loss is Keras' (B,B)
+        broadcast of (B,) targets against (B,1) predictions — what ModifiedDMF's list of (1,)-tensors produces."""
+        if variable.tensor.numel() != 1:
+            raise _lib.DrxError('the prediction scale is one scalar')
+        self.sw[self._scale_slot:self._scale_slot + 4].zero_()
+        variable._rebind(self.sw[self._scale_slot:self._scale_slot + 1])
+        variable._consumed_by = self
+        self.D.off_scale = self._scale_slot
+        self.scale_var = variable
+        self.broadcast_targets = bool(broadcast_targets)
+        self.state['sw'][0].zero_(); self.state['sw'][1].zero_()
 
     def tensors(self):
         return {'K0u': self.K0u, 'K0i': self.K0i, 'sw': self.sw}
@@ -67,8 +104,11 @@ class DmfEngine:
 
     def set_params(self, p):
         t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
+        keep_scale = float(self.sw[self._scale_slot].item()) if self.scale_var is not None else None
         for x in self.tensors().values():
             x.zero_()
+        if self.scale_var is not None:        # ('extra_w' before a scale is bound is left to the binder: ModifiedDMF assigns it afterwards)
+            self.sw[self._scale_slot] = float(np.asarray(p['extra_w']).reshape(-1)[0]) if 'extra_w' in p else keep_scale
         self.K0u[:, :self.factors[0][0]] = t(p['u0_k'])
         self.K0i[:, :self.factors[1][0]] = t(p['i0_k'])
         for name, start, n, _, _ in self.seg:
@@ -83,6 +123,8 @@ class DmfEngine:
                 l = int(name[1])
                 v = v.reshape(self.factors[tw][l - 1], self.factors[tw][l])
             p[name] = v
+        if self.scale_var is not None:
+            p['extra_w'] = c(self.sw[self._scale_slot:self._scale_slot + 1])
         return p
 
     def snapshot(self):
@@ -135,7 +177,10 @@ class DmfEngine:
         dev, views = self._stage([u64.astype(np.int32), i64.astype(np.int32), np.ascontiguousarray(y, dtype=np.float32), off_u, off_i])
         return (dev, views), [v.data_ptr() for v in views], B, int(off_u[-1]), int(off_i[-1])
 
-    def step(self, step_idx, uids, iids, y, want_loss=False):
+    def step(self, step_idx, uids, iids, y, want_loss=False, applies=None):
+        """applies = (n, j_user, j_item, j_scale): number of apply_gradients calls per step and the positions of user_nn, item_nn
+        and the prediction scale among them (the registration order, recommender_abc.py:194-196); default: the reference DMF's
+        (2, 0, 1), or (3, 1, 2, 0) with a bound scale."""
         L_ = lib()
         z = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
@@ -162,6 +207,9 @@ class DmfEngine:
         A.i_indptr, A.i_indices, A.i_values = (t.data_ptr() for t in self.csc)
         A.uid, A.iid, A.B = p_uid, p_iid, int(B)
         A.y, A.off_u, A.off_i = p_y, p_offu, p_offi
+        if self.broadcast_targets and self.scale_var is not None:
+            A.target_mode = 1
+            A.y_mean = float(np.asarray(y, dtype=np.float64).mean()) if not torch.is_tensor(y) else float(y.double().mean().item())
         A.dz0u, A.dz0i = dz0u.data_ptr(), dz0i.data_ptr()
         A.tkeys_u, A.tsrc_u, A.tcoef_u = tk_u.data_ptr(), ts_u.data_ptr(), tc_u.data_ptr()
         A.tkeys_i, A.tsrc_i, A.tcoef_i = tk_i.data_ptr(), ts_i.data_ptr(), tc_i.data_ptr()
@@ -177,26 +225,34 @@ class DmfEngine:
         self._g_arena.zero_()
         self._scatter(tk_u, Tu, dz0u, ts_u, tc_u, ld0u, self.N, self._g['K0u'])
         self._scatter(tk_i, Ti, dz0i, ts_i, tc_i, ld0i, self.U, self._g['K0i'])
-        alpha = [CdaeEngine.adam_alpha(self.lr, 2 * step_idx + j + 1) for j in range(2)]
+        if applies is None:
+            applies = (3, 1, 2, 0) if self.scale_var is not None else (2, 0, 1, None)
+        n_app = applies[0]
+        alpha = [CdaeEngine.adam_alpha(self.lr, n_app * step_idx + j + 1, self.beta1, self.beta2) if j is not None else 0.0 for j in applies[1:]]
         l2c = 2.0 * self.reg
         for name, tw in (('K0u', 0), ('K0i', 1)):
             p = self.tensors()[name]
             m, v = self.state[name]
-            check(L_.drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(self._g[name]), p.numel(), alpha[tw], l2c, ADAM_B1, ADAM_B2,
-                                    ADAM_EPS, stream_ptr(self.device)), 'drx_adam_dense')
+            check(L_.drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(self._g[name]), p.numel(), alpha[tw], l2c, self.beta1, self.beta2,
+                                    self.eps, stream_ptr(self.device)), 'drx_adam_dense')
         sg = AdamSegments()
         sg.n = len(self.seg)
         for i, (_, start, n, regd, tw) in enumerate(self.seg):
             sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[tw], (l2c if regd else 0.0)
+        if self.scale_var is not None:                     # the registered scalar: its own lr_t, no regulariser
+            i = sg.n
+            sg.n += 1
+            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = self._scale_slot, 1, alpha[2], 0.0
         m, v = self.state['sw']
-        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), ADAM_B1, ADAM_B2, ADAM_EPS,
+        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), self.beta1, self.beta2, self.eps,
                                    stream_ptr(self.device)), 'drx_adam_segments')
         if want_loss:
             return float((gsw[-1] + reg_loss).item())
         return None
 
-    def predict(self, uids, iids, want_reps=False):
-        """max(1e-6, cosine) for each (uid, iid) pair (dmf.py:88-96); optionally the normalised tower outputs [B,64]."""
+    def predict(self, uids, iids, want_reps=False, scaled=True):
+        """max(1e-6, cosine) for each (uid, iid) pair (dmf.py:88-96) — times the bound prediction scale unless scaled=False;
+        optionally the normalised tower outputs [B,64]."""
         uid, iid = self._i32(uids), self._i32(iids)
         B = uid.numel()
         pred = torch.empty(B, dtype=torch.float32, device=self.device)
@@ -207,7 +263,11 @@ class DmfEngine:
             ru = torch.empty(B, 64, dtype=torch.float32, device=self.device)
             ri = torch.empty(B, 64, dtype=torch.float32, device=self.device)
             A.rep_u_out, A.rep_i_out = ru.data_ptr(), ri.data_ptr()
-        check(lib().drx_dmf_predict(C.byref(self.D), C.byref(A), stream_ptr(self.device)), 'drx_dmf_predict')
+        D = self.D
+        if not scaled and self.D.off_scale >= 0:
+            D = DmfDims.from_buffer_copy(self.D)
+            D.off_scale = -1
+        check(lib().drx_dmf_predict(C.byref(D), C.byref(A), stream_ptr(self.device)), 'drx_dmf_predict')
         return (pred, ru, ri) if want_reps else pred
 
     def score_matrix_bf16(self, uids):
@@ -219,6 +279,7 @@ class DmfEngine:
         _, ru, _ = self.predict(uid, torch.zeros(n_u, dtype=torch.int32, device=self.device), want_reps=True)
         out = torch.empty(n_u, self.N, dtype=torch.float32, device=self.device)
         kdim = _round_up(self.factors[0][-1], 16)
-        check(lib().drx_score_pairs_bf16(ptr(ru), n_u, ptr(ri), self.N, 64, kdim, ptr(out), stream_ptr(self.device)),
+        scale = ptr(self.sw[self._scale_slot:]) if self.scale_var is not None else None
+        check(lib().drx_score_pairs_bf16(ptr(ru), n_u, ptr(ri), self.N, 64, kdim, scale, ptr(out), stream_ptr(self.device)),
               'drx_score_pairs_bf16')
         return out

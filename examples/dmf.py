@@ -1,5 +1,6 @@
-"""DMF: two dense towers over a user's rating row and an item's rating column, cosine score — the model DRecPy builds in
-examples/extending_recommender_dmf.py.  rank() scores a user against all candidates with the bf16 MFMA kernel.
+"""DMF: two dense towers over a user's rating row and an item's rating column, cosine score (DRecPy/Recommender/dmf.py) — the
+base class of the ModifiedDMF that DRecPy's examples/extending_recommender_dmf.py builds; its twin here is
+examples/extending_recommender_dmf.py.  score_matrix() scores users against all items with the bf16 MFMA kernel.
     python examples/dmf.py [--movielens /data/ml-1m] [--epochs 200]"""
 from _common import arguments, split, stopwatch
 

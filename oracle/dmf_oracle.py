@@ -12,6 +12,14 @@ Follows DRecPy/Recommender/dmf.py (paths under /root/reference):
   loss .............. dmf.py:98-99   Keras BCE, [B] vs [B], mean
   optimizer ......... one apply_gradients per registered model (recommender_abc.py:328-334): user_nn's weights use Adam
                       t = 2*step + 1, item_nn's t = 2*step + 2
+
+ModifiedDMF (examples/extending_recommender_dmf.py:5-18, BASELINE config 3) — present when p holds 'extra_w':
+  extra weight ...... :11-12  tf.Variable([1.]) registered AFTER DMF._pre_fit; a tf.Variable lands in trainable_weights
+                      (recommender_abc.py:274-275), which precede the models in the apply order (:194-196): Adam t =
+                      3*step + 1 for the scalar, 3*step + 2 for user_nn, 3*step + 3 for item_nn; no regulariser on it
+  predictions ....... :14-17  [extra_w * pred for pred in predictions]: a LIST of B (1,)-tensors -> Keras converts it to (B,1),
+                      the (B,) targets broadcast against it to (B,B) (lists skip the squeeze step):
+                      L = 1/B^2 sum_i sum_j bce(y_j, w*pred_i), computed literally here (`broadcast_targets=True`)
 """
 import numpy as np
 
@@ -65,19 +73,27 @@ def forward(p, xu, xi, nu_layers, ni_layers, l2_norm_vectors=True):
     c['nu'], c['qu'], c['rhou'] = l2_normalize(c['au'][-1])
     c['ni'], c['qi'], c['rhoi'] = l2_normalize(c['ai'][-1])
     c['s'] = (c['nu'] * c['ni']).sum(axis=1)
-    pred = np.maximum(xu.dtype.type(1e-6), c['s'])
+    c['cos'] = np.maximum(xu.dtype.type(1e-6), c['s'])
+    pred = c['cos'] * p['extra_w'][0] if 'extra_w' in p else c['cos']
     return pred, c
 
 
-def loss_and_grads(p, xu, xi, y, reg_rate, nu_layers, ni_layers, l2_norm_vectors=True):
+def loss_and_grads(p, xu, xi, y, reg_rate, nu_layers, ni_layers, l2_norm_vectors=True, broadcast_targets=False):
     dt = xu.dtype
     B = len(y)
     pred, c = forward(p, xu, xi, nu_layers, ni_layers, l2_norm_vectors)
     y = np.asarray(y, dt)
-    lval = co.bce_elem(y, pred, dt).mean()
-    dpred = co.bce_grad(y, pred, dt) / dt.type(B)
-    ds = np.where(c['s'] > 1e-6, dpred, dt.type(0))[:, None]
+    if broadcast_targets:                       # (B,) targets vs (B,1) predictions -> (B,B); mean over both axes
+        lval = co.bce_elem(y[None, :], pred[:, None], dt).mean(axis=-1).mean()
+        dpred = co.bce_grad(y[None, :], pred[:, None], dt).sum(axis=1) / dt.type(B * B)
+    else:
+        lval = co.bce_elem(y, pred, dt).mean()
+        dpred = co.bce_grad(y, pred, dt) / dt.type(B)
     g = {}
+    if 'extra_w' in p:
+        g['extra_w'] = np.array([(dpred * c['cos']).sum()], dt)
+        dpred = dpred * p['extra_w'][0]
+    ds = np.where(c['s'] > 1e-6, dpred, dt.type(0))[:, None]
     for tower, n_layers, dn, key in (('u', nu_layers, ds * c['ni'], 'u'), ('i', ni_layers, ds * c['nu'], 'i')):
         acts, pres = (c['au'], c['pu']) if tower == 'u' else (c['ai'], c['pi'])
         n, q, rho = (c['nu'], c['qu'], c['rhou']) if tower == 'u' else (c['ni'], c['qi'], c['rhoi'])
@@ -95,12 +111,13 @@ def adam_state(p):
     return {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in p.items()}
 
 
-def step(p, state, step_idx, xu, xi, y, lr, reg_rate, nu_layers, ni_layers, l2_norm_vectors=True):
+def step(p, state, step_idx, xu, xi, y, lr, reg_rate, nu_layers, ni_layers, l2_norm_vectors=True, broadcast_targets=False):
     dt = xu.dtype
-    lval, g, _ = loss_and_grads(p, xu, xi, y, reg_rate, nu_layers, ni_layers, l2_norm_vectors)
-    for j, tower in enumerate(('u', 'i')):
-        a = dt.type(co.adam_alpha(lr, 2 * step_idx + j + 1))
-        for name in [k for k in p if k.startswith(tower)]:
+    lval, g, _ = loss_and_grads(p, xu, xi, y, reg_rate, nu_layers, ni_layers, l2_norm_vectors, broadcast_targets)
+    groups = ([['extra_w']] if 'extra_w' in p else []) + [[k for k in p if k[0] == tower and k[1].isdigit()] for tower in ('u', 'i')]
+    for j, names in enumerate(groups):          # one apply_gradients per registered item, trainable_weights first
+        a = dt.type(co.adam_alpha(lr, len(groups) * step_idx + j + 1))
+        for name in names:
             m, v = state[name]
             m[...] = m + (g[name] - m) * dt.type(co.ADAM_OMB1)
             v[...] = v + (g[name] * g[name] - v) * dt.type(co.ADAM_OMB2)

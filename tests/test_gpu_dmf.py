@@ -119,3 +119,129 @@ def test_dmf_fit_matches_oracle_end_to_end():
     assert len(ranked) == 5 and all(ranked[j][0] >= ranked[j + 1][0] for j in range(4))
     sm = model.score_matrix([raw_u]).cpu().numpy()
     assert sm.shape == (1, N)
+
+
+# ---- ModifiedDMF: the model BASELINE.json config 3 names (examples/extending_recommender_dmf.py) ------------------------------
+def _modified_engine(U, N, csr, csc, p, uf=(64, 32), itf=(64, 32)):
+    from drecpy_amd.engine_dmf import DmfEngine
+    from drecpy_amd.Recommender import Variable
+    eng = DmfEngine(U, N, uf, itf, True)
+    eng.set_interactions(csr, csc)
+    w = Variable([1.0])
+    eng.bind_prediction_scale(w, broadcast_targets=True)
+    eng.set_params(p)
+    return eng, w
+
+
+@pytest.mark.parametrize('shape,B', [('small', 48), ('ml-1m', 256)])
+def test_modified_dmf_steps_match_oracle(shape, B):
+    """The registered scalar multiplies every prediction, the loss is the (B,B) Keras broadcast, three Adam applies per step with
+    the scalar first (t = 3s+1, 3s+2, 3s+3): HIP step against the fp64 oracle, which computes the broadcast literally."""
+    rng = np.random.default_rng(B)
+    if shape == 'small':
+        U, N = 70, 90
+        csr, csc, dense = _problem(rng, U, N, 1500)
+        uf, itf, steps = (16, 8), (24, 8), 8
+    else:
+        from test_gpu_baseline_shapes import _ml1m_ratings
+        U, N, csr, csc, dense = _ml1m_ratings()
+        uf, itf, steps = (64, 32), (64, 32), 3
+    p = dm.init_params(rng, U, N, uf, itf, np.float64)
+    p['extra_w'] = np.array([0.9])
+    eng, w = _modified_engine(U, N, csr, csc, p, uf, itf)
+    eng.lr, eng.reg = 2e-3, 1e-3
+    st = dm.adam_state(p)
+    for step in range(steps):
+        uids = rng.integers(0, U, size=B)
+        iids = rng.integers(0, N, size=B)
+        y = rng.random(B)
+        lo = dm.step(p, st, step, dense[uids], dense[:, iids].T.copy(), y, 2e-3, 1e-3, len(uf), len(itf), True, broadcast_targets=True)
+        lg = eng.step(step, uids, iids, y, want_loss=True)
+        assert abs(lg - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    assert abs(g['extra_w'][0] - 0.9) > 1e-3                     # the scalar trains ...
+    assert w.numpy()[0] == g['extra_w'][0]                       # ... and the registered handle sees the engine's memory
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
+    uids = rng.integers(0, U, size=40)
+    iids = rng.integers(0, N, size=40)
+    want, _ = dm.forward(p, dense[uids], dense[:, iids].T.copy(), len(uf), len(itf), True)
+    assert np.max(np.abs(eng.predict(uids, iids).cpu().numpy() - want) / np.maximum(np.abs(want), 1e-6)) < 1e-4
+    assert np.max(np.abs(eng.predict(uids, iids, scaled=False).cpu().numpy() * p['extra_w'][0] - want)) < 1e-5
+    sc = eng.score_matrix_bf16(uids[:4]).cpu().numpy()           # the MFMA scorer applies the scale too
+    want4, _ = dm.forward(p, np.repeat(dense[uids[0]:uids[0] + 1], N, axis=0), dense.T.copy(), len(uf), len(itf), True)
+    assert np.max(np.abs(sc[0] - want4)) < 1.5e-2
+
+
+def test_modified_dmf_fit_matches_oracle_end_to_end():
+    """examples/extending_recommender_dmf.py's ModifiedDMF through the public fit(): registration order -> Adam counters,
+    reference-exact PointSampler stream, _predict through the overridden _predict_batch."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
+    from extending_recommender_dmf import ModifiedDMF
+    from helpers import load_frames
+    from drecpy_amd.Dataset import InteractionDataset
+    frame = {k: v.copy() for k, v in load_frames()['pt_int_dense'].items()}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    uid, _ = do.first_appearance_codes(frame['user'].tolist())
+    iid, _ = do.first_appearance_codes(frame['item'].tolist())
+    U, N = int(uid.max()) + 1, int(iid.max()) + 1
+    p = dm.init_params(np.random.default_rng(2), U, N, (16, 8), (16, 8), np.float32)
+    epochs, B, seed = 8, 32, 10
+    model = ModifiedDMF(user_factors=[16, 8], item_factors=[16, 8], seed=seed, verbose=False)
+    model.fit(ds, epochs=epochs, batch_size=B, learning_rate=2e-3, reg_rate=1e-3, neg_ratio=3, initial_weights=p)
+    assert model.trainable_weights == [model._extra_weight] and len(model.trainable_models) == 2
+    assert model._apply_order()[0] is model._extra_weight            # the tf.Variable's apply comes first (recommender_abc.py:194-196)
+    dense = np.zeros((U, N))
+    np.add.at(dense, (uid, iid), frame['interaction'].astype(np.float64))
+    smp = do.PointSamplerOracle(uid, iid, frame['interaction'], 3, 1e-3, seed)
+    po = {k: v.astype(np.float64) for k, v in p.items()}
+    po['extra_w'] = np.array([1.0])
+    st = dm.adam_state(po)
+    mn, mx = float(frame['interaction'].min()), float(frame['interaction'].max())
+    mn = 0.0 if mn == 1 else mn
+    for s in range(epochs):
+        batch = smp.sample(B)
+        u = np.array([t[0] for t in batch]); i = np.array([t[1] for t in batch])
+        y = (np.array([float(t[2]) for t in batch]) - mn) / (mx - mn)
+        dm.step(po, st, s, dense[u], dense[:, i].T.copy(), y.astype(np.float32).astype(np.float64), 2e-3, 1e-3, 2, 2, True, broadcast_targets=True)
+    g = model._engine.get_params()
+    for k in po:
+        np.testing.assert_allclose(g[k], po[k], rtol=0, atol=3e-5, err_msg=k)
+    assert abs(g['extra_w'][0] - 1.0) > 1e-4
+    raw_u, raw_i = frame['user'][0], frame['item'][5]
+    u0, i0 = ds.user_to_uid(raw_u), ds.item_to_iid(raw_i)
+    want, _ = dm.forward(po, dense[u0:u0 + 1], dense[:, i0:i0 + 1].T.copy(), 2, 2)         # includes the scale
+    assert abs(model.predict(raw_u, raw_i) - (mn + (mx - mn) * want[0])) < 1e-4
+    ranked = model.rank(raw_u, [ds.iid_to_item(j) for j in range(N)], novelty=True, n=5)
+    assert len(ranked) == 5 and all(ranked[j][0] >= ranked[j + 1][0] for j in range(4))
+    # a plain DMF that registers something its fused step does not know fails loudly
+    from drecpy_amd.Recommender import DMF, Variable
+
+    class Stray(DMF):
+        def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):
+            super()._pre_fit(learning_rate, neg_ratio, reg_rate, **kwds)
+            self._register_trainable(Variable([1.]))
+    with pytest.raises(NotImplementedError, match='does not update them'):
+        Stray(user_factors=[16, 8], item_factors=[16, 8], seed=seed, verbose=False).fit(ds, epochs=1, batch_size=8)
+    with pytest.raises(Exception, match='supported'):
+        DMF(user_factors=[128, 64], item_factors=[64], verbose=False).fit(ds, epochs=1, batch_size=8)
+
+
+def test_update_weights_applies_keras_adam_on_the_device():
+    """RecommenderABC._update_weights (recommender_abc.py:328-334) with the registered optimizers.Adam: one apply per item, the
+    counter advancing per call — against the closed form."""
+    import torch
+    from drecpy_amd import optimizers
+    from drecpy_amd.Recommender import DMF, Variable
+    from oracle import cdae_oracle as co
+    m = DMF(verbose=False)
+    m._register_optimizer(optimizers.Adam(learning_rate=0.01))
+    a, b = Variable(np.arange(8, dtype=np.float32)), Variable([3.0, -1.0, 2.0])          # 3 elements: the padded path
+    ga, gb = torch.full((8,), 0.5, device='cuda'), torch.tensor([1.0, -2.0, 0.25], device='cuda')
+    m._update_weights([ga, [gb]], [a, [b]])
+    for var, g0, t, x0 in ((a, np.full(8, 0.5), 1, np.arange(8.0)), (b, np.array([1.0, -2.0, 0.25]), 2, np.array([3.0, -1.0, 2.0]))):
+        want = x0 - co.adam_alpha(0.01, t) * (co.ADAM_OMB1 * g0) / (np.sqrt(co.ADAM_OMB2 * g0 * g0) + co.ADAM_EPS)
+        np.testing.assert_allclose(var.numpy(), want, rtol=2e-6)
+    assert m.optimizer.iterations == 2

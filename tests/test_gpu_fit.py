@@ -210,3 +210,29 @@ def test_pipelined_sampled_fit_equals_the_inline_sequence():
     torch.cuda.synchronize()
     for a, b in zip(got, eng.tables()):
         assert torch.equal(a, b)
+
+
+def test_second_fit_on_another_dataset_drops_the_first_ones_caches():
+    """per-model caches derived from the dataset (user -> items table of rank(), epoch snapshots) must not survive
+    into a second fit() on different data."""
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    rng = np.random.default_rng(0)
+
+    def frame(U, N, n, seed):
+        r = np.random.default_rng(seed)
+        return InteractionDataset.read_df({'user': r.integers(0, U, n), 'item': r.integers(0, N, n), 'interaction': r.integers(1, 6, n)},
+                                          verbose=False)
+    a, b = frame(30, 50, 600, 1), frame(45, 80, 900, 2)
+    m = CDAE(hidden_factors=8, seed=3, verbose=False)
+    m.fit(a, epochs=3, batch_size=16)
+    u = a.uid_to_user(0)
+    m.rank(u, [a.iid_to_item(i) for i in range(50)], novelty=True, n=5)          # builds the user -> items table of dataset a
+    m.epoch_weights[2] = 'stale'
+    m.fit(b, epochs=3, batch_size=16)
+    assert m.epoch_weights == {} and len(m.trainable_weights) == 5
+    for uid in (0, 44):
+        raw = b.uid_to_user(uid)
+        got = m.rank(raw, [b.iid_to_item(i) for i in range(80)], novelty=True, n=80)
+        seen = set(b.select(f'uid == {uid}').values_list('iid', to_list=True))
+        assert {b.item_to_iid(i) for _, i in got} == set(range(80)) - seen       # the novelty mask is dataset b's

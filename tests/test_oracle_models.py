@@ -90,3 +90,56 @@ def test_dmf_grads_match_autograd():
     assert abs(lo - loss.item()) < 1e-12
     for k in g:
         np.testing.assert_allclose(g[k], tp[k].grad.numpy(), rtol=1e-9, atol=1e-13, err_msg=k)
+
+
+def test_modified_dmf_grads_match_autograd_of_the_literal_broadcast():
+    """ModifiedDMF (examples/extending_recommender_dmf.py:9-18): predictions = [extra_w * pred for pred in predictions] is a list
+    of B (1,)-tensors -> (B,1); Keras BCE against the (B,) targets broadcasts to (B,B), mean(axis=-1) then the batch mean.
+    Built literally in torch; also the identity the HIP kernel uses: that loss equals the BCE against the batch-MEAN target."""
+    from oracle import cdae_oracle as co
+    from oracle import dmf_oracle as dm
+    rng = np.random.default_rng(3)
+    U, N, B = 11, 19, 8
+    uf, itf = (8, 5), (6, 5)
+    p = dm.init_params(rng, U, N, uf, itf, np.float64)
+    p['extra_w'] = np.array([0.83])
+    xu = rng.integers(0, 6, size=(B, N)).astype(np.float64) * (rng.random((B, N)) < 0.5)
+    xi = rng.integers(0, 6, size=(B, U)).astype(np.float64) * (rng.random((B, U)) < 0.5)
+    y = rng.random(B)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+
+    def l2n(x):
+        return x * torch.rsqrt(torch.clamp((x * x).sum(dim=1, keepdim=True), min=1e-12))
+
+    def tower(t, x, n):
+        for l in range(n):
+            x = torch.relu(x @ tp[f'{t}{l}_k'] + tp[f'{t}{l}_b'])
+        return x
+    pred = torch.clamp((l2n(tower('u', l2n(torch.tensor(xu)), 2)) * l2n(tower('i', l2n(torch.tensor(xi)), 2))).sum(dim=1), min=1e-6)
+    preds = torch.stack([tp['extra_w'] * pr for pr in pred])              # list of (1,) tensors -> (B,1)
+    assert tuple(preds.shape) == (B, 1)
+    eps = 1e-7
+    pc = preds.clamp(eps, 1 - eps)
+    yt = torch.tensor(y)                                                   # (B,) broadcasts along the last axis -> (B,B)
+    elem = -(yt * torch.log(pc + eps) + (1 - yt) * torch.log(1 - pc + eps))
+    assert tuple(elem.shape) == (B, B)
+    loss = elem.mean(dim=-1).mean() + sum(1e-3 * (v ** 2).sum() for k, v in tp.items() if k.endswith('_k'))
+    loss.backward()
+    lo, g, po = dm.loss_and_grads(p, xu, xi, y, 1e-3, 2, 2, True, broadcast_targets=True)
+    assert abs(lo - loss.item()) < 1e-12
+    assert set(g) == set(p)
+    for k in g:
+        np.testing.assert_allclose(g[k], tp[k].grad.numpy(), rtol=1e-9, atol=1e-13, err_msg=k)
+    # the kernel's form: BCE against the batch-mean target (the element is affine in t)
+    dt = np.dtype(np.float64)
+    reg = sum(1e-3 * (v * v).sum() for k, v in p.items() if k.endswith('_k'))
+    assert abs(co.bce_elem(dt.type(y.mean()), po, dt).mean() + reg - lo) < 1e-12
+    # Adam order (recommender_abc.py:194-196,328-334): the scalar first, then user_nn, then item_nn -> t = 3s+1, 3s+2, 3s+3
+    st = dm.adam_state(p)
+    before = {k: v.copy() for k, v in p.items()}
+    dm.step(p, st, 4, xu, xi, y, 1e-3, 1e-3, 2, 2, True, broadcast_targets=True)
+    for name, j in (('extra_w', 0), ('u0_k', 1), ('i1_b', 2)):
+        a = co.adam_alpha(1e-3, 3 * 4 + j + 1)
+        m = g[name] * co.ADAM_OMB1
+        v = g[name] * g[name] * co.ADAM_OMB2
+        np.testing.assert_allclose(p[name], before[name] - (m * a) / (np.sqrt(v) + co.ADAM_EPS), rtol=1e-12, atol=0, err_msg=name)
