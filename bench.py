@@ -104,6 +104,57 @@ def kept_count(keep_off, seed, q):
     return int((hash_u32_torch(seed, row, j) >= q_threshold(q)).sum().item())
 
 
+def batch_row_stats(indptr, indices, uid, iid, keep_off, seed, q):
+    """Exact row statistics of ONE batch, counted on the device: per key class (W = input rows of the kept history items,
+    V = user rows, O = W2T output rows) the number of touches (occurrences) and of DISTINCT rows, and the rows a single triple
+    touches (the forward kernel updates those in place).  These are what the dedup-aware byte model of the roofline needs."""
+    B = uid.numel()
+    dev = uid.device
+    deg = (keep_off[1:] - keep_off[:-1]).long()
+    row = torch.repeat_interleave(torch.arange(B, device=dev), deg)
+    j = torch.arange(int(keep_off[-1].item()), device=dev) - keep_off[:-1].long()[row]
+    keep = hash_u32_torch(seed, row, j) >= q_threshold(q)
+    pos = (indptr[uid.long()][row] + j)[keep]
+    items = indices[pos]
+    st = {'B': B, 'history_items': int(deg.sum().item()), 'occ_W': int(keep.sum().item()), 'dist_W': int(torch.unique(items).numel())}
+    for name, col in (('V', uid), ('O', iid)):
+        _, cnt = torch.unique(col.long(), return_counts=True)
+        st['dist_' + name], st['solo_' + name] = int(cnt.numel()), int((cnt == 1).sum().item())
+    return st
+
+
+def byte_model(st, k, S, fused_solo):
+    """Dedup-aware algorithmic HBM bytes of one sparse step, rows of 4k bytes, S optimizer slots per parameter:
+      forward kernel : gathers one row per OCCURRENCE (kept W rows + V row + W2T row), writes dz1[b] for every triple and g2[b] for the
+                       triples whose W2T row is shared; the V / W2T rows only this triple touches are updated in place from registers
+                       (read S slot rows, write parameter + S slot rows) when the touch list was prepared ahead (fused_solo);
+                       + the CSR indices of the batch users (4 B per history item) and 40 B of ids / offsets per triple
+      reduction      : one read-modify-write of parameter + S slot rows per DISTINCT remaining row: (2 + 2S) rows, + 8 B per touch
+                       (sorted key, sample).  The gradient rows it sums (dz1 / g2, one read per occurrence) were written by the forward
+                       kernel just before — 2B rows = 67 MB at B = 65 536 — and are ASSUMED served by L2 / the 256 MiB Infinity Cache:
+                       they are reported as cache_bytes, not as HBM bytes.
+    Returns bytes per launch of each kernel."""
+    row = 4.0 * k
+    B = st['B']
+    solo_V, solo_O = (st['solo_V'], st['solo_O']) if fused_solo else (0, 0)
+    fwd = row * (st['occ_W'] + 2 * B) + row * (B + (B - solo_O)) + row * (solo_V + solo_O) * (1 + 2 * S) + 4.0 * st['history_items'] + 40.0 * B
+    n_touch = st['occ_W'] + (B - solo_V) + (B - solo_O)
+    red = row * (st['dist_W'] + st['dist_V'] - solo_V + st['dist_O'] - solo_O) * (2 + 2 * S) + 8.0 * n_touch
+    return {'k_sampled_fwd_bwd': fwd, 'k_seg_reduce': red, 'cache_bytes_k_seg_reduce': row * n_touch}
+
+
+def kernel_source_hash():
+    """sha256 over the sources libdrx.so is built from: a PMC profile is only quoted for the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'drecpy_amd', 'csrc')
+    for name in sorted(os.listdir(src)) + ['../../include/drx.h']:
+        if name.endswith(('.hip', '.hpp', '.cpp', '.h')):
+            with open(os.path.join(src, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_cpu=1024, optimizer='adagrad'):
     """Times the CPU oracle (oracle/cdae_oracle.py sparse_step: the NumPy restatement, 'port') on the first n_cpu triples
     of one bench batch.  The tables are compacted to the rows that sample touches (same arithmetic per sample; the
@@ -142,7 +193,51 @@ def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_c
                       f'rows), NumPy restatement oracle/cdae_oracle.py:sparse_step, {dt:.1f} s, host has {os.cpu_count()} cpus'}
 
 
-def hr_at_10(dev):
+def cpu_reference_fit(tr, budget_s=10.0, B=64, k=50, q=0.2, seed=10):
+    """BASELINE config 1 on the host: the reference's CDAE fit() loop (examples/cdae.py: K = 50, batch 64, lr 1e-3, reg 1e-3, neg_ratio 5)
+    as restated by the oracle — PointSampler draw (oracle/data_oracle.py), N uniform corruption draws per row from random.Random(seed)
+    (cdae.py:63), dense_step in fp32 (what TF computes in) with the (B,B,N) mean-target loss, L2/B on the full tables and 5 Keras-Adam
+    applies — on the SAME training set the GPU fit() above trains on, for `budget_s` seconds, numpy limited to one thread."""
+    import random
+    from oracle import cdae_oracle as co
+    from oracle import data_oracle as do
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    c = tr._cols
+    uid, iid, val = c['uid'].astype(np.int64), c['iid'].astype(np.int64), c['interaction']
+    U, N = int(uid.max()) + 1, int(iid.max()) + 1
+    smp = do.PointSamplerOracle(uid, iid, val, 5, 1e-3, seed)
+    rng = random.Random(seed)
+    pos = np.zeros((U, N), dtype=bool)
+    pos[uid[val >= 1e-3], iid[val >= 1e-3]] = True
+    p = co.init_params(np.random.default_rng(seed), U, N, k, np.float32)
+    st = co.adam_state(p)
+    scale = np.float32(1.0 / (1.0 - float(np.float32(q))))
+
+    def loop():
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget_s:
+            users = np.array([t[0] for t in smp.sample(B)])
+            t = pos[users]
+            mask = np.array([[rng.uniform(0, 1) >= q for _ in range(N)] for _ in range(B)])      # cdae.py:63: a draw for EVERY item
+            x = np.where(t & mask, scale, np.float32(0)).astype(np.float32)
+            co.dense_step(p, st, n, users, x, t, 1e-3, 1e-3, 'bce', 'reference')
+            n += 1
+        return n, time.perf_counter() - t0
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            n, dt = loop()
+    else:
+        n, dt = loop()
+    return {'value': n * B / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} one-batch epochs of {B} in {dt:.1f} s: oracle PointSampler + per-item corruption draws + oracle/cdae_oracle.py:dense_step '
+                      f'(fp32) on the {U} x {N} ml-100k-shaped training set of the GPU fit; numpy on 1 thread; host has {os.cpu_count()} cpus'}
+
+
+def hr_at_10(dev, with_cpu=True):
     """The HR@10 half of BASELINE.json's metric: CDAE in REFERENCE mode with the README configuration (K=50, q=0.2, BCE,
     100 one-batch epochs of 64, lr 1e-3, reg 1e-3, neg_ratio 5, seed 10) on the ml-100k-shaped synthetic set, leave-10-out,
     evaluated with the protocol of examples/cdae.py:15-17.  No MovieLens files exist offline: not comparable with
@@ -175,7 +270,9 @@ def hr_at_10(dev):
     m2.fit(tr, epochs=5000, batch_size=64, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
     torch.cuda.synchronize()
     long_s = time.perf_counter() - t0
-    return {'value': res['HitRatio@10'], 'ndcg_at_10': res['NDCG@10'], 'fit_seconds_100_steps_of_64': round(fit_s, 3),
+    cpu_ref = cpu_reference_fit(tr) if with_cpu else None
+    return {'value': res['HitRatio@10'], 'ndcg_at_10': res['NDCG@10'], 'cpu_baseline_reference_mode': cpu_ref,
+            'fit_seconds_100_steps_of_64': round(fit_s, 3),
             'fit_samples_per_s_incl_host': round(6400 / fit_s, 1),
             'fit_seconds_5000_steps_of_64': round(long_s, 3), 'fit_samples_per_s_5000_steps_incl_host_and_setup': round(320000 / long_s, 1),
             'setup': 'CDAE reference mode (dense Keras Adam), README.md:106-114 configuration, ml-100k-shaped synthetic '
@@ -506,18 +603,39 @@ def main():
         dom, dom_ms, dom_alg = 'k_shard_fwd_bwd+k_seg_reduce<LocalPolicy>', ph[1], 2.0 * B * 4.0 * K * rows_per_sample
     achieved = dom_alg / (dom_ms * 1e-3) / 1e9
     step_alg = B * 4.0 * K * rows_per_sample * (3.0 + 2.0 * S_opt)
-    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json), only when that
-    # profile was taken on this very configuration; rocprofv3 cannot run inside the bench itself.
-    traffic = None
+    # ---- dedup-aware byte model: exact occurrence / distinct-row counts of batches of the TIMED region ----------------------------
+    dedup = None
+    if stepper is None:
+        picks = sorted(set(int(x) for x in np.linspace(0, args.steps - 1, 6)))
+        stats = []
+        for s_ in picks:
+            if fresh:                                   # the pipeline drew step (warmup + s_) from these seeds: draw it again
+                seed_ = 5000 + 7919 * (args.warmup + s_) + 104729 * rank
+                u_, i_, _, ko_ = eng.sample_device(B, NEG_RATIO, seed_, n_items=N)
+            else:
+                u_, i_, _, ko_, seed_ = batches[(args.warmup + s_) % len(batches)]
+            stats.append(batch_row_stats(indptr, indices, u_, i_, ko_, seed_, Q))
+        mean_st = {k_: float(np.mean([st[k_] for st in stats])) for k_ in stats[0]}
+        bm = byte_model(mean_st, K, S_opt, fused_solo=overlap)
+        dedup = {'batches_counted': len(stats), 'per_batch_mean': {k_: round(v, 1) for k_, v in mean_st.items()}, 'bytes_per_launch': bm}
+    kernel_hash = kernel_source_hash()
+    # HBM traffic from the PMC passes (profiles/pmc_traffic.json), only when that profile was taken on this very workload AND on
+    # these very kernel sources (scripts/profile_round.sh stores their hash); rocprofv3 cannot run inside the bench itself.
+    traffic_of, traffic_note = {}, 'no PMC profile for this workload'
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             pmc = json.load(f)
         m = pmc['_meta']
-        if m['workload'] == args.workload and m['batch_per_gpu'] == B and m['n_gpus'] == world and not args.users:
-            traffic = pmc['kernels'].get('drx::' + dom, {}).get('hbm_bytes_per_launch')
+        if m['workload'] == args.workload and m['batch_per_gpu'] == B and m['n_gpus'] == world and not args.users and K == 128 \
+                and m.get('optimizer', 'adagrad') == args.optimizer:
+            if m.get('kernel_source_hash') == kernel_hash:
+                traffic_of = {k_.replace('drx::', ''): v['hbm_bytes_per_launch'] for k_, v in pmc['kernels'].items()}
+                traffic_note = f"profiles/pmc_traffic.json ({m.get('round')}), same kernel sources ({kernel_hash})"
+            else:
+                traffic_note = f"profiles/pmc_traffic.json is STALE: taken on kernel sources {m.get('kernel_source_hash')}, this tree is {kernel_hash}"
     except (OSError, KeyError, ValueError):
         pass
-
+    traffic = traffic_of.get(dom)
     copy_gbs = hbm_copy_gbs(dev) if rank == 0 else None
     if rank == 0:
         out = {
@@ -534,28 +652,56 @@ def main():
                        else f'{args.n_batches} pre-sampled batches cycled',
                        'micro_batches': (micro if stepper is not None else None),
                        'sharding': ('single GPU' if stepper is None else 'row-sharded code path at world 1') if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms),
-                         'timed_launches': int(len(phases)),   # steps of the timed region that carried phase events
-                         # DRAM rate actually sustained = PMC bytes / measured duration (duplicate rows of a batch are
-                         # reduced before the read-modify-write and gradient rows re-read from L2, so traffic < algorithmic)
-                         'traffic_rate': (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
-                         'traffic_frac': (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
-                         'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                         'hbm_copy_achievable': copy_gbs,
-                         'note': 'algorithmic bytes (SURVEY 8d) charge a parameter read-modify-write per touched-row OCCURRENCE; the kernel merges the occurrences of a row first, so frac can exceed 1 - traffic / traffic_rate are the bytes it really moves (DESIGN.md section 3)'},     # read+write rate of a 2 GiB device copy on this box, GB/s
+            'roofline': None,
             'phases_ms': {n: float(v) for n, v in zip(names, ph)},
             'setup_s': round(setup_s, 1),
             'host_issue_ms_per_step': ([round(1e3 * t / (args.warmup + args.steps), 4) for t in pipe.host_s + [stepper.wait_s]] if pipe is not None else None),
         }
+        ms_of = {'k_sampled_fwd_bwd': float(ph[0]), 'k_seg_reduce': float(ph[2])} if stepper is None else {}
+        if dedup is not None:
+            # `frac` = dedup-aware algorithmic HBM bytes / measured launch time / peak: a fraction by construction (what has to
+            # cross the HBM interface at least once; everything re-read is assumed cached).  `model_*` = SURVEY 8d's
+            # per-OCCURRENCE model (charges a read-modify-write per touch: the kernel merges touches first, so it can exceed 1).
+            per_kernel = {}
+            for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
+                byt, ms_ = dedup['bytes_per_launch'][kn], ms_of[kn]
+                per_kernel[kn] = {'bytes_per_launch': byt, 'avg_launch_ms': ms_, 'achieved': byt / (ms_ * 1e-3) / 1e9,
+                                  'frac': byt / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  'traffic': traffic_of.get(kn),
+                                  'traffic_frac': (traffic_of[kn] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS) if kn in traffic_of else None}
+            step_bytes = dedup['bytes_per_launch']['k_sampled_fwd_bwd'] + dedup['bytes_per_launch']['k_seg_reduce']
+            step_traffic = sum(traffic_of.get(kn, 0.0) for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce', 'k_sparse_tail_a', 'k_sparse_tail_b')) or None
+            dk = per_kernel[dom]
+            out['roofline'] = {
+                'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['frac'],
+                'traffic': traffic, 'traffic_source': traffic_note, 'kernel_source_hash': kernel_hash,
+                'traffic_rate': (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+                'traffic_frac': (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                'bytes_per_launch': dk['bytes_per_launch'], 'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(phases)),
+                'kernels': per_kernel, 'row_counts': dedup['per_batch_mean'], 'batches_counted': dedup['batches_counted'],
+                'cache_bytes_k_seg_reduce': dedup['bytes_per_launch']['cache_bytes_k_seg_reduce'],
+                'whole_step_bytes': step_bytes, 'whole_step_achieved': step_bytes / (dt / args.steps) / 1e9,
+                'whole_step_frac': step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                'whole_step_traffic': step_traffic,
+                'whole_step_traffic_frac': (step_traffic / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
+                'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
+                'model_whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                'hbm_copy_achievable': copy_gbs,
+                'definition': 'frac = dedup-aware algorithmic HBM bytes (bench.py:byte_model: one gather read per occurrence, dz1/g2 written once, '
+                              'one read-modify-write of parameter + slots per DISTINCT row, gradient re-reads assumed cached) / HIP-event launch time / 8 TB/s; '
+                              'traffic = PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; counts Infinity-Cache hits); model_* = SURVEY 8d per-occurrence bytes'}
+        else:
+            out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
+                               'traffic': None, 'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
+                               'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(phases)), 'hbm_copy_achievable': copy_gbs,
+                               'definition': 'row-sharded path: only the per-occurrence model (SURVEY 8d) is evaluated here'}
         if world == 1 and not args.no_cpu_baseline:
             uid, iid, y, keep_off, seed = batches[0]
             out['cpu_baseline'] = cpu_baseline(eng, indptr, indices, (uid, iid, y, keep_off), seed, optimizer=args.optimizer)
         else:
             out['cpu_baseline'] = None
-        out['hr_at_10'] = hr_at_10(dev) if (world == 1 and not args.no_hr and not args.users) else None
+        out['hr_at_10'] = hr_at_10(dev, with_cpu=not args.no_cpu_baseline) if (world == 1 and not args.no_hr and not args.users) else None
+        out['cpu_baseline_reference_mode'] = (out['hr_at_10'] or {}).get('cpu_baseline_reference_mode')
         print(json.dumps(out), flush=True)
     if world > 1 or rccl1:
         dist.barrier()

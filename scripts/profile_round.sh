@@ -17,6 +17,11 @@ cd $ROOT
 find $OUT -name '*.csv' | head -20
 python profiles/pmc_l2.py $(find $OUT/pmc_l2 -name '*counter_collection.csv' | head -1) $OUT/pmc_l2_hit_rate.json
 python profiles/pmc_summary.py $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) $OUT/pmc_traffic_raw.json
+python profiles/pmc_make_traffic.py $OUT/pmc_traffic_raw.json $OUT/pmc_traffic.json $TAG
+cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+python bench.py > $OUT/bench_with_traffic.json 2>> $OUT/bench.err     # the line as the driver will see it, quoting the PMC passes just taken
+grep -h "drx::" $(find $OUT/kt -name '*kernel_stats.csv' | head -1) | head -40 > $OUT/kernel_stats_drx.csv
+cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 # keep only the small summaries
 find $OUT -name '*kernel_trace.csv' -delete
 find $OUT -size +4M -delete
