@@ -198,9 +198,17 @@ def lib():
         # torch ships its own libamdhip64 (SONAME libamdhip64.so.7); it must be in the process BEFORE
         # libdrx.so so that both share ONE HIP runtime (otherwise torch's stream handles and device
         # pointers would belong to a different runtime instance than the one launching our kernels).
-        import torch  # noqa: F401
-        L = C.CDLL(LIB_PATH)
+        host_only = os.environ.get('DRX_HOST_SANITIZER_LIB')
+        if host_only:
+            # CPU sanitizer runs (scripts/sanitize_host.sh): the host half alone, built by `python -m drecpy_amd.build
+            # --sanitize=...`; device entry points are absent from it and stay unbound (calling one raises AttributeError)
+            L = C.CDLL(host_only)
+        else:
+            import torch  # noqa: F401
+            L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if host_only and not hasattr(L, name):
+                continue
             fn = getattr(L, name)            # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

@@ -2,6 +2,9 @@
 
     python -m drecpy_amd.build            # incremental
     python -m drecpy_amd.build --force
+    python -m drecpy_amd.build --sanitize=thread|address   # CPU only: the HOST half (csrc/drx_host.cpp: samplers, MT19937
+                                          # streams, draw-ahead worker threads) alone, g++ -fsanitize, into
+                                          # csrc/build/libdrx_host_<kind>.so; scripts/sanitize_host.sh runs tests/test_sampler.py on it
 """
 import os
 import subprocess
@@ -56,5 +59,25 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_sanitized(kind):
+    """The host-only translation unit under ThreadSanitizer / AddressSanitizer (never on a GPU box: no device code in it)."""
+    assert kind in ('thread', 'address'), kind
+    os.makedirs(OBJ, exist_ok=True)
+    out = os.path.join(OBJ, f'libdrx_host_{kind}.so')
+    stub = os.path.join(OBJ, 'drx_host_stub.cpp')
+    with open(stub, 'w') as f:          # the two bookkeeping symbols the loader asks for live in a .hip file of the full library
+        f.write('#include "drx.h"\nextern "C" { int drx_version(void) { return DRX_VERSION; }\n'
+                'const char *drx_strerror(int code) { (void)code; return "(host-only sanitizer build)"; } }\n')
+    cmd = [HOSTCXX, '-pthread', f'-fsanitize={kind}', '-g', '-O1', '-fno-omit-frame-pointer', '-fPIC', '-shared', '-std=c++17',
+           '-I', os.path.join(ROOT, 'include'), '-I', CSRC, os.path.join(CSRC, 'drx_host.cpp'), stub, '-o', out]
+    print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    san = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--sanitize=')]
+    if san:
+        print(build_sanitized(san[0]))
+    else:
+        build(force='--force' in sys.argv)

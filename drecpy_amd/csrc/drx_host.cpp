@@ -497,7 +497,10 @@ struct DrxDrawAhead {
             std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kPollUs) {
           std::unique_lock<std::mutex> lk(me.mu);
           me.sleeping.store(true);
-          me.cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return me.submitted.load() > next || stop.load(); });
+          // wait_until on the system clock = pthread_cond_timedwait; wait_for would use pthread_cond_clockwait, which GCC 11's
+          // ThreadSanitizer does not intercept (it then reports the re-acquired mutex as a "double lock")
+          me.cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(50),
+                           [&] { return me.submitted.load() > next || stop.load(); });
           me.sleeping.store(false);
           t0 = std::chrono::steady_clock::now();
         }

@@ -11,11 +11,19 @@ import sys
 from collections import defaultdict
 
 
+def base_name(kernel):
+    """'void drx::k_seg_reduce<32, 1, drx::DirectPolicy>(drx::SegBufs, ...)' -> 'drx::k_seg_reduce' (template arguments and
+    the return type differ between rocprofv3 versions; the bench looks kernels up by this name)."""
+    import re
+    m = re.search(r'drx::(\w+)', kernel)
+    return 'drx::' + m.group(1) if m else kernel.split('(')[0]
+
+
 def per_kernel(path, counter):
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] == counter:
-            acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+            acc[base_name(r['Kernel_Name'])].append(float(r['Counter_Value']))
     return acc
 
 
