@@ -502,7 +502,7 @@ def main():
     if fresh:
         from drecpy_amd.engine import SampledPipeline
         spipe = SampledPipeline(eng, B, NEG_RATIO, Q, lambda s: 5000 + 7919 * s + 104729 * rank,
-                                lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N)
+                                lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N, prep_ahead=int(os.environ.get('DRX_PREP_AHEAD', 2)))
 
     def batch_of(s):
         return structs[s % len(structs)][0]

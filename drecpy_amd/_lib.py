@@ -82,6 +82,11 @@ SIGNATURES = {
     'drx_version': (C.c_int, []),
     'drx_strerror': (C.c_char_p, [C.c_int]),
     'drx_hash_u32': (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32]),
+    'drx_event_create': (C.c_void_p, []),
+    'drx_event_destroy': (None, [C.c_void_p]),
+    'drx_event_record': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'drx_stream_wait_event': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'drx_event_synchronize': (C.c_int, [C.c_void_p]),
     'drx_cdae_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     'drx_cdae_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32, C.c_int32]),
@@ -100,7 +105,8 @@ SIGNATURES = {
                                                 C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     'drx_point_sample_scratch_bytes': (C.c_size_t, [C.c_int32]),
     'drx_point_sample': (C.c_int, [C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
+                                   C.c_void_p]),
     'drx_shard_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32]),
     'drx_shard_touches': (C.c_int, [C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

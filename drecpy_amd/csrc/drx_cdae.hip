@@ -1225,6 +1225,18 @@ const char *drx_strerror(int code) {
 
 uint32_t drx_hash_u32(uint64_t seed, uint32_t a, uint32_t b) { return hash_u32(seed, a, b); }
 
+// ---- light events for the run-ahead pipelines: ordering between two streams of ONE device.  hipEventDisableSystemFence: the record
+// releases at agent scope instead of writing the L2 back for the host and peers — all a same-device hipStreamWaitEvent needs.
+void *drx_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
+  return (void *)e;
+}
+void drx_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int drx_event_record(void *ev, void *stream) { return ev ? (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) : DRX_EINVAL; }
+int drx_stream_wait_event(void *stream, void *ev) { return ev ? (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0) : DRX_EINVAL; }
+int drx_event_synchronize(void *ev) { return ev ? (int)hipEventSynchronize((hipEvent_t)ev) : DRX_EINVAL; }
+
 int drx_cdae_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, float *h, float *pred,
                      void *stream) {
   int rc = check_params(p);
@@ -1340,7 +1352,8 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
   const int gpb = kBlock / 16;
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
                      q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v);
-  return sort_pairs(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, st);
+  // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
+  return sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, true, st);
 }
 
 // Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.

@@ -113,10 +113,13 @@ struct Carver {
   bool ok() const { return off <= cap; }
 };
 
-// Internal: radix sort of (key, val) pairs, implemented in drx_sort.hip.
+// Internal: stable radix sort of (key, val) pairs on the low end_bit bits of the key, implemented in drx_sort.hip.
 size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                uint32_t *vout, size_t n, int end_bit, hipStream_t stream);
+// drop_none: pairs with key DRX_KEY_NONE take no part (kout = the sorted pairs, then DRX_KEY_NONE up to n; their vals are not written).
+int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int end_bit,
+                  bool drop_none, hipStream_t stream);
 
 inline int bits_for(uint64_t max_key_exclusive) {
   int b = 1;

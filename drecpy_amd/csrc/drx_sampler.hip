@@ -3,10 +3,11 @@
 // sampler in drx_host.cpp):
 //   with probability neg_ratio/(neg_ratio+1) a negative: uniform (u, i) with i NOT among u's rows (mem_dataset.py:154-163;
 //   membership here = the positives CSR), else a positive: uniform user with >= 1 positive, then a uniform positive of
-//   that user (mem_dataset.py:119-129).  Also emits keep_off = exclusive scan of deg(uid[b]) for the step kernels.
+//   that user (mem_dataset.py:119-129).  Also emits keep_off = exclusive scan of deg(uid[b]) for the step kernels: one workgroup
+//   scans the B degrees (k_scan_degrees) and — when the host passes a pinned mailbox — posts the total, tagged, straight into host
+//   memory with one system-scope store: no copy kernel, no event, and no L2 write-back for the host's sake between training kernels.
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_scan.hpp>
 #include "drx_common.hpp"
 
 namespace drx {
@@ -46,19 +47,52 @@ __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_use
   deg[b] = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
 }
 
+// keep_off[1..B] = inclusive scan of deg[0..B): one workgroup of 1024 threads takes the batch in slabs of 8 192 degrees — a coalesced
+// load into LDS, every thread scans 8 neighbours there, wave scans + a scan of the 16 wave totals, a coalesced store — carrying the
+// running total from slab to slab (B = 65 536: eight slabs).  mailbox (pinned host memory or nullptr) receives (tag << 32) | total.
+__global__ __launch_bounds__(1024) void k_scan_degrees(const int32_t *__restrict__ deg, int B, int32_t *__restrict__ keep_off,
+                                                       unsigned long long *mailbox, uint32_t tag) {
+  constexpr int PER = 8, SLAB = 1024 * PER;
+  __shared__ int sl[SLAB + SLAB / PER];          // padded: thread t starts at t * (PER + 1)
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int carry = 0;
+  for (int base = 0; base < B; base += SLAB) {
+    const int n = B - base < SLAB ? B - base : SLAB;
+    for (int i = tid; i < SLAB; i += 1024) sl[i + (i >> 3)] = i < n ? deg[base + i] : 0;
+    __syncthreads();
+    int v[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { sum += sl[tid * (PER + 1) + q]; v[q] = sum; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int off = carry + inc - sum, total = 0;
+    for (int ww = 0; ww < 16; ++ww) { if (ww < w) off += wsum[ww]; total += wsum[ww]; }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) sl[tid * (PER + 1) + q] = v[q] + off;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) keep_off[base + i + 1] = sl[i + (i >> 3)];
+    carry += total;
+    __syncthreads();
+  }
+  if (tid == 0 && mailbox)
+    __hip_atomic_store(mailbox, ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)carry, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace drx
 
 extern "C" size_t drx_point_sample_scratch_bytes(int32_t B) {
   if (B < 1) return 0;
-  size_t tb = 0;
-  int *d = nullptr;
-  (void)rocprim::inclusive_scan(nullptr, tb, d, d, (size_t)B, rocprim::plus<int>(), (hipStream_t)0);
-  return drx::align_up((size_t)B * 4, 256) + drx::align_up(tb, 256) + 256;
+  return drx::align_up((size_t)B * 4, 256) + 256;
 }
 
 extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
                                 uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off, void *scratch,
-                                size_t scratch_bytes, void *stream) {
+                                size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream) {
   using namespace drx;
   if (!hist || !hist->indptr || !hist->indices || !uid || !iid || !y || !keep_off || !scratch || B < 1 || n_users < 1 ||
       n_items < 1 || neg_ratio < 0)
@@ -66,12 +100,9 @@ extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t
   if (scratch_bytes < drx_point_sample_scratch_bytes(B)) return DRX_ESCRATCH;
   hipStream_t st = (hipStream_t)stream;
   int32_t *deg = (int32_t *)scratch;
-  void *tmp = (char *)scratch + align_up((size_t)B * 4, 256);
-  size_t tb = scratch_bytes - align_up((size_t)B * 4, 256);
   hipLaunchKernelGGL(k_point_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, *hist, n_users, n_items, B,
                      neg_ratio, seed, uid, iid, y, deg, keep_off);
-  hipError_t e = rocprim::inclusive_scan(tmp, tb, deg, keep_off + 1, (size_t)B, rocprim::plus<int>(), st);
-  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, keep_off, (unsigned long long *)host_mailbox, tag);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

@@ -432,8 +432,9 @@ class CdaeEngine:
                   'drx_cdae_step_sparse_timed')
         return self._loss if want_loss else None
 
-    def sample_device(self, B, neg_ratio, seed, n_items=None, out=None):
-        """Throughput-mode PointSampler on the GPU: returns device tensors (uid, iid, y, keep_off); `out` reuses them."""
+    def sample_device(self, B, neg_ratio, seed, n_items=None, out=None, mailbox=None, tag=0):
+        """Throughput-mode PointSampler on the GPU: returns device tensors (uid, iid, y, keep_off); `out` reuses them.
+        mailbox: a pinned int64 tensor of one element that receives (tag << 32) | keep_off[B] straight from the last kernel."""
         if out is None:
             out = (torch.empty(B, dtype=torch.int32, device=self.device), torch.empty(B, dtype=torch.int32, device=self.device),
                    torch.empty(B, dtype=torch.float32, device=self.device), torch.empty(B + 1, dtype=torch.int32, device=self.device))
@@ -443,7 +444,8 @@ class CdaeEngine:
             self._sscratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         check(lib().drx_point_sample(C.byref(self._hist), self.n_users, n_items or self.n_items, B, neg_ratio,
                                      int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y), ptr(keep_off),
-                                     ptr(self._sscratch), self._sscratch.numel(), stream_ptr(self.device)),
+                                     ptr(self._sscratch), self._sscratch.numel(), ptr(mailbox), int(tag) & 0xFFFFFFFF,
+                                     stream_ptr(self.device)),
               'drx_point_sample')
         return out
 
@@ -520,6 +522,30 @@ class DeviceBatchSource:
         return self.made[s][0]
 
 
+class StreamEvent:
+    """Ordering between two streams of one device without the host-visibility part of a torch.cuda.Event: created by
+    drx_event_create (hipEventDisableTiming | hipEventDisableSystemFence), so a record is an agent-scope release instead of an L2
+    write-back between two training kernels (measured: two torch event records per step cost 7.6 us, two of these 5)."""
+
+    def __init__(self):
+        self._h = lib().drx_event_create()
+        if not self._h:
+            raise _lib.DrxError('drx_event_create failed')
+
+    def record(self, stream):
+        check(lib().drx_event_record(self._h, C.c_void_p(stream.cuda_stream)), 'drx_event_record')
+
+    def wait(self, stream):
+        """`stream` waits for the work recorded by the last record()."""
+        check(lib().drx_stream_wait_event(C.c_void_p(stream.cuda_stream), self._h), 'drx_stream_wait_event')
+
+    def __del__(self):
+        try:
+            lib().drx_event_destroy(self._h)
+        except Exception:
+            pass
+
+
 class SampledPipeline:
     """Keeps the training stream of the sampled-output mode free of everything that does not depend on the parameters.
 
@@ -529,11 +555,13 @@ class SampledPipeline:
     `CDAE.fit(mode='sampled', device_sampler=True)` and by bench.py — the same code path.
 
     sample_seed_of(s) / mask_seed_of(s): seeds of step s's triple draw and of its corruption mask.
-    prep_ahead: how many steps ahead the touch list is prepared (1; more when preparing takes longer than a step, as when
-    the ranks of a column-sharded job take turns preparing the list for all — dist.ColumnShardedCdae)."""
+    prep_ahead: how many steps ahead the touch list is prepared.  2 by default: the preparation shares the chip with the training
+    kernels and then takes about as long as a step, so with one step of lead the training stream sometimes waited for it (measured at
+    B = 65 536: 141 / 148 / 151 M triples/s at 1 / 2 / 3); more when preparing takes longer than a step, as when the ranks of a
+    column-sharded job take turns preparing the list for all — dist.ColumnShardedCdae."""
 
     def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None,
-                 prepare_fn=None, prep_ahead=1, deliver_fn=None):
+                 prepare_fn=None, prep_ahead=2, deliver_fn=None):
         self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
         # step_fn(s, bt, prepared, events, want_loss): what trains on a prepared batch (default: this engine's sparse step;
         # dist.ColumnShardedCdae.step for the column-sharded multi-GPU layout)
@@ -556,15 +584,19 @@ class SampledPipeline:
         self.SA = D + 1 if D == 1 else D + 2
         self.RS, self.RP = self.SA + 1, D + 1                 # ring sizes: drawn batches, prepared lists
         self.ring = [eng.sample_device(self.B, self.neg_ratio, 1, n_items=n_items) for _ in range(self.RS)]
-        self.ring_T = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(self.RS)]
-        self.ring_ev = [torch.cuda.Event() for _ in range(self.RS)]
-        self.ring_free = [torch.cuda.Event() for _ in range(self.RS)]
+        # a batch's touch count reaches the host through a pinned mailbox the sampler's last kernel writes itself, tagged with the
+        # step it belongs to (drx_point_sample): no copy kernel, no event, nothing for the host to synchronise with
+        self.ring_T = [torch.full((1,), -1, dtype=torch.int64).pin_memory() for _ in range(self.RS)]
+        self.ring_Tv = [t.numpy() for t in self.ring_T]
         self.ring_bt = [None] * self.RS
         self.prep = [None] * self.RP
-        self.prep_done = [torch.cuda.Event() for _ in range(self.RP)]
-        self.built = [torch.cuda.Event() for _ in range(self.RP)]
-        self.step_done = [torch.cuda.Event() for _ in range(self.RP)]
-        for e in self.step_done + self.ring_free:
+        self.prep_done = [StreamEvent() for _ in range(self.RP)]
+        self.built = [StreamEvent() for _ in range(self.RP)]
+        # ONE record per step on the training stream: step j's event frees both its drawn-batch slot (for the draw of step j + RS)
+        # and its prepared-list buffer (for the preparation of step j + RP)
+        self.NE = max(self.RS, self.RP) + 1
+        self.step_ev = [StreamEvent() for _ in range(self.NE)]
+        for e in self.step_ev:
             e.record(self.main)
         self.next = 0
         for i in range(self.SA):
@@ -576,40 +608,56 @@ class SampledPipeline:
 
     def _sample(self, s):
         k = s % self.RS
-        self.side.wait_event(self.ring_free[k])              # the slot's previous batch (step s - RS) has been consumed
+        if s >= self.RS:
+            self.step_ev[(s - self.RS) % self.NE].wait(self.side)   # the slot's previous batch (step s - RS) has been consumed
         with torch.cuda.stream(self.side):
-            self.eng.sample_device(self.B, self.neg_ratio, self.sample_seed_of(s), n_items=self.n_items, out=self.ring[k])
-            self.ring_T[k].copy_(self.ring[k][3][-1:], non_blocking=True)
-            self.ring_ev[k].record(self.side)
+            self.eng.sample_device(self.B, self.neg_ratio, self.sample_seed_of(s), n_items=self.n_items, out=self.ring[k],
+                                   mailbox=self.ring_T[k], tag=s + 1)
 
     def batch_of(self, s):
         k = s % self.RS
         if self.ring_bt[k] is None or self.ring_bt[k][0] != s:
-            self.ring_ev[k].synchronize()                    # the 4-byte count copied at least one step ago
             uid, iid, y, keep_off = self.ring[k]
             bt, alive = self.eng.make_batch(uid, iid, y, keep_off=keep_off, q=self.q, mask_seed=self.mask_seed_of(s),
-                                            n_touch_slots=int(self.ring_T[k][0]))
+                                            n_touch_slots=self._touch_count(k, s))
             self.ring_bt[k] = (s, bt, alive)
         return self.ring_bt[k][1]
+
+    def _touch_count(self, k, s):
+        """keep_off[B] of the batch drawn for step s, posted by the device at least one step ago: normally a plain read."""
+        want, box = (s + 1) & 0xFFFFFFFF, self.ring_Tv[k]
+        M = (1 << 64) - 1
+        v = int(box[0]) & M
+        if v >> 32 != want:
+            import time
+            t0 = time.perf_counter()
+            while True:
+                v = int(box[0]) & M
+                if v >> 32 == want:
+                    break
+                if time.perf_counter() - t0 > 60.0:
+                    raise _lib.DrxError(f'the device sampler did not deliver the batch of step {s} within 60 s')
+        return v & 0xFFFFFFFF
 
     def _prepare(self, s):
         bt = self.batch_of(s)
         k = s % self.RP
-        self.side.wait_event(self.step_done[k])              # the buffer's previous user (step s - RP) has finished
+        if s >= self.RP:
+            self.step_ev[(s - self.RP) % self.NE].wait(self.side)   # the buffer's previous user (step s - RP) has finished
         with torch.cuda.stream(self.side):
             if self.prepare_fn is not None:
                 self.prep[k] = self.prepare_fn(s, bt, self.prep[k])
             else:
                 self.prep[k] = self.eng.prepare_sparse(bt, self.prep[k])
-            (self.prep_done if self.deliver_fn is None else self.built)[k].record(self.side)
+        (self.prep_done if self.deliver_fn is None else self.built)[k].record(self.side)
 
     def _deliver(self, s):
         bt = self.batch_of(s)
         k = s % self.RP
-        self.comm.wait_event(self.built[k])
+        self.built[k].wait(self.comm)
         with torch.cuda.stream(self.comm):
             self.deliver_fn(s, bt, self.prep[k])
-            self.prep_done[k].record(self.comm)
+        self.prep_done[k].record(self.comm)
 
     def run_step(self, events=None, want_loss=False):
         """Queues step `self.next` (and the run-ahead work of the following steps); returns the loss tensor or None."""
@@ -620,12 +668,11 @@ class SampledPipeline:
             self._deliver(s + 1)
         bt = self.batch_of(s)
         k = s % self.RP
-        self.main.wait_event(self.prep_done[k])
+        self.prep_done[k].wait(self.main)
         if self.step_fn is not None:
             out = self.step_fn(s, bt, self.prep[k], events, want_loss)
         else:
             out = self.eng.step_sparse(s, bt, self.loss, want_loss=want_loss, events=events, prepared=self.prep[k])
-        self.step_done[k].record(self.main)
-        self.ring_free[s % self.RS].record(self.main)
+        self.step_ev[s % self.NE].record(self.main)
         self.next = s + 1
         return out

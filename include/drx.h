@@ -96,6 +96,15 @@ typedef struct DrxOptim {
 int drx_version(void);
 const char *drx_strerror(int code);
 
+/* Stream-ordering events for the host's run-ahead pipelines (sampler / touch-list preparation on a side stream of the same device):
+ * created with hipEventDisableTiming | hipEventDisableSystemFence, i.e. a record is an agent-scope release, not an L2 write-back
+ * for host visibility.  NOT for host-side reads of device results other than through drx_event_synchronize + pinned memory. */
+void *drx_event_create(void);
+void drx_event_destroy(void *ev);
+int drx_event_record(void *ev, void *stream);
+int drx_stream_wait_event(void *stream, void *ev);
+int drx_event_synchronize(void *ev);
+
 /* 64-bit mix used for the counter-based corruption mask; exported so hosts/tests can reproduce it. */
 uint32_t drx_hash_u32(uint64_t seed, uint32_t a, uint32_t b);
 
@@ -152,11 +161,13 @@ int drx_cdae_step_sparse_prepared(const DrxCdaeParams *p, const DrxOptim *opt, c
 /* ---- device-side point sampler (throughput mode; distribution of point_sampler.py:44-61) ------------
  * Draws B triples with a counter-based generator keyed by (seed, b): negatives with probability
  * neg_ratio/(neg_ratio+1) = uniform (u,i) outside u's positives, positives = uniform user then uniform positive.
- * Also writes keep_off[B+1] (exclusive prefix sum of deg(uid[b])). */
+ * Also writes keep_off[B+1] (exclusive prefix sum of deg(uid[b])).
+ * host_mailbox (optional): 8 bytes of PINNED host memory; the last kernel stores ((uint64)tag << 32) | keep_off[B] there with one
+ * system-scope store, so a host that runs ahead learns the batch's touch count by polling for its tag — no copy, no event. */
 size_t drx_point_sample_scratch_bytes(int32_t B);
 int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
                      uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
-                     void *scratch, size_t scratch_bytes, void *stream);
+                     void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
 
 /* ---- column-sharded ("K-sharded") multi-GPU step (no reference equivalent) ------------------------------------------------
  * Every rank holds ALL rows but only its own columns of W, W2T, V and b (DrxCdaeParams describes that slice: k = local columns;
