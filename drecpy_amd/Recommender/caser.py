@@ -5,7 +5,7 @@ Reference behaviour kept: ListSampler configured as caser.py:72-75 (window of L 
 negative ids, sorted by `sort_column`), vertical conv that sums over the embedding dimension (caser.py:53 — not the
 paper's per-dimension conv), max over time of the horizontal convs, dense Keras Adam with one apply per registered layer
 (6 + L per step), l2(reg_rate) on embeddings and kernels.  TF's dropout RNG cannot be reproduced: the keep mask comes
-from a numpy Generator seeded with the model seed (or is injected with `dropout_mask_fn` for tests); relu is the only
+from a counter-based hash of (model seed, step, sample, unit) evaluated in the kernel (or is injected with `dropout_mask_fn` for tests); relu is the only
 supported activation (the reference's default for both act_h and act_mlp).
 `_rank(novelty=False)` ignores the candidate list and ranks ALL items, exactly like caser.py:128-146 (only the novelty branch
 filters by `iids` there; ranking_evaluation defaults to novelty=False, so HR/NDCG@k are comparable with the reference's);
@@ -47,7 +47,7 @@ class Caser(RecommenderABC):
                                     interaction_threshold=self.interaction_threshold, negative_ids_col='iid',
                                     min_positive_records=self.L, max_positive_records=self.L,
                                     sort_column=self.sort_column, seed=self.seed)
-        self._drop_rng = np.random.default_rng(self.seed)
+        self._drop_seed = int(self.seed) if self.seed is not None else int(np.random.SeedSequence().entropy % (2 ** 62))
         self._dropout_mask_fn = kwds.get('dropout_mask_fn')
 
     def _fused_trainables(self):
@@ -106,10 +106,11 @@ class Caser(RecommenderABC):
         if self.dropout_rate and self.dropout_rate > 0:
             rate = float(self.dropout_rate)
             nx = self.n_v + self.L * self.n_h
-            keep = self._dropout_mask_fn(step, B, nx) if self._dropout_mask_fn is not None \
-                else (self._drop_rng.random((B, nx)) >= rate)
+            # an injected mask (tests), else the kernel's counter-based mask keyed by (model seed, step): TF's dropout stream
+            # cannot be reproduced, and 344 K host random numbers per batch of 4096 cost more than the device step
+            keep = self._dropout_mask_fn(step, B, nx) if self._dropout_mask_fn is not None else None
         return self._engine.step(step, np.asarray(uids), np.asarray(before), np.asarray(after), keep, rate,
-                                 want_loss=want_loss)
+                                 want_loss=want_loss, mask_seed=self._drop_seed * 0x9E3779B97F4A7C15 + step + 1)
 
     def _predict_batch(self, batch_samples, **kwds):
         """Sigmoid scores of the batch's targets (caser.py:86-95, evaluation mode: no dropout)."""

@@ -52,7 +52,7 @@ class CaserDims(C.Structure):
 class CaserArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('item_emb', 'user_emb', 'W1', 'b1', 'sw', 'uid', 'before', 'after', 'keep')] + \
                [('rate', C.c_float), ('B', C.c_int32)] + \
-               [(n, C.c_void_p) for n in ('dE', 'dW1', 'db1', 'dPu', 'gsw_part', 'loss_part', 'cat_out')]
+               [(n, C.c_void_p) for n in ('dE', 'dW1', 'db1', 'dPu', 'gsw_part', 'loss_part', 'cat_out')] + [('mask_seed', C.c_uint64)]
 
 
 class DmfDims(C.Structure):

@@ -43,33 +43,57 @@ struct CaserLds {
   float *pre;     // [nx] pre-activation at the arg-max step (horizontal convs)
   float *dx;      // [nx]
   int *arg;       // [nx]
+  float *dz0s;    // [64] dense_0's pre-activation gradient of the sample (read by the accumulator owners)
 };
 
+// Orders the LDS traffic of ONE wave (its private scratch is written by some lanes and read by others): every LDS operation of the
+// wave issued so far has completed.  A workgroup barrier is not needed for that and would tie unrelated samples together.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// A workgroup is W waves, one sample per wave and round, sharing ONE set of small-weight gradient accumulators in LDS (72 KB at the
+// reference configuration: with a private copy per wave only two waves fit a CU and the chip idles — 0.74 ms at B = 4096).  Forward
+// and backward of the W samples run side by side in per-wave scratch; afterwards the waves add their weight-gradient contributions
+// to the shared accumulators ONE AFTER THE OTHER, in sample order (a barrier between turns): no atomics, and the order of every
+// sum is fixed by the batch alone.
 template <bool TRAIN>
-__global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
+__global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
   extern __shared__ __align__(16) float lds[];
-  const int c = threadIdx.x;
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int L = D.L, d = D.d, nx = D.n_v + D.L * D.n_h;
+  const int per_wave = 2 * L * 64 + 5 * nx + 64;
   CaserLds S;
-  float *q = lds;
-  S.gsw = q; q += TRAIN ? D.n_small : 0;
+  S.gsw = lds;
+  float *q = lds + (TRAIN ? D.n_small : 0) + (size_t)w * per_wave;
   S.E = q; q += L * 64;
   S.dE = q; q += L * 64;
   S.x = q; q += nx;
   S.xd = q; q += nx;
   S.pre = q; q += nx;
   S.dx = q; q += nx;
-  S.arg = reinterpret_cast<int *>(q);
+  S.arg = reinterpret_cast<int *>(q); q += nx;
+  S.dz0s = q;
+  __shared__ float wloss[16];
   const float *sw = A.sw;
-  if (TRAIN)
-    for (int i = c; i < D.n_small; i += 64) S.gsw[i] = 0.f;
+  if (TRAIN) {
+    for (int i = threadIdx.x; i < D.n_small; i += blockDim.x) S.gsw[i] = 0.f;
+    __syncthreads();
+  }
   float loss_acc = 0.f;
   const bool live = c < d;
   const float inv_bt = 1.0f / ((float)A.B * (float)D.Tp);
   const float inv_keep = 1.0f / (1.0f - A.rate);
+  const bool hashed = TRAIN && !A.keep && A.rate > 0.f;                // counter-based dropout mask (DrxCaserArgs.mask_seed)
+  const uint32_t rthr = hashed ? q_threshold(A.rate) : 0u;
 
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
-    __syncthreads();
+  for (int b0 = blockIdx.x * W; b0 < A.B; b0 += gridDim.x * W) {      // uniform over the workgroup: its waves take b0 .. b0 + W - 1
+    const int b = b0 + w;
+    const bool has = b < A.B;
+    float dz0 = 0.f;
+    if (has) {
     // ---- 1. embeddings ---------------------------------------------------------------------------------------------
     for (int t = 0; t < L; ++t) {
       const int n = A.before[b * L + t];
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
     }
     const int u = A.uid[b];
     const float pu = live ? A.user_emb[(size_t)u * D.ld + c] : 0.f;
-    __syncthreads();
+    wave_lds_sync();
     // ---- 2. vertical conv ------------------------------------------------------------------------------------------
     for (int f = 0; f < D.n_v; ++f) {
       float part = 0.f;
@@ -118,14 +142,15 @@ __global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
         }
       }
     }
-    __syncthreads();
+    wave_lds_sync();
     // ---- 4. dropout (mask injected by the host; caser.py:61,114) -------------------------------------------------------
     for (int j = c; j < nx; j += 64) {
       float v = S.x[j];
       if (TRAIN && A.keep) v = A.keep[(size_t)b * nx + j] ? v * inv_keep : 0.f;
+      else if (hashed) v = hash_u32(A.mask_seed, (uint32_t)b, (uint32_t)j) >= rthr ? v * inv_keep : 0.f;
       S.xd[j] = v;
     }
-    __syncthreads();
+    wave_lds_sync();
     // ---- 5. dense_0 (relu) ---------------------------------------------------------------------------------------------
     float z0 = live ? sw[D.off_bd + c] : 0.f;
     if (live)
@@ -133,8 +158,7 @@ __global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
     const float z = fmaxf(z0, 0.f);
     if (!TRAIN) {
       if (live) { A.cat_out[(size_t)b * D.ld2 + c] = z; A.cat_out[(size_t)b * D.ld2 + d + c] = pu; }
-      continue;
-    }
+    } else {
     // ---- 6. targets: score, sigmoid, Keras BCE, backward to the lookups -------------------------------------------------
     float dz = 0.f, dpu = 0.f;
     for (int j = 0; j < D.Tp; ++j) {
@@ -153,36 +177,30 @@ __global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
       dpu = fmaf(ds, wb, dpu);
     }
     if (live) A.dPu[(size_t)b * D.ld + c] = dpu;
-    const float dz0 = z0 > 0.f ? dz : 0.f;
-    // ---- 7. dense_0 backward ---------------------------------------------------------------------------------------------
-    if (live) S.gsw[D.off_bd + c] += dz0;
-    for (int j0 = 0; j0 < nx; j0 += 16) {                       // dx[j] = sum_c dz0[c] * Wd[j][c], 16 rows of Wd per reduce16
+    dz0 = z0 > 0.f ? dz : 0.f;
+    // ---- 7. dense_0 backward: dx[j] = sum_c dz0[c] * Wd[j][c], 16 rows of Wd per reduce16 ---------------------------------------
+    for (int j0 = 0; j0 < nx; j0 += 16) {
       float prod[16];
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
         const int j = j0 + jj;
-        const float w = (live && j < nx) ? sw[D.off_wd + j * D.ld + c] : 0.f;
-        if (live && j < nx) S.gsw[D.off_wd + j * D.ld + c] = fmaf(S.xd[j], dz0, S.gsw[D.off_wd + j * D.ld + c]);
-        prod[jj] = dz0 * w;
+        const float wv = (live && j < nx) ? sw[D.off_wd + j * D.ld + c] : 0.f;
+        prod[jj] = dz0 * wv;
       }
       float g = reduce16(prod, c);
       const int j = j0 + slot16(c);
       if ((c & 3) == 0 && j < nx) {
         if (A.keep) g = A.keep[(size_t)b * nx + j] ? g * inv_keep : 0.f;
+        else if (hashed) g = hash_u32(A.mask_seed, (uint32_t)b, (uint32_t)j) >= rthr ? g * inv_keep : 0.f;
         S.dx[j] = g;
       }
     }
-    __syncthreads();
-    // ---- 8. vertical conv backward ---------------------------------------------------------------------------------------
+    wave_lds_sync();
+    // ---- 8. vertical conv backward (to the item rows) ------------------------------------------------------------------------
     for (int f = 0; f < D.n_v; ++f) {
       const float dv = S.dx[f];
-      if (c == 0) S.gsw[D.off_bv + f] += dv;
       if (live)
-        for (int t = 0; t < L; ++t) {
-          const int k = D.off_kv + (t * D.n_v + f) * D.ld + c;
-          S.gsw[k] = fmaf(S.E[t * 64 + c], dv, S.gsw[k]);
-          S.dE[t * 64 + c] = fmaf(dv, sw[k], S.dE[t * 64 + c]);
-        }
+        for (int t = 0; t < L; ++t) S.dE[t * 64 + c] = fmaf(dv, sw[D.off_kv + (t * D.n_v + f) * D.ld + c], S.dE[t * 64 + c]);
     }
     // ---- 9. horizontal convs backward (through relu at the arg-max step) -------------------------------------------------
     for (int i = 0; i < L; ++i)
@@ -191,22 +209,66 @@ __global__ __launch_bounds__(64) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
         const float dc = S.pre[j] > 0.f ? S.dx[j] : 0.f;
         if (dc == 0.f) continue;
         const int t = S.arg[j];
-        if (c == 0) S.gsw[D.off_bh[i] + f] += dc;
         if (live)
-          for (int s = 0; s <= i; ++s) {
-            const int k = D.off_kh[i] + (s * D.n_h + f) * D.ld + c;
-            S.gsw[k] = fmaf(S.E[(t + s) * 64 + c], dc, S.gsw[k]);
-            S.dE[(t + s) * 64 + c] = fmaf(dc, sw[k], S.dE[(t + s) * 64 + c]);
-          }
+          for (int s = 0; s <= i; ++s)
+            S.dE[(t + s) * 64 + c] = fmaf(dc, sw[D.off_kh[i] + (s * D.n_h + f) * D.ld + c], S.dE[(t + s) * 64 + c]);
       }
     // ---- 10. gradient rows of the item lookups ------------------------------------------------------------------------------
     if (live)
       for (int t = 0; t < L; ++t) A.dE[((size_t)b * L + t) * D.ld + c] = S.dE[t * 64 + c];
+    }   // TRAIN
+    }   // has
+    // ---- 11. small-weight gradients into the shared accumulators ---------------------------------------------------------------
+    // Every accumulator row has ONE owner wave (dense_0 row j: wave j % W; conv_v filter f: f % W; horizontal filter (i, f):
+    // (i * n_h + f) % W; the dense_0 bias: wave 0).  An owner walks the W samples of the round in sample order and adds their
+    // contributions to its rows out of the samples' scratch — no two waves ever touch the same accumulator, and every sum is taken
+    // in the order of the batch.
+    if (TRAIN) {
+      if (has) S.dz0s[c] = dz0;
+      __syncthreads();
+      for (int t = 0; t < W && b0 + t < A.B; ++t) {
+        const float *T0 = lds + D.n_small + (size_t)t * per_wave;
+        const float *tE = T0, *txd = T0 + 2 * L * 64 + nx, *tpre = txd + nx, *tdx = tpre + nx;
+        const int *targ = reinterpret_cast<const int *>(tdx + nx);
+        const float tdz0 = reinterpret_cast<const float *>(targ + nx)[c];
+        if (w == 0 && live) S.gsw[D.off_bd + c] += tdz0;
+        if (live)
+          for (int j = w; j < nx; j += W) S.gsw[D.off_wd + j * D.ld + c] = fmaf(txd[j], tdz0, S.gsw[D.off_wd + j * D.ld + c]);
+        for (int f = w; f < D.n_v; f += W) {
+          const float dv = tdx[f];
+          if (c == 0) S.gsw[D.off_bv + f] += dv;
+          if (live)
+            for (int tt = 0; tt < L; ++tt) {
+              const int k = D.off_kv + (tt * D.n_v + f) * D.ld + c;
+              S.gsw[k] = fmaf(tE[tt * 64 + c], dv, S.gsw[k]);
+            }
+        }
+        for (int pq = w; pq < L * D.n_h; pq += W) {
+          const int i = pq / D.n_h, f = pq - i * D.n_h;
+          const int j = D.n_v + pq;
+          const float dc = tpre[j] > 0.f ? tdx[j] : 0.f;
+          if (dc == 0.f) continue;
+          const int ta = targ[j];
+          if (c == 0) S.gsw[D.off_bh[i] + f] += dc;
+          if (live)
+            for (int s2 = 0; s2 <= i; ++s2) {
+              const int k = D.off_kh[i] + (s2 * D.n_h + f) * D.ld + c;
+              S.gsw[k] = fmaf(tE[(ta + s2) * 64 + c], dc, S.gsw[k]);
+            }
+        }
+      }
+      __syncthreads();
+    }
   }
   if (TRAIN) {
+    if (c == 0) wloss[w] = loss_acc;
     __syncthreads();
-    for (int i = c; i < D.n_small; i += 64) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = S.gsw[i];
-    if (c == 0) A.loss_part[blockIdx.x] = loss_acc * inv_bt;
+    for (int i = threadIdx.x; i < D.n_small; i += blockDim.x) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = S.gsw[i];
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int ww = 0; ww < W; ++ww) t += wloss[ww];
+      A.loss_part[blockIdx.x] = t * inv_bt;
+    }
   }
 }
 
@@ -244,16 +306,23 @@ __global__ __launch_bounds__(kBlock) void k_adam_segments(float *p, float *m, fl
   }
 }
 
-static size_t caser_lds_bytes(const DrxCaserDims &D, bool train) {
+static size_t caser_lds_bytes(const DrxCaserDims &D, bool train, int waves) {
   const int nx = D.n_v + D.L * D.n_h;
-  return ((size_t)(train ? D.n_small : 0) + 2 * (size_t)D.L * 64 + 5 * (size_t)nx) * 4 + 64;
+  return ((size_t)(train ? D.n_small : 0) + (size_t)waves * (2 * (size_t)D.L * 64 + 5 * (size_t)nx + 64)) * 4 + 64;
+}
+
+// waves per workgroup: as many (16, 8, 4, 2, 1) as fit the CU's LDS beside the shared accumulators, and no more than the batch needs
+static int caser_waves(const DrxCaserDims &D, bool train, int B) {
+  int w = 16;
+  while (w > 1 && (caser_lds_bytes(D, train, w) > 150 * 1024 || (B + w - 1) / w < 128)) w >>= 1;
+  return w;
 }
 
 static int check_dims(const DrxCaserDims *D) {
   if (!D || D->L < 1 || D->L > kCaserMaxL || D->d < 1 || D->d > 64 || D->ld < D->d || (D->ld & 3) || D->ld2 < 2 * D->d ||
       (D->ld2 & 3) || D->n_v < 1 || D->n_h < 1 || D->T < 1 || D->Tp < D->T || D->n_small < 1)
     return DRX_EINVAL;
-  return caser_lds_bytes(*D, true) <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
+  return caser_lds_bytes(*D, true, 1) <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
 }
 
 }  // namespace drx
@@ -263,8 +332,10 @@ using namespace drx;
 extern "C" {
 
 int drx_caser_grid(const DrxCaserDims *D, int32_t B) {
-  (void)D;
-  return B < 512 ? B : 512;
+  if (!D || B < 1) return 0;
+  const int w = caser_waves(*D, true, B);
+  const int g = (B + w - 1) / w;
+  return g < 512 ? g : 512;
 }
 
 int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, void *stream) {
@@ -275,9 +346,10 @@ int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_o
     return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = drx_caser_grid(D, A->B);
-  const size_t lds = caser_lds_bytes(*D, true);
+  const int waves = caser_waves(*D, true, A->B);
+  const size_t lds = caser_lds_bytes(*D, true, waves);
   DRX_HIP(hipFuncSetAttribute((const void *)k_caser<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_caser<true>, dim3(grid), dim3(64), lds, st, *D, *A);
+  hipLaunchKernelGGL(k_caser<true>, dim3(grid), dim3(64 * waves), lds, st, *D, *A);
   hipLaunchKernelGGL(k_sum_partials, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
                      A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();
@@ -289,8 +361,10 @@ int drx_caser_hidden(const DrxCaserDims *D, const DrxCaserArgs *A, void *stream)
   if (rc) return rc;
   if (!A || !A->item_emb || !A->user_emb || !A->sw || !A->uid || !A->before || !A->cat_out || A->B < 1) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = caser_lds_bytes(*D, false);
-  hipLaunchKernelGGL(k_caser<false>, dim3(A->B < 2048 ? A->B : 2048), dim3(64), lds, st, *D, *A);
+  const int waves = 4;
+  const size_t lds = caser_lds_bytes(*D, false, waves);
+  const int g = (A->B + waves - 1) / waves;
+  hipLaunchKernelGGL(k_caser<false>, dim3(g < 2048 ? g : 2048), dim3(64 * waves), lds, st, *D, *A);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

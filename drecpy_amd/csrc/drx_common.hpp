@@ -31,7 +31,7 @@ __host__ __device__ inline uint32_t hash_u32(uint64_t seed, uint32_t a, uint32_t
   return (uint32_t)(x >> 32);
 }
 
-__host__ inline uint32_t q_threshold(float q) {
+__host__ __device__ inline uint32_t q_threshold(float q) {
   double t = (double)q * 4294967296.0;
   if (t <= 0.0) return 0u;
   if (t >= 4294967295.0) return 0xFFFFFFFFu;

@@ -143,17 +143,20 @@ class CaserEngine:
         check(lib().drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(grad), p.numel(), alpha, l2c, self.beta1, self.beta2, self.eps,
                                    stream_ptr(self.device)), 'drx_adam_dense')
 
-    def _args(self, uid, before, after=None, keep=None, rate=0.0):
+    def _args(self, uid, before, after=None, keep=None, rate=0.0, mask_seed=0):
         A = CaserArgs()
         A.item_emb, A.user_emb, A.W1, A.b1, A.sw = (t.data_ptr() for t in (self.item_emb, self.user_emb, self.W1, self.b1, self.sw))
         A.uid, A.before = uid.data_ptr(), before.data_ptr()
         A.after = after.data_ptr() if after is not None else None
         A.keep = keep.data_ptr() if keep is not None else None
         A.rate, A.B = float(rate), int(uid.numel())
+        A.mask_seed = int(mask_seed) & (2 ** 64 - 1)
         return A
 
     # ---- one training step ---------------------------------------------------------------------------------------
-    def step(self, step_idx, uids, before, after, keep=None, rate=0.0, want_loss=False):
+    def step(self, step_idx, uids, before, after, keep=None, rate=0.0, want_loss=False, mask_seed=0):
+        """keep: explicit dropout keep mask [B, n_v + L*n_h] or None; with None and rate > 0 the kernel evaluates the counter-based
+        mask drx_hash_u32(mask_seed, b, j) >= rate * 2^32 itself (no 344 K host random numbers per batch of 4096)."""
         L_ = lib()
         if any(torch.is_tensor(a) for a in (uids, before, after, keep)):
             uid, bef, aft = self._dev_i32(uids), self._dev_i32(before), self._dev_i32(after)
@@ -184,7 +187,7 @@ class CaserEngine:
         lpart = torch.empty(grid, **z)
         gsw = torch.empty(self.D.n_small + 1, **z)
         self._grad_arena.zero_()
-        A = self._args(uid, bef, aft, kp, rate)
+        A = self._args(uid, bef, aft, kp, rate, mask_seed)
         A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = (t.data_ptr() for t in (dE, dW1, db1, dPu, gpart, lpart))
         reg_loss = None
         if want_loss:                                   # Keras l2(reg) on the pre-update weights

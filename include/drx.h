@@ -309,6 +309,8 @@ typedef struct DrxCaserArgs {
   float *gsw_part;         /* [drx_caser_grid(), n_small] */
   float *loss_part;        /* [drx_caser_grid()] */
   float *cat_out;          /* [B, ld2] (drx_caser_hidden only) */
+  uint64_t mask_seed;      /* keep == NULL and rate > 0: dropout keeps element (b, j) iff drx_hash_u32(mask_seed, b, j) >= rate * 2^32 —
+                            * a counter-based mask evaluated in the kernel (TF's dropout stream cannot be reproduced either way) */
 } DrxCaserArgs;
 int drx_caser_grid(const DrxCaserDims *D, int32_t B);
 /* forward + Keras BCE + backward (caser.py:86-120 under the tape of recommender_abc.py:191-203): fills the lookup

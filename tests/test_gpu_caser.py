@@ -91,3 +91,32 @@ def test_caser_fit_matches_oracle_end_to_end():
     from oracle import cdae_oracle as co
     want = co.rank_row(want_sc.astype(np.float32), range(0, N, 3), 8, exclude=set(seq.tolist()))
     assert [ds.item_to_iid(i) for _, i in got] == [i for _, i in want]
+
+
+def test_caser_counter_based_dropout_mask_matches_oracle():
+    """keep = None, rate > 0: the kernel evaluates the mask drx_hash_u32(mask_seed, b, j) >= rate * 2^32 itself; the same mask
+    rebuilt on the host (helpers.hash_u32) and injected into the oracle gives the same step."""
+    from helpers import hash_u32, q_threshold
+    from drecpy_amd.engine_caser import CaserEngine
+    rng = np.random.default_rng(5)
+    U, N, L, T, neg, d, n_v, n_h, B = 30, 80, 5, 3, 2, 24, 4, 16, 70
+    p = ca.init_params(rng, U, N, L, d, n_v, n_h, np.float64)
+    eng = CaserEngine(U, N, L, T, neg, d, n_v, n_h)
+    eng.set_params(p)
+    eng.lr, eng.reg = 5e-3, 1e-4
+    st = ca.adam_state(p)
+    nx = n_v + L * n_h
+    for step in range(3):
+        uids = rng.integers(0, U, size=B)
+        before = rng.integers(0, N, size=(B, L))
+        after = rng.integers(0, N, size=(B, T + T * neg))
+        seed = 0xABCDEF12345 + step
+        bb, jj = np.meshgrid(np.arange(B), np.arange(nx), indexing='ij')
+        keep = (hash_u32(seed, bb.ravel(), jj.ravel()) >= q_threshold(0.5)).reshape(B, nx)
+        assert 0.4 < keep.mean() < 0.6
+        lo = ca.step(p, st, step, uids, before, after, T, 5e-3, 1e-4, keep, 0.5)
+        lg = eng.step(step, uids, before, after, None, 0.5, want_loss=True, mask_seed=seed)
+        assert abs(lg - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
