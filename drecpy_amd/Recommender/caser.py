@@ -5,8 +5,8 @@ Reference behaviour kept: ListSampler configured as caser.py:72-75 (window of L 
 negative ids, sorted by `sort_column`), vertical conv that sums over the embedding dimension (caser.py:53 — not the
 paper's per-dimension conv), max over time of the horizontal convs, dense Keras Adam with one apply per registered layer
 (6 + L per step), l2(reg_rate) on embeddings and kernels.  TF's dropout RNG cannot be reproduced: the keep mask comes
-from a counter-based hash of (model seed, step, sample, unit) evaluated in the kernel (or is injected with `dropout_mask_fn` for tests); relu is the only
-supported activation (the reference's default for both act_h and act_mlp).
+from a counter-based hash of (model seed, step, sample, unit) evaluated in the kernel (or is injected with `dropout_mask_fn` for tests); act_h / act_mlp: relu (the
+reference's default for both), tanh, sigmoid, linear.
 `_rank(novelty=False)` ignores the candidate list and ranks ALL items, exactly like caser.py:128-146 (only the novelty branch
 filters by `iids` there; ranking_evaluation defaults to novelty=False, so HR/NDCG@k are comparable with the reference's);
 `Caser(reference_rank=False)` restricts that branch to the candidates instead.
@@ -24,8 +24,14 @@ class Caser(RecommenderABC):
                  sort_column='timestamp', device='cuda:0', reference_rank=True, **kwds):
         super().__init__(**kwds)
         self.reference_rank = reference_rank
-        if act_h != 'relu' or act_mlp != 'relu':
-            raise Exception('drecpy_amd.Caser supports relu activations only (the reference defaults).')
+        # the reference hands act_h / act_mlp to Keras (caser.py:57,63: any activation name or callable); the kernels implement
+        # relu, tanh, sigmoid and linear, and lanes = embedding channels of one wavefront bound d; other values are rejected HERE
+        supported = ('relu', 'tanh', 'sigmoid', 'linear', None)
+        if act_h not in supported or act_mlp not in supported:
+            raise Exception(f'drecpy_amd.Caser supports the activations {supported[:4]} (given: act_h={act_h!r}, act_mlp={act_mlp!r}).')
+        if not (1 <= L <= 8 and 1 <= d <= 64):
+            raise Exception(f'drecpy_amd.Caser supports 1 <= L <= 8 and 1 <= d <= 64 (given: L={L}, d={d}).')
+        self.act_h, self.act_mlp = act_h, act_mlp
         self.L, self.T, self.d, self.n_v, self.n_h = L, T, d, n_v, n_h
         self.dropout_rate = dropout_rate
         self.sort_column = sort_column
@@ -35,7 +41,7 @@ class Caser(RecommenderABC):
         from ..engine_caser import CaserEngine
         self.neg_ratio = neg_ratio
         self._engine = CaserEngine(self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v, self.n_h,
-                                   device=self.device)
+                                   device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
         self._engine.lr, self._engine.reg = float(learning_rate), float(reg_rate)
         weights = kwds.get('initial_weights')
         if weights is None:

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libdrx.so')
 LOSS_BCE, LOSS_MSE = 0, 1
 TARGETS_REFERENCE, TARGETS_PER_ROW = 0, 1
 OPT_ADAM, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
+DENSE_AUX_CLEAN = 0x100          # include/drx.h: DRX_DENSE_AUX_CLEAN
 KEY_NONE = 0xFFFFFFFF
 
 
@@ -46,7 +47,8 @@ class AdamSegments(C.Structure):
 
 class CaserDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('L', 'T', 'Tp', 'd', 'ld', 'ld2', 'n_v', 'n_h', 'n_small', 'off_kv', 'off_bv')] + \
-               [('off_kh', C.c_int32 * 8), ('off_bh', C.c_int32 * 8), ('off_wd', C.c_int32), ('off_bd', C.c_int32)]
+               [('off_kh', C.c_int32 * 8), ('off_bh', C.c_int32 * 8), ('off_wd', C.c_int32), ('off_bd', C.c_int32), ('act_h', C.c_int32),
+                ('act_mlp', C.c_int32)]
 
 
 class CaserArgs(C.Structure):

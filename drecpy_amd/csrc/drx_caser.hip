@@ -46,6 +46,24 @@ struct CaserLds {
   float *dz0s;    // [64] dense_0's pre-activation gradient of the sample (read by the accumulator owners)
 };
 
+// act_h / act_mlp of caser.py:29-30 (Keras activation names): value and derivative at pre-activation v (a = act(v)).
+__device__ __forceinline__ float act_f(int kind, float v) {
+  switch (kind) {
+    case DRX_ACT_RELU: return fmaxf(v, 0.f);
+    case DRX_ACT_TANH: return tanhf(v);
+    case DRX_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+__device__ __forceinline__ float act_df(int kind, float v) {
+  switch (kind) {
+    case DRX_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    case DRX_ACT_TANH: { const float a = tanhf(v); return 1.f - a * a; }
+    case DRX_ACT_SIGMOID: { const float a = sigmoidf_(v); return a * (1.f - a); }
+    default: return 1.f;
+  }
+}
+
 // Orders the LDS traffic of ONE wave (its private scratch is written by some lanes and read by others): every LDS operation of the
 // wave issued so far has completed.  A workgroup barrier is not needed for that and would tie unrelated samples together.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -110,13 +128,13 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
       const float v = wave_sum(part) + sw[D.off_bv + f];
       if (c == 0) { S.x[f] = v; S.pre[f] = v; S.arg[f] = 0; }
     }
-    // ---- 3. horizontal convs + relu + max over time -------------------------------------------------------------------
+    // ---- 3. horizontal convs + act_h + max over time -------------------------------------------------------------------
     // 16 filters at a time: their (i+1) x 16 kernel values of this channel are requested together, the 16 channel sums
     // leave through one reduce16, and the lanes that end up holding filter f track its maximum over the window positions.
     for (int i = 0; i < L; ++i) {
       for (int f0 = 0; f0 < D.n_h; f0 += 16) {
         const int fm = slot16(c);                               // the filter (of this block) whose total this lane receives
-        float best = -1.f, bpre = 0.f;
+        float best = -3.0e38f, bpre = 0.f;
         int bt = 0;
         for (int t = 0; t + i < L; ++t) {
           float part[16];
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
           }
           const float tot = reduce16(part, c);
           const float v = tot + ((f0 + fm < D.n_h) ? sw[D.off_bh[i] + f0 + fm] : 0.f);
-          const float r = fmaxf(v, 0.f);
+          const float r = act_f(D.act_h, v);
           if (r > best) { best = r; bt = t; bpre = v; }        // first maximum wins, like the max-pool gradient
         }
         if ((c & 3) == 0 && f0 + fm < D.n_h) {                  // one of the four lanes that hold filter fm
@@ -151,11 +169,11 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
       S.xd[j] = v;
     }
     wave_lds_sync();
-    // ---- 5. dense_0 (relu) ---------------------------------------------------------------------------------------------
+    // ---- 5. dense_0 (act_mlp) ---------------------------------------------------------------------------------------------
     float z0 = live ? sw[D.off_bd + c] : 0.f;
     if (live)
       for (int j = 0; j < nx; ++j) z0 = fmaf(S.xd[j], sw[D.off_wd + j * D.ld + c], z0);
-    const float z = fmaxf(z0, 0.f);
+    const float z = act_f(D.act_mlp, z0);
     if (!TRAIN) {
       if (live) { A.cat_out[(size_t)b * D.ld2 + c] = z; A.cat_out[(size_t)b * D.ld2 + d + c] = pu; }
     } else {
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
       dpu = fmaf(ds, wb, dpu);
     }
     if (live) A.dPu[(size_t)b * D.ld + c] = dpu;
-    dz0 = z0 > 0.f ? dz : 0.f;
+    dz0 = dz * act_df(D.act_mlp, z0);
     // ---- 7. dense_0 backward: dx[j] = sum_c dz0[c] * Wd[j][c], 16 rows of Wd per reduce16 ---------------------------------------
     for (int j0 = 0; j0 < nx; j0 += 16) {
       float prod[16];
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
     for (int i = 0; i < L; ++i)
       for (int f = 0; f < D.n_h; ++f) {
         const int j = D.n_v + i * D.n_h + f;
-        const float dc = S.pre[j] > 0.f ? S.dx[j] : 0.f;
+        const float dc = S.dx[j] * act_df(D.act_h, S.pre[j]);
         if (dc == 0.f) continue;
         const int t = S.arg[j];
         if (live)
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
         for (int pq = w; pq < L * D.n_h; pq += W) {
           const int i = pq / D.n_h, f = pq - i * D.n_h;
           const int j = D.n_v + pq;
-          const float dc = tpre[j] > 0.f ? tdx[j] : 0.f;
+          const float dc = tdx[j] * act_df(D.act_h, tpre[j]);
           if (dc == 0.f) continue;
           const int ta = targ[j];
           if (c == 0) S.gsw[D.off_bh[i] + f] += dc;
@@ -320,7 +338,8 @@ static int caser_waves(const DrxCaserDims &D, bool train, int B) {
 
 static int check_dims(const DrxCaserDims *D) {
   if (!D || D->L < 1 || D->L > kCaserMaxL || D->d < 1 || D->d > 64 || D->ld < D->d || (D->ld & 3) || D->ld2 < 2 * D->d ||
-      (D->ld2 & 3) || D->n_v < 1 || D->n_h < 1 || D->T < 1 || D->Tp < D->T || D->n_small < 1)
+      (D->ld2 & 3) || D->n_v < 1 || D->n_h < 1 || D->T < 1 || D->Tp < D->T || D->n_small < 1 || D->act_h < 0 || D->act_h > 3 ||
+      D->act_mlp < 0 || D->act_mlp > 3)
     return DRX_EINVAL;
   return caser_lds_bytes(*D, true, 1) <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
 }

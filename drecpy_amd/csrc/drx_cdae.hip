@@ -108,11 +108,11 @@ __global__ __launch_bounds__(kBlock) void k_hidden_fwd(DrxCdaeParams P, DrxHisto
 // Small batches (the reference's own B = 32..64): one WORKGROUP per batch row — its 256/G groups split the user's history,
 // each keeps 4 row loads in flight, and the partial bags are combined in LDS in group order.  With one group per row a
 // 155-item history is a chain of ~40 dependent load batches on 8 workgroups of the whole chip (measured 94 us at ml-1m).
-template <int G, int J, int MODE>
-__global__ __launch_bounds__(kBlock) void k_hidden_fwd_wg(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
+template <int G, int J, int MODE, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS) void k_hidden_fwd_wg(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
                                                           uint32_t qthr, float *__restrict__ hout, DenseAux aux) {
   extern __shared__ __align__(16) float lds[];   // [R, ld]
-  constexpr int R = kBlock / G;
+  constexpr int R = THREADS / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int b = blockIdx.x;
   float4 acc[J], h[J];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_out_fwd(DrxCdaeParams P, const float
 // ------------------------------------------------------------------------------------------------
 struct OutDenseArgs {
   const float *h;         // [B, ld]
-  const int32_t *cnt;     // [N]
+  int32_t *cnt;           // [N]  (zeroed again by the tile that read it: the next step finds it clean)
   const uint32_t *tb;     // [B, Nw] or null
   int Nw;
   int B, Bs, n_sub;       // sub-batch rows resident in LDS, number of sub-batches
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_out_dense(DrxCdaeParams P, DrxOptim 
         load_row<G, J>(P.W2T, (size_t)n, ld, lane, w);
         bias = P.b2[n];
         tbar = (float)A.cnt[n] * invB;
+        if (lane == 0 && sb + 1 == A.n_sub) A.cnt[n] = 0;       // (every lane of the group has read it: same instruction)
       }
       store_row<G, J>(w_s, (size_t)r, ld, lane, w);
       for (int b = 0; b < nb; ++b) {
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(kBlock) void k_out_dense_tile(DrxCdaeParams P, DrxO
       const int n = tile * R + threadIdx.x;
       bias_s[threadIdx.x] = n < P.n_items ? P.b2[n] : 0.f;
       tbar_s[threadIdx.x] = n < P.n_items ? (float)A.cnt[n] * invB : 0.f;
+      if (n < P.n_items) A.cnt[n] = 0;
     }
     __syncthreads();
     // A: dot products, predictions, dz
@@ -424,11 +426,11 @@ __global__ __launch_bounds__(kBlock) void k_out_dense_tile(DrxCdaeParams P, DrxO
 }
 
 // dz1[b,:] = (sum_slabs dh) * h (1-h)      one workgroup per batch row, groups stride over slabs
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_hidden_bwd(int ld, int B, int n_slabs, const float *__restrict__ slab,
+template <int G, int J, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS) void k_hidden_bwd(int ld, int B, int n_slabs, const float *__restrict__ slab,
                                                        const float *__restrict__ h, float *__restrict__ dz1) {
   extern __shared__ __align__(16) float lds[];   // [R, ld]
-  constexpr int R = kBlock / G;
+  constexpr int R = THREADS / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int b = blockIdx.x;
   float4 acc[J];
@@ -503,12 +505,13 @@ __global__ __launch_bounds__(kBlock) void k_in_sweep(DrxCdaeParams P, DrxOptim o
   for (int row = blockIdx.x * gpb + threadIdx.x / G; row < total; row += (gridDim.x - 1) * gpb) {
     const bool isW = row < P.n_items;
     const size_t rr = isW ? row : row - P.n_items;
-    const uint32_t *mask = isW ? aux.km + rr * aux.Bw : aux.vm + rr * aux.Bw;
+    uint32_t *mask = isW ? aux.km + rr * aux.Bw : aux.vm + rr * aux.Bw;
     float4 g[J], w[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) g[j] = f4_zero();
     for (int wd = 0; wd < aux.Bw; ++wd) {
       uint32_t m = mask[wd];
+      if (m && lane == 0) mask[wd] = 0;            // consumed (all lanes of the group loaded it with the same instruction): clean for the next step
       while (m) {
         const int b = wd * 32 + __builtin_ctz(m);
         m &= m - 1;
@@ -929,6 +932,7 @@ __global__ __launch_bounds__(kFixBlock) void k_sparse_tail_b(SegBufs S, DirectPo
 // scratch layouts (shared by the sizing entry point and the step functions)
 // ------------------------------------------------------------------------------------------------
 constexpr int kSmallBatch = 1024;    // at or below: one workgroup per batch row in the hidden-layer gather
+constexpr int kFewRows = 128;        // at or below: that workgroup has 1024 threads (fewer rows than CUs: spread each row wider)
 constexpr int kOutGrid = 512;        // persistent workgroups of k_out_dense (two per CU when LDS allows)
 constexpr int kSweepGrid = 1024;
 constexpr size_t kLdsBudget = 144 * 1024;
@@ -1292,12 +1296,17 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
     if (!opt->s1[i] || (opt->kind == DRX_OPT_ADAM && !opt->s2[i])) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   Carver cv(scratch, scratch_bytes);
+  // DRX_DENSE_AUX_CLEAN: the caller vouches that the batch-membership arrays in `scratch` are all zero — true for zero-initialised
+  // scratch and after every completed dense step of the same batch size, because the kernels that consume an entry clear it
+  const bool aux_clean = (targets_kind & DRX_DENSE_AUX_CLEAN) != 0;
+  targets_kind &= 0xFF;
   const bool per_row = targets_kind == DRX_TARGETS_PER_ROW;
   DenseLayout L = dense_layout(cv, *p, bt->B, per_row);
   if (!cv.ok()) return DRX_ESCRATCH;
   const float scale = 1.0f / (1.0f - bt->q);
   const uint32_t qthr = q_threshold(bt->q);
-  DRX_HIP(hipMemsetAsync((char *)scratch + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
+  if (!aux_clean) DRX_HIP(hipMemsetAsync((char *)scratch + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
+  else if (per_row) DRX_HIP(hipMemsetAsync(L.tb, 0, (size_t)bt->B * L.Nw * 4, st));      // (target bits are shared by tiles: no single consumer)
   DenseAux aux{L.cnt, L.km, L.vm, per_row ? L.tb : nullptr, L.Bw, L.Nw};
   OutDenseArgs A{};
   A.h = L.h; A.cnt = L.cnt; A.tb = aux.tb; A.Nw = L.Nw; A.B = bt->B; A.Bs = L.Bs; A.n_sub = L.n_sub;
@@ -1307,7 +1316,10 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
 #define CALL(G, J)                                                                                                   \
   {                                                                                                                  \
     const int gpb = kBlock / G;                                                                                      \
-    if (bt->B <= kSmallBatch)                                                                                        \
+    if (bt->B <= kFewRows)      /* the reference's own batch sizes: 1024 threads per batch row (32 groups split the history) */ \
+      hipLaunchKernelGGL((k_hidden_fwd_wg<G, J, 1, 1024>), dim3(bt->B), dim3(1024), (size_t)(1024 / G) * p->ld * 4, st, *p, *hist, \
+                         *bt, scale, qthr, L.h, aux);                                                                \
+    else if (bt->B <= kSmallBatch)                                                                                   \
       hipLaunchKernelGGL((k_hidden_fwd_wg<G, J, 1>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *hist, *bt, \
                          scale, qthr, L.h, aux);                                                                     \
     else                                                                                                             \
@@ -1332,8 +1344,12 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
                                   (int)L.lds_bytes));                                                                \
       hipLaunchKernelGGL((k_out_dense<G, J, false>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A);  \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_hidden_bwd<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B,   \
-                       L.out_grid, L.dh_slab, L.h, L.dz1);                                                           \
+    if (bt->B <= kFewRows)                                                                                           \
+      hipLaunchKernelGGL((k_hidden_bwd<G, J, 1024>), dim3(bt->B), dim3(1024), (size_t)(1024 / G) * p->ld * 4, st, p->ld, bt->B, \
+                         L.out_grid, L.dh_slab, L.h, L.dz1);                                                         \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_hidden_bwd<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, bt->B, \
+                         L.out_grid, L.dh_slab, L.h, L.dz1);                                                         \
     int sweep = (total_rows + gpb - 1) / gpb;                                                                        \
     if (sweep > kSweepGrid) sweep = kSweepGrid;                                                                      \
     hipLaunchKernelGGL((k_in_sweep<G, J>), dim3(sweep + 1), dim3(kBlock), 0, st, *p, *opt, bt->B, scale, aux, L.dz1, \

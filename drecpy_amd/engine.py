@@ -42,6 +42,7 @@ class CdaeEngine:
         self.hist_indptr = self.hist_indices = None
         self._hist = None
         self._scratch = None
+        self._dense_scratch, self._dense_scratch_B, self._dense_clean = None, None, False
         self._loss = torch.zeros(2, **z)
 
     # ---- parameters -------------------------------------------------------------------------
@@ -303,17 +304,24 @@ class CdaeEngine:
         return bt, (uid, iid, y, keep_off, keep)
 
     def _ensure_scratch(self, B, n_touch_slots, dense=False):
-        if dense:                      # the dense step's scratch depends on B only
-            if getattr(self, '_dense_scratch_B', None) == B and self._scratch is not None:
-                return self._scratch
-            self._dense_scratch_B = B
-        else:
-            self._dense_scratch_B = None
-        need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, n_touch_slots, 1 if dense else 0)
+        if dense:
+            return self._ensure_dense_scratch(B)
+        need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, n_touch_slots, 0)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = None
             self._scratch = torch.empty(int(need * 1.1) + 1024, dtype=torch.uint8, device=self.device)
         return self._scratch
+
+    def _ensure_dense_scratch(self, B):
+        """Scratch of the reference-mode step: a buffer of its own, ZERO-initialised and kept for one batch size.  The dense step
+        leaves its batch-membership arrays clean (the kernel that reads an entry clears it), so consecutive steps pass
+        DRX_DENSE_AUX_CLEAN and skip the memset; a step that raised, or another batch size, starts from fresh zeros."""
+        if getattr(self, '_dense_scratch', None) is None or self._dense_scratch_B != B or not self._dense_clean:
+            need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, 0, 1)
+            self._dense_scratch = None
+            self._dense_scratch = torch.zeros(int(need) + 1024, dtype=torch.uint8, device=self.device)
+            self._dense_scratch_B, self._dense_clean = B, True
+        return self._dense_scratch
 
     # ---- calls ------------------------------------------------------------------------------
     def forward(self, uid, keep_off=None, keep=None, q=0.0, mask_seed=0, want_pred=True):
@@ -329,13 +337,15 @@ class CdaeEngine:
     def step_dense(self, step, bt, loss='bce', targets='reference', want_loss=False):
         """One reference-mode fit() iteration; `step` is the 0-based batch index (Adam t = 5*step+j+1)."""
         o = self._optim(self._dense_alphas(step))
-        sc = self._ensure_scratch(bt.B, max(bt.n_touch_slots, 0), dense=True)
+        sc = self._ensure_dense_scratch(bt.B)
+        self._dense_clean = False                   # (stays False if the call raises: the next step then starts from fresh zeros)
         check(lib().drx_cdae_step_dense(
             C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
             _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE,
-            _lib.TARGETS_REFERENCE if targets == 'reference' else _lib.TARGETS_PER_ROW,
+            (_lib.TARGETS_REFERENCE if targets == 'reference' else _lib.TARGETS_PER_ROW) | _lib.DENSE_AUX_CLEAN,
             ptr(sc), sc.numel(), ptr(self._loss) if want_loss else None, stream_ptr(self.device)),
             'drx_cdae_step_dense')
+        self._dense_clean = True
         return self._loss if want_loss else None
 
     def prep_buffer(self, bt, out=None):

@@ -17,11 +17,16 @@ from .engine import ADAM_B1, ADAM_B2, ADAM_EPS, CdaeEngine, _round_up
 
 
 class CaserEngine:
-    def __init__(self, n_users, n_items, L=5, T=3, neg_ratio=3, d=50, n_v=4, n_h=16, device='cuda:0'):
+    ACTIVATIONS = {'relu': 0, 'tanh': 1, 'sigmoid': 2, 'linear': 3, None: 3}
+
+    def __init__(self, n_users, n_items, L=5, T=3, neg_ratio=3, d=50, n_v=4, n_h=16, device='cuda:0', act_h='relu', act_mlp='relu'):
         if not torch.cuda.is_available():
             raise _lib.DrxError('drecpy_amd needs a ROCm GPU (MI355X); there is no CPU fallback.')
         lib()
-        assert L <= 8 and d <= 64, 'Caser engine supports L <= 8 and d <= 64'
+        if not (1 <= L <= 8 and 1 <= d <= 64):
+            raise _lib.DrxError(f'Caser engine: 1 <= L <= 8 and 1 <= d <= 64 are supported (lane = embedding channel of one wavefront), got L={L}, d={d}')
+        if act_h not in self.ACTIVATIONS or act_mlp not in self.ACTIVATIONS:
+            raise _lib.DrxError(f'Caser engine: activations {sorted(k for k in self.ACTIVATIONS if k)} are supported, got act_h={act_h!r}, act_mlp={act_mlp!r}')
         self.device = torch.device(device)
         self.U, self.N, self.L, self.T, self.d, self.n_v, self.n_h = n_users, n_items, L, T, d, n_v, n_h
         self.Tp = T + T * neg_ratio
@@ -40,6 +45,7 @@ class CaserEngine:
         D.off_wd = off; self.seg.append(('dense0_k', off, self.nx * ld, True, 3 + L)); off += self.nx * ld
         D.off_bd = off; self.seg.append(('dense0_b', off, ld, False, 3 + L)); off += ld
         D.n_small = off
+        D.act_h, D.act_mlp = self.ACTIVATIONS[act_h], self.ACTIVATIONS[act_mlp]
         self.D = D
         self.n_layers = 6 + L
         z = dict(dtype=torch.float32, device=self.device)

@@ -40,6 +40,9 @@ enum {
 
 enum { DRX_LOSS_BCE = 0, DRX_LOSS_MSE = 1 };           /* cdae.py:30-31 */
 enum { DRX_TARGETS_REFERENCE = 0, DRX_TARGETS_PER_ROW = 1 };   /* (B,B,N) broadcast == batch-mean target, cdae.py:78-79 */
+/* or-ed into targets_kind of drx_cdae_step_dense: the batch-membership arrays inside `scratch` are known to be zero (zero-initialised
+ * scratch, or scratch last used by a COMPLETED dense step of the same batch size: consumers clear what they read) -> no memset */
+#define DRX_DENSE_AUX_CLEAN 0x100
 enum { DRX_OPT_ADAM = 0, DRX_OPT_ADAGRAD = 1,
        DRX_OPT_ROWWISE_ADAGRAD = 2   /* sampled mode only: ONE accumulator per table row, kept in the first float of the row's slot
                                         (s1[var][row * ld]): acc += mean_k(g^2), p -= lr * g / (sqrt(acc) + eps); b and b2 per element */ };
@@ -290,9 +293,11 @@ int drx_adam_segments(float *p, float *m, float *v, const float *g, const DrxAda
  * (one flat array, channel-fastest): conv_v kernel [L][n_v][ld] at off_kv + bias [n_v] at off_bv (caser.py:53);
  * convs_h[i] kernel [i+1][n_h][ld] at off_kh[i] + bias [n_h] at off_bh[i] (caser.py:55-58); dense_0 kernel
  * [n_v + L*n_h][ld] at off_wd + bias [ld] at off_bd (caser.py:63). */
+enum { DRX_ACT_RELU = 0, DRX_ACT_TANH = 1, DRX_ACT_SIGMOID = 2, DRX_ACT_LINEAR = 3 };
 typedef struct DrxCaserDims {
   int32_t L, T, Tp, d, ld, ld2, n_v, n_h, n_small;   /* Tp = T + T*neg_ratio targets per sample */
   int32_t off_kv, off_bv, off_kh[8], off_bh[8], off_wd, off_bd;
+  int32_t act_h, act_mlp;   /* DRX_ACT_*: activation of the horizontal convolutions and of dense_0 (caser.py:29-30; default relu) */
 } DrxCaserDims;
 typedef struct DrxCaserArgs {
   const float *item_emb, *user_emb, *W1, *b1, *sw;

@@ -36,6 +36,12 @@ def init_params(rng, n_users, n_items, L=5, d=50, n_v=4, n_h=16, dtype=np.float3
     return p
 
 
+ACT = {'relu': (lambda v: np.maximum(v, 0), lambda v: (v > 0).astype(v.dtype)),
+       'tanh': (np.tanh, lambda v: 1 - np.tanh(v) ** 2),
+       'sigmoid': (co.sigmoid, lambda v: co.sigmoid(v) * (1 - co.sigmoid(v))),
+       'linear': (lambda v: v, lambda v: np.ones_like(v))}      # act_h / act_mlp (caser.py:29-30,57,63): value, derivative
+
+
 def layer_order(L):
     """registration order -> list of (layer, [param names])"""
     order = [('user_emb', ['user_emb']), ('item_emb', ['item_emb']), ('conv_v', ['conv_v_k', 'conv_v_b'])]
@@ -47,7 +53,7 @@ def layer_order(L):
 REGULARISED = lambda name: name.endswith('_k') or name in ('user_emb', 'item_emb', 'W1')
 
 
-def forward(p, uids, before, after, keep=None, rate=0.0):
+def forward(p, uids, before, after, keep=None, rate=0.0, act_h='relu', act_mlp='relu'):
     """Scores [B, T'] (pre-sigmoid) + cache.  keep: dropout keep mask [B, n_v + L*n_h] (bool) or None."""
     dt = p['item_emb'].dtype
     E = p['item_emb'][before]                     # [B, L, d]
@@ -57,7 +63,7 @@ def forward(p, uids, before, after, keep=None, rate=0.0):
     for i in range(L):
         k = p[f'conv_h{i}_k']                     # [i+1, d, n_h]
         c = np.stack([np.einsum('bsc,scf->bf', E[:, t:t + i + 1], k) for t in range(L - i)], axis=1) + p[f'conv_h{i}_b']
-        r = np.maximum(c, 0)                      # [B, L-i, n_h]
+        r = ACT[act_h][0](c)                      # [B, L-i, n_h]
         a = r.argmax(axis=1)                      # first maximum, like max-pool's gradient routing
         outs.append(np.take_along_axis(r, a[:, None, :], axis=1)[:, 0])
         arg.append(a)
@@ -68,21 +74,21 @@ def forward(p, uids, before, after, keep=None, rate=0.0):
     else:
         xd = x
     z0 = xd @ p['dense0_k'] + p['dense0_b']
-    z = np.maximum(z0, 0)
+    z = ACT[act_mlp][0](z0)
     cat = np.concatenate([z, p['user_emb'][uids]], axis=1)            # [B, 2d]
     w = p['W1'][after]                                                 # [B, T', 2d]
     scores = np.einsum('bk,bjk->bj', cat, w) + p['b1'][after][:, :, 0]
     return scores, dict(E=E, out_v=out_v, arg=arg, pre=pre, x=x, xd=xd, z0=z0, z=z, cat=cat, w=w)
 
 
-def loss_and_grads(p, uids, before, after, T, reg_rate, keep=None, rate=0.0):
+def loss_and_grads(p, uids, before, after, T, reg_rate, keep=None, rate=0.0, act_h='relu', act_mlp='relu'):
     dt = p['item_emb'].dtype
     B, Tp = after.shape
     L = before.shape[1]
     d = p['item_emb'].shape[1]
     n_v = p['conv_v_k'].shape[2]
     n_h = p['conv_h0_k'].shape[2]
-    scores, c = forward(p, uids, before, after, keep, rate)
+    scores, c = forward(p, uids, before, after, keep, rate, act_h, act_mlp)
     pred = co.sigmoid(scores)
     y = np.zeros((B, Tp), dt); y[:, :T] = 1
     lval = co.bce_elem(y, pred, dt).mean(axis=-1).mean()
@@ -93,7 +99,7 @@ def loss_and_grads(p, uids, before, after, T, reg_rate, keep=None, rate=0.0):
     np.add.at(g['W1'], after, ds[:, :, None] * c['cat'][:, None, :])
     dcat = np.einsum('bj,bjk->bk', ds, c['w'])
     np.add.at(g['user_emb'], uids, dcat[:, d:])
-    dz0 = dcat[:, :d] * (c['z0'] > 0)
+    dz0 = dcat[:, :d] * ACT[act_mlp][1](c['z0'])
     g['dense0_k'] = c['xd'].T @ dz0
     g['dense0_b'] = dz0.sum(axis=0)
     dxd = dz0 @ p['dense0_k'].T
@@ -108,7 +114,7 @@ def loss_and_grads(p, uids, before, after, T, reg_rate, keep=None, rate=0.0):
         do = dx[:, n_v + i * n_h:n_v + (i + 1) * n_h]                  # [B, n_h]
         a = c['arg'][i]                                                # [B, n_h] argmax time step
         pre = np.take_along_axis(c['pre'][i], a[:, None, :], axis=1)[:, 0]
-        dc = do * (pre > 0)                                            # through relu at the arg-max position
+        dc = do * ACT[act_h][1](pre)                                   # through act_h at the arg-max position
         k = p[f'conv_h{i}_k']
         g[f'conv_h{i}_b'] = dc.sum(axis=0)
         for b in range(B):
@@ -130,10 +136,10 @@ def adam_state(p):
     return {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in p.items()}
 
 
-def step(p, state, step_idx, uids, before, after, T, lr, reg_rate, keep=None, rate=0.0):
+def step(p, state, step_idx, uids, before, after, T, lr, reg_rate, keep=None, rate=0.0, act_h='relu', act_mlp='relu'):
     dt = p['item_emb'].dtype
     L = before.shape[1]
-    lval, g, _ = loss_and_grads(p, uids, before, after, T, reg_rate, keep, rate)
+    lval, g, _ = loss_and_grads(p, uids, before, after, T, reg_rate, keep, rate, act_h, act_mlp)
     order = layer_order(L)
     for j, (_, names) in enumerate(order):
         a = dt.type(co.adam_alpha(lr, len(order) * step_idx + j + 1))

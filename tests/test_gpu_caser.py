@@ -120,3 +120,38 @@ def test_caser_counter_based_dropout_mask_matches_oracle():
     g = eng.get_params()
     for k in p:
         np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('act_h,act_mlp', [('tanh', 'sigmoid'), ('sigmoid', 'linear'), ('linear', 'tanh')])
+def test_caser_activations_match_oracle(act_h, act_mlp):
+    """act_h / act_mlp of caser.py:29-30 beyond the relu default."""
+    from drecpy_amd.engine_caser import CaserEngine
+    rng = np.random.default_rng(len(act_h) * 31 + len(act_mlp))
+    U, N, L, T, neg, d, n_v, n_h, B = 25, 60, 4, 2, 2, 20, 3, 8, 41
+    p = ca.init_params(rng, U, N, L, d, n_v, n_h, np.float64)
+    for k in p:
+        if k.endswith('_b'):
+            p[k] = rng.normal(0, 0.1, size=p[k].shape)
+    eng = CaserEngine(U, N, L, T, neg, d, n_v, n_h, act_h=act_h, act_mlp=act_mlp)
+    eng.set_params(p)
+    eng.lr, eng.reg = 5e-3, 1e-4
+    st = ca.adam_state(p)
+    nx = n_v + L * n_h
+    for step in range(4):
+        uids = rng.integers(0, U, size=B)
+        before = rng.integers(0, N, size=(B, L))
+        after = rng.integers(0, N, size=(B, T + T * neg))
+        keep = rng.random((B, nx)) >= 0.3
+        lo = ca.step(p, st, step, uids, before, after, T, 5e-3, 1e-4, keep, 0.3, act_h, act_mlp)
+        lg = eng.step(step, uids, before, after, keep, 0.3, want_loss=True)
+        assert abs(lg - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
+    from drecpy_amd.Recommender import Caser, DMF
+    with pytest.raises(Exception, match='supports the activations'):
+        Caser(act_h='gelu')
+    with pytest.raises(Exception, match='1 <= L <= 8'):
+        Caser(d=128)
+    with pytest.raises(Exception, match='towers of 1..4 layers of width 1..64'):
+        DMF(user_factors=[128, 64], item_factors=[64])

@@ -225,8 +225,8 @@ def test_modified_dmf_fit_matches_oracle_end_to_end():
             self._register_trainable(Variable([1.]))
     with pytest.raises(NotImplementedError, match='does not update them'):
         Stray(user_factors=[16, 8], item_factors=[16, 8], seed=seed, verbose=False).fit(ds, epochs=1, batch_size=8)
-    with pytest.raises(Exception, match='supported'):
-        DMF(user_factors=[128, 64], item_factors=[64], verbose=False).fit(ds, epochs=1, batch_size=8)
+    with pytest.raises(Exception, match='supports towers of 1..4 layers of width 1..64'):
+        DMF(user_factors=[128, 64], item_factors=[64], verbose=False)
 
 
 def test_update_weights_applies_keras_adam_on_the_device():

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 from oracle import caser_oracle as ca
 
 
-def _caser_torch(p, uids, before, after, T, reg, keep, rate):
+def _caser_torch(p, uids, before, after, T, reg, keep, rate, act_h=torch.relu, act_mlp=torch.relu):
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
     B, L = before.shape
     E = tp['item_emb'][torch.as_tensor(before)]                                  # [B,L,d]
@@ -15,12 +15,12 @@ def _caser_torch(p, uids, before, after, T, reg, keep, rate):
     out_v = F.conv1d(x, tp['conv_v_k'].permute(2, 1, 0), tp['conv_v_b']).reshape(B, -1)
     outs = []
     for i in range(L):
-        c = torch.relu(F.conv1d(x, tp[f'conv_h{i}_k'].permute(2, 1, 0), tp[f'conv_h{i}_b']))   # [B,n_h,L-i]
+        c = act_h(F.conv1d(x, tp[f'conv_h{i}_k'].permute(2, 1, 0), tp[f'conv_h{i}_b']))   # [B,n_h,L-i]
         outs.append(c.max(dim=2).values)
     cat0 = torch.cat([out_v] + outs, dim=1)
     if keep is not None:
         cat0 = torch.where(torch.as_tensor(keep), cat0 / (1 - rate), torch.zeros_like(cat0))
-    z = torch.relu(cat0 @ tp['dense0_k'] + tp['dense0_b'])
+    z = act_mlp(cat0 @ tp['dense0_k'] + tp['dense0_b'])
     cat = torch.cat([z, tp['user_emb'][torch.as_tensor(uids)]], dim=1).unsqueeze(1)
     w = tp['W1'][torch.as_tensor(after)]
     b = tp['b1'][torch.as_tensor(after)]
@@ -53,6 +53,13 @@ def test_caser_grads_match_autograd():
         assert abs(lo - lt) < 1e-12
         for k in g:
             np.testing.assert_allclose(g[k], gt[k], rtol=1e-9, atol=1e-13, err_msg=k)
+    # act_h / act_mlp other than relu (caser.py:29-30): tanh convolutions, sigmoid dense_0; linear
+    for ah, am, th, tm in (('tanh', 'sigmoid', torch.tanh, torch.sigmoid), ('linear', 'tanh', lambda v: v, torch.tanh)):
+        lo, g, _ = ca.loss_and_grads(p, uids, before, after, T, 1e-3, keep, 0.5, ah, am)
+        lt, gt = _caser_torch(p, uids, before, after, T, 1e-3, keep, 0.5, th, tm)
+        assert abs(lo - lt) < 1e-12
+        for k in g:
+            np.testing.assert_allclose(g[k], gt[k], rtol=1e-9, atol=1e-13, err_msg=(ah, am, k))
 
 
 def test_dmf_grads_match_autograd():
