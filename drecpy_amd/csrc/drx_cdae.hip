@@ -1316,7 +1316,9 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
 #define CALL(G, J)                                                                                                   \
   {                                                                                                                  \
     const int gpb = kBlock / G;                                                                                      \
-    if (bt->B <= kFewRows)      /* the reference's own batch sizes: 1024 threads per batch row (32 groups split the history) */ \
+    /* a 256-thread workgroup keeps 4 * gpb history rows in flight per round: go wide when a row needs more than two rounds */ \
+    const bool wide_fwd = bt->B <= kFewRows && (int64_t)bt->n_touch_slots > (int64_t)bt->B * 8 * gpb;                \
+    if (wide_fwd)               /* few rows with long histories: 1024 threads per batch row (32 groups split the history) */ \
       hipLaunchKernelGGL((k_hidden_fwd_wg<G, J, 1, 1024>), dim3(bt->B), dim3(1024), (size_t)(1024 / G) * p->ld * 4, st, *p, *hist, \
                          *bt, scale, qthr, L.h, aux);                                                                \
     else if (bt->B <= kSmallBatch)                                                                                   \
@@ -1344,7 +1346,7 @@ int drx_cdae_step_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHi
                                   (int)L.lds_bytes));                                                                \
       hipLaunchKernelGGL((k_out_dense<G, J, false>), dim3(L.out_grid), dim3(kBlock), L.lds_bytes, st, *p, *opt, A);  \
     }                                                                                                                \
-    if (bt->B <= kFewRows)                                                                                           \
+    if (bt->B <= kFewRows && L.out_grid > 16 * gpb)          /* many partial slabs per row: 1024 threads fold them */      \
       hipLaunchKernelGGL((k_hidden_bwd<G, J, 1024>), dim3(bt->B), dim3(1024), (size_t)(1024 / G) * p->ld * 4, st, p->ld, bt->B, \
                          L.out_grid, L.dh_slab, L.h, L.dz1);                                                         \
     else                                                                                                             \
