@@ -4,13 +4,15 @@
 
 A "step" is one pass of the hot path over one batch of B (u, i, y) triples per GPU: gather + hidden layer + sampled
 output unit + BCE + backward + sparse-Adagrad update (drx_cdae_step_sparse_prepared).  At 1 GPU every step trains on a
-FRESH batch drawn by the device PointSampler (drx_point_sample) two steps ahead on a side stream, and the batch's sorted
-touch list (drx_cdae_sparse_prepare) is built one step ahead on the same side stream — both depend only on the data,
+FRESH batch drawn by the device PointSampler (drx_point_sample) four steps ahead on a side stream, and the batch's sorted
+touch list (drx_cdae_sparse_prepare) is built two steps ahead on the same side stream — both depend only on the data,
 never on the parameters — so the timed region is the whole training loop including sampling (`--presampled` cycles
-through batches sampled at setup instead: +2.5 %).  All inputs live in HBM; nothing crosses PCIe in the timed region
-except one 4-byte touch count per step.  One process per GPU; for N > 1 launch with
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RCCL over xGMI, user-sharded tables,
-pre-sampled batches).
+through batches sampled at setup instead).  All inputs live in HBM; nothing crosses PCIe in the timed region except the
+8-byte touch count the sampler posts to a pinned mailbox per step.  One process per GPU; for N > 1 launch with
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RCCL over xGMI).  The N-GPU layout is chosen with
+`--layout`: `columns` (default: every rank holds all rows x K/N columns of every table and trains on the same global batch of
+N x B triples — one all-reduce of B floats per step) or `rows` (the partitioning BASELINE.json describes: users and item rows
+sharded by range, rows and gradient rows travel by all-to-all(v)); `config.sharding` in the output says which one ran.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline / hr_at_10).
 """
