@@ -77,21 +77,23 @@ class DMF(RecommenderABC):
 
     def _sample_batch(self, batch_size, **kwds):                          # dmf.py:64-73
         u, i, v, _ = self._sampler.sample_arrays(batch_size)
-        y = self._standardize_value(v) if self.use_nce else v
-        return u, i, np.asarray(y, dtype=np.float32)
+        y = np.asarray(self._standardize_value(v) if self.use_nce else v, dtype=np.float32)
+        # (u, i, y) plus the engine's host-side preparation of the batch (distinct users / items): this hook runs on fit()'s
+        # sampler thread while the previous batch trains
+        return u, i, y, self._engine.prepare_batch(u, i, y)
 
     def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
-        u, i, y = batch_samples
         e = self._engine
+        prep = batch_samples[3] if len(batch_samples) > 3 else e.prepare_batch(*batch_samples[:3])
         # one apply_gradients per registered item, in registration-list order (recommender_abc.py:194-196,328-334)
         applies = (len(self._apply_order()), self._apply_position(e.user_nn), self._apply_position(e.item_nn),
                    self._apply_position(e.scale_var) if e.scale_var is not None else None)
-        return e.step(step, u, i, y, want_loss=want_loss, applies=applies)
+        return e.step(step, prep, want_loss=want_loss, applies=applies)
 
     def _predict_batch(self, batch_samples, **kwds):
         """max(1e-6, cosine) of the batch pairs (dmf.py:88-96) as a device array [B] — WITHOUT any bound prediction scale: a
         subclass that registered one multiplies here itself, like the reference's ModifiedDMF._predict_batch."""
-        u, i, y = batch_samples
+        u, i, y = batch_samples[:3]
         with self._device_lock:
             return self._engine.predict(u, i, scaled=False), y
 

@@ -68,7 +68,8 @@ class DmfArgs(C.Structure):
                                           'i_values', 'uid', 'iid', 'y')] + [('target_mode', C.c_int32), ('y_mean', C.c_float)] + \
                [(n, C.c_void_p) for n in ('off_u', 'off_i')] + [('B', C.c_int32)] + \
                [(n, C.c_void_p) for n in ('dz0u', 'dz0i', 'tkeys_u', 'tsrc_u', 'tcoef_u', 'tkeys_i', 'tsrc_i', 'tcoef_i',
-                                          'gsw_part', 'loss_part', 'pred_out', 'rep_u_out', 'rep_i_out')]
+                                          'gsw_part', 'loss_part', 'pred_out', 'rep_u_out', 'rep_i_out', 'work', 'inv_u', 'inv_i',
+                                          'gptr_u', 'gptr_i', 'grows_u', 'grows_i')] + [('n_du', C.c_int32), ('n_di', C.c_int32)]
 
 
 class Optim(C.Structure):
@@ -142,6 +143,7 @@ SIGNATURES = {
     'drx_caser_fwd_bwd': (C.c_int, [C.POINTER(CaserDims), C.POINTER(CaserArgs), C.c_void_p, C.c_void_p]),
     'drx_caser_hidden': (C.c_int, [C.POINTER(CaserDims), C.POINTER(CaserArgs), C.c_void_p]),
     'drx_dmf_grid': (C.c_int, [C.c_int32]),
+    'drx_dmf_work_bytes': (C.c_size_t, [C.c_int32]),
     'drx_dmf_fwd_bwd': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p]),
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
     'drx_score_pairs_bf16': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -73,6 +73,53 @@ __device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const
   return acc;
 }
 
+// The same embedding bag with 16 lanes per kernel row (a float4 each): one load instruction of the wave fetches FOUR rows, one per
+// quarter-wave, so a non-zero costs a quarter of the loads and broadcasts of tower_gather.  Quarter r takes the non-zeros t with
+// t % 4 == r; the four partial sums are combined by two exchanges.  Writes this wave's partial pre-activations (column k at
+// out[k]) — the training path (k_dmf_gather).
+template <int WV>
+__device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out) {
+  const int id = T.ids[b];
+  const int64_t s = T.indptr[id], e = T.indptr[id + 1];
+  float q = 0.f;
+  for (int64_t j = s + k; j < e; j += 64) { const float v = T.values[j]; q = fmaf(v, v, q); }
+  q = group_sum<64>(q);
+  const float rho_in = D.l2_norm_vectors ? rsqrtf(fmaxf(q, kL2NEps)) : 1.0f;
+  const int r = k >> 4, c = k & 15;
+  const bool ok = 4 * c < T.ld0;
+  float4 acc = f4_zero();
+  const int base = T.off[b];
+  for (int64_t c0 = s + 64 * (int64_t)w; c0 < e; c0 += 64 * WV) {
+    const int64_t j = c0 + k;
+    int idx = 0;
+    float v = 0.f;
+    if (j < e) {
+      idx = T.indices[j];
+      v = T.values[j] * rho_in;
+      T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v;
+    }
+    const int n_here = (int)((e - c0) < 64 ? (e - c0) : 64);
+    for (int t = 0; t < n_here; t += 32) {
+      float4 rowv[8];
+      float vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int tt = t + 4 * u + r;
+        const int iu = __shfl(idx, tt & 63);
+        const float vs = __shfl(v, tt & 63);
+        const bool on = tt < n_here;
+        vv[u] = on ? vs : 0.f;
+        rowv[u] = (on && ok) ? *reinterpret_cast<const float4 *>(T.K0 + (size_t)iu * T.ld0 + 4 * c) : f4_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f4_fma(acc, vv[u], rowv[u]);
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+  if (r == 0) *reinterpret_cast<float4 *>(out + 4 * c) = acc;
+}
+
 // Dense layers of one tower from the summed first-layer pre-activation; returns the final activation of lane k.  z[l], a[l]
 // keep pre/post activations.
 __device__ __forceinline__ float tower_dense(const DrxDmfDims &D, int tw, const float *sw, int k, float acc,
@@ -187,6 +234,176 @@ __global__ __launch_bounds__(64 * WV) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
   }
 }
 
+// ---- training step in three kernels (r02) ------------------------------------------------------------------------------------
+// k_dmf<true> did everything for a sample inside one workgroup: its waves gathered the two sparse first layers together, then ONE of
+// them ran the dense layers, the loss and the whole backward while the others waited at the barrier, adding every small-weight
+// gradient into LDS accumulators on the way (0.47 ms at B = 4096; 84 % of the wave-cycles waiting).  The three phases want different
+// shapes, so they are kernels of their own:
+//   k_dmf_gather   memory-bound: the embedding bags of both towers, WV waves per sample -> z0[tw][b][64] (+ the scatter's touches)
+//   k_dmf_dense    ALU-bound: one wave per sample, small weights staged in LDS: dense layers, cosine, loss, backward; stores every
+//                  layer's activation and pre-activation gradient rows — no shared accumulators, no barrier between samples
+//   k_dmf_wgrad    the small-weight gradients as what they are, tiny products dW_l = A_{l-1}^T DZ_l (and column sums for the
+//                  biases), over fixed chunks of the batch in sample order -> partial rows for k_sum_partials2
+// work area (caller's, drx_dmf_work_bytes): z0 [2][B][64] | act [2][B][4][64] | dz [2][B][4][64] | samp [B][2] (loss, d scale)
+struct DmfWork {
+  float *z0, *act, *dz, *samp;
+};
+__host__ __device__ inline DmfWork dmf_work(float *base, int B) {
+  DmfWork W;
+  W.z0 = base;
+  W.act = W.z0 + (size_t)2 * B * 64;
+  W.dz = W.act + (size_t)2 * B * kDmfMaxLayers * 64;
+  W.samp = W.dz + (size_t)2 * B * kDmfMaxLayers * 64;
+  return W;
+}
+
+template <int WV>
+__global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs A) {
+  // one workgroup per DISTINCT user / item of the batch: the first layer of a tower depends on the id alone, and a batch of 4096
+  // pairs over 6040 users / 3706 items repeats ids a lot (popular items above all, whose columns are the long ones)
+  __shared__ __align__(16) float part[WV * 64];
+  const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const DmfWork Wk = dmf_work(A.work, A.B);
+  TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
+  TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
+  const int total = A.n_du + A.n_di;
+  for (int it = blockIdx.x; it < total; it += gridDim.x) {
+    const int tw = it < A.n_du ? 0 : 1, d = tw ? it - A.n_du : it;
+    if (tw) tower_gather_q<WV>(D, 1, Ti, d, k, w, part + w * 64); else tower_gather_q<WV>(D, 0, Tu, d, k, w, part + w * 64);
+    __syncthreads();
+    if (w == 0) {                                    // partials summed in wave order
+      float p = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) p += part[ww * 64 + k];
+      Wk.z0[((size_t)tw * A.B + d) * 64 + k] = p;
+    }
+    __syncthreads();
+  }
+}
+
+// dz0 of a distinct id = sum of the first-layer pre-activation gradients of the samples that carry it, in sample order (gptr / grows =
+// CSR of samples per distinct id): the scatter then runs over the touches of DISTINCT ids.
+__global__ __launch_bounds__(256) void k_dmf_dzsum(DrxDmfDims D, DrxDmfArgs A) {
+  const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const DmfWork Wk = dmf_work(A.work, A.B);
+  const int total = A.n_du + A.n_di;
+  for (int it = blockIdx.x * 4 + w; it < total; it += gridDim.x * 4) {
+    const int tw = it < A.n_du ? 0 : 1, d = tw ? it - A.n_du : it;
+    const int32_t *gp = tw ? A.gptr_i : A.gptr_u, *gr = tw ? A.grows_i : A.grows_u;
+    float acc = 0.f;
+    for (int q = gp[d]; q < gp[d + 1]; ++q) acc += Wk.dz[((size_t)tw * A.B + gr[q]) * kDmfMaxLayers * 64 + k];
+    const int ld0 = D.ld0[tw];
+    float *out = tw ? A.dz0i : A.dz0u;
+    if (k < ld0) out[(size_t)d * ld0 + k] = acc;
+  }
+}
+
+// Backward of one tower given da = dL/d(final activation) on lane k: stores dz_l rows (and leaves the activations stored by the
+// forward) for k_dmf_wgrad, the first layer's dz0 row for the scatter.
+__device__ __forceinline__ void tower_bwd_store(const DrxDmfDims &D, int tw, const TowerIO &T, const float *sw, float *dzrow /* [4][64] */,
+                                                int b, int k, const float (&zs)[kDmfMaxLayers], float da) {
+  const int nl = D.n_layers[tw];
+#pragma unroll
+  for (int l = kDmfMaxLayers - 1; l >= 1; --l) {
+    if (l >= nl) continue;
+    const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
+    const float dz = (k < fo && zs[l] > 0.f) ? da : 0.f;
+    dzrow[l * 64 + k] = dz;
+    float dprev = 0.f;
+    for (int kk = 0; kk < fo; ++kk) {                // da_{l-1}[j] = sum_k dz[k] * K[j][k] : lane j walks its kernel row
+      const float dzk = __shfl(dz, kk);
+      if (k < fin) dprev = fmaf(dzk, sw[D.off_k[tw][l] + k * fo + kk], dprev);
+    }
+    da = dprev;
+  }
+  const int f0 = D.f[tw][0];
+  const float dz0 = (k < f0 && zs[0] > 0.f) ? da : 0.f;
+  dzrow[k] = dz0;                                   // (zero beyond f0; k_dmf_dzsum folds these rows per distinct id)
+  (void)T; (void)b;
+}
+
+__global__ __launch_bounds__(256) void k_dmf_dense(DrxDmfDims D, DrxDmfArgs A) {
+  extern __shared__ __align__(16) float swl[];       // [n_small] the small weights
+  const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < D.n_small; i += 256) swl[i] = A.sw[i];
+  __syncthreads();
+  const DmfWork Wk = dmf_work(A.work, A.B);
+  TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
+  TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
+  const float inv_b = 1.0f / (float)A.B;
+  for (int b = blockIdx.x * 4 + w; b < A.B; b += gridDim.x * 4) {
+    const float pu = Wk.z0[((size_t)0 * A.B + A.inv_u[b]) * 64 + k], pi = Wk.z0[((size_t)1 * A.B + A.inv_i[b]) * 64 + k];
+    float zu[kDmfMaxLayers], au[kDmfMaxLayers], zi[kDmfMaxLayers], ai[kDmfMaxLayers];
+    const float ru = tower_dense(D, 0, swl, k, pu, zu, au);
+    const float ri = tower_dense(D, 1, swl, k, pi, zi, ai);
+    float *actu = Wk.act + ((size_t)0 * A.B + b) * kDmfMaxLayers * 64, *acti = Wk.act + ((size_t)1 * A.B + b) * kDmfMaxLayers * 64;
+#pragma unroll
+    for (int l = 0; l < kDmfMaxLayers; ++l) {
+      if (l < D.n_layers[0]) actu[l * 64 + k] = au[l];
+      if (l < D.n_layers[1]) acti[l * 64 + k] = ai[l];
+    }
+    const float qu = group_sum<64>(ru * ru), qi = group_sum<64>(ri * ri);
+    const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
+    const float nu = ru * rhou, ni = ri * rhoi;
+    const float s = group_sum<64>(nu * ni);
+    const float cosv = fmaxf(1e-6f, s);
+    const float wsc = D.off_scale >= 0 ? swl[D.off_scale] : 1.0f;
+    const float pred = wsc * cosv;
+    const float y = A.target_mode == 1 ? A.y_mean : A.y[b];
+    const float gp = bce_grad(y, pred) * inv_b;
+    if (k == 0) { Wk.samp[(size_t)b * 2] = bce_elem(y, pred); Wk.samp[(size_t)b * 2 + 1] = gp * cosv; }
+    const float ds = s > 1e-6f ? gp * wsc : 0.f;
+    const float dnu = ds * ni, dni = ds * nu;
+    const float du = group_sum<64>(nu * dnu), di = group_sum<64>(ni * dni);
+    const float dru = qu > kL2NEps ? rhou * (dnu - nu * du) : rhou * dnu;
+    const float dri = qi > kL2NEps ? rhoi * (dni - ni * di) : rhoi * dni;
+    tower_bwd_store(D, 0, Tu, swl, Wk.dz + ((size_t)0 * A.B + b) * kDmfMaxLayers * 64, b, k, zu, dru);
+    tower_bwd_store(D, 1, Ti, swl, Wk.dz + ((size_t)1 * A.B + b) * kDmfMaxLayers * 64, b, k, zi, dri);
+  }
+}
+
+// gsw_part[chunk][i] = sum over the chunk's samples (ascending b) of the gradient of small weight i:
+//   kernel element (tw, l >= 1, j, k): act[tw][b][l-1][j] * dz[tw][b][l][k];   bias (tw, l, k): dz[tw][b][l][k];   scale: samp[b][1]
+// loss_part[chunk] = sum of samp[b][0] / B.  One thread per small weight, blockIdx.y = chunk.
+__global__ __launch_bounds__(256) void k_dmf_wgrad(DrxDmfDims D, DrxDmfArgs A, int chunk) {
+  const DmfWork Wk = dmf_work(A.work, A.B);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * chunk, b1 = min(A.B, b0 + chunk);
+  if (i == D.n_small) {                              // the loss rides in the same launch
+    float t = 0.f;
+    for (int b = b0; b < b1; ++b) t += Wk.samp[(size_t)b * 2];
+    A.loss_part[blockIdx.y] = t / (float)A.B;
+    return;
+  }
+  if (i >= D.n_small) return;
+  const float *pa = nullptr, *pd = nullptr;          // per-sample strides of kDmfMaxLayers * 64 floats
+  bool is_scale = i == D.off_scale;
+  for (int tw = 0; tw < 2 && !pd && !is_scale; ++tw)
+    for (int l = 0; l < D.n_layers[tw]; ++l) {
+      const int fo = D.f[tw][l];
+      if (l >= 1) {
+        const int r = i - D.off_k[tw][l];
+        if (r >= 0 && r < D.f[tw][l - 1] * fo) {
+          pa = Wk.act + ((size_t)tw * A.B * kDmfMaxLayers + (l - 1)) * 64 + r / fo;
+          pd = Wk.dz + ((size_t)tw * A.B * kDmfMaxLayers + l) * 64 + r % fo;
+          break;
+        }
+      }
+      const int rb = i - D.off_b[tw][l];
+      if (rb >= 0 && rb < fo) { pd = Wk.dz + ((size_t)tw * A.B * kDmfMaxLayers + l) * 64 + rb; break; }
+    }
+  float g = 0.f;
+  const size_t stride = (size_t)kDmfMaxLayers * 64;
+  if (is_scale) {
+    for (int b = b0; b < b1; ++b) g += Wk.samp[(size_t)b * 2 + 1];
+  } else if (pd && pa) {
+    for (int b = b0; b < b1; ++b) g = fmaf(pa[b * stride], pd[b * stride], g);
+  } else if (pd) {
+    for (int b = b0; b < b1; ++b) g += pd[b * stride];
+  }
+  A.gsw_part[(size_t)blockIdx.y * D.n_small + i] = g;
+}
+
 // out[j] = sum_r part[r][j] for j < n, out[n] = sum_r tail[r]: 64 columns per workgroup, its 16 waves take every 16th row,
 // their partial sums are combined in wave order (fixed order of additions).
 __global__ __launch_bounds__(1024) void k_sum_partials2(const float *__restrict__ part, int n_rows, int n, const float *__restrict__ tail,
@@ -261,7 +478,13 @@ using namespace drx;
 
 extern "C" {
 
-int drx_dmf_grid(int32_t B) { return B < 1024 ? B : 1024; }
+// number of batch chunks of k_dmf_wgrad = rows of gsw_part / entries of loss_part the caller provides
+int drx_dmf_grid(int32_t B) { return B <= 64 ? 1 : (B + 63) / 64 < 64 ? (B + 63) / 64 : 64; }
+
+size_t drx_dmf_work_bytes(int32_t B) {
+  if (B < 1) return 0;
+  return ((size_t)2 * B * 64 + (size_t)4 * B * kDmfMaxLayers * 64 + (size_t)2 * B) * 4 + 256;
+}
 
 int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream) {
   int rc = check_dims(D);
@@ -271,19 +494,26 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
       !A->tsrc_u || !A->tcoef_u || !A->tkeys_i || !A->tsrc_i || !A->tcoef_i || !A->gsw_part || !A->loss_part || !gsw_out ||
       A->B < 1 || (A->target_mode != 0 && A->target_mode != 1))
     return DRX_EINVAL;
+  if (!A->work) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = drx_dmf_grid(A->B);
-  const int wv = dmf_waves(A->B);
-  const size_t lds = ((size_t)D->n_small + 2 * wv * 64) * 4;
-#define LAUNCH(WV)                                                                                                        \
-  {                                                                                                                       \
-    if (lds > 48 * 1024)                                                                                                  \
-      DRX_HIP(hipFuncSetAttribute((const void *)k_dmf<true, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-    hipLaunchKernelGGL((k_dmf<true, WV>), dim3(grid), dim3(64 * WV), lds, st, *D, *A);                                    \
-  }
-  if (wv == 16) LAUNCH(16) else if (wv == 8) LAUNCH(8) else LAUNCH(4)
-#undef LAUNCH
-  hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
+  const int chunks = drx_dmf_grid(A->B);
+  const int chunk = (A->B + chunks - 1) / chunks;
+  if (!A->inv_u || !A->inv_i || !A->gptr_u || !A->gptr_i || !A->grows_u || !A->grows_i || A->n_du < 1 || A->n_di < 1 || A->n_du > A->B ||
+      A->n_di > A->B)
+    return DRX_EINVAL;
+  const int wv = dmf_waves(A->n_du + A->n_di);
+  const int items = A->n_du + A->n_di;
+  const int ggrid = items < 8192 ? items : 8192;
+  if (wv == 16) hipLaunchKernelGGL((k_dmf_gather<16>), dim3(ggrid), dim3(64 * 16), 0, st, *D, *A);
+  else if (wv == 8) hipLaunchKernelGGL((k_dmf_gather<8>), dim3(ggrid), dim3(64 * 8), 0, st, *D, *A);
+  else hipLaunchKernelGGL((k_dmf_gather<4>), dim3(ggrid), dim3(64 * 4), 0, st, *D, *A);
+  const size_t lds = (size_t)D->n_small * 4;
+  if (lds > 48 * 1024) DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int dgrid = (A->B + 3) / 4;
+  hipLaunchKernelGGL(k_dmf_dense, dim3(dgrid < 2048 ? dgrid : 2048), dim3(256), lds, st, *D, *A);
+  hipLaunchKernelGGL(k_dmf_dzsum, dim3((items + 3) / 4 < 2048 ? (items + 3) / 4 : 2048), dim3(256), 0, st, *D, *A);
+  hipLaunchKernelGGL(k_dmf_wgrad, dim3((D->n_small + 1 + 255) / 256, chunks), dim3(256), 0, st, *D, *A, chunk);
+  hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, chunks, D->n_small,
                      A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();
   return DRX_OK;

@@ -163,39 +163,56 @@ class DmfEngine:
         check(lib().drx_scatter_rows(ptr(keys), T, ptr(src), ptr(src_index), ptr(coef), None, ld, n_rows, ptr(out), None,
                                      ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
 
-    def _upload_batch(self, uids, iids, y):
-        """Host batch -> device in one asynchronous copy (_staging.StagedUpload): uid, iid, y and the touch offsets, which are
-        computed on the host from the CSR / CSC row pointers — no device round trip for the counts."""
+    @staticmethod
+    def _distinct(ids, indptr):
+        """Distinct ids of a batch (ascending), every sample's index among them, the samples per distinct id as a CSR (samples
+        ascending: the order of the gradient sums) and the touch offsets of the distinct ids."""
+        d, inv = np.unique(ids, return_inverse=True)
+        order = np.argsort(inv, kind='stable').astype(np.int32)
+        gptr = np.zeros(len(d) + 1, np.int32)
+        np.cumsum(np.bincount(inv, minlength=len(d)), out=gptr[1:])
+        off = np.zeros(len(d) + 1, np.int32)
+        np.cumsum(indptr[d + 1] - indptr[d], out=off[1:])
+        return d.astype(np.int32), inv.astype(np.int32), gptr, order, off
+
+    def prepare_batch(self, uids, iids, y):
+        """Host half of a step, free of device work (DMF.fit() runs it on the sampler's worker thread): the distinct users / items of
+        the batch and everything the kernels index them with, as one list of arrays for ONE asynchronous upload."""
         u64, i64 = np.asarray(uids, dtype=np.int64), np.asarray(iids, dtype=np.int64)
-        B = len(u64)
-        off_u, off_i = np.zeros(B + 1, np.int32), np.zeros(B + 1, np.int32)
-        np.cumsum(self._h_indptr[0][u64 + 1] - self._h_indptr[0][u64], out=off_u[1:])
-        np.cumsum(self._h_indptr[1][i64 + 1] - self._h_indptr[1][i64], out=off_i[1:])
+        du, inv_u, gptr_u, grows_u, off_u = self._distinct(u64, self._h_indptr[0])
+        di, inv_i, gptr_i, grows_i, off_i = self._distinct(i64, self._h_indptr[1])
+        y32 = np.ascontiguousarray(y, dtype=np.float32)
+        arrays = [du, di, y32, off_u, off_i, inv_u, inv_i, gptr_u, gptr_i, grows_u, grows_i]
+        return {'arrays': arrays, 'B': len(u64), 'Tu': int(off_u[-1]), 'Ti': int(off_i[-1]), 'y_mean': float(y32.astype(np.float64).mean())}
+
+    def _upload_batch(self, prepared):
+        """Host batch -> device in one asynchronous copy (_staging.StagedUpload)."""
         if getattr(self, '_stage', None) is None:
             from ._staging import StagedUpload
             self._stage = StagedUpload(self.device)
-        dev, views = self._stage([u64.astype(np.int32), i64.astype(np.int32), np.ascontiguousarray(y, dtype=np.float32), off_u, off_i])
-        return (dev, views), [v.data_ptr() for v in views], B, int(off_u[-1]), int(off_i[-1])
+        dev, views = self._stage(prepared['arrays'])
+        return (dev, views), [v.data_ptr() for v in views]
 
-    def step(self, step_idx, uids, iids, y, want_loss=False, applies=None):
-        """applies = (n, j_user, j_item, j_scale): number of apply_gradients calls per step and the positions of user_nn, item_nn
+    def step(self, step_idx, uids, iids=None, y=None, want_loss=False, applies=None):
+        """uids, iids, y: the batch (arrays or tensors) — or `uids` = what prepare_batch returned for it.
+        applies = (n, j_user, j_item, j_scale): number of apply_gradients calls per step and the positions of user_nn, item_nn
         and the prediction scale among them (the registration order, recommender_abc.py:194-196); default: the reference DMF's
         (2, 0, 1), or (3, 1, 2, 0) with a bound scale."""
         L_ = lib()
         z = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
-        if torch.is_tensor(uids) or torch.is_tensor(iids):
-            uid, iid = self._i32(uids), self._i32(iids)
-            yv = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(self.device) if not torch.is_tensor(y) else y.to(self.device, torch.float32)
-            B = uid.numel()
-            off_u, Tu = self._offsets(uid, self.csr[0])
-            off_i, Ti = self._offsets(iid, self.csc[0])
-            alive = (uid, iid, yv, off_u, off_i)
-            p_uid, p_iid, p_y, p_offu, p_offi = (t.data_ptr() for t in alive)
-        else:
-            alive, (p_uid, p_iid, p_y, p_offu, p_offi), B, Tu, Ti = self._upload_batch(uids, iids, y)
+        if not isinstance(uids, dict):
+            if torch.is_tensor(uids) or torch.is_tensor(iids) or torch.is_tensor(y):
+                c = lambda a: a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+                uids, iids, y = c(uids), c(iids), c(y)
+            uids = self.prepare_batch(uids, iids, y)
+        prep = uids
+        alive, ptrs = self._upload_batch(prep)
+        p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri = ptrs
+        B, Tu, Ti = prep['B'], prep['Tu'], prep['Ti']
+        n_du, n_di = len(prep['arrays'][0]), len(prep['arrays'][1])
         ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
-        dz0u, dz0i = torch.empty(B, ld0u, **z), torch.empty(B, ld0i, **z)
+        dz0u, dz0i = torch.empty(n_du, ld0u, **z), torch.empty(n_di, ld0i, **z)
         tk_u, ts_u, tc_u = torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **z)
         tk_i, ts_i, tc_i = torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **z)
         grid = L_.drx_dmf_grid(B)
@@ -205,15 +222,21 @@ class DmfEngine:
         A.K0u, A.K0i, A.sw = self.K0u.data_ptr(), self.K0i.data_ptr(), self.sw.data_ptr()
         A.u_indptr, A.u_indices, A.u_values = (t.data_ptr() for t in self.csr)
         A.i_indptr, A.i_indices, A.i_values = (t.data_ptr() for t in self.csc)
-        A.uid, A.iid, A.B = p_uid, p_iid, int(B)
+        A.uid, A.iid, A.B = p_du, p_di, int(B)
         A.y, A.off_u, A.off_i = p_y, p_offu, p_offi
+        A.inv_u, A.inv_i, A.gptr_u, A.gptr_i, A.grows_u, A.grows_i = p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri
+        A.n_du, A.n_di = n_du, n_di
         if self.broadcast_targets and self.scale_var is not None:
             A.target_mode = 1
-            A.y_mean = float(np.asarray(y, dtype=np.float64).mean()) if not torch.is_tensor(y) else float(y.double().mean().item())
+            A.y_mean = prep['y_mean']
         A.dz0u, A.dz0i = dz0u.data_ptr(), dz0i.data_ptr()
         A.tkeys_u, A.tsrc_u, A.tcoef_u = tk_u.data_ptr(), ts_u.data_ptr(), tc_u.data_ptr()
         A.tkeys_i, A.tsrc_i, A.tcoef_i = tk_i.data_ptr(), ts_i.data_ptr(), tc_i.data_ptr()
         A.gsw_part, A.loss_part = gpart.data_ptr(), lpart.data_ptr()
+        need = L_.drx_dmf_work_bytes(B)
+        if getattr(self, '_work', None) is None or self._work.numel() < need:
+            self._work = torch.empty(int(need) + 1024, dtype=torch.uint8, device=self.device)
+        A.work = self._work.data_ptr()
         reg_loss = None
         if want_loss:
             sq = (self.K0u ** 2).sum() + (self.K0i ** 2).sum()

@@ -357,8 +357,19 @@ typedef struct DrxDmfArgs {
   float *gsw_part, *loss_part;                  /* [drx_dmf_grid(B), n_small], [drx_dmf_grid(B)] */
   float *pred_out;           /* [B]      (drx_dmf_predict) max(1e-6, cosine) */
   float *rep_u_out, *rep_i_out;   /* [B, 64] (drx_dmf_predict, optional) l2-normalised tower outputs */
+  float *work;               /* drx_dmf_work_bytes(B) bytes (drx_dmf_fwd_bwd): per-id first-layer sums, per-sample activations and
+                              * pre-activation gradients handed from the gather kernel to the dense one and to the weight-gradient one */
+  /* drx_dmf_fwd_bwd works on the DISTINCT users / items of the batch (a tower's first layer depends on the id alone): there
+   * uid [n_du] / iid [n_di] hold the distinct ids, off_u [n_du+1] / off_i [n_di+1] their touch offsets, dz0u [n_du, ld0] / dz0i
+   * [n_di, ld0] and the touches' sample field refer to distinct ids, and
+   *   inv_u / inv_i [B]        : index of sample b's user / item among the distinct ones
+   *   gptr_* [n_d+1], grows_* [B] : CSR of the samples per distinct id, samples ascending (order of the gradient sums)
+   * (drx_dmf_predict takes uid / iid per pair as before and ignores these) */
+  const int32_t *inv_u, *inv_i, *gptr_u, *gptr_i, *grows_u, *grows_i;
+  int32_t n_du, n_di;
 } DrxDmfArgs;
-int drx_dmf_grid(int32_t B);
+int drx_dmf_grid(int32_t B);      /* rows of gsw_part / entries of loss_part */
+size_t drx_dmf_work_bytes(int32_t B);
 /* forward + Keras BCE + backward (dmf.py:88-99 under the tape): dz0 rows + touches for drx_scatter_rows,
  * gsw_out[0..n_small) small-weight gradients, gsw_out[n_small] = prediction loss */
 int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream);

