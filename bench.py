@@ -4,8 +4,8 @@
 
 A "step" is one pass of the hot path over one batch of B (u, i, y) triples per GPU: gather + hidden layer + sampled
 output unit + BCE + backward + sparse-Adagrad update (drx_cdae_step_sparse_prepared).  At 1 GPU every step trains on a
-FRESH batch drawn by the device PointSampler (drx_point_sample) four steps ahead on a side stream, and the batch's sorted
-touch list (drx_cdae_sparse_prepare) is built two steps ahead on the same side stream — both depend only on the data,
+FRESH batch drawn by the device PointSampler (drx_point_sample) five steps ahead on a side stream, and the batch's sorted
+touch list (drx_cdae_sparse_prepare) is built three steps ahead on the same side stream — both depend only on the data,
 never on the parameters — so the timed region is the whole training loop including sampling (`--presampled` cycles
 through batches sampled at setup instead).  All inputs live in HBM; nothing crosses PCIe in the timed region except the
 8-byte touch count the sampler posts to a pinned mailbox per step.  One process per GPU; for N > 1 launch with
@@ -504,7 +504,7 @@ def main():
     if fresh:
         from drecpy_amd.engine import SampledPipeline
         spipe = SampledPipeline(eng, B, NEG_RATIO, Q, lambda s: 5000 + 7919 * s + 104729 * rank,
-                                lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N, prep_ahead=int(os.environ.get('DRX_PREP_AHEAD', 2)))
+                                lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N, prep_ahead=int(os.environ.get('DRX_PREP_AHEAD', 3)))
 
     def batch_of(s):
         return structs[s % len(structs)][0]

@@ -565,13 +565,13 @@ class SampledPipeline:
     `CDAE.fit(mode='sampled', device_sampler=True)` and by bench.py — the same code path.
 
     sample_seed_of(s) / mask_seed_of(s): seeds of step s's triple draw and of its corruption mask.
-    prep_ahead: how many steps ahead the touch list is prepared.  2 by default: the preparation shares the chip with the training
+    prep_ahead: how many steps ahead the touch list is prepared.  3 by default: the preparation shares the chip with the training
     kernels and then takes about as long as a step, so with one step of lead the training stream sometimes waited for it (measured at
-    B = 65 536: 141 / 148 / 151 M triples/s at 1 / 2 / 3); more when preparing takes longer than a step, as when the ranks of a
+    B = 65 536: 141 / 148 / 151 / 150 M triples/s at 1 / 2 / 3 / 4); more when preparing takes longer than a step, as when the ranks of a
     column-sharded job take turns preparing the list for all — dist.ColumnShardedCdae."""
 
     def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None,
-                 prepare_fn=None, prep_ahead=2, deliver_fn=None):
+                 prepare_fn=None, prep_ahead=3, deliver_fn=None):
         self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
         # step_fn(s, bt, prepared, events, want_loss): what trains on a prepared batch (default: this engine's sparse step;
         # dist.ColumnShardedCdae.step for the column-sharded multi-GPU layout)

@@ -166,14 +166,20 @@ class DmfEngine:
     @staticmethod
     def _distinct(ids, indptr):
         """Distinct ids of a batch (ascending), every sample's index among them, the samples per distinct id as a CSR (samples
-        ascending: the order of the gradient sums) and the touch offsets of the distinct ids."""
-        d, inv = np.unique(ids, return_inverse=True)
-        order = np.argsort(inv, kind='stable').astype(np.int32)
+        ascending: the order of the gradient sums) and the touch offsets of the distinct ids.  Counting instead of np.unique's sort
+        (ids are bounded by the table size): 0.10 ms instead of 0.46 ms per 4096 ids — this runs once per tower and step."""
+        n = len(indptr) - 1
+        cnt = np.bincount(ids, minlength=n)
+        d = np.flatnonzero(cnt)
+        rank = np.zeros(n, np.int32)
+        rank[d] = np.arange(len(d), dtype=np.int32)
+        inv = rank[ids]
+        order = np.argsort(inv.astype(np.uint16) if len(d) < 65536 else inv, kind='stable').astype(np.int32)     # (16-bit keys: radix sort)
         gptr = np.zeros(len(d) + 1, np.int32)
-        np.cumsum(np.bincount(inv, minlength=len(d)), out=gptr[1:])
+        np.cumsum(cnt[d], out=gptr[1:])
         off = np.zeros(len(d) + 1, np.int32)
         np.cumsum(indptr[d + 1] - indptr[d], out=off[1:])
-        return d.astype(np.int32), inv.astype(np.int32), gptr, order, off
+        return d.astype(np.int32), inv, gptr, order, off
 
     def prepare_batch(self, uids, iids, y):
         """Host half of a step, free of device work (DMF.fit() runs it on the sampler's worker thread): the distinct users / items of
