@@ -147,7 +147,7 @@ SIGNATURES = {
     'drx_dmf_fwd_bwd': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p]),
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
     'drx_score_pairs_bf16': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                       C.c_void_p]),
+                                       C.c_int32, C.c_void_p]),
     'drx_topk_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(1024) void k_sum_partials2(const float *__restrict_
 }
 
 // ---- bf16 MFMA all-pairs cosine scorer: out[u, n] = max(1e-6, ru[u] . ri[n]) for l2-normalised fp32 rows of width 32 -------
-// One wave per 32x32 tile, two v_mfma_f32_32x32x16_bf16 (K = 32).  A = users (row r = lane & 31, k = 8*(lane >> 5) + j),
+// v_mfma_f32_32x32x16_bf16 per 32x32 quarter and 16 k (K = 32: two of them).  A = users (row r = lane & 31, k = 8*(lane >> 5) + j),
 // B = items (col r, same k); C/D: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -435,28 +435,58 @@ __device__ __forceinline__ short f2bf(float x) {
   return (short)((c.u + 0x7FFFu + ((c.u >> 16) & 1u)) >> 16);      // round-to-nearest-even (inputs are finite, |x| <= 1)
 }
 
-__global__ __launch_bounds__(64) void k_score_pairs_bf16(const float *__restrict__ ru, int n_u, const float *__restrict__ ri, int n_i,
-                                                         int ld, int kdim, const float *__restrict__ scale, float *__restrict__ out) {
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-  const int u0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+// Workgroup = 4 waves = a 64 x 64 tile of scores (each wave a 32 x 32 quarter).  The two operand tiles are converted to bf16 ONCE,
+// by all 256 threads with coalesced 32-byte reads, and staged in LDS (rows padded by 8 bf16: 16-byte fragments, no two of a wave's rows
+// on the same bank group); every wave then takes its A / B fragments as one 16-byte LDS read per k-step.
+__global__ __launch_bounds__(256) void k_score_pairs_bf16(const float *__restrict__ ru, int n_u, const float *__restrict__ ri, int n_i,
+                                                          int ld, int kdim, const float *__restrict__ scale, float *__restrict__ out,
+                                                          int out_ld) {
+  constexpr int T = 64, KMAX = 64, LDSK = KMAX + 8;
+  __shared__ __align__(16) short As[T * LDSK], Bs[T * LDSK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int u0 = blockIdx.y * T, i0 = blockIdx.x * T;
   const float wsc = scale ? *scale : 1.0f;
+  // stage: thread t converts 16 consecutive k of row (t >> 2) [quarter t & 3 of a 64-wide row], for A and for B
+  {
+    const int row = tid >> 2, k0 = (tid & 3) * 16;
+    if (k0 < kdim) {
+      float4 fa[4], fb[4];                           // 16 consecutive floats of the row as four 16-byte loads (ld % 4 == 0)
+      const float4 *pa = reinterpret_cast<const float4 *>(ru + (size_t)(u0 + row) * ld + k0);
+      const float4 *pb = reinterpret_cast<const float4 *>(ri + (size_t)(i0 + row) * ld + k0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fa[j] = (u0 + row < n_u) ? pa[j] : f4_zero();
+        fb[j] = (i0 + row < n_i) ? pb[j] : f4_zero();
+      }
+      bf16x8 a0, a1, b0, b1;
+      a0[0] = f2bf(fa[0].x); a0[1] = f2bf(fa[0].y); a0[2] = f2bf(fa[0].z); a0[3] = f2bf(fa[0].w);
+      a0[4] = f2bf(fa[1].x); a0[5] = f2bf(fa[1].y); a0[6] = f2bf(fa[1].z); a0[7] = f2bf(fa[1].w);
+      a1[0] = f2bf(fa[2].x); a1[1] = f2bf(fa[2].y); a1[2] = f2bf(fa[2].z); a1[3] = f2bf(fa[2].w);
+      a1[4] = f2bf(fa[3].x); a1[5] = f2bf(fa[3].y); a1[6] = f2bf(fa[3].z); a1[7] = f2bf(fa[3].w);
+      b0[0] = f2bf(fb[0].x); b0[1] = f2bf(fb[0].y); b0[2] = f2bf(fb[0].z); b0[3] = f2bf(fb[0].w);
+      b0[4] = f2bf(fb[1].x); b0[5] = f2bf(fb[1].y); b0[6] = f2bf(fb[1].z); b0[7] = f2bf(fb[1].w);
+      b1[0] = f2bf(fb[2].x); b1[1] = f2bf(fb[2].y); b1[2] = f2bf(fb[2].z); b1[3] = f2bf(fb[2].w);
+      b1[4] = f2bf(fb[3].x); b1[5] = f2bf(fb[3].y); b1[6] = f2bf(fb[3].z); b1[7] = f2bf(fb[3].w);
+      *reinterpret_cast<bf16x8 *>(&As[row * LDSK + k0]) = a0;
+      *reinterpret_cast<bf16x8 *>(&As[row * LDSK + k0 + 8]) = a1;
+      *reinterpret_cast<bf16x8 *>(&Bs[row * LDSK + k0]) = b0;
+      *reinterpret_cast<bf16x8 *>(&Bs[row * LDSK + k0 + 8]) = b1;
+    }
+  }
+  __syncthreads();
+  const int wu = (w >> 1) * 32, wi = (w & 1) * 32;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   for (int ks = 0; ks < kdim / 16; ++ks) {
-    bf16x8 a, bb;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kk = ks * 16 + 8 * h + j;
-      a[j] = (u0 + r < n_u) ? f2bf(ru[(size_t)(u0 + r) * ld + kk]) : (short)0;
-      bb[j] = (i0 + r < n_i) ? f2bf(ri[(size_t)(i0 + r) * ld + kk]) : (short)0;
-    }
+    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[(wu + r) * LDSK + ks * 16 + 8 * h]);
+    const bf16x8 bb = *reinterpret_cast<const bf16x8 *>(&Bs[(wi + r) * LDSK + ks * 16 + 8 * h]);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc, 0, 0, 0);
   }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    if (u0 + row < n_u && i0 + r < n_i) out[(size_t)(u0 + row) * n_i + i0 + r] = wsc * fmaxf(1e-6f, acc[reg]);
+    if (u0 + wu + row < n_u && i0 + wi + r < n_i) out[(size_t)(u0 + wu + row) * out_ld + i0 + wi + r] = wsc * fmaxf(1e-6f, acc[reg]);
   }
 }
 
@@ -535,10 +565,12 @@ int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream) {
 }
 
 int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim, const float *scale,
-                         float *out, void *stream) {
-  if (!ru || !ri || !out || n_u < 1 || n_i < 1 || kdim < 16 || (kdim & 15) || ld < kdim) return DRX_EINVAL;
-  hipLaunchKernelGGL(k_score_pairs_bf16, dim3((n_i + 31) / 32, (n_u + 31) / 32), dim3(64), 0, (hipStream_t)stream, ru, n_u, ri, n_i,
-                     ld, kdim, scale, out);
+                         float *out, int32_t out_ld, void *stream) {
+  if (!ru || !ri || !out || n_u < 1 || n_i < 1 || kdim < 16 || (kdim & 15) || kdim > 64 || ld < kdim || (ld & 3) || out_ld < n_i ||
+      (((uintptr_t)ru | (uintptr_t)ri) & 15))
+    return DRX_EINVAL;
+  hipLaunchKernelGGL(k_score_pairs_bf16, dim3((n_i + 63) / 64, (n_u + 63) / 64), dim3(256), 0, (hipStream_t)stream, ru, n_u, ri, n_i,
+                     ld, kdim, scale, out, out_ld);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

@@ -306,9 +306,10 @@ class DmfEngine:
         all_items = torch.arange(self.N, dtype=torch.int32, device=self.device)
         _, _, ri = self.predict(torch.zeros(self.N, dtype=torch.int32, device=self.device), all_items, want_reps=True)
         _, ru, _ = self.predict(uid, torch.zeros(n_u, dtype=torch.int32, device=self.device), want_reps=True)
-        out = torch.empty(n_u, self.N, dtype=torch.float32, device=self.device)
+        pitch = _round_up(self.N, 32)                  # rows of 128-byte lines: a line then belongs to ONE tile of the scorer
+        out = torch.empty(n_u, pitch, dtype=torch.float32, device=self.device)
         kdim = _round_up(self.factors[0][-1], 16)
         scale = ptr(self.sw[self._scale_slot:]) if self.scale_var is not None else None
-        check(lib().drx_score_pairs_bf16(ptr(ru), n_u, ptr(ri), self.N, 64, kdim, scale, ptr(out), stream_ptr(self.device)),
+        check(lib().drx_score_pairs_bf16(ptr(ru), n_u, ptr(ri), self.N, 64, kdim, scale, ptr(out), pitch, stream_ptr(self.device)),
               'drx_score_pairs_bf16')
-        return out
+        return out[:, :self.N]

@@ -378,7 +378,9 @@ int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream);
  * fp32 accumulation (v_mfma_f32_32x32x16_bf16); ru, ri = l2-normalised tower outputs, kdim % 16 == 0 (dmf.py:92-95
  * evaluated for a block of users against all items instead of one _predict per pair, recommender_abc.py:460). */
 int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t n_i, int32_t ld, int32_t kdim,
-                         const float *scale /* device scalar multiplying every score, or NULL */, float *out, void *stream);
+                         const float *scale /* device scalar multiplying every score, or NULL */,
+                         float *out, int32_t out_ld /* floats between rows of out (>= n_i; a multiple of 32 keeps every 128-byte
+                                                       line inside one 64 x 64 tile, i.e. one workgroup / one XCD) */, void *stream);
 
 /* ---- ranking (cdae.py:90-103, recommender_abc.py:454-461) --------------------------------
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with

@@ -76,7 +76,7 @@ def test_mfma_bf16_all_pairs_scorer():
     a[:, :32] = torch.randint(-4, 5, (70, 32), device='cuda').float()
     b[:, :32] = torch.randint(-4, 5, (45, 32), device='cuda').float()
     out = torch.empty(70, 45, device='cuda')
-    _lib.check(_lib.lib().drx_score_pairs_bf16(_lib.ptr(a), 70, _lib.ptr(b), 45, 64, 32, None, _lib.ptr(out), _lib.stream_ptr()), "score")
+    _lib.check(_lib.lib().drx_score_pairs_bf16(_lib.ptr(a), 70, _lib.ptr(b), 45, 64, 32, None, _lib.ptr(out), 45, _lib.stream_ptr()), "score")
     want = torch.clamp(a[:, :32] @ b[:, :32].t(), min=1e-6)
     assert torch.equal(out, want)
 
