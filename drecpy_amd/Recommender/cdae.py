@@ -18,6 +18,8 @@ from ..Sampler import PointSampler
 
 
 class CDAE(RecommenderABC):
+    fused_fit = True      # reference mode: fit() runs its quiet loop inside the library (_run_steps); False = always step by step
+
     def __init__(self, hidden_factors=50, corruption_level=0.2, loss='bce', mode='reference', loss_targets='reference',
                  sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', **kwds):
         super().__init__(**kwds)
@@ -303,6 +305,27 @@ class CDAE(RecommenderABC):
             pending.append(self._submit_draw(batch_size))
         self._pending = pending or None
         return batch
+
+    def _run_steps(self, first_step, n_steps, batch_size, **kwds):
+        """fit()'s quiet path in reference mode: the whole sample -> step loop of the remaining epochs in one library call
+        (drx_cdae_fit_dense), when these very hooks would have run — a subclass or an instance that replaces _sample_batch or
+        _do_batch gets the per-step loop.  Same streams, same arithmetic, same launches as that loop; returns the steps done."""
+        if (self.mode != 'reference' or getattr(self, '_dist_model', None) is not None or self._engine.device.type != 'cuda'
+                or not getattr(self, 'fused_fit', True) or n_steps < 1 or getattr(self, '_pending', None)):
+            return 0
+        for hook in ('_sample_batch', '_do_batch', '_reference_batch', '_submit_draw', '_finish_draw'):
+            if hook in self.__dict__ or getattr(type(self), hook) is not getattr(CDAE, hook):
+                return 0
+        B = int(batch_size)
+        cursor = np.array([self._draw_ticket, self._mask_pos, self._mask_at[0], self._mask_at[1]], dtype=np.int64)
+        try:
+            with self._device_lock:
+                self._engine.fit_dense(self._drawahead, cursor, B, self.corruption_level, max(B * self._max_degree, 1), first_step,
+                                       n_steps, self._loss_name, self.loss_targets)
+        finally:                                        # (what the call consumed of the streams, also when it raised)
+            self._draw_ticket, self._mask_pos = int(cursor[0]), int(cursor[1])
+            self._mask_at = [int(cursor[2]), int(cursor[3])]
+        return n_steps
 
     # ---- fused training step (replaces recommender_abc.py:190-204 for this model) ------------------------------------
     def _batch_arrays(self, batch_samples):

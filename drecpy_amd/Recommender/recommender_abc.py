@@ -198,7 +198,10 @@ class RecommenderABC(ABC):
         monitor.before_training()
         bar = self._progress_bar(epochs)
         epoch, ahead = 0, None
-        for epoch in (bar if bar is not None else range(1, epochs + 1)):
+        if not monitor.needs_loss and bar is None and self._file_logger is None:
+            # nothing observes single steps (no loss, callback, rule or log line per epoch): a model may run the loop natively
+            epoch = int(self._run_steps(0, epochs, batch_size, **kwds) or 0)
+        for epoch in (bar if bar is not None else range(epoch + 1, epochs + 1)):
             # The host work of the NEXT batch overlaps this batch's device step — never beyond the last epoch, so the sampler
             # streams end exactly where the reference's do.  Models whose _sample_batch is independent of _do_batch opt in with
             # `_host_prefetch` (the draw runs on a worker thread; ctypes calls release the GIL); CDAE handles `more_to_come`
@@ -264,6 +267,11 @@ class RecommenderABC(ABC):
     def _configure_optimizer(self):
         """Called once per fit() after _pre_fit and the `optimizer=` override: models push the registered optimizer's kind and
         hyper-parameters into their engine (and reject kinds their fused step does not implement)."""
+
+    def _run_steps(self, first_step, n_steps, batch_size, **kwds):
+        """Optional: run steps first_step .. first_step + n_steps - 1 of fit() without returning to this loop in between (called
+        only when nothing observes single steps).  Returns how many were done; the per-step loop does the rest."""
+        return 0
 
     def _fused_trainables(self):
         """The handles a model's fused _do_batch updates, or None when the model manages its variables itself."""

@@ -165,6 +165,10 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     'drx_drawahead_wait': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     'drx_drawahead_destroy': (None, [C.c_void_p]),
+    'drx_cdae_fit_slot_bytes': (C.c_size_t, [C.c_int32, C.c_int64]),
+    'drx_cdae_fit_dense': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_float, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_sampler_draw': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_sampler_destroy': (None, [C.c_void_p]),
     'drx_cdae_kshard_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,

@@ -173,11 +173,15 @@ class CdaeEngine:
         c = getattr(self, '_alpha_tab', None)
         base = step - step % self._ALPHA_CHUNK
         if c is None or c[0] != base or c[1] != self.lr:
-            f = np.float32
-            t = (5 * base + 1 + np.arange(5 * self._ALPHA_CHUNK)).astype(np.float32)
-            tab = f(self.lr) * np.sqrt(f(1.0) - np.power(f(self.beta2), t)) / (f(1.0) - np.power(f(self.beta1), t))
-            c = self._alpha_tab = (base, self.lr, tab.astype(np.float32).reshape(-1, 5).tolist())
+            c = self._alpha_tab = (base, self.lr, self._alpha_table(base, self._ALPHA_CHUNK).tolist())
         return c[2][step - base]
+
+    def _alpha_table(self, first_step, n_steps):
+        """float32 [n_steps, 5]: lr_t of dense steps first_step .. first_step + n_steps - 1."""
+        f = np.float32
+        t = (5 * first_step + 1 + np.arange(5 * n_steps)).astype(np.float32)
+        tab = f(self.lr) * np.sqrt(f(1.0) - np.power(f(self.beta2), t)) / (f(1.0) - np.power(f(self.beta1), t))
+        return np.ascontiguousarray(tab.astype(np.float32).reshape(-1, 5))
 
     # ---- batches ----------------------------------------------------------------------------
     def _dev(self, a, dtype):
@@ -347,6 +351,30 @@ class CdaeEngine:
             'drx_cdae_step_dense')
         self._dense_clean = True
         return self._loss if want_loss else None
+
+    _FIT_SLOTS = 16
+
+    def fit_dense(self, drawahead, cursor, B, q, keep_capacity, first_step, n_steps, loss='bce', targets='reference'):
+        """n_steps reference-mode iterations in ONE library call (drx_cdae_fit_dense): the draw-ahead workers of `drawahead` fill
+        pinned staging slots, the library queues the steps.  cursor: int64[4] numpy array (sampler ticket, corruption-stream
+        position, words consumed per generator), updated in place.  Returns when the steps have run."""
+        L = lib()
+        need = int(L.drx_cdae_fit_slot_bytes(B, int(keep_capacity)))
+        slots = getattr(self, '_fit_slots', None)
+        if slots is None or slots[0] < need:
+            slots = self._fit_slots = (need, torch.empty(need * self._FIT_SLOTS, dtype=torch.uint8, pin_memory=True),
+                                       torch.empty(2 * need, dtype=torch.uint8, device=self.device))
+        o = self._optim([0.0] * 5)
+        sc = self._ensure_dense_scratch(B)
+        alphas = self._alpha_table(first_step, n_steps)
+        self._dense_clean = False
+        check(L.drx_cdae_fit_dense(
+            C.byref(self._params), C.byref(o), C.byref(self._hist), drawahead, cursor.ctypes.data, B, float(q), int(keep_capacity),
+            _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE, _lib.TARGETS_REFERENCE if targets == 'reference' else _lib.TARGETS_PER_ROW,
+            n_steps, alphas.ctypes.data, slots[1].data_ptr(), slots[0], self._FIT_SLOTS, ptr(slots[2]), slots[2].numel(), ptr(sc),
+            sc.numel(), stream_ptr(self.device)),
+            'drx_cdae_fit_dense')
+        self._dense_clean = True
 
     def prep_buffer(self, bt, out=None):
         """A buffer large enough for the prepared touch list of `bt` (`out` itself when it is)."""

@@ -474,6 +474,31 @@ int64_t drx_drawahead_submit(DrxDrawAhead *d, int32_t gen, int64_t ticket, uint6
 int drx_drawahead_wait(DrxDrawAhead *d, int32_t gen, int64_t job);
 void drx_drawahead_destroy(DrxDrawAhead *d);
 
+/* ---- the quiet fit() loop of reference-mode CDAE in one call ------------------------------------------------------------------
+ * n_steps iterations of recommender_abc.py:189-205 for the case in which nothing observes single steps (verbose off, no early-
+ * stopping rule: no per-step loss, callback or log line): per step, wait for the drawn batch (draw-ahead workers above), queue
+ * drx_cdae_step_dense on `stream`, submit the draws of later steps — at most 4 in flight and never beyond the last step, so the
+ * sampler and corruption streams end exactly where the reference's do.  The Python loop does the same through _sample_batch /
+ * _do_batch at ~40 us of interpreter time per step, which exceeds the device time of the ml-100k-shaped step.
+ *   cursor[4] (in/out)  next sampler ticket, word of the corruption stream where the next batch begins, words consumed by
+ *                       generator 0 and 1 of `draws` (what the Python loop keeps in _draw_ticket / _mask_pos / _mask_at)
+ *   h_alphas            n_steps x 5 Keras-Adam lr_t, host memory (opt->alpha is ignored)
+ *   h_slots             n_slots (8..64) staging slots of slot_bytes >= drx_cdae_fit_slot_bytes(B, keep_capacity) each, pinned host
+ *                       memory addressable from the device (the step's kernels read the batch in place); keep_capacity >= the
+ *                       largest possible sum of the B history lengths
+ *   d_stage             device memory, d_stage_bytes >= 2 * slot_bytes, or NULL: the step of batch s copies what step s+1 reads of
+ *                       its slot there from the last workgroup of its parameter sweep, so that only the first batch of a call is
+ *                       read over PCIe by the gather kernel itself (NULL: every batch is)
+ *   scratch             dense-step scratch (drx_cdae_scratch_bytes(p, B, 0, 1)) whose batch-membership arrays are zero
+ *                       (DRX_DENSE_AUX_CLEAN is implied)
+ * Returns after the queued steps have completed (the slots are the caller's again).  On error the draws in flight are waited for
+ * and the cursor says what was consumed. */
+size_t drx_cdae_fit_slot_bytes(int32_t B, int64_t keep_capacity);
+int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, DrxDrawAhead *draws, int64_t *cursor,
+                       int32_t B, float q, int64_t keep_capacity, int32_t loss_kind, int32_t targets_kind, int64_t n_steps,
+                       const float *h_alphas, void *h_slots, size_t slot_bytes, int32_t n_slots, void *d_stage,
+                       size_t d_stage_bytes, void *scratch, size_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

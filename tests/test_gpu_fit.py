@@ -236,3 +236,47 @@ def test_second_fit_on_another_dataset_drops_the_first_ones_caches():
         got = m.rank(raw, [b.iid_to_item(i) for i in range(80)], novelty=True, n=80)
         seen = set(b.select(f'uid == {uid}').values_list('iid', to_list=True))
         assert {b.item_to_iid(i) for _, i in got} == set(range(80)) - seen       # the novelty mask is dataset b's
+
+
+@pytest.mark.parametrize('epochs', [1, 3, 57])
+def test_quiet_fit_in_the_library_equals_the_step_by_step_loop(epochs):
+    """fit() with nobody watching runs its loop inside libdrx (drx_cdae_fit_dense): bit-identical tables, and the sampler and
+    corruption streams left exactly where the Python loop leaves them (the next fit continues identically)."""
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    ds = InteractionDataset.read_df(_frame(), verbose=False)
+    w = co.init_params(np.random.default_rng(5), 64, 40, 24, np.float32)
+    out = []
+    for fused in (True, False):
+        m = CDAE(hidden_factors=24, corruption_level=0.3, seed=21, verbose=False)
+        m.fused_fit = fused
+        m.fit(ds, epochs=epochs, batch_size=16, learning_rate=2e-3, reg_rate=1e-3, neg_ratio=3, initial_weights=w)
+        state = (m._draw_ticket, m._mask_pos, list(m._mask_at))
+        nxt = m._sampler.sample(5)                      # where the sampler stream stands
+        keep = m._corruption_keep(np.array([1, 2, 3], np.int32))     # where the corruption stream stands
+        e = m._engine
+        out.append(([t.cpu().numpy().copy() for t in (e.W, e.W2T, e.V, e.b, e.b2)], state, nxt, [np.asarray(k).copy() for k in keep]))
+    (pa, sa, na, ka), (pb, sb, nb, kb) = out
+    assert sa[0] == sb[0] == epochs and sa[1] == sb[1]
+    assert na == nb and all(np.array_equal(x, y) for x, y in zip(ka, kb))
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x, y)
+
+
+def test_quiet_fit_is_left_to_python_when_a_hook_is_replaced():
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    ds = InteractionDataset.read_df(_frame(), verbose=False)
+    seen = []
+
+    class Watching(CDAE):
+        def _do_batch(self, batch_samples, step=0, **kwds):
+            seen.append(step)
+            return super()._do_batch(batch_samples, step=step, **kwds)
+    Watching(hidden_factors=8, seed=1, verbose=False).fit(ds, epochs=5, batch_size=8)
+    assert seen == [0, 1, 2, 3, 4]
+    m = CDAE(hidden_factors=8, seed=1, verbose=False)
+    orig = m._sample_batch
+    m._sample_batch = lambda *a, **k: (seen.append('s'), orig(*a, **k))[1]
+    m.fit(ds, epochs=2, batch_size=8)
+    assert seen[-2:] == ['s', 's']
