@@ -69,7 +69,13 @@ class DmfArgs(C.Structure):
                [(n, C.c_void_p) for n in ('off_u', 'off_i')] + [('B', C.c_int32)] + \
                [(n, C.c_void_p) for n in ('dz0u', 'dz0i', 'tkeys_u', 'tsrc_u', 'tcoef_u', 'tkeys_i', 'tsrc_i', 'tcoef_i',
                                           'gsw_part', 'loss_part', 'pred_out', 'rep_u_out', 'rep_i_out', 'work', 'inv_u', 'inv_i',
-                                          'gptr_u', 'gptr_i', 'grows_u', 'grows_i')] + [('n_du', C.c_int32), ('n_di', C.c_int32)]
+                                          'gptr_u', 'gptr_i', 'grows_u', 'grows_i')] + [('n_du', C.c_int32), ('n_di', C.c_int32)] + \
+               [(n, C.c_void_p) for n in ('map_u', 'map_i', 'rho_u', 'rho_i')] + [('stamp', C.c_uint32)]
+
+
+class DmfK0Update(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('K0u', 'm_u', 'v_u', 'K0i', 'm_i', 'v_i')] + [('n_items', C.c_int32), ('n_users', C.c_int32)] + \
+               [(n, C.c_float) for n in ('alpha_u', 'alpha_i', 'l2_coef', 'beta1', 'beta2', 'eps')]
 
 
 class Optim(C.Structure):
@@ -146,6 +152,8 @@ SIGNATURES = {
     'drx_dmf_work_bytes': (C.c_size_t, [C.c_int32]),
     'drx_dmf_fwd_bwd': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p]),
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
+    'drx_dmf_norms': (C.c_int, [C.POINTER(DmfDims), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'drx_dmf_k0_update': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.POINTER(DmfK0Update), C.c_void_p]),
     'drx_score_pairs_bf16': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_void_p]),
     'drx_topk_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -64,14 +64,6 @@ __device__ __forceinline__ float act_df(int kind, float v) {
   }
 }
 
-// Orders the LDS traffic of ONE wave (its private scratch is written by some lanes and read by others): every LDS operation of the
-// wave issued so far has completed.  A workgroup barrier is not needed for that and would tie unrelated samples together.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 // A workgroup is W waves, one sample per wave and round, sharing ONE set of small-weight gradient accumulators in LDS (72 KB at the
 // reference configuration: with a private copy per wave only two waves fit a CU and the chip idles — 0.74 ms at B = 4096).  Forward
 // and backward of the W samples run side by side in per-wave scratch; afterwards the waves add their weight-gradient contributions

@@ -98,6 +98,14 @@ inline Geom pick_geom(int ld) {
     else { CALL(64, 4); }                                  \
   } while (0)
 
+// Orders the LDS traffic of ONE wave (its private scratch is written by some lanes and read by others): every LDS operation of the
+// wave issued so far has completed.  A workgroup barrier is not needed for that and would tie unrelated waves together.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Bump allocator over the caller's scratch buffer.

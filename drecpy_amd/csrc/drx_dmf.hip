@@ -25,7 +25,24 @@ struct TowerIO {
   float *dz0;                 // [B, ld0]
   uint32_t *tkeys, *tsrc;     // [T] touches: first-layer row, sample
   float *tcoef;               // [T] normalised input value
+  const float *rho = nullptr; // [ids' range] l2 normaliser of every row / column, precomputed (drx_dmf_norms), or null
 };
+
+// 1 / |row|_2 of a sparse row as every kernel here forms it (lane partial sums, then a butterfly): one value per id of the dataset
+__device__ __forceinline__ float row_rho(const DrxDmfDims &D, const float *values, int64_t s, int64_t e, int k) {
+  float q = 0.f;
+  for (int64_t j = s + k; j < e; j += 64) { const float v = values[j]; q = fmaf(v, v, q); }
+  q = group_sum<64>(q);
+  return D.l2_norm_vectors ? rsqrtf(fmaxf(q, kL2NEps)) : 1.0f;
+}
+
+__global__ __launch_bounds__(256) void k_dmf_norms(DrxDmfDims D, const int64_t *indptr, const float *values, int n, float *out) {
+  const int k = threadIdx.x & 63;
+  for (int id = blockIdx.x * 4 + (threadIdx.x >> 6); id < n; id += gridDim.x * 4) {
+    const float rho = row_rho(D, values, indptr[id], indptr[id + 1], k);
+    if (k == 0) out[id] = rho;
+  }
+}
 
 // waves of a workgroup that share the sparse first layer of one sample (WV below): 16 for batches that cannot fill the chip
 // otherwise (one workgroup per sample, the gather of ~150-250 rows is the sample's critical path: 0.37 -> 0.29 ms per step at
@@ -78,17 +95,17 @@ __device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const
 // t % 4 == r; the four partial sums are combined by two exchanges.  Writes this wave's partial pre-activations (column k at
 // out[k]) — the training path (k_dmf_gather).
 template <int WV>
-__device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out) {
+__device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out,
+                                               float &rho_in) {
   const int id = T.ids[b];
   const int64_t s = T.indptr[id], e = T.indptr[id + 1];
-  float q = 0.f;
-  for (int64_t j = s + k; j < e; j += 64) { const float v = T.values[j]; q = fmaf(v, v, q); }
-  q = group_sum<64>(q);
-  const float rho_in = D.l2_norm_vectors ? rsqrtf(fmaxf(q, kL2NEps)) : 1.0f;
+  // (a popular item has thousands of non-zeros: forming the norm here, one load in flight per wave, was the kernel's tail)
+  rho_in = T.rho ? T.rho[id] : row_rho(D, T.values, s, e, k);
   const int r = k >> 4, c = k & 15;
   const bool ok = 4 * c < T.ld0;
   float4 acc = f4_zero();
-  const int base = T.off[b];
+  const bool touches = T.tkeys != nullptr;          // (the scan update of the first layer needs none: k_dmf_k0_update)
+  const int base = touches ? T.off[b] : 0;
   for (int64_t c0 = s + 64 * (int64_t)w; c0 < e; c0 += 64 * WV) {
     const int64_t j = c0 + k;
     int idx = 0;
@@ -96,7 +113,7 @@ __device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, cons
     if (j < e) {
       idx = T.indices[j];
       v = T.values[j] * rho_in;
-      T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v;
+      if (touches) { T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v; }
     }
     const int n_here = (int)((e - c0) < 64 ? (e - c0) : 64);
     for (int t = 0; t < n_here; t += 32) {
@@ -266,10 +283,16 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
   const DmfWork Wk = dmf_work(A.work, A.B);
   TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
+  Tu.rho = A.rho_u; Ti.rho = A.rho_i;
   const int total = A.n_du + A.n_di;
   for (int it = blockIdx.x; it < total; it += gridDim.x) {
     const int tw = it < A.n_du ? 0 : 1, d = tw ? it - A.n_du : it;
-    if (tw) tower_gather_q<WV>(D, 1, Ti, d, k, w, part + w * 64); else tower_gather_q<WV>(D, 0, Tu, d, k, w, part + w * 64);
+    float rho;
+    if (tw) tower_gather_q<WV>(D, 1, Ti, d, k, w, part + w * 64, rho); else tower_gather_q<WV>(D, 0, Tu, d, k, w, part + w * 64, rho);
+    if (A.map_u && threadIdx.x == 0) {               // for k_dmf_k0_update: which distinct index this id has in THIS step
+      const int id = tw ? A.iid[d] : A.uid[d];
+      (tw ? A.map_i : A.map_u)[id] = ((unsigned long long)A.stamp << 32) | (unsigned long long)(uint32_t)d;
+    }
     __syncthreads();
     if (w == 0) {                                    // partials summed in wave order
       float p = 0.f;
@@ -295,6 +318,116 @@ __global__ __launch_bounds__(256) void k_dmf_dzsum(DrxDmfDims D, DrxDmfArgs A) {
     const int ld0 = D.ld0[tw];
     float *out = tw ? A.dz0i : A.dz0u;
     if (k < ld0) out[(size_t)d * ld0 + k] = acc;
+  }
+}
+
+// First-layer kernels K0u [N, ld0] / K0i [U, ld0]: gradient + dense Keras Adam in ONE pass over the table, no touch list and no sort.
+//   dK0u[n] = sum over the batch's distinct users d that have item n in their row of  (value(d, n) * rho_d) * dz0u[d]
+// Row n's candidates are column n of the interaction matrix — the CSC the item tower reads anyway (for K0i: the CSR) — and a
+// candidate is in the batch iff map[id] carries this step's stamp (written by k_dmf_gather together with rho_d; the map is never
+// cleared).  Every step walks all nnz entries once (8 bytes each + an L2-resident map probe: 16 MB at ml-1m) instead of sorting the
+// ~40 k - 500 k touches of the batch twice and reducing them through a dense gradient arena; Adam's moments decay on every row of
+// these tables anyway (dense tf.Variable), so the update of a row rides in the same workgroup.
+// One workgroup per row: its 4 waves take every 4th block of 64 candidates; a wave compacts its hits in LDS and its quarter-waves
+// (16 lanes x float4 = one dz0 row) take every 4th hit; sums are combined quarter by quarter, wave by wave: a fixed order.
+struct K0Tables {
+  float *K0[2], *m[2], *v[2];
+  int rows[2];
+  float alpha[2];
+  float l2c, b1, b2, eps;
+};
+
+__global__ __launch_bounds__(256) void k_dmf_k0_update(DrxDmfDims D, DrxDmfArgs A, K0Tables U) {
+  __shared__ int hd[4][64];
+  __shared__ float hc[4][64];
+  __shared__ float4 part[4][16];
+  const int k = threadIdx.x & 63, w = threadIdx.x >> 6, r = k >> 4, c = k & 15;
+  const int row = blockIdx.x;
+  const int tw = row < U.rows[0] ? 0 : 1;
+  const int n = tw ? row - U.rows[0] : row;
+  const int ld0 = D.ld0[tw];
+  const int64_t *ip = tw ? A.u_indptr : A.i_indptr;
+  const int32_t *ix = tw ? A.u_indices : A.i_indices;
+  const float *vals = tw ? A.u_values : A.i_values;
+  const unsigned long long *map = tw ? A.map_i : A.map_u;
+  const float *rho = tw ? A.rho_i : A.rho_u;
+  const float *dz0 = tw ? A.dz0i : A.dz0u;
+  const bool col = 4 * c < ld0;
+  const bool upd = w == 0 && r == 0 && col;
+  float4 p = f4_zero(), m = f4_zero(), v = f4_zero();
+  const size_t at = (size_t)n * ld0 + 4 * c;
+  if (upd) {                                         // (issued before the scan: the row is not written by anyone else)
+    p = *reinterpret_cast<const float4 *>(U.K0[tw] + at);
+    m = *reinterpret_cast<const float4 *>(U.m[tw] + at);
+    v = *reinterpret_cast<const float4 *>(U.v[tw] + at);
+  }
+  const int64_t s = ip[n], e = ip[n + 1];
+  float4 acc = f4_zero();
+  constexpr int UN = 4;                              // blocks of 64 candidates a wave has in flight (popular items: 3 400 candidates)
+  for (int64_t c0 = s + 64 * (int64_t)w; c0 < e; c0 += 256 * UN) {
+    int id[UN];
+    float val[UN];
+    unsigned long long ent[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t j = c0 + 256 * u + k;
+      id[u] = j < e ? ix[j] : -1;
+      val[u] = j < e ? vals[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      ent[u] = id[u] >= 0 ? map[id[u]] : 0ull;
+      val[u] *= id[u] >= 0 ? rho[id[u]] : 0.f;       // the normalised input value (what the forward multiplied the kernel row by)
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (c0 + 256 * u >= e) break;                  // (wave-uniform)
+      const bool hit = (uint32_t)(ent[u] >> 32) == A.stamp;
+      const unsigned long long mask = __ballot(hit);
+      if (!mask) continue;
+      if (hit) {
+        const int d = (int)(uint32_t)ent[u];
+        const int rank = __popcll(mask & ((1ull << k) - 1ull));
+        hd[w][rank] = d;
+        hc[w][rank] = val[u];
+      }
+      wave_lds_sync();
+      const int nh = __popcll(mask);
+      int t = r;
+      for (; t + 4 < nh; t += 8) {                   // two dz0 rows in flight per quarter-wave
+        const int d0 = hd[w][t], d1 = hd[w][t + 4];
+        const float c0f = hc[w][t], c1f = hc[w][t + 4];
+        float4 x0 = f4_zero(), x1 = f4_zero();
+        if (col) {
+          x0 = *reinterpret_cast<const float4 *>(dz0 + (size_t)d0 * ld0 + 4 * c);
+          x1 = *reinterpret_cast<const float4 *>(dz0 + (size_t)d1 * ld0 + 4 * c);
+        }
+        f4_fma(acc, c0f, x0);
+        f4_fma(acc, c1f, x1);
+      }
+      if (t < nh) {
+        const int dd = hd[w][t];
+        const float cc = hc[w][t];
+        if (col) f4_fma(acc, cc, *reinterpret_cast<const float4 *>(dz0 + (size_t)dd * ld0 + 4 * c));
+      }
+      wave_lds_sync();
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+  if (r == 0) part[w][c] = acc;
+  __syncthreads();
+  if (upd) {
+    float4 g = part[0][c];
+    f4_add(g, part[1][c]); f4_add(g, part[2][c]); f4_add(g, part[3][c]);
+    const OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, U.b1, U.b2, U.eps, U.alpha[tw]};
+    opt_update1(o, fmaf(U.l2c, p.x, g.x), p.x, m.x, v.x);
+    opt_update1(o, fmaf(U.l2c, p.y, g.y), p.y, m.y, v.y);
+    opt_update1(o, fmaf(U.l2c, p.z, g.z), p.z, m.z, v.z);
+    opt_update1(o, fmaf(U.l2c, p.w, g.w), p.w, m.w, v.w);
+    *reinterpret_cast<float4 *>(U.K0[tw] + at) = p;
+    *reinterpret_cast<float4 *>(U.m[tw] + at) = m;
+    *reinterpret_cast<float4 *>(U.v[tw] + at) = v;
   }
 }
 
@@ -520,10 +653,17 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   int rc = check_dims(D);
   if (rc) return rc;
   if (!A || !A->K0u || !A->K0i || !A->sw || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices ||
-      !A->i_values || !A->uid || !A->iid || !A->y || !A->off_u || !A->off_i || !A->dz0u || !A->dz0i || !A->tkeys_u ||
-      !A->tsrc_u || !A->tcoef_u || !A->tkeys_i || !A->tsrc_i || !A->tcoef_i || !A->gsw_part || !A->loss_part || !gsw_out ||
+      !A->i_values || !A->uid || !A->iid || !A->y || !A->dz0u || !A->dz0i || !A->gsw_part || !A->loss_part || !gsw_out ||
       A->B < 1 || (A->target_mode != 0 && A->target_mode != 1))
     return DRX_EINVAL;
+  // the first-layer gradient leaves either as touches for drx_scatter_rows or through the id maps for drx_dmf_k0_update
+  const bool touches = A->tkeys_u || A->tkeys_i;
+  if (touches && (!A->off_u || !A->off_i || !A->tkeys_u || !A->tsrc_u || !A->tcoef_u || !A->tkeys_i || !A->tsrc_i || !A->tcoef_i))
+    return DRX_EINVAL;
+  const bool maps = A->map_u || A->map_i;
+  if (maps && (!A->map_u || !A->map_i || !A->rho_u || !A->rho_i || A->stamp == 0)) return DRX_EINVAL;
+  if ((A->rho_u != nullptr) != (A->rho_i != nullptr)) return DRX_EINVAL;
+  if (!touches && !maps) return DRX_EINVAL;
   if (!A->work) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int chunks = drx_dmf_grid(A->B);
@@ -545,6 +685,33 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   hipLaunchKernelGGL(k_dmf_wgrad, dim3((D->n_small + 1 + 255) / 256, chunks), dim3(256), 0, st, *D, *A, chunk);
   hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, chunks, D->n_small,
                      A->loss_part, gsw_out);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_dmf_norms(const DrxDmfDims *D, const int64_t *indptr, const float *values, int32_t n, float *out, void *stream) {
+  int rc = check_dims(D);
+  if (rc) return rc;
+  if (!indptr || !values || !out || n < 1) return DRX_EINVAL;
+  const int grid = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  hipLaunchKernelGGL(k_dmf_norms, dim3(grid), dim3(256), 0, (hipStream_t)stream, *D, indptr, values, n, out);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_dmf_k0_update(const DrxDmfDims *D, const DrxDmfArgs *A, const DrxDmfK0Update *up, void *stream) {
+  int rc = check_dims(D);
+  if (rc) return rc;
+  if (!A || !up || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices || !A->i_values || !A->dz0u ||
+      !A->dz0i || !A->map_u || !A->map_i || !A->rho_u || !A->rho_i || A->stamp == 0 || up->n_items < 1 || up->n_users < 1)
+    return DRX_EINVAL;
+  if (!up->K0u || !up->K0i || !up->m_u || !up->m_i || !up->v_u || !up->v_i) return DRX_EINVAL;
+  if (((uintptr_t)up->K0u | (uintptr_t)up->K0i | (uintptr_t)up->m_u | (uintptr_t)up->m_i | (uintptr_t)up->v_u | (uintptr_t)up->v_i |
+       (uintptr_t)A->dz0u | (uintptr_t)A->dz0i) & 15)
+    return DRX_EINVAL;
+  K0Tables U{{up->K0u, up->K0i}, {up->m_u, up->m_i}, {up->v_u, up->v_i}, {up->n_items, up->n_users}, {up->alpha_u, up->alpha_i},
+             up->l2_coef, up->beta1, up->beta2, up->eps};
+  hipLaunchKernelGGL(k_dmf_k0_update, dim3((unsigned)(up->n_items + up->n_users)), dim3(256), 0, (hipStream_t)stream, *D, *A, U);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

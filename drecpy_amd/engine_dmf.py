@@ -2,10 +2,12 @@
 drx_score_pairs_bf16).
 
 One training step = the body of the reference fit() loop for DMF (recommender_abc.py:190-204 over dmf.py:64-99):
-  drx_dmf_fwd_bwd       both towers, cosine, clip, Keras BCE, backward -> dz0 rows + first-layer touches + small grads
-  drx_scatter_rows x2   first-layer kernel gradients (embedding-bag backward), deterministic
-  drx_adam_dense x2     Keras l2 + Adam on the two first-layer kernels (user_nn t = 2s+1, item_nn t = 2s+2)
+  drx_dmf_fwd_bwd       both towers, cosine, clip, Keras BCE, backward -> dz0 row per distinct id + small grads
+  drx_dmf_k0_update     first-layer kernel gradients (embedding-bag backward) + Keras l2 + dense Adam on both kernels in one walk
+                        over the interaction matrix (user_nn t = 2s+1, item_nn t = 2s+2), deterministic
   drx_adam_segments     deeper kernels and all biases
+(first_layer_update == 'scatter', for matrices too large to walk every step: touches from drx_dmf_fwd_bwd -> drx_scatter_rows x2
+-> drx_adam_dense x2 instead of drx_dmf_k0_update)
 
 `bind_prediction_scale(variable)` adds the ModifiedDMF extension of examples/extending_recommender_dmf.py:9-18 to the fused
 step: one registered scalar multiplies every prediction, the loss becomes Keras' (B,B) broadcast (= BCE against the batch-mean
@@ -17,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamSegments, DmfArgs, DmfDims, check, lib, ptr, stream_ptr
+from ._lib import AdamSegments, DmfArgs, DmfDims, DmfK0Update, check, lib, ptr, stream_ptr
 from .engine import ADAM_B1, ADAM_B2, ADAM_EPS, CdaeEngine, _round_up
 
 
@@ -65,6 +67,11 @@ class DmfEngine:
         self._g = {'K0u': self._g_arena[:nu].view(self.K0u.shape), 'K0i': self._g_arena[nu:].view(self.K0i.shape)}
         self._scratch = None
         self.lr, self.reg = 1e-3, 1e-3
+        # how the first-layer kernels are updated (set_interactions decides): 'scan' = drx_dmf_k0_update, one walk over all non-zeros
+        # per step; 'scatter' = touches -> drx_scatter_rows -> drx_adam_dense, for matrices too large to walk every step
+        self.first_layer_update = 'scan'
+        self._maps = (torch.zeros(n_users, dtype=torch.int64, device=self.device), torch.zeros(n_items, dtype=torch.int64, device=self.device))
+        self._stamp = 0
         from .Recommender.trainables import TrainableModel
         # what DMF._pre_fit registers (dmf.py:60): the two Sequential towers, each one apply_gradients per step
         self.user_nn = TrainableModel('user_nn', lambda: self._tower_weights(0))
@@ -101,6 +108,13 @@ class DmfEngine:
                         torch.as_tensor(np.asarray(t[2], np.float32)).to(d))
         self.csr, self.csc = mk(csr), mk(csc)
         self._h_indptr = (np.asarray(csr[0], np.int64).copy(), np.asarray(csc[0], np.int64).copy())   # host copies: batch offsets
+        self.first_layer_update = 'scan' if len(csr[1]) <= self.SCAN_MAX_NNZ else 'scatter'
+        # the l2 normaliser of every row / column depends on the dataset alone: once here, not per batch id and step
+        self._rho = (torch.empty(self.U, dtype=torch.float32, device=d), torch.empty(self.N, dtype=torch.float32, device=d))
+        for (ip, _, vals), n, out in ((self.csr, self.U, self._rho[0]), (self.csc, self.N, self._rho[1])):
+            check(lib().drx_dmf_norms(C.byref(self.D), ptr(ip), ptr(vals), n, ptr(out), stream_ptr(self.device)), 'drx_dmf_norms')
+
+    SCAN_MAX_NNZ = 1 << 25      # 32 M non-zeros = 0.5 GB walked per step: beyond that the touches of a batch are the smaller job
 
     def set_params(self, p):
         t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
@@ -219,8 +233,10 @@ class DmfEngine:
         n_du, n_di = len(prep['arrays'][0]), len(prep['arrays'][1])
         ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
         dz0u, dz0i = torch.empty(n_du, ld0u, **z), torch.empty(n_di, ld0i, **z)
-        tk_u, ts_u, tc_u = torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **z)
-        tk_i, ts_i, tc_i = torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **z)
+        scan = self.first_layer_update == 'scan'
+        if not scan:
+            tk_u, ts_u, tc_u = torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **z)
+            tk_i, ts_i, tc_i = torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **z)
         grid = L_.drx_dmf_grid(B)
         gpart, lpart = torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z)
         gsw = torch.empty(self.D.n_small + 1, **z)
@@ -236,8 +252,13 @@ class DmfEngine:
             A.target_mode = 1
             A.y_mean = prep['y_mean']
         A.dz0u, A.dz0i = dz0u.data_ptr(), dz0i.data_ptr()
-        A.tkeys_u, A.tsrc_u, A.tcoef_u = tk_u.data_ptr(), ts_u.data_ptr(), tc_u.data_ptr()
-        A.tkeys_i, A.tsrc_i, A.tcoef_i = tk_i.data_ptr(), ts_i.data_ptr(), tc_i.data_ptr()
+        A.rho_u, A.rho_i = self._rho[0].data_ptr(), self._rho[1].data_ptr()
+        if scan:
+            self._stamp += 1
+            A.map_u, A.map_i, A.stamp = self._maps[0].data_ptr(), self._maps[1].data_ptr(), self._stamp
+        else:
+            A.tkeys_u, A.tsrc_u, A.tcoef_u = tk_u.data_ptr(), ts_u.data_ptr(), tc_u.data_ptr()
+            A.tkeys_i, A.tsrc_i, A.tcoef_i = tk_i.data_ptr(), ts_i.data_ptr(), tc_i.data_ptr()
         A.gsw_part, A.loss_part = gpart.data_ptr(), lpart.data_ptr()
         need = L_.drx_dmf_work_bytes(B)
         if getattr(self, '_work', None) is None or self._work.numel() < need:
@@ -251,19 +272,27 @@ class DmfEngine:
                     sq = sq + (self.sw[start:start + n] ** 2).sum()
             reg_loss = self.reg * sq
         check(L_.drx_dmf_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream_ptr(self.device)), 'drx_dmf_fwd_bwd')
-        self._g_arena.zero_()
-        self._scatter(tk_u, Tu, dz0u, ts_u, tc_u, ld0u, self.N, self._g['K0u'])
-        self._scatter(tk_i, Ti, dz0i, ts_i, tc_i, ld0i, self.U, self._g['K0i'])
         if applies is None:
             applies = (3, 1, 2, 0) if self.scale_var is not None else (2, 0, 1, None)
         n_app = applies[0]
         alpha = [CdaeEngine.adam_alpha(self.lr, n_app * step_idx + j + 1, self.beta1, self.beta2) if j is not None else 0.0 for j in applies[1:]]
         l2c = 2.0 * self.reg
-        for name, tw in (('K0u', 0), ('K0i', 1)):
-            p = self.tensors()[name]
-            m, v = self.state[name]
-            check(L_.drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(self._g[name]), p.numel(), alpha[tw], l2c, self.beta1, self.beta2,
-                                    self.eps, stream_ptr(self.device)), 'drx_adam_dense')
+        if scan:
+            up = DmfK0Update()
+            (mu, vu), (mi, vi) = self.state['K0u'], self.state['K0i']
+            up.K0u, up.m_u, up.v_u, up.K0i, up.m_i, up.v_i = (t.data_ptr() for t in (self.K0u, mu, vu, self.K0i, mi, vi))
+            up.n_items, up.n_users = self.N, self.U
+            up.alpha_u, up.alpha_i, up.l2_coef, up.beta1, up.beta2, up.eps = alpha[0], alpha[1], l2c, self.beta1, self.beta2, self.eps
+            check(L_.drx_dmf_k0_update(C.byref(self.D), C.byref(A), C.byref(up), stream_ptr(self.device)), 'drx_dmf_k0_update')
+        else:
+            self._g_arena.zero_()
+            self._scatter(tk_u, Tu, dz0u, ts_u, tc_u, ld0u, self.N, self._g['K0u'])
+            self._scatter(tk_i, Ti, dz0i, ts_i, tc_i, ld0i, self.U, self._g['K0i'])
+            for name, tw in (('K0u', 0), ('K0i', 1)):
+                p = self.tensors()[name]
+                m, v = self.state[name]
+                check(L_.drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(self._g[name]), p.numel(), alpha[tw], l2c, self.beta1, self.beta2,
+                                        self.eps, stream_ptr(self.device)), 'drx_adam_dense')
         sg = AdamSegments()
         sg.n = len(self.seg)
         for i, (_, start, n, regd, tw) in enumerate(self.seg):

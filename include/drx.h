@@ -367,13 +367,37 @@ typedef struct DrxDmfArgs {
    * (drx_dmf_predict takes uid / iid per pair as before and ignores these) */
   const int32_t *inv_u, *inv_i, *gptr_u, *gptr_i, *grows_u, *grows_i;
   int32_t n_du, n_di;
+  /* Alternative to the touches (tkeys_* / tsrc_* / tcoef_* / off_* may then be NULL): drx_dmf_fwd_bwd records, for every distinct id
+   * of the batch, map[id] = (stamp << 32) | its distinct index, for drx_dmf_k0_update.  map_u [n_users] / map_i [n_items]:
+   * zero-initialised ONCE by the caller, never cleared; stamp: non-zero and different in every step. */
+  unsigned long long *map_u, *map_i;
+  /* l2 normalisers of every user row [n_users] / item column [n_items] of the interaction matrix (dmf.py:75-86), computed once per
+   * dataset by drx_dmf_norms: required with the maps, optional otherwise (NULL: drx_dmf_fwd_bwd forms them per batch id) */
+  const float *rho_u, *rho_i;
+  uint32_t stamp;
 } DrxDmfArgs;
+/* out[id] = 1 / max(|row id|_2, 1e-6) (1 when l2_norm_vectors == 0) for the n rows of a CSR, with the summation order of the towers */
+int drx_dmf_norms(const DrxDmfDims *D, const int64_t *indptr, const float *values, int32_t n, float *out, void *stream);
 int drx_dmf_grid(int32_t B);      /* rows of gsw_part / entries of loss_part */
 size_t drx_dmf_work_bytes(int32_t B);
 /* forward + Keras BCE + backward (dmf.py:88-99 under the tape): dz0 rows + touches for drx_scatter_rows,
  * gsw_out[0..n_small) small-weight gradients, gsw_out[n_small] = prediction loss */
 int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream);
 int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream);
+/* The update of the first-layer kernels (tf.keras Dense kernels [N, f0] of user_nn / [U, f0] of item_nn, dmf.py:44-60) after
+ * drx_dmf_fwd_bwd ran with the id maps: gradient (+ l2_coef * K0, dmf.py:101-103) and dense Keras Adam in one pass over both tables —
+ * replaces recommender_abc.py:328-334 for these two variables without a touch list, sort or gradient arena.  Row n of K0u collects
+ * from column n of the interaction matrix (i_* of A) the entries whose user carries this step's stamp in map_u; K0i likewise from
+ * u_* and map_i.  Cost per step: one walk over all non-zeros (8 bytes each) — pays while nnz is within ~64x the batch's touches;
+ * beyond that use the touches + drx_scatter_rows + drx_adam_dense. */
+typedef struct DrxDmfK0Update {
+  float *K0u, *m_u, *v_u;    /* [n_items, ld0[0]] kernel, Adam moments */
+  float *K0i, *m_i, *v_i;    /* [n_users, ld0[1]] */
+  int32_t n_items, n_users;
+  float alpha_u, alpha_i;    /* Keras-Adam lr_t of the apply_gradients call each kernel belongs to */
+  float l2_coef, beta1, beta2, eps;
+} DrxDmfK0Update;
+int drx_dmf_k0_update(const DrxDmfDims *D, const DrxDmfArgs *A, const DrxDmfK0Update *up, void *stream);
 /* all-pairs cosine scores on the matrix cores: out[u, n] = max(1e-6, ru[u,:kdim] . ri[n,:kdim]) with bf16 operands /
  * fp32 accumulation (v_mfma_f32_32x32x16_bf16); ru, ri = l2-normalised tower outputs, kdim % 16 == 0 (dmf.py:92-95
  * evaluated for a block of users against all items instead of one _predict per pair, recommender_abc.py:460). */

@@ -22,8 +22,9 @@ def _problem(rng, U, N, nnz):
     return csr, csc, dense
 
 
+@pytest.mark.parametrize('update', ['scan', 'scatter'])      # the two ways the first-layer kernels are updated (engine_dmf.py)
 @pytest.mark.parametrize('uf,itf,l2n,B', [((64, 32), (64, 32), True, 64), ((16,), (24, 16), True, 33), ((32, 20, 8), (12, 8), False, 50)])
-def test_dmf_steps_match_oracle(uf, itf, l2n, B):
+def test_dmf_steps_match_oracle(uf, itf, l2n, B, update):
     from drecpy_amd.engine_dmf import DmfEngine
     rng = np.random.default_rng(len(uf) * 7 + B)
     U, N = 70, 90
@@ -34,6 +35,8 @@ def test_dmf_steps_match_oracle(uf, itf, l2n, B):
             p[k] = rng.normal(0, 0.05, size=p[k].shape)
     eng = DmfEngine(U, N, uf, itf, l2n)
     eng.set_interactions(csr, csc)
+    assert eng.first_layer_update == 'scan'
+    eng.first_layer_update = update
     eng.set_params(p)
     eng.lr, eng.reg = 2e-3, 1e-3
     st = dm.adam_state(p)
