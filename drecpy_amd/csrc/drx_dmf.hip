@@ -530,8 +530,10 @@ __global__ __launch_bounds__(256) void k_dmf_wgrad(DrxDmfDims D, DrxDmfArgs A, i
   if (is_scale) {
     for (int b = b0; b < b1; ++b) g += Wk.samp[(size_t)b * 2 + 1];
   } else if (pd && pa) {
+#pragma unroll 8
     for (int b = b0; b < b1; ++b) g = fmaf(pa[b * stride], pd[b * stride], g);
   } else if (pd) {
+#pragma unroll 8
     for (int b = b0; b < b1; ++b) g += pd[b * stride];
   }
   A.gsw_part[(size_t)blockIdx.y * D.n_small + i] = g;
@@ -642,7 +644,9 @@ using namespace drx;
 extern "C" {
 
 // number of batch chunks of k_dmf_wgrad = rows of gsw_part / entries of loss_part the caller provides
-int drx_dmf_grid(int32_t B) { return B <= 64 ? 1 : (B + 63) / 64 < 64 ? (B + 63) / 64 : 64; }
+// (16 samples per chunk up to 256 chunks: a thread of k_dmf_wgrad walks its chunk serially, two strided loads per sample — 64-sample
+// chunks made that walk 25 us of a 130 us step)
+int drx_dmf_grid(int32_t B) { return B <= 16 ? 1 : (B + 15) / 16 < 256 ? (B + 15) / 16 : 256; }
 
 size_t drx_dmf_work_bytes(int32_t B) {
   if (B < 1) return 0;
