@@ -177,41 +177,64 @@ class DmfEngine:
         check(lib().drx_scatter_rows(ptr(keys), T, ptr(src), ptr(src_index), ptr(coef), None, ld, n_rows, ptr(out), None,
                                      ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
 
+    # what a step uploads, in this order, each array 16-byte aligned at a byte offset that depends on the batch size alone
+    _BATCH_ARRAYS = ('du', 'di', 'y', 'off_u', 'off_i', 'inv_u', 'inv_i', 'gptr_u', 'gptr_i', 'grows_u', 'grows_i')
+
     @staticmethod
-    def _distinct(ids, indptr):
-        """Distinct ids of a batch (ascending), every sample's index among them, the samples per distinct id as a CSR (samples
-        ascending: the order of the gradient sums) and the touch offsets of the distinct ids.  Counting instead of np.unique's sort
-        (ids are bounded by the table size): 0.10 ms instead of 0.46 ms per 4096 ids — this runs once per tower and step."""
-        n = len(indptr) - 1
-        cnt = np.bincount(ids, minlength=n)
-        d = np.flatnonzero(cnt)
-        rank = np.zeros(n, np.int32)
-        rank[d] = np.arange(len(d), dtype=np.int32)
-        inv = rank[ids]
-        order = np.argsort(inv.astype(np.uint16) if len(d) < 65536 else inv, kind='stable').astype(np.int32)     # (16-bit keys: radix sort)
-        gptr = np.zeros(len(d) + 1, np.int32)
-        np.cumsum(cnt[d], out=gptr[1:])
-        off = np.zeros(len(d) + 1, np.int32)
-        np.cumsum(indptr[d + 1] - indptr[d], out=off[1:])
-        return d.astype(np.int32), inv, gptr, order, off
+    def _batch_layout(B):
+        lens = (B, B, B, B + 1, B + 1, B, B, B + 1, B + 1, B, B)
+        offs, total = [], 0
+        for n in lens:
+            offs.append(total)
+            total += (4 * n + 15) & ~15
+        return offs, lens, total
 
     def prepare_batch(self, uids, iids, y):
         """Host half of a step, free of device work (DMF.fit() runs it on the sampler's worker thread): the distinct users / items of
-        the batch and everything the kernels index them with, as one list of arrays for ONE asynchronous upload."""
-        u64, i64 = np.asarray(uids, dtype=np.int64), np.asarray(iids, dtype=np.int64)
-        du, inv_u, gptr_u, grows_u, off_u = self._distinct(u64, self._h_indptr[0])
-        di, inv_i, gptr_i, grows_i, off_i = self._distinct(i64, self._h_indptr[1])
-        y32 = np.ascontiguousarray(y, dtype=np.float32)
-        arrays = [du, di, y32, off_u, off_i, inv_u, inv_i, gptr_u, gptr_i, grows_u, grows_i]
-        return {'arrays': arrays, 'B': len(u64), 'Tu': int(off_u[-1]), 'Ti': int(off_i[-1]), 'y_mean': float(y32.astype(np.float64).mean())}
+        the batch (ascending), every sample's index among them, the samples per distinct id as a CSR (samples ascending: the order of
+        the gradient sums) and the touch offsets of the distinct ids — drx_batch_distinct, counting through an id -> rank scratch
+        instead of a sort — written into ONE host buffer at fixed offsets for ONE asynchronous upload."""
+        B = len(uids)
+        offs, lens, total = self._batch_layout(B)
+        buf = np.empty(total, np.uint8)
+        base = buf.ctypes.data
+        at = dict(zip(self._BATCH_ARRAYS, offs))
+        sc = self.__dict__.setdefault('_distinct_scratch', (np.full(self.U, -1, np.int32), np.full(self.N, -1, np.int32)))
+        L_ = lib()
+        nd = []
+        for t, (ids, n, sfx) in enumerate(((uids, self.U, '_u'), (iids, self.N, '_i'))):
+            ids32 = np.ascontiguousarray(ids, dtype=np.int32)
+            r = L_.drx_batch_distinct(ids32.ctypes.data, B, n, self._h_indptr[t].ctypes.data, sc[t].ctypes.data, base + at['du' if t == 0 else 'di'],
+                                      base + at['inv' + sfx], base + at['gptr' + sfx], base + at['grows' + sfx], base + at['off' + sfx])
+            if r < 0:
+                check(int(r), 'drx_batch_distinct')
+            nd.append(int(r))
+        y32 = buf[at['y']:at['y'] + 4 * B].view(np.float32)
+        y32[:] = y
+        off_u = buf[at['off_u']:at['off_u'] + 4 * (nd[0] + 1)].view(np.int32)
+        off_i = buf[at['off_i']:at['off_i'] + 4 * (nd[1] + 1)].view(np.int32)
+        return {'buf': buf, 'offs': offs, 'B': B, 'n_du': nd[0], 'n_di': nd[1], 'Tu': int(off_u[-1]), 'Ti': int(off_i[-1]),
+                'y_mean': float(y32.astype(np.float64).mean())}
 
     def _upload_batch(self, prepared):
-        """Host batch -> device in one asynchronous copy (_staging.StagedUpload)."""
-        if getattr(self, '_stage', None) is None:
-            from ._staging import StagedUpload
-            self._stage = StagedUpload(self.device)
-        dev, views = self._stage(prepared['arrays'])
-        return (dev, views), [v.data_ptr() for v in views]
+        """Host batch -> device in one asynchronous copy from a pinned ring (so the host can run ahead of the device); returns the
+        device buffer and the addresses of the arrays in it."""
+        st = self.__dict__.setdefault('_stage', {'i': 0, 'host': [None] * 4, 'ev': [None] * 4})
+        buf = prepared['buf']
+        total = buf.nbytes
+        k = st['i'] % 4
+        st['i'] += 1
+        if st['host'][k] is None or st['host'][k].numel() < total:
+            st['host'][k] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
+            st['ev'][k] = torch.cuda.Event()
+        else:
+            st['ev'][k].synchronize()                 # the copy that last read this pinned slot has finished
+        st['host'][k].numpy()[:total] = buf
+        dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+        dev.copy_(st['host'][k][:total], non_blocking=True)
+        st['ev'][k].record(torch.cuda.current_stream(self.device))
+        base = dev.data_ptr()
+        return dev, [base + o for o in prepared['offs']]
 
     def step(self, step_idx, uids, iids=None, y=None, want_loss=False, applies=None):
         """uids, iids, y: the batch (arrays or tensors) — or `uids` = what prepare_batch returned for it.
@@ -230,16 +253,20 @@ class DmfEngine:
         alive, ptrs = self._upload_batch(prep)
         p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri = ptrs
         B, Tu, Ti = prep['B'], prep['Tu'], prep['Ti']
-        n_du, n_di = len(prep['arrays'][0]), len(prep['arrays'][1])
+        n_du, n_di = prep['n_du'], prep['n_di']
         ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
-        dz0u, dz0i = torch.empty(n_du, ld0u, **z), torch.empty(n_di, ld0i, **z)
+        stream = stream_ptr(self.device)
+        grid = L_.drx_dmf_grid(B)
+        # device work buffers of a batch size: steps run in order on one stream, so they are reused from step to step
+        wk = getattr(self, '_step_bufs', None)
+        if wk is None or wk[0] != B:
+            wk = self._step_bufs = (B, torch.empty(B, ld0u, **z), torch.empty(B, ld0i, **z), torch.empty(grid, self.D.n_small, **z),
+                                    torch.empty(grid, **z), torch.empty(self.D.n_small + 1, **z))
+        _, dz0u, dz0i, gpart, lpart, gsw = wk
         scan = self.first_layer_update == 'scan'
         if not scan:
             tk_u, ts_u, tc_u = torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **i32), torch.empty(max(Tu, 1), **z)
             tk_i, ts_i, tc_i = torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **i32), torch.empty(max(Ti, 1), **z)
-        grid = L_.drx_dmf_grid(B)
-        gpart, lpart = torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z)
-        gsw = torch.empty(self.D.n_small + 1, **z)
         A = DmfArgs()
         A.K0u, A.K0i, A.sw = self.K0u.data_ptr(), self.K0i.data_ptr(), self.sw.data_ptr()
         A.u_indptr, A.u_indices, A.u_values = (t.data_ptr() for t in self.csr)
@@ -271,7 +298,7 @@ class DmfEngine:
                 if regd:
                     sq = sq + (self.sw[start:start + n] ** 2).sum()
             reg_loss = self.reg * sq
-        check(L_.drx_dmf_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream_ptr(self.device)), 'drx_dmf_fwd_bwd')
+        check(L_.drx_dmf_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream), 'drx_dmf_fwd_bwd')
         if applies is None:
             applies = (3, 1, 2, 0) if self.scale_var is not None else (2, 0, 1, None)
         n_app = applies[0]
@@ -283,7 +310,7 @@ class DmfEngine:
             up.K0u, up.m_u, up.v_u, up.K0i, up.m_i, up.v_i = (t.data_ptr() for t in (self.K0u, mu, vu, self.K0i, mi, vi))
             up.n_items, up.n_users = self.N, self.U
             up.alpha_u, up.alpha_i, up.l2_coef, up.beta1, up.beta2, up.eps = alpha[0], alpha[1], l2c, self.beta1, self.beta2, self.eps
-            check(L_.drx_dmf_k0_update(C.byref(self.D), C.byref(A), C.byref(up), stream_ptr(self.device)), 'drx_dmf_k0_update')
+            check(L_.drx_dmf_k0_update(C.byref(self.D), C.byref(A), C.byref(up), stream), 'drx_dmf_k0_update')
         else:
             self._g_arena.zero_()
             self._scatter(tk_u, Tu, dz0u, ts_u, tc_u, ld0u, self.N, self._g['K0u'])
@@ -292,7 +319,7 @@ class DmfEngine:
                 p = self.tensors()[name]
                 m, v = self.state[name]
                 check(L_.drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(self._g[name]), p.numel(), alpha[tw], l2c, self.beta1, self.beta2,
-                                        self.eps, stream_ptr(self.device)), 'drx_adam_dense')
+                                        self.eps, stream), 'drx_adam_dense')
         sg = AdamSegments()
         sg.n = len(self.seg)
         for i, (_, start, n, regd, tw) in enumerate(self.seg):
@@ -303,7 +330,7 @@ class DmfEngine:
             sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = self._scale_slot, 1, alpha[2], 0.0
         m, v = self.state['sw']
         check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), self.beta1, self.beta2, self.eps,
-                                   stream_ptr(self.device)), 'drx_adam_segments')
+                                   stream), 'drx_adam_segments')
         if want_loss:
             return float((gsw[-1] + reg_loss).item())
         return None

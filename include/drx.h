@@ -376,6 +376,12 @@ typedef struct DrxDmfArgs {
   const float *rho_u, *rho_i;
   uint32_t stamp;
 } DrxDmfArgs;
+/* Host helper for the arrays above: the distinct ids of a batch, ascending.  distinct [<= B], inv [B], gptr [<= B+1], grows [B],
+ * off [<= B+1] (prefix sums of indptr row lengths of the distinct ids; NULL to skip; saturates at INT32_MAX) are host arrays;
+ * scratch = int32 [n_rows], all -1 on entry and again on return (the caller keeps it between steps).  Returns the number of distinct
+ * ids, or a negative DRX_E* code (an id outside [0, n_rows)). */
+int32_t drx_batch_distinct(const int32_t *ids, int32_t B, int32_t n_rows, const int64_t *indptr, int32_t *scratch, int32_t *distinct,
+                           int32_t *inv, int32_t *gptr, int32_t *grows, int32_t *off);
 /* out[id] = 1 / max(|row id|_2, 1e-6) (1 when l2_norm_vectors == 0) for the n rows of a CSR, with the summation order of the towers */
 int drx_dmf_norms(const DrxDmfDims *D, const int64_t *indptr, const float *values, int32_t n, float *out, void *stream);
 int drx_dmf_grid(int32_t B);      /* rows of gsw_part / entries of loss_part */

@@ -96,7 +96,7 @@ def main():
         state = {'s': 1}
 
         def dstep():
-            m._engine.step(state['s'], *batch); state['s'] += 1
+            m._do_batch(batch, step=state['s']); state['s'] += 1
         dev = timed(dstep, 30)
         t0 = time.perf_counter()           # the public call: a second fit() of 300 one-batch epochs, set-up included
         m.fit(ds, epochs=300, batch_size=B, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)

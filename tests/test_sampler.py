@@ -303,3 +303,25 @@ def test_c_program_links_and_runs_against_the_abi(tmp_path):
     got = out[0].split()
     assert float(got[0]) == a and float(got[1]) == b and int(got[2]) == c          # %.17g round-trips a double exactly
     assert out[1] == 'ok'
+
+
+def test_point_sampler_membership_by_rows_when_the_pair_bitmap_would_be_too_large():
+    """Above 2^28 (user, item) cells the native sampler looks a pair up in its user's sorted item row instead of a bitmap: the stream
+    must still be the oracle's (mem_dataset.py:154-163)."""
+    from oracle import data_oracle as do
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    U, N, n = 70001, 4001, 3000                        # 2.8e8 cells
+    uid = np.concatenate([rng.integers(0, 50, n), [U - 1]]).astype(np.int32)      # dense among the first users: rejections happen
+    iid = np.concatenate([rng.integers(0, 60, n), [N - 1]]).astype(np.int32)
+    val = rng.integers(0, 6, n + 1).astype(np.float64)
+    h = L.drx_sampler_create(uid.ctypes.data, iid.ctypes.data, val.ctypes.data, len(uid), 3, 1, 1.0, 11)
+    assert h
+    u = np.empty(400, np.int32); i = np.empty(400, np.int32); v = np.empty(400, np.float64); ng = np.empty(400, np.uint8)
+    assert L.drx_sampler_draw(h, 0, 400, u.ctypes.data, i.ctypes.data, v.ctypes.data, ng.ctypes.data) == 0
+    L.drx_sampler_destroy(h)
+    want = do.PointSamplerOracle(uid, iid, val, 3, 1.0, 11).sample(400)
+    assert [(int(a), int(b), float(c) if not g else 0.0) for a, b, c, g in zip(u, i, v, ng)] == [(a, b, float(c)) for a, b, c in want]
+    seen = set(zip(uid.tolist(), iid.tolist()))
+    assert all((int(a), int(b)) not in seen for a, b, g in zip(u, i, ng) if g)
