@@ -325,3 +325,29 @@ def test_point_sampler_membership_by_rows_when_the_pair_bitmap_would_be_too_larg
     assert [(int(a), int(b), float(c) if not g else 0.0) for a, b, c, g in zip(u, i, v, ng)] == [(a, b, float(c)) for a, b, c in want]
     seen = set(zip(uid.tolist(), iid.tolist()))
     assert all((int(a), int(b)) not in seen for a, b, g in zip(u, i, ng) if g)
+
+
+@pytest.mark.parametrize('n,B', [(6040, 4096), (3706, 256), (100000, 4096), (50, 200), (7, 1)])
+def test_batch_distinct_matches_numpy(n, B):
+    """drx_batch_distinct (the DMF step's host bookkeeping) against np.unique; the caller's scratch comes back clean."""
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(n + B)
+    ids = rng.integers(0, n, B).astype(np.int32)
+    ip = np.zeros(n + 1, np.int64)
+    ip[1:] = np.cumsum(rng.integers(0, 30, n))
+    sc = np.full(n, -1, np.int32)
+    d, inv, gptr, grows, off = (np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B + 1, np.int32), np.empty(B, np.int32),
+                                np.empty(B + 1, np.int32))
+    nd = L.drx_batch_distinct(ids.ctypes.data, B, n, ip.ctypes.data, sc.ctypes.data, d.ctypes.data, inv.ctypes.data, gptr.ctypes.data,
+                              grows.ctypes.data, off.ctypes.data)
+    ud, uinv = np.unique(ids, return_inverse=True)
+    assert nd == len(ud) and np.array_equal(d[:nd], ud) and np.array_equal(inv, uinv) and (sc == -1).all()
+    for j in range(nd):
+        assert np.array_equal(grows[gptr[j]:gptr[j + 1]], np.flatnonzero(ids == ud[j]))
+    assert off[0] == 0 and np.array_equal(off[1:nd + 1], np.cumsum(ip[ud + 1] - ip[ud]))
+    bad = ids.copy()
+    bad[B // 2] = n                                    # an id outside the table: refused, scratch untouched
+    assert L.drx_batch_distinct(bad.ctypes.data, B, n, ip.ctypes.data, sc.ctypes.data, d.ctypes.data, inv.ctypes.data, gptr.ctypes.data,
+                                grows.ctypes.data, off.ctypes.data) == -1          # DRX_EINVAL
+    assert (sc == -1).all()
