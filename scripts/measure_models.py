@@ -58,10 +58,12 @@ def main():
             m._do_batch(batch, step=state['s'])
             state['s'] += 1
         timed(full_step, 200)
-        t0 = time.perf_counter()           # the public call: second fit() of 2000 one-batch epochs (set-up included)
-        m.fit(ds, epochs=2000, batch_size=B, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
-        torch.cuda.synchronize()
-        e2e = (time.perf_counter() - t0) / 2000
+        e2e = 1e9                          # the public call: fit() of 2000 one-batch epochs, set-up included (the first such call of a
+        for _ in range(2):                 # process also loads the code objects and pins its staging memory: the second one counts)
+            t0 = time.perf_counter()
+            m.fit(ds, epochs=2000, batch_size=B, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
+            torch.cuda.synchronize()
+            e2e = min(e2e, (time.perf_counter() - t0) / 2000)
         batch = m._sample_batch(B)
         uid, _, _ = m._batch_arrays(batch)
         keep_off, keep = m._corruption_keep(uid)
