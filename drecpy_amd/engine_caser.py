@@ -134,20 +134,29 @@ class CaserEngine:
             return a.to(self.device, torch.int32).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
 
-    def _scatter(self, keys, src, ld, n_rows, out, src_s=None, out_s=None):
-        """`out` (and `out_s`) must already be zero: step() clears the whole gradient arena once."""
-        T = keys.numel()
-        need = lib().drx_scatter_scratch_bytes(ld, T, n_rows)
+    def _scatter(self, keys, T, src, ld, n_rows, out, src_s=None, out_s=None, stream=None):
+        """keys / src / src_s / out / out_s: device addresses.  `out` (and `out_s`) must already be zero: step() clears the whole
+        gradient arena once."""
+        sb = self.__dict__.setdefault('_scatter_need', {})
+        need = sb.get((ld, T, n_rows))
+        if need is None:
+            need = sb[(ld, T, n_rows)] = lib().drx_scatter_scratch_bytes(ld, T, n_rows)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(int(need * 1.2) + 1024, dtype=torch.uint8, device=self.device)
-        check(lib().drx_scatter_rows(ptr(keys), T, ptr(src), None, None, ptr(src_s), ld, n_rows, ptr(out), ptr(out_s),
-                                     ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
+        check(lib().drx_scatter_rows(keys, T, src, None, None, src_s, ld, n_rows, out, out_s, self._scratch.data_ptr(),
+                                     self._scratch.numel(), stream if stream is not None else stream_ptr(self.device)), 'drx_scatter_rows')
 
-    def _adam(self, name, grad, alpha, l2c):
-        p = self.tensors()[name]
+    def _adam(self, name, grad, alpha, l2c, stream=None):
+        p = getattr(self, name)
         m, v = self.state[name]
-        check(lib().drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(grad), p.numel(), alpha, l2c, self.beta1, self.beta2, self.eps,
-                                   stream_ptr(self.device)), 'drx_adam_dense')
+        check(lib().drx_adam_dense(p.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), p.numel(), alpha, l2c, self.beta1, self.beta2,
+                                   self.eps, stream if stream is not None else stream_ptr(self.device)), 'drx_adam_dense')
+
+    def _alphas(self, step_idx):
+        """Keras-Adam lr_t of the n_layers applies of step `step_idx` (t = n_layers * step + j + 1), fp32 like optimizer_v2/adam.py."""
+        f = np.float32
+        t = (self.n_layers * step_idx + 1 + np.arange(self.n_layers)).astype(np.float32)
+        return (f(self.lr) * np.sqrt(f(1.0) - np.power(f(self.beta2), t)) / (f(1.0) - np.power(f(self.beta1), t))).astype(np.float32).tolist()
 
     def _args(self, uid, before, after=None, keep=None, rate=0.0, mask_seed=0):
         A = CaserArgs()
@@ -184,17 +193,21 @@ class CaserEngine:
         B = uid.numel()
         assert bef.shape == (B, self.L) and aft.shape == (B, self.Tp)
         z = dict(dtype=torch.float32, device=self.device)
+        stream = stream_ptr(self.device)
         grid = L_.drx_caser_grid(C.byref(self.D), B)
         n_dE, n_dW1, n_dPu = B * self.L * self.ld, B * self.Tp * self.ld2, B * self.ld
-        rows = torch.zeros(n_dE + n_dW1 + n_dPu, **z)    # one buffer, one fill: the padding columns of the gradient rows are zero
-        dE, dW1, dPu = rows[:n_dE].view(B * self.L, self.ld), rows[n_dE:n_dE + n_dW1].view(B * self.Tp, self.ld2), rows[n_dE + n_dW1:].view(B, self.ld)
-        db1 = torch.empty(B * self.Tp, **z)
-        gpart = torch.empty(grid, self.D.n_small, **z)
-        lpart = torch.empty(grid, **z)
-        gsw = torch.empty(self.D.n_small + 1, **z)
+        # device work buffers of a batch size: steps run in order on one stream, so they are reused from step to step
+        wk = getattr(self, '_step_bufs', None)
+        if wk is None or wk[0] != B:
+            rows = torch.zeros(n_dE + n_dW1 + n_dPu, **z)    # the padding columns of the gradient rows stay zero: the kernel never writes them
+            wk = self._step_bufs = (B, rows, torch.empty(B * self.Tp, **z), torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z),
+                                    torch.empty(self.D.n_small + 1, **z))
+        _, rows, db1, gpart, lpart, gsw = wk
+        base = rows.data_ptr()
+        p_dE, p_dW1, p_dPu = base, base + 4 * n_dE, base + 4 * (n_dE + n_dW1)
         self._grad_arena.zero_()
         A = self._args(uid, bef, aft, kp, rate, mask_seed)
-        A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = (t.data_ptr() for t in (dE, dW1, db1, dPu, gpart, lpart))
+        A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = p_dE, p_dW1, db1.data_ptr(), p_dPu, gpart.data_ptr(), lpart.data_ptr()
         reg_loss = None
         if want_loss:                                   # Keras l2(reg) on the pre-update weights
             sq = (self.user_emb ** 2).sum() + (self.item_emb ** 2).sum() + (self.W1 ** 2).sum()
@@ -202,24 +215,25 @@ class CaserEngine:
                 if regd:
                     sq = sq + (self.sw[start:start + n] ** 2).sum()
             reg_loss = self.reg * sq
-        check(L_.drx_caser_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream_ptr(self.device)), 'drx_caser_fwd_bwd')
+        check(L_.drx_caser_fwd_bwd(C.byref(self.D), C.byref(A), gsw.data_ptr(), stream), 'drx_caser_fwd_bwd')
         g = self._grads
-        self._scatter(bef.reshape(-1), dE, self.ld, self.N, g['item_emb'])
-        self._scatter(aft.reshape(-1), dW1, self.ld2, self.N, g['W1'], src_s=db1, out_s=g['b1'])
-        self._scatter(uid, dPu, self.ld, self.U, g['user_emb'])
-        alpha = lambda j: CdaeEngine.adam_alpha(self.lr, self.n_layers * step_idx + j + 1, self.beta1, self.beta2)
+        self._scatter(bef.data_ptr(), B * self.L, p_dE, self.ld, self.N, g['item_emb'].data_ptr(), stream=stream)
+        self._scatter(aft.data_ptr(), B * self.Tp, p_dW1, self.ld2, self.N, g['W1'].data_ptr(), src_s=db1.data_ptr(), out_s=g['b1'].data_ptr(),
+                      stream=stream)
+        self._scatter(uid.data_ptr(), B, p_dPu, self.ld, self.U, g['user_emb'].data_ptr(), stream=stream)
+        alpha = self._alphas(step_idx)
         l2c = 2.0 * self.reg
-        self._adam('user_emb', g['user_emb'], alpha(0), l2c)
-        self._adam('item_emb', g['item_emb'], alpha(1), l2c)
-        self._adam('W1', g['W1'], alpha(4 + self.L), l2c)
-        self._adam('b1', g['b1'], alpha(5 + self.L), 0.0)
+        self._adam('user_emb', g['user_emb'], alpha[0], l2c, stream)
+        self._adam('item_emb', g['item_emb'], alpha[1], l2c, stream)
+        self._adam('W1', g['W1'], alpha[4 + self.L], l2c, stream)
+        self._adam('b1', g['b1'], alpha[5 + self.L], 0.0, stream)
         sg = AdamSegments()
         sg.n = len(self.seg)
         for i, (_, start, n, regd, layer) in enumerate(self.seg):
-            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha(layer), (l2c if regd else 0.0)
+            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[layer], (l2c if regd else 0.0)
         m, v = self.state['sw']
-        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), self.beta1, self.beta2, self.eps,
-                                   stream_ptr(self.device)), 'drx_adam_segments')
+        check(L_.drx_adam_segments(self.sw.data_ptr(), m.data_ptr(), v.data_ptr(), gsw.data_ptr(), C.byref(sg), self.beta1, self.beta2, self.eps,
+                                   stream), 'drx_adam_segments')
         if want_loss:
             return float((gsw[-1] + reg_loss).item())
         return None
