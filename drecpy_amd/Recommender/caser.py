@@ -97,6 +97,8 @@ class Caser(RecommenderABC):
             before = np.asarray(iid[in_rows], dtype=np.int64).reshape(batch_size, L)
             after = np.concatenate([np.asarray(iid[tg_rows], dtype=np.int64).reshape(batch_size, T),
                                     negs.astype(np.int64).reshape(batch_size, Tn)], axis=1)
+            # (the engine's host-side preparation of the batch — lookups grouped by table row — stays with _do_batch on the main
+            # thread: the ListSampler stream on this worker thread is what bounds Caser.fit())
             return np.asarray(grp, dtype=np.int64), before, after
         uids, before, after = [], [], []
         for pos, targets, negs in self._sampler.sample_group_records(batch_size):
@@ -106,7 +108,8 @@ class Caser(RecommenderABC):
         return uids, before, after
 
     def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
-        uids, before, after = batch_samples
+        uids, before, after = batch_samples[:3]
+        prep = batch_samples[3] if len(batch_samples) > 3 else None
         B = len(uids)
         keep, rate = None, 0.0
         if self.dropout_rate and self.dropout_rate > 0:
@@ -115,13 +118,16 @@ class Caser(RecommenderABC):
             # an injected mask (tests), else the kernel's counter-based mask keyed by (model seed, step): TF's dropout stream
             # cannot be reproduced, and 344 K host random numbers per batch of 4096 cost more than the device step
             keep = self._dropout_mask_fn(step, B, nx) if self._dropout_mask_fn is not None else None
+        if prep is not None:
+            return self._engine.step(step, prep, keep=keep, rate=rate, want_loss=want_loss,
+                                     mask_seed=self._drop_seed * 0x9E3779B97F4A7C15 + step + 1)
         return self._engine.step(step, np.asarray(uids), np.asarray(before), np.asarray(after), keep, rate,
                                  want_loss=want_loss, mask_seed=self._drop_seed * 0x9E3779B97F4A7C15 + step + 1)
 
     def _predict_batch(self, batch_samples, **kwds):
         """Sigmoid scores of the batch's targets (caser.py:86-95, evaluation mode: no dropout)."""
         import torch
-        uids, before, after = batch_samples
+        uids, before, after = batch_samples[:3]
         with self._device_lock:
             sc = self._engine.scores_all(np.asarray(uids), np.asarray(before))
         idx = torch.as_tensor(np.asarray(after), device=sc.device, dtype=torch.long)

@@ -34,6 +34,70 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ p, fl
   }
 }
 
+// A table whose gradient is a sum of lookup rows AND whose optimizer is dense (Keras Adam on an Embedding / Dense kernel: the
+// moments of every row decay every step): gradient and update in one pass over the table, from the lookups grouped by row on the
+// host (drx_batch_csr: counting sort, lookups of a row in batch order).  One group of G lanes per row:
+//   g = sum over the row's lookups q (ascending) of src[order[q]];  p, m, v <- Adam(g + l2c * p)     (+ the same for one scalar per row)
+// No touch keys on the device, no sort, no zeroed gradient table, no separate optimizer launch.
+template <int G, int J>
+__global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restrict__ ptr, const int32_t *__restrict__ order,
+                                                          const float *__restrict__ src, const float *__restrict__ src_s, int ld,
+                                                          int n_rows, float *p, float *m, float *v, float *ps, float *ms, float *vs,
+                                                          float alpha, float alpha_s, float l2c, float b1, float b2, float eps) {
+  const int lane = threadIdx.x % G;
+  const int gpb = kBlock / G;
+  for (int row = blockIdx.x * gpb + threadIdx.x / G; row < n_rows; row += gridDim.x * gpb) {
+    float4 w[J], mm[J], vv[J], g[J];
+    load_row<G, J>(p, (size_t)row, ld, lane, w);
+    load_row<G, J>(m, (size_t)row, ld, lane, mm);
+    load_row<G, J>(v, (size_t)row, ld, lane, vv);
+    float gs = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) g[j] = f4_zero();
+    const int q0 = ptr[row], q1 = ptr[row + 1];
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) {                    // four lookup rows in flight
+      const int o0 = order[q], o1 = order[q + 1], o2 = order[q + 2], o3 = order[q + 3];
+      float4 r0[J], r1[J], r2[J], r3[J];
+      load_row<G, J>(src, (size_t)o0, ld, lane, r0);
+      load_row<G, J>(src, (size_t)o1, ld, lane, r1);
+      load_row<G, J>(src, (size_t)o2, ld, lane, r2);
+      load_row<G, J>(src, (size_t)o3, ld, lane, r3);
+      if (src_s) gs = ((gs + src_s[o0]) + src_s[o1]) + src_s[o2] + src_s[o3];
+#pragma unroll
+      for (int j = 0; j < J; ++j) { f4_add(g[j], r0[j]); f4_add(g[j], r1[j]); f4_add(g[j], r2[j]); f4_add(g[j], r3[j]); }
+    }
+    for (; q < q1; ++q) {
+      const int o0 = order[q];
+      float4 r0[J];
+      load_row<G, J>(src, (size_t)o0, ld, lane, r0);
+      if (src_s) gs += src_s[o0];
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(g[j], r0[j]);
+    }
+    const OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, alpha};
+    float4 *pr = reinterpret_cast<float4 *>(p + (size_t)row * ld), *mr = reinterpret_cast<float4 *>(m + (size_t)row * ld),
+           *vr = reinterpret_cast<float4 *>(v + (size_t)row * ld);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = lane + j * G;
+      if (4 * c < ld) {
+        opt_update1(o, fmaf(l2c, w[j].x, g[j].x), w[j].x, mm[j].x, vv[j].x);
+        opt_update1(o, fmaf(l2c, w[j].y, g[j].y), w[j].y, mm[j].y, vv[j].y);
+        opt_update1(o, fmaf(l2c, w[j].z, g[j].z), w[j].z, mm[j].z, vv[j].z);
+        opt_update1(o, fmaf(l2c, w[j].w, g[j].w), w[j].w, mm[j].w, vv[j].w);
+        pr[c] = w[j]; mr[c] = mm[j]; vr[c] = vv[j];
+      }
+    }
+    if (ps && lane == 0) {
+      const OptScalars os{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, alpha_s};
+      float pp = ps[row], pm = ms[row], pv = vs[row];
+      opt_update1(os, gs, pp, pm, pv);
+      ps[row] = pp; ms[row] = pm; vs[row] = pv;
+    }
+  }
+}
+
 struct ScatterPolicy {
   const float *src;          // [n_src, ld]
   const uint32_t *src_index; // [T] row of src contributed by touch `pos` (nullptr: pos itself)
@@ -175,6 +239,27 @@ int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, floa
   int blocks = (int)std::min<int64_t>((n / 4 + kBlock - 1) / kBlock + 1, 4096);
   hipLaunchKernelGGL(k_adam_dense, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, p, m, v, g, (size_t)n, alpha, l2_coef,
                      beta1, beta2, eps);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float *src, const float *src_s, int32_t ld, int32_t n_rows,
+                      float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s, float l2_coef,
+                      float beta1, float beta2, float eps, void *stream) {
+  if (!row_ptr || !order || !src || !p || !m || !v || n_rows < 1 || ld < 4 || (ld & 3) || ld > DRX_MAX_K) return DRX_EINVAL;
+  if ((p_s != nullptr) != (src_s != nullptr) || (p_s && (!m_s || !v_s))) return DRX_EINVAL;
+  if (((uintptr_t)src | (uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(G, J)                                                                                                          \
+  {                                                                                                                         \
+    const int gpb = kBlock / G;                                                                                             \
+    int blocks = (n_rows + gpb - 1) / gpb;                                                                                  \
+    if (blocks > 8192) blocks = 8192;                                                                                       \
+    hipLaunchKernelGGL((k_rows_csr_adam<G, J>), dim3(blocks), dim3(kBlock), 0, st, row_ptr, order, src, src_s, ld, n_rows, p, m, v, \
+                       p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps);                                          \
+  }
+  DRX_DISPATCH_GEOM(ld, CALL);
+#undef CALL
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

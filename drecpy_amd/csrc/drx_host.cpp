@@ -594,6 +594,22 @@ void drx_drawahead_destroy(DrxDrawAhead *d) {
   delete d;
 }
 
+// Lookups grouped by the row they name: row_ptr [n_rows + 1], order [T] = the lookups (positions in `keys`) of row 0, then of row 1, ...,
+// each row's in ascending position — a stable counting sort on the host for drx_rows_csr_adam.
+int drx_batch_csr(const int32_t *keys, int32_t T, int32_t n_rows, int32_t *row_ptr, int32_t *order) {
+  if (!keys || !row_ptr || !order || T < 0 || n_rows < 1) return DRX_EINVAL;
+  for (int32_t r = 0; r <= n_rows; ++r) row_ptr[r] = 0;
+  for (int32_t t = 0; t < T; ++t) {
+    if (keys[t] < 0 || keys[t] >= n_rows) return DRX_EINVAL;
+    row_ptr[keys[t] + 1]++;
+  }
+  for (int32_t r = 0; r < n_rows; ++r) row_ptr[r + 1] += row_ptr[r];
+  for (int32_t t = 0; t < T; ++t) order[row_ptr[keys[t]]++] = t;
+  for (int32_t r = n_rows; r > 0; --r) row_ptr[r] = row_ptr[r - 1];
+  row_ptr[0] = 0;
+  return DRX_OK;
+}
+
 // Distinct ids of a batch (ascending) and what the DMF kernels index them with — counting through the caller's id -> rank scratch
 // instead of a sort (ids are bounded by the table size).  ~20 us for 4096 ids where the numpy version took 130.
 int32_t drx_batch_distinct(const int32_t *ids, int32_t B, int32_t n_rows, const int64_t *indptr, int32_t *scratch, int32_t *distinct,

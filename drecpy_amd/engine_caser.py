@@ -2,9 +2,10 @@
 
 One training step = the body of the reference fit() loop for Caser (recommender_abc.py:190-204 over caser.py:86-120):
   drx_caser_fwd_bwd     forward, Keras BCE, backward -> one gradient row per embedding lookup + small-weight gradients
-  drx_scatter_rows x3   lookups' rows -> dense gradient tables (item_emb, dense_1_W (+dense_1_b), user_emb)
-  drx_adam_dense x4     fused L2 (Keras l2(reg): 2*reg*w) + Keras Adam on the four tables, one lr_t per registered layer
+  drx_rows_csr_adam x3  lookups' rows -> gradient + L2 (Keras l2(reg): 2*reg*w) + Keras Adam of item_emb, dense_1_W (+dense_1_b), user_emb in
+                        one pass per table, from the lookups grouped by row on the host (drx_batch_csr); one lr_t per registered layer
   drx_adam_segments     the conv / dense_0 kernels and biases
+(table_update == 'scatter', for batches already on the device: drx_scatter_rows x3 into a zeroed gradient arena + drx_adam_dense x4)
 """
 import ctypes as C
 
@@ -168,30 +169,86 @@ class CaserEngine:
         A.mask_seed = int(mask_seed) & (2 ** 64 - 1)
         return A
 
+    # how the four lookup tables (user / item embeddings, dense_1_W + dense_1_b) are updated: 'csr' = drx_rows_csr_adam, gradient and
+    # dense Adam in one pass per table from the lookups grouped by row on the host (prepare_batch); 'scatter' = drx_scatter_rows into
+    # a zeroed gradient arena + drx_adam_dense (the only way for batches that are already on the device)
+    table_update = 'csr'
+
+    def prepare_batch(self, uids, before, after):
+        """Host half of a step (Caser.fit() runs it on the sampler's worker thread): the batch as int32 arrays plus, for each of the
+        three lookup lists, the lookups grouped by the table row they name (drx_batch_csr) — one host buffer for one upload."""
+        B = len(uids)
+        L_ = lib()
+        sizes = (B, B * self.L, B * self.Tp, self.N + 1, B * self.L, self.N + 1, B * self.Tp, self.U + 1, B)
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (4 * n + 15) & ~15
+        buf = np.empty(total, np.uint8)
+        view = lambda k: buf[offs[k]:offs[k] + 4 * sizes[k]].view(np.int32)
+        view(0)[:] = uids
+        view(1)[:] = np.asarray(before).reshape(-1)
+        view(2)[:] = np.asarray(after).reshape(-1)
+        base = buf.ctypes.data
+        for keys, T, n_rows, kp, ko in ((1, B * self.L, self.N, 3, 4), (2, B * self.Tp, self.N, 5, 6), (0, B, self.U, 7, 8)):
+            check(L_.drx_batch_csr(base + offs[keys], T, n_rows, base + offs[kp], base + offs[ko]), 'drx_batch_csr')
+        return {'buf': buf, 'offs': offs, 'B': B}
+
+    def _upload(self, buf):
+        st = self.__dict__.setdefault('_ring', {'i': 0, 'host': [None] * 4, 'ev': [None] * 4})
+        total = buf.nbytes
+        k = st['i'] % 4
+        st['i'] += 1
+        if st['host'][k] is None or st['host'][k].numel() < total:
+            st['host'][k] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
+            st['ev'][k] = torch.cuda.Event()
+        else:
+            st['ev'][k].synchronize()                 # the copy that last read this pinned slot has finished
+        st['host'][k].numpy()[:total] = buf
+        dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+        dev.copy_(st['host'][k][:total], non_blocking=True)
+        st['ev'][k].record(torch.cuda.current_stream(self.device))
+        return dev
+
     # ---- one training step ---------------------------------------------------------------------------------------
-    def step(self, step_idx, uids, before, after, keep=None, rate=0.0, want_loss=False, mask_seed=0):
-        """keep: explicit dropout keep mask [B, n_v + L*n_h] or None; with None and rate > 0 the kernel evaluates the counter-based
+    def step(self, step_idx, uids, before=None, after=None, keep=None, rate=0.0, want_loss=False, mask_seed=0):
+        """uids, before, after: the batch (arrays or device tensors) — or `uids` = what prepare_batch returned for it.
+        keep: explicit dropout keep mask [B, n_v + L*n_h] or None; with None and rate > 0 the kernel evaluates the counter-based
         mask drx_hash_u32(mask_seed, b, j) >= rate * 2^32 itself (no 344 K host random numbers per batch of 4096)."""
         L_ = lib()
-        if any(torch.is_tensor(a) for a in (uids, before, after, keep)):
-            uid, bef, aft = self._dev_i32(uids), self._dev_i32(before), self._dev_i32(after)
+        csr = None
+        if isinstance(uids, dict) or (self.table_update == 'csr' and not any(torch.is_tensor(a) for a in (uids, before, after))):
+            prep = uids if isinstance(uids, dict) else self.prepare_batch(uids, before, after)
+            dev = self._upload(prep['buf'])
+            B = prep['B']
+            pb = [dev.data_ptr() + o for o in prep['offs']]
+            uid_p, bef_p, aft_p = pb[0], pb[1], pb[2]
+            csr = pb[3:]
             kp = None
             if keep is not None:
-                kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
+                kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device, non_blocking=True) if not torch.is_tensor(keep) \
                     else keep.to(self.device, torch.uint8).contiguous()
-        else:                                          # host batch: one asynchronous copy for all of it
-            if getattr(self, '_stage', None) is None:
-                from ._staging import StagedUpload
-                self._stage = StagedUpload(self.device)
-            arrays = [np.ascontiguousarray(uids, dtype=np.int32), np.ascontiguousarray(before, dtype=np.int32),
-                      np.ascontiguousarray(after, dtype=np.int32)]
-            if keep is not None:
-                arrays.append(np.ascontiguousarray(keep, dtype=np.uint8))
-            _owner, views = self._stage(arrays)
-            uid, bef, aft = views[:3]
-            kp = views[3] if keep is not None else None
-        B = uid.numel()
-        assert bef.shape == (B, self.L) and aft.shape == (B, self.Tp)
+        else:
+            if any(torch.is_tensor(a) for a in (uids, before, after, keep)):
+                uid, bef, aft = self._dev_i32(uids), self._dev_i32(before), self._dev_i32(after)
+                kp = None
+                if keep is not None:
+                    kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
+                        else keep.to(self.device, torch.uint8).contiguous()
+            else:                                          # host batch: one asynchronous copy for all of it
+                if getattr(self, '_stage', None) is None:
+                    from ._staging import StagedUpload
+                    self._stage = StagedUpload(self.device)
+                arrays = [np.ascontiguousarray(uids, dtype=np.int32), np.ascontiguousarray(before, dtype=np.int32),
+                          np.ascontiguousarray(after, dtype=np.int32)]
+                if keep is not None:
+                    arrays.append(np.ascontiguousarray(keep, dtype=np.uint8))
+                _owner, views = self._stage(arrays)
+                uid, bef, aft = views[:3]
+                kp = views[3] if keep is not None else None
+            B = uid.numel()
+            assert bef.shape == (B, self.L) and aft.shape == (B, self.Tp)
+            uid_p, bef_p, aft_p = uid.data_ptr(), bef.data_ptr(), aft.data_ptr()
         z = dict(dtype=torch.float32, device=self.device)
         stream = stream_ptr(self.device)
         grid = L_.drx_caser_grid(C.byref(self.D), B)
@@ -205,8 +262,12 @@ class CaserEngine:
         _, rows, db1, gpart, lpart, gsw = wk
         base = rows.data_ptr()
         p_dE, p_dW1, p_dPu = base, base + 4 * n_dE, base + 4 * (n_dE + n_dW1)
-        self._grad_arena.zero_()
-        A = self._args(uid, bef, aft, kp, rate, mask_seed)
+        A = CaserArgs()
+        A.item_emb, A.user_emb, A.W1, A.b1, A.sw = (t.data_ptr() for t in (self.item_emb, self.user_emb, self.W1, self.b1, self.sw))
+        A.uid, A.before, A.after = uid_p, bef_p, aft_p
+        A.keep = kp.data_ptr() if kp is not None else None
+        A.rate, A.B = float(rate), int(B)
+        A.mask_seed = int(mask_seed) & (2 ** 64 - 1)
         A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = p_dE, p_dW1, db1.data_ptr(), p_dPu, gpart.data_ptr(), lpart.data_ptr()
         reg_loss = None
         if want_loss:                                   # Keras l2(reg) on the pre-update weights
@@ -216,17 +277,33 @@ class CaserEngine:
                     sq = sq + (self.sw[start:start + n] ** 2).sum()
             reg_loss = self.reg * sq
         check(L_.drx_caser_fwd_bwd(C.byref(self.D), C.byref(A), gsw.data_ptr(), stream), 'drx_caser_fwd_bwd')
-        g = self._grads
-        self._scatter(bef.data_ptr(), B * self.L, p_dE, self.ld, self.N, g['item_emb'].data_ptr(), stream=stream)
-        self._scatter(aft.data_ptr(), B * self.Tp, p_dW1, self.ld2, self.N, g['W1'].data_ptr(), src_s=db1.data_ptr(), out_s=g['b1'].data_ptr(),
-                      stream=stream)
-        self._scatter(uid.data_ptr(), B, p_dPu, self.ld, self.U, g['user_emb'].data_ptr(), stream=stream)
         alpha = self._alphas(step_idx)
         l2c = 2.0 * self.reg
-        self._adam('user_emb', g['user_emb'], alpha[0], l2c, stream)
-        self._adam('item_emb', g['item_emb'], alpha[1], l2c, stream)
-        self._adam('W1', g['W1'], alpha[4 + self.L], l2c, stream)
-        self._adam('b1', g['b1'], alpha[5 + self.L], 0.0, stream)
+        if csr is not None:
+            ptrE, ordE, ptrW, ordW, ptrU, ordU = csr
+            st_ = self.state
+            for rp, od, src, src_s, ld, n_rows, name, a, sname, a_s in (
+                    (ptrU, ordU, p_dPu, None, self.ld, self.U, 'user_emb', alpha[0], None, 0.0),
+                    (ptrE, ordE, p_dE, None, self.ld, self.N, 'item_emb', alpha[1], None, 0.0),
+                    (ptrW, ordW, p_dW1, db1.data_ptr(), self.ld2, self.N, 'W1', alpha[4 + self.L], 'b1', alpha[5 + self.L])):
+                p = getattr(self, name)
+                m, v = st_[name]
+                ps = ms = vs = None
+                if sname is not None:
+                    ps, (ms, vs) = getattr(self, sname).data_ptr(), (t.data_ptr() for t in st_[sname])
+                check(L_.drx_rows_csr_adam(rp, od, src, src_s, ld, n_rows, p.data_ptr(), m.data_ptr(), v.data_ptr(), ps, ms, vs, a, a_s, l2c,
+                                           self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam')
+        else:
+            self._grad_arena.zero_()
+            g = self._grads
+            self._scatter(bef_p, B * self.L, p_dE, self.ld, self.N, g['item_emb'].data_ptr(), stream=stream)
+            self._scatter(aft_p, B * self.Tp, p_dW1, self.ld2, self.N, g['W1'].data_ptr(), src_s=db1.data_ptr(), out_s=g['b1'].data_ptr(),
+                          stream=stream)
+            self._scatter(uid_p, B, p_dPu, self.ld, self.U, g['user_emb'].data_ptr(), stream=stream)
+            self._adam('user_emb', g['user_emb'], alpha[0], l2c, stream)
+            self._adam('item_emb', g['item_emb'], alpha[1], l2c, stream)
+            self._adam('W1', g['W1'], alpha[4 + self.L], l2c, stream)
+            self._adam('b1', g['b1'], alpha[5 + self.L], 0.0, stream)
         sg = AdamSegments()
         sg.n = len(self.seg)
         for i, (_, start, n, regd, layer) in enumerate(self.seg):

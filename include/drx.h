@@ -269,6 +269,18 @@ int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, floa
  *   touch names are left untouched (zero them first).  keys may hold DRX_KEY_NONE (ignored).  This is the gradient
  *   of an embedding lookup (tf.nn.embedding_lookup / Keras Embedding, caser.py:99-100,117-118; dmf.py:89-90 first layer). */
 size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows);
+/* The same gradient for a table whose optimizer is DENSE (Keras Adam on an Embedding / Dense kernel: every row's moments decay every
+ * step), fused with that optimizer's update — replaces drx_scatter_rows + drx_adam_dense (tape.gradient through the lookup and
+ * apply_gradients, recommender_abc.py:203-204, 328-334; caser.py:47-50, 66-69) without touch keys on the device, a sort or a zeroed
+ * gradient table.  row_ptr [n_rows + 1] / order [T]: the lookups grouped by the row they name, a row's lookups in batch order
+ * (drx_batch_csr on the host; device copies here).  Row r: g = sum of src[order[q]] for q in [row_ptr[r], row_ptr[r + 1]), ascending;
+ * p, m, v <- ApplyAdam(g + l2_coef * p) with lr_t = alpha.  src_s / p_s / m_s / v_s (all or none): one scalar per lookup / row
+ * updated the same way with alpha_s and no l2 (caser.py:69's dense_1_b next to dense_1_W). */
+int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float *src, const float *src_s, int32_t ld, int32_t n_rows,
+                      float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s, float l2_coef,
+                      float beta1, float beta2, float eps, void *stream);
+/* host: keys [T] in [0, n_rows) -> row_ptr [n_rows + 1], order [T] (stable counting sort) */
+int drx_batch_csr(const int32_t *keys, int32_t T, int32_t n_rows, int32_t *row_ptr, int32_t *order);
 int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const uint32_t *src_index, const float *coef,
                      const float *src_s, int32_t ld, int32_t n_rows, float *out, float *out_s, void *scratch,
                      size_t scratch_bytes, void *stream);

@@ -11,14 +11,16 @@ def _rel(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - b) / np.maximum(np.abs(b), 1e-12)))
 
 
+@pytest.mark.parametrize('update', ['csr', 'scatter'])      # the two ways the lookup tables are updated (engine_caser.py)
 @pytest.mark.parametrize('d,L,n_v,n_h,T,neg,B,drop', [(50, 5, 4, 16, 3, 3, 64, False), (16, 3, 2, 8, 2, 2, 37, True),
                                                       (64, 5, 4, 16, 3, 3, 300, True)])
-def test_caser_steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop):
+def test_caser_steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, update):
     from drecpy_amd.engine_caser import CaserEngine
     rng = np.random.default_rng(d + B)
     U, N = 40, 150
     p = ca.init_params(rng, U, N, L, d, n_v, n_h, np.float64)
     eng = CaserEngine(U, N, L, T, neg, d, n_v, n_h)
+    eng.table_update = update
     eng.set_params(p)
     eng.lr, eng.reg = 5e-3, 1e-4
     st = ca.adam_state(p)

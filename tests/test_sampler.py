@@ -351,3 +351,18 @@ def test_batch_distinct_matches_numpy(n, B):
     assert L.drx_batch_distinct(bad.ctypes.data, B, n, ip.ctypes.data, sc.ctypes.data, d.ctypes.data, inv.ctypes.data, gptr.ctypes.data,
                                 grows.ctypes.data, off.ctypes.data) == -1          # DRX_EINVAL
     assert (sc == -1).all()
+
+
+@pytest.mark.parametrize('n,T', [(3706, 20480), (6040, 512), (5, 0), (9, 40)])
+def test_batch_csr_is_a_stable_counting_sort(n, T):
+    """drx_batch_csr (the Caser step's host bookkeeping): lookups grouped by row, a row's lookups in batch order."""
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    keys = np.random.default_rng(n + T).integers(0, n, T).astype(np.int32)
+    ptr, order = np.empty(n + 1, np.int32), np.empty(max(T, 1), np.int32)
+    assert L.drx_batch_csr(keys.ctypes.data, T, n, ptr.ctypes.data, order.ctypes.data) == 0
+    assert np.array_equal(ptr, np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=n))]))
+    assert np.array_equal(order[:T], np.argsort(keys, kind='stable'))
+    if T:
+        keys[T // 2] = n
+        assert L.drx_batch_csr(keys.ctypes.data, T, n, ptr.ctypes.data, order.ctypes.data) == -1      # DRX_EINVAL
