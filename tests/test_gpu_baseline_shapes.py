@@ -2,6 +2,7 @@
 
   config 1  reference-mode CDAE step, ml-100k shape 943 x 1682, K = 50, B = 64  (examples/cdae.py)          vs fp64 oracle, 1/10/50 steps
   config 2  reference-mode CDAE step, ml-1m shape 6040 x 3706, K = 128, B = 64                              vs fp64 oracle, 1/10/50 steps
+            the same tables in the sampled-output / sparse-Adagrad engine mode, B = 4096, inline and prepared     vs fp64 oracle, 3 steps
   config 3  DMF [64,32] / [64,32] at 6040 x 3706, B = 256 and 4096 (+ the ModifiedDMF scalar, test_gpu_dmf)    vs dmf_oracle, 3 steps
             bf16-MFMA all-pairs scorer, 2048 users x 3706 items                                           vs fp32 and vs bf16-rounded fp32
   config 5  Caser d=50 L=5 T=3 n_v=4 n_h=16 at 6040 x 3706, B = 4096 (examples/caser.py:13-14)            vs caser_oracle, 2 steps
@@ -75,6 +76,46 @@ def test_reference_mode_cdae_at_baseline_shape(shape, K):
     g = eng.get_params()
     for k in p:
         np.testing.assert_allclose(g[k], p[k], rtol=0, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('prepared', [False, True])
+def test_sampled_mode_cdae_at_ml1m_shape(prepared):
+    """BASELINE config 1's engine mode at its shape: CDAE K = 128 on 6040 x 3706, one sampled output unit per triple, sparse Adagrad —
+    4096 triples per step (165-item histories: 0.54 M touches, every item row shared by ~150 samples), touch list inline and prepared
+    ahead (sole-toucher rows updated by the forward kernel), against the fp64 oracle."""
+    from drecpy_amd.engine import CdaeEngine
+    from helpers import hash_u32, q_threshold
+    U, N, indptr, indices = _history('ml-1m')
+    K, B, q, lr = 128, 4096, 0.2, 0.05
+    rng = np.random.default_rng(17)
+    p = co.init_params(rng, U, N, K, np.float64)
+    eng = CdaeEngine(U, N, K)
+    eng.set_params(**p)
+    eng.set_history(indptr, indices)
+    eng.init_optimizer('adagrad', lr, 1e-3)
+    st = co.sparse_state(p, 'adagrad')
+    qf, thr = float(np.float32(q)), q_threshold(q)
+    probe = rng.integers(0, U, size=32)
+    tp, _, _ = batch_rows(indptr, indices, probe, N)
+    for step in range(3):
+        uids = rng.integers(0, U, size=B)
+        iids = rng.integers(0, N, size=B)
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        _, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        seed = 4242 + step * 7919
+        deg = np.diff(keep_off)
+        keep = (hash_u32(seed, np.repeat(np.arange(B), deg), np.arange(keep_off[-1]) - np.repeat(keep_off[:-1], deg)) >= thr).astype(np.uint8)
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+        lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, lr, 1e-3, 'bce', 'adagrad')
+        lg = eng.step_sparse(step, bt, 'bce', want_loss=True, prepared=eng.prepare_sparse(bt) if prepared else None).cpu().numpy()
+        assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    _, pred = eng.forward(probe)
+    _, po = co.forward(p, probe, tp.astype(np.float64))
+    assert _relerr(pred.cpu().numpy(), po) < REL
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5, err_msg=k)
 
 
 def _ml1m_ratings():
