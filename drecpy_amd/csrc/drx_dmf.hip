@@ -14,6 +14,11 @@ namespace drx {
 constexpr float kL2NEps = 1e-12f;
 constexpr int kDmfMaxLayers = 4;
 
+// value of lane j (the same j for the whole wave: a loop counter) — v_readlane_b32 instead of a ds_bpermute through the LDS pipe
+__device__ __forceinline__ float lane_value(float x, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j));
+}
+
 struct TowerIO {
   const float *K0;            // [rows, ld0] first-layer kernel
   int ld0;
@@ -152,7 +157,7 @@ __device__ __forceinline__ float tower_dense(const DrxDmfDims &D, int tw, const 
     const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
     float zz = k < fo ? sw[D.off_b[tw][l] + k] : 0.f;
     for (int j = 0; j < fin; ++j) {
-      const float aj = __shfl(a, j);
+      const float aj = lane_value(a, j);
       if (k < fo) zz = fmaf(aj, sw[D.off_k[tw][l] + j * fo + k], zz);
     }
     z = zz; a = fmaxf(zz, 0.f);
@@ -173,12 +178,12 @@ __device__ __forceinline__ void tower_bwd(const DrxDmfDims &D, int tw, const Tow
     if (k < fo) gsw[D.off_b[tw][l] + k] += dz;
     float dprev = 0.f;
     for (int j = 0; j < fin; ++j) {
-      const float aj = __shfl(as[l - 1], j);
+      const float aj = lane_value(as[l - 1], j);
       if (k < fo) { const int w = D.off_k[tw][l] + j * fo + k; gsw[w] = fmaf(aj, dz, gsw[w]); }
     }
     // da_{l-1}[j] = sum_k dz[k] * K[j][k] : lane j walks its kernel row
     for (int kk = 0; kk < fo; ++kk) {
-      const float dzk = __shfl(dz, kk);
+      const float dzk = lane_value(dz, kk);
       if (k < fin) dprev = fmaf(dzk, sw[D.off_k[tw][l] + k * fo + kk], dprev);
     }
     da = dprev;
@@ -444,7 +449,7 @@ __device__ __forceinline__ void tower_bwd_store(const DrxDmfDims &D, int tw, con
     dzrow[l * 64 + k] = dz;
     float dprev = 0.f;
     for (int kk = 0; kk < fo; ++kk) {                // da_{l-1}[j] = sum_k dz[k] * K[j][k] : lane j walks its kernel row
-      const float dzk = __shfl(dz, kk);
+      const float dzk = lane_value(dz, kk);
       if (k < fin) dprev = fmaf(dzk, sw[D.off_k[tw][l] + k * fo + kk], dprev);
     }
     da = dprev;
