@@ -222,12 +222,14 @@ class MemoryInteractionDataset(InteractionDatasetABC):
             columns.append('rid')
         data_cols = [c for c in columns if c != 'rid']
         if len(self):
-            keys = [first_appearance_codes_host_safe(self._cols[c]) for c in data_cols]
-            comb = keys[0]
-            for k in keys[1:]:
-                comb = comb * (int(k.max()) + 1) + k
-            _, first = np.unique(comb, return_index=True)
-            first.sort()
+            first = _first_rows_of_dense_codes([self._cols[c] for c in data_cols])
+            if first is None:
+                keys = [first_appearance_codes_host_safe(self._cols[c]) for c in data_cols]
+                comb = keys[0]
+                for k in keys[1:]:
+                    comb = comb * (int(k.max()) + 1) + k
+                _, first = np.unique(comb, return_index=True)
+                first.sort()
         else:
             first = np.zeros(0, dtype=np.int64)
         new = self.copy() if copy else self
@@ -456,6 +458,35 @@ class MemoryInteractionDataset(InteractionDatasetABC):
             i = rng.randint(0, max_iid)
             if (u, i) not in pairs:
                 yield u, i
+
+
+def _first_rows_of_dense_codes(cols):
+    """Rows of the first occurrence of every distinct combination, ascending — for columns that are all small non-negative integers
+    (internal ids, ratings): one counting pass in libdrx (drx_first_occurrence) instead of np.unique's sort of every row.  None when the
+    columns are not of that kind (the general path then factorises them)."""
+    n = len(cols[0])
+    comb, span = None, 1
+    for c in cols:
+        a = np.asarray(c)
+        if a.dtype.kind not in 'iu' or n == 0:
+            return None
+        lo, hi = int(a.min()), int(a.max())
+        if lo < 0 or (hi + 1) * span > max(4 * n, 1 << 16):
+            return None
+        comb = a.astype(np.int64) if comb is None else comb * (hi + 1) + a
+        span *= hi + 1
+    try:
+        from .. import _lib
+        L = _lib.lib()
+    except Exception:
+        return None
+    comb = np.ascontiguousarray(comb, dtype=np.int64)
+    first = np.empty(span, np.int64)
+    if L.drx_first_occurrence(comb.ctypes.data, n, span, first.ctypes.data) < 0:
+        return None
+    first = first[first >= 0]
+    first.sort()
+    return first
 
 
 def first_appearance_codes_host_safe(col):

@@ -61,8 +61,11 @@ class ListSampler:
                 order = np.argsort(gcol, kind='stable')
             gs = gcol[order]
             cuts = np.flatnonzero(gs[1:] != gs[:-1]) + 1
-            for key, rows in zip(gs[np.concatenate([[0], cuts])].tolist(), np.split(order, cuts)):
-                self._rows_of_group[(key,)] = rows.tolist()
+            bounds = np.concatenate([[0], cuts, [len(order)]])
+            # (numpy slices of the one sorted order; a group's rows become a Python list only if the Python draw loop asks for them)
+            self._sorted_rows = (order, gs[bounds[:-1]], bounds)
+            for k, key in enumerate(gs[bounds[:-1]].tolist()):
+                self._rows_of_group[(key,)] = order[bounds[k]:bounds[k + 1]]
             self._presorted = True
         else:
             for row, key in enumerate(zip(*[ds._cols[c].tolist() for c in group_columns])):
@@ -89,16 +92,20 @@ class ListSampler:
         keep = None
         if self.interaction_threshold is not None:
             keep = np.asarray(ds._cols['interaction']) >= self.interaction_threshold
-        parts, lens = [], []
-        for g in self.unique_groups:                       # the order rng.choice indexes
-            rows = np.asarray(self._rows_of_group[self._group_key(g)], dtype=np.int64)
-            if keep is not None:
-                rows = rows[keep[rows]]
-            parts.append(rows)
-            lens.append(len(rows))
+        # every group's rows, groups in the order rng.choice indexes (first appearance), without a Python loop over the groups
+        order, sorted_keys, bounds = self._sorted_rows
+        pos = np.searchsorted(sorted_keys, np.asarray(self.unique_groups))
+        starts, glen = bounds[pos], bounds[pos + 1] - bounds[pos]
+        ends = np.cumsum(glen)
+        flat = order[np.repeat(starts - (ends - glen), glen) + np.arange(int(ends[-1]) if len(ends) else 0)].astype(np.int64)
+        gid = np.repeat(np.arange(len(glen)), glen)
+        if keep is not None:
+            sel = keep[flat]
+            flat, gid = flat[sel], gid[sel]
+        lens = np.bincount(gid, minlength=len(glen))
         from .. import _lib
         L = _lib.lib()
-        self._n_rows_flat = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        self._n_rows_flat = np.ascontiguousarray(flat)
         indptr = np.zeros(len(lens) + 1, dtype=np.int64)
         indptr[1:] = np.cumsum(lens)
         row_ids = np.ascontiguousarray(ids[self._n_rows_flat], dtype=np.int32)
@@ -109,7 +116,7 @@ class ListSampler:
         if not handle:
             return
         self._native = (L, handle)
-        self._max_group = max(lens) if lens else 0
+        self._max_group = int(lens.max()) if len(lens) else 0
         self._group_values = np.asarray(self.unique_groups)
 
     def __del__(self):
@@ -171,6 +178,8 @@ class ListSampler:
 
     def _positive_rows_uncached(self, key):
         rows = self._rows_of_group[key]
+        if isinstance(rows, np.ndarray):
+            rows = rows.tolist()
         if self.interaction_threshold is not None:
             values = self.interaction_dataset._cols['interaction']
             rows = [r for r in rows if values[r] >= self.interaction_threshold]

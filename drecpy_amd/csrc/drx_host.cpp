@@ -594,6 +594,20 @@ void drx_drawahead_destroy(DrxDrawAhead *d) {
   delete d;
 }
 
+// first[c] = position of the first occurrence of code c in codes[0..n) (or -1): Dataset.unique() on columns of small dense integer codes
+// without a sort.  Returns the number of distinct codes, or DRX_EINVAL for a code outside [0, n_codes).
+int64_t drx_first_occurrence(const int64_t *codes, int64_t n, int64_t n_codes, int64_t *first) {
+  if (!codes || !first || n < 0 || n_codes < 1) return DRX_EINVAL;
+  for (int64_t c = 0; c < n_codes; ++c) first[c] = -1;
+  int64_t distinct = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t c = codes[i];
+    if (c < 0 || c >= n_codes) return DRX_EINVAL;
+    if (first[c] < 0) { first[c] = i; ++distinct; }
+  }
+  return distinct;
+}
+
 // Lookups grouped by the row they name: row_ptr [n_rows + 1], order [T] = the lookups (positions in `keys`) of row 0, then of row 1, ...,
 // each row's in ascending position — a stable counting sort on the host for drx_rows_csr_adam.
 int drx_batch_csr(const int32_t *keys, int32_t T, int32_t n_rows, int32_t *row_ptr, int32_t *order) {

@@ -279,6 +279,9 @@ size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows);
 int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float *src, const float *src_s, int32_t ld, int32_t n_rows,
                       float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s, float l2_coef,
                       float beta1, float beta2, float eps, void *stream);
+/* host: first[c] = first position of code c in codes[0..n), -1 when absent; returns the number of distinct codes (Dataset.unique on
+ * dense integer code columns, mem_dataset.py's drop_duplicates, without a sort) */
+int64_t drx_first_occurrence(const int64_t *codes, int64_t n, int64_t n_codes, int64_t *first);
 /* host: keys [T] in [0, n_rows) -> row_ptr [n_rows + 1], order [T] (stable counting sort) */
 int drx_batch_csr(const int32_t *keys, int32_t T, int32_t n_rows, int32_t *row_ptr, int32_t *order);
 int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const uint32_t *src_index, const float *coef,
