@@ -1,0 +1,32 @@
+"""The one JSON line bench.py prints (the driver's contract): fields, types and internal consistency, on a short run of the small
+workload (a child process; the 10M x 1M default is what the driver itself times)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_has_the_contracted_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'ml-100k', '--batch', '4096', '--steps', '20',
+                          '--warmup', '5', '--no-hr'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['metric'].startswith('training samples/sec') and d['unit'] == 'samples/s' and d['higher_is_better'] is True
+    assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['scaling'] == 'weak' and d['data'] == 'synthetic'
+    assert d['vs_baseline'] is None and d['dtype'] == 'f32' and 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 4096 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6          # whole-job samples over the timed steps
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert 0.0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert r['traffic'] is None or r['traffic'] > 0                                       # (PMC passes are of the 10M x 1M workload)
+    for k in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
+        assert 0.0 < r['kernels'][k]['frac'] <= 1.0 and r['kernels'][k]['avg_launch_ms'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and c['unit'] == 'samples/s' and c['sample']
