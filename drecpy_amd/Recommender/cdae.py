@@ -168,8 +168,11 @@ class CDAE(RecommenderABC):
         self._mask_pos = 0                              # where the next batch begins
         self._draw_ticket = 0
         self._L, self._q_float = L, float(self.corruption_level)
-        self._drawahead = L.drx_drawahead_create(self._sampler._host._h, self._mask_rngs[0], self._mask_rngs[1],
-                                                 self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items)
+        # (reference mode only: the draw-ahead workers need the native host sampler, which a device-sampled fit never builds)
+        self._drawahead = None
+        if self.mode == 'reference':
+            self._drawahead = L.drx_drawahead_create(self._sampler._host._h, self._mask_rngs[0], self._mask_rngs[1],
+                                                     self._hist_indptr.ctypes.data, self._hist_indices.ctypes.data, self.n_items)
         self._mask_seed = int(seed)
 
     def _close_drawahead(self):
