@@ -157,3 +157,32 @@ def test_caser_activations_match_oracle(act_h, act_mlp):
         Caser(d=128)
     with pytest.raises(Exception, match='towers of 1..4 layers of width 1..64'):
         DMF(user_factors=[128, 64], item_factors=[64])
+
+
+@pytest.mark.parametrize('update', ['csr', 'scatter'])
+def test_caser_steps_with_repeated_lookups_and_single_sample(update):
+    """Edge cases of the lookup-table paths: one user in every sample, one item in every lookup of the batch (a table row that collects
+    hundreds of gradient rows while the others collect none), a window that names the same item L times, a batch of one — vs the oracle."""
+    from drecpy_amd.engine_caser import CaserEngine
+    rng = np.random.default_rng(5)
+    U, N, L, T, neg, d, n_v, n_h = 12, 30, 4, 2, 2, 20, 2, 8
+    Tp = T + T * neg
+    p = ca.init_params(rng, U, N, L, d, n_v, n_h, np.float64)
+    eng = CaserEngine(U, N, L, T, neg, d, n_v, n_h)
+    eng.table_update = update
+    eng.set_params(p)
+    eng.lr, eng.reg = 5e-3, 1e-4
+    st = ca.adam_state(p)
+    B = 40
+    batches = [(np.full(B, 7), rng.integers(0, N, size=(B, L)), rng.integers(0, N, size=(B, Tp))),            # one user
+               (rng.integers(0, U, size=B), np.full((B, L), 11), np.full((B, Tp), 11)),                        # one item everywhere
+               (rng.integers(0, U, size=B), np.repeat(rng.integers(0, N, size=(B, 1)), L, axis=1), rng.integers(0, N, size=(B, Tp))),
+               (np.array([3]), rng.integers(0, N, size=(1, L)), rng.integers(0, N, size=(1, Tp))),             # a batch of one
+               (rng.integers(0, U, size=B), rng.integers(0, N, size=(B, L)), rng.integers(0, N, size=(B, Tp)))]
+    for step, (uids, before, after) in enumerate(batches):
+        lo = ca.step(p, st, step, uids, before, after, T, 5e-3, 1e-4, None, 0.0)
+        lg = eng.step(step, uids, before, after, None, 0.0, want_loss=True)
+        assert abs(lg - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)

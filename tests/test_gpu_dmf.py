@@ -252,3 +252,41 @@ def test_update_weights_applies_keras_adam_on_the_device():
         want = x0 - co.adam_alpha(0.01, t) * (co.ADAM_OMB1 * g0) / (np.sqrt(co.ADAM_OMB2 * g0 * g0) + co.ADAM_EPS)
         np.testing.assert_allclose(var.numpy(), want, rtol=2e-6)
     assert m.optimizer.iterations == 2
+
+
+@pytest.mark.parametrize('update', ['scan', 'scatter'])
+def test_dmf_steps_with_empty_rows_columns_and_repeated_ids(update):
+    """Edge cases of the first-layer paths: users without any interaction and items nobody rated inside the batch (zero input vectors:
+    the l2 normaliser falls back to its epsilon), every sample the same user, every sample the same item — against the oracle."""
+    from drecpy_amd.engine_dmf import DmfEngine
+    rng = np.random.default_rng(23)
+    U, N = 40, 50
+    u = rng.integers(0, U - 5, size=400)                 # users U-5 .. U-1 have no row
+    i = rng.integers(0, N - 6, size=400)                 # items N-6 .. N-1 have no column
+    _, first = np.unique(u * N + i, return_index=True)
+    u, i = u[np.sort(first)], i[np.sort(first)]
+    v = rng.integers(1, 6, size=len(u)).astype(np.float64)
+    csr, csc = do.interaction_csr(u, i, v, U, N), do.interaction_csr(i, u, v, N, U)
+    dense = np.zeros((U, N))
+    dense[u, i] = v
+    p = dm.init_params(rng, U, N, (16, 8), (16, 8), np.float64)
+    eng = DmfEngine(U, N, (16, 8), (16, 8), True)
+    eng.set_interactions(csr, csc)
+    eng.first_layer_update = update
+    eng.set_params(p)
+    eng.lr, eng.reg = 2e-3, 1e-3
+    st = dm.adam_state(p)
+    B = 24
+    batches = [(rng.integers(0, U, size=B), rng.integers(0, N, size=B)),                       # mixes empty and non-empty ids
+               (np.full(B, U - 1), rng.integers(0, N, size=B)),                                # one user, and an empty one
+               (rng.integers(0, U, size=B), np.full(B, N - 1)),                                # one item, and an empty one
+               (np.full(B, 3), np.full(B, 7)),                                                 # one pair repeated
+               (rng.integers(0, U, size=B), rng.integers(0, N, size=B))]
+    for step, (uids, iids) in enumerate(batches):
+        y = rng.random(B)
+        lo = dm.step(p, st, step, dense[uids], dense[:, iids].T.copy(), y, 2e-3, 1e-3, 2, 2, True)
+        lg = eng.step(step, uids, iids, y, want_loss=True)
+        assert abs(lg - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
