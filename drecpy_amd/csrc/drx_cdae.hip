@@ -1594,6 +1594,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   S.solo_o = prepared ? R.solo_o : nullptr;
   SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
   DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
+  // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
+  const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
   // One workgroup per triple (its groups split the history) instead of one group per triple: when a group would walk many
   // dependent load rounds.  Short histories (mean <= 64 items): only while the batch cannot fill the chip anyway.
@@ -1621,8 +1623,12 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
       if (rc) return rc;                                                                                               \
     }                                                                                                                  \
     EV(2);                                                                                                             \
-    hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
-                       pol);                                                                                           \
+    if (long_segments)                                                                                               \
+      hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy, 8>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, \
+                         SB, pol);                                                                                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy, 2>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, \
+                         SB, pol);                                                                                     \
     EV(3);                                                                                                             \
     hipLaunchKernelGGL((k_sparse_tail_a<G, J>), dim3(1024 + n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, SB, pol, BA, \
                        1024);                                                                                          \

@@ -310,7 +310,7 @@ int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const ui
   DRX_HIP(hipMemsetAsync(L.sb.n_span, 0, 2 * sizeof(uint32_t), st));
 #define CALL(G, J)                                                                                                      \
   {                                                                                                                     \
-    hipLaunchKernelGGL((k_seg_reduce<G, J, ScatterPolicy>), dim3((L.sb.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)),        \
+    hipLaunchKernelGGL((k_seg_reduce<G, J, ScatterPolicy, 8>), dim3((L.sb.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)),     \
                        dim3(kBlock), 0, st, L.sb, pol);                                                                 \
     hipLaunchKernelGGL((k_span_short<G, J, ScatterPolicy>), dim3(256), dim3(kBlock), 0, st, L.sb, pol);                 \
     const size_t lds = ((size_t)(kFixBlock / G) * (ld + 1)) * 4;                                                        \
