@@ -1479,11 +1479,11 @@ int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHis
   };
   DrxOptim o = *opt;
   Pending cur{}, nxt{};
-  bool have_cur = false, have_nxt = false;
+  bool have_nxt = false;
   int64_t s = 0;
   if (n_steps > 0) {
     refill();
-    if (rc == DRX_OK) { take(cur); have_cur = true; }
+    if (rc == DRX_OK) take(cur);
   }
   for (; s < n_steps && rc == DRX_OK; ++s) {
     refill();
@@ -1527,11 +1527,9 @@ int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHis
       busy[released] = true;
     }
     cur = nxt;
-    have_cur = have_nxt;
   }
   // draws still in flight write into the caller's slots: wait for them whatever happened (their place in the streams is consumed)
   while (count > 0) { Pending drop; take(drop); }
-  (void)have_cur;
   cursor[0] = ticket;
   cursor[1] = (int64_t)mask_pos;
   cursor[2] = (int64_t)mask_at[0];

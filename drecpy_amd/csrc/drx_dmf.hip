@@ -100,12 +100,11 @@ __device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const
 // t % 4 == r; the four partial sums are combined by two exchanges.  Writes this wave's partial pre-activations (column k at
 // out[k]) — the training path (k_dmf_gather).
 template <int WV>
-__device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out,
-                                               float &rho_in) {
+__device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out) {
   const int id = T.ids[b];
   const int64_t s = T.indptr[id], e = T.indptr[id + 1];
   // (a popular item has thousands of non-zeros: forming the norm here, one load in flight per wave, was the kernel's tail)
-  rho_in = T.rho ? T.rho[id] : row_rho(D, T.values, s, e, k);
+  const float rho_in = T.rho ? T.rho[id] : row_rho(D, T.values, s, e, k);
   const int r = k >> 4, c = k & 15;
   const bool ok = 4 * c < T.ld0;
   float4 acc = f4_zero();
@@ -292,8 +291,7 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
   const int total = A.n_du + A.n_di;
   for (int it = blockIdx.x; it < total; it += gridDim.x) {
     const int tw = it < A.n_du ? 0 : 1, d = tw ? it - A.n_du : it;
-    float rho;
-    if (tw) tower_gather_q<WV>(D, 1, Ti, d, k, w, part + w * 64, rho); else tower_gather_q<WV>(D, 0, Tu, d, k, w, part + w * 64, rho);
+    if (tw) tower_gather_q<WV>(D, 1, Ti, d, k, w, part + w * 64); else tower_gather_q<WV>(D, 0, Tu, d, k, w, part + w * 64);
     if (A.map_u && threadIdx.x == 0) {               // for k_dmf_k0_update: which distinct index this id has in THIS step
       const int id = tw ? A.iid[d] : A.uid[d];
       (tw ? A.map_i : A.map_u)[id] = ((unsigned long long)A.stamp << 32) | (unsigned long long)(uint32_t)d;
