@@ -320,6 +320,9 @@ class CDAE(RecommenderABC):
             if hook in self.__dict__ or getattr(type(self), hook) is not getattr(CDAE, hook):
                 return 0
         B = int(batch_size)
+        from ..engine import CdaeEngine
+        if max(B * self._max_degree, 1) * CdaeEngine._FIT_SLOTS > (1 << 30):      # (the loop's pinned staging ring would exceed 1 GB)
+            return 0
         cursor = np.array([self._draw_ticket, self._mask_pos, self._mask_at[0], self._mask_at[1]], dtype=np.int64)
         try:
             with self._device_lock:
