@@ -615,7 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHisto
   }
 }
 
-template <int G, int J>
+template <int G, int J, int KIND = -1>
 __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOptim &opt, int B, uint32_t key, int lane,
                                              const float4 (&g)[J], float gs) {
   const uint32_t N = (uint32_t)P.n_items;
@@ -633,13 +633,14 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
   o.inv_k = 1.0f / (float)P.k;
   float4 w[J];
   load_row<G, J>(tab, row, P.ld, lane, w);
-  row_update<G, J>(o, tab, s1, s2, row, P.ld, lane, w, g);
+  row_update<G, J, KIND>(o, tab, s1, s2, row, P.ld, lane, w, g);
   if (var == 1 && lane == 0) {
-    float pb = P.b2[row], m = opt.s1[4][row], v = o.kind == DRX_OPT_ADAM ? opt.s2[4][row] : 0.f;
+    const int kind = KIND >= 0 ? KIND : o.kind;
+    float pb = P.b2[row], m = opt.s1[4][row], v = kind == DRX_OPT_ADAM ? opt.s2[4][row] : 0.f;
     o.rb = 0.f;
-    opt_update1(o, gs, pb, m, v);
+    opt_update1<KIND>(o, gs, pb, m, v);
     P.b2[row] = pb; opt.s1[4][row] = m;
-    if (o.kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
+    if (kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
   }
 }
 
@@ -676,7 +677,7 @@ __device__ __forceinline__ float sampled_hidden(const DrxCdaeParams &P, const Dr
   return group_sum<G>(d);
 }
 
-template <int G, int J>
+template <int G, int J, int KIND = -1>
 __device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, int loss_kind,
                                              const SparseBufs &S, int b, int lane, float d, const float4 (&h)[J],
                                              const float4 (&w2)[J]) {
@@ -700,20 +701,20 @@ __device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOp
   const uint8_t *const pv = S.solo_v, *const po = S.solo_o;
   const bool solo_v = pv && pv[b], solo_o = po && po[b];
   if (solo_o) {      // this sample alone touches W2T[i] and b2[i]: update them here (same arithmetic as the segment path)
-    sparse_apply<G, J>(P, opt, bt.B, (uint32_t)P.n_items + (uint32_t)i, lane, g2, dz2);
+    sparse_apply<G, J, KIND>(P, opt, bt.B, (uint32_t)P.n_items + (uint32_t)i, lane, g2, dz2);
   } else {
     store_row<G, J>(S.g2, (size_t)b, P.ld, lane, g2);
     if (lane == 0) S.dz2[b] = dz2;
   }
-  if (solo_v) sparse_apply<G, J>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
+  if (solo_v) sparse_apply<G, J, KIND>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
 }
 
-template <int G, int J>
+template <int G, int J, int KIND = -1>
 __device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, float scale,
                                                int loss_kind, const SparseBufs &S, int b, int lane, const float4 (&acc)[J]) {
   float4 h[J], w2[J];
   const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
-  sampled_rest<G, J>(P, opt, bt, loss_kind, S, b, lane, d, h, w2);
+  sampled_rest<G, J, KIND>(P, opt, bt, loss_kind, S, b, lane, d, h, w2);
 }
 
 // ---- column-sharded ("K-sharded") step: the two halves as kernels of their own, the all-reduce of dot[] between them ----------
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(kBlock) void k_kshard_rest(DrxCdaeParams P, DrxOpti
   sampled_rest<G, J>(P, opt, bt, loss_kind, S, b, lane, dot_total[b], h, w2);
 }
 
-template <int G, int J>
+template <int G, int J, int KIND = -1>
 __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
                                                             uint32_t qthr, int loss_kind, SparseBufs S) {
   const int lane = threadIdx.x % G;
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
   float4 acc[J];
   DenseAux none{};
   gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
-  sampled_finish<G, J>(P, opt, bt, scale, loss_kind, S, b, lane, acc);
+  sampled_finish<G, J, KIND>(P, opt, bt, scale, loss_kind, S, b, lane, acc);
 }
 
 // Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
@@ -814,7 +815,8 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_wg(DrxCdaeParams P, 
 
 // Policy of the single-GPU sparse step for the generic segmented reduction (drx_segreduce.hpp):
 // key space [0,N) W rows (contribution dz1[b] * 1/(1-q)), [N,2N) W2T rows (g2[b], scalar dz2[b] for b2), [2N,2N+U) V rows.
-struct DirectPolicy {
+template <int KIND>
+struct DirectPolicyT {
   DrxCdaeParams P;
   DrxOptim opt;
   int B;
@@ -835,9 +837,11 @@ struct DirectPolicy {
   }
   template <int G, int J>
   __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
-    sparse_apply<G, J>(P, opt, B, key, lane, g, gs);
+    sparse_apply<G, J, KIND>(P, opt, B, key, lane, g, gs);
   }
 };
+using DirectPolicy = DirectPolicyT<-1>;                      // optimizer chosen at run time
+using DirectPolicyAdagrad = DirectPolicyT<DRX_OPT_ADAGRAD>;  // the throughput configuration's optimizer, known at compile time
 
 // hidden bias b: column sums of dz1 in two deterministic stages, then a dense optimizer update.  Both stages are ROLES of
 // the two tail launches of the sparse step (k_sparse_tail_a / _b below): they share a launch with the span fix-ups, which
@@ -930,19 +934,19 @@ __device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const Dr
 // Tail of the sparse step in two launches instead of four:
 //   A (kBlock threads):    blocks [0, n_fix)  combine the SHORT chunk-crossing segments; the rest are the bias partials
 //   B (kFixBlock threads): blocks [0, n_fix)  combine the LONG ones (queued by A); one more block finishes the bias
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_sparse_tail_a(SegBufs S, DirectPolicy pol, BiasArgs A, int n_fix) {
+template <int G, int J, class POL = DirectPolicy>
+__global__ __launch_bounds__(kBlock) void k_sparse_tail_a(SegBufs S, POL pol, BiasArgs A, int n_fix) {
   extern __shared__ __align__(16) float lds[];   // [kBlock/G, ld]
   __shared__ float red[kBlock / 64];
-  if ((int)blockIdx.x < n_fix) span_short_body<G, J, DirectPolicy>(S, pol, (int)blockIdx.x, n_fix);
+  if ((int)blockIdx.x < n_fix) span_short_body<G, J, POL>(S, pol, (int)blockIdx.x, n_fix);
   else bias_partial_body<G, J, kBlock>(S.ld, A, (int)blockIdx.x - n_fix, lds, red);
 }
 
-template <int G, int J>
-__global__ __launch_bounds__(kFixBlock) void k_sparse_tail_b(SegBufs S, DirectPolicy pol, BiasArgs A, int n_fix) {
+template <int G, int J, class POL = DirectPolicy>
+__global__ __launch_bounds__(kFixBlock) void k_sparse_tail_b(SegBufs S, POL pol, BiasArgs A, int n_fix) {
   extern __shared__ __align__(16) float lds[];   // [kFixBlock/G, ld] + [kFixBlock/G]
   __shared__ float red[kFixBlock / 64];
-  if ((int)blockIdx.x < n_fix) span_long_body<G, J, DirectPolicy>(S, pol, (int)blockIdx.x, n_fix, lds);
+  if ((int)blockIdx.x < n_fix) span_long_body<G, J, POL>(S, pol, (int)blockIdx.x, n_fix, lds);
   else bias_final_body<G, J, kFixBlock>(pol.P, pol.opt, A, lds, red);
 }
 
@@ -1591,7 +1595,6 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   S.solo_v = prepared ? R.solo_v : nullptr;
   S.solo_o = prepared ? R.solo_o : nullptr;
   SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
-  DirectPolicy pol{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};
   // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
   const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
@@ -1601,6 +1604,26 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
+  // the segmented reduction and its two fix-up launches, with the policy type POLT (optimizer at run time, or Adagrad compiled in)
+#define REDUCE_AND_TAILS(G, J, POLT)                                                                                   \
+  {                                                                                                                    \
+    POLT polk{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};                                        \
+    if (long_segments)                                                                                                 \
+      hipLaunchKernelGGL((k_seg_reduce<G, J, POLT, 8>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
+                         polk);                                                                                        \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_seg_reduce<G, J, POLT, 2>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
+                         polk);                                                                                        \
+    EV(3);                                                                                                             \
+    hipLaunchKernelGGL((k_sparse_tail_a<G, J, POLT>), dim3(1024 + n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, SB, polk, BA, \
+                       1024);                                                                                          \
+    EV(4);                                                                                                             \
+    if (lds_b > 48 * 1024)                                                                                             \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_sparse_tail_b<G, J, POLT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds_b));                                                                        \
+    hipLaunchKernelGGL((k_sparse_tail_b<G, J, POLT>), dim3(256 + 1), dim3(kFixBlock), lds_b, st, SB, polk, BA, 256);   \
+    EV(5);                                                                                                             \
+  }
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
@@ -1612,6 +1635,9 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     else if (per_wg)                                                                                                   \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
                          *bt, scale, qthr, loss_kind, S);                                                              \
+    else if (opt->kind == DRX_OPT_ADAGRAD)                                                                             \
+      hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, \
+                         *hist, *bt, scale, qthr, loss_kind, S);                                                       \
     else                                                                                                               \
       hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt,  \
                          scale, qthr, loss_kind, S);                                                                   \
@@ -1621,24 +1647,12 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
       if (rc) return rc;                                                                                               \
     }                                                                                                                  \
     EV(2);                                                                                                             \
-    if (long_segments)                                                                                               \
-      hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy, 8>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, \
-                         SB, pol);                                                                                     \
-    else                                                                                                             \
-      hipLaunchKernelGGL((k_seg_reduce<G, J, DirectPolicy, 2>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, \
-                         SB, pol);                                                                                     \
-    EV(3);                                                                                                             \
-    hipLaunchKernelGGL((k_sparse_tail_a<G, J>), dim3(1024 + n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, SB, pol, BA, \
-                       1024);                                                                                          \
-    EV(4);                                                                                                             \
-    if (lds_b > 48 * 1024)                                                                                             \
-      DRX_HIP(hipFuncSetAttribute((const void *)k_sparse_tail_b<G, J>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                  (int)lds_b));                                                                        \
-    hipLaunchKernelGGL((k_sparse_tail_b<G, J>), dim3(256 + 1), dim3(kFixBlock), lds_b, st, SB, pol, BA, 256);          \
-    EV(5);                                                                                                             \
+    if (opt->kind == DRX_OPT_ADAGRAD) { REDUCE_AND_TAILS(G, J, DirectPolicyAdagrad); }                                 \
+    else { REDUCE_AND_TAILS(G, J, DirectPolicy); }                                                                     \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL
+#undef REDUCE_AND_TAILS
 #undef EV
   DRX_LAUNCH_CHECK();
   return DRX_OK;
