@@ -27,7 +27,7 @@ constexpr int kChunk = DRX_CHUNK;      // touches per group in the segmented red
 #define SEG_GPB(G) (drx::kBlock / (G))
 #endif
 constexpr int kShortSpan = 64;     // chunk borders a segment may cross and still be combined by one group
-constexpr int kFixBlock = 1024;
+constexpr int kFixBlock = 512;     // (1024: the long-span fix-up kernel hit the 128-VGPR cap of a 16-wave workgroup and spilled)
 
 struct SegBufs {
   const uint32_t *keys_s, *vals_s;            // [T] sorted touches (padding keys DRX_KEY_NONE sort last)
