@@ -122,6 +122,7 @@ __global__ __launch_bounds__(THREADS) void k_hidden_fwd_wg(DrxCdaeParams P, DrxH
   if (r == 0) {
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+#pragma unroll 8
     for (int rr = 0; rr < R; ++rr) {
       float4 v[J];
       load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(THREADS) void k_hidden_bwd(int ld, int B, int n_sla
     float4 t[J], hv[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) t[j] = f4_zero();
+#pragma unroll 8
     for (int rr = 0; rr < R; ++rr) {
       float4 v[J];
       load_row<G, J>(lds, (size_t)rr, ld, lane, v);
@@ -748,6 +750,7 @@ __global__ __launch_bounds__(kBlock) void k_kshard_fwd_wg(DrxCdaeParams P, DrxHi
   if (r != 0) return;
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+#pragma unroll 8
   for (int rr = 0; rr < R; ++rr) {
     float4 v[J];
     load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_wg(DrxCdaeParams P, 
   if (r != 0) return;
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+#pragma unroll 8
   for (int rr = 0; rr < R; ++rr) {
     float4 v[J];
     load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
@@ -874,6 +878,7 @@ __device__ __forceinline__ void bias_partial_body(int ld, const BiasArgs &A, int
     float4 t[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) t[j] = f4_zero();
+#pragma unroll 8
     for (int rr = 0; rr < R; ++rr) {
       float4 v[J];
       load_row<G, J>(lds, (size_t)rr, ld, lane, v);
@@ -910,6 +915,7 @@ __device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const Dr
     float4 g[J], w[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) g[j] = f4_zero();
+#pragma unroll 8
     for (int rr = 0; rr < R; ++rr) {
       float4 v[J];
       load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);

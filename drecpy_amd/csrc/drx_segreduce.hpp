@@ -279,6 +279,7 @@ __device__ __forceinline__ void span_long_body(const SegBufs &S, const Policy &p
       float4 t[J];
       load_row<G, J>(S.ptail, (size_t)g0, S.ld, lane, t);
       float ts = S.pts[g0];
+#pragma unroll 8
       for (int rr = 0; rr < R; ++rr) {
         float4 v[J];
         load_row<G, J>(lds, (size_t)rr, S.ld, lane, v);

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_colsum_partial(int ld, int B, const 
     float4 t[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) t[j] = f4_zero();
+#pragma unroll 8
     for (int rr = 0; rr < R; ++rr) {
       float4 v[J];
       load_row<G, J>(lds, (size_t)rr, ld, lane, v);
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_colsum_final(int ld, const float *__
     float4 t[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) t[j] = f4_zero();
+#pragma unroll 8
     for (int rr = 0; rr < R; ++rr) {
       float4 v[J];
       load_row<G, J>(lds, (size_t)rr, ld, lane, v);
