@@ -583,21 +583,25 @@ struct SparseBufs {
   uint8_t *cflag;                             // [n_chunks]
   uint32_t *n_span;                           // [0] crossing segments, [1] long ones
   float *bpart;                               // [n_bpart, ld]
-  const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row
+  const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row; solo_v + 2B:
+                                              //   [B] sample b holds at least one W row that only it touches
+  const uint32_t *solo_w;                     // [ceil(N/32)] or nullptr: bit n set = W row n is touched by ONE sample of the batch
   int T, n_chunks, n_bpart;
 };
 
 // Touch list of one batch (row key, sample): depends only on the batch, never on the parameters, so it can be built
 // and sorted for batch t+1 while batch t trains (drx_cdae_sparse_prepare on a second stream).
-// Also clears the sole-toucher marks of the batch (solo: [2B] bytes or nullptr) and pads the slots beyond the last sample's up to
-// T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — two memsets the preparation would otherwise launch.
+// Also clears the sole-toucher marks of the batch (solo: [2B] bytes, solo_w: one bit per item; or nullptr) and pads the slots beyond
+// the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
 __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
-                                                           uint32_t *vals, int T, uint8_t *solo) {
+                                                           uint32_t *vals, int T, uint8_t *solo, uint32_t *solo_w) {
   constexpr int G = 16;
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (solo_w)
+    for (int w = blockIdx.x * kBlock + threadIdx.x; w < (n_items + 31) / 32; w += gridDim.x * kBlock) solo_w[w] = 0u;
   if (b >= bt.B) return;
-  if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; }
+  if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; solo[2 * (size_t)bt.B + b] = 0; }
   if (b == bt.B - 1)
     for (int j = bt.keep_off[bt.B] + 2 * bt.B + lane; j < T; j += G) { keys[j] = DRX_KEY_NONE; vals[j] = 0; }
   const int u = bt.uid[b];
@@ -646,21 +650,74 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
   }
 }
 
-// V and W2T rows are mostly touched by ONE sample of the batch (a user is drawn once, output items are uniform).  When the
-// touch list is prepared ahead of the step, such rows are marked here: the forward/backward kernel, which holds the
+// V and W2T rows are mostly touched by ONE sample of the batch (a user is drawn once, output items are uniform), and so are the W
+// rows of the long tail of unpopular items (10M x 1M set, B = 65 536: 2/3 of the distinct W rows of a batch, 1/8 of the W touches).
+// When the touch list is prepared ahead of the step, such rows are marked here: the forward/backward kernel, which holds the
 // sample's gradient rows in registers, then applies their update itself (no g2 row written, no re-read of the gradient
 // and of the parameter row later), and the touch is blanked (DRX_KEY_NONE) so that the segmented reduction passes over
-// it.  A sole toucher cannot race: no other sample of the batch reads or writes that V / W2T row.
-__global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, uint32_t n_items, uint8_t *solo_v,
-                            uint8_t *solo_o) {
+// it.  A sole toucher cannot race: no other sample of the batch reads or writes that row.  V / W2T marks are a byte per sample;
+// a W mark is a bit per ITEM (solo_w; nullptr = W rows are not marked) plus a byte per sample "holds a marked item" (solo_v + 2B):
+// such a sample walks its history a second time and finds the item by its bit (solo_w_pass).
+__global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, uint32_t n_items, int B, uint8_t *solo_v,
+                            uint8_t *solo_o, uint32_t *solo_w) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
     const uint32_t k = keys_s[j];
-    if (k == DRX_KEY_NONE || k < n_items) continue;
+    if (k == DRX_KEY_NONE || (k < n_items && !solo_w)) continue;
     const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
     if (k == prev || k == next) continue;            // (a neighbour blanked concurrently was a different key anyway)
     const uint32_t b = vals_s[j];
-    if (k < 2 * n_items) solo_o[b] = 1; else solo_v[b] = 1;
+    if (k < n_items) { atomicOr(&solo_w[k >> 5], 1u << (k & 31)); solo_v[2 * (size_t)B + b] = 1; }
+    else if (k < 2 * n_items) solo_o[b] = 1;
+    else solo_v[b] = 1;
     keys_s[j] = DRX_KEY_NONE;
+  }
+}
+
+// Second walk over a triple's history, after its gradient row dz1 is known: the kept items whose W row carries a sole-toucher
+// mark get their sparse update here, from registers (gradient scale * dz1[b], exactly the one-touch segment the reduction would have
+// folded: same arithmetic, same bits).  The indices come from L1/L2 (the gather read them a moment ago), the mark words from the
+// 125 KB bitmap; per marked row: parameter row (just gathered: L2) + slot row in, both out.
+template <int G, int J, int KIND = -1>
+__device__ __forceinline__ void solo_w_pass(const DrxCdaeParams &P, const DrxOptim &opt, const DrxHistory &H, const DrxBatch &bt,
+                                            uint32_t qthr, float scale, const uint32_t *__restrict__ solo_w, int b, int lane,
+                                            const float4 (&dz1)[J]) {
+  const int gshift = (threadIdx.x & 63) / G * G;
+  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+  float4 g[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { g[j] = f4_zero(); f4_fma(g[j], scale, dz1[j]); }
+  // (b laundered: the walk re-reads uid / indptr instead of keeping the gather's copies alive in registers through the whole kernel —
+  // 65 instead of 62 VGPRs would cost the forward kernel its eighth wave per SIMD)
+  int bq = b;
+  asm volatile("" : "+v"(bq));
+  const int u = bt.uid[bq];
+  const int64_t s = H.indptr[u];
+  const int n = (int)(H.indptr[u + 1] - s);
+  const int32_t *const ind = H.indices + s;
+  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
+  constexpr int IPL = G >= 16 ? 1 : 16 / G;
+  constexpr int CH = G * IPL;
+  for (int c = 0; c < n; c += CH) {
+    int idx[IPL], sw[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int jj = c + r * G + lane;
+      idx[r] = 0; sw[r] = 0;
+      if (jj < n) {
+        idx[r] = ind[jj];
+        const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, (uint32_t)jj) >= qthr);
+        if (kf) sw[r] = (int)((solo_w[idx[r] >> 5] >> (idx[r] & 31)) & 1u);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      unsigned long long m = (__ballot(sw[r] != 0) >> gshift) & gmask;
+      while (m) {
+        const int t = __builtin_ctzll(m);
+        m &= m - 1;
+        sparse_apply<G, J, KIND>(P, opt, bt.B, (uint32_t)__shfl(idx[r], t, G), lane, g, 0.f);
+      }
+    }
   }
 }
 
@@ -680,9 +737,9 @@ __device__ __forceinline__ float sampled_hidden(const DrxCdaeParams &P, const Dr
 }
 
 template <int G, int J, int KIND = -1>
-__device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, int loss_kind,
-                                             const SparseBufs &S, int b, int lane, float d, const float4 (&h)[J],
-                                             const float4 (&w2)[J]) {
+__device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOptim &opt, const DrxHistory &H, const DrxBatch &bt,
+                                             float scale, uint32_t qthr, int loss_kind, const SparseBufs &S, int b, int lane,
+                                             float d, const float4 (&h)[J], const float4 (&w2)[J]) {
   const int u = bt.uid[b], i = bt.iid[b];
   const float y = bt.y[b];
   const float p = sigmoidf_(d + P.b2[i]);
@@ -709,14 +766,17 @@ __device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOp
     if (lane == 0) S.dz2[b] = dz2;
   }
   if (solo_v) sparse_apply<G, J, KIND>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
+  const uint32_t *const pw = S.solo_w;
+  if (pw && pv[2 * (size_t)bt.B + b]) solo_w_pass<G, J, KIND>(P, opt, H, bt, qthr, scale, pw, b, lane, dz1);
 }
 
 template <int G, int J, int KIND = -1>
-__device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const DrxOptim &opt, const DrxBatch &bt, float scale,
-                                               int loss_kind, const SparseBufs &S, int b, int lane, const float4 (&acc)[J]) {
+__device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const DrxOptim &opt, const DrxHistory &H, const DrxBatch &bt,
+                                               float scale, uint32_t qthr, int loss_kind, const SparseBufs &S, int b, int lane,
+                                               const float4 (&acc)[J]) {
   float4 h[J], w2[J];
   const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
-  sampled_rest<G, J, KIND>(P, opt, bt, loss_kind, S, b, lane, d, h, w2);
+  sampled_rest<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, d, h, w2);
 }
 
 // ---- column-sharded ("K-sharded") step: the two halves as kernels of their own, the all-reduce of dot[] between them ----------
@@ -763,7 +823,8 @@ __global__ __launch_bounds__(kBlock) void k_kshard_fwd_wg(DrxCdaeParams P, DrxHi
 }
 
 template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_kshard_rest(DrxCdaeParams P, DrxOptim opt, DrxBatch bt, int loss_kind, SparseBufs S,
+__global__ __launch_bounds__(kBlock) void k_kshard_rest(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+                                                        uint32_t qthr, int loss_kind, SparseBufs S,
                                                         const float *__restrict__ h_in, const float *__restrict__ dot_total) {
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
@@ -772,7 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_kshard_rest(DrxCdaeParams P, DrxOpti
   float4 h[J], w2[J];
   load_row<G, J>(h_in, (size_t)b, P.ld, lane, h);
   load_row<G, J>(P.W2T, (size_t)bt.iid[b], P.ld, lane, w2);
-  sampled_rest<G, J>(P, opt, bt, loss_kind, S, b, lane, dot_total[b], h, w2);
+  sampled_rest<G, J>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, dot_total[b], h, w2);
 }
 
 template <int G, int J, int KIND = -1>
@@ -785,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
   float4 acc[J];
   DenseAux none{};
   gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
-  sampled_finish<G, J, KIND>(P, opt, bt, scale, loss_kind, S, b, lane, acc);
+  sampled_finish<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, acc);
 }
 
 // Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
@@ -814,7 +875,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_wg(DrxCdaeParams P, 
 #pragma unroll
     for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
   }
-  sampled_finish<G, J>(P, opt, bt, scale, loss_kind, S, b, lane, acc);
+  sampled_finish<G, J>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, acc);
 }
 
 // Policy of the single-GPU sparse step for the generic segmented reduction (drx_segreduce.hpp):
@@ -1022,7 +1083,8 @@ struct PrepBufs {
   uint32_t *keys_s, *vals_s, *keys, *vals;
   void *sort_temp;
   size_t sort_bytes;
-  uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo)
+  uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo); then [B] "holds a marked W row"
+  uint32_t *solo_w;             // [ceil(N/32)] one bit per item
   size_t result_bytes;
   int T, bits;
 };
@@ -1035,8 +1097,9 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   // prepares a list for the others), then what only the preparation itself needs
   R.keys_s = cv.take<uint32_t>(R.T);
   R.vals_s = cv.take<uint32_t>(R.T);
-  R.solo_v = cv.take<uint8_t>((size_t)2 * B);
+  R.solo_v = cv.take<uint8_t>((size_t)3 * B);
   R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
+  R.solo_w = cv.take<uint32_t>(((size_t)P.n_items + 31) / 32);
   R.result_bytes = align_up(cv.off, 256);
   R.keys = cv.take<uint32_t>(R.T);
   R.vals = cv.take<uint32_t>(R.T);
@@ -1554,19 +1617,31 @@ int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHis
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
   const int gpb = kBlock / 16;
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
-                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v);
+                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w);
   // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
   return sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, true, st);
 }
 
+// W rows get sole-toucher marks where a batch leaves most of its distinct W rows with one touch: few touches per item on average.
+// (MovieLens shapes: every item collects hundreds of touches, nothing would be marked, and the second walk costs a pass over the
+// 165-item histories.)  DRX_SOLO_W=0/1 in the environment overrides the rule (experiments).
+static bool mark_w_rows(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &) {
+  static const int forced = [] { const char *e = getenv("DRX_SOLO_W"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  return (int64_t)bt->n_touch_slots <= 4 * (int64_t)p->n_items;
+}
+
 // Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
 static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
-  if (!cleared) DRX_HIP(hipMemsetAsync(R.solo_v, 0, (size_t)bt->B * 2, st));      // (prepare_impl's touch kernel clears them)
+  if (!cleared) {                                                                  // (prepare_impl's touch kernel clears them)
+    DRX_HIP(hipMemsetAsync(R.solo_v, 0, (size_t)bt->B * 3, st));
+    DRX_HIP(hipMemsetAsync(R.solo_w, 0, (((size_t)p->n_items + 31) / 32) * sizeof(uint32_t), st));
+  }
   // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
   // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
   if (p->ld <= 16) return DRX_OK;       // solo_v and solo_o are adjacent
-  hipLaunchKernelGGL(k_mark_solo, dim3(2048), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, (uint32_t)p->n_items, R.solo_v,
-                     R.solo_o);
+  hipLaunchKernelGGL(k_mark_solo, dim3(2048), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, (uint32_t)p->n_items, bt->B, R.solo_v,
+                     R.solo_o, mark_w_rows(p, bt, R) ? R.solo_w : nullptr);
   return DRX_OK;
 }
 
@@ -1600,6 +1675,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
   S.solo_v = prepared ? R.solo_v : nullptr;
   S.solo_o = prepared ? R.solo_o : nullptr;
+  S.solo_w = (prepared && p->ld > 16 && mark_w_rows(p, bt, R)) ? R.solo_w : nullptr;       // (the rule mark_solo followed)
   SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
   // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
   const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
@@ -1636,8 +1712,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
     EV(0);                                                                                                             \
     if (ks_h)                                                                                                          \
-      hipLaunchKernelGGL((k_kshard_rest<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *bt, loss_kind, S, \
-                         ks_h, ks_dot);                                                                                \
+      hipLaunchKernelGGL((k_kshard_rest<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt, scale, \
+                         qthr, loss_kind, S, ks_h, ks_dot);                                                            \
     else if (per_wg)                                                                                                   \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
                          *bt, scale, qthr, loss_kind, S);                                                              \
