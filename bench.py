@@ -2,23 +2,30 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synth-10m|ml-1m|ml-100k] [--batch B]
 
-A "step" is one pass of the hot path over one batch of B (u, i, y) triples per GPU: gather + hidden layer + sampled
-output unit + BCE + backward + sparse-Adagrad update (drx_cdae_step_sparse_prepared).  At 1 GPU every step trains on a
-FRESH batch drawn by the device PointSampler (drx_point_sample) five steps ahead on a side stream, and the batch's sorted
-touch list (drx_cdae_sparse_prepare) is built three steps ahead on the same side stream — both depend only on the data,
-never on the parameters — so the timed region is the whole training loop including sampling (`--presampled` cycles
-through batches sampled at setup instead).  All inputs live in HBM; nothing crosses PCIe in the timed region except the
-8-byte touch count the sampler posts to a pinned mailbox per step.  One process per GPU; for N > 1 launch with
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RCCL over xGMI).  The N-GPU layout is chosen with
-`--layout`: `columns` (default: every rank holds all rows x K/N columns of every table and trains on the same global batch of
-N x B triples — one all-reduce of B floats per step) or `rows` (the partitioning BASELINE.json describes: users and item rows
-sharded by range, rows and gradient rows travel by all-to-all(v)); `config.sharding` in the output says which one ran.
+A "step" is one pass of the hot path over one batch of B (u, i, y) triples per GPU: gather + hidden layer + sampled output unit + BCE +
+backward + sparse-Adagrad update (drx_cdae_step_sparse_prepared).  Every step trains on a FRESH batch drawn by the device PointSampler
+(drx_point_sample) on a side stream, and the batch's sorted touch list (drx_cdae_sparse_prepare) is built ahead on the same side stream —
+both depend only on the data, never on the parameters — so the timed region is the whole training loop including sampling.  All inputs
+live in HBM; nothing crosses PCIe in the timed region except the 8-byte touch count the sampler posts to a pinned mailbox per step.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline / hr_at_10).
+Timing: W warm-up steps, then `--windows` (default 5) back-to-back windows of EXACTLY K steps, each bracketed by barrier +
+synchronize on both sides and reduced by MAX over ranks; `value` and `ms_per_step` come from the MEDIAN window, `window_ms_min/max`
+give the spread (a 20-step window is 8 ms: one shot cannot tell 5 % from noise).
+
+N GPUs (one process per GPU, RCCL over xGMI).  `python bench.py --gpus N` starts the N ranks itself when WORLD_SIZE is not set (no
+GPU call is made by the starting process); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` every worker
+is its own rank's coordinator.  Either way each sharding LAYOUT runs in a fresh child process per rank (a fault in one layout cannot
+take the other's number with it): `rows` — BASELINE.json's partitioning: users (V rows, histories, samples) and item rows sharded by
+range, rows and gradient rows travel by all-to-all(v), bias by all-reduce — and `columns` — every rank all rows x K/N columns of every
+table on the same global batch, one all-reduce of B floats per step.  The line's headline is the faster layout; `layouts` carries
+both, `config.sharding` says which is which, `rccl_ranks` is the sum of an RCCL all-reduce of ones.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of roofline / cpu_baseline / hr_at_10 / configs).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,36 +40,190 @@ K = 128
 Q = 0.2
 NEG_RATIO = 5
 LR, REG = 0.05, 1e-3
+LAYOUTS = ('rows', 'columns')
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--windows', type=int, default=5, help='back-to-back timed windows of --steps steps; value = median window')
     ap.add_argument('--workload', default='synth-10m', choices=['synth-10m', 'ml-1m', 'ml-100k'])
     ap.add_argument('--batch', type=int, default=65536, help='triples per GPU per step')
     ap.add_argument('--n-batches', type=int, default=8, help='batches sampled at setup (R estimate, CPU baseline; cycled with --presampled)')
     ap.add_argument('--presampled', action='store_true', help='cycle through the setup batches instead of sampling a fresh batch every step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-all-cores', action='store_true', help='skip the all-cores CPU baseline (one worker process per host core)')
+    ap.add_argument('--cpu-budget-s', type=float, default=12.0)
+    ap.add_argument('--cpu-triples', type=int, default=1024)
     ap.add_argument('--no-hr', action='store_true', help='skip the HR@10 sanity run (ml-100k-shaped set, reference mode)')
-    ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of one batch ahead on a side stream')
+    ap.add_argument('--no-configs', action='store_true', help='skip the `configs` block (BASELINE configurations 2, 3, 5)')
+    ap.add_argument('--force-configs', action='store_true', help='emit the `configs` block whatever the main workload is (tests)')
+    ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of ahead on a side stream')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
     ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'adam', 'rowwise_adagrad'], help='sparse optimizer of the sampled mode (S = 1 / 2 slots per parameter; single-GPU path)')
     ap.add_argument('--k', type=int, default=0, help='hidden factors (default 128); with --force-columns --k 128/N --batch 65536*N one GPU runs the '
                                                       'shape of ONE rank of an N-GPU column-sharded job')
-    ap.add_argument('--layout', default='columns', choices=['columns', 'rows'],
-                    help='multi-GPU layout: columns = every rank all rows x K/N columns, same global batch, one all-reduce of B scalars per step; '
-                         'rows = users and item rows sharded by range, rows and gradient rows travel by all-to-all')
+    ap.add_argument('--layout', default='both', choices=['both', 'columns', 'rows'],
+                    help='multi-GPU layout(s) to measure: rows = users and item rows sharded by range, rows and gradient rows travel by all-to-all '
+                         '(BASELINE.json); columns = every rank all rows x K/N columns, same global batch, one all-reduce of B scalars per step')
     ap.add_argument('--force-columns', action='store_true', help='run the column-sharded code path even at 1 GPU')
     ap.add_argument('--prepare', default='auto', choices=['auto', 'local', 'turns', 'parts'],
                     help='column layout, who sorts the touch list of a step: every rank all of it (local), rank s %% N for all (turns), every rank '
                          '1/N of it (parts); auto = turns from 4 GPUs on (at 2 it saves nothing), else local')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
-    return ap.parse_args()
+    ap.add_argument('--launch-dry-run', action='store_true', help='print the per-rank child command lines of an N-GPU run and exit (no GPU call)')
+    ap.add_argument('--launch-selftest', action='store_true', help='children only rendezvous over gloo and all-reduce on the CPU (tests the launcher)')
+    ap.add_argument('--layout-timeout-s', type=float, default=900.0, help='a layout whose children run longer is killed and reported as an error')
+    ap.add_argument('--child-layout', default=None, choices=['columns', 'rows', 'selftest'], help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# N-GPU launch: no GPU call anywhere in this section
+# ------------------------------------------------------------------------------------------------------------------------------
+def _child_argv(argv, layout):
+    """The command line of one rank's child for `layout`: this script with the same measurement flags."""
+    drop_with_value = {'--layout', '--child-layout', '--layout-timeout-s'}
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in drop_with_value:
+            skip = True
+            continue
+        if any(a.startswith(d + '=') for d in drop_with_value) or a in ('--launch-dry-run',):
+            continue
+        out.append(a)
+    return [sys.executable, os.path.join(ROOT, 'bench.py')] + out + ['--child-layout', layout]
+
+
+def _child_env(rank, local_rank, world, addr, port):
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith('TORCHELASTIC_') or k in ('GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE'):
+            env.pop(k)            # the children rendezvous among themselves (rank 0's child hosts the store), not through an agent
+    env.update({'RANK': str(rank), 'LOCAL_RANK': str(local_rank), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
+                'MASTER_ADDR': addr, 'MASTER_PORT': str(port)})
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: the only kind the host driver supports
+    return env
+
+
+def _layout_port(base, i):
+    return base + 211 + 37 * i          # away from the launcher's own rendezvous port; one port per layout
+
+
+def coordinate(args, argv, ranks, world, base_port, addr='127.0.0.1', local_of=None):
+    """Runs every layout as a set of fresh child processes — one per rank in `ranks` (all of them when this process started the job,
+    just its own under torch.distributed.run) — and, where rank 0 is among them, returns the merged line.  A layout whose children
+    fail or exceed the time limit is reported inside `layouts` and cannot be the headline."""
+    layouts = ['selftest'] if args.launch_selftest else (list(LAYOUTS) if args.layout == 'both' else [args.layout])
+    results, errors = {}, {}
+    local_of = local_of or {}
+    for i, lay in enumerate(layouts):
+        port = _layout_port(base_port, i)
+        cmd = _child_argv(argv, lay)
+        if args.launch_dry_run:
+            for r in ranks:
+                print(f'[{lay}] RANK={r} LOCAL_RANK={r} WORLD_SIZE={world} MASTER_ADDR={addr} MASTER_PORT={port} ' + ' '.join(cmd), flush=True)
+            continue
+        procs = [(r, subprocess.Popen(cmd, env=_child_env(r, local_of.get(r, r), world, addr, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None)) for r in ranks]
+        t0, rcs, out0 = time.time(), {}, b''
+        for r, pr in procs:
+            try:
+                o, _ = pr.communicate(timeout=max(1.0, args.layout_timeout_s - (time.time() - t0)))
+                rcs[r] = pr.returncode
+                if r == 0:
+                    out0 = o or b''
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.communicate()
+                rcs[r] = 'timeout'
+        bad = {r: c for r, c in rcs.items() if c != 0}
+        line = None
+        for ln in out0.decode(errors='replace').splitlines():
+            if ln.startswith('{'):
+                line = ln
+        if bad:
+            errors[lay] = {'error': f'child exit codes {bad}', 'seconds': round(time.time() - t0, 1)}
+        elif 0 in ranks and line is None:
+            errors[lay] = {'error': 'rank 0 printed no JSON line', 'seconds': round(time.time() - t0, 1)}
+        elif line is not None:
+            results[lay] = json.loads(line)
+    if args.launch_dry_run:
+        return None, 0
+    rc = 0 if (results or (0 not in ranks and not errors)) else 1
+    if 0 not in ranks:
+        return None, (1 if len(errors) == len(layouts) else 0)
+    if not results:
+        return {'metric': 'training samples/sec (user-item pairs)', 'value': None, 'n_gpus': world, 'layouts': errors, 'error': 'every layout failed'}, rc
+    best = max(results, key=lambda l_: results[l_].get('value') or 0.0)
+    out = dict(results[best])
+    out['headline_layout'] = best
+    brief = {}
+    for lay, r in results.items():
+        brief[lay] = {k_: r.get(k_) for k_ in ('value', 'ms_per_step', 'window_ms_min', 'window_ms_max', 'phases_ms', 'rccl_ranks', 'host_issue_ms_per_step')}
+        brief[lay]['sharding'] = (r.get('config') or {}).get('sharding')
+        brief[lay]['roofline'] = {k_: (r.get('roofline') or {}).get(k_) for k_ in ('kernel', 'frac', 'achieved', 'whole_step_frac', 'model_frac')}
+    brief.update(errors)
+    out['layouts'] = brief
+    if 'config' in out and not args.launch_selftest:
+        out['config'] = dict(out['config'])
+        out['config']['sharding'] = {
+            'headline': best,
+            'rows': 'north_star / BASELINE.json configuration 4: V rows, histories and samples sharded by user range, W / W2T / b2 rows by item '
+                    'range; all-to-all(v) of requested rows and of merged gradient rows, all-reduce of the hidden-bias gradient (dist.ShardedCdae)',
+            'columns': 'every rank holds all rows x K/N columns of every table and trains on the same global batch; one all-reduce of B floats '
+                       'per step (dist.ColumnShardedCdae)',
+            'this_line': out['config'].get('sharding')}
+    return out, rc
+
+
+def launch_or_coordinate(args, argv):
+    """--gpus N > 1 without --child-layout: start (or, under torch.distributed.run, be) the per-rank coordinators."""
+    world = args.gpus
+    if 'WORLD_SIZE' in os.environ:
+        assert int(os.environ['WORLD_SIZE']) == world, f"--gpus {world} but WORLD_SIZE={os.environ['WORLD_SIZE']}"
+        ranks = [int(os.environ.get('RANK', 0))]
+        local_of = {ranks[0]: int(os.environ.get('LOCAL_RANK', ranks[0]))}
+        base_port = int(os.environ.get('MASTER_PORT', 29500))
+        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    else:
+        ranks, local_of = list(range(world)), None
+        base_port = int(os.environ.get('DRX_BENCH_PORT', 29500 + (os.getpid() % 2000)))
+        addr = '127.0.0.1'
+    out, rc = coordinate(args, argv, ranks, world, base_port, addr, local_of)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    return rc
+
+
+def selftest_child():
+    """Children of --launch-selftest: a gloo rendezvous and one all-reduce on the CPU; rank 0 prints a line of the bench's shape."""
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo')
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    t0 = time.perf_counter()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher selftest', 'selftest': True, 'value': float(world), 'unit': 'ranks', 'n_gpus': world,
+                          'rccl_ranks': int(t.item()), 'backend': 'gloo', 'ms_per_step': float(dt.item()) * 1e3,
+                          'config': {'sharding': 'none (launcher selftest)'}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# measurement helpers
+# ------------------------------------------------------------------------------------------------------------------------------
 def hbm_copy_gbs(dev, gib=2, reps=8):
     """Achievable HBM rate on this box: a device-to-device copy of `gib` GiB (read + write counted), GB/s."""
     n = gib * (1 << 30) // 4
@@ -118,18 +279,22 @@ def batch_row_stats(indptr, indices, uid, iid, keep_off, seed, q):
     keep = hash_u32_torch(seed, row, j) >= q_threshold(q)
     pos = (indptr[uid.long()][row] + j)[keep]
     items = indices[pos]
-    st = {'B': B, 'history_items': int(deg.sum().item()), 'occ_W': int(keep.sum().item()), 'dist_W': int(torch.unique(items).numel())}
+    _, cw = torch.unique(items, return_counts=True)
+    st = {'B': B, 'history_items': int(deg.sum().item()), 'occ_W': int(keep.sum().item()), 'dist_W': int(cw.numel()),
+          'solo_W': int((cw == 1).sum().item())}
     for name, col in (('V', uid), ('O', iid)):
         _, cnt = torch.unique(col.long(), return_counts=True)
         st['dist_' + name], st['solo_' + name] = int(cnt.numel()), int((cnt == 1).sum().item())
     return st
 
 
-def byte_model(st, k, S, fused_solo):
+def byte_model(st, k, S, fused_solo, fused_solo_w=False, n_users=None, n_items=None):
     """Dedup-aware algorithmic HBM bytes of one sparse step, rows of 4k bytes, S optimizer slots per parameter:
-      forward kernel : gathers one row per OCCURRENCE (kept W rows + V row + W2T row), writes dz1[b] for every triple and g2[b] for the
-                       triples whose W2T row is shared; the V / W2T rows only this triple touches are updated in place from registers
-                       (read S slot rows, write parameter + S slot rows) when the touch list was prepared ahead (fused_solo);
+      forward kernel : gathers one row per OCCURRENCE (kept W rows + V row + W2T row) from a table larger than the 256 MiB Infinity
+                       Cache, one per DISTINCT row from a table that fits it (MovieLens shapes: the whole model is cache-resident and
+                       re-reads never reach HBM); writes dz1[b] for every triple and g2[b] for the triples whose W2T row is shared; the
+                       V / W2T (/ W) rows only this triple touches are updated in place from registers (read S slot rows, write
+                       parameter + S slot rows) when the touch list was prepared ahead (fused_solo, fused_solo_w);
                        + the CSR indices of the batch users (4 B per history item) and 40 B of ids / offsets per triple
       reduction      : one read-modify-write of parameter + S slot rows per DISTINCT remaining row: (2 + 2S) rows, + 8 B per touch
                        (sorted key, sample).  The gradient rows it sums (dz1 / g2, one read per occurrence) were written by the forward
@@ -138,11 +303,17 @@ def byte_model(st, k, S, fused_solo):
     Returns bytes per launch of each kernel."""
     row = 4.0 * k
     B = st['B']
+    cache = 256.0 * (1 << 20)
+    big_items = n_items is None or n_items * row > cache
+    big_users = n_users is None or n_users * row > cache
     solo_V, solo_O = (st['solo_V'], st['solo_O']) if fused_solo else (0, 0)
-    fwd = row * (st['occ_W'] + 2 * B) + row * (B + (B - solo_O)) + row * (solo_V + solo_O) * (1 + 2 * S) + 4.0 * st['history_items'] + 40.0 * B
-    n_touch = st['occ_W'] + (B - solo_V) + (B - solo_O)
-    red = row * (st['dist_W'] + st['dist_V'] - solo_V + st['dist_O'] - solo_O) * (2 + 2 * S) + 8.0 * n_touch
-    return {'k_sampled_fwd_bwd': fwd, 'k_seg_reduce': red, 'cache_bytes_k_seg_reduce': row * n_touch}
+    solo_W = st['solo_W'] if (fused_solo and fused_solo_w) else 0       # W rows with one touch, updated by the forward kernel too
+    gather_rows = (st['occ_W'] if big_items else st['dist_W']) + (B if big_users else st['dist_V']) + (B if big_items else st['dist_O'])
+    fwd = row * gather_rows + row * (B + (B - solo_O)) + row * (solo_V + solo_O + solo_W) * (1 + 2 * S) + 4.0 * st['history_items'] + 40.0 * B
+    n_touch = st['occ_W'] - solo_W + (B - solo_V) + (B - solo_O)
+    red = row * (st['dist_W'] - solo_W + st['dist_V'] - solo_V + st['dist_O'] - solo_O) * (2 + 2 * S) + 8.0 * n_touch
+    return {'k_sampled_fwd_bwd': fwd, 'k_seg_reduce': red, 'cache_bytes_k_seg_reduce': row * n_touch,
+            'cache_bytes_k_sampled_fwd_bwd': row * (st['occ_W'] + 2 * B - gather_rows)}
 
 
 def kernel_source_hash():
@@ -155,88 +326,6 @@ def kernel_source_hash():
             with open(os.path.join(src, name), 'rb') as f:
                 h.update(name.encode() + b'\0' + f.read())
     return h.hexdigest()[:16]
-
-
-def cpu_baseline(eng, hist_indptr, hist_indices, batch, seed, budget_s=12.0, n_cpu=1024, optimizer='adagrad'):
-    """Times the CPU oracle (oracle/cdae_oracle.py sparse_step: the NumPy restatement, 'port') on the first n_cpu triples
-    of one bench batch.  The tables are compacted to the rows that sample touches (same arithmetic per sample; the
-    CPU sees a cache-friendlier table than the GPU does)."""
-    from oracle import cdae_oracle as co
-    n_cpu = min(n_cpu, batch[0].numel())
-    uid, iid, y = [t[:n_cpu].cpu().numpy() for t in batch[:3]]
-    ip = hist_indptr.cpu().numpy() if hist_indptr.numel() < 50_000_000 else None
-    thr = q_threshold(Q)
-    kept, users, items = [], {}, {}
-    for b in range(n_cpu):
-        u = int(uid[b])
-        s, e = (int(hist_indptr[u].item()), int(hist_indptr[u + 1].item())) if ip is None else (int(ip[u]), int(ip[u + 1]))
-        row = hist_indices[s:e].cpu().numpy()
-        kf = co.drx_hash_u32(seed, np.full(e - s, b), np.arange(e - s)) >= thr
-        users.setdefault(u, len(users))
-        for n in row[kf].tolist() + [int(iid[b])]:
-            items.setdefault(n, len(items))
-        kept.append([items[n] for n in row[kf].tolist()])
-    ul = torch.tensor(list(users.keys()), device=eng.device)
-    il = torch.tensor(list(items.keys()), device=eng.device)
-    k = eng.k
-    p = {'W': eng.W[il, :k].cpu().numpy().copy(), 'W_': eng.W2T[il, :k].t().cpu().numpy().copy(),
-         'V': eng.V[ul, :k].cpu().numpy().copy(), 'b': eng.b[:k].cpu().numpy().copy(), 'b_': eng.b2[il].cpu().numpy().copy()}
-    st = co.sparse_state(p, optimizer)
-    cu = np.array([users[int(u)] for u in uid])
-    ci = np.array([items[int(i)] for i in iid])
-    t0 = time.perf_counter()
-    n_done = 0
-    while time.perf_counter() - t0 < budget_s:
-        co.sparse_step(p, st, n_done, cu, ci, y, kept, float(np.float32(Q)), 1e-3 if optimizer == 'adam' else LR, REG, 'bce', optimizer)
-        n_done += 1
-    dt = time.perf_counter() - t0
-    return {'value': n_cpu * n_done / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n_done} steps of the first {n_cpu} triples of one bench batch (same tables, compacted to touched '
-                      f'rows), NumPy restatement oracle/cdae_oracle.py:sparse_step, {dt:.1f} s, host has {os.cpu_count()} cpus'}
-
-
-def cpu_reference_fit(tr, budget_s=10.0, B=64, k=50, q=0.2, seed=10):
-    """BASELINE config 1 on the host: the reference's CDAE fit() loop (examples/cdae.py: K = 50, batch 64, lr 1e-3, reg 1e-3, neg_ratio 5)
-    as restated by the oracle — PointSampler draw (oracle/data_oracle.py), N uniform corruption draws per row from random.Random(seed)
-    (cdae.py:63), dense_step in fp32 (what TF computes in) with the (B,B,N) mean-target loss, L2/B on the full tables and 5 Keras-Adam
-    applies — on the SAME training set the GPU fit() above trains on, for `budget_s` seconds, numpy limited to one thread."""
-    import random
-    from oracle import cdae_oracle as co
-    from oracle import data_oracle as do
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:
-        threadpool_limits = None
-    c = tr._cols
-    uid, iid, val = c['uid'].astype(np.int64), c['iid'].astype(np.int64), c['interaction']
-    U, N = int(uid.max()) + 1, int(iid.max()) + 1
-    smp = do.PointSamplerOracle(uid, iid, val, 5, 1e-3, seed)
-    rng = random.Random(seed)
-    pos = np.zeros((U, N), dtype=bool)
-    pos[uid[val >= 1e-3], iid[val >= 1e-3]] = True
-    p = co.init_params(np.random.default_rng(seed), U, N, k, np.float32)
-    st = co.adam_state(p)
-    scale = np.float32(1.0 / (1.0 - float(np.float32(q))))
-
-    def loop():
-        t0 = time.perf_counter()
-        n = 0
-        while time.perf_counter() - t0 < budget_s:
-            users = np.array([t[0] for t in smp.sample(B)])
-            t = pos[users]
-            mask = np.array([[rng.uniform(0, 1) >= q for _ in range(N)] for _ in range(B)])      # cdae.py:63: a draw for EVERY item
-            x = np.where(t & mask, scale, np.float32(0)).astype(np.float32)
-            co.dense_step(p, st, n, users, x, t, 1e-3, 1e-3, 'bce', 'reference')
-            n += 1
-        return n, time.perf_counter() - t0
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            n, dt = loop()
-    else:
-        n, dt = loop()
-    return {'value': n * B / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n} one-batch epochs of {B} in {dt:.1f} s: oracle PointSampler + per-item corruption draws + oracle/cdae_oracle.py:dense_step '
-                      f'(fp32) on the {U} x {N} ml-100k-shaped training set of the GPU fit; numpy on 1 thread; host has {os.cpu_count()} cpus'}
 
 
 def hr_at_10(dev, with_cpu=True):
@@ -272,6 +361,7 @@ def hr_at_10(dev, with_cpu=True):
     m2.fit(tr, epochs=5000, batch_size=64, learning_rate=1e-3, reg_rate=1e-3, neg_ratio=5)
     torch.cuda.synchronize()
     long_s = time.perf_counter() - t0
+    from bench_cpu import cpu_reference_fit
     cpu_ref = cpu_reference_fit(tr) if with_cpu else None
     return {'value': res['HitRatio@10'], 'ndcg_at_10': res['NDCG@10'], 'cpu_baseline_reference_mode': cpu_ref,
             'fit_seconds_100_steps_of_64': round(fit_s, 3),
@@ -279,6 +369,70 @@ def hr_at_10(dev, with_cpu=True):
             'fit_seconds_5000_steps_of_64': round(long_s, 3), 'fit_samples_per_s_5000_steps_incl_host_and_setup': round(320000 / long_s, 1),
             'setup': 'CDAE reference mode (dense Keras Adam), README.md:106-114 configuration, ml-100k-shaped synthetic '
                      f'({len(tr)} train / {len(te)} test rows), protocol examples/cdae.py:15-17'}
+
+
+
+class Windows:
+    """`windows` back-to-back timed windows of exactly `steps` steps, each bracketed by barrier + synchronize and reduced by MAX over
+    ranks.  Phase events are recorded by the library on every EVERY-th step of every window."""
+
+    def __init__(self, steps, windows, n_events, world, dist, dev):
+        self.steps, self.windows, self.world, self.dist, self.dev = steps, max(1, windows), world, dist, dev
+        # six event records per step cost ~4 % of the step: only every EVERY-th timed step carries them
+        self.every = max(1, int(os.environ.get('DRX_BENCH_EVENTS_EVERY', 4)))
+        total = self.steps * self.windows
+        self.evs = [[torch.cuda.Event(enable_timing=True) for _ in range(n_events)] if i % self.every == 0 else None for i in range(total)]
+        for es in self.evs:
+            for e in (es or []):
+                e.record()
+        self.times = []
+
+    def _fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, step_fn):
+        """step_fn(i, events_or_None, last): i = 0-based index over all timed steps."""
+        total = self.steps * self.windows
+        for w in range(self.windows):
+            self._fence()
+            t0 = time.perf_counter()
+            for j in range(self.steps):
+                i = w * self.steps + j
+                step_fn(i, self.evs[i], i == total - 1)
+            self._fence()
+            dt = time.perf_counter() - t0
+            if self.world > 1:
+                t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                dt = float(t.item())
+            self.times.append(dt)
+        return self
+
+    @property
+    def median(self):
+        return float(np.median(self.times))
+
+    def fields(self, samples_per_step):
+        ms = [t * 1e3 for t in self.times]
+        return {'value': samples_per_step * self.steps / self.median, 'ms_per_step': self.median / self.steps * 1e3,
+                'windows': self.windows, 'window_ms': [round(m, 4) for m in ms], 'window_ms_min': min(ms), 'window_ms_max': max(ms),
+                'value_from': 'median window'}
+
+    def phase_means(self, n_phases):
+        rows = [[es[i].elapsed_time(es[i + 1]) for i in range(n_phases)] for es in self.evs if es is not None]
+        return np.array(rows).mean(axis=0), len(rows)
+
+
+def rccl_ranks(dist, dev, world, debug_gloo):
+    """Sum over ranks of an all-reduce of ones: the number of ranks that really took part in a collective of this job's backend."""
+    if world == 1 and not dist.is_initialized():
+        return 1
+    t = torch.ones(1, device='cpu' if debug_gloo else dev)
+    dist.all_reduce(t)
+    return int(t.item())
 
 
 def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
@@ -344,98 +498,57 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
     pipe = model.pipeline(Bg, NEG_RATIO, seed_of, seed_of)
     for _ in range(args.warmup):
         pipe.run_step()
-    EVERY = max(1, int(os.environ.get('DRX_BENCH_EVENTS_EVERY', 4)))
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
-    for es in evs:
-        for e in es:
-            e.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        if s % EVERY == 0:
-            evs[s][0].record()                        # [0,1): forward half + all-reduce of the partial dot products
-            pipe.run_step(events=evs[s][1:])
+    win = Windows(args.steps, args.windows, 7, world, dist, dev)
+
+    def step_fn(i, es, last):
+        if es is not None:
+            es[0].record()                        # [0,1): forward half + all-reduce of the partial dot products
+            pipe.run_step(events=es[1:])
         else:
             pipe.run_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ph = np.array([[es[i].elapsed_time(es[i + 1]) for i in range(6)] for es in evs[::EVERY]]).mean(axis=0)
-    names = ['k_kshard_fwd+allreduce(dot)', 'k_kshard_rest', 'touch_sort(overlapped on side stream)', 'k_seg_reduce',
-             'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
+    win.run(step_fn)
+    ph, n_timed = win.phase_means(6)
+    names = ['k_kshard_fwd+allreduce(dot)', 'k_kshard_rest', 'touch_sort(overlapped on side stream)', 'k_seg_reduce_planned(+bias partials)',
+             'k_span_planned(short | long spans | bias update)', '(unused)']
     kl = model.k_hi - model.k_lo
     S_opt = 2.0 if args.optimizer == 'adam' else 1.0
     alg_upd = Bg * 4.0 * kl * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)      # this rank's columns of the global batch
     alg_fwd = Bg * 4.0 * kl * rows_per_sample
-    dom, dom_ms, dom_alg = ('k_seg_reduce', ph[3], alg_upd) if ph[3] >= ph[0] else ('k_kshard_fwd+allreduce(dot)', ph[0], alg_fwd)
+    dom, dom_ms, dom_alg = ('k_seg_reduce_planned', ph[3], alg_upd) if ph[3] >= ph[0] else ('k_kshard_fwd+allreduce(dot)', ph[0], alg_fwd)
     step_alg = Bg * 4.0 * kl * rows_per_sample * (3.0 + 2.0 * S_opt)
-    if rank == 0:
-        copy_gbs = hbm_copy_gbs(dev)
-        out = {'metric': 'training samples/sec (user-item pairs)', 'value': Bg * args.steps / dt, 'unit': 'samples/s', 'n_gpus': world,
-               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{"Adam (lazy)" if S_opt == 2.0 else "Adagrad"} on '
-                                      f'{args.workload}-shaped synthetic ({U} users x {N} items, {nnz} positives), corruption {Q}, neg_ratio {NEG_RATIO}',
-                          'batch_per_gpu': args.batch, 'global_batch': Bg, 'rows_per_sample': round(rows_per_sample, 3),
-                          'sole_toucher_rows_per_sample': round(f_solo, 3),
-                          'batches': 'fresh device-sampled global batch every step, drawn identically on every rank (sampler running ahead on a side stream)',
-                          'sharding': f'columns: every rank holds all rows x {kl} of {K} columns and trains on the whole global batch; '
-                                      f'one all-reduce of {Bg} floats per step; touch list '
-                                      + {'local': 'sorted whole on every rank', 'turns': 'of step s sorted by rank s % N and broadcast on a side stream',
-                                         'parts': 'sorted in parts (1/N per rank) + one all-gather on a side stream'}[model.prepare_mode]},
-               'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': dom_alg / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                            'frac': dom_alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                            'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(evs[::EVERY])),
-                            'whole_step_achieved': step_alg / (dt / args.steps) / 1e9,
-                            'whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 'hbm_copy_achievable': copy_gbs,
-                            'note': 'per-rank figures: this rank\'s K/N columns of the global batch; algorithmic bytes per SURVEY 8d charge a '
-                                    'read-modify-write per touched-row occurrence, the kernel merges occurrences first (DESIGN.md section 3)'},
-               'phases_ms': {n: float(v) for n, v in zip(names, ph)}, 'setup_s': round(setup_s, 1), 'cpu_baseline': None, 'hr_at_10': None}
-        print(json.dumps(out), flush=True)
+    n_ranks = rccl_ranks(dist, dev, world, debug_gloo)
+    if rank != 0:
+        return None
+    copy_gbs = hbm_copy_gbs(dev)
+    step_s = win.median / args.steps
+    out = {'metric': 'training samples/sec (user-item pairs)', 'unit': 'samples/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'rccl_ranks': n_ranks,
+           'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{"Adam (lazy)" if S_opt == 2.0 else "Adagrad"} on '
+                                  f'{args.workload}-shaped synthetic ({U} users x {N} items, {nnz} positives), corruption {Q}, neg_ratio {NEG_RATIO}',
+                      'batch_per_gpu': args.batch, 'global_batch': Bg, 'rows_per_sample': round(rows_per_sample, 3),
+                      'sole_toucher_rows_per_sample': round(f_solo, 3),
+                      'batches': 'fresh device-sampled global batch every step, drawn identically on every rank (sampler running ahead on a side stream)',
+                      'sharding': f'columns: every rank holds all rows x {kl} of {K} columns and trains on the whole global batch; '
+                                  f'one all-reduce of {Bg} floats per step; touch list '
+                                  + {'local': 'sorted whole on every rank', 'turns': 'of step s sorted by rank s % N and broadcast on a side stream',
+                                     'parts': 'sorted in parts (1/N per rank) + one all-gather on a side stream'}[model.prepare_mode]},
+           'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': dom_alg / (dom_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': None, 'model_frac': dom_alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                        'algorithmic_bytes_per_launch': dom_alg, 'avg_launch_ms': float(dom_ms), 'timed_launches': n_timed,
+                        'whole_step_achieved': step_alg / step_s / 1e9,
+                        'model_whole_step_frac': step_alg / step_s / 1e9 / HBM_PEAK_GBS, 'hbm_copy_achievable': copy_gbs,
+                        'note': 'per-rank figures: this rank\'s K/N columns of the global batch; bytes per SURVEY 8d charge a '
+                                'read-modify-write per touched-row occurrence, the kernel merges occurrences first (DESIGN.md section 3), '
+                                'so these are model_* numbers, not fractions'},
+           'phases_ms': {n: float(v) for n, v in zip(names, ph)}, 'setup_s': round(setup_s, 1), 'cpu_baseline': None, 'hr_at_10': None}
+    out.update(win.fields(Bg))
+    return out
 
 
-def main():
-    global K
-    args = parse()
-    if args.k:
-        K = args.k
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    debug_gloo = os.environ.get('DRX_BENCH_BACKEND') == 'gloo'     # debugging aid: N ranks sharing ONE GPU, host-staged exchange
-    dev_index = local_rank % torch.cuda.device_count() if debug_gloo else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
-    import torch.distributed as dist
-    rccl1 = world == 1 and os.environ.get('DRX_BENCH_RCCL1') == '1'     # debugging aid: 1-rank RCCL communicator, real collectives
-    if rccl1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29455')
-        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if debug_gloo:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
-
-    if (world > 1 and args.layout == 'columns' and not args.force_sharded) or args.force_columns:
-        run_columns(args, rank, world, dev, dist, debug_gloo, rccl1)
-        if world > 1 or rccl1:
-            dist.barrier()                      # rank 0 prints (and times a device copy) after the others are done
-            dist.destroy_process_group()
-        return
-
+def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
+    """The single-GPU step (world 1) or the ROW-sharded layout (dist.ShardedCdae; world > 1 or --force-sharded).  Returns the line's
+    dict on rank 0, None elsewhere."""
     from drecpy_amd import synth
     from drecpy_amd.engine import CdaeEngine
     U, N, md, mn, alpha = synth.SHAPES[args.workload]
@@ -456,7 +569,7 @@ def main():
     else:
         from drecpy_amd.dist import ShardedCdae
         stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
-                              cpu_staging=debug_gloo, force_collectives=(world == 1 and os.environ.get('DRX_BENCH_RCCL1') == '1'))
+                              cpu_staging=debug_gloo, force_collectives=rccl1)
         eng = stepper.engine
 
     micro = max(1, args.micro)       # > 1: micro-batches whose exchanges overlap each other's compute (measured at world 1: the split costs more than it hides)
@@ -487,8 +600,7 @@ def main():
     rows_per_sample = kept_tot / (args.n_batches * B) + 2.0          # R: kept W rows + V row + W2T row
     setup_s = time.time() - t_setup
 
-    # The touch list of a batch (sorted row keys) does not depend on the parameters: it is prepared for batch t+1 on a
-    # side stream while batch t trains (single GPU; the sharded path prepares inline).
+    # The touch list of a batch (sorted row keys) does not depend on the parameters: it is prepared ahead on a side stream
     overlap = not args.no_overlap
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream(priority=-1) if overlap else None
@@ -497,9 +609,8 @@ def main():
     step_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     fresh = overlap and stepper is None and not args.presampled
-    # fresh mode: the device PointSampler draws a NEW batch for every step, two steps ahead on a side stream, and the batch's
-    # touch list is sorted one step ahead — drecpy_amd.engine.SampledPipeline, the code path of
-    # CDAE.fit(mode='sampled', device_sampler=True).
+    # fresh mode: the device PointSampler draws a NEW batch for every step ahead on a side stream and the batch's touch list is sorted
+    # ahead too — drecpy_amd.engine.SampledPipeline, the code path of CDAE.fit(mode='sampled', device_sampler=True).
     spipe = None
     if fresh:
         from drecpy_amd.engine import SampledPipeline
@@ -516,7 +627,8 @@ def main():
             prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])
             prep_done[s % 2].record(side)
 
-    pipe = None
+    pipe, fresh_sharded = None, False
+    total_steps = args.warmup + args.steps * max(1, args.windows)
     if stepper is not None and overlap:
         from drecpy_amd.dist import ShardedPipeline
         fresh_sharded = not args.presampled and micro == 1 and not debug_gloo
@@ -526,7 +638,7 @@ def main():
                                        lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N)
         else:
             source = lambda s: structs[s % len(structs)][0]
-        pipe = ShardedPipeline(stepper, source, args.warmup + args.steps)
+        pipe = ShardedPipeline(stepper, source, total_steps)
 
     def run_step(s, events=None, last=False):
         if pipe is not None:           # keys of batch s+1 and counts of batch s+2 travel ahead of step s (dist.ShardedPipeline)
@@ -555,36 +667,13 @@ def main():
         prepare(0)
     for s in range(args.warmup):
         run_step(s)
-    # The library records the phase events (hipEventRecord between kernels) only on every EVERY-th timed step: six event
-    # records per step cost ~4 % of the step (137.7 vs 143.2 vs 144.5 M samples/s at EVERY = 1 / 4 / none).
-    EVERY = max(1, int(os.environ.get('DRX_BENCH_EVENTS_EVERY', 4)))
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
-    for es in evs:
-        for e in es:
-            e.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        run_step(args.warmup + s, events=(evs[s] if (s % EVERY == 0) else None), last=(s == args.steps - 1))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    phases = np.array([[es[i].elapsed_time(es[i + 1]) for i in range(5)] for es in evs[::EVERY]])     # ms
-    ph = phases.mean(axis=0)
-    # algorithmic bytes per launch: forward reads 4K*R per sample; the update reads and
-    # writes parameter + S optimizer slots per touched-row occurrence: 4K*R*(2+2S), S = 1 for Adagrad.
-    # With a touch list prepared ahead, V / W2T rows touched by a single triple of the batch are updated by the forward kernel
-    # (k_mark_solo): their (2+2S) update bytes are charged to it instead of the segmented reduction.
+    win = Windows(args.steps, args.windows, 6, world, dist, dev)
+    win.run(lambda i, es, last: run_step(args.warmup + i, events=es, last=last))
+    n_ranks = rccl_ranks(dist, dev, world, debug_gloo) if dist is not None else 1
+    ph, n_timed = win.phase_means(5)
+    step_s = win.median / args.steps
+    # SURVEY 8d's per-occurrence model (kept as model_*): forward reads 4K*R per sample; the update reads and writes parameter + S
+    # optimizer slots per touched-row occurrence: 4K*R*(2+2S), S = 1 for Adagrad.
     f_solo = 0.0
     if stepper is None and overlap:
         uid0, iid0 = batches[0][0].long(), batches[0][1].long()
@@ -596,9 +685,9 @@ def main():
     alg_fwd = B * 4.0 * K * (rows_per_sample + f_solo * (2.0 + 2.0 * S_opt))
     alg_upd = B * 4.0 * K * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)
     if stepper is None:
-        names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce',
-                 'k_sparse_tail_a(short spans | bias partials)', 'k_sparse_tail_b(long spans | bias update)']
-        dom, dom_ms, dom_alg = ('k_seg_reduce', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
+        names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce_planned(+bias partials)',
+                 'k_span_planned(short | long spans | bias update)', '(unused)']
+        dom, dom_ms, dom_alg = ('k_seg_reduce_planned', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
         names = ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce(+overlapped exchanges)', 'rest_of_grad_exchange', 'owner_apply', 'bias_allreduce']
         # forward reads one row per occurrence, the local reduce one gradient row per occurrence
@@ -607,8 +696,9 @@ def main():
     step_alg = B * 4.0 * K * rows_per_sample * (3.0 + 2.0 * S_opt)
     # ---- dedup-aware byte model: exact occurrence / distinct-row counts of batches of the TIMED region ----------------------------
     dedup = None
+    n_timed_steps = args.steps * max(1, args.windows)
     if stepper is None:
-        picks = sorted(set(int(x) for x in np.linspace(0, args.steps - 1, 6)))
+        picks = sorted(set(int(x) for x in np.linspace(0, n_timed_steps - 1, 6)))
         stats = []
         for s_ in picks:
             if fresh:                                   # the pipeline drew step (warmup + s_) from these seeds: draw it again
@@ -618,8 +708,10 @@ def main():
                 u_, i_, _, ko_, seed_ = batches[(args.warmup + s_) % len(batches)]
             stats.append(batch_row_stats(indptr, indices, u_, i_, ko_, seed_, Q))
         mean_st = {k_: float(np.mean([st[k_] for st in stats])) for k_ in stats[0]}
-        bm = byte_model(mean_st, K, S_opt, fused_solo=overlap)
-        dedup = {'batches_counted': len(stats), 'per_batch_mean': {k_: round(v, 1) for k_, v in mean_st.items()}, 'bytes_per_launch': bm}
+        solo_w_on = bool(eng._batch_flags(int(mean_st['history_items'])))      # W rows with one touch are updated by the forward kernel too
+        bm = byte_model(mean_st, K, S_opt, fused_solo=overlap, fused_solo_w=solo_w_on, n_users=hi - lo, n_items=N)
+        dedup = {'batches_counted': len(stats), 'per_batch_mean': {k_: round(v, 1) for k_, v in mean_st.items()}, 'bytes_per_launch': bm,
+                 'sole_toucher_w_rows_fused': solo_w_on}
     kernel_hash = kernel_source_hash()
     # HBM traffic from the PMC passes (profiles/pmc_traffic.json), only when that profile was taken on this very workload AND on
     # these very kernel sources (scripts/profile_round.sh stores their hash); rocprofv3 cannot run inside the bench itself.
@@ -638,77 +730,140 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     traffic = traffic_of.get(dom)
-    copy_gbs = hbm_copy_gbs(dev) if rank == 0 else None
-    if rank == 0:
-        out = {
-            'metric': 'training samples/sec (user-item pairs)', 'value': world * B * args.steps / dt, 'unit': 'samples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{dict(adam="Adam (lazy)", adagrad="Adagrad", rowwise_adagrad="row-wise Adagrad")[args.optimizer if stepper is None else "adagrad"]} on {args.workload}-shaped synthetic '
-                                   f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
-                                   f'corruption {Q}, neg_ratio {NEG_RATIO}',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
-                       'sole_toucher_rows_per_sample': round(f_solo, 3),
-                       'touch_list': ('keys exchanged one batch ahead, counts two (dist.ShardedPipeline)' if pipe is not None else 'prepared one batch ahead on a side stream') if overlap else 'inline',
-                       'batches': 'fresh device-sampled batch every step (sampler two steps ahead on the side stream)' if (fresh or (pipe is not None and fresh_sharded))
-                       else f'{args.n_batches} pre-sampled batches cycled',
-                       'micro_batches': (micro if stepper is not None else None),
-                       'sharding': ('single GPU' if stepper is None else 'row-sharded code path at world 1') if world == 1 else f'users row-sharded x{world}, item rows all-to-all'},
-            'roofline': None,
-            'phases_ms': {n: float(v) for n, v in zip(names, ph)},
-            'setup_s': round(setup_s, 1),
-            'host_issue_ms_per_step': ([round(1e3 * t / (args.warmup + args.steps), 4) for t in pipe.host_s + [stepper.wait_s]] if pipe is not None else None),
-        }
-        ms_of = {'k_sampled_fwd_bwd': float(ph[0]), 'k_seg_reduce': float(ph[2])} if stepper is None else {}
-        if dedup is not None:
-            # `frac` = dedup-aware algorithmic HBM bytes / measured launch time / peak: a fraction by construction (what has to
-            # cross the HBM interface at least once; everything re-read is assumed cached).  `model_*` = SURVEY 8d's
-            # per-OCCURRENCE model (charges a read-modify-write per touch: the kernel merges touches first, so it can exceed 1).
-            per_kernel = {}
-            for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
-                byt, ms_ = dedup['bytes_per_launch'][kn], ms_of[kn]
-                per_kernel[kn] = {'bytes_per_launch': byt, 'avg_launch_ms': ms_, 'achieved': byt / (ms_ * 1e-3) / 1e9,
-                                  'frac': byt / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  'traffic': traffic_of.get(kn),
-                                  'traffic_frac': (traffic_of[kn] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS) if kn in traffic_of else None}
-            step_bytes = dedup['bytes_per_launch']['k_sampled_fwd_bwd'] + dedup['bytes_per_launch']['k_seg_reduce']
-            step_traffic = sum(traffic_of.get(kn, 0.0) for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce', 'k_sparse_tail_a', 'k_sparse_tail_b')) or None
-            dk = per_kernel[dom]
-            out['roofline'] = {
-                'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['frac'],
-                'traffic': traffic, 'traffic_source': traffic_note, 'kernel_source_hash': kernel_hash,
-                'traffic_rate': (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
-                'traffic_frac': (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                'bytes_per_launch': dk['bytes_per_launch'], 'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(phases)),
-                'kernels': per_kernel, 'row_counts': dedup['per_batch_mean'], 'batches_counted': dedup['batches_counted'],
-                'cache_bytes_k_seg_reduce': dedup['bytes_per_launch']['cache_bytes_k_seg_reduce'],
-                'whole_step_bytes': step_bytes, 'whole_step_achieved': step_bytes / (dt / args.steps) / 1e9,
-                'whole_step_frac': step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                'whole_step_traffic': step_traffic,
-                'whole_step_traffic_frac': (step_traffic / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
-                'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
-                'model_whole_step_frac': step_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                'hbm_copy_achievable': copy_gbs,
-                'definition': 'frac = dedup-aware algorithmic HBM bytes (bench.py:byte_model: one gather read per occurrence, dz1/g2 written once, '
-                              'one read-modify-write of parameter + slots per DISTINCT row, gradient re-reads assumed cached) / HIP-event launch time / 8 TB/s; '
-                              'traffic = PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; counts Infinity-Cache hits); model_* = SURVEY 8d per-occurrence bytes'}
+    if rank != 0:
+        return None
+    copy_gbs = hbm_copy_gbs(dev)
+    out = {
+        'metric': 'training samples/sec (user-item pairs)', 'unit': 'samples/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'rccl_ranks': n_ranks,
+        'config': {'workload': f'CDAE hidden_factors={K} sampled-output sparse-{dict(adam="Adam (lazy)", adagrad="Adagrad", rowwise_adagrad="row-wise Adagrad")[args.optimizer if stepper is None else "adagrad"]} on {args.workload}-shaped synthetic '
+                               f'({U} users x {N} items, {nnz_local * world if world > 1 else nnz_local} positives), '
+                               f'corruption {Q}, neg_ratio {NEG_RATIO}',
+                   'batch_per_gpu': B, 'global_batch': B * world, 'rows_per_sample': round(rows_per_sample, 3),
+                   'sole_toucher_rows_per_sample': round(f_solo, 3),
+                   'touch_list': ('keys exchanged one batch ahead, counts two (dist.ShardedPipeline)' if pipe is not None else 'prepared ahead on a side stream') if overlap else 'inline',
+                   'batches': 'fresh device-sampled batch every step (sampler running ahead on the side stream)' if (fresh or (pipe is not None and fresh_sharded))
+                   else f'{args.n_batches} pre-sampled batches cycled',
+                   'micro_batches': (micro if stepper is not None else None),
+                   'sharding': ('single GPU' if stepper is None else 'row-sharded code path at world 1') if world == 1
+                   else f'rows: users (V rows, histories, samples) sharded x{world} by range, item rows sharded by range; all-to-all(v) of rows and gradient rows, all-reduce of the bias gradient'},
+        'roofline': None,
+        'phases_ms': {n: float(v) for n, v in zip(names, ph)},
+        'setup_s': round(setup_s, 1),
+        'host_issue_ms_per_step': ([round(1e3 * t / total_steps, 4) for t in pipe.host_s + [stepper.wait_s]] if pipe is not None else None),
+    }
+    out.update(win.fields(world * B))
+    ms_of = {'k_sampled_fwd_bwd': float(ph[0]), 'k_seg_reduce': float(ph[2])} if stepper is None else {}
+    if dedup is not None:
+        # `frac` = dedup-aware algorithmic HBM bytes / measured launch time / peak: a fraction by construction (what has to
+        # cross the HBM interface at least once; everything re-read is assumed cached).  `model_*` = SURVEY 8d's
+        # per-OCCURRENCE model (charges a read-modify-write per touch: the kernel merges touches first, so it can exceed 1).
+        per_kernel = {}
+        for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
+            byt, ms_ = dedup['bytes_per_launch'][kn], ms_of[kn]
+            kname = kn if kn != 'k_seg_reduce' else 'k_seg_reduce_planned'
+            per_kernel[kname] = {'bytes_per_launch': byt, 'avg_launch_ms': ms_, 'achieved': byt / (ms_ * 1e-3) / 1e9,
+                                 'frac': byt / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'traffic': traffic_of.get(kname),
+                                 'traffic_frac': (traffic_of[kname] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS) if kname in traffic_of else None}
+        step_bytes = dedup['bytes_per_launch']['k_sampled_fwd_bwd'] + dedup['bytes_per_launch']['k_seg_reduce']
+        step_traffic = sum(traffic_of.get(kn, 0.0) for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned', 'k_span_planned')) or None
+        dk = per_kernel[dom]
+        out['roofline'] = {
+            'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['frac'],
+            'traffic': traffic, 'traffic_source': traffic_note, 'kernel_source_hash': kernel_hash,
+            'traffic_rate': (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+            'traffic_frac': (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            'bytes_per_launch': dk['bytes_per_launch'], 'avg_launch_ms': float(dom_ms), 'timed_launches': n_timed,
+            'kernels': per_kernel, 'row_counts': dedup['per_batch_mean'], 'batches_counted': dedup['batches_counted'],
+            'sole_toucher_w_rows_fused': dedup['sole_toucher_w_rows_fused'],
+            'cache_bytes_k_seg_reduce': dedup['bytes_per_launch']['cache_bytes_k_seg_reduce'],
+            'cache_bytes_k_sampled_fwd_bwd': dedup['bytes_per_launch']['cache_bytes_k_sampled_fwd_bwd'],
+            'whole_step_bytes': step_bytes, 'whole_step_achieved': step_bytes / step_s / 1e9,
+            'whole_step_frac': step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+            'whole_step_traffic': step_traffic,
+            'whole_step_traffic_frac': (step_traffic / step_s / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
+            'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
+            'model_whole_step_frac': step_alg / step_s / 1e9 / HBM_PEAK_GBS,
+            'hbm_copy_achievable': copy_gbs,
+            'definition': 'frac = dedup-aware algorithmic HBM bytes (bench.py:byte_model: one gather read per occurrence — per distinct row where the table fits the 256 MiB Infinity Cache —, dz1/g2 written once, '
+                          'one read-modify-write of parameter + slots per DISTINCT row, gradient re-reads assumed cached) / HIP-event launch time / 8 TB/s; '
+                          'traffic = PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; counts Infinity-Cache hits); model_* = SURVEY 8d per-occurrence bytes'}
+    else:
+        out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
+                           'traffic': None, 'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
+                           'avg_launch_ms': float(dom_ms), 'timed_launches': n_timed, 'hbm_copy_achievable': copy_gbs,
+                           'definition': 'row-sharded path: only the per-occurrence model (SURVEY 8d) is evaluated here'}
+    out['cpu_baseline'] = out['cpu_baseline_all_cores'] = None
+    if world == 1 and not args.no_cpu_baseline:
+        from bench_cpu import cpu_baseline
+        uid, iid, y, keep_off, seed = batches[0]
+        one, many = cpu_baseline(eng, indptr, indices, (uid, iid, y, keep_off), seed, Q, LR, REG, q_threshold, budget_s=args.cpu_budget_s,
+                                 n_cpu=args.cpu_triples, optimizer=args.optimizer, all_cores=not args.no_all_cores)
+        out['cpu_baseline'], out['cpu_baseline_all_cores'] = one, many
+    return out
+
+
+def worker_main(args):
+    """One rank of a measurement (world 1: the whole bench; world > 1: one layout, in a child process of a coordinator)."""
+    global K
+    if args.k:
+        K = args.k
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    debug_gloo = os.environ.get('DRX_BENCH_BACKEND') == 'gloo'     # debugging aid: N ranks sharing ONE GPU, host-staged exchange
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if debug_gloo else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    import datetime
+    import torch.distributed as dist
+    rccl1 = world == 1 and os.environ.get('DRX_BENCH_RCCL1') == '1'     # debugging aid: 1-rank RCCL communicator, real collectives
+    tmo = datetime.timedelta(seconds=300)
+    if rccl1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29455')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        dist.init_process_group('nccl', device_id=dev, timeout=tmo)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if debug_gloo:
+            dist.init_process_group('gloo', timeout=tmo)
         else:
-            out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
-                               'traffic': None, 'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
-                               'avg_launch_ms': float(dom_ms), 'timed_launches': int(len(phases)), 'hbm_copy_achievable': copy_gbs,
-                               'definition': 'row-sharded path: only the per-occurrence model (SURVEY 8d) is evaluated here'}
-        if world == 1 and not args.no_cpu_baseline:
-            uid, iid, y, keep_off, seed = batches[0]
-            out['cpu_baseline'] = cpu_baseline(eng, indptr, indices, (uid, iid, y, keep_off), seed, optimizer=args.optimizer)
-        else:
-            out['cpu_baseline'] = None
-        out['hr_at_10'] = hr_at_10(dev, with_cpu=not args.no_cpu_baseline) if (world == 1 and not args.no_hr and not args.users) else None
+            dist.init_process_group('nccl', device_id=dev, timeout=tmo)
+    layout = args.child_layout or ('columns' if args.force_columns else 'rows')
+    if layout == 'columns' and (world > 1 or args.force_columns):
+        out = run_columns(args, rank, world, dev, dist, debug_gloo, rccl1)
+    else:
+        out = run_direct(args, rank, world, dev, dist, debug_gloo, rccl1)
+    if rank == 0 and world == 1 and not args.force_columns and not args.force_sharded:
+        out['hr_at_10'] = hr_at_10(dev, with_cpu=not args.no_cpu_baseline) if (not args.no_hr and not args.users) else None
         out['cpu_baseline_reference_mode'] = (out['hr_at_10'] or {}).get('cpu_baseline_reference_mode')
+        if args.force_configs or (not args.no_configs and not args.users and args.workload == 'synth-10m' and K == 128):
+            from bench_configs import configs_block
+            out['configs'] = configs_block(dev, run_direct, args, with_cpu=not args.no_cpu_baseline)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or rccl1:
-        dist.barrier()
+        dist.barrier()                      # rank 0 prints (and times a device copy) after the others are done
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.child_layout == 'selftest':
+        selftest_child()
+        return 0
+    if args.child_layout is None and (args.gpus > 1 or args.launch_dry_run):
+        # N GPUs: this process only starts children and merges their lines — it must not touch the GPU (and does not import anything
+        # that does): the children are fresh processes, never an exec of one that has initialised HIP
+        return launch_or_coordinate(args, argv)
+    if args.child_layout is None:
+        assert int(os.environ.get('WORLD_SIZE', 1)) == 1, 'WORLD_SIZE > 1 needs --gpus N'
+    return worker_main(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -1,0 +1,164 @@
+"""The `configs` block of bench.py's JSON line: BASELINE.json configurations 2, 3 and 5 measured in the driver's own run (VERDICT r02
+item 3), beside the headline (configuration 4 at one GPU) and `hr_at_10` (configuration 1).  Budget: about a minute.
+
+  cfg2  CDAE hidden_factors=128 at the ml-1m shape, sampled-output sparse-Adagrad step (the same kernels as the headline, MovieLens
+        geometry: 6040 x 3706, 165-item histories) — triples/s, per-kernel dedup-aware roofline fractions, its own cpu_baseline
+  cfg3  DMF and ModifiedDMF (examples/extending_recommender_dmf.py:5-18) at the ml-1m shape, B = 256 and 4096: device step and the
+        public fit() rate; the MFMA bf16 all-pairs scorer (2048 users x 3706 items): time and achieved write GB/s
+  cfg5  Caser (examples/caser.py:13-14) at the ml-1m shape, B = 4096: device step and fit() rate
+No MovieLens files exist offline: the sets are the seeded synthetic stand-ins of drecpy_amd.synth (same shapes)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def frame_of(shape, seed=0):
+    from drecpy_amd import synth
+    U, N, md, mn, a = synth.SHAPES[shape]
+    ip, idx = synth.synth_history(U, N, md, mn, a, seed=seed)
+    ip, idx = ip.numpy(), idx.numpy()
+    rng = np.random.RandomState(seed)
+    user = np.repeat(np.arange(U), np.diff(ip)) + 1
+    item = idx.astype(np.int64) + 1
+    perm = rng.permutation(len(user))                                   # shuffled row order, like a ratings file
+    return {'user': user[perm], 'item': item[perm], 'interaction': rng.randint(1, 6, size=len(user))[perm],
+            'timestamp': rng.randint(0, 10 ** 9, size=len(user))[perm]}
+
+
+def _timed(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def _events_ms(fn, n):
+    """Mean device time of fn() over n calls, HIP events on the current stream."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def dmf_block(ds, dev):
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    from drecpy_amd.Recommender import DMF
+    out = {}
+    classes = [('DMF', DMF)]
+    try:
+        from extending_recommender_dmf import ModifiedDMF
+        classes.append(('ModifiedDMF', ModifiedDMF))
+    except Exception as e:                                      # noqa: BLE001
+        out['ModifiedDMF'] = {'error': repr(e)}
+    m = None
+    for name, cls in classes:
+        for B in (256, 4096):
+            m = cls(user_factors=[64, 32], item_factors=[64, 32], seed=10, verbose=False, device=str(dev))
+            m.fit(ds, epochs=2, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)
+            batch = m._sample_batch(B)
+            state = {'s': 2}
+
+            def step():
+                m._do_batch(batch, step=state['s'])
+                state['s'] += 1
+            dev_s = _timed(step, 40)
+            t0 = time.perf_counter()
+            m.fit(ds, epochs=300, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)      # the public call, set-up included
+            torch.cuda.synchronize()
+            e2e = (time.perf_counter() - t0) / 300
+            out[f'{name}_B{B}'] = {'step_ms': dev_s * 1e3, 'step_samples_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
+                                   'fit_samples_per_s': B / e2e}
+    # the one MFMA kernel: all-pairs cosine scores of a block of users against every item (k_score_pairs_bf16)
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    n_u, n_i = 2048, m.n_items
+    ru = torch.nn.functional.normalize(torch.randn(n_u, 64, device=dev), dim=1)
+    ri = torch.nn.functional.normalize(torch.randn(n_i, 64, device=dev), dim=1)
+    pitch = (n_i + 31) // 32 * 32
+    sc = torch.empty(n_u, pitch, device=dev)
+
+    def score():
+        _lib.check(L.drx_score_pairs_bf16(_lib.ptr(ru), n_u, _lib.ptr(ri), n_i, 64, 32, None, _lib.ptr(sc), pitch, _lib.stream_ptr(dev)), 'score')
+    ms = _events_ms(score, 200)
+    wbytes = n_u * pitch * 4.0
+    flops = 2.0 * n_u * n_i * 32
+    out['mfma_scorer'] = {'kernel': 'k_score_pairs_bf16 (v_mfma_f32_32x32x16_bf16)', 'users': n_u, 'items': n_i, 'factors': 32, 'ms': ms,
+                          'write_bytes': wbytes, 'achieved_write_GBs': wbytes / (ms * 1e-3) / 1e9, 'frac_of_hbm_peak': wbytes / (ms * 1e-3) / 1e9 / 8000.0,
+                          'tflops': flops / (ms * 1e-3) / 1e12, 'bound': 'hbm (16 FLOP per output byte)'}
+    ue = torch.arange(0, n_u, device=dev)
+    out['score_matrix_incl_towers_ms'] = _timed(lambda: m._engine.score_matrix_bf16(ue), 10) * 1e3
+    return out
+
+
+def caser_block(ds, dev):
+    from drecpy_amd.Recommender import Caser
+    out = {}
+    for B in (4096,):
+        m = Caser(L=5, T=3, d=50, n_v=4, n_h=16, dropout_rate=0.5, seed=10, verbose=False, device=str(dev))
+        m.fit(ds, epochs=2, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3)
+        batch = m._sample_batch(B)
+        state = {'s': 2}
+
+        def step():
+            m._do_batch(batch, step=state['s'])
+            state['s'] += 1
+        dev_s = _timed(step, 30)
+        t0 = time.perf_counter()
+        m.fit(ds, epochs=200, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3)
+        torch.cuda.synchronize()
+        e2e = (time.perf_counter() - t0) / 200
+        out[f'Caser_B{B}'] = {'step_ms': dev_s * 1e3, 'step_windows_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
+                              'fit_windows_per_s': B / e2e, 'sampler': getattr(m, '_sampler_kind', 'reference-exact ListSampler stream (C++)')}
+    return out
+
+
+def configs_block(dev, run_direct, base_args, with_cpu=True):
+    """run_direct: bench.py's single-GPU sampled-step measurement (called again at the ml-1m shape)."""
+    import copy
+    out = {}
+    t_all = time.perf_counter()
+    # ---- cfg2 -----------------------------------------------------------------------------------------------------------------
+    try:
+        a = copy.copy(base_args)
+        a.workload, a.steps, a.warmup, a.windows, a.users = 'ml-1m', 30, 5, 3, 0
+        a.no_hr, a.no_configs = True, True
+        a.cpu_budget_s, a.cpu_triples, a.no_all_cores = 5.0, 128, True
+        a.no_cpu_baseline = not with_cpu
+        r = run_direct(a, 0, 1, dev, None)
+        out['cfg2_cdae_ml1m_sampled'] = {
+            'value': r['value'], 'unit': 'samples/s', 'ms_per_step': r['ms_per_step'], 'batch': r['config']['batch_per_gpu'],
+            'workload': r['config']['workload'], 'phases_ms': r['phases_ms'],
+            'roofline': {k_: r['roofline'].get(k_) for k_ in ('kernel', 'frac', 'achieved', 'whole_step_frac', 'kernels', 'cache_bytes_k_seg_reduce', 'cache_bytes_k_sampled_fwd_bwd')}
+            if r.get('roofline') else None,
+            'cpu_baseline': r.get('cpu_baseline')}
+    except Exception as e:                                      # noqa: BLE001
+        out['cfg2_cdae_ml1m_sampled'] = {'error': repr(e)}
+    # ---- cfg3, cfg5 -----------------------------------------------------------------------------------------------------------
+    ds = None
+    try:
+        from drecpy_amd.Dataset import InteractionDataset
+        ds = InteractionDataset.read_df(frame_of('ml-1m'), verbose=False)
+    except Exception as e:                                      # noqa: BLE001
+        out['dataset_error'] = repr(e)
+    if ds is not None:
+        for name, fn in (('cfg3_dmf_ml1m', dmf_block), ('cfg5_caser_ml1m', caser_block)):
+            try:
+                out[name] = fn(ds, dev)
+            except Exception as e:                              # noqa: BLE001
+                out[name] = {'error': repr(e)}
+    out['seconds'] = round(time.perf_counter() - t_all, 1)
+    out['data'] = 'synthetic ml-1m-shaped set (6040 users x 3706 items, ~1 M ratings), drecpy_amd.synth seed 0'
+    return out

@@ -14,6 +14,7 @@ TARGETS_REFERENCE, TARGETS_PER_ROW = 0, 1
 OPT_ADAM, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
 DENSE_AUX_CLEAN = 0x100          # include/drx.h: DRX_DENSE_AUX_CLEAN
 KEY_NONE = 0xFFFFFFFF
+BATCH_MARK_W = 1                 # include/drx.h: DRX_BATCH_MARK_W
 
 
 class DrxError(RuntimeError):
@@ -32,7 +33,7 @@ class History(C.Structure):
 class Batch(C.Structure):
     _fields_ = [('B', C.c_int32), ('uid', C.c_void_p), ('iid', C.c_void_p), ('y', C.c_void_p),
                 ('keep_off', C.c_void_p), ('keep', C.c_void_p), ('mask_seed', C.c_uint64), ('q', C.c_float),
-                ('n_touch_slots', C.c_int32)]
+                ('n_touch_slots', C.c_int32), ('flags', C.c_uint32)]
 
 
 class Shard(C.Structure):

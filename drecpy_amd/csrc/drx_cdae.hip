@@ -579,9 +579,7 @@ struct SparseBufs {
   float *lossb;     // [B]
   float *phead, *ptail;                       // [n_chunks, ld]
   float *phs, *pts;                           // [n_chunks] scalar (b2) partials
-  uint32_t *span_list, *long_list;            // [n_chunks] each
-  uint8_t *cflag;                             // [n_chunks]
-  uint32_t *n_span;                           // [0] crossing segments, [1] long ones
+  float *pblock, *pbs;                        // [n_blocks, ld], [n_blocks]: partials of all-inner workgroups (k_seg_reduce_planned)
   float *bpart;                               // [n_bpart, ld]
   const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row; solo_v + 2B:
                                               //   [B] sample b holds at least one W row that only it touches
@@ -739,7 +737,8 @@ __device__ __forceinline__ float sampled_hidden(const DrxCdaeParams &P, const Dr
 template <int G, int J, int KIND = -1>
 __device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOptim &opt, const DrxHistory &H, const DrxBatch &bt,
                                              float scale, uint32_t qthr, int loss_kind, const SparseBufs &S, int b, int lane,
-                                             float d, const float4 (&h)[J], const float4 (&w2)[J]) {
+                                             float d, const float4 (&h)[J], const float4 (&w2)[J],
+                                             float4 (*dz1_out)[J] = nullptr) {
   const int u = bt.uid[b], i = bt.iid[b];
   const float y = bt.y[b];
   const float p = sigmoidf_(d + P.b2[i]);
@@ -768,6 +767,10 @@ __device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOp
   if (solo_v) sparse_apply<G, J, KIND>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
   const uint32_t *const pw = S.solo_w;
   if (pw && pv[2 * (size_t)bt.B + b]) solo_w_pass<G, J, KIND>(P, opt, H, bt, qthr, scale, pw, b, lane, dz1);
+  if (dz1_out) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) (*dz1_out)[j] = dz1[j];
+  }
 }
 
 template <int G, int J, int KIND = -1>
@@ -828,7 +831,6 @@ __global__ __launch_bounds__(kBlock) void k_kshard_rest(DrxCdaeParams P, DrxOpti
                                                         const float *__restrict__ h_in, const float *__restrict__ dot_total) {
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;     // counters of the segmented reduction that follows
   if (b >= bt.B) return;
   float4 h[J], w2[J];
   load_row<G, J>(h_in, (size_t)b, P.ld, lane, h);
@@ -841,12 +843,144 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
                                                             uint32_t qthr, int loss_kind, SparseBufs S) {
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;     // counters of the segmented reduction that follows
   if (b >= bt.B) return;
   float4 acc[J];
   DenseAux none{};
   gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
   sampled_finish<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, acc);
+}
+
+// The forward/backward kernel with sole-toucher W rows (DRX_BATCH_MARK_W; Adagrad).  A triple that holds marked rows (byte mark)
+// fetches, beside the rows of its gather, the items' bits of the mark bitmap and notes the marked items in LDS.  Right after the
+// gather — when the 8 row buffers of the loop are free — the parameter rows (again: they are in L2) and accumulator rows of those
+// items are requested; they travel in the shadow of the hidden layer's own loads.  At the end the update is arithmetic on registers
+// and two stores per row: no second walk, no extra round trip in the triple's dependent chain (r03a measured the second walk at +120 us for the 10M x 1M batch; the reduction it relieves runs 50 us shorter).  A triple with
+// more than kStash marked rows (rare) takes the walk (solo_w_pass) for all of them.
+constexpr int kStash = 4;
+
+template <int G, int J>
+__device__ __forceinline__ void adagrad_commit(const OptScalars &o, float *tab, float *s1, size_t row, int ld, int lane,
+                                               const float4 (&w)[J], const float4 (&a)[J], const float4 (&g)[J]) {
+  float4 *pr = reinterpret_cast<float4 *>(tab + row * (size_t)ld), *ar = reinterpret_cast<float4 *>(s1 + row * (size_t)ld);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = lane + j * G;
+    if (4 * c < ld) {
+      float4 p = w[j], m = a[j];
+      float unused = 0.f;
+      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.x, g[j].x), p.x, m.x, unused);
+      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.y, g[j].y), p.y, m.y, unused);
+      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.z, g[j].z), p.z, m.z, unused);
+      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.w, g[j].w), p.w, m.w, unused);
+      pr[c] = p;
+      ar[c] = m;
+    }
+  }
+}
+
+#ifdef DRX_STASH_W8
+#define DRX_STASH_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define DRX_STASH_ATTR
+#endif
+template <int G, int J>      // J == 1 only (rows of <= 256 floats: a row is one 16-byte piece per lane)
+__global__ __launch_bounds__(kBlock) DRX_STASH_ATTR void k_sampled_fwd_bwd_stash(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+                                                                  uint32_t qthr, int loss_kind, SparseBufs S) {
+  __shared__ int ids_lds[(kBlock / G) * (kStash + 1)];   // per group: how many W rows this triple alone touches, and which items
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const int b = blockIdx.x * (kBlock / G) + r;
+  if (b >= bt.B) return;
+  const int gshift = (threadIdx.x & 63) / G * G;
+  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+  const uint32_t *const pw = S.solo_w;
+  const uint8_t *const pv = S.solo_v;
+  float4 acc[J];
+  DenseAux none{};
+  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
+  // A triple that holds marked rows (byte mark) walks its history once more right away — indices from L1/L2, mark bits from the
+  // 125 KB bitmap — and notes the marked items in LDS, in history order.  (Done inside the gather loop this cost the kernel its
+  // eighth wave per SIMD: 69 VGPRs; b is laundered so that the gather's copies of uid / indptr are not kept alive for it.)
+  int cnt = 0;
+  if (pv[2 * (size_t)bt.B + b]) {
+    int bq = b;
+    asm volatile("" : "+v"(bq));
+    const int u = bt.uid[bq];
+    const int64_t s = H.indptr[u];
+    const int n = (int)(H.indptr[u + 1] - s);
+    const int32_t *const ind = H.indices + s;
+    const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[bq] : nullptr;
+    for (int c = 0; c < n; c += G) {
+      const int jj = c + lane;
+      int item = 0;
+      bool mk = false;
+      if (jj < n) {
+        item = ind[jj];
+        const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)bq, (uint32_t)jj) >= qthr);
+        mk = kf && ((pw[item >> 5] >> (item & 31)) & 1u);
+      }
+      const unsigned long long m = (__ballot(mk) >> gshift) & gmask;
+      if (m) {
+        const int at = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (mk && at < kStash) ids_lds[r * (kStash + 1) + 1 + at] = item;
+        cnt += __popcll(m);
+      }
+    }
+  }
+  // accumulator rows of the marked items (HBM misses: the slow half of their update), requested NOW and straight into LDS
+  // (global_load_lds: no register is held while they travel in the shadow of the hidden layer's own loads).  One wave-instruction
+  // writes 64 lanes x 16 B = the rows of the wave's 64 / G groups side by side; slot q of the wave lives at q KiB of its region.
+  extern __shared__ __align__(16) float slot_lds[];          // [4 waves][kStash][64 lanes x 4 floats]
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
+  float *const wave_slots = slot_lds + (size_t)wave * kStash * 256;
+  if (lane == 0) ids_lds[r * (kStash + 1)] = cnt;          // (kept in LDS, not in a register, across the rest of the kernel: 64 VGPRs)
+  if (cnt > 0 && cnt <= kStash) {
+    wave_lds_sync();                            // (ids written by some lanes of the group are read by all of them)
+    const float *const a0 = opt.s1[0];
+#pragma unroll
+    for (int q = 0; q < kStash; ++q) {
+      if (q < cnt && 4 * lane < P.ld) {
+        const float *src = a0 + (size_t)ids_lds[r * (kStash + 1) + 1 + q] * P.ld + 4 * lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(wave_slots + q * 256), 16, 0, 0);
+      }
+    }
+  }
+  float4 h[J], w2[J];
+  const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
+  SparseBufs S2 = S;                            // (sampled_rest with the W walk switched off: the marks are served below)
+  S2.solo_w = nullptr;
+  float4 dz1[J];
+  sampled_rest<G, J, DRX_OPT_ADAGRAD>(P, opt, H, bt, scale, qthr, loss_kind, S2, b, lane, d, h, w2, &dz1);
+  wave_lds_sync();
+  const int cnt2 = ids_lds[(threadIdx.x / G) * (kStash + 1)];
+  const int *const my_ids = ids_lds + (threadIdx.x / G) * (kStash + 1) + 1;
+  if (cnt2 > 0 && cnt2 <= kStash) {
+    float4 g[J];
+#pragma unroll
+    for (int jx = 0; jx < J; ++jx) { g[jx] = f4_zero(); f4_fma(g[jx], scale, dz1[jx]); }
+    const OptScalars o = opt_for(opt, 0, bt.B);
+    float *const tW = P.W, *const a0 = opt.s1[0];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's LDS-DMA has landed (nothing else orders a ds_read behind it)
+#pragma unroll
+    for (int q0 = 0; q0 < kStash; q0 += 2) {
+      float4 prow[2][J];                         // the parameter rows again: the gather had them a moment ago, L2 still does
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        prow[q][0] = f4_zero();
+        if (q0 + q < cnt2) load_row<G, J>(tW, (size_t)my_ids[q0 + q], P.ld, lane, prow[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q0 + q < cnt2) {
+          float4 slot[J];
+          slot[0] = *reinterpret_cast<const float4 *>(wave_slots + (q0 + q) * 256 + 4 * (threadIdx.x % 64));
+          adagrad_commit<G, J>(o, tW, a0, (size_t)my_ids[q0 + q], P.ld, lane, prow[q], slot, g);
+        }
+      }
+    }
+  } else if (cnt2 > kStash) {
+    solo_w_pass<G, J, DRX_OPT_ADAGRAD>(P, opt, H, bt, qthr, scale, pw, b, lane, dz1);
+  }
 }
 
 // Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
@@ -859,7 +993,6 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_wg(DrxCdaeParams P, 
   constexpr int R = kBlock / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int b = blockIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x < 2) S.n_span[threadIdx.x] = 0;
   float4 acc[J];
   DenseAux none{};
   gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0, r, R);
@@ -927,11 +1060,19 @@ __device__ __forceinline__ void bias_partial_body(int ld, const BiasArgs &A, int
   float4 acc[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  for (int b = b0 + r; b < b1; b += R) {
-    float4 v[J];
-    load_row<G, J>(A.dz1, (size_t)b, ld, lane, v);
+  constexpr int NB = J == 1 ? 8 : 2;            // rows in flight per group (one at a time made these sums chains of dependent loads)
+  for (int b = b0 + r; b < b1; b += NB * R) {
+    float4 v[NB][J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+    for (int q = 0; q < NB; ++q) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
+      if (b + q * R < b1) load_row<G, J>(A.dz1, (size_t)(b + q * R), ld, lane, v[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(acc[j], v[q][j]);
   }
   store_row<G, J>(lds, (size_t)r, ld, lane, acc);
   __syncthreads();
@@ -964,11 +1105,19 @@ __device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const Dr
   float4 acc[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  for (int i = r; i < A.n_part; i += R) {
-    float4 v[J];
-    load_row<G, J>(A.part, (size_t)i, P.ld, lane, v);
+  constexpr int NB = J == 1 ? 8 : 2;
+  for (int i = r; i < A.n_part; i += NB * R) {
+    float4 v[NB][J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
+    for (int q = 0; q < NB; ++q) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
+      if (i + q * R < A.n_part) load_row<G, J>(A.part, (size_t)(i + q * R), P.ld, lane, v[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(acc[j], v[q][j]);
   }
   store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
   __syncthreads();
@@ -998,24 +1147,29 @@ __device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const Dr
   }
 }
 
-// Tail of the sparse step in two launches instead of four:
-//   A (kBlock threads):    blocks [0, n_fix)  combine the SHORT chunk-crossing segments; the rest are the bias partials
-//   B (kFixBlock threads): blocks [0, n_fix)  combine the LONG ones (queued by A); one more block finishes the bias
-template <int G, int J, class POL = DirectPolicy>
-__global__ __launch_bounds__(kBlock) void k_sparse_tail_a(SegBufs S, POL pol, BiasArgs A, int n_fix) {
-  extern __shared__ __align__(16) float lds[];   // [kBlock/G, ld]
-  __shared__ float red[kBlock / 64];
-  if ((int)blockIdx.x < n_fix) span_short_body<G, J, POL>(S, pol, (int)blockIdx.x, n_fix);
-  else bias_partial_body<G, J, kBlock>(S.ld, A, (int)blockIdx.x - n_fix, lds, red);
-}
+// The two stages of the hidden-bias gradient ride along with the planned segmented reduction (drx_segreduce.hpp): the column-sum
+// partials of dz1 as extra workgroups of k_seg_reduce_planned (they depend on the forward kernel only), the final sum + update of b
+// (+ the mean loss) as one extra workgroup of k_span_planned.  The sparse step is three launches: forward/backward, reduction, spans.
+template <int G, int J>
+struct BiasPartialExtra {
+  int ld;
+  BiasArgs A;
+  __device__ __forceinline__ void operator()(float *lds) const {
+    __shared__ float red[kBlock / 64];
+    bias_partial_body<G, J, kBlock>(ld, A, (int)blockIdx.x, lds, red);
+  }
+};
 
-template <int G, int J, class POL = DirectPolicy>
-__global__ __launch_bounds__(kFixBlock) void k_sparse_tail_b(SegBufs S, POL pol, BiasArgs A, int n_fix) {
-  extern __shared__ __align__(16) float lds[];   // [kFixBlock/G, ld] + [kFixBlock/G]
-  __shared__ float red[kFixBlock / 64];
-  if ((int)blockIdx.x < n_fix) span_long_body<G, J, POL>(S, pol, (int)blockIdx.x, n_fix, lds);
-  else bias_final_body<G, J, kFixBlock>(pol.P, pol.opt, A, lds, red);
-}
+template <int G, int J>
+struct BiasFinalExtra {
+  DrxCdaeParams P;
+  DrxOptim opt;
+  BiasArgs A;
+  __device__ __forceinline__ void operator()(float *lds) const {
+    __shared__ float red[kFixBlock / 64];
+    bias_final_body<G, J, kFixBlock>(P, opt, A, lds, red);
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // scratch layouts (shared by the sizing entry point and the step functions)
@@ -1024,6 +1178,7 @@ constexpr int kSmallBatch = 1024;    // at or below: one workgroup per batch row
 constexpr int kFewRows = 128;        // at or below: that workgroup has 1024 threads (fewer rows than CUs: spread each row wider)
 constexpr int kOutGrid = 512;        // persistent workgroups of k_out_dense (two per CU when LDS allows)
 constexpr int kSweepGrid = 1024;
+constexpr int kLongBlocks = 256, kShortBlocks = 512;   // k_span_planned: workgroups striding over the long / the short spans
 constexpr size_t kLdsBudget = 144 * 1024;
 
 struct DenseLayout {
@@ -1085,6 +1240,8 @@ struct PrepBufs {
   size_t sort_bytes;
   uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo); then [B] "holds a marked W row"
   uint32_t *solo_w;             // [ceil(N/32)] one bit per item
+  SpanPlan plan;                // chunk-crossing segments of the list (k_plan_spans)
+  int n_chunks;
   size_t result_bytes;
   int T, bits;
 };
@@ -1100,6 +1257,10 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.solo_v = cv.take<uint8_t>((size_t)3 * B);
   R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
   R.solo_w = cv.take<uint32_t>(((size_t)P.n_items + 31) / 32);
+  R.n_chunks = (R.T + kChunk - 1) / kChunk;
+  R.plan.desc = cv.take<uint2>(R.n_chunks);
+  R.plan.cnt = cv.take<uint32_t>(64);
+  R.plan.ext = cv.take<uint8_t>(R.n_chunks);
   R.result_bytes = align_up(cv.off, 256);
   R.keys = cv.take<uint32_t>(R.T);
   R.vals = cv.take<uint32_t>(R.T);
@@ -1121,10 +1282,12 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.ptail = cv.take<float>((size_t)S.n_chunks * P.ld);
   S.phs = cv.take<float>(S.n_chunks);
   S.pts = cv.take<float>(S.n_chunks);
-  S.span_list = cv.take<uint32_t>(S.n_chunks);
-  S.long_list = cv.take<uint32_t>(S.n_chunks);
-  S.n_span = cv.take<uint32_t>(64);
-  S.cflag = cv.take<uint8_t>(S.n_chunks);
+  {
+    const int cpb = kBlock / pick_geom(P.ld).G;
+    const int n_blocks = (S.n_chunks + cpb - 1) / cpb;
+    S.pblock = cv.take<float>((size_t)n_blocks * P.ld);
+    S.pbs = cv.take<float>(n_blocks);
+  }
   S.bpart = cv.take<float>((size_t)S.n_bpart * (P.ld + 1));     // partial rows + per-block loss partials
   return S;
 }
@@ -1614,22 +1777,30 @@ int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHis
   return rc;
 }
 
+// The chunk-crossing segments of a sorted list, short ones and long ones (drx_segreduce.hpp, planned variant).  On the pristine list:
+// BEFORE the sole-toucher marks blank any key.
+static int plan_spans(const DrxCdaeParams *p, const PrepBufs &R, hipStream_t st) {
+  DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, 2 * sizeof(uint32_t), st));
+  DRX_HIP(hipMemsetAsync(R.plan.ext, 0, (size_t)R.n_chunks, st));
+  hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.T, R.n_chunks,
+                     kBlock / pick_geom(p->ld).G, R.plan);
+  return DRX_OK;
+}
+
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
   const int gpb = kBlock / 16;
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
                      q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w);
   // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
-  return sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, true, st);
+  const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, true, st);
+  if (rc) return rc;
+  return plan_spans(p, R, st);
 }
 
-// W rows get sole-toucher marks where a batch leaves most of its distinct W rows with one touch: few touches per item on average.
-// (MovieLens shapes: every item collects hundreds of touches, nothing would be marked, and the second walk costs a pass over the
-// 165-item histories.)  DRX_SOLO_W=0/1 in the environment overrides the rule (experiments).
-static bool mark_w_rows(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &) {
-  static const int forced = [] { const char *e = getenv("DRX_SOLO_W"); return e ? atoi(e) : -1; }();
-  if (forced >= 0) return forced != 0;
-  return (int64_t)bt->n_touch_slots <= 4 * (int64_t)p->n_items;
-}
+// W rows get sole-toucher marks when the caller asks for them (DRX_BATCH_MARK_W: worth it where a batch leaves most of its distinct
+// W rows with one touch — large catalogues; at MovieLens shapes every item collects hundreds of touches and nothing would be marked).
+// Rows of <= 16 floats are never marked (see mark_solo).
+static bool mark_w_rows(const DrxCdaeParams *p, const DrxBatch *bt) { return (bt->flags & DRX_BATCH_MARK_W) != 0 && p->ld > 16; }
 
 // Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
 static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
@@ -1641,7 +1812,7 @@ static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs 
   // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
   if (p->ld <= 16) return DRX_OK;       // solo_v and solo_o are adjacent
   hipLaunchKernelGGL(k_mark_solo, dim3(2048), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, (uint32_t)p->n_items, bt->B, R.solo_v,
-                     R.solo_o, mark_w_rows(p, bt, R) ? R.solo_w : nullptr);
+                     R.solo_o, mark_w_rows(p, bt) ? R.solo_w : nullptr);
   return DRX_OK;
 }
 
@@ -1675,8 +1846,9 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
   S.solo_v = prepared ? R.solo_v : nullptr;
   S.solo_o = prepared ? R.solo_o : nullptr;
-  S.solo_w = (prepared && p->ld > 16 && mark_w_rows(p, bt, R)) ? R.solo_w : nullptr;       // (the rule mark_solo followed)
-  SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, S.span_list, S.long_list, S.n_span, S.cflag, S.T, S.n_chunks, p->ld};
+  S.solo_w = (prepared && mark_w_rows(p, bt)) ? R.solo_w : nullptr;       // (the rule mark_solo followed)
+  SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, nullptr, nullptr, nullptr, nullptr, S.T, S.n_chunks, p->ld};
+  PlanBufs PB{S.pblock, S.pbs};
   // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
   const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
@@ -1686,24 +1858,29 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
-  // the segmented reduction and its two fix-up launches, with the policy type POLT (optimizer at run time, or Adagrad compiled in)
-#define REDUCE_AND_TAILS(G, J, POLT)                                                                                   \
+  // the segmented reduction (+ the bias column sums as extra workgroups) and the ONE launch that combines the chunk-crossing segments
+  // (+ the bias update), with the policy type POLT (optimizer at run time, or Adagrad compiled in)
+#define REDUCE_AND_SPANS(G, J, POLT)                                                                                   \
   {                                                                                                                    \
     POLT polk{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};                                        \
+    BiasPartialExtra<G, J> bpx{p->ld, BA};                                                                             \
+    BiasFinalExtra<G, J> bfx{*p, *opt, BA};                                                                            \
+    const int cpb = kBlock / G;                                                                                        \
+    const dim3 rgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                                          \
+    const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
     if (long_segments)                                                                                                 \
-      hipLaunchKernelGGL((k_seg_reduce<G, J, POLT, 8>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
-                         polk);                                                                                        \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kBlock), lds_r, st, SB, PB,       \
+                         R.plan.ext, polk, n_bpart, bpx);                                                              \
     else                                                                                                               \
-      hipLaunchKernelGGL((k_seg_reduce<G, J, POLT, 2>), dim3((S.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, SB, \
-                         polk);                                                                                        \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kBlock), lds_r, st, SB, PB,       \
+                         R.plan.ext, polk, n_bpart, bpx);                                                              \
     EV(3);                                                                                                             \
-    hipLaunchKernelGGL((k_sparse_tail_a<G, J, POLT>), dim3(1024 + n_bpart), dim3(kBlock), (size_t)gpb * p->ld * 4, st, SB, polk, BA, \
-                       1024);                                                                                          \
-    EV(4);                                                                                                             \
     if (lds_b > 48 * 1024)                                                                                             \
-      DRX_HIP(hipFuncSetAttribute((const void *)k_sparse_tail_b<G, J, POLT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds_b));                                                                        \
-    hipLaunchKernelGGL((k_sparse_tail_b<G, J, POLT>), dim3(256 + 1), dim3(kFixBlock), lds_b, st, SB, polk, BA, 256);   \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>,                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                            \
+    hipLaunchKernelGGL((k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>), dim3(kLongBlocks + kShortBlocks + 1), dim3(kFixBlock), lds_b, \
+                       st, SB, PB, R.plan, polk, kLongBlocks, kShortBlocks, bfx);                                      \
+    EV(4);                                                                                                             \
     EV(5);                                                                                                             \
   }
 #define CALL(G, J)                                                                                                     \
@@ -1717,6 +1894,9 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     else if (per_wg)                                                                                                   \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
                          *bt, scale, qthr, loss_kind, S);                                                              \
+    else if (opt->kind == DRX_OPT_ADAGRAD && S.solo_w && J == 1)                                                       \
+      hipLaunchKernelGGL((k_sampled_fwd_bwd_stash<G, 1>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock),                 \
+                         (size_t)(kBlock / 64) * kStash * 1024, st, *p, *opt, *hist, *bt, scale, qthr, loss_kind, S);  \
     else if (opt->kind == DRX_OPT_ADAGRAD)                                                                             \
       hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, \
                          *hist, *bt, scale, qthr, loss_kind, S);                                                       \
@@ -1729,12 +1909,12 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
       if (rc) return rc;                                                                                               \
     }                                                                                                                  \
     EV(2);                                                                                                             \
-    if (opt->kind == DRX_OPT_ADAGRAD) { REDUCE_AND_TAILS(G, J, DirectPolicyAdagrad); }                                 \
-    else { REDUCE_AND_TAILS(G, J, DirectPolicy); }                                                                     \
+    if (opt->kind == DRX_OPT_ADAGRAD) { REDUCE_AND_SPANS(G, J, DirectPolicyAdagrad); }                                 \
+    else { REDUCE_AND_SPANS(G, J, DirectPolicy); }                                                                     \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL
-#undef REDUCE_AND_TAILS
+#undef REDUCE_AND_SPANS
 #undef EV
   DRX_LAUNCH_CHECK();
   return DRX_OK;
@@ -1837,6 +2017,8 @@ int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt,
   const PartOut o = part_out_layout(*p, bt->B, bt->n_touch_slots, parts);
   hipLaunchKernelGGL(k_assemble_parts, dim3(2048), dim3(256), 0, st, (const char *)all_parts, o.bytes, o.runs_off, o.vals_off, parts, R.T,
                      R.keys_s, R.vals_s, overflow_out);
+  rc = plan_spans(p, R, st);
+  if (rc) return rc;
   rc = mark_solo(p, bt, R, st, false);
   if (rc) return rc;
   DRX_LAUNCH_CHECK();

@@ -150,6 +150,313 @@ __global__ __launch_bounds__(kBlock) void k_seg_reduce(SegBufs S, Policy pol) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// PLANNED variant (the CDAE sparse step, r03): everything about the list's STRUCTURE — which segments cross chunk borders, how far,
+// which of them are long — depends on the sorted keys alone, so it is worked out when the list is prepared (k_plan_spans, on the
+// preparation's stream, ahead of the step) instead of between the training kernels:
+//   * k_seg_reduce_planned writes no chunk flags and appends to no list; a workgroup whose chunks ALL lie inside one segment that
+//     began before it ("all-inner": the middle of a hot row) folds its kBlock/G chunk sums in LDS, in chunk order, into ONE block
+//     partial — a row with 50 000 touches leaves 200 partial rows instead of 1 600;
+//   * a segment that starts in one chunk and ends inside the NEXT one is simply finished by the chunk it starts in (SpanPlan::ext: that
+//     chunk's window reaches ext touches into its neighbour's, whose window starts behind them) — r02 tried this with the lengths found
+//     at run time and lost to the extra dependent loads; here they are one byte per chunk, known beforehand;
+//   * k_span_planned combines short and long spans in ONE launch (their lengths are known: no flag probing, no second tier queued by
+//     the first) — the step's tail is one launch instead of two.
+// Sum order of a crossing segment: tail partial of its first chunk, then its partials in chunk order, a block partial being the
+// in-order sum of its chunks.  Fixed by the list alone: bit-reproducible.
+struct SpanPlan {
+  uint2 *desc;          // [n_chunks]: short spans from the front, long spans from the back; x = first chunk g0, y = m_in | has_end << 31
+  uint32_t *cnt;        // [0] short spans, [1] long spans
+  uint8_t *ext;         // [n_chunks] (zeroed before k_plan_spans): chunk g also takes the first ext[g] touches of chunk g + 1 — the end of
+                        //   a segment that starts in g and ends inside g + 1 (the commonest crossing by far: no partial rows, no span)
+};
+
+struct PlanBufs {
+  float *pblock;        // [n_blocks, ld] block partials (all-inner workgroups)
+  float *pbs;           // [n_blocks]
+};
+
+// partials of a span after its first chunk: lead chunks up to the next workgroup boundary, whole all-inner workgroups, trailing chunks
+struct SpanShape {
+  int first, n_lead, n_blk, n_trail;
+  __host__ __device__ SpanShape(uint2 d, int cpb) {
+    const int m_in = (int)(d.y & 0x7FFFFFFFu), has_end = (int)(d.y >> 31);
+    first = (int)d.x + 1;
+    const int to_boundary = (cpb - first % cpb) % cpb;
+    n_lead = m_in < to_boundary ? m_in : to_boundary;
+    n_blk = (m_in - n_lead) / cpb;
+    n_trail = m_in - n_lead - n_blk * cpb + has_end;
+  }
+  __host__ __device__ int total() const { return n_lead + n_blk + n_trail; }
+};
+
+// One thread per chunk of the PRISTINE sorted list (before sole-toucher blanking): a chunk whose last key continues into the next
+// chunk and that is not itself the inside of that segment starts a span; the segment's end is found by binary search.
+template <int DUMMY = 0>
+__global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, SpanPlan P) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_chunks) return;
+  const int start = g * kChunk, end = min(T, start + kChunk);
+  const uint32_t last = keys_s[end - 1];
+  if (last == DRX_KEY_NONE || end >= T || keys_s[end] != last) return;
+  const uint32_t first = keys_s[start], prev = start > 0 ? keys_s[start - 1] : DRX_KEY_NONE;
+  if (first == last && prev == last) return;                     // inside a segment that began earlier
+  // first position in [end, T) with another key.  The touches of a key are ONE run of the list (whether the list is sorted as a whole
+  // or assembled from sorted parts), so "key == last" is true up to the end of the run and false from there on.
+  int lo = end, hi = T;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys_s[mid] == last) lo = mid + 1; else hi = mid;
+  }
+  const int seg_end = lo;
+  const int full_end = seg_end / kChunk;                         // chunks [g + 1, full_end) lie wholly inside the segment
+  const uint32_t m_in = (uint32_t)(full_end - (g + 1)), has_end = (seg_end % kChunk) ? 1u : 0u;
+  if (m_in == 0) {                                               // ends inside the next chunk: this chunk's window takes those touches
+    P.ext[g] = (uint8_t)(seg_end - end);
+    return;
+  }
+  const uint2 d = make_uint2((uint32_t)g, m_in | (has_end << 31));
+  if (SpanShape(d, cpb).total() <= kShortSpan) P.desc[atomicAdd(&P.cnt[0], 1u)] = d;
+  else P.desc[n_chunks - 1 - (int)atomicAdd(&P.cnt[1], 1u)] = d;
+}
+
+// LDS: [kBlock/G, ld] floats + [kBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
+// CDAE step's bias column sums: independent work that fills the launch's ramp).
+#ifdef DRX_SEGP_W8
+#define DRX_SEGP_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define DRX_SEGP_ATTR
+#endif
+template <int G, int J, class Policy, int LB1, class Extra>
+__global__ __launch_bounds__(kBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(SegBufs S, PlanBufs PB, const uint8_t *__restrict__ ext, Policy pol,
+                                                                            int extra_blocks, Extra extra) {
+  extern __shared__ __align__(16) float seg_lds[];
+  constexpr int CPB = kBlock / G;
+  if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
+  const int blk = (int)blockIdx.x - extra_blocks;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const int g = blk * CPB + r;
+  bool inner = false;          // this chunk is one whole run of a segment that began before it
+  if (g < S.n_chunks && (g + 1) * kChunk <= S.T) {
+    const uint32_t f = S.keys_s[g * kChunk], l = S.keys_s[(g + 1) * kChunk - 1], pk = g > 0 ? S.keys_s[g * kChunk - 1] : DRX_KEY_NONE;
+    inner = f != DRX_KEY_NONE && f == pk && l == f;
+  }
+  const bool all_inner = __syncthreads_and(inner ? 1 : 0) != 0;
+  if (g >= S.n_chunks) return;          // (never in an all-inner workgroup: its second barrier below sees every thread)
+  // this chunk's window: behind the touches its left neighbour finishes for it, and into the right neighbour's for the segment it
+  // finishes itself (SpanPlan::ext); up to 2 * kChunk - 1 touches
+  const int start = min(S.T, g * kChunk + (g > 0 ? (int)ext[g - 1] : 0)), end = min(S.T, (g + 1) * kChunk + (int)ext[g]);
+  const int n = max(0, end - start);
+  const uint32_t prev_key = start > 0 ? S.keys_s[start - 1] : DRX_KEY_NONE;
+  const uint32_t next_key = end < S.T ? S.keys_s[end] : DRX_KEY_NONE;
+  constexpr int KPL = (2 * kChunk + G - 1) / G;
+  constexpr int LB = J == 1 ? LB1 : (J == 2 ? 4 : 2);
+  uint32_t kreg[KPL], vreg[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; ++q) {
+    const int t = q * G + lane;
+    const bool ok = t < n;
+    kreg[q] = ok ? S.keys_s[start + t] : DRX_KEY_NONE;
+    vreg[q] = ok ? S.vals_s[start + t] : 0u;
+  }
+  auto bcast = [&](const uint32_t (&reg)[KPL], int t) -> uint32_t {
+    uint32_t sel = reg[0];
+#pragma unroll
+    for (int q = 1; q < KPL; ++q) sel = (t / G == q) ? reg[q] : sel;
+    return (uint32_t)__shfl((int)sel, t % G, G);
+  };
+  float4 acc[J];
+#pragma unroll
+  for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+  float accs = 0.f;
+  uint32_t cur = DRX_KEY_NONE;
+  int cur_pos = 0;
+  bool cur_from_start = false;
+  auto flush = [&](bool at_end) {
+    if (cur == DRX_KEY_NONE) return;
+    const bool cont_left = cur_from_start && prev_key == cur;
+    const bool cont_right = at_end && next_key == cur;
+    if (!cont_left && !cont_right) {
+      pol.template finish<G, J>(cur, cur_pos, lane, acc, accs);
+    } else if (cont_left) {
+      if (!all_inner) {
+        store_row<G, J>(S.phead, (size_t)g, S.ld, lane, acc);
+        if (lane == 0) S.phs[g] = accs;
+      }
+    } else {
+      store_row<G, J>(S.ptail, (size_t)g, S.ld, lane, acc);
+      if (lane == 0) S.pts[g] = accs;
+    }
+  };
+  for (int t0 = 0; t0 < n; t0 += LB) {
+    uint32_t k8[LB];
+    float s8[LB], c8[LB];
+    float4 rows[LB][J];
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      const int t = t0 + u;
+      k8[u] = t < n ? bcast(kreg, t) : DRX_KEY_NONE;
+      const uint32_t b = bcast(vreg, t < n ? t : 0);
+      s8[u] = 0.f;
+      c8[u] = 1.f;
+#pragma unroll
+      for (int jx = 0; jx < J; ++jx) rows[u][jx] = f4_zero();
+      if (k8[u] != DRX_KEY_NONE) pol.template load<G, J>(k8[u], b, lane, rows[u], s8[u], c8[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      const uint32_t key = k8[u];
+      if (key != DRX_KEY_NONE) {
+        if (key != cur) {
+          flush(false);
+          cur = key;
+          cur_from_start = (t0 + u == 0);
+#pragma unroll
+          for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+          accs = 0.f;
+        }
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c8[u], rows[u][jx]);
+        accs += s8[u];
+        cur_pos = start + t0 + u;
+      }
+    }
+  }
+  flush(n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE);
+  if (all_inner) {                 // every chunk of this workgroup is one whole run of the same segment: one partial for all of them
+    float *sc = seg_lds + (size_t)CPB * S.ld;
+    store_row<G, J>(seg_lds, (size_t)r, S.ld, lane, acc);
+    if (lane == 0) sc[r] = accs;
+    __syncthreads();
+    if (r == 0) {
+      float4 t[J];
+#pragma unroll
+      for (int jx = 0; jx < J; ++jx) t[jx] = f4_zero();
+      float ts = 0.f;
+#pragma unroll 8
+      for (int rr = 0; rr < CPB; ++rr) {
+        float4 v[J];
+        load_row<G, J>(seg_lds, (size_t)rr, S.ld, lane, v);
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) f4_add(t[jx], v[jx]);
+        ts += sc[rr];
+      }
+      store_row<G, J>(PB.pblock, (size_t)blk, S.ld, lane, t);
+      if (lane == 0) PB.pbs[blk] = ts;
+    }
+  }
+}
+
+// partial i of a span (after the tail partial of its first chunk)
+template <int G, int J>
+__device__ __forceinline__ void span_partial(const SegBufs &S, const PlanBufs &PB, const SpanShape &sh, int cpb, int i, int lane,
+                                             float4 (&v)[J], float &sv) {
+  if (i < sh.n_lead) {
+    const int c = sh.first + i;
+    load_row<G, J>(S.phead, (size_t)c, S.ld, lane, v); sv = S.phs[c];
+  } else if (i < sh.n_lead + sh.n_blk) {
+    const int bb = (sh.first + sh.n_lead) / cpb + (i - sh.n_lead);
+    load_row<G, J>(PB.pblock, (size_t)bb, S.ld, lane, v); sv = PB.pbs[bb];
+  } else {
+    const int c = sh.first + sh.n_lead + sh.n_blk * cpb + (i - sh.n_lead - sh.n_blk);
+    load_row<G, J>(S.phead, (size_t)c, S.ld, lane, v); sv = S.phs[c];
+  }
+}
+
+// One launch, kFixBlock threads: workgroups [0, n_long_blocks) take the long spans (one workgroup per span, its groups stride over the
+// partials, group sums combined in LDS in group order), workgroups [n_long_blocks, n_long_blocks + n_short_blocks) the short ones (one
+// group per span), the rest run `extra` (the CDAE step: one workgroup finishing the hidden bias).  LDS: [R, ld] + [R] floats.
+template <int G, int J, class Policy, class Extra>
+__global__ __launch_bounds__(kFixBlock) void k_span_planned(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol, int n_long_blocks,
+                                                            int n_short_blocks, Extra extra) {
+  extern __shared__ __align__(16) float span_lds[];
+  constexpr int R = kFixBlock / G, CPB = kBlock / G;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  constexpr int UL = J == 1 ? 8 : 2;                       // partial rows in flight per group
+  if ((int)blockIdx.x >= n_long_blocks + n_short_blocks) { extra(span_lds); return; }
+  if ((int)blockIdx.x >= n_long_blocks) {
+    const uint32_t n_short = SP.cnt[0];
+    for (uint32_t si = ((int)blockIdx.x - n_long_blocks) * R + r; si < n_short; si += (uint32_t)n_short_blocks * R) {
+      const uint2 d = SP.desc[si];
+      const SpanShape sh(d, CPB);
+      const int g0 = (int)d.x, tot = sh.total();
+      const int kpos = min(S.T, (g0 + 1) * kChunk) - 1;
+      float4 t[J];
+      load_row<G, J>(S.ptail, (size_t)g0, S.ld, lane, t);
+      float ts = S.pts[g0];
+      for (int i0 = 0; i0 < tot; i0 += UL) {
+        float4 v[UL][J];
+        float sv[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          sv[u] = 0.f;
+#pragma unroll
+          for (int j = 0; j < J; ++j) v[u][j] = f4_zero();
+          if (i0 + u < tot) span_partial<G, J>(S, PB, sh, CPB, i0 + u, lane, v[u], sv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) f4_add(t[j], v[u][j]);
+          ts += sv[u];
+        }
+      }
+      pol.template finish<G, J>(S.keys_s[kpos], kpos, lane, t, ts);
+    }
+    return;
+  }
+  float *sc = span_lds + (size_t)R * S.ld;
+  const uint32_t n_long = SP.cnt[1];
+  for (uint32_t si = blockIdx.x; si < n_long; si += (uint32_t)n_long_blocks) {
+    const uint2 d = SP.desc[S.n_chunks - 1 - (int)si];
+    const SpanShape sh(d, CPB);
+    const int g0 = (int)d.x, tot = sh.total();
+    const int kpos = min(S.T, (g0 + 1) * kChunk) - 1;
+    float4 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+    float accs = 0.f;
+    // group r takes the contiguous slice [r * per, (r + 1) * per) of the partials, so that the combine below is in partial order
+    const int per = (tot + R - 1) / R;
+    const int i_lo = r * per, i_hi = min(tot, i_lo + per);
+    for (int i0 = i_lo; i0 < i_hi; i0 += UL) {
+      float4 v[UL][J];
+      float sv[UL];
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        sv[u] = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) v[u][j] = f4_zero();
+        if (i0 + u < i_hi) span_partial<G, J>(S, PB, sh, CPB, i0 + u, lane, v[u], sv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(acc[j], v[u][j]);
+        accs += sv[u];
+      }
+    }
+    __syncthreads();                                         // (the previous span's readers are done with the LDS rows)
+    store_row<G, J>(span_lds, (size_t)r, S.ld, lane, acc);
+    if (lane == 0) sc[r] = accs;
+    __syncthreads();
+    if (r == 0) {
+      float4 t[J];
+      load_row<G, J>(S.ptail, (size_t)g0, S.ld, lane, t);
+      float ts = S.pts[g0];
+#pragma unroll 8
+      for (int rr = 0; rr < R; ++rr) {
+        float4 v[J];
+        load_row<G, J>(span_lds, (size_t)rr, S.ld, lane, v);
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
+        ts += sc[rr];
+      }
+      pol.template finish<G, J>(S.keys_s[kpos], kpos, lane, t, ts);
+    }
+  }
+}
+
 // Fix-up of chunk-crossing segments, two tiers.
 //   k_span_short : one GROUP per crossing segment: tail partial of its first chunk + head partials of the next chunks
 //                  whose first key equals the segment key, in chunk order.  Segments that cross more than

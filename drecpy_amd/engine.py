@@ -44,6 +44,11 @@ class CdaeEngine:
         self._scratch = None
         self._dense_scratch, self._dense_scratch_B, self._dense_clean = None, None, False
         self._loss = torch.zeros(2, **z)
+        # sampled mode: ask drx_cdae_sparse_prepare to mark the W rows a single triple of the batch touches, for the forward kernel to
+        # update (include/drx.h DRX_BATCH_MARK_W).  'auto': where a batch leaves most of its distinct W rows with one touch — at most 4
+        # history slots per item of the catalogue — with Adagrad, on rows of 17..256 floats (the kernel that serves the marks);
+        # False: never (the column-sharded layout: its forward half is a kernel of its own)
+        self.mark_w_rows = 'auto'
 
     # ---- parameters -------------------------------------------------------------------------
     def tables(self):
@@ -227,7 +232,7 @@ class CdaeEngine:
         base = dev.data_ptr()
         at = lambda name: (base + offs[name]) if name in offs else None
         bt = Batch(B, at('uid'), at('iid'), at('y'), at('keep_off'), at('keep'), int(mask_seed) & (2 ** 64 - 1), float(q),
-                   int(n_touch_slots))
+                   int(n_touch_slots), self._batch_flags(n_touch_slots))
         return bt, (dev,)
 
     # ---- batches a producer thread writes straight into pinned memory (reference-mode fit()) -----------------------------
@@ -283,6 +288,15 @@ class CdaeEngine:
         st['ev'][slot[0]].record(torch.cuda.current_stream(self.device))
         st['busy'][slot[0]] = True
 
+    def _batch_flags(self, n_touch_slots):
+        import os
+        forced = os.environ.get('DRX_SOLO_W')
+        if forced is not None:
+            return _lib.BATCH_MARK_W if forced == '1' else 0
+        on = (self.mark_w_rows == 'auto' and getattr(self, 'opt_kind', None) == _lib.OPT_ADAGRAD and 16 < self.ld <= 256
+              and n_touch_slots is not None and 0 < int(n_touch_slots) <= 4 * self.n_items)
+        return _lib.BATCH_MARK_W if (on or self.mark_w_rows is True) else 0
+
     def make_batch(self, uid, iid=None, y=None, keep_off=None, keep=None, q=0.0, mask_seed=0, n_touch_slots=None):
         """Uploads (if needed) one batch and returns (Batch struct, keep-alive tensors)."""
         if (keep_off is not None and n_touch_slots is not None and self.device.type == 'cuda'
@@ -304,7 +318,7 @@ class CdaeEngine:
         if keep is not None and keep.numel() == 0:
             keep = torch.zeros(1, dtype=torch.uint8, device=self.device)
         bt = Batch(B, ptr(uid), ptr(iid), ptr(y), ptr(keep_off), ptr(keep), int(mask_seed) & (2 ** 64 - 1), float(q),
-                   int(n_touch_slots))
+                   int(n_touch_slots), self._batch_flags(n_touch_slots))
         return bt, (uid, iid, y, keep_off, keep)
 
     def _ensure_scratch(self, B, n_touch_slots, dense=False):

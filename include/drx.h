@@ -83,7 +83,13 @@ typedef struct DrxBatch {
   uint64_t mask_seed;
   float q;                  /* corruption level; survivors are scaled by 1/(1-q) */
   int32_t n_touch_slots;    /* host-known upper bound of keep_off[B] (sizes the sort) */
+  uint32_t flags;           /* DRX_BATCH_* (0: none) */
 } DrxBatch;
+
+/* drx_cdae_sparse_prepare also marks the W rows that ONE triple of the batch touches (a bit per item) and the step's forward kernel
+ * updates them itself — worth it where a batch leaves most of its distinct W rows with a single touch (large catalogues, long-tailed
+ * popularity); prepare and step must see the same flag.  Without it only V / W2T rows are marked. */
+#define DRX_BATCH_MARK_W 1u
 
 typedef struct DrxOptim {
   int32_t kind;             /* DRX_OPT_* */

@@ -1,0 +1,25 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/${1:-r03d}
+mkdir -p $OUT
+python -m pytest tests -x -q -m gpu > $OUT/tests.log 2>&1
+echo "tests rc=$?"; tail -4 $OUT/tests.log
+run() { # name env...
+  name=$1; shift
+  for rep in 1 2; do
+    env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-hr --no-configs > $OUT/bench_${name}_$rep.json 2>> $OUT/bench.err
+  done
+}
+run marks_auto X=0
+run marks_off DRX_SOLO_W=0
+run marks_auto_sw8 DRX_HOST_SANITIZER_LIB=$PWD/drecpy_amd/csrc/build/libdrx_sw8.so
+python - $OUT <<'PY'
+import glob, json, sys
+for f in sorted(glob.glob(sys.argv[1] + '/bench_*.json')):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith('{')][-1])
+        print(f.split('/')[-1], round(d['value'] / 1e6, 1), 'M/s', round(d['ms_per_step'], 4), [round(v * 1e3, 1) for v in d['phases_ms'].values()], 'frac', round(d['roofline']['frac'], 3), round(d['roofline']['whole_step_frac'], 3))
+    except Exception as e:
+        print(f, 'ERR', e)
+PY
+tail -3 $OUT/bench.err

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contracted_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'ml-100k', '--batch', '4096', '--steps', '20',
-                          '--warmup', '5', '--no-hr'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          '--warmup', '5', '--no-hr', '--force-configs', '--cpu-budget-s', '3'], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -22,11 +23,29 @@ def test_bench_line_has_the_contracted_fields():
     assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['scaling'] == 'weak' and d['data'] == 'synthetic'
     assert d['vs_baseline'] is None and d['dtype'] == 'f32' and 'workload' in d['config'] and 'model' not in d['config']
     assert abs(d['value'] - 4096 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6          # whole-job samples over the timed steps
+    # five back-to-back windows of exactly `steps` steps; the line's numbers are the median window's
+    assert d['windows'] == 5 and len(d['window_ms']) == 5 and d['window_ms_min'] <= d['ms_per_step'] * 20 * (1 + 1e-9) <= d['window_ms_max'] * (1 + 1e-6)
+    assert abs(sorted(d['window_ms'])[2] - d['ms_per_step'] * 20) < 1e-3 and d['rccl_ranks'] == 1
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert 0.0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert r['traffic'] is None or r['traffic'] > 0                                       # (PMC passes are of the 10M x 1M workload)
-    for k in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
+    for k in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned'):
         assert 0.0 < r['kernels'][k]['frac'] <= 1.0 and r['kernels'][k]['avg_launch_ms'] > 0
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and c['unit'] == 'samples/s' and c['sample']
+    a = d['cpu_baseline_all_cores']
+    assert a['kind'] == 'port' and a['cores'] >= 1 and a['value'] > 0 and a['unit'] == 'samples/s' and 'worker processes' in a['sample']
+    # BASELINE configurations 2, 3 and 5 in the same line
+    g = d['configs']
+    c2 = g['cfg2_cdae_ml1m_sampled']
+    assert c2['value'] > 0 and c2['unit'] == 'samples/s' and 0.0 < c2['roofline']['frac'] <= 1.0 and c2['cpu_baseline']['value'] > 0
+    for k in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned'):
+        assert 0.0 < c2['roofline']['kernels'][k]['frac'] <= 1.0
+    c3 = g['cfg3_dmf_ml1m']
+    for name in ('DMF_B256', 'DMF_B4096', 'ModifiedDMF_B256', 'ModifiedDMF_B4096'):
+        assert c3[name]['step_ms'] > 0 and c3[name]['fit_samples_per_s'] > 0
+    m = c3['mfma_scorer']
+    assert m['users'] == 2048 and m['achieved_write_GBs'] > 0 and 0.0 < m['frac_of_hbm_peak'] <= 1.0
+    c5 = g['cfg5_caser_ml1m']['Caser_B4096']
+    assert c5['step_ms'] > 0 and c5['fit_windows_per_s'] > 0
