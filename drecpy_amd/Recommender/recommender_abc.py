@@ -263,6 +263,8 @@ class RecommenderABC(ABC):
 
     def _register_optimizer(self, optimizer):
         self.optimizer = optimizer
+        if hasattr(optimizer, 'reset'):       # an optimizer object reused for another fit() starts over: call counter and moments
+            optimizer.reset()
 
     def _configure_optimizer(self):
         """Called once per fit() after _pre_fit and the `optimizer=` override: models push the registered optimizer's kind and

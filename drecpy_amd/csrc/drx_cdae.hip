@@ -11,7 +11,7 @@
 #include "drx_rows.hpp"
 #include "drx_segreduce.hpp"
 #include <cstring>
-#include <rocprim/device/device_scan.hpp>
+#include "drx_scan.hpp"
 
 #ifndef DRX_GATHER_ROWS
 #define DRX_GATHER_ROWS 8
@@ -983,6 +983,104 @@ __global__ __launch_bounds__(kBlock) DRX_STASH_ATTR void k_sampled_fwd_bwd_stash
   }
 }
 
+// The forward/backward kernel with its late rows PREFETCHED INTO LDS (Adagrad, one float4 per lane; r03).  One triple is a chain of
+// dependent round trips: uid -> indptr -> indices -> rows (two rounds) -> V[u], b -> W2T[i] -> b2[i], y -> marks -> slot rows of the
+// sole-toucher updates, and with 16 such chains per SIMD the kernel is bound by their LENGTH (r02: 69 % of the wave-cycles in
+// s_waitcnt at 3.6 TB/s).  Everything behind the gather depends on (u, i) alone, but fetching it early into registers cost two waves
+// per SIMD (r02e: 90 VGPRs, no gain).  global_load_lds needs no register: V[u], W2T[i] and — where the marks say this triple is their
+// only toucher — the two accumulator rows are requested as soon as uid / iid are known, land in LDS while the gather runs, and are
+// read back with ds_read: the chain behind the gather shrinks to one round trip (b, b2[i], y: L2 hits) and the stores.
+// One wave-instruction writes 64 lanes x 16 B: the rows of the wave's 64 / G groups side by side; slot s of a wave is at s KiB.
+template <int G>
+__device__ __forceinline__ void glds_row(const float *tab, size_t row, int ld, int lane, float *lds_slot) {
+  if (4 * lane < ld)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tab + row * (size_t)ld + 4 * lane),
+                                     (__attribute__((address_space(3))) void *)lds_slot, 16, 0, 0);
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_pf(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+                                                               uint32_t qthr, int loss_kind, SparseBufs S) {
+  extern __shared__ __align__(16) float pf_lds[];            // [kBlock / 64 waves][4 slots][64 lanes x 4 floats]
+  const int lane = threadIdx.x % G;
+  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (b >= bt.B) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
+  float *const ws = pf_lds + (size_t)wave * 4 * 256;
+  const int wl4 = 4 * (int)(threadIdx.x % 64);
+  const bool act = 4 * lane < P.ld;
+  {
+    // (the two accumulator rows are requested whatever the marks say — nine triples in ten are the only toucher of their V and
+    // W2T rows — so that nothing here waits for a mark byte before the gather's own chain starts)
+    const int u = bt.uid[b], i = bt.iid[b];
+    glds_row<G>(P.V, (size_t)u, P.ld, lane, ws);
+    glds_row<G>(P.W2T, (size_t)i, P.ld, lane, ws + 256);
+    if (S.solo_v) {
+      glds_row<G>(opt.s1[2], (size_t)u, P.ld, lane, ws + 512);
+      glds_row<G>(opt.s1[1], (size_t)i, P.ld, lane, ws + 768);
+    }
+  }
+  float4 acc[1];
+  DenseAux none{};
+  gather_bag<G, 1, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
+  // (b laundered: ids and marks are re-read — L1 hits — instead of living in registers through the gather)
+  int bq = b;
+  asm volatile("" : "+v"(bq));
+  const int u = bt.uid[bq], i = bt.iid[bq];
+  const uint8_t *const pv = S.solo_v, *const po = S.solo_o;
+  const bool solo_v = pv && pv[bq], solo_o = po && po[bq];
+  float4 bb[1];
+  load_row<G, 1>(P.b, 0, P.ld, lane, bb);
+  const float y = bt.y[bq], pb2 = P.b2[i];
+  const float mb2 = solo_o ? opt.s1[4][i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's LDS-DMA has landed (nothing else orders a ds_read behind it)
+  const float4 zero = f4_zero();
+  const float4 v = act ? *reinterpret_cast<const float4 *>(ws + wl4) : zero;
+  const float4 w2 = act ? *reinterpret_cast<const float4 *>(ws + 256 + wl4) : zero;
+  float4 h;
+  {
+    const int col = 4 * lane;
+    h.x = colmask(col + 0, P.k, sigmoidf_(fmaf(scale, acc[0].x, v.x + bb[0].x)));
+    h.y = colmask(col + 1, P.k, sigmoidf_(fmaf(scale, acc[0].y, v.y + bb[0].y)));
+    h.z = colmask(col + 2, P.k, sigmoidf_(fmaf(scale, acc[0].z, v.z + bb[0].z)));
+    h.w = colmask(col + 3, P.k, sigmoidf_(fmaf(scale, acc[0].w, v.w + bb[0].w)));
+  }
+  const float d = group_sum<G>(f4_dot(w2, h));
+  const float p = sigmoidf_(d + pb2);
+  const float invB = 1.0f / (float)bt.B;
+  float lval, dp;
+  if (loss_kind == DRX_LOSS_BCE) { lval = bce_elem(y, p); dp = bce_grad(y, p) * invB; }
+  else { lval = (p - y) * (p - y); dp = 2.0f * (p - y) * invB; }
+  const float dz2 = dp * p * (1.0f - p);
+  float4 dz1[1], g2[1];
+  dz1[0].x = dz2 * w2.x * h.x * (1.0f - h.x); dz1[0].y = dz2 * w2.y * h.y * (1.0f - h.y);
+  dz1[0].z = dz2 * w2.z * h.z * (1.0f - h.z); dz1[0].w = dz2 * w2.w * h.w * (1.0f - h.w);
+  g2[0].x = dz2 * h.x; g2[0].y = dz2 * h.y; g2[0].z = dz2 * h.z; g2[0].w = dz2 * h.w;
+  store_row<G, 1>(S.dz1, (size_t)b, P.ld, lane, dz1);
+  if (lane == 0) S.lossb[b] = lval;
+  OptScalars o = opt_for(opt, 0, bt.B);
+  if (solo_o) {      // this triple alone touches W2T[i] and b2[i] (same arithmetic as sparse_apply / the segment path)
+    float4 w[1] = {w2}, a[1];
+    a[0] = act ? *reinterpret_cast<const float4 *>(ws + 768 + wl4) : zero;
+    adagrad_commit<G, 1>(o, P.W2T, opt.s1[1], (size_t)i, P.ld, lane, w, a, g2);
+    if (lane == 0) {
+      OptScalars ob = o;
+      ob.rb = 0.f;
+      float pb = pb2, m = mb2, unused = 0.f;
+      opt_update1<DRX_OPT_ADAGRAD>(ob, dz2, pb, m, unused);
+      P.b2[i] = pb; opt.s1[4][i] = m;
+    }
+  } else {
+    store_row<G, 1>(S.g2, (size_t)b, P.ld, lane, g2);
+    if (lane == 0) S.dz2[b] = dz2;
+  }
+  if (solo_v) {
+    float4 w[1] = {v}, a[1];
+    a[0] = act ? *reinterpret_cast<const float4 *>(ws + 512 + wl4) : zero;
+    adagrad_commit<G, 1>(o, P.V, opt.s1[2], (size_t)u, P.ld, lane, w, a, dz1);
+  }
+}
+
 // Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
 // a chain of ~20 dependent load rounds on a chip that is mostly idle (measured 143 us at B = 4096).  Here one WORKGROUP
 // takes a triple: its 256/G groups split the history, the partial bags are summed in LDS in group order.
@@ -1178,7 +1276,7 @@ constexpr int kSmallBatch = 1024;    // at or below: one workgroup per batch row
 constexpr int kFewRows = 128;        // at or below: that workgroup has 1024 threads (fewer rows than CUs: spread each row wider)
 constexpr int kOutGrid = 512;        // persistent workgroups of k_out_dense (two per CU when LDS allows)
 constexpr int kSweepGrid = 1024;
-constexpr int kLongBlocks = 256, kShortBlocks = 512;   // k_span_planned: workgroups striding over the long / the short spans
+constexpr int kLongBlocks = 256, kShortBlocks = 1024;   // k_span_planned: workgroups striding over the long / the short spans
 constexpr size_t kLdsBudget = 144 * 1024;
 
 struct DenseLayout {
@@ -1453,9 +1551,7 @@ static PartBufs part_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   L.R = prep_layout(cv, P, B, n_touch_slots);
   L.out = part_out_layout(P, B, n_touch_slots, parts);
   L.flag = cv.take<int>(L.R.T);                 // [B] counts of the samples, later [cap] run flags
-  L.scan_bytes = 0;
-  int *d = nullptr;
-  (void)rocprim::inclusive_scan(nullptr, L.scan_bytes, d, d, (size_t)(L.R.T > 0 ? L.R.T : 1), rocprim::plus<int>(), (hipStream_t)0);
+  L.scan_bytes = scan_i32_temp_bytes((size_t)(L.R.T > 0 ? L.R.T : 1));
   L.scan_temp = cv.take<char>(L.scan_bytes);
   L.ck = cv.take<uint32_t>(L.out.cap); L.cv = cv.take<uint32_t>(L.out.cap);
   L.ck_s = cv.take<uint32_t>(L.out.cap);
@@ -1858,6 +1954,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
+  static const bool use_pf = [] { const char *e = getenv("DRX_FWD_PF"); return !e || atoi(e) != 0; }();      // (A/B switch)
   // the segmented reduction (+ the bias column sums as extra workgroups) and the ONE launch that combines the chunk-crossing segments
   // (+ the bias update), with the policy type POLT (optimizer at run time, or Adagrad compiled in)
 #define REDUCE_AND_SPANS(G, J, POLT)                                                                                   \
@@ -1897,6 +1994,9 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     else if (opt->kind == DRX_OPT_ADAGRAD && S.solo_w && J == 1)                                                       \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_stash<G, 1>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock),                 \
                          (size_t)(kBlock / 64) * kStash * 1024, st, *p, *opt, *hist, *bt, scale, qthr, loss_kind, S);  \
+    else if (opt->kind == DRX_OPT_ADAGRAD && J == 1 && use_pf)                                                         \
+      hipLaunchKernelGGL((k_sampled_fwd_bwd_pf<G>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), (size_t)(kBlock / 64) * 4 * 1024, \
+                         st, *p, *opt, *hist, *bt, scale, qthr, loss_kind, S);                                         \
     else if (opt->kind == DRX_OPT_ADAGRAD)                                                                             \
       hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, \
                          *hist, *bt, scale, qthr, loss_kind, S);                                                       \
@@ -1989,8 +2089,8 @@ int drx_cdae_sparse_prepare_part(const DrxCdaeParams *p, const DrxHistory *hist,
   const uint32_t qthr = q_threshold(bt->q);
   hipLaunchKernelGGL(k_owned_touches<false>, grid, dim3(kBlock), 0, st, p->n_items, *hist, *bt, qthr, part, parts, L.flag, cap, L.ck, L.cv,
                      header);
-  hipError_t e = rocprim::inclusive_scan(L.scan_temp, L.scan_bytes, L.flag, L.flag, (size_t)bt->B, rocprim::plus<int>(), st);
-  if (e != hipSuccess) return (int)e;
+  rc = scan_i32(L.scan_temp, L.scan_bytes, L.flag, L.flag, (size_t)bt->B, true, st);
+  if (rc) return rc;
   DRX_HIP(hipMemsetAsync(L.ck, 0xFF, (size_t)cap * sizeof(uint32_t), st));
   DRX_HIP(hipMemsetAsync(L.cv, 0, (size_t)cap * sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_owned_touches<true>, grid, dim3(kBlock), 0, st, p->n_items, *hist, *bt, qthr, part, parts, L.flag, cap, L.ck, L.cv,
@@ -1998,8 +2098,8 @@ int drx_cdae_sparse_prepare_part(const DrxCdaeParams *p, const DrxHistory *hist,
   rc = sort_pairs(L.R.sort_temp, L.R.sort_bytes, L.ck, L.ck_s, L.cv, vals_out, (size_t)cap, L.R.bits, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_run_flags, dim3(1024), dim3(256), 0, st, L.ck_s, cap, L.flag);
-  e = rocprim::inclusive_scan(L.scan_temp, L.scan_bytes, L.flag, L.flag, (size_t)cap, rocprim::plus<int>(), st);
-  if (e != hipSuccess) return (int)e;
+  rc = scan_i32(L.scan_temp, L.scan_bytes, L.flag, L.flag, (size_t)cap, true, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_take_runs, dim3(1024), dim3(256), 0, st, L.ck_s, L.flag, cap, L.out.rcap, runs, header);
   DRX_LAUNCH_CHECK();
   return DRX_OK;

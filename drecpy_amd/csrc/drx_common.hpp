@@ -121,7 +121,8 @@ struct Carver {
   bool ok() const { return off <= cap; }
 };
 
-// Internal: stable radix sort of (key, val) pairs on the low end_bit bits of the key, implemented in drx_sort.hip.
+// Internal: stable radix sort of (key, val) pairs, implemented in drx_sort.hip.  Keys must be < 2^end_bit (or DRX_KEY_NONE with drop_none):
+// the passes cover ceil(end_bit / digit) * digit bits, higher bits are not masked off.
 size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                uint32_t *vout, size_t n, int end_bit, hipStream_t stream);

@@ -652,16 +652,18 @@ int32_t drx_batch_distinct(const int32_t *ids, int32_t B, int32_t n_rows, const 
   for (int32_t b = 0; b < B; ++b) grows[gptr[inv[b]]++] = b;       // samples of a distinct id in ascending order
   for (int32_t j = nd; j > 0; --j) gptr[j] = gptr[j - 1];
   gptr[0] = 0;
+  bool overflow = false;
   if (off) {
     int64_t t = 0;
     off[0] = 0;
     for (int32_t j = 0; j < nd; ++j) {
       t += indptr ? indptr[distinct[j] + 1] - indptr[distinct[j]] : 0;
-      off[j + 1] = (int32_t)(t > INT32_MAX ? INT32_MAX : t);
+      if (t > INT32_MAX) { overflow = true; t = INT32_MAX; }      // (int32 touch offsets: a saturated prefix would make touches overlap)
+      off[j + 1] = (int32_t)t;
     }
   }
   for (int32_t j = 0; j < nd; ++j) scratch[distinct[j]] = -1;
-  return nd;
+  return overflow ? DRX_EINVAL : nd;
 }
 
 int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out) {

@@ -6,7 +6,7 @@
 // Integer-only, HBM/latency bound; the table has >= 2n slots (power of two).
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_scan.hpp>
+#include "drx_scan.hpp"
 #include "drx_common.hpp"
 
 namespace drx {
@@ -76,9 +76,7 @@ static IdmapLayout idmap_layout(Carver &cv, int64_t n) {
   L.slot_of = cv.take<unsigned>((size_t)n);
   L.flag = cv.take<int>((size_t)n);
   L.scan = cv.take<int>((size_t)n);
-  L.temp_bytes = 0;
-  int *d = nullptr;
-  (void)rocprim::exclusive_scan(nullptr, L.temp_bytes, d, d, 0, (size_t)n, rocprim::plus<int>(), (hipStream_t)0);
+  L.temp_bytes = scan_i32_temp_bytes((size_t)n);
   L.temp = cv.take<char>(L.temp_bytes);
   return L;
 }
@@ -105,8 +103,8 @@ extern "C" int drx_idmap_build(const int64_t *raw, int64_t n, int32_t *codes, in
   hipLaunchKernelGGL(k_idmap_insert, dim3(blocks), dim3(256), 0, st, (const long long *)raw, (long long)n, L.tkeys, L.tmin,
                      L.cap - 1, L.slot_of);
   hipLaunchKernelGGL(k_idmap_flag, dim3(blocks), dim3(256), 0, st, (long long)n, L.tmin, L.slot_of, L.flag);
-  hipError_t e = rocprim::exclusive_scan(L.temp, L.temp_bytes, L.flag, L.scan, 0, (size_t)n, rocprim::plus<int>(), st);
-  if (e != hipSuccess) return (int)e;
+  const int rc = scan_i32(L.temp, L.temp_bytes, L.flag, L.scan, (size_t)n, false, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_idmap_codes, dim3(blocks), dim3(256), 0, st, (const long long *)raw, (long long)n, L.tmin, L.slot_of,
                      L.flag, L.scan, (int *)codes, (long long *)uniques, (int *)n_unique);
   DRX_LAUNCH_CHECK();

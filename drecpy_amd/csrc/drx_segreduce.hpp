@@ -27,6 +27,8 @@ constexpr int kChunk = DRX_CHUNK;      // touches per group in the segmented red
 #define SEG_GPB(G) (drx::kBlock / (G))
 #endif
 constexpr int kShortSpan = 64;     // chunk borders a segment may cross and still be combined by one group
+constexpr int kPlanShort = 16;     // planned variant: spans of up to this many partial rows are combined by ONE group (two rounds of 8 loads in
+                                   //   flight), longer ones by a workgroup; 64 left the second-hottest rows to a single group each: 8 rounds
 constexpr int kFixBlock = 512;     // (1024: the long-span fix-up kernel hit the 128-VGPR cap of a 16-wave workgroup and spilled)
 
 struct SegBufs {
@@ -216,7 +218,7 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_c
     return;
   }
   const uint2 d = make_uint2((uint32_t)g, m_in | (has_end << 31));
-  if (SpanShape(d, cpb).total() <= kShortSpan) P.desc[atomicAdd(&P.cnt[0], 1u)] = d;
+  if (SpanShape(d, cpb).total() <= kPlanShort) P.desc[atomicAdd(&P.cnt[0], 1u)] = d;
   else P.desc[n_chunks - 1 - (int)atomicAdd(&P.cnt[1], 1u)] = d;
 }
 

@@ -13,7 +13,7 @@
 #include "drx_common.hpp"
 #include "drx_rows.hpp"
 #include "drx_segreduce.hpp"
-#include <rocprim/device/device_scan.hpp>
+#include "drx_scan.hpp"
 
 namespace drx {
 
@@ -446,9 +446,7 @@ static SegLayout seg_layout(Carver &cv, int ld, int T, int sort_bits) {
   L.sort_bytes = sort_pairs_temp_bytes((size_t)T, sort_bits);
   L.sort_temp = cv.take<char>(L.sort_bytes);
   L.flags = cv.take<int>(T);
-  L.scan_bytes = 0;
-  int *d = nullptr;
-  (void)rocprim::inclusive_scan(nullptr, L.scan_bytes, d, d, (size_t)(T > 0 ? T : 1), rocprim::plus<int>(), (hipStream_t)0);
+  L.scan_bytes = scan_i32_temp_bytes((size_t)(T > 0 ? T : 1));
   L.scan_temp = cv.take<char>(L.scan_bytes);
   L.part = cv.take<float>((size_t)256 * ld);
   return L;
@@ -535,8 +533,8 @@ int drx_shard_index(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *
   int rc = sort_pairs(L.sort_temp, L.sort_bytes, keys, keys_s, vals, vals_s, (size_t)T, key_bits(*sh), st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_head_flags, dim3(1024), dim3(256), 0, st, keys_s, T, L.flags);
-  hipError_t e = rocprim::inclusive_scan(L.scan_temp, L.scan_bytes, L.flags, slot_sorted, (size_t)T, rocprim::plus<int>(), st);
-  if (e != hipSuccess) return (int)e;
+  const int scan_rc = scan_i32(L.scan_temp, L.scan_bytes, L.flags, slot_sorted, (size_t)T, true, st);
+  if (scan_rc) return scan_rc;
   hipLaunchKernelGGL(k_slots, dim3(1024), dim3(256), 0, st, keys_s, vals_s, T, slot_sorted, slot_of_pos, uniq_keys);
   hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(256), 0, st, keys_s, slot_sorted, T, *sh, bounds);
   DRX_LAUNCH_CHECK();

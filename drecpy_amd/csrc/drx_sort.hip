@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep_pass(const uint32_t *
     const uint32_t below = __popcll(mask & ((1ull << lane) - 1ull));
     uint32_t old = 0;
     if (valid && below == 0) { old = whist[w][d]; whist[w][d] = old + (uint32_t)__popcll(mask); }
+    wave_lds_sync();      // the leader's counter update of row `it` is read by (another lane as) the leader of row `it + 1`
     const int leader = valid ? (__ffsll((long long)mask) - 1) : lane;
     old = __shfl(old, leader);
     pre[it] = old + below;

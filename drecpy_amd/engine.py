@@ -45,10 +45,11 @@ class CdaeEngine:
         self._dense_scratch, self._dense_scratch_B, self._dense_clean = None, None, False
         self._loss = torch.zeros(2, **z)
         # sampled mode: ask drx_cdae_sparse_prepare to mark the W rows a single triple of the batch touches, for the forward kernel to
-        # update (include/drx.h DRX_BATCH_MARK_W).  'auto': where a batch leaves most of its distinct W rows with one touch — at most 4
-        # history slots per item of the catalogue — with Adagrad, on rows of 17..256 floats (the kernel that serves the marks);
-        # False: never (the column-sharded layout: its forward half is a kernel of its own)
-        self.mark_w_rows = 'auto'
+        # update (include/drx.h DRX_BATCH_MARK_W).  False by default — measured on the 10M x 1M set (r03d): the reduction runs 64 us
+        # shorter without those 126 k one-touch segments, but the same read-modify-writes cost the latency-bound forward kernel 140 us.
+        # 'auto' (tests, experiments): where a batch leaves most of its distinct W rows with one touch — at most 4 history slots per
+        # item of the catalogue — with Adagrad, on rows of 17..256 floats; True: always.  DRX_SOLO_W=0/1 in the environment overrides.
+        self.mark_w_rows = False
 
     # ---- parameters -------------------------------------------------------------------------
     def tables(self):
@@ -331,15 +332,29 @@ class CdaeEngine:
         return self._scratch
 
     def _ensure_dense_scratch(self, B):
-        """Scratch of the reference-mode step: a buffer of its own, ZERO-initialised and kept for one batch size.  The dense step
-        leaves its batch-membership arrays clean (the kernel that reads an entry clears it), so consecutive steps pass
-        DRX_DENSE_AUX_CLEAN and skip the memset; a step that raised, or another batch size, starts from fresh zeros."""
-        if getattr(self, '_dense_scratch', None) is None or self._dense_scratch_B != B or not self._dense_clean:
+        """Scratch of the reference-mode step: ZERO-initialised, one buffer per batch size (a last partial batch or a second model
+        configuration alternates with the usual size without re-allocating either).  The dense step leaves its batch-membership
+        arrays clean (the kernel that reads an entry clears it), so consecutive steps pass DRX_DENSE_AUX_CLEAN and skip the
+        memset; a buffer whose step raised (or faulted asynchronously: see dense_fault()) is zeroed again before its next use."""
+        pool = self.__dict__.setdefault('_dense_pool', {})
+        ent = pool.get(B)
+        if ent is None:
+            if len(pool) >= 4:                      # a handful of batch sizes at most: drop the oldest
+                pool.pop(next(iter(pool)))
             need = lib().drx_cdae_scratch_bytes(C.byref(self._params), B, 0, 1)
-            self._dense_scratch = None
-            self._dense_scratch = torch.zeros(int(need) + 1024, dtype=torch.uint8, device=self.device)
-            self._dense_scratch_B, self._dense_clean = B, True
-        return self._dense_scratch
+            ent = pool[B] = [torch.zeros(int(need) + 1024, dtype=torch.uint8, device=self.device), True]
+        elif not ent[1]:
+            ent[0].zero_()
+            ent[1] = True
+        self._dense_scratch, self._dense_scratch_B, self._dense_clean = ent[0], B, True
+        self._dense_ent = ent
+        return ent[0]
+
+    def dense_fault(self):
+        """Call after catching a device fault: every dense scratch is zeroed before its next use (a kernel that died half-way may have
+        left batch-membership bits set that the AUX_CLEAN contract promises are clear)."""
+        for ent in self.__dict__.get('_dense_pool', {}).values():
+            ent[1] = False
 
     # ---- calls ------------------------------------------------------------------------------
     def forward(self, uid, keep_off=None, keep=None, q=0.0, mask_seed=0, want_pred=True):
@@ -356,14 +371,14 @@ class CdaeEngine:
         """One reference-mode fit() iteration; `step` is the 0-based batch index (Adam t = 5*step+j+1)."""
         o = self._optim(self._dense_alphas(step))
         sc = self._ensure_dense_scratch(bt.B)
-        self._dense_clean = False                   # (stays False if the call raises: the next step then starts from fresh zeros)
+        self._dense_clean = self._dense_ent[1] = False       # (stays False if the call raises: the next step then starts from fresh zeros)
         check(lib().drx_cdae_step_dense(
             C.byref(self._params), C.byref(o), C.byref(self._hist), C.byref(bt),
             _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE,
             (_lib.TARGETS_REFERENCE if targets == 'reference' else _lib.TARGETS_PER_ROW) | _lib.DENSE_AUX_CLEAN,
             ptr(sc), sc.numel(), ptr(self._loss) if want_loss else None, stream_ptr(self.device)),
             'drx_cdae_step_dense')
-        self._dense_clean = True
+        self._dense_clean = self._dense_ent[1] = True
         return self._loss if want_loss else None
 
     _FIT_SLOTS = 16
@@ -381,14 +396,14 @@ class CdaeEngine:
         o = self._optim([0.0] * 5)
         sc = self._ensure_dense_scratch(B)
         alphas = self._alpha_table(first_step, n_steps)
-        self._dense_clean = False
+        self._dense_clean = self._dense_ent[1] = False
         check(L.drx_cdae_fit_dense(
             C.byref(self._params), C.byref(o), C.byref(self._hist), drawahead, cursor.ctypes.data, B, float(q), int(keep_capacity),
             _lib.LOSS_BCE if loss == 'bce' else _lib.LOSS_MSE, _lib.TARGETS_REFERENCE if targets == 'reference' else _lib.TARGETS_PER_ROW,
             n_steps, alphas.ctypes.data, slots[1].data_ptr(), slots[0], self._FIT_SLOTS, ptr(slots[2]), slots[2].numel(), ptr(sc),
             sc.numel(), stream_ptr(self.device)),
             'drx_cdae_fit_dense')
-        self._dense_clean = True
+        self._dense_clean = self._dense_ent[1] = True
 
     def prep_buffer(self, bt, out=None):
         """A buffer large enough for the prepared touch list of `bt` (`out` itself when it is)."""

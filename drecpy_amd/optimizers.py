@@ -21,7 +21,30 @@ class Adam:
     def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
+        self._slots = {}              # id(variable / tensor object) -> (weak reference to it, m, v)
+
+    def reset(self):
+        """A fresh fit(): the call counter and the moments start over (RecommenderABC.fit registers the optimizer anew)."""
+        self.iterations = 0
         self._slots = {}
+
+    def _moments(self, owner, p):
+        """(m, v) of the variable OBJECT `owner` (a Variable handle or a tensor): keyed by identity, not by device address — a new
+        tensor that happens to be allocated at a freed variable's address must not inherit its moments."""
+        import weakref
+        import torch
+        ent = self._slots.get(id(owner))
+        if ent is not None and (ent[0]() is not owner or ent[1].shape != p.shape or ent[1].device != p.device):
+            ent = None                  # the id was recycled by another object, or the variable was rebound to another shape / device
+        if ent is None:
+            try:
+                ref = weakref.ref(owner)
+            except TypeError:
+                ref = (lambda o: (lambda: o))(owner)
+            ent = self._slots[id(owner)] = (ref, torch.zeros_like(p), torch.zeros_like(p))
+            for k in [k for k, e in self._slots.items() if e[0]() is None]:
+                del self._slots[k]
+        return ent[1], ent[2]
 
     def lr_t(self, t):
         """Keras-Adam step size for the 1-based call counter t, in fp32 like optimizer_v2/adam.py."""
@@ -38,10 +61,7 @@ class Adam:
             if not (torch.is_tensor(p) and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise Exception(f'apply_gradients needs contiguous fp32 device arrays (drecpy_amd Variable or tensor), got {type(var).__name__}')
             g = torch.as_tensor(g, dtype=torch.float32, device=p.device).reshape(p.shape).contiguous()
-            key = p.data_ptr()
-            if key not in self._slots:
-                self._slots[key] = (torch.zeros_like(p), torch.zeros_like(p))
-            m, v = self._slots[key]
+            m, v = self._moments(var, p)
             if p.data_ptr() % 16 or p.numel() % 4:                       # drx_adam_dense moves float4: pad odd-sized variables
                 n4 = (p.numel() + 3) // 4 * 4
                 buf = torch.zeros(4, n4, dtype=torch.float32, device=p.device)

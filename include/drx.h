@@ -398,9 +398,9 @@ typedef struct DrxDmfArgs {
   uint32_t stamp;
 } DrxDmfArgs;
 /* Host helper for the arrays above: the distinct ids of a batch, ascending.  distinct [<= B], inv [B], gptr [<= B+1], grows [B],
- * off [<= B+1] (prefix sums of indptr row lengths of the distinct ids; NULL to skip; saturates at INT32_MAX) are host arrays;
+ * off [<= B+1] (prefix sums of indptr row lengths of the distinct ids; NULL to skip) are host arrays;
  * scratch = int32 [n_rows], all -1 on entry and again on return (the caller keeps it between steps).  Returns the number of distinct
- * ids, or a negative DRX_E* code (an id outside [0, n_rows)). */
+ * ids, or a negative DRX_E* code (an id outside [0, n_rows); DRX_EINVAL when the prefix sums do not fit int32 — touch offsets would overlap). */
 int32_t drx_batch_distinct(const int32_t *ids, int32_t B, int32_t n_rows, const int64_t *indptr, int32_t *scratch, int32_t *distinct,
                            int32_t *inv, int32_t *gptr, int32_t *grows, int32_t *off);
 /* out[id] = 1 / max(|row id|_2, 1e-6) (1 when l2_norm_vectors == 0) for the n rows of a CSR, with the summation order of the towers */
@@ -441,9 +441,10 @@ size_t drx_topk_scratch_bytes(int32_t R, int32_t n);   /* 0 for n <= 16384 (LDS 
 int drx_topk(const float *scores, const uint32_t *cand_mask, int32_t R, int32_t n, int32_t k,
              int32_t *out_idx, float *out_val, void *scratch, size_t scratch_bytes, void *stream);
 
-/* ---- stable device radix sort of (key, val) pairs on the low key_bits bits of the key (the inverted-index builder of the
- * sparse steps; ties keep their input order).  keys_out / vals_out must not alias the inputs.  temp: >=
- * drx_sort_pairs_temp_bytes(n, key_bits). */
+/* ---- stable device radix sort of (key, val) pairs (the inverted-index builder of the sparse steps; ties keep their input order).
+ * Every key must be < 2^key_bits: the sort runs ceil(key_bits / digit) passes of 8-, 10- or 11-bit digits, i.e. it orders on
+ * passes * digit >= key_bits bits — bits above key_bits are NOT ignored (DRX_EINVAL is not raised for them: the result is then ordered
+ * on those bits too).  keys_out / vals_out must not alias the inputs.  temp: >= drx_sort_pairs_temp_bytes(n, key_bits). */
 size_t drx_sort_pairs_temp_bytes(int64_t n, int32_t key_bits);
 int drx_sort_pairs(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int32_t key_bits,
                    void *temp, size_t temp_bytes, void *stream);

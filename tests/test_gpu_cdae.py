@@ -123,13 +123,15 @@ def test_dense_steps_match_oracle(K, B, loss, targets):
                                                    (8, 100, 'adam', 'mse', True), (128, 4096, 'adagrad', 'bce', False),
                                                    (300, 50, 'adam', 'bce', False), (128, 300, 'rowwise_adagrad', 'bce', False),
                                                    (50, 64, 'rowwise_adagrad', 'mse', True)])
-@pytest.mark.parametrize('prepared', [False, True])
+@pytest.mark.parametrize('prepared', [False, True, 'mark_w'])
 def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
     """prepared=True: the touch list is built ahead by drx_cdae_sparse_prepare, which also marks the V / W2T rows a single
     sample touches; those are then updated by the forward kernel (batches of 50-100 over 120 users and 260 items mix sole
-    and shared rows)."""
+    and shared rows).  'mark_w': W rows with one touch are marked too (DRX_BATCH_MARK_W) and updated by the forward kernel —
+    from its LDS notes (Adagrad, one float4 per lane) or by a second walk over the history (the other kernels)."""
     U, N = 120, 260
     eng, p, rng = _engine(U, N, K, seed=2)
+    eng.mark_w_rows = prepared == 'mark_w'
     indptr, indices = synth_history(rng, U, N, 14, zipf=1.1)
     eng.set_history(indptr, indices)
     lr = 1e-3 if opt == 'adam' else 0.05

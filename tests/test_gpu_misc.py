@@ -64,7 +64,8 @@ def test_topk_matches_heapq(n, k):
         assert (idx[r] >= 0).sum() == min(k, int(mask[r].sum()))
 
 
-@pytest.mark.parametrize('n,bits', [(1, 1), (63, 9), (64, 10), (4096, 18), (4097, 18), (100_003, 25), (1_440_000, 25), (300_000, 27), (70_000, 32)])
+@pytest.mark.parametrize('n,bits', [(1, 1), (63, 9), (64, 10), (4096, 18), (4097, 18), (100_003, 25), (1_440_000, 25), (300_000, 27), (70_000, 32),
+                                    (200_000, 12), (500_000, 16), (33_000, 8)])      # narrow keys over many tiles: one- and two-pass plans
 def test_sort_pairs_is_a_stable_sort(n, bits):
     """drx_sort_pairs (the inverted-index builder of the sparse steps) against torch's stable sort: heavy duplicates (Zipf-like
     keys), padding keys 0xFFFFFFFF, sizes around tile and wave borders, only the low `bits` bits order the pairs."""
