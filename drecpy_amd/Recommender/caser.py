@@ -130,18 +130,18 @@ class Caser(RecommenderABC):
         uids, before, after = batch_samples[:3]
         with self._device_lock:
             sc = self._engine.scores_all(np.asarray(uids), np.asarray(before))
-        idx = torch.as_tensor(np.asarray(after), device=sc.device, dtype=torch.long)
-        preds = torch.sigmoid(torch.gather(sc, 1, idx))
+        # (an API-compatibility hook, never on the training path: the gather + sigmoid of caser.py:94 on the host)
+        logits = np.take_along_axis(sc.cpu().numpy().astype(np.float64), np.asarray(after, dtype=np.int64), axis=1)
+        preds = torch.as_tensor(1.0 / (1.0 + np.exp(-logits)), dtype=torch.float32)
         desired = np.tile(np.array([1.] * self.T + [0.] * (self.T * self.neg_ratio), dtype=np.float32), (len(uids), 1))
         return preds, desired
 
     def _compute_batch_loss(self, predictions, desired_values, **kwds):
-        import torch
-        p = predictions.double()
-        t = torch.as_tensor(np.asarray(desired_values), dtype=torch.float64, device=p.device)
+        p = np.asarray(predictions.cpu().numpy() if hasattr(predictions, 'cpu') else predictions, dtype=np.float64)
+        t = np.asarray(desired_values, dtype=np.float64)
         eps = 1e-7
-        pc = p.clamp(eps, 1 - eps)
-        return float((-(t * torch.log(pc + eps) + (1 - t) * torch.log(1 - pc + eps))).mean().item())
+        pc = np.clip(p, eps, 1 - eps)
+        return float((-(t * np.log(pc + eps) + (1 - t) * np.log(1 - pc + eps))).mean())
 
     def _predict(self, uid, iid, **kwds):
         raise NotImplementedError('This model does not support point-based predictions.')

@@ -411,19 +411,20 @@ class CDAE(RecommenderABC):
 
     def _compute_batch_loss(self, predictions, desired_values, **kwds):
         """Keras BCE / MSE of the reference on the (B,B,N) broadcast == against the batch-mean target (cdae.py:78-79)."""
-        import torch
-        p = predictions.double()
-        t = torch.as_tensor(np.asarray(desired_values), dtype=torch.float64, device=p.device)
-        tbar = t.mean(dim=0, keepdim=True)
+        # (an API-compatibility hook — the fused step computes the training loss itself: host numpy, no device arithmetic in torch)
+        p = np.asarray(predictions.cpu().numpy() if hasattr(predictions, 'cpu') else predictions, dtype=np.float64)
+        t = np.asarray(desired_values, dtype=np.float64)
+        tbar = t.mean(axis=0, keepdims=True)
         if self._loss_name == 'bce':
             eps = 1e-7
-            pc = p.clamp(eps, 1 - eps)
-            return float((-(tbar * torch.log(pc + eps) + (1 - tbar) * torch.log(1 - pc + eps))).mean().item())
-        return float((((p - tbar) ** 2) + tbar * (1 - tbar)).mean().item())
+            pc = np.clip(p, eps, 1 - eps)
+            return float((-(tbar * np.log(pc + eps) + (1 - tbar) * np.log(1 - pc + eps))).mean())
+        return float((((p - tbar) ** 2) + tbar * (1 - tbar)).mean())
 
     def _compute_reg_loss(self, reg_rate, batch_size, trainable_models=None, trainable_layers=None, trainable_weights=None, **kwds):
         e = self._engine                                   # cdae.py:81-82
-        return float(sum((t.double() ** 2).sum().item() for t in (e.W, e.W2T, e.V)) * 0.5 * reg_rate / batch_size)
+        from .. import _lib
+        return _lib.sumsq([e.W, e.W2T, e.V]) * 0.5 * reg_rate / batch_size
 
     # ---- inference (cdae.py:67-71, 84-103) -----------------------------------------------------------------
     def _predict(self, uid, iid=None, **kwds):

@@ -142,6 +142,7 @@ SIGNATURES = {
     'drx_scatter_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'drx_scatter_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_sumsq': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     'drx_rows_dot': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
     'drx_adam_segments': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamSegments), C.c_float,
@@ -165,6 +166,7 @@ SIGNATURES = {
     'drx_score_pairs_bf16': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_void_p]),
     'drx_topk_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
+    'drx_topk_scratch_bytes_k': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'drx_topk': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_idmap_scratch_bytes': (C.c_size_t, [C.c_int64]),
@@ -216,6 +218,20 @@ SIGNATURES = {
     'drx_rng_corruption_keep': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                           C.c_double, C.c_void_p, C.c_void_p, C.c_int64]),
 }
+
+
+def sumsq(tensors, device=None):
+    """sum of squares of the given fp32 device tensors (contiguous), as a Python float — drx_sumsq, no torch arithmetic."""
+    import torch
+    ts = [t for t in tensors if t is not None and t.numel()]
+    if not ts:
+        return 0.0
+    dev = ts[0].device
+    out = torch.zeros(1 + 1024, dtype=torch.float64, device=dev)
+    for i, t in enumerate(ts):
+        t = t if t.is_contiguous() else t.contiguous()
+        check(lib().drx_sumsq(ptr(t), t.numel(), ptr(out), 1 if i else 0, stream_ptr(dev)), 'drx_sumsq')
+    return float(out[:1].cpu().numpy()[0])
 
 
 def lib():

@@ -17,6 +17,11 @@
 #define DRX_GATHER_ROWS 8
 #endif
 
+#ifdef DRX_STAMPS
+static unsigned long long *h_stamps = nullptr;       // device buffer [110000 x 16], handed to the sparse step's kernels in their arguments
+extern "C" int drx_debug_set_stamps(unsigned long long *buf, unsigned int) { h_stamps = buf; return 0; }
+#endif
+
 namespace drx {
 
 // ------------------------------------------------------------------------------------------------
@@ -36,11 +41,16 @@ template <int G, int J, int MODE>
 __device__ __forceinline__ void gather_bag(const DrxCdaeParams &P, const DrxHistory &H, const DrxBatch &bt,
                                            uint32_t qthr, int b, int lane, float4 (&acc)[J],
                                            const DenseAux &aux, uint32_t *tkeys, uint32_t *tvals,
-                                           int touch_base, int part = 0, int nparts = 1) {
+                                           int touch_base, int part = 0, int nparts = 1, unsigned long long *stamps = nullptr) {
+  (void)stamps;
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
   const int u = bt.uid[b];
   const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+#ifdef DRX_STAMPS
+  if (s >= 0) DRX_STAMP(stamps, b, 2, lane);          // (uses s: the stamp waits for the row pointers)
+  bool first_rows = true;
+#endif
   const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
   // a group fetches CH history entries per round: its G lanes hold IPL each, so that narrow groups (rows of <= 32 floats:
   // G = 4 or 8) do not walk the history in rounds of 4 or 8 dependent index loads
@@ -69,6 +79,9 @@ __device__ __forceinline__ void gather_bag(const DrxCdaeParams &P, const DrxHist
     }
     const int n_here = (int)((e - c) < (int64_t)CH ? (e - c) : (int64_t)CH);
     constexpr int NF = J == 1 ? DRX_GATHER_ROWS : 4;       // rows in flight per group
+#ifdef DRX_STAMPS
+    if (first_rows && idx[0] >= -1) DRX_STAMP(stamps, b, 3, lane);      // (uses idx: the stamp waits for the indices)
+#endif
     for (int t = 0; t < n_here; t += NF) {
       float4 r[NF][J];
 #pragma unroll
@@ -87,6 +100,9 @@ __device__ __forceinline__ void gather_bag(const DrxCdaeParams &P, const DrxHist
       for (int q = 0; q < NF; ++q)
 #pragma unroll
         for (int jx = 0; jx < J; ++jx) f4_add(acc[jx], r[q][jx]);
+#ifdef DRX_STAMPS
+      if (first_rows && acc[0].x == acc[0].x) { DRX_STAMP(stamps, b, 4, lane); first_rows = false; }      // (uses acc: after the first rows landed)
+#endif
     }
   }
 }
@@ -584,6 +600,8 @@ struct SparseBufs {
   const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row; solo_v + 2B:
                                               //   [B] sample b holds at least one W row that only it touches
   const uint32_t *solo_w;                     // [ceil(N/32)] or nullptr: bit n set = W row n is touched by ONE sample of the batch
+  unsigned long long *stamps;                 // diagnostic builds (DRX_STAMPS) only
+  const int32_t *order;                       // [B] or nullptr: launch order of the forward kernel's triples (k_order_by_degree)
   int T, n_chunks, n_bpart;
 };
 
@@ -592,12 +610,16 @@ struct SparseBufs {
 // Also clears the sole-toucher marks of the batch (solo: [2B] bytes, solo_w: one bit per item; or nullptr) and pads the slots beyond
 // the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
 __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
-                                                           uint32_t *vals, int T, uint8_t *solo, uint32_t *solo_w) {
+                                                           uint32_t *vals, int T, uint8_t *solo, uint32_t *solo_w, uint32_t *zero_a,
+                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b) {
   constexpr int G = 16;
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
   if (solo_w)
     for (int w = blockIdx.x * kBlock + threadIdx.x; w < (n_items + 31) / 32; w += gridDim.x * kBlock) solo_w[w] = 0u;
+  // (two more ranges of words the preparation wants zeroed: the span plan's counters + window bytes, the degree-order work area)
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_a; w += gridDim.x * kBlock) zero_a[w] = 0u;
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_b; w += gridDim.x * kBlock) zero_b[w] = 0u;
   if (b >= bt.B) return;
   if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; solo[2 * (size_t)bt.B + b] = 0; }
   if (b == bt.B - 1)
@@ -646,6 +668,73 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
     P.b2[row] = pb; opt.s1[4][row] = m;
     if (kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
   }
+}
+
+// Launch order of the forward kernel's triples: longest histories first, triples of similar length side by side (r03 phase stamps:
+// a triple lives 19 us on average but 25 us at the 90th percentile and far longer for the few users with hundreds of items; a
+// workgroup waits for its slowest triple and the launch for its last workgroups — 47 % of the chip's group slots were occupied on
+// average).  A counting sort by history length in 256 buckets of 4 items, two small launches on the preparation's stream (counts;
+// scatter), each workgroup over 1024 triples; `work` = 512 zeroed ints (k_sparse_touches clears them).  A first version did it all
+// in ONE workgroup: 152 us of side-stream time per step, which made the preparation — not the training — the pipeline's bound.
+// The order inside a bucket comes from atomics and differs from run to run: it decides only WHERE a triple is computed, never a result.
+__device__ __forceinline__ int degree_bucket(const int32_t *keep_off, int b) {
+  const int d = (keep_off[b + 1] - keep_off[b]) >> 2;
+  return 255 - (d > 255 ? 255 : d);                  // descending
+}
+
+__device__ __forceinline__ unsigned long long same_bucket_lanes(bool valid, int d) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const bool one = (d >> bit) & 1;
+    const unsigned long long bl = __ballot(one);
+    m &= one ? bl : ~bl;
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(1024) void k_degree_counts(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work) {
+  __shared__ unsigned int cnt[256];
+  for (int i = threadIdx.x; i < 256; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  const int b = blockIdx.x * 1024 + (int)threadIdx.x, lane = threadIdx.x & 63;
+  const bool valid = b < B;
+  const int d = valid ? degree_bucket(keep_off, b) : 0;
+  const unsigned long long m = same_bucket_lanes(valid, d);
+  if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&cnt[d], (unsigned int)__popcll(m));
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += 1024)
+    if (cnt[i]) atomicAdd(&work[i], cnt[i]);
+}
+
+__global__ __launch_bounds__(1024) void k_degree_scatter(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
+                                                         int32_t *__restrict__ order) {
+  __shared__ unsigned int start[256], cnt[256], base[256];
+  for (int i = threadIdx.x; i < 256; i += 1024) cnt[i] = 0;
+  if (threadIdx.x < 64) {                            // exclusive scan of the 256 global counts by one wave: 4 bins per lane
+    unsigned int c[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c[q] = work[threadIdx.x * 4 + q]; sum += c[q]; }
+    unsigned int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
+    unsigned int run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { start[threadIdx.x * 4 + q] = run; run += c[q]; }
+  }
+  __syncthreads();
+  const int b = blockIdx.x * 1024 + (int)threadIdx.x, lane = threadIdx.x & 63;
+  const bool valid = b < B;
+  const int d = valid ? degree_bucket(keep_off, b) : 0;
+  const unsigned long long m = same_bucket_lanes(valid, d);
+  const int leader = valid ? __ffsll((long long)m) - 1 : lane;
+  unsigned int at = 0;
+  if (valid && lane == leader) at = atomicAdd(&cnt[d], (unsigned int)__popcll(m));        // place inside this workgroup's share
+  at = __shfl(at, leader);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += 1024) base[i] = cnt[i] ? atomicAdd(&work[256 + i], cnt[i]) : 0u;     // the share's place in the bucket
+  __syncthreads();
+  if (valid) order[start[d] + base[d] + at + __popcll(m & ((1ull << lane) - 1ull))] = b;
 }
 
 // V and W2T rows are mostly touched by ONE sample of the batch (a user is drawn once, output items are uniform), and so are the W
@@ -1003,12 +1092,15 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_pf(DrxCdaeParams P, 
                                                                uint32_t qthr, int loss_kind, SparseBufs S) {
   extern __shared__ __align__(16) float pf_lds[];            // [kBlock / 64 waves][4 slots][64 lanes x 4 floats]
   const int lane = threadIdx.x % G;
-  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (b >= bt.B) return;
+  const int slot = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (slot >= bt.B) return;
+  const int32_t *const ord = S.order;
+  const int b = ord ? ord[slot] : slot;            // longest histories first, similar lengths side by side
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
   float *const ws = pf_lds + (size_t)wave * 4 * 256;
   const int wl4 = 4 * (int)(threadIdx.x % 64);
   const bool act = 4 * lane < P.ld;
+  DRX_STAMP(S.stamps, b, 0, lane);
   {
     // (the two accumulator rows are requested whatever the marks say — nine triples in ten are the only toucher of their V and
     // W2T rows — so that nothing here waits for a mark byte before the gather's own chain starts)
@@ -1020,9 +1112,11 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_pf(DrxCdaeParams P, 
       glds_row<G>(opt.s1[1], (size_t)i, P.ld, lane, ws + 768);
     }
   }
+  DRX_STAMP(S.stamps, b, 1, lane);
   float4 acc[1];
   DenseAux none{};
-  gather_bag<G, 1, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
+  gather_bag<G, 1, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0, 0, 1, S.stamps);
+  DRX_STAMP(S.stamps, b, 5, lane);
   // (b laundered: ids and marks are re-read — L1 hits — instead of living in registers through the gather)
   int bq = b;
   asm volatile("" : "+v"(bq));
@@ -1034,6 +1128,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_pf(DrxCdaeParams P, 
   const float y = bt.y[bq], pb2 = P.b2[i];
   const float mb2 = solo_o ? opt.s1[4][i] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's LDS-DMA has landed (nothing else orders a ds_read behind it)
+  DRX_STAMP(S.stamps, b, 6, lane);
   const float4 zero = f4_zero();
   const float4 v = act ? *reinterpret_cast<const float4 *>(ws + wl4) : zero;
   const float4 w2 = act ? *reinterpret_cast<const float4 *>(ws + 256 + wl4) : zero;
@@ -1058,6 +1153,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_pf(DrxCdaeParams P, 
   g2[0].x = dz2 * h.x; g2[0].y = dz2 * h.y; g2[0].z = dz2 * h.z; g2[0].w = dz2 * h.w;
   store_row<G, 1>(S.dz1, (size_t)b, P.ld, lane, dz1);
   if (lane == 0) S.lossb[b] = lval;
+  DRX_STAMP(S.stamps, b, 7, lane);
   OptScalars o = opt_for(opt, 0, bt.B);
   if (solo_o) {      // this triple alone touches W2T[i] and b2[i] (same arithmetic as sparse_apply / the segment path)
     float4 w[1] = {w2}, a[1];
@@ -1079,6 +1175,7 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_pf(DrxCdaeParams P, 
     a[0] = act ? *reinterpret_cast<const float4 *>(ws + 512 + wl4) : zero;
     adagrad_commit<G, 1>(o, P.V, opt.s1[2], (size_t)u, P.ld, lane, w, a, dz1);
   }
+  DRX_STAMP(S.stamps, b, 8, lane);
 }
 
 // Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
@@ -1253,8 +1350,8 @@ struct BiasPartialExtra {
   int ld;
   BiasArgs A;
   __device__ __forceinline__ void operator()(float *lds) const {
-    __shared__ float red[kBlock / 64];
-    bias_partial_body<G, J, kBlock>(ld, A, (int)blockIdx.x, lds, red);
+    __shared__ float red[kSegBlock / 64 > 0 ? kSegBlock / 64 : 1];
+    bias_partial_body<G, J, kSegBlock>(ld, A, (int)blockIdx.x, lds, red);
   }
 };
 
@@ -1339,6 +1436,8 @@ struct PrepBufs {
   uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo); then [B] "holds a marked W row"
   uint32_t *solo_w;             // [ceil(N/32)] one bit per item
   SpanPlan plan;                // chunk-crossing segments of the list (k_plan_spans)
+  int32_t *order;               // [B] launch order of the forward kernel (k_degree_counts / k_degree_scatter)
+  unsigned int *order_work;     // [512] bucket counts | running places (zeroed by k_sparse_touches)
   int n_chunks;
   size_t result_bytes;
   int T, bits;
@@ -1359,11 +1458,13 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.plan.desc = cv.take<uint2>(R.n_chunks);
   R.plan.cnt = cv.take<uint32_t>(64);
   R.plan.ext = cv.take<uint8_t>(R.n_chunks);
+  R.order = cv.take<int32_t>(B);
   R.result_bytes = align_up(cv.off, 256);
   R.keys = cv.take<uint32_t>(R.T);
   R.vals = cv.take<uint32_t>(R.T);
   R.sort_bytes = sort_pairs_temp_bytes(R.T, R.bits);
   R.sort_temp = cv.take<char>(R.sort_bytes);
+  R.order_work = cv.take<unsigned int>(512);
   return R;
 }
 
@@ -1381,7 +1482,7 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.phs = cv.take<float>(S.n_chunks);
   S.pts = cv.take<float>(S.n_chunks);
   {
-    const int cpb = kBlock / pick_geom(P.ld).G;
+    const int cpb = kSegBlock / pick_geom(P.ld).G;
     const int n_blocks = (S.n_chunks + cpb - 1) / cpb;
     S.pblock = cv.take<float>((size_t)n_blocks * P.ld);
     S.pbs = cv.take<float>(n_blocks);
@@ -1873,24 +1974,34 @@ int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHis
   return rc;
 }
 
+// plan.cnt (64 words) and plan.ext (n_chunks bytes) are adjacent 256-byte-aligned allocations: one range of words to zero
+static int plan_zero_words(const PrepBufs &R) { return (int)(((const char *)R.plan.ext + R.n_chunks - (const char *)R.plan.cnt + 3) / 4); }
+
 // The chunk-crossing segments of a sorted list, short ones and long ones (drx_segreduce.hpp, planned variant).  On the pristine list:
 // BEFORE the sole-toucher marks blank any key.
-static int plan_spans(const DrxCdaeParams *p, const PrepBufs &R, hipStream_t st) {
-  DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, 2 * sizeof(uint32_t), st));
-  DRX_HIP(hipMemsetAsync(R.plan.ext, 0, (size_t)R.n_chunks, st));
+static int plan_spans(const DrxCdaeParams *p, const PrepBufs &R, hipStream_t st, bool cleared) {
+  if (!cleared) DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, (size_t)plan_zero_words(R) * 4, st));     // (prepare_impl's touch kernel clears them)
   hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.T, R.n_chunks,
-                     kBlock / pick_geom(p->ld).G, R.plan);
+                     kSegBlock / pick_geom(p->ld).G, R.plan);
   return DRX_OK;
+}
+
+// (see k_degree_counts)
+static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
+  if (!cleared) (void)hipMemsetAsync(R.order_work, 0, 512 * sizeof(unsigned int), st);
+  const int blocks = (bt->B + 1023) / 1024;
+  hipLaunchKernelGGL(k_degree_counts, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work);
+  hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
 }
 
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
   const int gpb = kBlock / 16;
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
-                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w);
+                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w, R.plan.cnt, plan_zero_words(R), R.order_work, 512);
   // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
   const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, true, st);
   if (rc) return rc;
-  return plan_spans(p, R, st);
+  return plan_spans(p, R, st, true);
 }
 
 // W rows get sole-toucher marks when the caller asks for them (DRX_BATCH_MARK_W: worth it where a batch leaves most of its distinct
@@ -1943,7 +2054,12 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   S.solo_v = prepared ? R.solo_v : nullptr;
   S.solo_o = prepared ? R.solo_o : nullptr;
   S.solo_w = (prepared && mark_w_rows(p, bt)) ? R.solo_w : nullptr;       // (the rule mark_solo followed)
-  SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, nullptr, nullptr, nullptr, nullptr, S.T, S.n_chunks, p->ld};
+  static const bool use_order = [] { const char *e = getenv("DRX_FWD_ORDER"); return !e || atoi(e) != 0; }();      // (A/B switch)
+  S.order = (prepared && use_order) ? R.order : nullptr;
+  SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, nullptr, nullptr, nullptr, nullptr, S.T, S.n_chunks, p->ld, nullptr};
+#ifdef DRX_STAMPS
+  S.stamps = SB.stamps = h_stamps;
+#endif
   PlanBufs PB{S.pblock, S.pbs};
   // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
   const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
@@ -1962,14 +2078,14 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     POLT polk{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};                                        \
     BiasPartialExtra<G, J> bpx{p->ld, BA};                                                                             \
     BiasFinalExtra<G, J> bfx{*p, *opt, BA};                                                                            \
-    const int cpb = kBlock / G;                                                                                        \
+    const int cpb = kSegBlock / G;                                                                                     \
     const dim3 rgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                                          \
     const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
     if (long_segments)                                                                                                 \
-      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kBlock), lds_r, st, SB, PB,       \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
                          R.plan.ext, polk, n_bpart, bpx);                                                              \
     else                                                                                                               \
-      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kBlock), lds_r, st, SB, PB,       \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
                          R.plan.ext, polk, n_bpart, bpx);                                                              \
     EV(3);                                                                                                             \
     if (lds_b > 48 * 1024)                                                                                             \
@@ -2040,6 +2156,7 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   if (rc) return rc;
   rc = mark_solo(p, bt, R, (hipStream_t)stream, true);
   if (rc) return rc;
+  order_by_degree(bt, R, (hipStream_t)stream, true);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
@@ -2117,10 +2234,11 @@ int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt,
   const PartOut o = part_out_layout(*p, bt->B, bt->n_touch_slots, parts);
   hipLaunchKernelGGL(k_assemble_parts, dim3(2048), dim3(256), 0, st, (const char *)all_parts, o.bytes, o.runs_off, o.vals_off, parts, R.T,
                      R.keys_s, R.vals_s, overflow_out);
-  rc = plan_spans(p, R, st);
+  rc = plan_spans(p, R, st, false);
   if (rc) return rc;
   rc = mark_solo(p, bt, R, st, false);
   if (rc) return rc;
+  order_by_degree(bt, R, st, false);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

@@ -106,6 +106,18 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// In-kernel phase stamps (diagnostic builds only: -DDRX_STAMPS, scripts/build_variant.sh): lane 0 of a row group writes the
+// constant-rate device clock (100 MHz) at a few points of its life into stamps[unit * 16 + i] — the buffer travels in the kernel
+// arguments (SparseBufs / SegBufs, set from drx_debug_set_stamps); scripts/stamps.py turns them into mean phase durations.
+#ifdef DRX_STAMPS
+#define DRX_STAMP(buf, unit, i, lane)                                                             \
+  do {                                                                                            \
+    if ((lane) == 0 && (buf) && (unsigned)(unit) < 110000u) (buf)[(size_t)(unit) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define DRX_STAMP(buf, unit, i, lane) do { } while (0)
+#endif
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Bump allocator over the caller's scratch buffer.

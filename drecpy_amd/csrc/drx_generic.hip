@@ -230,6 +230,31 @@ static ScatterLayout scatter_layout(Carver &cv, int ld, int T, int bits) {
 
 using namespace drx;
 
+// Sum of squares of a float array in double, two deterministic stages (the value of an L2 term for the loss log — cdae.py:82,
+// Keras `l2` regularizers: never on the training path, which applies reg * p inside the update kernels).
+constexpr int kSumsqBlocks = 1024;
+__global__ __launch_bounds__(kBlock) void k_sumsq_partial(const float *__restrict__ x, size_t n, double *__restrict__ part) {
+  __shared__ double red[kBlock / 64];
+  double a = 0.0;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) a += (double)x[i] * (double)x[i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) t += red[i];
+    part[blockIdx.x] = t;
+  }
+}
+__global__ void k_sumsq_final(const double *__restrict__ part, int n_part, double *__restrict__ out, int accumulate) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = accumulate ? out[0] : 0.0;
+    for (int i = 0; i < n_part; ++i) t += part[i];
+    out[0] = t;
+  }
+}
+
 extern "C" {
 
 int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, float alpha, float l2_coef, float beta1, float beta2,
@@ -338,6 +363,16 @@ int drx_rows_dot(const float *x, int32_t B, const float *table, int32_t n_rows, 
   }
   DRX_DISPATCH_GEOM(ld, CALL);
 #undef CALL
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+/* out[0] (+)= sum x[i]^2 in double; out: device double [1 + 1024] (out[1..] is scratch for the block partials) */
+int drx_sumsq(const float *x, int64_t n, double *out, int32_t accumulate, void *stream) {
+  if (!x || !out || n < 0) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(kSumsqBlocks), dim3(kBlock), 0, st, x, (size_t)n, out + 1);
+  hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(64), 0, st, out + 1, kSumsqBlocks, out, accumulate);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

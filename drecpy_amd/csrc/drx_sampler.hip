@@ -47,9 +47,63 @@ __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_use
   deg[b] = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
 }
 
-// keep_off[1..B] = inclusive scan of deg[0..B): one workgroup of 1024 threads takes the batch in slabs of 8 192 degrees — a coalesced
-// load into LDS, every thread scans 8 neighbours there, wave scans + a scan of the 16 wave totals, a coalesced store — carrying the
-// running total from slab to slab (B = 65 536: eight slabs).  mailbox (pinned host memory or nullptr) receives (tag << 32) | total.
+// keep_off[1..B] = inclusive scan of deg[0..B) in three small launches (r03; r02 used ONE workgroup walking the batch in slabs: 54 - 80 us
+// of side-stream time per step beside the training kernels, where the preparation had become the pipeline's bound): sums of tiles of 4096
+// degrees, the spine (one wave scans the <= 64 tile sums and — when the host passes a pinned mailbox — posts the total, tagged, straight
+// into host memory with one system-scope store: no copy kernel, no event, no L2 write-back for the host's sake), the tiles again with
+// their offsets.  Batches of more than 262 144 triples fall back to the one-workgroup form.
+constexpr int kDegTile = 4096;
+
+__global__ __launch_bounds__(1024) void k_deg_tile_sums(const int32_t *__restrict__ deg, int B, int *__restrict__ tsum) {
+  __shared__ int wsum[16];
+  const int base = blockIdx.x * kDegTile + (int)threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s += base + q < B ? deg[base + q] : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < 16; ++i) t += wsum[i];
+    tsum[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_deg_spine(int *__restrict__ tsum, int n_tiles, unsigned long long *mailbox, uint32_t tag) {
+  const int lane = threadIdx.x;
+  const int x = lane < n_tiles ? tsum[lane] : 0;
+  int inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+  if (lane < n_tiles) tsum[lane] = inc - x;                  // exclusive offsets of the tiles
+  const int total = __shfl(inc, 63);
+  if (lane == 0 && mailbox)
+    __hip_atomic_store(mailbox, ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)total, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(1024) void k_deg_apply(const int32_t *__restrict__ deg, int B, const int *__restrict__ toff,
+                                                    int32_t *__restrict__ keep_off) {
+  __shared__ int wsum[16];
+  const int base = blockIdx.x * kDegTile + (int)threadIdx.x * 4, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int v[4], sum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { sum += base + q < B ? deg[base + q] : 0; v[q] = sum; }
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int off = toff[blockIdx.x] + inc - sum;
+  for (int ww = 0; ww < w; ++ww) off += wsum[ww];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (base + q < B) keep_off[base + q + 1] = v[q] + off;
+}
+
+// (the one-workgroup form: any batch size)
 __global__ __launch_bounds__(1024) void k_scan_degrees(const int32_t *__restrict__ deg, int B, int32_t *__restrict__ keep_off,
                                                        unsigned long long *mailbox, uint32_t tag) {
   constexpr int PER = 8, SLAB = 1024 * PER;
@@ -87,7 +141,7 @@ __global__ __launch_bounds__(1024) void k_scan_degrees(const int32_t *__restrict
 
 extern "C" size_t drx_point_sample_scratch_bytes(int32_t B) {
   if (B < 1) return 0;
-  return drx::align_up((size_t)B * 4, 256) + 256;
+  return drx::align_up((size_t)B * 4, 256) + 256 + 256;        // degrees, then 64 tile sums
 }
 
 extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
@@ -102,7 +156,15 @@ extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t
   int32_t *deg = (int32_t *)scratch;
   hipLaunchKernelGGL(k_point_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, *hist, n_users, n_items, B,
                      neg_ratio, seed, uid, iid, y, deg, keep_off);
-  hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, keep_off, (unsigned long long *)host_mailbox, tag);
+  const int n_tiles = (B + kDegTile - 1) / kDegTile;
+  if (n_tiles <= 64) {
+    int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
+    hipLaunchKernelGGL(k_deg_tile_sums, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum);
+    hipLaunchKernelGGL(k_deg_spine, dim3(1), dim3(64), 0, st, tsum, n_tiles, (unsigned long long *)host_mailbox, tag);
+    hipLaunchKernelGGL(k_deg_apply, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum, keep_off);
+  } else {
+    hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, keep_off, (unsigned long long *)host_mailbox, tag);
+  }
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

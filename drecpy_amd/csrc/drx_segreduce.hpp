@@ -27,6 +27,11 @@ constexpr int kChunk = DRX_CHUNK;      // touches per group in the segmented red
 #define SEG_GPB(G) (drx::kBlock / (G))
 #endif
 constexpr int kShortSpan = 64;     // chunk borders a segment may cross and still be combined by one group
+#ifndef DRX_SEG_BLOCK
+#define DRX_SEG_BLOCK 128
+#endif
+constexpr int kSegBlock = DRX_SEG_BLOCK;   // threads per workgroup of k_seg_reduce_planned (a workgroup keeps its LDS and its slot until its
+                                   //   slowest chunk is done: smaller workgroups pack uneven chunks better, larger ones fold longer runs)
 constexpr int kPlanShort = 16;     // planned variant: spans of up to this many partial rows are combined by ONE group (two rounds of 8 loads in
                                    //   flight), longer ones by a workgroup; 64 left the second-hottest rows to a single group each: 8 rounds
 constexpr int kFixBlock = 512;     // (1024: the long-span fix-up kernel hit the 128-VGPR cap of a 16-wave workgroup and spilled)
@@ -40,6 +45,7 @@ struct SegBufs {
   uint8_t *cflag;                             // [n_chunks] 0: chunk's first segment starts here; 2: the whole chunk is the
                                               //   middle of one crossing segment; 1: it starts with the END of one
   int T, n_chunks, ld;
+  unsigned long long *stamps;                 // diagnostic builds (DRX_STAMPS) only; nullptr otherwise
 };
 
 // Segmented reduction over the sorted touch list in fixed chunks of kChunk touches per group.
@@ -222,7 +228,7 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_c
   else P.desc[n_chunks - 1 - (int)atomicAdd(&P.cnt[1], 1u)] = d;
 }
 
-// LDS: [kBlock/G, ld] floats + [kBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
+// LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
 // CDAE step's bias column sums: independent work that fills the launch's ramp).
 #ifdef DRX_SEGP_W8
 #define DRX_SEGP_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -230,10 +236,10 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_c
 #define DRX_SEGP_ATTR
 #endif
 template <int G, int J, class Policy, int LB1, class Extra>
-__global__ __launch_bounds__(kBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(SegBufs S, PlanBufs PB, const uint8_t *__restrict__ ext, Policy pol,
+__global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(SegBufs S, PlanBufs PB, const uint8_t *__restrict__ ext, Policy pol,
                                                                             int extra_blocks, Extra extra) {
   extern __shared__ __align__(16) float seg_lds[];
-  constexpr int CPB = kBlock / G;
+  constexpr int CPB = kSegBlock / G;
   if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
   const int blk = (int)blockIdx.x - extra_blocks;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(kBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(Seg
   }
   const bool all_inner = __syncthreads_and(inner ? 1 : 0) != 0;
   if (g >= S.n_chunks) return;          // (never in an all-inner workgroup: its second barrier below sees every thread)
+  DRX_STAMP(S.stamps, 65536 + g, 0, lane);
   // this chunk's window: behind the touches its left neighbour finishes for it, and into the right neighbour's for the segment it
   // finishes itself (SpanPlan::ext); up to 2 * kChunk - 1 touches
   const int start = min(S.T, g * kChunk + (g > 0 ? (int)ext[g - 1] : 0)), end = min(S.T, (g + 1) * kChunk + (int)ext[g]);
@@ -267,6 +274,10 @@ __global__ __launch_bounds__(kBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(Seg
     for (int q = 1; q < KPL; ++q) sel = (t / G == q) ? reg[q] : sel;
     return (uint32_t)__shfl((int)sel, t % G, G);
   };
+#ifdef DRX_STAMPS
+  if (kreg[0] != 12345u || prev_key != 12345u) DRX_STAMP(S.stamps, 65536 + g, 1, lane);      // (keys have landed)
+  unsigned n_flush = 0;
+#endif
   float4 acc[J];
 #pragma unroll
   for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
@@ -278,6 +289,9 @@ __global__ __launch_bounds__(kBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(Seg
     if (cur == DRX_KEY_NONE) return;
     const bool cont_left = cur_from_start && prev_key == cur;
     const bool cont_right = at_end && next_key == cur;
+#ifdef DRX_STAMPS
+    ++n_flush;
+#endif
     if (!cont_left && !cont_right) {
       pol.template finish<G, J>(cur, cur_pos, lane, acc, accs);
     } else if (cont_left) {
@@ -324,7 +338,14 @@ __global__ __launch_bounds__(kBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(Seg
       }
     }
   }
+#ifdef DRX_STAMPS
+  if (acc[0].x == acc[0].x) DRX_STAMP(S.stamps, 65536 + g, 2, lane);
+#endif
   flush(n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE);
+#ifdef DRX_STAMPS
+  DRX_STAMP(S.stamps, 65536 + g, 3, lane);
+  if (lane == 0 && S.stamps && (unsigned)(65536 + g) < 110000u) { S.stamps[(size_t)(65536 + g) * 16 + 4] = n_flush; S.stamps[(size_t)(65536 + g) * 16 + 5] = (unsigned)n; }
+#endif
   if (all_inner) {                 // every chunk of this workgroup is one whole run of the same segment: one partial for all of them
     float *sc = seg_lds + (size_t)CPB * S.ld;
     store_row<G, J>(seg_lds, (size_t)r, S.ld, lane, acc);
@@ -372,7 +393,7 @@ template <int G, int J, class Policy, class Extra>
 __global__ __launch_bounds__(kFixBlock) void k_span_planned(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol, int n_long_blocks,
                                                             int n_short_blocks, Extra extra) {
   extern __shared__ __align__(16) float span_lds[];
-  constexpr int R = kFixBlock / G, CPB = kBlock / G;
+  constexpr int R = kFixBlock / G, CPB = kSegBlock / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   constexpr int UL = J == 1 ? 8 : 2;                       // partial rows in flight per group
   if ((int)blockIdx.x >= n_long_blocks + n_short_blocks) { extra(span_lds); return; }

@@ -4,7 +4,6 @@
 // bitonic network in LDS (up to 16384 keys = 128 KiB of the CU's 160 KiB).
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include "drx_common.hpp"
 
 namespace drx {
@@ -55,80 +54,215 @@ __global__ __launch_bounds__(kBlock) void k_topk_lds(const float *__restrict__ s
   }
 }
 
-// ---- rows longer than the LDS path: one device-wide segmented radix sort of the 64-bit keys (descending) ----------
-__global__ void k_topk_keys(const float *__restrict__ scores, const uint32_t *__restrict__ mask, size_t total, int n,
-                            unsigned long long *keys) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const bool ok = !mask || ((mask[i >> 5] >> (i & 31)) & 1u);
-    keys[i] = ok ? (((unsigned long long)ordered_bits(scores[i]) << 32) | (unsigned)(i % n)) : 0ull;
+// ---- rows longer than the LDS path (the 1 M-item catalogue): RADIX SELECT, not a sort ------------------------------------------
+// One workgroup per row finds the k-th largest 64-bit key by walking its digits from the top, 11 bits at a time: a 2048-bin LDS
+// histogram of the digit among the keys that match the prefix found so far, the bin where the count from the top reaches k, next
+// digit (6 passes over the row, which L2 / the Infinity Cache hold after the first).  Keys are unique (the index is part of them),
+// so exactly k keys are >= the k-th one: they are collected (in any order) and a second launch orders those k in LDS with the
+// bitonic network above.  r02 sorted every row in full with rocprim::segmented_radix_sort_keys_desc.
+constexpr int kSelThreads = 1024;
+constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;
+
+__device__ __forceinline__ unsigned long long topk_key(const float *scores, const uint32_t *mask, size_t row_off, int i) {
+  const size_t bit = row_off + (size_t)i;
+  const bool ok = !mask || ((mask[bit >> 5] >> (bit & 31)) & 1u);
+  return ok ? (((unsigned long long)ordered_bits(scores[bit]) << 32) | (unsigned)i) : 0ull;
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_topk_select(const float *__restrict__ scores, const uint32_t *__restrict__ mask, int n,
+                                                             int k, unsigned long long *__restrict__ cand, int *__restrict__ n_cand) {
+  __shared__ unsigned int hist[kSelBins];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned int s_need, s_count;
+  __shared__ unsigned int wsum[kSelThreads / 64];
+  const size_t r = blockIdx.x, row_off = r * (size_t)n;
+  // valid candidates of the row
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  unsigned int mine = 0;
+  for (int i = threadIdx.x; i < n; i += kSelThreads) mine += topk_key(scores, mask, row_off, i) != 0ull;
+  atomicAdd(&s_count, mine);
+  __syncthreads();
+  const unsigned int want = min((unsigned int)k, s_count);
+  if (threadIdx.x == 0) { s_prefix = 0ull; s_need = want; n_cand[r] = (int)want; }
+  __syncthreads();
+  if (want == 0) return;
+  // digits from the top: after the pass at `shift`, s_prefix holds the k-th key's bits at and above it
+  for (int shift = 64 - kSelBits + (6 * kSelBits - 64); shift >= 0; shift -= kSelBits) {      // 55, 44, 33, 22, 11, 0 (the first digit is 9 bits wide)
+    for (int i = threadIdx.x; i < kSelBins; i += kSelThreads) hist[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    const int hi_shift = shift + kSelBits;               // bits at and above this position are decided
+    for (int i = threadIdx.x; i < n; i += kSelThreads) {
+      const unsigned long long key = topk_key(scores, mask, row_off, i);
+      if (key == 0ull) continue;
+      const bool match = hi_shift >= 64 || (key >> hi_shift) == (prefix >> hi_shift);
+      if (match) atomicAdd(&hist[(unsigned)(key >> shift) & (kSelBins - 1)], 1u);
+    }
+    __syncthreads();
+    // the bin, from the top, where the running count reaches what is still needed: thread t owns bins 2t and 2t + 1; an exclusive
+    // SUFFIX sum over the threads (wave shuffles + one LDS word per wave) gives every thread the count above its bins
+    {
+      const unsigned int c0 = hist[2 * threadIdx.x], c1 = hist[2 * threadIdx.x + 1];
+      const unsigned int pair = c0 + c1;
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      unsigned int v = pair;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const unsigned int o = __shfl_down(v, dd, 64);
+        if (lane + dd < 64) v += o;
+      }
+      if (lane == 0) wsum[w] = v;                        // the wave's total
+      __syncthreads();
+      unsigned int above = v - pair;                     // pairs of higher lanes of this wave
+      for (int ww = w + 1; ww < kSelThreads / 64; ++ww) above += wsum[ww];
+      const unsigned int need = s_need;
+      __syncthreads();                                   // (every thread has read s_need before one of them rewrites it)
+      if (above < need && need <= above + pair) {
+        const bool upper = above + c1 >= need;
+        s_need = need - (upper ? above : above + c1);
+        s_prefix = prefix | ((unsigned long long)(2 * threadIdx.x + (upper ? 1 : 0)) << shift);
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned long long kth = s_prefix;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += kSelThreads) {
+    const unsigned long long key = topk_key(scores, mask, row_off, i);
+    if (key != 0ull && key >= kth) {
+      const unsigned int at = atomicAdd(&s_count, 1u);
+      if (at < (unsigned)k) cand[r * (size_t)k + at] = key;
+    }
   }
 }
 
-__global__ void k_topk_offsets(int R, int n, int *off) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= R; i += gridDim.x * blockDim.x) off[i] = i * n;
-}
-
-__global__ void k_topk_emit(const unsigned long long *__restrict__ sorted, const float *__restrict__ scores, int R, int n, int k,
-                            int32_t *out_idx, float *out_val) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)R * k; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / k;
-    const int j = (int)(i % k);
-    const unsigned long long key = j < n ? sorted[r * n + j] : 0ull;
-    if (key == 0ull) { out_idx[i] = -1; out_val[i] = -INFINITY; }
-    else { const int idx = (int)(key & 0xFFFFFFFFull); out_idx[i] = idx; out_val[i] = scores[r * n + idx]; }
+// the k selected keys of every row, ordered in LDS (k <= 16384) and emitted
+__global__ __launch_bounds__(kBlock) void k_topk_order(const unsigned long long *__restrict__ cand, const int *__restrict__ n_cand,
+                                                       const float *__restrict__ scores, int n, int ks, int k, int kpad,
+                                                       int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+  extern __shared__ __align__(16) unsigned long long keys[];       // ks = selected per row (stride of cand), k = output columns
+  const size_t r = blockIdx.x;
+  const int have = n_cand[r];
+  for (int i = threadIdx.x; i < kpad; i += kBlock) keys[i] = i < have ? cand[r * (size_t)ks + i] : 0ull;
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (kpad >> 1); t += kBlock) {
+        const int a = 2 * t - (t & (stride - 1));
+        const int b = a + stride;
+        const unsigned long long ka = keys[a], kb = keys[b];
+        const bool desc = (a & size) == 0;
+        if (desc ? (ka < kb) : (ka > kb)) { keys[a] = kb; keys[b] = ka; }
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < k; j += kBlock) {
+    const unsigned long long key = j < kpad ? keys[j] : 0ull;
+    if (key == 0ull) { out_idx[r * (size_t)k + j] = -1; out_val[r * (size_t)k + j] = -INFINITY; }
+    else { const int idx = (int)(key & 0xFFFFFFFFull); out_idx[r * (size_t)k + j] = idx; out_val[r * (size_t)k + j] = scores[r * (size_t)n + idx]; }
   }
 }
 
-struct TopkLayout { unsigned long long *keys, *sorted; int *off; void *temp; size_t temp_bytes; };
+// k > 16384 of a long row (rank everything): the selected keys ordered by two stable passes of the library's own pair sort — by index
+// descending, then by score descending — one row at a time (rare: a full ranking of a large catalogue)
+__global__ void k_topk_split(const unsigned long long *__restrict__ cand, int have, uint32_t *__restrict__ kidx, uint32_t *__restrict__ vals) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < have; i += gridDim.x * blockDim.x) {
+    const uint32_t idx = (uint32_t)(cand[i] & 0xFFFFFFFFull);
+    kidx[i] = ~idx;                       // ascending ~idx = descending idx
+    vals[i] = (uint32_t)i;                // position in cand
+  }
+}
+__global__ void k_topk_score_keys(const unsigned long long *__restrict__ cand, const uint32_t *__restrict__ order, int have,
+                                  uint32_t *__restrict__ kscore) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < have; i += gridDim.x * blockDim.x)
+    kscore[i] = ~(uint32_t)(cand[order[i]] >> 32);      // ascending ~score = descending score
+}
+__global__ void k_topk_emit_sorted(const unsigned long long *__restrict__ cand, const uint32_t *__restrict__ order, int have,
+                                   const float *__restrict__ scores_row, int k, int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
+    if (j < have) { const int idx = (int)(cand[order[j]] & 0xFFFFFFFFull); out_idx[j] = idx; out_val[j] = scores_row[idx]; }
+    else { out_idx[j] = -1; out_val[j] = -INFINITY; }
+  }
+}
 
-static TopkLayout topk_layout(Carver &cv, int R, int n) {
+struct TopkLayout {
+  unsigned long long *cand;     // [R, k]
+  int *n_cand;                  // [R]
+  uint32_t *ka, *kb, *va, *vb;  // [k] each (k > 16384 only)
+  void *sort_temp;
+  size_t sort_bytes;
+};
+
+static TopkLayout topk_layout(Carver &cv, int R, int k) {
   TopkLayout L{};
-  const size_t total = (size_t)R * n;
-  L.keys = cv.take<unsigned long long>(total);
-  L.sorted = cv.take<unsigned long long>(total);
-  L.off = cv.take<int>(R + 1);
-  L.temp_bytes = 0;
-  unsigned long long *d = nullptr;
-  int *o = nullptr;
-  (void)rocprim::segmented_radix_sort_keys_desc(nullptr, L.temp_bytes, d, d, total, R, o, o, 0, 64, (hipStream_t)0);
-  L.temp = cv.take<char>(L.temp_bytes);
+  L.cand = cv.take<unsigned long long>((size_t)R * k);
+  L.n_cand = cv.take<int>(R);
+  if (k > 16384) {
+    L.ka = cv.take<uint32_t>(k); L.kb = cv.take<uint32_t>(k); L.va = cv.take<uint32_t>(k); L.vb = cv.take<uint32_t>(k);
+    L.sort_bytes = sort_pairs_temp_bytes((size_t)k, 32);
+    L.sort_temp = cv.take<char>(L.sort_bytes);
+  }
   return L;
 }
 
 }  // namespace drx
 
-extern "C" size_t drx_topk_scratch_bytes(int32_t R, int32_t n) {
-  if (R < 1 || n <= 16384) return 0;
+extern "C" size_t drx_topk_scratch_bytes_k(int32_t R, int32_t n, int32_t k) {
+  if (R < 1 || n <= 16384 || k < 1) return 0;
   drx::Carver cv(nullptr, 0);
-  (void)drx::topk_layout(cv, R, n);
+  (void)drx::topk_layout(cv, R, k < n ? k : n);
   return drx::align_up(cv.off, 256) + 256;
 }
+
+/* (kept for callers that size the scratch before they know k: the bound for k = n) */
+extern "C" size_t drx_topk_scratch_bytes(int32_t R, int32_t n) { return drx_topk_scratch_bytes_k(R, n, n); }
 
 extern "C" int drx_topk(const float *scores, const uint32_t *cand_mask, int32_t R, int32_t n, int32_t k, int32_t *out_idx,
                         float *out_val, void *scratch, size_t scratch_bytes, void *stream) {
   if (!scores || !out_idx || !out_val || R < 1 || n < 1 || k < 1) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
   int npad = 2;
   while (npad < n) npad <<= 1;
   if (npad > 16384) {
     if ((long long)R * n > 0x7FFFFFFFll || !scratch) return DRX_EINVAL;
+    const int ks = k < n ? k : n;                         // keys selected per row; out columns beyond them are "missing"
     drx::Carver cv(scratch, scratch_bytes);
-    drx::TopkLayout L = drx::topk_layout(cv, R, n);
+    drx::TopkLayout L = drx::topk_layout(cv, R, ks);
     if (!cv.ok()) return DRX_ESCRATCH;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t total = (size_t)R * n;
-    hipLaunchKernelGGL(drx::k_topk_keys, dim3(2048), dim3(256), 0, st, scores, cand_mask, total, n, L.keys);
-    hipLaunchKernelGGL(drx::k_topk_offsets, dim3(64), dim3(256), 0, st, R, n, L.off);
-    hipError_t e = rocprim::segmented_radix_sort_keys_desc(L.temp, L.temp_bytes, L.keys, L.sorted, total, R, L.off, L.off + 1, 0,
-                                                           64, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(drx::k_topk_emit, dim3(1024), dim3(256), 0, st, L.sorted, scores, R, n, k, out_idx, out_val);
+    hipLaunchKernelGGL(drx::k_topk_select, dim3(R), dim3(drx::kSelThreads), 0, st, scores, cand_mask, n, ks, L.cand, L.n_cand);
+    if (ks <= 16384) {
+      int kpad = 2;
+      while (kpad < ks) kpad <<= 1;
+      const size_t lds = (size_t)kpad * sizeof(unsigned long long);
+      DRX_HIP(hipFuncSetAttribute((const void *)drx::k_topk_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(drx::k_topk_order, dim3(R), dim3(drx::kBlock), lds, st, L.cand, L.n_cand, scores, n, ks, k, kpad, out_idx, out_val);
+    } else {
+      for (int r = 0; r < R; ++r) {
+        int have = 0;
+        DRX_HIP(hipMemcpyAsync(&have, L.n_cand + r, sizeof(int), hipMemcpyDeviceToHost, st));
+        DRX_HIP(hipStreamSynchronize(st));
+        const unsigned long long *cand = L.cand + (size_t)r * ks;
+        if (have > 0) {
+          hipLaunchKernelGGL(drx::k_topk_split, dim3(256), dim3(256), 0, st, cand, have, L.ka, L.va);
+          int rc = drx::sort_pairs(L.sort_temp, L.sort_bytes, L.ka, L.kb, L.va, L.vb, (size_t)have, 32, st);
+          if (rc) return rc;
+          hipLaunchKernelGGL(drx::k_topk_score_keys, dim3(256), dim3(256), 0, st, cand, L.vb, have, L.ka);
+          rc = drx::sort_pairs(L.sort_temp, L.sort_bytes, L.ka, L.kb, L.vb, L.va, (size_t)have, 32, st);
+          if (rc) return rc;
+        }
+        hipLaunchKernelGGL(drx::k_topk_emit_sorted, dim3(256), dim3(256), 0, st, cand, L.va, have, scores + (size_t)r * n, k,
+                           out_idx + (size_t)r * k, out_val + (size_t)r * k);
+      }
+    }
     DRX_LAUNCH_CHECK();
     return DRX_OK;
   }
   const size_t lds = (size_t)npad * sizeof(unsigned long long);
   DRX_HIP(hipFuncSetAttribute((const void *)drx::k_topk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(drx::k_topk_lds, dim3(R), dim3(drx::kBlock), lds, (hipStream_t)stream, scores, cand_mask, n, k, npad,
-                     out_idx, out_val);
+  hipLaunchKernelGGL(drx::k_topk_lds, dim3(R), dim3(drx::kBlock), lds, st, scores, cand_mask, n, k, npad, out_idx, out_val);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

@@ -643,6 +643,8 @@ class ColumnShardedCdae:
         if self.collectives:
             need = part.numel() * self.world
             if self._all[k] is None or self._all[k].numel() < need:
+                if self._all[k] is not None:
+                    e._retire(self._all[k])
                 self._all[k] = None
                 self._all[k] = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=part.device)
             allp = self._all[k][:need]

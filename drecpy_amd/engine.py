@@ -405,6 +405,12 @@ class CdaeEngine:
             'drx_cdae_fit_dense')
         self._dense_clean = self._dense_ent[1] = True
 
+    def _retire(self, t):
+        """A buffer about to be dropped while work on OTHER streams may still read it: its memory is not reused before every stream
+        that exists on this device now has passed this point (the caching allocator only orders reuse on the allocating stream)."""
+        t.record_stream(torch.cuda.default_stream(self.device))
+        t.record_stream(torch.cuda.current_stream(self.device))
+
     def prep_buffer(self, bt, out=None):
         """A buffer large enough for the prepared touch list of `bt` (`out` itself when it is)."""
         need = lib().drx_cdae_prep_bytes(C.byref(self._params), bt.B, bt.n_touch_slots)
@@ -436,11 +442,15 @@ class CdaeEngine:
         else:
             bufs = self.__dict__.setdefault('_part_bufs', {})
             if slot not in bufs or bufs[slot].numel() < nb:
+                if bufs.get(slot) is not None:
+                    self._retire(bufs[slot])
                 bufs[slot] = None
                 bufs[slot] = torch.empty(int(nb * 1.05) + 4096, dtype=torch.uint8, device=self.device)
             out = bufs[slot][:nb]
         need = lib().drx_cdae_prep_part_bytes(P, bt.B, bt.n_touch_slots, parts)
         if getattr(self, '_pscratch', None) is None or self._pscratch.numel() < need:
+            if getattr(self, '_pscratch', None) is not None:
+                self._retire(self._pscratch)
             self._pscratch = None
             self._pscratch = torch.empty(int(need * 1.1) + 1024, dtype=torch.uint8, device=self.device)
         check(lib().drx_cdae_sparse_prepare_part(P, C.byref(self._hist), C.byref(bt), part, parts, ptr(out), out.numel(),
@@ -522,7 +532,7 @@ class CdaeEngine:
         R, n = scores.shape
         out_idx = torch.empty(R, k, dtype=torch.int32, device=self.device)
         out_val = torch.empty(R, k, dtype=torch.float32, device=self.device)
-        sb = lib().drx_topk_scratch_bytes(R, n)
+        sb = lib().drx_topk_scratch_bytes_k(R, n, k)
         sc = torch.empty(sb, dtype=torch.uint8, device=self.device) if sb else None
         check(lib().drx_topk(ptr(scores), ptr(cand_mask), R, n, k, ptr(out_idx), ptr(out_val), ptr(sc), sb,
                              stream_ptr(self.device)), 'drx_topk')
@@ -645,6 +655,11 @@ class SampledPipeline:
         self.main = torch.cuda.current_stream(dev)
         # high priority: a normal stream may share a hardware queue with the training stream and inherit its barriers
         self.side = torch.cuda.Stream(dev, priority=-1)
+        # what the run-ahead work reads (histories, tables' shapes) may still be in flight on the caller's stream — a history generated on
+        # the device a moment ago (scripts/stamps.py hit this: the sampler read row pointers that were not written yet and faulted)
+        self.side.wait_stream(self.main)
+        if self.comm is not None:
+            self.comm.wait_stream(self.main)
         self.D = D = max(1, int(prep_ahead))
         # batches are drawn one step before their list is prepared; two when lists are prepared far ahead (a draw then never
         # queues right behind a long preparation whose count the host is about to wait for)
@@ -711,11 +726,21 @@ class SampledPipeline:
         k = s % self.RP
         if s >= self.RP:
             self.step_ev[(s - self.RP) % self.NE].wait(self.side)   # the buffer's previous user (step s - RP) has finished
+        old = self.prep[k]
         with torch.cuda.stream(self.side):
             if self.prepare_fn is not None:
-                self.prep[k] = self.prepare_fn(s, bt, self.prep[k])
+                self.prep[k] = self.prepare_fn(s, bt, old)
             else:
-                self.prep[k] = self.eng.prepare_sparse(bt, self.prep[k])
+                self.prep[k] = self.eng.prepare_sparse(bt, old)
+        if old is not None and self.prep[k].data_ptr() != old.data_ptr():
+            # the list grew into a new buffer.  The old one was allocated on the side stream, so the allocator would hand its memory to
+            # the next side-stream allocation at once — but its last reader is a training step on the MAIN stream that, when the host
+            # runs ahead of the device, has not even started (r03: a memory fault in scripts/stamps.py, whose first steps queue behind
+            # a second of table initialisation).  record_stream defers the reuse until the main stream has passed this point.
+            old.record_stream(self.main)
+            if self.comm is not None:
+                old.record_stream(self.comm)
+        del old
         (self.prep_done if self.deliver_fn is None else self.built)[k].record(self.side)
 
     def _deliver(self, s):

@@ -271,10 +271,7 @@ class CaserEngine:
         A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = p_dE, p_dW1, db1.data_ptr(), p_dPu, gpart.data_ptr(), lpart.data_ptr()
         reg_loss = None
         if want_loss:                                   # Keras l2(reg) on the pre-update weights
-            sq = (self.user_emb ** 2).sum() + (self.item_emb ** 2).sum() + (self.W1 ** 2).sum()
-            for name, start, n, regd, _ in self.seg:
-                if regd:
-                    sq = sq + (self.sw[start:start + n] ** 2).sum()
+            sq = _lib.sumsq([self.user_emb, self.item_emb, self.W1] + [self.sw[start:start + n] for _, start, n, regd, _ in self.seg if regd])
             reg_loss = self.reg * sq
         check(L_.drx_caser_fwd_bwd(C.byref(self.D), C.byref(A), gsw.data_ptr(), stream), 'drx_caser_fwd_bwd')
         alpha = self._alphas(step_idx)

@@ -293,10 +293,7 @@ class DmfEngine:
         A.work = self._work.data_ptr()
         reg_loss = None
         if want_loss:
-            sq = (self.K0u ** 2).sum() + (self.K0i ** 2).sum()
-            for _, start, n, regd, _ in self.seg:
-                if regd:
-                    sq = sq + (self.sw[start:start + n] ** 2).sum()
+            sq = _lib.sumsq([self.K0u, self.K0i] + [self.sw[start:start + n] for _, start, n, regd, _ in self.seg if regd])
             reg_loss = self.reg * sq
         check(L_.drx_dmf_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream), 'drx_dmf_fwd_bwd')
         if applies is None:

@@ -293,6 +293,10 @@ int drx_batch_csr(const int32_t *keys, int32_t T, int32_t n_rows, int32_t *row_p
 int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const uint32_t *src_index, const float *coef,
                      const float *src_s, int32_t ld, int32_t n_rows, float *out, float *out_s, void *scratch,
                      size_t scratch_bytes, void *stream);
+/* drx_sumsq: out[0] (+)= sum_i x[i]^2, accumulated in double in a fixed order; out = device double [1 + 1024] (out[1..] is scratch).
+ * The VALUE of an L2 term for the loss log (cdae.py:82 tf.nn.l2_loss, the Keras l2 regularizers of dmf.py / caser.py) — the training
+ * path never needs it (the update kernels apply reg * p themselves). */
+int drx_sumsq(const float *x, int64_t n, double *out, int32_t accumulate, void *stream);
 /* drx_rows_dot: out[b, n] = x[b, :] . table[n, :] + bias[n]   (all-item scoring, caser.py:137) */
 int drx_rows_dot(const float *x, int32_t B, const float *table, int32_t n_rows, int32_t ld, const float *bias, float *out,
                  void *stream);
@@ -437,7 +441,9 @@ int drx_score_pairs_bf16(const float *ru, int32_t n_u, const float *ri, int32_t 
  * For each of R rows of `scores` [R, n] select the top `k` entries among those with
  * cand_mask == NULL || bit (r*n + i) set; order = descending score, ties by larger index
  * (heapq.nlargest over (score, iid) tuples).  out_idx/out_val [R,k]; missing = -1 / -inf. */
-size_t drx_topk_scratch_bytes(int32_t R, int32_t n);   /* 0 for n <= 16384 (LDS bitonic path, scratch may be NULL) */
+size_t drx_topk_scratch_bytes_k(int32_t R, int32_t n, int32_t k);   /* 0 for n <= 16384 (LDS bitonic path, scratch may be NULL); longer rows:
+                                                                       * the k keys a radix select picks per row (+ sort space when k > 16384) */
+size_t drx_topk_scratch_bytes(int32_t R, int32_t n);                 /* the same for k = n (an upper bound for every k) */
 int drx_topk(const float *scores, const uint32_t *cand_mask, int32_t R, int32_t n, int32_t k,
              int32_t *out_idx, float *out_val, void *scratch, size_t scratch_bytes, void *stream);
 

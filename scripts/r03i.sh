@@ -1,0 +1,20 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/${1:-r03i}
+mkdir -p $OUT
+python -m pytest tests/test_gpu_cdae.py tests/test_gpu_fullsize.py -x -q -m gpu > $OUT/tests.log 2>&1
+echo "tests rc=$?"; tail -3 $OUT/tests.log
+run() { name=$1; shift; for rep in 1 2; do env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-hr --no-configs > $OUT/bench_${name}_$rep.json 2>> $OUT/bench.err; done; }
+run default X=0
+run noorder DRX_FWD_ORDER=0
+run seg128 DRX_HOST_SANITIZER_LIB=$PWD/drecpy_amd/csrc/build/libdrx_seg128.so
+python - $OUT <<'PY'
+import glob, json, sys
+for f in sorted(glob.glob(sys.argv[1] + '/bench_*.json')):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith('{')][-1])
+        print(f.split('/')[-1], round(d['value'] / 1e6, 1), 'M/s', round(d['ms_per_step'], 4), [round(v * 1e3, 1) for v in d['phases_ms'].values()], 'frac', round(d['roofline']['frac'], 3), round(d['roofline']['whole_step_frac'], 3))
+    except Exception as e:
+        print(f, 'ERR', e)
+PY
+tail -3 $OUT/bench.err

@@ -44,7 +44,8 @@ def test_dataset_assign_ids_on_gpu_matches_golden():
             assert ds.iid_to_item(iid) == want
 
 
-@pytest.mark.parametrize('n,k', [(40, 5), (1682, 10), (3706, 100), (5000, 5000), (16384, 7), (16385, 50), (100000, 1000)])
+@pytest.mark.parametrize('n,k', [(40, 5), (1682, 10), (3706, 100), (5000, 5000), (16384, 7), (16385, 50), (100000, 1000),
+                                 (1_000_000, 100), (40_000, 20_000), (20_000, 30_000)])      # long rows: radix select (+ the k > 16384 ordering)
 def test_topk_matches_heapq(n, k):
     import torch
     from drecpy_amd.engine import CdaeEngine, pack_mask_bits
