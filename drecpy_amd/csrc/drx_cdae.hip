@@ -605,20 +605,42 @@ struct SparseBufs {
   int T, n_chunks, n_bpart;
 };
 
+// The V keys of a touch list are 2N + user id: with ten million users that is a 24-bit key space and a THIRD pass of the radix sort
+// for the sake of 65 536 of 1.4 M touches.  A batch holds at most B distinct users, so they are numbered by their SLOT in an
+// open-addressing table of 4B entries (atomicCAS; cleared per batch): V key = 2N + slot, 22 bits at N = 10^6 — two 11-bit passes.
+// The table travels with the prepared list (the reduction turns a slot back into a user with one load per V segment).  Used when
+// n_users exceeds the table; smaller user sets keep their ids.
+__device__ __forceinline__ uint32_t user_hash(uint32_t u) { u *= 0x9E3779B1u; return u ^ (u >> 15); }
+
+__global__ __launch_bounds__(kBlock) void k_user_slots(const int32_t *__restrict__ uid, int B, uint32_t *__restrict__ vtab, uint32_t vt_mask,
+                                                       uint32_t *__restrict__ vslot) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t u = (uint32_t)uid[b];
+  uint32_t h = user_hash(u) & vt_mask;
+  for (;;) {
+    const uint32_t old = atomicCAS(&vtab[h], 0xFFFFFFFFu, u);
+    if (old == 0xFFFFFFFFu || old == u) break;
+    h = (h + 1) & vt_mask;
+  }
+  vslot[b] = h;
+}
+
 // Touch list of one batch (row key, sample): depends only on the batch, never on the parameters, so it can be built
 // and sorted for batch t+1 while batch t trains (drx_cdae_sparse_prepare on a second stream).
 // Also clears the sole-toucher marks of the batch (solo: [2B] bytes, solo_w: one bit per item; or nullptr) and pads the slots beyond
 // the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
 __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
                                                            uint32_t *vals, int T, uint8_t *solo, uint32_t *solo_w, uint32_t *zero_a,
-                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b) {
+                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b, const uint32_t *__restrict__ vslot) {
   constexpr int G = 16;
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
   if (solo_w)
     for (int w = blockIdx.x * kBlock + threadIdx.x; w < (n_items + 31) / 32; w += gridDim.x * kBlock) solo_w[w] = 0u;
   // (two more ranges of words the preparation wants zeroed: the span plan's counters + window bytes, the degree-order work area)
-  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_a; w += gridDim.x * kBlock) zero_a[w] = 0u;
+  // (word 2 of the first range = "the V keys are table slots")
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_a; w += gridDim.x * kBlock) zero_a[w] = (w == 2 && vslot) ? 1u : 0u;
   for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_b; w += gridDim.x * kBlock) zero_b[w] = 0u;
   if (b >= bt.B) return;
   if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; solo[2 * (size_t)bt.B + b] = 0; }
@@ -637,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHisto
   if (lane == 0) {
     const int deg = (int)(e - s);
     keys[base + deg] = (uint32_t)(n_items + bt.iid[b]);       vals[base + deg] = (uint32_t)b;
-    keys[base + deg + 1] = (uint32_t)(2 * n_items + u);       vals[base + deg + 1] = (uint32_t)b;
+    keys[base + deg + 1] = (uint32_t)(2 * n_items) + (vslot ? vslot[b] : (uint32_t)u);       vals[base + deg + 1] = (uint32_t)b;
   }
 }
 
@@ -752,6 +774,28 @@ __global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_
     if (k == DRX_KEY_NONE || (k < n_items && !solo_w)) continue;
     const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
     if (k == prev || k == next) continue;            // (a neighbour blanked concurrently was a different key anyway)
+    const uint32_t b = vals_s[j];
+    if (k < n_items) { atomicOr(&solo_w[k >> 5], 1u << (k & 31)); solo_v[2 * (size_t)B + b] = 1; }
+    else if (k < 2 * n_items) solo_o[b] = 1;
+    else solo_v[b] = 1;
+    keys_s[j] = DRX_KEY_NONE;
+  }
+}
+
+// The span plan and the sole-toucher marks in ONE launch over the freshly sorted list (two launches cost the preparation — the
+// pipeline's bound once the training kernels got faster — a launch gap and 15 us): the first n_chunks threads plan their chunk, then
+// every thread marks its share of the touches.  The two do not disturb each other: a key that is blanked has one touch, a key whose
+// run the plan measures crosses a chunk border (>= 2 touches), and the plan's searches only test keys for equality with such a key.
+__global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, int n_chunks, int cpb,
+                                                       SpanPlan P, uint32_t n_items, int B, uint8_t *solo_v, uint8_t *solo_o,
+                                                       uint32_t *solo_w) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
+  for (int j = tid; j < T; j += gridDim.x * blockDim.x) {
+    const uint32_t k = keys_s[j];
+    if (k == DRX_KEY_NONE || (k < n_items && !solo_w)) continue;
+    const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
+    if (k == prev || k == next) continue;
     const uint32_t b = vals_s[j];
     if (k < n_items) { atomicOr(&solo_w[k >> 5], 1u << (k & 31)); solo_v[2 * (size_t)B + b] = 1; }
     else if (k < 2 * n_items) solo_o[b] = 1;
@@ -1220,6 +1264,8 @@ struct DirectPolicyT {
   const float *dz1;
   long long g2_off;
   const float *dz2;
+  // V keys of this list: 2N + user id, or — cnt_flags[2] != 0 — 2N + the user's slot in the batch's user table vtab (see k_user_slots)
+  const uint32_t *vtab, *cnt_flags;
   template <int G, int J>
   __device__ __forceinline__ void load(uint32_t key, uint32_t b, int lane, float4 (&row)[J], float &sc, float &coef) const {
     const uint32_t N = (uint32_t)P.n_items;
@@ -1230,6 +1276,8 @@ struct DirectPolicyT {
   }
   template <int G, int J>
   __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
+    const uint32_t N2 = 2u * (uint32_t)P.n_items;
+    if (key >= N2 && cnt_flags[2]) key = N2 + vtab[key - N2];          // slot -> user
     sparse_apply<G, J, KIND>(P, opt, B, key, lane, g, gs);
   }
 };
@@ -1436,6 +1484,9 @@ struct PrepBufs {
   uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo); then [B] "holds a marked W row"
   uint32_t *solo_w;             // [ceil(N/32)] one bit per item
   SpanPlan plan;                // chunk-crossing segments of the list (k_plan_spans)
+  uint32_t *vtab;               // [vt] the batch's user table (k_user_slots), part of the result: slot -> user id
+  uint32_t *vslot;              // [B] slot of every sample's user (work area)
+  int vt, bits_hashed;          // table entries (power of two >= 4B); key bits when the V keys are slots
   int32_t *order;               // [B] launch order of the forward kernel (k_degree_counts / k_degree_scatter)
   unsigned int *order_work;     // [512] bucket counts | running places (zeroed by k_sparse_touches)
   int n_chunks;
@@ -1459,12 +1510,17 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.plan.cnt = cv.take<uint32_t>(64);
   R.plan.ext = cv.take<uint8_t>(R.n_chunks);
   R.order = cv.take<int32_t>(B);
+  R.vt = 1;
+  while (R.vt < 4 * B) R.vt <<= 1;
+  R.vtab = cv.take<uint32_t>(R.vt);
+  R.bits_hashed = bits_for((uint64_t)2 * P.n_items + (uint64_t)R.vt + 1);
   R.result_bytes = align_up(cv.off, 256);
   R.keys = cv.take<uint32_t>(R.T);
   R.vals = cv.take<uint32_t>(R.T);
-  R.sort_bytes = sort_pairs_temp_bytes(R.T, R.bits);
+  R.sort_bytes = std::max(sort_pairs_temp_bytes(R.T, R.bits), sort_pairs_temp_bytes(R.T, R.bits_hashed));     // (11-bit digits need more)
   R.sort_temp = cv.take<char>(R.sort_bytes);
   R.order_work = cv.take<unsigned int>(512);
+  R.vslot = cv.take<uint32_t>(B);
   return R;
 }
 
@@ -1994,20 +2050,40 @@ static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t s
   hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
 }
 
-static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
-  const int gpb = kBlock / 16;
-  hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
-                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w, R.plan.cnt, plan_zero_words(R), R.order_work, 512);
-  // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
-  const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, true, st);
-  if (rc) return rc;
-  return plan_spans(p, R, st, true);
-}
-
 // W rows get sole-toucher marks when the caller asks for them (DRX_BATCH_MARK_W: worth it where a batch leaves most of its distinct
 // W rows with one touch — large catalogues; at MovieLens shapes every item collects hundreds of touches and nothing would be marked).
-// Rows of <= 16 floats are never marked (see mark_solo).
+// Rows of <= 16 floats are never marked (see prepare_impl).
 static bool mark_w_rows(const DrxCdaeParams *p, const DrxBatch *bt) { return (bt->flags & DRX_BATCH_MARK_W) != 0 && p->ld > 16; }
+
+static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
+                        bool with_marks = false) {
+  const int gpb = kBlock / 16;
+  // V keys = slots of the batch's user table: on request (DRX_BATCH_V_SLOTS).  Measured at 10 M users (r03l): the narrower key trades
+  // three 8-bit passes of the sort (3 x 60 us beside the training kernels) for two 11-bit ones (2 x 109 us) — a loss with this sort,
+  // whose ranking step costs one ballot per digit bit; kept for sorts / shapes where the pass count decides.
+  const bool hashed = (bt->flags & DRX_BATCH_V_SLOTS) != 0 && p->n_users > R.vt && R.bits_hashed < R.bits;
+  if (hashed) {
+    DRX_HIP(hipMemsetAsync(R.vtab, 0xFF, (size_t)R.vt * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_user_slots, dim3((bt->B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, bt->uid, bt->B, R.vtab, (uint32_t)(R.vt - 1),
+                       R.vslot);
+  }
+  hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
+                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w, R.plan.cnt, plan_zero_words(R), R.order_work, 512,
+                     hashed ? R.vslot : nullptr);
+  // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
+  const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, hashed ? R.bits_hashed : R.bits,
+                               true, st);
+  if (rc) return rc;
+  // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
+  // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
+  if (with_marks && p->ld > 16) {
+    const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
+    hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks, kSegBlock / pick_geom(p->ld).G,
+                       R.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, mark_w_rows(p, bt) ? R.solo_w : nullptr);
+    return DRX_OK;
+  }
+  return plan_spans(p, R, st, true);
+}
 
 // Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
 static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
@@ -2075,7 +2151,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   // (+ the bias update), with the policy type POLT (optimizer at run time, or Adagrad compiled in)
 #define REDUCE_AND_SPANS(G, J, POLT)                                                                                   \
   {                                                                                                                    \
-    POLT polk{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};                                        \
+    POLT polk{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2, R.vtab, R.plan.cnt};                    \
     BiasPartialExtra<G, J> bpx{p->ld, BA};                                                                             \
     BiasFinalExtra<G, J> bfx{*p, *opt, BA};                                                                            \
     const int cpb = kSegBlock / G;                                                                                     \
@@ -2152,9 +2228,7 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   Carver cp(prepared, prepared_bytes);
   PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
   if (!cp.ok()) return DRX_ESCRATCH;
-  rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream);
-  if (rc) return rc;
-  rc = mark_solo(p, bt, R, (hipStream_t)stream, true);
+  rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream, true);      // touches, sort, span plan + sole-toucher marks
   if (rc) return rc;
   order_by_degree(bt, R, (hipStream_t)stream, true);
   DRX_LAUNCH_CHECK();

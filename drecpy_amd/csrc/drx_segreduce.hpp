@@ -200,17 +200,15 @@ struct SpanShape {
 
 // One thread per chunk of the PRISTINE sorted list (before sole-toucher blanking): a chunk whose last key continues into the next
 // chunk and that is not itself the inside of that segment starts a span; the segment's end is found by binary search.
-template <int DUMMY = 0>
-__global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, SpanPlan P) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_chunks) return;
+__device__ __forceinline__ void plan_chunk(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, const SpanPlan &P, int g) {
   const int start = g * kChunk, end = min(T, start + kChunk);
   const uint32_t last = keys_s[end - 1];
   if (last == DRX_KEY_NONE || end >= T || keys_s[end] != last) return;
   const uint32_t first = keys_s[start], prev = start > 0 ? keys_s[start - 1] : DRX_KEY_NONE;
   if (first == last && prev == last) return;                     // inside a segment that began earlier
   // first position in [end, T) with another key.  The touches of a key are ONE run of the list (whether the list is sorted as a whole
-  // or assembled from sorted parts), so "key == last" is true up to the end of the run and false from there on.
+  // or assembled from sorted parts), so "key == last" is true up to the end of the run and false from there on.  (Keys that a
+  // concurrent sole-toucher pass blanks are never `last`: a key that crosses a chunk border has at least two touches.)
   int lo = end, hi = T;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -226,6 +224,14 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_c
   const uint2 d = make_uint2((uint32_t)g, m_in | (has_end << 31));
   if (SpanShape(d, cpb).total() <= kPlanShort) P.desc[atomicAdd(&P.cnt[0], 1u)] = d;
   else P.desc[n_chunks - 1 - (int)atomicAdd(&P.cnt[1], 1u)] = d;
+}
+
+// One thread per chunk of the sorted list: a chunk whose last key continues into the next chunk and that is not itself the inside of
+// that segment starts a span; the segment's end is found by binary search.
+template <int DUMMY = 0>
+__global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, SpanPlan P) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, g);
 }
 
 // LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the

@@ -90,6 +90,9 @@ typedef struct DrxBatch {
  * updates them itself — worth it where a batch leaves most of its distinct W rows with a single touch (large catalogues, long-tailed
  * popularity); prepare and step must see the same flag.  Without it only V / W2T rows are marked. */
 #define DRX_BATCH_MARK_W 1u
+/* The V keys of the touch list are slots of a per-batch table of the batch's users (4B entries, part of the prepared list) instead of
+ * user ids: a narrower sort key when n_users is far beyond the batch size.  Only where n_users > 4B; prepare and step must agree. */
+#define DRX_BATCH_V_SLOTS 2u
 
 typedef struct DrxOptim {
   int32_t kind;             /* DRX_OPT_* */

@@ -169,6 +169,41 @@ def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
 
 
 @pytest.mark.parametrize('prepared', [False, True])
+@pytest.mark.parametrize('K', [50, 128])
+def test_sparse_steps_with_many_more_users_than_triples(K, prepared):
+    """3000 users, 64 triples: the V keys of the touch list are slots of the batch's user table (4B = 256 entries; k_user_slots) instead
+    of user ids — a narrower key, one radix pass fewer at 10 M users — and the reduction maps a slot back to its user.  Users repeat
+    inside a batch (shared V rows go through the list) and across batches."""
+    U, N, B = 3000, 260, 64
+    eng, p, rng = _engine(U, N, K, seed=4)
+    eng.v_slots = True
+    indptr, indices = synth_history(rng, U, N, 9, zipf=1.1)
+    eng.set_history(indptr, indices)
+    eng.init_optimizer('adagrad', 0.05, 1e-3)
+    st = co.sparse_state(p, 'adagrad')
+    q = 0.2
+    qf = float(np.float32(q))
+    pool = rng.integers(0, U, size=200)
+    for step in range(8):
+        uids = np.concatenate([rng.integers(0, U, size=B - 12), rng.choice(pool[:5], size=12)])      # a few users several times
+        rng.shuffle(uids)
+        iids = rng.integers(0, N, size=B)
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        seed = 4242 + step
+        keep = np.concatenate([hash_u32(seed, np.full(keep_off[b + 1] - keep_off[b], b), np.arange(keep_off[b + 1] - keep_off[b])) >= q_threshold(q)
+                               for b in range(B)]).astype(np.uint8)
+        bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, 0.05, 1e-3, 'bce', 'adagrad')
+        lg = eng.step_sparse(step, bt, 'bce', want_loss=True, prepared=eng.prepare_sparse(bt) if prepared else None).cpu().numpy()
+        assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('prepared', [False, True])
 def test_sparse_long_histories_take_the_workgroup_path(prepared):
     """Mean history of ~60 items, 48 triples: the forward/backward runs one WORKGROUP per triple (k_sampled_fwd_bwd_wg: its
     groups split the history, partial bags summed in LDS) — same oracle, same tolerance."""
