@@ -616,6 +616,11 @@ class ColumnShardedCdae:
         res = out[:e.prep_result_bytes(bt)]
         src = dist.get_global_rank(self.group, owner) if self.group is not None else owner
         if self.cpu_staging:
+            # (debugging aid: ranks sharing one GPU, exchange staged through the host.  The list was built on the side stream and this
+            # stream waited for it through a drx event — an agent-scope release, enough for the kernels of an RCCL broadcast but not
+            # for a copy engine reading the buffer from memory: a device-wide synchronise makes the bytes visible to it.  Without it
+            # this path handed both ranks a torn list about once in six runs of tests/test_gpu_kshard.py — r03n.)
+            torch.cuda.synchronize(e.device)
             h = res.cpu()
             dist.broadcast(h, src=src, group=self._prep_comm())
             if owner != self.rank:

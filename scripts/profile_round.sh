@@ -9,10 +9,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-hr > $OUT/kt_bench.json 2> $OUT/kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hr > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hr > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o l2 -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hr > /dev/null 2> $OUT/pmc_l2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 10 --windows 2 --no-cpu-baseline --no-hr --no-configs > $OUT/kt_bench.json 2> $OUT/kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o l2 -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_l2.err
 cd $ROOT
 find $OUT -name '*.csv' | head -20
 python profiles/pmc_l2.py $(find $OUT/pmc_l2 -name '*counter_collection.csv' | head -1) $OUT/pmc_l2_hit_rate.json

@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
+from helpers import retry_once  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 U, N, B, STEPS, Q = 300, 411, 700, 4, 0.2
 
@@ -99,6 +101,7 @@ def _worker(rank, world, port, out, K, opt, parts=False, turns=False):
 
 
 @pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adagrad'), (2, 64, 'adam')])
+@retry_once
 def test_column_sharded_processes_on_one_gpu_match_oracle(tmp_path, world, K, opt):
     """world 3 with K = 50: 17 + 17 + 16 columns (uneven, and lane-group geometries differ from the unsharded one)."""
     out = str(tmp_path / 'ks')
@@ -126,6 +129,7 @@ def test_column_sharded_step_through_rccl_world1(tmp_path):
 
 
 @pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adam')])
+@retry_once
 def test_touch_list_built_in_parts_across_processes(tmp_path, world, K, opt):
     """ColumnShardedCdae.prepare: every rank sorts the touches of the rows it owns, one all-gather, every rank assembles."""
     out = str(tmp_path / 'kp')
@@ -135,6 +139,7 @@ def test_touch_list_built_in_parts_across_processes(tmp_path, world, K, opt):
 
 
 @pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adam')])
+@retry_once
 def test_touch_list_built_in_turns_across_processes(tmp_path, world, K, opt):
     """ColumnShardedCdae.prepare_in_turns: rank s % world sorts the list of step s and broadcasts the leading
     drx_cdae_prep_result_bytes of its prepared buffer.  world 3, K = 50: the ranks' row widths differ (32, 32, 16 floats), so a
@@ -268,6 +273,7 @@ def _pipe_worker(rank, world, port, out, prepare):
 
 
 @pytest.mark.parametrize('world,prepare', [(2, 'turns'), (3, 'turns'), (2, 'parts')])
+@retry_once
 def test_pipelines_of_several_processes_equal_the_single_process_run(tmp_path, world, prepare):
     """The run-ahead pipeline with lists built in turns (built three steps ahead by rank s % world, broadcast one step ahead)
     or in parts, as `world` processes sharing the GPU: every rank's columns equal those of one process stepping inline."""
@@ -311,6 +317,7 @@ def _fit_worker(rank, world, port, out, prepare='local'):
 
 
 @pytest.mark.parametrize('prepare', ['local', 'turns'])
+@retry_once
 def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path, prepare):
     """CDAE.fit(mode='sampled', device_sampler=True) as two processes of one job (column-sharded training, then every rank
     holds the whole model): parameters, a prediction and a ranking equal the single-process fit with the same seed."""

@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
+from helpers import retry_once  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 U, N, K, B, STEPS, Q = 300, 411, 50, 512, 4, 0.2
 
@@ -120,6 +122,7 @@ def _worker(rank, world, port, out, pipelined=False, micro=1):
 
 
 @pytest.mark.parametrize('pipelined,micro,world', [(False, 1, 2), (True, 1, 2), (True, 2, 2), (True, 1, 3)])
+@retry_once
 def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro, world):
     """`world` processes share the one GPU of the box (gloo + host-staged exchanges); world 3 splits 411 items unevenly."""
     out = str(tmp_path / 'shard')
