@@ -546,6 +546,11 @@ def run_columns(args, rank, world, dev, dist, debug_gloo, rccl1):
     return out
 
 
+def _trace(msg):
+    if os.environ.get('DRX_BENCH_TRACE'):
+        print(f'[bench {time.time():.3f}] {msg}', file=sys.stderr, flush=True)
+
+
 def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     """The single-GPU step (world 1) or the ROW-sharded layout (dist.ShardedCdae; world > 1 or --force-sharded).  Returns the line's
     dict on rank 0, None elsewhere."""
@@ -599,6 +604,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
             structs.append((bt, alive))
     rows_per_sample = kept_tot / (args.n_batches * B) + 2.0          # R: kept W rows + V row + W2T row
     setup_s = time.time() - t_setup
+    _trace('setup done')
 
     # The touch list of a batch (sorted row keys) does not depend on the parameters: it is prepared ahead on a side stream
     overlap = not args.no_overlap
@@ -665,10 +671,13 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         e.record(main)
     if overlap and pipe is None and spipe is None:
         prepare(0)
+    _trace('pipeline created')
     for s in range(args.warmup):
         run_step(s)
+    _trace('warm-up queued')
     win = Windows(args.steps, args.windows, 6, world, dist, dev)
     win.run(lambda i, es, last: run_step(args.warmup + i, events=es, last=last))
+    _trace('windows done')
     n_ranks = rccl_ranks(dist, dev, world, debug_gloo) if dist is not None else 1
     ph, n_timed = win.phase_means(5)
     step_s = win.median / args.steps
@@ -707,6 +716,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
             else:
                 u_, i_, _, ko_, seed_ = batches[(args.warmup + s_) % len(batches)]
             stats.append(batch_row_stats(indptr, indices, u_, i_, ko_, seed_, Q))
+        _trace('row statistics done')
         mean_st = {k_: float(np.mean([st[k_] for st in stats])) for k_ in stats[0]}
         solo_w_on = bool(eng._batch_flags(int(mean_st['history_items'])))      # W rows with one touch are updated by the forward kernel too
         bm = byte_model(mean_st, K, S_opt, fused_solo=overlap, fused_solo_w=solo_w_on, n_users=hi - lo, n_items=N)

@@ -143,6 +143,7 @@ SIGNATURES = {
     'drx_scatter_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'drx_scatter_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_batch_offsets': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_sumsq': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     'drx_rows_dot': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
@@ -219,6 +220,17 @@ SIGNATURES = {
     'drx_rng_corruption_keep': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                           C.c_double, C.c_void_p, C.c_void_p, C.c_int64]),
 }
+
+
+def batch_offsets(indptr, ids):
+    """int32 [B + 1] exclusive prefix of the CSR row lengths of the device ids (drx_batch_offsets; no torch arithmetic)."""
+    import torch
+    B = int(ids.numel())
+    off = torch.empty(B + 1, dtype=torch.int32, device=ids.device)
+    need = int(lib().drx_point_sample_scratch_bytes(B))
+    sc = torch.empty(need, dtype=torch.uint8, device=ids.device)
+    check(lib().drx_batch_offsets(ptr(indptr), ptr(ids), B, ptr(off), ptr(sc), need, stream_ptr(ids.device)), 'drx_batch_offsets')
+    return off
 
 
 def sumsq(tensors, device=None):

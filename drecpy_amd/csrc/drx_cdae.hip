@@ -596,6 +596,7 @@ struct SparseBufs {
   float *phead, *ptail;                       // [n_chunks, ld]
   float *phs, *pts;                           // [n_chunks] scalar (b2) partials
   float *pblock, *pbs;                        // [n_blocks, ld], [n_blocks]: partials of all-inner workgroups (k_seg_reduce_planned)
+  float *hot_part, *hot_ps;                   // [kMaxHot * kHotTiles, ld], [kMaxHot * kHotTiles]: (hot segment, sample tile) partials
   float *bpart;                               // [n_bpart, ld]
   const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row; solo_v + 2B:
                                               //   [B] sample b holds at least one W row that only it touches
@@ -975,8 +976,10 @@ template <int G, int J, int KIND = -1>
 __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
                                                             uint32_t qthr, int loss_kind, SparseBufs S) {
   const int lane = threadIdx.x % G;
-  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (b >= bt.B) return;
+  const int slot = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (slot >= bt.B) return;
+  const int32_t *const ord = S.order;
+  const int b = ord ? ord[slot] : slot;            // longest histories first, similar lengths side by side (k_degree_counts)
   float4 acc[J];
   DenseAux none{};
   gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
@@ -1421,7 +1424,8 @@ constexpr int kSmallBatch = 1024;    // at or below: one workgroup per batch row
 constexpr int kFewRows = 128;        // at or below: that workgroup has 1024 threads (fewer rows than CUs: spread each row wider)
 constexpr int kOutGrid = 512;        // persistent workgroups of k_out_dense (two per CU when LDS allows)
 constexpr int kSweepGrid = 1024;
-constexpr int kLongBlocks = 256, kShortBlocks = 1024;   // k_span_planned: workgroups striding over the long / the short spans
+constexpr int kLongBlocks = 256, kShortBlocks = 1024, kHotFinBlocks = 256;
+constexpr int kHotBlocks = 2048;     // workgroups of the hot-tiles role inside the reduction's launch (a multiple of 8: one share per XCD)   // k_span_planned: workgroups striding over the long / the short spans
 constexpr size_t kLdsBudget = 144 * 1024;
 
 struct DenseLayout {
@@ -1509,6 +1513,10 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.plan.desc = cv.take<uint2>(R.n_chunks);
   R.plan.cnt = cv.take<uint32_t>(64);
   R.plan.ext = cv.take<uint8_t>(R.n_chunks);
+  R.plan.hflag = cv.take<uint8_t>(R.n_chunks);
+  R.plan.hot = cv.take<uint4>(kMaxHot);
+  R.plan.hot_bounds = cv.take<uint32_t>((size_t)kMaxHot * (kHotTiles + 1));
+  R.plan.hot_pref = cv.take<uint32_t>(kMaxHot + 1);
   R.order = cv.take<int32_t>(B);
   R.vt = 1;
   while (R.vt < 4 * B) R.vt <<= 1;
@@ -1542,6 +1550,11 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
     const int n_blocks = (S.n_chunks + cpb - 1) / cpb;
     S.pblock = cv.take<float>((size_t)n_blocks * P.ld);
     S.pbs = cv.take<float>(n_blocks);
+    // (a hot segment has at least max(32, T / kMaxHot) touches — plan_hot_min —; a tile's share of it is cut into hot_slices(len) slices:
+    // one partial row per (segment, tile, slice))
+    const size_t n_hp = ((size_t)S.T / (kHotTiles * kHotSlice) + 1 + (size_t)std::min<long long>(kMaxHot, (long long)S.T / 32 + 1)) * kHotTiles;
+    S.hot_part = cv.take<float>(n_hp * P.ld);
+    S.hot_ps = cv.take<float>(n_hp);
   }
   S.bpart = cv.take<float>((size_t)S.n_bpart * (P.ld + 1));     // partial rows + per-block loss partials
   return S;
@@ -2030,15 +2043,20 @@ int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHis
   return rc;
 }
 
-// plan.cnt (64 words) and plan.ext (n_chunks bytes) are adjacent 256-byte-aligned allocations: one range of words to zero
-static int plan_zero_words(const PrepBufs &R) { return (int)(((const char *)R.plan.ext + R.n_chunks - (const char *)R.plan.cnt + 3) / 4); }
+// plan.cnt (64 words), plan.ext and plan.hflag (n_chunks bytes each) are consecutive 256-byte-aligned allocations: one range of words to zero
+static int plan_zero_words(const PrepBufs &R) { return (int)(((const char *)R.plan.hflag + R.n_chunks - (const char *)R.plan.cnt + 3) / 4); }
 
 // The chunk-crossing segments of a sorted list, short ones and long ones (drx_segreduce.hpp, planned variant).  On the pristine list:
 // BEFORE the sole-toucher marks blank any key.
-static int plan_spans(const DrxCdaeParams *p, const PrepBufs &R, hipStream_t st, bool cleared) {
+static int plan_spans(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R0, hipStream_t st, bool cleared) {
+  PrepBufs R = R0;
+  R.plan.hot_min = plan_hot_min(R.T, bt->flags);
   if (!cleared) DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, (size_t)plan_zero_words(R) * 4, st));     // (prepare_impl's touch kernel clears them)
   hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.T, R.n_chunks,
                      kSegBlock / pick_geom(p->ld).G, R.plan);
+  if (R.plan.hot_min != 0x7FFFFFFF)
+    hipLaunchKernelGGL(k_hot_bounds, dim3((kMaxHot * (kHotTiles + 1) + 255) / 256), dim3(256), 0, st, R.vals_s, R.plan,
+                       (bt->B + kHotTiles - 1) / kHotTiles);
   return DRX_OK;
 }
 
@@ -2078,11 +2096,16 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
   // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
   if (with_marks && p->ld > 16) {
     const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
+    SpanPlan plan = R.plan;
+    plan.hot_min = plan_hot_min(R.T, bt->flags);
     hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks, kSegBlock / pick_geom(p->ld).G,
-                       R.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, mark_w_rows(p, bt) ? R.solo_w : nullptr);
+                       plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, mark_w_rows(p, bt) ? R.solo_w : nullptr);
+    if (plan.hot_min != 0x7FFFFFFF)
+      hipLaunchKernelGGL(k_hot_bounds, dim3((kMaxHot * (kHotTiles + 1) + 255) / 256), dim3(256), 0, st, R.vals_s, plan,
+                         (bt->B + kHotTiles - 1) / kHotTiles);
     return DRX_OK;
   }
-  return plan_spans(p, R, st, true);
+  return plan_spans(p, bt, R, st, true);
 }
 
 // Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
@@ -2136,7 +2159,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
 #ifdef DRX_STAMPS
   S.stamps = SB.stamps = h_stamps;
 #endif
-  PlanBufs PB{S.pblock, S.pbs};
+  PlanBufs PB{S.pblock, S.pbs, S.hot_part, S.hot_ps, (bt->B + kHotTiles - 1) / kHotTiles};
+  const int hot_blocks = (bt->flags >> 16) ? kHotBlocks : 0, hot_fin_blocks = (bt->flags >> 16) ? kHotFinBlocks : 0;
   // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
   const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
@@ -2146,7 +2170,11 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
-  static const bool use_pf = [] { const char *e = getenv("DRX_FWD_PF"); return !e || atoi(e) != 0; }();      // (A/B switch)
+  // the LDS-prefetch forward kernel (k_sampled_fwd_bwd_pf) is OPT-IN (DRX_FWD_PF=1): it is 3 us (2 %) faster than the plain kernel, but
+  // runs with it faulted about once in eight under rocprofv3 --pmc and never without it (r03r: 5 faults in ~20 runs against 0 in 17) —
+  // not understood (its ISA and its results check out; LDS-DMA in flight across a wave save / restore is the suspicion), so the plain
+  // kernel, with the same launch order, is the default
+  static const bool use_pf = [] { const char *e = getenv("DRX_FWD_PF"); return e && atoi(e) != 0; }();
   // the segmented reduction (+ the bias column sums as extra workgroups) and the ONE launch that combines the chunk-crossing segments
   // (+ the bias update), with the policy type POLT (optimizer at run time, or Adagrad compiled in)
 #define REDUCE_AND_SPANS(G, J, POLT)                                                                                   \
@@ -2155,20 +2183,20 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     BiasPartialExtra<G, J> bpx{p->ld, BA};                                                                             \
     BiasFinalExtra<G, J> bfx{*p, *opt, BA};                                                                            \
     const int cpb = kSegBlock / G;                                                                                     \
-    const dim3 rgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                                          \
+    const dim3 rgrid(n_bpart + hot_blocks + (S.n_chunks + cpb - 1) / cpb);                                             \
     const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
     if (long_segments)                                                                                                 \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
-                         R.plan.ext, polk, n_bpart, bpx);                                                              \
+                         R.plan, polk, n_bpart, hot_blocks, bpx);                                                      \
     else                                                                                                               \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
-                         R.plan.ext, polk, n_bpart, bpx);                                                              \
+                         R.plan, polk, n_bpart, hot_blocks, bpx);                                                      \
     EV(3);                                                                                                             \
     if (lds_b > 48 * 1024)                                                                                             \
       DRX_HIP(hipFuncSetAttribute((const void *)k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>,                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                            \
-    hipLaunchKernelGGL((k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>), dim3(kLongBlocks + kShortBlocks + 1), dim3(kFixBlock), lds_b, \
-                       st, SB, PB, R.plan, polk, kLongBlocks, kShortBlocks, bfx);                                      \
+    hipLaunchKernelGGL((k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>), dim3(kLongBlocks + kShortBlocks + hot_fin_blocks + 1), \
+                       dim3(kFixBlock), lds_b, st, SB, PB, R.plan, polk, kLongBlocks, kShortBlocks, hot_fin_blocks, bfx); \
     EV(4);                                                                                                             \
     EV(5);                                                                                                             \
   }
@@ -2308,7 +2336,7 @@ int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt,
   const PartOut o = part_out_layout(*p, bt->B, bt->n_touch_slots, parts);
   hipLaunchKernelGGL(k_assemble_parts, dim3(2048), dim3(256), 0, st, (const char *)all_parts, o.bytes, o.runs_off, o.vals_off, parts, R.T,
                      R.keys_s, R.vals_s, overflow_out);
-  rc = plan_spans(p, R, st, false);
+  rc = plan_spans(p, bt, R, st, false);
   if (rc) return rc;
   rc = mark_solo(p, bt, R, st, false);
   if (rc) return rc;

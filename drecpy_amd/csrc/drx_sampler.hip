@@ -137,6 +137,13 @@ __global__ __launch_bounds__(1024) void k_scan_degrees(const int32_t *__restrict
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__global__ __launch_bounds__(kBlock) void k_row_lengths(const int64_t *__restrict__ indptr, const int32_t *__restrict__ ids, int B,
+                                                        int32_t *__restrict__ deg, int32_t *__restrict__ off) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b == 0) off[0] = 0;
+  if (b < B) deg[b] = (int32_t)(indptr[ids[b] + 1] - indptr[ids[b]]);
+}
+
 }  // namespace drx
 
 extern "C" size_t drx_point_sample_scratch_bytes(int32_t B) {
@@ -164,6 +171,29 @@ extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t
     hipLaunchKernelGGL(k_deg_apply, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum, keep_off);
   } else {
     hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, keep_off, (unsigned long long *)host_mailbox, tag);
+  }
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+/* off[0] = 0, off[b + 1] = sum_{b' <= b} (indptr[ids[b'] + 1] - indptr[ids[b']]): the keep_off of a batch of users (DrxBatch) or the touch
+ * offsets of a batch of CSR rows, from device ids — what the host code otherwise asked torch.cumsum for.  scratch: drx_point_sample_scratch_bytes(B). */
+extern "C" int drx_batch_offsets(const int64_t *indptr, const int32_t *ids, int32_t B, int32_t *off, void *scratch, size_t scratch_bytes,
+                                 void *stream) {
+  using namespace drx;
+  if (!indptr || !ids || !off || !scratch || B < 1) return DRX_EINVAL;
+  if (scratch_bytes < drx_point_sample_scratch_bytes(B)) return DRX_ESCRATCH;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *deg = (int32_t *)scratch;
+  hipLaunchKernelGGL(k_row_lengths, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, indptr, ids, B, deg, off);
+  const int n_tiles = (B + kDegTile - 1) / kDegTile;
+  if (n_tiles <= 64) {
+    int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
+    hipLaunchKernelGGL(k_deg_tile_sums, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum);
+    hipLaunchKernelGGL(k_deg_spine, dim3(1), dim3(64), 0, st, tsum, n_tiles, (unsigned long long *)nullptr, 0u);
+    hipLaunchKernelGGL(k_deg_apply, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum, off);
+  } else {
+    hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, off, (unsigned long long *)nullptr, 0u);
   }
   DRX_LAUNCH_CHECK();
   return DRX_OK;

@@ -50,6 +50,7 @@ class CdaeEngine:
         # 'auto' (tests, experiments): where a batch leaves most of its distinct W rows with one touch — at most 4 history slots per
         # item of the catalogue — with Adagrad, on rows of 17..256 floats; True: always.  DRX_SOLO_W=0/1 in the environment overrides.
         self.mark_w_rows = False
+        self.hot_min = 0               # touches from which a segment is summed tile by tile (0 = the library's default; tests lower it)
         self.v_slots = False           # DRX_BATCH_V_SLOTS: V keys as slots of a per-batch user table (narrower sort key; off: r03l measurement)
 
     # ---- parameters -------------------------------------------------------------------------
@@ -292,7 +293,7 @@ class CdaeEngine:
 
     def _batch_flags(self, n_touch_slots):
         import os
-        vs = _lib.BATCH_V_SLOTS if self.v_slots else 0
+        vs = (_lib.BATCH_V_SLOTS if self.v_slots else 0) | ((int(self.hot_min) & 0xFFFF) << 16)
         forced = os.environ.get('DRX_SOLO_W')
         if forced is not None:
             return (_lib.BATCH_MARK_W if forced == '1' else 0) | vs
@@ -308,9 +309,7 @@ class CdaeEngine:
         uid = self._dev(uid, torch.int32)
         B = int(uid.numel())
         if keep_off is None:
-            deg = (self.hist_indptr[uid.long() + 1] - self.hist_indptr[uid.long()])
-            keep_off = torch.zeros(B + 1, dtype=torch.int32, device=self.device)
-            keep_off[1:] = torch.cumsum(deg, 0).to(torch.int32)
+            keep_off = _lib.batch_offsets(self.hist_indptr, uid)
         else:
             keep_off = self._dev(keep_off, torch.int32)
         if n_touch_slots is None:

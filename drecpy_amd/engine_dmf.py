@@ -162,9 +162,7 @@ class DmfEngine:
         return A
 
     def _offsets(self, ids, indptr):
-        deg = indptr[ids.long() + 1] - indptr[ids.long()]
-        off = torch.zeros(ids.numel() + 1, dtype=torch.int32, device=self.device)
-        off[1:] = torch.cumsum(deg, 0).to(torch.int32)
+        off = _lib.batch_offsets(indptr, ids if ids.dtype == torch.int32 else ids.to(torch.int32))
         return off, int(off[-1].item())
 
     def _scatter(self, keys, T, src, src_index, coef, ld, n_rows, out):

@@ -93,6 +93,9 @@ typedef struct DrxBatch {
 /* The V keys of the touch list are slots of a per-batch table of the batch's users (4B entries, part of the prepared list) instead of
  * user ids: a narrower sort key when n_users is far beyond the batch size.  Only where n_users > 4B; prepare and step must agree. */
 #define DRX_BATCH_V_SLOTS 2u
+/* bits 16..31: touches from which a segment of the list counts as HOT (0 = none, the default; otherwise at least 32 and at least list
+ * length / 1024): hot segments are summed sample tile by sample tile on the XCD that holds the tile's gradient rows
+ * (csrc/drx_segreduce.hpp, hot_tiles_body).  Off by default: measured slower end to end. */
 
 typedef struct DrxOptim {
   int32_t kind;             /* DRX_OPT_* */
@@ -169,6 +172,10 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
 int drx_cdae_step_sparse_prepared(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
                                   int32_t loss_kind, const void *prepared, size_t prepared_bytes, void *scratch,
                                   size_t scratch_bytes, float *loss_out, void *const *events, void *stream);
+
+/* off[0] = 0, off[b + 1] = sum_{b' <= b} (indptr[ids[b'] + 1] - indptr[ids[b']]) for device ids: the keep_off of a batch of users (DrxBatch)
+ * or the touch offsets of a batch of CSR rows.  scratch: drx_point_sample_scratch_bytes(B). */
+int drx_batch_offsets(const int64_t *indptr, const int32_t *ids, int32_t B, int32_t *off, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- device-side point sampler (throughput mode; distribution of point_sampler.py:44-61) ------------
  * Draws B triples with a counter-based generator keyed by (seed, b): negatives with probability

@@ -204,6 +204,40 @@ def test_sparse_steps_with_many_more_users_than_triples(K, prepared):
 
 
 @pytest.mark.parametrize('prepared', [False, True])
+@pytest.mark.parametrize('K,opt', [(128, 'adagrad'), (50, 'adam'), (16, 'adagrad')])
+def test_sparse_steps_with_hot_segments_summed_tile_by_tile(K, opt, prepared):
+    """60 items under a steep Zipf law, 768 triples: most rows collect hundreds of touches.  With the hot threshold lowered to 32 touches
+    (upper half of DrxBatch.flags) their segments take the hot path — (segment, sample tile) partial sums by the hot-tiles role of the
+    reduction's launch, combined in tile order by the span launch — while the short ones stay with the chunk windows: same oracle."""
+    U, N, B = 400, 60, 768
+    eng, p, rng = _engine(U, N, K, seed=11)
+    eng.hot_min = 32
+    indptr, indices = synth_history(rng, U, N, 12, zipf=1.4)
+    eng.set_history(indptr, indices)
+    lr = 1e-3 if opt == 'adam' else 0.05
+    eng.init_optimizer(opt, lr, 1e-3)
+    st = co.sparse_state(p, opt)
+    q = 0.2
+    qf = float(np.float32(q))
+    for step in range(5):
+        uids = rng.integers(0, U, size=B)
+        iids = np.minimum((rng.pareto(1.2, size=B)).astype(np.int64), N - 1)          # hot OUTPUT rows too
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        seed = 900 + step
+        keep = np.concatenate([hash_u32(seed, np.full(keep_off[b + 1] - keep_off[b], b), np.arange(keep_off[b + 1] - keep_off[b])) >= q_threshold(q)
+                               for b in range(B)]).astype(np.uint8)
+        bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, lr, 1e-3, 'bce', opt)
+        lg = eng.step_sparse(step, bt, 'bce', want_loss=True, prepared=eng.prepare_sparse(bt) if prepared else None).cpu().numpy()
+        assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize('prepared', [False, True])
 def test_sparse_long_histories_take_the_workgroup_path(prepared):
     """Mean history of ~60 items, 48 triples: the forward/backward runs one WORKGROUP per triple (k_sampled_fwd_bwd_wg: its
     groups split the history, partial bags summed in LDS) — same oracle, same tolerance."""
