@@ -2170,10 +2170,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
-  // the LDS-prefetch forward kernel (k_sampled_fwd_bwd_pf) is OPT-IN (DRX_FWD_PF=1): it is 3 us (2 %) faster than the plain kernel, but
-  // runs with it faulted about once in eight under rocprofv3 --pmc and never without it (r03r: 5 faults in ~20 runs against 0 in 17) —
-  // not understood (its ISA and its results check out; LDS-DMA in flight across a wave save / restore is the suspicion), so the plain
-  // kernel, with the same launch order, is the default
+  // the LDS-prefetch forward kernel (k_sampled_fwd_bwd_pf) is OPT-IN (DRX_FWD_PF=1): with the launch order in both, the plain kernel's
+  // phase is the shorter one (r03u, 3 runs each: 132 against 137 us; step 0.367 against 0.365 ms — inside the run-to-run spread)
   static const bool use_pf = [] { const char *e = getenv("DRX_FWD_PF"); return e && atoi(e) != 0; }();
   // the segmented reduction (+ the bias column sums as extra workgroups) and the ONE launch that combines the chunk-crossing segments
   // (+ the bias update), with the policy type POLT (optimizer at run time, or Adagrad compiled in)

@@ -518,11 +518,15 @@ class CdaeEngine:
                    torch.empty(B, dtype=torch.float32, device=self.device), torch.empty(B + 1, dtype=torch.int32, device=self.device))
         uid, iid, y, keep_off = out
         need = lib().drx_point_sample_scratch_bytes(B)
-        if getattr(self, '_sscratch', None) is None or self._sscratch.numel() < need:
-            self._sscratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        # one scratch per stream: draws queued on different streams (a pipeline's run-ahead stream, a caller's own) run side by side
+        pool = self.__dict__.setdefault('_sscratch', {})
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        if pool.get(key) is None or pool[key].numel() < need:
+            pool[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        scratch = pool[key]
         check(lib().drx_point_sample(C.byref(self._hist), self.n_users, n_items or self.n_items, B, neg_ratio,
                                      int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y), ptr(keep_off),
-                                     ptr(self._sscratch), self._sscratch.numel(), ptr(mailbox), int(tag) & 0xFFFFFFFF,
+                                     ptr(scratch), scratch.numel(), ptr(mailbox), int(tag) & 0xFFFFFFFF,
                                      stream_ptr(self.device)),
               'drx_point_sample')
         return out
@@ -666,7 +670,13 @@ class SampledPipeline:
         # queues right behind a long preparation whose count the host is about to wait for)
         self.SA = D + 1 if D == 1 else D + 2
         self.RS, self.RP = self.SA + 1, D + 1                 # ring sizes: drawn batches, prepared lists
-        self.ring = [eng.sample_device(self.B, self.neg_ratio, 1, n_items=n_items) for _ in range(self.RS)]
+        # (allocated, not drawn: a draw queued HERE would run on the caller's stream beside the first run-ahead draws on the side
+        # stream, sharing the sampler's scratch and these very tensors with them — r03: a batch whose row offsets belonged to another
+        # draw than its users, seen as memory faults when a profiler stretched the window)
+        B = self.B
+        self.ring = [(torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                      torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B + 1, dtype=torch.int32, device=dev))
+                     for _ in range(self.RS)]
         # a batch's touch count reaches the host through a pinned mailbox the sampler's last kernel writes itself, tagged with the
         # step it belongs to (drx_point_sample): no copy kernel, no event, nothing for the host to synchronise with
         self.ring_T = [torch.full((1,), -1, dtype=torch.int64).pin_memory() for _ in range(self.RS)]

@@ -80,12 +80,17 @@ def x_tilde(t, kept, q, dtype):
 
 def retry_once(fn):
     """For the tests that run N ranks as N PROCESSES TIME-SHARING THE ONE GPU of the box (a debugging configuration: gloo, exchanges
-    staged through the host).  Round 3 saw them fail about once in 40 runs — a torn list or a mismatch in one rank — in a way that
-    single-process runs (150 repetitions) and the round-2 sources (32) did not reproduce and that blocking launches hide; the cause
-    was not found.  One repetition keeps such a run from hiding every other test behind `-x`; a real defect
-    fails twice."""
+    staged through the host).  Round 3 saw them fail about once in 40 runs — a torn list or a mismatch in one rank.  The cause found
+    late in the round: SampledPipeline drew its ring's placeholder batches on the caller's stream while the first run-ahead draws ran
+    on the side stream, sharing the sampler's scratch and the ring tensors (engine.py); 54 repetitions without
+    the retry (DRX_TEST_NO_RETRY=1) have been clean since.  The retry stays as a guard for this time-shared configuration: one
+    repetition keeps a scheduling accident from hiding every other test behind `-x`; a real defect fails twice."""
     import functools
+    import os
     import time
+
+    if os.environ.get('DRX_TEST_NO_RETRY'):         # (flake-rate measurements)
+        return fn
 
     @functools.wraps(fn)
     def wrapper(*a, **k):
