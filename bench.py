@@ -626,8 +626,18 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     def batch_of(s):
         return structs[s % len(structs)][0]
 
+    prep_cache = {} if os.environ.get('DRX_BENCH_CACHE_PREP') == '1' else None     # diagnostic (with --presampled): every list built once
+
     def prepare(s):
         bt = batch_of(s)
+        if prep_cache is not None:
+            j = s % len(structs)
+            if j not in prep_cache:
+                with torch.cuda.stream(side):
+                    prep_cache[j] = eng.prepare_sparse(bt, None)
+            prep_bufs[s % 2] = prep_cache[j]
+            prep_done[s % 2].record(side)
+            return
         side.wait_event(step_done[s % 2])            # the buffer's previous user (step s-2) must be finished
         with torch.cuda.stream(side):
             prep_bufs[s % 2] = eng.prepare_sparse(bt, prep_bufs[s % 2])

@@ -3,12 +3,24 @@
 // One wavefront per sample, lane c = embedding channel (d <= 64): the L item rows and the user row are single
 // coalesced row reads; the vertical conv (caser.py:53,103 — kernel [L,d,n_v], it sums over d), the L horizontal convs
 // with relu + max over time (caser.py:55-58,106-108), dense_0 (caser.py:63,114) and the T' target dots
-// (caser.py:115-120) are channel-parallel FMAs followed by wave reductions.  The gradients of the small weights are
-// accumulated per workgroup in LDS by their owning lane (no atomics, fixed sample order) and reduced over workgroups
-// in a second, ordered pass; the gradients of the embedding lookups leave as one row per lookup for
-// drx_scatter_rows.  Small weights are stored channel-fastest ([s][f][c]) so that every lane reads its own column.
+// (caser.py:115-120) are channel-parallel FMAs followed by wave reductions.  A workgroup keeps a copy of the small weights
+// in LDS (channel-fastest, [s][f][c]: every lane reads its own column); their gradients are summed per workgroup in
+// registers, unit by unit, in sample order (no atomics) and reduced over workgroups in a second, ordered pass; the
+// gradients of the embedding lookups leave as one row per lookup for drx_rows_csr_adam.
 #include "drx_common.hpp"
 #include "drx_rows.hpp"
+
+#ifdef DRX_STAMPS
+static unsigned long long *h_caser_stamps = nullptr;       // device buffer [B x 16] (diagnostic builds: scripts/stamps_caser.py)
+extern "C" int drx_debug_set_caser_stamps(unsigned long long *buf) { h_caser_stamps = buf; return 0; }
+#define CASER_STAMP_ARG , unsigned long long *stamps
+#define CASER_STAMP_PASS , h_caser_stamps
+#define CSTAMP(i) DRX_STAMP(stamps, b, i, c)
+#else
+#define CASER_STAMP_ARG
+#define CASER_STAMP_PASS
+#define CSTAMP(i) do { } while (0)
+#endif
 
 namespace drx {
 
@@ -34,16 +46,34 @@ __device__ __forceinline__ float reduce16(const float (&v)[16], int lane) {
   return d;
 }
 
+// The same for 8 values (10 shuffles): afterwards lane l holds the wave total of v[slot8(l)] (eight lanes per value); lane8(j) is
+// the first lane that holds value j.
+__device__ __forceinline__ int slot8(int lane) { return ((lane >> 5) & 1) << 2 | ((lane >> 4) & 1) << 1 | ((lane >> 3) & 1); }
+__device__ __forceinline__ constexpr int lane8(int j) { return ((j >> 2) & 1) << 5 | ((j >> 1) & 1) << 4 | (j & 1) << 3; }
+__device__ __forceinline__ float reduce8(const float (&v)[8], int lane) {
+  float a[4], b[2];
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] = (h5 ? v[4 + k] : v[k]) + __shfl_xor(h5 ? v[k] : v[4 + k], 32);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) b[k] = (h4 ? a[2 + k] : a[k]) + __shfl_xor(h4 ? a[k] : a[2 + k], 16);
+  float d = (h3 ? b[1] : b[0]) + __shfl_xor(h3 ? b[0] : b[1], 8);
+  d += __shfl_xor(d, 4);
+  d += __shfl_xor(d, 2);
+  d += __shfl_xor(d, 1);
+  return d;
+}
+
+__device__ __forceinline__ float lane_f(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
+
 struct CaserLds {
-  float *gsw;     // [n_small] gradient accumulators of the small weights
   float *E;       // [L][64] item rows of the current sample
-  float *dE;      // [L][64]
   float *x;       // [nx] concat(out_v, out_h) before dropout
   float *xd;      // [nx] after dropout
   float *pre;     // [nx] pre-activation at the arg-max step (horizontal convs)
   float *dx;      // [nx]
   int *arg;       // [nx]
-  float *dz0s;    // [64] dense_0's pre-activation gradient of the sample (read by the accumulator owners)
+  float *dz0s;    // [64] dense_0's pre-activation gradient of the sample (read by the accumulating waves)
 };
 
 // act_h / act_mlp of caser.py:29-30 (Keras activation names): value and derivative at pre-activation v (a = act(v)).
@@ -64,22 +94,48 @@ __device__ __forceinline__ float act_df(int kind, float v) {
   }
 }
 
-// A workgroup is W waves, one sample per wave and round, sharing ONE set of small-weight gradient accumulators in LDS (72 KB at the
-// reference configuration: with a private copy per wave only two waves fit a CU and the chip idles — 0.74 ms at B = 4096).  Forward
-// and backward of the W samples run side by side in per-wave scratch; afterwards the waves add their weight-gradient contributions
-// to the shared accumulators ONE AFTER THE OTHER, in sample order (a barrier between turns): no atomics, and the order of every
-// sum is fixed by the batch alone.
+__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+
+// The NT tap rows of one horizontal (height, filter) pair: sum over the round's samples t of E_t[arg_t + s][c] * dc_t, samples in
+// order; lane t holds dc_t / arg_t (dcl / tal).  g = this lane's slot of tap 0 in the workgroup's partial sums, taps `tap` floats apart.
+template <int NT>
+__device__ __forceinline__ void pair_rows(float *g, int tap, bool first, bool wr, const float *sc /* scratch0 + c */, int per_wave, int nT,
+                                          float dcl, int tal) {
+  float acc[NT];
+#pragma unroll
+  for (int s2 = 0; s2 < NT; ++s2) acc[s2] = (first || !wr) ? 0.f : g[s2 * tap];
+#pragma unroll 4
+  for (int t = 0; t < nT; ++t) {
+    const float dc = lane_f(dcl, t);
+    const float *const Et = sc + (size_t)t * per_wave + __builtin_amdgcn_readlane(tal, t) * 64;
+#pragma unroll
+    for (int s2 = 0; s2 < NT; ++s2) acc[s2] = fmaf(Et[s2 * 64], dc, acc[s2]);
+  }
+  if (wr) {
+#pragma unroll
+    for (int s2 = 0; s2 < NT; ++s2) g[s2 * tap] = acc[s2];
+  }
+}
+
+// A workgroup is W waves, one sample per wave and round.  r03 (phase stamps, scripts/stamps_caser.py: a sample lived 163 us, 44 of them
+// in the horizontal convolutions' 560 weight loads from global memory, 46 in turn-taking over shared LDS gradient accumulators, 24 in
+// the chain of LDS read-modify-writes of the horizontal backward): the workgroup now keeps a COPY OF THE SMALL WEIGHTS in LDS where it
+// kept their gradient accumulators (same size), every weight read of the forward and backward passes is an LDS read of the lane's own
+// column, the item rows' gradients live in registers, and the small-weight gradients are summed by UNIT — a dense_0 row, a vertical
+// filter row, a horizontal (height, filter) pair with its taps, 64 bias entries — each unit by one wave (unit % W), in registers, over
+// the W samples of the round in sample order, out of the samples' scratch: no atomics, no shared accumulator, every sum in the order
+// of the batch (bit for bit the sums of the turn-taking version).  Partial sums of a workgroup go straight to gsw_part[block].
 template <bool TRAIN>
-__global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) {
+__global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A CASER_STAMP_ARG) {
   extern __shared__ __align__(16) float lds[];
-  const int c = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
-  const int L = D.L, d = D.d, nx = D.n_v + D.L * D.n_h;
-  const int per_wave = 2 * L * 64 + 5 * nx + 64;
+  const int c = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), W = blockDim.x >> 6;
+  const int L = D.L, d = D.d, ld = D.ld, nx = D.n_v + D.L * D.n_h;
+  const int per_wave = L * 64 + 5 * nx + 64;
+  float *const wl = lds;                                              // [n_small] small weights, then 64 zeros (a row read runs 64 wide)
+  float *const scratch0 = lds + D.n_small + 64;
   CaserLds S;
-  S.gsw = lds;
-  float *q = lds + (TRAIN ? D.n_small : 0) + (size_t)w * per_wave;
+  float *q = scratch0 + (size_t)w * per_wave;
   S.E = q; q += L * 64;
-  S.dE = q; q += L * 64;
   S.x = q; q += nx;
   S.xd = q; q += nx;
   S.pre = q; q += nx;
@@ -87,11 +143,10 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
   S.arg = reinterpret_cast<int *>(q); q += nx;
   S.dz0s = q;
   __shared__ float wloss[16];
-  const float *sw = A.sw;
-  if (TRAIN) {
-    for (int i = threadIdx.x; i < D.n_small; i += blockDim.x) S.gsw[i] = 0.f;
-    __syncthreads();
-  }
+  for (int i = threadIdx.x * 4; i < D.n_small; i += blockDim.x * 4)  // (every segment of sw is a multiple of 4 floats long)
+    *reinterpret_cast<float4 *>(wl + i) = *reinterpret_cast<const float4 *>(A.sw + i);
+  if (threadIdx.x < 64) wl[D.n_small + threadIdx.x] = 0.f;
+  __syncthreads();
   float loss_acc = 0.f;
   const bool live = c < d;
   const float inv_bt = 1.0f / ((float)A.B * (float)D.Tp);
@@ -104,45 +159,63 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
     const bool has = b < A.B;
     float dz0 = 0.f;
     if (has) {
-    // ---- 1. embeddings ---------------------------------------------------------------------------------------------
-    for (int t = 0; t < L; ++t) {
-      const int n = A.before[b * L + t];
-      S.E[t * 64 + c] = live ? A.item_emb[(size_t)n * D.ld + c] : 0.f;
-      S.dE[t * 64 + c] = 0.f;
+    CSTAMP(0);
+    // ---- 1. embeddings: the L row reads in flight together ---------------------------------------------------------------------
+    {
+      const int mine = c < L ? A.before[b * L + c] : 0;
+      float e[kCaserMaxL];
+#pragma unroll
+      for (int t = 0; t < kCaserMaxL; ++t) {
+        const int n = __shfl(mine, t);
+        e[t] = (t < L && live) ? A.item_emb[(size_t)n * ld + c] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < kCaserMaxL; ++t)
+        if (t < L) S.E[t * 64 + c] = e[t];
     }
     const int u = A.uid[b];
-    const float pu = live ? A.user_emb[(size_t)u * D.ld + c] : 0.f;
+    const float pu = live ? A.user_emb[(size_t)u * ld + c] : 0.f;
     wave_lds_sync();
-    // ---- 2. vertical conv ------------------------------------------------------------------------------------------
+    CSTAMP(1);
+    // ---- 2. vertical conv (dead lanes hold E = 0: whatever they read beside a weight row adds nothing) -------------------------
     for (int f = 0; f < D.n_v; ++f) {
       float part = 0.f;
-      for (int t = 0; t < L; ++t) part = fmaf(S.E[t * 64 + c], live ? sw[D.off_kv + (t * D.n_v + f) * D.ld + c] : 0.f, part);
-      const float v = wave_sum(part) + sw[D.off_bv + f];
+      for (int t = 0; t < L; ++t) part = fmaf(S.E[t * 64 + c], wl[D.off_kv + (t * D.n_v + f) * ld + c], part);
+      const float v = wave_sum(part) + wl[D.off_bv + f];
       if (c == 0) { S.x[f] = v; S.pre[f] = v; S.arg[f] = 0; }
     }
+    CSTAMP(2);
     // ---- 3. horizontal convs + act_h + max over time -------------------------------------------------------------------
-    // 16 filters at a time: their (i+1) x 16 kernel values of this channel are requested together, the 16 channel sums
-    // leave through one reduce16, and the lanes that end up holding filter f track its maximum over the window positions.
+    // 16 filters at a time: the 16 channel sums leave through one reduce16, and the lanes that end up holding filter f track its
+    // maximum over the window positions.
     for (int i = 0; i < L; ++i) {
+      const float *const kh = wl + D.off_kh[i] + c;
       for (int f0 = 0; f0 < D.n_h; f0 += 16) {
         const int fm = slot16(c);                               // the filter (of this block) whose total this lane receives
         float best = -3.0e38f, bpre = 0.f;
         int bt = 0;
+        const float bias = (f0 + fm < D.n_h) ? wl[D.off_bh[i] + f0 + fm] : 0.f;
         for (int t = 0; t + i < L; ++t) {
           float part[16];
 #pragma unroll
           for (int ff = 0; ff < 16; ++ff) part[ff] = 0.f;
-          for (int s2 = 0; s2 <= i; ++s2) {
-            const float e = S.E[(t + s2) * 64 + c];
-            float w16[16];
+          if (f0 + 16 <= D.n_h) {
+            for (int s2 = 0; s2 <= i; ++s2) {
+              const float e = S.E[(t + s2) * 64 + c];
+              const float *const row = kh + (s2 * D.n_h + f0) * ld;
 #pragma unroll
-            for (int ff = 0; ff < 16; ++ff)
-              w16[ff] = (live && f0 + ff < D.n_h) ? sw[D.off_kh[i] + (s2 * D.n_h + f0 + ff) * D.ld + c] : 0.f;
+              for (int ff = 0; ff < 16; ++ff) part[ff] = fmaf(e, row[ff * ld], part[ff]);
+            }
+          } else {
+            for (int s2 = 0; s2 <= i; ++s2) {
+              const float e = S.E[(t + s2) * 64 + c];
+              const float *const row = kh + (s2 * D.n_h + f0) * ld;
 #pragma unroll
-            for (int ff = 0; ff < 16; ++ff) part[ff] = fmaf(e, w16[ff], part[ff]);
+              for (int ff = 0; ff < 16; ++ff) part[ff] = fmaf(e, (f0 + ff < D.n_h) ? row[ff * ld] : 0.f, part[ff]);
+            }
           }
           const float tot = reduce16(part, c);
-          const float v = tot + ((f0 + fm < D.n_h) ? sw[D.off_bh[i] + f0 + fm] : 0.f);
+          const float v = tot + bias;
           const float r = act_f(D.act_h, v);
           if (r > best) { best = r; bt = t; bpre = v; }        // first maximum wins, like the max-pool gradient
         }
@@ -153,6 +226,7 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
       }
     }
     wave_lds_sync();
+    CSTAMP(3);
     // ---- 4. dropout (mask injected by the host; caser.py:61,114) -------------------------------------------------------
     for (int j = c; j < nx; j += 64) {
       float v = S.x[j];
@@ -161,41 +235,70 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
       S.xd[j] = v;
     }
     wave_lds_sync();
+    CSTAMP(4);
     // ---- 5. dense_0 (act_mlp) ---------------------------------------------------------------------------------------------
-    float z0 = live ? sw[D.off_bd + c] : 0.f;
-    if (live)
-      for (int j = 0; j < nx; ++j) z0 = fmaf(S.xd[j], sw[D.off_wd + j * D.ld + c], z0);
+    float z0 = wl[D.off_bd + c];
+    {
+      const float *const wd = wl + D.off_wd + c;
+#pragma unroll 4
+      for (int j = 0; j < nx; ++j) z0 = fmaf(S.xd[j], wd[j * ld], z0);
+    }
+    if (!live) z0 = 0.f;
     const float z = act_f(D.act_mlp, z0);
     if (!TRAIN) {
       if (live) { A.cat_out[(size_t)b * D.ld2 + c] = z; A.cat_out[(size_t)b * D.ld2 + d + c] = pu; }
     } else {
-    // ---- 6. targets: score, sigmoid, Keras BCE, backward to the lookups -------------------------------------------------
+    CSTAMP(5);
+    // ---- 6. targets: score, sigmoid, Keras BCE, backward to the lookups -------------------------------------------------------
+    // eight targets at a time: their sixteen row reads are in flight together, the eight dot products leave through ONE reduce8 (10
+    // shuffles instead of 48), the lanes that hold target j's score do its sigmoid / loss / gradient, every lane then fetches the eight
+    // gradients with v_readlane
     float dz = 0.f, dpu = 0.f;
-    for (int j = 0; j < D.Tp; ++j) {
-      const int n = A.after[b * D.Tp + j];
-      const float wa = live ? A.W1[(size_t)n * D.ld2 + c] : 0.f;
-      const float wb = live ? A.W1[(size_t)n * D.ld2 + d + c] : 0.f;
-      const float sc = wave_sum(fmaf(z, wa, pu * wb)) + A.b1[n];
+    for (int j0 = 0; j0 < D.Tp; j0 += 8) {
+      int n[8];
+      float wa[8], wb[8];
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) n[qq] = j0 + qq < D.Tp ? A.after[b * D.Tp + j0 + qq] : 0;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+        const bool on = live && j0 + qq < D.Tp;
+        wa[qq] = on ? A.W1[(size_t)n[qq] * D.ld2 + c] : 0.f;
+        wb[qq] = on ? A.W1[(size_t)n[qq] * D.ld2 + d + c] : 0.f;
+      }
+      const int jm = j0 + slot8(c);                           // the target whose score this lane receives
+      const float bm = jm < D.Tp ? A.b1[A.after[b * D.Tp + jm]] : 0.f;
+      float prod[8];
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) prod[qq] = fmaf(z, wa[qq], pu * wb[qq]);
+      const float sc = reduce8(prod, c) + bm;
       const float p = sigmoidf_(sc);
-      const float y = j < D.T ? 1.f : 0.f;
-      loss_acc += bce_elem(y, p);
-      const float ds = bce_grad(y, p) * inv_bt * p * (1.f - p);
-      const size_t row = (size_t)b * D.Tp + j;
-      if (live) { A.dW1[row * D.ld2 + c] = ds * z; A.dW1[row * D.ld2 + d + c] = ds * pu; }
-      if (c == 0) A.db1[row] = ds;
-      dz = fmaf(ds, wa, dz);
-      dpu = fmaf(ds, wb, dpu);
+      const float y = jm < D.T ? 1.f : 0.f;
+      const float dsm = jm < D.Tp ? bce_grad(y, p) * inv_bt * p * (1.f - p) : 0.f;
+      if ((c & 7) == 0 && jm < D.Tp) {
+        loss_acc += bce_elem(y, p);
+        A.db1[(size_t)b * D.Tp + jm] = dsm;
+      }
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+        if (j0 + qq < D.Tp) {
+          const float ds = lane_f(dsm, lane8(qq));
+          const size_t row = (size_t)b * D.Tp + j0 + qq;
+          if (live) { A.dW1[row * D.ld2 + c] = ds * z; A.dW1[row * D.ld2 + d + c] = ds * pu; }
+          dz = fmaf(ds, wa[qq], dz);
+          dpu = fmaf(ds, wb[qq], dpu);
+        }
+      }
     }
-    if (live) A.dPu[(size_t)b * D.ld + c] = dpu;
+    if (live) A.dPu[(size_t)b * ld + c] = dpu;
     dz0 = dz * act_df(D.act_mlp, z0);
-    // ---- 7. dense_0 backward: dx[j] = sum_c dz0[c] * Wd[j][c], 16 rows of Wd per reduce16 ---------------------------------------
+    CSTAMP(6);
+    // ---- 7. dense_0 backward: dx[j] = sum_c dz0[c] * Wd[j][c], 16 rows of Wd per reduce16 (dz0 = 0 in the dead lanes) -----------
     for (int j0 = 0; j0 < nx; j0 += 16) {
       float prod[16];
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
         const int j = j0 + jj;
-        const float wv = (live && j < nx) ? sw[D.off_wd + j * D.ld + c] : 0.f;
-        prod[jj] = dz0 * wv;
+        prod[jj] = dz0 * (j < nx ? wl[D.off_wd + j * ld + c] : 0.f);
       }
       float g = reduce16(prod, c);
       const int j = j0 + slot16(c);
@@ -206,74 +309,136 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A) 
       }
     }
     wave_lds_sync();
-    // ---- 8. vertical conv backward (to the item rows) ------------------------------------------------------------------------
+    CSTAMP(7);
+    // ---- 8. vertical conv backward (to the item rows; their gradients stay in registers) -----------------------------------------
+    float dEr[kCaserMaxL];
+#pragma unroll
+    for (int t = 0; t < kCaserMaxL; ++t) dEr[t] = 0.f;
     for (int f = 0; f < D.n_v; ++f) {
       const float dv = S.dx[f];
-      if (live)
-        for (int t = 0; t < L; ++t) S.dE[t * 64 + c] = fmaf(dv, sw[D.off_kv + (t * D.n_v + f) * D.ld + c], S.dE[t * 64 + c]);
+#pragma unroll
+      for (int t = 0; t < kCaserMaxL; ++t)
+        if (t < L) dEr[t] = fmaf(dv, wl[D.off_kv + (t * D.n_v + f) * ld + c], dEr[t]);
     }
-    // ---- 9. horizontal convs backward (through relu at the arg-max step) -------------------------------------------------
-    for (int i = 0; i < L; ++i)
-      for (int f = 0; f < D.n_h; ++f) {
-        const int j = D.n_v + i * D.n_h + f;
-        const float dc = S.dx[j] * act_df(D.act_h, S.pre[j]);
-        if (dc == 0.f) continue;
-        const int t = S.arg[j];
-        if (live)
-          for (int s = 0; s <= i; ++s)
-            S.dE[(t + s) * 64 + c] = fmaf(dc, sw[D.off_kh[i] + (s * D.n_h + f) * D.ld + c], S.dE[(t + s) * 64 + c]);
+    CSTAMP(8);
+    // ---- 9. horizontal convs backward (through act_h at the arg-max step) -------------------------------------------------
+    // 64 filters at a time: lane l works out filter l's gradient at its arg-max step and holds its position; the walk over the filters
+    // then reads both with v_readlane (a chain of three dependent LDS reads per filter took 23 us of a sample's 143).  The taps of a
+    // filter are read without a data-dependent branch — every position of the window asks for a weight (a clamped one where the filter
+    // has no tap, times zero) — so that the reads of a filter are in flight together.  (Four filters per turn spilled 46 registers at
+    // the 128 a 16-wave workgroup may hold and took three times as long.)
+    {
+      float dcl = 0.f;
+      int tl = 0, pq = 0;
+      const int tap = D.n_h * ld;
+      for (int i = 0; i < L; ++i) {
+        const float *const khi = wl + D.off_kh[i] + c;
+        for (int f = 0; f < D.n_h; ++f, ++pq) {
+          if ((pq & 63) == 0) {
+            const int jl = D.n_v + pq + c;
+            dcl = jl < nx ? S.dx[jl] * act_df(D.act_h, S.pre[jl]) : 0.f;
+            tl = jl < nx ? S.arg[jl] : 0;
+          }
+          const float dc = lane_f(dcl, pq & 63);
+          if (dc == 0.f) continue;
+          const int t0 = __builtin_amdgcn_readlane(tl, pq & 63);
+          const float *const kh = khi + f * ld;
+#pragma unroll
+          for (int tt = 0; tt < kCaserMaxL; ++tt) {
+            if (tt < L) {
+              const int s2 = tt - t0;
+              const bool on = s2 >= 0 && s2 <= i;
+              dEr[tt] = fmaf(on ? dc : 0.f, kh[(on ? s2 : 0) * tap], dEr[tt]);
+            }
+          }
+        }
       }
+    }
+    CSTAMP(9);
     // ---- 10. gradient rows of the item lookups ------------------------------------------------------------------------------
-    if (live)
-      for (int t = 0; t < L; ++t) A.dE[((size_t)b * L + t) * D.ld + c] = S.dE[t * 64 + c];
+#pragma unroll
+    for (int t = 0; t < kCaserMaxL; ++t)
+      if (t < L && live) A.dE[((size_t)b * L + t) * ld + c] = dEr[t];
+    CSTAMP(10);
     }   // TRAIN
     }   // has
-    // ---- 11. small-weight gradients into the shared accumulators ---------------------------------------------------------------
-    // Every accumulator row has ONE owner wave (dense_0 row j: wave j % W; conv_v filter f: f % W; horizontal filter (i, f):
-    // (i * n_h + f) % W; the dense_0 bias: wave 0).  An owner walks the W samples of the round in sample order and adds their
-    // contributions to its rows out of the samples' scratch — no two waves ever touch the same accumulator, and every sum is taken
-    // in the order of the batch.
+    // ---- 11. small-weight gradients, unit by unit ---------------------------------------------------------------------------------
     if (TRAIN) {
       if (has) S.dz0s[c] = dz0;
       __syncthreads();
-      for (int t = 0; t < W && b0 + t < A.B; ++t) {
-        const float *T0 = lds + D.n_small + (size_t)t * per_wave;
-        const float *tE = T0, *txd = T0 + 2 * L * 64 + nx, *tpre = txd + nx, *tdx = tpre + nx;
-        const int *targ = reinterpret_cast<const int *>(tdx + nx);
-        const float tdz0 = reinterpret_cast<const float *>(targ + nx)[c];
-        if (w == 0 && live) S.gsw[D.off_bd + c] += tdz0;
-        if (live)
-          for (int j = w; j < nx; j += W) S.gsw[D.off_wd + j * D.ld + c] = fmaf(txd[j], tdz0, S.gsw[D.off_wd + j * D.ld + c]);
-        for (int f = w; f < D.n_v; f += W) {
-          const float dv = tdx[f];
-          if (c == 0) S.gsw[D.off_bv + f] += dv;
-          if (live)
-            for (int tt = 0; tt < L; ++tt) {
-              const int k = D.off_kv + (tt * D.n_v + f) * D.ld + c;
-              S.gsw[k] = fmaf(tE[tt * 64 + c], dv, S.gsw[k]);
+      const int nT = min(W, A.B - b0);
+      const bool first = b0 == (int)blockIdx.x * W;
+      float *const gp = A.gsw_part + (size_t)blockIdx.x * D.n_small;
+      const int u_kv = nx, u_kh = u_kv + L * D.n_v, u_bd = u_kh + L * D.n_h, u_bv = u_bd + 1, nbv = (D.n_v + 63) / 64, nbh = (D.n_h + 63) / 64;
+      const int u_bh = u_bv + nbv, n_units = u_bh + L * nbh;
+      // a sample's scratch: E | x | xd | pre | dx | arg | dz0
+      const int o_xd = L * 64 + nx, o_pre = o_xd + nx, o_dx = o_pre + nx, o_arg = o_dx + nx, o_dz0 = o_arg + nx;
+      for (int un = w; un < n_units; un += W) {
+        // lane t of the wave first fetches sample t's scalar of this unit; the walk over the samples then reads it with v_readlane, so
+        // that the vector reads of the walk do not wait for one another
+        const float *const Tl = scratch0 + (size_t)(c < nT ? c : 0) * per_wave;
+        if (un < u_kv) {                                       // dense_0 row j: sum_t xd_t[j] * dz0_t[c]
+          const int off = D.off_wd + un * ld + c;
+          float acc = first ? 0.f : (c < ld ? gp[off] : 0.f);
+          const float xl = Tl[o_xd + un];
+#pragma unroll 4
+          for (int t = 0; t < nT; ++t) acc = fmaf(lane_f(xl, t), scratch0[(size_t)t * per_wave + o_dz0 + c], acc);
+          if (c < ld) gp[off] = acc;
+        } else if (un < u_kh) {                                // vertical filter row (tt, f): sum_t E_t[tt][c] * dx_t[f]
+          const int qv = un - u_kv, tt = qv / D.n_v, f = qv - tt * D.n_v;
+          const int off = D.off_kv + qv * ld + c;
+          float acc = first ? 0.f : (c < ld ? gp[off] : 0.f);
+          const float dl = Tl[o_dx + f];
+#pragma unroll 4
+          for (int t = 0; t < nT; ++t) acc = fmaf(scratch0[(size_t)t * per_wave + tt * 64 + c], lane_f(dl, t), acc);
+          if (c < ld) gp[off] = acc;
+        } else if (un < u_bd) {                                // horizontal pair (i, f): its i + 1 tap rows
+          const int pq = un - u_kh, i = pq / D.n_h, f = pq - i * D.n_h, j = D.n_v + pq;
+          const int off = D.off_kh[i] + f * ld + c;
+          const float dcl = Tl[o_dx + j] * act_df(D.act_h, Tl[o_pre + j]);
+          const int tal = reinterpret_cast<const int *>(Tl + o_arg)[j];
+          const int tap = D.n_h * ld;
+          const bool wr = c < ld;
+          switch (i) {                                         // (static tap counts: the reads of a sample's window are in flight together)
+            case 0: pair_rows<1>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+            case 1: pair_rows<2>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+            case 2: pair_rows<3>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+            case 3: pair_rows<4>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+            case 4: pair_rows<5>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+            case 5: pair_rows<6>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+            case 6: pair_rows<7>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+            default: pair_rows<8>(gp + off, tap, first, wr, scratch0 + c, per_wave, nT, dcl, tal); break;
+          }
+        } else if (un < u_bv) {                                // dense_0 bias
+          float acc = first ? 0.f : (c < ld ? gp[D.off_bd + c] : 0.f);
+          for (int t = 0; t < nT; ++t) acc += scratch0[(size_t)t * per_wave + o_dz0 + c];
+          if (c < ld) gp[D.off_bd + c] = acc;
+        } else if (un < u_bh) {                                // vertical biases, 64 per unit
+          const int f = (un - u_bv) * 64 + c, pad = (D.n_v + 3) & ~3;
+          float acc = (first || f >= D.n_v) ? 0.f : gp[D.off_bv + f];
+          if (f < D.n_v)
+            for (int t = 0; t < nT; ++t) acc += scratch0[(size_t)t * per_wave + o_dx + f];
+          if (f < pad) gp[D.off_bv + f] = f < D.n_v ? acc : 0.f;
+        } else {                                               // horizontal biases of height i, 64 per unit
+          const int ub = un - u_bh, i = ub / nbh, f = (ub - i * nbh) * 64 + c, pad = (D.n_h + 3) & ~3;
+          const int j = D.n_v + i * D.n_h + f;
+          float acc = (first || f >= D.n_h) ? 0.f : gp[D.off_bh[i] + f];
+          if (f < D.n_h)
+            for (int t = 0; t < nT; ++t) {
+              const float *T0 = scratch0 + (size_t)t * per_wave;
+              acc += T0[o_dx + j] * act_df(D.act_h, T0[o_pre + j]);
             }
-        }
-        for (int pq = w; pq < L * D.n_h; pq += W) {
-          const int i = pq / D.n_h, f = pq - i * D.n_h;
-          const int j = D.n_v + pq;
-          const float dc = tdx[j] * act_df(D.act_h, tpre[j]);
-          if (dc == 0.f) continue;
-          const int ta = targ[j];
-          if (c == 0) S.gsw[D.off_bh[i] + f] += dc;
-          if (live)
-            for (int s2 = 0; s2 <= i; ++s2) {
-              const int k = D.off_kh[i] + (s2 * D.n_h + f) * D.ld + c;
-              S.gsw[k] = fmaf(tE[(ta + s2) * 64 + c], dc, S.gsw[k]);
-            }
+          if (f < pad) gp[D.off_bh[i] + f] = f < D.n_h ? acc : 0.f;
         }
       }
       __syncthreads();
+      if (has) CSTAMP(11);
     }
   }
   if (TRAIN) {
+    loss_acc = wave_sum(loss_acc);                       // (the lanes that held a target's score carry its loss term)
     if (c == 0) wloss[w] = loss_acc;
     __syncthreads();
-    for (int i = threadIdx.x; i < D.n_small; i += blockDim.x) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = S.gsw[i];
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int ww = 0; ww < W; ++ww) t += wloss[ww];
@@ -316,9 +481,10 @@ __global__ __launch_bounds__(kBlock) void k_adam_segments(float *p, float *m, fl
   }
 }
 
-static size_t caser_lds_bytes(const DrxCaserDims &D, bool train, int waves) {
+// the small weights (+ 64 zeros) and a scratch per wave: E | x | xd | pre | dx | arg | dz0
+static size_t caser_lds_bytes(const DrxCaserDims &D, bool, int waves) {
   const int nx = D.n_v + D.L * D.n_h;
-  return ((size_t)(train ? D.n_small : 0) + (size_t)waves * (2 * (size_t)D.L * 64 + 5 * (size_t)nx + 64)) * 4 + 64;
+  return ((size_t)D.n_small + 64 + (size_t)waves * ((size_t)D.L * 64 + 5 * (size_t)nx + 64)) * 4 + 64;
 }
 
 // waves per workgroup: as many (16, 8, 4, 2, 1) as fit the CU's LDS beside the shared accumulators, and no more than the batch needs
@@ -330,7 +496,7 @@ static int caser_waves(const DrxCaserDims &D, bool train, int B) {
 
 static int check_dims(const DrxCaserDims *D) {
   if (!D || D->L < 1 || D->L > kCaserMaxL || D->d < 1 || D->d > 64 || D->ld < D->d || (D->ld & 3) || D->ld2 < 2 * D->d ||
-      (D->ld2 & 3) || D->n_v < 1 || D->n_h < 1 || D->T < 1 || D->Tp < D->T || D->n_small < 1 || D->act_h < 0 || D->act_h > 3 ||
+      (D->ld2 & 3) || D->n_v < 1 || D->n_h < 1 || D->T < 1 || D->Tp < D->T || D->n_small < 1 || (D->n_small & 3) || D->act_h < 0 || D->act_h > 3 ||
       D->act_mlp < 0 || D->act_mlp > 3)
     return DRX_EINVAL;
   return caser_lds_bytes(*D, true, 1) <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
@@ -360,7 +526,7 @@ int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_o
   const int waves = caser_waves(*D, true, A->B);
   const size_t lds = caser_lds_bytes(*D, true, waves);
   DRX_HIP(hipFuncSetAttribute((const void *)k_caser<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_caser<true>, dim3(grid), dim3(64 * waves), lds, st, *D, *A);
+  hipLaunchKernelGGL(k_caser<true>, dim3(grid), dim3(64 * waves), lds, st, *D, *A CASER_STAMP_PASS);
   hipLaunchKernelGGL(k_sum_partials, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
                      A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();
@@ -372,10 +538,11 @@ int drx_caser_hidden(const DrxCaserDims *D, const DrxCaserArgs *A, void *stream)
   if (rc) return rc;
   if (!A || !A->item_emb || !A->user_emb || !A->sw || !A->uid || !A->before || !A->cat_out || A->B < 1) return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int waves = 4;
+  const int waves = caser_waves(*D, false, A->B);       // (every workgroup copies the small weights into its LDS: few, large workgroups)
   const size_t lds = caser_lds_bytes(*D, false, waves);
   const int g = (A->B + waves - 1) / waves;
-  hipLaunchKernelGGL(k_caser<false>, dim3(g < 2048 ? g : 2048), dim3(64 * waves), lds, st, *D, *A);
+  DRX_HIP(hipFuncSetAttribute((const void *)k_caser<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_caser<false>, dim3(g < 512 ? g : 512), dim3(64 * waves), lds, st, *D, *A CASER_STAMP_PASS);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
