@@ -116,12 +116,26 @@ def caser_block(ds, dev):
             m._do_batch(batch, step=state['s'])
             state['s'] += 1
         dev_s = _timed(step, 30)
-        t0 = time.perf_counter()
-        m.fit(ds, epochs=200, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3)
-        torch.cuda.synchronize()
-        e2e = (time.perf_counter() - t0) / 200
+        def fit_times(model, **kw):
+            """seconds per step of a 200-epoch fit() (set-up included) and of the steady state (a 600-epoch fit minus a 200-epoch one)"""
+            res = []
+            for n in (200, 600):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.fit(ds, epochs=n, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3, **kw)
+                torch.cuda.synchronize()
+                res.append(time.perf_counter() - t0)
+            return res[0] / 200, (res[1] - res[0]) / 400
+        e2e, steady = fit_times(m)
         out[f'Caser_B{B}'] = {'step_ms': dev_s * 1e3, 'step_windows_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
-                              'fit_windows_per_s': B / e2e, 'sampler': getattr(m, '_sampler_kind', 'reference-exact ListSampler stream (C++)')}
+                              'fit_steady_ms_per_step': steady * 1e3, 'fit_windows_per_s': B / steady,
+                              'sampler': getattr(m, '_sampler_kind', 'reference-exact ListSampler stream (C++)')}
+        # throughput mode: windows drawn on the device (a named deviation, like CDAE's device PointSampler)
+        m2 = Caser(L=5, T=3, d=50, n_v=4, n_h=16, dropout_rate=0.5, seed=10, verbose=False, device=str(dev))
+        m2.fit(ds, epochs=3, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3, device_sampler=True)
+        e2d, steady_d = fit_times(m2, device_sampler=True)
+        out[f'Caser_B{B}_device_sampler'] = {'fit_ms_per_step_incl_setup': e2d * 1e3, 'fit_steady_ms_per_step': steady_d * 1e3,
+                                             'fit_windows_per_s': B / steady_d, 'sampler': getattr(m2, '_sampler_kind', None)}
     return out
 
 

@@ -118,12 +118,62 @@ class ListSampler:
         self._native = (L, handle)
         self._max_group = int(lens.max()) if len(lens) else 0
         self._group_values = np.asarray(self.unique_groups)
+        self._twin_arrays = (indptr, row_ids, n_ids)          # what device_twin() uploads
 
     def __del__(self):
         native = getattr(self, '_native', None)
         if native is not None:
             native[0].drx_list_sampler_destroy(native[1])
             self._native = None
+
+    # ---- device twin (throughput mode: libdrx.so drx_list_sample_device, a counter-based generator instead of the MT stream) --------
+    def twin_host_arrays(self):
+        """The arrays drx_list_sample_device reads (include/drx.h DrxListGroups), as numpy: indptr, seq_ids, held_indptr, held,
+        group_value, eligible, n_ids.  Needs a window configuration (n_targets and max_positive_records == min_positive_records)."""
+        assert self._native is not None and self.n_targets is not None and self.max_positive_records == self.min_positive_records, \
+            'the device list sampler draws fixed windows of min_positive_records inputs + n_targets targets over one group column'
+        indptr, row_ids, n_ids = self._twin_arrays
+        lens = np.diff(indptr)
+        gid = np.repeat(np.arange(len(lens), dtype=np.int64), lens)
+        pair = np.unique(gid * np.int64(n_ids) + row_ids.astype(np.int64))            # (group, id) pairs, ascending: a group's distinct ids
+        held = (pair % n_ids).astype(np.int32)
+        held_indptr = np.zeros(len(lens) + 1, dtype=np.int64)
+        held_indptr[1:] = np.cumsum(np.bincount(pair // n_ids, minlength=len(lens)))
+        n_held = np.diff(held_indptr)
+        L_, T = int(self.min_positive_records), int(self.n_targets)
+        eligible = np.flatnonzero((lens >= L_ + T) & (n_ids - n_held >= T * int(self.neg_ratio))).astype(np.int32)
+        if not len(eligible):
+            raise Exception('Failed to sample group records: no group holds a window of '
+                            f'{L_} + {T} records with {T * int(self.neg_ratio)} ids left to draw negatives from.')
+        return {'indptr': indptr, 'seq_ids': row_ids, 'held_indptr': held_indptr, 'held': held,
+                'group_value': np.ascontiguousarray(self._group_values, dtype=np.int32), 'eligible': eligible, 'n_ids': int(n_ids)}
+
+    def device_twin(self, device):
+        import torch
+        from .. import _lib
+        a = self.twin_host_arrays()
+        t = {k: torch.as_tensor(v).to(device) for k, v in a.items() if k != 'n_ids'}
+        G = _lib.ListGroups()
+        for k in ('indptr', 'seq_ids', 'held_indptr', 'held', 'group_value', 'eligible'):
+            setattr(G, k, t[k].data_ptr())
+        G.n_groups, G.n_eligible, G.n_ids = len(a['indptr']) - 1, len(a['eligible']), a['n_ids']
+        self._twin = (G, t, torch.device(device))
+        return self
+
+    def sample_device(self, n, seed):
+        """n windows drawn on the device (see include/drx.h drx_list_sample_device): int32 tensors group value [n], input ids
+        [n, min_positive_records], target ids followed by negative ids [n, n_targets * (1 + neg_ratio)]."""
+        import ctypes as C
+        import torch
+        from .. import _lib
+        G, _, dev = self._twin
+        L_, T, neg = int(self.min_positive_records), int(self.n_targets), int(self.neg_ratio)
+        grp = torch.empty(n, dtype=torch.int32, device=dev)
+        before = torch.empty(n, L_, dtype=torch.int32, device=dev)
+        after = torch.empty(n, T * (1 + neg), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().drx_list_sample_device(C.byref(G), n, L_, T, neg, int(seed) & (2 ** 64 - 1), grp.data_ptr(), before.data_ptr(),
+                                                     after.data_ptr(), _lib.stream_ptr(dev)), 'drx_list_sample_device')
+        return grp, before, after
 
     def sample_group_arrays(self, n=16):
         """n draws as arrays (native loop only): group values [n], offsets + dataset rows of the inputs and of the targets,

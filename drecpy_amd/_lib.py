@@ -37,6 +37,12 @@ class Batch(C.Structure):
                 ('n_touch_slots', C.c_int32), ('flags', C.c_uint32)]
 
 
+class ListGroups(C.Structure):
+    _fields_ = [('indptr', C.c_void_p), ('seq_ids', C.c_void_p), ('held_indptr', C.c_void_p), ('held', C.c_void_p),
+                ('group_value', C.c_void_p), ('eligible', C.c_void_p), ('n_groups', C.c_int32), ('n_eligible', C.c_int32),
+                ('n_ids', C.c_int32)]
+
+
 class Shard(C.Structure):
     _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('n_items', C.c_int32), ('items_per_rank', C.c_int32),
                 ('n_users_local', C.c_int32)]
@@ -115,6 +121,8 @@ SIGNATURES = {
                                                 C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
                                                 C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     'drx_point_sample_scratch_bytes': (C.c_size_t, [C.c_int32]),
+    'drx_list_sample_device': (C.c_int, [C.POINTER(ListGroups), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     'drx_point_sample': (C.c_int, [C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                    C.c_void_p]),

@@ -198,3 +198,68 @@ extern "C" int drx_batch_offsets(const int64_t *indptr, const int32_t *ids, int3
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
+
+// ---- device-side list sampler (include/drx.h: drx_list_sample_device) ---------------------------------------------------------
+namespace drx {
+
+__device__ __forceinline__ uint32_t scale_u32(uint32_t h, uint32_t n) { return (uint32_t)(((uint64_t)h * (uint64_t)n) >> 32); }
+
+// j-th (0-based) id of the ascending complement of held[0..nh) in [0, n_ids): the smallest v with v - #(held <= v) == j
+__device__ __forceinline__ int32_t complement_at(const int32_t *__restrict__ held, int nh, uint32_t j) {
+  int lo = 0, hi = nh;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)held[mid] - (int64_t)mid <= (int64_t)j) lo = mid + 1; else hi = mid;
+  }
+  return (int32_t)(j + (uint32_t)lo);
+}
+
+__global__ __launch_bounds__(kBlock) void k_list_sample(DrxListGroups G, int B, int L, int T, int neg, uint64_t seed,
+                                                        int32_t *__restrict__ grp, int32_t *__restrict__ before, int32_t *after) {
+  const int d = blockIdx.x * kBlock + threadIdx.x;
+  if (d >= B) return;
+  const int g = G.eligible[scale_u32(hash_u32(seed, (uint32_t)d, 0u), (uint32_t)G.n_eligible)];
+  const int64_t r0 = G.indptr[g];
+  const int n_rows = (int)(G.indptr[g + 1] - r0);
+  const int start = (int)scale_u32(hash_u32(seed, (uint32_t)d, 1u), (uint32_t)(n_rows - L - T + 1));
+  grp[d] = G.group_value[g];
+  for (int t = 0; t < L; ++t) before[(size_t)d * L + t] = G.seq_ids[r0 + start + t];
+  const int Tp = T * (1 + neg), n_neg = T * neg;
+  int32_t *const out = after + (size_t)d * Tp;
+  for (int t = 0; t < T; ++t) out[t] = G.seq_ids[r0 + start + L + t];
+  const int64_t h0 = G.held_indptr[g];
+  const int nh = (int)(G.held_indptr[g + 1] - h0);
+  const uint32_t n_pop = (uint32_t)(G.n_ids - nh);
+  for (int i = 0; i < n_neg; ++i) {
+    int32_t id = 0;
+    uint32_t j = 0;
+    bool dup = true;
+    for (int a = 0; a < 16 && dup; ++a) {
+      j = scale_u32(hash_u32(seed, (uint32_t)d, (uint32_t)(2 + 16 * i + a)), n_pop);
+      id = complement_at(G.held + h0, nh, j);
+      dup = false;
+      for (int p = 0; p < i; ++p) dup |= out[T + p] == id;
+    }
+    while (dup) {                                   // (sixteen collisions in a row: a catalogue barely larger than the draw)
+      j = j + 1 == n_pop ? 0u : j + 1;
+      id = complement_at(G.held + h0, nh, j);
+      dup = false;
+      for (int p = 0; p < i; ++p) dup |= out[T + p] == id;
+    }
+    out[T + i] = id;
+  }
+}
+
+}  // namespace drx
+
+extern "C" int drx_list_sample_device(const DrxListGroups *g, int32_t B, int32_t n_inputs, int32_t n_targets, int32_t neg_ratio,
+                                      uint64_t seed, int32_t *group_out, int32_t *before, int32_t *after, void *stream) {
+  using namespace drx;
+  if (!g || !g->indptr || !g->seq_ids || !g->held_indptr || !g->held || !g->group_value || !g->eligible || g->n_eligible < 1 ||
+      g->n_ids < 1 || B < 1 || n_inputs < 1 || n_targets < 1 || neg_ratio < 0 || !group_out || !before || !after)
+    return DRX_EINVAL;
+  hipLaunchKernelGGL(k_list_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, *g, B, n_inputs, n_targets,
+                     neg_ratio, seed, group_out, before, after);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}

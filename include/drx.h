@@ -188,6 +188,30 @@ int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, i
                      uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
                      void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
 
+/* ---- device-side list sampler (throughput mode; distribution of list_sampler.py:74-151 as caser.py:72-75 configures it) -----
+ * The reference's ListSampler is ONE MT19937 stream: draw d depends on every draw before it, so a reference-exact fit() is bound by
+ * one host thread (about 0.5 us per window).  This entry point draws B windows independently with the counter-based generator of
+ * the other throughput modes, draw d from drx_hash_u32(seed, d, k):
+ *   k = 0      group   = eligible[(h * n_eligible) >> 32]                 (rng.choice over the groups, ineligible ones re-drawn)
+ *   k = 1      start   = (h * (rows - n_inputs - n_targets + 1)) >> 32    (rng.randint(0, rows - max_positive_records - n_targets))
+ *   k = 2+16i+a  negative i, attempt a: the ((h * n_pop) >> 32)-th id of the ascending complement of the group's ids in
+ *              [0, n_ids); an id already drawn for this window is drawn again (a = 1 .. 15), then the next free one is taken
+ *              (rng.sample(eligible, n): uniform without replacement)
+ * before[d] = the ids of rows start .. start + n_inputs - 1 of the group (rows in the sampler's sort order), after[d] = the ids of
+ * the next n_targets rows followed by the n_targets * neg_ratio negatives.  Restated on the CPU by oracle/data_oracle.py::
+ * list_sample_counter (the test compares bit for bit). */
+typedef struct DrxListGroups {
+  const int64_t *indptr;       /* [n_groups + 1] rows of every group */
+  const int32_t *seq_ids;      /* [indptr[n_groups]] negative_ids_col value of every row, a group's rows in the sampler's order */
+  const int64_t *held_indptr;  /* [n_groups + 1] */
+  const int32_t *held;         /* ascending distinct ids among a group's rows */
+  const int32_t *group_value;  /* [n_groups] the value of the group column (Caser: uid) */
+  const int32_t *eligible;     /* [n_eligible] groups with >= n_inputs + n_targets rows and >= n_targets * neg_ratio ids outside */
+  int32_t n_groups, n_eligible, n_ids;
+} DrxListGroups;
+int drx_list_sample_device(const DrxListGroups *g, int32_t B, int32_t n_inputs, int32_t n_targets, int32_t neg_ratio, uint64_t seed,
+                           int32_t *group_out, int32_t *before, int32_t *after, void *stream);
+
 /* ---- column-sharded ("K-sharded") multi-GPU step (no reference equivalent) ------------------------------------------------
  * Every rank holds ALL rows but only its own columns of W, W2T, V and b (DrxCdaeParams describes that slice: k = local columns;
  * b2 is replicated) and trains on the SAME global batch.  The one exchange of a step is the sum over ranks of the per-triple

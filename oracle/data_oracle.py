@@ -211,3 +211,52 @@ def corruption_keep_mask(rng, n_rows, n_items, corruption_level):
         for n in range(n_items):
             keep[b, n] = not (rng.uniform(0, 1) < corruption_level)
     return keep
+
+
+def list_sample_counter(twin, n, n_inputs, n_targets, neg_ratio, seed):
+    """CPU restatement of drx_list_sample_device (include/drx.h): n windows from the counter-based generator drx_hash_u32(seed, d, k).
+    twin: the arrays of ListSampler.twin_host_arrays().  Returns (group values [n], before [n, n_inputs], after [n, T * (1 + neg)]).
+    Distribution of the reference's ListSampler as Caser configures it (list_sampler.py:74-151, caser.py:72-75): uniform group among
+    those that can yield a window, uniform window start, negatives uniform without replacement among the ids the group does not hold."""
+    from oracle.cdae_oracle import drx_hash_u32
+
+    def h(d, k):
+        return int(drx_hash_u32(seed, np.uint32(d), np.uint32(k)))
+
+    def complement_at(held, j):
+        lo, hi = 0, len(held)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if int(held[mid]) - mid <= j:
+                lo = mid + 1
+            else:
+                hi = mid
+        return j + lo
+    L, T = n_inputs, n_targets
+    grp = np.zeros(n, np.int32)
+    before = np.zeros((n, L), np.int32)
+    after = np.zeros((n, T * (1 + neg_ratio)), np.int32)
+    for d in range(n):
+        g = int(twin['eligible'][(h(d, 0) * len(twin['eligible'])) >> 32])
+        r0, r1 = int(twin['indptr'][g]), int(twin['indptr'][g + 1])
+        start = (h(d, 1) * (r1 - r0 - L - T + 1)) >> 32
+        grp[d] = twin['group_value'][g]
+        before[d] = twin['seq_ids'][r0 + start:r0 + start + L]
+        after[d, :T] = twin['seq_ids'][r0 + start + L:r0 + start + L + T]
+        held = twin['held'][int(twin['held_indptr'][g]):int(twin['held_indptr'][g + 1])]
+        n_pop = twin['n_ids'] - len(held)
+        picked = []
+        for i in range(T * neg_ratio):
+            dup, a, j, v = True, 0, 0, 0
+            while a < 16 and dup:
+                j = (h(d, 2 + 16 * i + a) * n_pop) >> 32
+                v = complement_at(held, j)
+                dup = v in picked
+                a += 1
+            while dup:
+                j = 0 if j + 1 == n_pop else j + 1
+                v = complement_at(held, j)
+                dup = v in picked
+            picked.append(v)
+            after[d, T + i] = v
+    return grp, before, after

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU-box call: bench line + kernel-trace stats + the two PMC passes (separate runs, per the microarch guide).
 # Usage (through gpurun): bash scripts/profile_round.sh <tag>
+# Every rocprofv3 call runs under `timeout -k`: r03 lost 50 GPU-minutes to a profiler that kept waiting after its child had faulted.
 set -u
 TAG=${1:-r01f}
 ROOT=$(pwd)
@@ -9,10 +10,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 10 --windows 2 --no-cpu-baseline --no-hr --no-configs > $OUT/kt_bench.json 2> $OUT/kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o l2 -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_l2.err
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 10 --windows 2 --no-cpu-baseline --no-hr --no-configs > $OUT/kt_bench.json 2> $OUT/kt.err
+timeout -k 5 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_fetch.err
+timeout -k 5 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_write.err
+timeout -k 5 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o l2 -- python3 $ROOT/bench.py --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_l2.err
+# the ml-1m-shaped sampled run of the `configs` block (BASELINE configuration 2): kernel stats of its own
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_ml1m -o kt -- python3 $ROOT/bench.py --workload ml-1m --steps 100 --warmup 10 --windows 2 --no-cpu-baseline --no-hr --no-configs > $OUT/kt_ml1m_bench.json 2> $OUT/kt_ml1m.err
+cp $(find $OUT/kt_ml1m -name '*kernel_stats.csv' | head -1) $OUT/ml1m_sampled_kernel_stats.csv
 cd $ROOT
 find $OUT -name '*.csv' | head -20
 python profiles/pmc_l2.py $(find $OUT/pmc_l2 -name '*counter_collection.csv' | head -1) $OUT/pmc_l2_hit_rate.json

@@ -48,4 +48,6 @@ def test_bench_line_has_the_contracted_fields():
     m = c3['mfma_scorer']
     assert m['users'] == 2048 and m['achieved_write_GBs'] > 0 and 0.0 < m['frac_of_hbm_peak'] <= 1.0
     c5 = g['cfg5_caser_ml1m']['Caser_B4096']
-    assert c5['step_ms'] > 0 and c5['fit_windows_per_s'] > 0
+    assert c5['step_ms'] > 0 and c5['fit_windows_per_s'] > 0 and c5['fit_steady_ms_per_step'] > 0
+    c5d = g['cfg5_caser_ml1m']['Caser_B4096_device_sampler']
+    assert c5d['sampler'].startswith('device') and 0 < c5d['fit_steady_ms_per_step'] < c5['fit_steady_ms_per_step']

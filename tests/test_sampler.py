@@ -366,3 +366,33 @@ def test_batch_csr_is_a_stable_counting_sort(n, T):
     if T:
         keys[T // 2] = n
         assert L.drx_batch_csr(keys.ctypes.data, T, n, ptr.ctypes.data, order.ctypes.data) == -1      # DRX_EINVAL
+
+
+def test_counter_based_list_sampler_restatement_draws_valid_windows():
+    """oracle/data_oracle.py::list_sample_counter (the CPU statement of the device list sampler's throughput mode): every draw is a
+    run of L + T consecutive records of one group in timestamp order, its negatives are distinct ids the group does not hold."""
+    from helpers import load_frames
+    from oracle import data_oracle as do
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Sampler import ListSampler
+    frame = {k: v.copy() for k, v in load_frames()['ls_int_ts'].items()}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    ds.assign_internal_ids()
+    L, T, neg = 4, 2, 3
+    s = ListSampler(ds, ['uid'], neg_ratio=neg, n_targets=T, interaction_threshold=1e-3, negative_ids_col='iid', min_positive_records=L,
+                    max_positive_records=L, sort_column='timestamp', seed=10)
+    tw = s.twin_host_arrays()
+    g, b, a = do.list_sample_counter(tw, 150, L, T, neg, 4242)
+    uid, iid, ts = ds._cols['uid'], ds._cols['iid'], ds._cols['timestamp']
+    seen_groups = set()
+    for d in range(150):
+        rows = np.flatnonzero((uid == g[d]) & (ds._cols['interaction'] >= 1e-3))
+        seq = iid[rows[np.argsort(ts[rows], kind='stable')]]
+        w = np.concatenate([b[d], a[d, :T]])
+        assert any(np.array_equal(seq[i:i + L + T], w) for i in range(len(seq) - L - T + 1)), d
+        negs = a[d, T:].tolist()
+        assert len(set(negs)) == T * neg and not (set(negs) & set(seq.tolist()))
+        seen_groups.add(int(g[d]))
+    assert len(seen_groups) > 20            # (uniform over the eligible groups, not stuck on one)
+    g2, b2, a2 = do.list_sample_counter(tw, 150, L, T, neg, 4242)
+    assert np.array_equal(a, a2) and np.array_equal(b, b2)
