@@ -16,9 +16,11 @@ __device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return (ui
 
 __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_users, int n_items, int B, int neg_ratio,
                                                          uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *deg,
-                                                         int32_t *keep_off) {
+                                                         int32_t *keep_off, int *sub_sums) {
+  __shared__ int wsum[kBlock / 64];
   const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= B) return;
+  int my_deg = 0;
+  if (b < B) {
   if (b == 0) keep_off[0] = 0;                 // the scan below fills keep_off[1..B]
   const uint32_t r0 = hash_u32(seed, (uint32_t)b, 0u);
   const bool null_pair = ((double)r0 * (1.0 / 4294967296.0)) * (double)(neg_ratio + 1) > 1.0;
@@ -44,7 +46,22 @@ __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_use
   uid[b] = u;
   iid[b] = i;
   y[b] = null_pair ? 0.0f : 1.0f;
-  deg[b] = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
+  my_deg = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
+  deg[b] = my_deg;
+  }
+  // the workgroup's degree sum (the scan's first level: one launch less on the preparation's stream)
+  if (sub_sums) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) my_deg += __shfl_xor(my_deg, m, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = my_deg;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+#pragma unroll
+      for (int i2 = 0; i2 < kBlock / 64; ++i2) t += wsum[i2];
+      sub_sums[blockIdx.x] = t;
+    }
+  }
 }
 
 // keep_off[1..B] = inclusive scan of deg[0..B) in three small launches (r03; r02 used ONE workgroup walking the batch in slabs: 54 - 80 us
@@ -71,9 +88,18 @@ __global__ __launch_bounds__(1024) void k_deg_tile_sums(const int32_t *__restric
   }
 }
 
-__global__ __launch_bounds__(64) void k_deg_spine(int *__restrict__ tsum, int n_tiles, unsigned long long *mailbox, uint32_t tag) {
+// sub (or nullptr): n_sub sums of kBlock degrees each (k_point_sample's workgroups) — a tile's sum is then taken from its kDegTile / kBlock of them
+__global__ __launch_bounds__(64) void k_deg_spine(int *__restrict__ tsum, int n_tiles, unsigned long long *mailbox, uint32_t tag,
+                                                  const int *__restrict__ sub, int n_sub) {
   const int lane = threadIdx.x;
-  const int x = lane < n_tiles ? tsum[lane] : 0;
+  int x = 0;
+  if (sub) {
+    constexpr int PER = kDegTile / kBlock;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) x += (lane * PER + q < n_sub) ? sub[lane * PER + q] : 0;
+  } else {
+    x = lane < n_tiles ? tsum[lane] : 0;
+  }
   int inc = x;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
@@ -148,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_row_lengths(const int64_t *__restric
 
 extern "C" size_t drx_point_sample_scratch_bytes(int32_t B) {
   if (B < 1) return 0;
-  return drx::align_up((size_t)B * 4, 256) + 256 + 256;        // degrees, then 64 tile sums
+  return drx::align_up((size_t)B * 4, 256) + 256 + 256 + 4096;        // degrees, then 64 tile sums, then 1024 workgroup sums
 }
 
 extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
@@ -161,13 +187,13 @@ extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t
   if (scratch_bytes < drx_point_sample_scratch_bytes(B)) return DRX_ESCRATCH;
   hipStream_t st = (hipStream_t)stream;
   int32_t *deg = (int32_t *)scratch;
-  hipLaunchKernelGGL(k_point_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, *hist, n_users, n_items, B,
-                     neg_ratio, seed, uid, iid, y, deg, keep_off);
-  const int n_tiles = (B + kDegTile - 1) / kDegTile;
+  const int n_tiles = (B + kDegTile - 1) / kDegTile, n_sub = (B + kBlock - 1) / kBlock;
+  int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
+  int *sub = n_tiles <= 64 ? tsum + 128 : nullptr;
+  hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, n_users, n_items, B, neg_ratio, seed, uid, iid, y, deg,
+                     keep_off, sub);
   if (n_tiles <= 64) {
-    int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
-    hipLaunchKernelGGL(k_deg_tile_sums, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum);
-    hipLaunchKernelGGL(k_deg_spine, dim3(1), dim3(64), 0, st, tsum, n_tiles, (unsigned long long *)host_mailbox, tag);
+    hipLaunchKernelGGL(k_deg_spine, dim3(1), dim3(64), 0, st, tsum, n_tiles, (unsigned long long *)host_mailbox, tag, (const int *)sub, n_sub);
     hipLaunchKernelGGL(k_deg_apply, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum, keep_off);
   } else {
     hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, keep_off, (unsigned long long *)host_mailbox, tag);
@@ -190,7 +216,7 @@ extern "C" int drx_batch_offsets(const int64_t *indptr, const int32_t *ids, int3
   if (n_tiles <= 64) {
     int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
     hipLaunchKernelGGL(k_deg_tile_sums, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum);
-    hipLaunchKernelGGL(k_deg_spine, dim3(1), dim3(64), 0, st, tsum, n_tiles, (unsigned long long *)nullptr, 0u);
+    hipLaunchKernelGGL(k_deg_spine, dim3(1), dim3(64), 0, st, tsum, n_tiles, (unsigned long long *)nullptr, 0u, (const int *)nullptr, 0);
     hipLaunchKernelGGL(k_deg_apply, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum, off);
   } else {
     hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, off, (unsigned long long *)nullptr, 0u);

@@ -25,9 +25,15 @@
 
 namespace drx {
 
-constexpr int kSortThreads = 512;
+#ifndef DRX_SORT_THREADS
+#define DRX_SORT_THREADS 512
+#endif
+#ifndef DRX_SORT_IPT
+#define DRX_SORT_IPT 8
+#endif
+constexpr int kSortThreads = DRX_SORT_THREADS;
 constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kSortIPT = 8;                       // items per thread
+constexpr int kSortIPT = DRX_SORT_IPT;            // items per thread
 constexpr int kSortTile = kSortThreads * kSortIPT;
 constexpr int kMaxPasses = 4;
 constexpr uint32_t kStAgg = 1u << 30, kStIncl = 2u << 30, kCountMask = (1u << 30) - 1;
@@ -86,6 +92,7 @@ inline SortLayout sort_layout(void *temp, size_t n, const SortPlan &P) {
 __global__ __launch_bounds__(512) void k_digit_histograms(const uint32_t *__restrict__ keys, size_t n, SortPlan P, uint32_t *__restrict__ hist,
                                                           int drop_none) {
   __shared__ uint32_t h[kMaxPasses * 2048];
+  // (P.passes here = the digit positions to count: only the first when every pass counts its successor's digits itself)
   for (int i = threadIdx.x; i < P.passes * 2048; i += blockDim.x) h[i] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
@@ -113,7 +120,7 @@ template <int R>
 __global__ __launch_bounds__(kSortThreads) void k_onesweep_pass(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                                uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
                                                                const uint32_t *__restrict__ ghist, uint32_t *ticket, uint32_t *desc, uint32_t n_tiles,
-                                                               int flags) {
+                                                               int flags, uint32_t *next_hist, int next_shift) {
   constexpr int RADIX = 1 << R;
   constexpr int BPT = (RADIX + kSortThreads - 1) / kSortThreads;      // bins per thread
   extern __shared__ __align__(16) uint32_t sort_lds[];                // onesweep_lds_bytes(R): 42 / 72 / 112 KB for R = 8 / 10 / 11
@@ -121,6 +128,12 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep_pass(const uint32_t *
   uint32_t *gbase = sort_lds + kSortWaves * RADIX;  // where LDS slot i of digit d goes: gbase[d] + i
   uint32_t *lstart = gbase + RADIX;                 // start of digit d's run inside the tile
   uint32_t *skey = lstart + RADIX, *sval = skey + kSortTile;
+  // next_hist (or nullptr): this pass also counts the NEXT pass's digits of the pairs it moves — 2048 LDS words per workgroup, REP =
+  // 2048 >> R replicas of the histogram (a lane adds to replica lane % REP: skewed digits would otherwise serialise), folded into the
+  // global histogram once, when the workgroup has run out of tiles.  r03: the one kernel that counted every digit position up front
+  // took 52 us of the preparation's stream beside the training kernels; it now counts the first position only.
+  constexpr int REPB = 11 - R, REP = 1 << REPB;
+  uint32_t *nh = sval + kSortTile;
   __shared__ uint32_t s_tile, s_tile_valid;
   __shared__ uint32_t wl[kSortWaves], wg[kSortWaves];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -142,6 +155,9 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep_pass(const uint32_t *
   }
   const size_t n_in = (drop && !first) ? n_valid : n;
   n_tiles = (uint32_t)((n_in + kSortTile - 1) / kSortTile);
+  if (next_hist) {
+    for (int i = tid; i < 2048; i += kSortThreads) nh[i] = 0;      // (the first tile's barriers order this before the first add)
+  }
   // a workgroup takes tiles by ticket until none is left: a grid much smaller than the number of tiles keeps the sort's footprint on
   // the chip small (it runs beside the training kernels), and a tile's predecessors are then mostly finished when it looks back
   for (;;) {
@@ -167,6 +183,7 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep_pass(const uint32_t *
     const int idx = w * (64 * kSortIPT) + it * 64 + lane;
     const bool valid = idx < tile_n && !(drop && key[it] == DRX_KEY_NONE);
     const uint32_t d = (key[it] >> shift) & (RADIX - 1);
+    if (next_hist && valid) atomicAdd(&nh[(((key[it] >> next_shift) & (RADIX - 1)) << REPB) + (lane & (REP - 1))], 1u);
     uint64_t mask = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < R; ++b) {
@@ -296,6 +313,14 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep_pass(const uint32_t *
     vout[o] = sval[i];
   }
   }   // tiles of this workgroup
+  if (next_hist) {                                    // (the loop's exit came right after a barrier: every add of this workgroup is visible)
+    for (int d = tid; d < RADIX; d += kSortThreads) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int r = 0; r < REP; ++r) c += nh[(d << REPB) + r];
+      if (c) atomicAdd(&next_hist[d], c);
+    }
+  }
   if (drop && last)
     for (size_t i = n_valid + (size_t)blockIdx.x * kSortThreads + tid; i < n; i += (size_t)gridDim.x * kSortThreads) kout[i] = DRX_KEY_NONE;
 }
@@ -309,15 +334,15 @@ inline int sort_grid() {
   return g;
 }
 
-inline size_t onesweep_lds_bytes(int r) { return ((size_t)(kSortWaves + 2) * ((size_t)1 << r) + 2 * (size_t)kSortTile) * 4; }
+inline size_t onesweep_lds_bytes(int r) { return ((size_t)(kSortWaves + 2) * ((size_t)1 << r) + 2 * (size_t)kSortTile + 2048) * 4; }
 
 template <int R>
 static int launch_pass(const uint32_t *sk, const uint32_t *sv, uint32_t *dk, uint32_t *dv, size_t n, int shift, const uint32_t *gh, uint32_t *ticket,
-                       uint32_t *desc, int tiles, int flags, hipStream_t stream) {
+                       uint32_t *desc, int tiles, int flags, uint32_t *next_hist, int next_shift, hipStream_t stream) {
   const size_t lds = onesweep_lds_bytes(R);
   if (lds > 48 * 1024) DRX_HIP(hipFuncSetAttribute((const void *)k_onesweep_pass<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_onesweep_pass<R>, dim3(tiles < sort_grid() ? tiles : sort_grid()), dim3(kSortThreads), lds, stream, sk, sv, dk, dv, n, shift, gh,
-                     ticket, desc, (uint32_t)tiles, flags);
+                     ticket, desc, (uint32_t)tiles, flags, next_hist, next_shift);
   return 0;
 }
 
@@ -337,7 +362,9 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
   DRX_HIP(hipMemsetAsync(t + L.zero_begin, 0, L.zero_bytes, stream));
   int hgrid = (int)((n + 8 * 512 - 1) / (8 * 512));
   if (hgrid > sort_grid()) hgrid = sort_grid();
-  hipLaunchKernelGGL(k_digit_histograms, dim3(hgrid), dim3(512), 0, stream, kin, n, P, L.hist, drop_none ? 1 : 0);
+  SortPlan P1 = P;
+  P1.passes = 1;                                               // every pass counts its successor's digits while it moves the pairs
+  hipLaunchKernelGGL(k_digit_histograms, dim3(hgrid), dim3(512), 0, stream, kin, n, P1, L.hist, drop_none ? 1 : 0);
   const uint32_t *src_k = kin, *src_v = vin;
   uint32_t *desc = L.desc;
   for (int p = 0; p < P.passes; ++p) {
@@ -346,9 +373,11 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
     const uint32_t *gh = L.hist + (size_t)p * 2048;
     const int flags = (drop_none ? kDropNone : 0) | (p == 0 ? kFirstPass : 0) | (p == P.passes - 1 ? kLastPass : 0);
     int rc;
-    if (P.rbits[p] == 8) rc = launch_pass<8>(src_k, src_v, dk, dv, n, P.shift[p], gh, L.ticket + p, desc, L.tiles, flags, stream);
-    else if (P.rbits[p] == 10) rc = launch_pass<10>(src_k, src_v, dk, dv, n, P.shift[p], gh, L.ticket + p, desc, L.tiles, flags, stream);
-    else rc = launch_pass<11>(src_k, src_v, dk, dv, n, P.shift[p], gh, L.ticket + p, desc, L.tiles, flags, stream);
+    uint32_t *nh = p + 1 < P.passes ? L.hist + (size_t)(p + 1) * 2048 : nullptr;
+    const int ns = p + 1 < P.passes ? P.shift[p + 1] : 0;
+    if (P.rbits[p] == 8) rc = launch_pass<8>(src_k, src_v, dk, dv, n, P.shift[p], gh, L.ticket + p, desc, L.tiles, flags, nh, ns, stream);
+    else if (P.rbits[p] == 10) rc = launch_pass<10>(src_k, src_v, dk, dv, n, P.shift[p], gh, L.ticket + p, desc, L.tiles, flags, nh, ns, stream);
+    else rc = launch_pass<11>(src_k, src_v, dk, dv, n, P.shift[p], gh, L.ticket + p, desc, L.tiles, flags, nh, ns, stream);
     if (rc) return rc;
     desc += (size_t)L.tiles << P.rbits[p];
     src_k = dk; src_v = dv;
