@@ -730,10 +730,11 @@ __global__ __launch_bounds__(1024) void k_degree_counts(const int32_t *__restric
     if (cnt[i]) atomicAdd(&work[i], cnt[i]);
 }
 
-__global__ __launch_bounds__(1024) void k_degree_scatter(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
-                                                         int32_t *__restrict__ order) {
-  __shared__ unsigned int start[256], cnt[256], base[256];
-  for (int i = threadIdx.x; i < 256; i += 1024) cnt[i] = 0;
+template <int NT>
+__device__ __forceinline__ void degree_scatter_body(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
+                                                    int32_t *__restrict__ order, int block_id, unsigned int *lds /* [768] */) {
+  unsigned int *start = lds, *cnt = lds + 256, *base = lds + 512;
+  for (int i = threadIdx.x; i < 256; i += NT) cnt[i] = 0;
   if (threadIdx.x < 64) {                            // exclusive scan of the 256 global counts by one wave: 4 bins per lane
     unsigned int c[4], sum = 0;
 #pragma unroll
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(1024) void k_degree_scatter(const int32_t *__restri
     for (int q = 0; q < 4; ++q) { start[threadIdx.x * 4 + q] = run; run += c[q]; }
   }
   __syncthreads();
-  const int b = blockIdx.x * 1024 + (int)threadIdx.x, lane = threadIdx.x & 63;
+  const int b = block_id * NT + (int)threadIdx.x, lane = threadIdx.x & 63;
   const bool valid = b < B;
   const int d = valid ? degree_bucket(keep_off, b) : 0;
   const unsigned long long m = same_bucket_lanes(valid, d);
@@ -755,9 +756,15 @@ __global__ __launch_bounds__(1024) void k_degree_scatter(const int32_t *__restri
   if (valid && lane == leader) at = atomicAdd(&cnt[d], (unsigned int)__popcll(m));        // place inside this workgroup's share
   at = __shfl(at, leader);
   __syncthreads();
-  for (int i = threadIdx.x; i < 256; i += 1024) base[i] = cnt[i] ? atomicAdd(&work[256 + i], cnt[i]) : 0u;     // the share's place in the bucket
+  for (int i = threadIdx.x; i < 256; i += NT) base[i] = cnt[i] ? atomicAdd(&work[256 + i], cnt[i]) : 0u;     // the share's place in the bucket
   __syncthreads();
   if (valid) order[start[d] + base[d] + at + __popcll(m & ((1ull << lane) - 1ull))] = b;
+}
+
+__global__ __launch_bounds__(1024) void k_degree_scatter(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
+                                                         int32_t *__restrict__ order) {
+  __shared__ unsigned int lds[768];
+  degree_scatter_body<1024>(keep_off, B, work, order, (int)blockIdx.x, lds);
 }
 
 // V and W2T rows are mostly touched by ONE sample of the batch (a user is drawn once, output items are uniform), and so are the W
@@ -787,12 +794,21 @@ __global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_
 // pipeline's bound once the training kernels got faster — a launch gap and 15 us): the first n_chunks threads plan their chunk, then
 // every thread marks its share of the touches.  The two do not disturb each other: a key that is blanked has one touch, a key whose
 // run the plan measures crosses a chunk border (>= 2 touches), and the plan's searches only test keys for equality with such a key.
+// order_blocks workgroups behind the plan's: the scatter half of the launch order (k_degree_scatter's work, 256 triples each; the
+// counts were taken before the sort) — one launch less for the preparation's stream to wait for.
 __global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, int n_chunks, int cpb,
                                                        SpanPlan P, uint32_t n_items, int B, uint8_t *solo_v, uint8_t *solo_o,
-                                                       uint32_t *solo_w) {
+                                                       uint32_t *solo_w, int order_blocks, const int32_t *keep_off, unsigned int *order_work,
+                                                       int32_t *order) {
+  const int plan_blocks = (int)gridDim.x - order_blocks;
+  if ((int)blockIdx.x >= plan_blocks) {
+    __shared__ unsigned int lds[768];
+    degree_scatter_body<256>(keep_off, B, order_work, order, (int)blockIdx.x - plan_blocks, lds);
+    return;
+  }
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
-  for (int j = tid; j < T; j += gridDim.x * blockDim.x) {
+  for (int j = tid; j < T; j += plan_blocks * blockDim.x) {
     const uint32_t k = keys_s[j];
     if (k == DRX_KEY_NONE || (k < n_items && !solo_w)) continue;
     const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
@@ -2061,11 +2077,11 @@ static int plan_spans(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs
 }
 
 // (see k_degree_counts)
-static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
+static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared, bool scatter = true) {
   if (!cleared) (void)hipMemsetAsync(R.order_work, 0, 512 * sizeof(unsigned int), st);
   const int blocks = (bt->B + 1023) / 1024;
   hipLaunchKernelGGL(k_degree_counts, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work);
-  hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
+  if (scatter) hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
 }
 
 // W rows get sole-toucher marks when the caller asks for them (DRX_BATCH_MARK_W: worth it where a batch leaves most of its distinct
@@ -2088,6 +2104,8 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
                      q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w, R.plan.cnt, plan_zero_words(R), R.order_work, 512,
                      hashed ? R.vslot : nullptr);
+  const bool fused_order = with_marks && p->ld > 16;       // the launch order's scatter rides in the plan + marks launch below
+  if (fused_order) order_by_degree(bt, R, st, true, false);            // (its counts: any time after the touch kernel cleared them)
   // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
   const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, hashed ? R.bits_hashed : R.bits,
                                true, st);
@@ -2098,8 +2116,10 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
     const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
     SpanPlan plan = R.plan;
     plan.hot_min = plan_hot_min(R.T, bt->flags);
-    hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks, kSegBlock / pick_geom(p->ld).G,
-                       plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, mark_w_rows(p, bt) ? R.solo_w : nullptr);
+    const int order_blocks = (bt->B + 255) / 256;
+    hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks + order_blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
+                       kSegBlock / pick_geom(p->ld).G, plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o,
+                       mark_w_rows(p, bt) ? R.solo_w : nullptr, order_blocks, bt->keep_off, R.order_work, R.order);
     if (plan.hot_min != 0x7FFFFFFF)
       hipLaunchKernelGGL(k_hot_bounds, dim3((kMaxHot * (kHotTiles + 1) + 255) / 256), dim3(256), 0, st, R.vals_s, plan,
                          (bt->B + kHotTiles - 1) / kHotTiles);
@@ -2254,9 +2274,9 @@ int drx_cdae_sparse_prepare(const DrxCdaeParams *p, const DrxHistory *hist, cons
   Carver cp(prepared, prepared_bytes);
   PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
   if (!cp.ok()) return DRX_ESCRATCH;
-  rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream, true);      // touches, sort, span plan + sole-toucher marks
+  rc = prepare_impl(p, hist, bt, R, (hipStream_t)stream, true);      // touches, sort, span plan + sole-toucher marks (+ launch order)
   if (rc) return rc;
-  order_by_degree(bt, R, (hipStream_t)stream, true);
+  if (p->ld <= 16) order_by_degree(bt, R, (hipStream_t)stream, true);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

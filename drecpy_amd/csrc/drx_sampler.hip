@@ -129,6 +129,38 @@ __global__ __launch_bounds__(1024) void k_deg_apply(const int32_t *__restrict__ 
     if (base + q < B) keep_off[base + q + 1] = v[q] + off;
 }
 
+// k_deg_apply with the spine folded in (r03: a launch on the preparation's stream waits 10 - 30 us for room beside the training kernels
+// whatever it computes): a tile's workgroup sums the workgroup sums of k_point_sample that lie before it itself — at most 1024 of
+// them — and the last tile posts the total.
+__global__ __launch_bounds__(1024) void k_deg_apply_sub(const int32_t *__restrict__ deg, int B, const int *__restrict__ sub, int n_sub,
+                                                        int32_t *__restrict__ keep_off, unsigned long long *mailbox, uint32_t tag) {
+  __shared__ int wsum[16], wpre[16];
+  const int base = blockIdx.x * kDegTile + (int)threadIdx.x * 4, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int PER = kDegTile / kBlock;
+  const int n_before = min(n_sub, (int)blockIdx.x * PER);
+  int pre = (int)threadIdx.x < n_before ? sub[threadIdx.x] : 0;          // (n_sub <= 1024)
+  int v[4], sum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { sum += base + q < B ? deg[base + q] : 0; v[q] = sum; }
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m, 64);
+  if (lane == 63) wsum[w] = inc;
+  if (lane == 0) wpre[w] = pre;
+  __syncthreads();
+  int off = inc - sum;
+#pragma unroll
+  for (int ww = 0; ww < 16; ++ww) off += wpre[ww] + (ww < w ? wsum[ww] : 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (base + q < B) keep_off[base + q + 1] = v[q] + off;
+  if (mailbox && blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023)
+    __hip_atomic_store(mailbox, ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)(off + sum), __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // (the one-workgroup form: any batch size)
 __global__ __launch_bounds__(1024) void k_scan_degrees(const int32_t *__restrict__ deg, int B, int32_t *__restrict__ keep_off,
                                                        unsigned long long *mailbox, uint32_t tag) {
@@ -193,8 +225,8 @@ extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t
   hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, n_users, n_items, B, neg_ratio, seed, uid, iid, y, deg,
                      keep_off, sub);
   if (n_tiles <= 64) {
-    hipLaunchKernelGGL(k_deg_spine, dim3(1), dim3(64), 0, st, tsum, n_tiles, (unsigned long long *)host_mailbox, tag, (const int *)sub, n_sub);
-    hipLaunchKernelGGL(k_deg_apply, dim3(n_tiles), dim3(1024), 0, st, deg, B, tsum, keep_off);
+    hipLaunchKernelGGL(k_deg_apply_sub, dim3(n_tiles), dim3(1024), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
+                       (unsigned long long *)host_mailbox, tag);
   } else {
     hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, keep_off, (unsigned long long *)host_mailbox, tag);
   }
