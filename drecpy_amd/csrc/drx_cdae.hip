@@ -633,7 +633,8 @@ __global__ __launch_bounds__(kBlock) void k_user_slots(const int32_t *__restrict
 // the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
 __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
                                                            uint32_t *vals, int T, uint8_t *solo, uint32_t *solo_w, uint32_t *zero_a,
-                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b, const uint32_t *__restrict__ vslot) {
+                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b, const uint32_t *__restrict__ vslot,
+                                                           uint32_t *zero_c, int n_zero_c) {
   constexpr int G = 16;
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHisto
   // (word 2 of the first range = "the V keys are table slots")
   for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_a; w += gridDim.x * kBlock) zero_a[w] = (w == 2 && vslot) ? 1u : 0u;
   for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_b; w += gridDim.x * kBlock) zero_b[w] = 0u;
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_c; w += gridDim.x * kBlock) zero_c[w] = 0u;      // (the sort's counters and tile words)
   if (b >= bt.B) return;
   if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; solo[2 * (size_t)bt.B + b] = 0; }
   if (b == bt.B - 1)
@@ -2101,14 +2103,17 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
     hipLaunchKernelGGL(k_user_slots, dim3((bt->B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, bt->uid, bt->B, R.vtab, (uint32_t)(R.vt - 1),
                        R.vslot);
   }
+  uint32_t *sort_zero = nullptr;
+  size_t sort_zero_words = 0;
+  sort_pairs_zero_region(R.sort_temp, (size_t)R.T, hashed ? R.bits_hashed : R.bits, &sort_zero, &sort_zero_words);
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
                      q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w, R.plan.cnt, plan_zero_words(R), R.order_work, 512,
-                     hashed ? R.vslot : nullptr);
+                     hashed ? R.vslot : nullptr, sort_zero, (int)sort_zero_words);
   const bool fused_order = with_marks && p->ld > 16;       // the launch order's scatter rides in the plan + marks launch below
   if (fused_order) order_by_degree(bt, R, st, true, false);            // (its counts: any time after the touch kernel cleared them)
   // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
   const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, hashed ? R.bits_hashed : R.bits,
-                               true, st);
+                               true, st, true);
   if (rc) return rc;
   // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
   // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion

@@ -139,8 +139,11 @@ size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                uint32_t *vout, size_t n, int end_bit, hipStream_t stream);
 // drop_none: pairs with key DRX_KEY_NONE take no part (kout = the sorted pairs, then DRX_KEY_NONE up to n; their vals are not written).
+// pre_zeroed: the caller has already cleared the words sort_pairs_zero_region names (a kernel of its own that runs before the sort
+// anyway: one launch less on the stream).
 int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int end_bit,
-                  bool drop_none, hipStream_t stream);
+                  bool drop_none, hipStream_t stream, bool pre_zeroed = false);
+void sort_pairs_zero_region(void *temp, size_t n, int end_bit, uint32_t **words, size_t *n_words);
 
 inline int bits_for(uint64_t max_key_exclusive) {
   int b = 1;

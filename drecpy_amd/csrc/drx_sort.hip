@@ -351,15 +351,23 @@ size_t sort_pairs_temp_bytes(size_t n, int end_bit) {
   return sort_layout(nullptr, n ? n : 1, P).total + 256;
 }
 
+void sort_pairs_zero_region(void *temp, size_t n, int end_bit, uint32_t **words, size_t *n_words) {
+  const SortPlan P = sort_plan(end_bit);
+  char *t = (char *)align_up((size_t)temp, 256);
+  const SortLayout L = sort_layout(t, n ? n : 1, P);
+  *words = (uint32_t *)(t + L.zero_begin);
+  *n_words = L.zero_bytes / 4;
+}
+
 int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int end_bit,
-                  bool drop_none, hipStream_t stream) {
+                  bool drop_none, hipStream_t stream, bool pre_zeroed) {
   if (n == 0) return 0;
   if (n >= (1u << 30)) return DRX_EINVAL;                      // tile words carry 30-bit counts
   const SortPlan P = sort_plan(end_bit);
   char *t = (char *)align_up((size_t)temp, 256);
   const SortLayout L = sort_layout(t, n, P);
   if ((size_t)(t - (char *)temp) + L.total > temp_bytes) return DRX_ESCRATCH;
-  DRX_HIP(hipMemsetAsync(t + L.zero_begin, 0, L.zero_bytes, stream));
+  if (!pre_zeroed) DRX_HIP(hipMemsetAsync(t + L.zero_begin, 0, L.zero_bytes, stream));
   int hgrid = (int)((n + 8 * 512 - 1) / (8 * 512));
   if (hgrid > sort_grid()) hgrid = sort_grid();
   SortPlan P1 = P;
