@@ -702,34 +702,10 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
 // scatter), each workgroup over 1024 triples; `work` = 512 zeroed ints (k_sparse_touches clears them).  A first version did it all
 // in ONE workgroup: 152 us of side-stream time per step, which made the preparation — not the training — the pipeline's bound.
 // The order inside a bucket comes from atomics and differs from run to run: it decides only WHERE a triple is computed, never a result.
-__device__ __forceinline__ int degree_bucket(const int32_t *keep_off, int b) {
-  const int d = (keep_off[b + 1] - keep_off[b]) >> 2;
-  return 255 - (d > 255 ? 255 : d);                  // descending
-}
-
-__device__ __forceinline__ unsigned long long same_bucket_lanes(bool valid, int d) {
-  unsigned long long m = __ballot(valid);
-#pragma unroll
-  for (int bit = 0; bit < 8; ++bit) {
-    const bool one = (d >> bit) & 1;
-    const unsigned long long bl = __ballot(one);
-    m &= one ? bl : ~bl;
-  }
-  return m;
-}
-
+// (degree_bucket / same_bucket_lanes / degree_counts_body: drx_common.hpp — the counts can ride in the sort's first launch)
 __global__ __launch_bounds__(1024) void k_degree_counts(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work) {
   __shared__ unsigned int cnt[256];
-  for (int i = threadIdx.x; i < 256; i += 1024) cnt[i] = 0;
-  __syncthreads();
-  const int b = blockIdx.x * 1024 + (int)threadIdx.x, lane = threadIdx.x & 63;
-  const bool valid = b < B;
-  const int d = valid ? degree_bucket(keep_off, b) : 0;
-  const unsigned long long m = same_bucket_lanes(valid, d);
-  if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&cnt[d], (unsigned int)__popcll(m));
-  __syncthreads();
-  for (int i = threadIdx.x; i < 256; i += 1024)
-    if (cnt[i]) atomicAdd(&work[i], cnt[i]);
+  degree_counts_body<1024>(keep_off, B, work, (int)blockIdx.x, cnt);
 }
 
 template <int NT>
@@ -2079,11 +2055,11 @@ static int plan_spans(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs
 }
 
 // (see k_degree_counts)
-static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared, bool scatter = true) {
+static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
   if (!cleared) (void)hipMemsetAsync(R.order_work, 0, 512 * sizeof(unsigned int), st);
   const int blocks = (bt->B + 1023) / 1024;
   hipLaunchKernelGGL(k_degree_counts, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work);
-  if (scatter) hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
+  hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
 }
 
 // W rows get sole-toucher marks when the caller asks for them (DRX_BATCH_MARK_W: worth it where a batch leaves most of its distinct
@@ -2109,11 +2085,12 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
                      q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w, R.plan.cnt, plan_zero_words(R), R.order_work, 512,
                      hashed ? R.vslot : nullptr, sort_zero, (int)sort_zero_words);
-  const bool fused_order = with_marks && p->ld > 16;       // the launch order's scatter rides in the plan + marks launch below
-  if (fused_order) order_by_degree(bt, R, st, true, false);            // (its counts: any time after the touch kernel cleared them)
+  // the launch order (see k_degree_counts): its counts ride in the sort's first launch, its scatter in the plan + marks launch below
+  const bool fused_order = with_marks && p->ld > 16;
+  const SortRider rider{fused_order ? bt->keep_off : nullptr, bt->B, R.order_work};
   // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
   const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, hashed ? R.bits_hashed : R.bits,
-                               true, st, true);
+                               true, st, true, rider);
   if (rc) return rc;
   // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
   // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion

@@ -139,10 +139,51 @@ size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                uint32_t *vout, size_t n, int end_bit, hipStream_t stream);
 // drop_none: pairs with key DRX_KEY_NONE take no part (kout = the sorted pairs, then DRX_KEY_NONE up to n; their vals are not written).
+// Launch order of the sampled forward kernel (drx_cdae.hip: k_degree_counts): the bucket of a triple's history length, the lanes of a
+// wave that share a bucket, and the counting half of the counting sort — here because the counts may ride in the sort's first launch.
+__device__ __forceinline__ int degree_bucket(const int32_t *keep_off, int b) {
+  const int d = (keep_off[b + 1] - keep_off[b]) >> 2;
+  return 255 - (d > 255 ? 255 : d);                  // descending
+}
+
+__device__ __forceinline__ unsigned long long same_bucket_lanes(bool valid, int d) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const bool one = (d >> bit) & 1;
+    const unsigned long long bl = __ballot(one);
+    m &= one ? bl : ~bl;
+  }
+  return m;
+}
+
+template <int NT>
+__device__ __forceinline__ void degree_counts_body(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work, int block_id,
+                                                   unsigned int *cnt /* LDS [256] */) {
+  for (int i = threadIdx.x; i < 256; i += NT) cnt[i] = 0;
+  __syncthreads();
+  const int b = block_id * NT + (int)threadIdx.x, lane = threadIdx.x & 63;
+  const bool valid = b < B;
+  const int d = valid ? degree_bucket(keep_off, b) : 0;
+  const unsigned long long m = same_bucket_lanes(valid, d);
+  if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&cnt[d], (unsigned int)__popcll(m));
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += NT)
+    if (cnt[i]) atomicAdd(&work[i], cnt[i]);
+}
+
+// Optional work that rides in the sort's first launch as extra workgroups (a launch on a stream that shares the chip with the training
+// kernels waits 10 - 30 us for room whatever it computes): the degree-bucket counts of a batch.  keep_off == nullptr: none.
+struct SortRider {
+  const int32_t *keep_off;
+  int B;
+  unsigned int *counts;      // [256], zero on entry
+};
+
 // pre_zeroed: the caller has already cleared the words sort_pairs_zero_region names (a kernel of its own that runs before the sort
 // anyway: one launch less on the stream).
 int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int end_bit,
-                  bool drop_none, hipStream_t stream, bool pre_zeroed = false);
+                  bool drop_none, hipStream_t stream, bool pre_zeroed = false, SortRider rider = SortRider{nullptr, 0, nullptr});
 void sort_pairs_zero_region(void *temp, size_t n, int end_bit, uint32_t **words, size_t *n_words);
 
 inline int bits_for(uint64_t max_key_exclusive) {

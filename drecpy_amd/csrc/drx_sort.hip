@@ -90,13 +90,18 @@ inline SortLayout sort_layout(void *temp, size_t n, const SortPlan &P) {
 // lane by lane; each digit's 2048 words hold REP = 2048 >> rbits REPLICAS of its histogram, a lane adds to replica lane % REP (8-bit
 // digits: 8 replicas, an eighth of the conflicts; r03: 45 - 60 us of the preparation's stream).
 __global__ __launch_bounds__(512) void k_digit_histograms(const uint32_t *__restrict__ keys, size_t n, SortPlan P, uint32_t *__restrict__ hist,
-                                                          int drop_none) {
+                                                          int drop_none, SortRider rider, int rider_blocks) {
   __shared__ uint32_t h[kMaxPasses * 2048];
+  if ((int)blockIdx.x >= (int)gridDim.x - rider_blocks) {          // (the caller's extra work: see SortRider)
+    degree_counts_body<512>(rider.keep_off, rider.B, rider.counts, (int)blockIdx.x - ((int)gridDim.x - rider_blocks), h);
+    return;
+  }
+  const size_t hist_threads = (size_t)((int)gridDim.x - rider_blocks) * blockDim.x;
   // (P.passes here = the digit positions to count: only the first when every pass counts its successor's digits itself)
   for (int i = threadIdx.x; i < P.passes * 2048; i += blockDim.x) h[i] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += hist_threads) {
     const uint32_t k = keys[i];
     if (drop_none && k == DRX_KEY_NONE) continue;
     for (int p = 0; p < P.passes; ++p) {
@@ -360,7 +365,7 @@ void sort_pairs_zero_region(void *temp, size_t n, int end_bit, uint32_t **words,
 }
 
 int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int end_bit,
-                  bool drop_none, hipStream_t stream, bool pre_zeroed) {
+                  bool drop_none, hipStream_t stream, bool pre_zeroed, SortRider rider) {
   if (n == 0) return 0;
   if (n >= (1u << 30)) return DRX_EINVAL;                      // tile words carry 30-bit counts
   const SortPlan P = sort_plan(end_bit);
@@ -372,7 +377,9 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
   if (hgrid > sort_grid()) hgrid = sort_grid();
   SortPlan P1 = P;
   P1.passes = 1;                                               // every pass counts its successor's digits while it moves the pairs
-  hipLaunchKernelGGL(k_digit_histograms, dim3(hgrid), dim3(512), 0, stream, kin, n, P1, L.hist, drop_none ? 1 : 0);
+  const int rider_blocks = rider.keep_off ? (rider.B + 511) / 512 : 0;
+  hipLaunchKernelGGL(k_digit_histograms, dim3(hgrid + rider_blocks), dim3(512), 0, stream, kin, n, P1, L.hist, drop_none ? 1 : 0, rider,
+                     rider_blocks);
   const uint32_t *src_k = kin, *src_v = vin;
   uint32_t *desc = L.desc;
   for (int p = 0; p < P.passes; ++p) {
