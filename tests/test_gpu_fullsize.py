@@ -86,3 +86,32 @@ def test_sharded_world1_agrees_with_direct_at_scale():
     torch.cuda.synchronize()
     for name, x, y in zip(('W', 'W2T', 'V', 'b', 'b2'), eng.tables(), m.engine.tables()):
         assert float((x - y).abs().max()) < 2e-6, name        # same sums, different chunking of the sorted touches
+
+
+def test_pipeline_batches_are_the_draws_of_their_seeds_while_the_callers_stream_is_busy():
+    """SampledPipeline's first run-ahead draws must not share anything with work on the caller's stream (r03: placeholder draws queued
+    there used the same sampler scratch and ring tensors, and whichever ran last won — a batch whose offsets belonged to another draw
+    than its users).  The caller's stream is kept busy while the pipeline is built; every batch it then trains on must be the draw of
+    its own seed, and its touch count the sum of its users' history lengths."""
+    from drecpy_amd.engine import SampledPipeline
+    eng, U, N, ip, idx = _setup('synth-10m', users=200_000)
+    B = 8192
+    seed_of = lambda s: 4242 + 31 * s
+    x = torch.randn(4096, 4096, device='cuda')
+    for _ in range(60):                                  # tens of milliseconds of queued work on the caller's stream
+        x = (x @ x).clamp_(-1, 1)
+    pipe = SampledPipeline(eng, B, 5, 0.2, seed_of, seed_of, n_items=N)
+    n_first = pipe.SA
+    counts = [pipe._touch_count(s % pipe.RS, s) for s in range(n_first)]
+    torch.cuda.synchronize()
+    ring = [[t.clone() for t in pipe.ring[s % pipe.RS]] for s in range(n_first)]
+    for s in range(n_first):
+        want = eng.sample_device(B, 5, seed_of(s), n_items=N)
+        torch.cuda.synchronize()
+        for got, w in zip(ring[s], want):
+            assert torch.equal(got, w), s
+        assert counts[s] == int(want[3][-1].item()), s
+    for _ in range(6):                                   # and the pipeline trains on from there
+        pipe.run_step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.W).all())
