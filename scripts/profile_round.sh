@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU-box call: bench line + kernel-trace stats + the two PMC passes (separate runs, per the microarch guide).
-# Usage (through gpurun): bash scripts/profile_round.sh <tag>
+# Usage (through gpurun): bash scripts/profile_round.sh <tag>; afterwards, HERE: cp gpurun_out/<tag>/pmc_traffic.json profiles/pmc_traffic.json
+# (the copy made below lands on the GPU box only; tests/test_bench_launcher.py checks the committed file against the kernel sources)
 # Every rocprofv3 call runs under `timeout -k`: r03 lost 50 GPU-minutes to a profiler that kept waiting after its child had faulted.
 set -u
 TAG=${1:-r01f}

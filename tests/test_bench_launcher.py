@@ -62,3 +62,18 @@ def test_a_failing_layout_is_reported_not_fatal(tmp_path):
                          capture_output=True, text=True, timeout=400)
     d = _one_line(out.stdout)
     assert out.returncode != 0 and d['value'] is None and 'error' in d['layouts']['columns']
+
+
+def test_pmc_traffic_profile_was_taken_on_these_kernel_sources():
+    """bench.py quotes profiles/pmc_traffic.json only when its kernel-source hash equals the tree's; a stale file means the driver's line
+    carries `traffic: null` (it happened in r03: the passes were re-taken on the GPU box and only the per-round copy was committed).
+    Re-run scripts/profile_round.sh and copy gpurun_out/<tag>/pmc_traffic.json to profiles/pmc_traffic.json when this fails."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, 'profiles', 'pmc_traffic.json')) as f:
+        meta = json.load(f)['_meta']
+    assert meta['kernel_source_hash'] == bench.kernel_source_hash()
