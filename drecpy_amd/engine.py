@@ -7,6 +7,8 @@ every computation to the hand-written HIP kernels through the C ABI of include/d
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -668,7 +670,7 @@ class SampledPipeline:
         self.D = D = max(1, int(prep_ahead))
         # batches are drawn one step before their list is prepared; two when lists are prepared far ahead (a draw then never
         # queues right behind a long preparation whose count the host is about to wait for)
-        self.SA = D + 1 if D == 1 else D + 2
+        self.SA = D + 1 if D == 1 else D + 2 + int(os.environ.get('DRX_SAMPLE_AHEAD_EXTRA', 0))
         self.RS, self.RP = self.SA + 1, D + 1                 # ring sizes: drawn batches, prepared lists
         # (allocated, not drawn: a draw queued HERE would run on the caller's stream beside the first run-ahead draws on the side
         # stream, sharing the sampler's scratch and these very tensors with them — r03: a batch whose row offsets belonged to another
