@@ -661,10 +661,15 @@ class SampledPipeline:
         dev = eng.device
         self.main = torch.cuda.current_stream(dev)
         # high priority: a normal stream may share a hardware queue with the training stream and inherit its barriers
-        self.side = torch.cuda.Stream(dev, priority=-1)
+        # TWO run-ahead streams, the work of step s on stream s % 2: a launch there mostly WAITS for room beside the training kernels
+        # (DESIGN.md section 3), and the waits of two independent preparations overlap — step 0.355 -> 0.347 ms; a third stream gave
+        # nothing (r03ah).  DRX_SIDE_STREAMS overrides.
+        self.sides = [torch.cuda.Stream(dev, priority=-1) for _ in range(max(1, int(os.environ.get('DRX_SIDE_STREAMS', 2))))]
+        self.side = self.sides[0]
         # what the run-ahead work reads (histories, tables' shapes) may still be in flight on the caller's stream — a history generated on
         # the device a moment ago (scripts/stamps.py hit this: the sampler read row pointers that were not written yet and faulted)
-        self.side.wait_stream(self.main)
+        for st_ in self.sides:
+            st_.wait_stream(self.main)
         if self.comm is not None:
             self.comm.wait_stream(self.main)
         self.D = D = max(1, int(prep_ahead))
@@ -704,8 +709,8 @@ class SampledPipeline:
     def _sample(self, s):
         k = s % self.RS
         if s >= self.RS:
-            self.step_ev[(s - self.RS) % self.NE].wait(self.side)   # the slot's previous batch (step s - RS) has been consumed
-        with torch.cuda.stream(self.side):
+            self.step_ev[(s - self.RS) % self.NE].wait(self.sides[s % len(self.sides)])   # the slot's previous batch (step s - RS) has been consumed
+        with torch.cuda.stream(self.sides[s % len(self.sides)]):
             self.eng.sample_device(self.B, self.neg_ratio, self.sample_seed_of(s), n_items=self.n_items, out=self.ring[k],
                                    mailbox=self.ring_T[k], tag=s + 1)
 
@@ -738,9 +743,9 @@ class SampledPipeline:
         bt = self.batch_of(s)
         k = s % self.RP
         if s >= self.RP:
-            self.step_ev[(s - self.RP) % self.NE].wait(self.side)   # the buffer's previous user (step s - RP) has finished
+            self.step_ev[(s - self.RP) % self.NE].wait(self.sides[s % len(self.sides)])   # the buffer's previous user (step s - RP) has finished
         old = self.prep[k]
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(self.sides[s % len(self.sides)]):
             if self.prepare_fn is not None:
                 self.prep[k] = self.prepare_fn(s, bt, old)
             else:
@@ -754,7 +759,7 @@ class SampledPipeline:
             if self.comm is not None:
                 old.record_stream(self.comm)
         del old
-        (self.prep_done if self.deliver_fn is None else self.built)[k].record(self.side)
+        (self.prep_done if self.deliver_fn is None else self.built)[k].record(self.sides[s % len(self.sides)])
 
     def _deliver(self, s):
         bt = self.batch_of(s)
