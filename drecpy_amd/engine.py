@@ -630,6 +630,21 @@ class StreamEvent:
             pass
 
 
+_RUN_AHEAD = {}
+
+
+def _run_ahead_streams(dev, n):
+    """The n high-priority run-ahead streams of a device, created ONCE per process: every new torch stream is the next of a pool and the
+    runtime spreads streams over a handful of hardware queues — the second pipeline of a process (bench.py's `configs` block after the
+    headline run) got two streams that shared a queue and ran the ml-1m-shaped steps at 43 instead of 61 M triples/s (r03)."""
+    dev = torch.device(dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    have = _RUN_AHEAD.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(dev, priority=-1))
+    return have[:n]
+
+
 class SampledPipeline:
     """Keeps the training stream of the sampled-output mode free of everything that does not depend on the parameters.
 
@@ -664,7 +679,7 @@ class SampledPipeline:
         # TWO run-ahead streams, the work of step s on stream s % 2: a launch there mostly WAITS for room beside the training kernels
         # (DESIGN.md section 3), and the waits of two independent preparations overlap — step 0.355 -> 0.347 ms; a third stream gave
         # nothing (r03ah).  DRX_SIDE_STREAMS overrides.
-        self.sides = [torch.cuda.Stream(dev, priority=-1) for _ in range(max(1, int(os.environ.get('DRX_SIDE_STREAMS', 2))))]
+        self.sides = _run_ahead_streams(dev, max(1, int(os.environ.get('DRX_SIDE_STREAMS', 2))))
         self.side = self.sides[0]
         # what the run-ahead work reads (histories, tables' shapes) may still be in flight on the caller's stream — a history generated on
         # the device a moment ago (scripts/stamps.py hit this: the sampler read row pointers that were not written yet and faulted)
