@@ -17,7 +17,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_REQ_sum TCC_READ_sum TCC_HIT_sum TCC_MISS_sum" \
            "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_TAG_STALL_sum"; do
   i=$((i+1))
-  STEPS=40 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o p -- python3 $ROOT/scripts/exp_events.py none > $OUT/p$i.txt 2> $OUT/p$i.err
+  STEPS=40 timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o p -- python3 $ROOT/scripts/exp_events.py none > $OUT/p$i.txt 2> $OUT/p$i.err
   tail -2 $OUT/p$i.err | cut -c1-200
 done
 cd $ROOT
