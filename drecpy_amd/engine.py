@@ -641,7 +641,7 @@ def _run_ahead_streams(dev, n):
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     have = _RUN_AHEAD.setdefault(key, [])
     while len(have) < n:
-        have.append(torch.cuda.Stream(dev, priority=-1))
+        have.append(torch.cuda.Stream(dev, priority=int(os.environ.get('DRX_SIDE_PRIORITY', -1))))
     return have[:n]
 
 
