@@ -201,6 +201,8 @@ SIGNATURES = {
     'drx_sampler_destroy': (None, [C.c_void_p]),
     'drx_cdae_kshard_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    'drx_cdae_kshard_forward_prepared': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_size_t, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]),
     'drx_cdae_kshard_step': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(History), C.POINTER(Batch), C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),

@@ -913,10 +913,12 @@ __device__ __forceinline__ void sampled_finish(const DrxCdaeParams &P, const Drx
 // ---- column-sharded ("K-sharded") step: the two halves as kernels of their own, the all-reduce of dot[] between them ----------
 template <int G, int J>
 __global__ __launch_bounds__(kBlock) void k_kshard_fwd(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale, uint32_t qthr,
-                                                       float *__restrict__ h_out, float *__restrict__ dot_out) {
+                                                       float *__restrict__ h_out, float *__restrict__ dot_out,
+                                                       const int32_t *__restrict__ order) {
   const int lane = threadIdx.x % G;
-  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (b >= bt.B) return;
+  const int slot = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (slot >= bt.B) return;
+  const int b = order ? order[slot] : slot;        // longest histories first, similar lengths side by side (k_degree_counts)
   float4 acc[J], h[J], w2[J];
   DenseAux none{};
   gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
@@ -2354,10 +2356,23 @@ int drx_cdae_step_sparse_prepared(const DrxCdaeParams *p, const DrxOptim *opt, c
 
 int drx_cdae_kshard_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, float *h_out, float *dot_partial,
                             void *stream) {
+  return drx_cdae_kshard_forward_prepared(p, hist, bt, nullptr, 0, h_out, dot_partial, stream);
+}
+
+int drx_cdae_kshard_forward_prepared(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const void *prepared,
+                                     size_t prepared_bytes, float *h_out, float *dot_partial, void *stream) {
   int rc = check_params(p);
   if (rc) return rc;
   rc = check_batch(hist, bt);
   if (rc || !bt->iid || !bt->keep_off || !h_out || !dot_partial) return DRX_EINVAL;
+  const int32_t *order = nullptr;                  // the launch order built with the prepared list (drx_cdae_sparse_prepare*)
+  if (prepared) {
+    Carver cp(const_cast<void *>(prepared), prepared_bytes);
+    const PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
+    if (!cp.ok()) return DRX_ESCRATCH;
+    static const bool use_order = [] { const char *e = getenv("DRX_FWD_ORDER"); return !e || atoi(e) != 0; }();      // (A/B switch)
+    if (use_order) order = R.order;
+  }
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / (1.0f - bt->q);
   const uint32_t qthr = q_threshold(bt->q);
@@ -2371,7 +2386,7 @@ int drx_cdae_kshard_forward(const DrxCdaeParams *p, const DrxHistory *hist, cons
                          qthr, h_out, dot_partial);                                                                    \
     else                                                                                                               \
       hipLaunchKernelGGL((k_kshard_fwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, scale, qthr, \
-                         h_out, dot_partial);                                                                          \
+                         h_out, dot_partial, order);                                                                   \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL

@@ -581,7 +581,7 @@ class ColumnShardedCdae:
 
     def step(self, step, bt, prepared=None, events=None, want_loss=False):
         e = self.engine
-        h, dot = e.kshard_forward(bt)
+        h, dot = e.kshard_forward(bt, prepared) if hasattr(e, '_params') else e.kshard_forward(bt)
         if self.collectives:
             if self.cpu_staging:
                 d = dot.cpu()

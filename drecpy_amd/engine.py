@@ -473,12 +473,14 @@ class CdaeEngine:
                                                      ptr(overflow), stream_ptr(self.device)), 'drx_cdae_sparse_prepare_assemble')
         return out, overflow
 
-    def kshard_forward(self, bt):
-        """Forward half of the column-sharded step on this engine's columns: (h [B, ld], partial dot products [B])."""
+    def kshard_forward(self, bt, prepared=None):
+        """Forward half of the column-sharded step on this engine's columns: (h [B, ld], partial dot products [B]).
+        prepared: the batch's prepared list (its launch order of history lengths is used, like the single-GPU forward kernel)."""
         h = torch.empty(bt.B, self.ld, dtype=torch.float32, device=self.device)
         d = torch.empty(bt.B, dtype=torch.float32, device=self.device)
-        check(lib().drx_cdae_kshard_forward(C.byref(self._params), C.byref(self._hist), C.byref(bt), ptr(h), ptr(d),
-                                            stream_ptr(self.device)), 'drx_cdae_kshard_forward')
+        check(lib().drx_cdae_kshard_forward_prepared(C.byref(self._params), C.byref(self._hist), C.byref(bt), ptr(prepared),
+                                                     prepared.numel() if prepared is not None else 0, ptr(h), ptr(d),
+                                                     stream_ptr(self.device)), 'drx_cdae_kshard_forward_prepared')
         return h, d
 
     def step_sparse(self, step, bt, loss='bce', want_loss=False, events=None, prepared=None, kshard=None):

@@ -220,6 +220,10 @@ int drx_list_sample_device(const DrxListGroups *g, int32_t B, int32_t n_inputs, 
  * replaced by (h, dot_total); `prepared` may be NULL (touch list built inline), `events` as in drx_cdae_step_sparse_timed. */
 int drx_cdae_kshard_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, float *h_out /* [B, ld] */,
                             float *dot_partial /* [B] */, void *stream);
+/* the same with the batch's prepared list at hand: the triples are launched in the list's order of history lengths (longest first,
+ * similar lengths side by side), like the single-GPU forward kernel; prepared == NULL: the batch's own order */
+int drx_cdae_kshard_forward_prepared(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const void *prepared,
+                                     size_t prepared_bytes, float *h_out /* [B, ld] */, float *dot_partial /* [B] */, void *stream);
 int drx_cdae_kshard_step(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt, int32_t loss_kind,
                          const float *h, const float *dot_total, const void *prepared, size_t prepared_bytes, void *scratch,
                          size_t scratch_bytes, float *loss_out, void *const *events, void *stream);
