@@ -396,3 +396,38 @@ def test_counter_based_list_sampler_restatement_draws_valid_windows():
     assert len(seen_groups) > 20            # (uniform over the eligible groups, not stuck on one)
     g2, b2, a2 = do.list_sample_counter(tw, 150, L, T, neg, 4242)
     assert np.array_equal(a, a2) and np.array_equal(b, b2)
+
+
+def test_counter_based_list_sampler_has_the_reference_samplers_distribution():
+    """The throughput-mode list sampler is a named deviation in HOW it draws (a counter-based generator, not the MT19937 stream), not in
+    WHAT: over many draws its groups, window starts and negative ids are distributed like the reference-exact sampler's (the C++ twin of
+    list_sampler.py, itself pinned to vectors recorded from the reference)."""
+    from helpers import load_frames
+    from oracle import data_oracle as do
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Sampler import ListSampler
+    frame = {k: v.copy() for k, v in load_frames()['ls_int_ts'].items()}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    ds.assign_internal_ids()
+    L, T, neg, n = 3, 1, 2, 12000
+    mk = lambda: ListSampler(ds, ['uid'], neg_ratio=neg, n_targets=T, interaction_threshold=1e-3, negative_ids_col='iid',
+                             min_positive_records=L, max_positive_records=L, sort_column='timestamp', seed=5)
+    s = mk()
+    tw = s.twin_host_arrays()
+    g_c, b_c, a_c = do.list_sample_counter(tw, n, L, T, neg, 777)
+    grp, in_off, in_rows, tg_off, tg_rows, ng_off, negs = mk().sample_group_arrays(n)
+    iid = ds._cols['iid']
+    n_groups, n_ids = len(tw['group_value']), tw['n_ids']
+    elig = set(tw['group_value'][tw['eligible']].tolist())
+    assert set(np.unique(grp).tolist()) <= elig and set(np.unique(g_c).tolist()) <= elig
+
+    def close(x, y, bins, what):
+        hx, hy = np.bincount(x, minlength=bins).astype(float), np.bincount(y, minlength=bins).astype(float)
+        live = (hx + hy) > 0
+        # two-sample chi-square statistic per degree of freedom: ~1 for samples of one distribution
+        chi = float((((hx - hy) ** 2) / (hx + hy))[live].sum() / max(1, live.sum() - 1))
+        assert chi < 1.6, (what, chi)
+    close(np.asarray(grp, np.int64), g_c.astype(np.int64), int(max(grp.max(), g_c.max())) + 1, 'groups')
+    first_ref = np.asarray(iid[in_rows], np.int64).reshape(n, L)[:, 0]
+    close(first_ref, b_c[:, 0].astype(np.int64), n_ids, 'first input id (group x window start)')
+    close(np.asarray(negs, np.int64), a_c[:, T:].reshape(-1).astype(np.int64), n_ids, 'negative ids')
