@@ -280,3 +280,40 @@ def test_quiet_fit_is_left_to_python_when_a_hook_is_replaced():
     m._sample_batch = lambda *a, **k: (seen.append('s'), orig(*a, **k))[1]
     m.fit(ds, epochs=2, batch_size=8)
     assert seen[-2:] == ['s', 's']
+
+
+def test_device_point_sampler_has_the_reference_samplers_distribution():
+    """drx_point_sample (the throughput mode's triples) against the reference-exact PointSampler stream over many draws: the share of
+    negatives, the users of positives (uniform USER, point_sampler.py:44-61), the (user, item) cells of positives and the users of
+    negatives are distributed alike (two-sample chi-square per degree of freedom ~ 1)."""
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    from drecpy_amd.Sampler import PointSampler
+    # (an implicit-feedback frame: every recorded pair is a positive.  Where a frame also records pairs BELOW the interaction threshold
+    # the two differ by definition — the reference draws its negatives among the pairs absent from the frame, the device sampler among
+    # the pairs that are not positives: include/drx.h, INTEGRATION.md)
+    frame = _frame()
+    keep = frame['interaction'] >= 1
+    frame = {k: v[keep] for k, v in frame.items()}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    model = CDAE(hidden_factors=8, mode='sampled', device_sampler=True, seed=3, verbose=False)
+    model.fit(ds, epochs=1, batch_size=64, learning_rate=0.05)
+    n = 60000
+    u, i, y, _ = model._engine.sample_device(n, 5, 99)
+    u, i, y = u.cpu().numpy().astype(np.int64), i.cpu().numpy().astype(np.int64), y.cpu().numpy()
+    ru, ri, rv, rneg = PointSampler(ds, 5, 1e-3, 11).sample_arrays(n)
+    ru, ri, rneg = np.asarray(ru, np.int64), np.asarray(ri, np.int64), np.asarray(rneg).astype(bool)
+    U, N = model.n_users, model.n_items
+    assert abs((y == 0).mean() - rneg.mean()) < 0.01
+
+    def close(x, ycol, bins, what):
+        hx, hy = np.bincount(x, minlength=bins).astype(float), np.bincount(ycol, minlength=bins).astype(float)
+        hx, hy = hx * (hy.sum() / hx.sum()), hy                       # (the two label shares differ by a fraction of a percent)
+        live = (hx + hy) > 0
+        chi = float((((hx - hy) ** 2) / (hx + hy))[live].sum() / max(1, live.sum() - 1))
+        assert chi < 1.6, (what, chi)
+    pos_d, pos_r = y == 1, ~rneg
+    close(u[pos_d], ru[pos_r], U, 'users of positives')
+    close(u[pos_d] * N + i[pos_d], ru[pos_r] * N + ri[pos_r], U * N, 'cells of positives')
+    close(u[~pos_d], ru[~pos_r], U, 'users of negatives')
+    close(i[~pos_d], ri[~pos_r], N, 'items of negatives')
