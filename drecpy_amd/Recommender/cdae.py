@@ -87,6 +87,8 @@ class CDAE(RecommenderABC):
         if weights is not None:
             m.set_params_global(**weights)
         self._dist_model, self._engine = m, m.engine
+        all_ip, all_cols, _ = ds.interaction_csr()                  # (negatives avoid every recorded pair: see _pre_fit)
+        m.engine.set_recorded_pairs(*((all_ip, all_cols) if len(all_cols) != len(self._hist_indices) else (None, None)))
         self._pipeline = self._pending = None
         self._register_tables()
         self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
@@ -151,6 +153,10 @@ class CDAE(RecommenderABC):
         self._hist_indptr, self._hist_indices = ds.positives_csr(self.interaction_threshold)
         self._max_degree = int(np.diff(self._hist_indptr).max()) if len(self._hist_indptr) > 1 else 0
         self._engine.set_history(self._hist_indptr, self._hist_indices)
+        # the device PointSampler draws negatives among the pairs ABSENT from the frame (point_sampler.py:56): where the frame records
+        # pairs below the threshold too, it needs the CSR of every recorded pair
+        all_ip, all_cols, _ = ds.interaction_csr()
+        self._engine.set_recorded_pairs(*((all_ip, all_cols) if len(all_cols) != len(self._hist_indices) else (None, None)))
         if self.mode == 'reference':
             self._engine.init_optimizer('adam', learning_rate, reg_rate)
         else:

@@ -126,6 +126,9 @@ SIGNATURES = {
     'drx_point_sample': (C.c_int, [C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                    C.c_void_p]),
+    'drx_point_sample_recorded': (C.c_int, [C.POINTER(History), C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
+                                   C.c_void_p]),
     'drx_shard_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32]),
     'drx_shard_touches': (C.c_int, [C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

@@ -14,7 +14,9 @@ namespace drx {
 
 __device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
 
-__global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_users, int n_items, int B, int neg_ratio,
+// PR: the pairs the training set RECORDS, positives or not (point_sampler.py:56: a negative is a pair absent from the frame,
+// whatever value a recorded pair carries) — the positives' CSR itself where every recorded pair is a positive
+__global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, DrxHistory PR, int n_users, int n_items, int B, int neg_ratio,
                                                          uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *deg,
                                                          int32_t *keep_off, int *sub_sums) {
   __shared__ int wsum[kBlock / 64];
@@ -31,12 +33,13 @@ __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, int n_use
     const int64_t s = H.indptr[u], e = H.indptr[u + 1];
     if (null_pair) {
       i = (int)bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)n_items);
-      int64_t lo = s, hi = e;                  // lower_bound in the sorted row
+      const int64_t pe = PR.indptr[u + 1];
+      int64_t lo = PR.indptr[u], hi = pe;      // lower_bound in the sorted row of recorded pairs
       while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (H.indices[mid] < i) lo = mid + 1; else hi = mid;
+        if (PR.indices[mid] < i) lo = mid + 1; else hi = mid;
       }
-      if (lo == e || H.indices[lo] != i) break;
+      if (lo == pe || PR.indices[lo] != i) break;
     } else {
       if (e == s) continue;
       i = H.indices[s + bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)(e - s))];
@@ -212,7 +215,15 @@ extern "C" size_t drx_point_sample_scratch_bytes(int32_t B) {
 extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
                                 uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off, void *scratch,
                                 size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream) {
+  return drx_point_sample_recorded(hist, nullptr, n_users, n_items, B, neg_ratio, seed, uid, iid, y, keep_off, scratch, scratch_bytes,
+                                   host_mailbox, tag, stream);
+}
+
+extern "C" int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistory *recorded, int32_t n_users, int32_t n_items, int32_t B,
+                                         int32_t neg_ratio, uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
+                                         void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream) {
   using namespace drx;
+  if (recorded && (!recorded->indptr || !recorded->indices)) return DRX_EINVAL;
   if (!hist || !hist->indptr || !hist->indices || !uid || !iid || !y || !keep_off || !scratch || B < 1 || n_users < 1 ||
       n_items < 1 || neg_ratio < 0)
     return DRX_EINVAL;
@@ -222,8 +233,8 @@ extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t
   const int n_tiles = (B + kDegTile - 1) / kDegTile, n_sub = (B + kBlock - 1) / kBlock;
   int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
   int *sub = n_tiles <= 64 ? tsum + 128 : nullptr;
-  hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, n_users, n_items, B, neg_ratio, seed, uid, iid, y, deg,
-                     keep_off, sub);
+  hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, recorded ? *recorded : *hist, n_users, n_items, B, neg_ratio,
+                     seed, uid, iid, y, deg, keep_off, sub);
   if (n_tiles <= 64) {
     hipLaunchKernelGGL(k_deg_apply_sub, dim3(n_tiles), dim3(1024), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
                        (unsigned long long *)host_mailbox, tag);

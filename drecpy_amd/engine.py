@@ -124,6 +124,20 @@ class CdaeEngine:
                     dst.copy_(src)
 
     # ---- training-set positives (CSR) ---------------------------------------------------------
+    def set_recorded_pairs(self, indptr, indices):
+        """CSR (columns ascending) of EVERY (user, item) pair the training set records, whatever its value: the device PointSampler then
+        draws its negatives among the pairs ABSENT from the frame, as the reference does (point_sampler.py:56), instead of among the
+        non-positives.  Only needed where the frame records pairs below the interaction threshold; None = the positives."""
+        if indptr is None:
+            self._recorded = None
+            return
+        ip = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device)
+        ix = torch.as_tensor(np.asarray(indices, dtype=np.int32)).to(self.device)
+        if ix.numel() == 0:
+            ix = torch.zeros(1, dtype=torch.int32, device=self.device)
+        assert ip.numel() == self.n_users + 1
+        self._recorded = (History(ptr(ip), ptr(ix)), ip, ix)
+
     def set_history(self, indptr, indices):
         self.hist_indptr = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device) \
             if not torch.is_tensor(indptr) else indptr.to(self.device, torch.int64)
@@ -528,11 +542,12 @@ class CdaeEngine:
         if pool.get(key) is None or pool[key].numel() < need:
             pool[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         scratch = pool[key]
-        check(lib().drx_point_sample(C.byref(self._hist), self.n_users, n_items or self.n_items, B, neg_ratio,
-                                     int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y), ptr(keep_off),
-                                     ptr(scratch), scratch.numel(), ptr(mailbox), int(tag) & 0xFFFFFFFF,
-                                     stream_ptr(self.device)),
-              'drx_point_sample')
+        rec = getattr(self, '_recorded', None)
+        check(lib().drx_point_sample_recorded(C.byref(self._hist), C.byref(rec[0]) if rec is not None else None, self.n_users,
+                                              n_items or self.n_items, B, neg_ratio, int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y),
+                                              ptr(keep_off), ptr(scratch), scratch.numel(), ptr(mailbox), int(tag) & 0xFFFFFFFF,
+                                              stream_ptr(self.device)),
+              'drx_point_sample_recorded')
         return out
 
     def topk(self, scores, k, cand_mask=None):

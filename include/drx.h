@@ -187,6 +187,12 @@ size_t drx_point_sample_scratch_bytes(int32_t B);
 int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
                      uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
                      void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
+/* recorded: CSR (columns ascending) of EVERY pair the training set records, whatever its value — the reference draws its negatives among
+ * the pairs absent from the frame (point_sampler.py:56, mem_dataset.py:131-163), not among the non-positives; NULL = hist (frames whose
+ * recorded pairs all are positives).  drx_point_sample = this with NULL. */
+int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistory *recorded, int32_t n_users, int32_t n_items, int32_t B,
+                              int32_t neg_ratio, uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
+                              void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
 
 /* ---- device-side list sampler (throughput mode; distribution of list_sampler.py:74-151 as caser.py:72-75 configures it) -----
  * The reference's ListSampler is ONE MT19937 stream: draw d depends on every draw before it, so a reference-exact fit() is bound by

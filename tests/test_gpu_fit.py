@@ -201,6 +201,7 @@ def test_pipelined_sampled_fit_equals_the_inline_sequence():
     eng = CdaeEngine(model.n_users, model.n_items, 16)
     eng.init_glorot(3)
     eng.set_history(model._hist_indptr, model._hist_indices)
+    eng.set_recorded_pairs(*ds.interaction_csr()[:2])       # (the frame records pairs below the threshold: negatives avoid those too)
     eng.init_optimizer('adagrad', 0.05, 1e-3)
     ms = model._mask_seed
     for s in range(25):
@@ -282,19 +283,21 @@ def test_quiet_fit_is_left_to_python_when_a_hook_is_replaced():
     assert seen[-2:] == ['s', 's']
 
 
-def test_device_point_sampler_has_the_reference_samplers_distribution():
+@pytest.mark.parametrize('implicit', [True, False])
+def test_device_point_sampler_has_the_reference_samplers_distribution(implicit):
     """drx_point_sample (the throughput mode's triples) against the reference-exact PointSampler stream over many draws: the share of
     negatives, the users of positives (uniform USER, point_sampler.py:44-61), the (user, item) cells of positives and the users of
     negatives are distributed alike (two-sample chi-square per degree of freedom ~ 1)."""
     from drecpy_amd.Dataset import InteractionDataset
     from drecpy_amd.Recommender import CDAE
     from drecpy_amd.Sampler import PointSampler
-    # (an implicit-feedback frame: every recorded pair is a positive.  Where a frame also records pairs BELOW the interaction threshold
-    # the two differ by definition — the reference draws its negatives among the pairs absent from the frame, the device sampler among
-    # the pairs that are not positives: include/drx.h, INTEGRATION.md)
+    # implicit: every recorded pair is a positive.  Otherwise the frame also records pairs BELOW the interaction threshold: the reference
+    # draws its negatives among the pairs ABSENT from the frame (point_sampler.py:56), and so does the device sampler once it is given
+    # the CSR of all recorded pairs (CDAE._pre_fit: engine.set_recorded_pairs)
     frame = _frame()
-    keep = frame['interaction'] >= 1
-    frame = {k: v[keep] for k, v in frame.items()}
+    if implicit:
+        keep = frame['interaction'] >= 1
+        frame = {k: v[keep] for k, v in frame.items()}
     ds = InteractionDataset.read_df(frame, verbose=False)
     model = CDAE(hidden_factors=8, mode='sampled', device_sampler=True, seed=3, verbose=False)
     model.fit(ds, epochs=1, batch_size=64, learning_rate=0.05)
