@@ -1,11 +1,12 @@
 // Device-side PointSampler for the throughput mode (counter-based draws instead of the MT19937 streams of
 // DRecPy/Sampler/point_sampler.py:44-61 — same distribution, different stream; the bit-exact stream is the host
 // sampler in drx_host.cpp):
-//   with probability neg_ratio/(neg_ratio+1) a negative: uniform (u, i) with i NOT among u's rows (mem_dataset.py:154-163;
-//   membership here = the positives CSR), else a positive: uniform user with >= 1 positive, then a uniform positive of
-//   that user (mem_dataset.py:119-129).  Also emits keep_off = exclusive scan of deg(uid[b]) for the step kernels: one workgroup
-//   scans the B degrees (k_scan_degrees) and — when the host passes a pinned mailbox — posts the total, tagged, straight into host
-//   memory with one system-scope store: no copy kernel, no event, and no L2 write-back for the host's sake between training kernels.
+//   with probability neg_ratio/(neg_ratio+1) a negative: uniform (u, i) with i NOT among the pairs the frame records for u
+//   (mem_dataset.py:154-163; the CSR of recorded pairs, or the positives CSR where every recorded pair is a positive), else a positive:
+//   uniform user with >= 1 positive, then a uniform positive of that user (mem_dataset.py:119-129).  Also emits keep_off = exclusive
+//   scan of deg(uid[b]) for the step kernels — the sampler's workgroups sum their degrees, k_deg_apply_sub turns the sums into offsets,
+//   any batch size — and, when the host passes a pinned mailbox, posts the total, tagged, straight into host memory with one
+//   system-scope store: no copy kernel, no event, and no L2 write-back for the host's sake between training kernels.
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include "drx_common.hpp"
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(1024) void k_deg_apply_sub(const int32_t *__restric
   const int base = blockIdx.x * kDegTile + (int)threadIdx.x * 4, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   constexpr int PER = kDegTile / kBlock;
   const int n_before = min(n_sub, (int)blockIdx.x * PER);
-  int pre = (int)threadIdx.x < n_before ? sub[threadIdx.x] : 0;          // (n_sub <= 1024)
+  int pre = 0;
+  for (int q = (int)threadIdx.x; q < n_before; q += 1024) pre += sub[q];
   int v[4], sum = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { sum += base + q < B ? deg[base + q] : 0; v[q] = sum; }
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(kBlock) void k_row_lengths(const int64_t *__restric
 
 extern "C" size_t drx_point_sample_scratch_bytes(int32_t B) {
   if (B < 1) return 0;
-  return drx::align_up((size_t)B * 4, 256) + 256 + 256 + 4096;        // degrees, then 64 tile sums, then 1024 workgroup sums
+  const size_t n_sub = ((size_t)B + drx::kBlock - 1) / drx::kBlock;
+  return drx::align_up((size_t)B * 4, 256) + 256 + 256 + drx::align_up(n_sub * 4, 4096);        // degrees, 64 tile sums, the sampler's workgroup sums
 }
 
 extern "C" int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio,
@@ -232,15 +235,11 @@ extern "C" int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistor
   int32_t *deg = (int32_t *)scratch;
   const int n_tiles = (B + kDegTile - 1) / kDegTile, n_sub = (B + kBlock - 1) / kBlock;
   int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
-  int *sub = n_tiles <= 64 ? tsum + 128 : nullptr;
+  int *sub = tsum + 128;
   hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, recorded ? *recorded : *hist, n_users, n_items, B, neg_ratio,
                      seed, uid, iid, y, deg, keep_off, sub);
-  if (n_tiles <= 64) {
-    hipLaunchKernelGGL(k_deg_apply_sub, dim3(n_tiles), dim3(1024), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
-                       (unsigned long long *)host_mailbox, tag);
-  } else {
-    hipLaunchKernelGGL(k_scan_degrees, dim3(1), dim3(1024), 0, st, deg, B, keep_off, (unsigned long long *)host_mailbox, tag);
-  }
+  hipLaunchKernelGGL(k_deg_apply_sub, dim3(n_tiles), dim3(1024), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
+                     (unsigned long long *)host_mailbox, tag);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
