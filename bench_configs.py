@@ -69,18 +69,24 @@ def dmf_block(ds, dev):
             m = cls(user_factors=[64, 32], item_factors=[64, 32], seed=10, verbose=False, device=str(dev))
             m.fit(ds, epochs=2, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)
             batch = m._sample_batch(B)
+            if len(batch) == 3:                                     # (large batches are prepared by _do_batch itself: here once, up front)
+                batch = tuple(batch) + (m._engine.prepare_batch(*batch[:3]),)
             state = {'s': 2}
 
             def step():
                 m._do_batch(batch, step=state['s'])
                 state['s'] += 1
             dev_s = _timed(step, 40)
-            t0 = time.perf_counter()
-            m.fit(ds, epochs=300, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)      # the public call, set-up included
-            torch.cuda.synchronize()
-            e2e = (time.perf_counter() - t0) / 300
+            times = []
+            for n in (300, 700):                                    # the public call: set-up included, and the steady state between two lengths
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                m.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            e2e, steady = times[0] / 300, (times[1] - times[0]) / 400
             out[f'{name}_B{B}'] = {'step_ms': dev_s * 1e3, 'step_samples_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
-                                   'fit_samples_per_s': B / e2e}
+                                   'fit_steady_ms_per_step': steady * 1e3, 'fit_samples_per_s': B / steady}
     # the one MFMA kernel: all-pairs cosine scores of a block of users against every item (k_score_pairs_bf16)
     from drecpy_amd import _lib
     L = _lib.lib()
