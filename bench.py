@@ -101,55 +101,82 @@ def _child_argv(argv, layout):
     return [sys.executable, os.path.join(ROOT, 'bench.py')] + out + ['--child-layout', layout]
 
 
-def _child_env(rank, local_rank, world, addr, port):
+def _child_env(rank, local_rank, world, rdzv):
     env = dict(os.environ)
     for k in list(env):
-        if k.startswith('TORCHELASTIC_') or k in ('GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE'):
-            env.pop(k)            # the children rendezvous among themselves (rank 0's child hosts the store), not through an agent
-    env.update({'RANK': str(rank), 'LOCAL_RANK': str(local_rank), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
-                'MASTER_ADDR': addr, 'MASTER_PORT': str(port)})
+        if k.startswith('TORCHELASTIC_') or k in ('GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'MASTER_ADDR',
+                                                  'MASTER_PORT'):
+            env.pop(k)            # the children rendezvous among themselves through a FILE store (DRX_RDZV), not through an agent or a port
+    env.update({'RANK': str(rank), 'LOCAL_RANK': str(local_rank), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world), 'DRX_RDZV': rdzv})
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: the only kind the host driver supports
     return env
 
 
-def _layout_port(base, i):
-    return base + 211 + 37 * i          # away from the launcher's own rendezvous port; one port per layout
+def _supervise(procs, limit_s):
+    """Waits for ALL children at once (waiting in rank order left rank 0 inside RCCL for minutes after another rank had
+    died).  The first child that exits non-zero — or the time limit — ends the layout: the survivors (children this process started,
+    by PID) are killed at once.  Returns ({rank: exit code | 'timeout' | 'killed'}, rank 0's stdout, the rank that failed first)."""
+    import threading
+    out0 = {}
+
+    def drain(pr):                       # rank 0's pipe must be read while it runs, or a long line blocks it
+        out0['b'] = pr.stdout.read()
+    readers = []
+    for r, pr in procs:
+        if pr.stdout is not None:
+            t = threading.Thread(target=drain, args=(pr,), daemon=True)
+            t.start()
+            readers.append(t)
+    t0, rcs, first_bad = time.time(), {}, None
+    live = dict(procs)
+    while live:
+        for r, pr in list(live.items()):
+            rc = pr.poll()
+            if rc is not None:
+                rcs[r] = rc
+                live.pop(r)
+                if rc != 0 and first_bad is None:
+                    first_bad = r
+        timed_out = time.time() - t0 > limit_s
+        if live and (first_bad is not None or timed_out):
+            for r, pr in live.items():
+                pr.kill()
+                pr.wait()
+                rcs[r] = 'timeout' if (timed_out and first_bad is None) else 'killed'
+            live = {}
+        if live:
+            time.sleep(0.05)
+    for t in readers:
+        t.join(timeout=10.0)
+    return rcs, out0.get('b') or b'', first_bad
 
 
-def coordinate(args, argv, ranks, world, base_port, addr='127.0.0.1', local_of=None):
+def coordinate(args, argv, ranks, world, rdzv_dir, local_of=None):
     """Runs every layout as a set of fresh child processes — one per rank in `ranks` (all of them when this process started the job,
     just its own under torch.distributed.run) — and, where rank 0 is among them, returns the merged line.  A layout whose children
-    fail or exceed the time limit is reported inside `layouts` and cannot be the headline."""
+    fail or exceed the time limit is reported inside `layouts` and cannot be the headline.  The children of a layout meet through
+    `file://<rdzv_dir>/<layout>`: no TCP port is chosen anywhere (a computed port inside the ephemeral range failed GPUTEST_r03)."""
     layouts = ['selftest'] if args.launch_selftest else (list(LAYOUTS) if args.layout == 'both' else [args.layout])
     results, errors = {}, {}
     local_of = local_of or {}
     for i, lay in enumerate(layouts):
-        port = _layout_port(base_port, i)
+        rdzv = f'file://{rdzv_dir}/{lay}'
         cmd = _child_argv(argv, lay)
         if args.launch_dry_run:
             for r in ranks:
-                print(f'[{lay}] RANK={r} LOCAL_RANK={r} WORLD_SIZE={world} MASTER_ADDR={addr} MASTER_PORT={port} ' + ' '.join(cmd), flush=True)
+                print(f'[{lay}] RANK={r} LOCAL_RANK={r} WORLD_SIZE={world} DRX_RDZV={rdzv} ' + ' '.join(cmd), flush=True)
             continue
-        procs = [(r, subprocess.Popen(cmd, env=_child_env(r, local_of.get(r, r), world, addr, port),
+        t0 = time.time()
+        procs = [(r, subprocess.Popen(cmd, env=_child_env(r, local_of.get(r, r), world, rdzv),
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None)) for r in ranks]
-        t0, rcs, out0 = time.time(), {}, b''
-        for r, pr in procs:
-            try:
-                o, _ = pr.communicate(timeout=max(1.0, args.layout_timeout_s - (time.time() - t0)))
-                rcs[r] = pr.returncode
-                if r == 0:
-                    out0 = o or b''
-            except subprocess.TimeoutExpired:
-                pr.kill()
-                pr.communicate()
-                rcs[r] = 'timeout'
+        rcs, out0, first_bad = _supervise(procs, args.layout_timeout_s)
         bad = {r: c for r, c in rcs.items() if c != 0}
         line = None
         for ln in out0.decode(errors='replace').splitlines():
             if ln.startswith('{'):
                 line = ln
         if bad:
-            errors[lay] = {'error': f'child exit codes {bad}', 'seconds': round(time.time() - t0, 1)}
+            errors[lay] = {'error': f'child exit codes {bad}', 'first_failed_rank': first_bad, 'seconds': round(time.time() - t0, 1)}
         elif 0 in ranks and line is None:
             errors[lay] = {'error': 'rank 0 printed no JSON line', 'seconds': round(time.time() - t0, 1)}
         elif line is not None:
@@ -183,30 +210,54 @@ def coordinate(args, argv, ranks, world, base_port, addr='127.0.0.1', local_of=N
     return out, rc
 
 
+def _shared_rendezvous_dir(rank):
+    """Under torch.distributed.run the ranks' coordinators are separate processes: rank 0 makes a fresh directory and publishes its
+    name through the AGENT's store (MASTER_ADDR:MASTER_PORT, which torch.distributed.run already hosts — this process only connects as
+    a client, it opens no port of its own); the others read it."""
+    import tempfile
+    from torch.distributed import TCPStore
+    store = TCPStore(os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ['MASTER_PORT']), is_master=False)
+    key = 'drx_bench/rendezvous_dir/' + os.environ.get('TORCHELASTIC_RUN_ID', 'none') + '/' + os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    if rank == 0:
+        d = tempfile.mkdtemp(prefix='drx_rdzv_')
+        store.set(key, d)
+        return d
+    return store.get(key).decode()
+
+
 def launch_or_coordinate(args, argv):
     """--gpus N > 1 without --child-layout: start (or, under torch.distributed.run, be) the per-rank coordinators."""
+    import tempfile
     world = args.gpus
-    if 'WORLD_SIZE' in os.environ:
+    if args.launch_dry_run:
+        ranks, local_of, rdzv_dir = list(range(world)), None, os.path.join(tempfile.gettempdir(), 'drx_rdzv_<fresh>')
+    elif 'WORLD_SIZE' in os.environ:
         assert int(os.environ['WORLD_SIZE']) == world, f"--gpus {world} but WORLD_SIZE={os.environ['WORLD_SIZE']}"
         ranks = [int(os.environ.get('RANK', 0))]
         local_of = {ranks[0]: int(os.environ.get('LOCAL_RANK', ranks[0]))}
-        base_port = int(os.environ.get('MASTER_PORT', 29500))
-        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        rdzv_dir = _shared_rendezvous_dir(ranks[0])
     else:
         ranks, local_of = list(range(world)), None
-        base_port = int(os.environ.get('DRX_BENCH_PORT', 29500 + (os.getpid() % 2000)))
-        addr = '127.0.0.1'
-    out, rc = coordinate(args, argv, ranks, world, base_port, addr, local_of)
+        rdzv_dir = tempfile.mkdtemp(prefix='drx_rdzv_')
+    out, rc = coordinate(args, argv, ranks, world, rdzv_dir, local_of)
     if out is not None:
         print(json.dumps(out), flush=True)
     return rc
+
+
+def _init_group(dist, backend, rank, world, **kw):
+    """The ranks of a measurement meet through the file store named by DRX_RDZV (set by the coordinator); a lone process
+    (1-rank RCCL debugging run) makes its own.  Never a TCP port."""
+    import tempfile
+    rdzv = os.environ.get('DRX_RDZV') or f"file://{tempfile.mkdtemp(prefix='drx_rdzv_')}/solo"
+    dist.init_process_group(backend, init_method=rdzv, rank=rank, world_size=world, **kw)
 
 
 def selftest_child():
     """Children of --launch-selftest: a gloo rendezvous and one all-reduce on the CPU; rank 0 prints a line of the bench's shape."""
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo')
+    _init_group(dist, 'gloo', rank, world)
     t = torch.ones(1)
     dist.all_reduce(t)
     t0 = time.perf_counter()
@@ -845,15 +896,12 @@ def worker_main(args):
     rccl1 = world == 1 and os.environ.get('DRX_BENCH_RCCL1') == '1'     # debugging aid: 1-rank RCCL communicator, real collectives
     tmo = datetime.timedelta(seconds=300)
     if rccl1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29455')
-        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev, timeout=tmo)
+        _init_group(dist, 'nccl', 0, 1, device_id=dev, timeout=tmo)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if debug_gloo:
-            dist.init_process_group('gloo', timeout=tmo)
+            _init_group(dist, 'gloo', rank, world, timeout=tmo)
         else:
-            dist.init_process_group('nccl', device_id=dev, timeout=tmo)
+            _init_group(dist, 'nccl', rank, world, device_id=dev, timeout=tmo)
     layout = args.child_layout or ('columns' if args.force_columns else 'rows')
     if layout == 'columns' and (world > 1 or args.force_columns):
         out = run_columns(args, rank, world, dev, dist, debug_gloo, rccl1)

@@ -21,7 +21,7 @@ class Adam:
     def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
-        self._slots = {}              # id(variable / tensor object) -> (weak reference to it, m, v)
+        self._slots = {}              # id(Variable) -> (weak reference, m, v);  ('view', storage, offset, shape, strides) -> (storage, m, v)
 
     def reset(self):
         """A fresh fit(): the call counter and the moments start over (RecommenderABC.fit registers the optimizer anew)."""
@@ -29,10 +29,20 @@ class Adam:
         self._slots = {}
 
     def _moments(self, owner, p):
-        """(m, v) of the variable OBJECT `owner` (a Variable handle or a tensor): keyed by identity, not by device address — a new
-        tensor that happens to be allocated at a freed variable's address must not inherit its moments."""
+        """(m, v) of one variable.  A Variable OBJECT is keyed by identity (weak reference: a new object at a recycled id starts
+        from zero).  A bare tensor is keyed by WHAT IT VIEWS — storage, offset, shape, strides: a layer / model handle hands out
+        fresh view objects of the same memory on every `trainable_weights` read (trainables._Handle), and those must find their
+        moments again (keyed by id() they silently restarted from zero every step).  The entry holds the storage, so
+        the memory cannot be freed and handed to another tensor while its moments exist (reset() drops them with a new fit())."""
         import weakref
         import torch
+        if torch.is_tensor(owner):
+            st = owner.untyped_storage()
+            key = ('view', st._cdata, owner.storage_offset(), tuple(owner.shape), tuple(owner.stride()))
+            ent = self._slots.get(key)
+            if ent is None:
+                ent = self._slots[key] = (st, torch.zeros_like(p), torch.zeros_like(p))
+            return ent[1], ent[2]
         ent = self._slots.get(id(owner))
         if ent is not None and (ent[0]() is not owner or ent[1].shape != p.shape or ent[1].device != p.device):
             ent = None                  # the id was recycled by another object, or the variable was rebound to another shape / device
@@ -42,7 +52,7 @@ class Adam:
             except TypeError:
                 ref = (lambda o: (lambda: o))(owner)
             ent = self._slots[id(owner)] = (ref, torch.zeros_like(p), torch.zeros_like(p))
-            for k in [k for k, e in self._slots.items() if e[0]() is None]:
+            for k in [k for k, e in self._slots.items() if not isinstance(k, tuple) and e[0]() is None]:
                 del self._slots[k]
         return ent[1], ent[2]
 

@@ -21,12 +21,12 @@ def test_dry_run_prints_one_command_line_per_rank_and_layout():
     for lay in ('rows', 'columns'):
         mine = [l for l in lines if l.startswith(f'[{lay}]')]
         assert sorted(int(l.split('RANK=')[1].split()[0]) for l in mine) == [0, 1, 2, 3]
-        ports = {l.split('MASTER_PORT=')[1].split()[0] for l in mine}
-        assert len(ports) == 1                                    # the ranks of a layout meet on one port ...
+        stores = {l.split('DRX_RDZV=')[1].split()[0] for l in mine}
+        assert len(stores) == 1 and next(iter(stores)).startswith('file://')    # the ranks of a layout meet in one FILE store ...
         for l in mine:
-            assert 'WORLD_SIZE=4' in l and 'MASTER_ADDR=127.0.0.1' in l and l.rstrip().endswith(f'--child-layout {lay}')
+            assert 'WORLD_SIZE=4' in l and 'MASTER_PORT' not in l and l.rstrip().endswith(f'--child-layout {lay}')
             assert '--gpus 4 --steps 20 --warmup 5' in l and '--launch-dry-run' not in l
-    assert len({l.split('MASTER_PORT=')[1].split()[0] for l in lines}) == 2       # ... and the two layouts on different ones
+    assert len({l.split('DRX_RDZV=')[1].split()[0] for l in lines}) == 2         # ... and the two layouts in different ones
 
 
 def _one_line(stdout):
@@ -45,7 +45,10 @@ def test_launcher_path_over_gloo_world_2():
 
 def test_launcher_path_under_torch_distributed_run():
     """The driver's command shape: every worker coordinates its own rank; rank 0 prints the one line."""
-    port = 29000 + os.getpid() % 500
+    import socket
+    with socket.socket() as so:               # torch.distributed.run itself wants a port: one the kernel just handed out, not a formula
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                           '--master-port', str(port), BENCH, '--gpus', '2', '--launch-selftest'], cwd=ROOT, env=ENV, capture_output=True,
                          text=True, timeout=300)

@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import new_rendezvous  # noqa: E402
 
 U, N, K, B, STEPS, Q = 40, 57, 6, 24, 3, 0.2
 
@@ -34,10 +35,8 @@ def _problem(world=2):
     return p, indptr, indices, batches
 
 
-def _worker(rank, world, port, out, pipelined=False, micro=1):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _worker(rank, world, rdzv, out, pipelined=False, micro=1):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     from drecpy_amd.dist import ShardedCdae
     from dist_ops_numpy import NumpyShardOps, np_batch
     p, indptr, indices, batches = _problem(world)
@@ -74,8 +73,8 @@ def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, w
     compute; the step must still equal the single-process step on the concatenated batch."""
     from oracle import cdae_oracle as co
     out = str(tmp_path / 'shard')
-    port = 29600 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0)) + 2000 * world
-    mp.spawn(_worker, args=(world, port, out, pipelined, micro), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro), nprocs=world, join=True)
     p, indptr, indices, batches = _problem(world)
     st = co.sparse_state(p, 'adagrad')
     want_losses = []
@@ -142,10 +141,8 @@ class _NumpyColumnEngine:
         return [lval]
 
 
-def _column_worker(rank, world, port, out):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _column_worker(rank, world, rdzv, out):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     from drecpy_amd.dist import ColumnShardedCdae
     p, indptr, indices, batches = _problem(1)
     m = ColumnShardedCdae(U, N, K, rank, world, 'cpu', indptr, indices, q=Q, engine=object())
@@ -167,8 +164,8 @@ def test_column_sharded_step_equals_single_process_oracle(tmp_path, world):
     products (dist.ColumnShardedCdae.step) — the result must equal the single-process step on all K columns (K = 6: 3 + 3, 2 + 2 + 2)."""
     from oracle import cdae_oracle as co
     out = str(tmp_path / 'cols')
-    port = 29100 + (os.getpid() % 200) + 300 * world
-    mp.spawn(_column_worker, args=(world, port, out), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_column_worker, args=(world, rdzv, out), nprocs=world, join=True)
     p, indptr, indices, batches = _problem(1)
     st = co.sparse_state(p, 'adagrad')
     want = []
@@ -215,10 +212,8 @@ class _FakePrepEngine:
         return out
 
 
-def _turns_worker(rank, world, port, out):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _turns_worker(rank, world, rdzv, out):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     from drecpy_amd.dist import ColumnShardedCdae
     p, indptr, indices, _ = _problem(1)
     m = ColumnShardedCdae(U, N, K, rank, world, 'cpu', indptr, indices, q=Q, engine=_FakePrepEngine(rank), prepare='turns')
@@ -242,8 +237,8 @@ def test_lists_built_in_turns_reach_every_rank(tmp_path, world):
     """prepare='turns': the list of step s is built by rank s % world only and every rank ends up with exactly its result bytes
     (the broadcast runs on a communicator of its own; the builder's scratch part never travels)."""
     out = str(tmp_path / 'turns')
-    port = 29400 + (os.getpid() % 200) + 300 * world
-    mp.spawn(_turns_worker, args=(world, port, out), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_turns_worker, args=(world, rdzv, out), nprocs=world, join=True)
     for r in range(world):
         got = torch.load(f'{out}.{r}', weights_only=False)
         for s, (built_here, res) in enumerate(got):

@@ -254,6 +254,35 @@ def test_update_weights_applies_keras_adam_on_the_device():
     assert m.optimizer.iterations == 2
 
 
+def test_update_weights_keeps_adam_moments_of_a_layer_handle_across_steps():
+    """A layer / model handle hands out FRESH view objects of the same memory on every `trainable_weights` read (trainables._Handle):
+    the moments must follow the memory, not the object (keyed by id() they restarted from zero each step while
+    `iterations` went on).  Three steps with changing gradients against closed-form Keras Adam."""
+    import torch
+    from drecpy_amd import optimizers
+    from drecpy_amd.Recommender import DMF
+    from drecpy_amd.Recommender.trainables import TrainableLayer
+    from oracle import cdae_oracle as co
+    m = DMF(verbose=False)
+    m._register_optimizer(optimizers.Adam(learning_rate=0.01))
+    flat = torch.arange(24, dtype=torch.float32, device='cuda') / 7.0
+    layer = TrainableLayer('dense', lambda: [flat[0:16].view(4, 4), flat[16:24]])          # kernel and bias as views of one array
+    x = [flat[0:16].cpu().numpy().astype(np.float64).reshape(4, 4), flat[16:24].cpu().numpy().astype(np.float64)]
+    mom = [[np.zeros_like(a), np.zeros_like(a)] for a in x]
+    rng = np.random.default_rng(3)
+    for t in range(1, 4):
+        g = [rng.normal(size=a.shape) for a in x]
+        m._update_weights([[torch.tensor(a, dtype=torch.float32, device='cuda') for a in g]], [layer])
+        for a, (m1, v1), ga in zip(x, mom, g):
+            m1 += (ga - m1) * co.ADAM_OMB1
+            v1 += (ga * ga - v1) * co.ADAM_OMB2
+            a -= co.adam_alpha(0.01, t) * m1 / (np.sqrt(v1) + co.ADAM_EPS)
+    got = [w.cpu().numpy() for w in layer.trainable_weights]
+    for a, w in zip(x, got):
+        np.testing.assert_allclose(w, a, rtol=5e-6, atol=1e-7)
+    assert m.optimizer.iterations == 3
+
+
 @pytest.mark.parametrize('update', ['scan', 'scatter'])
 def test_dmf_steps_with_empty_rows_columns_and_repeated_ids(update):
     """Edge cases of the first-layer paths: users without any interaction and items nobody rated inside the batch (zero input vectors:

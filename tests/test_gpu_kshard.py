@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-from helpers import retry_once  # noqa: E402
+from helpers import new_rendezvous, retry_infra  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 U, N, B, STEPS, Q = 300, 411, 700, 4, 0.2
@@ -90,10 +90,8 @@ def test_column_sharded_world1_matches_oracle(K, opt):
     _check(K, opt, [_run_rank(0, 1, K, opt, False)])
 
 
-def _worker(rank, world, port, out, K, opt, parts=False, turns=False):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _worker(rank, world, rdzv, out, K, opt, parts=False, turns=False):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     res = _run_rank(rank, world, K, opt, True, parts=parts, turns=turns)
     torch.save(res, f'{out}.{rank}')
     dist.barrier()
@@ -101,20 +99,18 @@ def _worker(rank, world, port, out, K, opt, parts=False, turns=False):
 
 
 @pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adagrad'), (2, 64, 'adam')])
-@retry_once
+@retry_infra
 def test_column_sharded_processes_on_one_gpu_match_oracle(tmp_path, world, K, opt):
     """world 3 with K = 50: 17 + 17 + 16 columns (uneven, and lane-group geometries differ from the unsharded one)."""
     out = str(tmp_path / 'ks')
-    port = 29800 + (os.getpid() % 200) + 300 * world + K
-    mp.spawn(_worker, args=(world, port, out, K, opt), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker, args=(world, rdzv, out, K, opt), nprocs=world, join=True)
     _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
 
 
-def _worker_rccl(rank, port, out, K, opt, parts=False, turns=False):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
+def _worker_rccl(rank, rdzv, out, K, opt, parts=False, turns=False):
     torch.cuda.set_device(0)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    dist.init_process_group('nccl', init_method=rdzv, rank=0, world_size=1, device_id=torch.device('cuda', 0))
     res = _run_rank(0, 1, K, opt, False, force=True, parts=parts, turns=turns)
     torch.save(res, f'{out}.0')
     dist.barrier()
@@ -123,44 +119,44 @@ def _worker_rccl(rank, port, out, K, opt, parts=False, turns=False):
 
 def test_column_sharded_step_through_rccl_world1(tmp_path):
     out = str(tmp_path / 'ksr')
-    port = 29300 + (os.getpid() % 200)
-    mp.spawn(_worker_rccl, args=(port, out, 128, 'adagrad'), nprocs=1, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker_rccl, args=(rdzv, out, 128, 'adagrad'), nprocs=1, join=True)
     _check(128, 'adagrad', [torch.load(f'{out}.0', weights_only=False)])
 
 
 @pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adam')])
-@retry_once
+@retry_infra
 def test_touch_list_built_in_parts_across_processes(tmp_path, world, K, opt):
     """ColumnShardedCdae.prepare: every rank sorts the touches of the rows it owns, one all-gather, every rank assembles."""
     out = str(tmp_path / 'kp')
-    port = 28800 + (os.getpid() % 200) + 300 * world + K
-    mp.spawn(_worker, args=(world, port, out, K, opt, True), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker, args=(world, rdzv, out, K, opt, True), nprocs=world, join=True)
     _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
 
 
 @pytest.mark.parametrize('world,K,opt', [(2, 128, 'adagrad'), (3, 50, 'adam')])
-@retry_once
+@retry_infra
 def test_touch_list_built_in_turns_across_processes(tmp_path, world, K, opt):
     """ColumnShardedCdae.prepare_in_turns: rank s % world sorts the list of step s and broadcasts the leading
     drx_cdae_prep_result_bytes of its prepared buffer.  world 3, K = 50: the ranks' row widths differ (32, 32, 16 floats), so a
     list marked for sole touchers by one geometry is consumed by another."""
     out = str(tmp_path / 'kt')
-    port = 27800 + (os.getpid() % 200) + 300 * world + K
-    mp.spawn(_worker, args=(world, port, out, K, opt, False, True), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker, args=(world, rdzv, out, K, opt, False, True), nprocs=world, join=True)
     _check(K, opt, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)])
 
 
 def test_touch_list_built_in_turns_through_rccl_world1(tmp_path):
     out = str(tmp_path / 'ktr')
-    port = 27300 + (os.getpid() % 200)
-    mp.spawn(_worker_rccl, args=(port, out, 128, 'adagrad', False, True), nprocs=1, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker_rccl, args=(rdzv, out, 128, 'adagrad', False, True), nprocs=1, join=True)
     _check(128, 'adagrad', [torch.load(f'{out}.0', weights_only=False)])
 
 
 def test_touch_list_built_in_parts_through_rccl_world1(tmp_path):
     out = str(tmp_path / 'kpr')
-    port = 28300 + (os.getpid() % 200)
-    mp.spawn(_worker_rccl, args=(port, out, 128, 'adagrad', True), nprocs=1, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker_rccl, args=(rdzv, out, 128, 'adagrad', True), nprocs=1, join=True)
     _check(128, 'adagrad', [torch.load(f'{out}.0', weights_only=False)])
 
 
@@ -255,10 +251,8 @@ def test_column_sharded_pipeline_equals_stepping_inline(prepare):
         assert torch.equal(a, b)
 
 
-def _pipe_worker(rank, world, port, out, prepare):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _pipe_worker(rank, world, rdzv, out, prepare):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     from drecpy_amd.dist import ColumnShardedCdae
     p, indptr, indices, _ = _problem(64)
     m = ColumnShardedCdae(U, N, 64, rank, world, 'cuda:0', indptr, indices, q=Q, cpu_staging=True, prepare=prepare)
@@ -273,14 +267,14 @@ def _pipe_worker(rank, world, port, out, prepare):
 
 
 @pytest.mark.parametrize('world,prepare', [(2, 'turns'), (3, 'turns'), (2, 'parts')])
-@retry_once
+@retry_infra
 def test_pipelines_of_several_processes_equal_the_single_process_run(tmp_path, world, prepare):
     """The run-ahead pipeline with lists built in turns (built three steps ahead by rank s % world, broadcast one step ahead)
     or in parts, as `world` processes sharing the GPU: every rank's columns equal those of one process stepping inline."""
     from drecpy_amd.dist import ColumnShardedCdae
     out = str(tmp_path / 'pp')
-    port = 26800 + (os.getpid() % 200) + 300 * world + (7 if prepare == 'parts' else 0)
-    mp.spawn(_pipe_worker, args=(world, port, out, prepare), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_pipe_worker, args=(world, rdzv, out, prepare), nprocs=world, join=True)
     p, indptr, indices, _ = _problem(64)
     m = ColumnShardedCdae(U, N, 64, 0, 1, 'cuda:0', indptr, indices, q=Q)
     m.set_params_global(**p)
@@ -298,10 +292,8 @@ def test_pipelines_of_several_processes_equal_the_single_process_run(tmp_path, w
         np.testing.assert_allclose(got['b_'], want['b_'], rtol=0, atol=2e-6)
 
 
-def _fit_worker(rank, world, port, out, prepare='local'):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _fit_worker(rank, world, rdzv, out, prepare='local'):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     from test_gpu_fit import _frame
     from drecpy_amd.Dataset import InteractionDataset
     from drecpy_amd.Recommender import CDAE
@@ -317,7 +309,7 @@ def _fit_worker(rank, world, port, out, prepare='local'):
 
 
 @pytest.mark.parametrize('prepare', ['local', 'turns'])
-@retry_once
+@retry_infra
 def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path, prepare):
     """CDAE.fit(mode='sampled', device_sampler=True) as two processes of one job (column-sharded training, then every rank
     holds the whole model): parameters, a prediction and a ranking equal the single-process fit with the same seed."""
@@ -325,8 +317,8 @@ def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path, pr
     from drecpy_amd.Dataset import InteractionDataset
     from drecpy_amd.Recommender import CDAE
     out = str(tmp_path / 'fit')
-    port = 29900 + (os.getpid() % 90) + (5 if prepare == 'turns' else 0)
-    mp.spawn(_fit_worker, args=(2, port, out, prepare), nprocs=2, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_fit_worker, args=(2, rdzv, out, prepare), nprocs=2, join=True)
     frame = _frame()
     ds = InteractionDataset.read_df(frame, verbose=False)
     single = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False)

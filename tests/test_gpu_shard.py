@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-from helpers import retry_once  # noqa: E402
+from helpers import new_rendezvous, retry_infra  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 U, N, K, B, STEPS, Q = 300, 411, 50, 512, 4, 0.2
@@ -111,10 +111,8 @@ def test_sharded_world1_matches_oracle(pipelined, micro):
     _check(1, [_run_rank(0, 1, False, pipelined=pipelined, micro=micro)], micro)
 
 
-def _worker(rank, world, port, out, pipelined=False, micro=1):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _worker(rank, world, rdzv, out, pipelined=False, micro=1):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     res = _run_rank(rank, world, True, pipelined=pipelined, micro=micro)
     torch.save(res, f'{out}.{rank}')
     dist.barrier()
@@ -122,20 +120,18 @@ def _worker(rank, world, port, out, pipelined=False, micro=1):
 
 
 @pytest.mark.parametrize('pipelined,micro,world', [(False, 1, 2), (True, 1, 2), (True, 2, 2), (True, 1, 3)])
-@retry_once
+@retry_infra
 def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro, world):
     """`world` processes share the one GPU of the box (gloo + host-staged exchanges); world 3 splits 411 items unevenly."""
     out = str(tmp_path / 'shard')
-    port = 29700 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0)) + 2000 * world
-    mp.spawn(_worker, args=(world, port, out, pipelined, micro), nprocs=world, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro), nprocs=world, join=True)
     _check(world, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)], micro)
 
 
-def _worker_rccl(rank, port, out, pipelined, micro):
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
+def _worker_rccl(rank, rdzv, out, pipelined, micro):
     torch.cuda.set_device(0)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    dist.init_process_group('nccl', init_method=rdzv, rank=0, world_size=1, device_id=torch.device('cuda', 0))
     res = _run_rank(0, 1, False, force=True, pipelined=pipelined, micro=micro)
     torch.save(res, f'{out}.0')
     dist.barrier()
@@ -147,8 +143,8 @@ def test_sharded_step_through_rccl_world1(tmp_path, pipelined, micro):
     """The N-rank call sequence (count / key / row / gradient all-to-all(v), bias all-reduce) on a real 1-rank RCCL
     communicator: device int32 and float32 buffers, uneven-split API, stream ordering with the drx kernels."""
     out = str(tmp_path / 'rccl')
-    port = 29400 + (os.getpid() % 200) + 200 * (2 * micro + (1 if pipelined else 0))
-    mp.spawn(_worker_rccl, args=(port, out, pipelined, micro), nprocs=1, join=True)
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker_rccl, args=(rdzv, out, pipelined, micro), nprocs=1, join=True)
     _check(1, [torch.load(f'{out}.0', weights_only=False)], micro)
 
 
