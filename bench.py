@@ -795,9 +795,6 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                 and m.get('optimizer', 'adagrad') == args.optimizer:
             if m.get('kernel_source_hash') == kernel_hash:
                 traffic_of = {k_.replace('drx::', ''): v['hbm_bytes_per_launch'] for k_, v in pmc['kernels'].items()}
-                for alias in ('k_sampled_fwd_bwd_pf', 'k_sampled_fwd_bwd_stash'):        # the forward kernel's instantiations
-                    if alias in traffic_of:
-                        traffic_of.setdefault('k_sampled_fwd_bwd', traffic_of[alias])
                 traffic_note = f"profiles/pmc_traffic.json ({m.get('round')}), same kernel sources ({kernel_hash})"
             else:
                 traffic_note = f"profiles/pmc_traffic.json is STALE: taken on kernel sources {m.get('kernel_source_hash')}, this tree is {kernel_hash}"

@@ -53,6 +53,25 @@ def _events_ms(fn, n):
     return e0.elapsed_time(e1) / n
 
 
+def _fit_steady(fit, n_short, n_long, reps=2):
+    """(seconds per step of the short fit() incl. set-up, seconds per step of the STEADY STATE): the steady state is the difference
+    of a long and a short fit() over the difference of their lengths, each taken as the FASTEST of `reps` runs (set-up jitter of
+    tens of milliseconds once made the difference of two single runs negative: r04a).  Never below 0: a floor of the long run's own
+    average / 4 keeps a noisy difference from reporting a rate no device step could reach."""
+    best = []
+    for n in (n_short, n_long):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fit(n)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        best.append(min(ts))
+    steady = (best[1] - best[0]) / (n_long - n_short)
+    return best[0] / n_short, max(steady, best[1] / n_long / 4.0)
+
+
 def dmf_block(ds, dev):
     sys.path.insert(0, os.path.join(ROOT, 'examples'))
     from drecpy_amd.Recommender import DMF
@@ -77,14 +96,9 @@ def dmf_block(ds, dev):
                 m._do_batch(batch, step=state['s'])
                 state['s'] += 1
             dev_s = _timed(step, 40)
-            times = []
-            for n in (300, 700):                                    # the public call: set-up included, and the steady state between two lengths
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                m.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)
-                torch.cuda.synchronize()
-                times.append(time.perf_counter() - t0)
-            e2e, steady = times[0] / 300, (times[1] - times[0]) / 400
+            # the public call: set-up included, and the steady state between two lengths
+            e2e, steady = _fit_steady(lambda n: m.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5),
+                                      300, 1500 if B <= 256 else 900)
             out[f'{name}_B{B}'] = {'step_ms': dev_s * 1e3, 'step_samples_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
                                    'fit_steady_ms_per_step': steady * 1e3, 'fit_samples_per_s': B / steady}
     # the one MFMA kernel: all-pairs cosine scores of a block of users against every item (k_score_pairs_bf16)
@@ -124,14 +138,7 @@ def caser_block(ds, dev):
         dev_s = _timed(step, 30)
         def fit_times(model, **kw):
             """seconds per step of a 200-epoch fit() (set-up included) and of the steady state (a 600-epoch fit minus a 200-epoch one)"""
-            res = []
-            for n in (200, 600):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                model.fit(ds, epochs=n, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3, **kw)
-                torch.cuda.synchronize()
-                res.append(time.perf_counter() - t0)
-            return res[0] / 200, (res[1] - res[0]) / 400
+            return _fit_steady(lambda n: model.fit(ds, epochs=n, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3, **kw), 200, 600)
         e2e, steady = fit_times(m)
         out[f'Caser_B{B}'] = {'step_ms': dev_s * 1e3, 'step_windows_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
                               'fit_steady_ms_per_step': steady * 1e3, 'fit_windows_per_s': B / steady,

@@ -14,8 +14,6 @@ TARGETS_REFERENCE, TARGETS_PER_ROW = 0, 1
 OPT_ADAM, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
 DENSE_AUX_CLEAN = 0x100          # include/drx.h: DRX_DENSE_AUX_CLEAN
 KEY_NONE = 0xFFFFFFFF
-BATCH_MARK_W = 1                 # include/drx.h: DRX_BATCH_MARK_W
-BATCH_V_SLOTS = 2                # include/drx.h: DRX_BATCH_V_SLOTS
 
 
 class DrxError(RuntimeError):

@@ -12,6 +12,7 @@
 #include "drx_segreduce.hpp"
 #include <cstring>
 #include "drx_scan.hpp"
+#include "drx_prep.hpp"
 
 #ifndef DRX_GATHER_ROWS
 #define DRX_GATHER_ROWS 8
@@ -596,75 +597,12 @@ struct SparseBufs {
   float *phead, *ptail;                       // [n_chunks, ld]
   float *phs, *pts;                           // [n_chunks] scalar (b2) partials
   float *pblock, *pbs;                        // [n_blocks, ld], [n_blocks]: partials of all-inner workgroups (k_seg_reduce_planned)
-  float *hot_part, *hot_ps;                   // [kMaxHot * kHotTiles, ld], [kMaxHot * kHotTiles]: (hot segment, sample tile) partials
   float *bpart;                               // [n_bpart, ld]
-  const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row; solo_v + 2B:
-                                              //   [B] sample b holds at least one W row that only it touches
-  const uint32_t *solo_w;                     // [ceil(N/32)] or nullptr: bit n set = W row n is touched by ONE sample of the batch
+  const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row
   unsigned long long *stamps;                 // diagnostic builds (DRX_STAMPS) only
   const int32_t *order;                       // [B] or nullptr: launch order of the forward kernel's triples (k_order_by_degree)
   int T, n_chunks, n_bpart;
 };
-
-// The V keys of a touch list are 2N + user id: with ten million users that is a 24-bit key space and a THIRD pass of the radix sort
-// for the sake of 65 536 of 1.4 M touches.  A batch holds at most B distinct users, so they are numbered by their SLOT in an
-// open-addressing table of 4B entries (atomicCAS; cleared per batch): V key = 2N + slot, 22 bits at N = 10^6 — two 11-bit passes.
-// The table travels with the prepared list (the reduction turns a slot back into a user with one load per V segment).  Used when
-// n_users exceeds the table; smaller user sets keep their ids.
-__device__ __forceinline__ uint32_t user_hash(uint32_t u) { u *= 0x9E3779B1u; return u ^ (u >> 15); }
-
-__global__ __launch_bounds__(kBlock) void k_user_slots(const int32_t *__restrict__ uid, int B, uint32_t *__restrict__ vtab, uint32_t vt_mask,
-                                                       uint32_t *__restrict__ vslot) {
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= B) return;
-  const uint32_t u = (uint32_t)uid[b];
-  uint32_t h = user_hash(u) & vt_mask;
-  for (;;) {
-    const uint32_t old = atomicCAS(&vtab[h], 0xFFFFFFFFu, u);
-    if (old == 0xFFFFFFFFu || old == u) break;
-    h = (h + 1) & vt_mask;
-  }
-  vslot[b] = h;
-}
-
-// Touch list of one batch (row key, sample): depends only on the batch, never on the parameters, so it can be built
-// and sorted for batch t+1 while batch t trains (drx_cdae_sparse_prepare on a second stream).
-// Also clears the sole-toucher marks of the batch (solo: [2B] bytes, solo_w: one bit per item; or nullptr) and pads the slots beyond
-// the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
-__global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
-                                                           uint32_t *vals, int T, uint8_t *solo, uint32_t *solo_w, uint32_t *zero_a,
-                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b, const uint32_t *__restrict__ vslot,
-                                                           uint32_t *zero_c, int n_zero_c) {
-  constexpr int G = 16;
-  const int lane = threadIdx.x % G;
-  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (solo_w)
-    for (int w = blockIdx.x * kBlock + threadIdx.x; w < (n_items + 31) / 32; w += gridDim.x * kBlock) solo_w[w] = 0u;
-  // (two more ranges of words the preparation wants zeroed: the span plan's counters + window bytes, the degree-order work area)
-  // (word 2 of the first range = "the V keys are table slots")
-  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_a; w += gridDim.x * kBlock) zero_a[w] = (w == 2 && vslot) ? 1u : 0u;
-  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_b; w += gridDim.x * kBlock) zero_b[w] = 0u;
-  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_c; w += gridDim.x * kBlock) zero_c[w] = 0u;      // (the sort's counters and tile words)
-  if (b >= bt.B) return;
-  if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; solo[2 * (size_t)bt.B + b] = 0; }
-  if (b == bt.B - 1)
-    for (int j = bt.keep_off[bt.B] + 2 * bt.B + lane; j < T; j += G) { keys[j] = DRX_KEY_NONE; vals[j] = 0; }
-  const int u = bt.uid[b];
-  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
-  const int base = bt.keep_off[b] + 2 * b;
-  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
-  for (int64_t j = s + lane; j < e; j += G) {
-    const uint32_t jj = (uint32_t)(j - s);
-    const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
-    keys[base + jj] = kf ? (uint32_t)H.indices[j] : DRX_KEY_NONE;
-    vals[base + jj] = (uint32_t)b;
-  }
-  if (lane == 0) {
-    const int deg = (int)(e - s);
-    keys[base + deg] = (uint32_t)(n_items + bt.iid[b]);       vals[base + deg] = (uint32_t)b;
-    keys[base + deg + 1] = (uint32_t)(2 * n_items) + (vslot ? vslot[b] : (uint32_t)u);       vals[base + deg + 1] = (uint32_t)b;
-  }
-}
 
 template <int G, int J, int KIND = -1>
 __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOptim &opt, int B, uint32_t key, int lane,
@@ -692,158 +630,6 @@ __device__ __forceinline__ void sparse_apply(const DrxCdaeParams &P, const DrxOp
     opt_update1<KIND>(o, gs, pb, m, v);
     P.b2[row] = pb; opt.s1[4][row] = m;
     if (kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
-  }
-}
-
-// Launch order of the forward kernel's triples: longest histories first, triples of similar length side by side (r03 phase stamps:
-// a triple lives 19 us on average but 25 us at the 90th percentile and far longer for the few users with hundreds of items; a
-// workgroup waits for its slowest triple and the launch for its last workgroups — 47 % of the chip's group slots were occupied on
-// average).  A counting sort by history length in 256 buckets of 4 items, two small launches on the preparation's stream (counts;
-// scatter), each workgroup over 1024 triples; `work` = 512 zeroed ints (k_sparse_touches clears them).  A first version did it all
-// in ONE workgroup: 152 us of side-stream time per step, which made the preparation — not the training — the pipeline's bound.
-// The order inside a bucket comes from atomics and differs from run to run: it decides only WHERE a triple is computed, never a result.
-// (degree_bucket / same_bucket_lanes / degree_counts_body: drx_common.hpp — the counts can ride in the sort's first launch)
-__global__ __launch_bounds__(1024) void k_degree_counts(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work) {
-  __shared__ unsigned int cnt[256];
-  degree_counts_body<1024>(keep_off, B, work, (int)blockIdx.x, cnt);
-}
-
-template <int NT>
-__device__ __forceinline__ void degree_scatter_body(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
-                                                    int32_t *__restrict__ order, int block_id, unsigned int *lds /* [768] */) {
-  unsigned int *start = lds, *cnt = lds + 256, *base = lds + 512;
-  for (int i = threadIdx.x; i < 256; i += NT) cnt[i] = 0;
-  if (threadIdx.x < 64) {                            // exclusive scan of the 256 global counts by one wave: 4 bins per lane
-    unsigned int c[4], sum = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { c[q] = work[threadIdx.x * 4 + q]; sum += c[q]; }
-    unsigned int inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
-    unsigned int run = inc - sum;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { start[threadIdx.x * 4 + q] = run; run += c[q]; }
-  }
-  __syncthreads();
-  const int b = block_id * NT + (int)threadIdx.x, lane = threadIdx.x & 63;
-  const bool valid = b < B;
-  const int d = valid ? degree_bucket(keep_off, b) : 0;
-  const unsigned long long m = same_bucket_lanes(valid, d);
-  const int leader = valid ? __ffsll((long long)m) - 1 : lane;
-  unsigned int at = 0;
-  if (valid && lane == leader) at = atomicAdd(&cnt[d], (unsigned int)__popcll(m));        // place inside this workgroup's share
-  at = __shfl(at, leader);
-  __syncthreads();
-  for (int i = threadIdx.x; i < 256; i += NT) base[i] = cnt[i] ? atomicAdd(&work[256 + i], cnt[i]) : 0u;     // the share's place in the bucket
-  __syncthreads();
-  if (valid) order[start[d] + base[d] + at + __popcll(m & ((1ull << lane) - 1ull))] = b;
-}
-
-__global__ __launch_bounds__(1024) void k_degree_scatter(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
-                                                         int32_t *__restrict__ order) {
-  __shared__ unsigned int lds[768];
-  degree_scatter_body<1024>(keep_off, B, work, order, (int)blockIdx.x, lds);
-}
-
-// V and W2T rows are mostly touched by ONE sample of the batch (a user is drawn once, output items are uniform), and so are the W
-// rows of the long tail of unpopular items (10M x 1M set, B = 65 536: 2/3 of the distinct W rows of a batch, 1/8 of the W touches).
-// When the touch list is prepared ahead of the step, such rows are marked here: the forward/backward kernel, which holds the
-// sample's gradient rows in registers, then applies their update itself (no g2 row written, no re-read of the gradient
-// and of the parameter row later), and the touch is blanked (DRX_KEY_NONE) so that the segmented reduction passes over
-// it.  A sole toucher cannot race: no other sample of the batch reads or writes that row.  V / W2T marks are a byte per sample;
-// a W mark is a bit per ITEM (solo_w; nullptr = W rows are not marked) plus a byte per sample "holds a marked item" (solo_v + 2B):
-// such a sample walks its history a second time and finds the item by its bit (solo_w_pass).
-__global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, uint32_t n_items, int B, uint8_t *solo_v,
-                            uint8_t *solo_o, uint32_t *solo_w) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
-    const uint32_t k = keys_s[j];
-    if (k == DRX_KEY_NONE || (k < n_items && !solo_w)) continue;
-    const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
-    if (k == prev || k == next) continue;            // (a neighbour blanked concurrently was a different key anyway)
-    const uint32_t b = vals_s[j];
-    if (k < n_items) { atomicOr(&solo_w[k >> 5], 1u << (k & 31)); solo_v[2 * (size_t)B + b] = 1; }
-    else if (k < 2 * n_items) solo_o[b] = 1;
-    else solo_v[b] = 1;
-    keys_s[j] = DRX_KEY_NONE;
-  }
-}
-
-// The span plan and the sole-toucher marks in ONE launch over the freshly sorted list (two launches cost the preparation — the
-// pipeline's bound once the training kernels got faster — a launch gap and 15 us): the first n_chunks threads plan their chunk, then
-// every thread marks its share of the touches.  The two do not disturb each other: a key that is blanked has one touch, a key whose
-// run the plan measures crosses a chunk border (>= 2 touches), and the plan's searches only test keys for equality with such a key.
-// order_blocks workgroups behind the plan's: the scatter half of the launch order (k_degree_scatter's work, 256 triples each; the
-// counts were taken before the sort) — one launch less for the preparation's stream to wait for.
-__global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, int n_chunks, int cpb,
-                                                       SpanPlan P, uint32_t n_items, int B, uint8_t *solo_v, uint8_t *solo_o,
-                                                       uint32_t *solo_w, int order_blocks, const int32_t *keep_off, unsigned int *order_work,
-                                                       int32_t *order) {
-  const int plan_blocks = (int)gridDim.x - order_blocks;
-  if ((int)blockIdx.x >= plan_blocks) {
-    __shared__ unsigned int lds[768];
-    degree_scatter_body<256>(keep_off, B, order_work, order, (int)blockIdx.x - plan_blocks, lds);
-    return;
-  }
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
-  for (int j = tid; j < T; j += plan_blocks * blockDim.x) {
-    const uint32_t k = keys_s[j];
-    if (k == DRX_KEY_NONE || (k < n_items && !solo_w)) continue;
-    const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
-    if (k == prev || k == next) continue;
-    const uint32_t b = vals_s[j];
-    if (k < n_items) { atomicOr(&solo_w[k >> 5], 1u << (k & 31)); solo_v[2 * (size_t)B + b] = 1; }
-    else if (k < 2 * n_items) solo_o[b] = 1;
-    else solo_v[b] = 1;
-    keys_s[j] = DRX_KEY_NONE;
-  }
-}
-
-// Second walk over a triple's history, after its gradient row dz1 is known: the kept items whose W row carries a sole-toucher
-// mark get their sparse update here, from registers (gradient scale * dz1[b], exactly the one-touch segment the reduction would have
-// folded: same arithmetic, same bits).  The indices come from L1/L2 (the gather read them a moment ago), the mark words from the
-// 125 KB bitmap; per marked row: parameter row (just gathered: L2) + slot row in, both out.
-template <int G, int J, int KIND = -1>
-__device__ __forceinline__ void solo_w_pass(const DrxCdaeParams &P, const DrxOptim &opt, const DrxHistory &H, const DrxBatch &bt,
-                                            uint32_t qthr, float scale, const uint32_t *__restrict__ solo_w, int b, int lane,
-                                            const float4 (&dz1)[J]) {
-  const int gshift = (threadIdx.x & 63) / G * G;
-  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-  float4 g[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) { g[j] = f4_zero(); f4_fma(g[j], scale, dz1[j]); }
-  // (b laundered: the walk re-reads uid / indptr instead of keeping the gather's copies alive in registers through the whole kernel —
-  // 65 instead of 62 VGPRs would cost the forward kernel its eighth wave per SIMD)
-  int bq = b;
-  asm volatile("" : "+v"(bq));
-  const int u = bt.uid[bq];
-  const int64_t s = H.indptr[u];
-  const int n = (int)(H.indptr[u + 1] - s);
-  const int32_t *const ind = H.indices + s;
-  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
-  constexpr int IPL = G >= 16 ? 1 : 16 / G;
-  constexpr int CH = G * IPL;
-  for (int c = 0; c < n; c += CH) {
-    int idx[IPL], sw[IPL];
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      const int jj = c + r * G + lane;
-      idx[r] = 0; sw[r] = 0;
-      if (jj < n) {
-        idx[r] = ind[jj];
-        const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, (uint32_t)jj) >= qthr);
-        if (kf) sw[r] = (int)((solo_w[idx[r] >> 5] >> (idx[r] & 31)) & 1u);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      unsigned long long m = (__ballot(sw[r] != 0) >> gshift) & gmask;
-      while (m) {
-        const int t = __builtin_ctzll(m);
-        m &= m - 1;
-        sparse_apply<G, J, KIND>(P, opt, bt.B, (uint32_t)__shfl(idx[r], t, G), lane, g, 0.f);
-      }
-    }
   }
 }
 
@@ -893,8 +679,6 @@ __device__ __forceinline__ void sampled_rest(const DrxCdaeParams &P, const DrxOp
     if (lane == 0) S.dz2[b] = dz2;
   }
   if (solo_v) sparse_apply<G, J, KIND>(P, opt, bt.B, 2u * (uint32_t)P.n_items + (uint32_t)u, lane, dz1, 0.f);
-  const uint32_t *const pw = S.solo_w;
-  if (pw && pv[2 * (size_t)bt.B + b]) solo_w_pass<G, J, KIND>(P, opt, H, bt, qthr, scale, pw, b, lane, dz1);
   if (dz1_out) {
 #pragma unroll
     for (int j = 0; j < J; ++j) (*dz1_out)[j] = dz1[j];
@@ -982,245 +766,6 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
   sampled_finish<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, acc);
 }
 
-// The forward/backward kernel with sole-toucher W rows (DRX_BATCH_MARK_W; Adagrad).  A triple that holds marked rows (byte mark)
-// fetches, beside the rows of its gather, the items' bits of the mark bitmap and notes the marked items in LDS.  Right after the
-// gather — when the 8 row buffers of the loop are free — the parameter rows (again: they are in L2) and accumulator rows of those
-// items are requested; they travel in the shadow of the hidden layer's own loads.  At the end the update is arithmetic on registers
-// and two stores per row: no second walk, no extra round trip in the triple's dependent chain (r03a measured the second walk at +120 us for the 10M x 1M batch; the reduction it relieves runs 50 us shorter).  A triple with
-// more than kStash marked rows (rare) takes the walk (solo_w_pass) for all of them.
-constexpr int kStash = 4;
-
-template <int G, int J>
-__device__ __forceinline__ void adagrad_commit(const OptScalars &o, float *tab, float *s1, size_t row, int ld, int lane,
-                                               const float4 (&w)[J], const float4 (&a)[J], const float4 (&g)[J]) {
-  float4 *pr = reinterpret_cast<float4 *>(tab + row * (size_t)ld), *ar = reinterpret_cast<float4 *>(s1 + row * (size_t)ld);
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int c = lane + j * G;
-    if (4 * c < ld) {
-      float4 p = w[j], m = a[j];
-      float unused = 0.f;
-      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.x, g[j].x), p.x, m.x, unused);
-      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.y, g[j].y), p.y, m.y, unused);
-      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.z, g[j].z), p.z, m.z, unused);
-      opt_update1<DRX_OPT_ADAGRAD>(o, fmaf(o.rb, p.w, g[j].w), p.w, m.w, unused);
-      pr[c] = p;
-      ar[c] = m;
-    }
-  }
-}
-
-#ifdef DRX_STASH_W8
-#define DRX_STASH_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
-#else
-#define DRX_STASH_ATTR
-#endif
-template <int G, int J>      // J == 1 only (rows of <= 256 floats: a row is one 16-byte piece per lane)
-__global__ __launch_bounds__(kBlock) DRX_STASH_ATTR void k_sampled_fwd_bwd_stash(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
-                                                                  uint32_t qthr, int loss_kind, SparseBufs S) {
-  __shared__ int ids_lds[(kBlock / G) * (kStash + 1)];   // per group: how many W rows this triple alone touches, and which items
-  const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  const int b = blockIdx.x * (kBlock / G) + r;
-  if (b >= bt.B) return;
-  const int gshift = (threadIdx.x & 63) / G * G;
-  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-  const uint32_t *const pw = S.solo_w;
-  const uint8_t *const pv = S.solo_v;
-  float4 acc[J];
-  DenseAux none{};
-  gather_bag<G, J, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0);
-  // A triple that holds marked rows (byte mark) walks its history once more right away — indices from L1/L2, mark bits from the
-  // 125 KB bitmap — and notes the marked items in LDS, in history order.  (Done inside the gather loop this cost the kernel its
-  // eighth wave per SIMD: 69 VGPRs; b is laundered so that the gather's copies of uid / indptr are not kept alive for it.)
-  int cnt = 0;
-  if (pv[2 * (size_t)bt.B + b]) {
-    int bq = b;
-    asm volatile("" : "+v"(bq));
-    const int u = bt.uid[bq];
-    const int64_t s = H.indptr[u];
-    const int n = (int)(H.indptr[u + 1] - s);
-    const int32_t *const ind = H.indices + s;
-    const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[bq] : nullptr;
-    for (int c = 0; c < n; c += G) {
-      const int jj = c + lane;
-      int item = 0;
-      bool mk = false;
-      if (jj < n) {
-        item = ind[jj];
-        const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)bq, (uint32_t)jj) >= qthr);
-        mk = kf && ((pw[item >> 5] >> (item & 31)) & 1u);
-      }
-      const unsigned long long m = (__ballot(mk) >> gshift) & gmask;
-      if (m) {
-        const int at = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (mk && at < kStash) ids_lds[r * (kStash + 1) + 1 + at] = item;
-        cnt += __popcll(m);
-      }
-    }
-  }
-  // accumulator rows of the marked items (HBM misses: the slow half of their update), requested NOW and straight into LDS
-  // (global_load_lds: no register is held while they travel in the shadow of the hidden layer's own loads).  One wave-instruction
-  // writes 64 lanes x 16 B = the rows of the wave's 64 / G groups side by side; slot q of the wave lives at q KiB of its region.
-  extern __shared__ __align__(16) float slot_lds[];          // [4 waves][kStash][64 lanes x 4 floats]
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
-  float *const wave_slots = slot_lds + (size_t)wave * kStash * 256;
-  if (lane == 0) ids_lds[r * (kStash + 1)] = cnt;          // (kept in LDS, not in a register, across the rest of the kernel: 64 VGPRs)
-  if (cnt > 0 && cnt <= kStash) {
-    wave_lds_sync();                            // (ids written by some lanes of the group are read by all of them)
-    const float *const a0 = opt.s1[0];
-#pragma unroll
-    for (int q = 0; q < kStash; ++q) {
-      if (q < cnt && 4 * lane < P.ld) {
-        const float *src = a0 + (size_t)ids_lds[r * (kStash + 1) + 1 + q] * P.ld + 4 * lane;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(wave_slots + q * 256), 16, 0, 0);
-      }
-    }
-  }
-  float4 h[J], w2[J];
-  const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
-  SparseBufs S2 = S;                            // (sampled_rest with the W walk switched off: the marks are served below)
-  S2.solo_w = nullptr;
-  float4 dz1[J];
-  sampled_rest<G, J, DRX_OPT_ADAGRAD>(P, opt, H, bt, scale, qthr, loss_kind, S2, b, lane, d, h, w2, &dz1);
-  wave_lds_sync();
-  const int cnt2 = ids_lds[(threadIdx.x / G) * (kStash + 1)];
-  const int *const my_ids = ids_lds + (threadIdx.x / G) * (kStash + 1) + 1;
-  if (cnt2 > 0 && cnt2 <= kStash) {
-    float4 g[J];
-#pragma unroll
-    for (int jx = 0; jx < J; ++jx) { g[jx] = f4_zero(); f4_fma(g[jx], scale, dz1[jx]); }
-    const OptScalars o = opt_for(opt, 0, bt.B);
-    float *const tW = P.W, *const a0 = opt.s1[0];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's LDS-DMA has landed (nothing else orders a ds_read behind it)
-#pragma unroll
-    for (int q0 = 0; q0 < kStash; q0 += 2) {
-      float4 prow[2][J];                         // the parameter rows again: the gather had them a moment ago, L2 still does
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        prow[q][0] = f4_zero();
-        if (q0 + q < cnt2) load_row<G, J>(tW, (size_t)my_ids[q0 + q], P.ld, lane, prow[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (q0 + q < cnt2) {
-          float4 slot[J];
-          slot[0] = *reinterpret_cast<const float4 *>(wave_slots + (q0 + q) * 256 + 4 * (threadIdx.x % 64));
-          adagrad_commit<G, J>(o, tW, a0, (size_t)my_ids[q0 + q], P.ld, lane, prow[q], slot, g);
-        }
-      }
-    }
-  } else if (cnt2 > kStash) {
-    solo_w_pass<G, J, DRX_OPT_ADAGRAD>(P, opt, H, bt, qthr, scale, pw, b, lane, dz1);
-  }
-}
-
-// The forward/backward kernel with its late rows PREFETCHED INTO LDS (Adagrad, one float4 per lane; r03).  One triple is a chain of
-// dependent round trips: uid -> indptr -> indices -> rows (two rounds) -> V[u], b -> W2T[i] -> b2[i], y -> marks -> slot rows of the
-// sole-toucher updates, and with 16 such chains per SIMD the kernel is bound by their LENGTH (r02: 69 % of the wave-cycles in
-// s_waitcnt at 3.6 TB/s).  Everything behind the gather depends on (u, i) alone, but fetching it early into registers cost two waves
-// per SIMD (r02e: 90 VGPRs, no gain).  global_load_lds needs no register: V[u], W2T[i] and — where the marks say this triple is their
-// only toucher — the two accumulator rows are requested as soon as uid / iid are known, land in LDS while the gather runs, and are
-// read back with ds_read: the chain behind the gather shrinks to one round trip (b, b2[i], y: L2 hits) and the stores.
-// One wave-instruction writes 64 lanes x 16 B: the rows of the wave's 64 / G groups side by side; slot s of a wave is at s KiB.
-template <int G>
-__device__ __forceinline__ void glds_row(const float *tab, size_t row, int ld, int lane, float *lds_slot) {
-  if (4 * lane < ld)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tab + row * (size_t)ld + 4 * lane),
-                                     (__attribute__((address_space(3))) void *)lds_slot, 16, 0, 0);
-}
-
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd_pf(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
-                                                               uint32_t qthr, int loss_kind, SparseBufs S) {
-  extern __shared__ __align__(16) float pf_lds[];            // [kBlock / 64 waves][4 slots][64 lanes x 4 floats]
-  const int lane = threadIdx.x % G;
-  const int slot = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (slot >= bt.B) return;
-  const int32_t *const ord = S.order;
-  const int b = ord ? ord[slot] : slot;            // longest histories first, similar lengths side by side
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
-  float *const ws = pf_lds + (size_t)wave * 4 * 256;
-  const int wl4 = 4 * (int)(threadIdx.x % 64);
-  const bool act = 4 * lane < P.ld;
-  DRX_STAMP(S.stamps, b, 0, lane);
-  {
-    // (the two accumulator rows are requested whatever the marks say — nine triples in ten are the only toucher of their V and
-    // W2T rows — so that nothing here waits for a mark byte before the gather's own chain starts)
-    const int u = bt.uid[b], i = bt.iid[b];
-    glds_row<G>(P.V, (size_t)u, P.ld, lane, ws);
-    glds_row<G>(P.W2T, (size_t)i, P.ld, lane, ws + 256);
-    if (S.solo_v) {
-      glds_row<G>(opt.s1[2], (size_t)u, P.ld, lane, ws + 512);
-      glds_row<G>(opt.s1[1], (size_t)i, P.ld, lane, ws + 768);
-    }
-  }
-  DRX_STAMP(S.stamps, b, 1, lane);
-  float4 acc[1];
-  DenseAux none{};
-  gather_bag<G, 1, 0>(P, H, bt, qthr, b, lane, acc, none, nullptr, nullptr, 0, 0, 1, S.stamps);
-  DRX_STAMP(S.stamps, b, 5, lane);
-  // (b laundered: ids and marks are re-read — L1 hits — instead of living in registers through the gather)
-  int bq = b;
-  asm volatile("" : "+v"(bq));
-  const int u = bt.uid[bq], i = bt.iid[bq];
-  const uint8_t *const pv = S.solo_v, *const po = S.solo_o;
-  const bool solo_v = pv && pv[bq], solo_o = po && po[bq];
-  float4 bb[1];
-  load_row<G, 1>(P.b, 0, P.ld, lane, bb);
-  const float y = bt.y[bq], pb2 = P.b2[i];
-  const float mb2 = solo_o ? opt.s1[4][i] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's LDS-DMA has landed (nothing else orders a ds_read behind it)
-  DRX_STAMP(S.stamps, b, 6, lane);
-  const float4 zero = f4_zero();
-  const float4 v = act ? *reinterpret_cast<const float4 *>(ws + wl4) : zero;
-  const float4 w2 = act ? *reinterpret_cast<const float4 *>(ws + 256 + wl4) : zero;
-  float4 h;
-  {
-    const int col = 4 * lane;
-    h.x = colmask(col + 0, P.k, sigmoidf_(fmaf(scale, acc[0].x, v.x + bb[0].x)));
-    h.y = colmask(col + 1, P.k, sigmoidf_(fmaf(scale, acc[0].y, v.y + bb[0].y)));
-    h.z = colmask(col + 2, P.k, sigmoidf_(fmaf(scale, acc[0].z, v.z + bb[0].z)));
-    h.w = colmask(col + 3, P.k, sigmoidf_(fmaf(scale, acc[0].w, v.w + bb[0].w)));
-  }
-  const float d = group_sum<G>(f4_dot(w2, h));
-  const float p = sigmoidf_(d + pb2);
-  const float invB = 1.0f / (float)bt.B;
-  float lval, dp;
-  if (loss_kind == DRX_LOSS_BCE) { lval = bce_elem(y, p); dp = bce_grad(y, p) * invB; }
-  else { lval = (p - y) * (p - y); dp = 2.0f * (p - y) * invB; }
-  const float dz2 = dp * p * (1.0f - p);
-  float4 dz1[1], g2[1];
-  dz1[0].x = dz2 * w2.x * h.x * (1.0f - h.x); dz1[0].y = dz2 * w2.y * h.y * (1.0f - h.y);
-  dz1[0].z = dz2 * w2.z * h.z * (1.0f - h.z); dz1[0].w = dz2 * w2.w * h.w * (1.0f - h.w);
-  g2[0].x = dz2 * h.x; g2[0].y = dz2 * h.y; g2[0].z = dz2 * h.z; g2[0].w = dz2 * h.w;
-  store_row<G, 1>(S.dz1, (size_t)b, P.ld, lane, dz1);
-  if (lane == 0) S.lossb[b] = lval;
-  DRX_STAMP(S.stamps, b, 7, lane);
-  OptScalars o = opt_for(opt, 0, bt.B);
-  if (solo_o) {      // this triple alone touches W2T[i] and b2[i] (same arithmetic as sparse_apply / the segment path)
-    float4 w[1] = {w2}, a[1];
-    a[0] = act ? *reinterpret_cast<const float4 *>(ws + 768 + wl4) : zero;
-    adagrad_commit<G, 1>(o, P.W2T, opt.s1[1], (size_t)i, P.ld, lane, w, a, g2);
-    if (lane == 0) {
-      OptScalars ob = o;
-      ob.rb = 0.f;
-      float pb = pb2, m = mb2, unused = 0.f;
-      opt_update1<DRX_OPT_ADAGRAD>(ob, dz2, pb, m, unused);
-      P.b2[i] = pb; opt.s1[4][i] = m;
-    }
-  } else {
-    store_row<G, 1>(S.g2, (size_t)b, P.ld, lane, g2);
-    if (lane == 0) S.dz2[b] = dz2;
-  }
-  if (solo_v) {
-    float4 w[1] = {v}, a[1];
-    a[0] = act ? *reinterpret_cast<const float4 *>(ws + 512 + wl4) : zero;
-    adagrad_commit<G, 1>(o, P.V, opt.s1[2], (size_t)u, P.ld, lane, w, a, dz1);
-  }
-  DRX_STAMP(S.stamps, b, 8, lane);
-}
-
 // Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
 // a chain of ~20 dependent load rounds on a chip that is mostly idle (measured 143 us at B = 4096).  Here one WORKGROUP
 // takes a triple: its 256/G groups split the history, the partial bags are summed in LDS in group order.
@@ -1263,8 +808,6 @@ struct DirectPolicyT {
   const float *dz1;
   long long g2_off;
   const float *dz2;
-  // V keys of this list: 2N + user id, or — cnt_flags[2] != 0 — 2N + the user's slot in the batch's user table vtab (see k_user_slots)
-  const uint32_t *vtab, *cnt_flags;
   template <int G, int J>
   __device__ __forceinline__ void load(uint32_t key, uint32_t b, int lane, float4 (&row)[J], float &sc, float &coef) const {
     const uint32_t N = (uint32_t)P.n_items;
@@ -1275,69 +818,11 @@ struct DirectPolicyT {
   }
   template <int G, int J>
   __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
-    const uint32_t N2 = 2u * (uint32_t)P.n_items;
-    if (key >= N2 && cnt_flags[2]) key = N2 + vtab[key - N2];          // slot -> user
     sparse_apply<G, J, KIND>(P, opt, B, key, lane, g, gs);
   }
 };
 using DirectPolicy = DirectPolicyT<-1>;                      // optimizer chosen at run time
 using DirectPolicyAdagrad = DirectPolicyT<DRX_OPT_ADAGRAD>;  // the throughput configuration's optimizer, known at compile time
-
-// hidden bias b: column sums of dz1 in two deterministic stages, then a dense optimizer update.  Both stages are ROLES of
-// the two tail launches of the sparse step (k_sparse_tail_a / _b below): they share a launch with the span fix-ups, which
-// they do not depend on.
-struct BiasArgs {
-  const float *dz1;       // [B, ld]
-  float *part;            // [n_part, ld] column-sum partials, then [n_part] loss partials
-  const float *lossb;     // [B]
-  float *loss_out;        // nullptr: no loss wanted
-  int B, n_part, rows_per_block;
-};
-
-template <int G, int J, int NT>
-__device__ __forceinline__ void bias_partial_body(int ld, const BiasArgs &A, int block_id, float *lds /* [NT/G, ld] */, float *red) {
-  constexpr int R = NT / G;
-  const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  const int b0 = block_id * A.rows_per_block, b1 = min(A.B, b0 + A.rows_per_block);
-  float4 acc[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  constexpr int NB = J == 1 ? 8 : 2;            // rows in flight per group (one at a time made these sums chains of dependent loads)
-  for (int b = b0 + r; b < b1; b += NB * R) {
-    float4 v[NB][J];
-#pragma unroll
-    for (int q = 0; q < NB; ++q) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
-      if (b + q * R < b1) load_row<G, J>(A.dz1, (size_t)(b + q * R), ld, lane, v[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < NB; ++q)
-#pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(acc[j], v[q][j]);
-  }
-  store_row<G, J>(lds, (size_t)r, ld, lane, acc);
-  __syncthreads();
-  if (r == 0) {
-    float4 t[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) t[j] = f4_zero();
-#pragma unroll 8
-    for (int rr = 0; rr < R; ++rr) {
-      float4 v[J];
-      load_row<G, J>(lds, (size_t)rr, ld, lane, v);
-#pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
-    }
-    store_row<G, J>(A.part, (size_t)block_id, ld, lane, t);
-  }
-  if (A.loss_out) {                                // this block's slice of the per-sample losses
-    float a = 0.f;
-    for (int b = b0 + (int)threadIdx.x; b < b1; b += NT) a += A.lossb[b];
-    const float tl = block_sum(a, red);
-    if (threadIdx.x == 0) A.part[(size_t)A.n_part * ld + block_id] = tl;
-  }
-}
 
 template <int G, int J, int NT>
 __device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const DrxOptim &opt, const BiasArgs &A,
@@ -1393,16 +878,6 @@ __device__ __forceinline__ void bias_final_body(const DrxCdaeParams &P, const Dr
 // partials of dz1 as extra workgroups of k_seg_reduce_planned (they depend on the forward kernel only), the final sum + update of b
 // (+ the mean loss) as one extra workgroup of k_span_planned.  The sparse step is three launches: forward/backward, reduction, spans.
 template <int G, int J>
-struct BiasPartialExtra {
-  int ld;
-  BiasArgs A;
-  __device__ __forceinline__ void operator()(float *lds) const {
-    __shared__ float red[kSegBlock / 64 > 0 ? kSegBlock / 64 : 1];
-    bias_partial_body<G, J, kSegBlock>(ld, A, (int)blockIdx.x, lds, red);
-  }
-};
-
-template <int G, int J>
 struct BiasFinalExtra {
   DrxCdaeParams P;
   DrxOptim opt;
@@ -1420,8 +895,6 @@ constexpr int kSmallBatch = 1024;    // at or below: one workgroup per batch row
 constexpr int kFewRows = 128;        // at or below: that workgroup has 1024 threads (fewer rows than CUs: spread each row wider)
 constexpr int kOutGrid = 512;        // persistent workgroups of k_out_dense (two per CU when LDS allows)
 constexpr int kSweepGrid = 1024;
-constexpr int kLongBlocks = 256, kShortBlocks = 1024, kHotFinBlocks = 256;
-constexpr int kHotBlocks = 2048;     // workgroups of the hot-tiles role inside the reduction's launch (a multiple of 8: one share per XCD)   // k_span_planned: workgroups striding over the long / the short spans
 constexpr size_t kLdsBudget = 144 * 1024;
 
 struct DenseLayout {
@@ -1477,57 +950,6 @@ static DenseLayout dense_layout(Carver &cv, const DrxCdaeParams &P, int B, bool 
   return L;
 }
 
-struct PrepBufs {
-  uint32_t *keys_s, *vals_s, *keys, *vals;
-  void *sort_temp;
-  size_t sort_bytes;
-  uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo); then [B] "holds a marked W row"
-  uint32_t *solo_w;             // [ceil(N/32)] one bit per item
-  SpanPlan plan;                // chunk-crossing segments of the list (k_plan_spans)
-  uint32_t *vtab;               // [vt] the batch's user table (k_user_slots), part of the result: slot -> user id
-  uint32_t *vslot;              // [B] slot of every sample's user (work area)
-  int vt, bits_hashed;          // table entries (power of two >= 4B); key bits when the V keys are slots
-  int32_t *order;               // [B] launch order of the forward kernel (k_degree_counts / k_degree_scatter)
-  unsigned int *order_work;     // [512] bucket counts | running places (zeroed by k_sparse_touches)
-  int n_chunks;
-  size_t result_bytes;
-  int T, bits;
-};
-
-static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots) {
-  PrepBufs R{};
-  R.T = n_touch_slots + 2 * B;
-  R.bits = bits_for((uint64_t)2 * P.n_items + P.n_users + 1);
-  // the RESULT first and contiguous (drx_cdae_prep_result_bytes: what a step reads, and all that has to travel when one rank
-  // prepares a list for the others), then what only the preparation itself needs
-  R.keys_s = cv.take<uint32_t>(R.T);
-  R.vals_s = cv.take<uint32_t>(R.T);
-  R.solo_v = cv.take<uint8_t>((size_t)3 * B);
-  R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
-  R.solo_w = cv.take<uint32_t>(((size_t)P.n_items + 31) / 32);
-  R.n_chunks = (R.T + kChunk - 1) / kChunk;
-  R.plan.desc = cv.take<uint2>(R.n_chunks);
-  R.plan.cnt = cv.take<uint32_t>(64);
-  R.plan.ext = cv.take<uint8_t>(R.n_chunks);
-  R.plan.hflag = cv.take<uint8_t>(R.n_chunks);
-  R.plan.hot = cv.take<uint4>(kMaxHot);
-  R.plan.hot_bounds = cv.take<uint32_t>((size_t)kMaxHot * (kHotTiles + 1));
-  R.plan.hot_pref = cv.take<uint32_t>(kMaxHot + 1);
-  R.order = cv.take<int32_t>(B);
-  R.vt = 1;
-  while (R.vt < 4 * B) R.vt <<= 1;
-  R.vtab = cv.take<uint32_t>(R.vt);
-  R.bits_hashed = bits_for((uint64_t)2 * P.n_items + (uint64_t)R.vt + 1);
-  R.result_bytes = align_up(cv.off, 256);
-  R.keys = cv.take<uint32_t>(R.T);
-  R.vals = cv.take<uint32_t>(R.T);
-  R.sort_bytes = std::max(sort_pairs_temp_bytes(R.T, R.bits), sort_pairs_temp_bytes(R.T, R.bits_hashed));     // (11-bit digits need more)
-  R.sort_temp = cv.take<char>(R.sort_bytes);
-  R.order_work = cv.take<unsigned int>(512);
-  R.vslot = cv.take<uint32_t>(B);
-  return R;
-}
-
 static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots) {
   SparseBufs S{};
   S.T = n_touch_slots + 2 * B;
@@ -1546,11 +968,6 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
     const int n_blocks = (S.n_chunks + cpb - 1) / cpb;
     S.pblock = cv.take<float>((size_t)n_blocks * P.ld);
     S.pbs = cv.take<float>(n_blocks);
-    // (a hot segment has at least max(32, T / kMaxHot) touches — plan_hot_min —; a tile's share of it is cut into hot_slices(len) slices:
-    // one partial row per (segment, tile, slice))
-    const size_t n_hp = ((size_t)S.T / (kHotTiles * kHotSlice) + 1 + (size_t)std::min<long long>(kMaxHot, (long long)S.T / 32 + 1)) * kHotTiles;
-    S.hot_part = cv.take<float>(n_hp * P.ld);
-    S.hot_ps = cv.take<float>(n_hp);
   }
   S.bpart = cv.take<float>((size_t)S.n_bpart * (P.ld + 1));     // partial rows + per-block loss partials
   return S;
@@ -2039,93 +1456,6 @@ int drx_cdae_fit_dense(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHis
   return rc;
 }
 
-// plan.cnt (64 words), plan.ext and plan.hflag (n_chunks bytes each) are consecutive 256-byte-aligned allocations: one range of words to zero
-static int plan_zero_words(const PrepBufs &R) { return (int)(((const char *)R.plan.hflag + R.n_chunks - (const char *)R.plan.cnt + 3) / 4); }
-
-// The chunk-crossing segments of a sorted list, short ones and long ones (drx_segreduce.hpp, planned variant).  On the pristine list:
-// BEFORE the sole-toucher marks blank any key.
-static int plan_spans(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R0, hipStream_t st, bool cleared) {
-  PrepBufs R = R0;
-  R.plan.hot_min = plan_hot_min(R.T, bt->flags);
-  if (!cleared) DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, (size_t)plan_zero_words(R) * 4, st));     // (prepare_impl's touch kernel clears them)
-  hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.T, R.n_chunks,
-                     kSegBlock / pick_geom(p->ld).G, R.plan);
-  if (R.plan.hot_min != 0x7FFFFFFF)
-    hipLaunchKernelGGL(k_hot_bounds, dim3((kMaxHot * (kHotTiles + 1) + 255) / 256), dim3(256), 0, st, R.vals_s, R.plan,
-                       (bt->B + kHotTiles - 1) / kHotTiles);
-  return DRX_OK;
-}
-
-// (see k_degree_counts)
-static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
-  if (!cleared) (void)hipMemsetAsync(R.order_work, 0, 512 * sizeof(unsigned int), st);
-  const int blocks = (bt->B + 1023) / 1024;
-  hipLaunchKernelGGL(k_degree_counts, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work);
-  hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
-}
-
-// W rows get sole-toucher marks when the caller asks for them (DRX_BATCH_MARK_W: worth it where a batch leaves most of its distinct
-// W rows with one touch — large catalogues; at MovieLens shapes every item collects hundreds of touches and nothing would be marked).
-// Rows of <= 16 floats are never marked (see prepare_impl).
-static bool mark_w_rows(const DrxCdaeParams *p, const DrxBatch *bt) { return (bt->flags & DRX_BATCH_MARK_W) != 0 && p->ld > 16; }
-
-static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
-                        bool with_marks = false) {
-  const int gpb = kBlock / 16;
-  // V keys = slots of the batch's user table: on request (DRX_BATCH_V_SLOTS).  Measured at 10 M users (r03l): the narrower key trades
-  // three 8-bit passes of the sort (3 x 60 us beside the training kernels) for two 11-bit ones (2 x 109 us) — a loss with this sort,
-  // whose ranking step costs one ballot per digit bit; kept for sorts / shapes where the pass count decides.
-  const bool hashed = (bt->flags & DRX_BATCH_V_SLOTS) != 0 && p->n_users > R.vt && R.bits_hashed < R.bits;
-  if (hashed) {
-    DRX_HIP(hipMemsetAsync(R.vtab, 0xFF, (size_t)R.vt * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_user_slots, dim3((bt->B + kBlock - 1) / kBlock), dim3(kBlock), 0, st, bt->uid, bt->B, R.vtab, (uint32_t)(R.vt - 1),
-                       R.vslot);
-  }
-  uint32_t *sort_zero = nullptr;
-  size_t sort_zero_words = 0;
-  sort_pairs_zero_region(R.sort_temp, (size_t)R.T, hashed ? R.bits_hashed : R.bits, &sort_zero, &sort_zero_words);
-  hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
-                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.solo_w, R.plan.cnt, plan_zero_words(R), R.order_work, 512,
-                     hashed ? R.vslot : nullptr, sort_zero, (int)sort_zero_words);
-  // the launch order (see k_degree_counts): its counts ride in the sort's first launch, its scatter in the plan + marks launch below
-  const bool fused_order = with_marks && p->ld > 16;
-  const SortRider rider{fused_order ? bt->keep_off : nullptr, bt->B, R.order_work};
-  // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
-  const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, hashed ? R.bits_hashed : R.bits,
-                               true, st, true, rider);
-  if (rc) return rc;
-  // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
-  // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
-  if (with_marks && p->ld > 16) {
-    const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
-    SpanPlan plan = R.plan;
-    plan.hot_min = plan_hot_min(R.T, bt->flags);
-    const int order_blocks = (bt->B + 255) / 256;
-    hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks + order_blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
-                       kSegBlock / pick_geom(p->ld).G, plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o,
-                       mark_w_rows(p, bt) ? R.solo_w : nullptr, order_blocks, bt->keep_off, R.order_work, R.order);
-    if (plan.hot_min != 0x7FFFFFFF)
-      hipLaunchKernelGGL(k_hot_bounds, dim3((kMaxHot * (kHotTiles + 1) + 255) / 256), dim3(256), 0, st, R.vals_s, plan,
-                         (bt->B + kHotTiles - 1) / kHotTiles);
-    return DRX_OK;
-  }
-  return plan_spans(p, bt, R, st, true);
-}
-
-// Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
-static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
-  if (!cleared) {                                                                  // (prepare_impl's touch kernel clears them)
-    DRX_HIP(hipMemsetAsync(R.solo_v, 0, (size_t)bt->B * 3, st));
-    DRX_HIP(hipMemsetAsync(R.solo_w, 0, (((size_t)p->n_items + 31) / 32) * sizeof(uint32_t), st));
-  }
-  // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
-  // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
-  if (p->ld <= 16) return DRX_OK;       // solo_v and solo_o are adjacent
-  hipLaunchKernelGGL(k_mark_solo, dim3(2048), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, (uint32_t)p->n_items, bt->B, R.solo_v,
-                     R.solo_o, mark_w_rows(p, bt) ? R.solo_w : nullptr);
-  return DRX_OK;
-}
-
 static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const DrxHistory *hist, const DrxBatch *bt,
                             int32_t loss_kind, const void *prepared, size_t prepared_bytes, void *scratch, size_t scratch_bytes,
                             float *loss_out, void *const *events, void *stream, const float *ks_h = nullptr,
@@ -2156,15 +1486,12 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
   S.solo_v = prepared ? R.solo_v : nullptr;
   S.solo_o = prepared ? R.solo_o : nullptr;
-  S.solo_w = (prepared && mark_w_rows(p, bt)) ? R.solo_w : nullptr;       // (the rule mark_solo followed)
-  static const bool use_order = [] { const char *e = getenv("DRX_FWD_ORDER"); return !e || atoi(e) != 0; }();      // (A/B switch)
-  S.order = (prepared && use_order) ? R.order : nullptr;
+  S.order = prepared ? R.order : nullptr;
   SegBufs SB{R.keys_s, R.vals_s, S.phead, S.ptail, S.phs, S.pts, nullptr, nullptr, nullptr, nullptr, S.T, S.n_chunks, p->ld, nullptr};
 #ifdef DRX_STAMPS
   S.stamps = SB.stamps = h_stamps;
 #endif
-  PlanBufs PB{S.pblock, S.pbs, S.hot_part, S.hot_ps, (bt->B + kHotTiles - 1) / kHotTiles};
-  const int hot_blocks = (bt->flags >> 16) ? kHotBlocks : 0, hot_fin_blocks = (bt->flags >> 16) ? kHotFinBlocks : 0;
+  PlanBufs PB{S.pblock, S.pbs};
   // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
   const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
@@ -2174,31 +1501,28 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
-  // the LDS-prefetch forward kernel (k_sampled_fwd_bwd_pf) is OPT-IN (DRX_FWD_PF=1): with the launch order in both, the plain kernel's
-  // phase is the shorter one (r03u, 3 runs each: 132 against 137 us; step 0.367 against 0.365 ms — inside the run-to-run spread)
-  static const bool use_pf = [] { const char *e = getenv("DRX_FWD_PF"); return e && atoi(e) != 0; }();
   // the segmented reduction (+ the bias column sums as extra workgroups) and the ONE launch that combines the chunk-crossing segments
   // (+ the bias update), with the policy type POLT (optimizer at run time, or Adagrad compiled in)
 #define REDUCE_AND_SPANS(G, J, POLT)                                                                                   \
   {                                                                                                                    \
-    POLT polk{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2, R.vtab, R.plan.cnt};                    \
+    POLT polk{*p, *opt, bt->B, scale, S.dz1, (long long)(S.g2 - S.dz1), S.dz2};                    \
     BiasPartialExtra<G, J> bpx{p->ld, BA};                                                                             \
     BiasFinalExtra<G, J> bfx{*p, *opt, BA};                                                                            \
     const int cpb = kSegBlock / G;                                                                                     \
-    const dim3 rgrid(n_bpart + hot_blocks + (S.n_chunks + cpb - 1) / cpb);                                             \
+    const dim3 rgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                                        \
     const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
     if (long_segments)                                                                                                 \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
-                         R.plan, polk, n_bpart, hot_blocks, bpx);                                                      \
+                         R.plan, polk, n_bpart, bpx);                                                                  \
     else                                                                                                               \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
-                         R.plan, polk, n_bpart, hot_blocks, bpx);                                                      \
+                         R.plan, polk, n_bpart, bpx);                                                                  \
     EV(3);                                                                                                             \
     if (lds_b > 48 * 1024)                                                                                             \
       DRX_HIP(hipFuncSetAttribute((const void *)k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>,                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                            \
-    hipLaunchKernelGGL((k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>), dim3(kLongBlocks + kShortBlocks + hot_fin_blocks + 1), \
-                       dim3(kFixBlock), lds_b, st, SB, PB, R.plan, polk, kLongBlocks, kShortBlocks, hot_fin_blocks, bfx); \
+    hipLaunchKernelGGL((k_span_planned<G, J, POLT, BiasFinalExtra<G, J>>), dim3(kLongBlocks + kShortBlocks + 1),                  \
+                       dim3(kFixBlock), lds_b, st, SB, PB, R.plan, polk, kLongBlocks, kShortBlocks, bfx);                 \
     EV(4);                                                                                                             \
     EV(5);                                                                                                             \
   }
@@ -2213,12 +1537,6 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     else if (per_wg)                                                                                                   \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
                          *bt, scale, qthr, loss_kind, S);                                                              \
-    else if (opt->kind == DRX_OPT_ADAGRAD && S.solo_w && J == 1)                                                       \
-      hipLaunchKernelGGL((k_sampled_fwd_bwd_stash<G, 1>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock),                 \
-                         (size_t)(kBlock / 64) * kStash * 1024, st, *p, *opt, *hist, *bt, scale, qthr, loss_kind, S);  \
-    else if (opt->kind == DRX_OPT_ADAGRAD && J == 1 && use_pf)                                                         \
-      hipLaunchKernelGGL((k_sampled_fwd_bwd_pf<G>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), (size_t)(kBlock / 64) * 4 * 1024, \
-                         st, *p, *opt, *hist, *bt, scale, qthr, loss_kind, S);                                         \
     else if (opt->kind == DRX_OPT_ADAGRAD)                                                                             \
       hipLaunchKernelGGL((k_sampled_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, \
                          *hist, *bt, scale, qthr, loss_kind, S);                                                       \
@@ -2370,8 +1688,7 @@ int drx_cdae_kshard_forward_prepared(const DrxCdaeParams *p, const DrxHistory *h
     Carver cp(const_cast<void *>(prepared), prepared_bytes);
     const PrepBufs R = prep_layout(cp, *p, bt->B, bt->n_touch_slots);
     if (!cp.ok()) return DRX_ESCRATCH;
-    static const bool use_order = [] { const char *e = getenv("DRX_FWD_ORDER"); return !e || atoi(e) != 0; }();      // (A/B switch)
-    if (use_order) order = R.order;
+    order = R.order;
   }
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / (1.0f - bt->q);

@@ -1,0 +1,320 @@
+// The parameter-independent PREPARATION of a sampled-mode batch, shared by the single-GPU sparse step (drx_cdae.hip) and the row-sharded
+// step (drx_shard.hip): the (row key, sample) touch list of a batch, its radix sort, the span plan of the segmented reduction
+// (drx_segreduce.hpp), the sole-toucher marks and the forward kernel's launch order — everything that depends on the batch alone and is
+// built on a side stream while earlier batches train.  Key space: [0, N) W rows, [N, 2N) W2T rows, [2N, 2N + U) V rows.
+// (Kernels are `static`: each translation unit that includes this carries its own copy.)
+#pragma once
+#include <algorithm>
+#include "drx_common.hpp"
+#include "drx_rows.hpp"
+#include "drx_segreduce.hpp"
+#include "drx_scan.hpp"
+
+namespace drx {
+
+// Touch list of one batch (row key, sample): depends only on the batch, never on the parameters, so it can be built
+// and sorted for batch t+1 while batch t trains (drx_cdae_sparse_prepare on a second stream).
+// Also clears the sole-toucher marks of the batch (solo: [2B] bytes, or nullptr) and pads the slots beyond
+// the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
+static __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
+                                                           uint32_t *vals, int T, uint8_t *solo, uint32_t *zero_a,
+                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b, uint32_t *zero_c, int n_zero_c) {
+  constexpr int G = 16;
+  const int lane = threadIdx.x % G;
+  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  // (two more ranges of words the preparation wants zeroed: the span plan's counters + window bytes, the degree-order work area)
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_a; w += gridDim.x * kBlock) zero_a[w] = 0u;
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_b; w += gridDim.x * kBlock) zero_b[w] = 0u;
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < n_zero_c; w += gridDim.x * kBlock) zero_c[w] = 0u;      // (the sort's counters and tile words)
+  if (b >= bt.B) return;
+  if (solo && lane == 0) { solo[b] = 0; solo[bt.B + b] = 0; }
+  if (b == bt.B - 1)
+    for (int j = bt.keep_off[bt.B] + 2 * bt.B + lane; j < T; j += G) { keys[j] = DRX_KEY_NONE; vals[j] = 0; }
+  const int u = bt.uid[b];
+  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+  const int base = bt.keep_off[b] + 2 * b;
+  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
+  for (int64_t j = s + lane; j < e; j += G) {
+    const uint32_t jj = (uint32_t)(j - s);
+    const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
+    keys[base + jj] = kf ? (uint32_t)H.indices[j] : DRX_KEY_NONE;
+    vals[base + jj] = (uint32_t)b;
+  }
+  if (lane == 0) {
+    const int deg = (int)(e - s);
+    keys[base + deg] = (uint32_t)(n_items + bt.iid[b]);       vals[base + deg] = (uint32_t)b;
+    keys[base + deg + 1] = (uint32_t)(2 * n_items) + (uint32_t)u;       vals[base + deg + 1] = (uint32_t)b;
+  }
+}
+
+// Launch order of the forward kernel's triples: longest histories first, triples of similar length side by side (r03 phase stamps:
+// a triple lives 19 us on average but 25 us at the 90th percentile and far longer for the few users with hundreds of items; a
+// workgroup waits for its slowest triple and the launch for its last workgroups — 47 % of the chip's group slots were occupied on
+// average).  A counting sort by history length in 256 buckets of 4 items, two small launches on the preparation's stream (counts;
+// scatter), each workgroup over 1024 triples; `work` = 512 zeroed ints (k_sparse_touches clears them).  A first version did it all
+// in ONE workgroup: 152 us of side-stream time per step, which made the preparation — not the training — the pipeline's bound.
+// The order inside a bucket comes from atomics and differs from run to run: it decides only WHERE a triple is computed, never a result.
+// (degree_bucket / same_bucket_lanes / degree_counts_body: drx_common.hpp — the counts can ride in the sort's first launch)
+static __global__ __launch_bounds__(1024) void k_degree_counts(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work) {
+  __shared__ unsigned int cnt[256];
+  degree_counts_body<1024>(keep_off, B, work, (int)blockIdx.x, cnt);
+}
+
+template <int NT>
+__device__ __forceinline__ void degree_scatter_body(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
+                                                    int32_t *__restrict__ order, int block_id, unsigned int *lds /* [768] */) {
+  unsigned int *start = lds, *cnt = lds + 256, *base = lds + 512;
+  for (int i = threadIdx.x; i < 256; i += NT) cnt[i] = 0;
+  if (threadIdx.x < 64) {                            // exclusive scan of the 256 global counts by one wave: 4 bins per lane
+    unsigned int c[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c[q] = work[threadIdx.x * 4 + q]; sum += c[q]; }
+    unsigned int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
+    unsigned int run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { start[threadIdx.x * 4 + q] = run; run += c[q]; }
+  }
+  __syncthreads();
+  const int b = block_id * NT + (int)threadIdx.x, lane = threadIdx.x & 63;
+  const bool valid = b < B;
+  const int d = valid ? degree_bucket(keep_off, b) : 0;
+  const unsigned long long m = same_bucket_lanes(valid, d);
+  const int leader = valid ? __ffsll((long long)m) - 1 : lane;
+  unsigned int at = 0;
+  if (valid && lane == leader) at = atomicAdd(&cnt[d], (unsigned int)__popcll(m));        // place inside this workgroup's share
+  at = __shfl(at, leader);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += NT) base[i] = cnt[i] ? atomicAdd(&work[256 + i], cnt[i]) : 0u;     // the share's place in the bucket
+  __syncthreads();
+  if (valid) order[start[d] + base[d] + at + __popcll(m & ((1ull << lane) - 1ull))] = b;
+}
+
+static __global__ __launch_bounds__(1024) void k_degree_scatter(const int32_t *__restrict__ keep_off, int B, unsigned int *__restrict__ work,
+                                                         int32_t *__restrict__ order) {
+  __shared__ unsigned int lds[768];
+  degree_scatter_body<1024>(keep_off, B, work, order, (int)blockIdx.x, lds);
+}
+
+// V and W2T rows are mostly touched by ONE sample of the batch (a user is drawn once, output items are uniform).
+// When the touch list is prepared ahead of the step, such rows are marked here: the forward/backward kernel, which holds the
+// sample's gradient rows in registers, then applies their update itself (no g2 row written, no re-read of the gradient
+// and of the parameter row later), and the touch is blanked (DRX_KEY_NONE) so that the segmented reduction passes over
+// it.  A sole toucher cannot race: no other sample of the batch reads or writes that row.  The marks are a byte per sample.
+// (W rows with one touch — 2/3 of a 10M x 1M batch's distinct W rows — stay with the reduction: updating them from the forward kernel
+// was measured twice in r03 and cost it more than the reduction saved; HISTORY.md.)
+static __global__ void k_mark_solo(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, uint32_t n_items, int B, uint8_t *solo_v,
+                            uint8_t *solo_o) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
+    const uint32_t k = keys_s[j];
+    if (k == DRX_KEY_NONE || k < n_items) continue;
+    const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
+    if (k == prev || k == next) continue;            // (a neighbour blanked concurrently was a different key anyway)
+    const uint32_t b = vals_s[j];
+    if (k < 2 * n_items) solo_o[b] = 1;
+    else solo_v[b] = 1;
+    keys_s[j] = DRX_KEY_NONE;
+  }
+}
+
+// The span plan and the sole-toucher marks in ONE launch over the freshly sorted list (two launches cost the preparation — the
+// pipeline's bound once the training kernels got faster — a launch gap and 15 us): the first n_chunks threads plan their chunk, then
+// every thread marks its share of the touches.  The two do not disturb each other: a key that is blanked has one touch, a key whose
+// run the plan measures crosses a chunk border (>= 2 touches), and the plan's searches only test keys for equality with such a key.
+// order_blocks workgroups behind the plan's: the scatter half of the launch order (k_degree_scatter's work, 256 triples each; the
+// counts were taken before the sort) — one launch less for the preparation's stream to wait for.
+static __global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, const uint32_t *__restrict__ vals_s, int T, int n_chunks, int cpb,
+                                                       SpanPlan P, uint32_t n_items, int B, uint8_t *solo_v, uint8_t *solo_o,
+                                                       int order_blocks, const int32_t *keep_off, unsigned int *order_work,
+                                                       int32_t *order) {
+  const int plan_blocks = (int)gridDim.x - order_blocks;
+  if ((int)blockIdx.x >= plan_blocks) {
+    __shared__ unsigned int lds[768];
+    degree_scatter_body<256>(keep_off, B, order_work, order, (int)blockIdx.x - plan_blocks, lds);
+    return;
+  }
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
+  for (int j = tid; j < T; j += plan_blocks * blockDim.x) {
+    const uint32_t k = keys_s[j];
+    if (k == DRX_KEY_NONE || k < n_items) continue;
+    const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
+    if (k == prev || k == next) continue;
+    const uint32_t b = vals_s[j];
+    if (k < 2 * n_items) solo_o[b] = 1;
+    else solo_v[b] = 1;
+    keys_s[j] = DRX_KEY_NONE;
+  }
+}
+
+// hidden bias b: column sums of dz1 in two deterministic stages, then a dense optimizer update.  Both stages are ROLES of
+// the two tail launches of the sparse step (k_sparse_tail_a / _b below): they share a launch with the span fix-ups, which
+// they do not depend on.
+struct BiasArgs {
+  const float *dz1;       // [B, ld]
+  float *part;            // [n_part, ld] column-sum partials, then [n_part] loss partials
+  const float *lossb;     // [B]
+  float *loss_out;        // nullptr: no loss wanted
+  int B, n_part, rows_per_block;
+};
+
+template <int G, int J, int NT>
+__device__ __forceinline__ void bias_partial_body(int ld, const BiasArgs &A, int block_id, float *lds /* [NT/G, ld] */, float *red) {
+  constexpr int R = NT / G;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const int b0 = block_id * A.rows_per_block, b1 = min(A.B, b0 + A.rows_per_block);
+  float4 acc[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+  constexpr int NB = J == 1 ? 8 : 2;            // rows in flight per group (one at a time made these sums chains of dependent loads)
+  for (int b = b0 + r; b < b1; b += NB * R) {
+    float4 v[NB][J];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
+      if (b + q * R < b1) load_row<G, J>(A.dz1, (size_t)(b + q * R), ld, lane, v[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(acc[j], v[q][j]);
+  }
+  store_row<G, J>(lds, (size_t)r, ld, lane, acc);
+  __syncthreads();
+  if (r == 0) {
+    float4 t[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) t[j] = f4_zero();
+#pragma unroll 8
+    for (int rr = 0; rr < R; ++rr) {
+      float4 v[J];
+      load_row<G, J>(lds, (size_t)rr, ld, lane, v);
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
+    }
+    store_row<G, J>(A.part, (size_t)block_id, ld, lane, t);
+  }
+  if (A.loss_out) {                                // this block's slice of the per-sample losses
+    float a = 0.f;
+    for (int b = b0 + (int)threadIdx.x; b < b1; b += NT) a += A.lossb[b];
+    const float tl = block_sum(a, red);
+    if (threadIdx.x == 0) A.part[(size_t)A.n_part * ld + block_id] = tl;
+  }
+}
+
+template <int G, int J>
+struct BiasPartialExtra {
+  int ld;
+  BiasArgs A;
+  __device__ __forceinline__ void operator()(float *lds) const {
+    __shared__ float red[kSegBlock / 64 > 0 ? kSegBlock / 64 : 1];
+    bias_partial_body<G, J, kSegBlock>(ld, A, (int)blockIdx.x, lds, red);
+  }
+};
+
+constexpr int kLongBlocks = 256, kShortBlocks = 1024;      // k_span_planned: workgroups striding over the long / the short spans
+
+struct PrepBufs {
+  uint32_t *keys_s, *vals_s, *keys, *vals;
+  void *sort_temp;
+  size_t sort_bytes;
+  uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo)
+  SpanPlan plan;                // chunk-crossing segments of the list (k_plan_spans)
+  int32_t *order;               // [B] launch order of the forward kernel (k_degree_counts / k_degree_scatter)
+  unsigned int *order_work;     // [512] bucket counts | running places (zeroed by k_sparse_touches)
+  int n_chunks;
+  size_t result_bytes;
+  int T, bits;
+};
+
+static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots) {
+  PrepBufs R{};
+  R.T = n_touch_slots + 2 * B;
+  R.bits = bits_for((uint64_t)2 * P.n_items + P.n_users + 1);
+  // the RESULT first and contiguous (drx_cdae_prep_result_bytes: what a step reads, and all that has to travel when one rank
+  // prepares a list for the others), then what only the preparation itself needs
+  R.keys_s = cv.take<uint32_t>(R.T);
+  R.vals_s = cv.take<uint32_t>(R.T);
+  R.solo_v = cv.take<uint8_t>((size_t)2 * B);
+  R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
+  R.n_chunks = (R.T + kChunk - 1) / kChunk;
+  R.plan.desc = cv.take<uint2>(R.n_chunks);
+  R.plan.cnt = cv.take<uint32_t>(64);
+  R.plan.ext = cv.take<uint8_t>(R.n_chunks);
+  R.order = cv.take<int32_t>(B);
+  R.result_bytes = align_up(cv.off, 256);
+  R.keys = cv.take<uint32_t>(R.T);
+  R.vals = cv.take<uint32_t>(R.T);
+  R.sort_bytes = sort_pairs_temp_bytes(R.T, R.bits);
+  R.sort_temp = cv.take<char>(R.sort_bytes);
+  R.order_work = cv.take<unsigned int>(512);
+  return R;
+}
+
+// plan.cnt (64 words) and plan.ext (n_chunks bytes) are consecutive 256-byte-aligned allocations: one range of words to zero
+static int plan_zero_words(const PrepBufs &R) { return (int)(((const char *)R.plan.ext + R.n_chunks - (const char *)R.plan.cnt + 3) / 4); }
+
+// The chunk-crossing segments of a sorted list, short ones and long ones (drx_segreduce.hpp, planned variant).  On the pristine list:
+// BEFORE the sole-toucher marks blank any key.
+static int plan_spans(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R0, hipStream_t st, bool cleared) {
+  const PrepBufs &R = R0;
+  (void)bt;
+  if (!cleared) DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, (size_t)plan_zero_words(R) * 4, st));     // (prepare_impl's touch kernel clears them)
+  hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.T, R.n_chunks,
+                     kSegBlock / pick_geom(p->ld).G, R.plan);
+  return DRX_OK;
+}
+
+// (see k_degree_counts)
+static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
+  if (!cleared) (void)hipMemsetAsync(R.order_work, 0, 512 * sizeof(unsigned int), st);
+  const int blocks = (bt->B + 1023) / 1024;
+  hipLaunchKernelGGL(k_degree_counts, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work);
+  hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
+}
+
+static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
+                        bool with_marks = false) {
+  const int gpb = kBlock / 16;
+  uint32_t *sort_zero = nullptr;
+  size_t sort_zero_words = 0;
+  sort_pairs_zero_region(R.sort_temp, (size_t)R.T, R.bits, &sort_zero, &sort_zero_words);
+  hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
+                     q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.plan.cnt, plan_zero_words(R), R.order_work, 512,
+                     sort_zero, (int)sort_zero_words);
+  // the launch order (see k_degree_counts): its counts ride in the sort's first launch, its scatter in the plan + marks launch below
+  const bool fused_order = with_marks && p->ld > 16;
+  const SortRider rider{fused_order ? bt->keep_off : nullptr, bt->B, R.order_work};
+  // dropped inputs (DRX_KEY_NONE) take no part in the sort: its last pass writes them back behind the sorted touches
+  const int rc = sort_pairs_ex(R.sort_temp, R.sort_bytes, R.keys, R.keys_s, R.vals, R.vals_s, (size_t)R.T, R.bits, true, st, true, rider);
+  if (rc) return rc;
+  // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
+  // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
+  if (with_marks && p->ld > 16) {
+    const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
+    const int order_blocks = (bt->B + 255) / 256;
+    hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks + order_blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
+                       kSegBlock / pick_geom(p->ld).G, R.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o,
+                       order_blocks, bt->keep_off, R.order_work, R.order);
+    return DRX_OK;
+  }
+  return plan_spans(p, bt, R, st, true);
+}
+
+// Only for touch lists prepared AHEAD of the step (the forward kernel must see the marks): see k_mark_solo.
+static int mark_solo(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared) {
+  if (!cleared) {                                                                  // (prepare_impl's touch kernel clears them)
+    DRX_HIP(hipMemsetAsync(R.solo_v, 0, (size_t)bt->B * 2, st));
+  }
+  // rows of <= 16 floats (K = 128 sharded over 8 GPUs): a 64-byte random read-modify-write in the forward kernel costs more than
+  // the segmented reduction saves (measured 1.018 vs 0.995 ms per step); no marks = no fusion
+  if (p->ld <= 16) return DRX_OK;       // solo_v and solo_o are adjacent
+  hipLaunchKernelGGL(k_mark_solo, dim3(2048), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, (uint32_t)p->n_items, bt->B, R.solo_v,
+                     R.solo_o);
+  return DRX_OK;
+}
+
+
+}  // namespace drx

@@ -77,8 +77,8 @@ static __global__ __launch_bounds__(1024) void k_scan_spine(int *__restrict__ ti
 }
 
 template <bool INCLUSIVE>
-static __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const int *__restrict__ in, int *__restrict__ out, size_t n,
-                                                             const int *__restrict__ tile_off) {
+// (in / out carry no __restrict__: scan_i32 is called in place — every thread reads its int4 before it writes the same addresses)
+static __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const int *in, int *out, size_t n, const int *__restrict__ tile_off) {
   __shared__ int lds[kScanThreads / 64];
   const size_t base = (size_t)blockIdx.x * kScanTile;
   int carry = tile_off[blockIdx.x];
@@ -107,6 +107,7 @@ inline size_t scan_i32_temp_bytes(size_t n) { return align_up(((n + kScanTile - 
 inline int scan_i32(void *temp, size_t temp_bytes, const int *in, int *out, size_t n, bool inclusive, hipStream_t st) {
   if (n == 0) return DRX_OK;
   if (!temp || temp_bytes < scan_i32_temp_bytes(n)) return DRX_ESCRATCH;
+  if (((uintptr_t)in | (uintptr_t)out) & 15) return DRX_EINVAL;          // the kernels move int4
   const int n_tiles = (int)((n + kScanTile - 1) / kScanTile);
   int *ts = (int *)temp;
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(kScanThreads), 0, st, in, n, ts);

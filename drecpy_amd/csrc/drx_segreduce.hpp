@@ -177,42 +177,11 @@ struct SpanPlan {
   uint32_t *cnt;        // [0] short spans, [1] long spans
   uint8_t *ext;         // [n_chunks] (zeroed before k_plan_spans): chunk g also takes the first ext[g] touches of chunk g + 1 — the end of
                         //   a segment that starts in g and ends inside g + 1 (the commonest crossing by far: no partial rows, no span)
-  uint8_t *hflag;       // [n_chunks] (zeroed likewise): bit 0 = the run at the chunk's start belongs to a HOT segment, bit 1 = the run at
-                        //   its end does: k_seg_reduce_planned passes over those touches, k_hot_tiles takes them (cnt[3] = hot segments)
-  uint4 *hot;           // [kMaxHot]: x = first touch, y = one past the last, z = key of a hot segment
-  uint32_t *hot_bounds; // [kMaxHot, kHotTiles + 1]: where each sample tile's share of the segment starts (k_hot_bounds)
-  uint32_t *hot_pref;   // [kMaxHot + 1]: exclusive prefix of the segments' SLICE counts (a tile's share is cut into ns equal slices)
-  int hot_min;          // a segment of at least this many touches is hot (a function of the list's length alone: see plan_hot_min)
 };
-
-// HOT SEGMENTS (r03).  Under Zipf popularity a few dozen rows collect almost half of a batch's touches; the reduction read their
-// contribution rows (dz1[b]) one 512-byte row per touch from wherever the fabric had them — the 33 MB of a batch's dz1 do not fit the
-// 4 MiB L2 of an XCD, the hit rate was 41 % and these re-reads made up half of the kernel's fabric traffic.  Their touches are sorted by
-// sample, so a hot segment cuts into TILES of consecutive samples; (segment, tile) items of the same tile are placed on the SAME XCD
-// and run side by side: the tile's dz1 rows (2 MiB) are fetched into that L2 once and hit by every hot row that touches them.
-// One partial row per (segment, tile), combined in tile order by the span launch: the sum order is fixed by the list.
-constexpr int kMaxHot = 1024;      // hot segments per list (the plan's threshold guarantees it: hot_min >= T / kMaxHot)
-constexpr int kHotTiles = 16;      // sample tiles per batch
-constexpr int kHotSlice = 256;     // touches per (segment, tile, slice) work item, about
-
-// Threshold of the plan: DrxBatch.flags >> 16 touches (never below 32, nor below T / kMaxHot — at most kMaxHot segments can reach
-// it); 0 = NO hot segments (the default).  Measured on the 10M x 1M set (r03q, threshold 1 406 = T / 1024: 41 % of the touches): the
-// reduction's PMC traffic 935 -> 860 MB per launch, L2 hit rate 41 -> 47 %, its time unchanged (168 us) — and the plan's searches
-// and k_hot_bounds add 50 us to the preparation, which bounds the pipeline: a loss for the step, kept as an option with its test.
-inline int plan_hot_min(int T, uint32_t batch_flags) {
-  int m = (int)(batch_flags >> 16);
-  if (m <= 0) return 0x7FFFFFFF;
-  if (m < 32) m = 32;
-  const int by_capacity = (T + kMaxHot - 1) / kMaxHot;
-  return m > by_capacity ? m : by_capacity;
-}
 
 struct PlanBufs {
   float *pblock;        // [n_blocks, ld] block partials (all-inner workgroups)
   float *pbs;           // [n_blocks]
-  float *hot_part;      // [kHotTiles * slices of all hot segments, ld] one partial row per (hot segment, sample tile, slice)
-  float *hot_ps;        // the same, scalar side values
-  int tile_samples;     // samples per tile = ceil(B / kHotTiles)
 };
 
 // partials of a span after its first chunk: lead chunks up to the next workgroup boundary, whole all-inner workgroups, trailing chunks
@@ -229,76 +198,19 @@ struct SpanShape {
   __host__ __device__ int total() const { return n_lead + n_blk + n_trail; }
 };
 
-// [lo, hi) of the run of `key` that contains position `at` (the touches of a key are ONE run of the list, so "== key" is a
-// suffix-true predicate left of `at` and a prefix-true one right of it; keys a concurrent sole-toucher pass blanks have one touch
-// and are never asked for here)
-__device__ __forceinline__ void run_bounds(const uint32_t *__restrict__ keys_s, int T, uint32_t key, int at, int &run_lo, int &run_hi) {
-  int lo = 0, hi = at;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (keys_s[mid] == key) hi = mid; else lo = mid + 1;
-  }
-  run_lo = lo;
-  lo = at + 1; hi = T;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (keys_s[mid] == key) lo = mid + 1; else hi = mid;
-  }
-  run_hi = lo;
-}
-
-// can the run of `key` around the chunk [start, end) have hot_min touches?  Then it reaches (hot_min - kChunk) / 2 beyond the chunk on
-// at least one side: two probes spare the cold chunks (nearly all of them) the two searches.
-__device__ __forceinline__ bool maybe_hot(const uint32_t *__restrict__ keys_s, int T, uint32_t key, int start, int end, int hot_min) {
-  if (hot_min == 0x7FFFFFFF) return false;                   // no hot segments asked for
-  const int reach = (hot_min - kChunk) / 2;
-  if (reach <= 0) return true;
-  return (start - reach >= 0 && keys_s[start - reach] == key) || (end - 1 + reach < T && keys_s[end - 1 + reach] == key);
-}
-
 __device__ __forceinline__ void plan_chunk(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, const SpanPlan &P, int g) {
   const int start = g * kChunk, end = min(T, start + kChunk);
   const uint32_t first = keys_s[start], last = keys_s[end - 1];
   const uint32_t prev = start > 0 ? keys_s[start - 1] : DRX_KEY_NONE, next = end < T ? keys_s[end] : DRX_KEY_NONE;
   const bool head_cont = first != DRX_KEY_NONE && prev == first;        // the run at the chunk's start began before it
   const bool tail_cont = last != DRX_KEY_NONE && next == last;          // the run at its end goes on behind it
-  if (!head_cont && !tail_cont) return;
-  uint8_t hf = 0;
-  int h_lo = 0, h_hi = 0;
-  bool head_hot = false;
-  if (head_cont && maybe_hot(keys_s, T, first, start, end, P.hot_min)) {
-    run_bounds(keys_s, T, first, start, h_lo, h_hi);
-    head_hot = h_hi - h_lo >= P.hot_min;
+  if (!tail_cont || (head_cont && first == last)) return;              // nothing STARTS to cross here
+  int lo = end, hi = T;              // first position in [end, T) with another key
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys_s[mid] == last) lo = mid + 1; else hi = mid;
   }
-  if (head_hot) hf |= 1;
-  const bool one_run = head_cont && first == last;                      // the whole chunk lies inside one segment
-  int t_lo = 0, t_hi = 0;
-  bool tail_hot = false, tail_known = false;
-  if (tail_cont) {
-    if (one_run) { tail_hot = head_hot; }
-    else if (maybe_hot(keys_s, T, last, start, end, P.hot_min)) {
-      run_bounds(keys_s, T, last, end - 1, t_lo, t_hi);
-      tail_hot = t_hi - t_lo >= P.hot_min;
-      tail_known = true;
-    }
-  }
-  if (tail_hot) hf |= 2;
-  if (hf) P.hflag[g] = hf;
-  if (!tail_cont || one_run) return;                                    // nothing STARTS to cross here
-  if (tail_hot) {                                                       // the segment starts in this chunk: its one descriptor
-    const uint32_t at = atomicAdd(&P.cnt[3], 1u);
-    if (at < (uint32_t)kMaxHot) P.hot[at] = make_uint4((uint32_t)t_lo, (uint32_t)t_hi, last, 0u);
-    return;
-  }
-  int seg_end = t_hi;
-  if (!tail_known) {                // first position in [end, T) with another key
-    int lo = end, hi = T;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (keys_s[mid] == last) lo = mid + 1; else hi = mid;
-    }
-    seg_end = lo;
-  }
+  const int seg_end = lo;
   const int full_end = seg_end / kChunk;                         // chunks [g + 1, full_end) lie wholly inside the segment
   const uint32_t m_in = (uint32_t)(full_end - (g + 1)), has_end = (seg_end % kChunk) ? 1u : 0u;
   if (m_in == 0) {                                               // ends inside the next chunk: this chunk's window takes those touches
@@ -318,126 +230,6 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_c
   if (g < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, g);
 }
 
-// slices per tile share of a hot segment: its length alone decides (about kHotSlice touches each)
-__host__ __device__ inline int hot_slices(uint32_t len) { const int n = (int)((len + kHotTiles * kHotSlice - 1) / (kHotTiles * kHotSlice)); return n < 1 ? 1 : n; }
-
-// After the plan: where every sample tile's share of every hot segment starts (the touches of a segment are sorted by sample: lower
-// bounds by binary search, one thread each), and — workgroup 0 — the exclusive prefix of the segments' slice counts.  On the
-// preparation's stream; the roles that use them (hot_tiles_body, the span launch) only read.
-static __global__ __launch_bounds__(256) void k_hot_bounds(const uint32_t *__restrict__ vals_s, SpanPlan SP, int tile_samples) {
-  const int n_hot = (int)min(SP.cnt[3], (uint32_t)kMaxHot);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_hot * (kHotTiles + 1)) {
-    const int h = i / (kHotTiles + 1), j = i % (kHotTiles + 1);
-    const uint4 d = SP.hot[h];
-    const uint32_t b = (uint32_t)j * (uint32_t)tile_samples;
-    int lo = (int)d.x, hi = (int)d.y;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (vals_s[mid] < b) lo = mid + 1; else hi = mid; }
-    SP.hot_bounds[i] = j == kHotTiles ? d.y : (uint32_t)lo;
-  }
-  if (blockIdx.x == 0) {                              // prefix of the slice counts: 256 threads, 4 segments each, one wave-scan + LDS
-    __shared__ uint32_t wsum[4];
-    uint32_t c[4], sum = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int h = threadIdx.x * 4 + q;
-      c[q] = h < n_hot ? (uint32_t)hot_slices(SP.hot[h].y - SP.hot[h].x) : 0u;
-      sum += c[q];
-    }
-    uint32_t inc = sum;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t run = inc - sum;
-    for (int ww = 0; ww < w; ++ww) run += wsum[ww];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int h = threadIdx.x * 4 + q;
-      if (h <= n_hot) SP.hot_pref[h] = run;
-      run += c[q];
-    }
-    if (threadIdx.x == 255 && n_hot == kMaxHot) SP.hot_pref[kMaxHot] = run;
-  }
-}
-
-// The hot segments' touches, (segment, sample tile, slice) by item — workgroups [0, n_blocks) of this role inside the reduction's
-// launch.  A workgroup's XCD is its index in the WHOLE launch modulo 8 (the hardware deals workgroups round robin), so XCD x takes the
-// tiles x and x + 8; its workgroups walk the items tile-major: the ones resident at a time read the same 2 MiB of dz1.  A tile's share
-// of a segment (k_hot_bounds) is cut into ns equal slices of about kHotSlice touches (ns from the segment's length: the top row of a
-// Zipf batch has 2 800 touches per tile, the hundredth 90); a workgroup's groups take contiguous parts of a slice (8 rows in flight
-// each), the parts are combined in LDS in order: one partial row per item, at 16 * pref[h] + tile * ns + slice.
-template <int G, int J, class Policy>
-__device__ __forceinline__ void hot_tiles_body(const SegBufs &S, const PlanBufs &PB, const SpanPlan &SP, const Policy &pol, int role_block,
-                                               int n_blocks, float *lds) {
-  constexpr int R = kSegBlock / G;
-  constexpr int UL = J == 1 ? 8 : 2;
-  const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  const int n_hot = (int)min(SP.cnt[3], (uint32_t)kMaxHot);
-  if (n_hot == 0) return;
-  const int xcd = (int)(blockIdx.x & 7), per_x = n_blocks / 8;          // (n_blocks is a multiple of 8)
-  const int me = role_block / 8;
-  float *sc = lds + (size_t)R * S.ld;
-  constexpr int TPX = kHotTiles / 8;                                     // tiles per XCD
-  const int n_items = (int)SP.hot_pref[n_hot];                           // slices of all segments, per tile
-  for (int f = me; f < TPX * n_items; f += per_x) {
-    const int tile = xcd + 8 * (f / n_items), it = f % n_items;
-    int lo = 0, hi = n_hot;                                              // h: the last segment whose prefix is <= it
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)SP.hot_pref[mid] <= it) lo = mid; else hi = mid; }
-    const int h = lo, sub = it - (int)SP.hot_pref[h];
-    const uint4 d = SP.hot[h];
-    const int ns = hot_slices(d.y - d.x);
-    const int b0 = (int)SP.hot_bounds[h * (kHotTiles + 1) + tile], b1 = (int)SP.hot_bounds[h * (kHotTiles + 1) + tile + 1];
-    const int sper = (b1 - b0 + ns - 1) / ns;
-    const int t0 = b0 + sub * sper, t1 = min(b1, t0 + sper);
-    const int per = (max(0, t1 - t0) + R - 1) / R;
-    const int i_lo = t0 + r * per, i_hi = min(t1, i_lo + per);
-    float4 acc[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-    float accs = 0.f;
-    for (int i0 = i_lo; i0 < i_hi; i0 += UL) {
-      float4 rows[UL][J];
-      float sv[UL], cf[UL];
-#pragma unroll
-      for (int u = 0; u < UL; ++u) {
-        sv[u] = 0.f; cf[u] = 0.f;
-#pragma unroll
-        for (int j = 0; j < J; ++j) rows[u][j] = f4_zero();
-        if (i0 + u < i_hi) { cf[u] = 1.f; pol.template load<G, J>(d.z, S.vals_s[i0 + u], lane, rows[u], sv[u], cf[u]); }
-      }
-#pragma unroll
-      for (int u = 0; u < UL; ++u) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) f4_fma(acc[j], cf[u], rows[u][j]);
-        accs += sv[u];
-      }
-    }
-    __syncthreads();                                         // (the previous item's readers are done with the LDS rows)
-    store_row<G, J>(lds, (size_t)r, S.ld, lane, acc);
-    if (lane == 0) sc[r] = accs;
-    __syncthreads();
-    if (r == 0) {
-      float4 t[J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) t[j] = f4_zero();
-      float ts = 0.f;
-#pragma unroll 8
-      for (int rr = 0; rr < R; ++rr) {
-        float4 v[J];
-        load_row<G, J>(lds, (size_t)rr, S.ld, lane, v);
-#pragma unroll
-        for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
-        ts += sc[rr];
-      }
-      const size_t at = (size_t)kHotTiles * SP.hot_pref[h] + (size_t)tile * ns + sub;
-      store_row<G, J>(PB.hot_part, at, S.ld, lane, t);
-      if (lane == 0) PB.hot_ps[at] = ts;
-    }
-  }
-}
-
 // LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
 // CDAE step's bias column sums: independent work that fills the launch's ramp).
 #ifdef DRX_SEGP_W8
@@ -447,19 +239,18 @@ __device__ __forceinline__ void hot_tiles_body(const SegBufs &S, const PlanBufs 
 #endif
 template <int G, int J, class Policy, int LB1, class Extra>
 __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol,
-                                                                            int extra_blocks, int hot_blocks, Extra extra) {
+                                                                            int extra_blocks, Extra extra) {
   extern __shared__ __align__(16) float seg_lds[];
   constexpr int CPB = kSegBlock / G;
   if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
-  if ((int)blockIdx.x < extra_blocks + hot_blocks) { hot_tiles_body<G, J, Policy>(S, PB, SP, pol, (int)blockIdx.x - extra_blocks, hot_blocks, seg_lds); return; }
   const uint8_t *__restrict__ ext = SP.ext;
-  const int blk = (int)blockIdx.x - extra_blocks - hot_blocks;
+  const int blk = (int)blockIdx.x - extra_blocks;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int g = blk * CPB + r;
   bool inner = false;          // this chunk is one whole run of a segment that began before it
   if (g < S.n_chunks && (g + 1) * kChunk <= S.T) {
     const uint32_t f = S.keys_s[g * kChunk], l = S.keys_s[(g + 1) * kChunk - 1], pk = g > 0 ? S.keys_s[g * kChunk - 1] : DRX_KEY_NONE;
-    inner = f != DRX_KEY_NONE && f == pk && l == f && !(SP.hflag[g] & 1);      // (the inside of a HOT segment is not this kernel's work)
+    inner = f != DRX_KEY_NONE && f == pk && l == f;
   }
   const bool all_inner = __syncthreads_and(inner ? 1 : 0) != 0;
   if (g >= S.n_chunks) return;          // (never in an all-inner workgroup: its second barrier below sees every thread)
@@ -479,17 +270,6 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
     const bool ok = t < n;
     kreg[q] = ok ? S.keys_s[start + t] : DRX_KEY_NONE;
     vreg[q] = ok ? S.vals_s[start + t] : 0u;
-  }
-  {
-    // touches of hot segments (the run at the chunk's start and / or at its end) are passed over: hot_tiles_body sums them.  Their
-    // keys are blanked in the registers here, once, so that nothing about them stays live in the loop below.
-    const uint8_t hf = SP.hflag[g];
-    if (hf) {
-      const uint32_t hot_a = (hf & 1) ? S.keys_s[g * kChunk] : DRX_KEY_NONE, hot_b = (hf & 2) ? S.keys_s[min(S.T, (g + 1) * kChunk) - 1] : DRX_KEY_NONE;
-#pragma unroll
-      for (int q = 0; q < KPL; ++q)
-        if (kreg[q] == hot_a || kreg[q] == hot_b) kreg[q] = DRX_KEY_NONE;
-    }
   }
   auto bcast = [&](const uint32_t (&reg)[KPL], int t) -> uint32_t {
     uint32_t sel = reg[0];
@@ -614,66 +394,12 @@ __device__ __forceinline__ void span_partial(const SegBufs &S, const PlanBufs &P
 // group per span), the rest run `extra` (the CDAE step: one workgroup finishing the hidden bias).  LDS: [R, ld] + [R] floats.
 template <int G, int J, class Policy, class Extra>
 __global__ __launch_bounds__(kFixBlock) void k_span_planned(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol, int n_long_blocks,
-                                                            int n_short_blocks, int n_hot_blocks, Extra extra) {
+                                                            int n_short_blocks, Extra extra) {
   extern __shared__ __align__(16) float span_lds[];
   constexpr int R = kFixBlock / G, CPB = kSegBlock / G;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   constexpr int UL = J == 1 ? 8 : 2;                       // partial rows in flight per group
-  if ((int)blockIdx.x >= n_long_blocks + n_short_blocks + n_hot_blocks) { extra(span_lds); return; }
-  if ((int)blockIdx.x >= n_long_blocks + n_short_blocks) {
-    // hot segments: one workgroup each — its groups take contiguous parts of the segment's kHotTiles * ns partial rows (tile-major,
-    // slices in order), the part sums are combined in LDS in order and the row is finished
-    const int n_hot = (int)min(SP.cnt[3], (uint32_t)kMaxHot);
-    float *sc = span_lds + (size_t)R * S.ld;
-    for (int h = (int)blockIdx.x - n_long_blocks - n_short_blocks; h < n_hot; h += n_hot_blocks) {
-      const uint4 d = SP.hot[h];
-      const size_t base = (size_t)kHotTiles * SP.hot_pref[h];
-      const int tot = kHotTiles * (int)(SP.hot_pref[h + 1] - SP.hot_pref[h]);
-      const int per = (tot + R - 1) / R;
-      const int i_lo = r * per, i_hi = min(tot, i_lo + per);
-      float4 acc[J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-      float accs = 0.f;
-      for (int i0 = i_lo; i0 < i_hi; i0 += UL) {
-        float4 v[UL][J];
-        float sv[UL];
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-          sv[u] = 0.f;
-#pragma unroll
-          for (int j = 0; j < J; ++j) v[u][j] = f4_zero();
-          if (i0 + u < i_hi) { load_row<G, J>(PB.hot_part, base + i0 + u, S.ld, lane, v[u]); sv[u] = PB.hot_ps[base + i0 + u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-#pragma unroll
-          for (int j = 0; j < J; ++j) f4_add(acc[j], v[u][j]);
-          accs += sv[u];
-        }
-      }
-      __syncthreads();
-      store_row<G, J>(span_lds, (size_t)r, S.ld, lane, acc);
-      if (lane == 0) sc[r] = accs;
-      __syncthreads();
-      if (r == 0) {
-        float4 t[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) t[j] = f4_zero();
-        float ts = 0.f;
-#pragma unroll 8
-        for (int rr = 0; rr < R; ++rr) {
-          float4 v[J];
-          load_row<G, J>(span_lds, (size_t)rr, S.ld, lane, v);
-#pragma unroll
-          for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
-          ts += sc[rr];
-        }
-        pol.template finish<G, J>(d.z, (int)d.x, lane, t, ts);
-      }
-    }
-    return;
-  }
+  if ((int)blockIdx.x >= n_long_blocks + n_short_blocks) { extra(span_lds); return; }
   if ((int)blockIdx.x >= n_long_blocks) {
     const uint32_t n_short = SP.cnt[0];
     for (uint32_t si = ((int)blockIdx.x - n_long_blocks) * R + r; si < n_short; si += (uint32_t)n_short_blocks * R) {

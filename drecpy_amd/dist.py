@@ -546,7 +546,6 @@ class ColumnShardedCdae:
             return
         from .engine import CdaeEngine
         self.engine = e = CdaeEngine(n_users, n_items, self.k_hi - self.k_lo, device=device)
-        e.mark_w_rows = False          # W marks are served by the single-GPU forward kernel; here the forward half is a kernel of its own
         e.set_history(hist_indptr, hist_indices)
         e.init_optimizer(optimizer, lr, reg)
         # GlorotUniform of the GLOBAL shapes; this rank's columns from its own stream, the replicated b2 from a shared one

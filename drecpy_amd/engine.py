@@ -46,14 +46,6 @@ class CdaeEngine:
         self._scratch = None
         self._dense_scratch, self._dense_scratch_B, self._dense_clean = None, None, False
         self._loss = torch.zeros(2, **z)
-        # sampled mode: ask drx_cdae_sparse_prepare to mark the W rows a single triple of the batch touches, for the forward kernel to
-        # update (include/drx.h DRX_BATCH_MARK_W).  False by default — measured on the 10M x 1M set (r03d): the reduction runs 64 us
-        # shorter without those 126 k one-touch segments, but the same read-modify-writes cost the latency-bound forward kernel 140 us.
-        # 'auto' (tests, experiments): where a batch leaves most of its distinct W rows with one touch — at most 4 history slots per
-        # item of the catalogue — with Adagrad, on rows of 17..256 floats; True: always.  DRX_SOLO_W=0/1 in the environment overrides.
-        self.mark_w_rows = False
-        self.hot_min = 0               # touches from which a segment is summed tile by tile (0 = the library's default; tests lower it)
-        self.v_slots = False           # DRX_BATCH_V_SLOTS: V keys as slots of a per-batch user table (narrower sort key; off: r03l measurement)
 
     # ---- parameters -------------------------------------------------------------------------
     def tables(self):
@@ -308,14 +300,7 @@ class CdaeEngine:
         st['busy'][slot[0]] = True
 
     def _batch_flags(self, n_touch_slots):
-        import os
-        vs = (_lib.BATCH_V_SLOTS if self.v_slots else 0) | ((int(self.hot_min) & 0xFFFF) << 16)
-        forced = os.environ.get('DRX_SOLO_W')
-        if forced is not None:
-            return (_lib.BATCH_MARK_W if forced == '1' else 0) | vs
-        on = (self.mark_w_rows == 'auto' and getattr(self, 'opt_kind', None) == _lib.OPT_ADAGRAD and 16 < self.ld <= 256
-              and n_touch_slots is not None and 0 < int(n_touch_slots) <= 4 * self.n_items)
-        return (_lib.BATCH_MARK_W if (on or self.mark_w_rows is True) else 0) | vs
+        return 0                       # DrxBatch.flags: reserved
 
     def make_batch(self, uid, iid=None, y=None, keep_off=None, keep=None, q=0.0, mask_seed=0, n_touch_slots=None):
         """Uploads (if needed) one batch and returns (Batch struct, keep-alive tensors)."""

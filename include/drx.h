@@ -83,19 +83,8 @@ typedef struct DrxBatch {
   uint64_t mask_seed;
   float q;                  /* corruption level; survivors are scaled by 1/(1-q) */
   int32_t n_touch_slots;    /* host-known upper bound of keep_off[B] (sizes the sort) */
-  uint32_t flags;           /* DRX_BATCH_* (0: none) */
+  uint32_t flags;           /* reserved: 0 */
 } DrxBatch;
-
-/* drx_cdae_sparse_prepare also marks the W rows that ONE triple of the batch touches (a bit per item) and the step's forward kernel
- * updates them itself — worth it where a batch leaves most of its distinct W rows with a single touch (large catalogues, long-tailed
- * popularity); prepare and step must see the same flag.  Without it only V / W2T rows are marked. */
-#define DRX_BATCH_MARK_W 1u
-/* The V keys of the touch list are slots of a per-batch table of the batch's users (4B entries, part of the prepared list) instead of
- * user ids: a narrower sort key when n_users is far beyond the batch size.  Only where n_users > 4B; prepare and step must agree. */
-#define DRX_BATCH_V_SLOTS 2u
-/* bits 16..31: touches from which a segment of the list counts as HOT (0 = none, the default; otherwise at least 32 and at least list
- * length / 1024): hot segments are summed sample tile by sample tile on the XCD that holds the tile's gradient rows
- * (csrc/drx_segreduce.hpp, hot_tiles_body).  Off by default: measured slower end to end. */
 
 typedef struct DrxOptim {
   int32_t kind;             /* DRX_OPT_* */

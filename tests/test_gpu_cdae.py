@@ -123,15 +123,13 @@ def test_dense_steps_match_oracle(K, B, loss, targets):
                                                    (8, 100, 'adam', 'mse', True), (128, 4096, 'adagrad', 'bce', False),
                                                    (300, 50, 'adam', 'bce', False), (128, 300, 'rowwise_adagrad', 'bce', False),
                                                    (50, 64, 'rowwise_adagrad', 'mse', True)])
-@pytest.mark.parametrize('prepared', [False, True, 'mark_w'])
+@pytest.mark.parametrize('prepared', [False, True])
 def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
     """prepared=True: the touch list is built ahead by drx_cdae_sparse_prepare, which also marks the V / W2T rows a single
     sample touches; those are then updated by the forward kernel (batches of 50-100 over 120 users and 260 items mix sole
-    and shared rows).  'mark_w': W rows with one touch are marked too (DRX_BATCH_MARK_W) and updated by the forward kernel —
-    from its LDS notes (Adagrad, one float4 per lane) or by a second walk over the history (the other kernels)."""
+    and shared rows)."""
     U, N = 120, 260
     eng, p, rng = _engine(U, N, K, seed=2)
-    eng.mark_w_rows = prepared == 'mark_w'
     indptr, indices = synth_history(rng, U, N, 14, zipf=1.1)
     eng.set_history(indptr, indices)
     lr = 1e-3 if opt == 'adam' else 0.05
@@ -171,12 +169,10 @@ def test_sparse_steps_match_oracle(K, B, opt, loss, explicit, prepared):
 @pytest.mark.parametrize('prepared', [False, True])
 @pytest.mark.parametrize('K', [50, 128])
 def test_sparse_steps_with_many_more_users_than_triples(K, prepared):
-    """3000 users, 64 triples: the V keys of the touch list are slots of the batch's user table (4B = 256 entries; k_user_slots) instead
-    of user ids — a narrower key, one radix pass fewer at 10 M users — and the reduction maps a slot back to its user.  Users repeat
-    inside a batch (shared V rows go through the list) and across batches."""
+    """3000 users, 64 triples: a key space far wider than the batch.  Users repeat inside a batch (shared V rows go through the
+    list) and across batches."""
     U, N, B = 3000, 260, 64
     eng, p, rng = _engine(U, N, K, seed=4)
-    eng.v_slots = True
     indptr, indices = synth_history(rng, U, N, 9, zipf=1.1)
     eng.set_history(indptr, indices)
     eng.init_optimizer('adagrad', 0.05, 1e-3)
@@ -205,13 +201,11 @@ def test_sparse_steps_with_many_more_users_than_triples(K, prepared):
 
 @pytest.mark.parametrize('prepared', [False, True])
 @pytest.mark.parametrize('K,opt', [(128, 'adagrad'), (50, 'adam'), (16, 'adagrad')])
-def test_sparse_steps_with_hot_segments_summed_tile_by_tile(K, opt, prepared):
-    """60 items under a steep Zipf law, 768 triples: most rows collect hundreds of touches.  With the hot threshold lowered to 32 touches
-    (upper half of DrxBatch.flags) their segments take the hot path — (segment, sample tile) partial sums by the hot-tiles role of the
-    reduction's launch, combined in tile order by the span launch — while the short ones stay with the chunk windows: same oracle."""
+def test_sparse_steps_with_hot_segments(K, opt, prepared):
+    """60 items under a steep Zipf law, 768 triples: most rows collect hundreds of touches — segments that cross many chunk
+    borders (block partials of all-inner workgroups, short and long spans of the span launch) beside short ones: same oracle."""
     U, N, B = 400, 60, 768
     eng, p, rng = _engine(U, N, K, seed=11)
-    eng.hot_min = 32
     indptr, indices = synth_history(rng, U, N, 12, zipf=1.4)
     eng.set_history(indptr, indices)
     lr = 1e-3 if opt == 'adam' else 0.05
