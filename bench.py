@@ -73,6 +73,8 @@ def parse(argv=None):
     ap.add_argument('--prepare', default='auto', choices=['auto', 'local', 'turns', 'parts'],
                     help='column layout, who sorts the touch list of a step: every rank all of it (local), rank s %% N for all (turns), every rank '
                          '1/N of it (parts); auto = turns from 4 GPUs on (at 2 it saves nothing), else local')
+    ap.add_argument('--no-self-bypass', action='store_true', help='row layout: send the rank\'s OWN rows through the collectives too (at world 1: the '
+                    'whole exchange goes through the communicator — every row "remote", the link replaced by a device copy)')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     ap.add_argument('--launch-dry-run', action='store_true', help='print the per-rank child command lines of an N-GPU run and exit (no GPU call)')
     ap.add_argument('--launch-selftest', action='store_true', help='children only rendezvous over gloo and all-reduce on the CPU (tests the launcher)')
@@ -625,7 +627,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     else:
         from drecpy_amd.dist import ShardedCdae
         stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
-                              cpu_staging=debug_gloo, force_collectives=rccl1)
+                              cpu_staging=debug_gloo, force_collectives=rccl1, self_bypass=not args.no_self_bypass)
         eng = stepper.engine
 
     micro = max(1, args.micro)       # > 1: micro-batches whose exchanges overlap each other's compute (measured at world 1: the split costs more than it hides)
@@ -759,7 +761,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                  'k_span_planned(short | long spans | bias update)', '(unused)']
         dom, dom_ms, dom_alg = ('k_seg_reduce_planned', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
-        names = ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce(+overlapped exchanges)', 'rest_of_grad_exchange', 'owner_apply', 'bias_allreduce']
+        names = ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce(+overlapped exchanges)', 'rest_of_grad_exchange', 'owner_apply+bias_update', '(unused)']
         # forward reads one row per occurrence, the local reduce one gradient row per occurrence
         dom, dom_ms, dom_alg = 'k_shard_fwd_bwd+k_seg_reduce<LocalPolicy>', ph[1], 2.0 * B * 4.0 * K * rows_per_sample
     achieved = dom_alg / (dom_ms * 1e-3) / 1e9
@@ -817,8 +819,12 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                    'batches': 'fresh device-sampled batch every step (sampler running ahead on the side stream)' if (fresh or (pipe is not None and fresh_sharded))
                    else f'{args.n_batches} pre-sampled batches cycled',
                    'micro_batches': (micro if stepper is not None else None),
-                   'sharding': ('single GPU' if stepper is None else 'row-sharded code path at world 1') if world == 1
-                   else f'rows: users (V rows, histories, samples) sharded x{world} by range, item rows sharded by range; all-to-all(v) of rows and gradient rows, all-reduce of the bias gradient'},
+                   'sharding': ('single GPU' if stepper is None else
+                                'row-sharded code path at world 1, ' + ('every row sent through the communicator (--no-self-bypass: all rows "remote", the link '
+                                                                        'replaced by a device copy)' if args.no_self_bypass else
+                                                                        'own rows bypass the collectives (at world 1: all of them; the exchanges are empty)')) if world == 1
+                   else f'rows: users (V rows, histories, samples) sharded x{world} by range, item rows sharded by range; all-to-all(v) of rows and gradient '
+                        f'rows (one float buffer per direction; a rank\'s own rows bypass them), bias gradient in the sentinel rows of the gradient exchange'},
         'roofline': None,
         'phases_ms': {n: float(v) for n, v in zip(names, ph)},
         'setup_s': round(setup_s, 1),

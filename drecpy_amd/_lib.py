@@ -14,6 +14,7 @@ TARGETS_REFERENCE, TARGETS_PER_ROW = 0, 1
 OPT_ADAM, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
 DENSE_AUX_CLEAN = 0x100          # include/drx.h: DRX_DENSE_AUX_CLEAN
 KEY_NONE = 0xFFFFFFFF
+SHARD_SELF_BYPASS = 1            # include/drx.h: DRX_SHARD_SELF_BYPASS
 
 
 class DrxError(RuntimeError):
@@ -43,7 +44,7 @@ class ListGroups(C.Structure):
 
 class Shard(C.Structure):
     _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('n_items', C.c_int32), ('items_per_rank', C.c_int32),
-                ('n_users_local', C.c_int32)]
+                ('n_users_local', C.c_int32), ('flags', C.c_uint32)]
 
 
 class AdamSegments(C.Structure):
@@ -127,26 +128,23 @@ SIGNATURES = {
     'drx_point_sample_recorded': (C.c_int, [C.POINTER(History), C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                    C.c_void_p]),
-    'drx_shard_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32]),
-    'drx_shard_touches': (C.c_int, [C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p]),
-    'drx_shard_index': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                  C.c_void_p]),
-    'drx_shard_gather_rows': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_int32, C.c_void_p,
-                                        C.c_void_p, C.c_void_p]),
-    'drx_shard_fwd_bwd': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p]),
-    'drx_shard_reduce': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_float,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    'drx_shard_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_size_t,
-                                  C.c_void_p]),
-    'drx_shard_bias_grad': (C.c_int, [C.POINTER(CdaeParams), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                      C.c_size_t, C.c_void_p]),
-    'drx_shard_bias_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.c_int32, C.c_void_p, C.c_void_p]),
+    'drx_shard_prep_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32, C.c_int32]),
+    'drx_shard_work_bytes': (C.c_size_t, [C.POINTER(Shard)]),
+    'drx_shard_prep_layout': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    'drx_shard_prepare': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch), C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_shard_owner_table_bytes': (C.c_size_t, [C.POINTER(Shard), C.c_int32]),
+    'drx_shard_owner_index': (C.c_int, [C.POINTER(Shard), C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
+                                        C.c_size_t, C.c_void_p]),
+    'drx_shard_gather_rows': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                        C.c_int32, C.c_void_p, C.c_void_p]),
+    'drx_shard_step_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32]),
+    'drx_shard_step_local': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch),
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_void_p), C.c_void_p]),
+    'drx_shard_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                  C.c_void_p, C.c_void_p]),
     'drx_adam_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_void_p]),
     'drx_scatter_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -295,9 +293,15 @@ def check(rc, what):
 
 
 def stream_ptr(device=None):
-    """Raw hipStream_t of torch's current stream (0 = default stream)."""
+    """Raw hipStream_t of torch's current stream (0 = default stream).  torch.cuda.current_stream() builds a Stream object
+    and resolves the device through several Python layers (6 us a call, ~18 calls per row-sharded step): the raw getter is the
+    same lookup without them."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    try:
+        idx = device.index if (device is not None and getattr(device, 'index', None) is not None) else torch._C._cuda_getDevice()
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+    except AttributeError:
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def ptr(t):

@@ -16,9 +16,23 @@ namespace drx {
 // and sorted for batch t+1 while batch t trains (drx_cdae_sparse_prepare on a second stream).
 // Also clears the sole-toucher marks of the batch (solo: [2B] bytes, or nullptr) and pads the slots beyond
 // the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
+// `present` (row-sharded step, or nullptr): one byte per WIRE key of an item row — owner-major, owner o = item / ipr at
+// (o << shift) + (W2T row ? ipr : 0) + item - o * ipr — set to 1 for every item row this batch touches (plain byte stores: every
+// writer writes 1); drx_shard.hip turns the map into the batch's distinct rows, their positions in the exchange buffers and the
+// per-owner counts without waiting for the sort.
+struct TouchPresence {
+  uint8_t *present;
+  int ipr, shift;
+  __device__ __forceinline__ uint32_t wire(int item, int is_out) const {
+    const int o = item / ipr;
+    return ((uint32_t)o << shift) + (uint32_t)(is_out ? ipr : 0) + (uint32_t)(item - o * ipr);
+  }
+};
+
 static __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
                                                            uint32_t *vals, int T, uint8_t *solo, uint32_t *zero_a,
-                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b, uint32_t *zero_c, int n_zero_c) {
+                                                           int n_zero_a, uint32_t *zero_b, int n_zero_b, uint32_t *zero_c, int n_zero_c,
+                                                           TouchPresence pres) {
   constexpr int G = 16;
   const int lane = threadIdx.x % G;
   const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
@@ -37,12 +51,15 @@ static __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, D
   for (int64_t j = s + lane; j < e; j += G) {
     const uint32_t jj = (uint32_t)(j - s);
     const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
-    keys[base + jj] = kf ? (uint32_t)H.indices[j] : DRX_KEY_NONE;
+    const int item = H.indices[j];
+    keys[base + jj] = kf ? (uint32_t)item : DRX_KEY_NONE;
     vals[base + jj] = (uint32_t)b;
+    if (pres.present && kf) pres.present[pres.wire(item, 0)] = 1;
   }
   if (lane == 0) {
     const int deg = (int)(e - s);
     keys[base + deg] = (uint32_t)(n_items + bt.iid[b]);       vals[base + deg] = (uint32_t)b;
+    if (pres.present) pres.present[pres.wire(bt.iid[b], 1)] = 1;
     keys[base + deg + 1] = (uint32_t)(2 * n_items) + (uint32_t)u;       vals[base + deg + 1] = (uint32_t)b;
   }
 }
@@ -276,14 +293,14 @@ static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t s
 }
 
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
-                        bool with_marks = false) {
+                        bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, 1, 0}) {
   const int gpb = kBlock / 16;
   uint32_t *sort_zero = nullptr;
   size_t sort_zero_words = 0;
   sort_pairs_zero_region(R.sort_temp, (size_t)R.T, R.bits, &sort_zero, &sort_zero_words);
   hipLaunchKernelGGL(k_sparse_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, p->n_items, *hist, *bt,
                      q_threshold(bt->q), R.keys, R.vals, R.T, R.solo_v, R.plan.cnt, plan_zero_words(R), R.order_work, 512,
-                     sort_zero, (int)sort_zero_words);
+                     sort_zero, (int)sort_zero_words, pres);
   // the launch order (see k_degree_counts): its counts ride in the sort's first launch, its scatter in the plan + marks launch below
   const bool fused_order = with_marks && p->ld > 16;
   const SortRider rider{fused_order ? bt->keep_off : nullptr, bt->B, R.order_work};

@@ -1,167 +1,346 @@
-// Row-sharded (multi-GPU) CDAE sampled step: the per-rank device work around the two RCCL all-to-all exchanges.
+// Row-sharded (multi-GPU) CDAE sampled step: the per-rank device work around the two RCCL all-to-all exchanges (round-4 rewrite on
+// the single-GPU step's machinery: prepared touch list, span plan, sole-toucher marks, launch order — drx_prep.hpp / drx_segreduce.hpp).
 //
-// Layout: users — V rows, their histories and the triples sampled for them — are sharded by contiguous
-// uid range and never move.  Item-side rows (W, W2T, b2 and their optimizer slots) are sharded by contiguous item
-// range; a step requests each DISTINCT item row it touches from its owner (all-to-all of ids, then of rows), runs
-// forward/backward against that row cache, reduces its contributions per distinct row, and returns one gradient row
-// per distinct row to the owner (all-to-all), which sums duplicates across ranks in rank order and applies the sparse
-// optimizer.  Everything here is per-rank and collective-free; drecpy_amd/dist.py drives the exchanges.
+// Layout (BASELINE.json configuration 4): users — V rows, their histories and the triples sampled for them — are sharded
+// by contiguous uid range and never move.  Item-side rows (W, W2T, b2 and their optimizer slots) are sharded by contiguous item range
+// of ipr = ceil(N / world) rows.  A step requests each DISTINCT item row it touches from its owner (all-to-all of keys, then of rows),
+// runs forward / backward against that row cache, reduces its contributions to one gradient row per distinct row, and returns those to
+// the owners (all-to-all), which sum what the ranks sent in rank order and apply the sparse optimizer once per row.
+// Everything here is per-rank and collective-free; drecpy_amd/dist.py drives the exchanges.
 //
-// Key space (owner-major so that a rank's sorted distinct keys are contiguous per owner):
-//     item n -> owner o = n / ipr, l = n - o*ipr ;  W row: o*2ipr + l ;  W2T row: o*2ipr + ipr + l
-//     local user u -> world*2ipr + u
+// Two key spaces:
+//   * the touch list is sorted in the single-GPU step's keys ([0,N) W rows, [N,2N) W2T rows of GLOBAL item ids, 2N + local user):
+//     preparation, plan, marks and reduction are the shared code;
+//   * rows travel under WIRE keys, owner-major: item n of owner o = n / ipr is (o << shift) + (W2T ? ipr : 0) + n - o * ipr, with
+//     1 << shift >= 2 * ipr a multiple of the 8192-key tile — an owner's keys are whole tiles of the presence map.
+//
+// Exchange buffers (both directions, one float buffer per direction = ONE collective): destination o's chunk is n_o rows of ld floats
+// followed by n_o scalars padded to 32 floats (rows stay 128-byte aligned for ld % 32 == 0).  n_o = the distinct rows asked of o + 1:
+// the chunk's last row is a SENTINEL (key DRX_KEY_NONE) — unused on the way out, and on the way back it carries this rank's gradient
+// of the replicated hidden bias (its scalar: the rank's loss sum), so that every rank sums the same `world` rows in rank order: no
+// all-reduce, no extra collective.  The scalar of a W2T row is b2 on the way out and its gradient on the way back.
 #include "drx_common.hpp"
 #include "drx_rows.hpp"
 #include "drx_segreduce.hpp"
 #include "drx_scan.hpp"
+#include "drx_prep.hpp"
 
 namespace drx {
 
-__device__ __forceinline__ uint32_t item_key(const DrxShard &sh, int n, int is_out) {
-  const int o = n / sh.items_per_rank;
-  return (uint32_t)(o * 2 * sh.items_per_rank + (is_out ? sh.items_per_rank : 0) + (n - o * sh.items_per_rank));
-}
-__device__ __forceinline__ uint32_t user_key0(const DrxShard &sh) { return (uint32_t)(sh.world * 2 * sh.items_per_rank); }
+constexpr int kTileKeys = 8192;            // wire keys per workgroup of the presence-map kernels (256 words of 32 keys)
+constexpr int kTileWords = kTileKeys / 32;
 
-// ---- 1. touches of the local batch -----------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_shard_touches(DrxShard sh, DrxHistory H, DrxBatch bt, uint32_t qthr,
-                                                          uint32_t *keys, uint32_t *vals, uint32_t *b_of_pos) {
-  // one 16-lane group per sample
-  constexpr int G = 16;
-  const int lane = threadIdx.x % G;
-  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (b >= bt.B) return;
-  const int u = bt.uid[b];
-  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
-  const int base = bt.keep_off[b] + 2 * b;
-  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
-  for (int64_t j = s + lane; j < e; j += G) {
-    const uint32_t jj = (uint32_t)(j - s);
-    const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
-    keys[base + jj] = kf ? item_key(sh, H.indices[j], 0) : DRX_KEY_NONE;
-    vals[base + jj] = (uint32_t)(base + jj);
-    b_of_pos[base + jj] = (uint32_t)b;
+struct ShardGeo {
+  int world, rank, ipr, shift, ld, bypass;      // bypass: this rank's OWN rows never pass through a collective (DRX_SHARD_SELF_BYPASS)
+  uint32_t n_words, n_tiles, tiles_per_owner;
+  __host__ __device__ uint32_t wire(int item, int is_out) const {
+    const int o = item / ipr;
+    return ((uint32_t)o << shift) + (uint32_t)(is_out ? ipr : 0) + (uint32_t)(item - o * ipr);
   }
-  if (lane == 0) {
-    const int deg = (int)(e - s);
-    keys[base + deg] = item_key(sh, bt.iid[b], 1);
-    keys[base + deg + 1] = user_key0(sh) + (uint32_t)u;
-    vals[base + deg] = (uint32_t)(base + deg);
-    vals[base + deg + 1] = (uint32_t)(base + deg + 1);
-    b_of_pos[base + deg] = b_of_pos[base + deg + 1] = (uint32_t)b;
-  }
-}
-
-// ---- 2. distinct keys, slots, per-owner bounds -----------------------------------------------------------------------
-__global__ void k_head_flags(const uint32_t *__restrict__ keys_s, int T, int *flag) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
-    const uint32_t k = keys_s[j];
-    flag[j] = (k != DRX_KEY_NONE && (j == 0 || keys_s[j - 1] != k)) ? 1 : 0;
-  }
-}
-
-// slot_sorted holds the INCLUSIVE scan of the head flags; slot = scan - 1
-__global__ void k_slots(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s, int T, int *slot_sorted,
-                        uint32_t *slot_of_pos, uint32_t *uniq_keys) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
-    const uint32_t k = keys_s[j];
-    if (k == DRX_KEY_NONE) { slot_of_pos[vals_s[j]] = DRX_KEY_NONE; slot_sorted[j] = -1; continue; }
-    const int slot = slot_sorted[j] - 1;
-    slot_sorted[j] = slot;
-    slot_of_pos[vals_s[j]] = (uint32_t)slot;
-    if (j == 0 || keys_s[j - 1] != k) uniq_keys[slot] = k;
-  }
-}
-
-// bounds[o] = number of distinct keys < o*2ipr for o = 0..world (bounds[world] = first user key); bounds[world+1] = Q
-__global__ void k_owner_bounds(const uint32_t *__restrict__ keys_s, const int *__restrict__ slot_sorted, int T, DrxShard sh,
-                               int32_t *bounds) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o > sh.world + 1) return;
-  const uint32_t target = o <= sh.world ? (uint32_t)(o * 2 * sh.items_per_rank) : DRX_KEY_NONE;
-  int lo = 0, hi = T;                         // lower_bound of target over the sorted touches
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (keys_s[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  // distinct keys before position lo = slot of the last real touch before lo, + 1
-  bounds[o] = lo == 0 ? 0 : slot_sorted[lo - 1] + 1;
-}
-
-// ---- 3. owner side: fetch requested rows -------------------------------------------------------------------------
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_shard_gather_rows(DrxCdaeParams P, DrxShard sh, const uint32_t *__restrict__ req, int n,
-                                                              float *__restrict__ rows, float *__restrict__ b2out) {
-  const int lane = threadIdx.x % G;
-  const int gpb = kBlock / G;
-  for (int i = blockIdx.x * gpb + threadIdx.x / G; i < n; i += gridDim.x * gpb) {
-    const uint32_t t = req[i] - (uint32_t)(sh.rank * 2 * sh.items_per_rank);     // local key in [0, 2*ipr)
-    const bool is_out = t >= (uint32_t)sh.items_per_rank;
-    const size_t row = is_out ? t - sh.items_per_rank : t;
-    float4 v[J];
-    load_row<G, J>(is_out ? P.W2T : P.W, row, P.ld, lane, v);
-    store_row<G, J>(rows, (size_t)i, P.ld, lane, v);
-    if (lane == 0) b2out[i] = is_out ? P.b2[row] : 0.f;
-  }
-}
-
-// ---- 4. forward/backward against the row cache -----------------------------------------------------------------------
-struct ShardFwd {
-  const uint32_t *slot_of_pos;   // [T]
-  const float *rows;             // [Q_item, ld] requested rows, in distinct-key order
-  const float *b2c;              // [Q_item]
-  float *dz1, *g2, *dz2, *lossb;
-  float inv_b_norm;              // 1 / global batch
 };
 
+static ShardGeo geo_of(const DrxShard &sh, int ld) {
+  ShardGeo g{};
+  g.world = sh.world; g.rank = sh.rank; g.ipr = sh.items_per_rank; g.ld = ld;
+  g.bypass = (sh.flags & DRX_SHARD_SELF_BYPASS) ? 1 : 0;
+  g.shift = 13;
+  while ((1ll << g.shift) < 2ll * sh.items_per_rank) ++g.shift;
+  g.tiles_per_owner = (uint32_t)((1ull << g.shift) / kTileKeys);
+  g.n_tiles = g.tiles_per_owner * (uint32_t)sh.world;
+  g.n_words = g.n_tiles * kTileWords;
+  return g;
+}
+
+__host__ __device__ inline uint32_t pad32(uint32_t n) { return (n + 31u) & ~31u; }
+
+// Where the rows of a prepared batch sit in its exchange buffers.
+struct ShardXfer {
+  const uint2 *ptab;          // [n_words]: x = the word's 32 presence bits, y = position of its first present key
+  const uint32_t *first;      // [world + 1]: position of owner o's first row (sentinels included); first[world] = all rows
+  const uint32_t *foff;       // [world + 1]: float offset of owner o's chunk in this rank's exchange buffers — the chunks in rank order;
+                              //   with the self-bypass the rank's own chunk comes LAST (it does not travel); foff[world] = all floats
+  int shift, ld;
+  __device__ __forceinline__ uint32_t pos_of(uint32_t w) const {
+    const uint2 e = ptab[w >> 5];
+    return e.y + (uint32_t)__popc(e.x & ((1u << (w & 31u)) - 1u));
+  }
+  __device__ __forceinline__ size_t row_off(uint32_t w, uint32_t pos) const {
+    const uint32_t o = w >> shift;
+    return (size_t)foff[o] + (size_t)(pos - first[o]) * ld;
+  }
+  __device__ __forceinline__ size_t scal_off(uint32_t w, uint32_t pos) const {
+    const uint32_t o = w >> shift;
+    return (size_t)foff[o] + (size_t)(first[o + 1] - first[o]) * ld + (pos - first[o]);
+  }
+  __device__ __forceinline__ size_t sentinel_row(int o) const { return (size_t)foff[o] + (size_t)(first[o + 1] - 1 - first[o]) * ld; }
+  __device__ __forceinline__ size_t sentinel_scal(int o) const { return (size_t)foff[o] + (size_t)(first[o + 1] - first[o]) * (ld + 1) - 1; }
+};
+
+// ---- 1. presence map -> distinct rows, positions, per-owner counts (two small launches; independent of the sort) -----------------
+static __global__ __launch_bounds__(kTileWords) void k_shard_pack(uint8_t *__restrict__ present, uint2 *__restrict__ ptab,
+                                                                  int *__restrict__ tile_sum) {
+  __shared__ int lds[kScanThreads / 64];
+  const uint32_t w = blockIdx.x * kTileWords + threadIdx.x;
+  uint4 *src = reinterpret_cast<uint4 *>(present + (size_t)w * 32);
+  const uint4 a = src[0], c = src[1];
+  const uint32_t x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+  uint32_t bits = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    bits |= (((x[i] & 0xFFu) ? 1u : 0u) | ((x[i] & 0xFF00u) ? 2u : 0u) | ((x[i] & 0xFF0000u) ? 4u : 0u) | ((x[i] & 0xFF000000u) ? 8u : 0u)) << (4 * i);
+  if (bits) { src[0] = make_uint4(0, 0, 0, 0); src[1] = make_uint4(0, 0, 0, 0); }       // the map is all zero again for the next batch
+  ptab[w].x = bits;
+  int total;
+  (void)block_scan_incl((int)__popc(bits), lds, total);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+// Positions: every workgroup sums the tile sums in front of its tile itself (n_tiles is a few hundred: cheaper than a launch of ONE
+// workgroup between the two — a launch on the preparation's stream waits 10 - 40 us for room whatever it computes); one sentinel
+// position behind every owner's keys.  Workgroup 0 also writes first / foff / counts and the sentinels.
+static __global__ __launch_bounds__(kTileWords) void k_shard_emit(uint2 *__restrict__ ptab, const int *__restrict__ tile_sum, ShardGeo g,
+                                                                  uint32_t *__restrict__ first, uint32_t *__restrict__ foff,
+                                                                  long long *__restrict__ counts, uint32_t *__restrict__ uniq) {
+  __shared__ int lds[kScanThreads / 64];
+  __shared__ uint32_t sfirst[DRX_MAX_WORLD + 1];
+  const int tpo = (int)g.tiles_per_owner, blk = (int)blockIdx.x;
+  int before = 0;
+  for (int i = threadIdx.x; i < blk; i += kTileWords) before += tile_sum[i];
+  int tile_off;
+  (void)block_scan_incl(before, lds, tile_off);
+  tile_off += blk / tpo;                                   // the sentinels of the owners that end in front of this tile
+  const uint32_t w = blockIdx.x * kTileWords + threadIdx.x;
+  uint32_t bits = ptab[w].x;
+  const int c = (int)__popc(bits);
+  int total;
+  const int incl = block_scan_incl(c, lds, total);
+  uint32_t pos = (uint32_t)(tile_off + incl - c);
+  ptab[w].y = pos;
+  while (bits) {
+    const int i = __builtin_ctz(bits);
+    bits &= bits - 1;
+    uniq[pos++] = w * 32 + (uint32_t)i;
+  }
+  if (blk != 0) return;
+  if ((int)threadIdx.x <= g.world) {                       // thread o: where owner o's rows start
+    const int o = threadIdx.x;
+    int sum = o;
+    for (int i = 0; i < o * tpo; ++i) sum += tile_sum[i];
+    sfirst[o] = (uint32_t)sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int o = 0; o <= g.world; ++o) {
+      first[o] = sfirst[o];
+      if (o == g.world) break;
+      const uint32_t n = sfirst[o + 1] - sfirst[o];
+      counts[o] = (long long)n;
+      uniq[sfirst[o + 1] - 1] = DRX_KEY_NONE;
+      if (g.bypass && o == g.rank) continue;            // the own chunk: behind all the others
+      foff[o] = run;
+      run += n * (uint32_t)g.ld + pad32(n);
+    }
+    if (g.bypass) {
+      const uint32_t n = sfirst[g.rank + 1] - sfirst[g.rank];
+      foff[g.rank] = run;
+      run += n * (uint32_t)g.ld + pad32(n);
+    }
+    foff[g.world] = run;
+  }
+}
+
+// ---- 2. owner side ------------------------------------------------------------------------------------------------------------------
+// The keys a rank receives are n_seg segments — micro-batch-major, then source rank — of ascending distinct wire keys closed by a
+// sentinel.  koff: key index where a segment starts; foff: where its chunk (m rows, then m scalars padded to 32) starts in the
+// exchange buffer.
+struct SegOff {
+  int koff[DRX_MAX_WORLD * DRX_MAX_MICRO + 1];
+  uint32_t foff[DRX_MAX_WORLD * DRX_MAX_MICRO + 1];     // float offset of the segment's chunk in the exchange buffer
+  int n_seg;
+  // self-bypass: the segments this rank sent to itself (one per micro-batch, s % world == rank) are not in the exchange buffer —
+  // their chunk lies in the rank's own gradient buffer of that micro-batch, at own_off floats
+  int self_rank, world;                                  // self_rank < 0: no bypass
+  const float *own_buf[DRX_MAX_MICRO];
+  uint32_t own_off[DRX_MAX_MICRO];
+  __device__ __forceinline__ bool is_own(int s) const { return self_rank >= 0 && s % world == self_rank; }
+  __device__ __forceinline__ const float *chunk(const float *xbuf, int s) const {
+    return is_own(s) ? own_buf[s / world] + own_off[s / world] : xbuf + foff[s];
+  }
+};
+
+__device__ __forceinline__ int source_of(const SegOff &so, int j) {
+  int lo = 0, hi = so.n_seg;                      // last segment whose start is <= j
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (so.koff[mid] <= j) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+static int seg_off(const ShardGeo &g, const int32_t *recv_counts, int n_segments, int n, SegOff &so) {
+  so.n_seg = n_segments;
+  so.world = g.world;
+  so.self_rank = g.bypass ? g.rank : -1;
+  so.koff[0] = 0; so.foff[0] = 0;
+  unsigned long long f = 0;
+  for (int s = 0; s < n_segments; ++s) {
+    if (recv_counts[s] < 1) return DRX_EINVAL;                 // every segment holds at least its sentinel
+    so.koff[s + 1] = so.koff[s] + recv_counts[s];
+    if (!(g.bypass && s % g.world == g.rank)) f += (unsigned long long)recv_counts[s] * g.ld + pad32((uint32_t)recv_counts[s]);
+    if (f >= 0xFFFFFFFFull) return DRX_EINVAL;
+    so.foff[s + 1] = (uint32_t)f;
+  }
+  for (int m = 0; m < DRX_MAX_MICRO; ++m) { so.own_buf[m] = nullptr; so.own_off[m] = 0; }
+  return so.koff[n_segments] == n ? DRX_OK : DRX_EINVAL;
+}
+
+// Every received key is entered in a direct-address table tab[local key][segment] = key index (no two writers per entry): the owner
+// apply then lets the row of the LOWEST segment holding a key sum all holders in segment order — one pass, fixed order, no sort, no
+// atomics.  Parameter-independent: built when the keys arrive, ahead of the step.
+static __global__ void k_owner_scatter(ShardGeo g, SegOff so, const uint32_t *__restrict__ recv_keys, int n, uint32_t *tab) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t k = recv_keys[j];
+    if (k == DRX_KEY_NONE) continue;
+    const uint32_t lk = k - ((uint32_t)g.rank << g.shift);
+    tab[(size_t)lk * so.n_seg + source_of(so, j)] = (uint32_t)j;
+  }
+}
+
+// rows[j] = the W / W2T row named by recv_keys[j], its scalar = the output bias (W2T rows); sentinels are skipped
 template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_shard_fwd_bwd(DrxCdaeParams P, DrxHistory H, DrxBatch bt, float scale,
-                                                          int loss_kind, ShardFwd F) {
+static __global__ __launch_bounds__(kBlock) void k_shard_gather_rows(DrxCdaeParams P, ShardGeo g, SegOff so,
+                                                                     const uint32_t *__restrict__ recv_keys, int n, float *__restrict__ out) {
   const int lane = threadIdx.x % G;
-  const int b = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (b >= bt.B) return;
+  const int gpb = kBlock / G;
+  constexpr int NF = J == 1 ? 4 : 2;
+  for (int j0 = (blockIdx.x * gpb + threadIdx.x / G) * NF; j0 < n; j0 += gridDim.x * gpb * NF) {
+    float4 v[NF][J];
+    size_t dst[NF], sdst[NF];
+    float bv[NF];
+    bool live[NF], outr[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      const int j = j0 + q;
+      live[q] = false; outr[q] = false; bv[q] = 0.f; dst[q] = 0; sdst[q] = 0;
+      const uint32_t k = j < n ? recv_keys[j] : DRX_KEY_NONE;
+      if (k == DRX_KEY_NONE) continue;
+      const uint32_t t = k - ((uint32_t)g.rank << g.shift);            // local key in [0, 2 * ipr)
+      const bool is_out = t >= (uint32_t)g.ipr;
+      const size_t row = is_out ? t - g.ipr : t;
+      const int s = source_of(so, j);
+      if (so.is_own(s)) continue;                                      // the requester reads its own rows from the tables
+      dst[q] = (size_t)so.foff[s] + (size_t)(j - so.koff[s]) * P.ld;
+      sdst[q] = (size_t)so.foff[s] + (size_t)(so.koff[s + 1] - so.koff[s]) * P.ld + (size_t)(j - so.koff[s]);
+      live[q] = true; outr[q] = is_out;
+      float *const tw = P.W, *const to = P.W2T;
+      load_row<G, J>(is_out ? to : tw, row, P.ld, lane, v[q]);
+      if (is_out && lane == 0) bv[q] = P.b2[row];
+    }
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+      if (live[q]) {
+        store_row<G, J>(out + dst[q], 0, P.ld, lane, v[q]);
+        if (outr[q] && lane == 0) out[sdst[q]] = bv[q];
+      }
+  }
+}
+
+// ---- 3. forward / backward of the local triples against the row cache -------------------------------------------------------------
+struct ShardStep {
+  float *dz1, *g2, *dz2, *lossb;              // [B, ld] x 2, [B] x 2
+  const uint8_t *solo_v, *solo_o;             // sole-toucher marks of the prepared list ([B] each) or nullptr (rows of <= 16 floats)
+  const int32_t *order;                       // launch order (longest histories first)
+  const float *cache;                         // the rows this rank asked for, as they arrived
+  float *gsend;                               // gradient rows on their way back: same geometry
+  ShardXfer X;
+  int ipr, b_norm, n_items;                   // n_items: GLOBAL
+  int self;                                   // this rank when its own rows bypass the exchange (read from the tables), else -1
+};
+
+template <int G, int J, int KIND>
+static __global__ __launch_bounds__(kBlock) void k_shard_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+                                                                 uint32_t qthr, int loss_kind, ShardStep S) {
+  const int lane = threadIdx.x % G;
+  const int slot = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (slot >= bt.B) return;
+  const int b = S.order ? S.order[slot] : slot;
   const int u = bt.uid[b];
-  const float y = bt.y[b];
-  const int base = bt.keep_off[b] + 2 * b;
-  const int deg = bt.keep_off[b + 1] - bt.keep_off[b];
-  float4 acc[J], h[J], w2[J];
+  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+  const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
+  float4 acc[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  for (int c = 0; c < deg; c += G) {
-    const int jj = c + lane;
-    uint32_t slot = DRX_KEY_NONE;
-    if (jj < deg) slot = F.slot_of_pos[base + jj];
-    const int n_here = min(G, deg - c);
-    for (int t = 0; t < n_here; t += 4) {
-      uint32_t s0 = (uint32_t)__shfl((int)slot, t, G), s1 = (uint32_t)__shfl((int)slot, t + 1, G);
-      uint32_t s2 = (uint32_t)__shfl((int)slot, t + 2, G), s3 = (uint32_t)__shfl((int)slot, t + 3, G);
-      if (t + 1 >= n_here) s1 = DRX_KEY_NONE;
-      if (t + 2 >= n_here) s2 = DRX_KEY_NONE;
-      if (t + 3 >= n_here) s3 = DRX_KEY_NONE;
-      float4 r0[J], r1[J], r2[J], r3[J];
+  // a group fetches CH history entries per round; every lane turns ITS entries into cache offsets (index -> wire key -> position: two
+  // small dependent loads, in parallel over the lanes), then the rows are fetched NF at a time
+  constexpr int IPL = G >= 16 ? 1 : 16 / G;
+  constexpr int CH = G * IPL;
+  constexpr int NF = J == 1 ? 8 : 4;
+  for (int64_t c = s; c < e; c += CH) {
+    uint32_t off[IPL];              // in floats (the host checked that the buffer stays below 2^32 floats)
 #pragma unroll
-      for (int jx = 0; jx < J; ++jx) r0[jx] = r1[jx] = r2[jx] = r3[jx] = f4_zero();
-      if (s0 != DRX_KEY_NONE) load_row<G, J>(F.rows, (size_t)s0, P.ld, lane, r0);
-      if (s1 != DRX_KEY_NONE) load_row<G, J>(F.rows, (size_t)s1, P.ld, lane, r1);
-      if (s2 != DRX_KEY_NONE) load_row<G, J>(F.rows, (size_t)s2, P.ld, lane, r2);
-      if (s3 != DRX_KEY_NONE) load_row<G, J>(F.rows, (size_t)s3, P.ld, lane, r3);
-#pragma unroll
-      for (int jx = 0; jx < J; ++jx) {
-        f4_add(acc[jx], r0[jx]); f4_add(acc[jx], r1[jx]); f4_add(acc[jx], r2[jx]); f4_add(acc[jx], r3[jx]);
+    for (int r = 0; r < IPL; ++r) {
+      const int64_t j = c + r * G + lane;
+      off[r] = DRX_KEY_NONE;
+      if (j < e) {
+        const int item = H.indices[j];
+        const uint32_t jj = (uint32_t)(j - s);
+        const bool kf = kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
+        if (kf) {
+          const int o = item / S.ipr;
+          if (o == S.self) off[r] = 0x80000000u | (uint32_t)((item - o * S.ipr) * P.ld);        // an own row: straight from the table
+          else {
+            const uint32_t w = ((uint32_t)o << S.X.shift) + (uint32_t)(item - o * S.ipr);
+            off[r] = (uint32_t)S.X.row_off(w, S.X.pos_of(w));
+          }
+        }
       }
     }
+    const int n_here = (int)((e - c) < (int64_t)CH ? (e - c) : (int64_t)CH);
+    for (int t = 0; t < n_here; t += NF) {
+      float4 r[NF][J];
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        const int tt = t + q;
+        uint32_t so_ = off[0];
+#pragma unroll
+        for (int rr = 1; rr < IPL; ++rr) so_ = (tt / G == rr) ? off[rr] : so_;
+        const uint32_t oq = tt < n_here ? (uint32_t)__shfl((int)so_, tt % G, G) : DRX_KEY_NONE;
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) r[q][jx] = f4_zero();
+        if (oq != DRX_KEY_NONE) {
+          const float *const cb = S.cache, *const wb = P.W;             // (pointers read as scalars, the VALUE selected)
+          load_row<G, J>(((oq & 0x80000000u) ? wb : cb) + (size_t)(oq & 0x7FFFFFFFu), 0, P.ld, lane, r[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NF; ++q)
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) f4_add(acc[jx], r[q][jx]);
+    }
   }
+  float4 h[J], w2[J];
   hidden_act<G, J>(P, u, scale, lane, acc, h);
-  const uint32_t so = F.slot_of_pos[base + deg];
-  load_row<G, J>(F.rows, (size_t)so, P.ld, lane, w2);
+  const int i = bt.iid[b];
+  const int oo = i / S.ipr;
+  const uint32_t wo = ((uint32_t)oo << S.X.shift) + (uint32_t)S.ipr + (uint32_t)(i - oo * S.ipr);
+  const uint32_t po = S.X.pos_of(wo);
+  const size_t ro = S.X.row_off(wo, po), sco = S.X.scal_off(wo, po);
+  const bool own_out = oo == S.self;
+  {
+    const float *const cb = S.cache, *const tb = P.W2T;
+    load_row<G, J>(own_out ? tb + (size_t)(i - oo * S.ipr) * P.ld : cb + ro, 0, P.ld, lane, w2);
+  }
   float d = 0.f;
 #pragma unroll
   for (int j = 0; j < J; ++j) d += f4_dot(w2[j], h[j]);
   d = group_sum<G>(d);
-  const float p = sigmoidf_(d + F.b2c[so]);
+  const float y = bt.y[b];
+  const float p = sigmoidf_(d + (own_out ? P.b2[i - oo * S.ipr] : S.cache[sco]));
+  const float invB = 1.0f / (float)S.b_norm;
   float lval, dp;
-  if (loss_kind == DRX_LOSS_BCE) { lval = bce_elem(y, p); dp = bce_grad(y, p) * F.inv_b_norm; }
-  else { lval = (p - y) * (p - y); dp = 2.0f * (p - y) * F.inv_b_norm; }
+  if (loss_kind == DRX_LOSS_BCE) { lval = bce_elem(y, p); dp = bce_grad(y, p) * invB; }
+  else { lval = (p - y) * (p - y); dp = 2.0f * (p - y) * invB; }
   const float dz2 = dp * p * (1.0f - p);
   float4 dz1[J], g2[J];
 #pragma unroll
@@ -170,322 +349,344 @@ __global__ __launch_bounds__(kBlock) void k_shard_fwd_bwd(DrxCdaeParams P, DrxHi
     dz1[j].z = dz2 * w2[j].z * h[j].z * (1.0f - h[j].z); dz1[j].w = dz2 * w2[j].w * h[j].w * (1.0f - h[j].w);
     g2[j].x = dz2 * h[j].x; g2[j].y = dz2 * h[j].y; g2[j].z = dz2 * h[j].z; g2[j].w = dz2 * h[j].w;
   }
-  store_row<G, J>(F.dz1, (size_t)b, P.ld, lane, dz1);
-  store_row<G, J>(F.g2, (size_t)b, P.ld, lane, g2);
-  if (lane == 0) { F.dz2[b] = dz2; F.lossb[b] = lval; }
+  store_row<G, J>(S.dz1, (size_t)b, P.ld, lane, dz1);
+  if (lane == 0) S.lossb[b] = lval;
+  const bool solo_v = S.solo_v && S.solo_v[b], solo_o = S.solo_o && S.solo_o[b];
+  if (solo_o) {          // this sample alone touches W2T[i] on this rank: its gradient row goes straight into the exchange buffer
+    store_row<G, J>(S.gsend + ro, 0, P.ld, lane, g2);
+    if (lane == 0) S.gsend[sco] = dz2;
+  } else {
+    store_row<G, J>(S.g2, (size_t)b, P.ld, lane, g2);
+    if (lane == 0) S.dz2[b] = dz2;
+  }
+  if (solo_v) {          // V rows are local: a row only this sample touches is updated here (same arithmetic as the segment path)
+    OptScalars o = opt_for(opt, 0, S.b_norm);
+    o.inv_k = 1.0f / (float)P.k;
+    float4 w[J];
+    load_row<G, J>(P.V, (size_t)u, P.ld, lane, w);
+    row_update<G, J, KIND>(o, P.V, opt.s1[2], opt.s2[2], (size_t)u, P.ld, lane, w, dz1);
+  }
 }
 
-// ---- 5. local reduction: one gradient row per distinct item row, V rows updated in place -----------------------------------
-struct LocalPolicy {
+// ---- 4. local reduction: one gradient row per distinct item row into the exchange buffer, V rows updated in place -----------------
+template <int KIND>
+struct LocalPolicyT {
   DrxCdaeParams P;               // local tables (V used here)
   DrxOptim opt;
-  DrxShard sh;
-  int b_norm;
+  int b_norm, n_items, ipr;      // n_items: GLOBAL
   float scale;
-  const float *dz1;              // g2 = dz1 + g2_off (value select, see DirectPolicy in drx_cdae.hip)
+  const float *dz1;              // g2 = dz1 + g2_off (value select, see DirectPolicyT in drx_cdae.hip)
   long long g2_off;
   const float *dz2;
-  const uint32_t *b_of_pos;
-  const int *slot_sorted;
-  float *gc, *gb2c;              // [Q_item, ld], [Q_item]
+  float *gsend;
+  ShardXfer X;
   template <int G, int J>
-  __device__ __forceinline__ void load(uint32_t key, uint32_t pos, int lane, float4 (&row)[J], float &sc, float &coef) const {
-    const uint32_t b = b_of_pos[pos];
-    const uint32_t uk0 = user_key0(sh);
-    const bool is_user = key >= uk0;
-    const bool is_out = !is_user && (key % (2u * sh.items_per_rank)) >= (uint32_t)sh.items_per_rank;
+  __device__ __forceinline__ void load(uint32_t key, uint32_t b, int lane, float4 (&row)[J], float &sc, float &coef) const {
+    const uint32_t N = (uint32_t)n_items;
+    const bool is_out = key >= N && key < 2 * N;
     load_row<G, J>(dz1 + (is_out ? g2_off : 0ll), (size_t)b, P.ld, lane, row);
     if (is_out) sc = dz2[b];
-    coef = (!is_user && !is_out) ? scale : 1.0f;
+    coef = key < N ? scale : 1.0f;
   }
   template <int G, int J>
-  __device__ __forceinline__ void finish(uint32_t key, int pos, int lane, const float4 (&g)[J], float gs) const {
-    const uint32_t uk0 = user_key0(sh);
-    if (key >= uk0) {
-      const size_t row = key - uk0;
+  __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
+    const uint32_t N = (uint32_t)n_items;
+    if (key >= 2 * N) {
+      const size_t row = key - 2 * N;
       OptScalars o = opt_for(opt, 0, b_norm);
       o.inv_k = 1.0f / (float)P.k;
       float4 w[J];
       load_row<G, J>(P.V, row, P.ld, lane, w);
-      row_update<G, J>(o, P.V, opt.s1[2], opt.s2[2], row, P.ld, lane, w, g);
+      row_update<G, J, KIND>(o, P.V, opt.s1[2], opt.s2[2], row, P.ld, lane, w, g);
     } else {
-      const int slot = slot_sorted[pos];
-      store_row<G, J>(gc, (size_t)slot, P.ld, lane, g);
-      if (lane == 0) gb2c[slot] = gs;
+      const bool is_out = key >= N;
+      const int item = (int)(is_out ? key - N : key);
+      const int o = item / ipr;
+      const uint32_t w = ((uint32_t)o << X.shift) + (uint32_t)(is_out ? ipr : 0) + (uint32_t)(item - o * ipr);
+      const uint32_t pos = X.pos_of(w);
+      store_row<G, J>(gsend + X.row_off(w, pos), 0, P.ld, lane, g);
+      if (is_out && lane == 0) gsend[X.scal_off(w, pos)] = gs;
     }
   }
 };
 
-// ---- 6. owner side: sum the gradient rows received for each owned row (rank order) and apply the optimizer ----------
-struct OwnerPolicy {
-  DrxCdaeParams P;               // local (owned) item tables
-  DrxOptim opt;
-  DrxShard sh;
-  int b_norm;
-  const float *recv_rows, *recv_b2;
-  template <int G, int J>
-  __device__ __forceinline__ void load(uint32_t, uint32_t idx, int lane, float4 (&row)[J], float &sc, float &coef) const {
-    load_row<G, J>(recv_rows, (size_t)idx, P.ld, lane, row);
-    sc = recv_b2[idx];
-    coef = 1.0f;
-  }
-  template <int G, int J>
-  __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
-    const uint32_t t = key - (uint32_t)(sh.rank * 2 * sh.items_per_rank);
-    const bool is_out = t >= (uint32_t)sh.items_per_rank;
-    const size_t row = is_out ? t - sh.items_per_rank : t;
-    OptScalars o = opt_for(opt, 0, b_norm);
-    o.inv_k = 1.0f / (float)P.k;
-    float4 w[J];
-    float *wt = P.W, *w2 = P.W2T, *a0 = opt.s1[0], *a1 = opt.s1[1], *c0 = opt.s2[0], *c1 = opt.s2[1];   // scalar loads first
-    float *tab = is_out ? w2 : wt;
-    load_row<G, J>(tab, row, P.ld, lane, w);
-    row_update<G, J>(o, tab, is_out ? a1 : a0, is_out ? c1 : c0, row, P.ld, lane, w, g);
-    if (is_out && lane == 0) {
-      float pb = P.b2[row], m = opt.s1[4][row], v = o.kind == DRX_OPT_ADAM ? opt.s2[4][row] : 0.f;
-      o.rb = 0.f;
-      opt_update1(o, gs, pb, m, v);
-      P.b2[row] = pb; opt.s1[4][row] = m;
-      if (o.kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
-    }
-  }
-};
-
-// The rows a rank receives are W segments (one per source rank, in rank order), each with ascending DISTINCT keys.  Instead
-// of sorting them again, every received row is entered in a direct-address table tab[local key][source] = row index
-// (no two writers per entry); then the row of the LOWEST source holding a key sums all holders in source order and
-// applies the optimizer — one pass, fixed summation order, no sort, no atomics.
-struct SegOff { int off[DRX_MAX_WORLD * DRX_MAX_MICRO + 1]; int n_seg; };   // segments: micro-batch-major, then source rank
-
-__device__ __forceinline__ int source_of(const SegOff &so, int j) {
-  int s = 0;
-  while (s + 1 < so.n_seg && j >= so.off[s + 1]) ++s;
-  return s;
-}
-
-__global__ void k_owner_scatter(DrxShard sh, SegOff so, const uint32_t *__restrict__ recv_keys, int n, uint32_t *tab) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const uint32_t lk = recv_keys[j] - (uint32_t)(sh.rank * 2 * sh.items_per_rank);
-    tab[(size_t)lk * so.n_seg + source_of(so, j)] = (uint32_t)j;
-  }
-}
-
+// Last extra workgroup of the span launch: the rank's gradient of the hidden bias (sum of the column-sum partials the reduction's
+// extra workgroups left) into the sentinel row of EVERY destination, the rank's loss sum into that row's scalar.
 template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_owner_apply(OwnerPolicy pol, SegOff so, const uint32_t *__restrict__ recv_keys, int n,
-                                                        const uint32_t *__restrict__ tab) {
-  const int lane = threadIdx.x % G;
-  const int gpb = kBlock / G;
-  const int W = so.n_seg;                          // holders of a key are looked up per (micro-batch, source rank) segment
-  for (int j = blockIdx.x * gpb + threadIdx.x / G; j < n; j += gridDim.x * gpb) {
-    const uint32_t key = recv_keys[j];
-    const uint32_t lk = key - (uint32_t)(pol.sh.rank * 2 * pol.sh.items_per_rank);
-    const uint32_t *row_tab = tab + (size_t)lk * W;
-    float4 g[J];
+struct ShardBiasExtra {
+  int ld, world;
+  BiasArgs A;
+  float *gsend;
+  ShardXfer X;
+  __device__ __forceinline__ void operator()(float *lds) const {
+    __shared__ float red[kFixBlock / 64];
+    constexpr int R = kFixBlock / G;
+    const int lane = threadIdx.x % G, r = threadIdx.x / G;
+    float4 acc[J];
 #pragma unroll
-    for (int jx = 0; jx < J; ++jx) g[jx] = f4_zero();
-    float gs = 0.f;
-    bool leader = true, first = true;
-    for (int s0 = 0; s0 < W && leader; s0 += G) {                 // G sources at a time, one table entry per lane
-      const uint32_t e = (s0 + lane < W) ? row_tab[s0 + lane] : DRX_KEY_NONE;
-      const int n_here = min(G, W - s0);
-      for (int t = 0; t < n_here; t += 4) {
-        uint32_t r[4];
-        float4 v[4][J];
-        float sc[4];
+    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+    constexpr int NB = J == 1 ? 8 : 2;
+    for (int i = r; i < A.n_part; i += NB * R) {
+      float4 v[NB][J];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          r[q] = (t + q < n_here) ? (uint32_t)__shfl((int)e, t + q, G) : DRX_KEY_NONE;
-          sc[q] = 0.f;
+      for (int q = 0; q < NB; ++q) {
 #pragma unroll
-          for (int jx = 0; jx < J; ++jx) v[q][jx] = f4_zero();
-        }
-        if (first) {                                               // the first holder must be this very row
-          uint32_t r0 = DRX_KEY_NONE;
+        for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
+        if (i + q * R < A.n_part) load_row<G, J>(A.part, (size_t)(i + q * R), ld, lane, v[q]);
+      }
 #pragma unroll
-          for (int q = 3; q >= 0; --q) if (r[q] != DRX_KEY_NONE) r0 = r[q];
-          if (r0 != DRX_KEY_NONE) { first = false; if (r0 != (uint32_t)j) { leader = false; break; } }
-        }
+      for (int q = 0; q < NB; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (r[q] != DRX_KEY_NONE) { load_row<G, J>(pol.recv_rows, (size_t)r[q], pol.P.ld, lane, v[q]); sc[q] = pol.recv_b2[r[q]]; }
+        for (int j = 0; j < J; ++j) f4_add(acc[j], v[q][j]);
+    }
+    store_row<G, J>(lds, (size_t)r, ld, lane, acc);
+    __syncthreads();
+    const float *lp = A.part + (size_t)A.n_part * ld;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < A.n_part; i += kFixBlock) a += lp[i];
+    const float tl = block_sum(a, red);                        // (thread 0 holds it)
+    if (r == 0) {
+      float4 g[J];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      for (int j = 0; j < J; ++j) g[j] = f4_zero();
+#pragma unroll 8
+      for (int rr = 0; rr < R; ++rr) {
+        float4 v[J];
+        load_row<G, J>(lds, (size_t)rr, ld, lane, v);
 #pragma unroll
-          for (int jx = 0; jx < J; ++jx) f4_add(g[jx], v[q][jx]);
-          gs += sc[q];
-        }
+        for (int j = 0; j < J; ++j) f4_add(g[j], v[j]);
+      }
+      for (int o = 0; o < world; ++o) {                        // the sentinel closes owner o's chunk
+        store_row<G, J>(gsend + X.sentinel_row(o), 0, ld, lane, g);
+        if (threadIdx.x == 0) gsend[X.sentinel_scal(o)] = tl;
       }
     }
-    if (leader && !first) pol.template finish<G, J>(key, 0, lane, g, gs);
   }
-}
-
-__global__ void k_iota(uint32_t *v, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = (uint32_t)i;
-}
-
-// ---- 7. hidden bias --------------------------------------------------------------------------------------------
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_colsum_partial(int ld, int B, const float *__restrict__ x, float *__restrict__ part,
-                                                           int rows_per_block, const float *__restrict__ lossb,
-                                                           float *__restrict__ loss_part) {
-  extern __shared__ __align__(16) float lds[];
-  __shared__ float red[kBlock / 64];
-  constexpr int R = kBlock / G;
-  const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
-  float4 acc[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  for (int b = b0 + r; b < b1; b += R) {
-    float4 v[J];
-    load_row<G, J>(x, (size_t)b, ld, lane, v);
-#pragma unroll
-    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
-  }
-  store_row<G, J>(lds, (size_t)r, ld, lane, acc);
-  __syncthreads();
-  if (r == 0) {
-    float4 t[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) t[j] = f4_zero();
-#pragma unroll 8
-    for (int rr = 0; rr < R; ++rr) {
-      float4 v[J];
-      load_row<G, J>(lds, (size_t)rr, ld, lane, v);
-#pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
-    }
-    store_row<G, J>(part, (size_t)blockIdx.x, ld, lane, t);
-  }
-  float a = 0.f;                                   // this block's slice of the per-sample losses
-  for (int b = b0 + (int)threadIdx.x; b < b1; b += kBlock) a += lossb[b];
-  const float tl = block_sum(a, red);
-  if (threadIdx.x == 0) loss_part[blockIdx.x] = tl;
-}
-
-// out[0..ld) = sum of the n_part partial rows; out[ld] = sum of the n_part loss partials   (one workgroup, fixed order)
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_colsum_final(int ld, const float *__restrict__ part, int n_part,
-                                                         const float *__restrict__ lossb, int B, float *__restrict__ out) {
-  extern __shared__ __align__(16) float lds[];
-  __shared__ float red[kBlock / 64];
-  constexpr int R = kBlock / G;
-  const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  float4 acc[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-  for (int i = r; i < n_part; i += R) {
-    float4 v[J];
-    load_row<G, J>(part, (size_t)i, ld, lane, v);
-#pragma unroll
-    for (int j = 0; j < J; ++j) f4_add(acc[j], v[j]);
-  }
-  store_row<G, J>(lds, (size_t)r, ld, lane, acc);
-  __syncthreads();
-  if (r == 0) {
-    float4 t[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) t[j] = f4_zero();
-#pragma unroll 8
-    for (int rr = 0; rr < R; ++rr) {
-      float4 v[J];
-      load_row<G, J>(lds, (size_t)rr, ld, lane, v);
-#pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
-    }
-    store_row<G, J>(out, 0, ld, lane, t);
-  }
-  float a = 0.f;
-  for (int i = threadIdx.x; i < n_part; i += kBlock) a += lossb[i];      // lossb = per-block loss partials here
-  const float tl = block_sum(a, red);
-  if (threadIdx.x == 0) out[ld] = tl;
-  (void)B;
-}
-
-template <int G, int J>
-__global__ __launch_bounds__(kBlock) void k_bias_apply(DrxCdaeParams P, DrxOptim opt, int b_norm, const float *__restrict__ grad) {
-  const int lane = threadIdx.x % G;
-  if (threadIdx.x < G) {
-    float4 g[J], w[J];
-    load_row<G, J>(grad, 0, P.ld, lane, g);
-    load_row<G, J>(P.b, 0, P.ld, lane, w);
-    OptScalars o = opt_for(opt, 0, b_norm);
-    if (o.kind == DRX_OPT_ROWWISE_ADAGRAD) o.kind = DRX_OPT_ADAGRAD;
-    o.rb = 0.f;
-    row_update<G, J>(o, P.b, opt.s1[3], opt.s2[3], 0, P.ld, lane, w, g);
-  }
-}
-
-struct SegLayout {
-  SegBufs sb;
-  uint32_t *idx, *keys_s, *vals_s;
-  void *sort_temp;
-  size_t sort_bytes;
-  int *flags;
-  void *scan_temp;
-  size_t scan_bytes;
-  float *part;
 };
 
-static SegLayout seg_layout(Carver &cv, int ld, int T, int sort_bits) {
-  SegLayout L{};
-  const int n_chunks = (T + kChunk - 1) / kChunk;
-  L.sb.T = T; L.sb.n_chunks = n_chunks; L.sb.ld = ld;
-  L.sb.phead = cv.take<float>((size_t)n_chunks * ld);
-  L.sb.ptail = cv.take<float>((size_t)n_chunks * ld);
-  L.sb.phs = cv.take<float>(n_chunks);
-  L.sb.pts = cv.take<float>(n_chunks);
-  L.sb.span_list = cv.take<uint32_t>(n_chunks);
-  L.sb.long_list = cv.take<uint32_t>(n_chunks);
-  L.sb.n_span = cv.take<uint32_t>(64);
-  L.sb.cflag = cv.take<uint8_t>(n_chunks);
-  L.idx = cv.take<uint32_t>(T);
-  L.keys_s = cv.take<uint32_t>(T);
-  L.vals_s = cv.take<uint32_t>(T);
-  L.sort_bytes = sort_pairs_temp_bytes((size_t)T, sort_bits);
-  L.sort_temp = cv.take<char>(L.sort_bytes);
-  L.flags = cv.take<int>(T);
-  L.scan_bytes = scan_i32_temp_bytes((size_t)(T > 0 ? T : 1));
-  L.scan_temp = cv.take<char>(L.scan_bytes);
-  L.part = cv.take<float>((size_t)256 * ld);
+// ---- 5. owner side: sum the gradient rows received for each owned row in segment order, apply the optimizer once per row ----------
+template <int G, int J, int KIND>
+static __global__ __launch_bounds__(kBlock) void k_shard_apply(DrxCdaeParams P, DrxOptim opt, ShardGeo g, int b_norm, SegOff so,
+                                                               const uint32_t *__restrict__ recv_keys, int n,
+                                                               const uint32_t *__restrict__ tab, const float *__restrict__ grecv,
+                                                               int row_blocks, float *loss_out) {
+  const int lane = threadIdx.x % G;
+  const int gpb = kBlock / G;
+  const int W = so.n_seg;
+  if ((int)blockIdx.x >= row_blocks) {
+    // the hidden bias: the sentinel rows of all segments in order (every rank sums the same rows: b stays identical everywhere)
+    if (threadIdx.x < G) {
+      float4 gb[J], w[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) gb[j] = f4_zero();
+      float ls = 0.f;
+      for (int s = 0; s < W; ++s) {
+        const int m = so.koff[s + 1] - so.koff[s], i = m - 1;
+        const float *ch = so.chunk(grecv, s);
+        float4 v[J];
+        load_row<G, J>(ch + (size_t)i * P.ld, 0, P.ld, lane, v);
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(gb[j], v[j]);
+        ls += ch[(size_t)m * P.ld + i];
+      }
+      load_row<G, J>(P.b, 0, P.ld, lane, w);
+      OptScalars o = opt_for(opt, 0, b_norm);
+      if (o.kind == DRX_OPT_ROWWISE_ADAGRAD) o.kind = DRX_OPT_ADAGRAD;      // the bias vectors keep one accumulator per element
+      o.rb = 0.f;
+      row_update<G, J>(o, P.b, opt.s1[3], opt.s2[3], 0, P.ld, lane, w, gb);
+      if (threadIdx.x == 0 && loss_out) { loss_out[0] = ls / (float)b_norm; loss_out[1] = 0.f; }
+    }
+    return;
+  }
+  // NR consecutive keys per group and round: their holder lists, gradient rows, parameter and slot rows are requested side by side
+  // (one key at a time left the kernel a chain of four dependent round trips per row: 141 us for 260 k rows; the keys of a segment
+  // are ascending, so consecutive keys walk the tables and the gradient buffer in order)
+  constexpr int NR = J == 1 ? 4 : 2;
+  for (int j0 = (blockIdx.x * gpb + threadIdx.x / G) * NR; j0 < n; j0 += row_blocks * gpb * NR) {
+    uint32_t lk[NR];
+    bool live[NR];
+    float4 gsum[NR][J];
+    float gs[NR];
+    if (W == 1) {                                                  // one segment: every key is its own (only) holder
+      const float *ch = so.chunk(grecv, 0);
+      const int m = so.koff[1];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int j = j0 + q;
+        const uint32_t key = j < n ? recv_keys[j] : DRX_KEY_NONE;
+        live[q] = key != DRX_KEY_NONE;
+        lk[q] = key - ((uint32_t)g.rank << g.shift);
+        gs[q] = 0.f;
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) gsum[q][jx] = f4_zero();
+        if (live[q]) {
+          load_row<G, J>(ch + (size_t)j * P.ld, 0, P.ld, lane, gsum[q]);
+          gs[q] = ch[(size_t)m * P.ld + j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int j = j0 + q;
+        const uint32_t key = j < n ? recv_keys[j] : DRX_KEY_NONE;
+        live[q] = key != DRX_KEY_NONE;
+        lk[q] = key - ((uint32_t)g.rank << g.shift);
+        gs[q] = 0.f;
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) gsum[q][jx] = f4_zero();
+        if (!live[q]) continue;
+        const uint32_t *row_tab = tab + (size_t)lk[q] * W;
+        bool leader = true, first = true;
+        for (int s0 = 0; s0 < W && leader; s0 += G) {               // G segments at a time, one table entry per lane
+          const uint32_t ent = (s0 + lane < W) ? row_tab[s0 + lane] : DRX_KEY_NONE;
+          const int n_here = min(G, W - s0);
+          for (int t = 0; t < n_here; t += 4) {
+            uint32_t r[4];
+            float4 v[4][J];
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              r[u] = (t + u < n_here) ? (uint32_t)__shfl((int)ent, t + u, G) : DRX_KEY_NONE;
+              sc[u] = 0.f;
+#pragma unroll
+              for (int jx = 0; jx < J; ++jx) v[u][jx] = f4_zero();
+            }
+            if (first) {                                           // the first holder must be this very row
+              uint32_t r0 = DRX_KEY_NONE;
+#pragma unroll
+              for (int u = 3; u >= 0; --u) if (r[u] != DRX_KEY_NONE) r0 = r[u];
+              if (r0 != DRX_KEY_NONE) { first = false; if (r0 != (uint32_t)j) { leader = false; break; } }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (r[u] != DRX_KEY_NONE) {
+                const int sg = s0 + t + u;                         // the table's column IS the segment
+                const int i = (int)r[u] - so.koff[sg];
+                const float *ch = so.chunk(grecv, sg);
+                load_row<G, J>(ch + (size_t)i * P.ld, 0, P.ld, lane, v[u]);
+                sc[u] = ch[(size_t)(so.koff[sg + 1] - so.koff[sg]) * P.ld + i];
+              }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+              for (int jx = 0; jx < J; ++jx) f4_add(gsum[q][jx], v[u][jx]);
+              gs[q] += sc[u];
+            }
+          }
+        }
+        if (!leader || first) live[q] = false;
+      }
+    }
+    // the NR rows' parameter rows first (independent loads), then the updates
+    float4 w[NR][J];
+    float *const wt = P.W, *const w2 = P.W2T, *const a0 = opt.s1[0], *const a1 = opt.s1[1], *const c0 = opt.s2[0], *const c1 = opt.s2[1];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+#pragma unroll
+      for (int jx = 0; jx < J; ++jx) w[q][jx] = f4_zero();
+      if (live[q]) {
+        const bool is_out = lk[q] >= (uint32_t)g.ipr;
+        load_row<G, J>(is_out ? w2 : wt, is_out ? lk[q] - g.ipr : lk[q], P.ld, lane, w[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      if (!live[q]) continue;
+      const bool is_out = lk[q] >= (uint32_t)g.ipr;
+      const size_t row = is_out ? lk[q] - g.ipr : lk[q];
+      OptScalars o = opt_for(opt, 0, b_norm);
+      o.inv_k = 1.0f / (float)P.k;
+      row_update<G, J, KIND>(o, is_out ? w2 : wt, is_out ? a1 : a0, is_out ? c1 : c0, row, P.ld, lane, w[q], gsum[q]);
+      if (is_out && lane == 0) {
+        const int kind = KIND >= 0 ? KIND : o.kind;
+        float pb = P.b2[row], m = opt.s1[4][row], v = kind == DRX_OPT_ADAM ? opt.s2[4][row] : 0.f;
+        o.rb = 0.f;
+        opt_update1<KIND>(o, gs[q], pb, m, v);
+        P.b2[row] = pb; opt.s1[4][row] = m;
+        if (kind == DRX_OPT_ADAM) opt.s2[4][row] = v;
+      }
+    }
+  }
+}
+
+// ---- layouts ------------------------------------------------------------------------------------------------------------------------
+struct ShardPrepBufs {
+  PrepBufs R;
+  uint2 *ptab;
+  uint32_t *uniq;
+  uint32_t *first, *foff;
+  long long *counts;
+  size_t off_uniq, off_counts, uniq_cap, result_bytes;
+};
+
+static DrxCdaeParams key_params(const DrxCdaeParams &p, const DrxShard &sh) {
+  DrxCdaeParams g = p;
+  g.n_items = sh.n_items;              // the touch list's key space: GLOBAL item ids, local users
+  g.n_users = sh.n_users_local;
+  return g;
+}
+
+static ShardPrepBufs shard_prep_layout(Carver &cv, const DrxCdaeParams &p, const DrxShard &sh, int B, int n_touch_slots) {
+  ShardPrepBufs L{};
+  const ShardGeo g = geo_of(sh, p.ld);
+  L.R = prep_layout(cv, key_params(p, sh), B, n_touch_slots);
+  L.ptab = cv.take<uint2>(g.n_words);
+  L.uniq_cap = (size_t)n_touch_slots + (size_t)B + (size_t)sh.world;
+  L.off_uniq = align_up(cv.off, 256);
+  L.uniq = cv.take<uint32_t>(L.uniq_cap);
+  L.first = cv.take<uint32_t>(DRX_MAX_WORLD + 1);
+  L.foff = cv.take<uint32_t>(DRX_MAX_WORLD + 1);
+  L.off_counts = align_up(cv.off, 256);
+  L.counts = cv.take<long long>(DRX_MAX_WORLD);
+  L.result_bytes = align_up(cv.off, 256);
   return L;
 }
 
-static uint32_t *owner_table(Carver &cv, const DrxShard &sh) {
-  return cv.take<uint32_t>((size_t)2 * sh.items_per_rank * sh.world * DRX_MAX_MICRO);
+struct ShardStepBufs {
+  float *dz1, *g2, *dz2, *lossb, *phead, *ptail, *phs, *pts, *pblock, *pbs, *bpart;
+  int T, n_chunks, n_bpart;
+};
+
+static ShardStepBufs shard_step_layout(Carver &cv, int ld, int B, int n_touch_slots) {
+  ShardStepBufs S{};
+  S.T = n_touch_slots + 2 * B;
+  S.n_chunks = (S.T + kChunk - 1) / kChunk;
+  S.n_bpart = 1024;
+  S.dz1 = cv.take<float>((size_t)B * ld);
+  S.g2 = cv.take<float>((size_t)B * ld);
+  S.dz2 = cv.take<float>(B);
+  S.lossb = cv.take<float>(B);
+  S.phead = cv.take<float>((size_t)S.n_chunks * ld);
+  S.ptail = cv.take<float>((size_t)S.n_chunks * ld);
+  S.phs = cv.take<float>(S.n_chunks);
+  S.pts = cv.take<float>(S.n_chunks);
+  const int cpb = kSegBlock / pick_geom(ld).G;
+  const int n_blocks = (S.n_chunks + cpb - 1) / cpb;
+  S.pblock = cv.take<float>((size_t)n_blocks * ld);
+  S.pbs = cv.take<float>(n_blocks);
+  S.bpart = cv.take<float>((size_t)S.n_bpart * (ld + 1));
+  return S;
 }
 
-static int key_bits(const DrxShard &sh) {
-  return bits_for((uint64_t)sh.world * 2 * sh.items_per_rank + (uint64_t)sh.n_users_local + 1);
+static int check_shard(const DrxShard *sh);
+static int check_bypass(const DrxShard *sh, int ld) {       // own rows are addressed by a 31-bit float offset into the local table
+  return ((sh->flags & DRX_SHARD_SELF_BYPASS) && (unsigned long long)sh->items_per_rank * ld >= 0x80000000ull) ? DRX_EINVAL : DRX_OK;
 }
-
 static int check_shard(const DrxShard *sh) {
   if (!sh || sh->world < 1 || sh->world > DRX_MAX_WORLD || sh->rank < 0 || sh->rank >= sh->world || sh->items_per_rank < 1 || sh->n_items < 1 ||
       sh->n_users_local < 1)
     return DRX_EINVAL;
-  if ((uint64_t)sh->world * 2 * sh->items_per_rank + (uint64_t)sh->n_users_local + 1 >= 0xFFFFFFFFull) return DRX_EINVAL;
+  if ((long long)sh->items_per_rank * sh->world < (long long)sh->n_items) return DRX_EINVAL;
+  if ((uint64_t)2 * sh->n_items + (uint64_t)sh->n_users_local + 1 >= 0xFFFFFFFFull) return DRX_EINVAL;
+  const ShardGeo g = geo_of(*sh, 4);
+  if (g.shift > 26 || ((uint64_t)sh->world << g.shift) >= 0x80000000ull) return DRX_EINVAL;
   return DRX_OK;
 }
 
-template <class Policy>
-static int run_segreduce(const DrxCdaeParams &P, const SegBufs &sb, const Policy &pol, hipStream_t st) {
-  if (sb.T == 0) return DRX_OK;
-  DRX_HIP(hipMemsetAsync(sb.n_span, 0, 2 * sizeof(uint32_t), st));
-#define CALL(G, J)                                                                                                     \
-  {                                                                                                                    \
-    const int gpb = kBlock / G;                                                                                        \
-    hipLaunchKernelGGL((k_seg_reduce<G, J, Policy>), dim3((sb.n_chunks + SEG_GPB(G) - 1) / SEG_GPB(G)), dim3(kBlock), 0, st, sb, pol); \
-    hipLaunchKernelGGL((k_span_short<G, J, Policy>), dim3(1024), dim3(kBlock), 0, st, sb, pol);                        \
-    const size_t lds = ((size_t)(kFixBlock / G) * (P.ld + 1)) * 4;                                                     \
-    if (lds > 48 * 1024)                                                                                               \
-      DRX_HIP(hipFuncSetAttribute((const void *)k_span_long<G, J, Policy>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                  (int)lds));                                                                          \
-    hipLaunchKernelGGL((k_span_long<G, J, Policy>), dim3(256), dim3(kFixBlock), lds, st, sb, pol);                     \
-  }
-  DRX_DISPATCH_GEOM(P.ld, CALL);
-#undef CALL
-  DRX_LAUNCH_CHECK();
+static int check_local_params(const DrxCdaeParams *p, const DrxShard *sh) {
+  if (!p || !p->W || !p->W2T || !p->V || !p->b || !p->b2) return DRX_EINVAL;
+  if (p->k < 1 || p->k > DRX_MAX_K || p->ld < p->k || (p->ld & 3) || p->ld > DRX_MAX_K) return DRX_EINVAL;
+  if (p->n_items != sh->items_per_rank || p->n_users != sh->n_users_local) return DRX_EINVAL;       // the LOCAL tables
   return DRX_OK;
 }
 
@@ -495,167 +696,223 @@ using namespace drx;
 
 extern "C" {
 
-size_t drx_shard_scratch_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32_t n_touches) {
-  if (!p || check_shard(sh) || n_touches < 0) return 0;
+size_t drx_shard_prep_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32_t B, int32_t n_touch_slots) {
+  if (!p || check_shard(sh) || B < 1 || n_touch_slots < 0) return 0;
   Carver cv(nullptr, 0);
-  (void)seg_layout(cv, p->ld, n_touches, key_bits(*sh));
-  (void)owner_table(cv, *sh);
+  (void)shard_prep_layout(cv, *p, *sh, B, n_touch_slots);
   return align_up(cv.off, 256) + 256;
 }
 
-int drx_shard_touches(const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt, uint32_t *keys, uint32_t *vals,
-                      uint32_t *b_of_pos, void *stream) {
-  if (check_shard(sh) || !hist || !hist->indptr || !hist->indices || !bt || !bt->uid || !bt->iid || !bt->keep_off ||
-      !keys || !vals || !b_of_pos || bt->B < 1)
-    return DRX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int T = bt->n_touch_slots + 2 * bt->B;
-  DRX_HIP(hipMemsetAsync(keys, 0xFF, (size_t)T * 4, st));
-  DRX_HIP(hipMemsetAsync(b_of_pos, 0, (size_t)T * 4, st));
-  hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, st, vals, T);
-  const int gpb = kBlock / 16;
-  hipLaunchKernelGGL(k_shard_touches, dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *sh, *hist, *bt,
-                     q_threshold(bt->q), keys, vals, b_of_pos);
-  DRX_LAUNCH_CHECK();
+size_t drx_shard_work_bytes(const DrxShard *sh) {
+  if (check_shard(sh)) return 0;
+  const ShardGeo g = geo_of(*sh, 4);
+  return align_up((size_t)g.n_words * 32, 256) + align_up((size_t)g.n_tiles * sizeof(int), 256) + 256;
+}
+
+int drx_shard_prep_layout(const DrxCdaeParams *p, const DrxShard *sh, int32_t B, int32_t n_touch_slots, size_t *out4) {
+  if (!p || check_shard(sh) || B < 1 || n_touch_slots < 0 || !out4) return DRX_EINVAL;
+  Carver cv(nullptr, 0);
+  const ShardPrepBufs L = shard_prep_layout(cv, *p, *sh, B, n_touch_slots);
+  out4[0] = L.off_uniq; out4[1] = L.off_counts; out4[2] = L.uniq_cap; out4[3] = L.result_bytes;
   return DRX_OK;
 }
 
-int drx_shard_index(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *keys, const uint32_t *vals, int32_t T,
-                    uint32_t *keys_s, uint32_t *vals_s, int32_t *slot_sorted, uint32_t *slot_of_pos, uint32_t *uniq_keys,
-                    int32_t *bounds, void *scratch, size_t scratch_bytes, void *stream) {
-  if (!p || check_shard(sh) || !keys || !vals || !keys_s || !vals_s || !slot_sorted || !slot_of_pos || !uniq_keys ||
-      !bounds || !scratch || T < 1)
-    return DRX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  Carver cv(scratch, scratch_bytes);
-  SegLayout L = seg_layout(cv, p->ld, T, key_bits(*sh));
-  if (!cv.ok()) return DRX_ESCRATCH;
-  int rc = sort_pairs(L.sort_temp, L.sort_bytes, keys, keys_s, vals, vals_s, (size_t)T, key_bits(*sh), st);
+int drx_shard_prepare(const DrxCdaeParams *p, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt, void *prepared,
+                      size_t prepared_bytes, void *work, size_t work_bytes, void *stream) {
+  if (check_shard(sh)) return DRX_EINVAL;
+  int rc = check_local_params(p, sh);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_head_flags, dim3(1024), dim3(256), 0, st, keys_s, T, L.flags);
-  const int scan_rc = scan_i32(L.scan_temp, L.scan_bytes, L.flags, slot_sorted, (size_t)T, true, st);
-  if (scan_rc) return scan_rc;
-  hipLaunchKernelGGL(k_slots, dim3(1024), dim3(256), 0, st, keys_s, vals_s, T, slot_sorted, slot_of_pos, uniq_keys);
-  hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(256), 0, st, keys_s, slot_sorted, T, *sh, bounds);
-  DRX_LAUNCH_CHECK();
-  return sh->world + 2 <= 256 ? DRX_OK : DRX_EINVAL;
-}
-
-int drx_shard_gather_rows(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *req_keys, int32_t n, float *rows,
-                          float *b2_out, void *stream) {
-  if (!p || check_shard(sh) || n < 0 || (n > 0 && (!req_keys || !rows || !b2_out))) return DRX_EINVAL;
-  if (n == 0) return DRX_OK;
+  if (!hist || !hist->indptr || !hist->indices || !bt || !bt->uid || !bt->iid || !bt->keep_off || bt->B < 1 || !prepared || !work ||
+      bt->q < 0.f || bt->q >= 1.f)
+    return DRX_EINVAL;
+  if (((uintptr_t)prepared | (uintptr_t)work) & 255) return DRX_EINVAL;
+  if (work_bytes < drx_shard_work_bytes(sh)) return DRX_ESCRATCH;
   hipStream_t st = (hipStream_t)stream;
-#define CALL(G, J)                                                                                              \
-  {                                                                                                             \
-    const int gpb = kBlock / G;                                                                                 \
-    int blocks = (n + gpb - 1) / gpb;                                                                           \
-    if (blocks > 4096) blocks = 4096;                                                                           \
-    hipLaunchKernelGGL((k_shard_gather_rows<G, J>), dim3(blocks), dim3(kBlock), 0, st, *p, *sh, req_keys, n, rows, b2_out); \
-  }
-  DRX_DISPATCH_GEOM(p->ld, CALL);
-#undef CALL
+  Carver cp(prepared, prepared_bytes);
+  const ShardPrepBufs L = shard_prep_layout(cp, *p, *sh, bt->B, bt->n_touch_slots);
+  if (!cp.ok()) return DRX_ESCRATCH;
+  const ShardGeo g = geo_of(*sh, p->ld);
+  uint8_t *present = (uint8_t *)work;
+  int *tile_sum = (int *)((char *)work + align_up((size_t)g.n_words * 32, 256));
+  const DrxCdaeParams pk = key_params(*p, *sh);
+  rc = prepare_impl(&pk, hist, bt, L.R, st, true, TouchPresence{present, g.ipr, g.shift});
+  if (rc) return rc;
+  if (p->ld <= 16) order_by_degree(bt, L.R, st, true);
+  hipLaunchKernelGGL(k_shard_pack, dim3(g.n_tiles), dim3(kTileWords), 0, st, present, L.ptab, tile_sum);
+  hipLaunchKernelGGL(k_shard_emit, dim3(g.n_tiles), dim3(kTileWords), 0, st, L.ptab, tile_sum, g, L.first, L.foff, L.counts, L.uniq);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
 
-int drx_shard_fwd_bwd(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const uint32_t *slot_of_pos,
-                      const float *rows_cache, const float *b2_cache, int32_t b_norm, int32_t loss_kind, float *dz1, float *g2,
-                      float *dz2, float *lossb, void *stream) {
-  if (!p || !hist || !bt || !bt->uid || !bt->iid || !bt->y || !bt->keep_off || !slot_of_pos || !rows_cache || !b2_cache ||
-      !dz1 || !g2 || !dz2 || !lossb || b_norm < 1)
-    return DRX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  ShardFwd F{slot_of_pos, rows_cache, b2_cache, dz1, g2, dz2, lossb, 1.0f / (float)b_norm};
-  const float scale = 1.0f / (1.0f - bt->q);
-#define CALL(G, J)                                                                                               \
-  {                                                                                                              \
-    const int gpb = kBlock / G;                                                                                  \
-    hipLaunchKernelGGL((k_shard_fwd_bwd<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *hist, *bt, scale, \
-                       loss_kind, F);                                                                            \
-  }
-  DRX_DISPATCH_GEOM(p->ld, CALL);
-#undef CALL
-  DRX_LAUNCH_CHECK();
-  return DRX_OK;
+size_t drx_shard_owner_table_bytes(const DrxShard *sh, int32_t n_segments) {
+  if (check_shard(sh) || n_segments < 1 || n_segments > DRX_MAX_WORLD * DRX_MAX_MICRO) return 0;
+  return align_up((size_t)2 * sh->items_per_rank * n_segments * sizeof(uint32_t), 256);
 }
 
-int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, float q,
-                     const uint32_t *keys_s, const uint32_t *vals_s, const int32_t *slot_sorted, const uint32_t *b_of_pos,
-                     int32_t T, const float *dz1, const float *g2, const float *dz2, float *gc, float *gb2c, void *scratch,
-                     size_t scratch_bytes, void *stream) {
-  if (!p || !opt || check_shard(sh) || !keys_s || !vals_s || !slot_sorted || !b_of_pos || !dz1 || !g2 || !dz2 || !gc ||
-      !gb2c || !scratch || T < 1 || b_norm < 1)
-    return DRX_EINVAL;
-  Carver cv(scratch, scratch_bytes);
-  SegLayout L = seg_layout(cv, p->ld, T, key_bits(*sh));
-  if (!cv.ok()) return DRX_ESCRATCH;
-  L.sb.keys_s = keys_s; L.sb.vals_s = vals_s;
-  LocalPolicy pol{*p, *opt, *sh, b_norm, 1.0f / (1.0f - q), dz1, (long long)(g2 - dz1), dz2, b_of_pos, slot_sorted, gc, gb2c};
-  return run_segreduce(*p, L.sb, pol, (hipStream_t)stream);
-}
-
-int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, int32_t n_segments,
-                    void *scratch, size_t scratch_bytes, void *stream) {
-  if (!p || !opt || check_shard(sh) || n < 0 || b_norm < 1 || !scratch || !recv_counts) return DRX_EINVAL;
+int drx_shard_owner_index(const DrxShard *sh, const uint32_t *recv_keys, int32_t n, const int32_t *recv_counts, int32_t n_segments,
+                          void *table, size_t table_bytes, void *stream) {
+  if (check_shard(sh) || !recv_keys || !recv_counts || !table || n < 1) return DRX_EINVAL;
   if (n_segments < sh->world || n_segments % sh->world || n_segments > sh->world * DRX_MAX_MICRO) return DRX_EINVAL;
-  if (n == 0) return DRX_OK;
-  if (!recv_keys || !recv_rows || !recv_b2) return DRX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
+  if (table_bytes < drx_shard_owner_table_bytes(sh, n_segments)) return DRX_ESCRATCH;
   SegOff so{};
-  so.n_seg = n_segments;
-  for (int s = 0; s < n_segments; ++s) {
-    if (recv_counts[s] < 0) return DRX_EINVAL;
-    so.off[s + 1] = so.off[s] + recv_counts[s];
+  const ShardGeo g = geo_of(*sh, 4);
+  const int rc = seg_off(g, recv_counts, n_segments, n, so);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  DRX_HIP(hipMemsetAsync(table, 0xFF, (size_t)2 * sh->items_per_rank * n_segments * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_owner_scatter, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, g, so, recv_keys, n,
+                     (uint32_t *)table);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_shard_gather_rows(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *recv_keys, int32_t n, const int32_t *recv_counts,
+                          int32_t n_segments, float *out, void *stream) {
+  if (check_shard(sh)) return DRX_EINVAL;
+  int rc = check_local_params(p, sh);
+  if (rc) return rc;
+  if (!recv_keys || !recv_counts || !out || n < 1 || n_segments < 1 || n_segments > DRX_MAX_WORLD * DRX_MAX_MICRO) return DRX_EINVAL;
+  SegOff so{};
+  const ShardGeo g = geo_of(*sh, p->ld);
+  rc = seg_off(g, recv_counts, n_segments, n, so);
+  if (rc) return rc;
+  if (g.bypass && sh->world == 1) return DRX_OK;               // every request is the rank's own: nothing to gather
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(G, J)                                                                                                   \
+  {                                                                                                                  \
+    const int per = (kBlock / G) * (J == 1 ? 4 : 2);                                                                 \
+    int blocks = (n + per - 1) / per;                                                                                \
+    if (blocks > 16384) blocks = 16384;                                                                              \
+    hipLaunchKernelGGL((k_shard_gather_rows<G, J>), dim3(blocks), dim3(kBlock), 0, st, *p, g, so, recv_keys, n, out); \
   }
-  if (so.off[n_segments] != n) return DRX_EINVAL;
+  DRX_DISPATCH_GEOM(p->ld, CALL);
+#undef CALL
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+size_t drx_shard_step_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots) {
+  if (!p || B < 1 || n_touch_slots < 0) return 0;
+  Carver cv(nullptr, 0);
+  (void)shard_step_layout(cv, p->ld, B, n_touch_slots);
+  return align_up(cv.off, 256) + 256;
+}
+
+int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt,
+                         const void *prepared, size_t prepared_bytes, const float *rows_cache, float *grad_send, int32_t b_norm,
+                         int32_t loss_kind, void *scratch, size_t scratch_bytes, void *const *events, void *stream) {
+  if (check_shard(sh)) return DRX_EINVAL;
+  int rc = check_local_params(p, sh);
+  if (rc) return rc;
+  if (!opt || !hist || !hist->indptr || !hist->indices || !bt || !bt->uid || !bt->iid || !bt->y || !bt->keep_off || bt->B < 1 ||
+      !prepared || !rows_cache || !grad_send || !scratch || b_norm < 1)
+    return DRX_EINVAL;
+  if (opt->kind != DRX_OPT_ADAM && opt->kind != DRX_OPT_ADAGRAD && opt->kind != DRX_OPT_ROWWISE_ADAGRAD) return DRX_EINVAL;
+  for (int i = 0; i < 5; ++i)
+    if (!opt->s1[i] || (opt->kind == DRX_OPT_ADAM && !opt->s2[i])) return DRX_EINVAL;
+  if (check_bypass(sh, p->ld)) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  Carver cp(const_cast<void *>(prepared), prepared_bytes);
+  const ShardPrepBufs L = shard_prep_layout(cp, *p, *sh, bt->B, bt->n_touch_slots);
+  if (!cp.ok()) return DRX_ESCRATCH;
   Carver cv(scratch, scratch_bytes);
-  uint32_t *tab = owner_table(cv, *sh);
+  const ShardStepBufs B = shard_step_layout(cv, p->ld, bt->B, bt->n_touch_slots);
   if (!cv.ok()) return DRX_ESCRATCH;
-  DRX_HIP(hipMemsetAsync(tab, 0xFF, (size_t)2 * sh->items_per_rank * n_segments * 4, st));
-  hipLaunchKernelGGL(k_owner_scatter, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, *sh, so, recv_keys, n, tab);
-  OwnerPolicy pol{*p, *opt, *sh, b_norm, recv_rows, recv_b2};
+  const ShardGeo g = geo_of(*sh, p->ld);
+  const float scale = 1.0f / (1.0f - bt->q);
+  const uint32_t qthr = q_threshold(bt->q);
+  const bool marks = p->ld > 16;                               // (prepare_impl: rows of <= 16 floats carry no sole-toucher marks)
+  const ShardXfer X{L.ptab, L.first, L.foff, g.shift, p->ld};
+  ShardStep S{B.dz1, B.g2, B.dz2, B.lossb, marks ? L.R.solo_v : nullptr, marks ? L.R.solo_o : nullptr, L.R.order, rows_cache, grad_send,
+              X, g.ipr, b_norm, sh->n_items, g.bypass ? g.rank : -1};
+  SegBufs SB{L.R.keys_s, L.R.vals_s, B.phead, B.ptail, B.phs, B.pts, nullptr, nullptr, nullptr, nullptr, B.T, B.n_chunks, p->ld, nullptr};
+  PlanBufs PB{B.pblock, B.pbs};
+  const int rows_per_block = (bt->B + B.n_bpart - 1) / B.n_bpart;
+  const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
+  BiasArgs BA{B.dz1, B.bpart, B.lossb, B.lossb /* non-null: the loss partials are always taken */, bt->B, n_bpart, rows_per_block};
+  const bool long_segments = (int64_t)B.T > 8 * ((int64_t)2 * sh->n_items + sh->n_users_local);
+#define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
+#define REDUCE_AND_SPANS(G, J, KIND)                                                                                   \
+  {                                                                                                                    \
+    using POLT = LocalPolicyT<KIND>;                                                                                   \
+    POLT polk{*p, *opt, b_norm, sh->n_items, g.ipr, scale, B.dz1, (long long)(B.g2 - B.dz1), B.dz2, grad_send, X};    \
+    BiasPartialExtra<G, J> bpx{p->ld, BA};                                                                             \
+    ShardBiasExtra<G, J> bfx{p->ld, sh->world, BA, grad_send, X};                                                      \
+    const int cpb = kSegBlock / G;                                                                                     \
+    const dim3 rgrid(n_bpart + (B.n_chunks + cpb - 1) / cpb);                                                          \
+    const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
+    const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
+    if (long_segments)                                                                                                 \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \
+                         L.R.plan, polk, n_bpart, bpx);                                                                \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \
+                         L.R.plan, polk, n_bpart, bpx);                                                                \
+    EV(2);                                                                                                             \
+    if (lds_b > 48 * 1024)                                                                                             \
+      DRX_HIP(hipFuncSetAttribute((const void *)k_span_planned<G, J, POLT, ShardBiasExtra<G, J>>,                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                            \
+    hipLaunchKernelGGL((k_span_planned<G, J, POLT, ShardBiasExtra<G, J>>), dim3(kLongBlocks + kShortBlocks + 1), dim3(kFixBlock),   \
+                       lds_b, st, SB, PB, L.R.plan, polk, kLongBlocks, kShortBlocks, bfx);                             \
+    EV(3);                                                                                                             \
+  }
 #define CALL(G, J)                                                                                                     \
   {                                                                                                                    \
     const int gpb = kBlock / G;                                                                                        \
+    EV(0);                                                                                                             \
+    if (opt->kind == DRX_OPT_ADAGRAD) {                                                                                \
+      hipLaunchKernelGGL((k_shard_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, \
+                         *bt, scale, qthr, loss_kind, S);                                                              \
+      EV(1);                                                                                                           \
+      REDUCE_AND_SPANS(G, J, DRX_OPT_ADAGRAD);                                                                         \
+    } else {                                                                                                           \
+      hipLaunchKernelGGL((k_shard_fwd_bwd<G, J, -1>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt, scale, \
+                         qthr, loss_kind, S);                                                                          \
+      EV(1);                                                                                                           \
+      REDUCE_AND_SPANS(G, J, -1);                                                                                      \
+    }                                                                                                                  \
+  }
+  DRX_DISPATCH_GEOM(p->ld, CALL);
+#undef CALL
+#undef REDUCE_AND_SPANS
+#undef EV
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
+                    const float *grad_recv, int32_t n, const int32_t *recv_counts, int32_t n_segments, const void *table,
+                    const float *const *own_grad, const int64_t *own_off, float *loss_out, void *stream) {
+  if (check_shard(sh)) return DRX_EINVAL;
+  int rc = check_local_params(p, sh);
+  if (rc) return rc;
+  if (!opt || n < 1 || b_norm < 1 || !recv_counts || !recv_keys || !grad_recv || !table) return DRX_EINVAL;
+  if (n_segments < sh->world || n_segments % sh->world || n_segments > sh->world * DRX_MAX_MICRO) return DRX_EINVAL;
+  SegOff so{};
+  const ShardGeo g = geo_of(*sh, p->ld);
+  rc = seg_off(g, recv_counts, n_segments, n, so);
+  if (rc) return rc;
+  if (g.bypass) {                                  // the chunks this rank "sent" to itself: still in its own gradient buffers
+    if (!own_grad || !own_off) return DRX_EINVAL;
+    for (int m = 0; m < n_segments / sh->world; ++m) {
+      if (!own_grad[m] || own_off[m] < 0 || own_off[m] >= 0xFFFFFFFFll) return DRX_EINVAL;
+      so.own_buf[m] = own_grad[m];
+      so.own_off[m] = (uint32_t)own_off[m];
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(G, J)                                                                                                     \
+  {                                                                                                                    \
+    const int gpb = (kBlock / G) * (J == 1 ? 4 : 2);                                                                   \
     int blocks = (n + gpb - 1) / gpb;                                                                                  \
-    if (blocks > 8192) blocks = 8192;                                                                                  \
-    hipLaunchKernelGGL((k_owner_apply<G, J>), dim3(blocks), dim3(kBlock), 0, st, pol, so, recv_keys, n, tab);          \
+    if (blocks > 16384) blocks = 16384;                                                                                \
+    if (opt->kind == DRX_OPT_ADAGRAD)                                                                                  \
+      hipLaunchKernelGGL((k_shard_apply<G, J, DRX_OPT_ADAGRAD>), dim3(blocks + 1), dim3(kBlock), 0, st, *p, *opt, g, b_norm, so,    \
+                         recv_keys, n, (const uint32_t *)table, grad_recv, blocks, loss_out);                          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_shard_apply<G, J, -1>), dim3(blocks + 1), dim3(kBlock), 0, st, *p, *opt, g, b_norm, so, recv_keys, n, \
+                         (const uint32_t *)table, grad_recv, blocks, loss_out);                                        \
   }
-  DRX_DISPATCH_GEOM(p->ld, CALL);
-#undef CALL
-  DRX_LAUNCH_CHECK();
-  return DRX_OK;
-}
-
-int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *lossb, int32_t B, float *out, void *scratch,
-                        size_t scratch_bytes, void *stream) {
-  if (!p || !dz1 || !lossb || !out || !scratch || B < 1) return DRX_EINVAL;
-  if (scratch_bytes < (size_t)256 * (p->ld + 1) * 4) return DRX_ESCRATCH;
-  hipStream_t st = (hipStream_t)stream;
-  float *part = (float *)scratch;
-  float *loss_part = part + (size_t)256 * p->ld;
-  const int rows_per_block = (B + 255) / 256;
-  const int n_part = (B + rows_per_block - 1) / rows_per_block;
-#define CALL(G, J)                                                                                                  \
-  {                                                                                                                 \
-    const int gpb = kBlock / G;                                                                                     \
-    hipLaunchKernelGGL((k_colsum_partial<G, J>), dim3(n_part), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, B, dz1, \
-                       part, rows_per_block, lossb, loss_part);                                                     \
-    hipLaunchKernelGGL((k_colsum_final<G, J>), dim3(1), dim3(kBlock), (size_t)gpb * p->ld * 4, st, p->ld, part, n_part,  \
-                       loss_part, B, out);                                                                          \
-  }
-  DRX_DISPATCH_GEOM(p->ld, CALL);
-#undef CALL
-  DRX_LAUNCH_CHECK();
-  return DRX_OK;
-}
-
-int drx_shard_bias_apply(const DrxCdaeParams *p, const DrxOptim *opt, int32_t b_norm, const float *grad, void *stream) {
-  if (!p || !opt || !grad || b_norm < 1) return DRX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-#define CALL(G, J) { hipLaunchKernelGGL((k_bias_apply<G, J>), dim3(1), dim3(kBlock), 0, st, *p, *opt, b_norm, grad); }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL
   DRX_LAUNCH_CHECK();

@@ -1,27 +1,32 @@
-"""Row-sharded CDAE across the GPUs of one node: one process per GPU, `torch.distributed` over
-RCCL/xGMI (backend "nccl"); the same orchestration runs over gloo on CPU tensors in the world-size-2 tests, with the
-per-rank device work swapped for a NumPy statement (tests/dist_ops_numpy.py).
+"""Row-sharded CDAE across the GPUs of one node (BASELINE.json configuration 4): one process per GPU,
+`torch.distributed` over RCCL/xGMI (backend "nccl"); the same orchestration runs over gloo on CPU tensors in the world-size-2 tests,
+with the per-rank device work swapped for a NumPy statement (tests/dist_ops_numpy.py).
 
 Sharding
   * users (V rows + optimizer state, their positives CSR, and the triples sampled for them): contiguous uid ranges —
     the 5 GB table of the 10M-user configuration never leaves its GPU and needs no exchange;
-  * item rows (W, W2T, b2 + state): contiguous item ranges of `ipr = ceil(N / world)` rows.
-  * hidden bias b (K floats): replicated, its gradient all-reduced.
+  * item rows (W, W2T, b2 + state): contiguous item ranges of `ipr = ceil(N / world)` rows;
+  * hidden bias b (K floats): replicated; every rank adds the same `world` gradient rows in rank order (they travel as the
+    sentinel rows of the gradient exchange: no all-reduce).
 
-One step (every rank, its own B triples; losses/L2 are normalised by the GLOBAL batch so the step equals a single-GPU
-step on the concatenated batch):
-  1. touches of the local batch -> stable sort -> DISTINCT row keys (owner-major key space: a rank's distinct keys are
-     contiguous per owner) -> per-owner counts                                       [drx_shard_touches / _index]
-  2. all-to-all counts, all-to-all(v) of the requested keys                          [xGMI, 4 B per distinct row]
-  3. owners gather the requested rows; all-to-all(v) of rows (+ output biases)       [xGMI, 4K B per distinct row]
-  4. forward/backward against the row cache                                          [drx_shard_fwd_bwd]
-  5. local segmented reduction: ONE gradient row per distinct item row (hot Zipf rows are merged before they travel);
-     V rows are updated in place                                                     [drx_shard_reduce]
-  6. all-to-all(v) of the gradient rows back to the owners                           [xGMI, 4K B per distinct row]
-  7. owners sum duplicates across ranks in rank order and apply sparse Adagrad/Adam  [drx_shard_apply]
-  8. all-reduce of the K-float bias gradient (+ loss), dense update of b.
-Direct all-to-all drives all 7 xGMI links of a GPU at once (ring all-reduce would be bound by one link), and only
-distinct rows travel.
+One step (every rank, its own B triples; losses / L2 are normalised by the GLOBAL batch so the step equals a single-GPU step on
+the concatenated batch).  Parameter-independent, run ahead of the step (ShardedPipeline: on a side stream, 1 - 3 steps early):
+  1. prepare: sorted touch list + span plan + sole-toucher marks + launch order (the single-GPU step's preparation), and — from a
+     presence map of the wire keys, without waiting for the sort — the batch's DISTINCT item rows, their places in the exchange
+     buffers and the per-owner counts                                                                        [drx_shard_prepare]
+  2. all-to-all of the counts (results to pinned host memory), all-to-all(v) of the keys (4 B per distinct row); the owner enters
+     the keys it received in its direct-address table                                                        [drx_shard_owner_index]
+Parameter-dependent, on the training stream:
+  3. owners gather the requested rows + output biases into ONE float buffer; all-to-all(v)                   [drx_shard_gather_rows]
+  4. forward / backward against the received rows, planned segmented reduction: ONE gradient row per distinct item row (hot Zipf
+     rows are merged before they travel), V rows updated in place, bias gradient into the sentinel rows      [drx_shard_step_local]
+  5. all-to-all(v) of the gradient buffer back to the owners
+  6. owners sum what the ranks sent per row in rank order and apply the sparse optimizer; bias update        [drx_shard_apply]
+Four collectives per step (two of them run ahead), four library calls on the training stream's critical path.  Direct all-to-all
+drives all 7 xGMI links of a GPU at once (a ring would be bound by one link), and only distinct rows travel.
+
+Exchange buffer geometry (include/drx.h): per peer, in rank order, n rows of ld floats then n scalars padded to 32 floats;
+n = distinct rows + 1 sentinel.
 """
 import ctypes as C
 import math
@@ -31,21 +36,40 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+KEY_NONE = 0xFFFFFFFF
+
 
 def items_per_rank(n_items, world):
     return (n_items + world - 1) // world
 
 
-def item_key(n, ipr, is_out):
-    """owner-major row key of item n (numpy / python ints)"""
+def wire_shift(ipr):
+    """log2 of the wire-key span of one owner: the smallest power of two >= max(2 * ipr, 8192) (include/drx.h)."""
+    s = 13
+    while (1 << s) < 2 * ipr:
+        s += 1
+    return s
+
+
+def wire_key(n, ipr, is_out):
+    """owner-major wire key of item n's W (is_out False) or W2T row (python ints)"""
     o = n // ipr
-    return o * 2 * ipr + (ipr if is_out else 0) + (n - o * ipr)
+    return (o << wire_shift(ipr)) + (ipr if is_out else 0) + (n - o * ipr)
+
+
+def pad32(n):
+    return (int(n) + 31) // 32 * 32
+
+
+def chunk_floats(counts, ld):
+    """float split sizes of an exchange buffer whose peers hold `counts` rows (sentinels included)"""
+    return [int(c) * ld + pad32(c) for c in counts]
 
 
 class HipShardOps:
     """Per-rank device work through the C ABI (include/drx.h, drx_shard_*)."""
 
-    def __init__(self, n_users_local, n_items, k, rank, world, device, optimizer, lr, reg):
+    def __init__(self, n_users_local, n_items, k, rank, world, device, optimizer, lr, reg, self_bypass=True):
         from . import _lib
         from .engine import CdaeEngine
         self._lib = _lib
@@ -56,109 +80,95 @@ class HipShardOps:
         self.engine.init_optimizer(optimizer, lr, reg)
         self.device = self.engine.device
         self.ld = self.engine.ld
-        self.shard = _lib.Shard(world, rank, n_items, self.ipr, n_users_local)
-        self._scratch = {}
-
-    # -- helpers
-    def _sc(self, n, stage='step'):
-        """Scratch of one stage: `index` may run ahead on a side stream while reduce/apply of an earlier batch run on the
-        training stream, so the two never share a buffer."""
-        need = self.L.drx_shard_scratch_bytes(C.byref(self.engine._params), C.byref(self.shard), int(n))
-        cur = self._scratch.get(stage)
-        if cur is None or cur.numel() < need:
-            cur = self._scratch[stage] = torch.empty(int(need * 1.3) + 4096, dtype=torch.uint8, device=self.device)
-        return cur
-
-    def _e(self, *shape, dtype=torch.float32):
-        return torch.empty(*shape, dtype=dtype, device=self.device)
+        # the rank's own rows never pass through a collective (include/drx.h DRX_SHARD_SELF_BYPASS); off: every row travels (a
+        # measurement aid: at world 1 it sends the whole exchange through the communicator)
+        self.self_bypass = bool(self_bypass) and self.ipr * self.ld < (1 << 31)
+        self.shard = _lib.Shard(world, rank, n_items, self.ipr, n_users_local, _lib.SHARD_SELF_BYPASS if self.self_bypass else 0)
+        wb = int(self.L.drx_shard_work_bytes(C.byref(self.shard)))
+        if wb <= 0:
+            raise _lib.DrxError('drx_shard_work_bytes: invalid shard description')
+        self._work = torch.zeros(wb, dtype=torch.uint8, device=self.device)      # the presence map: zero between preparations
+        self._scratch = None
+        self._loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._tables = {}
 
     def _stream(self):
         return self._lib.stream_ptr(self.device)
 
-    # -- ops
-    def touches(self, bt):
-        T = bt.n_touch_slots + 2 * bt.B
-        keys, vals, bpos = (self._e(T, dtype=torch.int32) for _ in range(3))
-        p = self._lib.ptr
-        self._lib.check(self.L.drx_shard_touches(C.byref(self.shard), C.byref(self.engine._hist), C.byref(bt), p(keys), p(vals),
-                                                 p(bpos), self._stream()), 'drx_shard_touches')
-        return keys, vals, bpos
+    def _e(self, n, dtype=torch.float32):
+        return torch.empty(int(n), dtype=dtype, device=self.device)
 
-    def index(self, keys, vals):
-        T = keys.numel()
-        ks, vs, ss, sp, uk = (self._e(T, dtype=torch.int32) for _ in range(5))
-        bounds = self._e(self.world + 2, dtype=torch.int32)
-        sc = self._sc(T, 'prepare')
-        p = self._lib.ptr
-        self._lib.check(self.L.drx_shard_index(C.byref(self.engine._params), C.byref(self.shard), p(keys), p(vals), T, p(ks),
-                                               p(vs), p(ss), p(sp), p(uk), p(bounds), p(sc), sc.numel(), self._stream()),
-                        'drx_shard_index')
-        host = torch.empty(self.world + 2, dtype=torch.int32, pin_memory=True)
-        host.copy_(bounds, non_blocking=True)          # read by bounds_of() after the stream (or its event) is reached
-        return {'keys_s': ks, 'vals_s': vs, 'slot_sorted': ss, 'slot_of_pos': sp, 'uniq_keys': uk, 'bounds_dev': bounds,
-                'bounds_host': host}
+    # -- parameter-independent
+    def prepare(self, bt, out=None):
+        """drx_shard_prepare on the CURRENT stream; returns the views a step and the exchanges need.  `out`: a buffer to reuse."""
+        P, sh, lib = self.engine._params, self.shard, self.L
+        need = int(lib.drx_shard_prep_bytes(C.byref(P), C.byref(sh), bt.B, bt.n_touch_slots))
+        if out is None or out.numel() < need:
+            out = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+        lay = (C.c_size_t * 4)()
+        self._lib.check(lib.drx_shard_prep_layout(C.byref(P), C.byref(sh), bt.B, bt.n_touch_slots, lay), 'drx_shard_prep_layout')
+        self._lib.check(lib.drx_shard_prepare(C.byref(P), C.byref(sh), C.byref(self.engine._hist), C.byref(bt), self._lib.ptr(out),
+                                              out.numel(), self._lib.ptr(self._work), self._work.numel(), self._stream()),
+                        'drx_shard_prepare')
+        uniq = out[lay[0]:lay[0] + 4 * lay[2]].view(torch.int32)
+        counts = out[lay[1]:lay[1] + 8 * self.world].view(torch.int64)
+        return {'buf': out, 'uniq': uniq, 'counts_dev': counts}
 
-    @staticmethod
-    def bounds_of(idx, event=None):
-        if 'bounds' not in idx:
-            (event.synchronize() if event is not None else torch.cuda.current_stream().synchronize())
-            idx['bounds'] = idx['bounds_host'].tolist()
-        return idx['bounds']
+    def owner_index(self, req, recv_counts, slot=0):
+        """The owner's table of the keys it received (parameter-independent; one table per in-flight step `slot`)."""
+        n_seg = len(recv_counts)
+        nb = int(self.L.drx_shard_owner_table_bytes(C.byref(self.shard), n_seg))
+        tab = self._tables.get(slot)
+        if tab is None or tab.numel() < nb:
+            tab = self._tables[slot] = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        cnt = (C.c_int32 * n_seg)(*[int(c) for c in recv_counts])
+        self._lib.check(self.L.drx_shard_owner_index(C.byref(self.shard), self._lib.ptr(req), req.numel(), cnt, n_seg,
+                                                     self._lib.ptr(tab), tab.numel(), self._stream()), 'drx_shard_owner_index')
+        return tab
 
-    def gather_rows(self, req):
-        n = req.numel()
-        rows, b2v = self._e(max(n, 1), self.ld), self._e(max(n, 1))
-        p = self._lib.ptr
-        self._lib.check(self.L.drx_shard_gather_rows(C.byref(self.engine._params), C.byref(self.shard), p(req), n, p(rows),
-                                                     p(b2v), self._stream()), 'drx_shard_gather_rows')
-        return rows[:n], b2v[:n]
+    # -- parameter-dependent
+    def xsplits(self, counts):
+        """float split sizes of an exchange among the peers that hold `counts` rows: nothing travels to the rank itself when its
+        own rows bypass the collectives"""
+        f = chunk_floats(counts, self.ld)
+        if self.self_bypass:
+            f = [0 if (i % self.world) == self.rank else x for i, x in enumerate(f)]
+        return f
 
-    def fwd_bwd(self, bt, slot_of_pos, rows_cache, b2_cache, b_norm, loss_kind):
-        """Returns the per-sample gradient buffers of this (micro-)batch: the context reduce() and bias_grad() consume."""
-        B = bt.B
-        ctx = {'dz1': self._e(B, self.ld), 'g2': self._e(B, self.ld), 'dz2': self._e(B), 'lossb': self._e(B)}
-        if rows_cache.numel() == 0:
-            rows_cache, b2_cache = self._e(1, self.ld), self._e(1)
-        p = self._lib.ptr
-        self._lib.check(self.L.drx_shard_fwd_bwd(C.byref(self.engine._params), C.byref(self.engine._hist), C.byref(bt),
-                                                 p(slot_of_pos), p(rows_cache), p(b2_cache), b_norm, loss_kind, p(ctx['dz1']),
-                                                 p(ctx['g2']), p(ctx['dz2']), p(ctx['lossb']), self._stream()), 'drx_shard_fwd_bwd')
-        return ctx
-
-    def reduce(self, idx, bpos, q_item, b_norm, q, opt, ctx):
-        T = idx['keys_s'].numel()
-        gc, gb2c = self._e(max(q_item, 1), self.ld), self._e(max(q_item, 1))
-        sc = self._sc(T)
-        p = self._lib.ptr
-        self._lib.check(self.L.drx_shard_reduce(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), b_norm,
-                                                float(q), p(idx['keys_s']), p(idx['vals_s']), p(idx['slot_sorted']), p(bpos),
-                                                T, p(ctx['dz1']), p(ctx['g2']), p(ctx['dz2']), p(gc), p(gb2c), p(sc), sc.numel(),
-                                                self._stream()), 'drx_shard_reduce')
-        return gc[:q_item], gb2c[:q_item]
-
-    def apply(self, recv_keys, recv_rows, recv_b2, b_norm, opt, recv_counts):
-        n = recv_keys.numel()
-        if n == 0:
-            return
-        sc = self._sc(n)
-        p = self._lib.ptr
-        counts = (C.c_int32 * len(recv_counts))(*[int(c) for c in recv_counts])      # world x micro-batches segments
-        self._lib.check(self.L.drx_shard_apply(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), b_norm,
-                                               p(recv_keys), p(recv_rows.contiguous()), p(recv_b2.contiguous()), n, counts,
-                                               len(recv_counts), p(sc), sc.numel(), self._stream()), 'drx_shard_apply')
-
-    def bias_grad(self, B, ctx):
-        out = self._e(self.ld + 1)
-        sc = self._sc(1)
-        p = self._lib.ptr
-        self._lib.check(self.L.drx_shard_bias_grad(C.byref(self.engine._params), p(ctx['dz1']), p(ctx['lossb']), B, p(out), p(sc),
-                                                   sc.numel(), self._stream()), 'drx_shard_bias_grad')
+    def gather_rows(self, req, recv_counts):
+        out = self._e(max(32, sum(self.xsplits(recv_counts))))
+        cnt = (C.c_int32 * len(recv_counts))(*[int(c) for c in recv_counts])
+        self._lib.check(self.L.drx_shard_gather_rows(C.byref(self.engine._params), C.byref(self.shard), self._lib.ptr(req), req.numel(),
+                                                     cnt, len(recv_counts), self._lib.ptr(out), self._stream()), 'drx_shard_gather_rows')
         return out
 
-    def bias_apply(self, grad, b_norm, opt):
-        g = grad[:self.ld].contiguous()
-        self._lib.check(self.L.drx_shard_bias_apply(C.byref(self.engine._params), C.byref(opt), b_norm, self._lib.ptr(g),
-                                                    self._stream()), 'drx_shard_bias_apply')
+    def local_step(self, bt, prep, rows_cache, b_norm, loss_kind, opt, events=None):
+        """Forward / backward + reduction of one (micro-)batch: the gradient buffer on its way back (same geometry as rows_cache)."""
+        P = self.engine._params
+        need = int(self.L.drx_shard_step_scratch_bytes(C.byref(P), bt.B, bt.n_touch_slots))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(int(need * 1.1) + 4096, dtype=torch.uint8, device=self.device)
+        gsend = self._e(max(32, sum(chunk_floats(prep['send_counts'], self.ld))))     # (with the bypass: the own chunk at its end)
+        arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events]) if events is not None else None
+        buf = prep['buf']
+        self._lib.check(self.L.drx_shard_step_local(C.byref(P), C.byref(opt), C.byref(self.shard), C.byref(self.engine._hist), C.byref(bt),
+                                                    self._lib.ptr(buf), buf.numel(), self._lib.ptr(rows_cache), self._lib.ptr(gsend),
+                                                    int(b_norm), int(loss_kind), self._lib.ptr(self._scratch), self._scratch.numel(), arr,
+                                                    self._stream()), 'drx_shard_step_local')
+        return gsend
+
+    def apply(self, req, grecv, recv_counts, table, b_norm, opt, want_loss=False, own=None):
+        """own: per micro-batch (its gradient buffer, the send counts it was built for) — where the rank's own chunks are"""
+        cnt = (C.c_int32 * len(recv_counts))(*[int(c) for c in recv_counts])
+        og = oo = None
+        if self.self_bypass:
+            og = (C.c_void_p * len(own))(*[self._lib.ptr(g) for g, _ in own])
+            oo = (C.c_int64 * len(own))(*[sum(self.xsplits(sc)) for _, sc in own])
+        self._lib.check(self.L.drx_shard_apply(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), int(b_norm),
+                                               self._lib.ptr(req), self._lib.ptr(grecv), req.numel(), cnt, len(recv_counts),
+                                               self._lib.ptr(table), og, oo, self._lib.ptr(self._loss) if want_loss else None,
+                                               self._stream()), 'drx_shard_apply')
+        return self._loss if want_loss else None
 
     def optim(self, step):
         a = self.engine.adam_alpha(self.engine.lr, step + 1, self.engine.beta1, self.engine.beta2)
@@ -178,7 +188,8 @@ class ShardedCdae:
     """One rank of the row-sharded sampled-mode CDAE.  `ops` = per-rank compute backend (HipShardOps on a GPU)."""
 
     def __init__(self, n_users_total, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
-                 optimizer='adagrad', ops=None, group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False):
+                 optimizer='adagrad', ops=None, group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False,
+                 self_bypass=True):
         self.rank, self.world, self.group = rank, world, group
         # world 1 normally bypasses torch.distributed; `force_collectives` sends every exchange through the process group
         # anyway (a 1-rank RCCL communicator exercises the exact call sequence of the N-rank step on one GPU)
@@ -190,15 +201,17 @@ class ShardedCdae:
         self.user_hi = n_users_total * (rank + 1) // world
         self.n_users_total = n_users_total
         n_local = self.user_hi - self.user_lo
-        self.ops = ops if ops is not None else HipShardOps(n_local, n_items, k, rank, world, device, optimizer, lr, reg)
+        self.ops = ops if ops is not None else HipShardOps(n_local, n_items, k, rank, world, device, optimizer, lr, reg, self_bypass)
         self.engine = getattr(self.ops, 'engine', None)
+        self.ld = getattr(self.ops, 'ld', k)
         self.loss_kind = 0 if loss == 'bce' else 1
         self.q = q
         if self.engine is not None:
             self.engine.set_history(hist_indptr, hist_indices)
             self._init_random(seed)
         self.last_loss = None
-        self.wait_s = 0.0                     # host time spent waiting for count exchanges (should stay ~0 when pipelined)
+        self._cur = self._main = None         # ShardedPipeline: the stream its run-ahead stages are queued on / the training stream
+        self.wait_s = 0.0                     # host time spent waiting for count exchanges (stays ~0 when pipelined)
 
     def _init_random(self, seed):
         """GlorotUniform of the GLOBAL shapes, drawn per shard on the device (cdae.py:35-41)."""
@@ -232,76 +245,53 @@ class ShardedCdae:
         self.ops.set_params(Wl, W_l, np.asarray(V[self.user_lo:self.user_hi], dt), np.asarray(b, dt), b_l)
 
     # ---- exchanges ---------------------------------------------------------------------------------------
-    def _a2a(self, send, send_counts, recv_counts):
-        shape = (int(sum(recv_counts)),) + tuple(send.shape[1:])
-        out = torch.empty(shape, dtype=send.dtype, device=send.device)
-        if not self.collectives:
-            out.copy_(send[:shape[0]])
-            return out
-        if self.cpu_staging and send.is_cuda:
-            o = torch.empty(shape, dtype=send.dtype)
-            dist.all_to_all_single(o, send.contiguous().cpu(), output_split_sizes=list(recv_counts),
-                                   input_split_sizes=list(send_counts), group=self.group)
-            return o.to(send.device)
-        dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
-                               input_split_sizes=list(send_counts), group=self.group)
-        return out
-
-    def _a2a_start(self, send, send_counts, recv_counts, out=None, overlap=False):
-        """all-to-all(v) that the caller waits for later: returns (received tensor, wait()-able or None).  The training stream
-        keeps running kernels of another micro-batch while the rows travel."""
+    def _a2a(self, send, send_counts, recv_counts, out=None, overlap=False):
+        """all-to-all(v) of a 1-D tensor with per-peer split sizes; returns (received tensor, wait()-able or None).  overlap: the
+        training stream keeps running kernels of another micro-batch while the rows travel.  The returned tensor is never empty
+        (at least 32 elements are allocated: an exchange may be empty when a rank's own rows bypass it, and the library wants a
+        pointer); its first sum(recv_counts) elements are the received ones."""
         n = int(sum(recv_counts))
         if out is None:
-            out = torch.empty((n,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            out = torch.empty(max(n, 32), dtype=send.dtype, device=send.device)
+        dst = out[:n]
+        send = send[:int(sum(send_counts))]
         if not self.collectives:
-            out.copy_(send[:n])
+            dst.copy_(send)
             return out, None
+        if self.world == 1 and n == 0 and send.numel() == 0:
+            return out, None                           # (a 1-rank communicator with the self-bypass: nothing to exchange)
         if (self.cpu_staging and send.is_cuda) or not send.is_cuda:
-            out.copy_(self._a2a(send, send_counts, recv_counts))
+            o = torch.empty(n, dtype=send.dtype)
+            dist.all_to_all_single(o, send.contiguous().cpu(), output_split_sizes=[int(c) for c in recv_counts],
+                                   input_split_sizes=[int(c) for c in send_counts], group=self.group)
+            dst.copy_(o)
             return out, None
-        # async_op only when there is another micro-batch to compute meanwhile: on one micro-batch the asynchronous form was
-        # measured slower (1-rank RCCL: 1.15 vs 1.05 ms/step)
-        work = dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
-                                      input_split_sizes=list(send_counts), group=self.group, async_op=overlap)
+        # async_op only when there is another micro-batch to compute meanwhile (on one micro-batch the asynchronous form only
+        # adds a stream hop)
+        work = dist.all_to_all_single(dst, send, output_split_sizes=[int(c) for c in recv_counts],
+                                      input_split_sizes=[int(c) for c in send_counts], group=self.group, async_op=overlap)
         return out, (work if overlap else None)
 
-    def _counts(self, send_counts, device):
-        if not self.collectives:
-            return list(send_counts)
-        s = torch.tensor(send_counts, dtype=torch.int64, device='cpu' if self.cpu_staging else device)
-        r = torch.empty_like(s)
-        dist.all_to_all_single(r, s, group=self.group)
-        return r.cpu().tolist()
-
-    # ---- one step ------------------------------------------------------------------------------------------
-    # A step has three parameter-independent stages that may run ahead of the training stream (ShardedPipeline below):
-    #   prepare(bt)            local: touches, stable sort, distinct keys, slots, per-owner bounds      [no collective]
-    #   exchange_counts(P)     all-to-all of the per-owner distinct-key counts; the result goes to pinned host memory
+    # ---- the parameter-independent stages ---------------------------------------------------------------------
+    # They may run ahead of the training stream (ShardedPipeline below):
+    #   prepare(bt)            local: touch list, plan, marks, distinct rows, per-owner counts          [no collective]
+    #   exchange_counts(P)     all-to-all of the per-owner counts; the result goes to pinned host memory
     #   exchange_keys(P)       all-to-all(v) of the distinct keys each owner is asked for (needs the counts on the host)
-    # and the parameter-dependent rest in step().  Every rank must call the stages in the same program order: they all
-    # run on one communicator.
-    def prepare(self, bt, consumer_stream=None):
-        """Parameter-independent, collective-free part of a step: touches of the local batch, stable sort, distinct
-        keys, slots, per-owner bounds.  May run on a side stream for a later batch while the current one trains;
-        `consumer_stream` is the stream that will later read the result (allocator bookkeeping)."""
-        keys, vals, bpos = self.ops.touches(bt)
-        idx = self.ops.index(keys, vals)
-        ev = None
-        if torch.is_tensor(keys) and keys.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record()
-            if consumer_stream is not None:
-                for t in [bpos] + [v for v in idx.values() if torch.is_tensor(v) and v.is_cuda]:
-                    t.record_stream(consumer_stream)
-        return {'idx': idx, 'bpos': bpos, 'event': ev, 'keys': keys, 'vals': vals, 'consumer': consumer_stream}
+    #   index_owner(Ps)        the owner's table of the keys it received for all micro-batches of a step
+    # Every rank must call the stages in the same program order: they all run on one communicator.
+    def prepare(self, bt, consumer_stream=None, out=None):
+        P = self.ops.prepare(bt, out) if out is not None else self.ops.prepare(bt)
+        P.setdefault('buf', None)
+        P['consumer'] = consumer_stream             # the stream that will run the step, when the stages run ahead on another one
+        P['event'] = None                           # recorded behind the LAST run-ahead stage (index_owner): what the step waits for
+        return P
 
     def exchange_counts(self, P):
-        """Stage 2: how many distinct keys every rank asks of every owner.  On the device path nothing here waits on the
-        host: the send counts are differences of the device-side bounds, the received counts land in pinned memory."""
-        idx, W = P['idx'], self.world
-        if 'bounds_dev' in idx and not self.cpu_staging:
-            bd = idx['bounds_dev']
-            send = (bd[1:W + 1] - bd[0:W]).to(torch.int64)
+        """How many rows (sentinel included) every rank asks of every owner.  On the device path nothing here waits on the host:
+        the send counts are a view of the prepared buffer, both count vectors land in pinned memory."""
+        W = self.world
+        if 'counts_dev' in P and not self.cpu_staging:
+            send = P['counts_dev']
             recv = torch.empty_like(send)
             if self.collectives:
                 dist.all_to_all_single(recv, send, group=self.group)
@@ -311,51 +301,67 @@ class ShardedCdae:
             host[0].copy_(send, non_blocking=True)
             host[1].copy_(recv, non_blocking=True)
             P['counts_host'] = host
-            P['event'] = torch.cuda.Event()
-            P['event'].record()
-            if P.get('consumer') is not None:
-                send.record_stream(P['consumer']); recv.record_stream(P['consumer'])
+            P['counts_event'] = torch.cuda.Event()
+            P['counts_event'].record(self._cur) if self._cur is not None else P['counts_event'].record()
         else:
-            bounds = self.ops.bounds_of(idx, P['event']) if hasattr(self.ops, 'bounds_of') else idx['bounds']
-            send_counts = [bounds[o + 1] - bounds[o] for o in range(W)]
+            if 'counts' in P:
+                send_counts = [int(c) for c in P['counts']]
+            else:
+                send_counts = P['counts_dev'].cpu().tolist()
             P['send_counts'] = send_counts
-            P['recv_counts'] = self._counts(send_counts, idx['uniq_keys'].device)
+            if self.collectives:
+                s = torch.tensor(send_counts, dtype=torch.int64)
+                r = torch.empty_like(s)
+                dist.all_to_all_single(r, s, group=self.group)
+                P['recv_counts'] = r.tolist()
+            else:
+                P['recv_counts'] = list(send_counts)
         return P
 
     def exchange_keys(self, P):
-        """Stage 3: every owner learns which of its rows each rank wants (4 B per distinct row)."""
+        """Every owner learns which of its rows each rank wants (4 B per distinct row)."""
         if 'send_counts' not in P:
             if 'counts_host' not in P:
                 self.exchange_counts(P)
             if 'counts_host' in P:
                 t0 = time.perf_counter()
-                P['event'].synchronize()                # the tiny count exchange, issued at least one step earlier
+                P['counts_event'].synchronize()         # the tiny count exchange, issued at least two steps earlier
                 self.wait_s += time.perf_counter() - t0
                 P['send_counts'] = P['counts_host'][0].tolist()
                 P['recv_counts'] = P['counts_host'][1].tolist()
-        q_item = int(sum(P['send_counts']))
-        P['q_item'] = q_item
-        P['req'] = self._a2a(P['idx']['uniq_keys'][:q_item], P['send_counts'], P['recv_counts'])
-        if torch.is_tensor(P['req']) and P['req'].is_cuda:
-            P['event'] = torch.cuda.Event()
-            P['event'].record()
-            if P.get('consumer') is not None:
-                P['req'].record_stream(P['consumer'])
+        P['req'], _ = self._a2a(P['uniq'], P['send_counts'], P['recv_counts'])
+        P['req'] = P['req'][:int(sum(P['recv_counts']))]
+        if P['req'].is_cuda and P.get('consumer') is not None:
+            P['req'].record_stream(P['consumer'])
         return P
 
+    def index_owner(self, Ps, slot=0):
+        """The owner side of a step's key exchange(s): one table over the segments of all micro-batches (micro-batch-major)."""
+        head = Ps[0]
+        head['req_all'] = Ps[0]['req'] if len(Ps) == 1 else torch.cat([P['req'] for P in Ps])
+        head['counts_all'] = [int(c) for P in Ps for c in P['recv_counts']]
+        head['table'] = self.ops.owner_index(head['req_all'], head['counts_all'], slot)
+        if head['req_all'].is_cuda and head.get('consumer') is not None:
+            head['event'] = torch.cuda.Event()
+            head['event'].record(self._cur) if self._cur is not None else head['event'].record()
+            if len(Ps) > 1:
+                head['req_all'].record_stream(head['consumer'])
+        return head
+
+    # ---- one step ------------------------------------------------------------------------------------------
     def step(self, step, bt, events=None, want_loss=False, prepared=None, after_row_requests=None):
         """One training step of this rank.  `bt` is a DrxBatch or a list of up to DRX_MAX_MICRO micro-batches with pairwise
         DISJOINT users (then `prepared` is the matching list): all micro-batches read the pre-step parameters and every
         owned row is updated once with the sum of their gradients — the step still equals the single-process step on the
         concatenated batch — but the row exchange of micro-batch m+1 and the gradient exchange of micro-batch m travel while
         the other one computes.
-        Event slots (bench): [0,1) row gather + the first row exchange, [1,2) forward/backward + local reduce of all
+        Event slots (bench): [0,1) row gather + the first row exchange, [1,2) forward/backward + local reduction of all
         micro-batches (later row / earlier gradient exchanges hidden behind them), [2,3) rest of the gradient exchange,
-        [3,4) owner apply, [4,5) bias.
-        after_row_requests: called once the row exchanges of this step are queued — ShardedPipeline queues the run-ahead
-        count / key exchanges of later batches there, so that on the communicator they sit behind this step's row exchange
-        (and travel while it computes) instead of in front of it."""
-        ops = self.ops
+        [3,4) owner apply + bias.
+        after_row_requests: called once the row exchanges of this step and the kernels of its first micro-batch are queued —
+        ShardedPipeline queues the run-ahead count / key exchanges of later batches there, so that on the communicator they sit
+        behind this step's row exchange (and travel while it computes) instead of in front of it."""
+        ops, ld = self.ops, self.ld
         bts = list(bt) if isinstance(bt, (list, tuple)) else [bt]
         Ps = (list(prepared) if isinstance(prepared, (list, tuple)) else [prepared]) if prepared is not None else [None] * len(bts)
         b_norm = sum(b.B for b in bts) * self.world
@@ -367,54 +373,45 @@ class ShardedCdae:
             P = Ps[m] = Ps[m] if Ps[m] is not None else self.prepare(b)
             if 'req' not in P:
                 self.exchange_keys(P)
-            elif P['event'] is not None:
-                torch.cuda.current_stream().wait_event(P['event'])
+        if 'table' not in Ps[0]:
+            self.index_owner(Ps)
+        if Ps[0]['event'] is not None:                 # the run-ahead stages of this step, all queued on one side stream
+            (self._main or torch.cuda.current_stream()).wait_event(Ps[0]['event'])
+        ov = len(Ps) > 1
         fetched = []
         for P in Ps:                                   # owners answer every micro-batch's request from the pre-step tables
-            rows, b2v = ops.gather_rows(P['req'])
-            fetched.append((self._a2a_start(rows, P['recv_counts'], P['send_counts'], overlap=len(Ps) > 1),
-                            self._a2a_start(b2v, P['recv_counts'], P['send_counts'], overlap=len(Ps) > 1)))
-        if after_row_requests is not None:
-            after_row_requests()
-        wait(fetched[0][0][1]); wait(fetched[0][1][1])
+            rows = ops.gather_rows(P['req'], P['recv_counts'])
+            fetched.append(self._a2a(rows, ops.xsplits(P['recv_counts']), ops.xsplits(P['send_counts']), overlap=ov))
+        wait(fetched[0][1])
         rec(1)
-        n_recv = [int(sum(P['recv_counts'])) for P in Ps]
-        rg = rb2 = None
-        pushed, ctxs, off = [], [], 0
+        n_recv = [sum(ops.xsplits(P['recv_counts'])) for P in Ps]
+        grecv = None
+        pushed, off = [], 0
         for m, (b, P) in enumerate(zip(bts, Ps)):
-            (rows_cache, w1), (b2_cache, w2) = fetched[m]
-            wait(w1); wait(w2)
-            ctx = ops.fwd_bwd(b, P['idx']['slot_of_pos'], rows_cache, b2_cache, b_norm, self.loss_kind)
-            gc, gb2c = ops.reduce(P['idx'], P['bpos'], P['q_item'], b_norm, b.q, opt, ctx)
-            if rg is None:                             # one receive buffer for all micro-batches: segments stay adjacent
-                rg = torch.empty((sum(n_recv),) + tuple(gc.shape[1:]), dtype=gc.dtype, device=gc.device)
-                rb2 = torch.empty(sum(n_recv), dtype=gb2c.dtype, device=gb2c.device)
-            ov = len(Ps) > 1
-            pushed.append((self._a2a_start(gc, P['send_counts'], P['recv_counts'], out=rg[off:off + n_recv[m]], overlap=ov)[1],
-                           self._a2a_start(gb2c, P['send_counts'], P['recv_counts'], out=rb2[off:off + n_recv[m]], overlap=ov)[1], gc, gb2c))
-            ctxs.append(ctx)
+            cache, w1 = fetched[m]
+            wait(w1)
+            gsend = ops.local_step(b, P, cache, b_norm, self.loss_kind, opt)
+            if m == 0 and after_row_requests is not None:
+                # the run-ahead stages are ISSUED here — behind this step's row exchange on the communicator (they travel while the
+                # step computes) and in front of its gradient exchange, and while the training stream has the forward / backward and
+                # the reduction of this batch queued: the host time they take is hidden behind those kernels
+                after_row_requests()
+            if grecv is None:                          # one receive buffer for all micro-batches: segments stay adjacent
+                grecv = torch.empty(max(32, sum(n_recv)), dtype=gsend.dtype, device=gsend.device)
+            pushed.append((self._a2a(gsend, ops.xsplits(P['send_counts']), ops.xsplits(P['recv_counts']),
+                                     out=grecv[off:off + max(n_recv[m], 1)], overlap=ov)[1], gsend))
             off += n_recv[m]
         rec(2)
-        for w1, w2, _, _ in pushed:
-            wait(w1); wait(w2)
+        for w1, _ in pushed:
+            wait(w1)
         rec(3)
-        req = Ps[0]['req'] if len(Ps) == 1 else torch.cat([P['req'] for P in Ps])
-        ops.apply(req, rg, rb2, b_norm, opt, [c for P in Ps for c in P['recv_counts']])
+        head = Ps[0]
+        loss = ops.apply(head['req_all'], grecv, head['counts_all'], head['table'], b_norm, opt, want_loss=want_loss,
+                         own=[(g, P['send_counts']) for (_, g), P in zip(pushed, Ps)])
         rec(4)
-        gb = ops.bias_grad(bts[0].B, ctxs[0])
-        for b, ctx in zip(bts[1:], ctxs[1:]):
-            gb = gb + ops.bias_grad(b.B, ctx)
-        if self.collectives:
-            if self.cpu_staging and gb.is_cuda:
-                g = gb.cpu()
-                dist.all_reduce(g, group=self.group)
-                gb = g.to(gb.device)
-            else:
-                dist.all_reduce(gb, group=self.group)
-        ops.bias_apply(gb, b_norm, opt)
         rec(5)
         if want_loss:
-            self.last_loss = float(gb[-1].item()) / b_norm
+            self.last_loss = float(loss[0].item()) if torch.is_tensor(loss) else float(loss)
             return self.last_loss
         return None
 
@@ -423,14 +420,14 @@ class ShardedPipeline:
     """Drives ShardedCdae so that no step waits on the host or on a parameter-independent exchange.
 
     Iteration s issues, in this program order (identical on every rank — one communicator):
-        step(batch s) up to its row exchange  ·  exchange_keys(batch s+1)  ·  exchange_counts(batch s+2)  ·
-        prepare(batch s+3)  ·  rest of step(batch s)
-    The run-ahead exchanges sit behind step s's row exchange on the communicator and travel while step s computes; the
-    count exchange of batch s+2 has long finished when iteration s+1 reads its host-side result.  On a GPU the run-ahead stages use a side stream; on CPU (gloo tests) everything runs inline in the
-    same order.  `batch_of(s)` must return the DrxBatch (or the list of micro-batches) of step s and be callable three
-    steps ahead."""
+        step(batch s) up to its forward / backward + reduction  ·  exchange_keys + index_owner(batch s+1)  ·
+        exchange_counts(batch s+3)  ·  prepare(batch s+4)  ·  rest of step(batch s)
+    The run-ahead exchanges sit behind step s's row exchange on the communicator and travel while step s computes; the count
+    exchange of batch s+1 was issued two iterations before iteration s reads its host-side result: the host never waits for it.  On a GPU the run-ahead stages use a side
+    stream; on CPU (gloo tests) everything runs inline in the same order.  `batch_of(s)` must return the DrxBatch (or the list of
+    micro-batches) of step s and be callable LOOKAHEAD steps ahead."""
 
-    LOOKAHEAD = 3
+    LOOKAHEAD = 4
 
     def __init__(self, model, batch_of, n_steps, use_side_stream=None):
         self.m, self.batch_of, self.n = model, batch_of, n_steps
@@ -439,6 +436,7 @@ class ShardedPipeline:
         if use_side_stream is None:
             use_side_stream = self.cuda
         self.main = torch.cuda.current_stream(eng.device) if self.cuda else None
+        model._main = self.main
         # High priority: ROCm multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and a stream that
         # lands on the queue of the training or the RCCL stream inherits their barriers (measured: the count exchange then
         # completes only when the GPU drains, +0.2 ms/step); priority streams get queues of their own.
@@ -446,37 +444,52 @@ class ShardedPipeline:
         self.P = {}
         self.next = 0
         self.host_s = [0.0, 0.0, 0.0]
+        # prepared buffers are reused LOOKAHEAD + 2 steps later: step s's buffer is rewritten by the preparation of step
+        # s + RING, issued during iteration s + RING - LOOKAHEAD >= s + 2, behind the event recorded after step s
+        self.RING = self.LOOKAHEAD + 2
+        self.bufs = {}
+        self.done = {}
         if self.side is not None:
             self.side.wait_stream(self.main)            # histories / batches set up on the training stream
         # Staggered run-ahead: a collective queued on the communicator must only depend on work that finished long ago —
         # it sits in FRONT of the current step's gradient exchange there, and would hold it up while, say, a sort that was
-        # queued a moment ago is still running.  So batch s+3 is indexed, batch s+2 exchanges counts, batch s+1 keys.
-        for s in range(min(3, n_steps)):
-            self._prepare(s)
-        for s in range(min(2, n_steps)):
-            self._counts(s)
-        self._keys(0)
+        # queued a moment ago is still running.  So batch s+4 is prepared, batch s+3 exchanges counts, batch s+1 keys.
+        with self._on_side():
+            for s in range(min(self.LOOKAHEAD, n_steps)):
+                self._prepare(s)
+            for s in range(min(self.LOOKAHEAD - 1, n_steps)):
+                self._counts(s)
+            self._keys(0)
 
     def _on_side(self):
-        return torch.cuda.stream(self.side) if self.side is not None else _Null()
+        return _SideStream(self.m, self.side) if self.side is not None else _Null()
 
     def _micro(self, s):
         bt = self.batch_of(s)
         return list(bt) if isinstance(bt, (list, tuple)) else [bt]
 
+    # (the three stages below run with the side stream current: _on_side())
     def _prepare(self, s):
-        with self._on_side():
-            self.P[s] = [self.m.prepare(bt, consumer_stream=self.main if self.side is not None else None) for bt in self._micro(s)]
+        k = s % self.RING
+        if self.side is not None and k in self.done:
+            self.side.wait_event(self.done[k])             # the step that last read this slot's buffers has finished
+        out = []
+        for i, bt in enumerate(self._micro(s)):
+            buf = self.bufs.get((k, i)) if self.cuda else None
+            P = self.m.prepare(bt, consumer_stream=self.main if self.side is not None else None, out=buf)
+            if self.cuda:
+                self.bufs[(k, i)] = P['buf']
+            out.append(P)
+        self.P[s] = out
 
     def _counts(self, s):
-        with self._on_side():
-            for P in self.P[s]:
-                self.m.exchange_counts(P)
+        for P in self.P[s]:
+            self.m.exchange_counts(P)
 
     def _keys(self, s):
-        with self._on_side():
-            for P in self.P[s]:
-                self.m.exchange_keys(P)
+        for P in self.P[s]:
+            self.m.exchange_keys(P)
+        self.m.index_owner(self.P[s], slot=s % self.RING)
 
     def run_step(self, events=None, want_loss=False):
         s = self.next
@@ -486,21 +499,44 @@ class ShardedPipeline:
 
         def run_ahead():                       # queued behind this step's row exchange on the communicator
             ta = time.perf_counter()
-            if s + 1 < self.n:
-                self._keys(s + 1)
-            if s + 2 < self.n:
-                self._counts(s + 2)
-            if s + 3 < self.n:
-                self._prepare(s + 3)
+            with self._on_side():
+                if s + 1 < self.n:
+                    self._keys(s + 1)
+                if s + self.LOOKAHEAD - 1 < self.n:
+                    self._counts(s + self.LOOKAHEAD - 1)
+                if s + self.LOOKAHEAD < self.n:
+                    self._prepare(s + self.LOOKAHEAD)
             ahead_s[0] = time.perf_counter() - ta
         out = self.m.step(s, self._micro(s), events=events, want_loss=want_loss, prepared=self.P.pop(s),
                           after_row_requests=run_ahead)
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.done[s % self.RING] = ev
         t3 = time.perf_counter()
         self.host_s[1] += ahead_s[0]; self.host_s[2] += t3 - t0 - ahead_s[0]                 # host time issuing each part
         if hasattr(self.batch_of, 'release'):
             self.batch_of.release(s)                   # e.g. engine.DeviceBatchSource: the batch's buffers may be reused
         self.next = s + 1
         return out
+
+
+class _SideStream:
+    """`with torch.cuda.stream(side)` that also tells the model which stream is current (event records without the
+    current-stream lookup)"""
+
+    def __init__(self, model, side):
+        self.model, self.ctx = model, torch.cuda.stream(side)
+        self.side = side
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        self.model._cur = self.side
+        return self
+
+    def __exit__(self, *a):
+        self.model._cur = None
+        return self.ctx.__exit__(*a)
 
 
 class _Null:

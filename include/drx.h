@@ -248,55 +248,75 @@ int drx_cdae_sparse_prepare_part(const DrxCdaeParams *p, const DrxHistory *hist,
 int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt, const void *all_parts, int32_t parts, void *prepared,
                                      size_t prepared_bytes, int32_t *overflow_out, void *stream);
 
-/* ---- row-sharded multi-GPU step (no reference equivalent — DRecPy is single-process) ---------------
- * Per-rank, collective-free pieces of the sampled step; the host (drecpy_amd/dist.py) runs the RCCL all-to-all
- * exchanges between them.  Users (V, histories, samples) are sharded by uid range; item rows (W, W2T, b2) by item range
- * of `items_per_rank` rows; in this mode DrxCdaeParams describes the LOCAL tables (n_users = local users,
- * n_items = items_per_rank).  Row keys are owner-major: item n of owner o = n / ipr -> o*2*ipr + (n - o*ipr) for its W
- * row, + ipr for its W2T row; local user u -> world*2*ipr + u. */
-#define DRX_MAX_WORLD 64                /* ranks of one sharded job (per-source offsets travel as a kernel argument) */
+/* ---- row-sharded multi-GPU step (BASELINE.json configuration 4; no reference equivalent — DRecPy is single-process:
+ * recommender_abc.py:16 is its only device line) -------------------------------------------------------------------------------------
+ * Per-rank, collective-free pieces of the sampled step; the host (drecpy_amd/dist.py) runs the RCCL all-to-all exchanges between
+ * them.  Users (V, histories, samples) are sharded by uid range; item rows (W, W2T, b2) by item range of `items_per_rank` rows; in
+ * this mode DrxCdaeParams describes the LOCAL tables (n_users = local users, n_items = items_per_rank).
+ *
+ * WIRE keys of item rows are owner-major: item n of owner o = n / ipr is (o << shift) + (W2T row ? ipr : 0) + n - o * ipr, where
+ * 1 << shift is the smallest power of two >= max(2 * ipr, 8192).  A rank's distinct keys ("uniq"), ascending, are contiguous per
+ * owner, each owner's run closed by one SENTINEL key DRX_KEY_NONE: counts[o] = distinct rows asked of owner o + 1.
+ *
+ * EXCHANGE BUFFER (float32, the same geometry in both directions, ONE collective each): for every peer, in rank order, a chunk of
+ * n rows of ld floats followed by n scalars padded to a multiple of 32 floats — n * ld + roundup(n, 32) floats (n = counts[o] on the
+ * requester's side, the received counts on the owner's).  Row i of a chunk answers key i of the peer's run.  Owner -> requester: the
+ * parameter row, scalar = b2 of a W2T row; the sentinel row is unused.  Requester -> owner: the rank's summed gradient row, scalar =
+ * gradient of b2; the SENTINEL row carries the rank's gradient of the replicated hidden bias b and, as its scalar, the rank's loss
+ * sum — every rank adds the same `world` rows in rank order, so b needs no all-reduce. */
+#define DRX_MAX_WORLD 64                /* ranks of one sharded job (per-segment offsets travel as a kernel argument) */
+#define DRX_MAX_MICRO 4                 /* micro-batches of one step (their exchanges overlap each other's compute) */
 typedef struct DrxShard {
   int32_t world, rank;
   int32_t n_items;          /* global number of items */
   int32_t items_per_rank;   /* ceil(n_items / world) */
   int32_t n_users_local;
+  uint32_t flags;           /* DRX_SHARD_* */
 } DrxShard;
+/* The rank's OWN item rows never pass through a collective: the forward kernel reads them from the local tables, the gather skips
+ * the requests the rank sent to itself, and its own gradient chunk is read by drx_shard_apply where drx_shard_step_local left it.
+ * The float exchange buffers then hold the chunks of the OTHER peers in rank order (split size 0 for the rank itself), and on the
+ * requester's side the own chunk follows them (rows_cache never reads it, grad_send keeps it).  The KEY exchange is unchanged. */
+#define DRX_SHARD_SELF_BYPASS 1u
 
-size_t drx_shard_scratch_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32_t n_touches);
-/* keys/vals/b_of_pos [n_touch_slots + 2B]: row key (or DRX_KEY_NONE for dropped inputs), position, sample of each touch */
-int drx_shard_touches(const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt, uint32_t *keys, uint32_t *vals,
-                      uint32_t *b_of_pos, void *stream);
-/* stable sort by key; slot_sorted[j] / slot_of_pos[p] = index of the touch's key among the DISTINCT keys (ascending);
- * uniq_keys[slot]; bounds[o] = #distinct keys owned by ranks < o (o = 0..world; bounds[world] = first user key),
- * bounds[world+1] = #distinct keys. */
-int drx_shard_index(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *keys, const uint32_t *vals, int32_t T,
-                    uint32_t *keys_s, uint32_t *vals_s, int32_t *slot_sorted, uint32_t *slot_of_pos, uint32_t *uniq_keys,
-                    int32_t *bounds, void *scratch, size_t scratch_bytes, void *stream);
-/* owner side: rows[i] = the W / W2T row named by req_keys[i], b2_out[i] = its output bias (0 for W rows) */
-int drx_shard_gather_rows(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *req_keys, int32_t n, float *rows,
-                          float *b2_out, void *stream);
-/* forward + backward of the local triples against the fetched rows (rows_cache[slot]); losses are scaled by 1/b_norm
- * (the GLOBAL batch size) */
-int drx_shard_fwd_bwd(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const uint32_t *slot_of_pos,
-                      const float *rows_cache, const float *b2_cache, int32_t b_norm, int32_t loss_kind, float *dz1, float *g2,
-                      float *dz2, float *lossb, void *stream);
-/* one summed gradient row per distinct item row -> gc[slot] / gb2c[slot]; V rows are updated in place */
-int drx_shard_reduce(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, float q,
-                     const uint32_t *keys_s, const uint32_t *vals_s, const int32_t *slot_sorted, const uint32_t *b_of_pos,
-                     int32_t T, const float *dz1, const float *g2, const float *dz2, float *gc, float *gb2c, void *scratch,
-                     size_t scratch_bytes, void *stream);
-/* owner side: sum the received gradient rows per owned row in segment order and apply the optimizer ONCE per row.  The n
- * received rows are `n_segments` = world x (micro-batches of the step, <= DRX_MAX_MICRO) segments, micro-batch-major then
- * source rank, recv_counts[s] (HOST array) rows in segment s, each segment holding ascending distinct keys (what
- * drx_shard_index produces on the sender). */
-#define DRX_MAX_MICRO 4
+/* Parameter-independent preparation of one local batch, built ahead on a side stream: the sorted touch list with its span plan,
+ * sole-toucher marks and launch order (as drx_cdae_sparse_prepare), plus the batch's distinct item rows: wire keys with sentinels, their
+ * positions in the exchange buffers, per-owner counts.  `prepared` (256-byte aligned, drx_shard_prep_bytes) is opaque except for the
+ * two arrays drx_shard_prep_layout names: out4 = { byte offset of uniq (uint32[capacity]), byte offset of counts (int64[world]),
+ * capacity of uniq in keys, bytes a step reads }.  `work` (drx_shard_work_bytes) must be ZERO when first handed in; the library
+ * leaves it zero after every call (it may be shared by all preparations issued on one stream). */
+size_t drx_shard_prep_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32_t B, int32_t n_touch_slots);
+size_t drx_shard_work_bytes(const DrxShard *sh);
+int drx_shard_prep_layout(const DrxCdaeParams *p, const DrxShard *sh, int32_t B, int32_t n_touch_slots, size_t *out4);
+int drx_shard_prepare(const DrxCdaeParams *p, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt, void *prepared,
+                      size_t prepared_bytes, void *work, size_t work_bytes, void *stream);
+/* Owner side.  The n keys a rank received are `n_segments` = world x (micro-batches of the step, <= DRX_MAX_MICRO) segments,
+ * micro-batch-major then source rank, recv_counts[s] (HOST array, sentinel included) keys in segment s.
+ * drx_shard_owner_index: parameter-independent, run when the keys arrive: table[local key][segment] = index of the key
+ * (drx_shard_owner_table_bytes).  drx_shard_gather_rows: the requested rows + scalars into an exchange buffer of the geometry above
+ * (segment after segment). */
+size_t drx_shard_owner_table_bytes(const DrxShard *sh, int32_t n_segments);
+int drx_shard_owner_index(const DrxShard *sh, const uint32_t *recv_keys, int32_t n, const int32_t *recv_counts, int32_t n_segments,
+                          void *table, size_t table_bytes, void *stream);
+int drx_shard_gather_rows(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *recv_keys, int32_t n, const int32_t *recv_counts,
+                          int32_t n_segments, float *out, void *stream);
+/* Requester side, three launches: forward + backward of the local triples against the received rows (`rows_cache`; V rows and W2T
+ * gradient rows only one triple touches are finished there), the planned segmented reduction and its span launch: one summed
+ * gradient row per distinct item row into `grad_send` (same geometry as rows_cache), shared V rows updated in place, the bias
+ * gradient + loss sum into the sentinel rows.  Losses and L2 are normalised by b_norm, the GLOBAL batch size.
+ * events: NULL or 4 hipEvent_t recorded before / between / after the launches. */
+size_t drx_shard_step_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots);
+int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt,
+                         const void *prepared, size_t prepared_bytes, const float *rows_cache, float *grad_send, int32_t b_norm,
+                         int32_t loss_kind, void *scratch, size_t scratch_bytes, void *const *events, void *stream);
+/* Owner side: sum the gradient rows received for each owned row in segment order and apply the optimizer ONCE per row; one extra
+ * workgroup sums the sentinel rows in segment order, updates b and writes loss_out[0] = global loss sum / b_norm (loss_out may be
+ * NULL).  `table` = what drx_shard_owner_index built from the same keys.  With DRX_SHARD_SELF_BYPASS: own_grad[m] = the grad_send
+ * buffer of the step's micro-batch m, own_off[m] = float offset of the rank's own chunk in it (= the floats of the chunks sent to
+ * the other peers); otherwise both NULL. */
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *recv_rows, const float *recv_b2, int32_t n, const int32_t *recv_counts, int32_t n_segments,
-                    void *scratch, size_t scratch_bytes, void *stream);
-/* out[0..ld) = column sums of dz1 (gradient of the hidden bias), out[ld] = sum of the per-sample losses */
-int drx_shard_bias_grad(const DrxCdaeParams *p, const float *dz1, const float *lossb, int32_t B, float *out, void *scratch,
-                        size_t scratch_bytes, void *stream);
-int drx_shard_bias_apply(const DrxCdaeParams *p, const DrxOptim *opt, int32_t b_norm, const float *grad, void *stream);
+                    const float *grad_recv, int32_t n, const int32_t *recv_counts, int32_t n_segments, const void *table,
+                    const float *const *own_grad, const int64_t *own_off, float *loss_out, void *stream);
 
 /* ---- model-independent pieces of the dense (Keras-Adam) steps of DMF / Caser ------------------------------------
  * drx_adam_dense: p, m, v [n] (16-B aligned): g_total = g + l2_coef * p (g may be NULL); TF ApplyAdam update with the

@@ -1,12 +1,13 @@
-"""NumPy statement of the per-rank work of the row-sharded step (same interface as drecpy_amd.dist.HipShardOps), used by
-the world-size-2 gloo tests to exercise drecpy_amd/dist.py's exchange logic on CPU.  TEST INFRASTRUCTURE: float64, loops."""
+"""NumPy statement of the per-rank work of the row-sharded step (same interface as drecpy_amd.dist.HipShardOps, same wire format:
+include/drx.h "EXCHANGE BUFFER"), used by the world-size-2 gloo tests to exercise drecpy_amd/dist.py's exchange logic on CPU.
+TEST INFRASTRUCTURE: float64, loops."""
 import types
 
 import numpy as np
 import torch
 
 from oracle import cdae_oracle as co
-from drecpy_amd.dist import item_key, items_per_rank
+from drecpy_amd.dist import chunk_floats, items_per_rank, pad32, wire_key, wire_shift
 
 NONE = 0xFFFFFFFF
 
@@ -21,15 +22,34 @@ def np_batch(uid, iid, y, indptr, q, mask_seed=0, keep=None):
                                  n_touch_slots=int(keep_off[-1]))
 
 
+def _chunk_offsets(counts, ld, skip=None, world=1, own_last=False):
+    """(first key index, float offset of the rows, float offset of the scalars) of every chunk of an exchange buffer.  skip: the
+    rank whose chunks are NOT in the buffer (self-bypass) — entry None, or, with own_last (requester side), placed behind the others"""
+    out, k, f = [], 0, 0
+    for i, c in enumerate(counts):
+        if skip is not None and i % world == skip:
+            out.append(None)
+        else:
+            out.append((k, f, f + int(c) * ld))
+            f += int(c) * ld + pad32(c)
+        k += int(c)
+    if own_last and skip is not None:
+        k0 = sum(int(c) for c in counts[:skip])
+        out[skip] = (k0, f, f + int(counts[skip]) * ld)
+    return out
+
+
 class NumpyShardOps:
-    def __init__(self, n_users_local, n_items, k, rank, world, indptr, indices, lr, reg):
+    def __init__(self, n_users_local, n_items, k, rank, world, indptr, indices, lr, reg, self_bypass=True):
         self.rank, self.world, self.k = rank, world, k
+        self.self_bypass = self_bypass
+        self.ld = k
         self.ipr = items_per_rank(n_items, world)
+        self.shift = wire_shift(self.ipr)
         self.n_items, self.n_users_local = n_items, n_users_local
         self.indptr, self.indices = np.asarray(indptr, np.int64), np.asarray(indices, np.int64)
         self.lr, self.reg = lr, reg
         self.engine = None
-        self.uk0 = world * 2 * self.ipr
 
     def set_params(self, W, W_, V, b, b_):
         f = np.float64
@@ -49,83 +69,54 @@ class NumpyShardOps:
             kf = bt.keep[bt.keep_off[b]:bt.keep_off[b + 1]].astype(bool)
         else:
             kf = co.drx_hash_u32(bt.mask_seed, np.full(e - s, b), np.arange(e - s)) >= co.q_threshold(bt.q)
-        return self.indices[s:e], kf
+        return self.indices[s:e][kf]
 
-    def touches(self, bt):
-        T = bt.n_touch_slots + 2 * bt.B
-        keys = np.full(T, NONE, np.int64)
-        bpos = np.zeros(T, np.int64)
+    # -- parameter-independent
+    def prepare(self, bt):
+        """Distinct wire keys of the batch's item rows, ascending, every owner's run closed by a sentinel; counts per owner."""
+        keys = set()
         for b in range(bt.B):
-            base = bt.keep_off[b] + 2 * b
-            items, kf = self._kept(bt, b)
-            for jj, (n, k) in enumerate(zip(items, kf)):
-                if k:
-                    keys[base + jj] = item_key(int(n), self.ipr, False)
-                bpos[base + jj] = b
-            d = len(items)
-            keys[base + d] = item_key(int(bt.iid[b]), self.ipr, True)
-            keys[base + d + 1] = self.uk0 + bt.uid[b]
-            bpos[base + d] = bpos[base + d + 1] = b
-        self._bt = bt
-        return torch.from_numpy(keys), torch.arange(T), torch.from_numpy(bpos)
+            for n in self._kept(bt, b):
+                keys.add(wire_key(int(n), self.ipr, False))
+            keys.add(wire_key(int(bt.iid[b]), self.ipr, True))
+        uniq, counts = [], []
+        for o in range(self.world):
+            mine = sorted(k for k in keys if (k >> self.shift) == o)
+            uniq += mine + [NONE]
+            counts.append(len(mine) + 1)
+        pos = {k: i for i, k in enumerate(uniq) if k != NONE}
+        return {'uniq': torch.tensor(uniq, dtype=torch.int64), 'counts': counts, 'pos': pos}
 
-    def index(self, keys, vals):
-        k = keys.numpy()
-        order = np.argsort(k, kind='stable')
-        ks, vs = k[order], vals.numpy()[order]
-        real = ks != NONE
-        uniq, inv = np.unique(ks[real], return_inverse=True)
-        slot_sorted = np.full(len(ks), -1, np.int64)
-        slot_sorted[real] = inv
-        slot_of_pos = np.full(len(ks), NONE, np.int64)
-        slot_of_pos[vs[real]] = inv
-        bounds = [int(np.searchsorted(uniq, o * 2 * self.ipr)) for o in range(self.world + 1)] + [len(uniq)]
-        return {'keys_s': torch.from_numpy(ks), 'vals_s': torch.from_numpy(vs), 'slot_sorted': torch.from_numpy(slot_sorted),
-                'slot_of_pos': torch.from_numpy(slot_of_pos), 'uniq_keys': torch.from_numpy(uniq), 'bounds': bounds}
+    def owner_index(self, req, recv_counts, slot=0):
+        return None
 
     def _local(self, key):
-        t = key - self.rank * 2 * self.ipr
+        t = key - (self.rank << self.shift)
         return (t >= self.ipr), (t - self.ipr if t >= self.ipr else t)
 
-    def gather_rows(self, req):
-        r = req.numpy()
-        rows = np.zeros((len(r), self.k))
-        b2v = np.zeros(len(r))
-        for i, key in enumerate(r):
-            is_out, row = self._local(int(key))
-            rows[i] = self.W2T[row] if is_out else self.W[row]
-            b2v[i] = self.b2[row] if is_out else 0.0
-        return torch.from_numpy(rows), torch.from_numpy(b2v)
+    def xsplits(self, counts):
+        f = chunk_floats(counts, self.ld)
+        return [0 if (self.self_bypass and i % self.world == self.rank) else x for i, x in enumerate(f)]
 
-    def fwd_bwd(self, bt, slot_of_pos, rows_cache, b2_cache, b_norm, loss_kind):
-        sp, rc, bc = slot_of_pos.numpy(), rows_cache.numpy(), b2_cache.numpy()
-        B, K = bt.B, self.k
-        dt = np.dtype(np.float64)
-        ctx = {'dz1': np.zeros((B, K)), 'g2': np.zeros((B, K)), 'dz2': np.zeros(B), 'lossb': np.zeros(B)}
-        s = 1.0 / (1.0 - bt.q)
-        for b in range(B):
-            base = bt.keep_off[b] + 2 * b
-            d = bt.keep_off[b + 1] - bt.keep_off[b]
-            acc = np.zeros(K)
-            for jj in range(d):
-                if sp[base + jj] != NONE:
-                    acc += rc[sp[base + jj]]
-            h = co.sigmoid(s * acc + self.V[bt.uid[b]] + self.b)
-            so = sp[base + d]
-            w2 = rc[so]
-            p = co.sigmoid(h @ w2 + bc[so])
-            y = bt.y[b]
-            if loss_kind == 0:
-                ctx['lossb'][b] = co.bce_elem(np.float64(y), p, dt)
-                dp = co.bce_grad(np.float64(y), p, dt) / b_norm
-            else:
-                ctx['lossb'][b] = (p - y) ** 2
-                dp = 2 * (p - y) / b_norm
-            dz2 = dp * p * (1 - p)
-            ctx['dz2'][b] = dz2
-            ctx['g2'][b] = dz2 * h
-            ctx['dz1'][b] = dz2 * w2 * h * (1 - h)
-        return ctx
+    def _skip(self):
+        return self.rank if self.self_bypass else None
+
+    # -- parameter-dependent
+    def gather_rows(self, req, recv_counts):
+        r = req.numpy()
+        out = np.zeros(sum(self.xsplits(recv_counts)))
+        for ch, c in zip(_chunk_offsets(recv_counts, self.ld, self._skip(), self.world), recv_counts):
+            if ch is None:
+                continue
+            k0, f0, s0 = ch
+            for i in range(int(c)):
+                key = int(r[k0 + i])
+                if key == NONE:
+                    continue
+                is_out, row = self._local(key)
+                out[f0 + i * self.ld:f0 + (i + 1) * self.ld] = self.W2T[row] if is_out else self.W[row]
+                out[s0 + i] = self.b2[row] if is_out else 0.0
+        return torch.from_numpy(out)
 
     def _update(self, name, row, g, b_norm, reg=True):
         p = getattr(self, name)
@@ -134,40 +125,89 @@ class NumpyShardOps:
         self.acc[name][row] = self.acc[name][row] + g * g
         p[row] = p[row] - float(np.float32(self.lr)) * g / (np.sqrt(self.acc[name][row]) + co.ADAGRAD_EPS)
 
-    def reduce(self, idx, bpos, q_item, b_norm, q, opt, ctx):
-        ks, vs, ss, bp = idx['keys_s'].numpy(), idx['vals_s'].numpy(), idx['slot_sorted'].numpy(), bpos.numpy()
-        gc, gb2c = np.zeros((q_item, self.k)), np.zeros(q_item)
-        s = 1.0 / (1.0 - q)
-        gv = {}
-        for key, pos, slot in zip(ks, vs, ss):
-            if key == NONE:
-                continue
-            b = bp[pos]
-            if key >= self.uk0:
-                gv[key - self.uk0] = gv.get(key - self.uk0, 0) + ctx['dz1'][b]
-            elif (key % (2 * self.ipr)) >= self.ipr:
-                gc[slot] += ctx['g2'][b]
-                gb2c[slot] += ctx['dz2'][b]
+    def local_step(self, bt, P, rows_cache, b_norm, loss_kind, opt, events=None):
+        cache = rows_cache.numpy()
+        B, K = bt.B, self.k
+        dt = np.dtype(np.float64)
+        offs = _chunk_offsets(P['counts'], self.ld, self._skip(), self.world, own_last=True)
+
+        def where(key):
+            o = key >> self.shift
+            k0, f0, s0 = offs[o]
+            i = P['pos'][key] - k0
+            return f0 + i * self.ld, s0 + i
+
+        def row_of(key):                       # an own row comes from the tables, any other from the cache
+            if self.self_bypass and (key >> self.shift) == self.rank:
+                is_out, row = self._local(key)
+                return (self.W2T[row], self.b2[row]) if is_out else (self.W[row], 0.0)
+            r0, s0 = where(key)
+            return cache[r0:r0 + K], cache[s0]
+        gsend = np.zeros(sum(chunk_floats(P['counts'], self.ld)))
+        s = 1.0 / (1.0 - bt.q)
+        gv, gb, loss = {}, np.zeros(K), 0.0
+        for b in range(B):
+            kept = [wire_key(int(n), self.ipr, False) for n in self._kept(bt, b)]
+            acc = np.zeros(K)
+            for key in kept:
+                acc += row_of(key)[0]
+            u = int(bt.uid[b])
+            h = co.sigmoid(s * acc + self.V[u] + self.b)
+            ko = wire_key(int(bt.iid[b]), self.ipr, True)
+            ro, so = where(ko)
+            w2, b2v = row_of(ko)
+            p = co.sigmoid(h @ w2 + b2v)
+            y = bt.y[b]
+            if loss_kind == 0:
+                loss += co.bce_elem(np.float64(y), p, dt)
+                dp = co.bce_grad(np.float64(y), p, dt) / b_norm
             else:
-                gc[slot] += s * ctx['dz1'][b]
+                loss += (p - y) ** 2
+                dp = 2 * (p - y) / b_norm
+            dz2 = dp * p * (1 - p)
+            dz1 = dz2 * w2 * h * (1 - h)
+            gsend[ro:ro + K] += dz2 * h
+            gsend[so] += dz2
+            for key in kept:
+                r0, _ = where(key)
+                gsend[r0:r0 + K] += s * dz1
+            gv[u] = gv.get(u, 0) + dz1
+            gb += dz1
         for u, g in gv.items():
             self._update('V', u, g, b_norm)
-        return torch.from_numpy(gc), torch.from_numpy(gb2c)
+        for (k0, f0, s0), c in zip(offs, P['counts']):              # the sentinel rows: bias gradient, loss sum
+            i = int(c) - 1
+            gsend[f0 + i * self.ld:f0 + (i + 1) * self.ld] = gb
+            gsend[s0 + i] = loss
+        return torch.from_numpy(gsend)
 
-    def apply(self, recv_keys, recv_rows, recv_b2, b_norm, opt, recv_counts=None):
-        k, r, s = recv_keys.numpy(), recv_rows.numpy(), recv_b2.numpy()
+    def apply(self, req, grecv, recv_counts, table, b_norm, opt, want_loss=False, own=None):
+        k, g = req.numpy(), grecv.numpy()
         tot, tots = {}, {}
-        for i, key in enumerate(k):              # arrival order = source-rank order
-            tot[int(key)] = tot.get(int(key), 0) + r[i]
-            tots[int(key)] = tots.get(int(key), 0) + s[i]
+        gb, loss = np.zeros(self.k), 0.0
+        offs = _chunk_offsets(recv_counts, self.ld, self._skip(), self.world)
+        k0 = 0
+        for s, (ch, c) in enumerate(zip(offs, recv_counts)):       # segment order = micro-batch, then source rank
+            if ch is None:                                          # the chunk this rank "sent" to itself: still in its own buffer
+                og, sc_ = own[s // self.world]
+                src = og.numpy()
+                f0 = sum(self.xsplits(sc_))
+                s0 = f0 + int(c) * self.ld
+            else:
+                src, (_, f0, s0) = g, ch
+            for i in range(int(c)):
+                key = int(k[k0 + i])
+                row, sc = src[f0 + i * self.ld:f0 + (i + 1) * self.ld], src[s0 + i]
+                if key == NONE:
+                    gb, loss = gb + row, loss + sc
+                else:
+                    tot[key] = tot.get(key, 0) + row
+                    tots[key] = tots.get(key, 0) + sc
+            k0 += int(c)
         for key in sorted(tot):
             is_out, row = self._local(key)
             self._update('W2T' if is_out else 'W', row, tot[key], b_norm)
             if is_out:
                 self._update('b2', row, tots[key], b_norm, reg=False)
-
-    def bias_grad(self, B, ctx):
-        return torch.from_numpy(np.concatenate([ctx['dz1'].sum(axis=0), [ctx['lossb'].sum()]]))
-
-    def bias_apply(self, grad, b_norm, opt):
-        self._update('b', slice(None), grad.numpy()[:self.k], b_norm, reg=False)
+        self._update('b', slice(None), gb, b_norm, reg=False)
+        return loss / b_norm if want_loss else None

@@ -35,7 +35,7 @@ def _problem(world=2):
     return p, indptr, indices, batches
 
 
-def _worker(rank, world, rdzv, out, pipelined=False, micro=1):
+def _worker(rank, world, rdzv, out, pipelined=False, micro=1, bypass=True):
     dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     from drecpy_amd.dist import ShardedCdae
     from dist_ops_numpy import NumpyShardOps, np_batch
@@ -43,7 +43,7 @@ def _worker(rank, world, rdzv, out, pipelined=False, micro=1):
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
-    ops = NumpyShardOps(hi - lo, N, K, rank, world, lip, lidx, 0.05, 1e-3)
+    ops = NumpyShardOps(hi - lo, N, K, rank, world, lip, lidx, 0.05, 1e-3, self_bypass=bypass)
     m = ShardedCdae(U, N, K, rank, world, 'cpu', lip, lidx, ops=ops, q=Q)
     m.set_params_global(**p)
     losses = []
@@ -67,14 +67,16 @@ def _worker(rank, world, rdzv, out, pipelined=False, micro=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined,micro,world', [(False, 1, 2), (True, 1, 2), (True, 2, 2), (False, 3, 2), (True, 1, 3), (True, 2, 4)])
-def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, world):
+@pytest.mark.parametrize('pipelined,micro,world,bypass', [(False, 1, 2, True), (True, 1, 2, True), (True, 2, 2, True), (False, 3, 2, False),
+                                                          (True, 1, 3, True), (True, 2, 4, True), (True, 1, 2, False), (True, 2, 3, False)])
+def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, world, bypass):
     """micro > 1: every rank's batch is split into micro-batches with disjoint users whose exchanges overlap each other's
-    compute; the step must still equal the single-process step on the concatenated batch."""
+    compute; the step must still equal the single-process step on the concatenated batch.  bypass: a rank's own rows never pass
+    through the collectives (split size 0 for itself); off: every row travels."""
     from oracle import cdae_oracle as co
     out = str(tmp_path / 'shard')
     rdzv = new_rendezvous(tmp_path)
-    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro, bypass), nprocs=world, join=True)
     p, indptr, indices, batches = _problem(world)
     st = co.sparse_state(p, 'adagrad')
     want_losses = []

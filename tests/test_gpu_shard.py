@@ -62,13 +62,13 @@ def _oracle(world, micro=1):
     return p, losses
 
 
-def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1):
+def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1, bypass=True):
     from drecpy_amd.dist import ShardedCdae
     p, indptr, indices, batches = _problem(world)
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
-    m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force)
+    m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force, self_bypass=bypass)
     m.set_params_global(**p)
     losses, made = [], {}
 
@@ -106,45 +106,49 @@ def _check(world, results, micro=1):
         np.testing.assert_allclose(losses, want_losses, rtol=1e-5)
 
 
+@pytest.mark.parametrize('bypass', [True, False])
 @pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2)])
-def test_sharded_world1_matches_oracle(pipelined, micro):
-    _check(1, [_run_rank(0, 1, False, pipelined=pipelined, micro=micro)], micro)
+def test_sharded_world1_matches_oracle(pipelined, micro, bypass):
+    """bypass: the rank's own rows are read from its tables and its own gradient chunk stays where the reduction left it
+    (DRX_SHARD_SELF_BYPASS) — at world 1 that is every row; off: every row goes through gather / exchange buffer / cache."""
+    _check(1, [_run_rank(0, 1, False, pipelined=pipelined, micro=micro, bypass=bypass)], micro)
 
 
-def _worker(rank, world, rdzv, out, pipelined=False, micro=1):
+def _worker(rank, world, rdzv, out, pipelined=False, micro=1, bypass=True):
     dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
-    res = _run_rank(rank, world, True, pipelined=pipelined, micro=micro)
+    res = _run_rank(rank, world, True, pipelined=pipelined, micro=micro, bypass=bypass)
     torch.save(res, f'{out}.{rank}')
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined,micro,world', [(False, 1, 2), (True, 1, 2), (True, 2, 2), (True, 1, 3)])
+@pytest.mark.parametrize('pipelined,micro,world,bypass', [(False, 1, 2, True), (True, 1, 2, True), (True, 2, 2, True), (True, 1, 3, True),
+                                                          (True, 1, 2, False), (True, 2, 3, False)])
 @retry_infra
-def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro, world):
+def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro, world, bypass):
     """`world` processes share the one GPU of the box (gloo + host-staged exchanges); world 3 splits 411 items unevenly."""
     out = str(tmp_path / 'shard')
     rdzv = new_rendezvous(tmp_path)
-    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro, bypass), nprocs=world, join=True)
     _check(world, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)], micro)
 
 
-def _worker_rccl(rank, rdzv, out, pipelined, micro):
+def _worker_rccl(rank, rdzv, out, pipelined, micro, bypass=True):
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', init_method=rdzv, rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    res = _run_rank(0, 1, False, force=True, pipelined=pipelined, micro=micro)
+    res = _run_rank(0, 1, False, force=True, pipelined=pipelined, micro=micro, bypass=bypass)
     torch.save(res, f'{out}.0')
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined,micro', [(False, 1), (True, 1), (True, 2)])
-def test_sharded_step_through_rccl_world1(tmp_path, pipelined, micro):
+@pytest.mark.parametrize('pipelined,micro,bypass', [(False, 1, False), (True, 1, False), (True, 2, False), (True, 1, True)])
+def test_sharded_step_through_rccl_world1(tmp_path, pipelined, micro, bypass):
     """The N-rank call sequence (count / key / row / gradient all-to-all(v), bias all-reduce) on a real 1-rank RCCL
     communicator: device int32 and float32 buffers, uneven-split API, stream ordering with the drx kernels."""
     out = str(tmp_path / 'rccl')
     rdzv = new_rendezvous(tmp_path)
-    mp.spawn(_worker_rccl, args=(rdzv, out, pipelined, micro), nprocs=1, join=True)
+    mp.spawn(_worker_rccl, args=(rdzv, out, pipelined, micro, bypass), nprocs=1, join=True)
     _check(1, [torch.load(f'{out}.0', weights_only=False)], micro)
 
 
