@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+L2_GATHER_GBS = 17000.0      # indexed rows shared by every workgroup, served by the XCDs' L2 (guide: 16.8-18.8 TB/s chip-wide)
+MALL_GATHER_GBS = 8600.0     # uniformly random rows of a 38 MB table, served by the Infinity Cache (guide: 8.6 TB/s)
 K = 128
 Q = 0.2
 NEG_RATIO = 5
@@ -365,8 +367,19 @@ def byte_model(st, k, S, fused_solo, fused_solo_w=False, n_users=None, n_items=N
     fwd = row * gather_rows + row * (B + (B - solo_O)) + row * (solo_V + solo_O + solo_W) * (1 + 2 * S) + 4.0 * st['history_items'] + 40.0 * B
     n_touch = st['occ_W'] - solo_W + (B - solo_V) + (B - solo_O)
     red = row * (st['dist_W'] - solo_W + st['dist_V'] - solo_V + st['dist_O'] - solo_O) * (2 + 2 * S) + 8.0 * n_touch
+    # STRICTLY NECESSARY bytes: every gathered row counted once per DISTINCT row whatever the table's size — what
+    # must cross the HBM interface even with a perfect cache.  The headline `frac` is priced on these: it can never exceed the
+    # fraction the PMC counters support (r03: the per-occurrence model gave the forward kernel 0.71 against 0.52 of counted traffic).
+    fwd_nec = fwd - row * (gather_rows - (st['dist_W'] + st['dist_V'] + st['dist_O']))
+    # REQUESTED bytes, cache level: what the kernels ask of L2 / the Infinity Cache — one row per occurrence in the forward kernel,
+    # one gradient row per touch in the reduction, on top of their HBM bytes (for cache-resident shapes this is the binding traffic)
+    fwd_req = fwd_nec + row * (st['occ_W'] + 2 * B - (st['dist_W'] + st['dist_V'] + st['dist_O']))
+    red_req = red + row * n_touch
     return {'k_sampled_fwd_bwd': fwd, 'k_seg_reduce': red, 'cache_bytes_k_seg_reduce': row * n_touch,
-            'cache_bytes_k_sampled_fwd_bwd': row * (st['occ_W'] + 2 * B - gather_rows)}
+            'cache_bytes_k_sampled_fwd_bwd': row * (st['occ_W'] + 2 * B - gather_rows),
+            'necessary_k_sampled_fwd_bwd': fwd_nec, 'necessary_k_seg_reduce': red,
+            'requested_k_sampled_fwd_bwd': fwd_req, 'requested_k_seg_reduce': red_req,
+            'cache_resident': not big_items and not big_users}
 
 
 def kernel_source_hash():
@@ -790,7 +803,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     # these very kernel sources (scripts/profile_round.sh stores their hash); rocprofv3 cannot run inside the bench itself.
     traffic_of, traffic_note = {}, 'no PMC profile for this workload'
     try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json' if args.workload == 'synth-10m' else f'pmc_traffic_{args.workload}.json')) as f:
             pmc = json.load(f)
         m = pmc['_meta']
         if m['workload'] == args.workload and m['batch_per_gpu'] == B and m['n_gpus'] == world and not args.users and K == 128 \
@@ -837,14 +850,22 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         # cross the HBM interface at least once; everything re-read is assumed cached).  `model_*` = SURVEY 8d's
         # per-OCCURRENCE model (charges a read-modify-write per touch: the kernel merges touches first, so it can exceed 1).
         per_kernel = {}
+        bpl = dedup['bytes_per_launch']
         for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
-            byt, ms_ = dedup['bytes_per_launch'][kn], ms_of[kn]
+            byt, occ, req, ms_ = bpl['necessary_' + kn], bpl[kn], bpl['requested_' + kn], ms_of[kn]
             kname = kn if kn != 'k_seg_reduce' else 'k_seg_reduce_planned'
-            per_kernel[kname] = {'bytes_per_launch': byt, 'avg_launch_ms': ms_, 'achieved': byt / (ms_ * 1e-3) / 1e9,
-                                 'frac': byt / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            rate = lambda b_: b_ / (ms_ * 1e-3) / 1e9
+            per_kernel[kname] = {'bytes_per_launch': byt, 'avg_launch_ms': ms_, 'achieved': rate(byt), 'frac': rate(byt) / HBM_PEAK_GBS,
+                                 'per_occurrence_bytes': occ, 'per_occurrence_frac': rate(occ) / HBM_PEAK_GBS,
                                  'traffic': traffic_of.get(kname),
-                                 'traffic_frac': (traffic_of[kname] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS) if kname in traffic_of else None}
-        step_bytes = dedup['bytes_per_launch']['k_sampled_fwd_bwd'] + dedup['bytes_per_launch']['k_seg_reduce']
+                                 'traffic_frac': (rate(traffic_of[kname]) / HBM_PEAK_GBS) if kname in traffic_of else None,
+                                 # cache level: the rows the kernel REQUESTS (one per occurrence / per touch), against the guide's gather rates
+                                 'requested_bytes': req, 'requested_GBs': rate(req),
+                                 'requested_frac_of_l2_gather': rate(req) / L2_GATHER_GBS,
+                                 'requested_frac_of_infinity_cache': rate(req) / MALL_GATHER_GBS}
+        step_bytes = bpl['necessary_k_sampled_fwd_bwd'] + bpl['necessary_k_seg_reduce']
+        step_occ = bpl['k_sampled_fwd_bwd'] + bpl['k_seg_reduce']
+        step_req = bpl['requested_k_sampled_fwd_bwd'] + bpl['requested_k_seg_reduce']
         step_traffic = sum(traffic_of.get(kn, 0.0) for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned', 'k_span_planned')) or None
         dk = per_kernel[dom]
         out['roofline'] = {
@@ -859,14 +880,25 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
             'cache_bytes_k_sampled_fwd_bwd': dedup['bytes_per_launch']['cache_bytes_k_sampled_fwd_bwd'],
             'whole_step_bytes': step_bytes, 'whole_step_achieved': step_bytes / step_s / 1e9,
             'whole_step_frac': step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+            'whole_step_per_occurrence_frac': step_occ / step_s / 1e9 / HBM_PEAK_GBS,
+            'cache_resident': bpl['cache_resident'],
+            'cache_level': {'requested_bytes_per_step': step_req, 'requested_GBs': step_req / step_s / 1e9,
+                            'frac_of_l2_gather': step_req / step_s / 1e9 / L2_GATHER_GBS, 'l2_gather_peak': L2_GATHER_GBS,
+                            'frac_of_infinity_cache': step_req / step_s / 1e9 / MALL_GATHER_GBS, 'infinity_cache_peak': MALL_GATHER_GBS,
+                            'note': 'rows the kernels request from L2 / Infinity Cache (one per occurrence, one gradient row per touch) over the '
+                                    'whole step; for a cache-resident model (MovieLens shapes) this, not HBM, is the binding traffic: peaks = '
+                                    'MI355X_MICROARCH.md "Indexed rows": rows shared by every workgroup 16.8-18.8 TB/s (L2), 38 MB table of '
+                                    'random rows 8.6 TB/s (Infinity Cache)'},
             'whole_step_traffic': step_traffic,
             'whole_step_traffic_frac': (step_traffic / step_s / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
             'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
             'model_whole_step_frac': step_alg / step_s / 1e9 / HBM_PEAK_GBS,
             'hbm_copy_achievable': copy_gbs,
-            'definition': 'frac = dedup-aware algorithmic HBM bytes (bench.py:byte_model: one gather read per occurrence — per distinct row where the table fits the 256 MiB Infinity Cache —, dz1/g2 written once, '
-                          'one read-modify-write of parameter + slots per DISTINCT row, gradient re-reads assumed cached) / HIP-event launch time / 8 TB/s; '
-                          'traffic = PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; counts Infinity-Cache hits); model_* = SURVEY 8d per-occurrence bytes'}
+            'definition': 'frac = STRICTLY NECESSARY HBM bytes (bench.py:byte_model: every gathered row once per DISTINCT row, dz1/g2 written once, one '
+                          'read-modify-write of parameter + slots per DISTINCT row, 8 B per touch; everything re-read assumed cached) / HIP-event '
+                          'launch time / 8 TB/s — never above traffic_frac; per_occurrence_* = one gather read per occurrence where the table '
+                          'exceeds the 256 MiB Infinity Cache (the r01-r03 headline); traffic = PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; '
+                          'counts Infinity-Cache hits); requested_* = cache-level rows; model_* = SURVEY 8d per-occurrence read-modify-write bytes'}
     else:
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
                            'traffic': None, 'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,

@@ -168,7 +168,9 @@ def configs_block(dev, run_direct, base_args, with_cpu=True):
         out['cfg2_cdae_ml1m_sampled'] = {
             'value': r['value'], 'unit': 'samples/s', 'ms_per_step': r['ms_per_step'], 'batch': r['config']['batch_per_gpu'],
             'workload': r['config']['workload'], 'phases_ms': r['phases_ms'],
-            'roofline': {k_: r['roofline'].get(k_) for k_ in ('kernel', 'frac', 'achieved', 'whole_step_frac', 'kernels', 'cache_bytes_k_seg_reduce', 'cache_bytes_k_sampled_fwd_bwd')}
+            'roofline': {k_: r['roofline'].get(k_) for k_ in ('kernel', 'frac', 'achieved', 'whole_step_frac', 'whole_step_per_occurrence_frac', 'kernels', 'cache_bytes_k_seg_reduce',
+                                                                        'cache_bytes_k_sampled_fwd_bwd', 'cache_resident', 'cache_level', 'traffic', 'traffic_source',
+                                                                        'whole_step_traffic', 'whole_step_traffic_frac')}
             if r.get('roofline') else None,
             'cpu_baseline': r.get('cpu_baseline')}
     except Exception as e:                                      # noqa: BLE001

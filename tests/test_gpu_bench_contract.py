@@ -31,7 +31,15 @@ def test_bench_line_has_the_contracted_fields():
     assert 0.0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert r['traffic'] is None or r['traffic'] > 0                                       # (PMC passes are of the 10M x 1M workload)
     for k in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned'):
-        assert 0.0 < r['kernels'][k]['frac'] <= 1.0 and r['kernels'][k]['avg_launch_ms'] > 0
+        kr = r['kernels'][k]
+        assert 0.0 < kr['frac'] <= 1.0 and kr['avg_launch_ms'] > 0
+        # the headline fraction is priced on the strictly necessary bytes: never above the per-occurrence reading, never above what
+        # the counters support, never above the rows the kernel requests at cache level
+        assert kr['frac'] <= kr['per_occurrence_frac'] * (1 + 1e-9) and kr['bytes_per_launch'] <= kr['requested_bytes']
+        assert kr['traffic_frac'] is None or kr['frac'] <= kr['traffic_frac'] * 1.05
+        assert kr['requested_frac_of_l2_gather'] > 0 and kr['requested_frac_of_infinity_cache'] > kr['requested_frac_of_l2_gather']
+    assert r['whole_step_frac'] <= r['whole_step_per_occurrence_frac'] * (1 + 1e-9)
+    assert r['cache_resident'] is True and r['cache_level']['requested_GBs'] > r['whole_step_achieved']      # ml-100k shape: all in cache
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and c['unit'] == 'samples/s' and c['sample']
     a = d['cpu_baseline_all_cores']
@@ -42,6 +50,8 @@ def test_bench_line_has_the_contracted_fields():
     assert c2['value'] > 0 and c2['unit'] == 'samples/s' and 0.0 < c2['roofline']['frac'] <= 1.0 and c2['cpu_baseline']['value'] > 0
     for k in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned'):
         assert 0.0 < c2['roofline']['kernels'][k]['frac'] <= 1.0
+    # the ml-1m model is cache-resident: its line carries the cache-level reading (rows requested from L2 / Infinity Cache)
+    assert c2['roofline']['cache_resident'] is True and 0.0 < c2['roofline']['cache_level']['frac_of_l2_gather'] < 1.5
     c3 = g['cfg3_dmf_ml1m']
     for name in ('DMF_B256', 'DMF_B4096', 'ModifiedDMF_B256', 'ModifiedDMF_B4096'):
         assert c3[name]['step_ms'] > 0 and c3[name]['fit_samples_per_s'] > 0
