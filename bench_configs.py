@@ -101,6 +101,13 @@ def dmf_block(ds, dev):
                                       300, 1500 if B <= 256 else 900)
             out[f'{name}_B{B}'] = {'step_ms': dev_s * 1e3, 'step_samples_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
                                    'fit_steady_ms_per_step': steady * 1e3, 'fit_samples_per_s': B / steady}
+            # throughput mode: triples drawn and prepared on the device, one step ahead (a named deviation, like CDAE's and Caser's)
+            md = cls(user_factors=[64, 32], item_factors=[64, 32], seed=10, verbose=False, device=str(dev))
+            md.fit(ds, epochs=3, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5, device_sampler=True)
+            e2d, steady_d = _fit_steady(lambda n: md.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5,
+                                                         device_sampler=True), 300, 1500 if B <= 256 else 900)
+            out[f'{name}_B{B}_device_sampler'] = {'fit_ms_per_step_incl_setup': e2d * 1e3, 'fit_steady_ms_per_step': steady_d * 1e3,
+                                                  'fit_samples_per_s': B / steady_d, 'sampler': getattr(md, '_sampler_kind', None)}
     # the one MFMA kernel: all-pairs cosine scores of a block of users against every item (k_score_pairs_bf16)
     from drecpy_amd import _lib
     L = _lib.lib()

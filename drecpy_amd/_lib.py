@@ -77,7 +77,8 @@ class DmfArgs(C.Structure):
                [(n, C.c_void_p) for n in ('dz0u', 'dz0i', 'tkeys_u', 'tsrc_u', 'tcoef_u', 'tkeys_i', 'tsrc_i', 'tcoef_i',
                                           'gsw_part', 'loss_part', 'pred_out', 'rep_u_out', 'rep_i_out', 'work', 'inv_u', 'inv_i',
                                           'gptr_u', 'gptr_i', 'grows_u', 'grows_i')] + [('n_du', C.c_int32), ('n_di', C.c_int32)] + \
-               [(n, C.c_void_p) for n in ('map_u', 'map_i', 'rho_u', 'rho_i')] + [('stamp', C.c_uint32)]
+               [(n, C.c_void_p) for n in ('map_u', 'map_i', 'rho_u', 'rho_i')] + [('stamp', C.c_uint32)] + \
+               [(n, C.c_void_p) for n in ('nd_dev', 'y_mean_dev')]
 
 
 class DmfK0Update(C.Structure):
@@ -128,6 +129,11 @@ SIGNATURES = {
     'drx_point_sample_recorded': (C.c_int, [C.POINTER(History), C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                    C.c_void_p]),
+    'drx_point_sample_valued': (C.c_int, [C.POINTER(History), C.POINTER(History), C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'drx_dmf_distinct_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'drx_dmf_batch_distinct_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10 +
+                                      [C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_shard_prep_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32, C.c_int32]),
     'drx_shard_work_bytes': (C.c_size_t, [C.POINTER(Shard)]),
     'drx_shard_prep_layout': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * WV) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
       } else {
         // target_mode 1: Keras BCE of (B,) targets against (B,1) predictions broadcasts to (B,B); its mean equals the BCE
         // against the batch-mean target because the element is affine in t
-        const float y = A.target_mode == 1 ? A.y_mean : A.y[b];
+        const float y = A.target_mode == 1 ? (A.y_mean_dev ? A.y_mean_dev[0] : A.y_mean) : A.y[b];
         loss_acc += bce_elem(y, pred);
         const float gp = bce_grad(y, pred) * inv_b;
         if (D.off_scale >= 0 && k == 0) gsw[D.off_scale] = fmaf(gp, cosv, gsw[D.off_scale]);
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
   TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
   Tu.rho = A.rho_u; Ti.rho = A.rho_i;
-  const int total = A.n_du + A.n_di;
+  const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du, total = n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
   for (int it = blockIdx.x; it < total; it += gridDim.x) {
-    const int tw = it < A.n_du ? 0 : 1, d = tw ? it - A.n_du : it;
+    const int tw = it < n_du ? 0 : 1, d = tw ? it - n_du : it;
     if (tw) tower_gather_q<WV>(D, 1, Ti, d, k, w, part + w * 64); else tower_gather_q<WV>(D, 0, Tu, d, k, w, part + w * 64);
     if (A.map_u && threadIdx.x == 0) {               // for k_dmf_k0_update: which distinct index this id has in THIS step
       const int id = tw ? A.iid[d] : A.uid[d];
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
 __global__ __launch_bounds__(256) void k_dmf_dzsum(DrxDmfDims D, DrxDmfArgs A) {
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
   const DmfWork Wk = dmf_work(A.work, A.B);
-  const int total = A.n_du + A.n_di;
+  const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du, total = n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
   for (int it = blockIdx.x * 4 + w; it < total; it += gridDim.x * 4) {
-    const int tw = it < A.n_du ? 0 : 1, d = tw ? it - A.n_du : it;
+    const int tw = it < n_du ? 0 : 1, d = tw ? it - n_du : it;
     const int32_t *gp = tw ? A.gptr_i : A.gptr_u, *gr = tw ? A.grows_i : A.grows_u;
     float acc = 0.f;
     for (int q = gp[d]; q < gp[d + 1]; ++q) acc += Wk.dz[((size_t)tw * A.B + gr[q]) * kDmfMaxLayers * 64 + k];
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_dmf_dense(DrxDmfDims D, DrxDmfArgs A) {
     const float cosv = fmaxf(1e-6f, s);
     const float wsc = D.off_scale >= 0 ? swl[D.off_scale] : 1.0f;
     const float pred = wsc * cosv;
-    const float y = A.target_mode == 1 ? A.y_mean : A.y[b];
+    const float y = A.target_mode == 1 ? (A.y_mean_dev ? A.y_mean_dev[0] : A.y_mean) : A.y[b];
     const float gp = bce_grad(y, pred) * inv_b;
     if (k == 0) { Wk.samp[(size_t)b * 2] = bce_elem(y, pred); Wk.samp[(size_t)b * 2 + 1] = gp * cosv; }
     const float ds = s > 1e-6f ? gp * wsc : 0.f;
@@ -640,11 +640,104 @@ static int check_dims(const DrxDmfDims *D) {
   return (size_t)D->n_small * 4 <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
 }
 
+// ---- distinct ids of a batch on the device (DMF.fit(device_sampler=True)) --------------------------------------------------------
+// keys: users [0, U), items U + iid; vals: the sample (items: B + sample).  After ONE stable sort the B user pairs come first, every
+// id's samples ascending — grows IS the sorted sample column.
+static __global__ void k_distinct_keys(const int32_t *__restrict__ uid, const int32_t *__restrict__ iid, int B, int n_users,
+                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * B; j += gridDim.x * blockDim.x) {
+    keys[j] = j < B ? (uint32_t)uid[j] : (uint32_t)n_users + (uint32_t)iid[j - B];
+    vals[j] = (uint32_t)j;
+  }
+}
+
+// ONE workgroup numbers the runs of the sorted list: threads [0, 512) share the user half, [512, 1024) the item half, a contiguous
+// slice each — heads counted, block-scanned, then slots handed out in a second walk.  Also the batch mean of y, summed in a fixed order.
+static __global__ __launch_bounds__(1024) void k_distinct_number(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B,
+                                                                 int n_users, const float *__restrict__ y, int32_t *du, int32_t *di,
+                                                                 int32_t *inv_u, int32_t *inv_i, int32_t *gptr_u, int32_t *gptr_i,
+                                                                 int32_t *grows_u, int32_t *grows_i, int32_t *nd, float *y_mean) {
+  __shared__ int wsum[16];
+  __shared__ double red[16];
+  const int t = threadIdx.x, half = t >> 9, th = t & 511, lane = t & 63, w = t >> 6;
+  const int per = (B + 511) / 512;
+  const int lo = half * B + min(B, th * per), hi = half * B + min(B, (th + 1) * per);
+  int heads = 0;
+  for (int j = lo; j < hi; ++j) heads += (j == half * B || ks[j] != ks[j - 1]) ? 1 : 0;
+  int inc = heads;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int before = inc - heads, n_half[2] = {0, 0};
+  for (int ww = 0; ww < 16; ++ww) {
+    if ((ww >> 3) == half && ww < w) before += wsum[ww];
+    n_half[ww >> 3] += wsum[ww];
+  }
+  int32_t *const dd = half ? di : du, *const inv = half ? inv_i : inv_u, *const gp = half ? gptr_i : gptr_u, *const gr = half ? grows_i : grows_u;
+  int slot = before - 1;
+  for (int j = lo; j < hi; ++j) {
+    const uint32_t k = ks[j];
+    const int jl = j - half * B, b = (int)vs[j] - half * B;
+    if (j == half * B || k != ks[j - 1]) { ++slot; dd[slot] = (int32_t)(k - (half ? (uint32_t)n_users : 0u)); gp[slot] = jl; }
+    inv[b] = slot;
+    gr[jl] = b;
+  }
+  if (th == 0) { gp[n_half[half]] = B; nd[half] = n_half[half]; }
+  double a = 0.0;                                  // (fp64: the host path hands the kernels float(mean in fp64))
+  for (int b = t; b < B; b += 1024) a += (double)y[b];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+  if (lane == 0) red[w] = a;
+  __syncthreads();
+  if (t == 0) { double s = 0.0; for (int ww = 0; ww < 16; ++ww) s += red[ww]; y_mean[0] = (float)(s / (double)B); }
+}
+
+struct DistinctLayout { uint32_t *keys, *vals, *ks, *vs; void *sort_temp; size_t sort_bytes; int bits; };
+static DistinctLayout distinct_layout(Carver &cv, int B, int n_users, int n_items) {
+  DistinctLayout L{};
+  L.bits = bits_for((uint64_t)n_users + (uint64_t)n_items + 1);
+  L.keys = cv.take<uint32_t>((size_t)2 * B); L.vals = cv.take<uint32_t>((size_t)2 * B);
+  L.ks = cv.take<uint32_t>((size_t)2 * B); L.vs = cv.take<uint32_t>((size_t)2 * B);
+  L.sort_bytes = sort_pairs_temp_bytes((size_t)2 * B, L.bits);
+  L.sort_temp = cv.take<char>(L.sort_bytes);
+  return L;
+}
+
 }  // namespace drx
 
 using namespace drx;
 
 extern "C" {
+
+size_t drx_dmf_distinct_scratch_bytes(int32_t B, int32_t n_users, int32_t n_items) {
+  if (B < 1 || n_users < 1 || n_items < 1) return 0;
+  Carver cv(nullptr, 0);
+  (void)distinct_layout(cv, B, n_users, n_items);
+  return align_up(cv.off, 256) + 256;
+}
+
+int drx_dmf_batch_distinct_device(const int32_t *uid, const int32_t *iid, const float *y, int32_t B, int32_t n_users, int32_t n_items,
+                                  int32_t *du, int32_t *di, int32_t *inv_u, int32_t *inv_i, int32_t *gptr_u, int32_t *gptr_i,
+                                  int32_t *grows_u, int32_t *grows_i, int32_t *nd, float *y_mean, void *scratch, size_t scratch_bytes,
+                                  void *stream) {
+  if (!uid || !iid || !y || !du || !di || !inv_u || !inv_i || !gptr_u || !gptr_i || !grows_u || !grows_i || !nd || !y_mean || !scratch ||
+      B < 1 || B > (1 << 20) || n_users < 1 || n_items < 1 || (int64_t)n_users + n_items >= 0x7FFFFFFFll)
+    return DRX_EINVAL;
+  Carver cv(scratch, scratch_bytes);
+  const DistinctLayout L = distinct_layout(cv, B, n_users, n_items);
+  if (!cv.ok()) return DRX_ESCRATCH;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_distinct_keys, dim3((2 * B + 255) / 256 < 1024 ? (2 * B + 255) / 256 : 1024), dim3(256), 0, st, uid, iid, B, n_users,
+                     L.keys, L.vals);
+  const int rc = sort_pairs(L.sort_temp, L.sort_bytes, L.keys, L.ks, L.vals, L.vs, (size_t)2 * B, L.bits, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_distinct_number, dim3(1), dim3(1024), 0, st, L.ks, L.vs, B, n_users, y, du, di, inv_u, inv_i, gptr_u, gptr_i,
+                     grows_u, grows_i, nd, y_mean);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
 
 // number of batch chunks of k_dmf_wgrad = rows of gsw_part / entries of loss_part the caller provides
 // (16 samples per chunk up to 256 chunks: a thread of k_dmf_wgrad walks its chunk serially, two strided loads per sample — 64-sample
@@ -678,6 +771,7 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   if (!A->inv_u || !A->inv_i || !A->gptr_u || !A->gptr_i || !A->grows_u || !A->grows_i || A->n_du < 1 || A->n_di < 1 || A->n_du > A->B ||
       A->n_di > A->B)
     return DRX_EINVAL;
+  if (A->target_mode == 1 && A->nd_dev && !A->y_mean_dev) return DRX_EINVAL;      // a device-prepared batch knows its mean only there
   const int wv = dmf_waves(A->n_du + A->n_di);
   const int items = A->n_du + A->n_di;
   const int ggrid = items < 8192 ? items : 8192;

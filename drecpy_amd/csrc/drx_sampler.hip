@@ -19,15 +19,17 @@ __device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return (ui
 // whatever value a recorded pair carries) — the positives' CSR itself where every recorded pair is a positive
 __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, DrxHistory PR, int n_users, int n_items, int B, int neg_ratio,
                                                          uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *deg,
-                                                         int32_t *keep_off, int *sub_sums) {
+                                                         int32_t *keep_off, int *sub_sums, const float *__restrict__ values, float vmin,
+                                                         float vrange) {
   __shared__ int wsum[kBlock / 64];
   const int b = blockIdx.x * kBlock + threadIdx.x;
   int my_deg = 0;
   if (b < B) {
-  if (b == 0) keep_off[0] = 0;                 // the scan below fills keep_off[1..B]
+  if (b == 0 && keep_off) keep_off[0] = 0;     // the scan below fills keep_off[1..B]
   const uint32_t r0 = hash_u32(seed, (uint32_t)b, 0u);
   const bool null_pair = ((double)r0 * (1.0 / 4294967296.0)) * (double)(neg_ratio + 1) > 1.0;
   int u = 0, i = 0;
+  float val = 1.0f;
   uint32_t c = 1;
   for (int tries = 0; tries < 4096; ++tries) {
     u = (int)bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)n_users);
@@ -43,15 +45,18 @@ __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, DrxHistor
       if (lo == pe || PR.indices[lo] != i) break;
     } else {
       if (e == s) continue;
-      i = H.indices[s + bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)(e - s))];
+      const int64_t at = s + bounded(hash_u32(seed, (uint32_t)b, c++), (uint32_t)(e - s));
+      i = H.indices[at];
+      // value-carrying draw (DMF: the target is the pair's interaction value, standardised as recommender_abc.py:463-465)
+      if (values) val = vrange > 0.f ? (values[at] - vmin) / vrange : values[at];
       break;
     }
   }
   uid[b] = u;
   iid[b] = i;
-  y[b] = null_pair ? 0.0f : 1.0f;
+  y[b] = null_pair ? 0.0f : val;
   my_deg = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
-  deg[b] = my_deg;
+  if (deg) deg[b] = my_deg;
   }
   // the workgroup's degree sum (the scan's first level: one launch less on the preparation's stream)
   if (sub_sums) {
@@ -237,9 +242,23 @@ extern "C" int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistor
   int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
   int *sub = tsum + 128;
   hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, recorded ? *recorded : *hist, n_users, n_items, B, neg_ratio,
-                     seed, uid, iid, y, deg, keep_off, sub);
+                     seed, uid, iid, y, deg, keep_off, sub, nullptr, 0.f, 0.f);
   hipLaunchKernelGGL(k_deg_apply_sub, dim3(n_tiles), dim3(1024), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
                      (unsigned long long *)host_mailbox, tag);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+extern "C" int drx_point_sample_valued(const DrxHistory *hist, const DrxHistory *recorded, const float *pos_values, float vmin,
+                                       float vrange, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio, uint64_t seed,
+                                       int32_t *uid, int32_t *iid, float *y, void *stream) {
+  using namespace drx;
+  if (recorded && (!recorded->indptr || !recorded->indices)) return DRX_EINVAL;
+  if (!hist || !hist->indptr || !hist->indices || !pos_values || !uid || !iid || !y || B < 1 || n_users < 1 || n_items < 1 || neg_ratio < 0)
+    return DRX_EINVAL;
+  hipLaunchKernelGGL(k_point_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, *hist,
+                     recorded ? *recorded : *hist, n_users, n_items, B, neg_ratio, seed, uid, iid, y, (int32_t *)nullptr,
+                     (int32_t *)nullptr, (int *)nullptr, pos_values, vmin, vrange);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

@@ -214,6 +214,60 @@ class DmfEngine:
         return {'buf': buf, 'offs': offs, 'B': B, 'n_du': nd[0], 'n_di': nd[1], 'Tu': int(off_u[-1]), 'Ti': int(off_i[-1]),
                 'y_mean': float(y32.astype(np.float64).mean())}
 
+    # ---- batches drawn and prepared ON THE DEVICE (DMF.fit(device_sampler=True): throughput mode) --------------------------------
+    def set_sampler_frame(self, positives, recorded, vmin, vrange):
+        """positives = (indptr, indices, values) of the pairs a positive draw may return (interaction >= threshold) with their
+        values; recorded = (indptr, indices) of every pair the frame holds (a negative is a pair absent from it) or None when all
+        recorded pairs are positives; vmin / vrange: the standardisation of recommender_abc.py:463-465 (vrange 0 = raw values)."""
+        d = self.device
+        ip, idx, val = positives
+        self._pos = (torch.as_tensor(np.asarray(ip, np.int64)).to(d), torch.as_tensor(np.asarray(idx, np.int32)).to(d),
+                     torch.as_tensor(np.asarray(val, np.float32)).to(d))
+        self._rec = None
+        if recorded is not None:
+            self._rec = (torch.as_tensor(np.asarray(recorded[0], np.int64)).to(d), torch.as_tensor(np.asarray(recorded[1], np.int32)).to(d))
+        self._vstd = (float(vmin), float(vrange))
+        self._dev_ring, self._dev_i = {}, 0
+
+    def _ensure_dev_ring(self):
+        if not hasattr(self, '_dev_ring'):
+            self._dev_ring, self._dev_i = {}, 0
+
+    def prepare_batch_device(self, B, neg_ratio, seed, triples=None):
+        """One batch drawn by the device PointSampler (drx_point_sample_valued: the reference sampler's distribution, a counter-based
+        stream) and prepared there (drx_dmf_batch_distinct_device) on the CURRENT stream — DMF.fit() runs it one step ahead on a side
+        stream.  Returns what step() takes in place of prepare_batch()'s host arrays.  A ring of 3 buffers per batch size: the
+        caller keeps at most two batches in flight.  triples: (uid, iid, y) device tensors to prepare INSTEAD of drawing (tests)."""
+        from ._lib import History
+        L_ = lib()
+        self._ensure_dev_ring()
+        k = self._dev_i % 3
+        self._dev_i += 1
+        slot = self._dev_ring.get((B, k))
+        if slot is None:
+            i32 = dict(dtype=torch.int32, device=self.device)
+            need = int(L_.drx_dmf_distinct_scratch_bytes(B, self.U, self.N))
+            slot = self._dev_ring[(B, k)] = {
+                'ids': torch.empty(2, B, **i32), 'y': torch.empty(B, dtype=torch.float32, device=self.device),
+                'arr': torch.empty(8, B + 4, **i32),          # du, di, inv_u, inv_i, gptr_u, gptr_i, grows_u, grows_i
+                'nd': torch.empty(2, **i32), 'y_mean': torch.empty(1, dtype=torch.float32, device=self.device),
+                'scratch': torch.empty(need, dtype=torch.uint8, device=self.device)}
+        st = stream_ptr(self.device)
+        uid, iid = slot['ids'][0], slot['ids'][1]
+        if triples is not None:
+            uid.copy_(triples[0]); iid.copy_(triples[1]); slot['y'].copy_(triples[2])
+        else:
+            H = History(ptr(self._pos[0]), ptr(self._pos[1]))
+            R = History(ptr(self._rec[0]), ptr(self._rec[1])) if self._rec is not None else None
+            check(L_.drx_point_sample_valued(C.byref(H), C.byref(R) if R is not None else None, ptr(self._pos[2]), self._vstd[0],
+                                             self._vstd[1], self.U, self.N, B, int(neg_ratio), int(seed) & ((1 << 64) - 1), ptr(uid), ptr(iid),
+                                             ptr(slot['y']), st), 'drx_point_sample_valued')
+        a = slot['arr']
+        check(L_.drx_dmf_batch_distinct_device(ptr(uid), ptr(iid), ptr(slot['y']), B, self.U, self.N, *[ptr(a[r]) for r in range(8)],
+                                               ptr(slot['nd']), ptr(slot['y_mean']), ptr(slot['scratch']), slot['scratch'].numel(), st),
+              'drx_dmf_batch_distinct_device')
+        return {'device': slot, 'B': B}
+
     def _upload_batch(self, prepared):
         """Host batch -> device in one asynchronous copy from a pinned ring (so the host can run ahead of the device); returns the
         device buffer and the addresses of the arrays in it."""
@@ -248,10 +302,22 @@ class DmfEngine:
                 uids, iids, y = c(uids), c(iids), c(y)
             uids = self.prepare_batch(uids, iids, y)
         prep = uids
-        alive, ptrs = self._upload_batch(prep)
-        p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri = ptrs
-        B, Tu, Ti = prep['B'], prep['Tu'], prep['Ti']
-        n_du, n_di = prep['n_du'], prep['n_di']
+        on_device = prep.get('device') is not None
+        if on_device:                       # drawn and prepared on the device: the distinct counts and the batch mean live there
+            if self.first_layer_update != 'scan':
+                raise _lib.DrxError('device-prepared DMF batches need the scan update of the first-layer kernels (set_interactions chose '
+                                    '"scatter": more than SCAN_MAX_NNZ interactions)')
+            sl = prep['device']
+            a = sl['arr']
+            p_du, p_di, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri = (a[r].data_ptr() for r in range(8))
+            p_y, p_offu, p_offi = sl['y'].data_ptr(), 0, 0
+            B, Tu, Ti = prep['B'], 0, 0
+            n_du = n_di = B                 # upper bounds: they size the launches; the kernels read nd_dev
+        else:
+            alive, ptrs = self._upload_batch(prep)
+            p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri = ptrs
+            B, Tu, Ti = prep['B'], prep['Tu'], prep['Ti']
+            n_du, n_di = prep['n_du'], prep['n_di']
         ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
         stream = stream_ptr(self.device)
         grid = L_.drx_dmf_grid(B)
@@ -273,9 +339,11 @@ class DmfEngine:
         A.y, A.off_u, A.off_i = p_y, p_offu, p_offi
         A.inv_u, A.inv_i, A.gptr_u, A.gptr_i, A.grows_u, A.grows_i = p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri
         A.n_du, A.n_di = n_du, n_di
+        if on_device:
+            A.nd_dev, A.y_mean_dev = prep['device']['nd'].data_ptr(), prep['device']['y_mean'].data_ptr()
         if self.broadcast_targets and self.scale_var is not None:
             A.target_mode = 1
-            A.y_mean = prep['y_mean']
+            A.y_mean = 0.0 if on_device else prep['y_mean']
         A.dz0u, A.dz0i = dz0u.data_ptr(), dz0i.data_ptr()
         A.rho_u, A.rho_i = self._rho[0].data_ptr(), self._rho[1].data_ptr()
         if scan:

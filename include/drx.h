@@ -183,6 +183,13 @@ int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistory *recorded
                               int32_t neg_ratio, uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
                               void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
 
+/* The same draws carrying VALUES (DMF.fit(device_sampler=True), dmf.py:64-73): y[b] = 0 for a negative, else the drawn pair's
+ * interaction value pos_values[position in hist] — standardised (v - vmin) / vrange when vrange > 0 (use_nce:
+ * recommender_abc.py:463-465), raw otherwise.  No keep_off / mailbox: DMF needs neither. */
+int drx_point_sample_valued(const DrxHistory *hist, const DrxHistory *recorded, const float *pos_values, float vmin, float vrange,
+                            int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio, uint64_t seed, int32_t *uid, int32_t *iid,
+                            float *y, void *stream);
+
 /* ---- device-side list sampler (throughput mode; distribution of list_sampler.py:74-151 as caser.py:72-75 configures it) -----
  * The reference's ListSampler is ONE MT19937 stream: draw d depends on every draw before it, so a reference-exact fit() is bound by
  * one host thread (about 0.5 us per window).  This entry point draws B windows independently with the counter-based generator of
@@ -453,6 +460,10 @@ typedef struct DrxDmfArgs {
    * dataset by drx_dmf_norms: required with the maps, optional otherwise (NULL: drx_dmf_fwd_bwd forms them per batch id) */
   const float *rho_u, *rho_i;
   uint32_t stamp;
+  /* A batch prepared ON THE DEVICE (drx_dmf_batch_distinct_device): the numbers of distinct ids and the batch mean of y are only known
+   * there.  nd_dev [2] = {n_du, n_di} (n_du / n_di above then are upper bounds that size the launches), y_mean_dev [1]; or NULL. */
+  const int32_t *nd_dev;
+  const float *y_mean_dev;
 } DrxDmfArgs;
 /* Host helper for the arrays above: the distinct ids of a batch, ascending.  distinct [<= B], inv [B], gptr [<= B+1], grows [B],
  * off [<= B+1] (prefix sums of indptr row lengths of the distinct ids; NULL to skip) are host arrays;
@@ -460,6 +471,15 @@ typedef struct DrxDmfArgs {
  * ids, or a negative DRX_E* code (an id outside [0, n_rows); DRX_EINVAL when the prefix sums do not fit int32 — touch offsets would overlap). */
 int32_t drx_batch_distinct(const int32_t *ids, int32_t B, int32_t n_rows, const int64_t *indptr, int32_t *scratch, int32_t *distinct,
                            int32_t *inv, int32_t *gptr, int32_t *grows, int32_t *off);
+/* The same on the device, both towers at once, for batches drawn there (DMF.fit(device_sampler=True)): uid / iid / y [B] device
+ * arrays in; du, di [B], inv_u, inv_i [B], gptr_u, gptr_i [B + 1], grows_u, grows_i [B], nd [2] = {distinct users, distinct items},
+ * y_mean [1] out — what DrxDmfArgs wants (uid = du, iid = di, nd_dev = nd, y_mean_dev = y_mean).  One stable sort of the 2B
+ * (id, sample) pairs + one workgroup that numbers the runs.  n_users + n_items < 2^31, B <= 2^20. */
+size_t drx_dmf_distinct_scratch_bytes(int32_t B, int32_t n_users, int32_t n_items);
+int drx_dmf_batch_distinct_device(const int32_t *uid, const int32_t *iid, const float *y, int32_t B, int32_t n_users, int32_t n_items,
+                                  int32_t *du, int32_t *di, int32_t *inv_u, int32_t *inv_i, int32_t *gptr_u, int32_t *gptr_i,
+                                  int32_t *grows_u, int32_t *grows_i, int32_t *nd, float *y_mean, void *scratch, size_t scratch_bytes,
+                                  void *stream);
 /* out[id] = 1 / max(|row id|_2, 1e-6) (1 when l2_norm_vectors == 0) for the n rows of a CSR, with the summation order of the towers */
 int drx_dmf_norms(const DrxDmfDims *D, const int64_t *indptr, const float *values, int32_t n, float *out, void *stream);
 int drx_dmf_grid(int32_t B);      /* rows of gsw_part / entries of loss_part */

@@ -319,3 +319,109 @@ def test_dmf_steps_with_empty_rows_columns_and_repeated_ids(update):
     g = eng.get_params()
     for k in p:
         np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
+
+
+# ---- DMF.fit(device_sampler=True): batches drawn and prepared on the device ----------------------------------------------------------
+@pytest.mark.parametrize('B,U,N', [(64, 70, 90), (4096, 600, 300), (1000, 5000, 20)])
+def test_distinct_ids_on_the_device_equal_the_host_helper(B, U, N):
+    """drx_dmf_batch_distinct_device (one stable sort of the 2B (id, sample) pairs + one workgroup numbering the runs) against
+    drx_batch_distinct on the host: distinct ids ascending, every sample's index among them, the samples per distinct id ascending,
+    the counts, the batch mean of y."""
+    import torch
+    from drecpy_amd.engine_dmf import DmfEngine
+    rng = np.random.default_rng(B)
+    csr, csc, _ = _problem(rng, U, N, 4 * (U + N))
+    eng = DmfEngine(U, N, (16, 8), (16, 8), True)
+    eng.set_interactions(csr, csc)
+    u = rng.integers(0, U, size=B).astype(np.int32)
+    i = np.minimum(rng.pareto(1.1, size=B).astype(np.int64), N - 1).astype(np.int32)       # a few hot items, many repeats
+    y = rng.random(B).astype(np.float32)
+    host = eng.prepare_batch(u, i, y)
+    offs, lens, _ = eng._batch_layout(B)
+    at = dict(zip(eng._BATCH_ARRAYS, offs))
+    view = lambda name, n: host['buf'][at[name]:at[name] + 4 * n].view(np.int32)
+    dev = eng.prepare_batch_device(B, 0, 0, triples=[torch.as_tensor(a).cuda() for a in (u, i, y)])['device']
+    torch.cuda.synchronize()
+    nd = dev['nd'].cpu().numpy()
+    assert (int(nd[0]), int(nd[1])) == (host['n_du'], host['n_di'])
+    a = dev['arr'].cpu().numpy()
+    for r, (name, n) in enumerate((('du', nd[0]), ('di', nd[1]), ('inv_u', B), ('inv_i', B), ('gptr_u', nd[0] + 1), ('gptr_i', nd[1] + 1),
+                                   ('grows_u', B), ('grows_i', B))):
+        assert np.array_equal(a[r][:n], view(name, n)), name
+    assert abs(float(dev['y_mean'].item()) - float(y.astype(np.float64).mean())) < 1e-6
+
+
+@pytest.mark.parametrize('modified', [False, True])
+def test_a_step_on_a_device_prepared_batch_equals_the_host_prepared_one(modified):
+    """The same triples through prepare_batch (host arrays, one upload) and through prepare_batch_device (the distinct counts and the
+    batch mean stay on the device: DrxDmfArgs.nd_dev / y_mean_dev): identical parameters after three steps, bit for bit."""
+    import torch
+    from drecpy_amd.engine_dmf import DmfEngine
+    from drecpy_amd.Recommender import Variable
+    rng = np.random.default_rng(17)
+    U, N, B = 120, 80, 200
+    csr, csc, _ = _problem(rng, U, N, 2500)
+    p = dm.init_params(rng, U, N, (32, 16), (24, 16), np.float64)
+    engs = []
+    for _ in range(2):
+        e = DmfEngine(U, N, (32, 16), (24, 16), True)
+        e.set_interactions(csr, csc)
+        if modified:
+            e.bind_prediction_scale(Variable([1.0]), broadcast_targets=True)
+        e.set_params(p)
+        e.lr, e.reg = 2e-3, 1e-3
+        engs.append(e)
+    for step in range(3):
+        u = rng.integers(0, U, size=B).astype(np.int32)
+        i = rng.integers(0, N // 4, size=B).astype(np.int32)
+        y = rng.random(B).astype(np.float32)
+        la = engs[0].step(step, u, i, y, want_loss=True)
+        lb = engs[1].step(step, engs[1].prepare_batch_device(B, 0, 0, triples=[torch.as_tensor(a).cuda() for a in (u, i, y)]), want_loss=True)
+        assert la == lb, (step, la, lb)
+    ga, gb = engs[0].get_params(), engs[1].get_params()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+
+
+def test_dmf_fit_with_the_device_sampler():
+    """DMF.fit(device_sampler=True): the device PointSampler's triples carry the reference sampler's distribution AND values
+    (two-sample chi-square against the reference-exact stream: users of positives, cells of positives, users / items of
+    negatives; the standardised targets of the positives), and the fit runs and learns (the loss falls)."""
+    import torch
+    from helpers import load_frames
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import DMF
+    from drecpy_amd.Sampler import PointSampler
+    frame = {k: v.copy() for k, v in load_frames()['pt_int_dense'].items()}     # 64 users x 40 items, values 0..5: pairs below the threshold
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    model = DMF(user_factors=[16, 8], item_factors=[16, 8], seed=5, verbose=False)
+    model.fit(ds, epochs=60, batch_size=256, learning_rate=5e-3, reg_rate=1e-4, neg_ratio=3, device_sampler=True)
+    assert model._sampler_kind.startswith('device')
+    e = model._engine
+    n = 60000
+    prep = e.prepare_batch_device(n, 3, 4242)
+    torch.cuda.synchronize()
+    u, i = (t.cpu().numpy().astype(np.int64) for t in prep['device']['ids'])
+    y = prep['device']['y'].cpu().numpy()
+    ru, ri, rv, rneg = PointSampler(ds, 3, 1e-3, 11).sample_arrays(n)
+    ru, ri, rneg = np.asarray(ru, np.int64), np.asarray(ri, np.int64), np.asarray(rneg).astype(bool)
+    ry = np.asarray(model._standardize_value(np.asarray(rv, np.float64)), np.float64)
+    U, N = model.n_users, model.n_items
+    # negatives are the draws of pairs ABSENT from the frame; a positive's target is > 0 here (values 1..5 over a range of 5)
+    neg_d = y == 0
+    assert abs(neg_d.mean() - rneg.mean()) < 0.01
+
+    def close(x, ycol, bins, what):
+        hx, hy = np.bincount(x, minlength=bins).astype(float), np.bincount(ycol, minlength=bins).astype(float)
+        hx = hx * (hy.sum() / hx.sum())
+        live = (hx + hy) > 0
+        chi = float((((hx - hy) ** 2) / (hx + hy))[live].sum() / max(1, live.sum() - 1))
+        assert chi < 1.6, (what, chi)
+    close(u[~neg_d], ru[~rneg], U, 'users of positives')
+    close(u[~neg_d] * N + i[~neg_d], ru[~rneg] * N + ri[~rneg], U * N, 'cells of positives')
+    close(u[neg_d], ru[rneg], U, 'users of negatives')
+    close(i[neg_d], ri[rneg], N, 'items of negatives')
+    close(np.rint(y[~neg_d] * 5).astype(np.int64), np.rint(ry[~rneg] * 5).astype(np.int64), 6, 'targets of positives')
+    # the fit learned something: the model separates positives from negatives of a fresh device batch better than chance
+    pred = e.predict(u[:4000], i[:4000]).cpu().numpy()
+    assert pred[~neg_d[:4000]].mean() > pred[neg_d[:4000]].mean()
