@@ -14,9 +14,13 @@ The registration half of the surface is kept too (recommender_abc.py:66-69, 266-
 fill `trainable_weights / trainable_layers / trainable_models` with HANDLES over device arrays (trainables.py) instead of
 TensorFlow objects; their concatenation, weights first (:194-196), is the order of the per-step optimizer applies and fixes
 each variable's Adam counter.  `_update_weights(gradients, trainable_weights)` applies gradients a model computed itself
-with the registered optimizer (optimizers.py) on the device.  What the engine does NOT have is the tape: a model whose
-trainables are only reachable through `_predict_batch` + `_compute_batch_loss` cannot be differentiated here and fit()
-says so (NotImplementedError) instead of returning an untrained model.
+with the registered optimizer (optimizers.py) on the device.  A model that defines NO `_do_batch` — only the reference's
+hooks `_predict_batch` + `_compute_batch_loss` (+ `_compute_reg_loss`) — is trained by the GENERIC TAPE STEP
+(`_tape_do_batch`): recommender_abc.py:186-205 with torch.autograd standing where tf.GradientTape stands, the hooks
+written with torch operations on `Variable.tensor` instead of TensorFlow ones, the update still one `apply_gradients` per
+registered item through the library's Adam kernel.  CDAE / DMF / Caser never take it (their steps are the fused HIP
+kernels); a hook that returns a loss the registered variables cannot be differentiated through fails with a sentence
+(NotImplementedError) instead of returning an untrained model.
 Weights are snapshotted on the device only at epochs an early-stopping rule can choose (those where the epoch callback
 ran) instead of deep-copied every step (recommender_abc.py:336-341).  The loss is read back from the device only when it
 is logged or an early-stopping rule needs it.
@@ -173,17 +177,14 @@ class RecommenderABC(ABC):
         self._configure_optimizer()
         self.fitted = True  # should be able to make predictions after pre fit
         registered = self.trainable_weights + self.trainable_layers + self.trainable_models
-        if not hasattr(self, '_do_batch'):
+        do_batch = getattr(self, '_do_batch', None)
+        if do_batch is None:
             if len(registered) == 0:
                 self._info('No trainable vars found: skipping further model training. If this is non-intentional, please '
                            'use self._register_trainable or self._register_trainables to register variables that are '
                            'subject to weight updates.')
                 return
-            raise NotImplementedError(
-                f'{type(self).__name__} registers {len(registered)} trainable variable(s) but defines no fused training step. This '
-                f'engine has no autodiff tape (recommender_abc.py:191-204 is replaced by hand-written HIP kernels), so a model '
-                f'defined only by _predict_batch / _compute_batch_loss cannot be trained: implement '
-                f'_do_batch(batch_samples, step, want_loss, **kwds) (see INTEGRATION.md), or derive from CDAE / DMF / Caser.')
+            do_batch = self._tape_do_batch          # a reference-style model: hooks only (recommender_abc.py:186-205)
         fused = self._fused_trainables()
         if fused is not None:
             stray = [t for t in registered if not any(t is f for f in fused)]
@@ -212,7 +213,7 @@ class RecommenderABC(ABC):
             else:
                 batch = self._sample_batch(batch_size, more_to_come=epoch < epochs, batches_after=epochs - epoch, **kwds)
             with self._device_lock:
-                loss = self._do_batch(batch, step=epoch - 1, want_loss=monitor.needs_loss, **kwds)
+                loss = do_batch(batch, step=epoch - 1, want_loss=monitor.needs_loss, **kwds)
             if monitor.rule is not None and monitor.callback_due(epoch):
                 self._store_epoch_weights(epoch)
             stop, text = monitor.after_step(epoch, float(loss) if monitor.needs_loss else None)
@@ -288,6 +289,48 @@ class RecommenderABC(ABC):
             if t is handle:
                 return j
         raise Exception(f'{handle} is not registered (self._register_trainable)')
+
+    def _tape_do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
+        """The reference's training step (recommender_abc.py:186-205) for models that define only its hooks: predictions and loss
+        under a tape, the gradient of loss + regularisation w.r.t. every registered item, one apply_gradients per item.  The tape is
+        torch.autograd on the device: `_predict_batch` / `_compute_batch_loss` / `_compute_reg_loss` must build the loss with torch
+        operations on the registered arrays (`Variable.tensor`, or the tensors a layer / model handle returns — the SAME tensor
+        objects on every read).  The built-in models do not come here."""
+        import torch
+        items = self._apply_order()
+        groups = []
+        for it in items:
+            ts = list(it.trainable_weights) if hasattr(it, 'trainable_weights') else [getattr(it, 'tensor', it)]
+            if hasattr(it, 'trainable_weights') and any(a is not b for a, b in zip(ts, it.trainable_weights)):
+                raise NotImplementedError(f'{it}: the generic tape step needs a handle whose trainable_weights are the same tensor objects '
+                                          f'on every read (views made anew per call cannot be tracked); implement _do_batch instead.')
+            for t in ts:
+                t.requires_grad_(True)
+            groups.append(ts)
+        try:
+            predictions, desired_values = self._predict_batch(batch_samples, **kwds)
+            loss = self._compute_batch_loss(predictions, desired_values, **kwds)
+            loss = loss + self._compute_reg_loss(self.reg_rate, len(batch_samples), self.trainable_models, self.trainable_layers,
+                                                 self.trainable_weights, **kwds)
+            if not (torch.is_tensor(loss) and loss.requires_grad):
+                raise NotImplementedError(
+                    f'{type(self).__name__} defines no _do_batch and the loss its hooks return ({type(loss).__name__}) cannot be differentiated '
+                    f'w.r.t. the {len(items)} registered trainable(s): build it with torch operations on the registered arrays in '
+                    f'_predict_batch / _compute_batch_loss (the generic tape step), or implement the fused step '
+                    f'_do_batch(batch_samples, step, want_loss, **kwds) (see INTEGRATION.md), or derive from CDAE / DMF / Caser.')
+            flat = [t for ts in groups for t in ts]
+            grads = torch.autograd.grad(loss.reshape(()), flat, allow_unused=True)
+        finally:
+            for ts in groups:
+                for t in ts:
+                    t.requires_grad_(False)
+        grads = [g if g is not None else torch.zeros_like(t) for g, t in zip(grads, flat)]
+        per_item, at = [], 0
+        for ts in groups:
+            per_item.append(list(grads[at:at + len(ts)]))
+            at += len(ts)
+        self._update_weights(per_item, items)
+        return float(loss.detach().item()) if want_loss else None
 
     def _update_weights(self, gradients, trainable_weights):
         """One optimizer.apply_gradients per registered item (recommender_abc.py:328-334), on the device: `gradients[j]` is a

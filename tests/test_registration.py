@@ -41,7 +41,9 @@ def test_no_trainables_means_no_training_like_the_reference():
     assert isinstance(m.optimizer, optimizers.Adam) and m.optimizer.learning_rate == 0.001      # default optimizer (:153)
 
 
-def test_tape_only_model_fails_with_a_sentence_not_silently():
+def test_a_hooks_only_model_whose_loss_is_not_differentiable_fails_with_a_sentence_not_silently():
+    """No _do_batch: the generic tape step (torch.autograd in tf.GradientTape's place) runs the hooks — a loss that is a plain
+    number cannot be differentiated w.r.t. the registered variable, and fit() says so."""
     class Tape(_Hooks):
         registers = (Variable([1.], device='cpu'),)
     m = Tape(verbose=False)
