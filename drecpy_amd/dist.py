@@ -349,7 +349,7 @@ class ShardedCdae:
         return head
 
     # ---- one step ------------------------------------------------------------------------------------------
-    def step(self, step, bt, events=None, want_loss=False, prepared=None, after_row_requests=None):
+    def step(self, step, bt, events=None, want_loss=False, prepared=None, after_row_requests=None, after_apply=None):
         """One training step of this rank.  `bt` is a DrxBatch or a list of up to DRX_MAX_MICRO micro-batches with pairwise
         DISJOINT users (then `prepared` is the matching list): all micro-batches read the pre-step parameters and every
         owned row is updated once with the sum of their gradients — the step still equals the single-process step on the
@@ -360,7 +360,9 @@ class ShardedCdae:
         [3,4) owner apply + bias.
         after_row_requests: called once the row exchanges of this step and the kernels of its first micro-batch are queued —
         ShardedPipeline queues the run-ahead count / key exchanges of later batches there, so that on the communicator they sit
-        behind this step's row exchange (and travel while it computes) instead of in front of it."""
+        behind this step's row exchange (and travel while it computes) instead of in front of it.
+        after_apply: called once the whole step is queued — the pipeline's collective-free preparation of a later batch goes there
+        (its host time would otherwise delay the issue of this step's owner apply)."""
         ops, ld = self.ops, self.ld
         bts = list(bt) if isinstance(bt, (list, tuple)) else [bt]
         Ps = (list(prepared) if isinstance(prepared, (list, tuple)) else [prepared]) if prepared is not None else [None] * len(bts)
@@ -410,6 +412,8 @@ class ShardedCdae:
                          own=[(g, P['send_counts']) for (_, g), P in zip(pushed, Ps)])
         rec(4)
         rec(5)
+        if after_apply is not None:
+            after_apply()
         if want_loss:
             self.last_loss = float(loss[0].item()) if torch.is_tensor(loss) else float(loss)
             return self.last_loss
@@ -504,11 +508,16 @@ class ShardedPipeline:
                     self._keys(s + 1)
                 if s + self.LOOKAHEAD - 1 < self.n:
                     self._counts(s + self.LOOKAHEAD - 1)
-                if s + self.LOOKAHEAD < self.n:
+            ahead_s[0] += time.perf_counter() - ta
+
+        def prepare_ahead():                   # no collective in it: issued when the whole step is queued
+            ta = time.perf_counter()
+            if s + self.LOOKAHEAD < self.n:
+                with self._on_side():
                     self._prepare(s + self.LOOKAHEAD)
-            ahead_s[0] = time.perf_counter() - ta
+            ahead_s[0] += time.perf_counter() - ta
         out = self.m.step(s, self._micro(s), events=events, want_loss=want_loss, prepared=self.P.pop(s),
-                          after_row_requests=run_ahead)
+                          after_row_requests=run_ahead, after_apply=prepare_ahead)
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(self.main)
