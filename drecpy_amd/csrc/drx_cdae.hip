@@ -1492,8 +1492,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   S.stamps = SB.stamps = h_stamps;
 #endif
   PlanBufs PB{S.pblock, S.pbs};
-  // more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes), k_seg_reduce's LB1 = 8
-  const bool long_segments = (int64_t)S.T > 8 * ((int64_t)2 * p->n_items + p->n_users);
+  // rows collect long runs of touches (MovieLens shapes): k_seg_reduce's LB1 = 8, XCD placement of its workgroups
+  const bool long_segments = drx::long_segments(S.T, *p);
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
   // One workgroup per triple (its groups split the history) instead of one group per triple: when a group would walk many
   // dependent load rounds.  Short histories (mean <= 64 items): only while the batch cannot fill the chip anyway.

@@ -153,6 +153,8 @@ static __global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, 
   }
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
+  const int nb = (n_chunks + cpb - 1) / cpb;
+  if (P.xlist && (tid & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, tid, tid < nb);
   for (int j = tid; j < T; j += plan_blocks * blockDim.x) {
     const uint32_t k = keys_s[j];
     if (k == DRX_KEY_NONE || k < n_items) continue;
@@ -246,6 +248,9 @@ struct PrepBufs {
   int T, bits;
 };
 
+// more than 8 touches per table row on average: rows collect long runs of touches (MovieLens shapes)
+static inline bool long_segments(int T, const DrxCdaeParams &P) { return (int64_t)T > 8 * ((int64_t)2 * P.n_items + P.n_users); }
+
 static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots) {
   PrepBufs R{};
   R.T = n_touch_slots + 2 * B;
@@ -260,6 +265,13 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.plan.desc = cv.take<uint2>(R.n_chunks);
   R.plan.cnt = cv.take<uint32_t>(64);
   R.plan.ext = cv.take<uint8_t>(R.n_chunks);
+  {
+    // XCD placement of the reduction's workgroups (SpanPlan::xlist): lists of LONG segments only — more than 8 touches per table row
+    // (the lists' STRIDE is that of the smallest block — two chunks — so that the layout of a prepared list does not depend on the
+    // row width: a column-sharded job hands lists between ranks of different widths)
+    R.plan.xstride = (R.n_chunks + 1) / 2;
+    R.plan.xlist = long_segments(R.T, P) ? cv.take<uint32_t>((size_t)8 * R.plan.xstride) : nullptr;
+  }
   R.order = cv.take<int32_t>(B);
   R.result_bytes = align_up(cv.off, 256);
   R.keys = cv.take<uint32_t>(R.T);
@@ -277,10 +289,9 @@ static int plan_zero_words(const PrepBufs &R) { return (int)(((const char *)R.pl
 // BEFORE the sole-toucher marks blank any key.
 static int plan_spans(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs &R0, hipStream_t st, bool cleared) {
   const PrepBufs &R = R0;
-  (void)bt;
   if (!cleared) DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, (size_t)plan_zero_words(R) * 4, st));     // (prepare_impl's touch kernel clears them)
-  hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.T, R.n_chunks,
-                     kSegBlock / pick_geom(p->ld).G, R.plan);
+  hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
+                     kSegBlock / pick_geom(p->ld).G, bt->B, R.plan);
   return DRX_OK;
 }
 

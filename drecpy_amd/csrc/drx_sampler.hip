@@ -139,16 +139,18 @@ __global__ __launch_bounds__(1024) void k_deg_apply(const int32_t *__restrict__ 
 }
 
 // k_deg_apply with the spine folded in (r03: a launch on the preparation's stream waits 10 - 30 us for room beside the training kernels
-// whatever it computes): a tile's workgroup sums the workgroup sums of k_point_sample that lie before it itself — at most 1024 of
-// them — and the last tile posts the total.
-__global__ __launch_bounds__(1024) void k_deg_apply_sub(const int32_t *__restrict__ deg, int B, const int *__restrict__ sub, int n_sub,
-                                                        int32_t *__restrict__ keep_off, unsigned long long *mailbox, uint32_t tag) {
-  __shared__ int wsum[16], wpre[16];
-  const int base = blockIdx.x * kDegTile + (int)threadIdx.x * 4, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  constexpr int PER = kDegTile / kBlock;
+// whatever it computes): a tile's workgroup sums the workgroup sums of k_point_sample that lie before it itself, and the last tile
+// posts the total.  r04: tiles of 1024 degrees in workgroups of 256 threads — a 1024-thread workgroup needs a whole CU's wave slots
+// free at once, and beside the training kernels it waited for them (rocprofv3: 44 - 64 us for 13 us of work).
+constexpr int kSubTile = 1024;
+__global__ __launch_bounds__(256) void k_deg_apply_sub(const int32_t *__restrict__ deg, int B, const int *__restrict__ sub, int n_sub,
+                                                       int32_t *__restrict__ keep_off, unsigned long long *mailbox, uint32_t tag) {
+  __shared__ int wsum[4], wpre[4];
+  const int base = blockIdx.x * kSubTile + (int)threadIdx.x * 4, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int PER = kSubTile / kBlock;
   const int n_before = min(n_sub, (int)blockIdx.x * PER);
   int pre = 0;
-  for (int q = (int)threadIdx.x; q < n_before; q += 1024) pre += sub[q];
+  for (int q = (int)threadIdx.x; q < n_before; q += 256) pre += sub[q];
   int v[4], sum = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { sum += base + q < B ? deg[base + q] : 0; v[q] = sum; }
@@ -162,11 +164,11 @@ __global__ __launch_bounds__(1024) void k_deg_apply_sub(const int32_t *__restric
   __syncthreads();
   int off = inc - sum;
 #pragma unroll
-  for (int ww = 0; ww < 16; ++ww) off += wpre[ww] + (ww < w ? wsum[ww] : 0);
+  for (int ww = 0; ww < 4; ++ww) off += wpre[ww] + (ww < w ? wsum[ww] : 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     if (base + q < B) keep_off[base + q + 1] = v[q] + off;
-  if (mailbox && blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023)
+  if (mailbox && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255)
     __hip_atomic_store(mailbox, ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)(off + sum), __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -238,12 +240,12 @@ extern "C" int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistor
   if (scratch_bytes < drx_point_sample_scratch_bytes(B)) return DRX_ESCRATCH;
   hipStream_t st = (hipStream_t)stream;
   int32_t *deg = (int32_t *)scratch;
-  const int n_tiles = (B + kDegTile - 1) / kDegTile, n_sub = (B + kBlock - 1) / kBlock;
+  const int n_sub = (B + kBlock - 1) / kBlock;
   int *tsum = (int *)((char *)scratch + align_up((size_t)B * 4, 256));
   int *sub = tsum + 128;
   hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, recorded ? *recorded : *hist, n_users, n_items, B, neg_ratio,
                      seed, uid, iid, y, deg, keep_off, sub, nullptr, 0.f, 0.f);
-  hipLaunchKernelGGL(k_deg_apply_sub, dim3(n_tiles), dim3(1024), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
+  hipLaunchKernelGGL(k_deg_apply_sub, dim3((B + kSubTile - 1) / kSubTile), dim3(256), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
                      (unsigned long long *)host_mailbox, tag);
   DRX_LAUNCH_CHECK();
   return DRX_OK;

@@ -177,7 +177,68 @@ struct SpanPlan {
   uint32_t *cnt;        // [0] short spans, [1] long spans
   uint8_t *ext;         // [n_chunks] (zeroed before k_plan_spans): chunk g also takes the first ext[g] touches of chunk g + 1 — the end of
                         //   a segment that starts in g and ends inside g + 1 (the commonest crossing by far: no partial rows, no span)
+  // XCD PLACEMENT (r04; lists of LONG segments only — MovieLens shapes: a few thousand rows, thousands of touches each).  The touches
+  // of a segment are sorted by sample, so a workgroup's chunks read a narrow band of the batch's gradient rows (dz1 / g2: 33 MB at
+  // B = 65 536, eight times an XCD's L2).  xlist [8][xstride] lists, per eighth of the batch, the workgroup-sized blocks of chunks
+  // whose first touch falls into it (cnt[8 + x] of them; cnt[16] != 0: the lists are valid); the hardware deals workgroups to the 8
+  // XCDs round robin, so a workgroup of residue x takes a block of eighth x: every XCD then re-reads ONE eighth of the gradient rows
+  // (4 MB: its L2) instead of all of them.  Which workgroup sums which block never changes a result.  nullptr: blocks in list order.
+  uint32_t *xlist;
+  int xstride;          // entries per list (the number of blocks of the smallest block size: a layout independent of the row width)
 };
+
+// block `blk` (chunks blk * cpb ...) goes to the list of the eighth of the batch its first touch's sample lies in.  Called by whole
+// waves (`on`: this lane has a block): the lanes of a wave that chose the same list take their places with ONE atomic (65 k single
+// atomics on 8 counters took the planning kernel from 30 to 480 us and slowed everything beside it).
+__device__ __forceinline__ void place_block(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s, int T, int cpb, int B,
+                                            const SpanPlan &P, int blk, bool on) {
+  int x = blk & 7;
+  if (on) {
+    const int at = blk * cpb * kChunk;
+    if (at < T && keys_s[at] != DRX_KEY_NONE) {                 // (a blanked or dropped touch carries no sample: any list will do)
+      const uint32_t b = vals_s[at];
+      x = (int)min(7u, (uint32_t)(((unsigned long long)b * 8ull) / (unsigned long long)(B > 0 ? B : 1)));
+    }
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const unsigned long long m = __ballot(on && x == r);
+    if (m == 0ull) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&P.cnt[8 + r], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (on && x == r) P.xlist[(size_t)r * P.xstride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+  }
+  if (on && blk == 0) { P.cnt[16] = 1u; P.cnt[17] = (uint32_t)cpb; }
+}
+
+// the block a reduction workgroup takes: launch index j (its XCD = j % 8), `extra` workgroups of another role in front, n_wg of this one
+__device__ __forceinline__ int placed_block(const SpanPlan &P, int j, int extra, int n_wg, int cpb) {
+  // (cnt[17]: the block size the lists were made for — a list prepared by a rank of another row width is taken in list order)
+  if (!P.xlist || P.cnt[16] == 0u || P.cnt[17] != (uint32_t)cpb) return j - extra;
+  const int x = j & 7;
+  int own[8], q[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int first = extra + ((r - extra) & 7);                 // smallest launch index >= extra with residue r
+    q[r] = first < extra + n_wg ? (extra + n_wg - 1 - first) / 8 + 1 : 0;
+    own[r] = min((int)P.cnt[8 + r], q[r]);
+  }
+  const int i = (j - (extra + ((x - extra) & 7))) / 8;
+  if (i < own[x]) return (int)P.xlist[(size_t)x * P.xstride + i];
+  int f = i - own[x];                                            // this workgroup's number among the FREE ones ...
+#pragma unroll
+  for (int r = 0; r < 8; ++r) f += r < x ? q[r] - own[r] : 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {                                  // ... takes the f-th block its list's workgroups could not
+    const int over = (int)P.cnt[8 + r] - own[r];
+    if (f < over) return (int)P.xlist[(size_t)r * P.xstride + own[r] + f];
+    f -= over;
+  }
+  return j - extra;                                              // (unreachable: as many free workgroups as overflow blocks)
+}
 
 struct PlanBufs {
   float *pblock;        // [n_blocks, ld] block partials (all-inner workgroups)
@@ -225,9 +286,12 @@ __device__ __forceinline__ void plan_chunk(const uint32_t *__restrict__ keys_s, 
 // One thread per chunk of the sorted list: a chunk whose last key continues into the next chunk and that is not itself the inside of
 // that segment starts a span; the segment's end is found by binary search.
 template <int DUMMY = 0>
-__global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, SpanPlan P) {
+__global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s, int T, int n_chunks, int cpb, int B,
+                             SpanPlan P) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, g);
+  const int nb = (n_chunks + cpb - 1) / cpb;
+  if (P.xlist && (g & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, g, g < nb);
 }
 
 // LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
@@ -244,7 +308,7 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
   constexpr int CPB = kSegBlock / G;
   if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
   const uint8_t *__restrict__ ext = SP.ext;
-  const int blk = (int)blockIdx.x - extra_blocks;
+  const int blk = placed_block(SP, (int)blockIdx.x, extra_blocks, (int)gridDim.x - extra_blocks, CPB);
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int g = blk * CPB + r;
   bool inner = false;          // this chunk is one whole run of a segment that began before it

@@ -830,7 +830,7 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
   const int rows_per_block = (bt->B + B.n_bpart - 1) / B.n_bpart;
   const int n_bpart = (bt->B + rows_per_block - 1) / rows_per_block;
   BiasArgs BA{B.dz1, B.bpart, B.lossb, B.lossb /* non-null: the loss partials are always taken */, bt->B, n_bpart, rows_per_block};
-  const bool long_segments = (int64_t)B.T > 8 * ((int64_t)2 * sh->n_items + sh->n_users_local);
+  const bool long_segments = drx::long_segments(B.T, key_params(*p, *sh));
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
 #define REDUCE_AND_SPANS(G, J, KIND)                                                                                   \
   {                                                                                                                    \
