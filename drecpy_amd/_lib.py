@@ -27,7 +27,8 @@ class CdaeParams(C.Structure):
 
 
 class History(C.Structure):
-    _fields_ = [('indptr', C.c_void_p), ('indices', C.c_void_p)]
+    _fields_ = [('indptr', C.c_void_p), ('indices', C.c_void_p), ('t_indptr', C.c_void_p), ('t_users', C.c_void_p), ('t_pos', C.c_void_p),
+                ('t_nnz', C.c_int64)]
 
 
 class Batch(C.Structure):
@@ -129,6 +130,10 @@ SIGNATURES = {
     'drx_point_sample_recorded': (C.c_int, [C.POINTER(History), C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                    C.c_void_p]),
+    'drx_point_sample_by_user_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
+    'drx_point_sample_by_user': (C.c_int, [C.POINTER(History), C.POINTER(History), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
+                                           C.c_void_p]),
     'drx_point_sample_valued': (C.c_int, [C.POINTER(History), C.POINTER(History), C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_dmf_distinct_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

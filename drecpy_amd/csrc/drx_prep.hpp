@@ -154,7 +154,7 @@ static __global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, 
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
   const int nb = (n_chunks + cpb - 1) / cpb;
-  if (P.xlist && (tid & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, tid, tid < nb);
+  if (P.xrank && (tid & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, tid, tid < nb);
   for (int j = tid; j < T; j += plan_blocks * blockDim.x) {
     const uint32_t k = keys_s[j];
     if (k == DRX_KEY_NONE || k < n_items) continue;
@@ -263,14 +263,16 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
   R.n_chunks = (R.T + kChunk - 1) / kChunk;
   R.plan.desc = cv.take<uint2>(R.n_chunks);
-  R.plan.cnt = cv.take<uint32_t>(64);
+  R.plan.cnt = cv.take<uint32_t>(128);        // [0] short spans, [1] long spans, [16], [17], [kXBase ..): XCD placement (drx_segreduce.hpp)
   R.plan.ext = cv.take<uint8_t>(R.n_chunks);
   {
     // XCD placement of the reduction's workgroups (SpanPlan::xlist): lists of LONG segments only — more than 8 touches per table row
     // (the lists' STRIDE is that of the smallest block — two chunks — so that the layout of a prepared list does not depend on the
     // row width: a column-sharded job hands lists between ranks of different widths)
     R.plan.xstride = (R.n_chunks + 1) / 2;
-    R.plan.xlist = long_segments(R.T, P) ? cv.take<uint32_t>((size_t)8 * R.plan.xstride) : nullptr;
+    const bool placed = long_segments(R.T, P);
+    R.plan.xrank = placed ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
+    R.plan.xperm = placed ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
   }
   R.order = cv.take<int32_t>(B);
   R.result_bytes = align_up(cv.off, 256);
@@ -292,6 +294,7 @@ static int plan_spans(const DrxCdaeParams *p, const DrxBatch *bt, const PrepBufs
   if (!cleared) DRX_HIP(hipMemsetAsync(R.plan.cnt, 0, (size_t)plan_zero_words(R) * 4, st));     // (prepare_impl's touch kernel clears them)
   hipLaunchKernelGGL(k_plan_spans<0>, dim3((R.n_chunks + 255) / 256), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
                      kSegBlock / pick_geom(p->ld).G, bt->B, R.plan);
+  if (R.plan.xrank) hipLaunchKernelGGL(k_place_blocks, dim3(256), dim3(256), 0, st, R.plan, R.n_chunks);
   return DRX_OK;
 }
 
@@ -303,9 +306,140 @@ static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t s
   hipLaunchKernelGGL(k_degree_scatter, dim3(blocks), dim3(1024), 0, st, bt->keep_off, bt->B, R.order_work, R.order);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Preparation through the history's TRANSPOSE (r04; DrxHistory::t_*): lists of LONG segments — MovieLens shapes, where a batch of 65 536
+// triples over 6 040 users and 3 706 items has 10 M touches and the sort of those pairs (two passes of 320 us + a histogram) had made
+// the PREPARATION, not the training kernels, the bound of a step.  The sorted list is the static item -> users structure of the training
+// set expanded by the batch's samples of every user: only the 2B (user | item, sample) pairs of the batch are sorted (one stable sort:
+// samples ascending per id), then every transpose entry (item n, user u, position j) counts the samples of u whose corruption mask
+// keeps position j, a scan places them, and a second walk writes (n, sample) — the W part of the list, item-major, compact; the W2T
+// part (N + item) and the V part (2N + user) ARE the sorted batch pairs.  Inside a segment the touches come user by user, samples
+// ascending: another FIXED order than the sort's (samples ascending) — a function of the batch alone, as bit-reproducible as before.
+// Work areas are carved out of the regions the big sort would have used (keys / vals / sort_temp); returns kTpFallback when they do
+// not fit (the caller then sorts).
+constexpr int kTpFallback = 0x7fff0001;
+
+static __global__ __launch_bounds__(256) void k_tp_begin(DrxBatch bt, int n_users, uint32_t *__restrict__ k2, uint32_t *__restrict__ v2,
+                                                         int32_t *__restrict__ se, int n_se, uint8_t *solo, uint32_t *zero_a, int n_zero_a,
+                                                         uint32_t *zero_b, int n_zero_b) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int j = tid; j < 2 * bt.B; j += nt) {
+    k2[j] = j < bt.B ? (uint32_t)bt.uid[j] : (uint32_t)n_users + (uint32_t)bt.iid[j - bt.B];
+    v2[j] = (uint32_t)j;
+  }
+  for (int j = tid; j < n_se; j += nt) se[j] = 0;                      // start / end of every id's run in the sorted pairs
+  for (int j = tid; j < 2 * bt.B; j += nt) solo[j] = 0;
+  for (int j = tid; j < n_zero_a; j += nt) zero_a[j] = 0u;
+  for (int j = tid; j < n_zero_b; j += nt) zero_b[j] = 0u;
+}
+
+static __global__ __launch_bounds__(256) void k_tp_runs(const uint32_t *__restrict__ ks, int n, int32_t *__restrict__ start, int32_t *__restrict__ end) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const uint32_t k = ks[p];
+    if (p == 0 || ks[p - 1] != k) start[k] = p;
+    if (p == n - 1 || ks[p + 1] != k) end[k] = p + 1;
+  }
+}
+
+// WRITE = false: cnt[e] = kept samples of entry e;  WRITE = true: cnt holds the exclusive scan, the pairs are written
+template <bool WRITE>
+static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch bt, uint32_t qthr, int n_items, const int32_t *__restrict__ start,
+                                                          const int32_t *__restrict__ end, const uint32_t *__restrict__ vs,
+                                                          int *__restrict__ cnt, uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s) {
+  // one thread per transpose entry; the item of an entry: lower bound over t_indptr, once per thread
+  const int64_t nnz = H.t_nnz;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    const int u = H.t_users[e], j = H.t_pos[e];
+    const int s0 = start[u], c = end[u] - s0;
+    int n = 0;
+    if (WRITE && c > 0) {
+      int lo = 0, hi = n_items;                     // the last item whose row starts at or before e
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (H.t_indptr[mid] <= e) lo = mid; else hi = mid; }
+      n = lo;
+    }
+    int at = WRITE ? cnt[e] : 0, kept = 0;
+    for (int q = 0; q < c; ++q) {
+      const uint32_t b = vs[s0 + q];
+      const bool kf = bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr);
+      if (kf) {
+        if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = b; ++at; }
+        ++kept;
+      }
+    }
+    if (!WRITE) cnt[e] = kept;
+  }
+}
+
+// the W2T and V parts (the sorted batch pairs themselves) behind the W part, and DRX_KEY_NONE up to T
+static __global__ __launch_bounds__(256) void k_tp_tail(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B, int n_users,
+                                                        int n_items, const int *__restrict__ off_last, const int *__restrict__ cnt_last, int T,
+                                                        uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s) {
+  const int Tw = off_last[0] + cnt_last[0];          // (exclusive scan: the last entry's offset + its count)
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < T - Tw; p += gridDim.x * blockDim.x) {
+    uint32_t k = DRX_KEY_NONE, v = 0;
+    if (p < B) { k = (uint32_t)n_items + (ks[B + p] - (uint32_t)n_users); v = vs[B + p] - (uint32_t)B; }        // items: sorted positions B .. 2B-1
+    else if (p < 2 * B) { k = 2u * (uint32_t)n_items + ks[p - B]; v = vs[p - B]; }                              // users: positions 0 .. B-1
+    keys_s[Tw + p] = k; vals_s[Tw + p] = v;
+  }
+}
+
+static int plan_zero_words(const PrepBufs &R);
+static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared);
+
+static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
+  const int B = bt->B, U = p->n_users, N = p->n_items;
+  const int64_t nnz = hist->t_nnz;
+  if (nnz < 1 || nnz > (int64_t)R.T || nnz >= (1ll << 30) || (int64_t)U + N >= 0x7FFFFFFFll) return kTpFallback;
+  // work areas: cnt in the big sort's key buffer, the rest in its temp
+  int *cnt = (int *)R.keys;
+  Carver cw(R.sort_temp, R.sort_bytes);
+  const int bits2 = bits_for((uint64_t)U + (uint64_t)N + 1);
+  uint32_t *k2 = cw.take<uint32_t>((size_t)2 * B), *v2 = cw.take<uint32_t>((size_t)2 * B);
+  uint32_t *ks = cw.take<uint32_t>((size_t)2 * B), *vs = cw.take<uint32_t>((size_t)2 * B);
+  int32_t *start = cw.take<int32_t>((size_t)U + N), *end = start + ((size_t)U + N);
+  (void)cw.take<int32_t>((size_t)U + N);
+  const size_t sb = sort_pairs_temp_bytes((size_t)2 * B, bits2);
+  void *stemp = cw.take<char>(sb);
+  const size_t scb = scan_i32_temp_bytes((size_t)nnz);
+  void *sctemp = cw.take<char>(scb);
+  if (!cw.ok()) return kTpFallback;
+  const uint32_t qthr = q_threshold(bt->q);
+  hipLaunchKernelGGL(k_tp_begin, dim3(512), dim3(256), 0, st, *bt, U, k2, v2, start, 2 * (U + N), R.solo_v, R.plan.cnt, plan_zero_words(R),
+                     R.order_work, 512);
+  int rc = sort_pairs(stemp, sb, k2, ks, v2, vs, (size_t)2 * B, bits2, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tp_runs, dim3((2 * B + 255) / 256 < 1024 ? (2 * B + 255) / 256 : 1024), dim3(256), 0, st, ks, 2 * B, start, end);
+  const int egrid = (int)((nnz + 255) / 256 < 8192 ? (nnz + 255) / 256 : 8192);
+  hipLaunchKernelGGL((k_tp_expand<false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s);
+  // (the counts of the LAST entry are needed after the scan overwrote them: a copy)
+  int *cnt_last = (int *)R.vals;
+  DRX_HIP(hipMemcpyAsync(cnt_last, cnt + (nnz - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
+  rc = scan_i32(sctemp, scb, cnt, cnt, (size_t)nnz, false, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_tp_expand<true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s);
+  hipLaunchKernelGGL(k_tp_tail, dim3(2048), dim3(256), 0, st, ks, vs, B, U, N, cnt + (nnz - 1), cnt_last, R.T, R.keys_s, R.vals_s);
+  return DRX_OK;
+}
+
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
                         bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, 1, 0}) {
   const int gpb = kBlock / 16;
+  if (hist->t_indptr && hist->t_users && hist->t_pos && !pres.present && long_segments(R.T, *p)) {
+    const int rc = prepare_transposed(p, hist, bt, R, st);
+    if (rc == DRX_OK) {                                        // the list stands, sorted: what is left is what follows the sort below
+      if (with_marks && p->ld > 16) {
+        order_by_degree(bt, R, st, true);
+        const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
+        hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
+                           kSegBlock / pick_geom(p->ld).G, R.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, 0, bt->keep_off,
+                           R.order_work, R.order);
+        if (R.plan.xrank) hipLaunchKernelGGL(k_place_blocks, dim3(256), dim3(256), 0, st, R.plan, R.n_chunks);
+        return DRX_OK;
+      }
+      return plan_spans(p, bt, R, st, true);
+    }
+    if (rc != kTpFallback) return rc;
+  }
   uint32_t *sort_zero = nullptr;
   size_t sort_zero_words = 0;
   sort_pairs_zero_region(R.sort_temp, (size_t)R.T, R.bits, &sort_zero, &sort_zero_words);
@@ -326,6 +460,7 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
     hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks + order_blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
                        kSegBlock / pick_geom(p->ld).G, R.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o,
                        order_blocks, bt->keep_off, R.order_work, R.order);
+    if (R.plan.xrank) hipLaunchKernelGGL(k_place_blocks, dim3(256), dim3(256), 0, st, R.plan, R.n_chunks);
     return DRX_OK;
   }
   return plan_spans(p, bt, R, st, true);

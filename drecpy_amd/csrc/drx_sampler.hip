@@ -251,6 +251,81 @@ extern "C" int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistor
   return DRX_OK;
 }
 
+// ---- the same draws handed out in USER order (batches whose touch lists are prepared through the history's transpose) -------------
+namespace drx {
+static __global__ void k_by_user_keys(const int32_t *__restrict__ uid, int B, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B; j += gridDim.x * blockDim.x) { keys[j] = (uint32_t)uid[j]; vals[j] = (uint32_t)j; }
+}
+// triple p of the output = draw vs[p]; its degree, and the workgroup's degree sum (the scan's first level, as in k_point_sample)
+static __global__ __launch_bounds__(kBlock) void k_by_user_gather(DrxHistory H, const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs,
+                                                                  const int32_t *__restrict__ iid_d, const float *__restrict__ y_d, int B,
+                                                                  int32_t *uid, int32_t *iid, float *y, int32_t *deg, int32_t *keep_off,
+                                                                  int *sub_sums) {
+  __shared__ int wsum[kBlock / 64];
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  int my_deg = 0;
+  if (p < B) {
+    if (p == 0) keep_off[0] = 0;
+    const int u = (int)ks[p];
+    const uint32_t d = vs[p];
+    uid[p] = u; iid[p] = iid_d[d]; y[p] = y_d[d];
+    my_deg = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
+    deg[p] = my_deg;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) my_deg += __shfl_xor(my_deg, m, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = my_deg;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int i2 = 0; i2 < kBlock / 64; ++i2) t += wsum[i2];
+    sub_sums[blockIdx.x] = t;
+  }
+}
+}  // namespace drx
+
+extern "C" size_t drx_point_sample_by_user_scratch_bytes(int32_t B, int32_t n_users) {
+  if (B < 1 || n_users < 1) return 0;
+  return drx_point_sample_scratch_bytes(B) + 7 * drx::align_up((size_t)B * 4, 256) +
+         drx::sort_pairs_temp_bytes((size_t)B, drx::bits_for((uint64_t)n_users + 1)) + 512;
+}
+
+extern "C" int drx_point_sample_by_user(const DrxHistory *hist, const DrxHistory *recorded, int32_t n_users, int32_t n_items, int32_t B,
+                                        int32_t neg_ratio, uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
+                                        void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream) {
+  using namespace drx;
+  if (recorded && (!recorded->indptr || !recorded->indices)) return DRX_EINVAL;
+  if (!hist || !hist->indptr || !hist->indices || !uid || !iid || !y || !keep_off || !scratch || B < 1 || n_users < 1 || n_items < 1 ||
+      neg_ratio < 0)
+    return DRX_EINVAL;
+  if (scratch_bytes < drx_point_sample_by_user_scratch_bytes(B, n_users)) return DRX_ESCRATCH;
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(scratch, scratch_bytes);
+  int32_t *deg = cv.take<int32_t>(B);
+  int *tsum = cv.take<int>(64);
+  int *sub = cv.take<int>(((size_t)B + kBlock - 1) / kBlock + 64);
+  (void)tsum;
+  int32_t *uid_d = cv.take<int32_t>(B), *iid_d = cv.take<int32_t>(B);
+  float *y_d = cv.take<float>(B);
+  uint32_t *k0 = cv.take<uint32_t>(B), *v0 = cv.take<uint32_t>(B), *ks = cv.take<uint32_t>(B), *vs = cv.take<uint32_t>(B);
+  const int bits = bits_for((uint64_t)n_users + 1);
+  const size_t sb = sort_pairs_temp_bytes((size_t)B, bits);
+  void *stemp = cv.take<char>(sb);
+  if (!cv.ok()) return DRX_ESCRATCH;
+  const int n_sub = (B + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_point_sample, dim3(n_sub), dim3(kBlock), 0, st, *hist, recorded ? *recorded : *hist, n_users, n_items, B, neg_ratio,
+                     seed, uid_d, iid_d, y_d, (int32_t *)nullptr, (int32_t *)nullptr, (int *)nullptr, (const float *)nullptr, 0.f, 0.f);
+  hipLaunchKernelGGL(k_by_user_keys, dim3(n_sub < 1024 ? n_sub : 1024), dim3(256), 0, st, uid_d, B, k0, v0);
+  const int rc = sort_pairs(stemp, sb, k0, ks, v0, vs, (size_t)B, bits, st);          // stable: a user's draws keep their order
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_by_user_gather, dim3(n_sub), dim3(kBlock), 0, st, *hist, ks, vs, iid_d, y_d, B, uid, iid, y, deg, keep_off, sub);
+  hipLaunchKernelGGL(k_deg_apply_sub, dim3((B + kSubTile - 1) / kSubTile), dim3(256), 0, st, deg, B, (const int *)sub, n_sub, keep_off,
+                     (unsigned long long *)host_mailbox, tag);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
 extern "C" int drx_point_sample_valued(const DrxHistory *hist, const DrxHistory *recorded, const float *pos_values, float vmin,
                                        float vrange, int32_t n_users, int32_t n_items, int32_t B, int32_t neg_ratio, uint64_t seed,
                                        int32_t *uid, int32_t *iid, float *y, void *stream) {

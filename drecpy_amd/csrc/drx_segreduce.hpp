@@ -179,62 +179,91 @@ struct SpanPlan {
                         //   a segment that starts in g and ends inside g + 1 (the commonest crossing by far: no partial rows, no span)
   // XCD PLACEMENT (r04; lists of LONG segments only — MovieLens shapes: a few thousand rows, thousands of touches each).  The touches
   // of a segment are sorted by sample, so a workgroup's chunks read a narrow band of the batch's gradient rows (dz1 / g2: 33 MB at
-  // B = 65 536, eight times an XCD's L2).  xlist [8][xstride] lists, per eighth of the batch, the workgroup-sized blocks of chunks
-  // whose first touch falls into it (cnt[8 + x] of them; cnt[16] != 0: the lists are valid); the hardware deals workgroups to the 8
-  // XCDs round robin, so a workgroup of residue x takes a block of eighth x: every XCD then re-reads ONE eighth of the gradient rows
-  // (4 MB: its L2) instead of all of them.  Which workgroup sums which block never changes a result.  nullptr: blocks in list order.
-  uint32_t *xlist;
-  int xstride;          // entries per list (the number of blocks of the smallest block size: a layout independent of the row width)
+  // B = 65 536, eight times an XCD's L2).  The workgroup-sized blocks of chunks are binned by the 64th of the batch their first touch's
+  // sample lies in (cnt[kXBase + t] blocks in bin t; xrank[blk] = bin << 24-bit rank inside it) and xperm lists them bin by bin.  The
+  // hardware deals workgroups to the 8 XCDs round robin: a workgroup of residue x takes the blocks of bins 8x .. 8x + 7 in that order,
+  // so the workgroups resident on an XCD at a time re-read ONE 64th of the gradient rows (0.5 MB: its L2) instead of all of them.
+  // Which workgroup sums which block never changes a result.  nullptr: blocks in list order.
+  uint32_t *xrank;      // [xstride] block -> bin << 24 | rank      (k_plan_spans / k_plan_and_mark)
+  uint32_t *xperm;      // [xstride] slot -> block                  (k_place_blocks)
+  int xstride;          // entries (the number of blocks of the smallest block size: a layout independent of the row width)
 };
+#ifndef DRX_XBINS
+#define DRX_XBINS 8      // (64 — bins of 0.5 MB of gradient rows, taken in order — measured SLOWER at the ml-1m shape: 0.60 against 0.54 ms)
+#endif
+constexpr int kXBase = 32, kXBins = DRX_XBINS;     // SpanPlan::cnt[kXBase ..]: the bins' counts; cnt[16] != 0: placed; cnt[17]: the block size
 
-// block `blk` (chunks blk * cpb ...) goes to the list of the eighth of the batch its first touch's sample lies in.  Called by whole
-// waves (`on`: this lane has a block): the lanes of a wave that chose the same list take their places with ONE atomic (65 k single
-// atomics on 8 counters took the planning kernel from 30 to 480 us and slowed everything beside it).
+// block `blk` (chunks blk * cpb ...) joins the bin of the 64th of the batch its first touch's sample lies in.  Called by whole waves
+// (`on`: this lane has a block): the lanes of a wave that chose the same bin take their ranks with ONE atomic (single atomics on a
+// handful of counters took the planning kernel from 30 to 480 us and slowed everything beside it).
 __device__ __forceinline__ void place_block(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s, int T, int cpb, int B,
                                             const SpanPlan &P, int blk, bool on) {
-  int x = blk & 7;
+  int x = blk & (kXBins - 1);
   if (on) {
     const int at = blk * cpb * kChunk;
-    if (at < T && keys_s[at] != DRX_KEY_NONE) {                 // (a blanked or dropped touch carries no sample: any list will do)
+    if (at < T && keys_s[at] != DRX_KEY_NONE) {                 // (a blanked or dropped touch carries no sample: any bin will do)
       const uint32_t b = vals_s[at];
-      x = (int)min(7u, (uint32_t)(((unsigned long long)b * 8ull) / (unsigned long long)(B > 0 ? B : 1)));
+      x = (int)min((uint32_t)(kXBins - 1), (uint32_t)(((unsigned long long)b * (unsigned long long)kXBins) / (unsigned long long)(B > 0 ? B : 1)));
     }
   }
   const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
+  unsigned long long todo = __ballot(on);
+  while (todo) {                                                  // one round per bin present in the wave
+    const int first = __ffsll((long long)todo) - 1;
+    const int r = __shfl(x, first);
     const unsigned long long m = __ballot(on && x == r);
-    if (m == 0ull) continue;
-    const int leader = __ffsll((long long)m) - 1;
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&P.cnt[8 + r], (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader);
-    if (on && x == r) P.xlist[(size_t)r * P.xstride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+    if (lane == first) base = atomicAdd(&P.cnt[kXBase + r], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, first);
+    if (on && x == r) P.xrank[blk] = ((uint32_t)r << 24) | (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+    todo &= ~m;
   }
   if (on && blk == 0) { P.cnt[16] = 1u; P.cnt[17] = (uint32_t)cpb; }
 }
 
+// after the plan: slot -> block, bin by bin (one more small launch on the preparation's stream, lists of long segments only)
+static __global__ __launch_bounds__(256) void k_place_blocks(SpanPlan P, int n_chunks) {
+  __shared__ uint32_t pre[kXBins];
+  if (threadIdx.x < kXBins) {
+    uint32_t run = 0;
+    for (int t = 0; t < (int)threadIdx.x; ++t) run += P.cnt[kXBase + t];
+    pre[threadIdx.x] = run;
+  }
+  __syncthreads();
+  const int cpb = (int)P.cnt[17];
+  const int nb = cpb > 0 ? (n_chunks + cpb - 1) / cpb : 0;
+  for (int blk = blockIdx.x * blockDim.x + threadIdx.x; blk < nb; blk += gridDim.x * blockDim.x) {
+    const uint32_t e = P.xrank[blk];
+    P.xperm[pre[e >> 24] + (e & 0xFFFFFFu)] = (uint32_t)blk;
+  }
+}
+
 // the block a reduction workgroup takes: launch index j (its XCD = j % 8), `extra` workgroups of another role in front, n_wg of this one
 __device__ __forceinline__ int placed_block(const SpanPlan &P, int j, int extra, int n_wg, int cpb) {
-  // (cnt[17]: the block size the lists were made for — a list prepared by a rank of another row width is taken in list order)
-  if (!P.xlist || P.cnt[16] == 0u || P.cnt[17] != (uint32_t)cpb) return j - extra;
+  // (cnt[17]: the block size the bins were made for — a list prepared by a rank of another row width is taken in list order)
+  if (!P.xperm || P.cnt[16] == 0u || P.cnt[17] != (uint32_t)cpb) return j - extra;
   const int x = j & 7;
-  int own[8], q[8];
+  int own[8], q[8], have[8], start[8];
+  int run = 0;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
+    int c = 0;
+#pragma unroll
+    for (int t = 0; t < kXBins / 8; ++t) c += (int)P.cnt[kXBase + r * (kXBins / 8) + t];
+    have[r] = c; start[r] = run; run += c;
     const int first = extra + ((r - extra) & 7);                 // smallest launch index >= extra with residue r
     q[r] = first < extra + n_wg ? (extra + n_wg - 1 - first) / 8 + 1 : 0;
-    own[r] = min((int)P.cnt[8 + r], q[r]);
+    own[r] = min(c, q[r]);
   }
   const int i = (j - (extra + ((x - extra) & 7))) / 8;
-  if (i < own[x]) return (int)P.xlist[(size_t)x * P.xstride + i];
+  if (i < own[x]) return (int)P.xperm[start[x] + i];
   int f = i - own[x];                                            // this workgroup's number among the FREE ones ...
 #pragma unroll
   for (int r = 0; r < 8; ++r) f += r < x ? q[r] - own[r] : 0;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {                                  // ... takes the f-th block its list's workgroups could not
-    const int over = (int)P.cnt[8 + r] - own[r];
-    if (f < over) return (int)P.xlist[(size_t)r * P.xstride + own[r] + f];
+  for (int r = 0; r < 8; ++r) {                                  // ... takes the f-th block its XCD's workgroups could not
+    const int over = have[r] - own[r];
+    if (f < over) return (int)P.xperm[start[r] + own[r] + f];
     f -= over;
   }
   return j - extra;                                              // (unreachable: as many free workgroups as overflow blocks)
@@ -291,7 +320,7 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, const uint32_t
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, g);
   const int nb = (n_chunks + cpb - 1) / cpb;
-  if (P.xlist && (g & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, g, g < nb);
+  if (P.xrank && (g & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, g, g < nb);
 }
 
 // LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the

@@ -130,7 +130,10 @@ class CdaeEngine:
         assert ip.numel() == self.n_users + 1
         self._recorded = (History(ptr(ip), ptr(ix)), ip, ix)
 
-    def set_history(self, indptr, indices):
+    TRANSPOSE_MAX_NNZ, TRANSPOSE_MAX_ROWS = 1 << 27, 1 << 22
+    sample_by_user = True        # device-sampled batches in user order where the history's transpose exists (sample_device)
+
+    def set_history(self, indptr, indices, with_transpose=True):
         self.hist_indptr = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device) \
             if not torch.is_tensor(indptr) else indptr.to(self.device, torch.int64)
         self.hist_indices = torch.as_tensor(np.asarray(indices, dtype=np.int32)).to(self.device) \
@@ -139,6 +142,21 @@ class CdaeEngine:
             self.hist_indices = torch.zeros(1, dtype=torch.int32, device=self.device)
         assert self.hist_indptr.numel() == self.n_users + 1
         self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices))
+        self._hist_t = None
+        nnz = int(self.hist_indptr[-1].item())
+        if with_transpose and 0 < nnz <= self.TRANSPOSE_MAX_NNZ and 2 * self.n_items + self.n_users <= self.TRANSPOSE_MAX_ROWS:
+            # the transpose of the history (item -> users, with every entry's position in its user's row): batches whose rows collect
+            # long runs of touches (MovieLens shapes) are then prepared by expanding it instead of sorting millions of pairs per step
+            # (include/drx.h DrxHistory::t_*).  Once per dataset, with torch ops on the device (set-up, not the hot path).
+            ip, idx = self.hist_indptr, self.hist_indices[:nnz].long()
+            rows = torch.repeat_interleave(torch.arange(self.n_users, device=self.device), (ip[1:] - ip[:-1]))
+            pos = torch.arange(nnz, device=self.device) - ip[rows]
+            order = torch.argsort(idx * self.n_users + rows)
+            t_indptr = torch.zeros(self.n_items + 1, dtype=torch.int64, device=self.device)
+            t_indptr[1:] = torch.cumsum(torch.bincount(idx, minlength=self.n_items), 0)
+            self._hist_t = (t_indptr, rows[order].to(torch.int32).contiguous(), pos[order].to(torch.int32).contiguous())
+            self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices), ptr(self._hist_t[0]), ptr(self._hist_t[1]),
+                                 ptr(self._hist_t[2]), nnz)
 
     # ---- optimizer --------------------------------------------------------------------------
     def init_optimizer(self, kind, lr, reg_rate, beta1=ADAM_B1, beta2=ADAM_B2, eps=None, initial_accumulator=ADAGRAD_INIT):
@@ -520,7 +538,10 @@ class CdaeEngine:
             out = (torch.empty(B, dtype=torch.int32, device=self.device), torch.empty(B, dtype=torch.int32, device=self.device),
                    torch.empty(B, dtype=torch.float32, device=self.device), torch.empty(B + 1, dtype=torch.int32, device=self.device))
         uid, iid, y, keep_off = out
-        need = lib().drx_point_sample_scratch_bytes(B)
+        # with the history's transpose (MovieLens shapes) the batch is handed out in user order: its touch list then has every row's
+        # touches sample-ascending (include/drx.h drx_point_sample_by_user)
+        by_user = getattr(self, '_hist_t', None) is not None and self.sample_by_user
+        need = lib().drx_point_sample_by_user_scratch_bytes(B, self.n_users) if by_user else lib().drx_point_sample_scratch_bytes(B)
         # one scratch per stream: draws queued on different streams (a pipeline's run-ahead stream, a caller's own) run side by side
         pool = self.__dict__.setdefault('_sscratch', {})
         key = torch.cuda.current_stream(self.device).cuda_stream
@@ -528,11 +549,12 @@ class CdaeEngine:
             pool[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         scratch = pool[key]
         rec = getattr(self, '_recorded', None)
-        check(lib().drx_point_sample_recorded(C.byref(self._hist), C.byref(rec[0]) if rec is not None else None, self.n_users,
-                                              n_items or self.n_items, B, neg_ratio, int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y),
-                                              ptr(keep_off), ptr(scratch), scratch.numel(), ptr(mailbox), int(tag) & 0xFFFFFFFF,
-                                              stream_ptr(self.device)),
-              'drx_point_sample_recorded')
+        fn = lib().drx_point_sample_by_user if by_user else lib().drx_point_sample_recorded
+        check(fn(C.byref(self._hist), C.byref(rec[0]) if rec is not None else None, self.n_users,
+                 n_items or self.n_items, B, neg_ratio, int(seed) & (2 ** 64 - 1), ptr(uid), ptr(iid), ptr(y),
+                 ptr(keep_off), ptr(scratch), scratch.numel(), ptr(mailbox), int(tag) & 0xFFFFFFFF,
+                 stream_ptr(self.device)),
+              'drx_point_sample_by_user' if by_user else 'drx_point_sample_recorded')
         return out
 
     def topk(self, scores, k, cand_mask=None):

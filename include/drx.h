@@ -64,6 +64,14 @@ typedef struct DrxCdaeParams {
 typedef struct DrxHistory {
   const int64_t *indptr;   /* [n_users + 1] */
   const int32_t *indices;  /* [indptr[n_users]] */
+  /* Optional TRANSPOSE of the same matrix (all NULL / 0: none): for every item the users that hold it, ascending, and where the item
+   * sits in each such user's row — indices[indptr[t_users[e]] + t_pos[e]] == item of entry e.  With it the preparation of a sampled
+   * batch whose rows collect long runs of touches (MovieLens shapes: more than 8 touches per table row) EXPANDS this static structure
+   * by the batch's samples of every user instead of sorting millions of (row, sample) pairs per step (csrc/drx_prep.hpp). */
+  const int64_t *t_indptr; /* [n_items + 1] */
+  const int32_t *t_users;  /* [t_nnz] */
+  const int32_t *t_pos;    /* [t_nnz] */
+  int64_t t_nnz;           /* = indptr[n_users] */
 } DrxHistory;
 
 /* One mini-batch (one fit() "epoch", recommender_abc.py:189-205).
@@ -182,6 +190,15 @@ int drx_point_sample(const DrxHistory *hist, int32_t n_users, int32_t n_items, i
 int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistory *recorded, int32_t n_users, int32_t n_items, int32_t B,
                               int32_t neg_ratio, uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off,
                               void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
+
+/* The same draws (the same triples for the same seed), handed out SORTED BY USER, a user's triples in the order they were drawn —
+ * for batches whose touch lists are prepared through the history's transpose (DrxHistory::t_*): with the batch in user order the
+ * expanded list has every row's touches sample-ascending, i.e. the reduction streams through the gradient rows instead of hopping,
+ * and the triples of one user sit side by side in the forward kernel.  The order of a batch changes no sum's terms. */
+size_t drx_point_sample_by_user_scratch_bytes(int32_t B, int32_t n_users);
+int drx_point_sample_by_user(const DrxHistory *hist, const DrxHistory *recorded, int32_t n_users, int32_t n_items, int32_t B,
+                             int32_t neg_ratio, uint64_t seed, int32_t *uid, int32_t *iid, float *y, int32_t *keep_off, void *scratch,
+                             size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
 
 /* The same draws carrying VALUES (DMF.fit(device_sampler=True), dmf.py:64-73): y[b] = 0 for a negative, else the drawn pair's
  * interaction value pos_values[position in hist] — standardised (v - vmin) / vrange when vrange > 0 (use_nce:

@@ -281,3 +281,71 @@ def test_sparse_step_is_deterministic():
         outs.append([t.clone() for t in eng.tables()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('explicit', [False, True])
+@pytest.mark.parametrize('K,opt', [(128, 'adagrad'), (50, 'adam'), (16, 'adagrad')])
+def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_sorted_lists(K, opt, explicit):
+    """Lists of long segments (more than 8 touches per table row: MovieLens shapes) are prepared by expanding the history's transpose
+    (DrxHistory::t_*: only the batch's 2B (id, sample) pairs are sorted) instead of sorting every (row, sample) pair: same oracle;
+    against the sort path the parameters agree to rounding (inside a segment the touches come user by user instead of sample by
+    sample: another fixed order of the same sum), and two runs of the transposed path agree bit for bit."""
+    U, N, B = 150, 70, 1024
+    results = []
+    for mode in ('transpose', 'transpose', 'sort'):
+        eng, p, rng = _engine(U, N, K, seed=21)
+        indptr, indices = synth_history(rng, U, N, 14, zipf=1.0)
+        eng.set_history(indptr, indices, with_transpose=mode == 'transpose')
+        assert (eng._hist_t is not None) == (mode == 'transpose')
+        lr = 1e-3 if opt == 'adam' else 0.05
+        eng.init_optimizer(opt, lr, 1e-3)
+        st = co.sparse_state(p, opt)
+        q = 0.2
+        qf = float(np.float32(q))
+        for step in range(4):
+            uids = rng.integers(0, U, size=B)
+            iids = rng.integers(0, N, size=B)
+            y = (rng.random(B) < 0.3).astype(np.float32)
+            t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+            seed = 300 + step
+            if explicit:
+                keep = (rng.random(keep_off[-1]) >= q).astype(np.uint8)
+                bt, alive = eng.make_batch(uids, iids, y, keep_off=keep_off, keep=keep, q=q)
+            else:
+                keep = np.concatenate([hash_u32(seed, np.full(keep_off[b + 1] - keep_off[b], b), np.arange(keep_off[b + 1] - keep_off[b])) >= q_threshold(q)
+                                       for b in range(B)]).astype(np.uint8)
+                bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+            assert bt.n_touch_slots + 2 * B > 8 * (2 * N + U)                      # long segments: the rule of csrc/drx_prep.hpp
+            _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+            lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, lr, 1e-3, 'bce', opt)
+            lg = eng.step_sparse(step, bt, 'bce', want_loss=True, prepared=eng.prepare_sparse(bt)).cpu().numpy()
+            assert abs(lg[0] - lo) / abs(lo) < 1e-4, (mode, step, lg, lo)
+        g = eng.get_params()
+        for k in p:
+            np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5, err_msg=f'{mode} {k}')
+        results.append(g)
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k]), k                      # the transposed path twice: bit for bit
+        np.testing.assert_allclose(results[0][k], results[2][k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_device_sampler_in_user_order_draws_the_same_triples():
+    """drx_point_sample_by_user: the draws of drx_point_sample_recorded for the same seed, sorted by user (a user's triples in draw
+    order), keep_off the prefix sums of the sorted users' degrees, the total posted to the mailbox."""
+    import torch
+    U, N, B = 200, 90, 4096
+    eng, p, rng = _engine(U, N, 16, seed=8)
+    indptr, indices = synth_history(rng, U, N, 9, zipf=1.0, min_deg=1)
+    eng.set_history(indptr, indices)
+    assert eng._hist_t is not None
+    mb = torch.zeros(1, dtype=torch.int64).pin_memory()
+    su, si, sy, sko = [t.clone() for t in eng.sample_device(B, 3, 77, mailbox=mb, tag=5)]
+    eng.sample_by_user = False
+    du, di, dy, _ = [t.clone() for t in eng.sample_device(B, 3, 77)]
+    torch.cuda.synchronize()
+    du, di, dy = du.cpu().numpy(), di.cpu().numpy(), dy.cpu().numpy()
+    order = np.argsort(du, kind='stable')
+    assert np.array_equal(su.cpu().numpy(), du[order]) and np.array_equal(si.cpu().numpy(), di[order]) and np.array_equal(sy.cpu().numpy(), dy[order])
+    deg = (indptr[1:] - indptr[:-1])[du[order]]
+    assert np.array_equal(sko.cpu().numpy(), np.concatenate([[0], np.cumsum(deg)]))
+    assert int(mb[0]) == (5 << 32) | int(deg.sum())
