@@ -207,7 +207,8 @@ class ShardedCdae:
         self.loss_kind = 0 if loss == 'bce' else 1
         self.q = q
         if self.engine is not None:
-            self.engine.set_history(hist_indptr, hist_indices)
+            # (the engine's tables are this rank's SHARD — its item rows are local, the history's item ids global: no transpose)
+            self.engine.set_history(hist_indptr, hist_indices, with_transpose=False)
             self._init_random(seed)
         self.last_loss = None
         self._cur = self._main = None         # ShardedPipeline: the stream its run-ahead stages are queued on / the training stream
