@@ -774,19 +774,21 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                  'k_span_planned(short | long spans | bias update)', '(unused)']
         dom, dom_ms, dom_alg = ('k_seg_reduce_planned', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
     else:
-        names = ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce(+overlapped exchanges)', 'rest_of_grad_exchange', 'owner_apply+bias_update', '(unused)']
+        names = (['row_gather+row_exchange', 'k_shard_fwd_bwd', 'k_seg_reduce_planned<LocalPolicy>(+bias partials)',
+                  'k_span_planned(+bias row)', 'grad_exchange+k_shard_apply(+bias update)'] if micro == 1 else
+                 ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce of all micro-batches', '-', '-', 'grad_exchange+k_shard_apply'])
         # forward reads one row per occurrence, the local reduce one gradient row per occurrence
-        dom, dom_ms, dom_alg = 'k_shard_fwd_bwd+k_seg_reduce<LocalPolicy>', ph[1], 2.0 * B * 4.0 * K * rows_per_sample
+        dom, dom_ms, dom_alg = 'k_shard_fwd_bwd+k_seg_reduce<LocalPolicy>', ph[1] + ph[2], 2.0 * B * 4.0 * K * rows_per_sample
     achieved = dom_alg / (dom_ms * 1e-3) / 1e9
     step_alg = B * 4.0 * K * rows_per_sample * (3.0 + 2.0 * S_opt)
     # ---- dedup-aware byte model: exact occurrence / distinct-row counts of batches of the TIMED region ----------------------------
     dedup = None
     n_timed_steps = args.steps * max(1, args.windows)
-    if stepper is None:
+    if stepper is None or (world == 1 and micro == 1):
         picks = sorted(set(int(x) for x in np.linspace(0, n_timed_steps - 1, 6)))
         stats = []
         for s_ in picks:
-            if fresh:                                   # the pipeline drew step (warmup + s_) from these seeds: draw it again
+            if fresh or fresh_sharded:                  # the pipeline drew step (warmup + s_) from these seeds: draw it again
                 seed_ = 5000 + 7919 * (args.warmup + s_) + 104729 * rank
                 u_, i_, _, ko_ = eng.sample_device(B, NEG_RATIO, seed_, n_items=N)
             else:
@@ -845,6 +847,32 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     }
     out.update(win.fields(world * B))
     ms_of = {'k_sampled_fwd_bwd': float(ph[0]), 'k_seg_reduce': float(ph[2])} if stepper is None else {}
+    if dedup is not None and stepper is not None:
+        # row layout at world 1: strictly necessary HBM bytes of its three big kernels from the same exact row counts —
+        #   forward   : every distinct W / W2T row once (from the tables with the self-bypass, from the received buffer otherwise), the V
+        #               row of every triple, dz1 written, g2 written where the W2T row is shared, else the gradient row straight into the
+        #               exchange buffer; V rows one triple touches updated in place (S slot rows in, parameter + S slot rows out)
+        #   reduction : one gradient row WRITTEN per distinct W row and shared W2T row, 8 B per touch, shared V rows read-modify-written
+        #   apply     : per distinct item row the gradient row in, parameter + S slot rows in and out
+        st_, row_ = dedup['per_batch_mean'], 4.0 * K
+        dist_item = st_['dist_W'] + st_['dist_O']
+        nb = {'k_shard_fwd_bwd': row_ * (dist_item + st_['dist_V'] + B + (B - st_['solo_O']) + st_['solo_O'] + st_['solo_V'] * (1 + 2 * S_opt))
+                                 + 4.0 * st_['history_items'] + 40.0 * B,
+              'k_seg_reduce_planned': row_ * (st_['dist_W'] + (st_['dist_O'] - st_['solo_O']) + (st_['dist_V'] - st_['solo_V']) * (2 + 2 * S_opt))
+                                      + 8.0 * (st_['occ_W'] + (B - st_['solo_O']) + (B - st_['solo_V'])),
+              'k_shard_apply': row_ * dist_item * (3 + 2 * S_opt)}
+        tm = {'k_shard_fwd_bwd': float(ph[1]), 'k_seg_reduce_planned': float(ph[2]), 'k_shard_apply': float(ph[4])}
+        per_kernel = {k_: {'bytes_per_launch': nb[k_], 'avg_launch_ms': tm[k_], 'achieved': nb[k_] / (tm[k_] * 1e-3) / 1e9,
+                           'frac': nb[k_] / (tm[k_] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k_ in nb}
+        domk = max(tm, key=lambda k_: tm[k_])
+        step_bytes = sum(nb.values())
+        out['roofline'] = {'bound': 'hbm', 'kernel': domk, 'achieved': per_kernel[domk]['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': per_kernel[domk]['frac'], 'traffic': None, 'kernels': per_kernel, 'row_counts': dedup['per_batch_mean'],
+                           'avg_launch_ms': tm[domk], 'timed_launches': n_timed, 'whole_step_bytes': step_bytes,
+                           'whole_step_frac': step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 'hbm_copy_achievable': copy_gbs,
+                           'definition': 'row layout at world 1: strictly necessary HBM bytes of its three big kernels (bench.py) / HIP-event time between '
+                                         'the library\'s launches / 8 TB/s; `k_shard_apply` time includes the (empty, with the self-bypass) gradient exchange'}
+        dedup = None
     if dedup is not None:
         # `frac` = dedup-aware algorithmic HBM bytes / measured launch time / peak: a fraction by construction (what has to
         # cross the HBM interface at least once; everything re-read is assumed cached).  `model_*` = SURVEY 8d's
@@ -899,7 +927,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                           'launch time / 8 TB/s — never above traffic_frac; per_occurrence_* = one gather read per occurrence where the table '
                           'exceeds the 256 MiB Infinity Cache (the r01-r03 headline); traffic = PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; '
                           'counts Infinity-Cache hits); requested_* = cache-level rows; model_* = SURVEY 8d per-occurrence read-modify-write bytes'}
-    else:
+    elif out.get('roofline') is None:
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
                            'traffic': None, 'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
                            'avg_launch_ms': float(dom_ms), 'timed_launches': n_timed, 'hbm_copy_achievable': copy_gbs,

@@ -330,14 +330,14 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep_pass(const uint32_t *
     for (size_t i = n_valid + (size_t)blockIdx.x * kSortThreads + tid; i < n; i += (size_t)gridDim.x * kSortThreads) kout[i] = DRX_KEY_NONE;
 }
 
-// workgroups per launch (each loops over tiles): DRX_SORT_GRID overrides for experiments.  r02 kept the grid at 128 so that the sort
+// workgroups per launch (each loops over tiles; -DDRX_SORT_GRID=n builds a variant).  r02 kept the grid at 128 so that the sort
 // stayed out of the training kernels' way; with the r03 training kernels the PREPARATION is what bounds the pipeline and the
 // measurement turned around (r03m, step time at 64 / 128 / 192 / 256 / 352 workgroups: 0.424 / 0.394 / 0.383 / 0.380 / 0.375 ms;
 // 352 = one workgroup per tile of the 1.44 M-pair list): 512, i.e. a workgroup per tile up to 2 M pairs.
-inline int sort_grid() {
-  static int g = [] { const char *e = getenv("DRX_SORT_GRID"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
-  return g;
-}
+#ifndef DRX_SORT_GRID
+#define DRX_SORT_GRID 512
+#endif
+inline int sort_grid() { return DRX_SORT_GRID; }
 
 inline size_t onesweep_lds_bytes(int r) { return ((size_t)(kSortWaves + 2) * ((size_t)1 << r) + 2 * (size_t)kSortTile + 2048) * 4; }
 

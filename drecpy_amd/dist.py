@@ -356,9 +356,9 @@ class ShardedCdae:
         owned row is updated once with the sum of their gradients — the step still equals the single-process step on the
         concatenated batch — but the row exchange of micro-batch m+1 and the gradient exchange of micro-batch m travel while
         the other one computes.
-        Event slots (bench): [0,1) row gather + the first row exchange, [1,2) forward/backward + local reduction of all
-        micro-batches (later row / earlier gradient exchanges hidden behind them), [2,3) rest of the gradient exchange,
-        [3,4) owner apply + bias.
+        Event slots (bench; one micro-batch): [0,1) row gather + row exchange, [1,2) forward / backward kernel, [2,3) planned
+        reduction, [3,4) span launch (+ the rank's bias row), [4,5) gradient exchange + owner apply (+ bias update) — slots 1..4 are
+        recorded by the library between its launches (drx_shard_step_local).  With several micro-batches: [1,4) = all of them.
         after_row_requests: called once the row exchanges of this step and the kernels of its first micro-batch are queued —
         ShardedPipeline queues the run-ahead count / key exchanges of later batches there, so that on the communicator they sit
         behind this step's row exchange (and travel while it computes) instead of in front of it.
@@ -386,14 +386,16 @@ class ShardedCdae:
             rows = ops.gather_rows(P['req'], P['recv_counts'])
             fetched.append(self._a2a(rows, ops.xsplits(P['recv_counts']), ops.xsplits(P['send_counts']), overlap=ov))
         wait(fetched[0][1])
-        rec(1)
+        inner = events[1:5] if (events is not None and len(Ps) == 1) else None
+        if inner is None:
+            rec(1)
         n_recv = [sum(ops.xsplits(P['recv_counts'])) for P in Ps]
         grecv = None
         pushed, off = [], 0
         for m, (b, P) in enumerate(zip(bts, Ps)):
             cache, w1 = fetched[m]
             wait(w1)
-            gsend = ops.local_step(b, P, cache, b_norm, self.loss_kind, opt)
+            gsend = ops.local_step(b, P, cache, b_norm, self.loss_kind, opt, events=inner)
             if m == 0 and after_row_requests is not None:
                 # the run-ahead stages are ISSUED here — behind this step's row exchange on the communicator (they travel while the
                 # step computes) and in front of its gradient exchange, and while the training stream has the forward / backward and
@@ -404,14 +406,13 @@ class ShardedCdae:
             pushed.append((self._a2a(gsend, ops.xsplits(P['send_counts']), ops.xsplits(P['recv_counts']),
                                      out=grecv[off:off + max(n_recv[m], 1)], overlap=ov)[1], gsend))
             off += n_recv[m]
-        rec(2)
+        if inner is None:
+            rec(2); rec(3); rec(4)
         for w1, _ in pushed:
             wait(w1)
-        rec(3)
         head = Ps[0]
         loss = ops.apply(head['req_all'], grecv, head['counts_all'], head['table'], b_norm, opt, want_loss=want_loss,
                          own=[(g, P['send_counts']) for (_, g), P in zip(pushed, Ps)])
-        rec(4)
         rec(5)
         if after_apply is not None:
             after_apply()
