@@ -15,6 +15,7 @@ OPT_ADAM, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
 DENSE_AUX_CLEAN = 0x100          # include/drx.h: DRX_DENSE_AUX_CLEAN
 KEY_NONE = 0xFFFFFFFF
 SHARD_SELF_BYPASS = 1            # include/drx.h: DRX_SHARD_SELF_BYPASS
+BATCH_SHARE_USERS = 1            # include/drx.h: DRX_BATCH_SHARE_USERS
 
 
 class DrxError(RuntimeError):

@@ -601,6 +601,9 @@ struct SparseBufs {
   const uint8_t *solo_v, *solo_o;             // [B] each or nullptr: sample b is the ONLY toucher of its V / W2T row
   unsigned long long *stamps;                 // diagnostic builds (DRX_STAMPS) only
   const int32_t *order;                       // [B] or nullptr: launch order of the forward kernel's triples (k_order_by_degree)
+  // DRX_BATCH_SHARE_USERS (k_items_fwd_bwd): the batch's work items (drx_prep.hpp PrepBufs); dz1 then holds B more rows behind the
+  // samples': the items' summed gradients.  Else nullptr.
+  const int32_t *usamp, *wfirst, *n_items;
   int T, n_chunks, n_bpart;
 };
 
@@ -766,6 +769,137 @@ __global__ __launch_bounds__(kBlock) void k_sampled_fwd_bwd(DrxCdaeParams P, Drx
   sampled_finish<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, acc);
 }
 
+// the lanes of this thread's row group for which f holds (bit i: lane i of the group)
+template <int G>
+__device__ __forceinline__ unsigned long long group_ballot(bool f) {
+  const unsigned long long m = __ballot(f);
+  if (G >= 64) return m;
+  const int sh = ((int)(threadIdx.x & 63) / G) * G;
+  return (m >> sh) & ((1ull << (G & 63)) - 1ull);
+}
+
+// DRX_BATCH_SHARE_USERS: one WORKGROUP per work item — up to kBlock / G triples of ONE user (drx_prep.hpp k_tp_number_items).
+//   A. the row groups split the user's WHOLE history, the partial sums are combined in LDS in group order: S_u, in every group;
+//   B. group r takes the item's r-th triple: its bag = S_u - the rows its corruption mask DROPPED (q of the history: at q = 0.2 a fifth
+//      of the rows the plain kernel gathers; the dropped entries of a round of G are taken 8 at a time, compacted by a ballot),
+//      then forward / loss / backward as in k_sampled_fwd_bwd;
+//   C. the item's summed gradient row dz1[B + item] = sum of its triples' dz1, in group order: what the touch list's shared entries
+//      (sample field B + item) name.
+// At the ml-1m shape (6 040 users, 65 536 triples: 11 per user) the three launches this replaces (all-rows sums per user; dropped rows
+// per triple; gradient sums per user) took 116 + 191 + 60 us, the plain kernel 350 us.
+template <int G, int J, int KIND = -1>
+__global__ __launch_bounds__(kBlock) void k_items_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+                                                          uint32_t qthr, int loss_kind, SparseBufs S) {
+  extern __shared__ __align__(16) float lds[];   // [R, ld]
+  constexpr int R = kBlock / G;
+  constexpr int NF = J == 1 ? 8 : 4;
+  const int w = blockIdx.x;
+  if (w >= S.n_items[0]) return;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  const int p0 = S.wfirst[w], p1 = S.wfirst[w + 1];
+  const int u = bt.uid[S.usamp[p0]];
+  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+  // A
+  float4 su[J];
+  {
+    float4 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+    for (int64_t c = s + (int64_t)r * NF; c < e; c += (int64_t)R * NF) {
+      float4 v[NF][J];
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
+        if (c + q < e) load_row<G, J>(P.W, (size_t)H.indices[c + q], P.ld, lane, v[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NF; ++q)
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(acc[j], v[q][j]);
+    }
+    const int n_groups = (int)min((int64_t)R, (e - s + NF - 1) / NF);          // groups that had rows at all
+    if (r < n_groups) store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) su[j] = f4_zero();
+    for (int rr = 0; rr < n_groups; ++rr) {
+      float4 v[J];
+      load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(su[j], v[j]);
+    }
+  }
+  // B
+  const bool have = p0 + r < p1;
+  float4 dz1[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) dz1[j] = f4_zero();
+  if (have) {
+    const int b = S.usamp[p0 + r];
+    const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
+    float4 drop[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) drop[j] = f4_zero();
+    auto fetch = [&](int64_t c, int &idx, bool &df) {
+      const int64_t j = c + lane;
+      idx = 0; df = false;
+      if (j < e) {
+        idx = H.indices[j];
+        const uint32_t jj = (uint32_t)(j - s);
+        df = !(kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr));
+      }
+    };
+    int idx; bool df;
+    fetch(s, idx, df);
+    for (int64_t c = s; c < e; c += G) {
+      int idx_n = 0; bool df_n = false;
+      if (c + G < e) fetch(c + G, idx_n, df_n);          // the next round's entries are under way while this round's rows are
+      unsigned long long m = group_ballot<G>(df);
+      while (m) {
+        float4 v[NF][J];
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
+          if (m) {
+            const int t = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const int iq = __shfl(idx, t, G);
+            load_row<G, J>(P.W, (size_t)iq, P.ld, lane, v[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NF; ++q)
+#pragma unroll
+          for (int j = 0; j < J; ++j) f4_add(drop[j], v[q][j]);
+      }
+      idx = idx_n; df = df_n;
+    }
+    float4 acc[J], h[J], w2[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { acc[j].x = su[j].x - drop[j].x; acc[j].y = su[j].y - drop[j].y; acc[j].z = su[j].z - drop[j].z; acc[j].w = su[j].w - drop[j].w; }
+    const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
+    sampled_rest<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, d, h, w2, &dz1);
+  }
+  // C
+  __syncthreads();                                   // (every group has read the partial sums of A)
+  if (have) store_row<G, J>(lds, (size_t)r, P.ld, lane, dz1);
+  __syncthreads();
+  if (r == 0) {
+    float4 t[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) t[j] = f4_zero();
+    for (int rr = 0; rr < p1 - p0; ++rr) {
+      float4 v[J];
+      load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
+    }
+    store_row<G, J>(S.dz1, (size_t)bt.B + w, P.ld, lane, t);
+  }
+}
+
 // Small batches of long histories (ml-1m: 155 items per user, B of a few thousand): with one group per triple the gather is
 // a chain of ~20 dependent load rounds on a chip that is mostly idle (measured 143 us at B = 4096).  Here one WORKGROUP
 // takes a triple: its 256/G groups split the history, the partial bags are summed in LDS in group order.
@@ -809,12 +943,15 @@ struct DirectPolicyT {
   long long g2_off;
   const float *dz2;
   template <int G, int J>
-  __device__ __forceinline__ void load(uint32_t key, uint32_t b, int lane, float4 (&row)[J], float &sc, float &coef) const {
+  __device__ __forceinline__ void load(uint32_t key, uint32_t bv, int lane, float4 (&row)[J], float &sc, float &coef) const {
     const uint32_t N = (uint32_t)P.n_items;
     const bool is_out = key >= N && key < 2 * N;
+    // (DRX_BATCH_SHARE_USERS lists: the top bit of a W touch's sample field says "subtract"; fields >= B name a user's summed row,
+    // stored behind the samples' rows)
+    const uint32_t b = bv & 0x7FFFFFFFu;
     load_row<G, J>(dz1 + (is_out ? g2_off : 0ll), (size_t)b, P.ld, lane, row);
     if (is_out) sc = dz2[b];
-    coef = key < N ? scale : 1.0f;
+    coef = key < N ? ((bv >> 31) ? -scale : scale) : 1.0f;
   }
   template <int G, int J>
   __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
@@ -955,7 +1092,7 @@ static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n
   S.T = n_touch_slots + 2 * B;
   S.n_chunks = (S.T + kChunk - 1) / kChunk;
   S.n_bpart = 1024;      // (256: each row group of a bias block summed 32 rows one load at a time; tail_a 25.0 -> 23.5 us)
-  S.dz1 = cv.take<float>((size_t)B * P.ld);
+  S.dz1 = cv.take<float>((size_t)2 * B * P.ld);       // (the second half: the work items' summed rows of DRX_BATCH_SHARE_USERS)
   S.g2 = cv.take<float>((size_t)B * P.ld);
   S.dz2 = cv.take<float>(B);
   S.lossb = cv.take<float>(B);
@@ -1498,6 +1635,12 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   // One workgroup per triple (its groups split the history) instead of one group per triple: when a group would walk many
   // dependent load rounds.  Short histories (mean <= 64 items): only while the batch cannot fill the chip anyway.
   constexpr int wg_long = 64;
+  // DRX_BATCH_SHARE_USERS (lists prepared ahead through the history's transpose only): one forward workgroup per work item
+  // (k_items_fwd_bwd); the reduction reads the items' summed gradient rows
+  const bool share = prepared && !ks_h && share_users(p, hist, bt, R);
+  S.usamp = share ? R.usamp : nullptr;
+  S.wfirst = share ? R.wfirst : nullptr;
+  S.n_items = share ? R.n_du : nullptr;
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);
   BiasArgs BA{S.dz1, S.bpart, S.lossb, loss_out, bt->B, n_bpart, rows_per_block};
@@ -1534,7 +1677,17 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     if (ks_h)                                                                                                          \
       hipLaunchKernelGGL((k_kshard_rest<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt, scale, \
                          qthr, loss_kind, S, ks_h, ks_dot);                                                            \
-    else if (per_wg)                                                                                                   \
+    else if (share) {                                                                                                  \
+      /* work items: at most one per distinct user + one per gpb triples, never more than triples */                  \
+      const long long wmax = (long long)(p->n_users < bt->B ? p->n_users : bt->B) + bt->B / gpb + 1;                   \
+      const dim3 igrid((unsigned)(wmax < bt->B ? wmax : bt->B));                                                       \
+      if (opt->kind == DRX_OPT_ADAGRAD)                                                                                \
+        hipLaunchKernelGGL((k_items_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), igrid, dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
+                           *bt, scale, qthr, loss_kind, S);                                                            \
+      else                                                                                                             \
+        hipLaunchKernelGGL((k_items_fwd_bwd<G, J>), igrid, dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, *bt, scale, \
+                           qthr, loss_kind, S);                                                                        \
+    } else if (per_wg)                                                                                                 \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
                          *bt, scale, qthr, loss_kind, S);                                                              \
     else if (opt->kind == DRX_OPT_ADAGRAD)                                                                             \

@@ -242,6 +242,12 @@ struct PrepBufs {
   uint8_t *solo_v, *solo_o;     // [B] each (see k_mark_solo)
   SpanPlan plan;                // chunk-crossing segments of the list (k_plan_spans)
   int32_t *order;               // [B] launch order of the forward kernel (k_degree_counts / k_degree_scatter)
+  // DRX_BATCH_SHARE_USERS (lists of long segments only): the batch's WORK ITEMS — the samples of one user, in pieces of at most
+  // share_item_triples(ld) (the row groups of a forward workgroup), in the order of the sorted (user, sample) pairs
+  int32_t *usamp;               // [B] sorted position -> sample (the samples grouped by user, ascending inside a user)
+  int32_t *pitem;               // [B] sorted position -> its work item
+  int32_t *wfirst;              // [B + 1] work item -> its first sorted position; wfirst[n_items] = B
+  int32_t *n_du;                // [0] work items
   unsigned int *order_work;     // [512] bucket counts | running places (zeroed by k_sparse_touches)
   int n_chunks;
   size_t result_bytes;
@@ -273,6 +279,10 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
     const bool placed = long_segments(R.T, P);
     R.plan.xrank = placed ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
     R.plan.xperm = placed ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
+    R.usamp = placed ? cv.take<int32_t>(B) : nullptr;
+    R.pitem = placed ? cv.take<int32_t>(B) : nullptr;
+    R.wfirst = placed ? cv.take<int32_t>((size_t)B + 1) : nullptr;
+    R.n_du = placed ? cv.take<int32_t>(64) : nullptr;
   }
   R.order = cv.take<int32_t>(B);
   R.result_bytes = align_up(cv.off, 256);
@@ -341,11 +351,46 @@ static __global__ __launch_bounds__(256) void k_tp_runs(const uint32_t *__restri
   }
 }
 
-// WRITE = false: cnt[e] = kept samples of entry e;  WRITE = true: cnt holds the exclusive scan, the pairs are written
-template <bool WRITE>
+// triples of one work item (DRX_BATCH_SHARE_USERS): one per row group of the forward workgroup
+static inline int share_item_triples(int ld) { return kBlock / pick_geom(ld).G; }
+
+// ONE workgroup numbers the batch's work items from the sorted (user, sample) pairs — the first B of the 2B sorted pairs; start[]: the
+// first sorted position of every user's run (k_tp_runs).  A work item begins at every rt-th position of a run.
+static __global__ __launch_bounds__(1024) void k_tp_number_items(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B, int rt,
+                                                                 const int32_t *__restrict__ start, int32_t *__restrict__ usamp,
+                                                                 int32_t *__restrict__ pitem, int32_t *__restrict__ wfirst, int32_t *n_du,
+                                                                 uint32_t *plan_cnt) {
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int per = (B + 1023) / 1024;
+  const int lo = min(B, t * per), hi = min(B, (t + 1) * per);
+  int heads = 0;
+  for (int p = lo; p < hi; ++p) heads += ((p - start[ks[p]]) % rt == 0) ? 1 : 0;
+  int inc = heads;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int before = inc - heads, total = 0;
+  for (int ww = 0; ww < 16; ++ww) { if (ww < w) before += wsum[ww]; total += wsum[ww]; }
+  int item = before - 1;
+  for (int p = lo; p < hi; ++p) {
+    if ((p - start[ks[p]]) % rt == 0) { ++item; wfirst[item] = p; }
+    pitem[p] = item;
+    usamp[p] = (int32_t)vs[p];
+  }
+  if (t == 0) { wfirst[total] = B; n_du[0] = total; plan_cnt[21] = (uint32_t)total; }     // (SpanPlan::cnt[21]: place_block)
+}
+
+// WRITE = false: cnt[e] = touches of entry e;  WRITE = true: cnt holds the exclusive scan, the pairs are written.
+// SHARE (DRX_BATCH_SHARE_USERS): per work item of the entry's user (rt samples of the user's run), ONE touch of the item's summed
+// gradient row (sample field B + the work item) and one touch per sample of the item that DROPPED the entry (sample field | 0x80000000:
+// the reduction subtracts those) — where that is the shorter form; otherwise, as without the flag, one touch per sample that kept it.
+template <bool WRITE, bool SHARE>
 static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch bt, uint32_t qthr, int n_items, const int32_t *__restrict__ start,
                                                           const int32_t *__restrict__ end, const uint32_t *__restrict__ vs,
-                                                          int *__restrict__ cnt, uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s) {
+                                                          int *__restrict__ cnt, uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s,
+                                                          const int32_t *__restrict__ pitem, int rt) {
   // one thread per transpose entry; the item of an entry: lower bound over t_indptr, once per thread
   const int64_t nnz = H.t_nnz;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
@@ -358,12 +403,28 @@ static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch
       n = lo;
     }
     int at = WRITE ? cnt[e] : 0, kept = 0;
-    for (int q = 0; q < c; ++q) {
-      const uint32_t b = vs[s0 + q];
-      const bool kf = bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr);
-      if (kf) {
-        if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = b; ++at; }
+    auto keeps = [&](uint32_t b) -> bool {
+      return bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr);
+    };
+    const int piece = SHARE ? rt : (c > 0 ? c : 1);
+    for (int q0 = 0; q0 < c; q0 += piece) {
+      const int q1 = min(c, q0 + piece);
+      bool shared = false;
+      if (SHARE && q1 - q0 > 1) {                      // the shorter form of the two: never more touches than the plain list holds
+        int k = 0;
+        for (int q = q0; q < q1; ++q) k += keeps(vs[s0 + q]) ? 1 : 0;
+        shared = 1 + (q1 - q0 - k) < k;
+      }
+      if (shared) {
+        if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = (uint32_t)bt.B + (uint32_t)pitem[s0 + q0]; ++at; }
         ++kept;
+      }
+      for (int q = q0; q < q1; ++q) {
+        const uint32_t b = vs[s0 + q];
+        if (keeps(b) != shared) {
+          if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at; }      // top bit: subtracted
+          ++kept;
+        }
       }
     }
     if (!WRITE) cnt[e] = kept;
@@ -373,8 +434,9 @@ static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch
 // the W2T and V parts (the sorted batch pairs themselves) behind the W part, and DRX_KEY_NONE up to T
 static __global__ __launch_bounds__(256) void k_tp_tail(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B, int n_users,
                                                         int n_items, const int *__restrict__ off_last, const int *__restrict__ cnt_last, int T,
-                                                        uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s) {
+                                                        uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s, uint32_t *plan_cnt) {
   const int Tw = off_last[0] + cnt_last[0];          // (exclusive scan: the last entry's offset + its count)
+  if (blockIdx.x == 0 && threadIdx.x == 0) plan_cnt[20] = (uint32_t)(Tw + 2 * B);      // the list's real length (SpanPlan::cnt[20])
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < T - Tw; p += gridDim.x * blockDim.x) {
     uint32_t k = DRX_KEY_NONE, v = 0;
     if (p < B) { k = (uint32_t)n_items + (ks[B + p] - (uint32_t)n_users); v = vs[B + p] - (uint32_t)B; }        // items: sorted positions B .. 2B-1
@@ -386,8 +448,28 @@ static __global__ __launch_bounds__(256) void k_tp_tail(const uint32_t *__restri
 static int plan_zero_words(const PrepBufs &R);
 static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t st, bool cleared);
 
+// does the transposed preparation apply to this batch (and fit its work areas)?  The step asks the same question (share_users below).
+static bool transposed_applies(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R) {
+  if (!hist->t_indptr || !hist->t_users || !hist->t_pos || !long_segments(R.T, *p)) return false;
+  const int B = bt->B, U = p->n_users, N = p->n_items;
+  const int64_t nnz = hist->t_nnz;
+  if (nnz < 1 || nnz > (int64_t)R.T || nnz >= (1ll << 30) || (int64_t)U + N >= 0x7FFFFFFFll) return false;
+  Carver cw(nullptr, R.sort_bytes);
+  for (int i = 0; i < 4; ++i) (void)cw.take<uint32_t>((size_t)2 * B);
+  (void)cw.take<int32_t>((size_t)U + N); (void)cw.take<int32_t>((size_t)U + N);
+  (void)cw.take<char>(sort_pairs_temp_bytes((size_t)2 * B, bits_for((uint64_t)U + (uint64_t)N + 1)));
+  (void)cw.take<char>(scan_i32_temp_bytes((size_t)nnz));
+  return cw.ok();
+}
+// DRX_BATCH_SHARE_USERS takes effect: the list is in the shared form, the step forms S_u / D_u
+static bool share_users(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R) {
+  return (bt->flags & DRX_BATCH_SHARE_USERS) != 0 && R.pitem != nullptr && transposed_applies(p, hist, bt, R);
+}
+
 static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
   const int B = bt->B, U = p->n_users, N = p->n_items;
+  if (!transposed_applies(p, hist, bt, R)) return kTpFallback;
+  const bool share = share_users(p, hist, bt, R);
   const int64_t nnz = hist->t_nnz;
   if (nnz < 1 || nnz > (int64_t)R.T || nnz >= (1ll << 30) || (int64_t)U + N >= 0x7FFFFFFFll) return kTpFallback;
   // work areas: cnt in the big sort's key buffer, the rest in its temp
@@ -410,14 +492,22 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   if (rc) return rc;
   hipLaunchKernelGGL(k_tp_runs, dim3((2 * B + 255) / 256 < 1024 ? (2 * B + 255) / 256 : 1024), dim3(256), 0, st, ks, 2 * B, start, end);
   const int egrid = (int)((nnz + 255) / 256 < 8192 ? (nnz + 255) / 256 : 8192);
-  hipLaunchKernelGGL((k_tp_expand<false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s);
+  const int rt = share_item_triples(p->ld);
+  if (share) {
+    hipLaunchKernelGGL(k_tp_number_items, dim3(1), dim3(1024), 0, st, ks, vs, B, rt, start, R.usamp, R.pitem, R.wfirst, R.n_du, R.plan.cnt);
+    hipLaunchKernelGGL((k_tp_expand<false, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+  } else
+    hipLaunchKernelGGL((k_tp_expand<false, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
   // (the counts of the LAST entry are needed after the scan overwrote them: a copy)
   int *cnt_last = (int *)R.vals;
   DRX_HIP(hipMemcpyAsync(cnt_last, cnt + (nnz - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
   rc = scan_i32(sctemp, scb, cnt, cnt, (size_t)nnz, false, st);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_tp_expand<true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s);
-  hipLaunchKernelGGL(k_tp_tail, dim3(2048), dim3(256), 0, st, ks, vs, B, U, N, cnt + (nnz - 1), cnt_last, R.T, R.keys_s, R.vals_s);
+  if (share)
+    hipLaunchKernelGGL((k_tp_expand<true, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+  else
+    hipLaunchKernelGGL((k_tp_expand<true, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+  hipLaunchKernelGGL(k_tp_tail, dim3(2048), dim3(256), 0, st, ks, vs, B, U, N, cnt + (nnz - 1), cnt_last, R.T, R.keys_s, R.vals_s, R.plan.cnt);
   return DRX_OK;
 }
 

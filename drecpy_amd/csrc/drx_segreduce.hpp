@@ -202,7 +202,11 @@ __device__ __forceinline__ void place_block(const uint32_t *__restrict__ keys_s,
   if (on) {
     const int at = blk * cpb * kChunk;
     if (at < T && keys_s[at] != DRX_KEY_NONE) {                 // (a blanked or dropped touch carries no sample: any bin will do)
-      const uint32_t b = vals_s[at];
+      uint32_t b = vals_s[at];
+      // (DRX_BATCH_SHARE_USERS: a subtracted touch carries its sample under the top bit; a touch of a user's summed row carries B + the
+      // user's slot — slots ascend with the samples of a by-user batch: cnt[21] distinct users)
+      if (b & 0x80000000u) b &= 0x7FFFFFFFu;
+      else if (b >= (uint32_t)B) b = (uint32_t)(((unsigned long long)(b - (uint32_t)B) * (unsigned long long)B) / (unsigned long long)max(1u, P.cnt[21]));
       x = (int)min((uint32_t)(kXBins - 1), (uint32_t)(((unsigned long long)b * (unsigned long long)kXBins) / (unsigned long long)(B > 0 ? B : 1)));
     }
   }
@@ -338,6 +342,9 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
   if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
   const uint8_t *__restrict__ ext = SP.ext;
   const int blk = placed_block(SP, (int)blockIdx.x, extra_blocks, (int)gridDim.x - extra_blocks, CPB);
+  // (lists laid down compact — the transposed preparation — say how long they are: SpanPlan::cnt[20] real touches, the rest of the
+  // T slots is padding; a workgroup whose chunks all lie in the padding has nothing to do)
+  if (SP.cnt[20] != 0u && (long long)blk * CPB * kChunk >= (long long)SP.cnt[20] + kChunk) return;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int g = blk * CPB + r;
   bool inner = false;          // this chunk is one whole run of a segment that began before it

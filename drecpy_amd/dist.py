@@ -593,6 +593,7 @@ class ColumnShardedCdae:
             return
         from .engine import CdaeEngine
         self.engine = e = CdaeEngine(n_users, n_items, self.k_hi - self.k_lo, device=device)
+        e.share_users = False          # (the forward half here is a kernel of its own: plain lists)
         e.set_history(hist_indptr, hist_indices)
         e.init_optimizer(optimizer, lr, reg)
         # GlorotUniform of the GLOBAL shapes; this rank's columns from its own stream, the replicated b2 from a shared one

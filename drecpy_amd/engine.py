@@ -131,7 +131,8 @@ class CdaeEngine:
         self._recorded = (History(ptr(ip), ptr(ix)), ip, ix)
 
     TRANSPOSE_MAX_NNZ, TRANSPOSE_MAX_ROWS = 1 << 27, 1 << 22
-    sample_by_user = True        # device-sampled batches in user order where the history's transpose exists (sample_device)
+    sample_by_user = os.environ.get('DRX_SAMPLE_BY_USER', '1') != '0'   # device-sampled batches in user order where the history's transpose exists
+    share_users = os.environ.get('DRX_SHARE_USERS', '1') != '0'         # include/drx.h DRX_BATCH_SHARE_USERS (the triples of one user share their gather and their gradient)
 
     def set_history(self, indptr, indices, with_transpose=True):
         self.hist_indptr = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device) \
@@ -318,7 +319,8 @@ class CdaeEngine:
         st['busy'][slot[0]] = True
 
     def _batch_flags(self, n_touch_slots):
-        return 0                       # DrxBatch.flags: reserved
+        # DRX_BATCH_SHARE_USERS: takes effect only where a list is prepared through the history's transpose (MovieLens shapes)
+        return _lib.BATCH_SHARE_USERS if (self.share_users and getattr(self, '_hist_t', None) is not None) else 0
 
     def make_batch(self, uid, iid=None, y=None, keep_off=None, keep=None, q=0.0, mask_seed=0, n_touch_slots=None):
         """Uploads (if needed) one batch and returns (Batch struct, keep-alive tensors)."""

@@ -91,8 +91,16 @@ typedef struct DrxBatch {
   uint64_t mask_seed;
   float q;                  /* corruption level; survivors are scaled by 1/(1-q) */
   int32_t n_touch_slots;    /* host-known upper bound of keep_off[B] (sizes the sort) */
-  uint32_t flags;           /* reserved: 0 */
+  uint32_t flags;           /* DRX_BATCH_* (0: none) */
 } DrxBatch;
+/* Sampled mode, batches in which users REPEAT (B several times the number of users: MovieLens shapes), prepared through the history's
+ * transpose (DrxHistory::t_*; lists of long segments): the triples of one user share their gather and their gradient —
+ *   forward : bag(b) = S_u - sum of the DROPPED rows of b,   S_u = the sum of ALL rows of u's history, formed once per user and step
+ *   backward: an item row of u's history receives  D_u - sum of dz1[b] over the triples b of u that DROPPED it,  D_u = sum of dz1 over u's triples
+ * (with corruption level q a triple drops a fraction q of its rows and keeps 1 - q: 1 / q fewer row reads per triple on both sides, plus one
+ * pass per distinct user).  Another association of the same sums: same oracle, same tolerance.  Prepare and step must see the same flag;
+ * it is ignored (plain lists) where the transposed preparation does not apply.  Single-GPU step only. */
+#define DRX_BATCH_SHARE_USERS 1u
 
 typedef struct DrxOptim {
   int32_t kind;             /* DRX_OPT_* */

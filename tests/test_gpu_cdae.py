@@ -289,14 +289,17 @@ def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_
     """Lists of long segments (more than 8 touches per table row: MovieLens shapes) are prepared by expanding the history's transpose
     (DrxHistory::t_*: only the batch's 2B (id, sample) pairs are sorted) instead of sorting every (row, sample) pair: same oracle;
     against the sort path the parameters agree to rounding (inside a segment the touches come user by user instead of sample by
-    sample: another fixed order of the same sum), and two runs of the transposed path agree bit for bit."""
+    sample: another fixed order of the same sum), and two runs of the transposed path agree bit for bit.  'shared'
+    (DRX_BATCH_SHARE_USERS): the ~7 triples of a user share their gather (full sum minus the dropped rows) and their gradient (the user's
+    summed row minus the droppers'): same oracle, same tolerance."""
     U, N, B = 150, 70, 1024
     results = []
-    for mode in ('transpose', 'transpose', 'sort'):
+    for mode in ('transpose', 'transpose', 'sort', 'shared', 'shared'):
         eng, p, rng = _engine(U, N, K, seed=21)
         indptr, indices = synth_history(rng, U, N, 14, zipf=1.0)
-        eng.set_history(indptr, indices, with_transpose=mode == 'transpose')
-        assert (eng._hist_t is not None) == (mode == 'transpose')
+        eng.set_history(indptr, indices, with_transpose=mode != 'sort')
+        eng.share_users = mode == 'shared'             # DRX_BATCH_SHARE_USERS: a user's triples share their gather and their gradient
+        assert (eng._hist_t is not None) == (mode != 'sort')
         lr = 1e-3 if opt == 'adam' else 0.05
         eng.init_optimizer(opt, lr, 1e-3)
         st = co.sparse_state(p, opt)
@@ -327,6 +330,8 @@ def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_
     for k in results[0]:
         assert np.array_equal(results[0][k], results[1][k]), k                      # the transposed path twice: bit for bit
         np.testing.assert_allclose(results[0][k], results[2][k], rtol=0, atol=2e-6, err_msg=k)
+        assert np.array_equal(results[3][k], results[4][k]), k                      # ... and the shared form twice
+        np.testing.assert_allclose(results[3][k], results[2][k], rtol=0, atol=5e-6, err_msg=k)
 
 
 def test_device_sampler_in_user_order_draws_the_same_triples():
