@@ -778,123 +778,160 @@ __device__ __forceinline__ unsigned long long group_ballot(bool f) {
   return (m >> sh) & ((1ull << (G & 63)) - 1ull);
 }
 
-// DRX_BATCH_SHARE_USERS: one WORKGROUP per work item — up to kBlock / G triples of ONE user (drx_prep.hpp k_tp_number_items).
-//   A. the row groups split the user's WHOLE history, the partial sums are combined in LDS in group order: S_u, in every group;
-//   B. group r takes the item's r-th triple: its bag = S_u - the rows its corruption mask DROPPED (q of the history: at q = 0.2 a fifth
-//      of the rows the plain kernel gathers; the dropped entries of a round of G are taken 8 at a time, compacted by a ballot),
-//      then forward / loss / backward as in k_sampled_fwd_bwd;
-//   C. the item's summed gradient row dz1[B + item] = sum of its triples' dz1, in group order: what the touch list's shared entries
-//      (sample field B + item) name.
-// At the ml-1m shape (6 040 users, 65 536 triples: 11 per user) the three launches this replaces (all-rows sums per user; dropped rows
-// per triple; gradient sums per user) took 116 + 191 + 60 us, the plain kernel 350 us.
+// DRX_BATCH_SHARE_USERS: one WORKGROUP per work item — up to kShareTriples triples of ONE user (drx_prep.hpp k_tp_number_items).
+// Every row of the user's history is loaded ONCE for all the item's triples (the plain kernel: once per triple):
+//   A. the workgroup's WAVES split the history, NF rows per wave and round, a row spread over the 64 lanes (CPL columns each).  The
+//      (row, triple) keep bits of a round are evaluated one pair per lane, as 0 / 1 coefficients; a pair's coefficient is read out of
+//      its lane (v_readlane) and every wave adds its rows into one bag per triple under it: a small masked matrix product
+//      [triples x history] x [history x K], fp32 on the vector ALUs (packed FMAs);
+//   B. the waves' partial bags meet in LDS; row group r (the G x J geometry of every other kernel) sums those of triples r, r + R, ...
+//      in wave order, then forward / loss / backward as in k_sampled_fwd_bwd;
+//   C. the item's summed gradient row dz1[B + item] = sum of its triples' dz1 (per group, then in group order): what the touch
+//      list's shared entries (sample field B + item) name.
+// At the ml-1m shape (6 040 users, 65 536 triples: 11 per user, 165 rows per history) the plain kernel gathers 8.6 M rows in 350 us;
+// summing every user's rows once and subtracting each triple's dropped rows (4.1 M rows): 222 us; row groups of 32 lanes with per-group
+// ballots (coefficients on the vector ALUs: 7 instructions per row and triple) and items of 8 triples: 187 us.
+typedef float drx_f2 __attribute__((ext_vector_type(2)));
+template <int CPL>
+__device__ __forceinline__ void load_cols(const float *__restrict__ row, int lane, int ld, float (&x)[CPL]) {
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) x[k] = 0.f;
+  if (lane * CPL >= ld) return;
+  if (CPL == 1) x[0] = row[lane];
+  else if (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(row + lane * 2); x[0] = t.x; x[1] = t.y; }
+  else {
+#pragma unroll
+    for (int k = 0; k < CPL; k += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(row + lane * CPL + k);
+      x[k] = t.x; x[k + 1] = t.y; x[k + 2] = t.z; x[k + 3] = t.w;
+    }
+  }
+}
 template <int G, int J, int KIND = -1>
 __global__ __launch_bounds__(kBlock) void k_items_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
                                                           uint32_t qthr, int loss_kind, SparseBufs S) {
-  extern __shared__ __align__(16) float lds[];   // [R, ld]
-  constexpr int R = kBlock / G;
-  constexpr int NF = J == 1 ? 8 : 4;
+  extern __shared__ __align__(16) float lds[];   // [NWV * RT, ld] floats, then RT sample ids
+  constexpr int R = kBlock / G, NWV = kBlock / 64, RT = kShareTriples;
+  constexpr int CPL = 4 * G * J / 64;                              // columns per lane in A
+  static_assert(CPL >= 1 && CPL <= 8, "rows of 64 .. 512 floats");
+  constexpr int NF = CPL <= 2 ? 16 : (CPL == 4 ? 8 : 4);           // rows in flight per wave
+  constexpr int NP = NF * RT, NB = (NP + 63) / 64;                 // (row, triple) pairs of a round; ballots holding their bits
+  constexpr int TPG = (RT + R - 1) / R;                            // triples per row group in B
   const int w = blockIdx.x;
   if (w >= S.n_items[0]) return;
-  const int lane = threadIdx.x % G, r = threadIdx.x / G;
-  const int p0 = S.wfirst[w], p1 = S.wfirst[w + 1];
-  const int u = bt.uid[S.usamp[p0]];
+  const int p0 = S.wfirst[w], n = S.wfirst[w + 1] - p0;
+  int *lb = (int *)(lds + (size_t)NWV * RT * P.ld);
+  if ((int)threadIdx.x < RT) lb[threadIdx.x] = (int)threadIdx.x < n ? S.usamp[p0 + threadIdx.x] : 0;
+  __syncthreads();
+  const int u = bt.uid[lb[0]];
   const int64_t s = H.indptr[u], e = H.indptr[u + 1];
-  // A
-  float4 su[J];
-  {
-    float4 acc[J];
+  const int n_waves = (int)min((int64_t)NWV, (e - s + NF - 1) / NF);         // waves that have rows at all
+  {  // A
+    const int wl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float bag[RT][CPL];
 #pragma unroll
-    for (int j = 0; j < J; ++j) acc[j] = f4_zero();
-    for (int64_t c = s + (int64_t)r * NF; c < e; c += (int64_t)R * NF) {
-      float4 v[NF][J];
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) bag[t][k] = 0.f;
+    const int64_t c0 = s + (int64_t)wv * NF;
+    int idx = (wl < NF && c0 + wl < e) ? H.indices[c0 + wl] : 0;
+    for (int64_t c = c0; c < e; c += (int64_t)NWV * NF) {
+      const int64_t cn = c + (int64_t)NWV * NF;
+      const int idx_n = (wl < NF && cn + wl < e) ? H.indices[cn + wl] : 0;      // (under way while this round's rows are)
+      float v[NF][CPL];
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
+        const int iq = __builtin_amdgcn_readlane(idx, q);
+        if (c + q < e) load_cols<CPL>(P.W + (size_t)iq * P.ld, wl, P.ld, v[q]);
+        else {
 #pragma unroll
-        for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
-        if (c + q < e) load_row<G, J>(P.W, (size_t)H.indices[c + q], P.ld, lane, v[q]);
+          for (int k = 0; k < CPL; ++k) v[q][k] = 0.f;
+        }
+      }
+      float cf[NB];                       // lane wl: the 0 / 1 coefficient of pair k * 64 + wl
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int i = k * 64 + wl, q = i / RT, t = i % RT;
+        bool kf = false;
+        if (i < NP && t < n && c + q < e) {
+          const int b = lb[t];
+          const uint32_t jj = (uint32_t)(c + q - s);
+          kf = bt.keep ? (bt.keep[bt.keep_off[b] + jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
+        }
+        cf[k] = kf ? 1.0f : 0.0f;
       }
 #pragma unroll
-      for (int q = 0; q < NF; ++q)
+      for (int t = 0; t < RT; ++t) {
+        if (t < n) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) f4_add(acc[j], v[q][j]);
-    }
-    const int n_groups = (int)min((int64_t)R, (e - s + NF - 1) / NF);          // groups that had rows at all
-    if (r < n_groups) store_row<G, J>(lds, (size_t)r, P.ld, lane, acc);
-    __syncthreads();
+          for (int q = 0; q < NF; ++q) {
+            const int i = q * RT + t;
+            // (one v_readlane per pair; taking the bit out of a ballot instead costs 3 - 4 instructions on the CU's single scalar ALU)
+            const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf[i / 64]), i % 64));
+            if (CPL == 1) bag[t][0] = fmaf(coef, v[q][0], bag[t][0]);
+            else {
 #pragma unroll
-    for (int j = 0; j < J; ++j) su[j] = f4_zero();
-    for (int rr = 0; rr < n_groups; ++rr) {
-      float4 v[J];
-      load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
-#pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(su[j], v[j]);
-    }
-  }
-  // B
-  const bool have = p0 + r < p1;
-  float4 dz1[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) dz1[j] = f4_zero();
-  if (have) {
-    const int b = S.usamp[p0 + r];
-    const uint8_t *kp = bt.keep ? bt.keep + bt.keep_off[b] : nullptr;
-    float4 drop[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) drop[j] = f4_zero();
-    auto fetch = [&](int64_t c, int &idx, bool &df) {
-      const int64_t j = c + lane;
-      idx = 0; df = false;
-      if (j < e) {
-        idx = H.indices[j];
-        const uint32_t jj = (uint32_t)(j - s);
-        df = !(kp ? (kp[jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr));
-      }
-    };
-    int idx; bool df;
-    fetch(s, idx, df);
-    for (int64_t c = s; c < e; c += G) {
-      int idx_n = 0; bool df_n = false;
-      if (c + G < e) fetch(c + G, idx_n, df_n);          // the next round's entries are under way while this round's rows are
-      unsigned long long m = group_ballot<G>(df);
-      while (m) {
-        float4 v[NF][J];
-#pragma unroll
-        for (int q = 0; q < NF; ++q) {
-#pragma unroll
-          for (int j = 0; j < J; ++j) v[q][j] = f4_zero();
-          if (m) {
-            const int t = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            const int iq = __shfl(idx, t, G);
-            load_row<G, J>(P.W, (size_t)iq, P.ld, lane, v[q]);
+              for (int k = 0; k < CPL; k += 2) {
+                drx_f2 a = {bag[t][k], bag[t][k + 1]};
+                const drx_f2 x = {v[q][k], v[q][k + 1]}, cc = {coef, coef};
+                a = __builtin_elementwise_fma(cc, x, a);
+                bag[t][k] = a.x; bag[t][k + 1] = a.y;
+              }
+            }
           }
         }
-#pragma unroll
-        for (int q = 0; q < NF; ++q)
-#pragma unroll
-          for (int j = 0; j < J; ++j) f4_add(drop[j], v[q][j]);
       }
-      idx = idx_n; df = df_n;
+      idx = idx_n;
     }
-    float4 acc[J], h[J], w2[J];
+    if (wv < n_waves && wl * CPL < P.ld) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) { acc[j].x = su[j].x - drop[j].x; acc[j].y = su[j].y - drop[j].y; acc[j].z = su[j].z - drop[j].z; acc[j].w = su[j].w - drop[j].w; }
-    const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
-    sampled_rest<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, d, h, w2, &dz1);
+      for (int t = 0; t < RT; ++t)
+        if (t < n) {
+          float *dst = lds + (size_t)(wv * RT + t) * P.ld + wl * CPL;
+#pragma unroll
+          for (int k = 0; k < CPL; ++k) dst[k] = bag[t][k];
+        }
+    }
+  }
+  __syncthreads();
+  // B
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
+  float4 dsum[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) dsum[j] = f4_zero();
+#pragma unroll
+  for (int kt = 0; kt < TPG; ++kt) {
+    const int t = r + kt * R;
+    if (t < n) {
+      const int b = lb[t];
+      float4 acc[J], h[J], w2[J], dz1[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc[j] = f4_zero();
+      for (int wv = 0; wv < n_waves; ++wv) {
+        float4 x[J];
+        load_row<G, J>(lds, (size_t)(wv * RT + t), P.ld, lane, x);
+#pragma unroll
+        for (int j = 0; j < J; ++j) f4_add(acc[j], x[j]);
+      }
+      const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
+      sampled_rest<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, d, h, w2, &dz1);
+#pragma unroll
+      for (int j = 0; j < J; ++j) f4_add(dsum[j], dz1[j]);
+    }
   }
   // C
-  __syncthreads();                                   // (every group has read the partial sums of A)
-  if (have) store_row<G, J>(lds, (size_t)r, P.ld, lane, dz1);
+  __syncthreads();                                   // (every group has read its partial bags)
+  if (r < n) store_row<G, J>(lds, (size_t)r, P.ld, lane, dsum);
   __syncthreads();
   if (r == 0) {
     float4 t[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) t[j] = f4_zero();
-    for (int rr = 0; rr < p1 - p0; ++rr) {
-      float4 v[J];
-      load_row<G, J>(lds, (size_t)rr, P.ld, lane, v);
+    for (int rr = 0; rr < min(n, R); ++rr) {
+      float4 x[J];
+      load_row<G, J>(lds, (size_t)rr, P.ld, lane, x);
 #pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(t[j], v[j]);
+      for (int j = 0; j < J; ++j) f4_add(t[j], x[j]);
     }
     store_row<G, J>(S.dz1, (size_t)bt.B + w, P.ld, lane, t);
   }
@@ -1090,7 +1127,8 @@ static DenseLayout dense_layout(Carver &cv, const DrxCdaeParams &P, int B, bool 
 static SparseBufs sparse_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_touch_slots) {
   SparseBufs S{};
   S.T = n_touch_slots + 2 * B;
-  S.n_chunks = (S.T + kChunk - 1) / kChunk;
+  const int chunk = seg_chunk(long_segments(S.T, P));           // (as prep_layout: the list's chunks)
+  S.n_chunks = (S.T + chunk - 1) / chunk;
   S.n_bpart = 1024;      // (256: each row group of a bias block summed 32 rows one load at a time; tail_a 25.0 -> 23.5 us)
   S.dz1 = cv.take<float>((size_t)2 * B * P.ld);       // (the second half: the work items' summed rows of DRX_BATCH_SHARE_USERS)
   S.g2 = cv.take<float>((size_t)B * P.ld);
@@ -1629,7 +1667,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   S.stamps = SB.stamps = h_stamps;
 #endif
   PlanBufs PB{S.pblock, S.pbs};
-  // rows collect long runs of touches (MovieLens shapes): k_seg_reduce's LB1 = 8, XCD placement of its workgroups
+  // rows collect long runs of touches (MovieLens shapes): k_seg_reduce_planned's LONG form (chunks of 64, 8 rows in flight), XCD placement of its workgroups
   const bool long_segments = drx::long_segments(S.T, *p);
 #define EV(i) do { if (events) DRX_HIP(hipEventRecord((hipEvent_t)events[i], st)); } while (0)
   // One workgroup per triple (its groups split the history) instead of one group per triple: when a group would walk many
@@ -1655,10 +1693,10 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     const dim3 rgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                                        \
     const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
     if (long_segments)                                                                                                 \
-      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, true, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
                          R.plan, polk, n_bpart, bpx);                                                                  \
     else                                                                                                               \
-      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, false, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
                          R.plan, polk, n_bpart, bpx);                                                                  \
     EV(3);                                                                                                             \
     if (lds_b > 48 * 1024)                                                                                             \
@@ -1678,15 +1716,17 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
       hipLaunchKernelGGL((k_kshard_rest<G, J>), dim3((bt->B + gpb - 1) / gpb), dim3(kBlock), 0, st, *p, *opt, *hist, *bt, scale, \
                          qthr, loss_kind, S, ks_h, ks_dot);                                                            \
     else if (share) {                                                                                                  \
-      /* work items: at most one per distinct user + one per gpb triples, never more than triples */                  \
-      const long long wmax = (long long)(p->n_users < bt->B ? p->n_users : bt->B) + bt->B / gpb + 1;                   \
+      /* work items: at most one per distinct user + one per full item, never more than triples */                   \
+      const long long wmax = (long long)(p->n_users < bt->B ? p->n_users : bt->B) + bt->B / share_item_triples(p->ld) + 1;                   \
       const dim3 igrid((unsigned)(wmax < bt->B ? wmax : bt->B));                                                       \
-      if (opt->kind == DRX_OPT_ADAGRAD)                                                                                \
-        hipLaunchKernelGGL((k_items_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), igrid, dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
-                           *bt, scale, qthr, loss_kind, S);                                                            \
-      else                                                                                                             \
-        hipLaunchKernelGGL((k_items_fwd_bwd<G, J>), igrid, dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, *bt, scale, \
-                           qthr, loss_kind, S);                                                                        \
+      if constexpr (G >= 16 && J <= 2) {                        /* (share_users(): rows of 64 .. 512 floats) */        \
+        if (opt->kind == DRX_OPT_ADAGRAD)                                                                              \
+          hipLaunchKernelGGL((k_items_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), igrid, dim3(kBlock), share_item_lds_bytes(p->ld), st, *p, *opt, \
+                             *hist, *bt, scale, qthr, loss_kind, S);                                                   \
+        else                                                                                                           \
+          hipLaunchKernelGGL((k_items_fwd_bwd<G, J>), igrid, dim3(kBlock), share_item_lds_bytes(p->ld), st, *p, *opt, *hist, *bt, \
+                             scale, qthr, loss_kind, S);                                                               \
+      }                                                                                                                \
     } else if (per_wg)                                                                                                 \
       hipLaunchKernelGGL((k_sampled_fwd_bwd_wg<G, J>), dim3(bt->B), dim3(kBlock), (size_t)gpb * p->ld * 4, st, *p, *opt, *hist, \
                          *bt, scale, qthr, loss_kind, S);                                                              \

@@ -155,7 +155,10 @@ static __global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, 
   if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
   const int nb = (n_chunks + cpb - 1) / cpb;
   if (P.xrank && (tid & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, tid, tid < nb);
-  for (int j = tid; j < T; j += plan_blocks * blockDim.x) {
+  // (a list laid down compact by the transposed preparation says where its W2T / V parts are: the last 2B of its cnt[20] touches)
+  const int real = (int)P.cnt[20];
+  const int j_lo = real != 0 ? max(0, real - 2 * B) : 0, j_hi = real != 0 ? min(T, real) : T;
+  for (int j = j_lo + tid; j < j_hi; j += plan_blocks * blockDim.x) {
     const uint32_t k = keys_s[j];
     if (k == DRX_KEY_NONE || k < n_items) continue;
     const uint32_t prev = j > 0 ? keys_s[j - 1] : DRX_KEY_NONE, next = j + 1 < T ? keys_s[j + 1] : DRX_KEY_NONE;
@@ -267,7 +270,8 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
   R.vals_s = cv.take<uint32_t>(R.T);
   R.solo_v = cv.take<uint8_t>((size_t)2 * B);
   R.solo_o = R.solo_v ? R.solo_v + B : nullptr;
-  R.n_chunks = (R.T + kChunk - 1) / kChunk;
+  R.plan.chunk = seg_chunk(long_segments(R.T, P));
+  R.n_chunks = (R.T + R.plan.chunk - 1) / R.plan.chunk;
   R.plan.desc = cv.take<uint2>(R.n_chunks);
   R.plan.cnt = cv.take<uint32_t>(128);        // [0] short spans, [1] long spans, [16], [17], [kXBase ..): XCD placement (drx_segreduce.hpp)
   R.plan.ext = cv.take<uint8_t>(R.n_chunks);
@@ -351,8 +355,15 @@ static __global__ __launch_bounds__(256) void k_tp_runs(const uint32_t *__restri
   }
 }
 
-// triples of one work item (DRX_BATCH_SHARE_USERS): one per row group of the forward workgroup
-static inline int share_item_triples(int ld) { return kBlock / pick_geom(ld).G; }
+// triples of one work item (DRX_BATCH_SHARE_USERS; k_items_fwd_bwd keeps one bag per triple in registers); its LDS: the partial bags
+// of its waves + the item's sample ids.  Rows of 33 .. 512 floats only (narrower rows: the plain kernels).
+constexpr int kShareTriples = 16;
+static inline int share_item_triples(int) { return kShareTriples; }
+static inline size_t share_item_lds_bytes(int ld) { return ((size_t)(kBlock / 64) * kShareTriples * ld + kShareTriples) * 4; }
+static inline bool share_geometry_ok(int ld) {
+  const Geom g = pick_geom(ld);
+  return g.G >= 16 && g.J <= 2 && share_item_lds_bytes(ld) <= 64 * 1024;
+}
 
 // ONE workgroup numbers the batch's work items from the sorted (user, sample) pairs — the first B of the 2B sorted pairs; start[]: the
 // first sorted position of every user's run (k_tp_runs).  A work item begins at every rt-th position of a run.
@@ -406,23 +417,28 @@ static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch
     auto keeps = [&](uint32_t b) -> bool {
       return bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr);
     };
-    const int piece = SHARE ? rt : (c > 0 ? c : 1);
-    for (int q0 = 0; q0 < c; q0 += piece) {
-      const int q1 = min(c, q0 + piece);
-      bool shared = false;
-      if (SHARE && q1 - q0 > 1) {                      // the shorter form of the two: never more touches than the plain list holds
-        int k = 0;
-        for (int q = q0; q < q1; ++q) k += keeps(vs[s0 + q]) ? 1 : 0;
-        shared = 1 + (q1 - q0 - k) < k;
+    if (SHARE) {                                       // pieces of rt <= 32 samples: the keep bits of a piece, evaluated once
+      for (int q0 = 0; q0 < c; q0 += rt) {
+        const int nq = min(c - q0, rt);
+        uint32_t km = 0;
+        for (int q = 0; q < nq; ++q) km |= (keeps(vs[s0 + q0 + q]) ? 1u : 0u) << q;
+        const int k = __popc(km);
+        const bool shared = nq > 1 && 1 + (nq - k) < k;           // the shorter form of the two: never more touches than the plain list
+        if (!WRITE) { kept += shared ? 1 + (nq - k) : k; continue; }
+        if (shared) { keys_s[at] = (uint32_t)n; vals_s[at] = (uint32_t)bt.B + (uint32_t)pitem[s0 + q0]; ++at; }
+        uint32_t em = shared ? (~km & (nq >= 32 ? 0xFFFFFFFFu : ((1u << nq) - 1u))) : km;      // the samples that emit a touch
+        while (em) {
+          const int q = __ffs((int)em) - 1;
+          em &= em - 1u;
+          const uint32_t b = vs[s0 + q0 + q];
+          keys_s[at] = (uint32_t)n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at;      // top bit: subtracted
+        }
       }
-      if (shared) {
-        if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = (uint32_t)bt.B + (uint32_t)pitem[s0 + q0]; ++at; }
-        ++kept;
-      }
-      for (int q = q0; q < q1; ++q) {
+    } else {
+      for (int q = 0; q < c; ++q) {
         const uint32_t b = vs[s0 + q];
-        if (keeps(b) != shared) {
-          if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at; }      // top bit: subtracted
+        if (keeps(b)) {
+          if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = b; ++at; }
           ++kept;
         }
       }
@@ -463,7 +479,8 @@ static bool transposed_applies(const DrxCdaeParams *p, const DrxHistory *hist, c
 }
 // DRX_BATCH_SHARE_USERS takes effect: the list is in the shared form, the step forms S_u / D_u
 static bool share_users(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R) {
-  return (bt->flags & DRX_BATCH_SHARE_USERS) != 0 && R.pitem != nullptr && transposed_applies(p, hist, bt, R);
+  return (bt->flags & DRX_BATCH_SHARE_USERS) != 0 && R.pitem != nullptr && share_geometry_ok(p->ld) &&
+         transposed_applies(p, hist, bt, R);
 }
 
 static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {

@@ -21,6 +21,10 @@ namespace drx {
 #define DRX_CHUNK 32
 #endif
 constexpr int kChunk = DRX_CHUNK;      // touches per group in the segmented reduction
+// ... and for lists of LONG segments (planned variant only; SpanPlan::chunk): rows collect thousands of touches, longer chunks halve
+// the partial rows and the workgroups (ml-1m shape: 0.685 -> 0.630 ms per step; the headline's short segments: 0.346 -> 0.375 with 64)
+constexpr int kChunkLong = 64;
+static inline int seg_chunk(bool long_segments) { return long_segments ? kChunkLong : kChunk; }
 #ifdef DRX_SEG_WAVE_PER_CHUNK
 #define SEG_GPB(G) (drx::kBlock / 64)
 #else
@@ -187,6 +191,7 @@ struct SpanPlan {
   uint32_t *xrank;      // [xstride] block -> bin << 24 | rank      (k_plan_spans / k_plan_and_mark)
   uint32_t *xperm;      // [xstride] slot -> block                  (k_place_blocks)
   int xstride;          // entries (the number of blocks of the smallest block size: a layout independent of the row width)
+  int chunk;            // touches per chunk of THIS list: seg_chunk(long segments?)
 };
 #ifndef DRX_XBINS
 #define DRX_XBINS 8      // (64 — bins of 0.5 MB of gradient rows, taken in order — measured SLOWER at the ml-1m shape: 0.60 against 0.54 ms)
@@ -200,7 +205,7 @@ __device__ __forceinline__ void place_block(const uint32_t *__restrict__ keys_s,
                                             const SpanPlan &P, int blk, bool on) {
   int x = blk & (kXBins - 1);
   if (on) {
-    const int at = blk * cpb * kChunk;
+    const int at = blk * cpb * P.chunk;
     if (at < T && keys_s[at] != DRX_KEY_NONE) {                 // (a blanked or dropped touch carries no sample: any bin will do)
       uint32_t b = vals_s[at];
       // (DRX_BATCH_SHARE_USERS: a subtracted touch carries its sample under the top bit; a touch of a user's summed row carries B + the
@@ -293,7 +298,8 @@ struct SpanShape {
 };
 
 __device__ __forceinline__ void plan_chunk(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, const SpanPlan &P, int g) {
-  const int start = g * kChunk, end = min(T, start + kChunk);
+  const int CH = P.chunk;
+  const int start = g * CH, end = min(T, start + CH);
   const uint32_t first = keys_s[start], last = keys_s[end - 1];
   const uint32_t prev = start > 0 ? keys_s[start - 1] : DRX_KEY_NONE, next = end < T ? keys_s[end] : DRX_KEY_NONE;
   const bool head_cont = first != DRX_KEY_NONE && prev == first;        // the run at the chunk's start began before it
@@ -305,8 +311,8 @@ __device__ __forceinline__ void plan_chunk(const uint32_t *__restrict__ keys_s, 
     if (keys_s[mid] == last) lo = mid + 1; else hi = mid;
   }
   const int seg_end = lo;
-  const int full_end = seg_end / kChunk;                         // chunks [g + 1, full_end) lie wholly inside the segment
-  const uint32_t m_in = (uint32_t)(full_end - (g + 1)), has_end = (seg_end % kChunk) ? 1u : 0u;
+  const int full_end = seg_end / CH;                           // chunks [g + 1, full_end) lie wholly inside the segment
+  const uint32_t m_in = (uint32_t)(full_end - (g + 1)), has_end = (seg_end % CH) ? 1u : 0u;
   if (m_in == 0) {                                               // ends inside the next chunk: this chunk's window takes those touches
     P.ext[g] = (uint8_t)(seg_end - end);
     return;
@@ -334,34 +340,36 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, const uint32_t
 #else
 #define DRX_SEGP_ATTR
 #endif
-template <int G, int J, class Policy, int LB1, class Extra>
+template <int G, int J, class Policy, bool LONG, class Extra>
 __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol,
                                                                             int extra_blocks, Extra extra) {
   extern __shared__ __align__(16) float seg_lds[];
   constexpr int CPB = kSegBlock / G;
+  constexpr int CH = LONG ? kChunkLong : kChunk;          // (= SP.chunk: the list was laid out for it)
+  constexpr int LB1 = LONG ? 8 : 2;
   if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
   const uint8_t *__restrict__ ext = SP.ext;
   const int blk = placed_block(SP, (int)blockIdx.x, extra_blocks, (int)gridDim.x - extra_blocks, CPB);
   // (lists laid down compact — the transposed preparation — say how long they are: SpanPlan::cnt[20] real touches, the rest of the
   // T slots is padding; a workgroup whose chunks all lie in the padding has nothing to do)
-  if (SP.cnt[20] != 0u && (long long)blk * CPB * kChunk >= (long long)SP.cnt[20] + kChunk) return;
+  if (SP.cnt[20] != 0u && (long long)blk * CPB * CH >= (long long)SP.cnt[20] + CH) return;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int g = blk * CPB + r;
   bool inner = false;          // this chunk is one whole run of a segment that began before it
-  if (g < S.n_chunks && (g + 1) * kChunk <= S.T) {
-    const uint32_t f = S.keys_s[g * kChunk], l = S.keys_s[(g + 1) * kChunk - 1], pk = g > 0 ? S.keys_s[g * kChunk - 1] : DRX_KEY_NONE;
+  if (g < S.n_chunks && (g + 1) * CH <= S.T) {
+    const uint32_t f = S.keys_s[g * CH], l = S.keys_s[(g + 1) * CH - 1], pk = g > 0 ? S.keys_s[g * CH - 1] : DRX_KEY_NONE;
     inner = f != DRX_KEY_NONE && f == pk && l == f;
   }
   const bool all_inner = __syncthreads_and(inner ? 1 : 0) != 0;
   if (g >= S.n_chunks) return;          // (never in an all-inner workgroup: its second barrier below sees every thread)
   DRX_STAMP(S.stamps, 65536 + g, 0, lane);
   // this chunk's window: behind the touches its left neighbour finishes for it, and into the right neighbour's for the segment it
-  // finishes itself (SpanPlan::ext); up to 2 * kChunk - 1 touches
-  const int start = min(S.T, g * kChunk + (g > 0 ? (int)ext[g - 1] : 0)), end = min(S.T, (g + 1) * kChunk + (int)ext[g]);
+  // finishes itself (SpanPlan::ext); up to 2 * CH - 1 touches
+  const int start = min(S.T, g * CH + (g > 0 ? (int)ext[g - 1] : 0)), end = min(S.T, (g + 1) * CH + (int)ext[g]);
   const int n = max(0, end - start);
   const uint32_t prev_key = start > 0 ? S.keys_s[start - 1] : DRX_KEY_NONE;
   const uint32_t next_key = end < S.T ? S.keys_s[end] : DRX_KEY_NONE;
-  constexpr int KPL = (2 * kChunk + G - 1) / G;
+  constexpr int KPL = (2 * CH + G - 1) / G;
   constexpr int LB = J == 1 ? LB1 : (J == 2 ? 4 : 2);
   uint32_t kreg[KPL], vreg[KPL];
 #pragma unroll
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(kFixBlock) void k_span_planned(SegBufs S, PlanBufs 
       const uint2 d = SP.desc[si];
       const SpanShape sh(d, CPB);
       const int g0 = (int)d.x, tot = sh.total();
-      const int kpos = min(S.T, (g0 + 1) * kChunk) - 1;
+      const int kpos = min(S.T, (g0 + 1) * SP.chunk) - 1;
       float4 t[J];
       load_row<G, J>(S.ptail, (size_t)g0, S.ld, lane, t);
       float ts = S.pts[g0];
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(kFixBlock) void k_span_planned(SegBufs S, PlanBufs 
     const uint2 d = SP.desc[S.n_chunks - 1 - (int)si];
     const SpanShape sh(d, CPB);
     const int g0 = (int)d.x, tot = sh.total();
-    const int kpos = min(S.T, (g0 + 1) * kChunk) - 1;
+    const int kpos = min(S.T, (g0 + 1) * SP.chunk) - 1;
     float4 acc[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = f4_zero();

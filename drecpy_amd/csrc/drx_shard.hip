@@ -647,10 +647,10 @@ struct ShardStepBufs {
   int T, n_chunks, n_bpart;
 };
 
-static ShardStepBufs shard_step_layout(Carver &cv, int ld, int B, int n_touch_slots) {
+static ShardStepBufs shard_step_layout(Carver &cv, int chunk /* of the list: SpanPlan::chunk */, int ld, int B, int n_touch_slots) {
   ShardStepBufs S{};
   S.T = n_touch_slots + 2 * B;
-  S.n_chunks = (S.T + kChunk - 1) / kChunk;
+  S.n_chunks = (S.T + chunk - 1) / chunk;
   S.n_bpart = 1024;
   S.dz1 = cv.take<float>((size_t)B * ld);
   S.g2 = cv.take<float>((size_t)B * ld);
@@ -794,7 +794,7 @@ int drx_shard_gather_rows(const DrxCdaeParams *p, const DrxShard *sh, const uint
 size_t drx_shard_step_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n_touch_slots) {
   if (!p || B < 1 || n_touch_slots < 0) return 0;
   Carver cv(nullptr, 0);
-  (void)shard_step_layout(cv, p->ld, B, n_touch_slots);
+  (void)shard_step_layout(cv, kChunk, p->ld, B, n_touch_slots);          // (the shorter chunks: the larger of the two layouts)
   return align_up(cv.off, 256) + 256;
 }
 
@@ -816,7 +816,7 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
   const ShardPrepBufs L = shard_prep_layout(cp, *p, *sh, bt->B, bt->n_touch_slots);
   if (!cp.ok()) return DRX_ESCRATCH;
   Carver cv(scratch, scratch_bytes);
-  const ShardStepBufs B = shard_step_layout(cv, p->ld, bt->B, bt->n_touch_slots);
+  const ShardStepBufs B = shard_step_layout(cv, L.R.plan.chunk, p->ld, bt->B, bt->n_touch_slots);
   if (!cv.ok()) return DRX_ESCRATCH;
   const ShardGeo g = geo_of(*sh, p->ld);
   const float scale = 1.0f / (1.0f - bt->q);
@@ -843,10 +843,10 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
     const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
     const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
     if (long_segments)                                                                                                 \
-      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 8, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, true, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \
                          L.R.plan, polk, n_bpart, bpx);                                                                \
     else                                                                                                               \
-      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, 2, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \
+      hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, false, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \
                          L.R.plan, polk, n_bpart, bpx);                                                                \
     EV(2);                                                                                                             \
     if (lds_b > 48 * 1024)                                                                                             \
