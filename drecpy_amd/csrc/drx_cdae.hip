@@ -603,7 +603,7 @@ struct SparseBufs {
   const int32_t *order;                       // [B] or nullptr: launch order of the forward kernel's triples (k_order_by_degree)
   // DRX_BATCH_SHARE_USERS (k_items_fwd_bwd): the batch's work items (drx_prep.hpp PrepBufs); dz1 then holds B more rows behind the
   // samples': the items' summed gradients.  Else nullptr.
-  const int32_t *usamp, *wfirst, *n_items;
+  const int32_t *usamp, *wfirst, *worder, *n_items;
   int T, n_chunks, n_bpart;
 };
 
@@ -817,8 +817,8 @@ __global__ __launch_bounds__(kBlock) void k_items_fwd_bwd(DrxCdaeParams P, DrxOp
   constexpr int NF = CPL <= 2 ? 16 : (CPL == 4 ? 8 : 4);           // rows in flight per wave
   constexpr int NP = NF * RT, NB = (NP + 63) / 64;                 // (row, triple) pairs of a round; ballots holding their bits
   constexpr int TPG = (RT + R - 1) / R;                            // triples per row group in B
-  const int w = blockIdx.x;
-  if (w >= S.n_items[0]) return;
+  if ((int)blockIdx.x >= S.n_items[0]) return;
+  const int w = S.worder[blockIdx.x];              // longest histories first
   const int p0 = S.wfirst[w], n = S.wfirst[w + 1] - p0;
   int *lb = (int *)(lds + (size_t)NWV * RT * P.ld);
   if ((int)threadIdx.x < RT) lb[threadIdx.x] = (int)threadIdx.x < n ? S.usamp[p0 + threadIdx.x] : 0;
@@ -1678,6 +1678,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   const bool share = prepared && !ks_h && share_users(p, hist, bt, R);
   S.usamp = share ? R.usamp : nullptr;
   S.wfirst = share ? R.wfirst : nullptr;
+  S.worder = share ? R.worder : nullptr;
   S.n_items = share ? R.n_du : nullptr;
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;
   const bool per_wg = mean_hist > wg_long || (bt->B <= 8192 && mean_hist > 16);

@@ -250,7 +250,8 @@ struct PrepBufs {
   int32_t *usamp;               // [B] sorted position -> sample (the samples grouped by user, ascending inside a user)
   int32_t *pitem;               // [B] sorted position -> its work item
   int32_t *wfirst;              // [B + 1] work item -> its first sorted position; wfirst[n_items] = B
-  int32_t *n_du;                // [0] work items
+  int32_t *worder;              // [B] launch slot -> work item, longest histories first (buckets of log2(history length))
+  int32_t *n_du;                // [128]: [0] work items (k_tp_item_*)
   unsigned int *order_work;     // [512] bucket counts | running places (zeroed by k_sparse_touches)
   int n_chunks;
   size_t result_bytes;
@@ -286,7 +287,8 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
     R.usamp = placed ? cv.take<int32_t>(B) : nullptr;
     R.pitem = placed ? cv.take<int32_t>(B) : nullptr;
     R.wfirst = placed ? cv.take<int32_t>((size_t)B + 1) : nullptr;
-    R.n_du = placed ? cv.take<int32_t>(64) : nullptr;
+    R.worder = placed ? cv.take<int32_t>(B) : nullptr;
+    R.n_du = placed ? cv.take<int32_t>(128) : nullptr;
   }
   R.order = cv.take<int32_t>(B);
   R.result_bytes = align_up(cv.off, 256);
@@ -365,32 +367,48 @@ static inline bool share_geometry_ok(int ld) {
   return g.G >= 16 && g.J <= 2 && share_item_lds_bytes(ld) <= 64 * 1024;
 }
 
-// ONE workgroup numbers the batch's work items from the sorted (user, sample) pairs — the first B of the 2B sorted pairs; start[]: the
-// first sorted position of every user's run (k_tp_runs).  A work item begins at every rt-th position of a run.
-static __global__ __launch_bounds__(1024) void k_tp_number_items(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B, int rt,
-                                                                 const int32_t *__restrict__ start, int32_t *__restrict__ usamp,
-                                                                 int32_t *__restrict__ pitem, int32_t *__restrict__ wfirst, int32_t *n_du,
-                                                                 uint32_t *plan_cnt) {
-  __shared__ int wsum[16];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int per = (B + 1023) / 1024;
-  const int lo = min(B, t * per), hi = min(B, (t + 1) * per);
-  int heads = 0;
-  for (int p = lo; p < hi; ++p) heads += ((p - start[ks[p]]) % rt == 0) ? 1 : 0;
-  int inc = heads;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int before = inc - heads, total = 0;
-  for (int ww = 0; ww < 16; ++ww) { if (ww < w) before += wsum[ww]; total += wsum[ww]; }
-  int item = before - 1;
-  for (int p = lo; p < hi; ++p) {
-    if ((p - start[ks[p]]) % rt == 0) { ++item; wfirst[item] = p; }
-    pitem[p] = item;
-    usamp[p] = (int32_t)vs[p];
+// The batch's work items from the sorted (user, sample) pairs — the first B of the 2B sorted pairs; start[]: the first sorted position
+// of every user's run (k_tp_runs).  A work item begins at every rt-th position of a run: flags -> inclusive scan (drx_scan.hpp) ->
+// items, and their launch order by history length (a counting sort over 32 buckets of log2(length)).  (r04, first form: ONE workgroup
+// numbering all B positions — 230 us, 395 us with the launch order — was the longest link of the preparation's chain.)
+// n_du words: [0] items, [32 + b] items of bucket b, [64 + b] the scatter's cursor of bucket b.
+static __global__ __launch_bounds__(256) void k_tp_item_flags(const uint32_t *__restrict__ ks, int B, int rt, const int32_t *__restrict__ start,
+                                                              int32_t *__restrict__ pitem, int32_t *n_du) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 128) n_du[threadIdx.x] = 0;
+  if (p < B) pitem[p] = ((p - start[ks[p]]) % rt == 0) ? 1 : 0;
+}
+// bucket 0: the longest histories (2^30 ..), bucket 31: one row or none
+__device__ __forceinline__ int tp_bucket_of(const int64_t *__restrict__ indptr, uint32_t u) {
+  const long long d = (long long)(indptr[u + 1] - indptr[u]);
+  return __clz((int)min(d, 0x7FFFFFFFll) | 1);
+}
+// pitem holds the inclusive scan of the flags
+static __global__ __launch_bounds__(256) void k_tp_item_finish(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B, int rt,
+                                                               const int32_t *__restrict__ start, const int64_t *__restrict__ indptr,
+                                                               int32_t *__restrict__ usamp, int32_t *__restrict__ pitem,
+                                                               int32_t *__restrict__ wfirst, int32_t *n_du, uint32_t *plan_cnt) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const int item = pitem[p] - 1;
+  pitem[p] = item;
+  usamp[p] = (int32_t)vs[p];
+  if ((p - start[ks[p]]) % rt == 0) {
+    wfirst[item] = p;
+    atomicAdd(&n_du[32 + tp_bucket_of(indptr, ks[p])], 1);
   }
-  if (t == 0) { wfirst[total] = B; n_du[0] = total; plan_cnt[21] = (uint32_t)total; }     // (SpanPlan::cnt[21]: place_block)
+  if (p == B - 1) { wfirst[item + 1] = B; n_du[0] = item + 1; plan_cnt[21] = (uint32_t)(item + 1); }     // (SpanPlan::cnt[21]: place_block)
+}
+// the launch order of the forward workgroups: which workgroup takes which item never changes a result (inside a bucket: any order)
+static __global__ __launch_bounds__(256) void k_tp_item_order(const uint32_t *__restrict__ ks, int B, int rt, const int32_t *__restrict__ start,
+                                                              const int64_t *__restrict__ indptr, const int32_t *__restrict__ pitem,
+                                                              int32_t *__restrict__ worder, int32_t *n_du) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B || (p - start[ks[p]]) % rt != 0) return;
+  const int b = tp_bucket_of(indptr, ks[p]);
+  int base = 0;
+  for (int x = 0; x < b; ++x) base += n_du[32 + x];
+  worder[base + atomicAdd(&n_du[64 + b], 1)] = pitem[p];
 }
 
 // WRITE = false: cnt[e] = touches of entry e;  WRITE = true: cnt holds the exclusive scan, the pairs are written.
@@ -475,6 +493,7 @@ static bool transposed_applies(const DrxCdaeParams *p, const DrxHistory *hist, c
   (void)cw.take<int32_t>((size_t)U + N); (void)cw.take<int32_t>((size_t)U + N);
   (void)cw.take<char>(sort_pairs_temp_bytes((size_t)2 * B, bits_for((uint64_t)U + (uint64_t)N + 1)));
   (void)cw.take<char>(scan_i32_temp_bytes((size_t)nnz));
+  (void)cw.take<char>(scan_i32_temp_bytes((size_t)B));
   return cw.ok();
 }
 // DRX_BATCH_SHARE_USERS takes effect: the list is in the shared form, the step forms S_u / D_u
@@ -501,6 +520,8 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   void *stemp = cw.take<char>(sb);
   const size_t scb = scan_i32_temp_bytes((size_t)nnz);
   void *sctemp = cw.take<char>(scb);
+  const size_t scb2 = scan_i32_temp_bytes((size_t)B);
+  void *sctemp2 = cw.take<char>(scb2);
   if (!cw.ok()) return kTpFallback;
   const uint32_t qthr = q_threshold(bt->q);
   hipLaunchKernelGGL(k_tp_begin, dim3(512), dim3(256), 0, st, *bt, U, k2, v2, start, 2 * (U + N), R.solo_v, R.plan.cnt, plan_zero_words(R),
@@ -511,7 +532,13 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   const int egrid = (int)((nnz + 255) / 256 < 8192 ? (nnz + 255) / 256 : 8192);
   const int rt = share_item_triples(p->ld);
   if (share) {
-    hipLaunchKernelGGL(k_tp_number_items, dim3(1), dim3(1024), 0, st, ks, vs, B, rt, start, R.usamp, R.pitem, R.wfirst, R.n_du, R.plan.cnt);
+    const int ig = (B + 255) / 256;
+    hipLaunchKernelGGL(k_tp_item_flags, dim3(ig), dim3(256), 0, st, ks, B, rt, start, R.pitem, R.n_du);
+    rc = scan_i32(sctemp2, scb2, R.pitem, R.pitem, (size_t)B, true, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tp_item_finish, dim3(ig), dim3(256), 0, st, ks, vs, B, rt, start, hist->indptr, R.usamp, R.pitem, R.wfirst, R.n_du,
+                       R.plan.cnt);
+    hipLaunchKernelGGL(k_tp_item_order, dim3(ig), dim3(256), 0, st, ks, B, rt, start, hist->indptr, R.pitem, R.worder, R.n_du);
     hipLaunchKernelGGL((k_tp_expand<false, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
   } else
     hipLaunchKernelGGL((k_tp_expand<false, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);

@@ -204,6 +204,9 @@ constexpr int kXBase = 32, kXBins = DRX_XBINS;     // SpanPlan::cnt[kXBase ..]: 
 __device__ __forceinline__ void place_block(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s, int T, int cpb, int B,
                                             const SpanPlan &P, int blk, bool on) {
   int x = blk & (kXBins - 1);
+  // (a list that says how long it is — cnt[20], the transposed preparation's — places only the blocks that hold touches: the others
+  // have no workgroup to wait for, and every rank taken is an atomic on one of kXBins counters)
+  if (on && P.cnt[20] != 0u && (long long)blk * cpb * P.chunk >= (long long)P.cnt[20]) on = false;
   if (on) {
     const int at = blk * cpb * P.chunk;
     if (at < T && keys_s[at] != DRX_KEY_NONE) {                 // (a blanked or dropped touch carries no sample: any bin will do)
@@ -242,6 +245,7 @@ static __global__ __launch_bounds__(256) void k_place_blocks(SpanPlan P, int n_c
   const int cpb = (int)P.cnt[17];
   const int nb = cpb > 0 ? (n_chunks + cpb - 1) / cpb : 0;
   for (int blk = blockIdx.x * blockDim.x + threadIdx.x; blk < nb; blk += gridDim.x * blockDim.x) {
+    if (P.cnt[20] != 0u && (long long)blk * cpb * P.chunk >= (long long)P.cnt[20]) continue;      // (not placed: see place_block)
     const uint32_t e = P.xrank[blk];
     P.xperm[pre[e >> 24] + (e & 0xFFFFFFu)] = (uint32_t)blk;
   }
@@ -275,7 +279,7 @@ __device__ __forceinline__ int placed_block(const SpanPlan &P, int j, int extra,
     if (f < over) return (int)P.xperm[start[r] + own[r] + f];
     f -= over;
   }
-  return j - extra;                                              // (unreachable: as many free workgroups as overflow blocks)
+  return -1;                       // more workgroups than placed blocks (a compact list's padding): nothing to do
 }
 
 struct PlanBufs {
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
   const int blk = placed_block(SP, (int)blockIdx.x, extra_blocks, (int)gridDim.x - extra_blocks, CPB);
   // (lists laid down compact — the transposed preparation — say how long they are: SpanPlan::cnt[20] real touches, the rest of the
   // T slots is padding; a workgroup whose chunks all lie in the padding has nothing to do)
-  if (SP.cnt[20] != 0u && (long long)blk * CPB * CH >= (long long)SP.cnt[20] + CH) return;
+  if (blk < 0 || (SP.cnt[20] != 0u && (long long)blk * CPB * CH >= (long long)SP.cnt[20] + CH)) return;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int g = blk * CPB + r;
   bool inner = false;          // this chunk is one whole run of a segment that began before it
