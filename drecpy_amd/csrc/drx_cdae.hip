@@ -603,7 +603,8 @@ struct SparseBufs {
   const int32_t *order;                       // [B] or nullptr: launch order of the forward kernel's triples (k_order_by_degree)
   // DRX_BATCH_SHARE_USERS (k_items_fwd_bwd): the batch's work items (drx_prep.hpp PrepBufs); dz1 then holds B more rows behind the
   // samples': the items' summed gradients.  Else nullptr.
-  const int32_t *usamp, *wfirst, *worder, *n_items;
+  const int32_t *usamp, *worder, *n_items;
+  const WorkItem *witem;
   int T, n_chunks, n_bpart;
 };
 
@@ -778,124 +779,108 @@ __device__ __forceinline__ unsigned long long group_ballot(bool f) {
   return (m >> sh) & ((1ull << (G & 63)) - 1ull);
 }
 
-// DRX_BATCH_SHARE_USERS: one WORKGROUP per work item — up to kShareTriples triples of ONE user (drx_prep.hpp k_tp_number_items).
+// DRX_BATCH_SHARE_USERS: one WORKGROUP per work item — up to kShareTriples (16) triples of ONE user (drx_prep.hpp k_tp_item_*).
 // Every row of the user's history is loaded ONCE for all the item's triples (the plain kernel: once per triple):
-//   A. the workgroup's WAVES split the history, NF rows per wave and round, a row spread over the 64 lanes (CPL columns each).  The
-//      (row, triple) keep bits of a round are evaluated one pair per lane, as 0 / 1 coefficients; a pair's coefficient is read out of
-//      its lane (v_readlane) and every wave adds its rows into one bag per triple under it: a small masked matrix product
-//      [triples x history] x [history x K], fp32 on the vector ALUs (packed FMAs);
+//   A. the bags of the item's triples are a small masked matrix product [16 triples x history] x [history x K]: the workgroup's waves
+//      split the history, 16 rows per wave and round, and v_mfma_f32_16x16x4_f32 adds them into the 16 bags under the 0 / 1 keep
+//      coefficients — fp32 products with 0 or 1 are exact; the sums run in the instruction's fixed order.  The coefficient a lane
+//      feeds the instruction is the one (triple, row) pair whose mask bit it evaluates: no ballot, no broadcast;
 //   B. the waves' partial bags meet in LDS; row group r (the G x J geometry of every other kernel) sums those of triples r, r + R, ...
 //      in wave order, then forward / loss / backward as in k_sampled_fwd_bwd;
 //   C. the item's summed gradient row dz1[B + item] = sum of its triples' dz1 (per group, then in group order): what the touch
 //      list's shared entries (sample field B + item) name.
 // At the ml-1m shape (6 040 users, 65 536 triples: 11 per user, 165 rows per history) the plain kernel gathers 8.6 M rows in 350 us;
-// summing every user's rows once and subtracting each triple's dropped rows (4.1 M rows): 222 us; row groups of 32 lanes with per-group
-// ballots (coefficients on the vector ALUs: 7 instructions per row and triple) and items of 8 triples: 187 us.
-typedef float drx_f2 __attribute__((ext_vector_type(2)));
-template <int CPL>
-__device__ __forceinline__ void load_cols(const float *__restrict__ row, int lane, int ld, float (&x)[CPL]) {
-#pragma unroll
-  for (int k = 0; k < CPL; ++k) x[k] = 0.f;
-  if (lane * CPL >= ld) return;
-  if (CPL == 1) x[0] = row[lane];
-  else if (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(row + lane * 2); x[0] = t.x; x[1] = t.y; }
-  else {
-#pragma unroll
-    for (int k = 0; k < CPL; k += 4) {
-      const float4 t = *reinterpret_cast<const float4 *>(row + lane * CPL + k);
-      x[k] = t.x; x[k + 1] = t.y; x[k + 2] = t.z; x[k + 3] = t.w;
-    }
-  }
-}
+// summing every user's rows once and subtracting each triple's dropped rows (4.1 M rows): 222 us; the masked product on the vector
+// ALUs (a v_readlane + a packed FMA per row and triple: the kernel was bound by instruction issue): 200 us.
 template <int G, int J, int KIND = -1>
-__global__ __launch_bounds__(kBlock) void k_items_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+__global__ __launch_bounds__(kBlock, (4 * G * J <= 128 ? 5 : 1)) void k_items_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
                                                           uint32_t qthr, int loss_kind, SparseBufs S) {
   extern __shared__ __align__(16) float lds[];   // [NWV * RT, ld] floats, then RT sample ids
   constexpr int R = kBlock / G, NWV = kBlock / 64, RT = kShareTriples;
-  constexpr int CPL = 4 * G * J / 64;                              // columns per lane in A
-  static_assert(CPL >= 1 && CPL <= 8, "rows of 64 .. 512 floats");
-  constexpr int NF = CPL <= 2 ? 16 : (CPL == 4 ? 8 : 4);           // rows in flight per wave
-  constexpr int NP = NF * RT, NB = (NP + 63) / 64;                 // (row, triple) pairs of a round; ballots holding their bits
+  constexpr int NH = 4 * G * J / 64;                               // blocks of 64 columns of a row
+  static_assert(NH >= 1 && NH <= 8 && RT == 16, "rows of 64 .. 512 floats; the 16 x 16 x 4 matrix instruction");
+  constexpr int NF = NH <= 2 ? 16 : (NH == 4 ? 8 : 4);             // rows in flight per wave
   constexpr int TPG = (RT + R - 1) / R;                            // triples per row group in B
   if ((int)blockIdx.x >= S.n_items[0]) return;
   const int w = S.worder[blockIdx.x];              // longest histories first
-  const int p0 = S.wfirst[w], n = S.wfirst[w + 1] - p0;
+  const WorkItem wi = S.witem[w];
+  const int p0 = wi.p0, n = wi.n, u = wi.user;
+  const int64_t s = wi.hist_start, e = s + wi.deg;
+  const int lane = threadIdx.x % G, r = threadIdx.x / G;
   int *lb = (int *)(lds + (size_t)NWV * RT * P.ld);
   if ((int)threadIdx.x < RT) lb[threadIdx.x] = (int)threadIdx.x < n ? S.usamp[p0 + threadIdx.x] : 0;
-  __syncthreads();
-  const int u = bt.uid[lb[0]];
-  const int64_t s = H.indptr[u], e = H.indptr[u + 1];
+  // the user's row of V (B needs it, not the bags): under way before A's rounds
+  float4 vrow[J];
+  load_row<G, J>(P.V, (size_t)u, P.ld, lane, vrow);
   const int n_waves = (int)min((int64_t)NWV, (e - s + NF - 1) / NF);         // waves that have rows at all
   {  // A
+    // v_mfma_f32_16x16x4_f32 per (4 rows, 16 columns): A[m][k] = the keep coefficient of (triple m, row k) — lane l supplies
+    // A[l % 16][l / 16], the very pair whose mask bit it evaluates; B[k][n] = lane l's column of row k = l / 16.  A lane loads float4s
+    // (columns 64 h + 4 (l % 16) ...), so the tile of (h, j) holds columns 64 h + 4 n + j: C[4 (l / 16) + i][l % 16] in register i.
+    typedef float f4v __attribute__((ext_vector_type(4)));
     const int wl = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float bag[RT][CPL];
+    const int kr = wl >> 4, nc = wl & 15;            // this lane's row of a group of 4, its triple (A) / its column quad (B)
+    f4v acc[NH][4];
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int k = 0; k < CPL; ++k) bag[t][k] = 0.f;
+      for (int j = 0; j < 4; ++j) acc[h][j] = f4v{0.f, 0.f, 0.f, 0.f};
     const int64_t c0 = s + (int64_t)wv * NF;
-    int idx = (wl < NF && c0 + wl < e) ? H.indices[c0 + wl] : 0;
+    int ridx[NF / 4];
+#pragma unroll
+    for (int g = 0; g < NF / 4; ++g) ridx[g] = c0 + 4 * g + kr < e ? H.indices[c0 + 4 * g + kr] : 0;
+    __syncthreads();                                 // (lb)
+    const int bmine = lb[nc];
     for (int64_t c = c0; c < e; c += (int64_t)NWV * NF) {
       const int64_t cn = c + (int64_t)NWV * NF;
-      const int idx_n = (wl < NF && cn + wl < e) ? H.indices[cn + wl] : 0;      // (under way while this round's rows are)
-      float v[NF][CPL];
+      int ridx_n[NF / 4];
 #pragma unroll
-      for (int q = 0; q < NF; ++q) {
-        const int iq = __builtin_amdgcn_readlane(idx, q);
-        if (c + q < e) load_cols<CPL>(P.W + (size_t)iq * P.ld, wl, P.ld, v[q]);
-        else {
+      for (int g = 0; g < NF / 4; ++g) ridx_n[g] = cn + 4 * g + kr < e ? H.indices[cn + 4 * g + kr] : 0;      // (under way while this round's rows are)
+      float4 bv[NF / 4][NH];
 #pragma unroll
-          for (int k = 0; k < CPL; ++k) v[q][k] = 0.f;
+      for (int g = 0; g < NF / 4; ++g)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          bv[g][h] = f4_zero();
+          if (c + 4 * g + kr < e && 64 * h + 4 * nc < P.ld)
+            bv[g][h] = *reinterpret_cast<const float4 *>(P.W + (size_t)ridx[g] * P.ld + 64 * h + 4 * nc);
         }
-      }
-      float cf[NB];                       // lane wl: the 0 / 1 coefficient of pair k * 64 + wl
 #pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const int i = k * 64 + wl, q = i / RT, t = i % RT;
+      for (int g = 0; g < NF / 4; ++g) {
+        const int64_t row = c + 4 * g + kr;
         bool kf = false;
-        if (i < NP && t < n && c + q < e) {
-          const int b = lb[t];
-          const uint32_t jj = (uint32_t)(c + q - s);
-          kf = bt.keep ? (bt.keep[bt.keep_off[b] + jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)b, jj) >= qthr);
+        if (nc < n && row < e) {
+          const uint32_t jj = (uint32_t)(row - s);
+          kf = bt.keep ? (bt.keep[bt.keep_off[bmine] + jj] != 0) : (hash_u32(bt.mask_seed, (uint32_t)bmine, jj) >= qthr);
         }
-        cf[k] = kf ? 1.0f : 0.0f;
-      }
+        const float a = kf ? 1.0f : 0.0f;
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        if (t < n) {
-#pragma unroll
-          for (int q = 0; q < NF; ++q) {
-            const int i = q * RT + t;
-            // (one v_readlane per pair; taking the bit out of a ballot instead costs 3 - 4 instructions on the CU's single scalar ALU)
-            const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf[i / 64]), i % 64));
-            if (CPL == 1) bag[t][0] = fmaf(coef, v[q][0], bag[t][0]);
-            else {
-#pragma unroll
-              for (int k = 0; k < CPL; k += 2) {
-                drx_f2 a = {bag[t][k], bag[t][k + 1]};
-                const drx_f2 x = {v[q][k], v[q][k + 1]}, cc = {coef, coef};
-                a = __builtin_elementwise_fma(cc, x, a);
-                bag[t][k] = a.x; bag[t][k + 1] = a.y;
-              }
-            }
-          }
+        for (int h = 0; h < NH; ++h) {
+          acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[g][h].x, acc[h][0], 0, 0, 0);
+          acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[g][h].y, acc[h][1], 0, 0, 0);
+          acc[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[g][h].z, acc[h][2], 0, 0, 0);
+          acc[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[g][h].w, acc[h][3], 0, 0, 0);
         }
       }
-      idx = idx_n;
+#pragma unroll
+      for (int g = 0; g < NF / 4; ++g) ridx[g] = ridx_n[g];
     }
-    if (wv < n_waves && wl * CPL < P.ld) {
+    if (wv < n_waves) {
 #pragma unroll
-      for (int t = 0; t < RT; ++t)
+      for (int i = 0; i < 4; ++i) {
+        const int t = 4 * kr + i;
         if (t < n) {
-          float *dst = lds + (size_t)(wv * RT + t) * P.ld + wl * CPL;
 #pragma unroll
-          for (int k = 0; k < CPL; ++k) dst[k] = bag[t][k];
+          for (int h = 0; h < NH; ++h)
+            if (64 * h + 4 * nc < P.ld)
+              *reinterpret_cast<float4 *>(lds + (size_t)(wv * RT + t) * P.ld + 64 * h + 4 * nc) =
+                  make_float4(acc[h][0][i], acc[h][1][i], acc[h][2][i], acc[h][3][i]);
         }
+      }
     }
   }
   __syncthreads();
   // B
-  const int lane = threadIdx.x % G, r = threadIdx.x / G;
   float4 dsum[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) dsum[j] = f4_zero();
@@ -913,7 +898,14 @@ __global__ __launch_bounds__(kBlock) void k_items_fwd_bwd(DrxCdaeParams P, DrxOp
 #pragma unroll
         for (int j = 0; j < J; ++j) f4_add(acc[j], x[j]);
       }
-      const float d = sampled_hidden<G, J>(P, bt, scale, b, lane, acc, h, w2);
+      float4 brow[J];
+      load_row<G, J>(P.b, 0, P.ld, lane, brow);
+      hidden_act_rows<G, J>(P, scale, lane, acc, vrow, brow, h);
+      load_row<G, J>(P.W2T, (size_t)bt.iid[b], P.ld, lane, w2);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) d += f4_dot(w2[j], h[j]);
+      d = group_sum<G>(d);
       sampled_rest<G, J, KIND>(P, opt, H, bt, scale, qthr, loss_kind, S, b, lane, d, h, w2, &dz1);
 #pragma unroll
       for (int j = 0; j < J; ++j) f4_add(dsum[j], dz1[j]);
@@ -1677,7 +1669,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   // (k_items_fwd_bwd); the reduction reads the items' summed gradient rows
   const bool share = prepared && !ks_h && share_users(p, hist, bt, R);
   S.usamp = share ? R.usamp : nullptr;
-  S.wfirst = share ? R.wfirst : nullptr;
+  S.witem = share ? R.witem : nullptr;
   S.worder = share ? R.worder : nullptr;
   S.n_items = share ? R.n_du : nullptr;
   const long long mean_hist = bt->n_touch_slots / (long long)bt->B;

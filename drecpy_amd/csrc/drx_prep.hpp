@@ -238,6 +238,10 @@ struct BiasPartialExtra {
 
 constexpr int kLongBlocks = 256, kShortBlocks = 1024;      // k_span_planned: workgroups striding over the long / the short spans
 
+// a work item of DRX_BATCH_SHARE_USERS: n <= kShareTriples consecutive sorted positions p0 .. of ONE user's samples, and where that user's
+// history lies (the forward workgroup reads ONE record instead of walking usamp -> uid -> indptr)
+struct __attribute__((aligned(32))) WorkItem { int32_t p0, n, user, deg; long long hist_start, pad_; };
+
 struct PrepBufs {
   uint32_t *keys_s, *vals_s, *keys, *vals;
   void *sort_temp;
@@ -249,7 +253,7 @@ struct PrepBufs {
   // share_item_triples(ld) (the row groups of a forward workgroup), in the order of the sorted (user, sample) pairs
   int32_t *usamp;               // [B] sorted position -> sample (the samples grouped by user, ascending inside a user)
   int32_t *pitem;               // [B] sorted position -> its work item
-  int32_t *wfirst;              // [B + 1] work item -> its first sorted position; wfirst[n_items] = B
+  WorkItem *witem;              // [B] work item -> its record
   int32_t *worder;              // [B] launch slot -> work item, longest histories first (buckets of log2(history length))
   int32_t *n_du;                // [128]: [0] work items (k_tp_item_*)
   unsigned int *order_work;     // [512] bucket counts | running places (zeroed by k_sparse_touches)
@@ -286,7 +290,7 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
     R.plan.xperm = placed ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
     R.usamp = placed ? cv.take<int32_t>(B) : nullptr;
     R.pitem = placed ? cv.take<int32_t>(B) : nullptr;
-    R.wfirst = placed ? cv.take<int32_t>((size_t)B + 1) : nullptr;
+    R.witem = placed ? cv.take<WorkItem>((size_t)B) : nullptr;
     R.worder = placed ? cv.take<int32_t>(B) : nullptr;
     R.n_du = placed ? cv.take<int32_t>(128) : nullptr;
   }
@@ -385,19 +389,22 @@ __device__ __forceinline__ int tp_bucket_of(const int64_t *__restrict__ indptr, 
 }
 // pitem holds the inclusive scan of the flags
 static __global__ __launch_bounds__(256) void k_tp_item_finish(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B, int rt,
-                                                               const int32_t *__restrict__ start, const int64_t *__restrict__ indptr,
-                                                               int32_t *__restrict__ usamp, int32_t *__restrict__ pitem,
-                                                               int32_t *__restrict__ wfirst, int32_t *n_du, uint32_t *plan_cnt) {
+                                                               const int32_t *__restrict__ start, const int32_t *__restrict__ end,
+                                                               const int64_t *__restrict__ indptr, int32_t *__restrict__ usamp,
+                                                               int32_t *__restrict__ pitem, WorkItem *__restrict__ witem, int32_t *n_du,
+                                                               uint32_t *plan_cnt) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B) return;
   const int item = pitem[p] - 1;
   pitem[p] = item;
   usamp[p] = (int32_t)vs[p];
-  if ((p - start[ks[p]]) % rt == 0) {
-    wfirst[item] = p;
-    atomicAdd(&n_du[32 + tp_bucket_of(indptr, ks[p])], 1);
+  const uint32_t u = ks[p];
+  if ((p - start[u]) % rt == 0) {
+    const long long hs = indptr[u], he = indptr[u + 1];
+    witem[item] = WorkItem{p, min(rt, end[u] - p), (int32_t)u, (int32_t)min(he - hs, 0x7FFFFFFFll), hs, 0};
+    atomicAdd(&n_du[32 + tp_bucket_of(indptr, u)], 1);
   }
-  if (p == B - 1) { wfirst[item + 1] = B; n_du[0] = item + 1; plan_cnt[21] = (uint32_t)(item + 1); }     // (SpanPlan::cnt[21]: place_block)
+  if (p == B - 1) { n_du[0] = item + 1; plan_cnt[21] = (uint32_t)(item + 1); }     // (SpanPlan::cnt[21]: place_block)
 }
 // the launch order of the forward workgroups: which workgroup takes which item never changes a result (inside a bucket: any order)
 static __global__ __launch_bounds__(256) void k_tp_item_order(const uint32_t *__restrict__ ks, int B, int rt, const int32_t *__restrict__ start,
@@ -536,8 +543,8 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
     hipLaunchKernelGGL(k_tp_item_flags, dim3(ig), dim3(256), 0, st, ks, B, rt, start, R.pitem, R.n_du);
     rc = scan_i32(sctemp2, scb2, R.pitem, R.pitem, (size_t)B, true, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tp_item_finish, dim3(ig), dim3(256), 0, st, ks, vs, B, rt, start, hist->indptr, R.usamp, R.pitem, R.wfirst, R.n_du,
-                       R.plan.cnt);
+    hipLaunchKernelGGL(k_tp_item_finish, dim3(ig), dim3(256), 0, st, ks, vs, B, rt, start, end, hist->indptr, R.usamp, R.pitem, R.witem,
+                       R.n_du, R.plan.cnt);
     hipLaunchKernelGGL(k_tp_item_order, dim3(ig), dim3(256), 0, st, ks, B, rt, start, hist->indptr, R.pitem, R.worder, R.n_du);
     hipLaunchKernelGGL((k_tp_expand<false, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
   } else

@@ -27,13 +27,10 @@ __device__ __forceinline__ void store_row(float *base, size_t row, int ld, int l
 
 __device__ __forceinline__ float colmask(int col, int k, float v) { return col < k ? v : 0.0f; }
 
-// h = sigmoid(scale*bag + V[u] + b), zero in the padding columns.
+// h = sigmoid(scale*bag + V[u] + b), zero in the padding columns (v, bb: the rows V[u] and b).
 template <int G, int J>
-__device__ __forceinline__ void hidden_act(const DrxCdaeParams &P, int u, float scale, int lane,
-                                           const float4 (&acc)[J], float4 (&h)[J]) {
-  float4 v[J], bb[J];
-  load_row<G, J>(P.V, (size_t)u, P.ld, lane, v);
-  load_row<G, J>(P.b, 0, P.ld, lane, bb);
+__device__ __forceinline__ void hidden_act_rows(const DrxCdaeParams &P, float scale, int lane, const float4 (&acc)[J], const float4 (&v)[J],
+                                                const float4 (&bb)[J], float4 (&h)[J]) {
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int col = 4 * (lane + j * G);
@@ -42,6 +39,14 @@ __device__ __forceinline__ void hidden_act(const DrxCdaeParams &P, int u, float 
     h[j].z = colmask(col + 2, P.k, sigmoidf_(fmaf(scale, acc[j].z, v[j].z + bb[j].z)));
     h[j].w = colmask(col + 3, P.k, sigmoidf_(fmaf(scale, acc[j].w, v[j].w + bb[j].w)));
   }
+}
+template <int G, int J>
+__device__ __forceinline__ void hidden_act(const DrxCdaeParams &P, int u, float scale, int lane,
+                                           const float4 (&acc)[J], float4 (&h)[J]) {
+  float4 v[J], bb[J];
+  load_row<G, J>(P.V, (size_t)u, P.ld, lane, v);
+  load_row<G, J>(P.b, 0, P.ld, lane, bb);
+  hidden_act_rows<G, J>(P, scale, lane, acc, v, bb, h);
 }
 
 // ------------------------------------------------------------------------------------------------
