@@ -322,7 +322,10 @@ def kept_count(keep_off, seed, q):
     return int((hash_u32_torch(seed, row, j) >= q_threshold(q)).sum().item())
 
 
-def batch_row_stats(indptr, indices, uid, iid, keep_off, seed, q):
+SHARE_TRIPLES = 16          # csrc/drx_prep.hpp kShareTriples: triples of one work item of DRX_BATCH_SHARE_USERS
+
+
+def batch_row_stats(indptr, indices, uid, iid, keep_off, seed, q, share=False):
     """Exact row statistics of ONE batch, counted on the device: per key class (W = input rows of the kept history items,
     V = user rows, O = W2T output rows) the number of touches (occurrences) and of DISTINCT rows, and the rows a single triple
     touches (the forward kernel updates those in place).  These are what the dedup-aware byte model of the roofline needs."""
@@ -340,6 +343,30 @@ def batch_row_stats(indptr, indices, uid, iid, keep_off, seed, q):
     for name, col in (('V', uid), ('O', iid)):
         _, cnt = torch.unique(col.long(), return_counts=True)
         st['dist_' + name], st['solo_' + name] = int(cnt.numel()), int((cnt == 1).sum().item())
+    if share:
+        # DRX_BATCH_SHARE_USERS (csrc/drx_prep.hpp k_tp_item_* / k_tp_expand<SHARE>): the samples of a user, ascending, in work items of
+        # 16; per (work item, history position): nq samples, k of them keep the position -> one touch of the item's summed row and one
+        # per dropper where that is the shorter form (1 + nq - k < k), else one per keeper.  The forward kernel loads a history row once
+        # per work item.
+        order = torch.argsort(uid.long(), stable=True)
+        su = uid.long()[order]
+        head = torch.ones(B, dtype=torch.bool, device=dev)
+        head[1:] = su[1:] != su[:-1]
+        run_start = torch.cummax(torch.where(head, torch.arange(B, device=dev), torch.zeros(B, dtype=torch.long, device=dev)), 0).values
+        item_head = (torch.arange(B, device=dev) - run_start) % SHARE_TRIPLES == 0
+        item_sorted = torch.cumsum(item_head.long(), 0) - 1
+        witem = torch.empty(B, dtype=torch.long, device=dev)
+        witem[order] = item_sorted
+        n_items = int(item_sorted[-1].item()) + 1
+        max_deg = int(deg.max().item()) + 1
+        grp = witem[row] * max_deg + j
+        ug, inv = torch.unique(grp, return_inverse=True)
+        nq = torch.zeros(ug.numel(), dtype=torch.long, device=dev).scatter_add_(0, inv, torch.ones_like(inv))
+        kk = torch.zeros(ug.numel(), dtype=torch.long, device=dev).scatter_add_(0, inv, keep.long())
+        shared = (nq > 1) & (1 + nq - kk < kk)
+        st['share_touches'] = int(torch.where(shared, 1 + nq - kk, kk).sum().item())
+        st['share_item_rows'] = int(ug.numel())
+        st['share_items'] = n_items
     return st
 
 
@@ -366,6 +393,10 @@ def byte_model(st, k, S, fused_solo, fused_solo_w=False, n_users=None, n_items=N
     gather_rows = (st['occ_W'] if big_items else st['dist_W']) + (B if big_users else st['dist_V']) + (B if big_items else st['dist_O'])
     fwd = row * gather_rows + row * (B + (B - solo_O)) + row * (solo_V + solo_O + solo_W) * (1 + 2 * S) + 4.0 * st['history_items'] + 40.0 * B
     n_touch = st['occ_W'] - solo_W + (B - solo_V) + (B - solo_O)
+    share = 'share_touches' in st
+    if share:                        # the W part of the list in the shared form; one more gradient row written per work item
+        n_touch = st['share_touches'] + (B - solo_V) + (B - solo_O)
+        fwd += row * st['share_items']
     red = row * (st['dist_W'] - solo_W + st['dist_V'] - solo_V + st['dist_O'] - solo_O) * (2 + 2 * S) + 8.0 * n_touch
     # STRICTLY NECESSARY bytes: every gathered row counted once per DISTINCT row whatever the table's size — what
     # must cross the HBM interface even with a perfect cache.  The headline `frac` is priced on these: it can never exceed the
@@ -374,6 +405,8 @@ def byte_model(st, k, S, fused_solo, fused_solo_w=False, n_users=None, n_items=N
     # REQUESTED bytes, cache level: what the kernels ask of L2 / the Infinity Cache — one row per occurrence in the forward kernel,
     # one gradient row per touch in the reduction, on top of their HBM bytes (for cache-resident shapes this is the binding traffic)
     fwd_req = fwd_nec + row * (st['occ_W'] + 2 * B - (st['dist_W'] + st['dist_V'] + st['dist_O']))
+    if share:                        # a history row once per work item, the user's V row once per work item, a W2T row per triple
+        fwd_req = fwd_nec + row * (st['share_item_rows'] + st['share_items'] + B - (st['dist_W'] + st['dist_V'] + st['dist_O']))
     red_req = red + row * n_touch
     return {'k_sampled_fwd_bwd': fwd, 'k_seg_reduce': red, 'cache_bytes_k_seg_reduce': row * n_touch,
             'cache_bytes_k_sampled_fwd_bwd': row * (st['occ_W'] + 2 * B - gather_rows),
@@ -769,10 +802,15 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     S_opt = {'adam': 2.0, 'adagrad': 1.0, 'rowwise_adagrad': 1.0 / K}[args.optimizer] if stepper is None else 1.0
     alg_fwd = B * 4.0 * K * (rows_per_sample + f_solo * (2.0 + 2.0 * S_opt))
     alg_upd = B * 4.0 * K * (rows_per_sample - f_solo) * (2.0 + 2.0 * S_opt)
+    # the lists of this run are in the shared form (DRX_BATCH_SHARE_USERS; csrc/drx_prep.hpp share_users(): the history's transpose exists,
+    # long segments, rows of 33 .. 255 floats, lists prepared ahead): the forward kernel is then k_items_fwd_bwd
+    may_share = bool(stepper is None and overlap and getattr(eng, '_hist_t', None) is not None and eng.share_users and 32 < K < 256)
+    shared_run = may_share and int(batches[0][3][-1].item()) + 2 * B > 8 * (2 * N + (hi - lo))
+    FWD = 'k_items_fwd_bwd' if shared_run else 'k_sampled_fwd_bwd'
     if stepper is None:
-        names = ['k_sampled_fwd_bwd', 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce_planned(+bias partials)',
+        names = [FWD, 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce_planned(+bias partials)',
                  'k_span_planned(short | long spans | bias update)', '(unused)']
-        dom, dom_ms, dom_alg = ('k_seg_reduce_planned', ph[2], alg_upd) if ph[2] >= ph[0] else ('k_sampled_fwd_bwd', ph[0], alg_fwd)
+        dom, dom_ms, dom_alg = ('k_seg_reduce_planned', ph[2], alg_upd) if ph[2] >= ph[0] else (FWD, ph[0], alg_fwd)
     else:
         names = (['row_gather+row_exchange', 'k_shard_fwd_bwd', 'k_seg_reduce_planned<LocalPolicy>(+bias partials)',
                   'k_span_planned(+bias row)', 'grad_exchange+k_shard_apply(+bias update)'] if micro == 1 else
@@ -793,10 +831,11 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                 u_, i_, _, ko_ = eng.sample_device(B, NEG_RATIO, seed_, n_items=N)
             else:
                 u_, i_, _, ko_, seed_ = batches[(args.warmup + s_) % len(batches)]
-            stats.append(batch_row_stats(indptr, indices, u_, i_, ko_, seed_, Q))
+            long_segments = int(ko_[-1].item()) + 2 * B > 8 * (2 * N + (hi - lo))             # csrc/drx_prep.hpp long_segments()
+            stats.append(batch_row_stats(indptr, indices, u_, i_, ko_, seed_, Q, share=may_share and long_segments))
         _trace('row statistics done')
         mean_st = {k_: float(np.mean([st[k_] for st in stats])) for k_ in stats[0]}
-        solo_w_on = bool(eng._batch_flags(int(mean_st['history_items'])))      # W rows with one touch are updated by the forward kernel too
+        solo_w_on = False           # (the variant whose forward kernel also updated W rows with one touch was removed in r04: HISTORY.md)
         bm = byte_model(mean_st, K, S_opt, fused_solo=overlap, fused_solo_w=solo_w_on, n_users=hi - lo, n_items=N)
         dedup = {'batches_counted': len(stats), 'per_batch_mean': {k_: round(v, 1) for k_, v in mean_st.items()}, 'bytes_per_launch': bm,
                  'sole_toucher_w_rows_fused': solo_w_on}
@@ -881,7 +920,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         bpl = dedup['bytes_per_launch']
         for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
             byt, occ, req, ms_ = bpl['necessary_' + kn], bpl[kn], bpl['requested_' + kn], ms_of[kn]
-            kname = kn if kn != 'k_seg_reduce' else 'k_seg_reduce_planned'
+            kname = FWD if kn != 'k_seg_reduce' else 'k_seg_reduce_planned'
             rate = lambda b_: b_ / (ms_ * 1e-3) / 1e9
             per_kernel[kname] = {'bytes_per_launch': byt, 'avg_launch_ms': ms_, 'achieved': rate(byt), 'frac': rate(byt) / HBM_PEAK_GBS,
                                  'per_occurrence_bytes': occ, 'per_occurrence_frac': rate(occ) / HBM_PEAK_GBS,
@@ -894,7 +933,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         step_bytes = bpl['necessary_k_sampled_fwd_bwd'] + bpl['necessary_k_seg_reduce']
         step_occ = bpl['k_sampled_fwd_bwd'] + bpl['k_seg_reduce']
         step_req = bpl['requested_k_sampled_fwd_bwd'] + bpl['requested_k_seg_reduce']
-        step_traffic = sum(traffic_of.get(kn, 0.0) for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned', 'k_span_planned')) or None
+        step_traffic = sum(traffic_of.get(kn, 0.0) for kn in (FWD, 'k_seg_reduce_planned', 'k_span_planned')) or None
         dk = per_kernel[dom]
         out['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['frac'],

@@ -30,7 +30,9 @@ def test_bench_line_has_the_contracted_fields():
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert 0.0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert r['traffic'] is None or r['traffic'] > 0                                       # (PMC passes are of the 10M x 1M workload)
-    for k in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned'):
+    # (MovieLens shapes: the lists are in the shared form — DRX_BATCH_SHARE_USERS — and the forward kernel is k_items_fwd_bwd)
+    assert 'k_items_fwd_bwd' in r['kernels'] and r['row_counts']['share_touches'] < r['row_counts']['occ_W']
+    for k in ('k_items_fwd_bwd', 'k_seg_reduce_planned'):
         kr = r['kernels'][k]
         assert 0.0 < kr['frac'] <= 1.0 and kr['avg_launch_ms'] > 0
         # the headline fraction is priced on the strictly necessary bytes: never above the per-occurrence reading, never above what
@@ -48,7 +50,7 @@ def test_bench_line_has_the_contracted_fields():
     g = d['configs']
     c2 = g['cfg2_cdae_ml1m_sampled']
     assert c2['value'] > 0 and c2['unit'] == 'samples/s' and 0.0 < c2['roofline']['frac'] <= 1.0 and c2['cpu_baseline']['value'] > 0
-    for k in ('k_sampled_fwd_bwd', 'k_seg_reduce_planned'):
+    for k in ('k_items_fwd_bwd', 'k_seg_reduce_planned'):
         assert 0.0 < c2['roofline']['kernels'][k]['frac'] <= 1.0
     # the ml-1m model is cache-resident: its line carries the cache-level reading (rows requested from L2 / Infinity Cache)
     assert c2['roofline']['cache_resident'] is True and 0.0 < c2['roofline']['cache_level']['frac_of_l2_gather'] < 1.5
