@@ -509,10 +509,13 @@ static bool share_users(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
          transposed_applies(p, hist, bt, R);
 }
 
-static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st) {
+// allow_share: the list is prepared AHEAD of its step (drx_cdae_sparse_prepare) — a step that builds its list inline runs the plain
+// forward kernel and must get the plain list
+static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
+                              bool allow_share) {
   const int B = bt->B, U = p->n_users, N = p->n_items;
   if (!transposed_applies(p, hist, bt, R)) return kTpFallback;
-  const bool share = share_users(p, hist, bt, R);
+  const bool share = allow_share && share_users(p, hist, bt, R);
   const int64_t nnz = hist->t_nnz;
   if (nnz < 1 || nnz > (int64_t)R.T || nnz >= (1ll << 30) || (int64_t)U + N >= 0x7FFFFFFFll) return kTpFallback;
   // work areas: cnt in the big sort's key buffer, the rest in its temp
@@ -566,7 +569,7 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
                         bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, 1, 0}) {
   const int gpb = kBlock / 16;
   if (hist->t_indptr && hist->t_users && hist->t_pos && !pres.present && long_segments(R.T, *p)) {
-    const int rc = prepare_transposed(p, hist, bt, R, st);
+    const int rc = prepare_transposed(p, hist, bt, R, st, with_marks);
     if (rc == DRX_OK) {                                        // the list stands, sorted: what is left is what follows the sort below
       if (with_marks && p->ld > 16) {
         order_by_degree(bt, R, st, true);

@@ -94,12 +94,20 @@ typedef struct DrxBatch {
   uint32_t flags;           /* DRX_BATCH_* (0: none) */
 } DrxBatch;
 /* Sampled mode, batches in which users REPEAT (B several times the number of users: MovieLens shapes), prepared through the history's
- * transpose (DrxHistory::t_*; lists of long segments): the triples of one user share their gather and their gradient —
- *   forward : bag(b) = S_u - sum of the DROPPED rows of b,   S_u = the sum of ALL rows of u's history, formed once per user and step
- *   backward: an item row of u's history receives  D_u - sum of dz1[b] over the triples b of u that DROPPED it,  D_u = sum of dz1 over u's triples
- * (with corruption level q a triple drops a fraction q of its rows and keeps 1 - q: 1 / q fewer row reads per triple on both sides, plus one
- * pass per distinct user).  Another association of the same sums: same oracle, same tolerance.  Prepare and step must see the same flag;
- * it is ignored (plain lists) where the transposed preparation does not apply.  Single-GPU step only. */
+ * transpose (DrxHistory::t_*; lists of long segments): the triples of one user share their gather and their gradient.  The samples
+ * of a user, ascending, are cut into WORK ITEMS of up to 16 triples (csrc/drx_prep.hpp k_tp_item_*):
+ *   forward : one workgroup per work item loads every row of the user's history ONCE and adds it into the bags of the item's triples
+ *             under their keep bits — a masked matrix product [16 triples x history] x [history x K] (csrc/drx_cdae.hip
+ *             k_items_fwd_bwd, v_mfma_f32_16x16x4_f32: fp32, products with 0 / 1) — instead of one gather per triple;
+ *   backward: an item row of the user's history receives, per work item,  D_w - sum of dz1[b] over the triples b of the item that
+ *             DROPPED it,  D_w = sum of dz1 over the item's triples (a row of its own behind the samples' gradient rows) — where
+ *             that is the shorter form (1 + droppers < keepers), else one touch per keeper as without the flag.
+ * With corruption level q the touch list shrinks towards q + 1/16 of its plain length (ml-1m shape: 8.0 M -> 2.9 M touches), the rows
+ * the forward kernel loads to 1 / (triples per work item) (8.0 M -> 1.0 M).  Another association of the same sums: same oracle, same
+ * tolerance; bit-reproducible (every order is a function of the batch).  Prepare and step must see the same flag; it is ignored
+ * (plain lists) where the transposed preparation does not apply, rows are narrower than 33 / wider than 255 floats, or the step
+ * builds its list inline (drx_cdae_step_sparse: only lists prepared ahead, drx_cdae_sparse_prepare, take the shared form).
+ * Single-GPU step only. */
 #define DRX_BATCH_SHARE_USERS 1u
 
 typedef struct DrxOptim {

@@ -39,9 +39,21 @@ def test_full_size_properties(shape, users, B):
     eng, U, N, ip, idx = _setup(shape, users)
     a = _run(eng, N, B, 3, prepared=False)
     eng2, _, _, _, _ = _setup(shape, users)
+    shared_form = eng2._hist_t is not None             # (MovieLens shapes: lists prepared AHEAD are in the shared form, DRX_BATCH_SHARE_USERS)
+    eng2.share_users = False
     b = _run(eng2, N, B, 3, prepared=True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)                       # deterministic, and prepared == inline bit for bit
+    if shared_form:
+        # the shared form: another association of the same sums — bit-reproducible, and the inline steps' tables to rounding
+        outs = []
+        for _ in range(2):
+            eng3, _, _, _, _ = _setup(shape, users)
+            assert eng3.share_users
+            outs.append(_run(eng3, N, B, 3, prepared=True))
+        for x, y, z in zip(outs[0], outs[1], a):
+            assert torch.equal(x, y)
+            assert float((x - z).abs().max()) < 2e-5 * max(1.0, float(z.abs().max()))
     # rows that no triple of a further step touches keep their bits (parameters and Adagrad accumulators)
     before = [t.clone() for t in eng.tables()] + [t.clone() for t in eng.s1]
     uid, iid, y, ko = eng.sample_device(B, 5, 999, n_items=N)
