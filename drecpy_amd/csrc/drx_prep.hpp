@@ -152,7 +152,8 @@ static __global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, 
     return;
   }
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid < n_chunks) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
+  // (a list laid down compact by the transposed preparation says how long it is: chunks behind its cnt[20] touches hold padding only)
+  if (tid < n_chunks && (P.cnt[20] == 0u || (long long)tid * P.chunk < (long long)P.cnt[20])) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
   const int nb = (n_chunks + cpb - 1) / cpb;
   if (P.xrank && (tid & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, tid, tid < nb);
   // (a list laid down compact by the transposed preparation says where its W2T / V parts are: the last 2B of its cnt[20] touches)
@@ -327,16 +328,16 @@ static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Preparation through the history's TRANSPOSE (r04; DrxHistory::t_*): lists of LONG segments — MovieLens shapes, where a batch of 65 536
-// triples over 6 040 users and 3 706 items has 10 M touches and the sort of those pairs (two passes of 320 us + a histogram) had made
-// the PREPARATION, not the training kernels, the bound of a step.  The sorted list is the static item -> users structure of the training
-// set expanded by the batch's samples of every user: only the 2B (user | item, sample) pairs of the batch are sorted (one stable sort:
-// samples ascending per id), then every transpose entry (item n, user u, position j) counts the samples of u whose corruption mask
-// keeps position j, a scan places them, and a second walk writes (n, sample) — the W part of the list, item-major, compact; the W2T
-// part (N + item) and the V part (2N + user) ARE the sorted batch pairs.  Inside a segment the touches come user by user, samples
-// ascending: another FIXED order than the sort's (samples ascending) — a function of the batch alone, as bit-reproducible as before.
-// Work areas are carved out of the regions the big sort would have used (keys / vals / sort_temp); returns kTpFallback when they do
-// not fit (the caller then sorts).
+// Preparation through the history's TRANSPOSE (r04; DrxHistory::t_rank): lists of LONG segments — MovieLens shapes, where a batch of
+// 65 536 triples over 6 040 users and 3 706 items has 10 M touches and the sort of those pairs (two passes of 320 us + a histogram) had
+// made the PREPARATION, not the training kernels, the bound of a step.  The sorted list is the static item -> users order of the
+// training set expanded by the batch's samples of every user: only the 2B (user | item, sample) pairs of the batch are sorted (one
+// stable sort: samples ascending per id), then every history entry (user u, position j, item n) of a user of the batch counts the
+// samples of u whose corruption mask keeps position j — the count stored at the entry's ITEM-MAJOR RANK — a scan places them, and a
+// second walk writes (n, sample): the W part of the list, item-major, compact; the W2T part (N + item) and the V part (2N + user) ARE
+// the sorted batch pairs.  Inside a segment the touches come user by user, samples ascending: another FIXED order than the sort's
+// (samples ascending) — a function of the batch alone, as bit-reproducible as before.  Work areas are carved out of the regions the
+// big sort would have used (keys / vals / sort_temp); returns kTpFallback when they do not fit (the caller then sorts).
 constexpr int kTpFallback = 0x7fff0001;
 
 static __global__ __launch_bounds__(256) void k_tp_begin(DrxBatch bt, int n_users, uint32_t *__restrict__ k2, uint32_t *__restrict__ v2,
@@ -387,88 +388,112 @@ __device__ __forceinline__ int tp_bucket_of(const int64_t *__restrict__ indptr, 
   const long long d = (long long)(indptr[u + 1] - indptr[u]);
   return __clz((int)min(d, 0x7FFFFFFFll) | 1);
 }
-// pitem holds the inclusive scan of the flags
+// pitem holds the inclusive scan of the flags.  (The bucket counts are summed per workgroup in LDS first: 6 000 atomics on half a dozen
+// words took 40 us in each of the two kernels.)
 static __global__ __launch_bounds__(256) void k_tp_item_finish(const uint32_t *__restrict__ ks, const uint32_t *__restrict__ vs, int B, int rt,
                                                                const int32_t *__restrict__ start, const int32_t *__restrict__ end,
                                                                const int64_t *__restrict__ indptr, int32_t *__restrict__ usamp,
                                                                int32_t *__restrict__ pitem, WorkItem *__restrict__ witem, int32_t *n_du,
                                                                uint32_t *plan_cnt) {
+  __shared__ int lcnt[32];
+  if (threadIdx.x < 32) lcnt[threadIdx.x] = 0;
+  __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= B) return;
-  const int item = pitem[p] - 1;
-  pitem[p] = item;
-  usamp[p] = (int32_t)vs[p];
-  const uint32_t u = ks[p];
-  if ((p - start[u]) % rt == 0) {
-    const long long hs = indptr[u], he = indptr[u + 1];
-    witem[item] = WorkItem{p, min(rt, end[u] - p), (int32_t)u, (int32_t)min(he - hs, 0x7FFFFFFFll), hs, 0};
-    atomicAdd(&n_du[32 + tp_bucket_of(indptr, u)], 1);
+  if (p < B) {
+    const int item = pitem[p] - 1;
+    pitem[p] = item;
+    usamp[p] = (int32_t)vs[p];
+    const uint32_t u = ks[p];
+    if ((p - start[u]) % rt == 0) {
+      const long long hs = indptr[u], he = indptr[u + 1];
+      witem[item] = WorkItem{p, min(rt, end[u] - p), (int32_t)u, (int32_t)min(he - hs, 0x7FFFFFFFll), hs, 0};
+      atomicAdd(&lcnt[tp_bucket_of(indptr, u)], 1);
+    }
+    if (p == B - 1) { n_du[0] = item + 1; plan_cnt[21] = (uint32_t)(item + 1); }     // (SpanPlan::cnt[21]: place_block)
   }
-  if (p == B - 1) { n_du[0] = item + 1; plan_cnt[21] = (uint32_t)(item + 1); }     // (SpanPlan::cnt[21]: place_block)
+  __syncthreads();
+  if (threadIdx.x < 32 && lcnt[threadIdx.x]) atomicAdd(&n_du[32 + threadIdx.x], lcnt[threadIdx.x]);
 }
 // the launch order of the forward workgroups: which workgroup takes which item never changes a result (inside a bucket: any order)
 static __global__ __launch_bounds__(256) void k_tp_item_order(const uint32_t *__restrict__ ks, int B, int rt, const int32_t *__restrict__ start,
                                                               const int64_t *__restrict__ indptr, const int32_t *__restrict__ pitem,
                                                               int32_t *__restrict__ worder, int32_t *n_du) {
+  __shared__ int lcnt[32], lbase[32];
+  if (threadIdx.x < 32) lcnt[threadIdx.x] = 0;
+  __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= B || (p - start[ks[p]]) % rt != 0) return;
-  const int b = tp_bucket_of(indptr, ks[p]);
-  int base = 0;
-  for (int x = 0; x < b; ++x) base += n_du[32 + x];
-  worder[base + atomicAdd(&n_du[64 + b], 1)] = pitem[p];
+  const bool head = p < B && (p - start[ks[p]]) % rt == 0;
+  int b = 0, local = 0;
+  if (head) { b = tp_bucket_of(indptr, ks[p]); local = atomicAdd(&lcnt[b], 1); }
+  __syncthreads();
+  if (threadIdx.x < 32) {                                  // this workgroup's range inside bucket t: behind the buckets before it
+    const int t = threadIdx.x;
+    int base = 0;
+    for (int x = 0; x < t; ++x) base += n_du[32 + x];
+    lbase[t] = lcnt[t] ? base + atomicAdd(&n_du[64 + t], lcnt[t]) : 0;
+  }
+  __syncthreads();
+  if (head) worder[lbase[b] + local] = pitem[p];
 }
 
 // WRITE = false: cnt[e] = touches of entry e;  WRITE = true: cnt holds the exclusive scan, the pairs are written.
 // SHARE (DRX_BATCH_SHARE_USERS): per work item of the entry's user (rt samples of the user's run), ONE touch of the item's summed
 // gradient row (sample field B + the work item) and one touch per sample of the item that DROPPED the entry (sample field | 0x80000000:
 // the reduction subtracts those) — where that is the shorter form; otherwise, as without the flag, one touch per sample that kept it.
+// One WORKGROUP per user of the batch, its waves take the user's history 64 positions at a time, lane = position: every lane walks the
+// SAME samples (uniform trip counts; r04, first form: one thread per transpose entry — neighbouring lanes held users of 1 .. 79
+// samples, a wave took as long as its longest — and a 12-step search for the entry's item: 60 + 40 us for the two passes, alone).
+// The place of a position's touches: the item-major rank of its entry (DrxHistory::t_rank) through the scan.
 template <bool WRITE, bool SHARE>
-static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch bt, uint32_t qthr, int n_items, const int32_t *__restrict__ start,
+static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch bt, uint32_t qthr, int n_users, const int32_t *__restrict__ start,
                                                           const int32_t *__restrict__ end, const uint32_t *__restrict__ vs,
                                                           int *__restrict__ cnt, uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s,
                                                           const int32_t *__restrict__ pitem, int rt) {
-  // one thread per transpose entry; the item of an entry: lower bound over t_indptr, once per thread
-  const int64_t nnz = H.t_nnz;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
-    const int u = H.t_users[e], j = H.t_pos[e];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  for (int u = blockIdx.x; u < n_users; u += gridDim.x) {
     const int s0 = start[u], c = end[u] - s0;
-    int n = 0;
-    if (WRITE && c > 0) {
-      int lo = 0, hi = n_items;                     // the last item whose row starts at or before e
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (H.t_indptr[mid] <= e) lo = mid; else hi = mid; }
-      n = lo;
+    if (WRITE && c <= 0) continue;
+    const int64_t hs = H.indptr[u];
+    const int deg = (int)(H.indptr[u + 1] - hs);
+    if (c <= 0) {                                          // a user without a sample in this batch: its entries hold no touch
+      for (int j = wv * 64 + lane; j < deg; j += nwv * 64) cnt[H.t_rank[hs + j]] = 0;
+      continue;
     }
-    int at = WRITE ? cnt[e] : 0, kept = 0;
-    auto keeps = [&](uint32_t b) -> bool {
-      return bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr);
-    };
-    if (SHARE) {                                       // pieces of rt <= 32 samples: the keep bits of a piece, evaluated once
-      for (int q0 = 0; q0 < c; q0 += rt) {
-        const int nq = min(c - q0, rt);
-        uint32_t km = 0;
-        for (int q = 0; q < nq; ++q) km |= (keeps(vs[s0 + q0 + q]) ? 1u : 0u) << q;
-        const int k = __popc(km);
-        const bool shared = nq > 1 && 1 + (nq - k) < k;           // the shorter form of the two: never more touches than the plain list
-        if (!WRITE) { kept += shared ? 1 + (nq - k) : k; continue; }
-        if (shared) { keys_s[at] = (uint32_t)n; vals_s[at] = (uint32_t)bt.B + (uint32_t)pitem[s0 + q0]; ++at; }
-        uint32_t em = shared ? (~km & (nq >= 32 ? 0xFFFFFFFFu : ((1u << nq) - 1u))) : km;      // the samples that emit a touch
-        while (em) {
-          const int q = __ffs((int)em) - 1;
-          em &= em - 1u;
-          const uint32_t b = vs[s0 + q0 + q];
-          keys_s[at] = (uint32_t)n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at;      // top bit: subtracted
+    for (int j = wv * 64 + lane; j < deg; j += nwv * 64) {
+      const int e = H.t_rank[hs + j];
+      const uint32_t n = (uint32_t)H.indices[hs + j];
+      int at = WRITE ? cnt[e] : 0, kept = 0;
+      auto keeps = [&](uint32_t b) -> bool {
+        return bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr);
+      };
+      if (SHARE) {                                       // pieces of rt <= 32 samples: the keep bits of a piece, evaluated once
+        for (int q0 = 0; q0 < c; q0 += rt) {
+          const int nq = min(c - q0, rt);
+          uint32_t km = 0;
+          for (int q = 0; q < nq; ++q) km |= (keeps(vs[s0 + q0 + q]) ? 1u : 0u) << q;
+          const int k = __popc(km);
+          const bool shared = nq > 1 && 1 + (nq - k) < k;           // the shorter form of the two: never more touches than the plain list
+          if (!WRITE) { kept += shared ? 1 + (nq - k) : k; continue; }
+          if (shared) { keys_s[at] = n; vals_s[at] = (uint32_t)bt.B + (uint32_t)pitem[s0 + q0]; ++at; }
+          uint32_t em = shared ? (~km & (nq >= 32 ? 0xFFFFFFFFu : ((1u << nq) - 1u))) : km;      // the samples that emit a touch
+          while (em) {
+            const int q = __ffs((int)em) - 1;
+            em &= em - 1u;
+            const uint32_t b = vs[s0 + q0 + q];
+            keys_s[at] = n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at;      // top bit: subtracted
+          }
+        }
+      } else {
+        for (int q = 0; q < c; ++q) {
+          const uint32_t b = vs[s0 + q];
+          if (keeps(b)) {
+            if (WRITE) { keys_s[at] = n; vals_s[at] = b; ++at; }
+            ++kept;
+          }
         }
       }
-    } else {
-      for (int q = 0; q < c; ++q) {
-        const uint32_t b = vs[s0 + q];
-        if (keeps(b)) {
-          if (WRITE) { keys_s[at] = (uint32_t)n; vals_s[at] = b; ++at; }
-          ++kept;
-        }
-      }
+      if (!WRITE) cnt[e] = kept;
     }
-    if (!WRITE) cnt[e] = kept;
   }
 }
 
@@ -491,7 +516,7 @@ static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t s
 
 // does the transposed preparation apply to this batch (and fit its work areas)?  The step asks the same question (share_users below).
 static bool transposed_applies(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R) {
-  if (!hist->t_indptr || !hist->t_users || !hist->t_pos || !long_segments(R.T, *p)) return false;
+  if (!hist->t_rank || !long_segments(R.T, *p)) return false;
   const int B = bt->B, U = p->n_users, N = p->n_items;
   const int64_t nnz = hist->t_nnz;
   if (nnz < 1 || nnz > (int64_t)R.T || nnz >= (1ll << 30) || (int64_t)U + N >= 0x7FFFFFFFll) return false;
@@ -539,7 +564,7 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   int rc = sort_pairs(stemp, sb, k2, ks, v2, vs, (size_t)2 * B, bits2, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tp_runs, dim3((2 * B + 255) / 256 < 1024 ? (2 * B + 255) / 256 : 1024), dim3(256), 0, st, ks, 2 * B, start, end);
-  const int egrid = (int)((nnz + 255) / 256 < 8192 ? (nnz + 255) / 256 : 8192);
+  const int egrid = U < (1 << 20) ? U : (1 << 20);      // one workgroup per user
   const int rt = share_item_triples(p->ld);
   if (share) {
     const int ig = (B + 255) / 256;
@@ -549,18 +574,18 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
     hipLaunchKernelGGL(k_tp_item_finish, dim3(ig), dim3(256), 0, st, ks, vs, B, rt, start, end, hist->indptr, R.usamp, R.pitem, R.witem,
                        R.n_du, R.plan.cnt);
     hipLaunchKernelGGL(k_tp_item_order, dim3(ig), dim3(256), 0, st, ks, B, rt, start, hist->indptr, R.pitem, R.worder, R.n_du);
-    hipLaunchKernelGGL((k_tp_expand<false, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_expand<false, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
   } else
-    hipLaunchKernelGGL((k_tp_expand<false, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_expand<false, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
   // (the counts of the LAST entry are needed after the scan overwrote them: a copy)
   int *cnt_last = (int *)R.vals;
   DRX_HIP(hipMemcpyAsync(cnt_last, cnt + (nnz - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
   rc = scan_i32(sctemp, scb, cnt, cnt, (size_t)nnz, false, st);
   if (rc) return rc;
   if (share)
-    hipLaunchKernelGGL((k_tp_expand<true, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_expand<true, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
   else
-    hipLaunchKernelGGL((k_tp_expand<true, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, N, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_expand<true, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
   hipLaunchKernelGGL(k_tp_tail, dim3(2048), dim3(256), 0, st, ks, vs, B, U, N, cnt + (nnz - 1), cnt_last, R.T, R.keys_s, R.vals_s, R.plan.cnt);
   return DRX_OK;
 }
@@ -568,7 +593,7 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
                         bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, 1, 0}) {
   const int gpb = kBlock / 16;
-  if (hist->t_indptr && hist->t_users && hist->t_pos && !pres.present && long_segments(R.T, *p)) {
+  if (hist->t_rank && !pres.present && long_segments(R.T, *p)) {
     const int rc = prepare_transposed(p, hist, bt, R, st, with_marks);
     if (rc == DRX_OK) {                                        // the list stands, sorted: what is left is what follows the sort below
       if (with_marks && p->ld > 16) {

@@ -146,18 +146,16 @@ class CdaeEngine:
         self._hist_t = None
         nnz = int(self.hist_indptr[-1].item())
         if with_transpose and 0 < nnz <= self.TRANSPOSE_MAX_NNZ and 2 * self.n_items + self.n_users <= self.TRANSPOSE_MAX_ROWS:
-            # the transpose of the history (item -> users, with every entry's position in its user's row): batches whose rows collect
-            # long runs of touches (MovieLens shapes) are then prepared by expanding it instead of sorting millions of pairs per step
-            # (include/drx.h DrxHistory::t_*).  Once per dataset, with torch ops on the device (set-up, not the hot path).
+            # the item-major rank of every history entry (the permutation that transposes the history, inverted): batches whose rows
+            # collect long runs of touches (MovieLens shapes) are then prepared through this static order instead of sorting millions of
+            # pairs per step (include/drx.h DrxHistory::t_rank).  Once per dataset, with torch ops on the device (set-up, not the hot path).
             ip, idx = self.hist_indptr, self.hist_indices[:nnz].long()
             rows = torch.repeat_interleave(torch.arange(self.n_users, device=self.device), (ip[1:] - ip[:-1]))
-            pos = torch.arange(nnz, device=self.device) - ip[rows]
             order = torch.argsort(idx * self.n_users + rows)
-            t_indptr = torch.zeros(self.n_items + 1, dtype=torch.int64, device=self.device)
-            t_indptr[1:] = torch.cumsum(torch.bincount(idx, minlength=self.n_items), 0)
-            self._hist_t = (t_indptr, rows[order].to(torch.int32).contiguous(), pos[order].to(torch.int32).contiguous())
-            self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices), ptr(self._hist_t[0]), ptr(self._hist_t[1]),
-                                 ptr(self._hist_t[2]), nnz)
+            rank = torch.empty(nnz, dtype=torch.int32, device=self.device)
+            rank[order] = torch.arange(nnz, dtype=torch.int32, device=self.device)
+            self._hist_t = (rank,)
+            self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices), ptr(rank), nnz)
 
     # ---- optimizer --------------------------------------------------------------------------
     def init_optimizer(self, kind, lr, reg_rate, beta1=ADAM_B1, beta2=ADAM_B2, eps=None, initial_accumulator=ADAGRAD_INIT):

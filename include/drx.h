@@ -64,14 +64,13 @@ typedef struct DrxCdaeParams {
 typedef struct DrxHistory {
   const int64_t *indptr;   /* [n_users + 1] */
   const int32_t *indices;  /* [indptr[n_users]] */
-  /* Optional TRANSPOSE of the same matrix (all NULL / 0: none): for every item the users that hold it, ascending, and where the item
-   * sits in each such user's row — indices[indptr[t_users[e]] + t_pos[e]] == item of entry e.  With it the preparation of a sampled
-   * batch whose rows collect long runs of touches (MovieLens shapes: more than 8 touches per table row) EXPANDS this static structure
-   * by the batch's samples of every user instead of sorting millions of (row, sample) pairs per step (csrc/drx_prep.hpp). */
-  const int64_t *t_indptr; /* [n_items + 1] */
-  const int32_t *t_users;  /* [t_nnz] */
-  const int32_t *t_pos;    /* [t_nnz] */
-  int64_t t_nnz;           /* = indptr[n_users] */
+  /* Optional ITEM-MAJOR RANK of every entry (NULL / 0: none): t_rank[p] = the place of entry p = indptr[u] + j (item indices[p] in the
+   * row of user u) when all entries are ordered by (item, user) — the permutation that transposes the matrix, inverted.  With it the
+   * preparation of a sampled batch whose rows collect long runs of touches (MovieLens shapes: more than 8 touches per table row) lays
+   * the batch's touches down item by item through this static order (a count per entry, a scan, a write) instead of sorting millions
+   * of (row, sample) pairs per step (csrc/drx_prep.hpp). */
+  const int32_t *t_rank;   /* [t_nnz] */
+  int64_t t_nnz;           /* = indptr[n_users] < 2^30 */
 } DrxHistory;
 
 /* One mini-batch (one fit() "epoch", recommender_abc.py:189-205).
@@ -94,7 +93,7 @@ typedef struct DrxBatch {
   uint32_t flags;           /* DRX_BATCH_* (0: none) */
 } DrxBatch;
 /* Sampled mode, batches in which users REPEAT (B several times the number of users: MovieLens shapes), prepared through the history's
- * transpose (DrxHistory::t_*; lists of long segments): the triples of one user share their gather and their gradient.  The samples
+ * transpose (DrxHistory::t_rank; lists of long segments): the triples of one user share their gather and their gradient.  The samples
  * of a user, ascending, are cut into WORK ITEMS of up to 16 triples (csrc/drx_prep.hpp k_tp_item_*):
  *   forward : one workgroup per work item loads every row of the user's history ONCE and adds it into the bags of the item's triples
  *             under their keep bits — a masked matrix product [16 triples x history] x [history x K] (csrc/drx_cdae.hip
@@ -208,7 +207,7 @@ int drx_point_sample_recorded(const DrxHistory *hist, const DrxHistory *recorded
                               void *scratch, size_t scratch_bytes, uint64_t *host_mailbox, uint32_t tag, void *stream);
 
 /* The same draws (the same triples for the same seed), handed out SORTED BY USER, a user's triples in the order they were drawn —
- * for batches whose touch lists are prepared through the history's transpose (DrxHistory::t_*): with the batch in user order the
+ * for batches whose touch lists are prepared through the history's transpose (DrxHistory::t_rank): with the batch in user order the
  * expanded list has every row's touches sample-ascending, i.e. the reduction streams through the gradient rows instead of hopping,
  * and the triples of one user sit side by side in the forward kernel.  The order of a batch changes no sum's terms. */
 size_t drx_point_sample_by_user_scratch_bytes(int32_t B, int32_t n_users);

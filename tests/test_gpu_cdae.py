@@ -287,7 +287,7 @@ def test_sparse_step_is_deterministic():
 @pytest.mark.parametrize('K,opt,U', [(128, 'adagrad', 150), (50, 'adam', 150), (16, 'adagrad', 150), (128, 'adagrad', 24), (200, 'adam', 24)])
 def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_sorted_lists(K, opt, U, explicit):
     """Lists of long segments (more than 8 touches per table row: MovieLens shapes) are prepared by expanding the history's transpose
-    (DrxHistory::t_*: only the batch's 2B (id, sample) pairs are sorted) instead of sorting every (row, sample) pair: same oracle;
+    (DrxHistory::t_rank: only the batch's 2B (id, sample) pairs are sorted) instead of sorting every (row, sample) pair: same oracle;
     against the sort path the parameters agree to rounding (inside a segment the touches come user by user instead of sample by
     sample: another fixed order of the same sum), and two runs of the transposed path agree bit for bit.  'shared'
     (DRX_BATCH_SHARE_USERS): the ~7 triples of a user share their gather (full sum minus the dropped rows) and their gradient (the user's
