@@ -153,11 +153,12 @@ static __global__ __launch_bounds__(256) void k_plan_and_mark(uint32_t *keys_s, 
   }
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   // (a list laid down compact by the transposed preparation says how long it is: chunks behind its cnt[20] touches hold padding only)
-  if (tid < n_chunks && (P.cnt[20] == 0u || (long long)tid * P.chunk < (long long)P.cnt[20])) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
+  // (only lists with placed blocks — long segments — can be compact ones: the others never read the word)
+  const int real = P.xrank ? (int)P.cnt[20] : 0;
+  if (tid < n_chunks && (real == 0 || (long long)tid * P.chunk < (long long)real)) plan_chunk(keys_s, T, n_chunks, cpb, P, tid);
   const int nb = (n_chunks + cpb - 1) / cpb;
   if (P.xrank && (tid & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, tid, tid < nb);
   // (a list laid down compact by the transposed preparation says where its W2T / V parts are: the last 2B of its cnt[20] touches)
-  const int real = (int)P.cnt[20];
   const int j_lo = real != 0 ? max(0, real - 2 * B) : 0, j_hi = real != 0 ? min(T, real) : T;
   for (int j = j_lo + tid; j < j_hi; j += plan_blocks * blockDim.x) {
     const uint32_t k = keys_s[j];

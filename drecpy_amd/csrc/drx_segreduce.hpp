@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
   const int blk = placed_block(SP, (int)blockIdx.x, extra_blocks, (int)gridDim.x - extra_blocks, CPB);
   // (lists laid down compact — the transposed preparation — say how long they are: SpanPlan::cnt[20] real touches, the rest of the
   // T slots is padding; a workgroup whose chunks all lie in the padding has nothing to do)
-  if (blk < 0 || (SP.cnt[20] != 0u && (long long)blk * CPB * CH >= (long long)SP.cnt[20] + CH)) return;
+  if (blk < 0 || (LONG && SP.cnt[20] != 0u && (long long)blk * CPB * CH >= (long long)SP.cnt[20] + CH)) return;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int g = blk * CPB + r;
   bool inner = false;          // this chunk is one whole run of a segment that began before it
