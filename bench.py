@@ -843,17 +843,18 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     # HBM traffic from the PMC passes (profiles/pmc_traffic.json), only when that profile was taken on this very workload AND on
     # these very kernel sources (scripts/profile_round.sh stores their hash); rocprofv3 cannot run inside the bench itself.
     traffic_of, traffic_note = {}, 'no PMC profile for this workload'
+    pmc_name = 'pmc_traffic.json' if args.workload == 'synth-10m' else f'pmc_traffic_{args.workload}.json'
     try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json' if args.workload == 'synth-10m' else f'pmc_traffic_{args.workload}.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', pmc_name)) as f:
             pmc = json.load(f)
         m = pmc['_meta']
         if m['workload'] == args.workload and m['batch_per_gpu'] == B and m['n_gpus'] == world and not args.users and K == 128 \
                 and m.get('optimizer', 'adagrad') == args.optimizer:
             if m.get('kernel_source_hash') == kernel_hash:
                 traffic_of = {k_.replace('drx::', ''): v['hbm_bytes_per_launch'] for k_, v in pmc['kernels'].items()}
-                traffic_note = f"profiles/pmc_traffic.json ({m.get('round')}), same kernel sources ({kernel_hash})"
+                traffic_note = f"profiles/{pmc_name} ({m.get('round')}), same kernel sources ({kernel_hash})"
             else:
-                traffic_note = f"profiles/pmc_traffic.json is STALE: taken on kernel sources {m.get('kernel_source_hash')}, this tree is {kernel_hash}"
+                traffic_note = f"profiles/{pmc_name} is STALE: taken on kernel sources {m.get('kernel_source_hash')}, this tree is {kernel_hash}"
     except (OSError, KeyError, ValueError):
         pass
     traffic = traffic_of.get(dom)

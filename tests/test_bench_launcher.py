@@ -80,3 +80,42 @@ def test_pmc_traffic_profile_was_taken_on_these_kernel_sources():
     with open(os.path.join(root, 'profiles', 'pmc_traffic.json')) as f:
         meta = json.load(f)['_meta']
     assert meta['kernel_source_hash'] == bench.kernel_source_hash()
+
+
+def test_row_statistics_of_the_shared_form_match_a_brute_force_count():
+    """bench.batch_row_stats(share=True) — the byte model's touches / row loads / work items of DRX_BATCH_SHARE_USERS lists — against a
+    plain-Python count of the rule of csrc/drx_prep.hpp (k_tp_item_* / k_tp_expand<SHARE>): the samples of a user, ascending, in work
+    items of 16; per (work item, history position) one touch of the item's summed row + one per dropper where 1 + droppers < keepers,
+    else one per keeper."""
+    import numpy as np
+    import torch
+    import bench
+    from helpers import hash_u32, q_threshold
+    rng = np.random.default_rng(3)
+    U, N, B, q, seed = 9, 40, 300, 0.3, 77
+    deg = rng.integers(1, 12, size=U)
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    indices = np.concatenate([np.sort(rng.choice(N, size=d, replace=False)) for d in deg]).astype(np.int32)
+    uid = rng.integers(0, U, size=B)
+    uid[:60] = 4                                                   # one user with several work items
+    iid = rng.integers(0, N, size=B)
+    keep_off = np.zeros(B + 1, np.int64)
+    keep_off[1:] = np.cumsum(deg[uid])
+    st = bench.batch_row_stats(torch.as_tensor(indptr), torch.as_tensor(indices), torch.as_tensor(uid, dtype=torch.int32),
+                               torch.as_tensor(iid, dtype=torch.int32), torch.as_tensor(keep_off, dtype=torch.int32), seed, q, share=True)
+    touches = item_rows = items = 0
+    thr = q_threshold(q)
+    for u in range(U):
+        samples = [b for b in range(B) if uid[b] == u]
+        for p0 in range(0, len(samples), bench.SHARE_TRIPLES):
+            piece = samples[p0:p0 + bench.SHARE_TRIPLES]
+            items += 1
+            for j in range(deg[u]):
+                k = sum(int(hash_u32(seed, np.asarray([b]), np.asarray([j]))[0] >= thr) for b in piece)
+                item_rows += 1
+                touches += (1 + len(piece) - k) if (len(piece) > 1 and 1 + len(piece) - k < k) else k
+    assert (st['share_touches'], st['share_item_rows'], st['share_items']) == (touches, item_rows, items)
+    assert st['share_touches'] <= st['occ_W']                      # never more touches than the plain list holds
+    bm = bench.byte_model({k_: float(v) for k_, v in st.items()}, 128, 1.0, fused_solo=True, n_users=U, n_items=N)
+    assert bm['necessary_k_sampled_fwd_bwd'] <= bm['requested_k_sampled_fwd_bwd'] and bm['necessary_k_seg_reduce'] <= bm['requested_k_seg_reduce']
