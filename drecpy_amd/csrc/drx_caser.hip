@@ -117,6 +117,44 @@ __device__ __forceinline__ void pair_rows(float *g, int tap, bool first, bool wr
   }
 }
 
+// Horizontal convs backward, the filters of height I + 1 (and, recursively, the taller ones): lane l works out filter l's gradient at
+// its arg-max step and holds its position (64 filters at a time); the walk over the filters reads both with v_readlane.  The taps of a
+// filter touch the item rows t0 .. t0 + I: t0 is uniform, so each possible t0 is a branch of its own with COMPILE-TIME row indices —
+// I + 1 weight reads and FMAs per filter.  (r03 asked every window position for a weight — a clamped one times zero where the filter
+// has no tap — so that no index depended on data: 5 reads + 5 FMAs + 15 selects per filter at L = 5, 20 us of a sample's 96.)
+// Same FMAs on the same values in the same order as that form: bit for bit.
+template <int I>
+__device__ __forceinline__ void hconv_backward(const DrxCaserDims &D, const CaserLds &S, const float *wl, int c, int nx, int ld,
+                                               float (&dEr)[kCaserMaxL], float &dcl, int &tl, int &pq) {
+  if constexpr (I < kCaserMaxL) {
+    if (I >= D.L) return;
+    const int tap = D.n_h * ld;
+    const float *const khi = wl + D.off_kh[I] + c;
+    for (int f = 0; f < D.n_h; ++f, ++pq) {
+      if ((pq & 63) == 0) {
+        const int jl = D.n_v + pq + c;
+        dcl = jl < nx ? S.dx[jl] * act_df(D.act_h, S.pre[jl]) : 0.f;
+        tl = jl < nx ? S.arg[jl] : 0;
+      }
+      const float dc = lane_f(dcl, pq & 63);
+      if (dc == 0.f) continue;
+      const int t0 = __builtin_amdgcn_readlane(tl, pq & 63);
+      const float *const kh = khi + f * ld;
+#pragma unroll
+      for (int T = 0; T + I < kCaserMaxL; ++T) {
+        if (t0 == T) {
+          float w[I + 1];
+#pragma unroll
+          for (int s2 = 0; s2 <= I; ++s2) w[s2] = kh[s2 * tap];
+#pragma unroll
+          for (int s2 = 0; s2 <= I; ++s2) dEr[T + s2] = fmaf(dc, w[s2], dEr[T + s2]);
+        }
+      }
+    }
+    hconv_backward<I + 1>(D, S, wl, c, nx, ld, dEr, dcl, tl, pq);
+  }
+}
+
 // A workgroup is W waves, one sample per wave and round.  r03 (phase stamps, scripts/stamps_caser.py: a sample lived 163 us, 44 of them
 // in the horizontal convolutions' 560 weight loads from global memory, 46 in turn-taking over shared LDS gradient accumulators, 24 in
 // the chain of LDS read-modify-writes of the horizontal backward): the workgroup now keeps a COPY OF THE SMALL WEIGHTS in LDS where it
@@ -321,38 +359,11 @@ __global__ __launch_bounds__(1024) void k_caser(DrxCaserDims D, DrxCaserArgs A C
         if (t < L) dEr[t] = fmaf(dv, wl[D.off_kv + (t * D.n_v + f) * ld + c], dEr[t]);
     }
     CSTAMP(8);
-    // ---- 9. horizontal convs backward (through act_h at the arg-max step) -------------------------------------------------
-    // 64 filters at a time: lane l works out filter l's gradient at its arg-max step and holds its position; the walk over the filters
-    // then reads both with v_readlane (a chain of three dependent LDS reads per filter took 23 us of a sample's 143).  The taps of a
-    // filter are read without a data-dependent branch — every position of the window asks for a weight (a clamped one where the filter
-    // has no tap, times zero) — so that the reads of a filter are in flight together.  (Four filters per turn spilled 46 registers at
-    // the 128 a 16-wave workgroup may hold and took three times as long.)
+    // ---- 9. horizontal convs backward (through act_h at the arg-max step): hconv_backward above ------------------------------
     {
       float dcl = 0.f;
       int tl = 0, pq = 0;
-      const int tap = D.n_h * ld;
-      for (int i = 0; i < L; ++i) {
-        const float *const khi = wl + D.off_kh[i] + c;
-        for (int f = 0; f < D.n_h; ++f, ++pq) {
-          if ((pq & 63) == 0) {
-            const int jl = D.n_v + pq + c;
-            dcl = jl < nx ? S.dx[jl] * act_df(D.act_h, S.pre[jl]) : 0.f;
-            tl = jl < nx ? S.arg[jl] : 0;
-          }
-          const float dc = lane_f(dcl, pq & 63);
-          if (dc == 0.f) continue;
-          const int t0 = __builtin_amdgcn_readlane(tl, pq & 63);
-          const float *const kh = khi + f * ld;
-#pragma unroll
-          for (int tt = 0; tt < kCaserMaxL; ++tt) {
-            if (tt < L) {
-              const int s2 = tt - t0;
-              const bool on = s2 >= 0 && s2 <= i;
-              dEr[tt] = fmaf(on ? dc : 0.f, kh[(on ? s2 : 0) * tap], dEr[tt]);
-            }
-          }
-        }
-      }
+      hconv_backward<0>(D, S, wl, c, nx, ld, dEr, dcl, tl, pq);
     }
     CSTAMP(9);
     // ---- 10. gradient rows of the item lookups ------------------------------------------------------------------------------
