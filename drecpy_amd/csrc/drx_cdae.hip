@@ -1684,7 +1684,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     BiasFinalExtra<G, J> bfx{*p, *opt, BA};                                                                            \
     const int cpb = kSegBlock / G;                                                                                     \
     const dim3 rgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                                        \
-    const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
+    const size_t lds_r = seg_reduce_lds_bytes(cpb, p->ld, long_segments);                                              \
     if (long_segments)                                                                                                 \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, true, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
                          R.plan, polk, n_bpart, bpx);                                                                  \

@@ -337,13 +337,16 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, const uint32_t
   if (P.xrank && (g & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, g, g < nb);
 }
 
-// LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats.  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
+// LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats (+, LONG: 4 * CH words per chunk — seg_reduce_lds_bytes).  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
 // CDAE step's bias column sums: independent work that fills the launch's ramp).
 #ifdef DRX_SEGP_W8
 #define DRX_SEGP_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #else
 #define DRX_SEGP_ATTR
 #endif
+static inline size_t seg_reduce_lds_bytes(int cpb, int ld, bool long_segments) {
+  return (size_t)((cpb * (ld + 1) + 3) & ~3) * 4 + (long_segments ? (size_t)cpb * 4 * kChunkLong * 4 : 0);
+}
 template <int G, int J, class Policy, bool LONG, class Extra>
 __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol,
                                                                             int extra_blocks, Extra extra) {
@@ -419,37 +422,102 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
       if (lane == 0) S.pts[g] = accs;
     }
   };
-  for (int t0 = 0; t0 < n; t0 += LB) {
-    uint32_t k8[LB];
-    float s8[LB], c8[LB];
-    float4 rows[LB][J];
+  if constexpr (LONG) {
+    // Lists of LONG segments: a round of LB touches nearly always continues the running segment.  The window's keys / samples are staged
+    // in LDS (group-private: 2 CH words each) and a round reads its LB of each with four 16-byte broadcast reads — the register form
+    // below spends 4 selects + a shuffle per key and per sample — then, when the round's first and last key ARE the running key (sorted:
+    // so is everything between), its LB rows go out together and are added without a compare.  Any other round walks its touches one
+    // by one (boundaries of the short W2T / V segments, blanked touches, the first round of a window).
+    static_assert(LB == 8 || LB == 4 || LB == 2, "a round is one or two 16-byte reads of each kind");
+    uint32_t *const lk = reinterpret_cast<uint32_t *>(seg_lds + ((CPB * (S.ld + 1) + 3) & ~3)) + (size_t)r * 4 * CH;
+    uint32_t *const lv = lk + 2 * CH;
 #pragma unroll
-    for (int u = 0; u < LB; ++u) {
-      const int t = t0 + u;
-      k8[u] = t < n ? bcast(kreg, t) : DRX_KEY_NONE;
-      const uint32_t b = bcast(vreg, t < n ? t : 0);
-      s8[u] = 0.f;
-      c8[u] = 1.f;
-#pragma unroll
-      for (int jx = 0; jx < J; ++jx) rows[u][jx] = f4_zero();
-      if (k8[u] != DRX_KEY_NONE) pol.template load<G, J>(k8[u], b, lane, rows[u], s8[u], c8[u]);
+    for (int q = 0; q < KPL; ++q) {
+      if (q * G + lane < 2 * CH) { lk[q * G + lane] = kreg[q]; lv[q * G + lane] = vreg[q]; }
     }
+    wave_lds_sync();
+    for (int t0 = 0; t0 < n; t0 += LB) {
+      uint32_t k8[LB], b8[LB];
+      if constexpr (LB >= 4) {
 #pragma unroll
-    for (int u = 0; u < LB; ++u) {
-      const uint32_t key = k8[u];
-      if (key != DRX_KEY_NONE) {
-        if (key != cur) {
-          flush(false);
-          cur = key;
-          cur_from_start = (t0 + u == 0);
+        for (int u = 0; u < LB; u += 4) {
+          const uint4 kk = *reinterpret_cast<const uint4 *>(lk + t0 + u), bb = *reinterpret_cast<const uint4 *>(lv + t0 + u);
+          k8[u] = kk.x; k8[u + 1] = kk.y; k8[u + 2] = kk.z; k8[u + 3] = kk.w;
+          b8[u] = bb.x; b8[u + 1] = bb.y; b8[u + 2] = bb.z; b8[u + 3] = bb.w;
+        }
+      } else {
+        k8[0] = lk[t0]; k8[1] = lk[t0 + 1]; b8[0] = lv[t0]; b8[1] = lv[t0 + 1];
+      }
+      if (cur != DRX_KEY_NONE && k8[0] == cur && k8[LB - 1] == cur) {
+        float s8[LB], c8[LB];
+        float4 rows[LB][J];
 #pragma unroll
-          for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
-          accs = 0.f;
+        for (int u = 0; u < LB; ++u) {
+          s8[u] = 0.f; c8[u] = 1.f;
+          pol.template load<G, J>(cur, b8[u], lane, rows[u], s8[u], c8[u]);
         }
 #pragma unroll
-        for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c8[u], rows[u][jx]);
-        accs += s8[u];
-        cur_pos = start + t0 + u;
+        for (int u = 0; u < LB; ++u) {
+#pragma unroll
+          for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c8[u], rows[u][jx]);
+          accs += s8[u];
+        }
+        cur_pos = start + t0 + LB - 1;
+      } else {
+        for (int u = 0; u < LB; ++u) {
+          const uint32_t key = lk[t0 + u];
+          if (key == DRX_KEY_NONE) continue;
+          float sv = 0.f, cv = 1.f;
+          float4 row[J];
+          pol.template load<G, J>(key, lv[t0 + u], lane, row, sv, cv);
+          if (key != cur) {
+            flush(false);
+            cur = key;
+            cur_from_start = (t0 + u == 0);
+#pragma unroll
+            for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+            accs = 0.f;
+          }
+#pragma unroll
+          for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], cv, row[jx]);
+          accs += sv;
+          cur_pos = start + t0 + u;
+        }
+      }
+    }
+  } else {
+    for (int t0 = 0; t0 < n; t0 += LB) {
+      uint32_t k8[LB];
+      float s8[LB], c8[LB];
+      float4 rows[LB][J];
+  #pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const int t = t0 + u;
+        k8[u] = t < n ? bcast(kreg, t) : DRX_KEY_NONE;
+        const uint32_t b = bcast(vreg, t < n ? t : 0);
+        s8[u] = 0.f;
+        c8[u] = 1.f;
+  #pragma unroll
+        for (int jx = 0; jx < J; ++jx) rows[u][jx] = f4_zero();
+        if (k8[u] != DRX_KEY_NONE) pol.template load<G, J>(k8[u], b, lane, rows[u], s8[u], c8[u]);
+      }
+  #pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const uint32_t key = k8[u];
+        if (key != DRX_KEY_NONE) {
+          if (key != cur) {
+            flush(false);
+            cur = key;
+            cur_from_start = (t0 + u == 0);
+  #pragma unroll
+            for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+            accs = 0.f;
+          }
+  #pragma unroll
+          for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c8[u], rows[u][jx]);
+          accs += s8[u];
+          cur_pos = start + t0 + u;
+        }
       }
     }
   }

@@ -840,7 +840,7 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
     ShardBiasExtra<G, J> bfx{p->ld, sh->world, BA, grad_send, X};                                                      \
     const int cpb = kSegBlock / G;                                                                                     \
     const dim3 rgrid(n_bpart + (B.n_chunks + cpb - 1) / cpb);                                                          \
-    const size_t lds_r = (size_t)cpb * (p->ld + 1) * 4;                                                                \
+    const size_t lds_r = seg_reduce_lds_bytes(cpb, p->ld, long_segments);                                              \
     const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
     if (long_segments)                                                                                                 \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, true, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \

@@ -18,7 +18,7 @@ from drecpy_amd.engine import CdaeEngine, SampledPipeline      # noqa: E402
 
 def main():
     dev = torch.device('cuda:0')
-    U, N, md, mn, a = synth.SHAPES['synth-10m']
+    U, N, md, mn, a = synth.SHAPES[os.environ.get('SHAPE', 'synth-10m')]          # SHAPE=ml-1m: the shared-form step (only the reduction's stamps apply)
     U = int(os.environ.get('USERS', U))
     B = 65536
     indptr, indices = synth.synth_history(U, N, md, mn, a, seed=0, device=dev)
@@ -56,8 +56,9 @@ def main():
         alive = [(int(((t[:, 0] <= x) & (t[:, -1] > x)).sum())) for x in grid]
         res['alive_units_mean'] = float(np.mean(alive)); res['alive_units_max'] = int(np.max(alive))
         out[name] = res
-    report('k_sampled_fwd_bwd_pf (per triple)', st[:B], [0, 1, 2, 3, 4, 5, 6, 7, 8],
-           ['uid/iid -> LDS-DMA issued', 'indptr', 'indices + mask', 'first rows', 'rest of the gather', 'b, b2, y + DMA landed', 'loss, dz1 stored', 'sole-toucher updates'])
+    if os.environ.get('SHAPE', 'synth-10m') == 'synth-10m':
+      report('k_sampled_fwd_bwd_pf (per triple)', st[:B], [0, 1, 2, 3, 4, 5, 6, 7, 8],
+             ['uid/iid -> LDS-DMA issued', 'indptr', 'indices + mask', 'first rows', 'rest of the gather', 'b, b2, y + DMA landed', 'loss, dz1 stored', 'sole-toucher updates'])
     seg = st[65536:]
     seg = seg[seg[:, 0] > 0]
     report('k_seg_reduce_planned (per chunk)', seg, [0, 1, 2, 3], ['keys', 'contribution rows + in-chunk segments', 'last flush'])
