@@ -28,7 +28,8 @@ class CdaeParams(C.Structure):
 
 
 class History(C.Structure):
-    _fields_ = [('indptr', C.c_void_p), ('indices', C.c_void_p), ('t_rank', C.c_void_p), ('t_nnz', C.c_int64)]
+    _fields_ = [('indptr', C.c_void_p), ('indices', C.c_void_p), ('t_rank', C.c_void_p), ('t_nnz', C.c_int64), ('t_users', C.c_void_p),
+                ('t_pos', C.c_void_p), ('t_items', C.c_void_p)]
 
 
 class Batch(C.Structure):

@@ -793,10 +793,10 @@ __device__ __forceinline__ unsigned long long group_ballot(bool f) {
 // summing every user's rows once and subtracting each triple's dropped rows (4.1 M rows): 222 us; the masked product on the vector
 // ALUs (a v_readlane + a packed FMA per row and triple: the kernel was bound by instruction issue): 200 us.
 template <int G, int J, int KIND = -1>
-__global__ __launch_bounds__(kBlock, (4 * G * J <= 128 ? 5 : 1)) void k_items_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
+__global__ __launch_bounds__(kItemThreads, (4 * G * J <= 128 ? 5 : 1)) void k_items_fwd_bwd(DrxCdaeParams P, DrxOptim opt, DrxHistory H, DrxBatch bt, float scale,
                                                           uint32_t qthr, int loss_kind, SparseBufs S) {
   extern __shared__ __align__(16) float lds[];   // [NWV * RT, ld] floats, then RT sample ids
-  constexpr int R = kBlock / G, NWV = kBlock / 64, RT = kShareTriples;
+  constexpr int R = kItemThreads / G, NWV = kItemThreads / 64, RT = kShareTriples;
   constexpr int NH = 4 * G * J / 64;                               // blocks of 64 columns of a row
   static_assert(NH >= 1 && NH <= 8 && RT == 16, "rows of 64 .. 512 floats; the 16 x 16 x 4 matrix instruction");
   constexpr int NF = NH <= 2 ? 16 : (NH == 4 ? 8 : 4);             // rows in flight per wave
@@ -1714,10 +1714,10 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
       const dim3 igrid((unsigned)(wmax < bt->B ? wmax : bt->B));                                                       \
       if constexpr (G >= 16 && J <= 2) {                        /* (share_users(): rows of 64 .. 512 floats) */        \
         if (opt->kind == DRX_OPT_ADAGRAD)                                                                              \
-          hipLaunchKernelGGL((k_items_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), igrid, dim3(kBlock), share_item_lds_bytes(p->ld), st, *p, *opt, \
+          hipLaunchKernelGGL((k_items_fwd_bwd<G, J, DRX_OPT_ADAGRAD>), igrid, dim3(kItemThreads), share_item_lds_bytes(p->ld), st, *p, *opt, \
                              *hist, *bt, scale, qthr, loss_kind, S);                                                   \
         else                                                                                                           \
-          hipLaunchKernelGGL((k_items_fwd_bwd<G, J>), igrid, dim3(kBlock), share_item_lds_bytes(p->ld), st, *p, *opt, *hist, *bt, \
+          hipLaunchKernelGGL((k_items_fwd_bwd<G, J>), igrid, dim3(kItemThreads), share_item_lds_bytes(p->ld), st, *p, *opt, *hist, *bt, \
                              scale, qthr, loss_kind, S);                                                               \
       }                                                                                                                \
     } else if (per_wg)                                                                                                 \

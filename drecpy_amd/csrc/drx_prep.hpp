@@ -365,9 +365,13 @@ static __global__ __launch_bounds__(256) void k_tp_runs(const uint32_t *__restri
 
 // triples of one work item (DRX_BATCH_SHARE_USERS; k_items_fwd_bwd keeps one bag per triple in registers); its LDS: the partial bags
 // of its waves + the item's sample ids.  Rows of 33 .. 512 floats only (narrower rows: the plain kernels).
+#ifndef DRX_ITEM_THREADS
+#define DRX_ITEM_THREADS 256
+#endif
 constexpr int kShareTriples = 16;
 static inline int share_item_triples(int) { return kShareTriples; }
-static inline size_t share_item_lds_bytes(int ld) { return ((size_t)(kBlock / 64) * kShareTriples * ld + kShareTriples) * 4; }
+constexpr int kItemThreads = DRX_ITEM_THREADS;          // threads of a forward workgroup of the shared form (k_items_fwd_bwd)
+static inline size_t share_item_lds_bytes(int ld) { return ((size_t)(kItemThreads / 64) * kShareTriples * ld + kShareTriples) * 4; }
 static inline bool share_geometry_ok(int ld) {
   const Geom g = pick_geom(ld);
   return g.G >= 16 && g.J <= 2 && share_item_lds_bytes(ld) <= 64 * 1024;
@@ -437,23 +441,22 @@ static __global__ __launch_bounds__(256) void k_tp_item_order(const uint32_t *__
   if (head) worder[lbase[b] + local] = pitem[p];
 }
 
-// WRITE = false: cnt[e] = touches of entry e;  WRITE = true: cnt holds the exclusive scan, the pairs are written.
+// The W part of the list in two passes over the history of the batch's users and a scan between them.
 // SHARE (DRX_BATCH_SHARE_USERS): per work item of the entry's user (rt samples of the user's run), ONE touch of the item's summed
 // gradient row (sample field B + the work item) and one touch per sample of the item that DROPPED the entry (sample field | 0x80000000:
 // the reduction subtracts those) — where that is the shorter form; otherwise, as without the flag, one touch per sample that kept it.
-// One WORKGROUP per user of the batch, its waves take the user's history 64 positions at a time, lane = position: every lane walks the
-// SAME samples (uniform trip counts; r04, first form: one thread per transpose entry — neighbouring lanes held users of 1 .. 79
-// samples, a wave took as long as its longest — and a 12-step search for the entry's item: 60 + 40 us for the two passes, alone).
-// The place of a position's touches: the item-major rank of its entry (DrxHistory::t_rank) through the scan.
-template <bool WRITE, bool SHARE>
-static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch bt, uint32_t qthr, int n_users, const int32_t *__restrict__ start,
-                                                          const int32_t *__restrict__ end, const uint32_t *__restrict__ vs,
-                                                          int *__restrict__ cnt, uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s,
-                                                          const int32_t *__restrict__ pitem, int rt) {
+//
+// COUNT, user-major: one WORKGROUP per user of the batch, its waves take the user's history 64 positions at a time, lane = position:
+// every lane walks the SAME samples (uniform trip counts; r04, first form: one thread per transpose entry — neighbouring lanes held
+// users of 1 .. 79 samples, a wave took as long as its longest).  Beside the count it leaves the keep bits of the user's first 64
+// samples at this position (km): the write pass evaluates no mask for them.  Both land at the entry's item-major rank (t_rank).
+template <bool SHARE>
+static __global__ __launch_bounds__(256) void k_tp_count(DrxHistory H, DrxBatch bt, uint32_t qthr, int n_users, const int32_t *__restrict__ start,
+                                                         const int32_t *__restrict__ end, const uint32_t *__restrict__ vs,
+                                                         int *__restrict__ cnt, unsigned long long *__restrict__ km, int rt) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   for (int u = blockIdx.x; u < n_users; u += gridDim.x) {
     const int s0 = start[u], c = end[u] - s0;
-    if (WRITE && c <= 0) continue;
     const int64_t hs = H.indptr[u];
     const int deg = (int)(H.indptr[u + 1] - hs);
     if (c <= 0) {                                          // a user without a sample in this batch: its entries hold no touch
@@ -462,38 +465,64 @@ static __global__ __launch_bounds__(256) void k_tp_expand(DrxHistory H, DrxBatch
     }
     for (int j = wv * 64 + lane; j < deg; j += nwv * 64) {
       const int e = H.t_rank[hs + j];
-      const uint32_t n = (uint32_t)H.indices[hs + j];
-      int at = WRITE ? cnt[e] : 0, kept = 0;
-      auto keeps = [&](uint32_t b) -> bool {
-        return bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr);
-      };
-      if (SHARE) {                                       // pieces of rt <= 32 samples: the keep bits of a piece, evaluated once
-        for (int q0 = 0; q0 < c; q0 += rt) {
-          const int nq = min(c - q0, rt);
-          uint32_t km = 0;
-          for (int q = 0; q < nq; ++q) km |= (keeps(vs[s0 + q0 + q]) ? 1u : 0u) << q;
-          const int k = __popc(km);
-          const bool shared = nq > 1 && 1 + (nq - k) < k;           // the shorter form of the two: never more touches than the plain list
-          if (!WRITE) { kept += shared ? 1 + (nq - k) : k; continue; }
-          if (shared) { keys_s[at] = n; vals_s[at] = (uint32_t)bt.B + (uint32_t)pitem[s0 + q0]; ++at; }
-          uint32_t em = shared ? (~km & (nq >= 32 ? 0xFFFFFFFFu : ((1u << nq) - 1u))) : km;      // the samples that emit a touch
-          while (em) {
-            const int q = __ffs((int)em) - 1;
-            em &= em - 1u;
-            const uint32_t b = vs[s0 + q0 + q];
-            keys_s[at] = n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at;      // top bit: subtracted
-          }
+      unsigned long long bits = 0ull;
+      int kept = 0;
+      for (int q0 = 0; q0 < c; q0 += rt) {                 // pieces of rt <= 32 samples (SHARE: the work items; else any cut will do)
+        const int nq = min(c - q0, rt);
+        uint32_t m = 0;
+        for (int q = 0; q < nq; ++q) {
+          const uint32_t b = vs[s0 + q0 + q];
+          m |= ((bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr)) ? 1u : 0u) << q;
         }
-      } else {
-        for (int q = 0; q < c; ++q) {
-          const uint32_t b = vs[s0 + q];
-          if (keeps(b)) {
-            if (WRITE) { keys_s[at] = n; vals_s[at] = b; ++at; }
-            ++kept;
-          }
+        if (q0 < 64) bits |= (unsigned long long)m << q0;
+        const int k = __popc(m);
+        kept += (SHARE && nq > 1 && 1 + (nq - k) < k) ? 1 + (nq - k) : k;      // the shorter form of the two
+      }
+      cnt[e] = kept;
+      km[e] = bits;
+    }
+  }
+}
+
+// WRITE, item-major: one thread per entry of the item-major order (its user, position and item: DrxHistory::t_users / t_pos / t_items),
+// cnt holds the exclusive scan: neighbouring threads write neighbouring runs of the list.  (r04, second form: the user-major walk
+// wrote too — a lane's touches go to ITS item's segment, 5.8 M scattered 4-byte stores: 79 us alone against 20 for the count pass.)
+template <bool SHARE>
+static __global__ __launch_bounds__(256) void k_tp_write(DrxHistory H, DrxBatch bt, uint32_t qthr, const int32_t *__restrict__ start,
+                                                         const int32_t *__restrict__ end, const uint32_t *__restrict__ vs,
+                                                         const int *__restrict__ cnt, const unsigned long long *__restrict__ km,
+                                                         uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s,
+                                                         const int32_t *__restrict__ pitem, int rt) {
+  const int64_t nnz = H.t_nnz;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    const int u = H.t_users[e];
+    const int s0 = start[u], c = end[u] - s0;
+    if (c <= 0) continue;
+    const uint32_t n = (uint32_t)H.t_items[e];
+    const unsigned long long bits = km[e];
+    int at = cnt[e];
+    for (int q0 = 0; q0 < c; q0 += rt) {
+      const int nq = min(c - q0, rt);
+      uint32_t m;
+      if (q0 + nq <= 64) m = (uint32_t)(bits >> q0) & (nq >= 32 ? 0xFFFFFFFFu : ((1u << nq) - 1u));
+      else {                                               // (a user with more than 64 samples in the batch: the rest is evaluated here)
+        const int j = H.t_pos[e];
+        m = 0;
+        for (int q = 0; q < nq; ++q) {
+          const uint32_t b = vs[s0 + q0 + q];
+          m |= ((bt.keep ? (bt.keep[bt.keep_off[b] + j] != 0) : (hash_u32(bt.mask_seed, b, (uint32_t)j) >= qthr)) ? 1u : 0u) << q;
         }
       }
-      if (!WRITE) cnt[e] = kept;
+      const int k = __popc(m);
+      const bool shared = SHARE && nq > 1 && 1 + (nq - k) < k;
+      if (shared) { keys_s[at] = n; vals_s[at] = (uint32_t)bt.B + (uint32_t)pitem[s0 + q0]; ++at; }
+      uint32_t em = shared ? (~m & (nq >= 32 ? 0xFFFFFFFFu : ((1u << nq) - 1u))) : m;      // the samples that emit a touch
+      while (em) {
+        const int q = __ffs((int)em) - 1;
+        em &= em - 1u;
+        const uint32_t b = vs[s0 + q0 + q];
+        keys_s[at] = n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at;      // top bit: subtracted
+      }
     }
   }
 }
@@ -517,7 +546,7 @@ static void order_by_degree(const DrxBatch *bt, const PrepBufs &R, hipStream_t s
 
 // does the transposed preparation apply to this batch (and fit its work areas)?  The step asks the same question (share_users below).
 static bool transposed_applies(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R) {
-  if (!hist->t_rank || !long_segments(R.T, *p)) return false;
+  if (!hist->t_rank || !hist->t_users || !hist->t_pos || !hist->t_items || !long_segments(R.T, *p)) return false;
   const int B = bt->B, U = p->n_users, N = p->n_items;
   const int64_t nnz = hist->t_nnz;
   if (nnz < 1 || nnz > (int64_t)R.T || nnz >= (1ll << 30) || (int64_t)U + N >= 0x7FFFFFFFll) return false;
@@ -527,6 +556,7 @@ static bool transposed_applies(const DrxCdaeParams *p, const DrxHistory *hist, c
   (void)cw.take<char>(sort_pairs_temp_bytes((size_t)2 * B, bits_for((uint64_t)U + (uint64_t)N + 1)));
   (void)cw.take<char>(scan_i32_temp_bytes((size_t)nnz));
   (void)cw.take<char>(scan_i32_temp_bytes((size_t)B));
+  (void)cw.take<unsigned long long>((size_t)nnz);
   return cw.ok();
 }
 // DRX_BATCH_SHARE_USERS takes effect: the list is in the shared form, the step forms S_u / D_u
@@ -558,6 +588,7 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   void *sctemp = cw.take<char>(scb);
   const size_t scb2 = scan_i32_temp_bytes((size_t)B);
   void *sctemp2 = cw.take<char>(scb2);
+  unsigned long long *km = cw.take<unsigned long long>((size_t)nnz);
   if (!cw.ok()) return kTpFallback;
   const uint32_t qthr = q_threshold(bt->q);
   hipLaunchKernelGGL(k_tp_begin, dim3(512), dim3(256), 0, st, *bt, U, k2, v2, start, 2 * (U + N), R.solo_v, R.plan.cnt, plan_zero_words(R),
@@ -565,7 +596,8 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   int rc = sort_pairs(stemp, sb, k2, ks, v2, vs, (size_t)2 * B, bits2, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tp_runs, dim3((2 * B + 255) / 256 < 1024 ? (2 * B + 255) / 256 : 1024), dim3(256), 0, st, ks, 2 * B, start, end);
-  const int egrid = U < (1 << 20) ? U : (1 << 20);      // one workgroup per user
+  const int egrid = U < (1 << 20) ? U : (1 << 20);      // count pass: one workgroup per user
+  const int wgrid = (int)((nnz + 255) / 256 < 16384 ? (nnz + 255) / 256 : 16384);      // write pass: one thread per entry
   const int rt = share_item_triples(p->ld);
   if (share) {
     const int ig = (B + 255) / 256;
@@ -575,18 +607,18 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
     hipLaunchKernelGGL(k_tp_item_finish, dim3(ig), dim3(256), 0, st, ks, vs, B, rt, start, end, hist->indptr, R.usamp, R.pitem, R.witem,
                        R.n_du, R.plan.cnt);
     hipLaunchKernelGGL(k_tp_item_order, dim3(ig), dim3(256), 0, st, ks, B, rt, start, hist->indptr, R.pitem, R.worder, R.n_du);
-    hipLaunchKernelGGL((k_tp_expand<false, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_count<true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, km, rt);
   } else
-    hipLaunchKernelGGL((k_tp_expand<false, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_count<false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, km, rt);
   // (the counts of the LAST entry are needed after the scan overwrote them: a copy)
   int *cnt_last = (int *)R.vals;
   DRX_HIP(hipMemcpyAsync(cnt_last, cnt + (nnz - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
   rc = scan_i32(sctemp, scb, cnt, cnt, (size_t)nnz, false, st);
   if (rc) return rc;
   if (share)
-    hipLaunchKernelGGL((k_tp_expand<true, true>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_write<true>), dim3(wgrid), dim3(256), 0, st, *hist, *bt, qthr, start, end, vs, cnt, km, R.keys_s, R.vals_s, R.pitem, rt);
   else
-    hipLaunchKernelGGL((k_tp_expand<true, false>), dim3(egrid), dim3(256), 0, st, *hist, *bt, qthr, U, start, end, vs, cnt, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_write<false>), dim3(wgrid), dim3(256), 0, st, *hist, *bt, qthr, start, end, vs, cnt, km, R.keys_s, R.vals_s, R.pitem, rt);
   hipLaunchKernelGGL(k_tp_tail, dim3(2048), dim3(256), 0, st, ks, vs, B, U, N, cnt + (nnz - 1), cnt_last, R.T, R.keys_s, R.vals_s, R.plan.cnt);
   return DRX_OK;
 }
@@ -594,7 +626,7 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
                         bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, 1, 0}) {
   const int gpb = kBlock / 16;
-  if (hist->t_rank && !pres.present && long_segments(R.T, *p)) {
+  if (hist->t_rank && hist->t_users && hist->t_pos && hist->t_items && !pres.present && long_segments(R.T, *p)) {
     const int rc = prepare_transposed(p, hist, bt, R, st, with_marks);
     if (rc == DRX_OK) {                                        // the list stands, sorted: what is left is what follows the sort below
       if (with_marks && p->ld > 16) {

@@ -151,11 +151,13 @@ class CdaeEngine:
             # pairs per step (include/drx.h DrxHistory::t_rank).  Once per dataset, with torch ops on the device (set-up, not the hot path).
             ip, idx = self.hist_indptr, self.hist_indices[:nnz].long()
             rows = torch.repeat_interleave(torch.arange(self.n_users, device=self.device), (ip[1:] - ip[:-1]))
+            pos = torch.arange(nnz, device=self.device) - ip[rows]
             order = torch.argsort(idx * self.n_users + rows)
             rank = torch.empty(nnz, dtype=torch.int32, device=self.device)
             rank[order] = torch.arange(nnz, dtype=torch.int32, device=self.device)
-            self._hist_t = (rank,)
-            self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices), ptr(rank), nnz)
+            self._hist_t = (rank, rows[order].to(torch.int32).contiguous(), pos[order].to(torch.int32).contiguous(),
+                            idx[order].to(torch.int32).contiguous())
+            self._hist = History(ptr(self.hist_indptr), ptr(self.hist_indices), ptr(rank), nnz, *[ptr(t) for t in self._hist_t[1:]])
 
     # ---- optimizer --------------------------------------------------------------------------
     def init_optimizer(self, kind, lr, reg_rate, beta1=ADAM_B1, beta2=ADAM_B2, eps=None, initial_accumulator=ADAGRAD_INIT):

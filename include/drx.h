@@ -67,10 +67,15 @@ typedef struct DrxHistory {
   /* Optional ITEM-MAJOR RANK of every entry (NULL / 0: none): t_rank[p] = the place of entry p = indptr[u] + j (item indices[p] in the
    * row of user u) when all entries are ordered by (item, user) — the permutation that transposes the matrix, inverted.  With it the
    * preparation of a sampled batch whose rows collect long runs of touches (MovieLens shapes: more than 8 touches per table row) lays
-   * the batch's touches down item by item through this static order (a count per entry, a scan, a write) instead of sorting millions
+   * the batch's touches down item by item through this static order (a count per entry, a scan, a write entry by entry) instead of sorting millions
    * of (row, sample) pairs per step (csrc/drx_prep.hpp). */
   const int32_t *t_rank;   /* [t_nnz] */
   int64_t t_nnz;           /* = indptr[n_users] < 2^30 */
+  /* ... and the entries IN that order (the transpose itself): entry e = item t_items[e] in the row of user t_users[e], at position
+   * t_pos[e] of that row — t_rank[indptr[t_users[e]] + t_pos[e]] == e.  All four or none. */
+  const int32_t *t_users;  /* [t_nnz] */
+  const int32_t *t_pos;    /* [t_nnz] */
+  const int32_t *t_items;  /* [t_nnz] */
 } DrxHistory;
 
 /* One mini-batch (one fit() "epoch", recommender_abc.py:189-205).
