@@ -492,13 +492,19 @@ static __global__ __launch_bounds__(256) void k_tp_write(DrxHistory H, DrxBatch 
                                                          const int32_t *__restrict__ end, const uint32_t *__restrict__ vs,
                                                          const int *__restrict__ cnt, const unsigned long long *__restrict__ km,
                                                          uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s,
-                                                         const int32_t *__restrict__ pitem, int rt) {
+                                                         const int32_t *__restrict__ pitem, int rt, int32_t *__restrict__ row_end) {
   const int64_t nnz = H.t_nnz;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
     const int u = H.t_users[e];
     const int s0 = start[u], c = end[u] - s0;
-    if (c <= 0) continue;
     const uint32_t n = (uint32_t)H.t_items[e];
+    // where this item's segment ends (SpanPlan::row_end): the offset of the next item's first entry
+    const bool last_of_item = e + 1 == nnz || (uint32_t)H.t_items[e + 1] != n;
+    if (last_of_item && e + 1 < nnz) row_end[n] = cnt[e + 1];
+    if (c <= 0) {
+      if (last_of_item && e + 1 == nnz) row_end[n] = cnt[e];
+      continue;
+    }
     const unsigned long long bits = km[e];
     int at = cnt[e];
     for (int q0 = 0; q0 < c; q0 += rt) {
@@ -524,6 +530,7 @@ static __global__ __launch_bounds__(256) void k_tp_write(DrxHistory H, DrxBatch 
         keys_s[at] = n; vals_s[at] = shared ? (b | 0x80000000u) : b; ++at;      // top bit: subtracted
       }
     }
+    if (last_of_item && e + 1 == nnz) row_end[n] = at;
   }
 }
 
@@ -533,7 +540,9 @@ static __global__ __launch_bounds__(256) void k_tp_tail(const uint32_t *__restri
                                                         uint32_t *__restrict__ keys_s, uint32_t *__restrict__ vals_s, uint32_t *plan_cnt) {
   const int Tw = off_last[0] + cnt_last[0];          // (exclusive scan: the last entry's offset + its count)
   if (blockIdx.x == 0 && threadIdx.x == 0) plan_cnt[20] = (uint32_t)(Tw + 2 * B);      // the list's real length (SpanPlan::cnt[20])
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < T - Tw; p += gridDim.x * blockDim.x) {
+  // (the list says how long it is: behind its 2B pairs only the chunks a reader of its last block may look into are blanked)
+  const int n_tail = min(T - Tw, 2 * B + 8 * kChunkLong);
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_tail; p += gridDim.x * blockDim.x) {
     uint32_t k = DRX_KEY_NONE, v = 0;
     if (p < B) { k = (uint32_t)n_items + (ks[B + p] - (uint32_t)n_users); v = vs[B + p] - (uint32_t)B; }        // items: sorted positions B .. 2B-1
     else if (p < 2 * B) { k = 2u * (uint32_t)n_items + ks[p - B]; v = vs[p - B]; }                              // users: positions 0 .. B-1
@@ -557,6 +566,7 @@ static bool transposed_applies(const DrxCdaeParams *p, const DrxHistory *hist, c
   (void)cw.take<char>(scan_i32_temp_bytes((size_t)nnz));
   (void)cw.take<char>(scan_i32_temp_bytes((size_t)B));
   (void)cw.take<unsigned long long>((size_t)nnz);
+  (void)cw.take<int32_t>((size_t)N);
   return cw.ok();
 }
 // DRX_BATCH_SHARE_USERS takes effect: the list is in the shared form, the step forms S_u / D_u
@@ -568,7 +578,7 @@ static bool share_users(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
 // allow_share: the list is prepared AHEAD of its step (drx_cdae_sparse_prepare) — a step that builds its list inline runs the plain
 // forward kernel and must get the plain list
 static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
-                              bool allow_share) {
+                              bool allow_share, const int32_t **row_end_out) {
   const int B = bt->B, U = p->n_users, N = p->n_items;
   if (!transposed_applies(p, hist, bt, R)) return kTpFallback;
   const bool share = allow_share && share_users(p, hist, bt, R);
@@ -589,7 +599,9 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   const size_t scb2 = scan_i32_temp_bytes((size_t)B);
   void *sctemp2 = cw.take<char>(scb2);
   unsigned long long *km = cw.take<unsigned long long>((size_t)nnz);
+  int32_t *row_end = cw.take<int32_t>((size_t)N);
   if (!cw.ok()) return kTpFallback;
+  *row_end_out = row_end;
   const uint32_t qthr = q_threshold(bt->q);
   hipLaunchKernelGGL(k_tp_begin, dim3(512), dim3(256), 0, st, *bt, U, k2, v2, start, 2 * (U + N), R.solo_v, R.plan.cnt, plan_zero_words(R),
                      R.order_work, 512);
@@ -616,9 +628,9 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
   rc = scan_i32(sctemp, scb, cnt, cnt, (size_t)nnz, false, st);
   if (rc) return rc;
   if (share)
-    hipLaunchKernelGGL((k_tp_write<true>), dim3(wgrid), dim3(256), 0, st, *hist, *bt, qthr, start, end, vs, cnt, km, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_write<true>), dim3(wgrid), dim3(256), 0, st, *hist, *bt, qthr, start, end, vs, cnt, km, R.keys_s, R.vals_s, R.pitem, rt, row_end);
   else
-    hipLaunchKernelGGL((k_tp_write<false>), dim3(wgrid), dim3(256), 0, st, *hist, *bt, qthr, start, end, vs, cnt, km, R.keys_s, R.vals_s, R.pitem, rt);
+    hipLaunchKernelGGL((k_tp_write<false>), dim3(wgrid), dim3(256), 0, st, *hist, *bt, qthr, start, end, vs, cnt, km, R.keys_s, R.vals_s, R.pitem, rt, row_end);
   hipLaunchKernelGGL(k_tp_tail, dim3(2048), dim3(256), 0, st, ks, vs, B, U, N, cnt + (nnz - 1), cnt_last, R.T, R.keys_s, R.vals_s, R.plan.cnt);
   return DRX_OK;
 }
@@ -627,18 +639,22 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
                         bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, 1, 0}) {
   const int gpb = kBlock / 16;
   if (hist->t_rank && hist->t_users && hist->t_pos && hist->t_items && !pres.present && long_segments(R.T, *p)) {
-    const int rc = prepare_transposed(p, hist, bt, R, st, with_marks);
+    const int32_t *row_end = nullptr;
+    const int rc = prepare_transposed(p, hist, bt, R, st, with_marks, &row_end);
     if (rc == DRX_OK) {                                        // the list stands, sorted: what is left is what follows the sort below
+      PrepBufs Rb = R;
+      Rb.plan.row_end = row_end;                               // (where every input row's segment ends: plan_chunk)
+      Rb.plan.row_end_keys = (uint32_t)p->n_items;
       if (with_marks && p->ld > 16) {
         order_by_degree(bt, R, st, true);
         const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
         hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
-                           kSegBlock / pick_geom(p->ld).G, R.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, 0, bt->keep_off,
+                           kSegBlock / pick_geom(p->ld).G, Rb.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, 0, bt->keep_off,
                            R.order_work, R.order);
-        if (R.plan.xrank) hipLaunchKernelGGL(k_place_blocks, dim3(256), dim3(256), 0, st, R.plan, R.n_chunks);
+        if (R.plan.xrank) hipLaunchKernelGGL(k_place_blocks, dim3(256), dim3(256), 0, st, Rb.plan, R.n_chunks);
         return DRX_OK;
       }
-      return plan_spans(p, bt, R, st, true);
+      return plan_spans(p, bt, Rb, st, true);
     }
     if (rc != kTpFallback) return rc;
   }

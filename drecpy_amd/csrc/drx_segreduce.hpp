@@ -192,6 +192,10 @@ struct SpanPlan {
   uint32_t *xperm;      // [xstride] slot -> block                  (k_place_blocks)
   int xstride;          // entries (the number of blocks of the smallest block size: a layout independent of the row width)
   int chunk;            // touches per chunk of THIS list: seg_chunk(long segments?)
+  // lists laid down by the transposed preparation know where the segment of every INPUT row ends (plan_chunk then looks the end of a
+  // crossing segment up instead of searching for it: 22 dependent probes were the planning kernel's longest chain); nullptr: search
+  const int32_t *row_end;     // [row_end_keys] list position behind the last touch of key k
+  uint32_t row_end_keys;
 };
 #ifndef DRX_XBINS
 #define DRX_XBINS 8      // (64 — bins of 0.5 MB of gradient rows, taken in order — measured SLOWER at the ml-1m shape: 0.60 against 0.54 ms)
@@ -303,13 +307,17 @@ struct SpanShape {
 
 __device__ __forceinline__ void plan_chunk(const uint32_t *__restrict__ keys_s, int T, int n_chunks, int cpb, const SpanPlan &P, int g) {
   const int CH = P.chunk;
+  // (a compact list — SpanPlan::cnt[20], lists with placed blocks only — holds nothing behind its real length but a few chunks of padding)
+  if (P.xrank && P.cnt[20] != 0u) T = min(T, (int)P.cnt[20]);
   const int start = g * CH, end = min(T, start + CH);
+  if (start >= T) return;
   const uint32_t first = keys_s[start], last = keys_s[end - 1];
   const uint32_t prev = start > 0 ? keys_s[start - 1] : DRX_KEY_NONE, next = end < T ? keys_s[end] : DRX_KEY_NONE;
   const bool head_cont = first != DRX_KEY_NONE && prev == first;        // the run at the chunk's start began before it
   const bool tail_cont = last != DRX_KEY_NONE && next == last;          // the run at its end goes on behind it
   if (!tail_cont || (head_cont && first == last)) return;              // nothing STARTS to cross here
   int lo = end, hi = T;              // first position in [end, T) with another key
+  if (P.row_end && last < P.row_end_keys) lo = hi = P.row_end[last];
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (keys_s[mid] == last) lo = mid + 1; else hi = mid;
