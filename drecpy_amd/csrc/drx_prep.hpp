@@ -646,7 +646,8 @@ static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const Dr
       Rb.plan.row_end = row_end;                               // (where every input row's segment ends: plan_chunk)
       Rb.plan.row_end_keys = (uint32_t)p->n_items;
       if (with_marks && p->ld > 16) {
-        order_by_degree(bt, R, st, true);
+        // (the launch order by history length is the plain forward kernel's: the shared form has its own, by work item)
+        if (!share_users(p, hist, bt, R)) order_by_degree(bt, R, st, true);
         const int blocks = std::max(2048, (R.n_chunks + 255) / 256);
         hipLaunchKernelGGL(k_plan_and_mark, dim3(blocks), dim3(256), 0, st, R.keys_s, R.vals_s, R.T, R.n_chunks,
                            kSegBlock / pick_geom(p->ld).G, Rb.plan, (uint32_t)p->n_items, bt->B, R.solo_v, R.solo_o, 0, bt->keep_off,

@@ -222,18 +222,20 @@ __device__ __forceinline__ void place_block(const uint32_t *__restrict__ keys_s,
       x = (int)min((uint32_t)(kXBins - 1), (uint32_t)(((unsigned long long)b * (unsigned long long)kXBins) / (unsigned long long)(B > 0 ? B : 1)));
     }
   }
+  // the wave's blocks bin by bin: ONE atomic per bin present, all of them in flight together (lane r takes the ranks of bin r) — one
+  // round trip instead of one per bin, one after the other
   const int lane = threadIdx.x & 63;
-  unsigned long long todo = __ballot(on);
-  while (todo) {                                                  // one round per bin present in the wave
-    const int first = __ffsll((long long)todo) - 1;
-    const int r = __shfl(x, first);
+  unsigned long long mine = 0ull, of_lane = 0ull;
+#pragma unroll
+  for (int r = 0; r < kXBins; ++r) {
     const unsigned long long m = __ballot(on && x == r);
-    uint32_t base = 0;
-    if (lane == first) base = atomicAdd(&P.cnt[kXBase + r], (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, first);
-    if (on && x == r) P.xrank[blk] = ((uint32_t)r << 24) | (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-    todo &= ~m;
+    if (x == r) mine = m;
+    if (lane == r) of_lane = m;
   }
+  uint32_t base = 0;
+  if (lane < kXBins && of_lane) base = atomicAdd(&P.cnt[kXBase + lane], (uint32_t)__popcll(of_lane));
+  base = (uint32_t)__shfl((int)base, x);
+  if (on) P.xrank[blk] = ((uint32_t)x << 24) | (base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull)));
   if (on && blk == 0) { P.cnt[16] = 1u; P.cnt[17] = (uint32_t)cpb; }
 }
 
