@@ -284,7 +284,8 @@ def test_sparse_step_is_deterministic():
 
 
 @pytest.mark.parametrize('explicit', [False, True])
-@pytest.mark.parametrize('K,opt,U', [(128, 'adagrad', 150), (50, 'adam', 150), (16, 'adagrad', 150), (128, 'adagrad', 24), (200, 'adam', 24)])
+@pytest.mark.parametrize('K,opt,U', [(128, 'adagrad', 150), (50, 'adam', 150), (16, 'adagrad', 150), (128, 'adagrad', 24), (200, 'adam', 24),
+                                     (128, 'adagrad', 8)])
 def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_sorted_lists(K, opt, U, explicit):
     """Lists of long segments (more than 8 touches per table row: MovieLens shapes) are prepared by expanding the history's transpose
     (DrxHistory::t_rank: only the batch's 2B (id, sample) pairs are sorted) instead of sorting every (row, sample) pair: same oracle;
@@ -292,7 +293,8 @@ def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_
     sample: another fixed order of the same sum), and two runs of the transposed path agree bit for bit.  'shared'
     (DRX_BATCH_SHARE_USERS): the ~7 triples of a user share their gather (full sum minus the dropped rows) and their gradient (the user's
     summed row minus the droppers'): same oracle, same tolerance.  U = 24: ~43 triples per user, three work items of up to 16 triples
-    each (csrc/drx_prep.hpp k_tp_item_*); K = 16: rows too narrow for the shared form (share_geometry_ok) — the plain transposed list."""
+    each (csrc/drx_prep.hpp k_tp_item_*); U = 8: ~128 triples per user — more than the 64 whose keep bits the count pass hands the
+    write pass (k_tp_write evaluates the rest itself); K = 16: rows too narrow for the shared form (share_geometry_ok) — the plain transposed list."""
     N, B = 70, 1024
     results = []
     for mode in ('transpose', 'transpose', 'sort', 'shared', 'shared'):
