@@ -310,8 +310,10 @@ class RecommenderABC(ABC):
         try:
             predictions, desired_values = self._predict_batch(batch_samples, **kwds)
             loss = self._compute_batch_loss(predictions, desired_values, **kwds)
+            # (recommender_abc.py:200: the reference's five positional arguments and no keyword ones — a subclass written against it
+            # may define _compute_reg_loss without **kwds)
             loss = loss + self._compute_reg_loss(self.reg_rate, len(batch_samples), self.trainable_models, self.trainable_layers,
-                                                 self.trainable_weights, **kwds)
+                                                 self.trainable_weights)
             if not (torch.is_tensor(loss) and loss.requires_grad):
                 raise NotImplementedError(
                     f'{type(self).__name__} defines no _do_batch and the loss its hooks return ({type(loss).__name__}) cannot be differentiated '

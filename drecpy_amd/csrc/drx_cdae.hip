@@ -1667,6 +1667,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
   constexpr int wg_long = 64;
   // DRX_BATCH_SHARE_USERS (lists prepared ahead through the history's transpose only): one forward workgroup per work item
   // (k_items_fwd_bwd); the reduction reads the items' summed gradient rows
+  // (a list in the shared form has no gradient row per triple: the column-sharded step's forward kernels cannot read it)
+  if (prepared && ks_h && share_users(p, hist, bt, R)) return DRX_EINVAL;
   const bool share = prepared && !ks_h && share_users(p, hist, bt, R);
   S.usamp = share ? R.usamp : nullptr;
   S.witem = share ? R.witem : nullptr;

@@ -541,7 +541,9 @@ static __global__ __launch_bounds__(256) void k_tp_tail(const uint32_t *__restri
   const int Tw = off_last[0] + cnt_last[0];          // (exclusive scan: the last entry's offset + its count)
   if (blockIdx.x == 0 && threadIdx.x == 0) plan_cnt[20] = (uint32_t)(Tw + 2 * B);      // the list's real length (SpanPlan::cnt[20])
   // (the list says how long it is: behind its 2B pairs only the chunks a reader of its last block may look into are blanked)
-  const int n_tail = min(T - Tw, 2 * B + 8 * kChunkLong);
+  // (the reduction reads no slot behind cnt[20] — k_seg_reduce_planned's Tn; the planning kernels look one key past it — the tail is
+  // sized for the widest workgroup all the same: kSegBlock / 4 chunks at 4 lanes per row)
+  const int n_tail = min(T - Tw, 2 * B + (kSegBlock / 4 + 1) * kChunkLong);
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_tail; p += gridDim.x * blockDim.x) {
     uint32_t k = DRX_KEY_NONE, v = 0;
     if (p < B) { k = (uint32_t)n_items + (ks[B + p] - (uint32_t)n_users); v = vs[B + p] - (uint32_t)B; }        // items: sorted positions B .. 2B-1

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(kBlock) void k_point_sample(DrxHistory H, DrxHistor
   }
   uid[b] = u;
   iid[b] = i;
-  y[b] = null_pair ? 0.0f : val;
+  // (a negative carries the interaction value 0, standardised like every other target when use_nce is on: dmf.py:68 with
+  // recommender_abc.py:463-465 — (0 - min) / (max - min), non-zero whenever min_interaction is)
+  y[b] = null_pair ? ((values && vrange > 0.f) ? (0.0f - vmin) / vrange : 0.0f) : val;
   my_deg = (int32_t)(H.indptr[u + 1] - H.indptr[u]);
   if (deg) deg[b] = my_deg;
   }

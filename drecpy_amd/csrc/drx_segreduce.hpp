@@ -372,8 +372,11 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
   if (blk < 0 || (LONG && SP.cnt[20] != 0u && (long long)blk * CPB * CH >= (long long)SP.cnt[20] + CH)) return;
   const int lane = threadIdx.x % G, r = threadIdx.x / G;
   const int g = blk * CPB + r;
+  // (the slots behind a compact list's real length are NOT the list: only a few chunks of them are blanked, the rest is whatever the
+  // buffer held before — every chunk reads the list up to its real end and no further)
+  const int Tn = (LONG && SP.cnt[20] != 0u) ? min(S.T, (int)SP.cnt[20]) : S.T;
   bool inner = false;          // this chunk is one whole run of a segment that began before it
-  if (g < S.n_chunks && (g + 1) * CH <= S.T) {
+  if (g < S.n_chunks && (g + 1) * CH <= Tn) {
     const uint32_t f = S.keys_s[g * CH], l = S.keys_s[(g + 1) * CH - 1], pk = g > 0 ? S.keys_s[g * CH - 1] : DRX_KEY_NONE;
     inner = f != DRX_KEY_NONE && f == pk && l == f;
   }
@@ -382,10 +385,10 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
   DRX_STAMP(S.stamps, 65536 + g, 0, lane);
   // this chunk's window: behind the touches its left neighbour finishes for it, and into the right neighbour's for the segment it
   // finishes itself (SpanPlan::ext); up to 2 * CH - 1 touches
-  const int start = min(S.T, g * CH + (g > 0 ? (int)ext[g - 1] : 0)), end = min(S.T, (g + 1) * CH + (int)ext[g]);
+  const int start = min(Tn, g * CH + (g > 0 ? (int)ext[g - 1] : 0)), end = min(Tn, (g + 1) * CH + (int)ext[g]);
   const int n = max(0, end - start);
   const uint32_t prev_key = start > 0 ? S.keys_s[start - 1] : DRX_KEY_NONE;
-  const uint32_t next_key = end < S.T ? S.keys_s[end] : DRX_KEY_NONE;
+  const uint32_t next_key = end < Tn ? S.keys_s[end] : DRX_KEY_NONE;
   constexpr int KPL = (2 * CH + G - 1) / G;
   constexpr int LB = J == 1 ? LB1 : (J == 2 ? 4 : 2);
   uint32_t kreg[KPL], vreg[KPL];

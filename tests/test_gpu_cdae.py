@@ -337,6 +337,39 @@ def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_
         np.testing.assert_allclose(results[3][k], results[2][k], rtol=0, atol=5e-6, err_msg=k)
 
 
+@pytest.mark.parametrize('K', [16, 32, 128])
+@pytest.mark.parametrize('fill', [0, 0x11])
+def test_compact_lists_never_read_the_slots_behind_their_real_length(K, fill):
+    """A list laid down by the transposed preparation is COMPACT: its real touches, a few blanked chunks, then whatever the buffer held
+    before (SpanPlan::cnt[20] says where the list ends).  With rows of 16 / 32 floats a reduction workgroup covers 32 / 16 chunks:
+    more than the blanked tail.  The buffer is handed over full of bytes that read as VALID keys and samples (key 0 / sample 0, or
+    0x11111111 — an out-of-range key and sample): the step must give the result of a clean buffer, bit for bit."""
+    import torch
+    U, N, B = 150, 70, 1024
+    results = []
+    for poison in (None, fill, fill):
+        eng, p, rng = _engine(U, N, K, seed=33)
+        indptr, indices = synth_history(rng, U, N, 14, zipf=1.0)
+        eng.set_history(indptr, indices, with_transpose=True)
+        eng.init_optimizer('adagrad', 0.05, 1e-3)
+        buf = None
+        for step in range(3):
+            uids = rng.integers(0, U, size=B); iids = rng.integers(0, N, size=B)
+            y = (rng.random(B) < 0.3).astype(np.float32)
+            bt, alive = eng.make_batch(uids, iids, y, q=0.2, mask_seed=900 + step)
+            buf = eng.prep_buffer(bt, buf)
+            if poison is None:
+                buf.fill_(0xFF)                      # DRX_KEY_NONE everywhere: what the blanked tail looks like
+            else:
+                buf.fill_(poison)
+            eng.step_sparse(step, bt, 'bce', prepared=eng.prepare_sparse(bt, buf))
+        torch.cuda.synchronize()
+        results.append(eng.get_params())
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k]), (K, fill, k)
+        assert np.array_equal(results[0][k], results[2][k]), (K, fill, k)
+
+
 def test_device_sampler_in_user_order_draws_the_same_triples():
     """drx_point_sample_by_user: the draws of drx_point_sample_recorded for the same seed, sorted by user (a user's triples in draw
     order), keep_off the prefix sums of the sorted users' degrees, the total posted to the mailbox."""

@@ -425,3 +425,34 @@ def test_dmf_fit_with_the_device_sampler():
     # the fit learned something: the model separates positives from negatives of a fresh device batch better than chance
     pred = e.predict(u[:4000], i[:4000]).cpu().numpy()
     assert pred[~neg_d[:4000]].mean() > pred[neg_d[:4000]].mean()
+
+
+def test_device_sampled_negatives_carry_the_standardised_zero():
+    """dmf.py:68 with recommender_abc.py:463-465: with use_nce every target — a negative's interaction value 0 included — is
+    (v - min) / (max - min).  A frame whose smallest rating is 2 (range 2..7) gives negatives the target -0.4, not 0: the device
+    sampler's targets equal the host stream's on both kinds of triple; with use_nce off both are raw (negatives 0)."""
+    import torch
+    from helpers import load_frames
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import DMF
+    from drecpy_amd.Sampler import PointSampler
+    frame = {k: v.copy() for k, v in load_frames()['pt_int_dense'].items()}
+    frame['interaction'] = np.asarray(frame['interaction'], np.float64) + 2.0            # 2..7: min_interaction = 2
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    for use_nce in (True, False):
+        model = DMF(user_factors=[16, 8], item_factors=[16, 8], seed=5, verbose=False, use_nce=use_nce)
+        model.fit(ds, epochs=2, batch_size=64, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=3, device_sampler=True)
+        assert model.min_interaction == 2.0 and model.max_interaction == 7.0
+        prep = model._engine.prepare_batch_device(20000, 3, 77)
+        torch.cuda.synchronize()
+        y = prep['device']['y'].cpu().numpy()
+        ru, ri, rv, rneg = PointSampler(ds, 3, model.interaction_threshold, 11).sample_arrays(20000)
+        rv, rneg = np.asarray(rv, np.float64), np.asarray(rneg).astype(bool)
+        ry = np.asarray(model._standardize_value(rv), np.float32) if use_nce else rv.astype(np.float32)
+        want_neg = np.float32((0.0 - 2.0) / 5.0) if use_nce else np.float32(0.0)
+        assert np.all(ry[rneg] == want_neg)                                  # the reference stream's own negatives
+        neg_d = y == want_neg
+        assert abs(neg_d.mean() - rneg.mean()) < 0.015, (use_nce, neg_d.mean(), rneg.mean())
+        # every other target is a positive's: the same set of values as the host stream's positives
+        assert set(np.unique(y[~neg_d]).tolist()) <= set(np.unique(ry[~rneg]).tolist()), use_nce
+        assert y[~neg_d].min() >= (0.0 if use_nce else 2.0)
