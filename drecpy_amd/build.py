@@ -32,7 +32,7 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(ROOT, 'include', 'drx.h')] + [os.path.join(CSRC, h) for h in
-               ('drx_common.hpp', 'drx_rows.hpp', 'drx_segreduce.hpp', 'drx_scan.hpp', 'drx_prep.hpp')]
+               ('drx_common.hpp', 'drx_rows.hpp', 'drx_segreduce.hpp', 'drx_scan.hpp', 'drx_prep.hpp', 'drx_segstream.hpp')]
     objs = []
     procs = []
     for src in SOURCES:

@@ -13,6 +13,8 @@
 #include <cstring>
 #include "drx_scan.hpp"
 #include "drx_prep.hpp"
+#include "drx_segstream.hpp"
+#include <type_traits>
 
 #ifndef DRX_GATHER_ROWS
 #define DRX_GATHER_ROWS 8
@@ -986,6 +988,21 @@ struct DirectPolicyT {
   __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
     sparse_apply<G, J, KIND>(P, opt, B, key, lane, g, gs);
   }
+  // what the streamed reduction (drx_segstream.hpp) needs to know: the keys of W rows stream — touches of plain lists carry the sample
+  // whose dz1 row they add, all with the coefficient 1/(1-q); the optimizer is element-wise with one slot (Adagrad: KIND says so at
+  // compile time); a row's own value enters its gradient with reg/B (sparse_apply -> row_update)
+  __device__ __forceinline__ uint32_t stream_rows() const { return (uint32_t)P.n_items; }
+  __device__ __forceinline__ const float *stream_grad() const { return dz1; }
+  __device__ __forceinline__ float *stream_table() const { return P.W; }
+  __device__ __forceinline__ float *stream_slot() const { return opt.s1[0]; }
+  __device__ __forceinline__ float stream_coef() const { return scale; }
+  __device__ __forceinline__ float stream_decay() const { return opt.reg_rate / (float)B; }
+  __device__ __forceinline__ void stream_update(float g, float &p, float &a) const {
+    static_assert(KIND == DRX_OPT_ADAGRAD || KIND < 0, "one slot per element");
+    OptScalars o = opt_for(opt, 0, B);
+    float unused = 0.f;
+    opt_update1<DRX_OPT_ADAGRAD>(o, g, p, a, unused);
+  }
 };
 using DirectPolicy = DirectPolicyT<-1>;                      // optimizer chosen at run time
 using DirectPolicyAdagrad = DirectPolicyT<DRX_OPT_ADAGRAD>;  // the throughput configuration's optimizer, known at compile time
@@ -1687,7 +1704,19 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     const int cpb = kSegBlock / G;                                                                                     \
     const dim3 rgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                                        \
     const size_t lds_r = seg_reduce_lds_bytes(cpb, p->ld, long_segments);                                              \
-    if (long_segments)                                                                                                 \
+    bool streamed = false;                                                                                             \
+    if constexpr (kStreamDepth > 0 && J == 1 && G >= 16 && std::is_same<POLT, DirectPolicyAdagrad>::value) {           \
+      /* lists of short segments over rows of exactly 64 / 128 / 256 floats: the streamed form (drx_segstream.hpp) */  \
+      if (!long_segments && p->ld == 4 * G && bt->B < (1 << kStreamIndexBits) && p->n_items < (1 << kStreamIndexBits)) { \
+        BiasPartialExtra<G, J, cpb * 64> bpxs{p->ld, BA};                                                              \
+        const dim3 sgrid(n_bpart + seg_stream_grid(p->ld, (S.n_chunks + cpb - 1) / cpb));               \
+        hipLaunchKernelGGL((k_seg_reduce_stream<4 * G, kStreamDepth, POLT, BiasPartialExtra<G, J, cpb * 64>>), sgrid, dim3(cpb * 64), \
+                           seg_stream_lds_bytes(p->ld, kStreamDepth), st, SB, PB, R.plan, polk, n_bpart, bpxs);        \
+        streamed = true;                                                                                               \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if (streamed) { }                                                                                                  \
+    else if (long_segments)                                                                                            \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, true, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB,    \
                          R.plan, polk, n_bpart, bpx);                                                                  \
     else                                                                                                               \

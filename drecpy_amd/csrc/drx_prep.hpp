@@ -228,13 +228,14 @@ __device__ __forceinline__ void bias_partial_body(int ld, const BiasArgs &A, int
   }
 }
 
-template <int G, int J>
+// NT: threads of the launch it rides in (k_seg_reduce_planned: kSegBlock; the streamed form: one wave per chunk)
+template <int G, int J, int NT = kSegBlock>
 struct BiasPartialExtra {
   int ld;
   BiasArgs A;
   __device__ __forceinline__ void operator()(float *lds) const {
-    __shared__ float red[kSegBlock / 64 > 0 ? kSegBlock / 64 : 1];
-    bias_partial_body<G, J, kSegBlock>(ld, A, (int)blockIdx.x, lds, red);
+    __shared__ float red[NT / 64 > 0 ? NT / 64 : 1];
+    bias_partial_body<G, J, NT>(ld, A, (int)blockIdx.x, lds, red);
   }
 };
 

@@ -347,6 +347,89 @@ __global__ void k_plan_spans(const uint32_t *__restrict__ keys_s, const uint32_t
   if (P.xrank && (g & ~63) < nb) place_block(keys_s, vals_s, T, cpb, B, P, g, g < nb);
 }
 
+// The fold of ONE chunk window of a list of SHORT segments by a row group of G lanes (the planned reduction's plain form; the streamed
+// kernel of drx_segstream.hpp runs it for the few windows it does not stream): the window's (key, sample) pairs are fetched with one
+// coalesced load per lane and broadcast by shuffles; contribution rows go out LB at a time and are folded in list order.  Segments inside
+// the window are finished in place; the run that began before the window / goes on behind it leaves a head / tail partial (no head
+// partial in an all-inner workgroup: the caller folds its chunks' sums into one block partial).  acc / accs: the last run's sum.
+template <int G, int J, int CH, int LB1, class Policy>
+__device__ __forceinline__ void seg_fold_short(const SegBufs &S, const Policy &pol, int g, int lane, int start, int n, uint32_t prev_key,
+                                               uint32_t next_key, bool all_inner, float4 (&acc)[J], float &accs) {
+  constexpr int KPL = (2 * CH + G - 1) / G;
+  constexpr int LB = J == 1 ? LB1 : (J == 2 ? 4 : 2);
+  uint32_t kreg[KPL], vreg[KPL];
+#pragma unroll
+  for (int q = 0; q < KPL; ++q) {
+    const int t = q * G + lane;
+    const bool ok = t < n;
+    kreg[q] = ok ? S.keys_s[start + t] : DRX_KEY_NONE;
+    vreg[q] = ok ? S.vals_s[start + t] : 0u;
+  }
+  auto bcast = [&](const uint32_t (&reg)[KPL], int t) -> uint32_t {
+    uint32_t sel = reg[0];
+#pragma unroll
+    for (int q = 1; q < KPL; ++q) sel = (t / G == q) ? reg[q] : sel;
+    return (uint32_t)__shfl((int)sel, t % G, G);
+  };
+#pragma unroll
+  for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+  accs = 0.f;
+  uint32_t cur = DRX_KEY_NONE;
+  int cur_pos = 0;
+  bool cur_from_start = false;
+  auto flush = [&](bool at_end) {
+    if (cur == DRX_KEY_NONE) return;
+    const bool cont_left = cur_from_start && prev_key == cur;
+    const bool cont_right = at_end && next_key == cur;
+    if (!cont_left && !cont_right) {
+      pol.template finish<G, J>(cur, cur_pos, lane, acc, accs);
+    } else if (cont_left) {
+      if (!all_inner) {
+        store_row<G, J>(S.phead, (size_t)g, S.ld, lane, acc);
+        if (lane == 0) S.phs[g] = accs;
+      }
+    } else {
+      store_row<G, J>(S.ptail, (size_t)g, S.ld, lane, acc);
+      if (lane == 0) S.pts[g] = accs;
+    }
+  };
+  for (int t0 = 0; t0 < n; t0 += LB) {
+    uint32_t k8[LB];
+    float s8[LB], c8[LB];
+    float4 rows[LB][J];
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      const int t = t0 + u;
+      k8[u] = t < n ? bcast(kreg, t) : DRX_KEY_NONE;
+      const uint32_t b = bcast(vreg, t < n ? t : 0);
+      s8[u] = 0.f;
+      c8[u] = 1.f;
+#pragma unroll
+      for (int jx = 0; jx < J; ++jx) rows[u][jx] = f4_zero();
+      if (k8[u] != DRX_KEY_NONE) pol.template load<G, J>(k8[u], b, lane, rows[u], s8[u], c8[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      const uint32_t key = k8[u];
+      if (key != DRX_KEY_NONE) {
+        if (key != cur) {
+          flush(false);
+          cur = key;
+          cur_from_start = (t0 + u == 0);
+#pragma unroll
+          for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
+          accs = 0.f;
+        }
+#pragma unroll
+        for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c8[u], rows[u][jx]);
+        accs += s8[u];
+        cur_pos = start + t0 + u;
+      }
+    }
+  }
+  flush(n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE);
+}
+
 // LDS: [kSegBlock/G, ld] floats + [kSegBlock/G] floats (+, LONG: 4 * CH words per chunk — seg_reduce_lds_bytes).  extra_blocks workgroups in front of the chunk workgroups run `extra(block)` (the
 // CDAE step's bias column sums: independent work that fills the launch's ramp).
 #ifdef DRX_SEGP_W8
@@ -382,60 +465,52 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
   }
   const bool all_inner = __syncthreads_and(inner ? 1 : 0) != 0;
   if (g >= S.n_chunks) return;          // (never in an all-inner workgroup: its second barrier below sees every thread)
-  DRX_STAMP(S.stamps, 65536 + g, 0, lane);
   // this chunk's window: behind the touches its left neighbour finishes for it, and into the right neighbour's for the segment it
   // finishes itself (SpanPlan::ext); up to 2 * CH - 1 touches
   const int start = min(Tn, g * CH + (g > 0 ? (int)ext[g - 1] : 0)), end = min(Tn, (g + 1) * CH + (int)ext[g]);
   const int n = max(0, end - start);
   const uint32_t prev_key = start > 0 ? S.keys_s[start - 1] : DRX_KEY_NONE;
   const uint32_t next_key = end < Tn ? S.keys_s[end] : DRX_KEY_NONE;
-  constexpr int KPL = (2 * CH + G - 1) / G;
-  constexpr int LB = J == 1 ? LB1 : (J == 2 ? 4 : 2);
-  uint32_t kreg[KPL], vreg[KPL];
-#pragma unroll
-  for (int q = 0; q < KPL; ++q) {
-    const int t = q * G + lane;
-    const bool ok = t < n;
-    kreg[q] = ok ? S.keys_s[start + t] : DRX_KEY_NONE;
-    vreg[q] = ok ? S.vals_s[start + t] : 0u;
-  }
-  auto bcast = [&](const uint32_t (&reg)[KPL], int t) -> uint32_t {
-    uint32_t sel = reg[0];
-#pragma unroll
-    for (int q = 1; q < KPL; ++q) sel = (t / G == q) ? reg[q] : sel;
-    return (uint32_t)__shfl((int)sel, t % G, G);
-  };
-#ifdef DRX_STAMPS
-  if (kreg[0] != 12345u || prev_key != 12345u) DRX_STAMP(S.stamps, 65536 + g, 1, lane);      // (keys have landed)
-  unsigned n_flush = 0;
-#endif
   float4 acc[J];
 #pragma unroll
   for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
   float accs = 0.f;
-  uint32_t cur = DRX_KEY_NONE;
-  int cur_pos = 0;
-  bool cur_from_start = false;
-  auto flush = [&](bool at_end) {
-    if (cur == DRX_KEY_NONE) return;
-    const bool cont_left = cur_from_start && prev_key == cur;
-    const bool cont_right = at_end && next_key == cur;
-#ifdef DRX_STAMPS
-    ++n_flush;
-#endif
-    if (!cont_left && !cont_right) {
-      pol.template finish<G, J>(cur, cur_pos, lane, acc, accs);
-    } else if (cont_left) {
-      if (!all_inner) {
-        store_row<G, J>(S.phead, (size_t)g, S.ld, lane, acc);
-        if (lane == 0) S.phs[g] = accs;
-      }
-    } else {
-      store_row<G, J>(S.ptail, (size_t)g, S.ld, lane, acc);
-      if (lane == 0) S.pts[g] = accs;
-    }
-  };
   if constexpr (LONG) {
+    constexpr int KPL = (2 * CH + G - 1) / G;
+    constexpr int LB = J == 1 ? LB1 : (J == 2 ? 4 : 2);
+    uint32_t kreg[KPL], vreg[KPL];
+  #pragma unroll
+    for (int q = 0; q < KPL; ++q) {
+      const int t = q * G + lane;
+      const bool ok = t < n;
+      kreg[q] = ok ? S.keys_s[start + t] : DRX_KEY_NONE;
+      vreg[q] = ok ? S.vals_s[start + t] : 0u;
+    }
+    auto bcast = [&](const uint32_t (&reg)[KPL], int t) -> uint32_t {
+      uint32_t sel = reg[0];
+  #pragma unroll
+      for (int q = 1; q < KPL; ++q) sel = (t / G == q) ? reg[q] : sel;
+      return (uint32_t)__shfl((int)sel, t % G, G);
+    };
+    uint32_t cur = DRX_KEY_NONE;
+    int cur_pos = 0;
+    bool cur_from_start = false;
+    auto flush = [&](bool at_end) {
+      if (cur == DRX_KEY_NONE) return;
+      const bool cont_left = cur_from_start && prev_key == cur;
+      const bool cont_right = at_end && next_key == cur;
+      if (!cont_left && !cont_right) {
+        pol.template finish<G, J>(cur, cur_pos, lane, acc, accs);
+      } else if (cont_left) {
+        if (!all_inner) {
+          store_row<G, J>(S.phead, (size_t)g, S.ld, lane, acc);
+          if (lane == 0) S.phs[g] = accs;
+        }
+      } else {
+        store_row<G, J>(S.ptail, (size_t)g, S.ld, lane, acc);
+        if (lane == 0) S.pts[g] = accs;
+      }
+    };
     // Lists of LONG segments: a round of LB touches nearly always continues the running segment.  The window's keys / samples are staged
     // in LDS (group-private: 2 CH words each) and a round reads its LB of each with four 16-byte broadcast reads — the register form
     // below spends 4 selects + a shuffle per key and per sample — then, when the round's first and last key ARE the running key (sorted:
@@ -498,50 +573,10 @@ __global__ __launch_bounds__(kSegBlock) DRX_SEGP_ATTR void k_seg_reduce_planned(
         }
       }
     }
+    flush(n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE);
   } else {
-    for (int t0 = 0; t0 < n; t0 += LB) {
-      uint32_t k8[LB];
-      float s8[LB], c8[LB];
-      float4 rows[LB][J];
-  #pragma unroll
-      for (int u = 0; u < LB; ++u) {
-        const int t = t0 + u;
-        k8[u] = t < n ? bcast(kreg, t) : DRX_KEY_NONE;
-        const uint32_t b = bcast(vreg, t < n ? t : 0);
-        s8[u] = 0.f;
-        c8[u] = 1.f;
-  #pragma unroll
-        for (int jx = 0; jx < J; ++jx) rows[u][jx] = f4_zero();
-        if (k8[u] != DRX_KEY_NONE) pol.template load<G, J>(k8[u], b, lane, rows[u], s8[u], c8[u]);
-      }
-  #pragma unroll
-      for (int u = 0; u < LB; ++u) {
-        const uint32_t key = k8[u];
-        if (key != DRX_KEY_NONE) {
-          if (key != cur) {
-            flush(false);
-            cur = key;
-            cur_from_start = (t0 + u == 0);
-  #pragma unroll
-            for (int jx = 0; jx < J; ++jx) acc[jx] = f4_zero();
-            accs = 0.f;
-          }
-  #pragma unroll
-          for (int jx = 0; jx < J; ++jx) f4_fma(acc[jx], c8[u], rows[u][jx]);
-          accs += s8[u];
-          cur_pos = start + t0 + u;
-        }
-      }
-    }
+    seg_fold_short<G, J, CH, LB1>(S, pol, g, lane, start, n, prev_key, next_key, all_inner, acc, accs);
   }
-#ifdef DRX_STAMPS
-  if (acc[0].x == acc[0].x) DRX_STAMP(S.stamps, 65536 + g, 2, lane);
-#endif
-  flush(n > 0 && bcast(kreg, n - 1) != DRX_KEY_NONE);
-#ifdef DRX_STAMPS
-  DRX_STAMP(S.stamps, 65536 + g, 3, lane);
-  if (lane == 0 && S.stamps && (unsigned)(65536 + g) < 110000u) { S.stamps[(size_t)(65536 + g) * 16 + 4] = n_flush; S.stamps[(size_t)(65536 + g) * 16 + 5] = (unsigned)n; }
-#endif
   if (all_inner) {                 // every chunk of this workgroup is one whole run of the same segment: one partial for all of them
     float *sc = seg_lds + (size_t)CPB * S.ld;
     store_row<G, J>(seg_lds, (size_t)r, S.ld, lane, acc);

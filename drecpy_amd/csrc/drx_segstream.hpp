@@ -1,0 +1,295 @@
+// STREAMED form of the planned segmented reduction (drx_segreduce.hpp) for lists of SHORT segments whose rows are exactly one, two or
+// four wave-wide pieces (ld = 256 / 128 / 64 floats) — the headline shape of the CDAE sparse step (K = 128).
+//
+// Why.  The planned kernel keeps every row it is waiting for in registers: 2 contribution rows per group in flight, and each finished
+// segment pays a dependent read of its parameter + slot row before the next round may start (40 KB in flight per CU: by Little's law
+// the 4.3 TB/s that kernel fetches at).  Here a wave turns its chunk window into ONE ordered stream of 16-byte-aligned ROW FETCHES —
+// the contribution row of every touch, and behind the last touch of every segment that ends inside the window the segment's parameter
+// row and its slot row — and moves that stream through a ring in LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source address, no
+// destination registers), D instructions (D KiB) ahead of the fold.  Nothing the fold needs is ever requested when it is needed.
+//
+//   * one chunk per WAVE: the 64 lanes hold one row (ld / 64 floats each); one LDS-DMA instruction brings 1 KiB = 256 / ld rows, all
+//     64 lanes busy whatever the window looks like; every branch of the fold is wave-uniform (a scalar branch on the item's code);
+//   * the stream's items live in LDS as 4-byte words: the row's index in its array << 4 | its kind;
+//   * a wave loads all it must know about a chunk — 64 list positions, two ext bytes, the block's border keys — as independent loads, ONE
+//     round instead of the planned kernel's three dependent ones (ext -> window -> keys), and a workgroup takes kStreamBpw consecutive
+//     blocks: the next block's round is in flight while this one streams;
+//   * vmcnt is counted by hand (the DMA is inline asm: hipcc neither counts it nor drains it): `s_waitcnt vmcnt(D - 1)` after issuing
+//     instruction j + D - 1 guarantees instruction j has landed — loads, stores and LDS-DMA retire in issue order, so the stores of a
+//     finished segment issued in between only make the wait stricter, never weaker;
+//   * sums keep the planned kernel's order (a segment's touches in list order, fma(coef, row, acc) from zero; block partials of
+//     all-inner workgroups in chunk order): the result is bit-identical to k_seg_reduce_planned's.
+// Windows that hold anything but streamable rows (the W2T / V tail of the list with its scalar side-values and blanked touches, the
+// padding) run the planned kernel's own fold, seg_fold_short, on the first G lanes of the wave: under 1 % of the headline's chunks.
+//
+// The POLICY says which keys stream (DirectPolicyT, drx_cdae.hip):
+//   uint32_t stream_rows()            keys below this are rows of ONE table, every touch of them with the coefficient stream_coef()
+//   const float *stream_grad()        contribution row of touch (key, val): stream_grad() + val * ld
+//   float *stream_table(), *stream_slot()   the table and its one slot array (an element-wise optimizer with one slot)
+//   float stream_coef(), stream_decay()     coefficient of a contribution row; weight of the row's own value in its gradient (reg / B)
+//   void stream_update(g, p, a)       one element: gradient g (decay applied), parameter p, slot a
+#pragma once
+#include "drx_segreduce.hpp"
+
+namespace drx {
+
+// one LDS-DMA instruction: 16 bytes per lane from gsrc (per lane) to LDS bytes [lds_dst, lds_dst + 1024) in lane order (lds_dst
+// wave-uniform).  M0 carries the destination and belongs to the compiler: saved and restored around the instruction.  The wait in front
+// retires every LDS read this wave has issued — the reads of the ring slot about to be overwritten among them.
+__device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// (native vectors: assignable through address-space-qualified pointers, which HIP's float2 / float4 structs are not)
+template <int VL> struct LaneVec;
+template <> struct LaneVec<1> { using T = float; };
+template <> struct LaneVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct LaneVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+// ring depth of the streamed reduction in LDS-DMA instructions (KiB) per wave; 0: the planned kernel everywhere (a variant is a build:
+// scripts/build_variant.sh <name> "-DDRX_STREAM_DEPTH=..")
+#ifndef DRX_STREAM_DEPTH
+#define DRX_STREAM_DEPTH 8
+#endif
+constexpr int kStreamDepth = DRX_STREAM_DEPTH;
+constexpr int kStreamItems = 3 * (2 * kChunk - 1) + 3;        // a window's items at most (every touch a segment of its own), rounded up to a multiple of 4
+constexpr int kStreamIndexBits = 28;                          // an item word: row index << 4 | kind
+static inline size_t seg_stream_lds_bytes(int ld, int depth) {
+  const int cpb = kSegBlock / (ld / 4);
+  return (size_t)cpb * ((size_t)depth * 1024 + (size_t)kStreamItems * 4) + (size_t)cpb * (ld + 4) * 4;
+}
+// consecutive blocks of the list per workgroup.  The hardware deals workgroups out as slots free up — a static split of the list over
+// resident workgroups (a persistent launch: 6 blocks each at the headline shape, 4 or 5 of them real work) measured 30 % SLOWER than
+// one block per workgroup — so the launch stays fine-grained: a workgroup streams its first block while the second one's keys load.
+#ifndef DRX_STREAM_BPW
+#define DRX_STREAM_BPW 2
+#endif
+constexpr int kStreamBpw = DRX_STREAM_BPW;
+static inline int seg_stream_grid(int ld, int n_blocks) {
+  (void)ld;
+  return (n_blocks + kStreamBpw - 1) / kStreamBpw;
+}
+
+// item kinds (low 4 bits of an item word)
+enum : uint32_t { kItGrad = 0, kItGradHead = 1, kItGradTail = 2, kItParam = 3, kItSlot = 4 };
+
+template <int LD, int D, class Policy, class Extra>
+__global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) void k_seg_reduce_stream(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol,
+                                                                               int extra_blocks, Extra extra) {
+  extern __shared__ __align__(16) float seg_lds[];
+  constexpr int G = LD / 4;                  // the row group the list's plan was made for (pick_geom(LD): J == 1)
+  constexpr int CPB = kSegBlock / G;         // chunks per workgroup: the plan's block size (SpanShape, PlanBufs::pblock)
+  constexpr int VL = LD / 64;                // floats of a row per lane
+  constexpr int IPI = 256 / LD;              // rows per LDS-DMA instruction
+  constexpr int LPI = 64 / IPI;              // lanes per row in that instruction (16 bytes each)
+  constexpr int CH = kChunk;
+  using V = typename LaneVec<VL>::T;
+  using GV = V __attribute__((address_space(1)));
+  static_assert(LD == 64 || LD == 128 || LD == 256, "one, two or four rows per KiB");
+  static_assert(D >= 2 && D <= 32, "ring depth");
+  static_assert(2 * CH <= 64 && 3 * CPB <= 64, "a window is one touch per lane; a block's border keys one per lane");
+  if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n_blocks = (S.n_chunks + CPB - 1) / CPB;
+  const uint32_t *__restrict__ const ks = S.keys_s, *__restrict__ const vs = S.vals_s;
+  const uint8_t *__restrict__ const ext = SP.ext;
+  // LDS: the waves' rings, their item tables, the rows of an all-inner workgroup's chunk sums
+  char *const lds_b = reinterpret_cast<char *>(seg_lds);
+  float *const ring = reinterpret_cast<float *>(lds_b + (size_t)wv * D * 1024);
+  uint32_t *const tab = reinterpret_cast<uint32_t *>(lds_b + (size_t)CPB * D * 1024 + (size_t)wv * kStreamItems * 4);
+  float *const comb = reinterpret_cast<float *>(lds_b + (size_t)CPB * (D * 1024 + kStreamItems * 4));      // [CPB, LD] then [CPB]
+  const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)ring);
+  const char *const gradb = reinterpret_cast<const char *>(pol.stream_grad());
+  const char *const tableb = reinterpret_cast<const char *>(pol.stream_table());
+  const char *const slotb = reinterpret_cast<const char *>(pol.stream_slot());
+  const long long off_table = tableb - gradb, off_slot = slotb - gradb;
+  const float coef = pol.stream_coef(), decay = pol.stream_decay();
+  const int sub = lane / LPI, piece = lane % LPI;     // this lane's row of an LDS-DMA instruction, its 16 bytes of that row
+
+  // Everything a wave must know about a chunk before it can stream it, in ONE round of independent loads (the planned kernel walks
+  // ext -> window -> keys: three dependent rounds, 2 - 3 us each beside the streams of the other waves): the 64 list positions behind
+  // the chunk's start (its window lies in them: it begins ext[g - 1] <= 31 positions in and ends before position 32 + ext[g] <= 63),
+  // the key in front of them, the two ext bytes, and — lanes 0 .. 3 CPB - 1 — the first / last / preceding key of every chunk of the
+  // block (is the block all-inner?).  Loaded for the workgroup's NEXT block while it streams this one.
+  struct Meta { uint32_t key, val, bk, prevk; int e0, e1; };
+  auto load_meta = [&](int blk, Meta &m) __attribute__((always_inline)) {
+    const int g = blk * CPB + wv, base = g * CH, pos = base + lane;
+    const bool have = g < S.n_chunks;
+    m.key = have && pos < S.T ? ks[pos] : DRX_KEY_NONE;
+    m.val = have && pos < S.T ? vs[pos] : 0u;
+    m.prevk = have && g > 0 ? ks[base - 1] : DRX_KEY_NONE;
+    m.e0 = have && g > 0 ? (int)ext[g - 1] : 0;
+    m.e1 = have ? (int)ext[g] : 0;
+    const int c = blk * CPB + lane % CPB, role = lane / CPB;
+    const int p = role == 0 ? c * CH : (role == 1 ? (c + 1) * CH - 1 : c * CH - 1);
+    m.bk = lane < 3 * CPB && c < S.n_chunks && (c + 1) * CH <= S.T && p >= 0 ? ks[p] : DRX_KEY_NONE;
+  };
+  Meta nxt;
+  int blk = ((int)blockIdx.x - extra_blocks) * kStreamBpw;
+  const int blk_end = min(n_blocks, blk + kStreamBpw);
+  if (blk < blk_end) load_meta(blk, nxt);
+  for (; blk < blk_end; ++blk) {
+    const Meta m = nxt;
+    if (blk + 1 < blk_end) load_meta(blk + 1, nxt);
+    // a chunk is INNER when it is one whole run of a segment that began before it; a block of inner chunks leaves one partial
+    const uint32_t bl = (uint32_t)__shfl((int)m.bk, lane + CPB, 64), bp = (uint32_t)__shfl((int)m.bk, lane + 2 * CPB, 64);
+    const bool inner = lane < CPB && m.bk != DRX_KEY_NONE && m.bk == bp && bl == m.bk;
+    const bool all_inner = (__ballot(inner) & ((1ull << CPB) - 1ull)) == ((1ull << CPB) - 1ull);
+    const int g = blk * CPB + wv;
+    V acc;                                                 // this lane's floats of the running segment's sum
+    float accs = 0.f;
+    float *const accf = reinterpret_cast<float *>(&acc);
+#pragma unroll
+    for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+    if (g < S.n_chunks) {
+      // the chunk's window: behind the touches its left neighbour finishes for it, and into the right neighbour's for the segment it
+      // finishes itself (SpanPlan::ext)
+      const int base = g * CH;
+      const int e0 = __builtin_amdgcn_readfirstlane(m.e0), e1 = __builtin_amdgcn_readfirstlane(m.e1);
+      const int end_off = min(CH + e1, S.T - base);                // <= 63
+      const int n = max(0, end_off - e0);
+      const uint32_t key = m.key, val = m.val;
+      const bool valid = lane >= e0 && lane < end_off;
+      const uint32_t prev_key = e0 > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key, e0 - 1) : (uint32_t)__builtin_amdgcn_readfirstlane((int)m.prevk);
+      const uint32_t next_key = n > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key, end_off) : DRX_KEY_NONE;      // (a position behind T reads as DRX_KEY_NONE)
+      const uint32_t last_key = n > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key, end_off - 1) : 0u;
+      // sorted: the window streams iff its LAST key does
+      if (n == 0 || last_key < pol.stream_rows()) {
+        // ---- the window's items -----------------------------------------------------------------------------------------------
+        const uint32_t key_right = (uint32_t)__shfl_down((int)key, 1, 64);
+        const uint32_t key0 = (uint32_t)__builtin_amdgcn_readlane((int)key, n > 0 ? e0 : 0);
+        const bool seg_end = valid && (lane == end_off - 1 || key_right != key);
+        const bool cont_left = key == key0 && prev_key == key;            // the window's first run began before it
+        const bool cont_right = lane == end_off - 1 && next_key == key;   // its last run goes on behind it
+        const bool apply = seg_end && !cont_left && !cont_right;
+        const int w = valid ? (apply ? 3 : 1) : 0;
+        int incl = w;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += t;
+        }
+        const int pos = incl - w;
+        const int M = __builtin_amdgcn_readlane(incl, 63);
+        if (valid) {
+          const uint32_t kind = !seg_end || apply ? kItGrad : (cont_left ? kItGradHead : kItGradTail);
+          tab[pos] = (val << 4) | kind;
+          if (apply) { tab[pos + 1] = (key << 4) | kItParam; tab[pos + 2] = (key << 4) | kItSlot; }
+        }
+        wave_lds_sync();
+        // ---- the stream -------------------------------------------------------------------------------------------------------
+        const int ns = (M + IPI - 1) / IPI;                 // LDS-DMA instructions
+        auto issue = [&](int j, int slot) __attribute__((always_inline)) {
+          const int i = j * IPI + sub;
+          const uint32_t it = tab[i < kStreamItems ? i : kStreamItems - 1];
+          const uint32_t kind = it & 15u;
+          // (the three arrays as VALUE offsets from one base: a select between pointers is lowered to a table in scratch memory)
+          const long long off = (kind == kItParam ? off_table : (kind == kItSlot ? off_slot : 0ll)) + (long long)(it >> 4) * (LD * 4);
+          const char *const src = gradb + (i < M ? off : 0ll);                       // (lanes behind the stream's end re-read a hot line)
+          lds_dma16(src + piece * 16, ring_lds + (uint32_t)slot * 1024u);
+        };
+        V prow;                                             // the parameter row of the segment being finished
+        float *const pf = reinterpret_cast<float *>(&prow);
+#pragma unroll
+        for (int v = 0; v < VL; ++v) pf[v] = 0.f;
+        int issued = 0;
+        for (; issued < D - 1 && issued < ns; ++issued) issue(issued, issued);
+        bool drained = false;
+        int slot = 0, islot = issued % D;
+        for (int j = 0; j < ns; ++j) {
+          if (issued < ns) {
+            issue(issued, islot);
+            ++issued;
+            islot = islot + 1 == D ? 0 : islot + 1;
+            wait_vmcnt<D - 1>();
+          } else if (!drained) {
+            wait_vmcnt<0>();
+            drained = true;
+          }
+          const float *const rows = ring + (size_t)slot * 256;
+          slot = slot + 1 == D ? 0 : slot + 1;
+#pragma unroll
+          for (int s = 0; s < IPI; ++s) {
+            const int i = j * IPI + s;
+            if (i < M) {
+              const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[i]);
+              const uint32_t kind = it & 15u;
+              const V row = *reinterpret_cast<const V *>(rows + s * LD + lane * VL);
+              const float *const rf = reinterpret_cast<const float *>(&row);
+              if (kind <= kItGradTail) {
+#pragma unroll
+                for (int v = 0; v < VL; ++v) accf[v] = fmaf(coef, rf[v], accf[v]);
+                if (kind == kItGradHead) {
+                  if (!all_inner) {
+                    *reinterpret_cast<V *>(S.phead + (size_t)g * LD + lane * VL) = acc;
+                    if (lane == 0) S.phs[g] = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+                  }
+                } else if (kind == kItGradTail) {
+                  *reinterpret_cast<V *>(S.ptail + (size_t)g * LD + lane * VL) = acc;
+                  if (lane == 0) S.pts[g] = 0.f;
+#pragma unroll
+                  for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+                }
+              } else if (kind == kItParam) {
+                prow = row;
+              } else {
+                V slotv = row;
+                float *const sf = reinterpret_cast<float *>(&slotv);
+#pragma unroll
+                for (int v = 0; v < VL; ++v) pol.stream_update(fmaf(decay, pf[v], accf[v]), pf[v], sf[v]);
+                // (addresses rebuilt from integers: said to be GLOBAL ones, or the stores become flat_store — counted in lgkmcnt too
+                // and retired out of order)
+                const size_t off = (size_t)(it >> 4) * (LD * 4);
+                ((GV *)(uintptr_t)(tableb + off))[lane] = prow;
+                ((GV *)(uintptr_t)(slotb + off))[lane] = slotv;
+#pragma unroll
+                for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+              }
+            }
+          }
+        }
+        if (all_inner) *reinterpret_cast<V *>(comb + (size_t)wv * LD + lane * VL) = acc;
+      } else {
+        // the W2T / V tail of the list (scalar side-values, blanked touches) and its padding: the planned kernel's own fold
+        float4 acc4[1];
+        if (lane < G) {
+#ifndef DRX_STREAM_NO_SLOW
+          seg_fold_short<G, 1, CH, 2>(S, pol, g, lane, base + e0, n, prev_key, next_key, all_inner, acc4, accs);
+#endif
+          if (all_inner) store_row<G, 1>(comb, (size_t)wv, LD, lane, acc4);
+        }
+      }
+    }
+    if (all_inner) {               // every chunk of this block is one whole run of the same segment: one partial for all of them
+      float *const sc = comb + (size_t)CPB * LD;
+      if (lane == 0) sc[wv] = accs;
+      __syncthreads();
+      if (wv == 0) {
+        V t;
+        float *const tf = reinterpret_cast<float *>(&t);
+#pragma unroll
+        for (int v = 0; v < VL; ++v) tf[v] = 0.f;
+        float ts = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < CPB; ++rr) {
+          const V x = *reinterpret_cast<const V *>(comb + (size_t)rr * LD + lane * VL);
+          const float *const xf = reinterpret_cast<const float *>(&x);
+#pragma unroll
+          for (int v = 0; v < VL; ++v) tf[v] += xf[v];
+          ts += sc[rr];
+        }
+        *reinterpret_cast<V *>(PB.pblock + (size_t)blk * LD + lane * VL) = t;
+        if (lane == 0) PB.pbs[blk] = ts;
+      }
+      __syncthreads();             // (the rows are free for the workgroup's next all-inner block)
+    }
+  }
+}
+
+}  // namespace drx
