@@ -63,6 +63,12 @@ def parse(argv=None):
     ap.add_argument('--no-configs', action='store_true', help='skip the `configs` block (BASELINE configurations 2, 3, 5)')
     ap.add_argument('--force-configs', action='store_true', help='emit the `configs` block whatever the main workload is (tests)')
     ap.add_argument('--no-overlap', action='store_true', help='build the touch list inline instead of ahead on a side stream')
+    ap.add_argument('--prep-cus', type=int, default=-1, help='CUs of every XCD the run-ahead streams (sampler, list preparation) are confined to '
+                    '(drx_stream_create_cu_slice); 0: the whole chip, high priority; default: engine.PREP_CUS_PER_XCD')
+    ap.add_argument('--side-streams', type=int, default=2, help='run-ahead streams (the work of step s on stream s %% n)')
+    ap.add_argument('--prep-ahead', type=int, default=3, help='steps of lead of the list preparation')
+    ap.add_argument('--no-share-users', action='store_true', help='A/B: plain lists where DRX_BATCH_SHARE_USERS would apply')
+    ap.add_argument('--no-sample-by-user', action='store_true', help='A/B: device-sampled batches in draw order')
     ap.add_argument('--users', type=int, default=0, help='override the number of users (debug)')
     ap.add_argument('--force-sharded', action='store_true', help='run the row-sharded step even at 1 GPU (measures its overhead)')
     ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'adam', 'rowwise_adagrad'], help='sparse optimizer of the sampled mode (S = 1 / 2 slots per parameter; single-GPU path)')
@@ -666,6 +672,8 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
 
     if world == 1 and not args.force_sharded:
         eng = CdaeEngine(hi - lo, N, K, device=dev)
+        eng.share_users = not args.no_share_users
+        eng.sample_by_user = not args.no_sample_by_user
         eng.init_glorot_device(10)
         eng.set_history(indptr, indices)
         eng.init_optimizer(args.optimizer, 1e-3 if args.optimizer == 'adam' else LR, REG)
@@ -720,7 +728,8 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     if fresh:
         from drecpy_amd.engine import SampledPipeline
         spipe = SampledPipeline(eng, B, NEG_RATIO, Q, lambda s: 5000 + 7919 * s + 104729 * rank,
-                                lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N, prep_ahead=int(os.environ.get('DRX_PREP_AHEAD', 3)))
+                                lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N, prep_ahead=args.prep_ahead,
+                                side_streams=args.side_streams, side_cus_per_xcd=None if args.prep_cus < 0 else args.prep_cus)
 
     def batch_of(s):
         return structs[s % len(structs)][0]

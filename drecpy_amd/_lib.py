@@ -106,6 +106,8 @@ SIGNATURES = {
     'drx_event_record': (C.c_int, [C.c_void_p, C.c_void_p]),
     'drx_stream_wait_event': (C.c_int, [C.c_void_p, C.c_void_p]),
     'drx_event_synchronize': (C.c_int, [C.c_void_p]),
+    'drx_stream_create_cu_slice': (C.c_void_p, [C.c_int32]),
+    'drx_stream_destroy': (None, [C.c_void_p]),
     'drx_cdae_forward': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(History), C.POINTER(Batch), C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     'drx_cdae_scratch_bytes': (C.c_size_t, [C.POINTER(CdaeParams), C.c_int32, C.c_int32, C.c_int32]),

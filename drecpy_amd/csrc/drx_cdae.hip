@@ -988,14 +988,15 @@ struct DirectPolicyT {
   __device__ __forceinline__ void finish(uint32_t key, int, int lane, const float4 (&g)[J], float gs) const {
     sparse_apply<G, J, KIND>(P, opt, B, key, lane, g, gs);
   }
-  // what the streamed reduction (drx_segstream.hpp) needs to know: the keys of W rows stream — touches of plain lists carry the sample
-  // whose dz1 row they add, all with the coefficient 1/(1-q); the optimizer is element-wise with one slot (Adagrad: KIND says so at
-  // compile time); a row's own value enters its gradient with reg/B (sparse_apply -> row_update)
-  __device__ __forceinline__ uint32_t stream_rows() const { return (uint32_t)P.n_items; }
-  __device__ __forceinline__ const float *stream_grad() const { return dz1; }
-  __device__ __forceinline__ float *stream_table() const { return P.W; }
-  __device__ __forceinline__ float *stream_slot() const { return opt.s1[0]; }
-  __device__ __forceinline__ float stream_coef() const { return scale; }
+  // what the streamed reduction (drx_segstream.hpp) needs to know — the key space as three row arrays: W rows (touches carry the sample
+  // whose dz1 row they add, with the coefficient 1/(1-q)), W2T rows (g2 rows, coefficient 1, and the scalar dz2 for the output bias),
+  // V rows (dz1 rows, coefficient 1); the optimizer is element-wise with one slot (Adagrad: KIND says so at compile time); a row's
+  // own value enters its gradient with reg/B (sparse_apply -> row_update), the output bias's does not
+  __device__ __forceinline__ StreamArrays stream_arrays() const {
+    const uint32_t N = (uint32_t)P.n_items;
+    return StreamArrays{{0u, N, 2u * N}, {dz1, dz1 + g2_off, dz1}, {P.W, P.W2T, P.V}, {opt.s1[0], opt.s1[1], opt.s1[2]},
+                        {scale, 1.0f, 1.0f}, {nullptr, dz2, nullptr}, {nullptr, P.b2, nullptr}, {nullptr, opt.s1[4], nullptr}};
+  }
   __device__ __forceinline__ float stream_decay() const { return opt.reg_rate / (float)B; }
   __device__ __forceinline__ void stream_update(float g, float &p, float &a) const {
     static_assert(KIND == DRX_OPT_ADAGRAD || KIND < 0, "one slot per element");
@@ -1003,6 +1004,7 @@ struct DirectPolicyT {
     float unused = 0.f;
     opt_update1<DRX_OPT_ADAGRAD>(o, g, p, a, unused);
   }
+  __device__ __forceinline__ void stream_update_scalar(float g, float &p, float &a) const { stream_update(g, p, a); }      // sparse_apply's output-bias half
 };
 using DirectPolicy = DirectPolicyT<-1>;                      // optimizer chosen at run time
 using DirectPolicyAdagrad = DirectPolicyT<DRX_OPT_ADAGRAD>;  // the throughput configuration's optimizer, known at compile time
@@ -1358,6 +1360,21 @@ int drx_event_record(void *ev, void *stream) { return ev ? (int)hipEventRecord((
 int drx_stream_wait_event(void *stream, void *ev) { return ev ? (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0) : DRX_EINVAL; }
 int drx_event_synchronize(void *ev) { return ev ? (int)hipEventSynchronize((hipEvent_t)ev) : DRX_EINVAL; }
 
+void *drx_stream_create_cu_slice(int32_t cus_per_xcd) {
+  constexpr int kXcds = 8, kCusPerXcd = 32;          // gfx950
+  if (cus_per_xcd < 1 || cus_per_xcd > kCusPerXcd) return nullptr;
+  uint32_t mask[kXcds * kCusPerXcd / 32] = {};
+  for (int c = kCusPerXcd - cus_per_xcd; c < kCusPerXcd; ++c)
+    for (int x = 0; x < kXcds; ++x) {
+      const int bit = c * kXcds + x;
+      mask[bit >> 5] |= 1u << (bit & 31);
+    }
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)(sizeof(mask) / sizeof(mask[0])), mask) != hipSuccess) return nullptr;
+  return (void *)st;
+}
+void drx_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+
 int drx_cdae_forward(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, float *h, float *pred,
                      void *stream) {
   int rc = check_params(p);
@@ -1707,7 +1724,8 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
     bool streamed = false;                                                                                             \
     if constexpr (kStreamDepth > 0 && J == 1 && G >= 16 && std::is_same<POLT, DirectPolicyAdagrad>::value) {           \
       /* lists of short segments over rows of exactly 64 / 128 / 256 floats: the streamed form (drx_segstream.hpp) */  \
-      if (!long_segments && p->ld == 4 * G && bt->B < (1 << kStreamIndexBits) && p->n_items < (1 << kStreamIndexBits)) { \
+      if (!long_segments && p->ld == 4 * G && bt->B < (1 << kStreamIndexBits) && p->n_items < (1 << kStreamIndexBits) &&           \
+          p->n_users < (1 << kStreamIndexBits)) { \
         BiasPartialExtra<G, J, cpb * 64> bpxs{p->ld, BA};                                                              \
         const dim3 sgrid(n_bpart + seg_stream_grid(p->ld, (S.n_chunks + cpb - 1) / cpb));               \
         hipLaunchKernelGGL((k_seg_reduce_stream<4 * G, kStreamDepth, POLT, BiasPartialExtra<G, J, cpb * 64>>), sgrid, dim3(cpb * 64), \

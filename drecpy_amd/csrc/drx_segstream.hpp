@@ -19,26 +19,31 @@
 //     finished segment issued in between only make the wait stricter, never weaker;
 //   * sums keep the planned kernel's order (a segment's touches in list order, fma(coef, row, acc) from zero; block partials of
 //     all-inner workgroups in chunk order): the result is bit-identical to k_seg_reduce_planned's.
-// Windows that hold anything but streamable rows (the W2T / V tail of the list with its scalar side-values and blanked touches, the
-// padding) run the planned kernel's own fold, seg_fold_short, on the first G lanes of the wave: under 1 % of the headline's chunks.
+// Every key of the CDAE step's list streams: the key space is three row arrays side by side (W, W2T, V: SURVEY App. A) and an item's
+// kind says which; touches of W2T rows also carry a scalar (the output bias's gradient).  Scalars do not ride in the ring: every lane
+// loads its touch's scalar, and the bias + slot of the row its touch finishes, BEFORE the stream starts — a compiler-counted load
+// waited for inside the loop would drain the ring at every use (hipcc waits vmcnt(0) for it: a window of 32 output-row touches then
+// costs 32 full round trips and ends the launch 100 us late).  Blanked touches (DRX_KEY_NONE) are not items.
 //
-// The POLICY says which keys stream (DirectPolicyT, drx_cdae.hip):
-//   uint32_t stream_rows()            keys below this are rows of ONE table, every touch of them with the coefficient stream_coef()
-//   const float *stream_grad()        contribution row of touch (key, val): stream_grad() + val * ld
-//   float *stream_table(), *stream_slot()   the table and its one slot array (an element-wise optimizer with one slot)
-//   float stream_coef(), stream_decay()     coefficient of a contribution row; weight of the row's own value in its gradient (reg / B)
+// The POLICY describes the arrays (DirectPolicyT, drx_cdae.hip):
+//   StreamArrays stream_arrays()      per array v = 0, 1, 2: first key, contribution rows (touch (key, val): grad[v] + val * ld) and their
+//                                     coefficient, the table and its one slot array (an element-wise optimizer with one slot)
+//   float stream_decay()              weight of a row's own value in its gradient (reg / B)
 //   void stream_update(g, p, a)       one element: gradient g (decay applied), parameter p, slot a
+//   void stream_update_scalar(g, p, a)   the same for an array's scalar side (the output biases: no decay)
 #pragma once
 #include "drx_segreduce.hpp"
 
 namespace drx {
 
 // one LDS-DMA instruction: 16 bytes per lane from gsrc (per lane) to LDS bytes [lds_dst, lds_dst + 1024) in lane order (lds_dst
-// wave-uniform).  M0 carries the destination and belongs to the compiler: saved and restored around the instruction.  The wait in front
-// retires every LDS read this wave has issued — the reads of the ring slot about to be overwritten among them.
+// wave-uniform).  M0 carries the destination and belongs to the compiler: saved and restored around the instruction.
+// The ring slot it overwrites was read (ds_read) by the SAME wave an iteration earlier, and the values read were used (an fma: hipcc
+// waits lgkmcnt for them in front of it) before this statement in program order — no wait needed here, and none wanted: an
+// `s_waitcnt lgkmcnt(0)` would also wait for the scalar loads a pipelined caller has in flight for its next work item.
 __device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_dst) {
   uint32_t keep;
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 template <int N>
@@ -53,20 +58,27 @@ template <> struct LaneVec<4> { typedef float T __attribute__((ext_vector_type(4
 // ring depth of the streamed reduction in LDS-DMA instructions (KiB) per wave; 0: the planned kernel everywhere (a variant is a build:
 // scripts/build_variant.sh <name> "-DDRX_STREAM_DEPTH=..")
 #ifndef DRX_STREAM_DEPTH
-#define DRX_STREAM_DEPTH 8
+#define DRX_STREAM_DEPTH 4
 #endif
 constexpr int kStreamDepth = DRX_STREAM_DEPTH;
+// The streamed kernels take their arguments (five structs of pointers) in ~106 scalar registers; a CU admits 256-thread workgroups up to
+// 800 / (sgprs rounded up to 16, + 16): 6 at 106, 8 at 80 (MI355X_MICROARCH: Residency).  Capped, the compiler parks the surplus in
+// lanes of a vector register (v_writelane / v_readlane): 8 workgroups = all 32 wave slots of a CU.
+#ifndef DRX_STREAM_SGPRS
+#define DRX_STREAM_SGPRS 80
+#endif
+#define DRX_STREAM_SGPR_CAP __attribute__((amdgpu_num_sgpr(DRX_STREAM_SGPRS)))
 constexpr int kStreamItems = 3 * (2 * kChunk - 1) + 3;        // a window's items at most (every touch a segment of its own), rounded up to a multiple of 4
 constexpr int kStreamIndexBits = 28;                          // an item word: row index << 4 | kind
 static inline size_t seg_stream_lds_bytes(int ld, int depth) {
   const int cpb = kSegBlock / (ld / 4);
-  return (size_t)cpb * ((size_t)depth * 1024 + (size_t)kStreamItems * 4) + (size_t)cpb * (ld + 4) * 4;
+  return (size_t)cpb * ((size_t)depth * 1024 + (size_t)kStreamItems * 4 + 128) + (size_t)cpb * (ld + 4) * 4;
 }
 // consecutive blocks of the list per workgroup.  The hardware deals workgroups out as slots free up — a static split of the list over
 // resident workgroups (a persistent launch: 6 blocks each at the headline shape, 4 or 5 of them real work) measured 30 % SLOWER than
 // one block per workgroup — so the launch stays fine-grained: a workgroup streams its first block while the second one's keys load.
 #ifndef DRX_STREAM_BPW
-#define DRX_STREAM_BPW 2
+#define DRX_STREAM_BPW 1
 #endif
 constexpr int kStreamBpw = DRX_STREAM_BPW;
 static inline int seg_stream_grid(int ld, int n_blocks) {
@@ -74,11 +86,21 @@ static inline int seg_stream_grid(int ld, int n_blocks) {
   return (n_blocks + kStreamBpw - 1) / kStreamBpw;
 }
 
-// item kinds (low 4 bits of an item word)
+struct StreamArrays {
+  uint32_t first_key[3];       // keys [first_key[v], first_key[v + 1]) are rows of array v (ascending; the last array is open-ended)
+  const float *grad[3];
+  float *table[3], *slot[3];
+  float coef[3];
+  // scalar side of an array (nullptr: none): per touch (key, val) the value sgrad[v][val]; per finished row one parameter + slot scalar
+  const float *sgrad[3];
+  float *sparam[3], *sslot[3];
+};
+
+// item kinds (low 4 bits of an item word): 5 * array + ...
 enum : uint32_t { kItGrad = 0, kItGradHead = 1, kItGradTail = 2, kItParam = 3, kItSlot = 4 };
 
 template <int LD, int D, class Policy, class Extra>
-__global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) void k_seg_reduce_stream(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol,
+__global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP void k_seg_reduce_stream(SegBufs S, PlanBufs PB, SpanPlan SP, Policy pol,
                                                                                int extra_blocks, Extra extra) {
   extern __shared__ __align__(16) float seg_lds[];
   constexpr int G = LD / 4;                  // the row group the list's plan was made for (pick_geom(LD): J == 1)
@@ -97,17 +119,24 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) void k_seg_reduce_stre
   const int n_blocks = (S.n_chunks + CPB - 1) / CPB;
   const uint32_t *__restrict__ const ks = S.keys_s, *__restrict__ const vs = S.vals_s;
   const uint8_t *__restrict__ const ext = SP.ext;
-  // LDS: the waves' rings, their item tables, the rows of an all-inner workgroup's chunk sums
+  // LDS: the waves' rings, their item tables, their copies of the arrays' offsets, the rows of an all-inner workgroup's chunk sums
   char *const lds_b = reinterpret_cast<char *>(seg_lds);
   float *const ring = reinterpret_cast<float *>(lds_b + (size_t)wv * D * 1024);
   uint32_t *const tab = reinterpret_cast<uint32_t *>(lds_b + (size_t)CPB * D * 1024 + (size_t)wv * kStreamItems * 4);
-  float *const comb = reinterpret_cast<float *>(lds_b + (size_t)CPB * (D * 1024 + kStreamItems * 4));      // [CPB, LD] then [CPB]
+  long long *const offs = reinterpret_cast<long long *>(lds_b + (size_t)CPB * (D * 1024 + kStreamItems * 4) + (size_t)wv * 128);
+  float *const comb = reinterpret_cast<float *>(lds_b + (size_t)CPB * (D * 1024 + kStreamItems * 4 + 128));      // [CPB, LD] then [CPB]
   const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)ring);
-  const char *const gradb = reinterpret_cast<const char *>(pol.stream_grad());
-  const char *const tableb = reinterpret_cast<const char *>(pol.stream_table());
-  const char *const slotb = reinterpret_cast<const char *>(pol.stream_slot());
-  const long long off_table = tableb - gradb, off_slot = slotb - gradb;
-  const float coef = pol.stream_coef(), decay = pol.stream_decay();
+  const StreamArrays A = pol.stream_arrays();
+  const char *const origin = reinterpret_cast<const char *>(A.grad[0]);
+  // an item's row array as a byte OFFSET from `origin`, by kind (a select between pointers is lowered to a table in scratch memory)
+  if (lane < 15) {
+    const int v = lane / 5, k = lane % 5;
+    const char *const g = reinterpret_cast<const char *>(v == 0 ? A.grad[0] : (v == 1 ? A.grad[1] : A.grad[2]));
+    const char *const t = reinterpret_cast<const char *>(v == 0 ? A.table[0] : (v == 1 ? A.table[1] : A.table[2]));
+    const char *const sl = reinterpret_cast<const char *>(v == 0 ? A.slot[0] : (v == 1 ? A.slot[1] : A.slot[2]));
+    offs[lane] = (k <= (int)kItGradTail ? g : (k == (int)kItParam ? t : sl)) - origin;
+  }
+  const float decay = pol.stream_decay();
   const int sub = lane / LPI, piece = lane % LPI;     // this lane's row of an LDS-DMA instruction, its 16 bytes of that row
 
   // Everything a wave must know about a chunk before it can stream it, in ONE round of independent loads (the planned kernel walks
@@ -132,6 +161,7 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) void k_seg_reduce_stre
   int blk = ((int)blockIdx.x - extra_blocks) * kStreamBpw;
   const int blk_end = min(n_blocks, blk + kStreamBpw);
   if (blk < blk_end) load_meta(blk, nxt);
+  wave_lds_sync();                                      // (offs)
   for (; blk < blk_end; ++blk) {
     const Meta m = nxt;
     if (blk + 1 < blk_end) load_meta(blk + 1, nxt);
@@ -141,7 +171,7 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) void k_seg_reduce_stre
     const bool all_inner = (__ballot(inner) & ((1ull << CPB) - 1ull)) == ((1ull << CPB) - 1ull);
     const int g = blk * CPB + wv;
     V acc;                                                 // this lane's floats of the running segment's sum
-    float accs = 0.f;
+    float accs = 0.f;                                      // ... and its scalar side-sum
     float *const accf = reinterpret_cast<float *>(&acc);
 #pragma unroll
     for (int v = 0; v < VL; ++v) accf[v] = 0.f;
@@ -153,118 +183,132 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) void k_seg_reduce_stre
       const int end_off = min(CH + e1, S.T - base);                // <= 63
       const int n = max(0, end_off - e0);
       const uint32_t key = m.key, val = m.val;
-      const bool valid = lane >= e0 && lane < end_off;
+      const bool valid = lane >= e0 && lane < end_off && key != DRX_KEY_NONE;      // (blanked and dropped touches are no items)
       const uint32_t prev_key = e0 > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key, e0 - 1) : (uint32_t)__builtin_amdgcn_readfirstlane((int)m.prevk);
       const uint32_t next_key = n > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key, end_off) : DRX_KEY_NONE;      // (a position behind T reads as DRX_KEY_NONE)
-      const uint32_t last_key = n > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key, end_off - 1) : 0u;
-      // sorted: the window streams iff its LAST key does
-      if (n == 0 || last_key < pol.stream_rows()) {
-        // ---- the window's items -----------------------------------------------------------------------------------------------
-        const uint32_t key_right = (uint32_t)__shfl_down((int)key, 1, 64);
-        const uint32_t key0 = (uint32_t)__builtin_amdgcn_readlane((int)key, n > 0 ? e0 : 0);
-        const bool seg_end = valid && (lane == end_off - 1 || key_right != key);
-        const bool cont_left = key == key0 && prev_key == key;            // the window's first run began before it
-        const bool cont_right = lane == end_off - 1 && next_key == key;   // its last run goes on behind it
-        const bool apply = seg_end && !cont_left && !cont_right;
-        const int w = valid ? (apply ? 3 : 1) : 0;
-        int incl = w;
+      // ---- the window's items -------------------------------------------------------------------------------------------------
+      const uint32_t key_right = (uint32_t)__shfl_down((int)key, 1, 64);
+      const uint32_t key0 = (uint32_t)__builtin_amdgcn_readlane((int)key, n > 0 ? e0 : 0);
+      const bool seg_end = valid && (lane == end_off - 1 || key_right != key);
+      const bool cont_left = key == key0 && prev_key == key;            // the window's first run began before it
+      const bool cont_right = lane == end_off - 1 && next_key == key;   // its last run goes on behind it
+      const bool apply = seg_end && !cont_left && !cont_right;
+      const int w = valid ? (apply ? 3 : 1) : 0;
+      int incl = w;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int t = __shfl_up(incl, d, 64);
-          if (lane >= d) incl += t;
-        }
-        const int pos = incl - w;
-        const int M = __builtin_amdgcn_readlane(incl, 63);
-        if (valid) {
-          const uint32_t kind = !seg_end || apply ? kItGrad : (cont_left ? kItGradHead : kItGradTail);
-          tab[pos] = (val << 4) | kind;
-          if (apply) { tab[pos + 1] = (key << 4) | kItParam; tab[pos + 2] = (key << 4) | kItSlot; }
-        }
-        wave_lds_sync();
-        // ---- the stream -------------------------------------------------------------------------------------------------------
-        const int ns = (M + IPI - 1) / IPI;                 // LDS-DMA instructions
-        auto issue = [&](int j, int slot) __attribute__((always_inline)) {
-          const int i = j * IPI + sub;
-          const uint32_t it = tab[i < kStreamItems ? i : kStreamItems - 1];
-          const uint32_t kind = it & 15u;
-          // (the three arrays as VALUE offsets from one base: a select between pointers is lowered to a table in scratch memory)
-          const long long off = (kind == kItParam ? off_table : (kind == kItSlot ? off_slot : 0ll)) + (long long)(it >> 4) * (LD * 4);
-          const char *const src = gradb + (i < M ? off : 0ll);                       // (lanes behind the stream's end re-read a hot line)
-          lds_dma16(src + piece * 16, ring_lds + (uint32_t)slot * 1024u);
-        };
-        V prow;                                             // the parameter row of the segment being finished
-        float *const pf = reinterpret_cast<float *>(&prow);
-#pragma unroll
-        for (int v = 0; v < VL; ++v) pf[v] = 0.f;
-        int issued = 0;
-        for (; issued < D - 1 && issued < ns; ++issued) issue(issued, issued);
-        bool drained = false;
-        int slot = 0, islot = issued % D;
-        for (int j = 0; j < ns; ++j) {
-          if (issued < ns) {
-            issue(issued, islot);
-            ++issued;
-            islot = islot + 1 == D ? 0 : islot + 1;
-            wait_vmcnt<D - 1>();
-          } else if (!drained) {
-            wait_vmcnt<0>();
-            drained = true;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+      }
+      const int pos = incl - w;
+      const int M = __builtin_amdgcn_readlane(incl, 63);
+      float sc = 0.f, sp = 0.f, ss = 0.f;                  // this touch's scalar; bias + slot of the row it finishes
+      if (valid) {
+        const uint32_t av = key < A.first_key[1] ? 0u : (key < A.first_key[2] ? 1u : 2u);
+        const uint32_t row = key - (av == 0 ? A.first_key[0] : (av == 1 ? A.first_key[1] : A.first_key[2]));
+        const uint32_t kind = 5u * av + (!seg_end || apply ? kItGrad : (cont_left ? kItGradHead : kItGradTail));
+        tab[pos] = (val << 4) | kind;
+        if (apply) { tab[pos + 1] = (row << 4) | (5u * av + kItParam); tab[pos + 2] = (row << 4) | (5u * av + kItSlot); }
+        const float *const sg = av == 0 ? A.sgrad[0] : (av == 1 ? A.sgrad[1] : A.sgrad[2]);
+        if (sg) {
+          sc = sg[val];
+          if (apply) {
+            sp = (av == 0 ? A.sparam[0] : (av == 1 ? A.sparam[1] : A.sparam[2]))[row];
+            ss = (av == 0 ? A.sslot[0] : (av == 1 ? A.sslot[1] : A.sslot[2]))[row];
           }
-          const float *const rows = ring + (size_t)slot * 256;
-          slot = slot + 1 == D ? 0 : slot + 1;
+        }
+      }
+      // (the scalars have LANDED before the first LDS-DMA goes out: used here, never waited for inside the loop)
+      asm volatile("" : "+v"(sc), "+v"(sp), "+v"(ss));
+      unsigned long long todo = __ballot(valid);            // the window's touches not yet folded (bit = lane)
+      int at_lane = 0;                                      // lane of the touch folded last
+      wave_lds_sync();
+      // ---- the stream ---------------------------------------------------------------------------------------------------------
+      const int ns = (M + IPI - 1) / IPI;                 // LDS-DMA instructions
+      auto issue = [&](int j, int slot) __attribute__((always_inline)) {
+        const int i = j * IPI + sub;
+        const uint32_t it = tab[i < kStreamItems ? i : kStreamItems - 1];
+        const long long off = offs[it & 15u] + (long long)(it >> 4) * (LD * 4);
+        const char *const src = origin + (i < M ? off : 0ll);                       // (lanes behind the stream's end re-read a hot line)
+        lds_dma16(src + piece * 16, ring_lds + (uint32_t)slot * 1024u);
+      };
+      V prow;                                             // the parameter row of the segment being finished
+      float *const pf = reinterpret_cast<float *>(&prow);
 #pragma unroll
-          for (int s = 0; s < IPI; ++s) {
-            const int i = j * IPI + s;
-            if (i < M) {
-              const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[i]);
-              const uint32_t kind = it & 15u;
-              const V row = *reinterpret_cast<const V *>(rows + s * LD + lane * VL);
-              const float *const rf = reinterpret_cast<const float *>(&row);
-              if (kind <= kItGradTail) {
+      for (int v = 0; v < VL; ++v) pf[v] = 0.f;
+      int issued = 0;
+      for (; issued < D - 1 && issued < ns; ++issued) issue(issued, issued);
+      bool drained = false;
+      int slot = 0, islot = issued % D;
+      for (int j = 0; j < ns; ++j) {
+        if (issued < ns) {
+          issue(issued, islot);
+          ++issued;
+          islot = islot + 1 == D ? 0 : islot + 1;
+          wait_vmcnt<D - 1>();
+        } else if (!drained) {
+          wait_vmcnt<0>();
+          drained = true;
+        }
+        const float *const rows = ring + (size_t)slot * 256;
+        slot = slot + 1 == D ? 0 : slot + 1;
 #pragma unroll
-                for (int v = 0; v < VL; ++v) accf[v] = fmaf(coef, rf[v], accf[v]);
-                if (kind == kItGradHead) {
-                  if (!all_inner) {
-                    *reinterpret_cast<V *>(S.phead + (size_t)g * LD + lane * VL) = acc;
-                    if (lane == 0) S.phs[g] = 0.f;
+        for (int s = 0; s < IPI; ++s) {
+          const int i = j * IPI + s;
+          if (i < M) {
+            const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[i]);
+            const uint32_t av = (it & 15u) / 5u, kind = (it & 15u) % 5u, idx = it >> 4;
+            const V row = *reinterpret_cast<const V *>(rows + s * LD + lane * VL);
+            const float *const rf = reinterpret_cast<const float *>(&row);
+            if (kind <= kItGradTail) {
+              const float coef = av == 0 ? A.coef[0] : (av == 1 ? A.coef[1] : A.coef[2]);
 #pragma unroll
-                    for (int v = 0; v < VL; ++v) accf[v] = 0.f;
-                  }
-                } else if (kind == kItGradTail) {
-                  *reinterpret_cast<V *>(S.ptail + (size_t)g * LD + lane * VL) = acc;
-                  if (lane == 0) S.pts[g] = 0.f;
+              for (int v = 0; v < VL; ++v) accf[v] = fmaf(coef, rf[v], accf[v]);
+              at_lane = __builtin_ctzll(todo);
+              todo &= todo - 1ull;
+              accs += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), at_lane));
+              if (kind == kItGradHead) {
+                if (!all_inner) {
+                  *reinterpret_cast<V *>(S.phead + (size_t)g * LD + lane * VL) = acc;
+                  if (lane == 0) S.phs[g] = accs;
 #pragma unroll
                   for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+                  accs = 0.f;
                 }
-              } else if (kind == kItParam) {
-                prow = row;
-              } else {
-                V slotv = row;
-                float *const sf = reinterpret_cast<float *>(&slotv);
-#pragma unroll
-                for (int v = 0; v < VL; ++v) pol.stream_update(fmaf(decay, pf[v], accf[v]), pf[v], sf[v]);
-                // (addresses rebuilt from integers: said to be GLOBAL ones, or the stores become flat_store — counted in lgkmcnt too
-                // and retired out of order)
-                const size_t off = (size_t)(it >> 4) * (LD * 4);
-                ((GV *)(uintptr_t)(tableb + off))[lane] = prow;
-                ((GV *)(uintptr_t)(slotb + off))[lane] = slotv;
+              } else if (kind == kItGradTail) {
+                *reinterpret_cast<V *>(S.ptail + (size_t)g * LD + lane * VL) = acc;
+                if (lane == 0) S.pts[g] = accs;
 #pragma unroll
                 for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+                accs = 0.f;
               }
+            } else if (kind == kItParam) {
+              prow = row;
+            } else {
+              V slotv = row;
+              float *const sf = reinterpret_cast<float *>(&slotv);
+#pragma unroll
+              for (int v = 0; v < VL; ++v) pol.stream_update(fmaf(decay, pf[v], accf[v]), pf[v], sf[v]);
+              // (addresses rebuilt from integers: said to be GLOBAL ones, or the stores become flat_store — counted in lgkmcnt too and
+              // retired out of order)
+              const long long roff = (long long)idx * (LD * 4);
+              ((GV *)(uintptr_t)(origin + offs[5u * av + kItParam] + roff))[lane] = prow;
+              ((GV *)(uintptr_t)(origin + offs[5u * av + kItSlot] + roff))[lane] = slotv;
+              float *const spar = av == 0 ? A.sparam[0] : (av == 1 ? A.sparam[1] : A.sparam[2]);
+              if (spar) {                                     // the row's scalar side: bias and slot came with the touch that finished it
+                float pb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sp), at_lane));
+                float ps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ss), at_lane));
+                pol.stream_update_scalar(accs, pb, ps);
+                if (lane == 0) { spar[idx] = pb; (av == 0 ? A.sslot[0] : (av == 1 ? A.sslot[1] : A.sslot[2]))[idx] = ps; }
+              }
+#pragma unroll
+              for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+              accs = 0.f;
             }
           }
         }
-        if (all_inner) *reinterpret_cast<V *>(comb + (size_t)wv * LD + lane * VL) = acc;
-      } else {
-        // the W2T / V tail of the list (scalar side-values, blanked touches) and its padding: the planned kernel's own fold
-        float4 acc4[1];
-        if (lane < G) {
-#ifndef DRX_STREAM_NO_SLOW
-          seg_fold_short<G, 1, CH, 2>(S, pol, g, lane, base + e0, n, prev_key, next_key, all_inner, acc4, accs);
-#endif
-          if (all_inner) store_row<G, 1>(comb, (size_t)wv, LD, lane, acc4);
-        }
       }
+      if (all_inner) *reinterpret_cast<V *>(comb + (size_t)wv * LD + lane * VL) = acc;
     }
     if (all_inner) {               // every chunk of this block is one whole run of the same segment: one partial for all of them
       float *const sc = comb + (size_t)CPB * LD;

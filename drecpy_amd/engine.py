@@ -131,8 +131,8 @@ class CdaeEngine:
         self._recorded = (History(ptr(ip), ptr(ix)), ip, ix)
 
     TRANSPOSE_MAX_NNZ, TRANSPOSE_MAX_ROWS = 1 << 27, 1 << 22
-    sample_by_user = os.environ.get('DRX_SAMPLE_BY_USER', '1') != '0'   # device-sampled batches in user order where the history's transpose exists
-    share_users = os.environ.get('DRX_SHARE_USERS', '1') != '0'         # include/drx.h DRX_BATCH_SHARE_USERS (the triples of one user share their gather and their gradient)
+    sample_by_user = True    # device-sampled batches in user order where the history's transpose exists (an attribute: A/B runs set it, bench.py --no-sample-by-user)
+    share_users = True       # include/drx.h DRX_BATCH_SHARE_USERS: the triples of one user share their gather and their gradient (bench.py --no-share-users)
 
     def set_history(self, indptr, indices, with_transpose=True):
         self.hist_indptr = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device) \
@@ -657,17 +657,29 @@ class StreamEvent:
 
 
 _RUN_AHEAD = {}
+# CUs of every XCD the run-ahead streams are confined to by default (0: the whole chip, high priority).
+PREP_CUS_PER_XCD = 0
 
 
-def _run_ahead_streams(dev, n):
-    """The n high-priority run-ahead streams of a device, created ONCE per process: every new torch stream is the next of a pool and the
-    runtime spreads streams over a handful of hardware queues — the second pipeline of a process (bench.py's `configs` block after the
-    headline run) got two streams that shared a queue and ran the ml-1m-shaped steps at 43 instead of 61 M triples/s (r03)."""
+def _run_ahead_streams(dev, n, cus_per_xcd=0):
+    """The n run-ahead streams of a device, created ONCE per process: every new torch stream is the next of a pool and the runtime
+    spreads streams over a handful of hardware queues — the second pipeline of a process (bench.py's `configs` block after the headline
+    run) got two streams that shared a queue and ran the ml-1m-shaped steps at 43 instead of 61 M triples/s (r03).
+    cus_per_xcd == 0: high-priority torch streams over the whole chip; > 0: streams confined to that many CUs of every XCD
+    (drx_stream_create_cu_slice: the preparation's launches queue for their slice instead of displacing training waves everywhere)."""
     dev = torch.device(dev)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (dev.type, index, int(cus_per_xcd))
     have = _RUN_AHEAD.setdefault(key, [])
     while len(have) < n:
-        have.append(torch.cuda.Stream(dev, priority=int(os.environ.get('DRX_SIDE_PRIORITY', -1))))
+        if cus_per_xcd > 0:
+            with torch.cuda.device(index):
+                h = lib().drx_stream_create_cu_slice(int(cus_per_xcd))
+            if not h:
+                raise _lib.DrxError(f'drx_stream_create_cu_slice({cus_per_xcd}) failed')
+            have.append(torch.cuda.ExternalStream(h, device=torch.device('cuda', index)))      # (lives as long as the process)
+        else:
+            have.append(torch.cuda.Stream(dev, priority=-1))
     return have[:n]
 
 
@@ -686,7 +698,7 @@ class SampledPipeline:
     column-sharded job take turns preparing the list for all — dist.ColumnShardedCdae."""
 
     def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, loss='bce', step_fn=None,
-                 prepare_fn=None, prep_ahead=3, deliver_fn=None):
+                 prepare_fn=None, prep_ahead=3, deliver_fn=None, side_streams=2, side_cus_per_xcd=None):
         self.eng, self.B, self.neg_ratio, self.q, self.loss = eng, int(batch_size), int(neg_ratio), float(q), loss
         # step_fn(s, bt, prepared, events, want_loss): what trains on a prepared batch (default: this engine's sparse step;
         # dist.ColumnShardedCdae.step for the column-sharded multi-GPU layout)
@@ -704,8 +716,8 @@ class SampledPipeline:
         # high priority: a normal stream may share a hardware queue with the training stream and inherit its barriers
         # TWO run-ahead streams, the work of step s on stream s % 2: a launch there mostly WAITS for room beside the training kernels
         # (DESIGN.md section 3), and the waits of two independent preparations overlap — step 0.355 -> 0.347 ms; a third stream gave
-        # nothing (r03ah).  DRX_SIDE_STREAMS overrides.
-        self.sides = _run_ahead_streams(dev, max(1, int(os.environ.get('DRX_SIDE_STREAMS', 2))))
+        # nothing (r03ah).  side_cus_per_xcd > 0: the streams are confined to a slice of the chip.
+        self.sides = _run_ahead_streams(dev, max(1, int(side_streams)), PREP_CUS_PER_XCD if side_cus_per_xcd is None else int(side_cus_per_xcd))
         self.side = self.sides[0]
         # what the run-ahead work reads (histories, tables' shapes) may still be in flight on the caller's stream — a history generated on
         # the device a moment ago (scripts/stamps.py hit this: the sampler read row pointers that were not written yet and faulted)
@@ -716,7 +728,7 @@ class SampledPipeline:
         self.D = D = max(1, int(prep_ahead))
         # batches are drawn one step before their list is prepared; two when lists are prepared far ahead (a draw then never
         # queues right behind a long preparation whose count the host is about to wait for)
-        self.SA = D + 1 if D == 1 else D + 2 + int(os.environ.get('DRX_SAMPLE_AHEAD_EXTRA', 0))
+        self.SA = D + 1 if D == 1 else D + 2
         self.RS, self.RP = self.SA + 1, D + 1                 # ring sizes: drawn batches, prepared lists
         # (allocated, not drawn: a draw queued HERE would run on the caller's stream beside the first run-ahead draws on the side
         # stream, sharing the sampler's scratch and these very tensors with them — r03: a batch whose row offsets belonged to another

@@ -137,6 +137,13 @@ int drx_event_record(void *ev, void *stream);
 int drx_stream_wait_event(void *stream, void *ev);
 int drx_event_synchronize(void *ev);
 
+/* A stream confined to a slice of the chip, for the run-ahead work that shares it with the training kernels (sampler, touch-list
+ * preparation): hipExtStreamCreateWithCUMask.  cus_per_xcd CUs of EVERY XCD (1 .. 32 on gfx950; mask bit i names CU i / 8 of XCD i % 8 —
+ * scripts/mb/mb_cumask.hip prints the census), taken from the top of each XCD's CUs.  The preparation's small launches then queue for
+ * THEIR CUs instead of displacing the training kernels' waves everywhere.  Returns NULL when the runtime refuses. */
+void *drx_stream_create_cu_slice(int32_t cus_per_xcd);
+void drx_stream_destroy(void *stream);
+
 /* 64-bit mix used for the counter-based corruption mask; exported so hosts/tests can reproduce it. */
 uint32_t drx_hash_u32(uint64_t seed, uint32_t a, uint32_t b);
 

@@ -232,6 +232,49 @@ def test_sparse_steps_with_hot_segments(K, opt, prepared):
 
 
 @pytest.mark.parametrize('prepared', [False, True])
+@pytest.mark.parametrize('K,users', [(128, 30000), (64, 30000), (256, 12000), (125, 30000)])
+def test_streamed_reduction_with_hot_rows_in_a_short_list(K, users, prepared):
+    """Lists of SHORT segments over rows of exactly 64 / 128 / 256 floats with Adagrad take the streamed reduction
+    (csrc/drx_segstream.hpp: one chunk per wave, its rows through an LDS ring by LDS-DMA).  A key space far wider than the batch
+    (30 000 users: fewer than 8 touches per table row, the rule of csrc/drx_prep.hpp) with 60 items under a steep Zipf law and hot
+    OUTPUT rows: W and W2T rows that collect hundreds of touches (block partials of all-inner blocks, head / tail partials, short and
+    long spans, the output bias's scalar sums) beside rows of a few, users that repeat (V rows through the list), blanked touches of
+    sole-toucher rows when the list is prepared ahead.  K = 125: rows padded to 128 floats.  Same oracle, same tolerance."""
+    U, N, B = users, 60, 768
+    eng, p, rng = _engine(U, N, K, seed=13)
+    indptr, indices = synth_history(rng, U, N, 12, zipf=1.4)
+    eng.set_history(indptr, indices)
+    eng.init_optimizer('adagrad', 0.05, 1e-3)
+    st = co.sparse_state(p, 'adagrad')
+    q = 0.2
+    qf = float(np.float32(q))
+    pool = rng.integers(0, U, size=40)
+    for step in range(4):
+        uids = np.concatenate([rng.integers(0, U, size=B - 64), rng.choice(pool[:6], size=64)])      # a few users many times
+        rng.shuffle(uids)
+        iids = np.minimum((rng.pareto(1.2, size=B)).astype(np.int64), N - 1)
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        t, keep_off, _ = batch_rows(indptr, indices, uids, N)
+        seed = 7100 + step
+        keep = np.concatenate([hash_u32(seed, np.full(keep_off[b + 1] - keep_off[b], b), np.arange(keep_off[b + 1] - keep_off[b])) >= q_threshold(q)
+                               for b in range(B)]).astype(np.uint8)
+        bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+        assert bt.n_touch_slots + 2 * B <= 8 * (2 * N + U)                        # short segments: the rule of csrc/drx_prep.hpp
+        _, _, kept = batch_rows(indptr, indices, uids, N, keep)
+        lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, 0.05, 1e-3, 'bce', 'adagrad')
+        lg = eng.step_sparse(step, bt, 'bce', want_loss=True, prepared=eng.prepare_sparse(bt) if prepared else None).cpu().numpy()
+        assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    probe = np.concatenate([pool[:6], rng.integers(0, U, size=58)])
+    tp, _, _ = batch_rows(indptr, indices, probe, N)
+    _, pred = eng.forward(probe)
+    _, po = co.forward(p, probe, tp.astype(np.float64))
+    assert _relerr(pred.cpu().numpy(), po) < REL
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('prepared', [False, True])
 def test_sparse_long_histories_take_the_workgroup_path(prepared):
     """Mean history of ~60 items, 48 triples: the forward/backward runs one WORKGROUP per triple (k_sampled_fwd_bwd_wg: its
     groups split the history, partial bags summed in LDS) — same oracle, same tolerance."""
