@@ -38,6 +38,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 L2_GATHER_GBS = 17000.0      # indexed rows shared by every workgroup, served by the XCDs' L2 (guide: 16.8-18.8 TB/s chip-wide)
 MALL_GATHER_GBS = 8600.0     # uniformly random rows of a 38 MB table, served by the Infinity Cache (guide: 8.6 TB/s)
+# What THIS chip delivered for the step's two access patterns free of any segment logic (scripts/mb/mb_rows.hip, mb_tlb.hip; logs:
+# profiles/r05_mb_rows_*.log, r05_mb_footprint.log): 512-byte rows gathered from a 33.5 MB buffer 7.3 - 7.9 TB/s; read-modify-write of
+# random 512-byte rows of tables far larger than the Infinity Cache, cold, 4.6 - 4.9 TB/s (whatever the table's size, 0.5 - 5 GB);
+# both in ONE launch took the SUM of their times.  `measured_reference` prices a kernel's bytes at these rates: context, not a bound.
+MB_GATHER_GBS = 7600.0
+MB_RMW_COLD_GBS = 4800.0
 K = 128
 Q = 0.2
 NEG_RATIO = 5
@@ -816,10 +822,13 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     may_share = bool(stepper is None and overlap and getattr(eng, '_hist_t', None) is not None and eng.share_users and 32 < K < 256)
     shared_run = may_share and int(batches[0][3][-1].item()) + 2 * B > 8 * (2 * N + (hi - lo))
     FWD = 'k_items_fwd_bwd' if shared_run else 'k_sampled_fwd_bwd'
+    # lists of SHORT segments over rows of exactly 64 / 128 / 256 floats, Adagrad: the streamed reduction (csrc/drx_segstream.hpp)
+    long_run = int(batches[0][3][-1].item()) + 2 * B > 8 * (2 * N + (hi - lo))              # csrc/drx_prep.hpp long_segments()
+    RED = 'k_seg_reduce_stream' if (stepper is None and args.optimizer == 'adagrad' and K in (64, 128, 256) and not long_run) else 'k_seg_reduce_planned'
     if stepper is None:
-        names = [FWD, 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', 'k_seg_reduce_planned(+bias partials)',
+        names = [FWD, 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', RED + '(+bias partials)',
                  'k_span_planned(short | long spans | bias update)', '(unused)']
-        dom, dom_ms, dom_alg = ('k_seg_reduce_planned', ph[2], alg_upd) if ph[2] >= ph[0] else (FWD, ph[0], alg_fwd)
+        dom, dom_ms, dom_alg = (RED, ph[2], alg_upd) if ph[2] >= ph[0] else (FWD, ph[0], alg_fwd)
     else:
         names = (['row_gather+row_exchange', 'k_shard_fwd_bwd', 'k_seg_reduce_planned<LocalPolicy>(+bias partials)',
                   'k_span_planned(+bias row)', 'grad_exchange+k_shard_apply(+bias update)'] if micro == 1 else
@@ -851,7 +860,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     kernel_hash = kernel_source_hash()
     # HBM traffic from the PMC passes (profiles/pmc_traffic.json), only when that profile was taken on this very workload AND on
     # these very kernel sources (scripts/profile_round.sh stores their hash); rocprofv3 cannot run inside the bench itself.
-    traffic_of, traffic_note = {}, 'no PMC profile for this workload'
+    traffic_of, hit_of, traffic_note = {}, {}, 'no PMC profile for this workload'
     pmc_name = 'pmc_traffic.json' if args.workload == 'synth-10m' else f'pmc_traffic_{args.workload}.json'
     try:
         with open(os.path.join(ROOT, 'profiles', pmc_name)) as f:
@@ -861,6 +870,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                 and m.get('optimizer', 'adagrad') == args.optimizer:
             if m.get('kernel_source_hash') == kernel_hash:
                 traffic_of = {k_.replace('drx::', ''): v['hbm_bytes_per_launch'] for k_, v in pmc['kernels'].items()}
+                hit_of = {k_.replace('drx::', ''): v['l2_hit_rate'] for k_, v in pmc['kernels'].items() if v.get('l2_hit_rate') is not None}
                 traffic_note = f"profiles/{pmc_name} ({m.get('round')}), same kernel sources ({kernel_hash})"
             else:
                 traffic_note = f"profiles/{pmc_name} is STALE: taken on kernel sources {m.get('kernel_source_hash')}, this tree is {kernel_hash}"
@@ -930,20 +940,32 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         bpl = dedup['bytes_per_launch']
         for kn in ('k_sampled_fwd_bwd', 'k_seg_reduce'):
             byt, occ, req, ms_ = bpl['necessary_' + kn], bpl[kn], bpl['requested_' + kn], ms_of[kn]
-            kname = FWD if kn != 'k_seg_reduce' else 'k_seg_reduce_planned'
+            kname = FWD if kn != 'k_seg_reduce' else RED
             rate = lambda b_: b_ / (ms_ * 1e-3) / 1e9
+            # cache level: the rows the kernel REQUESTS (one per occurrence / per touch) against ONE bound — the guide's two gather
+            # rates mixed by the L2 hit rate the counters measured on this kernel (TCC_HIT / TCC_MISS, the same profile script):
+            # hit x 17 TB/s (rows served by the XCDs' L2) + (1 - hit) x 8.6 TB/s (rows served by the Infinity Cache).  Quoted only with
+            # a profile of these very kernel sources; r04 printed the two rates as two "peaks", one of which the kernel exceeded.
+            hit = hit_of.get(kname)
+            bound = (hit * L2_GATHER_GBS + (1.0 - hit) * MALL_GATHER_GBS) if hit is not None else None
+            ref_ms = 1e3 * ((req - byt) / (MB_GATHER_GBS * 1e9) + byt / (MB_RMW_COLD_GBS * 1e9))
             per_kernel[kname] = {'bytes_per_launch': byt, 'avg_launch_ms': ms_, 'achieved': rate(byt), 'frac': rate(byt) / HBM_PEAK_GBS,
                                  'per_occurrence_bytes': occ, 'per_occurrence_frac': rate(occ) / HBM_PEAK_GBS,
                                  'traffic': traffic_of.get(kname),
                                  'traffic_frac': (rate(traffic_of[kname]) / HBM_PEAK_GBS) if kname in traffic_of else None,
-                                 # cache level: the rows the kernel REQUESTS (one per occurrence / per touch), against the guide's gather rates
-                                 'requested_bytes': req, 'requested_GBs': rate(req),
-                                 'requested_frac_of_l2_gather': rate(req) / L2_GATHER_GBS,
-                                 'requested_frac_of_infinity_cache': rate(req) / MALL_GATHER_GBS}
+                                 'requested_bytes': req, 'requested_GBs': rate(req), 'l2_hit_rate': hit, 'cache_bound_GBs': bound,
+                                 'requested_frac_of_cache_bound': (rate(req) / bound) if bound else None,
+                                 # context: the kernel's bytes priced at what micro-benchmarks of the two access patterns delivered
+                                 'measured_reference': {'cache_served_bytes': req - byt, 'hbm_bytes': byt, 'reference_ms': ref_ms,
+                                                        'time_over_reference': ms_ / ref_ms if ref_ms > 0 else None}}
         step_bytes = bpl['necessary_k_sampled_fwd_bwd'] + bpl['necessary_k_seg_reduce']
         step_occ = bpl['k_sampled_fwd_bwd'] + bpl['k_seg_reduce']
         step_req = bpl['requested_k_sampled_fwd_bwd'] + bpl['requested_k_seg_reduce']
-        step_traffic = sum(traffic_of.get(kn, 0.0) for kn in (FWD, 'k_seg_reduce_planned', 'k_span_planned')) or None
+        step_traffic = sum(traffic_of.get(kn, 0.0) for kn in (FWD, RED, 'k_span_planned')) or None
+        # the step's cache-level bound: its kernels' bounds weighted by the time each would need for its requested rows
+        step_bound = None
+        if all(per_kernel[kn_]['cache_bound_GBs'] for kn_ in per_kernel):
+            step_bound = step_req / sum(pk_['requested_bytes'] / pk_['cache_bound_GBs'] for pk_ in per_kernel.values())
         dk = per_kernel[dom]
         out['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['frac'],
@@ -960,22 +982,24 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
             'whole_step_per_occurrence_frac': step_occ / step_s / 1e9 / HBM_PEAK_GBS,
             'cache_resident': bpl['cache_resident'],
             'cache_level': {'requested_bytes_per_step': step_req, 'requested_GBs': step_req / step_s / 1e9,
-                            'frac_of_l2_gather': step_req / step_s / 1e9 / L2_GATHER_GBS, 'l2_gather_peak': L2_GATHER_GBS,
-                            'frac_of_infinity_cache': step_req / step_s / 1e9 / MALL_GATHER_GBS, 'infinity_cache_peak': MALL_GATHER_GBS,
+                            'bound_GBs': step_bound, 'frac_of_bound': (step_req / step_s / 1e9 / step_bound) if step_bound else None,
                             'note': 'rows the kernels request from L2 / Infinity Cache (one per occurrence, one gradient row per touch) over the '
-                                    'whole step; for a cache-resident model (MovieLens shapes) this, not HBM, is the binding traffic: peaks = '
-                                    'MI355X_MICROARCH.md "Indexed rows": rows shared by every workgroup 16.8-18.8 TB/s (L2), 38 MB table of '
-                                    'random rows 8.6 TB/s (Infinity Cache)'},
+                                    'whole step; for a cache-resident model (MovieLens shapes) this, not HBM, is the binding traffic.  ONE bound '
+                                    'per kernel: L2 hit rate (PMC, same kernel sources) x 17 TB/s + (1 - hit) x 8.6 TB/s (MI355X_MICROARCH.md '
+                                    '"Indexed rows"); the step\'s = its kernels\' weighted by the time their rows need; null without a profile'},
             'whole_step_traffic': step_traffic,
             'whole_step_traffic_frac': (step_traffic / step_s / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
-            'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
-            'model_whole_step_frac': step_alg / step_s / 1e9 / HBM_PEAK_GBS,
+            # (SURVEY 8d's per-occurrence read-modify-write model: the kernels merge occurrences first, so it is not a fraction — r01 - r04
+            # printed it beside the headline; kept for comparison with those rounds only)
+            'legacy': {'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,
+                       'model_whole_step_frac': step_alg / step_s / 1e9 / HBM_PEAK_GBS},
             'hbm_copy_achievable': copy_gbs,
             'definition': 'frac = STRICTLY NECESSARY HBM bytes (bench.py:byte_model: every gathered row once per DISTINCT row, dz1/g2 written once, one '
                           'read-modify-write of parameter + slots per DISTINCT row, 8 B per touch; everything re-read assumed cached) / HIP-event '
                           'launch time / 8 TB/s — never above traffic_frac; per_occurrence_* = one gather read per occurrence where the table '
                           'exceeds the 256 MiB Infinity Cache (the r01-r03 headline); traffic = PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; '
-                          'counts Infinity-Cache hits); requested_* = cache-level rows; model_* = SURVEY 8d per-occurrence read-modify-write bytes'}
+                          'counts Infinity-Cache hits); requested_* = cache-level rows against cache_bound_GBs (PMC L2 hit rate); measured_reference = '
+                          'the bytes at the rates scripts/mb/*.hip measured on this chip (gather 7.6 TB/s, cold read-modify-write 4.8 TB/s, no overlap)'}
     elif out.get('roofline') is None:
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
                            'traffic': None, 'model_bytes_per_launch': dom_alg, 'model_frac': achieved / HBM_PEAK_GBS,

@@ -53,23 +53,30 @@ def _events_ms(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-def _fit_steady(fit, n_short, n_long, reps=2):
-    """(seconds per step of the short fit() incl. set-up, seconds per step of the STEADY STATE): the steady state is the difference
-    of a long and a short fit() over the difference of their lengths, each taken as the FASTEST of `reps` runs (set-up jitter of
-    tens of milliseconds once made the difference of two single runs negative: r04a).  Never below 0: a floor of the long run's own
-    average / 4 keeps a noisy difference from reporting a rate no device step could reach."""
-    best = []
-    for n in (n_short, n_long):
-        ts = []
-        for _ in range(reps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            fit(n)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        best.append(min(ts))
-    steady = (best[1] - best[0]) / (n_long - n_short)
-    return best[0] / n_short, max(steady, best[1] / n_long / 4.0)
+def _fit_steady(fit, every, n_windows=6):
+    """(seconds per step of the whole fit() incl. set-up, seconds per step of the STEADY STATE, the windows' spread): ONE long fit() of
+    (n_windows + 1) * every one-batch epochs whose `epoch_callback_fn` (recommender_abc.py:222-226: every `epoch_callback_freq` epochs)
+    synchronises the device and stamps the host clock; the steady state is the MEDIAN of the n_windows fenced windows behind the
+    first stamp (the first `every` epochs carry the set-up and are not a window).  r01 - r04 took the difference of a long and a short
+    fit: at 50 - 170 us per step the two runs' set-up jitter was larger than what it measured (a "steady" rate
+    below the device step).  fit(n, callback, freq) runs the model's fit with those arguments."""
+    stamps = []
+
+    def cb(_model):
+        torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+        return {}
+    n = (n_windows + 1) * every
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fit(n, cb, every)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    w = np.diff(np.asarray(stamps[:n_windows + 1])) / every
+    if len(w) == 0:                                   # (a model whose fit ignored the callback: the whole run, set-up included)
+        return total / n, total / n, {'windows': 0}
+    return total / n, float(np.median(w)), {'windows': int(len(w)), 'every': every, 'window_ms_per_step_min': float(w.min() * 1e3),
+                                           'window_ms_per_step_max': float(w.max() * 1e3)}
 
 
 def dmf_block(ds, dev):
@@ -97,17 +104,19 @@ def dmf_block(ds, dev):
                 state['s'] += 1
             dev_s = _timed(step, 40)
             # the public call: set-up included, and the steady state between two lengths
-            e2e, steady = _fit_steady(lambda n: m.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5),
-                                      300, 1500 if B <= 256 else 900)
+            every = 400 if B <= 256 else 150
+            e2e, steady, spread = _fit_steady(lambda n, cb, fr: m.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5,
+                                                                      epoch_callback_fn=cb, epoch_callback_freq=fr), every)
             out[f'{name}_B{B}'] = {'step_ms': dev_s * 1e3, 'step_samples_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
-                                   'fit_steady_ms_per_step': steady * 1e3, 'fit_samples_per_s': B / steady}
+                                   'fit_steady_ms_per_step': steady * 1e3, 'fit_samples_per_s': B / steady, 'fit_windows': spread}
             # throughput mode: triples drawn and prepared on the device, one step ahead (a named deviation, like CDAE's and Caser's)
             md = cls(user_factors=[64, 32], item_factors=[64, 32], seed=10, verbose=False, device=str(dev))
             md.fit(ds, epochs=3, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5, device_sampler=True)
-            e2d, steady_d = _fit_steady(lambda n: md.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5,
-                                                         device_sampler=True), 300, 1500 if B <= 256 else 900)
+            e2d, steady_d, spread_d = _fit_steady(lambda n, cb, fr: md.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5,
+                                                                           device_sampler=True, epoch_callback_fn=cb, epoch_callback_freq=fr), every)
             out[f'{name}_B{B}_device_sampler'] = {'fit_ms_per_step_incl_setup': e2d * 1e3, 'fit_steady_ms_per_step': steady_d * 1e3,
-                                                  'fit_samples_per_s': B / steady_d, 'sampler': getattr(md, '_sampler_kind', None)}
+                                                  'fit_samples_per_s': B / steady_d, 'fit_windows': spread_d,
+                                                  'sampler': getattr(md, '_sampler_kind', None)}
     # the one MFMA kernel: all-pairs cosine scores of a block of users against every item (k_score_pairs_bf16)
     from drecpy_amd import _lib
     L = _lib.lib()
@@ -143,19 +152,21 @@ def caser_block(ds, dev):
             m._do_batch(batch, step=state['s'])
             state['s'] += 1
         dev_s = _timed(step, 30)
-        def fit_times(model, **kw):
-            """seconds per step of a 200-epoch fit() (set-up included) and of the steady state (a 600-epoch fit minus a 200-epoch one)"""
-            return _fit_steady(lambda n: model.fit(ds, epochs=n, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3, **kw), 200, 600)
-        e2e, steady = fit_times(m)
+        def fit_times(model, every, **kw):
+            """seconds per step of one long fit() (set-up included) and of its steady state (median of fenced windows: _fit_steady)"""
+            return _fit_steady(lambda n, cb, fr: model.fit(ds, epochs=n, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3,
+                                                           epoch_callback_fn=cb, epoch_callback_freq=fr, **kw), every)
+        e2e, steady, spread = fit_times(m, 60)
         out[f'Caser_B{B}'] = {'step_ms': dev_s * 1e3, 'step_windows_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
-                              'fit_steady_ms_per_step': steady * 1e3, 'fit_windows_per_s': B / steady,
+                              'fit_steady_ms_per_step': steady * 1e3, 'fit_windows_per_s': B / steady, 'fit_windows': spread,
                               'sampler': getattr(m, '_sampler_kind', 'reference-exact ListSampler stream (C++)')}
         # throughput mode: windows drawn on the device (a named deviation, like CDAE's device PointSampler)
         m2 = Caser(L=5, T=3, d=50, n_v=4, n_h=16, dropout_rate=0.5, seed=10, verbose=False, device=str(dev))
         m2.fit(ds, epochs=3, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3, device_sampler=True)
-        e2d, steady_d = fit_times(m2, device_sampler=True)
+        e2d, steady_d, spread_d = fit_times(m2, 120, device_sampler=True)
         out[f'Caser_B{B}_device_sampler'] = {'fit_ms_per_step_incl_setup': e2d * 1e3, 'fit_steady_ms_per_step': steady_d * 1e3,
-                                             'fit_windows_per_s': B / steady_d, 'sampler': getattr(m2, '_sampler_kind', None)}
+                                             'fit_windows_per_s': B / steady_d, 'fit_windows': spread_d,
+                                             'sampler': getattr(m2, '_sampler_kind', None)}
     return out
 
 
@@ -176,7 +187,7 @@ def configs_block(dev, run_direct, base_args, with_cpu=True):
             'value': r['value'], 'unit': 'samples/s', 'ms_per_step': r['ms_per_step'], 'batch': r['config']['batch_per_gpu'],
             'workload': r['config']['workload'], 'phases_ms': r['phases_ms'],
             'roofline': {k_: r['roofline'].get(k_) for k_ in ('kernel', 'frac', 'achieved', 'whole_step_frac', 'whole_step_per_occurrence_frac', 'kernels', 'cache_bytes_k_seg_reduce',
-                                                                        'cache_bytes_k_sampled_fwd_bwd', 'cache_resident', 'cache_level', 'traffic', 'traffic_source',
+                                                                        'cache_bytes_k_sampled_fwd_bwd', 'cache_resident', 'cache_level', 'traffic', 'traffic_source', 'row_counts',
                                                                         'whole_step_traffic', 'whole_step_traffic_frac')}
             if r.get('roofline') else None,
             'cpu_baseline': r.get('cpu_baseline')}

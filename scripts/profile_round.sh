@@ -21,14 +21,16 @@ cp $(find $OUT/kt_ml1m -name '*kernel_stats.csv' | head -1) $OUT/ml1m_sampled_ke
 # ... and its two PMC passes (`configs.cfg2...traffic` was null)
 timeout -k 5 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_ml1m -o f -- python3 $ROOT/bench.py --workload ml-1m --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_fetch_ml1m.err
 timeout -k 5 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_ml1m -o w -- python3 $ROOT/bench.py --workload ml-1m --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_write_ml1m.err
+timeout -k 5 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2_ml1m -o l2 -- python3 $ROOT/bench.py --workload ml-1m --steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-hr --no-configs > /dev/null 2> $OUT/pmc_l2_ml1m.err
 cd $ROOT
 find $OUT -name '*.csv' | head -20
 python profiles/pmc_l2.py $(find $OUT/pmc_l2 -name '*counter_collection.csv' | head -1) $OUT/pmc_l2_hit_rate.json
 python profiles/pmc_summary.py $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) $OUT/pmc_traffic_raw.json
-python profiles/pmc_make_traffic.py $OUT/pmc_traffic_raw.json $OUT/pmc_traffic.json $TAG
+python profiles/pmc_make_traffic.py $OUT/pmc_traffic_raw.json $OUT/pmc_traffic.json $TAG synth-10m 65536 adagrad $OUT/pmc_l2_hit_rate.json
 cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
 python profiles/pmc_summary.py $(find $OUT/pmc_fetch_ml1m -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write_ml1m -name '*counter_collection.csv' | head -1) $OUT/pmc_traffic_raw_ml1m.json
-python profiles/pmc_make_traffic.py $OUT/pmc_traffic_raw_ml1m.json $OUT/pmc_traffic_ml-1m.json $TAG ml-1m 65536
+python profiles/pmc_l2.py $(find $OUT/pmc_l2_ml1m -name '*counter_collection.csv' | head -1) $OUT/pmc_l2_hit_rate_ml1m.json
+python profiles/pmc_make_traffic.py $OUT/pmc_traffic_raw_ml1m.json $OUT/pmc_traffic_ml-1m.json $TAG ml-1m 65536 adagrad $OUT/pmc_l2_hit_rate_ml1m.json
 cp $OUT/pmc_traffic_ml-1m.json profiles/pmc_traffic_ml-1m.json
 python bench.py > $OUT/bench_with_traffic.json 2>> $OUT/bench.err     # the line as the driver will see it, quoting the PMC passes just taken
 grep -h "drx::" $(find $OUT/kt -name '*kernel_stats.csv' | head -1) | head -40 > $OUT/kernel_stats_drx.csv
