@@ -53,27 +53,36 @@ def _events_ms(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-def _fit_steady(fit, every, n_windows=6):
+def _fit_steady(model, fit, every, n_windows=6):
     """(seconds per step of the whole fit() incl. set-up, seconds per step of the STEADY STATE, the windows' spread): ONE long fit() of
-    (n_windows + 1) * every one-batch epochs whose `epoch_callback_fn` (recommender_abc.py:222-226: every `epoch_callback_freq` epochs)
-    synchronises the device and stamps the host clock; the steady state is the MEDIAN of the n_windows fenced windows behind the
-    first stamp (the first `every` epochs carry the set-up and are not a window).  r01 - r04 took the difference of a long and a short
-    fit: at 50 - 170 us per step the two runs' set-up jitter was larger than what it measured (a "steady" rate
-    below the device step).  fit(n, callback, freq) runs the model's fit with those arguments."""
-    stamps = []
+    (n_windows + 1) * every one-batch epochs; behind every `every`-th step the device is synchronised and the host clock stamped, and
+    the steady state is the MEDIAN of the n_windows fenced windows behind the first stamp (the first `every` epochs carry the set-up
+    and are not a window).  r01 - r04 took the difference of a long and a short fit: at 50 - 170 us per step the two runs' set-up
+    jitter was larger than what it measured (a "steady" rate below the device step).
+    The stamps ride on the model's own `_do_batch` (wrapped for the duration of the fit): fit()'s `epoch_callback_fn` only runs for
+    verbose fits and fits with an early-stopping rule (recommender_abc.py:207-214), both of which read the loss back every epoch."""
+    stamps, count = [], [0]
+    inner = model._do_batch
 
-    def cb(_model):
-        torch.cuda.synchronize()
-        stamps.append(time.perf_counter())
-        return {}
+    def stamped(batch_samples, **kw):
+        r = inner(batch_samples, **kw)
+        count[0] += 1
+        if count[0] % every == 0:
+            torch.cuda.synchronize()
+            stamps.append(time.perf_counter())
+        return r
     n = (n_windows + 1) * every
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fit(n, cb, every)
-    torch.cuda.synchronize()
-    total = time.perf_counter() - t0
+    model._do_batch = stamped
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fit(n)
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+    finally:
+        del model._do_batch                          # (the instance attribute: the class's method is back)
     w = np.diff(np.asarray(stamps[:n_windows + 1])) / every
-    if len(w) == 0:                                   # (a model whose fit ignored the callback: the whole run, set-up included)
+    if len(w) == 0:                                   # (a model that ran its loop natively: the whole run, set-up included)
         return total / n, total / n, {'windows': 0}
     return total / n, float(np.median(w)), {'windows': int(len(w)), 'every': every, 'window_ms_per_step_min': float(w.min() * 1e3),
                                            'window_ms_per_step_max': float(w.max() * 1e3)}
@@ -105,15 +114,14 @@ def dmf_block(ds, dev):
             dev_s = _timed(step, 40)
             # the public call: set-up included, and the steady state between two lengths
             every = 400 if B <= 256 else 150
-            e2e, steady, spread = _fit_steady(lambda n, cb, fr: m.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5,
-                                                                      epoch_callback_fn=cb, epoch_callback_freq=fr), every)
+            e2e, steady, spread = _fit_steady(m, lambda n: m.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5), every)
             out[f'{name}_B{B}'] = {'step_ms': dev_s * 1e3, 'step_samples_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
                                    'fit_steady_ms_per_step': steady * 1e3, 'fit_samples_per_s': B / steady, 'fit_windows': spread}
             # throughput mode: triples drawn and prepared on the device, one step ahead (a named deviation, like CDAE's and Caser's)
             md = cls(user_factors=[64, 32], item_factors=[64, 32], seed=10, verbose=False, device=str(dev))
             md.fit(ds, epochs=3, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5, device_sampler=True)
-            e2d, steady_d, spread_d = _fit_steady(lambda n, cb, fr: md.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5,
-                                                                           device_sampler=True, epoch_callback_fn=cb, epoch_callback_freq=fr), every)
+            e2d, steady_d, spread_d = _fit_steady(md, lambda n: md.fit(ds, epochs=n, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5,
+                                                                       device_sampler=True), every)
             out[f'{name}_B{B}_device_sampler'] = {'fit_ms_per_step_incl_setup': e2d * 1e3, 'fit_steady_ms_per_step': steady_d * 1e3,
                                                   'fit_samples_per_s': B / steady_d, 'fit_windows': spread_d,
                                                   'sampler': getattr(md, '_sampler_kind', None)}
@@ -154,8 +162,7 @@ def caser_block(ds, dev):
         dev_s = _timed(step, 30)
         def fit_times(model, every, **kw):
             """seconds per step of one long fit() (set-up included) and of its steady state (median of fenced windows: _fit_steady)"""
-            return _fit_steady(lambda n, cb, fr: model.fit(ds, epochs=n, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3,
-                                                           epoch_callback_fn=cb, epoch_callback_freq=fr, **kw), every)
+            return _fit_steady(model, lambda n: model.fit(ds, epochs=n, batch_size=B, learning_rate=5e-3, reg_rate=1e-6, neg_ratio=3, **kw), every)
         e2e, steady, spread = fit_times(m, 60)
         out[f'Caser_B{B}'] = {'step_ms': dev_s * 1e3, 'step_windows_per_s': B / dev_s, 'fit_ms_per_step_incl_setup': e2e * 1e3,
                               'fit_steady_ms_per_step': steady * 1e3, 'fit_windows_per_s': B / steady, 'fit_windows': spread,

@@ -33,11 +33,12 @@ class DMF(RecommenderABC):
         assert len(self.item_factors) > 0, 'The "item_factors" argument must have at least 1 element.'
         assert self.user_factors[-1] == self.item_factors[-1], \
             f'The last user and item factors dimension must be equal ({self.user_factors[-1]} != {self.item_factors[-1]})'
-        # the reference accepts any factor lists (dmf.py:22-44); here a hidden unit is a lane of one wavefront and a tower is
-        # unrolled over at most 4 layers: say so at construction, not at the first step
+        # the reference accepts any factor lists (dmf.py:22-44); here the hidden units of a layer are the lanes of one wavefront, two
+        # units per lane at most, and a tower is unrolled over at most 4 layers (examples/consistency_eval/dmf.py:20 builds [128, 64]):
+        # say so at construction, not at the first step
         for name, f in (('user_factors', self.user_factors), ('item_factors', self.item_factors)):
-            if len(f) > 4 or any((not isinstance(x, (int, np.integer))) or x < 1 or x > 64 for x in f):
-                raise Exception(f'drecpy_amd.DMF supports towers of 1..4 layers of width 1..64 (given: {name}={f}).')
+            if len(f) > 4 or any((not isinstance(x, (int, np.integer))) or x < 1 or x > 128 for x in f):
+                raise Exception(f'drecpy_amd.DMF supports towers of 1..4 layers of width 1..128 (given: {name}={f}).')
         self.use_nce = use_nce
         self.l2_norm_vectors = l2_norm_vectors
         self.device = device

@@ -1,6 +1,7 @@
 // DMF (DRecPy/Recommender/dmf.py) forward / backward on gfx950, plus the bf16-MFMA all-pairs cosine scorer.
 //
-// One wavefront per (user, item, target) triple, lane k = hidden unit (layer widths <= 64).  The first Dense layer of
+// One wavefront per (user, item, target) triple, lane k = hidden units k, k + 64, ... (NU = 1: layer widths <= 64 — the default towers
+// [64, 32]; NU = 2: widths <= 128 — examples/consistency_eval/dmf.py:20 builds [128, 64]).  The first Dense layer of
 // each tower acts on an l2-normalised sparse interaction row / column (dmf.py:75-86): it is an embedding bag over the
 // first-layer kernel rows (one coalesced row read per non-zero), not a [1,N]x[N,f] product.  Deeper layers are tiny
 // (64x32): activations are broadcast with wave shuffles, kernels read straight from L2.  Small-weight gradients are
@@ -58,18 +59,17 @@ inline int dmf_waves(int B) { return B <= 512 ? 16 : (B <= 2048 ? 8 : 4); }
 // an embedding bag.  The workgroup's WV waves take every WV-th block of 64 non-zeros, 8 kernel rows in flight each;
 // returns this wave's partial pre-activation of lane k (popular items have thousands of non-zeros: with one wave and
 // 4 loads in flight this loop was 60 % of a DMF step).
-template <bool TRAIN, int WV>
-__device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float &rho_in) {
+template <int WV, int NU>
+__device__ __forceinline__ void tower_gather(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float (&acc)[NU]) {
   const int id = T.ids[b];
   const int64_t s = T.indptr[id], e = T.indptr[id + 1];
   float q = 0.f;
   for (int64_t j = s + k; j < e; j += 64) { const float v = T.values[j]; q = fmaf(v, v, q); }
   q = group_sum<64>(q);
-  rho_in = D.l2_norm_vectors ? rsqrtf(fmaxf(q, kL2NEps)) : 1.0f;
+  const float rho_in = D.l2_norm_vectors ? rsqrtf(fmaxf(q, kL2NEps)) : 1.0f;
   const int f0 = D.f[tw][0];
-  const bool ok = k < f0;
-  float acc = 0.f;
-  const int base = TRAIN ? T.off[b] : 0;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[u] = 0.f;
   for (int64_t c = s + 64 * (int64_t)w; c < e; c += 64 * WV) {   // lanes fetch 64 (index, value) pairs, then broadcast them
     const int64_t j = c + k;
     int idx = 0;
@@ -77,35 +77,38 @@ __device__ __forceinline__ float tower_gather(const DrxDmfDims &D, int tw, const
     if (j < e) {
       idx = T.indices[j];
       v = T.values[j] * rho_in;
-      if (TRAIN) { T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v; }
     }
     const int n_here = (int)((e - c) < 64 ? (e - c) : 64);
-    for (int t = 0; t < n_here; t += 8) {
-      float r[8], vv[8];
+    constexpr int UF = 8 / NU;                        // kernel rows in flight
+    for (int t = 0; t < n_here; t += UF) {
+      float r[UF][NU], vv[UF];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < UF; ++u) {
         const int iu = __shfl(idx, t + u);
         vv[u] = (t + u < n_here) ? __shfl(v, t + u) : 0.f;
-        r[u] = (ok && t + u < n_here) ? T.K0[(size_t)iu * T.ld0 + k] : 0.f;
+#pragma unroll
+        for (int h = 0; h < NU; ++h) r[u][h] = (k + 64 * h < f0 && t + u < n_here) ? T.K0[(size_t)iu * T.ld0 + k + 64 * h] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc = fmaf(vv[u], r[u], acc);
+      for (int u = 0; u < UF; ++u)
+#pragma unroll
+        for (int h = 0; h < NU; ++h) acc[h] = fmaf(vv[u], r[u][h], acc[h]);
     }
   }
-  return acc;
 }
 
-// The same embedding bag with 16 lanes per kernel row (a float4 each): one load instruction of the wave fetches FOUR rows, one per
-// quarter-wave, so a non-zero costs a quarter of the loads and broadcasts of tower_gather.  Quarter r takes the non-zeros t with
-// t % 4 == r; the four partial sums are combined by two exchanges.  Writes this wave's partial pre-activations (column k at
-// out[k]) — the training path (k_dmf_gather).
-template <int WV>
+// The same embedding bag with 16 NU lanes per kernel row (a float4 each): one load instruction of the wave fetches 4 / NU rows, one per
+// part of the wave, so a non-zero costs a fraction of the loads and broadcasts of tower_gather.  Part r takes the non-zeros t with
+// t % (4 / NU) == r; the partial sums are combined by exchanges.  Writes this wave's partial pre-activations (column k at out[k]) —
+// the training path (k_dmf_gather).
+template <int WV, int NU>
 __device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out) {
+  constexpr int LPR = 16 * NU, RPW = 64 / LPR;      // lanes per kernel row, rows per load instruction
   const int id = T.ids[b];
   const int64_t s = T.indptr[id], e = T.indptr[id + 1];
   // (a popular item has thousands of non-zeros: forming the norm here, one load in flight per wave, was the kernel's tail)
   const float rho_in = T.rho ? T.rho[id] : row_rho(D, T.values, s, e, k);
-  const int r = k >> 4, c = k & 15;
+  const int r = k / LPR, c = k % LPR;
   const bool ok = 4 * c < T.ld0;
   float4 acc = f4_zero();
   const bool touches = T.tkeys != nullptr;          // (the scan update of the first layer needs none: k_dmf_k0_update)
@@ -120,12 +123,12 @@ __device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, cons
       if (touches) { T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v; }
     }
     const int n_here = (int)((e - c0) < 64 ? (e - c0) : 64);
-    for (int t = 0; t < n_here; t += 32) {
+    for (int t = 0; t < n_here; t += 8 * RPW) {
       float4 rowv[8];
       float vv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int tt = t + 4 * u + r;
+        const int tt = t + RPW * u + r;
         const int iu = __shfl(idx, tt & 63);
         const float vs = __shfl(v, tt & 63);
         const bool on = tt < n_here;
@@ -136,122 +139,105 @@ __device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, cons
       for (int u = 0; u < 8; ++u) f4_fma(acc, vv[u], rowv[u]);
     }
   }
-  acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
-  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) {
+    acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m); acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
+  }
   if (r == 0) *reinterpret_cast<float4 *>(out + 4 * c) = acc;
 }
 
-// Dense layers of one tower from the summed first-layer pre-activation; returns the final activation of lane k.  z[l], a[l]
-// keep pre/post activations.
-__device__ __forceinline__ float tower_dense(const DrxDmfDims &D, int tw, const float *sw, int k, float acc,
-                                             float (&zs)[kDmfMaxLayers], float (&as)[kDmfMaxLayers]) {
+// Dense layers of one tower from the summed first-layer pre-activation; returns the final activation of lane k's units.  zs[l], as[l]
+// keep pre/post activations.  Unit j of a layer lives on lane j % 64, slot j / 64.
+template <int NU>
+__device__ __forceinline__ void tower_dense(const DrxDmfDims &D, int tw, const float *sw, int k, const float (&acc)[NU],
+                                            float (&zs)[kDmfMaxLayers][NU], float (&as)[kDmfMaxLayers][NU], float (&out)[NU]) {
   const int nl = D.n_layers[tw];
   const int f0 = D.f[tw][0];
-  float z = k < f0 ? acc + sw[D.off_b[tw][0] + k] : 0.f;
-  float a = fmaxf(z, 0.f);
-  zs[0] = z; as[0] = a;
+  float a[NU];
+#pragma unroll
+  for (int h = 0; h < NU; ++h) {
+    const float z = k + 64 * h < f0 ? acc[h] + sw[D.off_b[tw][0] + k + 64 * h] : 0.f;
+    a[h] = fmaxf(z, 0.f);
+    zs[0][h] = z; as[0][h] = a[h];
+  }
 #pragma unroll
   for (int l = 1; l < kDmfMaxLayers; ++l) {
     if (l >= nl) break;
     const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
-    float zz = k < fo ? sw[D.off_b[tw][l] + k] : 0.f;
-    for (int j = 0; j < fin; ++j) {
-      const float aj = lane_value(a, j);
-      if (k < fo) zz = fmaf(aj, sw[D.off_k[tw][l] + j * fo + k], zz);
-    }
-    z = zz; a = fmaxf(zz, 0.f);
-    zs[l] = z; as[l] = a;
-  }
-  return a;
-}
-
-// Backward of one tower given dr = dL/d(final activation) on lane k; accumulates small-weight gradients in LDS.
-__device__ __forceinline__ void tower_bwd(const DrxDmfDims &D, int tw, const TowerIO &T, const float *sw, float *gsw, int b, int k,
-                                          const float (&zs)[kDmfMaxLayers], const float (&as)[kDmfMaxLayers], float da) {
-  const int nl = D.n_layers[tw];
+    float zz[NU];
 #pragma unroll
-  for (int l = kDmfMaxLayers - 1; l >= 1; --l) {
-    if (l >= nl) continue;
-    const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
-    const float dz = (k < fo && zs[l] > 0.f) ? da : 0.f;
-    if (k < fo) gsw[D.off_b[tw][l] + k] += dz;
-    float dprev = 0.f;
-    for (int j = 0; j < fin; ++j) {
-      const float aj = lane_value(as[l - 1], j);
-      if (k < fo) { const int w = D.off_k[tw][l] + j * fo + k; gsw[w] = fmaf(aj, dz, gsw[w]); }
+    for (int h = 0; h < NU; ++h) zz[h] = k + 64 * h < fo ? sw[D.off_b[tw][l] + k + 64 * h] : 0.f;
+#pragma unroll
+    for (int hj = 0; hj < NU; ++hj) {
+      const int jn = min(64, fin - 64 * hj);
+      for (int j = 0; j < jn; ++j) {
+        const float aj = lane_value(a[hj], j);
+#pragma unroll
+        for (int h = 0; h < NU; ++h)
+          if (k + 64 * h < fo) zz[h] = fmaf(aj, sw[D.off_k[tw][l] + (64 * hj + j) * fo + k + 64 * h], zz[h]);
+      }
     }
-    // da_{l-1}[j] = sum_k dz[k] * K[j][k] : lane j walks its kernel row
-    for (int kk = 0; kk < fo; ++kk) {
-      const float dzk = lane_value(dz, kk);
-      if (k < fin) dprev = fmaf(dzk, sw[D.off_k[tw][l] + k * fo + kk], dprev);
-    }
-    da = dprev;
+#pragma unroll
+    for (int h = 0; h < NU; ++h) { a[h] = fmaxf(zz[h], 0.f); zs[l][h] = zz[h]; as[l][h] = a[h]; }
   }
-  const int f0 = D.f[tw][0];
-  const float dz0 = (k < f0 && zs[0] > 0.f) ? da : 0.f;
-  if (k < f0) gsw[D.off_b[tw][0] + k] += dz0;
-  if (k < T.ld0) T.dz0[(size_t)b * T.ld0 + k] = k < f0 ? dz0 : 0.f;
+#pragma unroll
+  for (int h = 0; h < NU; ++h) out[h] = a[h];
 }
 
-template <bool TRAIN, int WV>
-__global__ __launch_bounds__(64 * WV) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
-  extern __shared__ __align__(16) float lds[];       // [2][WV][64] first-layer partials, then gsw [n_small] (TRAIN)
+// the sample's cosine from its towers' outputs (l2_normalize each, dot): shared by the predict kernel and the training step
+template <int NU>
+__device__ __forceinline__ float wave_sum_units(const float (&x)[NU], const float (&y)[NU]) {
+  float t = 0.f;
+#pragma unroll
+  for (int h = 0; h < NU; ++h) t = fmaf(x[h], y[h], t);
+  return group_sum<64>(t);
+}
+
+// drx_dmf_predict: one workgroup per pair — its WV waves gather the two sparse first layers together, one of them runs the dense
+// layers and the cosine.  (r01's training step had this shape too; r02 split it into the three kernels below.)
+template <int WV, int NU>
+__global__ __launch_bounds__(64 * WV) void k_dmf_predict(DrxDmfDims D, DrxDmfArgs A) {
+  extern __shared__ __align__(16) float lds[];       // [2][WV][64 NU] first-layer partials
+  constexpr int W = 64 * NU;
   float *part = lds;
-  float *gsw = lds + 2 * WV * 64;
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (TRAIN)
-    for (int i = threadIdx.x; i < D.n_small; i += 64 * WV) gsw[i] = 0.f;
   TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
-  float loss_acc = 0.f;
-  const float inv_b = 1.0f / (float)A.B;
-  __syncthreads();
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
-    float rin_u, rin_i;
-    part[(0 * WV + w) * 64 + k] = tower_gather<TRAIN, WV>(D, 0, Tu, b, k, w, rin_u);
-    part[(1 * WV + w) * 64 + k] = tower_gather<TRAIN, WV>(D, 1, Ti, b, k, w, rin_i);
-    __syncthreads();
-    if (w == 0) {                                    // one wave finishes the sample: dense layers, loss, backward
-      float pu = 0.f, pi = 0.f;
+    float gu[NU], gi[NU];
+    tower_gather<WV, NU>(D, 0, Tu, b, k, w, gu);
+    tower_gather<WV, NU>(D, 1, Ti, b, k, w, gi);
 #pragma unroll
-      for (int ww = 0; ww < WV; ++ww) { pu += part[(0 * WV + ww) * 64 + k]; pi += part[(1 * WV + ww) * 64 + k]; }
-      float zu[kDmfMaxLayers], au[kDmfMaxLayers], zi[kDmfMaxLayers], ai[kDmfMaxLayers];
-      const float ru = tower_dense(D, 0, A.sw, k, pu, zu, au);
-      const float ri = tower_dense(D, 1, A.sw, k, pi, zi, ai);
-      const float qu = group_sum<64>(ru * ru), qi = group_sum<64>(ri * ri);
+    for (int h = 0; h < NU; ++h) { part[(0 * WV + w) * W + k + 64 * h] = gu[h]; part[(1 * WV + w) * W + k + 64 * h] = gi[h]; }
+    __syncthreads();
+    if (w == 0) {                                    // one wave finishes the sample: dense layers, cosine
+      float pu[NU], pi[NU];
+#pragma unroll
+      for (int h = 0; h < NU; ++h) {
+        pu[h] = 0.f; pi[h] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WV; ++ww) { pu[h] += part[(0 * WV + ww) * W + k + 64 * h]; pi[h] += part[(1 * WV + ww) * W + k + 64 * h]; }
+      }
+      float zu[kDmfMaxLayers][NU], au[kDmfMaxLayers][NU], zi[kDmfMaxLayers][NU], ai[kDmfMaxLayers][NU], ru[NU], ri[NU];
+      tower_dense<NU>(D, 0, A.sw, k, pu, zu, au, ru);
+      tower_dense<NU>(D, 1, A.sw, k, pi, zi, ai, ri);
+      const float qu = wave_sum_units<NU>(ru, ru), qi = wave_sum_units<NU>(ri, ri);
       const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
-      const float nu = ru * rhou, ni = ri * rhoi;
-      const float s = group_sum<64>(nu * ni);
+      float nu[NU], ni[NU];
+#pragma unroll
+      for (int h = 0; h < NU; ++h) { nu[h] = ru[h] * rhou; ni[h] = ri[h] * rhoi; }
+      const float s = wave_sum_units<NU>(nu, ni);
       const float cosv = fmaxf(1e-6f, s);
       // optional registered scalar multiplying every prediction (examples/extending_recommender_dmf.py:9-18)
       const float wsc = D.off_scale >= 0 ? A.sw[D.off_scale] : 1.0f;
-      const float pred = wsc * cosv;
-      if (!TRAIN) {
-        if (k == 0 && A.pred_out) A.pred_out[b] = pred;
-        if (A.rep_u_out) A.rep_u_out[(size_t)b * 64 + k] = nu;       // l2-normalised representations (zero beyond f_last)
-        if (A.rep_i_out) A.rep_i_out[(size_t)b * 64 + k] = ni;
-      } else {
-        // target_mode 1: Keras BCE of (B,) targets against (B,1) predictions broadcasts to (B,B); its mean equals the BCE
-        // against the batch-mean target because the element is affine in t
-        const float y = A.target_mode == 1 ? (A.y_mean_dev ? A.y_mean_dev[0] : A.y_mean) : A.y[b];
-        loss_acc += bce_elem(y, pred);
-        const float gp = bce_grad(y, pred) * inv_b;
-        if (D.off_scale >= 0 && k == 0) gsw[D.off_scale] = fmaf(gp, cosv, gsw[D.off_scale]);
-        const float ds = s > 1e-6f ? gp * wsc : 0.f;
-        // l2_normalize backward (tf.nn.l2_normalize: x * rsqrt(max(sum x^2, eps)))
-        const float dnu = ds * ni, dni = ds * nu;
-        const float du = group_sum<64>(nu * dnu), di = group_sum<64>(ni * dni);
-        const float dru = qu > kL2NEps ? rhou * (dnu - nu * du) : rhou * dnu;
-        const float dri = qi > kL2NEps ? rhoi * (dni - ni * di) : rhoi * dni;
-        tower_bwd(D, 0, Tu, A.sw, gsw, b, k, zu, au, dru);
-        tower_bwd(D, 1, Ti, A.sw, gsw, b, k, zi, ai, dri);
+      if (k == 0 && A.pred_out) A.pred_out[b] = wsc * cosv;
+#pragma unroll
+      for (int h = 0; h < NU; ++h) {                 // l2-normalised representations (zero beyond f_last), rows of 64 NU floats
+        if (A.rep_u_out) A.rep_u_out[(size_t)b * W + k + 64 * h] = nu[h];
+        if (A.rep_i_out) A.rep_i_out[(size_t)b * W + k + 64 * h] = ni[h];
       }
     }
     __syncthreads();                                 // the partials are free for the next sample
-  }
-  if (TRAIN) {
-    for (int i = threadIdx.x; i < D.n_small; i += 64 * WV) A.gsw_part[(size_t)blockIdx.x * D.n_small + i] = gsw[i];
-    if (threadIdx.x == 0) A.loss_part[blockIdx.x] = loss_acc * inv_b;
   }
 }
 
@@ -265,43 +251,57 @@ __global__ __launch_bounds__(64 * WV) void k_dmf(DrxDmfDims D, DrxDmfArgs A) {
 //                  layer's activation and pre-activation gradient rows — no shared accumulators, no barrier between samples
 //   k_dmf_wgrad    the small-weight gradients as what they are, tiny products dW_l = A_{l-1}^T DZ_l (and column sums for the
 //                  biases), over fixed chunks of the batch in sample order -> partial rows for k_sum_partials2
-// work area (caller's, drx_dmf_work_bytes): z0 [2][B][64] | act [2][B][4][64] | dz [2][B][4][64] | samp [B][2] (loss, d scale)
+// work area (caller's, drx_dmf_work_bytes): z0 [2][B][W] | act [2][B][4][W] | dz [2][B][4][W] | samp [B][2] (loss, d scale), W = 64 unit slots
 struct DmfWork {
   float *z0, *act, *dz, *samp;
+  int W;                       // floats per row of z0 / act / dz: 64 per unit slot of a lane
 };
-__host__ __device__ inline DmfWork dmf_work(float *base, int B) {
-  DmfWork W;
-  W.z0 = base;
-  W.act = W.z0 + (size_t)2 * B * 64;
-  W.dz = W.act + (size_t)2 * B * kDmfMaxLayers * 64;
-  W.samp = W.dz + (size_t)2 * B * kDmfMaxLayers * 64;
-  return W;
+__host__ __device__ inline int dmf_units(const DrxDmfDims &D) {      // unit slots per lane: 1 (widths <= 64) or 2 (<= 128)
+  int m = 0;
+  for (int tw = 0; tw < 2; ++tw) {
+    for (int l = 0; l < D.n_layers[tw]; ++l) m = D.f[tw][l] > m ? D.f[tw][l] : m;
+    m = D.ld0[tw] > m ? D.ld0[tw] : m;
+  }
+  return m > 64 ? 2 : 1;
+}
+__host__ __device__ inline DmfWork dmf_work(float *base, int B, int W) {
+  DmfWork Wk;
+  Wk.W = W;
+  Wk.z0 = base;
+  Wk.act = Wk.z0 + (size_t)2 * B * W;
+  Wk.dz = Wk.act + (size_t)2 * B * kDmfMaxLayers * W;
+  Wk.samp = Wk.dz + (size_t)2 * B * kDmfMaxLayers * W;
+  return Wk;
 }
 
-template <int WV>
+template <int WV, int NU>
 __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs A) {
   // one workgroup per DISTINCT user / item of the batch: the first layer of a tower depends on the id alone, and a batch of 4096
   // pairs over 6040 users / 3706 items repeats ids a lot (popular items above all, whose columns are the long ones)
-  __shared__ __align__(16) float part[WV * 64];
+  constexpr int W = 64 * NU;
+  __shared__ __align__(16) float part[WV * W];
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const DmfWork Wk = dmf_work(A.work, A.B);
+  const DmfWork Wk = dmf_work(A.work, A.B, W);
   TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
   Tu.rho = A.rho_u; Ti.rho = A.rho_i;
   const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du, total = n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
   for (int it = blockIdx.x; it < total; it += gridDim.x) {
     const int tw = it < n_du ? 0 : 1, d = tw ? it - n_du : it;
-    if (tw) tower_gather_q<WV>(D, 1, Ti, d, k, w, part + w * 64); else tower_gather_q<WV>(D, 0, Tu, d, k, w, part + w * 64);
+    if (tw) tower_gather_q<WV, NU>(D, 1, Ti, d, k, w, part + w * W); else tower_gather_q<WV, NU>(D, 0, Tu, d, k, w, part + w * W);
     if (A.map_u && threadIdx.x == 0) {               // for k_dmf_k0_update: which distinct index this id has in THIS step
       const int id = tw ? A.iid[d] : A.uid[d];
       (tw ? A.map_i : A.map_u)[id] = ((unsigned long long)A.stamp << 32) | (unsigned long long)(uint32_t)d;
     }
     __syncthreads();
     if (w == 0) {                                    // partials summed in wave order
-      float p = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < WV; ++ww) p += part[ww * 64 + k];
-      Wk.z0[((size_t)tw * A.B + d) * 64 + k] = p;
+      for (int h = 0; h < NU; ++h) {
+        float p = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WV; ++ww) p += part[ww * W + k + 64 * h];
+        Wk.z0[((size_t)tw * A.B + d) * W + k + 64 * h] = p;
+      }
     }
     __syncthreads();
   }
@@ -309,18 +309,20 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
 
 // dz0 of a distinct id = sum of the first-layer pre-activation gradients of the samples that carry it, in sample order (gptr / grows =
 // CSR of samples per distinct id): the scatter then runs over the touches of DISTINCT ids.
-__global__ __launch_bounds__(256) void k_dmf_dzsum(DrxDmfDims D, DrxDmfArgs A) {
+__global__ __launch_bounds__(256) void k_dmf_dzsum(DrxDmfDims D, DrxDmfArgs A, int W) {
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const DmfWork Wk = dmf_work(A.work, A.B);
+  const DmfWork Wk = dmf_work(A.work, A.B, W);
   const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du, total = n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
   for (int it = blockIdx.x * 4 + w; it < total; it += gridDim.x * 4) {
     const int tw = it < n_du ? 0 : 1, d = tw ? it - n_du : it;
     const int32_t *gp = tw ? A.gptr_i : A.gptr_u, *gr = tw ? A.grows_i : A.grows_u;
-    float acc = 0.f;
-    for (int q = gp[d]; q < gp[d + 1]; ++q) acc += Wk.dz[((size_t)tw * A.B + gr[q]) * kDmfMaxLayers * 64 + k];
     const int ld0 = D.ld0[tw];
     float *out = tw ? A.dz0i : A.dz0u;
-    if (k < ld0) out[(size_t)d * ld0 + k] = acc;
+    for (int kk = k; kk < ld0; kk += 64) {
+      float acc = 0.f;
+      for (int q = gp[d]; q < gp[d + 1]; ++q) acc += Wk.dz[((size_t)tw * A.B + gr[q]) * kDmfMaxLayers * W + kk];
+      out[(size_t)d * ld0 + kk] = acc;
+    }
   }
 }
 
@@ -434,75 +436,109 @@ __global__ __launch_bounds__(256) void k_dmf_k0_update(DrxDmfDims D, DrxDmfArgs 
   }
 }
 
-// Backward of one tower given da = dL/d(final activation) on lane k: stores dz_l rows (and leaves the activations stored by the
+// Backward of one tower given da = dL/d(final activation) on lane k's units: stores dz_l rows (and leaves the activations stored by the
 // forward) for k_dmf_wgrad, the first layer's dz0 row for the scatter.
-__device__ __forceinline__ void tower_bwd_store(const DrxDmfDims &D, int tw, const TowerIO &T, const float *sw, float *dzrow /* [4][64] */,
-                                                int b, int k, const float (&zs)[kDmfMaxLayers], float da) {
+template <int NU>
+__device__ __forceinline__ void tower_bwd_store(const DrxDmfDims &D, int tw, const float *sw, float *dzrow /* [4][64 NU] */, int k,
+                                                const float (&zs)[kDmfMaxLayers][NU], const float (&da_in)[NU]) {
+  constexpr int W = 64 * NU;
   const int nl = D.n_layers[tw];
+  float da[NU];
+#pragma unroll
+  for (int h = 0; h < NU; ++h) da[h] = da_in[h];
 #pragma unroll
   for (int l = kDmfMaxLayers - 1; l >= 1; --l) {
     if (l >= nl) continue;
     const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
-    const float dz = (k < fo && zs[l] > 0.f) ? da : 0.f;
-    dzrow[l * 64 + k] = dz;
-    float dprev = 0.f;
-    for (int kk = 0; kk < fo; ++kk) {                // da_{l-1}[j] = sum_k dz[k] * K[j][k] : lane j walks its kernel row
-      const float dzk = lane_value(dz, kk);
-      if (k < fin) dprev = fmaf(dzk, sw[D.off_k[tw][l] + k * fo + kk], dprev);
+    float dz[NU], dprev[NU];
+#pragma unroll
+    for (int h = 0; h < NU; ++h) {
+      dz[h] = (k + 64 * h < fo && zs[l][h] > 0.f) ? da[h] : 0.f;
+      dzrow[l * W + k + 64 * h] = dz[h];
+      dprev[h] = 0.f;
     }
-    da = dprev;
+#pragma unroll
+    for (int hk = 0; hk < NU; ++hk) {                // da_{l-1}[j] = sum_k dz[k] * K[j][k] : lane j walks its kernel rows
+      const int kn = min(64, fo - 64 * hk);
+      for (int kk = 0; kk < kn; ++kk) {
+        const float dzk = lane_value(dz[hk], kk);
+#pragma unroll
+        for (int h = 0; h < NU; ++h)
+          if (k + 64 * h < fin) dprev[h] = fmaf(dzk, sw[D.off_k[tw][l] + (k + 64 * h) * fo + 64 * hk + kk], dprev[h]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NU; ++h) da[h] = dprev[h];
   }
   const int f0 = D.f[tw][0];
-  const float dz0 = (k < f0 && zs[0] > 0.f) ? da : 0.f;
-  dzrow[k] = dz0;                                   // (zero beyond f0; k_dmf_dzsum folds these rows per distinct id)
-  (void)T; (void)b;
+#pragma unroll
+  for (int h = 0; h < NU; ++h)                       // (zero beyond f0; k_dmf_dzsum folds these rows per distinct id)
+    dzrow[k + 64 * h] = (k + 64 * h < f0 && zs[0][h] > 0.f) ? da[h] : 0.f;
 }
 
+template <int NU>
 __global__ __launch_bounds__(256) void k_dmf_dense(DrxDmfDims D, DrxDmfArgs A) {
   extern __shared__ __align__(16) float swl[];       // [n_small] the small weights
+  constexpr int W = 64 * NU;
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < D.n_small; i += 256) swl[i] = A.sw[i];
   __syncthreads();
-  const DmfWork Wk = dmf_work(A.work, A.B);
-  TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
-  TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
+  const DmfWork Wk = dmf_work(A.work, A.B, W);
   const float inv_b = 1.0f / (float)A.B;
   for (int b = blockIdx.x * 4 + w; b < A.B; b += gridDim.x * 4) {
-    const float pu = Wk.z0[((size_t)0 * A.B + A.inv_u[b]) * 64 + k], pi = Wk.z0[((size_t)1 * A.B + A.inv_i[b]) * 64 + k];
-    float zu[kDmfMaxLayers], au[kDmfMaxLayers], zi[kDmfMaxLayers], ai[kDmfMaxLayers];
-    const float ru = tower_dense(D, 0, swl, k, pu, zu, au);
-    const float ri = tower_dense(D, 1, swl, k, pi, zi, ai);
-    float *actu = Wk.act + ((size_t)0 * A.B + b) * kDmfMaxLayers * 64, *acti = Wk.act + ((size_t)1 * A.B + b) * kDmfMaxLayers * 64;
+    float pu[NU], pi[NU];
+#pragma unroll
+    for (int h = 0; h < NU; ++h) {
+      pu[h] = Wk.z0[((size_t)0 * A.B + A.inv_u[b]) * W + k + 64 * h];
+      pi[h] = Wk.z0[((size_t)1 * A.B + A.inv_i[b]) * W + k + 64 * h];
+    }
+    float zu[kDmfMaxLayers][NU], au[kDmfMaxLayers][NU], zi[kDmfMaxLayers][NU], ai[kDmfMaxLayers][NU], ru[NU], ri[NU];
+    tower_dense<NU>(D, 0, swl, k, pu, zu, au, ru);
+    tower_dense<NU>(D, 1, swl, k, pi, zi, ai, ri);
+    float *actu = Wk.act + ((size_t)0 * A.B + b) * kDmfMaxLayers * W, *acti = Wk.act + ((size_t)1 * A.B + b) * kDmfMaxLayers * W;
 #pragma unroll
     for (int l = 0; l < kDmfMaxLayers; ++l) {
-      if (l < D.n_layers[0]) actu[l * 64 + k] = au[l];
-      if (l < D.n_layers[1]) acti[l * 64 + k] = ai[l];
+#pragma unroll
+      for (int h = 0; h < NU; ++h) {
+        if (l < D.n_layers[0]) actu[l * W + k + 64 * h] = au[l][h];
+        if (l < D.n_layers[1]) acti[l * W + k + 64 * h] = ai[l][h];
+      }
     }
-    const float qu = group_sum<64>(ru * ru), qi = group_sum<64>(ri * ri);
+    const float qu = wave_sum_units<NU>(ru, ru), qi = wave_sum_units<NU>(ri, ri);
     const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
-    const float nu = ru * rhou, ni = ri * rhoi;
-    const float s = group_sum<64>(nu * ni);
+    float nu[NU], ni[NU];
+#pragma unroll
+    for (int h = 0; h < NU; ++h) { nu[h] = ru[h] * rhou; ni[h] = ri[h] * rhoi; }
+    const float s = wave_sum_units<NU>(nu, ni);
     const float cosv = fmaxf(1e-6f, s);
     const float wsc = D.off_scale >= 0 ? swl[D.off_scale] : 1.0f;
     const float pred = wsc * cosv;
+    // target_mode 1: Keras BCE of (B,) targets against (B,1) predictions broadcasts to (B,B); its mean equals the BCE against the
+    // batch-mean target because the element is affine in t
     const float y = A.target_mode == 1 ? (A.y_mean_dev ? A.y_mean_dev[0] : A.y_mean) : A.y[b];
     const float gp = bce_grad(y, pred) * inv_b;
     if (k == 0) { Wk.samp[(size_t)b * 2] = bce_elem(y, pred); Wk.samp[(size_t)b * 2 + 1] = gp * cosv; }
     const float ds = s > 1e-6f ? gp * wsc : 0.f;
-    const float dnu = ds * ni, dni = ds * nu;
-    const float du = group_sum<64>(nu * dnu), di = group_sum<64>(ni * dni);
-    const float dru = qu > kL2NEps ? rhou * (dnu - nu * du) : rhou * dnu;
-    const float dri = qi > kL2NEps ? rhoi * (dni - ni * di) : rhoi * dni;
-    tower_bwd_store(D, 0, Tu, swl, Wk.dz + ((size_t)0 * A.B + b) * kDmfMaxLayers * 64, b, k, zu, dru);
-    tower_bwd_store(D, 1, Ti, swl, Wk.dz + ((size_t)1 * A.B + b) * kDmfMaxLayers * 64, b, k, zi, dri);
+    // l2_normalize backward (tf.nn.l2_normalize: x * rsqrt(max(sum x^2, eps)))
+    float dnu[NU], dni[NU], dru[NU], dri[NU];
+#pragma unroll
+    for (int h = 0; h < NU; ++h) { dnu[h] = ds * ni[h]; dni[h] = ds * nu[h]; }
+    const float du = wave_sum_units<NU>(nu, dnu), di = wave_sum_units<NU>(ni, dni);
+#pragma unroll
+    for (int h = 0; h < NU; ++h) {
+      dru[h] = qu > kL2NEps ? rhou * (dnu[h] - nu[h] * du) : rhou * dnu[h];
+      dri[h] = qi > kL2NEps ? rhoi * (dni[h] - ni[h] * di) : rhoi * dni[h];
+    }
+    tower_bwd_store<NU>(D, 0, swl, Wk.dz + ((size_t)0 * A.B + b) * kDmfMaxLayers * W, k, zu, dru);
+    tower_bwd_store<NU>(D, 1, swl, Wk.dz + ((size_t)1 * A.B + b) * kDmfMaxLayers * W, k, zi, dri);
   }
 }
 
 // gsw_part[chunk][i] = sum over the chunk's samples (ascending b) of the gradient of small weight i:
 //   kernel element (tw, l >= 1, j, k): act[tw][b][l-1][j] * dz[tw][b][l][k];   bias (tw, l, k): dz[tw][b][l][k];   scale: samp[b][1]
 // loss_part[chunk] = sum of samp[b][0] / B.  One thread per small weight, blockIdx.y = chunk.
-__global__ __launch_bounds__(256) void k_dmf_wgrad(DrxDmfDims D, DrxDmfArgs A, int chunk) {
-  const DmfWork Wk = dmf_work(A.work, A.B);
+__global__ __launch_bounds__(256) void k_dmf_wgrad(DrxDmfDims D, DrxDmfArgs A, int chunk, int W) {
+  const DmfWork Wk = dmf_work(A.work, A.B, W);
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int b0 = blockIdx.y * chunk, b1 = min(A.B, b0 + chunk);
   if (i == D.n_small) {                              // the loss rides in the same launch
@@ -512,7 +548,7 @@ __global__ __launch_bounds__(256) void k_dmf_wgrad(DrxDmfDims D, DrxDmfArgs A, i
     return;
   }
   if (i >= D.n_small) return;
-  const float *pa = nullptr, *pd = nullptr;          // per-sample strides of kDmfMaxLayers * 64 floats
+  const float *pa = nullptr, *pd = nullptr;          // per-sample strides of kDmfMaxLayers * W floats
   bool is_scale = i == D.off_scale;
   for (int tw = 0; tw < 2 && !pd && !is_scale; ++tw)
     for (int l = 0; l < D.n_layers[tw]; ++l) {
@@ -520,16 +556,16 @@ __global__ __launch_bounds__(256) void k_dmf_wgrad(DrxDmfDims D, DrxDmfArgs A, i
       if (l >= 1) {
         const int r = i - D.off_k[tw][l];
         if (r >= 0 && r < D.f[tw][l - 1] * fo) {
-          pa = Wk.act + ((size_t)tw * A.B * kDmfMaxLayers + (l - 1)) * 64 + r / fo;
-          pd = Wk.dz + ((size_t)tw * A.B * kDmfMaxLayers + l) * 64 + r % fo;
+          pa = Wk.act + ((size_t)tw * A.B * kDmfMaxLayers + (l - 1)) * W + r / fo;
+          pd = Wk.dz + ((size_t)tw * A.B * kDmfMaxLayers + l) * W + r % fo;
           break;
         }
       }
       const int rb = i - D.off_b[tw][l];
-      if (rb >= 0 && rb < fo) { pd = Wk.dz + ((size_t)tw * A.B * kDmfMaxLayers + l) * 64 + rb; break; }
+      if (rb >= 0 && rb < fo) { pd = Wk.dz + ((size_t)tw * A.B * kDmfMaxLayers + l) * W + rb; break; }
     }
   float g = 0.f;
-  const size_t stride = (size_t)kDmfMaxLayers * 64;
+  const size_t stride = (size_t)kDmfMaxLayers * W;
   if (is_scale) {
     for (int b = b0; b < b1; ++b) g += Wk.samp[(size_t)b * 2 + 1];
   } else if (pd && pa) {
@@ -633,8 +669,8 @@ static int check_dims(const DrxDmfDims *D) {
   for (int tw = 0; tw < 2; ++tw) {
     if (D->n_layers[tw] < 1 || D->n_layers[tw] > kDmfMaxLayers) return DRX_EINVAL;
     for (int l = 0; l < D->n_layers[tw]; ++l)
-      if (D->f[tw][l] < 1 || D->f[tw][l] > 64) return DRX_EINVAL;
-    if (D->ld0[tw] < D->f[tw][0] || (D->ld0[tw] & 3) || D->ld0[tw] > 64) return DRX_EINVAL;
+      if (D->f[tw][l] < 1 || D->f[tw][l] > 128) return DRX_EINVAL;
+    if (D->ld0[tw] < D->f[tw][0] || (D->ld0[tw] & 3) || D->ld0[tw] > 128) return DRX_EINVAL;
   }
   if (D->off_scale < -1 || D->off_scale >= D->n_small) return DRX_EINVAL;
   return (size_t)D->n_small * 4 <= 150 * 1024 ? DRX_OK : DRX_EINVAL;
@@ -746,7 +782,7 @@ int drx_dmf_grid(int32_t B) { return B <= 16 ? 1 : (B + 15) / 16 < 256 ? (B + 15
 
 size_t drx_dmf_work_bytes(int32_t B) {
   if (B < 1) return 0;
-  return ((size_t)2 * B * 64 + (size_t)4 * B * kDmfMaxLayers * 64 + (size_t)2 * B) * 4 + 256;
+  return ((size_t)2 * B * 128 + (size_t)4 * B * kDmfMaxLayers * 128 + (size_t)2 * B) * 4 + 256;      // (rows of 128: the widest towers)
 }
 
 int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream) {
@@ -775,15 +811,22 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   const int wv = dmf_waves(A->n_du + A->n_di);
   const int items = A->n_du + A->n_di;
   const int ggrid = items < 8192 ? items : 8192;
-  if (wv == 16) hipLaunchKernelGGL((k_dmf_gather<16>), dim3(ggrid), dim3(64 * 16), 0, st, *D, *A);
-  else if (wv == 8) hipLaunchKernelGGL((k_dmf_gather<8>), dim3(ggrid), dim3(64 * 8), 0, st, *D, *A);
-  else hipLaunchKernelGGL((k_dmf_gather<4>), dim3(ggrid), dim3(64 * 4), 0, st, *D, *A);
+  const int nu = dmf_units(*D), W = 64 * nu;
+#define DRX_DMF_GATHER(WVN, NUN) hipLaunchKernelGGL((k_dmf_gather<WVN, NUN>), dim3(ggrid), dim3(64 * WVN), 0, st, *D, *A)
+  if (nu == 1) { if (wv == 16) DRX_DMF_GATHER(16, 1); else if (wv == 8) DRX_DMF_GATHER(8, 1); else DRX_DMF_GATHER(4, 1); }
+  else { if (wv == 16) DRX_DMF_GATHER(16, 2); else if (wv == 8) DRX_DMF_GATHER(8, 2); else DRX_DMF_GATHER(4, 2); }
+#undef DRX_DMF_GATHER
   const size_t lds = (size_t)D->n_small * 4;
-  if (lds > 48 * 1024) DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int dgrid = (A->B + 3) / 4;
-  hipLaunchKernelGGL(k_dmf_dense, dim3(dgrid < 2048 ? dgrid : 2048), dim3(256), lds, st, *D, *A);
-  hipLaunchKernelGGL(k_dmf_dzsum, dim3((items + 3) / 4 < 2048 ? (items + 3) / 4 : 2048), dim3(256), 0, st, *D, *A);
-  hipLaunchKernelGGL(k_dmf_wgrad, dim3((D->n_small + 1 + 255) / 256, chunks), dim3(256), 0, st, *D, *A, chunk);
+  if (nu == 1) {
+    if (lds > 48 * 1024) DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_dmf_dense<1>, dim3(dgrid < 2048 ? dgrid : 2048), dim3(256), lds, st, *D, *A);
+  } else {
+    if (lds > 48 * 1024) DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_dmf_dense<2>, dim3(dgrid < 2048 ? dgrid : 2048), dim3(256), lds, st, *D, *A);
+  }
+  hipLaunchKernelGGL(k_dmf_dzsum, dim3((items + 3) / 4 < 2048 ? (items + 3) / 4 : 2048), dim3(256), 0, st, *D, *A, W);
+  hipLaunchKernelGGL(k_dmf_wgrad, dim3((D->n_small + 1 + 255) / 256, chunks), dim3(256), 0, st, *D, *A, chunk, W);
   hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, chunks, D->n_small,
                      A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();
@@ -807,6 +850,7 @@ int drx_dmf_k0_update(const DrxDmfDims *D, const DrxDmfArgs *A, const DrxDmfK0Up
       !A->dz0i || !A->map_u || !A->map_i || !A->rho_u || !A->rho_i || A->stamp == 0 || up->n_items < 1 || up->n_users < 1)
     return DRX_EINVAL;
   if (!up->K0u || !up->K0i || !up->m_u || !up->m_i || !up->v_u || !up->v_i) return DRX_EINVAL;
+  if (D->ld0[0] > 64 || D->ld0[1] > 64) return DRX_EINVAL;      // (a quarter-wave per dz0 row; wider first layers: touches + drx_scatter_rows)
   if (((uintptr_t)up->K0u | (uintptr_t)up->K0i | (uintptr_t)up->m_u | (uintptr_t)up->m_i | (uintptr_t)up->v_u | (uintptr_t)up->v_i |
        (uintptr_t)A->dz0u | (uintptr_t)A->dz0i) & 15)
     return DRX_EINVAL;
@@ -825,9 +869,11 @@ int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream) {
     return DRX_EINVAL;
   const int wv = dmf_waves(A->B);
   const dim3 grid(A->B < 4096 ? A->B : 4096);
-  if (wv == 16) hipLaunchKernelGGL((k_dmf<false, 16>), grid, dim3(64 * 16), (size_t)2 * 16 * 64 * 4, (hipStream_t)stream, *D, *A);
-  else if (wv == 8) hipLaunchKernelGGL((k_dmf<false, 8>), grid, dim3(64 * 8), (size_t)2 * 8 * 64 * 4, (hipStream_t)stream, *D, *A);
-  else hipLaunchKernelGGL((k_dmf<false, 4>), grid, dim3(64 * 4), (size_t)2 * 4 * 64 * 4, (hipStream_t)stream, *D, *A);
+  const int nu = dmf_units(*D);
+#define DRX_DMF_PREDICT(WVN, NUN) hipLaunchKernelGGL((k_dmf_predict<WVN, NUN>), grid, dim3(64 * WVN), (size_t)2 * WVN * 64 * NUN * 4, (hipStream_t)stream, *D, *A)
+  if (nu == 1) { if (wv == 16) DRX_DMF_PREDICT(16, 1); else if (wv == 8) DRX_DMF_PREDICT(8, 1); else DRX_DMF_PREDICT(4, 1); }
+  else { if (wv == 16) DRX_DMF_PREDICT(16, 2); else if (wv == 8) DRX_DMF_PREDICT(8, 2); else DRX_DMF_PREDICT(4, 2); }
+#undef DRX_DMF_PREDICT
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

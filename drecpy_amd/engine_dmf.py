@@ -31,9 +31,11 @@ class DmfEngine:
         self.device = torch.device(device)
         self.U, self.N = n_users, n_items
         self.factors = [list(user_factors), list(item_factors)]
-        if not all(1 <= len(f) <= 4 and 1 <= min(f) and max(f) <= 64 for f in self.factors):
-            raise _lib.DrxError(f'DMF engine: towers of 1..4 layers of width 1..64 are supported (lane = hidden unit of one wavefront), got '
-                                f'user_factors={self.factors[0]}, item_factors={self.factors[1]}')
+        if not all(1 <= len(f) <= 4 and 1 <= min(f) and max(f) <= 128 for f in self.factors):
+            raise _lib.DrxError(f'DMF engine: towers of 1..4 layers of width 1..128 are supported (a lane of one wavefront holds hidden units '
+                                f'k and k + 64), got user_factors={self.factors[0]}, item_factors={self.factors[1]}')
+        # floats per row of the per-sample work rows and of the representations predict() hands out: 64 per unit slot of a lane
+        self.W = 128 if max(max(f) for f in self.factors) > 64 else 64
         D = DmfDims()
         self.seg = []                      # (name, start, len, regularised, tower)
         off = 0
@@ -108,7 +110,8 @@ class DmfEngine:
                         torch.as_tensor(np.asarray(t[2], np.float32)).to(d))
         self.csr, self.csc = mk(csr), mk(csc)
         self._h_indptr = (np.asarray(csr[0], np.int64).copy(), np.asarray(csc[0], np.int64).copy())   # host copies: batch offsets
-        self.first_layer_update = 'scan' if len(csr[1]) <= self.SCAN_MAX_NNZ else 'scatter'
+        # (the scan update gives a quarter-wave to a first-layer gradient row: rows of up to 64 floats)
+        self.first_layer_update = 'scan' if len(csr[1]) <= self.SCAN_MAX_NNZ and max(self.D.ld0[0], self.D.ld0[1]) <= 64 else 'scatter'
         # the l2 normaliser of every row / column depends on the dataset alone: once here, not per batch id and step
         self._rho = (torch.empty(self.U, dtype=torch.float32, device=d), torch.empty(self.N, dtype=torch.float32, device=d))
         for (ip, _, vals), n, out in ((self.csr, self.U, self._rho[0]), (self.csc, self.N, self._rho[1])):
@@ -400,7 +403,7 @@ class DmfEngine:
 
     def predict(self, uids, iids, want_reps=False, scaled=True):
         """max(1e-6, cosine) for each (uid, iid) pair (dmf.py:88-96) — times the bound prediction scale unless scaled=False;
-        optionally the normalised tower outputs [B,64]."""
+        optionally the normalised tower outputs [B, self.W]."""
         uid, iid = self._i32(uids), self._i32(iids)
         B = uid.numel()
         pred = torch.empty(B, dtype=torch.float32, device=self.device)
@@ -408,8 +411,8 @@ class DmfEngine:
         A.pred_out = pred.data_ptr()
         ru = ri = None
         if want_reps:
-            ru = torch.empty(B, 64, dtype=torch.float32, device=self.device)
-            ri = torch.empty(B, 64, dtype=torch.float32, device=self.device)
+            ru = torch.empty(B, self.W, dtype=torch.float32, device=self.device)
+            ri = torch.empty(B, self.W, dtype=torch.float32, device=self.device)
             A.rep_u_out, A.rep_i_out = ru.data_ptr(), ri.data_ptr()
         D = self.D
         if not scaled and self.D.off_scale >= 0:
@@ -428,7 +431,9 @@ class DmfEngine:
         pitch = _round_up(self.N, 32)                  # rows of 128-byte lines: a line then belongs to ONE tile of the scorer
         out = torch.empty(n_u, pitch, dtype=torch.float32, device=self.device)
         kdim = _round_up(self.factors[0][-1], 16)
+        if kdim > 64:
+            raise _lib.DrxError(f'score_matrix_bf16: representations of up to 64 factors (the scorer stages 64-wide bf16 tiles), got {self.factors[0][-1]}')
         scale = ptr(self.sw[self._scale_slot:]) if self.scale_var is not None else None
-        check(lib().drx_score_pairs_bf16(ptr(ru), n_u, ptr(ri), self.N, 64, kdim, scale, ptr(out), pitch, stream_ptr(self.device)),
+        check(lib().drx_score_pairs_bf16(ptr(ru), n_u, ptr(ri), self.N, self.W, kdim, scale, ptr(out), pitch, stream_ptr(self.device)),
               'drx_score_pairs_bf16')
         return out[:, :self.N]

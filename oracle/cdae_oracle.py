@@ -197,7 +197,7 @@ def sparse_state(params, optimizer='adagrad'):
 
 
 def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss='bce',
-                optimizer='adagrad', dot_reduce=None):
+                optimizer='adagrad', dot_reduce=None, accumulate='loop'):
     """One step over B triples (u_b, i_b, y_b).  kept[b] = item ids of u_b's positives that
     survive corruption (cdae.py:61-63 restricted to the non-zero entries).
 
@@ -208,15 +208,29 @@ def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss=
         b: dense gradient; b_: touched entries only
         Adagrad (Keras: acc0 = .1, eps = 1e-7): acc += g^2 ; p -= lr * g / (sqrt(acc) + eps)
         lazy Adam: m, v, p of touched rows only, global step t = step + 1, Keras lr_t.
+
+    accumulate: how the row gradients are summed over the batch.  'loop' (the definition): triple by triple, a Python loop — seconds
+    per thousand triples.  'matrix': the same sums as sparse matrix products (scipy: indicator^T @ per-triple gradients), for batches
+    the loop cannot follow (65 536 triples over MovieLens-length histories: 8.6 M row additions); another association of the same
+    fp64 sums — tests/test_oracle_cdae.py holds the two to 1e-12 of each other.
     """
     dt = params['W'].dtype
     W, W_, V, b, b_ = (params[k] for k in ('W', 'W_', 'V', 'b', 'b_'))
     B = len(uids)
     s = dt.type(1.0 / (1.0 - q))
     z1 = np.zeros((B, W.shape[1]), dtype=dt)
-    for bi in range(B):
-        if len(kept[bi]):
-            z1[bi] = W[np.asarray(kept[bi])].sum(axis=0, dtype=dt) * s
+    if accumulate == 'matrix':
+        import scipy.sparse as sp
+        lens = np.fromiter((len(k_) for k_ in kept), dtype=np.int64, count=B)
+        ip = np.zeros(B + 1, dtype=np.int64)
+        ip[1:] = np.cumsum(lens)
+        cols = np.concatenate([np.asarray(k_, dtype=np.int64) for k_ in kept]) if ip[-1] else np.zeros(0, np.int64)
+        A = sp.csr_matrix((np.ones(len(cols), dtype=dt), cols, ip), shape=(B, W.shape[0]))        # [B, N]: triple b keeps item n
+        z1 = np.asarray(A @ W, dtype=dt) * s
+    else:
+        for bi in range(B):
+            if len(kept[bi]):
+                z1[bi] = W[np.asarray(kept[bi])].sum(axis=0, dtype=dt) * s
     z1 = z1 + V[uids] + b
     h = sigmoid(z1)
     w2 = W_[:, iids].T                                   # [B,K]
@@ -236,21 +250,34 @@ def sparse_step(params, state, step, uids, iids, y, kept, q, lr, reg_rate, loss=
     dz1 = dh * h * (1 - h)
     rb = dt.type(reg_rate) / dt.type(B)
 
-    gW_ = {}
-    gb_ = {}
-    for bi in range(B):
-        i = int(iids[bi])
-        gW_[i] = gW_.get(i, 0) + dz2[bi] * h[bi]
-        gb_[i] = gb_.get(i, 0) + dz2[bi]
-    gV = {}
-    for bi in range(B):
-        u = int(uids[bi])
-        gV[u] = gV.get(u, 0) + dz1[bi]
-    gW = {}
-    for bi in range(B):
-        for n in kept[bi]:
-            n = int(n)
-            gW[n] = gW.get(n, 0) + dz1[bi] * s
+    if accumulate == 'matrix':
+        def by_key(keys, rows, n_keys):
+            """{key: sum of rows[b] over the triples b with keys[b] == key} as one indicator^T @ rows product"""
+            keys = np.asarray(keys, dtype=np.int64)
+            Ik = sp.csr_matrix((np.ones(B, dtype=dt), (keys, np.arange(B))), shape=(n_keys, B))
+            G = np.asarray(Ik @ rows, dtype=dt)
+            return {int(k_): G[k_] for k_ in np.unique(keys)}
+        gW_ = by_key(iids, dz2[:, None] * h, W_.shape[1])
+        gb_ = {k_: v_[0] for k_, v_ in by_key(iids, dz2[:, None], W_.shape[1]).items()}
+        gV = by_key(uids, dz1, V.shape[0])
+        GW = np.asarray(A.T @ (dz1 * s), dtype=dt)
+        gW = {int(n): GW[n] for n in np.unique(cols)}
+    else:
+        gW_ = {}
+        gb_ = {}
+        for bi in range(B):
+            i = int(iids[bi])
+            gW_[i] = gW_.get(i, 0) + dz2[bi] * h[bi]
+            gb_[i] = gb_.get(i, 0) + dz2[bi]
+        gV = {}
+        for bi in range(B):
+            u = int(uids[bi])
+            gV[u] = gV.get(u, 0) + dz1[bi]
+        gW = {}
+        for bi in range(B):
+            for n in kept[bi]:
+                n = int(n)
+                gW[n] = gW.get(n, 0) + dz1[bi] * s
     gb = dz1.sum(axis=0)
 
     def upd(name, index, g):

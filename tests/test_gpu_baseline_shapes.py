@@ -118,6 +118,54 @@ def test_sampled_mode_cdae_at_ml1m_shape(prepared):
         np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5, err_msg=k)
 
 
+def test_shared_form_at_the_bench_batch_on_the_ml1m_shape_matches_the_oracle():
+    """The configuration bench.py times as `cfg2`: CDAE K = 128 on 6040 x 3706, B = 65 536 triples per step in USER order, lists
+    prepared through the history's transpose in the shared form (DRX_BATCH_SHARE_USERS: ~11 triples of a user share their gather —
+    the fp32 MFMA masked product — and their gradient row), sparse Adagrad.  Two steps against the fp64 oracle (row gradients as
+    sparse matrix products: cdae_oracle.sparse_step accumulate='matrix' — 8.6 M row additions per step), then the 1e-5 gate on the
+    predictions of a probe of users and 2e-5 on every parameter."""
+    from drecpy_amd.engine import CdaeEngine
+    from helpers import hash_u32, q_threshold
+    U, N, indptr, indices = _history('ml-1m')
+    K, B, q, lr = 128, 65536, 0.2, 0.05
+    rng = np.random.default_rng(23)
+    p = co.init_params(rng, U, N, K, np.float64)
+    eng = CdaeEngine(U, N, K)
+    eng.set_params(**p)
+    eng.set_history(indptr, indices)
+    assert eng.share_users and eng._hist_t is not None
+    eng.init_optimizer('adagrad', lr, 1e-3)
+    st = co.sparse_state(p, 'adagrad')
+    qf, thr = float(np.float32(q)), q_threshold(q)
+    for step in range(2):
+        uids = np.sort(rng.integers(0, U, size=B))
+        iids = rng.integers(0, N, size=B)
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        deg = (indptr[uids + 1] - indptr[uids]).astype(np.int64)
+        keep_off = np.zeros(B + 1, dtype=np.int64)
+        keep_off[1:] = np.cumsum(deg)
+        row = np.repeat(np.arange(B), deg)
+        j = np.arange(keep_off[-1]) - keep_off[:-1][row]
+        seed = 9100 + step * 7919
+        keep = hash_u32(seed, row, j) >= thr
+        items = indices[indptr[uids][row] + j]
+        kept_flat, cuts = items[keep], np.cumsum(np.bincount(row[keep], minlength=B))[:-1]
+        kept = np.split(kept_flat, cuts)
+        bt, alive = eng.make_batch(uids, iids, y, q=q, mask_seed=seed)
+        assert bt.n_touch_slots + 2 * B > 8 * (2 * N + U) and (bt.flags & 1)               # long segments, DRX_BATCH_SHARE_USERS
+        lo, _ = co.sparse_step(p, st, step, uids, iids, y, kept, qf, lr, 1e-3, 'bce', 'adagrad', accumulate='matrix')
+        lg = eng.step_sparse(step, bt, 'bce', want_loss=True, prepared=eng.prepare_sparse(bt)).cpu().numpy()
+        assert abs(lg[0] - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    probe = rng.integers(0, U, size=64)
+    tp, _, _ = batch_rows(indptr, indices, probe, N)
+    _, pred = eng.forward(probe)
+    _, po = co.forward(p, probe, tp.astype(np.float64))
+    assert _relerr(pred.cpu().numpy(), po) < REL
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5, err_msg=k)
+
+
 def _ml1m_ratings():
     """Interaction matrix of the ml-1m shape with ratings 1..5: CSR, CSC and the dense fp64 matrix the oracle reads."""
     U, N, indptr, indices = _history('ml-1m')

@@ -372,6 +372,12 @@ def test_lists_prepared_through_the_historys_transpose_match_the_oracle_and_the_
         g = eng.get_params()
         for k in p:
             np.testing.assert_allclose(g[k], p[k], rtol=0, atol=2e-5, err_msg=f'{mode} {k}')
+        # ... and the gate every other sparse test applies: predictions within 1e-5 relative of the oracle's
+        probe = np.arange(min(U, 64))
+        tpr, _, _ = batch_rows(indptr, indices, probe, N)
+        _, pred = eng.forward(probe)
+        _, po = co.forward(p, probe, tpr.astype(np.float64))
+        assert _relerr(pred.cpu().numpy(), po) < REL, mode
         results.append(g)
     for k in results[0]:
         assert np.array_equal(results[0][k], results[1][k]), k                      # the transposed path twice: bit for bit

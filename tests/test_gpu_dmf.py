@@ -23,7 +23,10 @@ def _problem(rng, U, N, nnz):
 
 
 @pytest.mark.parametrize('update', ['scan', 'scatter'])      # the two ways the first-layer kernels are updated (engine_dmf.py)
-@pytest.mark.parametrize('uf,itf,l2n,B', [((64, 32), (64, 32), True, 64), ((16,), (24, 16), True, 33), ((32, 20, 8), (12, 8), False, 50)])
+@pytest.mark.parametrize('uf,itf,l2n,B', [((64, 32), (64, 32), True, 64), ((16,), (24, 16), True, 33), ((32, 20, 8), (12, 8), False, 50),
+                                          # towers wider than a wavefront (a lane holds units k and k + 64): the reference's own
+                                          # examples/consistency_eval/dmf.py:20 builds [128, 64]
+                                          ((128, 64), (128, 64), True, 64), ((100, 70, 40), (90, 40), True, 33), ((128,), (72, 128), False, 50)])
 def test_dmf_steps_match_oracle(uf, itf, l2n, B, update):
     from drecpy_amd.engine_dmf import DmfEngine
     rng = np.random.default_rng(len(uf) * 7 + B)
@@ -35,7 +38,10 @@ def test_dmf_steps_match_oracle(uf, itf, l2n, B, update):
             p[k] = rng.normal(0, 0.05, size=p[k].shape)
     eng = DmfEngine(U, N, uf, itf, l2n)
     eng.set_interactions(csr, csc)
-    assert eng.first_layer_update == 'scan'
+    wide0 = max(uf[0], itf[0]) > 64              # (first layers wider than 64: a quarter-wave cannot hold a gradient row — touches + scatter)
+    assert eng.first_layer_update == ('scatter' if wide0 else 'scan')
+    if wide0 and update == 'scan':
+        pytest.skip('the scan update of the first-layer kernels takes rows of up to 64 floats')
     eng.first_layer_update = update
     eng.set_params(p)
     eng.lr, eng.reg = 2e-3, 1e-3
@@ -232,8 +238,8 @@ def test_modified_dmf_fit_matches_oracle_end_to_end():
             self._register_trainable(Variable([1.]))
     with pytest.raises(NotImplementedError, match='does not update them'):
         Stray(user_factors=[16, 8], item_factors=[16, 8], seed=seed, verbose=False).fit(ds, epochs=1, batch_size=8)
-    with pytest.raises(Exception, match='supports towers of 1..4 layers of width 1..64'):
-        DMF(user_factors=[128, 64], item_factors=[64], verbose=False)
+    with pytest.raises(Exception, match='supports towers of 1..4 layers of width 1..128'):
+        DMF(user_factors=[256, 64], item_factors=[64], verbose=False)
 
 
 def test_update_weights_applies_keras_adam_on_the_device():
@@ -456,3 +462,26 @@ def test_device_sampled_negatives_carry_the_standardised_zero():
         # every other target is a positive's: the same set of values as the host stream's positives
         assert set(np.unique(y[~neg_d]).tolist()) <= set(np.unique(ry[~rneg]).tolist()), use_nce
         assert y[~neg_d].min() >= (0.0 if use_nce else 2.0)
+
+
+def test_dmf_of_the_references_consistency_script_fits_and_ranks():
+    """examples/consistency_eval/dmf.py:20 of the reference: DMF(user_factors=[128, 64], item_factors=[128, 64]) — fit, predict and the
+    all-pairs scorer (64 final factors) through the public classes; the fused step against the oracle is test_dmf_steps_match_oracle."""
+    from helpers import load_frames
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import DMF
+    frame = {k: v.copy() for k, v in load_frames()['pt_int_dense'].items()}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    model = DMF(user_factors=[128, 64], item_factors=[128, 64], seed=10, verbose=False)
+    model.fit(ds, epochs=30, batch_size=64, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)
+    assert model._engine.W == 128 and model._engine.first_layer_update == 'scatter'
+    u, i = int(frame['user'][0]), int(frame['item'][0])
+    p = model.predict(u, i)
+    assert np.isfinite(p)
+    rec = model.recommend(u, n=5)
+    assert len(rec) == 5
+    # the scorer's rows are 128 floats wide here (64 factors used): equal to per-pair predictions to bf16 accuracy
+    e = model._engine
+    sc = e.score_matrix_bf16(np.arange(4)).cpu().numpy()
+    pr = e.predict(np.repeat(np.arange(4), e.N), np.tile(np.arange(e.N), 4)).cpu().numpy().reshape(4, e.N)
+    assert np.max(np.abs(sc - pr)) < 1.5e-2

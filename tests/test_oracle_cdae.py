@@ -120,3 +120,26 @@ def test_sparse_step_matches_autograd():
     assert abs(lval - L.item()) < 1e-12
     for k in p:
         np.testing.assert_allclose(p[k], want[k], rtol=1e-9, atol=1e-13)
+
+
+def test_sparse_step_matrix_accumulation_equals_the_loop():
+    """accumulate='matrix' (the row gradients as sparse matrix products, for batches the Python loop cannot follow) is the same step
+    as the definition ('loop'): three steps, Adagrad and lazy Adam, users and items that repeat, an empty history."""
+    import copy
+    for opt in ('adagrad', 'adam'):
+        rng = np.random.default_rng(8)
+        U, N, K, B = 14, 23, 7, 40
+        p0 = co.init_params(rng, U, N, K, np.float64)
+        pa, pb = copy.deepcopy(p0), copy.deepcopy(p0)
+        sa, sb = co.sparse_state(pa, opt), co.sparse_state(pb, opt)
+        for step in range(3):
+            uids = rng.integers(0, U, size=B)
+            iids = rng.integers(0, N, size=B)
+            y = (rng.random(B) < 0.4).astype(np.float64)
+            kept = [sorted(rng.choice(N, size=rng.integers(0, 7), replace=False).tolist()) for _ in range(B)]
+            kept[3] = []
+            la, _ = co.sparse_step(pa, sa, step, uids, iids, y, kept, 0.2, 0.05, 1e-3, 'bce', opt)
+            lb, _ = co.sparse_step(pb, sb, step, uids, iids, y, kept, 0.2, 0.05, 1e-3, 'bce', opt, accumulate='matrix')
+            assert abs(la - lb) < 1e-13
+        for k in pa:
+            np.testing.assert_allclose(pb[k], pa[k], rtol=1e-12, atol=1e-14, err_msg=f'{opt} {k}')
