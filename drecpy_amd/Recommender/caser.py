@@ -29,8 +29,12 @@ class Caser(RecommenderABC):
         supported = ('relu', 'tanh', 'sigmoid', 'linear', None)
         if act_h not in supported or act_mlp not in supported:
             raise Exception(f'drecpy_amd.Caser supports the activations {supported[:4]} (given: act_h={act_h!r}, act_mlp={act_mlp!r}).')
-        if not (1 <= L <= 8 and 1 <= d <= 64):
-            raise Exception(f'drecpy_amd.Caser supports 1 <= L <= 8 and 1 <= d <= 64 (given: L={L}, d={d}).')
+        if not (1 <= L <= 64 and 1 <= d <= 1024):
+            raise Exception(f'drecpy_amd.Caser supports 1 <= L <= 64 and 1 <= d <= 1024 (given: L={L}, d={d}).')
+        # the fused kernel (drx_caser.hip: a lane per embedding channel, the window unrolled) takes L <= 8 and d <= 64 — BASELINE
+        # configuration 5 and examples/caser.py (L = 5, d = 50); beyond that the reference's semantics are kept by the generic engine
+        # (engine_caser_wide.py: torch.autograd in tf.GradientTape's place, the library's Keras-Adam kernel per registered layer)
+        self._fused = L <= 8 and d <= 64
         self.act_h, self.act_mlp = act_h, act_mlp
         self.L, self.T, self.d, self.n_v, self.n_h = L, T, d, n_v, n_h
         self.dropout_rate = dropout_rate
@@ -39,9 +43,10 @@ class Caser(RecommenderABC):
 
     def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):          # caser.py:45-75
         from ..engine_caser import CaserEngine
+        from ..engine_caser_wide import CaserWideEngine
         self.neg_ratio = neg_ratio
-        self._engine = CaserEngine(self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v, self.n_h,
-                                   device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
+        self._engine = (CaserEngine if self._fused else CaserWideEngine)(self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v,
+                                                                       self.n_h, device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
         self._engine.lr, self._engine.reg = float(learning_rate), float(reg_rate)
         weights = kwds.get('initial_weights')
         if weights is None:

@@ -49,6 +49,59 @@ def test_caser_steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, update):
         assert np.max(np.abs(sc[r] - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))
 
 
+@pytest.mark.parametrize('d,L,n_v,n_h,T,neg,B,drop', [(100, 9, 4, 16, 3, 3, 64, True), (128, 16, 2, 8, 2, 2, 37, False), (72, 5, 4, 16, 3, 3, 50, True)])
+def test_caser_beyond_the_fused_kernels_domain_matches_oracle(d, L, n_v, n_h, T, neg, B, drop):
+    """caser.py:29-30 takes any L / d; the fused kernel L <= 8, d <= 64.  Beyond that the generic engine (engine_caser_wide.py:
+    torch.autograd in tf.GradientTape's place, the library's Keras-Adam kernel per registered layer with the reference's counters)
+    keeps the step: same oracle, same tolerances as the fused step's test."""
+    from drecpy_amd.engine_caser_wide import CaserWideEngine
+    rng = np.random.default_rng(d + B)
+    U, N = 40, 150
+    p = ca.init_params(rng, U, N, L, d, n_v, n_h, np.float64)
+    eng = CaserWideEngine(U, N, L, T, neg, d, n_v, n_h)
+    eng.set_params(p)
+    eng.lr, eng.reg = 5e-3, 1e-4
+    st = ca.adam_state(p)
+    nx = n_v + L * n_h
+    for step in range(5):
+        uids = rng.integers(0, U, size=B)
+        before = rng.integers(0, N, size=(B, L))
+        after = rng.integers(0, N, size=(B, T + T * neg))
+        keep = (rng.random((B, nx)) >= 0.5) if drop else None
+        rate = 0.5 if drop else 0.0
+        lo = ca.step(p, st, step, uids, before, after, T, 5e-3, 1e-4, keep, rate)
+        lg = eng.step(step, uids, before, after, keep, rate, want_loss=True)
+        assert abs(lg - lo) / abs(lo) < 1e-4, (step, lg, lo)
+    g = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(g[k], p[k], rtol=0, atol=3e-5, err_msg=k)
+    uids = rng.integers(0, U, size=5)
+    before = rng.integers(0, N, size=(5, L))
+    sc = eng.scores_all(uids, before).cpu().numpy()
+    for r in range(5):
+        want = ca.rank_scores(p, uids[r], before[r])
+        assert np.max(np.abs(sc[r] - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))
+
+
+def test_caser_with_a_long_window_fits_and_ranks_through_the_public_class():
+    """Caser(L=9, d=100) — outside the fused kernel's domain — through fit() / rank(): the generic engine behind the same class."""
+    from helpers import load_frames
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import Caser
+    frame = {k: v.copy() for k, v in load_frames()['ls_int_ts'].items()}
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    model = Caser(L=3, T=2, d=100, n_v=2, n_h=4, seed=10, verbose=False)
+    assert not model._fused
+    model.fit(ds, epochs=8, batch_size=16, learning_rate=5e-3, reg_rate=1e-4, neg_ratio=2)
+    from drecpy_amd.engine_caser_wide import CaserWideEngine
+    assert isinstance(model._engine, CaserWideEngine)
+    u = int(frame['user'][0])
+    rec = model.recommend(u, n=3, novelty=False)
+    assert len(rec) == 3 and all(np.isfinite(v) for v, _ in rec)
+    with pytest.raises(Exception, match='supports 1 <= L <= 64'):
+        Caser(L=65, d=16, verbose=False)
+
+
 def test_caser_fit_matches_oracle_end_to_end():
     """Caser.fit() with the reference-exact ListSampler stream and injected weights / dropout masks vs the oracle."""
     from helpers import load_frames
@@ -153,10 +206,11 @@ def test_caser_activations_match_oracle(act_h, act_mlp):
     from drecpy_amd.Recommender import Caser, DMF
     with pytest.raises(Exception, match='supports the activations'):
         Caser(act_h='gelu')
-    with pytest.raises(Exception, match='1 <= L <= 8'):
-        Caser(d=128)
-    with pytest.raises(Exception, match='towers of 1..4 layers of width 1..64'):
-        DMF(user_factors=[128, 64], item_factors=[64])
+    with pytest.raises(Exception, match='1 <= L <= 64'):
+        Caser(d=2048)
+    with pytest.raises(Exception, match='towers of 1..4 layers of width 1..128'):
+        DMF(user_factors=[256, 64], item_factors=[64])
+    assert Caser(d=128, verbose=False)._fused is False and Caser(L=5, d=50, verbose=False)._fused is True
 
 
 @pytest.mark.parametrize('update', ['csr', 'scatter'])
