@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, stream_ptr
-from .optimizers import ADAM_B1, ADAM_B2, ADAM_EPS
+from .engine import ADAM_B1, ADAM_B2, ADAM_EPS
 
 
 def _act(kind):
