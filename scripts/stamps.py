@@ -59,14 +59,8 @@ def main():
     if os.environ.get('SHAPE', 'synth-10m') == 'synth-10m':
       report('k_sampled_fwd_bwd_pf (per triple)', st[:B], [0, 1, 2, 3, 4, 5, 6, 7, 8],
              ['uid/iid -> LDS-DMA issued', 'indptr', 'indices + mask', 'first rows', 'rest of the gather', 'b, b2, y + DMA landed', 'loss, dz1 stored', 'sole-toucher updates'])
-    seg = st[65536:]
-    seg = seg[seg[:, 0] > 0]
-    report('k_seg_reduce_planned (per chunk)', seg, [0, 1, 2, 3], ['keys', 'contribution rows + in-chunk segments', 'last flush'])
-    out['k_seg_reduce_planned (per chunk)']['flushes_per_chunk_mean'] = float(seg[:, 4].mean())
-    out['k_seg_reduce_planned (per chunk)']['window_touches_mean'] = float(seg[:, 5].mean())
-    life = (seg[:, 3] - seg[:, 0]) * 0.01
-    fl = seg[:, 4]
-    out['k_seg_reduce_planned (per chunk)']['life_us_by_flushes'] = {str(k): round(float(life[fl == k].mean()), 2) for k in (0, 1, 2, 4, 8, 12, 16) if (fl == k).any()}
+    # (the reduction's kernels carry no stamps since r05: the planned kernel's were taken out of the hot loop, the streamed one never had
+    # any — its phases were sized with library variants side by side, scripts/ab_headline.sh)
     print(json.dumps(out, indent=1))
 
 

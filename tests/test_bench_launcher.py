@@ -124,3 +124,31 @@ def test_row_statistics_of_the_shared_form_match_a_brute_force_count():
     assert st['share_touches'] <= st['occ_W']                      # never more touches than the plain list holds
     bm = bench.byte_model({k_: float(v) for k_, v in st.items()}, 128, 1.0, fused_solo=True, n_users=U, n_items=N)
     assert bm['necessary_k_sampled_fwd_bwd'] <= bm['requested_k_sampled_fwd_bwd'] and bm['necessary_k_seg_reduce'] <= bm['requested_k_seg_reduce']
+
+
+def test_byte_model_against_hand_computed_bytes():
+    """bench.byte_model — the function every roofline fraction of the line is priced on — on a batch small enough to count by hand:
+    B = 10 triples, K = 128 (rows of 512 B), Adagrad (S = 1), tables larger than the Infinity Cache; 40 history items of which 30 are
+    kept (22 distinct, 16 of them touched once); 9 distinct users (8 sole), 7 distinct output items (5 sole)."""
+    import bench
+    st = {'B': 10, 'history_items': 40, 'occ_W': 30, 'dist_W': 22, 'solo_W': 16, 'dist_V': 9, 'solo_V': 8, 'dist_O': 7, 'solo_O': 5}
+    bm = bench.byte_model(st, 128, 1.0, fused_solo=True)
+    row = 512.0
+    # reduction: one read-modify-write of parameter + slot (4 rows' worth) per distinct row that reaches the list — every distinct W row,
+    # the V / W2T rows more than one triple touches — and 8 bytes per touch (kept W occurrences + the non-sole V / W2T touches)
+    rows = 22 + (9 - 8) + (7 - 5)
+    touches = 30 + (10 - 8) + (10 - 5)
+    assert bm['k_seg_reduce'] == bm['necessary_k_seg_reduce'] == row * rows * 4 + 8.0 * touches
+    assert bm['cache_bytes_k_seg_reduce'] == row * touches and bm['requested_k_seg_reduce'] == bm['k_seg_reduce'] + row * touches
+    # forward, per-occurrence reading: one gathered row per kept occurrence + V + W2T row per triple, dz1 per triple and g2 where the
+    # output row is shared, sole-toucher V / W2T rows updated in place (1 slot read + parameter and slot written), indices, 40 B ids
+    fwd = row * (30 + 10 + 10) + row * (10 + (10 - 5)) + row * (8 + 5) * 3 + 4.0 * 40 + 40.0 * 10
+    assert bm['k_sampled_fwd_bwd'] == fwd
+    # strictly necessary: every gathered row once per DISTINCT row
+    assert bm['necessary_k_sampled_fwd_bwd'] == fwd - row * ((30 + 10 + 10) - (22 + 9 + 7))
+    assert bm['requested_k_sampled_fwd_bwd'] == fwd and bm['cache_resident'] is False
+    # a model that fits the Infinity Cache (MovieLens shapes): gathers are counted once per distinct row in the first place
+    small = bench.byte_model(st, 128, 1.0, fused_solo=True, n_users=1000, n_items=1000)
+    assert small['cache_resident'] is True and small['k_sampled_fwd_bwd'] == small['necessary_k_sampled_fwd_bwd']
+    # Adam keeps two slots per parameter: (2 + 2 S) rows per read-modify-write
+    assert bench.byte_model(st, 128, 2.0, fused_solo=True)['k_seg_reduce'] == row * rows * 6 + 8.0 * touches
