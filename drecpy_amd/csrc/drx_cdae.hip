@@ -1727,7 +1727,7 @@ static int step_sparse_impl(const DrxCdaeParams *p, const DrxOptim *opt, const D
       if (!long_segments && p->ld == 4 * G && bt->B < (1 << kStreamIndexBits) && p->n_items < (1 << kStreamIndexBits) &&           \
           p->n_users < (1 << kStreamIndexBits)) { \
         BiasPartialExtra<G, J, cpb * 64> bpxs{p->ld, BA};                                                              \
-        const dim3 sgrid(n_bpart + seg_stream_grid(p->ld, (S.n_chunks + cpb - 1) / cpb));               \
+        const dim3 sgrid(n_bpart + (S.n_chunks + cpb - 1) / cpb);                                        \
         hipLaunchKernelGGL((k_seg_reduce_stream<4 * G, kStreamDepth, POLT, BiasPartialExtra<G, J, cpb * 64>>), sgrid, dim3(cpb * 64), \
                            seg_stream_lds_bytes(p->ld, kStreamDepth), st, SB, PB, R.plan, polk, n_bpart, bpxs);        \
         streamed = true;                                                                                               \

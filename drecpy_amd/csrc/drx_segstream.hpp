@@ -12,8 +12,10 @@
 //     64 lanes busy whatever the window looks like; every branch of the fold is wave-uniform (a scalar branch on the item's code);
 //   * the stream's items live in LDS as 4-byte words: the row's index in its array << 4 | its kind;
 //   * a wave loads all it must know about a chunk — 64 list positions, two ext bytes, the block's border keys — as independent loads, ONE
-//     round instead of the planned kernel's three dependent ones (ext -> window -> keys), and a workgroup takes kStreamBpw consecutive
-//     blocks: the next block's round is in flight while this one streams;
+//     round instead of the planned kernel's three dependent ones (ext -> window -> keys).  One block of the plan per workgroup, dealt out
+//     by the hardware as slots free up: a persistent launch striding over the blocks (6 per workgroup at the headline shape, 4 or 5 of
+//     them real work: a static split is unbalanced) measured 30 % slower, two or four consecutive blocks per workgroup with the next
+//     block's round prefetched no faster;
 //   * vmcnt is counted by hand (the DMA is inline asm: hipcc neither counts it nor drains it): `s_waitcnt vmcnt(D - 1)` after issuing
 //     instruction j + D - 1 guarantees instruction j has landed — loads, stores and LDS-DMA retire in issue order, so the stores of a
 //     finished segment issued in between only make the wait stricter, never weaker;
@@ -39,8 +41,7 @@ namespace drx {
 // one LDS-DMA instruction: 16 bytes per lane from gsrc (per lane) to LDS bytes [lds_dst, lds_dst + 1024) in lane order (lds_dst
 // wave-uniform).  M0 carries the destination and belongs to the compiler: saved and restored around the instruction.
 // The ring slot it overwrites was read (ds_read) by the SAME wave an iteration earlier, and the values read were used (an fma: hipcc
-// waits lgkmcnt for them in front of it) before this statement in program order — no wait needed here, and none wanted: an
-// `s_waitcnt lgkmcnt(0)` would also wait for the scalar loads a pipelined caller has in flight for its next work item.
+// waits lgkmcnt for them in front of it) before this statement in program order — no wait is needed here.
 __device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_dst) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -74,18 +75,6 @@ static inline size_t seg_stream_lds_bytes(int ld, int depth) {
   const int cpb = kSegBlock / (ld / 4);
   return (size_t)cpb * ((size_t)depth * 1024 + (size_t)kStreamItems * 4 + 128) + (size_t)cpb * (ld + 4) * 4;
 }
-// consecutive blocks of the list per workgroup.  The hardware deals workgroups out as slots free up — a static split of the list over
-// resident workgroups (a persistent launch: 6 blocks each at the headline shape, 4 or 5 of them real work) measured 30 % SLOWER than
-// one block per workgroup — so the launch stays fine-grained: a workgroup streams its first block while the second one's keys load.
-#ifndef DRX_STREAM_BPW
-#define DRX_STREAM_BPW 1
-#endif
-constexpr int kStreamBpw = DRX_STREAM_BPW;
-static inline int seg_stream_grid(int ld, int n_blocks) {
-  (void)ld;
-  return (n_blocks + kStreamBpw - 1) / kStreamBpw;
-}
-
 struct StreamArrays {
   uint32_t first_key[3];       // keys [first_key[v], first_key[v + 1]) are rows of array v (ascending; the last array is open-ended)
   const float *grad[3];
@@ -116,7 +105,6 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
   static_assert(2 * CH <= 64 && 3 * CPB <= 64, "a window is one touch per lane; a block's border keys one per lane");
   if ((int)blockIdx.x < extra_blocks) { extra(seg_lds); return; }
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int n_blocks = (S.n_chunks + CPB - 1) / CPB;
   const uint32_t *__restrict__ const ks = S.keys_s, *__restrict__ const vs = S.vals_s;
   const uint8_t *__restrict__ const ext = SP.ext;
   // LDS: the waves' rings, their item tables, their copies of the arrays' offsets, the rows of an all-inner workgroup's chunk sums
@@ -143,9 +131,10 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
   // ext -> window -> keys: three dependent rounds, 2 - 3 us each beside the streams of the other waves): the 64 list positions behind
   // the chunk's start (its window lies in them: it begins ext[g - 1] <= 31 positions in and ends before position 32 + ext[g] <= 63),
   // the key in front of them, the two ext bytes, and — lanes 0 .. 3 CPB - 1 — the first / last / preceding key of every chunk of the
-  // block (is the block all-inner?).  Loaded for the workgroup's NEXT block while it streams this one.
-  struct Meta { uint32_t key, val, bk, prevk; int e0, e1; };
-  auto load_meta = [&](int blk, Meta &m) __attribute__((always_inline)) {
+  // block (is the block all-inner?).
+  struct Meta { uint32_t key, val, bk, prevk; int e0, e1; } m;
+  const int blk = (int)blockIdx.x - extra_blocks;
+  {
     const int g = blk * CPB + wv, base = g * CH, pos = base + lane;
     const bool have = g < S.n_chunks;
     m.key = have && pos < S.T ? ks[pos] : DRX_KEY_NONE;
@@ -156,15 +145,9 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
     const int c = blk * CPB + lane % CPB, role = lane / CPB;
     const int p = role == 0 ? c * CH : (role == 1 ? (c + 1) * CH - 1 : c * CH - 1);
     m.bk = lane < 3 * CPB && c < S.n_chunks && (c + 1) * CH <= S.T && p >= 0 ? ks[p] : DRX_KEY_NONE;
-  };
-  Meta nxt;
-  int blk = ((int)blockIdx.x - extra_blocks) * kStreamBpw;
-  const int blk_end = min(n_blocks, blk + kStreamBpw);
-  if (blk < blk_end) load_meta(blk, nxt);
+  }
   wave_lds_sync();                                      // (offs)
-  for (; blk < blk_end; ++blk) {
-    const Meta m = nxt;
-    if (blk + 1 < blk_end) load_meta(blk + 1, nxt);
+  {
     // a chunk is INNER when it is one whole run of a segment that began before it; a block of inner chunks leaves one partial
     const uint32_t bl = (uint32_t)__shfl((int)m.bk, lane + CPB, 64), bp = (uint32_t)__shfl((int)m.bk, lane + 2 * CPB, 64);
     const bool inner = lane < CPB && m.bk != DRX_KEY_NONE && m.bk == bp && bl == m.bk;
@@ -331,7 +314,6 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
         *reinterpret_cast<V *>(PB.pblock + (size_t)blk * LD + lane * VL) = t;
         if (lane == 0) PB.pbs[blk] = ts;
       }
-      __syncthreads();             // (the rows are free for the workgroup's next all-inner block)
     }
   }
 }
