@@ -992,6 +992,7 @@ struct DirectPolicyT {
   // whose dz1 row they add, with the coefficient 1/(1-q)), W2T rows (g2 rows, coefficient 1, and the scalar dz2 for the output bias),
   // V rows (dz1 rows, coefficient 1); the optimizer is element-wise with one slot (Adagrad: KIND says so at compile time); a row's
   // own value enters its gradient with reg/B (sparse_apply -> row_update), the output bias's does not
+  static constexpr bool kStreamParks = false;                  // every finished row is applied to its table
   __device__ __forceinline__ StreamArrays stream_arrays() const {
     const uint32_t N = (uint32_t)P.n_items;
     return StreamArrays{{0u, N, 2u * N}, {dz1, dz1 + g2_off, dz1}, {P.W, P.W2T, P.V}, {opt.s1[0], opt.s1[1], opt.s1[2]},

@@ -33,6 +33,11 @@
 //   float stream_decay()              weight of a row's own value in its gradient (reg / B)
 //   void stream_update(g, p, a)       one element: gradient g (decay applied), parameter p, slot a
 //   void stream_update_scalar(g, p, a)   the same for an array's scalar side (the output biases: no decay)
+//   static constexpr bool kStreamParks   true: finished rows of some arrays are not applied to a table but PARKED — the sum stored at a
+//                                     place the policy computes (the row-sharded step's gradient exchange buffer, drx_shard.hip):
+//   bool stream_parked(v)             ... rows of array v
+//   void stream_park_at(v, row, roff, soff)   float offsets of the row's sum / of its scalar sum in stream_park_base() (may load: runs
+//                                     before the stream starts, on the lane whose touch finishes the row)
 #pragma once
 #include "drx_segreduce.hpp"
 
@@ -119,10 +124,10 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
   // an item's row array as a byte OFFSET from `origin`, by kind (a select between pointers is lowered to a table in scratch memory)
   if (lane < 15) {
     const int v = lane / 5, k = lane % 5;
-    const char *const g = reinterpret_cast<const char *>(v == 0 ? A.grad[0] : (v == 1 ? A.grad[1] : A.grad[2]));
-    const char *const t = reinterpret_cast<const char *>(v == 0 ? A.table[0] : (v == 1 ? A.table[1] : A.table[2]));
-    const char *const sl = reinterpret_cast<const char *>(v == 0 ? A.slot[0] : (v == 1 ? A.slot[1] : A.slot[2]));
-    offs[lane] = (k <= (int)kItGradTail ? g : (k == (int)kItParam ? t : sl)) - origin;
+    const uintptr_t g = (uintptr_t)(v == 0 ? A.grad[0] : (v == 1 ? A.grad[1] : A.grad[2]));
+    const uintptr_t t = (uintptr_t)(v == 0 ? A.table[0] : (v == 1 ? A.table[1] : A.table[2]));      // (nullptr: a parked array — never an item)
+    const uintptr_t sl = (uintptr_t)(v == 0 ? A.slot[0] : (v == 1 ? A.slot[1] : A.slot[2]));
+    offs[lane] = (long long)((k <= (int)kItGradTail ? g : (k == (int)kItParam ? t : sl)) - (uintptr_t)origin);
   }
   const float decay = pol.stream_decay();
   const int sub = lane / LPI, piece = lane % LPI;     // this lane's row of an LDS-DMA instruction, its 16 bytes of that row
@@ -176,7 +181,11 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
       const bool cont_left = key == key0 && prev_key == key;            // the window's first run began before it
       const bool cont_right = lane == end_off - 1 && next_key == key;   // its last run goes on behind it
       const bool apply = seg_end && !cont_left && !cont_right;
-      const int w = valid ? (apply ? 3 : 1) : 0;
+      const uint32_t av = key < A.first_key[1] ? 0u : (key < A.first_key[2] ? 1u : 2u);        // the touch's array, its row there
+      const uint32_t row = key - (av == 0 ? A.first_key[0] : (av == 1 ? A.first_key[1] : A.first_key[2]));
+      bool parked = false;                                              // the finished row's sum is stored, not applied
+      if constexpr (Policy::kStreamParks) parked = apply && pol.stream_parked(av);
+      const int w = valid ? (apply && !parked ? 3 : 1) : 0;
       int incl = w;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -186,23 +195,25 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
       const int pos = incl - w;
       const int M = __builtin_amdgcn_readlane(incl, 63);
       float sc = 0.f, sp = 0.f, ss = 0.f;                  // this touch's scalar; bias + slot of the row it finishes
+      uint32_t park_row = 0xFFFFFFFFu, park_scal = 0u;     // where the sum of the row this touch finishes is parked (float offsets)
       if (valid) {
-        const uint32_t av = key < A.first_key[1] ? 0u : (key < A.first_key[2] ? 1u : 2u);
-        const uint32_t row = key - (av == 0 ? A.first_key[0] : (av == 1 ? A.first_key[1] : A.first_key[2]));
         const uint32_t kind = 5u * av + (!seg_end || apply ? kItGrad : (cont_left ? kItGradHead : kItGradTail));
         tab[pos] = (val << 4) | kind;
-        if (apply) { tab[pos + 1] = (row << 4) | (5u * av + kItParam); tab[pos + 2] = (row << 4) | (5u * av + kItSlot); }
+        if (apply && !parked) { tab[pos + 1] = (row << 4) | (5u * av + kItParam); tab[pos + 2] = (row << 4) | (5u * av + kItSlot); }
         const float *const sg = av == 0 ? A.sgrad[0] : (av == 1 ? A.sgrad[1] : A.sgrad[2]);
         if (sg) {
           sc = sg[val];
-          if (apply) {
+          if (apply && !parked) {
             sp = (av == 0 ? A.sparam[0] : (av == 1 ? A.sparam[1] : A.sparam[2]))[row];
             ss = (av == 0 ? A.sslot[0] : (av == 1 ? A.sslot[1] : A.sslot[2]))[row];
           }
         }
+        if constexpr (Policy::kStreamParks) {
+          if (parked) pol.stream_park_at(av, row, park_row, park_scal);
+        }
       }
-      // (the scalars have LANDED before the first LDS-DMA goes out: used here, never waited for inside the loop)
-      asm volatile("" : "+v"(sc), "+v"(sp), "+v"(ss));
+      // (the scalars and places have LANDED before the first LDS-DMA goes out: used here, never waited for inside the loop)
+      asm volatile("" : "+v"(sc), "+v"(sp), "+v"(ss), "+v"(park_row), "+v"(park_scal));
       unsigned long long todo = __ballot(valid);            // the window's touches not yet folded (bit = lane)
       int at_lane = 0;                                      // lane of the touch folded last
       wave_lds_sync();
@@ -250,6 +261,19 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
               at_lane = __builtin_ctzll(todo);
               todo &= todo - 1ull;
               accs += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), at_lane));
+              if constexpr (Policy::kStreamParks) {
+                const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)park_row, at_lane);
+                if (ro != 0xFFFFFFFFu) {                      // this touch finished a row whose sum is parked
+                  float *const pb = pol.stream_park_base();
+                  ((GV *)(uintptr_t)(pb + ro))[lane] = acc;
+                  if (av == 0 ? A.sgrad[0] != nullptr : (av == 1 ? A.sgrad[1] != nullptr : A.sgrad[2] != nullptr)) {
+                    if (lane == 0) pb[(uint32_t)__builtin_amdgcn_readlane((int)park_scal, at_lane)] = accs;
+                  }
+#pragma unroll
+                  for (int v = 0; v < VL; ++v) accf[v] = 0.f;
+                  accs = 0.f;
+                }
+              }
               if (kind == kItGradHead) {
                 if (!all_inner) {
                   *reinterpret_cast<V *>(S.phead + (size_t)g * LD + lane * VL) = acc;

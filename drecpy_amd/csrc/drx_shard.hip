@@ -24,6 +24,7 @@
 #include "drx_segreduce.hpp"
 #include "drx_scan.hpp"
 #include "drx_prep.hpp"
+#include "drx_segstream.hpp"
 
 namespace drx {
 
@@ -408,6 +409,31 @@ struct LocalPolicyT {
       if (is_out && lane == 0) gsend[X.scal_off(w, pos)] = gs;
     }
   }
+  // for the streamed reduction (drx_segstream.hpp): three arrays — W and W2T rows (GLOBAL item ids) whose sums are PARKED in the
+  // gradient exchange buffer at the row's place there, V rows (local) applied in place
+  static constexpr bool kStreamParks = true;
+  __device__ __forceinline__ StreamArrays stream_arrays() const {
+    const uint32_t N = (uint32_t)n_items;
+    return StreamArrays{{0u, N, 2u * N}, {dz1, dz1 + g2_off, dz1}, {nullptr, nullptr, P.V}, {nullptr, nullptr, opt.s1[2]},
+                        {scale, 1.0f, 1.0f}, {nullptr, dz2, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  }
+  __device__ __forceinline__ bool stream_parked(uint32_t av) const { return av < 2u; }
+  __device__ __forceinline__ void stream_park_at(uint32_t av, uint32_t item, uint32_t &roff, uint32_t &soff) const {
+    const int o = (int)item / ipr;
+    const uint32_t w = ((uint32_t)o << X.shift) + (uint32_t)(av == 1u ? ipr : 0) + (item - (uint32_t)(o * ipr));
+    const uint32_t pos = X.pos_of(w);
+    roff = (uint32_t)X.row_off(w, pos);
+    soff = (uint32_t)X.scal_off(w, pos);
+  }
+  __device__ __forceinline__ float *stream_park_base() const { return gsend; }
+  __device__ __forceinline__ float stream_decay() const { return opt.reg_rate / (float)b_norm; }
+  __device__ __forceinline__ void stream_update(float g, float &p, float &a) const {
+    static_assert(KIND == DRX_OPT_ADAGRAD || KIND < 0, "one slot per element");
+    OptScalars o = opt_for(opt, 0, b_norm);
+    float unused = 0.f;
+    opt_update1<DRX_OPT_ADAGRAD>(o, g, p, a, unused);
+  }
+  __device__ __forceinline__ void stream_update_scalar(float g, float &p, float &a) const { stream_update(g, p, a); }
 };
 
 // Last extra workgroup of the span launch: the rank's gradient of the hidden bias (sum of the column-sum partials the reduction's
@@ -842,7 +868,19 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
     const dim3 rgrid(n_bpart + (B.n_chunks + cpb - 1) / cpb);                                                          \
     const size_t lds_r = seg_reduce_lds_bytes(cpb, p->ld, long_segments);                                              \
     const size_t lds_b = ((size_t)(kFixBlock / G) * (p->ld + 1)) * 4;                                                  \
-    if (long_segments)                                                                                                 \
+    bool streamed = false;                                                                                             \
+    if constexpr (kStreamDepth > 0 && J == 1 && G >= 16 && KIND == DRX_OPT_ADAGRAD) {                                  \
+      /* lists of short segments over rows of exactly 64 / 128 / 256 floats: the streamed form (drx_segstream.hpp) */  \
+      if (!long_segments && p->ld == 4 * G && bt->B < (1 << kStreamIndexBits) && sh->n_items < (1 << kStreamIndexBits) && \
+          p->n_users < (1 << kStreamIndexBits)) {           /* (places in the exchange buffer are 32-bit float offsets: ShardXfer::foff) */ \
+        BiasPartialExtra<G, J, cpb * 64> bpxs{p->ld, BA};                                                              \
+        hipLaunchKernelGGL((k_seg_reduce_stream<4 * G, kStreamDepth, POLT, BiasPartialExtra<G, J, cpb * 64>>), rgrid, dim3(cpb * 64), \
+                           seg_stream_lds_bytes(p->ld, kStreamDepth), st, SB, PB, L.R.plan, polk, n_bpart, bpxs);      \
+        streamed = true;                                                                                               \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if (streamed) { }                                                                                                  \
+    else if (long_segments)                                                                                            \
       hipLaunchKernelGGL((k_seg_reduce_planned<G, J, POLT, true, BiasPartialExtra<G, J>>), rgrid, dim3(kSegBlock), lds_r, st, SB, PB, \
                          L.R.plan, polk, n_bpart, bpx);                                                                \
     else                                                                                                               \

@@ -533,21 +533,23 @@ class ShardedPipeline:
 
 
 class _SideStream:
-    """`with torch.cuda.stream(side)` that also tells the model which stream is current (event records without the
-    current-stream lookup)"""
+    """Makes `side` torch's current stream for the duration of the block and tells the model which stream is current (event records
+    without the current-stream lookup).  torch.cuda.set_stream on the way in and out: the `torch.cuda.stream(...)` context manager
+    resolves devices and the previous stream through several Python layers — 25 - 30 us per block, three blocks per step (r05:
+    scripts/rows_host_profile.py)."""
 
     def __init__(self, model, side):
-        self.model, self.ctx = model, torch.cuda.stream(side)
-        self.side = side
+        self.model, self.side = model, side
 
     def __enter__(self):
-        self.ctx.__enter__()
+        torch.cuda.set_stream(self.side)
         self.model._cur = self.side
         return self
 
     def __exit__(self, *a):
         self.model._cur = None
-        return self.ctx.__exit__(*a)
+        torch.cuda.set_stream(self.model._main)
+        return False
 
 
 class _Null:

@@ -18,6 +18,7 @@ from helpers import new_rendezvous, retry_infra  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 U, N, K, B, STEPS, Q = 300, 411, 50, 512, 4, 0.2
+K = int(os.environ.get('DRX_TEST_SHARD_K', K))          # (spawned ranks re-import this module: a test hands its K over this way)
 
 
 def _problem(world):
@@ -133,6 +134,20 @@ def test_sharded_world2_on_one_gpu_matches_oracle(tmp_path, pipelined, micro, wo
     _check(world, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)], micro)
 
 
+@pytest.mark.parametrize('world,bypass', [(2, True), (3, False)])
+@retry_infra
+def test_sharded_ranks_with_the_streamed_local_reduction(tmp_path, monkeypatch, world, bypass):
+    """K = 128 (rows of exactly 128 floats: the local reduction is the streamed one) over 2 / 3 ranks sharing the GPU: the parked
+    sums go to the chunks of SEVERAL owners (world 3 splits 411 items unevenly), own chunk last with the bypass."""
+    import sys as _sys
+    monkeypatch.setenv('DRX_TEST_SHARD_K', '128')
+    monkeypatch.setattr(_sys.modules[__name__], 'K', 128)
+    out = str(tmp_path / 'shard')
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker, args=(world, rdzv, out, True, 1, bypass), nprocs=world, join=True)
+    _check(world, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)], 1)
+
+
 def _worker_rccl(rank, rdzv, out, pipelined, micro, bypass=True):
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', init_method=rdzv, rank=0, world_size=1, device_id=torch.device('cuda', 0))
@@ -152,9 +167,11 @@ def test_sharded_step_through_rccl_world1(tmp_path, pipelined, micro, bypass):
     _check(1, [torch.load(f'{out}.0', weights_only=False)], micro)
 
 
-@pytest.mark.parametrize('k', [7, 130, 600])
+@pytest.mark.parametrize('k', [7, 130, 600, 64, 128, 256])
 def test_sharded_world1_other_row_geometries(k, monkeypatch):
-    """The shard kernels in the (8,1), (64,1) and (64,4) lane-group geometries (the tests above run K = 50: (16,1))."""
+    """The shard kernels in the (8,1), (64,1) and (64,4) lane-group geometries (the tests above run K = 50: (16,1)); K = 64 / 128 / 256:
+    rows of exactly 64 / 128 / 256 floats, whose local reduction is the STREAMED one (csrc/drx_segstream.hpp with LocalPolicyT: item
+    rows' sums parked in the gradient exchange buffer, V rows applied in place)."""
     import sys as _sys
     monkeypatch.setattr(_sys.modules[__name__], 'K', k)
     _check(1, [_run_rank(0, 1, False, pipelined=True)])
