@@ -7,64 +7,10 @@
 // in LDS (channel-fastest, [s][f][c]: every lane reads its own column); their gradients are summed per workgroup in
 // registers, unit by unit, in sample order (no atomics) and reduced over workgroups in a second, ordered pass; the
 // gradients of the embedding lookups leave as one row per lookup for drx_rows_csr_adam.
-#include "drx_common.hpp"
-#include "drx_rows.hpp"
+#include "drx_caser_tile.hpp"
 
-#ifdef DRX_STAMPS
-static unsigned long long *h_caser_stamps = nullptr;       // device buffer [B x 16] (diagnostic builds: scripts/stamps_caser.py)
-extern "C" int drx_debug_set_caser_stamps(unsigned long long *buf) { h_caser_stamps = buf; return 0; }
-#define CASER_STAMP_ARG , unsigned long long *stamps
-#define CASER_STAMP_PASS , h_caser_stamps
-#define CSTAMP(i) DRX_STAMP(stamps, b, i, c)
-#else
-#define CASER_STAMP_ARG
-#define CASER_STAMP_PASS
-#define CSTAMP(i) do { } while (0)
-#endif
 
 namespace drx {
-
-constexpr int kCaserMaxL = 8;
-
-__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
-
-// Sums 16 per-lane values across the 64 lanes with 17 shuffles instead of 16 full butterflies (96): each exchange halves
-// the number of values a lane carries.  Afterwards lane l holds the wave total of v[slot16(l)] (four lanes per value).
-__device__ __forceinline__ int slot16(int lane) { return ((lane >> 5) & 1) << 3 | ((lane >> 4) & 1) << 2 | ((lane >> 3) & 1) << 1 | ((lane >> 2) & 1); }
-__device__ __forceinline__ float reduce16(const float (&v)[16], int lane) {
-  float a[8], b[4], c[2];
-  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = (h5 ? v[8 + k] : v[k]) + __shfl_xor(h5 ? v[k] : v[8 + k], 32);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) b[k] = (h4 ? a[4 + k] : a[k]) + __shfl_xor(h4 ? a[k] : a[4 + k], 16);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) c[k] = (h3 ? b[2 + k] : b[k]) + __shfl_xor(h3 ? b[k] : b[2 + k], 8);
-  float d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4);
-  d += __shfl_xor(d, 2);
-  d += __shfl_xor(d, 1);
-  return d;
-}
-
-// The same for 8 values (10 shuffles): afterwards lane l holds the wave total of v[slot8(l)] (eight lanes per value); lane8(j) is
-// the first lane that holds value j.
-__device__ __forceinline__ int slot8(int lane) { return ((lane >> 5) & 1) << 2 | ((lane >> 4) & 1) << 1 | ((lane >> 3) & 1); }
-__device__ __forceinline__ constexpr int lane8(int j) { return ((j >> 2) & 1) << 5 | ((j >> 1) & 1) << 4 | (j & 1) << 3; }
-__device__ __forceinline__ float reduce8(const float (&v)[8], int lane) {
-  float a[4], b[2];
-  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) a[k] = (h5 ? v[4 + k] : v[k]) + __shfl_xor(h5 ? v[k] : v[4 + k], 32);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) b[k] = (h4 ? a[2 + k] : a[k]) + __shfl_xor(h4 ? a[k] : a[2 + k], 16);
-  float d = (h3 ? b[1] : b[0]) + __shfl_xor(h3 ? b[0] : b[1], 8);
-  d += __shfl_xor(d, 4);
-  d += __shfl_xor(d, 2);
-  d += __shfl_xor(d, 1);
-  return d;
-}
-
-__device__ __forceinline__ float lane_f(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 
 struct CaserLds {
   float *E;       // [L][64] item rows of the current sample
@@ -75,26 +21,6 @@ struct CaserLds {
   int *arg;       // [nx]
   float *dz0s;    // [64] dense_0's pre-activation gradient of the sample (read by the accumulating waves)
 };
-
-// act_h / act_mlp of caser.py:29-30 (Keras activation names): value and derivative at pre-activation v (a = act(v)).
-__device__ __forceinline__ float act_f(int kind, float v) {
-  switch (kind) {
-    case DRX_ACT_RELU: return fmaxf(v, 0.f);
-    case DRX_ACT_TANH: return tanhf(v);
-    case DRX_ACT_SIGMOID: return sigmoidf_(v);
-    default: return v;
-  }
-}
-__device__ __forceinline__ float act_df(int kind, float v) {
-  switch (kind) {
-    case DRX_ACT_RELU: return v > 0.f ? 1.f : 0.f;
-    case DRX_ACT_TANH: { const float a = tanhf(v); return 1.f - a * a; }
-    case DRX_ACT_SIGMOID: { const float a = sigmoidf_(v); return a * (1.f - a); }
-    default: return 1.f;
-  }
-}
-
-__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
 // The NT tap rows of one horizontal (height, filter) pair: sum over the round's samples t of E_t[arg_t + s][c] * dc_t, samples in
 // order; lane t holds dc_t / arg_t (dcl / tal).  g = this lane's slot of tap 0 in the workgroup's partial sums, taps `tap` floats apart.
@@ -493,6 +419,8 @@ __global__ __launch_bounds__(kBlock) void k_adam_segments(float *p, float *m, fl
 }
 
 // the small weights (+ 64 zeros) and a scratch per wave: E | x | xd | pre | dx | arg | dz0
+constexpr size_t kCaserLdsLimit = 160 * 1024 - 256;    // dynamic LDS a workgroup may ask for (beside the kernel's static words)
+
 static size_t caser_lds_bytes(const DrxCaserDims &D, bool, int waves) {
   const int nx = D.n_v + D.L * D.n_h;
   return ((size_t)D.n_small + 64 + (size_t)waves * ((size_t)D.L * 64 + 5 * (size_t)nx + 64)) * 4 + 64;
@@ -519,11 +447,25 @@ using namespace drx;
 
 extern "C" {
 
+// the training kernel's variant for these dimensions: 1 = convolution weights in LDS, 0 = read from global memory, -1 = the tile's own
+// scratch does not fit a workgroup's LDS (nx too large)
+static int caser_tile_variant(const DrxCaserDims &D) {
+  if ((size_t)caser_tile_geom(D, true).floats * 4 <= kCaserLdsLimit) return 1;
+  if ((size_t)caser_tile_geom(D, false).floats * 4 <= kCaserLdsLimit) return 0;
+  return -1;
+}
+
 int drx_caser_grid(const DrxCaserDims *D, int32_t B) {
-  if (!D || B < 1) return 0;
+  if (!D || B < 1 || check_dims(D) != DRX_OK) return 0;
+#ifdef DRX_CASER_WAVE
   const int w = caser_waves(*D, true, B);
   const int g = (B + w - 1) / w;
   return g < 512 ? g : 512;
+#else
+  if (caser_tile_variant(*D) < 0) return 0;
+  const int g = (B + kTileSamples - 1) / kTileSamples;       // one workgroup per CU (its LDS), tiles of 16 samples in turn
+  return g < 256 ? g : 256;
+#endif
 }
 
 int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, void *stream) {
@@ -534,10 +476,23 @@ int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_o
     return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = drx_caser_grid(D, A->B);
+  if (grid < 1) return DRX_EINVAL;
+#ifdef DRX_CASER_WAVE
   const int waves = caser_waves(*D, true, A->B);
   const size_t lds = caser_lds_bytes(*D, true, waves);
   DRX_HIP(hipFuncSetAttribute((const void *)k_caser<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_caser<true>, dim3(grid), dim3(64 * waves), lds, st, *D, *A CASER_STAMP_PASS);
+#else
+  const int var = caser_tile_variant(*D);
+  const size_t lds = (size_t)caser_tile_geom(*D, var == 1).floats * 4;
+  if (var == 1) {
+    DRX_HIP(hipFuncSetAttribute((const void *)k_caser_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_caser_tile<true>, dim3(grid), dim3(64 * kTileWaves), lds, st, *D, *A CASER_STAMP_PASS);
+  } else {
+    DRX_HIP(hipFuncSetAttribute((const void *)k_caser_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_caser_tile<false>, dim3(grid), dim3(64 * kTileWaves), lds, st, *D, *A CASER_STAMP_PASS);
+  }
+#endif
   hipLaunchKernelGGL(k_sum_partials, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
                      A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();

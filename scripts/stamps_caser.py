@@ -1,6 +1,6 @@
 """Phase stamps of k_caser (diagnostic build: bash scripts/build_variant.sh stamps "-DDRX_STAMPS").
     DRX_HOST_SANITIZER_LIB=$PWD/drecpy_amd/csrc/build/libdrx_stamps.so python scripts/stamps_caser.py
-One Caser step at the ml-1m shape, B = 4096 (BASELINE configuration 5); prints each phase's mean / p50 / p90 per sample (wave) in
+One Caser step at the ml-1m shape, B = 4096 (BASELINE configuration 5); prints each phase's mean / p50 / p90 per workgroup (its first tile of 16 samples) in
 microseconds of the device's 100 MHz clock."""
 import ctypes as C
 import json
@@ -33,14 +33,16 @@ def main():
     m._do_batch(batch, step=8)
     torch.cuda.synchronize()
     assert L.drx_debug_set_caser_stamps(None) == 0
-    st = buf.cpu().numpy().reshape(B, 16)[:, :12].astype(np.float64) * 0.01
+    G = (B + 15) // 16
+    G = min(G, 256)
+    st = buf.cpu().numpy().reshape(B, 16)[:G, :11].astype(np.float64) * 0.01
     ok = (st > 0).all(axis=1)
     st = st[ok]
-    labels = ['embeddings', 'vertical conv', 'horizontal convs', 'dropout', 'dense_0', 'targets + BCE', 'dense_0 backward', 'vertical backward',
-              'horizontal backward', 'dE rows out', 'wait + small-weight accumulation (W turns)']
+    labels = ['weights -> LDS', '0 rows in', '1 convs forward', '2 max / act / dropout', '3 dense_0', '4 targets', '5 dense_0 backward',
+              '6 act_h backward, scatter', '7 dE rows', '8 small-weight gradients']
     d = np.diff(st, axis=1)
-    out = {'samples': int(ok.sum()), 'kernel_span_us': float(st.max() - st.min()),
-           'sample_life_us': {'mean': float((st[:, -1] - st[:, 0]).mean()), 'p90': float(np.percentile(st[:, -1] - st[:, 0], 90))},
+    out = {'workgroups': int(ok.sum()), 'kernel_span_us': float(st.max() - st.min()),
+           'first_tile_life_us': {'mean': float((st[:, -1] - st[:, 0]).mean()), 'p90': float(np.percentile(st[:, -1] - st[:, 0], 90))},
            'first_start_spread_us': float(st[:, 0].max() - st[:, 0].min())}
     for i, lab in enumerate(labels):
         out[lab] = {'mean': round(float(d[:, i].mean()), 2), 'p50': round(float(np.median(d[:, i])), 2), 'p90': round(float(np.percentile(d[:, i], 90)), 2)}
