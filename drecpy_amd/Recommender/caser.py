@@ -31,7 +31,7 @@ class Caser(RecommenderABC):
             raise Exception(f'drecpy_amd.Caser supports the activations {supported[:4]} (given: act_h={act_h!r}, act_mlp={act_mlp!r}).')
         if not (1 <= L <= 64 and 1 <= d <= 1024):
             raise Exception(f'drecpy_amd.Caser supports 1 <= L <= 64 and 1 <= d <= 1024 (given: L={L}, d={d}).')
-        # the fused kernel (drx_caser.hip: a lane per embedding channel, the window unrolled) takes L <= 8 and d <= 64 — BASELINE
+        # the fused kernels (drx_caser_tile.hpp: tiles of 16 samples on the matrix cores; drx_caser.hip: inference) take L <= 8 and d <= 64 — BASELINE
         # configuration 5 and examples/caser.py (L = 5, d = 50); beyond that the reference's semantics are kept by the generic engine
         # (engine_caser_wide.py: torch.autograd in tf.GradientTape's place, the library's Keras-Adam kernel per registered layer)
         self._fused = L <= 8 and d <= 64
@@ -45,8 +45,17 @@ class Caser(RecommenderABC):
         from ..engine_caser import CaserEngine
         from ..engine_caser_wide import CaserWideEngine
         self.neg_ratio = neg_ratio
-        self._engine = (CaserEngine if self._fused else CaserWideEngine)(self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v,
-                                                                       self.n_h, device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
+        args = (self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v, self.n_h)
+        if self._fused:
+            from .._lib import DrxError
+            try:
+                self._engine = CaserEngine(*args, device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
+            except DrxError as e:
+                if 'LDS tiles' not in str(e):
+                    raise
+                self._fused = False               # (very many filters: the kernels' tiles do not fit the LDS — the generic engine takes it)
+        if not self._fused:
+            self._engine = CaserWideEngine(*args, device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
         self._engine.lr, self._engine.reg = float(learning_rate), float(reg_rate)
         weights = kwds.get('initial_weights')
         if weights is None:

@@ -49,9 +49,12 @@ class Shard(C.Structure):
                 ('n_users_local', C.c_int32), ('flags', C.c_uint32)]
 
 
+MAX_SEGMENTS = 24                       # include/drx.h DRX_MAX_SEGMENTS
+
+
 class AdamSegments(C.Structure):
-    _fields_ = [('n', C.c_int32), ('start', C.c_int32 * 16), ('len', C.c_int32 * 16), ('alpha', C.c_float * 16),
-                ('l2_coef', C.c_float * 16)]
+    _fields_ = [('n', C.c_int32), ('start', C.c_int32 * MAX_SEGMENTS), ('len', C.c_int32 * MAX_SEGMENTS), ('alpha', C.c_float * MAX_SEGMENTS),
+                ('l2_coef', C.c_float * MAX_SEGMENTS)]
 
 
 class CaserDims(C.Structure):

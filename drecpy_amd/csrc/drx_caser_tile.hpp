@@ -23,16 +23,14 @@
 #include "drx_rows.hpp"
 
 #ifdef DRX_STAMPS
-static unsigned long long *h_caser_stamps = nullptr;       // device buffer [B x 16] (diagnostic builds: scripts/stamps_caser.py)
+static unsigned long long *h_caser_stamps = nullptr;       // device buffer [tiles x 16] (diagnostic builds: scripts/stamps_caser.py)
 extern "C" int drx_debug_set_caser_stamps(unsigned long long *buf) { h_caser_stamps = buf; return 0; }
 #define CASER_STAMP_ARG , unsigned long long *stamps
 #define CASER_STAMP_PASS , h_caser_stamps
-#define CSTAMP(i) DRX_STAMP(stamps, b, i, c)
-#define TSTAMP(i) DRX_STAMP(stamps, blockIdx.x, i, threadIdx.x)
+#define TSTAMP(i) DRX_STAMP(stamps, tile_id, i, threadIdx.x)
 #else
 #define CASER_STAMP_ARG
 #define CASER_STAMP_PASS
-#define CSTAMP(i) do { } while (0)
 #define TSTAMP(i) do { } while (0)
 #endif
 
@@ -40,28 +38,9 @@ namespace drx {
 
 constexpr int kCaserMaxL = 8;
 
-__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
-
-// Sums 16 per-lane values across the 64 lanes with 17 shuffles instead of 16 full butterflies (96): each exchange halves
-// the number of values a lane carries.  Afterwards lane l holds the wave total of v[slot16(l)] (four lanes per value).
-__device__ __forceinline__ int slot16(int lane) { return ((lane >> 5) & 1) << 3 | ((lane >> 4) & 1) << 2 | ((lane >> 3) & 1) << 1 | ((lane >> 2) & 1); }
-__device__ __forceinline__ float reduce16(const float (&v)[16], int lane) {
-  float a[8], b[4], c[2];
-  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = (h5 ? v[8 + k] : v[k]) + __shfl_xor(h5 ? v[k] : v[8 + k], 32);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) b[k] = (h4 ? a[4 + k] : a[k]) + __shfl_xor(h4 ? a[k] : a[4 + k], 16);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) c[k] = (h3 ? b[2 + k] : b[k]) + __shfl_xor(h3 ? b[k] : b[2 + k], 8);
-  float d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4);
-  d += __shfl_xor(d, 2);
-  d += __shfl_xor(d, 1);
-  return d;
-}
-
-// The same for 8 values (10 shuffles): afterwards lane l holds the wave total of v[slot8(l)] (eight lanes per value); lane8(j) is
-// the first lane that holds value j.
+// Sums 8 per-lane values across the 64 lanes with 10 shuffles instead of 8 full butterflies (48): each exchange halves the number of
+// values a lane carries.  Afterwards lane l holds the wave total of v[slot8(l)] (eight lanes per value); lane8(j) is the first lane that
+// holds value j.
 __device__ __forceinline__ int slot8(int lane) { return ((lane >> 5) & 1) << 2 | ((lane >> 4) & 1) << 1 | ((lane >> 3) & 1); }
 __device__ __forceinline__ constexpr int lane8(int j) { return ((j >> 2) & 1) << 5 | ((j >> 1) & 1) << 4 | (j & 1) << 3; }
 __device__ __forceinline__ float reduce8(const float (&v)[8], int lane) {
@@ -98,17 +77,19 @@ __device__ __forceinline__ float act_df(int kind, float v) {
   }
 }
 
-__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
-constexpr int kTileWaves = 8;
 constexpr int kTileSamples = 16;
 constexpr int kCT = 16 * 17;            // floats of one 16 x 16 tile in LDS: [column][17]
 constexpr int kSP = 68;                 // per-sample stride of the 64-wide vectors (quarter odd)
+#ifndef DRX_CASER_TILE_WAVES
+#define DRX_CASER_TILE_WAVES 8
+#endif
+constexpr int kTileWaves = DRX_CASER_TILE_WAVES;       // 16: one sample per wave in the per-sample phases, 8: two
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 struct CaserTileGeom {
-  int nwl;          // floats of weights kept in LDS (0: read from global)
+  int nwl;          // floats of weights kept in LDS
   int SB;           // per-sample stride of E
   int SX;           // per-sample stride of x / pre / dx / arg
   int KC;           // k-steps over the channels (ceil(d / 4))
@@ -117,7 +98,7 @@ struct CaserTileGeom {
   int NJ;           // 16-unit tiles over nx
   int TV0;          // first vertical tile in the tile array
   int n_ct;         // tiles in the array
-  int o_E, o_PU, o_Z0, o_Z, o_DZ0, o_XD, o_PRE, o_DX, o_ARG, o_CT;   // float offsets in dynamic LDS
+  int o_E, o_PU, o_Z0, o_Z1, o_DZ0, o_XD, o_PRE, o_DX, o_ARG, o_CT;   // float offsets in dynamic LDS
   int floats;
 };
 
@@ -126,10 +107,11 @@ __host__ __device__ inline int odd_quarter(int n) {          // n rounded up to 
   return ((n >> 2) & 1) ? n : n + 4;
 }
 
-__host__ __device__ inline CaserTileGeom caser_tile_geom(const DrxCaserDims &D, bool weights_in_lds) {
+// wl: 2 = every small weight in LDS, 1 = the convolution weights (sw[0 .. off_wd)), 0 = none (read from global memory)
+__host__ __device__ inline CaserTileGeom caser_tile_geom(const DrxCaserDims &D, int wl) {
   CaserTileGeom g;
   const int nx = D.n_v + D.L * D.n_h;
-  g.nwl = weights_in_lds ? D.off_wd + 64 : 0;
+  g.nwl = wl == 2 ? D.n_small + 64 : wl == 1 ? D.off_wd + 64 : 0;
   g.SB = odd_quarter(D.L * D.ld);
   g.SX = odd_quarter(nx);
   g.KC = (D.d + 3) / 4;
@@ -143,7 +125,7 @@ __host__ __device__ inline CaserTileGeom caser_tile_geom(const DrxCaserDims &D, 
   g.o_E = o; o += kTileSamples * g.SB + 64;
   g.o_PU = o; o += kTileSamples * kSP;
   g.o_Z0 = o; o += kTileSamples * kSP;
-  g.o_Z = o; o += kTileSamples * kSP;
+  g.o_Z1 = o; o += kTileSamples * kSP;
   g.o_DZ0 = o; o += kTileSamples * kSP;
   g.o_XD = o; o += kTileSamples * g.SX;
   g.o_PRE = o; o += kTileSamples * g.SX;
@@ -156,37 +138,59 @@ __host__ __device__ inline CaserTileGeom caser_tile_geom(const DrxCaserDims &D, 
 
 __device__ __forceinline__ f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// N k-steps of one 16 x 16 product: the 2 N fragment loads first (fa(k), fb(k): unconditional loads — a branch per load would put a
+// wait in front of every one of them), then the N MFMAs, alternating between two accumulators
+template <int N, class FA, class FB>
+__device__ __forceinline__ void mfma_chunk(int k0, FA fa, FB fb, f4v &a0, f4v &a1) {
+  float av[N], bv[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) { av[n] = fa(k0 + n); bv[n] = fb(k0 + n); }
+  __builtin_amdgcn_sched_barrier(0);            // (left alone the scheduler pairs every two loads with a wait and two MFMAs)
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    if (n & 1) a1 = mfma4(av[n], bv[n], a1);
+    else a0 = mfma4(av[n], bv[n], a0);
+  }
+}
+// k-steps [k, K): chunks of 8, one of 4, single steps — no step is padded
+template <class FA, class FB>
+__device__ __forceinline__ void mfma_k(int k, int K, FA fa, FB fb, f4v &a0, f4v &a1) {
+  for (; k + 8 <= K; k += 8) mfma_chunk<8>(k, fa, fb, a0, a1);
+  if (k + 4 <= K) { mfma_chunk<4>(k, fa, fb, a0, a1); k += 4; }
+  for (; k < K; ++k) mfma_chunk<1>(k, fa, fb, a0, a1);
+}
+
+// Workgroup barrier that orders LDS traffic only: the waves of a tile exchange everything through LDS, and a __syncthreads() would also
+// wait for every global store in flight (the gradient rows of the lookups, the partial sums) at each of the tile's seven barriers.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // first tile of (height i, position 0) in the tile array, NTh tiles per (i, t)
 __device__ __forceinline__ int ct_first(int i, int L, int NTh) { return (i * L - (i * (i - 1)) / 2) * NTh; }
 
-template <bool WL>
-__global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D, DrxCaserArgs A CASER_STAMP_ARG) {
+// FX = 1: the dimensions of examples/caser.py:13 (BASELINE configuration 5: L = 5, d = 50, n_v = 4, n_h = 16, T = 3, 9 negatives) as
+// compile-time constants — trip counts, strides and tile counts fold, the loops over heights / positions / taps unroll; FX = 0: any.
+template <int WL, int FX>
+__global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_in, DrxCaserArgs A CASER_STAMP_ARG) {
+  DrxCaserDims D = D_in;
+  if (FX == 1) { D.L = 5; D.d = 50; D.ld = 52; D.ld2 = 100; D.n_v = 4; D.n_h = 16; D.T = 3; D.Tp = 12; }
+  constexpr int NW = kTileWaves, SPW = kTileSamples / NW;          // samples per wave in the per-sample phases
   extern __shared__ __align__(16) float lds[];
   const CaserTileGeom G = caser_tile_geom(D, WL);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int m16 = lane & 15, q4 = lane >> 4;
   const int L = D.L, d = D.d, ld = D.ld, n_v = D.n_v, n_h = D.n_h, nx = n_v + L * n_h;
   const int SB = G.SB, SX = G.SX, KC = G.KC, NC = G.NC, NTh = G.NTh, NTv = G.NTv, NJ = G.NJ, TV0 = G.TV0;
   float *const wl = lds;
-  float *const E = lds + G.o_E, *const PU = lds + G.o_PU, *const Z0 = lds + G.o_Z0, *const Z = lds + G.o_Z, *const DZ0 = lds + G.o_DZ0;
+  float *const E = lds + G.o_E, *const PU = lds + G.o_PU, *const Z0 = lds + G.o_Z0, *const Z1 = lds + G.o_Z1, *const DZ0 = lds + G.o_DZ0;
   float *const XD = lds + G.o_XD, *const PRE = lds + G.o_PRE, *const DX = lds + G.o_DX, *const CT = lds + G.o_CT;
   int *const ARG = reinterpret_cast<int *>(lds + G.o_ARG);
-  __shared__ float wloss[kTileWaves];
+  __shared__ float wloss[NW];
   // a convolution weight / a dense_0 weight
-  auto cw = [&](int off) __attribute__((always_inline)) -> float { return WL ? wl[off] : A.sw[off]; };
-  auto gw = [&](int off) __attribute__((always_inline)) -> float { return A.sw[off]; };
-
-  TSTAMP(0);
-  if (WL) {
-    for (int i = threadIdx.x * 4; i < D.off_wd; i += blockDim.x * 4)   // (every segment of sw is a multiple of 4 floats long)
-      *reinterpret_cast<float4 *>(wl + i) = *reinterpret_cast<const float4 *>(A.sw + i);
-    if (threadIdx.x < 64) wl[D.off_wd + threadIdx.x] = 0.f;
-  }
-  // E's padding (gaps between samples, the tail a 16-column read runs into) and x's k-padding stay zero throughout
-  for (int i = threadIdx.x; i < kTileSamples * SB + 64; i += blockDim.x) E[i] = 0.f;
-  for (int i = threadIdx.x; i < kTileSamples * SX; i += blockDim.x) XD[i] = 0.f;
-  __syncthreads();
-  TSTAMP(1);
+  auto cw = [&](int off) __attribute__((always_inline)) -> float { return WL >= 1 ? wl[off] : A.sw[off]; };
+  auto gw = [&](int off) __attribute__((always_inline)) -> float { return WL == 2 ? wl[off] : A.sw[off]; };
 
   float loss_acc = 0.f;
   const float inv_bt = 1.0f / ((float)A.B * (float)D.Tp);
@@ -199,167 +203,218 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D, 
     if (hashed) return hash_u32(A.mask_seed, (uint32_t)gb, (uint32_t)j) >= rthr;
     return true;
   };
+  // the rows of dense_1 of eight targets of sample gb (targets j0 .. j0 + 7) and, in the lanes that will hold target jm's score, its bias
+  auto load_targets = [&](int gb, int j0, float (&wa)[8], float (&wb)[8], float &bm) __attribute__((always_inline)) {
+    const bool live = lane < d;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      const bool on = live && gb < A.B && j0 + qq < D.Tp;
+      const int n = on ? A.after[(size_t)gb * D.Tp + j0 + qq] : 0;
+      wa[qq] = on ? A.W1[(size_t)n * D.ld2 + lane] : 0.f;
+      wb[qq] = on ? A.W1[(size_t)n * D.ld2 + d + lane] : 0.f;
+    }
+    const int jm = j0 + slot8(lane);
+    bm = (gb < A.B && jm < D.Tp) ? A.b1[A.after[(size_t)gb * D.Tp + jm]] : 0.f;
+  };
   float *const gp = A.gsw_part + (size_t)blockIdx.x * D.n_small;
   const int n_tiles = (A.B + kTileSamples - 1) / kTileSamples;
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b0 = tile * kTileSamples;
     const bool first = tile == (int)blockIdx.x;
-    // ---- 0. the tile's item rows and user rows: every wave its two samples, all row reads in flight together ------------------
-    {
-      float e[2][kCaserMaxL], pu[2];
+    [[maybe_unused]] const int tile_id = tile;
+    TSTAMP(0);
+    // (the lane's coordinates in an MFMA fragment, opaque per tile: what is derived from them is computed where it is used instead of
+    //  being hoisted — by the dozen — in front of the tile loop)
+    int m16 = lane & 15, q4 = lane >> 4;
+    asm volatile("" : "+v"(m16), "+v"(q4));
+    // ---- 0. the tile's item rows and user rows, and the dense_1 rows of the first 16 targets of every sample (used in step 4):
+    //         every wave its samples, all row reads in flight together, the weights' copy into LDS behind them ----------------------
+    // Loads in the order of their dependence chains: the samples' indices, the weights (first tile), the item / user rows (they need
+    // the indices), the dense_1 rows.  Loads return in order, so the stores into LDS below wait for no more than they need.
+    constexpr int WCH = 10;                               // float4s of weights a thread has in flight: 80 KB per workgroup and pass
+    const int nw = WL == 2 ? D.n_small : WL == 1 ? D.off_wd : 0;
+    int ib[SPW], ia[SPW], iu[SPW];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int gb = b0 + w + kTileWaves * k;
-        const bool has = gb < A.B;
-        const int mine = (has && lane < L) ? A.before[(size_t)gb * L + lane] : 0;
+    for (int k = 0; k < SPW; ++k) {
+      const int gb = b0 + w + NW * k;
+      const bool has = gb < A.B;
+      ib[k] = (has && lane < L) ? A.before[(size_t)gb * L + lane] : 0;
+      ia[k] = (has && lane < D.Tp) ? A.after[(size_t)gb * D.Tp + lane] : 0;      // (lane j: target j; the first 16 are used here)
+      iu[k] = has ? A.uid[gb] : 0;
+    }
+    float4 wbuf[WCH];
+    if (first && WL) {
 #pragma unroll
-        for (int t = 0; t < kCaserMaxL; ++t) {
-          const int n = __shfl(mine, t);
-          e[k][t] = (t < L && has && lane < d) ? A.item_emb[(size_t)n * ld + lane] : 0.f;
-        }
-        const int u = has ? A.uid[gb] : 0;
-        pu[k] = (has && lane < d) ? A.user_emb[(size_t)u * ld + lane] : 0.f;
+      for (int c = 0; c < WCH; ++c)                       // (every segment of sw is a multiple of 4 floats long; clamped: no branch per load)
+        wbuf[c] = *reinterpret_cast<const float4 *>(A.sw + min((int)(threadIdx.x + c * blockDim.x) * 4, nw - 4));
+    }
+    float e[SPW][kCaserMaxL], pu[SPW];
+    float pwa[SPW][2][8], pwb[SPW][2][8], pbm[SPW][2];
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+      const bool on = b0 + w + NW * k < A.B && lane < d;
+#pragma unroll
+      for (int t = 0; t < kCaserMaxL; ++t) {
+        const int n = __shfl(ib[k], t);
+        e[k][t] = (t < L && on) ? A.item_emb[(size_t)n * ld + lane] : 0.f;
       }
+      pu[k] = on ? A.user_emb[(size_t)iu[k] * ld + lane] : 0.f;
+    }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int b = w + kTileWaves * k;
+    for (int k = 0; k < SPW; ++k) {
+      const bool on = b0 + w + NW * k < A.B && lane < d;
+      const float b1v = (b0 + w + NW * k < A.B && lane < D.Tp) ? A.b1[ia[k]] : 0.f;        // (lane j: the bias of target j)
 #pragma unroll
-        for (int t = 0; t < kCaserMaxL; ++t)
-          if (t < L && lane < ld) E[b * SB + t * ld + lane] = e[k][t];
-        PU[b * kSP + lane] = pu[k];
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+          const int n = __shfl(ia[k], 8 * r + qq);
+          const bool t_on = on && 8 * r + qq < D.Tp;
+          pwa[k][r][qq] = t_on ? A.W1[(size_t)n * D.ld2 + lane] : 0.f;
+          pwb[k][r][qq] = t_on ? A.W1[(size_t)n * D.ld2 + d + lane] : 0.f;
+        }
+        pbm[k][r] = __shfl(b1v, 8 * r + slot8(lane));
       }
     }
-    __syncthreads();
+    if (first) {
+      if (WL) {
+#pragma unroll
+        for (int c = 0; c < WCH; ++c) {
+          const int i = (int)(threadIdx.x + c * blockDim.x) * 4;
+          if (i < nw) *reinterpret_cast<float4 *>(wl + i) = wbuf[c];
+        }
+        for (int i = (int)(threadIdx.x + WCH * blockDim.x) * 4; i < nw; i += blockDim.x * 4)      // (more than 80 KB of weights)
+          *reinterpret_cast<float4 *>(wl + i) = *reinterpret_cast<const float4 *>(A.sw + i);
+        if (threadIdx.x < 64) wl[nw + threadIdx.x] = 0.f;
+      }
+      // E's padding (the gap behind every sample's rows, the tail a 16-column read runs into), x's k-padding and the tiles' unused
+      // columns stay zero throughout (none of it is a place a row is written to: no barrier between this and the rows' stores)
+      const int gapE = SB - L * ld, gapX = SX - nx;
+      for (int i = threadIdx.x; i < kTileSamples * gapE; i += blockDim.x) E[(i / gapE) * SB + L * ld + i % gapE] = 0.f;
+      if (threadIdx.x < 64) E[kTileSamples * SB + threadIdx.x] = 0.f;
+      for (int i = threadIdx.x; i < kTileSamples * gapX; i += blockDim.x) XD[(i / gapX) * SX + nx + i % gapX] = 0.f;
+      for (int i = threadIdx.x; i < G.n_ct * kCT; i += blockDim.x) CT[i] = 0.f;
+    }
+    TSTAMP(1);
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+      const int b = w + NW * k;
+#pragma unroll
+      for (int t = 0; t < kCaserMaxL; ++t)
+        if (t < L && lane < ld) E[b * SB + t * ld + lane] = e[k][t];
+      PU[b * kSP + lane] = pu[k];
+    }
+    lds_barrier();
     TSTAMP(2);
-    // ---- 1. convolutions forward: one 16 x 16 tile of pre-activations per (vertical filter tile) / (height, position, filter tile)
+    // ---- 1. convolutions forward.  One unit = a 16-filter tile of the vertical conv, or of the horizontal conv of height i with its
+    //         positions t in turn: 16 samples x 16 filters of pre-activations per position in the MFMA's accumulators, the lane keeps
+    //         the running maximum of its four (sample, filter) pairs — the first maximum wins, like the max-pool gradient — and writes
+    //         x after dropout, the pre-activation at the arg-max and the arg-max (caser.py:103-114) ------------------------------------
     {
       int u = 0;
       for (int nt = 0; nt < NTv; ++nt, ++u) {
-        if (u % kTileWaves != w) continue;
+        if (u % NW != w) continue;
         const int f = 16 * nt + m16;
         const bool fv = f < n_v;
         f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
         for (int t = 0; t < L; ++t) {
-          const float *const e = E + m16 * SB + t * ld + q4;
+          const float *const ep = E + m16 * SB + t * ld + q4;
           const int wo = D.off_kv + (t * n_v + (fv ? f : 0)) * ld + q4;
-          int kc = 0;
-          for (; kc + 1 < KC; kc += 2) {
-            a0 = mfma4(e[4 * kc], fv ? cw(wo + 4 * kc) : 0.f, a0);
-            a1 = mfma4(e[4 * kc + 4], fv ? cw(wo + 4 * kc + 4) : 0.f, a1);
-          }
-          if (kc < KC) a0 = mfma4(e[4 * kc], fv ? cw(wo + 4 * kc) : 0.f, a0);
+          mfma_k(0, KC, [&](int k) __attribute__((always_inline)) { return ep[4 * k]; },
+                 [&](int k) __attribute__((always_inline)) { const float v = cw(wo + 4 * k); return fv ? v : 0.f; }, a0, a1);
         }
-        float *const ct = CT + (TV0 + nt) * kCT + m16 * 17 + 4 * q4;
+        if (fv) {
+          const float bias = cw(D.off_bv + f);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ct[r] = a0[r] + a1[r];
+          for (int r = 0; r < 4; ++r) {
+            const int b = 4 * q4 + r;
+            XD[b * SX + f] = kept(b0 + b, f) ? (a0[r] + a1[r] + bias) * inv_keep : 0.f;
+          }
+        }
       }
-      for (int i = L - 1; i >= 0; --i)                      // (tallest filters first: the units are dealt out in order of cost)
-        for (int t = 0; t + i < L; ++t)
-          for (int nt = 0; nt < NTh; ++nt, ++u) {
-            if (u % kTileWaves != w) continue;
-            const int f = 16 * nt + m16;
-            const bool fv = f < n_h;
+      for (int i = L - 1; i >= 0; --i)
+        for (int nt = 0; nt < NTh; ++nt, ++u) {
+          if (u % NW != w) continue;
+          const int f = 16 * nt + m16;
+          const bool fv = f < n_h;
+          const float bias = fv ? cw(D.off_bh[i] + f) : 0.f;
+          float best[4], bpre[4];
+          int barg[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { best[r] = -3.0e38f; bpre[r] = 0.f; barg[r] = 0; }
+          for (int t = 0; t + i < L; ++t) {
             f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
             for (int s = 0; s <= i; ++s) {
-              const float *const e = E + m16 * SB + (t + s) * ld + q4;
+              const float *const ep = E + m16 * SB + (t + s) * ld + q4;
               const int wo = D.off_kh[i] + (s * n_h + (fv ? f : 0)) * ld + q4;
-              int kc = 0;
-              for (; kc + 1 < KC; kc += 2) {
-                a0 = mfma4(e[4 * kc], fv ? cw(wo + 4 * kc) : 0.f, a0);
-                a1 = mfma4(e[4 * kc + 4], fv ? cw(wo + 4 * kc + 4) : 0.f, a1);
-              }
-              if (kc < KC) a0 = mfma4(e[4 * kc], fv ? cw(wo + 4 * kc) : 0.f, a0);
+              mfma_k(0, KC, [&](int k) __attribute__((always_inline)) { return ep[4 * k]; },
+                     [&](int k) __attribute__((always_inline)) { const float v = cw(wo + 4 * k); return fv ? v : 0.f; }, a0, a1);
             }
-            float *const ct = CT + ((ct_first(i, L, NTh) + t * NTh) + nt) * kCT + m16 * 17 + 4 * q4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ct[r] = a0[r] + a1[r];
+            for (int r = 0; r < 4; ++r) {
+              const float v = a0[r] + a1[r] + bias;
+              const float rr = act_f(D.act_h, v);
+              if (rr > best[r]) { best[r] = rr; barg[r] = t; bpre[r] = v; }
+            }
           }
-    }
-    __syncthreads();
-    TSTAMP(3);
-    // ---- 2. bias, act_h, max over time (the first maximum wins, like the max-pool gradient), dropout (caser.py:103-114) -----------
-    for (int idx = threadIdx.x; idx < kTileSamples * nx; idx += blockDim.x) {
-      const int b = idx & 15, j = idx >> 4;
-      float x, pre;
-      int arg = 0;
-      if (j < n_v) {
-        x = pre = CT[(TV0 + (j >> 4)) * kCT + (j & 15) * 17 + b] + cw(D.off_bv + j);
-      } else {
-        const int pq = j - n_v, i = pq / n_h, f = pq - i * n_h;
-        const float bias = cw(D.off_bh[i] + f);
-        const float *const c0 = CT + (ct_first(i, L, NTh) + (f >> 4)) * kCT + (f & 15) * 17 + b;
-        float best = -3.0e38f;
-        pre = 0.f;
-        for (int t = 0; t + i < L; ++t) {
-          const float v = c0[t * NTh * kCT] + bias;
-          const float r = act_f(D.act_h, v);
-          if (r > best) { best = r; arg = t; pre = v; }
-        }
-        x = best;
-      }
-      XD[b * SX + j] = kept(b0 + b, j) ? x * ((A.keep || hashed) ? inv_keep : 1.f) : 0.f;
-      PRE[b * SX + j] = pre;
-      ARG[b * SX + j] = arg;
-    }
-    __syncthreads();
-    TSTAMP(4);
-    // ---- 3. dense_0: [16 x nx] . [nx x 16 channels] per channel tile (kernel rows from global memory) ------------------------------
-    for (int nc = w; nc < NC; nc += kTileWaves) {
-      const int cc = 16 * nc + m16;
-      const bool cv = cc < ld;
-      f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-      const float *const xa = XD + m16 * SX + q4;
-      const int KX = (nx + 3) >> 2;
-      int kj = 0;
-      for (; kj + 1 < KX; kj += 2) {
-        const int j0 = 4 * kj + q4, j1 = j0 + 4;
-        a0 = mfma4(xa[4 * kj], (cv && j0 < nx) ? gw(D.off_wd + j0 * ld + cc) : 0.f, a0);
-        a1 = mfma4(xa[4 * kj + 4], (cv && j1 < nx) ? gw(D.off_wd + j1 * ld + cc) : 0.f, a1);
-      }
-      if (kj < KX) {
-        const int j0 = 4 * kj + q4;
-        a0 = mfma4(xa[4 * kj], (cv && j0 < nx) ? gw(D.off_wd + j0 * ld + cc) : 0.f, a0);
-      }
-      const float bias = cc < d ? gw(D.off_bd + cc) : 0.f;
+          if (fv) {
+            const int j = n_v + i * n_h + f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int b = 4 * q4 + r;
-        const float z0 = cc < d ? a0[r] + a1[r] + bias : 0.f;
-        Z0[b * kSP + cc] = z0;
-        Z[b * kSP + cc] = cc < d ? act_f(D.act_mlp, z0) : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              const int b = 4 * q4 + r;
+              XD[b * SX + j] = kept(b0 + b, j) ? best[r] * inv_keep : 0.f;
+              PRE[b * SX + j] = bpre[r];
+              ARG[b * SX + j] = barg[r];
+            }
+          }
+        }
+    }
+    lds_barrier();
+    TSTAMP(3);
+    // ---- 3. dense_0: [16 x nx] . [nx x 16 channels] per channel tile, the k range in two halves (Z0 = first half + bias, Z1 = second) --
+    {
+      const int KX = (nx + 3) >> 2, KXh = (KX + 1) >> 1;
+      for (int u = w; u < 2 * NC; u += NW) {
+        const int nc = u >> 1, half = u & 1;
+        const int cc = 16 * nc + m16;
+        const bool cv = cc < ld;
+        const int lo = half * KXh, hi = half ? KX : KXh;
+        f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const float *const xa = XD + m16 * SX + q4;
+        const int ccs = cv ? cc : 0;
+        mfma_k(lo, hi, [&](int k) __attribute__((always_inline)) { return xa[4 * k]; },
+               [&](int k) __attribute__((always_inline)) {
+                 const int j = 4 * k + q4;
+                 const float v = gw(D.off_wd + min(j, nx - 1) * ld + ccs);
+                 return (cv && j < nx) ? v : 0.f;
+               }, a0, a1);
+        const float bias = (cc < d && !half) ? gw(D.off_bd + cc) : 0.f;
+        float *const zo = half ? Z1 : Z0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zo[(4 * q4 + r) * kSP + cc] = cc < d ? a0[r] + a1[r] + bias : 0.f;
       }
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(5);
     // ---- 4. targets: score, sigmoid, Keras BCE, backward to the lookups — per sample, lane = channel (caser.py:115-120) ------------
-    // eight targets at a time: their sixteen row reads are in flight together, the eight dot products leave through ONE reduce8, the
-    // lanes that hold target j's score do its sigmoid / loss / gradient, every lane then fetches the eight gradients with v_readlane
-#pragma unroll 1
-    for (int k = 0; k < 2; ++k) {
-      const int b = w + kTileWaves * k, gb = b0 + b;
+    // eight targets at a time: the eight dot products leave through ONE reduce8, the lanes that hold target j's score do its sigmoid /
+    // loss / gradient, every lane then fetches the eight gradients with v_readlane.  (The rows of the first sixteen came with step 0.)
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+      const int b = w + NW * k, gb = b0 + b;
       float dz0 = 0.f;
       if (gb < A.B) {
         const int c = lane;
         const bool live = c < d;
-        const float z = live ? Z[b * kSP + c] : 0.f, z0 = live ? Z0[b * kSP + c] : 0.f, pu = PU[b * kSP + c];
+        const float z0 = live ? Z0[b * kSP + c] + Z1[b * kSP + c] : 0.f, pu1 = PU[b * kSP + c];
+        const float z = live ? act_f(D.act_mlp, z0) : 0.f;
         float dz = 0.f, dpu = 0.f;
-        for (int j0 = 0; j0 < D.Tp; j0 += 8) {
-          int n[8];
-          float wa[8], wb[8];
-#pragma unroll
-          for (int qq = 0; qq < 8; ++qq) n[qq] = j0 + qq < D.Tp ? A.after[(size_t)gb * D.Tp + j0 + qq] : 0;
-#pragma unroll
-          for (int qq = 0; qq < 8; ++qq) {
-            const bool on = live && j0 + qq < D.Tp;
-            wa[qq] = on ? A.W1[(size_t)n[qq] * D.ld2 + c] : 0.f;
-            wb[qq] = on ? A.W1[(size_t)n[qq] * D.ld2 + d + c] : 0.f;
-          }
+        auto round8 = [&](int j0, const float (&wa)[8], const float (&wb)[8], float bm) __attribute__((always_inline)) {
           const int jm = j0 + slot8(c);                           // the target whose score this lane receives
-          const float bm = jm < D.Tp ? A.b1[A.after[(size_t)gb * D.Tp + jm]] : 0.f;
           float prod[8];
 #pragma unroll
-          for (int qq = 0; qq < 8; ++qq) prod[qq] = fmaf(z, wa[qq], pu * wb[qq]);
+          for (int qq = 0; qq < 8; ++qq) prod[qq] = fmaf(z, wa[qq], pu1 * wb[qq]);
           const float sc = reduce8(prod, c) + bm;
           const float p = sigmoidf_(sc);
           const float y = jm < D.T ? 1.f : 0.f;
@@ -373,91 +428,96 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D, 
             if (j0 + qq < D.Tp) {
               const float ds = lane_f(dsm, lane8(qq));
               const size_t row = (size_t)gb * D.Tp + j0 + qq;
-              if (live) { A.dW1[row * D.ld2 + c] = ds * z; A.dW1[row * D.ld2 + d + c] = ds * pu; }
+              if (live) { A.dW1[row * D.ld2 + c] = ds * z; A.dW1[row * D.ld2 + d + c] = ds * pu1; }
               dz = fmaf(ds, wa[qq], dz);
               dpu = fmaf(ds, wb[qq], dpu);
             }
           }
+        };
+        round8(0, pwa[k][0], pwb[k][0], pbm[k][0]);
+        if (D.Tp > 8) round8(8, pwa[k][1], pwb[k][1], pbm[k][1]);
+#pragma unroll 1
+        for (int j0 = 16; j0 < D.Tp; j0 += 8) {
+          float wa[8], wb[8], bm;
+          load_targets(gb, j0, wa, wb, bm);
+          round8(j0, wa, wb, bm);
         }
         if (live) A.dPu[(size_t)gb * ld + c] = dpu;
         dz0 = live ? dz * act_df(D.act_mlp, z0) : 0.f;
       }
       DZ0[b * kSP + lane] = dz0;
+      if (k == 0) TSTAMP(4);
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(6);
-    // ---- 5. dense_0 backward: dx[16 x 16 units] = dz0[16 x c] . Wd^T, through the dropout mask ----------------------------------
-    for (int nt = w; nt < NJ; nt += kTileWaves) {
+    // ---- 5. dense_0 backward: dx[16 x 16 units] = dz0[16 x c] . Wd^T, through the dropout mask; a horizontal unit goes on through
+    //         act_h at its arg-max step: the tile array receives dC[(i, t)][f][b] (zero away from the arg-max) and dV[f][b], DX the
+    //         pre-activation gradients (the bias sums of step 8 read them) ------------------------------------------------------------
+    for (int nt = w; nt < NJ; nt += NW) {
       const int jj = 16 * nt + m16;
       const bool jv = jj < nx;
       f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
       const float *const za = DZ0 + m16 * kSP + q4;
       const int wo = D.off_wd + (jv ? jj : 0) * ld + q4;
-      int kc = 0;
-      for (; kc + 1 < KC; kc += 2) {
-        a0 = mfma4(za[4 * kc], jv ? gw(wo + 4 * kc) : 0.f, a0);
-        a1 = mfma4(za[4 * kc + 4], jv ? gw(wo + 4 * kc + 4) : 0.f, a1);
-      }
-      if (kc < KC) a0 = mfma4(za[4 * kc], jv ? gw(wo + 4 * kc) : 0.f, a0);
+      mfma_k(0, KC, [&](int k) __attribute__((always_inline)) { return za[4 * k]; },
+             [&](int k) __attribute__((always_inline)) { const float v = gw(wo + 4 * k); return jv ? v : 0.f; }, a0, a1);
       if (jv) {
+        const int pq = jj - n_v, i = pq >= 0 ? pq / n_h : 0, f = pq - i * n_h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int b = 4 * q4 + r;
-          const float g = a0[r] + a1[r];
-          DX[b * SX + jj] = kept(b0 + b, jj) ? g * ((A.keep || hashed) ? inv_keep : 1.f) : 0.f;
+          const float g = kept(b0 + b, jj) ? (a0[r] + a1[r]) * inv_keep : 0.f;
+          if (pq < 0) {
+            DX[b * SX + jj] = g;
+            CT[(TV0 + (jj >> 4)) * kCT + (jj & 15) * 17 + b] = g;
+          } else {
+            const float dc = g * act_df(D.act_h, PRE[b * SX + jj]);
+            const int arg = ARG[b * SX + jj];
+            DX[b * SX + jj] = dc;
+            float *const c0 = CT + (ct_first(i, L, NTh) + (f >> 4)) * kCT + (f & 15) * 17 + b;
+            for (int t = 0; t + i < L; ++t) c0[t * NTh * kCT] = t == arg ? dc : 0.f;
+          }
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(7);
-    // ---- 6. through act_h at the arg-max step: the tile array now holds dC[(i, t)][f][b] (zero away from the arg-max) and dV[f][b];
-    //         dx of a horizontal unit becomes its pre-activation gradient in place (the bias sums of step 8 read it) -------------------
-    for (int idx = threadIdx.x; idx < kTileSamples * 16 * NTv; idx += blockDim.x) {
-      const int b = idx & 15, f = idx >> 4;
-      CT[(TV0 + (f >> 4)) * kCT + (f & 15) * 17 + b] = f < n_v ? DX[b * SX + f] : 0.f;
-    }
-    for (int idx = threadIdx.x; idx < kTileSamples * 16 * NTh * L; idx += blockDim.x) {
-      const int b = idx & 15, fi = idx >> 4, i = fi / (16 * NTh), f = fi - i * 16 * NTh;
-      float dc = 0.f;
-      int arg = -1;
-      if (f < n_h) {
-        const int j = n_v + i * n_h + f;
-        dc = DX[b * SX + j] * act_df(D.act_h, PRE[b * SX + j]);
-        arg = ARG[b * SX + j];
-        DX[b * SX + j] = dc;
-      }
-      float *const c0 = CT + (ct_first(i, L, NTh) + (f >> 4)) * kCT + (f & 15) * 17 + b;
-      for (int t = 0; t + i < L; ++t) c0[t * NTh * kCT] = t == arg ? dc : 0.f;
-    }
-    __syncthreads();
-    TSTAMP(8);
-    // ---- 7. gradient rows of the item lookups: dE[16 x 16 channels] at position t' = dV . Kv[t'] + sum over taps (i, s) of
-    //         dC[(i, t' - s)] . Kh_i[s] -----------------------------------------------------------------------------------------------
+    // ---- 7 + 8. one list of units dealt out over the waves:
+    //   gradient rows of the item lookups, dE[16 x 16 channels] at position t' = dV . Kv[t'] + sum over the taps (i, s) that reach t' of
+    //     dC[(i, t' - s)] . Kh_i[s];
+    //   small-weight gradients of the tile (K = the 16 samples; the channel tiles of a unit share its A fragments), added to the
+    //     workgroup's partial sums -------------------------------------------------------------------------------------------------
     {
       int u = 0;
       for (int tp = 0; tp < L; ++tp)
         for (int nc = 0; nc < NC; ++nc, ++u) {
-          if (u % kTileWaves != w) continue;
+          if (u % NW != w) continue;
           const int cc = 16 * nc + m16;
           const bool cv = cc < ld;
           const int cs = cv ? cc : 0;
           f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-          for (int kf = 0; 4 * kf < n_v; ++kf) {
-            const int f = 4 * kf + q4;
-            const float a = CT[(TV0 + (f >> 4)) * kCT + (f & 15) * 17 + m16];
-            a0 = mfma4(a, (cv && f < n_v) ? cw(D.off_kv + (tp * n_v + f) * ld + cs) : 0.f, a0);
+          {
+            const float *const c0 = CT + TV0 * kCT + m16;
+            const int wo = D.off_kv + tp * n_v * ld + cs;
+            mfma_k(0, (n_v + 3) >> 2, [&](int k) __attribute__((always_inline)) { const int f = 4 * k + q4; return c0[(f >> 4) * kCT + (f & 15) * 17]; },
+                   [&](int k) __attribute__((always_inline)) {
+                     const int f = 4 * k + q4;
+                     const float v = cw(wo + min(f, n_v - 1) * ld);
+                     return (cv && f < n_v) ? v : 0.f;
+                   }, a0, a1);
           }
           for (int i = 0; i < L; ++i)
             for (int s = 0; s <= i; ++s) {
               const int t = tp - s;
               if (t < 0 || t + i >= L) continue;
               const float *const c0 = CT + (ct_first(i, L, NTh) + t * NTh) * kCT + m16;
-              for (int kf = 0; 4 * kf < n_h; kf += 2) {
-                const int f0 = 4 * kf + q4, f1 = f0 + 4;
-                a0 = mfma4(c0[(f0 >> 4) * kCT + (f0 & 15) * 17], (cv && f0 < n_h) ? cw(D.off_kh[i] + (s * n_h + f0) * ld + cs) : 0.f, a0);
-                if (4 * (kf + 1) < n_h)
-                  a1 = mfma4(c0[(f1 >> 4) * kCT + (f1 & 15) * 17], (cv && f1 < n_h) ? cw(D.off_kh[i] + (s * n_h + f1) * ld + cs) : 0.f, a1);
-              }
+              const int wo = D.off_kh[i] + s * n_h * ld + cs;
+              mfma_k(0, (n_h + 3) >> 2, [&](int k) __attribute__((always_inline)) { const int f = 4 * k + q4; return c0[(f >> 4) * kCT + (f & 15) * 17]; },
+                     [&](int k) __attribute__((always_inline)) {
+                       const int f = 4 * k + q4;
+                       const float v = cw(wo + min(f, n_h - 1) * ld);
+                       return (cv && f < n_h) ? v : 0.f;
+                     }, a0, a1);
             }
           if (cc < d) {
 #pragma unroll
@@ -467,95 +527,84 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D, 
             }
           }
         }
-    }
-#ifdef DRX_STAMPS
-    __syncthreads();
-    TSTAMP(9);
-#endif
-    // ---- 8. small-weight gradients of the tile (K = the 16 samples), added to the workgroup's partial sums -------------------------
-    {
-      int u = 0;
-      // horizontal kernels: g[(i, s)][f][c] = sum over t, b of dC[(i, t)][f][b] * E[b][t + s][c]
-      for (int i = 0; i < L; ++i)
-        for (int s = 0; s <= i; ++s)
-          for (int nt = 0; nt < NTh; ++nt)
-            for (int nc = 0; nc < NC; ++nc, ++u) {
-              if (u % kTileWaves != w) continue;
-              f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-              for (int t = 0; t + i < L; ++t) {
-                const float *const ca = CT + (ct_first(i, L, NTh) + t * NTh + nt) * kCT + m16 * 17 + q4;
-                const float *const eb = E + q4 * SB + (t + s) * ld + 16 * nc + m16;
-                a0 = mfma4(ca[0], eb[0], a0);
-                a1 = mfma4(ca[4], eb[4 * SB], a1);
-                a0 = mfma4(ca[8], eb[8 * SB], a0);
-                a1 = mfma4(ca[12], eb[12 * SB], a1);
-              }
-              const int cc = 16 * nc + m16;
+      TSTAMP(8);
+      // three kinds of units, one loop: A = 16 weights x 16 samples (a tile of dC / dV, or 16 units of x), B = 16 samples x 16 channels
+      // (item rows at one position, or dz0), summed over `nit` positions
+      //   horizontal kernels  g[(i, s)][f][c] = sum over t, b of dC[(i, t)][f][b] * E[b][t + s][c]
+      //   vertical kernel     g[t][f][c]      = sum over b of dV[f][b] * E[b][t][c]
+      //   dense_0 kernel      g[j][c]         = sum over b of xd[b][j] * dz0[b][c]
+      const int nH = (L * (L + 1) / 2) * NTh, nV = L * NTv;
+#pragma unroll 1
+      for (int v = 0; v < nH + nV + NJ; ++v, ++u) {
+        if (u % NW != w) continue;
+        const float *ap, *bp;
+        int ak, at, bk, bt, nit, off, row0, n_rows;
+        if (v < nH) {
+          int r = v / NTh, i = 0;
+          const int nt = v - r * NTh;
+          while (r > i) { r -= i + 1; ++i; }
+          ap = CT + (ct_first(i, L, NTh) + nt) * kCT + m16 * 17 + q4; ak = 4; at = NTh * kCT;
+          bp = E + q4 * SB + r * ld + m16; bk = 4 * SB; bt = ld;
+          nit = L - i; off = D.off_kh[i] + r * n_h * ld; row0 = 16 * nt; n_rows = n_h;
+        } else if (v < nH + nV) {
+          const int t = (v - nH) / NTv, nt = (v - nH) - t * NTv;
+          ap = CT + (TV0 + nt) * kCT + m16 * 17 + q4; ak = 4; at = 0;
+          bp = E + q4 * SB + t * ld + m16; bk = 4 * SB; bt = 0;
+          nit = 1; off = D.off_kv + t * n_v * ld; row0 = 16 * nt; n_rows = n_v;
+        } else {
+          const int nt = v - nH - nV, ja = min(16 * nt + m16, nx - 1);        // (rows beyond nx are computed and not stored)
+          ap = XD + q4 * SX + ja; ak = 4 * SX; at = 0;
+          bp = DZ0 + q4 * kSP + m16; bk = 4 * kSP; bt = 0;
+          nit = 1; off = D.off_wd; row0 = 16 * nt; n_rows = nx;
+        }
+        f4v acc[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int f = 16 * nt + 4 * q4 + r;
-                if (f < n_h && cc < ld) {
-                  float *const o = gp + D.off_kh[i] + (s * n_h + f) * ld + cc;
-                  *o = (first ? 0.f : *o) + (a0[r] + a1[r]);
-                }
-              }
-            }
-      // vertical kernel: g[t][f][c] = sum over b of dV[f][b] * E[b][t][c]
-      for (int t = 0; t < L; ++t)
-        for (int nt = 0; nt < NTv; ++nt)
-          for (int nc = 0; nc < NC; ++nc, ++u) {
-            if (u % kTileWaves != w) continue;
-            f4v a0 = {0.f, 0.f, 0.f, 0.f};
-            const float *const ca = CT + (TV0 + nt) * kCT + m16 * 17 + q4;
-            const float *const eb = E + q4 * SB + t * ld + 16 * nc + m16;
+        for (int nc = 0; nc < 4; ++nc) acc[nc] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int it = 0; it < nit; ++it, ap += at, bp += bt) {
+          float av[4], bv[4][4];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) a0 = mfma4(ca[4 * kb], eb[4 * kb * SB], a0);
+          for (int kb = 0; kb < 4; ++kb) {
+            av[kb] = ap[kb * ak];
+#pragma unroll
+            for (int nc = 0; nc < 4; ++nc) bv[kb][nc] = bp[kb * bk + 16 * nc];     // (tiles beyond NC: finite values, never stored)
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int nc = 0; nc < 4; ++nc) acc[nc] = mfma4(av[kb], bv[kb][nc], acc[nc]);
+        }
+#pragma unroll
+        for (int nc = 0; nc < 4; ++nc)
+          if (nc < NC) {
             const int cc = 16 * nc + m16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int f = 16 * nt + 4 * q4 + r;
-              if (f < n_v && cc < ld) {
-                float *const o = gp + D.off_kv + (t * n_v + f) * ld + cc;
-                *o = (first ? 0.f : *o) + a0[r];
+              const int row = row0 + 4 * q4 + r;
+              if (row < n_rows && cc < ld) {
+                float *const o = gp + off + row * ld + cc;
+                *o = (first ? 0.f : *o) + acc[nc][r];
               }
             }
           }
-      // dense_0 kernel: g[j][c] = sum over b of xd[b][j] * dz0[b][c]
-      for (int nt = 0; nt < NJ; ++nt)
-        for (int nc = 0; nc < NC; ++nc, ++u) {
-          if (u % kTileWaves != w) continue;
-          f4v a0 = {0.f, 0.f, 0.f, 0.f};
-          const int ja = 16 * nt + m16;
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) {
-            const int b = 4 * kb + q4;
-            a0 = mfma4(ja < nx ? XD[b * SX + ja] : 0.f, DZ0[b * kSP + 16 * nc + m16], a0);
-          }
-          const int cc = 16 * nc + m16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * nt + 4 * q4 + r;
-            if (j < nx && cc < ld) {
-              float *const o = gp + D.off_wd + j * ld + cc;
-              *o = (first ? 0.f : *o) + a0[r];
-            }
-          }
-        }
+      }
+      TSTAMP(9);
       // biases (and the zero padding of their segments): one thread per entry, the tile's samples in order
       const int padv = (n_v + 3) & ~3, padh = (n_h + 3) & ~3;
-      for (int e = threadIdx.x; e < ld + padv + L * padh; e += blockDim.x) {
+      for (int en = threadIdx.x; en < ld + padv + L * padh; en += blockDim.x) {
         float acc = 0.f;
         float *o;
-        if (e < ld) {
-          o = gp + D.off_bd + e;
-          for (int b = 0; b < kTileSamples; ++b) acc += DZ0[b * kSP + e];
-        } else if (e < ld + padv) {
-          const int f = e - ld;
+        if (en < ld) {
+          o = gp + D.off_bd + en;
+          for (int b = 0; b < kTileSamples; ++b) acc += DZ0[b * kSP + en];
+        } else if (en < ld + padv) {
+          const int f = en - ld;
           o = gp + D.off_bv + f;
           if (f < n_v)
             for (int b = 0; b < kTileSamples; ++b) acc += DX[b * SX + f];
         } else {
-          const int q = e - ld - padv, i = q / padh, f = q - i * padh;
+          const int q = en - ld - padv, i = q / padh, f = q - i * padh;
           o = gp + D.off_bh[i] + f;
           if (f < n_h)
             for (int b = 0; b < kTileSamples; ++b) acc += DX[b * SX + n_v + i * n_h + f];
@@ -563,7 +612,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D, 
         *o = (first ? 0.f : *o) + acc;
       }
     }
-    __syncthreads();                                  // (the next tile rewrites E and the vectors)
+    lds_barrier();                                    // (the next tile rewrites E and the vectors)
     TSTAMP(10);
   }
   loss_acc = group_sum<64>(loss_acc);                 // (the lanes that held a target's score carry its loss term)
@@ -571,7 +620,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D, 
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int ww = 0; ww < kTileWaves; ++ww) t += wloss[ww];
+    for (int ww = 0; ww < NW; ++ww) t += wloss[ww];
     A.loss_part[blockIdx.x] = t * inv_bt;
   }
 }

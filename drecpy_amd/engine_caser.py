@@ -48,6 +48,10 @@ class CaserEngine:
         D.n_small = off
         D.act_h, D.act_mlp = self.ACTIVATIONS[act_h], self.ACTIVATIONS[act_mlp]
         self.D = D
+        # (the kernels keep a tile's scratch and, where they fit, the small weights in a workgroup's LDS: drx_caser_grid answers 0 when
+        #  n_v + L * n_h is too large for that — Recommender/caser.py then takes the generic engine)
+        if int(lib().drx_caser_grid(C.byref(D), 16)) < 1:
+            raise _lib.DrxError(f'Caser engine: n_v + L * n_h = {self.nx} units (n_v={n_v}, n_h={n_h}, L={L}, d={d}) do not fit the kernels\' LDS tiles')
         self.n_layers = 6 + L
         z = dict(dtype=torch.float32, device=self.device)
         self.item_emb = torch.zeros(n_items, ld, **z)

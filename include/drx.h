@@ -407,7 +407,7 @@ int drx_rows_dot(const float *x, int32_t B, const float *table, int32_t n_rows, 
 
 /* Adam over up to DRX_MAX_SEGMENTS slices of one flat array, each with its own Keras lr_t and L2 coefficient: the
  * small conv/dense weights of a model, one slice per registered layer kernel / bias (recommender_abc.py:328-334). */
-#define DRX_MAX_SEGMENTS 16
+#define DRX_MAX_SEGMENTS 24   /* (Caser with L = 8: 2 L + 4 = 20 registered kernels and biases) */
 typedef struct DrxAdamSegments {
   int32_t n;
   int32_t start[DRX_MAX_SEGMENTS], len[DRX_MAX_SEGMENTS];

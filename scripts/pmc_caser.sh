@@ -1,0 +1,31 @@
+#!/bin/bash
+# Issue / stall counters of the Caser training kernel (100 steps at the ml-1m shape, B = 4096).  Separate rocprofv3 --pmc passes.
+# Usage (gpurun): bash scripts/pmc_caser.sh <tag>
+set -u
+TAG=${1:-r05}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/${TAG}_pmc_caser
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+i=0
+for set in "GRBM_GUI_ACTIVE GRBM_COUNT" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+           "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_IFETCH SQ_INSTS_WAVE32_LDS" \
+           "SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH_LEVEL SQ_LDS_ADDR_CONFLICT"; do
+  i=$((i+1))
+  timeout -k 5 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o p -- python3 $ROOT/scripts/prof_models.py caser 4096 > $OUT/p$i.txt 2> $OUT/p$i.err
+  tail -2 $OUT/p$i.err | cut -c1-200
+done
+cd $ROOT
+python - <<P
+import csv, glob, collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'k_caser_tile' not in r['Kernel_Name']: continue
+        a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
+for k in sorted(acc): print(f'{k:32s} {acc[k][0] / acc[k][1]:14.1f}  ({acc[k][1]} dispatches)')
+P
+find $OUT -name '*.csv' -size +2M -delete

@@ -33,13 +33,22 @@ def main():
     m._do_batch(batch, step=8)
     torch.cuda.synchronize()
     assert L.drx_debug_set_caser_stamps(None) == 0
-    G = (B + 15) // 16
-    G = min(G, 256)
-    st = buf.cpu().numpy().reshape(B, 16)[:G, :11].astype(np.float64) * 0.01
+    G = (B + 15) // 16                                  # one row of stamps per tile
+    grid = int(os.environ.get('GRID', 256))
+    raw = buf.cpu().numpy().reshape(B, 16)[:G].astype(np.float64) * 0.01
+    st = raw[:, :11]
+    cols = [0, 1, 2, 3, 5, 4, 6, 7, 8, 9, 10]      # (stamp 4 is taken inside step 4, after stamp 5)
+    st = st[:, cols]
     ok = (st > 0).all(axis=1)
     st = st[ok]
-    labels = ['weights -> LDS', '0 rows in', '1 convs forward', '2 max / act / dropout', '3 dense_0', '4 targets', '5 dense_0 backward',
-              '6 act_h backward, scatter', '7 dE rows', '8 small-weight gradients']
+    labels = ['0a rows + target rows issued, weights -> LDS (first tile)', '0b rows into LDS', '1 convs forward + max / act / dropout', '3 dense_0',
+              '4a targets, first sample of wave 0', '4b targets, second sample + barrier', '5 dense_0 backward + act_h backward, scatter',
+              '7 dE rows (wave 0)', '8 small-weight gradients (wave 0)', '8b biases + barrier']
+    later = np.arange(G)[ok] >= grid                  # tiles a workgroup takes after its first one
+    if later.any():
+        dl = np.diff(st[later], axis=1)
+        print('later tiles:', {lab: round(float(dl[:, i].mean()), 2) for i, lab in enumerate(labels)}, 'life', round(float((st[later][:, -1] - st[later][:, 0]).mean()), 2))
+        st = st[~later]
     d = np.diff(st, axis=1)
     out = {'workgroups': int(ok.sum()), 'kernel_span_us': float(st.max() - st.min()),
            'first_tile_life_us': {'mean': float((st[:, -1] - st[:, 0]).mean()), 'p90': float(np.percentile(st[:, -1] - st[:, 0], 90))},

@@ -15,6 +15,22 @@ def _rel(a, b):
 @pytest.mark.parametrize('d,L,n_v,n_h,T,neg,B,drop', [(50, 5, 4, 16, 3, 3, 64, False), (16, 3, 2, 8, 2, 2, 37, True),
                                                       (64, 5, 4, 16, 3, 3, 300, True)])
 def test_caser_steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, update):
+    """(50, 5, 4, 16, 3, 3) is the training kernel's compile-time instantiation (examples/caser.py), (64, 5, ...) keeps only the
+    convolution weights in LDS; more geometries of the tile kernel: test_caser_tile_geometries below."""
+    _steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, update)
+
+
+# the tile kernel's other paths: no weights in LDS (L = 8, d = 32: 96 KB of small weights beside 108 KB of tile scratch), two 16-filter
+# tiles per horizontal convolution (n_h = 24), two for the vertical one (n_v = 18), more than 16 targets per sample (the rows of the
+# first 16 are fetched ahead, the rest where they are used), several tiles per workgroup (B = 4200 > 256 tiles of 16)
+@pytest.mark.parametrize('d,L,n_v,n_h,T,neg,B,drop', [(32, 8, 4, 16, 2, 3, 100, True), (20, 4, 3, 24, 2, 2, 50, True),
+                                                      (16, 3, 18, 8, 2, 2, 33, False), (24, 5, 4, 16, 3, 6, 41, True),
+                                                      (16, 3, 2, 8, 1, 2, 4200, True)])
+def test_caser_tile_geometries(d, L, n_v, n_h, T, neg, B, drop):
+    _steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, 'csr', steps=2 if B > 1000 else 3)
+
+
+def _steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, update, steps=3):
     from drecpy_amd.engine_caser import CaserEngine
     rng = np.random.default_rng(d + B)
     U, N = 40, 150
@@ -28,7 +44,7 @@ def test_caser_steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, update):
     for k in p:
         np.testing.assert_allclose(g0[k], p[k].astype(np.float32), rtol=0, atol=0)
     nx = n_v + L * n_h
-    for step in range(6):
+    for step in range(2 * steps):
         uids = rng.integers(0, U, size=B)
         before = rng.integers(0, N, size=(B, L))
         after = rng.integers(0, N, size=(B, T + T * neg))
