@@ -185,6 +185,9 @@ SIGNATURES = {
     'drx_rows_csr_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_void_p]),
+    'drx_rows_csr_adam_outer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'drx_batch_distinct': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     'drx_dmf_norms': (C.c_int, [C.POINTER(DmfDims), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

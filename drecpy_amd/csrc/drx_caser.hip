@@ -180,6 +180,9 @@ static int hidden_waves(const DrxCaserDims &D, int B) {
 // the training kernel's variant for these dimensions: 2 = every small weight in LDS, 1 = the convolution weights, 0 = all read from global
 // memory, -1 = the tile's own scratch does not fit a workgroup's LDS (nx too large)
 static int caser_tile_variant(const DrxCaserDims &D) {
+#ifdef DRX_CASER_FORCE_WL                                   // (diagnostic builds)
+  return DRX_CASER_FORCE_WL;
+#endif
   for (int wl = 2; wl >= 0; --wl)
     if ((size_t)caser_tile_geom(D, wl).floats * 4 <= kCaserLdsLimit) return wl;
   return -1;
@@ -213,7 +216,7 @@ int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_o
   int rc = check_dims(D);
   if (rc) return rc;
   if (!A || !A->item_emb || !A->user_emb || !A->W1 || !A->b1 || !A->sw || !A->uid || !A->before || !A->after || !A->dE ||
-      !A->dW1 || !A->db1 || !A->dPu || !A->gsw_part || !A->loss_part || !gsw_out || A->B < 1 || A->rate < 0.f || A->rate >= 1.f)
+      (!A->dW1 && !A->cat_out) || !A->db1 || !A->dPu || !A->gsw_part || !A->loss_part || !gsw_out || A->B < 1 || A->rate < 0.f || A->rate >= 1.f)
     return DRX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int grid = drx_caser_grid(D, A->B);

@@ -174,14 +174,17 @@ __device__ __forceinline__ int ct_first(int i, int L, int NTh) { return (i * L -
 // FX = 1: the dimensions of examples/caser.py:13 (BASELINE configuration 5: L = 5, d = 50, n_v = 4, n_h = 16, T = 3, 9 negatives) as
 // compile-time constants — trip counts, strides and tile counts fold, the loops over heights / positions / taps unroll; FX = 0: any.
 template <int WL, int FX>
-__global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_in, DrxCaserArgs A CASER_STAMP_ARG) {
-  DrxCaserDims D = D_in;
-  if (FX == 1) { D.L = 5; D.d = 50; D.ld = 52; D.ld2 = 100; D.n_v = 4; D.n_h = 16; D.T = 3; D.Tp = 12; }
+__global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D, DrxCaserArgs A CASER_STAMP_ARG) {
+  // (D stays the kernel argument — its offset arrays are indexed with run-time heights, which would send a modified copy to scratch
+  //  memory, every field read a scratch load; the dimensions the instantiation fixes are local constants instead)
+  const int L = FX ? 5 : D.L, d = FX ? 50 : D.d, ld = FX ? 52 : D.ld, ld2 = FX ? 100 : D.ld2, n_v = FX ? 4 : D.n_v, n_h = FX ? 16 : D.n_h;
+  const int T = FX ? 3 : D.T, Tp = FX ? 12 : D.Tp, nx = n_v + L * n_h;
+  DrxCaserDims Dg = {};                                // (what the LDS geometry depends on)
+  Dg.L = L; Dg.d = d; Dg.ld = ld; Dg.n_v = n_v; Dg.n_h = n_h; Dg.n_small = D.n_small; Dg.off_wd = D.off_wd;
   constexpr int NW = kTileWaves, SPW = kTileSamples / NW;          // samples per wave in the per-sample phases
   extern __shared__ __align__(16) float lds[];
-  const CaserTileGeom G = caser_tile_geom(D, WL);
+  const CaserTileGeom G = caser_tile_geom(Dg, WL);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int L = D.L, d = D.d, ld = D.ld, n_v = D.n_v, n_h = D.n_h, nx = n_v + L * n_h;
   const int SB = G.SB, SX = G.SX, KC = G.KC, NC = G.NC, NTh = G.NTh, NTv = G.NTv, NJ = G.NJ, TV0 = G.TV0;
   float *const wl = lds;
   float *const E = lds + G.o_E, *const PU = lds + G.o_PU, *const Z0 = lds + G.o_Z0, *const Z1 = lds + G.o_Z1, *const DZ0 = lds + G.o_DZ0;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_i
   auto gw = [&](int off) __attribute__((always_inline)) -> float { return WL == 2 ? wl[off] : A.sw[off]; };
 
   float loss_acc = 0.f;
-  const float inv_bt = 1.0f / ((float)A.B * (float)D.Tp);
+  const float inv_bt = 1.0f / ((float)A.B * (float)Tp);
   const float inv_keep = 1.0f / (1.0f - A.rate);
   const bool hashed = !A.keep && A.rate > 0.f;
   const uint32_t rthr = hashed ? q_threshold(A.rate) : 0u;
@@ -205,16 +208,21 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_i
   };
   // the rows of dense_1 of eight targets of sample gb (targets j0 .. j0 + 7) and, in the lanes that will hold target jm's score, its bias
   auto load_targets = [&](int gb, int j0, float (&wa)[8], float (&wb)[8], float &bm) __attribute__((always_inline)) {
+    // (clamped indices, unconditional loads, the value selected afterwards: a load under a predicate becomes a branch, and the counter
+    //  waits behind branches drain every load in flight)
     const bool live = lane < d;
+    const int cl = min(lane, d - 1), gbc = min(gb, A.B - 1);
 #pragma unroll
     for (int qq = 0; qq < 8; ++qq) {
-      const bool on = live && gb < A.B && j0 + qq < D.Tp;
-      const int n = on ? A.after[(size_t)gb * D.Tp + j0 + qq] : 0;
-      wa[qq] = on ? A.W1[(size_t)n * D.ld2 + lane] : 0.f;
-      wb[qq] = on ? A.W1[(size_t)n * D.ld2 + d + lane] : 0.f;
+      const bool on = live && gb < A.B && j0 + qq < Tp;
+      const int n = A.after[(size_t)gbc * Tp + min(j0 + qq, Tp - 1)];
+      const float va = A.W1[(size_t)n * ld2 + cl], vb = A.W1[(size_t)n * ld2 + d + cl];
+      wa[qq] = on ? va : 0.f;
+      wb[qq] = on ? vb : 0.f;
     }
     const int jm = j0 + slot8(lane);
-    bm = (gb < A.B && jm < D.Tp) ? A.b1[A.after[(size_t)gb * D.Tp + jm]] : 0.f;
+    const float vbm = A.b1[A.after[(size_t)gbc * Tp + min(jm, Tp - 1)]];
+    bm = (gb < A.B && jm < Tp) ? vbm : 0.f;
   };
   float *const gp = A.gsw_part + (size_t)blockIdx.x * D.n_small;
   const int n_tiles = (A.B + kTileSamples - 1) / kTileSamples;
@@ -224,70 +232,63 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_i
     const bool first = tile == (int)blockIdx.x;
     [[maybe_unused]] const int tile_id = tile;
     TSTAMP(0);
+#ifdef DRX_CASER_EXIT_EARLY                                  // (diagnostic builds: what an empty launch of this shape costs)
+    if (A.B > 0) break;
+#endif
     // (the lane's coordinates in an MFMA fragment, opaque per tile: what is derived from them is computed where it is used instead of
     //  being hoisted — by the dozen — in front of the tile loop)
     int m16 = lane & 15, q4 = lane >> 4;
     asm volatile("" : "+v"(m16), "+v"(q4));
-    // ---- 0. the tile's item rows and user rows, and the dense_1 rows of the first 16 targets of every sample (used in step 4):
-    //         every wave its samples, all row reads in flight together, the weights' copy into LDS behind them ----------------------
+    // ---- 0. the tile's item rows and user rows: every wave its samples, all row reads in flight together, with the weights' copy
+    //         into LDS (first tile) ------------------------------------------------------------------------------------------------
     // Loads in the order of their dependence chains: the samples' indices, the weights (first tile), the item / user rows (they need
-    // the indices), the dense_1 rows.  Loads return in order, so the stores into LDS below wait for no more than they need.
+    // the indices).  Loads return in order, so the stores into LDS below wait for no more than they need.  (The dense_1 rows of the
+    // targets — 64 more loads per wave, used in step 4 — are issued behind the barrier: in front of it they held up these stores.)
     constexpr int WCH = 10;                               // float4s of weights a thread has in flight: 80 KB per workgroup and pass
     const int nw = WL == 2 ? D.n_small : WL == 1 ? D.off_wd : 0;
     int ib[SPW], ia[SPW], iu[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; ++k) {
-      const int gb = b0 + w + NW * k;
-      const bool has = gb < A.B;
-      ib[k] = (has && lane < L) ? A.before[(size_t)gb * L + lane] : 0;
-      ia[k] = (has && lane < D.Tp) ? A.after[(size_t)gb * D.Tp + lane] : 0;      // (lane j: target j; the first 16 are used here)
-      iu[k] = has ? A.uid[gb] : 0;
-    }
-    float4 wbuf[WCH];
-    if (first && WL) {
-#pragma unroll
-      for (int c = 0; c < WCH; ++c)                       // (every segment of sw is a multiple of 4 floats long; clamped: no branch per load)
-        wbuf[c] = *reinterpret_cast<const float4 *>(A.sw + min((int)(threadIdx.x + c * blockDim.x) * 4, nw - 4));
+      const int gb = min(b0 + w + NW * k, A.B - 1);       // (a sample of the tile's padding reads the last sample's indices; its rows are zeroed below)
+      ib[k] = A.before[(size_t)gb * L + min(lane, L - 1)];
+      ia[k] = A.after[(size_t)gb * Tp + min(lane, Tp - 1)];                     // (lane j: target j; the first 16 are used here)
+      iu[k] = A.uid[gb];
     }
     float e[SPW][kCaserMaxL], pu[SPW];
-    float pwa[SPW][2][8], pwb[SPW][2][8], pbm[SPW][2];
+    auto fetch_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < SPW; ++k) {
-      const bool on = b0 + w + NW * k < A.B && lane < d;
+      for (int k = 0; k < SPW; ++k) {
+        const bool on = b0 + w + NW * k < A.B && lane < d;
+        const int cl = min(lane, d - 1);
 #pragma unroll
-      for (int t = 0; t < kCaserMaxL; ++t) {
-        const int n = __shfl(ib[k], t);
-        e[k][t] = (t < L && on) ? A.item_emb[(size_t)n * ld + lane] : 0.f;
-      }
-      pu[k] = on ? A.user_emb[(size_t)iu[k] * ld + lane] : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < SPW; ++k) {
-      const bool on = b0 + w + NW * k < A.B && lane < d;
-      const float b1v = (b0 + w + NW * k < A.B && lane < D.Tp) ? A.b1[ia[k]] : 0.f;        // (lane j: the bias of target j)
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int qq = 0; qq < 8; ++qq) {
-          const int n = __shfl(ia[k], 8 * r + qq);
-          const bool t_on = on && 8 * r + qq < D.Tp;
-          pwa[k][r][qq] = t_on ? A.W1[(size_t)n * D.ld2 + lane] : 0.f;
-          pwb[k][r][qq] = t_on ? A.W1[(size_t)n * D.ld2 + d + lane] : 0.f;
+        for (int t = 0; t < kCaserMaxL; ++t) {
+          const int n = __shfl(ib[k], min(t, L - 1));
+          const float v = A.item_emb[(size_t)n * ld + cl];
+          e[k][t] = (t < L && on) ? v : 0.f;
         }
-        pbm[k][r] = __shfl(b1v, 8 * r + slot8(lane));
+        const float vu = A.user_emb[(size_t)iu[k] * ld + cl];
+        pu[k] = on ? vu : 0.f;
       }
+    };
+    if (first && WL) {
+      // (one block from the weights' loads to their stores: registers; split around the rows' loads the buffer went to scratch memory.
+      //  Clamped indices: the last float4 may be read and written more than once — no branch per load or store, so the wait in front of
+      //  the stores counts loads instead of draining them all)
+      float4 wbuf[WCH];
+#pragma unroll
+      for (int c = 0; c < WCH; ++c)                       // (every segment of sw is a multiple of 4 floats long)
+        wbuf[c] = *reinterpret_cast<const float4 *>(A.sw + min((int)(threadIdx.x + c * blockDim.x) * 4, nw - 4));
+      fetch_rows();
+#pragma unroll
+      for (int c = 0; c < WCH; ++c)
+        *reinterpret_cast<float4 *>(wl + min((int)(threadIdx.x + c * blockDim.x) * 4, nw - 4)) = wbuf[c];
+      for (int i = (int)(threadIdx.x + WCH * blockDim.x) * 4; i < nw; i += blockDim.x * 4)      // (more than 80 KB of weights)
+        *reinterpret_cast<float4 *>(wl + i) = *reinterpret_cast<const float4 *>(A.sw + i);
+      if (threadIdx.x < 64) wl[nw + threadIdx.x] = 0.f;
+    } else {
+      fetch_rows();
     }
     if (first) {
-      if (WL) {
-#pragma unroll
-        for (int c = 0; c < WCH; ++c) {
-          const int i = (int)(threadIdx.x + c * blockDim.x) * 4;
-          if (i < nw) *reinterpret_cast<float4 *>(wl + i) = wbuf[c];
-        }
-        for (int i = (int)(threadIdx.x + WCH * blockDim.x) * 4; i < nw; i += blockDim.x * 4)      // (more than 80 KB of weights)
-          *reinterpret_cast<float4 *>(wl + i) = *reinterpret_cast<const float4 *>(A.sw + i);
-        if (threadIdx.x < 64) wl[nw + threadIdx.x] = 0.f;
-      }
       // E's padding (the gap behind every sample's rows, the tail a 16-column read runs into), x's k-padding and the tiles' unused
       // columns stay zero throughout (none of it is a place a row is written to: no barrier between this and the rows' stores)
       const int gapE = SB - L * ld, gapX = SX - nx;
@@ -307,6 +308,27 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_i
     }
     lds_barrier();
     TSTAMP(2);
+    // the dense_1 rows (and biases) of the first 8 targets of every sample: issued now, used in step 4 (the next 8 behind step 1: a wave
+    // cannot have more than 63 loads in flight, and would wait here for the first ones to return)
+    float pwa[SPW][2][8], pwb[SPW][2][8], b1v[SPW];
+    auto fetch_targets = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < SPW; ++k) {
+        const bool on = b0 + w + NW * k < A.B && lane < d;
+        const int cl = min(lane, d - 1);
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+          const int n = __shfl(ia[k], 8 * r + qq);                      // (lanes beyond Tp hold target Tp - 1: a valid row)
+          const bool t_on = on && 8 * r + qq < Tp;
+          const float va = A.W1[(size_t)n * ld2 + cl], vb = A.W1[(size_t)n * ld2 + d + cl];
+          pwa[k][r][qq] = t_on ? va : 0.f;
+          pwb[k][r][qq] = t_on ? vb : 0.f;
+        }
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) b1v[k] = A.b1[ia[k]];                  // (lane j: the bias of target j; lanes beyond Tp are not read)
+    fetch_targets(0);
     // ---- 1. convolutions forward.  One unit = a 16-filter tile of the vertical conv, or of the horizontal conv of height i with its
     //         positions t in turn: 16 samples x 16 filters of pre-activations per position in the MFMA's accumulators, the lane keeps
     //         the running maximum of its four (sample, filter) pairs — the first maximum wins, like the max-pool gradient — and writes
@@ -372,6 +394,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_i
     }
     lds_barrier();
     TSTAMP(3);
+    fetch_targets(1);
     // ---- 3. dense_0: [16 x nx] . [nx x 16 channels] per channel tile, the k range in two halves (Z0 = first half + bias, Z1 = second) --
     {
       const int KX = (nx + 3) >> 2, KXh = (KX + 1) >> 1;
@@ -417,32 +440,33 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_caser_tile(DrxCaserDims D_i
           for (int qq = 0; qq < 8; ++qq) prod[qq] = fmaf(z, wa[qq], pu1 * wb[qq]);
           const float sc = reduce8(prod, c) + bm;
           const float p = sigmoidf_(sc);
-          const float y = jm < D.T ? 1.f : 0.f;
-          const float dsm = jm < D.Tp ? bce_grad(y, p) * inv_bt * p * (1.f - p) : 0.f;
-          if ((c & 7) == 0 && jm < D.Tp) {
+          const float y = jm < T ? 1.f : 0.f;
+          const float dsm = jm < Tp ? bce_grad(y, p) * inv_bt * p * (1.f - p) : 0.f;
+          if ((c & 7) == 0 && jm < Tp) {
             loss_acc += bce_elem(y, p);
-            A.db1[(size_t)gb * D.Tp + jm] = dsm;
+            A.db1[(size_t)gb * Tp + jm] = dsm;
           }
 #pragma unroll
           for (int qq = 0; qq < 8; ++qq) {
-            if (j0 + qq < D.Tp) {
+            if (j0 + qq < Tp) {
               const float ds = lane_f(dsm, lane8(qq));
-              const size_t row = (size_t)gb * D.Tp + j0 + qq;
-              if (live) { A.dW1[row * D.ld2 + c] = ds * z; A.dW1[row * D.ld2 + d + c] = ds * pu1; }
+              const size_t row = (size_t)gb * Tp + j0 + qq;
+              if (live && A.dW1) { A.dW1[row * ld2 + c] = ds * z; A.dW1[row * ld2 + d + c] = ds * pu1; }
               dz = fmaf(ds, wa[qq], dz);
               dpu = fmaf(ds, wb[qq], dpu);
             }
           }
         };
-        round8(0, pwa[k][0], pwb[k][0], pbm[k][0]);
-        if (D.Tp > 8) round8(8, pwa[k][1], pwb[k][1], pbm[k][1]);
+        round8(0, pwa[k][0], pwb[k][0], __shfl(b1v[k], slot8(c)));
+        if (Tp > 8) round8(8, pwa[k][1], pwb[k][1], __shfl(b1v[k], 8 + slot8(c)));
 #pragma unroll 1
-        for (int j0 = 16; j0 < D.Tp; j0 += 8) {
+        for (int j0 = 16; j0 < Tp; j0 += 8) {
           float wa[8], wb[8], bm;
           load_targets(gb, j0, wa, wb, bm);
           round8(j0, wa, wb, bm);
         }
         if (live) A.dPu[(size_t)gb * ld + c] = dpu;
+        if (live && A.cat_out) { A.cat_out[(size_t)gb * ld2 + c] = z; A.cat_out[(size_t)gb * ld2 + d + c] = pu1; }
         dz0 = live ? dz * act_df(D.act_mlp, z0) : 0.f;
       }
       DZ0[b * kSP + lane] = dz0;

@@ -39,11 +39,13 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ p, fl
 // host (drx_batch_csr: counting sort, lookups of a row in batch order).  One group of G lanes per row:
 //   g = sum over the row's lookups q (ascending) of src[order[q]];  p, m, v <- Adam(g + l2c * p)     (+ the same for one scalar per row)
 // No touch keys on the device, no sort, no zeroed gradient table, no separate optimizer launch.
-template <int G, int J>
+// OUTER: the gradient row of lookup o is src_s[o] * src[o / group] — an outer product the producer does not write out (Caser's dense_1
+// rows: the score's gradient times the sample's hidden state, drx.h drx_rows_csr_adam_outer); src_s doubles as the per-lookup scalar.
+template <int G, int J, bool OUTER>
 __global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restrict__ ptr, const int32_t *__restrict__ order,
                                                           const float *__restrict__ src, const float *__restrict__ src_s, int ld,
                                                           int n_rows, float *p, float *m, float *v, float *ps, float *ms, float *vs,
-                                                          float alpha, float alpha_s, float l2c, float b1, float b2, float eps) {
+                                                          float alpha, float alpha_s, float l2c, float b1, float b2, float eps, int group) {
   const int lane = threadIdx.x % G;
   const int gpb = kBlock / G;
   for (int row = blockIdx.x * gpb + threadIdx.x / G; row < n_rows; row += gridDim.x * gpb) {
@@ -59,21 +61,30 @@ __global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restr
     for (; q + 4 <= q1; q += 4) {                    // four lookup rows in flight
       const int o0 = order[q], o1 = order[q + 1], o2 = order[q + 2], o3 = order[q + 3];
       float4 r0[J], r1[J], r2[J], r3[J];
-      load_row<G, J>(src, (size_t)o0, ld, lane, r0);
-      load_row<G, J>(src, (size_t)o1, ld, lane, r1);
-      load_row<G, J>(src, (size_t)o2, ld, lane, r2);
-      load_row<G, J>(src, (size_t)o3, ld, lane, r3);
-      if (src_s) gs = ((gs + src_s[o0]) + src_s[o1]) + src_s[o2] + src_s[o3];
+      load_row<G, J>(src, (size_t)(OUTER ? o0 / group : o0), ld, lane, r0);
+      load_row<G, J>(src, (size_t)(OUTER ? o1 / group : o1), ld, lane, r1);
+      load_row<G, J>(src, (size_t)(OUTER ? o2 / group : o2), ld, lane, r2);
+      load_row<G, J>(src, (size_t)(OUTER ? o3 / group : o3), ld, lane, r3);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      if (OUTER || src_s) { s0 = src_s[o0]; s1 = src_s[o1]; s2 = src_s[o2]; s3 = src_s[o3]; }
+      gs = ((gs + s0) + s1) + s2 + s3;
 #pragma unroll
-      for (int j = 0; j < J; ++j) { f4_add(g[j], r0[j]); f4_add(g[j], r1[j]); f4_add(g[j], r2[j]); f4_add(g[j], r3[j]); }
+      for (int j = 0; j < J; ++j) {
+        if (OUTER) { f4_fma(g[j], s0, r0[j]); f4_fma(g[j], s1, r1[j]); f4_fma(g[j], s2, r2[j]); f4_fma(g[j], s3, r3[j]); }
+        else { f4_add(g[j], r0[j]); f4_add(g[j], r1[j]); f4_add(g[j], r2[j]); f4_add(g[j], r3[j]); }
+      }
     }
     for (; q < q1; ++q) {
       const int o0 = order[q];
       float4 r0[J];
-      load_row<G, J>(src, (size_t)o0, ld, lane, r0);
-      if (src_s) gs += src_s[o0];
+      load_row<G, J>(src, (size_t)(OUTER ? o0 / group : o0), ld, lane, r0);
+      const float s0 = (OUTER || src_s) ? src_s[o0] : 0.f;
+      gs += s0;
 #pragma unroll
-      for (int j = 0; j < J; ++j) f4_add(g[j], r0[j]);
+      for (int j = 0; j < J; ++j) {
+        if (OUTER) f4_fma(g[j], s0, r0[j]);
+        else f4_add(g[j], r0[j]);
+      }
     }
     const OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, alpha};
     float4 *pr = reinterpret_cast<float4 *>(p + (size_t)row * ld), *mr = reinterpret_cast<float4 *>(m + (size_t)row * ld),
@@ -268,9 +279,10 @@ int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, floa
   return DRX_OK;
 }
 
-int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float *src, const float *src_s, int32_t ld, int32_t n_rows,
-                      float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s, float l2_coef,
-                      float beta1, float beta2, float eps, void *stream) {
+// the two entry points below: lookups' rows as they are / as scale[o] * src[o / group]
+static int rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float *src, const float *src_s, int32_t group, int32_t ld,
+                         int32_t n_rows, float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s,
+                         float l2_coef, float beta1, float beta2, float eps, void *stream) {
   if (!row_ptr || !order || !src || !p || !m || !v || n_rows < 1 || ld < 4 || (ld & 3) || ld > DRX_MAX_K) return DRX_EINVAL;
   if ((p_s != nullptr) != (src_s != nullptr) || (p_s && (!m_s || !v_s))) return DRX_EINVAL;
   if (((uintptr_t)src | (uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) return DRX_EINVAL;
@@ -280,13 +292,30 @@ int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float 
     const int gpb = kBlock / G;                                                                                             \
     int blocks = (n_rows + gpb - 1) / gpb;                                                                                  \
     if (blocks > 8192) blocks = 8192;                                                                                       \
-    hipLaunchKernelGGL((k_rows_csr_adam<G, J>), dim3(blocks), dim3(kBlock), 0, st, row_ptr, order, src, src_s, ld, n_rows, p, m, v, \
-                       p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps);                                          \
+    if (group > 0)                                                                                                          \
+      hipLaunchKernelGGL((k_rows_csr_adam<G, J, true>), dim3(blocks), dim3(kBlock), 0, st, row_ptr, order, src, src_s, ld, n_rows, p, m, \
+                         v, p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps, group);                              \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_rows_csr_adam<G, J, false>), dim3(blocks), dim3(kBlock), 0, st, row_ptr, order, src, src_s, ld, n_rows, p, m, \
+                         v, p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps, 1);                                  \
   }
   DRX_DISPATCH_GEOM(ld, CALL);
 #undef CALL
   DRX_LAUNCH_CHECK();
   return DRX_OK;
+}
+
+int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float *src, const float *src_s, int32_t ld, int32_t n_rows,
+                      float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s, float l2_coef,
+                      float beta1, float beta2, float eps, void *stream) {
+  return rows_csr_adam(row_ptr, order, src, src_s, 0, ld, n_rows, p, m, v, p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps, stream);
+}
+
+int drx_rows_csr_adam_outer(const int32_t *row_ptr, const int32_t *order, const float *scale, const float *src, int32_t group, int32_t ld,
+                            int32_t n_rows, float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s,
+                            float l2_coef, float beta1, float beta2, float eps, void *stream) {
+  if (!scale || group < 1 || !p_s) return DRX_EINVAL;
+  return rows_csr_adam(row_ptr, order, src, scale, group, ld, n_rows, p, m, v, p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps, stream);
 }
 
 size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows) {

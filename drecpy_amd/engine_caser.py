@@ -256,23 +256,28 @@ class CaserEngine:
         z = dict(dtype=torch.float32, device=self.device)
         stream = stream_ptr(self.device)
         grid = L_.drx_caser_grid(C.byref(self.D), B)
-        n_dE, n_dW1, n_dPu = B * self.L * self.ld, B * self.Tp * self.ld2, B * self.ld
+        # dense_1's gradient rows are outer products, score gradient x [dense_0 output | user row]: with the 'csr' update the kernel writes
+        # the B hidden rows and drx_rows_csr_adam_outer forms the B * Tp rows where it sums them (19.7 MB less to write and to read back
+        # per step of 4096); the 'scatter' update takes them written out
+        outer = csr is not None
+        n_dE, n_dW1, n_dPu = B * self.L * self.ld, (B if outer else B * self.Tp) * self.ld2, B * self.ld
         # device work buffers of a batch size: steps run in order on one stream, so they are reused from step to step
         wk = getattr(self, '_step_bufs', None)
-        if wk is None or wk[0] != B:
+        if wk is None or wk[0] != (B, outer):
             rows = torch.zeros(n_dE + n_dW1 + n_dPu, **z)    # the padding columns of the gradient rows stay zero: the kernel never writes them
-            wk = self._step_bufs = (B, rows, torch.empty(B * self.Tp, **z), torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z),
+            wk = self._step_bufs = ((B, outer), rows, torch.empty(B * self.Tp, **z), torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z),
                                     torch.empty(self.D.n_small + 1, **z))
         _, rows, db1, gpart, lpart, gsw = wk
         base = rows.data_ptr()
-        p_dE, p_dW1, p_dPu = base, base + 4 * n_dE, base + 4 * (n_dE + n_dW1)
+        p_dE, p_dW1, p_dPu = base, base + 4 * n_dE, base + 4 * (n_dE + n_dW1)       # (p_dW1: the rows, or the B hidden rows)
         A = CaserArgs()
         A.item_emb, A.user_emb, A.W1, A.b1, A.sw = (t.data_ptr() for t in (self.item_emb, self.user_emb, self.W1, self.b1, self.sw))
         A.uid, A.before, A.after = uid_p, bef_p, aft_p
         A.keep = kp.data_ptr() if kp is not None else None
         A.rate, A.B = float(rate), int(B)
         A.mask_seed = int(mask_seed) & (2 ** 64 - 1)
-        A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part = p_dE, p_dW1, db1.data_ptr(), p_dPu, gpart.data_ptr(), lpart.data_ptr()
+        A.dE, A.db1, A.dPu, A.gsw_part, A.loss_part = p_dE, db1.data_ptr(), p_dPu, gpart.data_ptr(), lpart.data_ptr()
+        A.dW1, A.cat_out = (None, p_dW1) if outer else (p_dW1, None)
         reg_loss = None
         if want_loss:                                   # Keras l2(reg) on the pre-update weights
             sq = _lib.sumsq([self.user_emb, self.item_emb, self.W1] + [self.sw[start:start + n] for _, start, n, regd, _ in self.seg if regd])
@@ -292,8 +297,12 @@ class CaserEngine:
                 ps = ms = vs = None
                 if sname is not None:
                     ps, (ms, vs) = getattr(self, sname).data_ptr(), (t.data_ptr() for t in st_[sname])
-                check(L_.drx_rows_csr_adam(rp, od, src, src_s, ld, n_rows, p.data_ptr(), m.data_ptr(), v.data_ptr(), ps, ms, vs, a, a_s, l2c,
-                                           self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam')
+                if name == 'W1':
+                    check(L_.drx_rows_csr_adam_outer(rp, od, src_s, src, self.Tp, ld, n_rows, p.data_ptr(), m.data_ptr(), v.data_ptr(), ps, ms, vs,
+                                                     a, a_s, l2c, self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam_outer')
+                else:
+                    check(L_.drx_rows_csr_adam(rp, od, src, src_s, ld, n_rows, p.data_ptr(), m.data_ptr(), v.data_ptr(), ps, ms, vs, a, a_s, l2c,
+                                               self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam')
         else:
             self._grad_arena.zero_()
             g = self._grads

@@ -389,6 +389,14 @@ size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows);
 int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float *src, const float *src_s, int32_t ld, int32_t n_rows,
                       float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s, float l2_coef,
                       float beta1, float beta2, float eps, void *stream);
+/* The same where the gradient row of lookup o is an OUTER PRODUCT the producer did not write out: scale[o] * src[o / group]
+ * (src [T / group, ld]; `group` consecutive lookups share a row of src), and scale[o] itself is the lookup's scalar gradient (p_s, m_s,
+ * v_s required).  Caser's dense_1: the gradient of dense_1_W[n] through target j of sample b is dscore[b, j] * [dense_0 output | user
+ * row](b) (caser.py:115-120) — drx_caser_fwd_bwd with dW1 == NULL writes the B hidden rows (cat_out) and the B * Tp score gradients
+ * (db1) instead of B * Tp rows: 1.6 MB instead of 19.7 MB at examples/caser.py's batch of 4096. */
+int drx_rows_csr_adam_outer(const int32_t *row_ptr, const int32_t *order, const float *scale, const float *src, int32_t group, int32_t ld,
+                            int32_t n_rows, float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s,
+                            float l2_coef, float beta1, float beta2, float eps, void *stream);
 /* host: first[c] = first position of code c in codes[0..n), -1 when absent; returns the number of distinct codes (Dataset.unique on
  * dense integer code columns, mem_dataset.py's drop_duplicates, without a sort) */
 int64_t drx_first_occurrence(const int64_t *codes, int64_t n, int64_t n_codes, int64_t *first);
@@ -437,12 +445,13 @@ typedef struct DrxCaserArgs {
   float rate;
   int32_t B;
   float *dE;               /* [B*L, ld]   gradient row of every item lookup */
-  float *dW1;              /* [B*Tp, ld2] gradient row of every dense_1_W lookup */
+  float *dW1;              /* [B*Tp, ld2] gradient row of every dense_1_W lookup = db1[row] * cat_out[row / Tp]; NULL: not written
+                            * (cat_out required then: drx_rows_csr_adam_outer forms the rows where it sums them) */
   float *db1;              /* [B*Tp] */
   float *dPu;              /* [B, ld]     gradient row of every user lookup */
   float *gsw_part;         /* [drx_caser_grid(), n_small] */
   float *loss_part;        /* [drx_caser_grid()] */
-  float *cat_out;          /* [B, ld2] (drx_caser_hidden only) */
+  float *cat_out;          /* [B, ld2] [dense_0 output | user row] of every sample: drx_caser_hidden; drx_caser_fwd_bwd when non-NULL */
   uint64_t mask_seed;      /* keep == NULL and rate > 0: dropout keeps element (b, j) iff drx_hash_u32(mask_seed, b, j) >= rate * 2^32 —
                             * a counter-based mask evaluated in the kernel (TF's dropout stream cannot be reproduced either way) */
 } DrxCaserArgs;
