@@ -69,6 +69,11 @@ class CaserArgs(C.Structure):
                [(n, C.c_void_p) for n in ('dE', 'dW1', 'db1', 'dPu', 'gsw_part', 'loss_part', 'cat_out')] + [('mask_seed', C.c_uint64)]
 
 
+class CsrAdamTable(C.Structure):                        # include/drx.h DrxCsrAdamTable
+    _fields_ = [(n, C.c_void_p) for n in ('row_ptr', 'order', 'src', 'scale')] + [(n, C.c_int32) for n in ('group', 'ld', 'n_rows')] + \
+               [(n, C.c_void_p) for n in ('p', 'm', 'v', 'p_s', 'm_s', 'v_s')] + [(n, C.c_float) for n in ('alpha', 'alpha_s', 'l2_coef')]
+
+
 class DmfDims(C.Structure):
     _fields_ = [('n_layers', C.c_int32 * 2), ('f', (C.c_int32 * 4) * 2), ('ld0', C.c_int32 * 2),
                 ('off_k', (C.c_int32 * 4) * 2), ('off_b', (C.c_int32 * 4) * 2), ('n_small', C.c_int32),
@@ -175,7 +180,10 @@ SIGNATURES = {
                                     C.c_float, C.c_float, C.c_void_p]),
     'drx_caser_grid': (C.c_int, [C.POINTER(CaserDims), C.c_int32]),
     'drx_caser_fwd_bwd': (C.c_int, [C.POINTER(CaserDims), C.POINTER(CaserArgs), C.c_void_p, C.c_void_p]),
+    'drx_caser_step_small': (C.c_int, [C.POINTER(CaserDims), C.POINTER(CaserArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(AdamSegments), C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'drx_caser_hidden': (C.c_int, [C.POINTER(CaserDims), C.POINTER(CaserArgs), C.c_void_p]),
+    'drx_rows_csr_adam_multi': (C.c_int, [C.POINTER(CsrAdamTable), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'drx_dmf_grid': (C.c_int, [C.c_int32]),
     'drx_dmf_work_bytes': (C.c_size_t, [C.c_int32]),
     'drx_dmf_fwd_bwd': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p]),

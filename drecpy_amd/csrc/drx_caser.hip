@@ -149,6 +149,38 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const float *__restrict__
   }
 }
 
+// k_sum_partials with the small weights' Keras Adam behind it: the thread that has column j's sum applies l2 + Adam of j's segment
+// (one launch instead of two; same operations in the same order as k_sum_partials + k_adam_segments).
+__global__ __launch_bounds__(1024) void k_sum_partials_adam(const float *__restrict__ part, int n_rows, int n, const float *__restrict__ tail,
+                                                            float *__restrict__ out, float *p, float *m, float *v, DrxAdamSegments sg,
+                                                            float b1, float b2, float eps) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float a = 0.f;
+  if (j < n) for (int r = q; r < n_rows; r += 16) a += part[(size_t)r * n + j];
+  else if (j == n) for (int r = q; r < n_rows; r += 16) a += tail[r];
+  red[q][c] = a;
+  __syncthreads();
+  if (q == 0 && j <= n) {
+    float t = 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) t += red[qq][c];
+    out[j] = t;
+    if (j < n) {
+      int s = -1;
+      for (int k = 0; k < sg.n; ++k)
+        if (j >= sg.start[k] && j < sg.start[k] + sg.len[k]) s = k;
+      if (s >= 0) {                                  // (padding entries of a bias segment belong to no segment: left alone)
+        const OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, sg.alpha[s]};
+        float pp = p[j], mm = m[j], vv = v[j];
+        opt_update1(o, fmaf(sg.l2_coef[s], pp, t), pp, mm, vv);
+        p[j] = pp; m[j] = mm; v[j] = vv;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_adam_segments(float *p, float *m, float *v, const float *g, DrxAdamSegments sg, float b1,
                                                           float b2, float eps) {
   for (int s = 0; s < sg.n; ++s) {
@@ -212,13 +244,13 @@ int drx_caser_grid(const DrxCaserDims *D, int32_t B) {
   return g < 256 ? g : 256;
 }
 
-int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, void *stream) {
+// the training kernel of drx_caser_fwd_bwd / drx_caser_step_small (the partial sums are reduced by the caller)
+static int launch_caser_tile(const DrxCaserDims *D, const DrxCaserArgs *A, const float *gsw_out, hipStream_t st, int *grid_out) {
   int rc = check_dims(D);
   if (rc) return rc;
   if (!A || !A->item_emb || !A->user_emb || !A->W1 || !A->b1 || !A->sw || !A->uid || !A->before || !A->after || !A->dE ||
       (!A->dW1 && !A->cat_out) || !A->db1 || !A->dPu || !A->gsw_part || !A->loss_part || !gsw_out || A->B < 1 || A->rate < 0.f || A->rate >= 1.f)
     return DRX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
   const int grid = drx_caser_grid(D, A->B);
   const int var = caser_tile_variant(*D);
   const size_t lds = (size_t)caser_tile_geom(*D, var).floats * 4;
@@ -230,9 +262,30 @@ int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_o
   // (examples/caser.py:13 with fit(neg_ratio=3): its dimensions as compile-time constants)
   const bool fx = var == 2 && D->L == 5 && D->d == 50 && D->ld == 52 && D->ld2 == 100 && D->n_v == 4 && D->n_h == 16 && D->T == 3 && D->Tp == 12;
   rc = fx ? launch(k_caser_tile<2, 1>) : var == 2 ? launch(k_caser_tile<2, 0>) : var == 1 ? launch(k_caser_tile<1, 0>) : launch(k_caser_tile<0, 0>);
+  *grid_out = grid;
+  return rc;
+}
+
+int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int grid = 0;
+  const int rc = launch_caser_tile(D, A, gsw_out, st, &grid);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sum_partials, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
                      A->loss_part, gsw_out);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
+int drx_caser_step_small(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, float *sw, float *sw_m, float *sw_v,
+                         const DrxAdamSegments *sg, float beta1, float beta2, float eps, void *stream) {
+  if (!sw || !sw_m || !sw_v || !sg || sg->n < 1 || sg->n > DRX_MAX_SEGMENTS || (A && sw != A->sw)) return DRX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = 0;
+  const int rc = launch_caser_tile(D, A, gsw_out, st, &grid);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sum_partials_adam, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, grid, D->n_small,
+                     A->loss_part, gsw_out, sw, sw_m, sw_v, *sg, beta1, beta2, eps);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

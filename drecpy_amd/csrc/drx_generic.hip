@@ -41,24 +41,22 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ p, fl
 // No touch keys on the device, no sort, no zeroed gradient table, no separate optimizer launch.
 // OUTER: the gradient row of lookup o is src_s[o] * src[o / group] — an outer product the producer does not write out (Caser's dense_1
 // rows: the score's gradient times the sample's hidden state, drx.h drx_rows_csr_adam_outer); src_s doubles as the per-lookup scalar.
+// blk of n_blk: this workgroup's share of the table's rows (a launch of its own, or a table's part of drx_rows_csr_adam_multi's).
+constexpr int kCsrSplit = 64;     // lookups from which a row's sum is split over the groups of its workgroup
+
 template <int G, int J, bool OUTER>
-__global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restrict__ ptr, const int32_t *__restrict__ order,
-                                                          const float *__restrict__ src, const float *__restrict__ src_s, int ld,
-                                                          int n_rows, float *p, float *m, float *v, float *ps, float *ms, float *vs,
-                                                          float alpha, float alpha_s, float l2c, float b1, float b2, float eps, int group) {
-  const int lane = threadIdx.x % G;
-  const int gpb = kBlock / G;
-  for (int row = blockIdx.x * gpb + threadIdx.x / G; row < n_rows; row += gridDim.x * gpb) {
-    float4 w[J], mm[J], vv[J], g[J];
-    load_row<G, J>(p, (size_t)row, ld, lane, w);
-    load_row<G, J>(m, (size_t)row, ld, lane, mm);
-    load_row<G, J>(v, (size_t)row, ld, lane, vv);
-    float gs = 0.f;
-#pragma unroll
-    for (int j = 0; j < J; ++j) g[j] = f4_zero();
-    const int q0 = ptr[row], q1 = ptr[row + 1];
-    int q = q0;
-    for (; q + 4 <= q1; q += 4) {                    // four lookup rows in flight
+__device__ __forceinline__ void rows_csr_adam_body(const int32_t *__restrict__ ptr, const int32_t *__restrict__ order,
+                                                   const float *__restrict__ src, const float *__restrict__ src_s, int ld, int n_rows,
+                                                   float *p, float *m, float *v, float *ps, float *ms, float *vs, float alpha,
+                                                   float alpha_s, float l2c, float b1, float b2, float eps, int group, int blk, int n_blk,
+                                                   float *part /* LDS [kBlock / G][4 * G * J] */, float *part_s /* LDS [kBlock / G] */,
+                                                   int *cnt /* LDS [kBlock / G] */) {
+  const int lane = threadIdx.x % G, gid = threadIdx.x / G;
+  constexpr int gpb = kBlock / G;
+  // g, gs += the gradient rows / scalars of the lookups [qa, qb) of the list, in list order, four rows in flight
+  auto sum_range = [&](int qa, int qb, float4 (&g)[J], float &gs) __attribute__((always_inline)) {
+    int q = qa;
+    for (; q + 4 <= qb; q += 4) {
       const int o0 = order[q], o1 = order[q + 1], o2 = order[q + 2], o3 = order[q + 3];
       float4 r0[J], r1[J], r2[J], r3[J];
       load_row<G, J>(src, (size_t)(OUTER ? o0 / group : o0), ld, lane, r0);
@@ -74,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restr
         else { f4_add(g[j], r0[j]); f4_add(g[j], r1[j]); f4_add(g[j], r2[j]); f4_add(g[j], r3[j]); }
       }
     }
-    for (; q < q1; ++q) {
+    for (; q < qb; ++q) {
       const int o0 = order[q];
       float4 r0[J];
       load_row<G, J>(src, (size_t)(OUTER ? o0 / group : o0), ld, lane, r0);
@@ -86,6 +84,9 @@ __global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restr
         else f4_add(g[j], r0[j]);
       }
     }
+  };
+  // l2 + Keras Adam of table row `row` (and of its scalar) with the gradient g / gs
+  auto apply = [&](int row, const float4 (&w)[J], float4 (&mm)[J], float4 (&vv)[J], const float4 (&g)[J], float gs) __attribute__((always_inline)) {
     const OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, alpha};
     float4 *pr = reinterpret_cast<float4 *>(p + (size_t)row * ld), *mr = reinterpret_cast<float4 *>(m + (size_t)row * ld),
            *vr = reinterpret_cast<float4 *>(v + (size_t)row * ld);
@@ -93,11 +94,12 @@ __global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restr
     for (int j = 0; j < J; ++j) {
       const int c = lane + j * G;
       if (4 * c < ld) {
-        opt_update1(o, fmaf(l2c, w[j].x, g[j].x), w[j].x, mm[j].x, vv[j].x);
-        opt_update1(o, fmaf(l2c, w[j].y, g[j].y), w[j].y, mm[j].y, vv[j].y);
-        opt_update1(o, fmaf(l2c, w[j].z, g[j].z), w[j].z, mm[j].z, vv[j].z);
-        opt_update1(o, fmaf(l2c, w[j].w, g[j].w), w[j].w, mm[j].w, vv[j].w);
-        pr[c] = w[j]; mr[c] = mm[j]; vr[c] = vv[j];
+        float4 ww = w[j];
+        opt_update1(o, fmaf(l2c, ww.x, g[j].x), ww.x, mm[j].x, vv[j].x);
+        opt_update1(o, fmaf(l2c, ww.y, g[j].y), ww.y, mm[j].y, vv[j].y);
+        opt_update1(o, fmaf(l2c, ww.z, g[j].z), ww.z, mm[j].z, vv[j].z);
+        opt_update1(o, fmaf(l2c, ww.w, g[j].w), ww.w, mm[j].w, vv[j].w);
+        pr[c] = ww; mr[c] = mm[j]; vr[c] = vv[j];
       }
     }
     if (ps && lane == 0) {
@@ -106,7 +108,98 @@ __global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restr
       opt_update1(os, gs, pp, pm, pv);
       ps[row] = pp; ms[row] = pm; vs[row] = pv;
     }
+  };
+  // A workgroup takes gpb rows at a time, a group each.  A row named by kCsrSplit lookups or more (a popular item: thousands at a
+  // batch of 4096 windows) would keep ONE group busy long after the others are done: its list is cut into gpb slices, every group sums
+  // one, the partial sums are added in slice order by group 0 — a fixed order, like the single walk.
+  for (int row0 = blk * gpb; row0 < n_rows; row0 += n_blk * gpb) {
+    const int row = row0 + gid;
+    const bool valid = row < n_rows;
+    const int q0 = valid ? ptr[row] : 0, q1 = valid ? ptr[row + 1] : 0;
+    if (lane == 0) cnt[gid] = q1 - q0;
+    __syncthreads();
+    if (valid && q1 - q0 < kCsrSplit) {
+      float4 w[J], mm[J], vv[J], g[J];
+      load_row<G, J>(p, (size_t)row, ld, lane, w);
+      load_row<G, J>(m, (size_t)row, ld, lane, mm);
+      load_row<G, J>(v, (size_t)row, ld, lane, vv);
+      float gs = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) g[j] = f4_zero();
+      sum_range(q0, q1, g, gs);
+      apply(row, w, mm, vv, g, gs);
+    }
+    for (int k = 0; k < gpb; ++k) {                    // (uniform over the workgroup: cnt is shared)
+      const int n = cnt[k];
+      if (n < kCsrSplit) continue;
+      const int hrow = row0 + k, h0 = ptr[hrow];
+      const int per = (((n + gpb - 1) / gpb) + 3) & ~3;
+      float4 g[J];
+      float gs = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) g[j] = f4_zero();
+      sum_range(min(h0 + gid * per, h0 + n), min(h0 + (gid + 1) * per, h0 + n), g, gs);
+#pragma unroll
+      for (int j = 0; j < J; ++j) *reinterpret_cast<float4 *>(part + (size_t)gid * (4 * G * J) + 4 * (lane + j * G)) = g[j];
+      if (lane == 0) part_s[gid] = gs;
+      __syncthreads();
+      if (gid == 0) {
+        float4 w[J], mm[J], vv[J];
+        load_row<G, J>(p, (size_t)hrow, ld, lane, w);
+        load_row<G, J>(m, (size_t)hrow, ld, lane, mm);
+        load_row<G, J>(v, (size_t)hrow, ld, lane, vv);
+        gs = part_s[0];
+        for (int kk = 1; kk < gpb; ++kk) {
+          gs += part_s[kk];
+#pragma unroll
+          for (int j = 0; j < J; ++j) f4_add(g[j], *reinterpret_cast<const float4 *>(part + (size_t)kk * (4 * G * J) + 4 * (lane + j * G)));
+        }
+        apply(hrow, w, mm, vv, g, gs);
+      }
+      __syncthreads();
+    }
+    __syncthreads();                                    // (cnt is rewritten by the next round)
   }
+}
+
+template <int G, int J, bool OUTER>
+__global__ __launch_bounds__(kBlock) void k_rows_csr_adam(const int32_t *__restrict__ ptr, const int32_t *__restrict__ order,
+                                                          const float *__restrict__ src, const float *__restrict__ src_s, int ld,
+                                                          int n_rows, float *p, float *m, float *v, float *ps, float *ms, float *vs,
+                                                          float alpha, float alpha_s, float l2c, float b1, float b2, float eps, int group) {
+  __shared__ __align__(16) float part[(kBlock / G) * 4 * G * J];
+  __shared__ float part_s[kBlock / G];
+  __shared__ int cnt[kBlock / G];
+  rows_csr_adam_body<G, J, OUTER>(ptr, order, src, src_s, ld, n_rows, p, m, v, ps, ms, vs, alpha, alpha_s, l2c, b1, b2, eps, group,
+                                  (int)blockIdx.x, (int)gridDim.x, part, part_s, cnt);
+}
+
+// Several tables in one launch (Caser's three lookup tables: three launches of a few microseconds of work each spent most of their
+// time starting and draining): consecutive ranges of workgroups take a table each.
+struct CsrMulti { DrxCsrAdamTable t[DRX_MAX_CSR_TABLES]; int blocks[DRX_MAX_CSR_TABLES]; int n; };
+__global__ __launch_bounds__(kBlock) void k_rows_csr_adam_multi(CsrMulti M, float b1, float b2, float eps) {
+  int blk = blockIdx.x, ti = 0;
+  while (ti + 1 < M.n && blk >= M.blocks[ti]) { blk -= M.blocks[ti]; ++ti; }
+  const DrxCsrAdamTable &T = M.t[ti];
+  const int nb = M.blocks[ti];
+  __shared__ __align__(16) float part[kBlock * 4];           // (J = 1: (kBlock / G) * 4 G floats whatever G)
+  __shared__ float part_s[kBlock / 4];
+  __shared__ int cnt[kBlock / 4];
+#define BODY(G, OUTER)                                                                                                             \
+  rows_csr_adam_body<G, 1, OUTER>(T.row_ptr, T.order, T.src, T.scale, T.ld, T.n_rows, T.p, T.m, T.v, T.p_s, T.m_s, T.v_s, T.alpha,    \
+                                  T.alpha_s, T.l2_coef, b1, b2, eps, T.group, blk, nb, part, part_s, cnt)
+#define GEOM(OUTER)                                         \
+  do {                                                      \
+    if (T.ld <= 16) BODY(4, OUTER);                         \
+    else if (T.ld <= 32) BODY(8, OUTER);                    \
+    else if (T.ld <= 64) BODY(16, OUTER);                   \
+    else if (T.ld <= 128) BODY(32, OUTER);                  \
+    else BODY(64, OUTER);                                   \
+  } while (0)
+  if (T.group > 0) GEOM(true);
+  else GEOM(false);
+#undef GEOM
+#undef BODY
 }
 
 struct ScatterPolicy {
@@ -316,6 +409,29 @@ int drx_rows_csr_adam_outer(const int32_t *row_ptr, const int32_t *order, const 
                             float l2_coef, float beta1, float beta2, float eps, void *stream) {
   if (!scale || group < 1 || !p_s) return DRX_EINVAL;
   return rows_csr_adam(row_ptr, order, src, scale, group, ld, n_rows, p, m, v, p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps, stream);
+}
+
+int drx_rows_csr_adam_multi(const DrxCsrAdamTable *tables, int32_t n_tables, float beta1, float beta2, float eps, void *stream) {
+  if (!tables || n_tables < 1 || n_tables > DRX_MAX_CSR_TABLES) return DRX_EINVAL;
+  CsrMulti M;
+  M.n = n_tables;
+  int total = 0;
+  for (int i = 0; i < n_tables; ++i) {
+    const DrxCsrAdamTable &T = tables[i];
+    if (!T.row_ptr || !T.order || !T.src || !T.p || !T.m || !T.v || T.n_rows < 1 || T.ld < 4 || (T.ld & 3) || T.ld > 256 || T.group < 0)
+      return DRX_EINVAL;
+    if ((T.p_s != nullptr) != (T.scale != nullptr) || (T.p_s && (!T.m_s || !T.v_s)) || (T.group > 0 && !T.scale)) return DRX_EINVAL;
+    if (((uintptr_t)T.src | (uintptr_t)T.p | (uintptr_t)T.m | (uintptr_t)T.v) & 15) return DRX_EINVAL;
+    const int gpb = kBlock / pick_geom(T.ld).G;
+    int blocks = (T.n_rows + gpb - 1) / gpb;
+    if (blocks > 4096) blocks = 4096;
+    M.t[i] = T;
+    M.blocks[i] = blocks;
+    total += blocks;
+  }
+  hipLaunchKernelGGL(k_rows_csr_adam_multi, dim3(total), dim3(kBlock), 0, (hipStream_t)stream, M, beta1, beta2, eps);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
 }
 
 size_t drx_scatter_scratch_bytes(int32_t ld, int32_t n_touches, int32_t n_rows) {

@@ -1,10 +1,12 @@
 """Device-side state of one Caser model and the calls into libdrx.so (drx_caser_*, drx_scatter_rows, drx_adam_*).
 
-One training step = the body of the reference fit() loop for Caser (recommender_abc.py:190-204 over caser.py:86-120):
-  drx_caser_fwd_bwd     forward, Keras BCE, backward -> one gradient row per embedding lookup + small-weight gradients
-  drx_rows_csr_adam x3  lookups' rows -> gradient + L2 (Keras l2(reg): 2*reg*w) + Keras Adam of item_emb, dense_1_W (+dense_1_b), user_emb in
-                        one pass per table, from the lookups grouped by row on the host (drx_batch_csr); one lr_t per registered layer
-  drx_adam_segments     the conv / dense_0 kernels and biases
+One training step = the body of the reference fit() loop for Caser (recommender_abc.py:190-204 over caser.py:86-120), three launches:
+  drx_caser_step_small      forward, Keras BCE, backward (k_caser_tile: tiles of 16 samples on the matrix cores) -> one gradient row per
+                            item / user lookup, the score gradients and hidden rows of the dense_1 lookups, the workgroups' partial sums of
+                            the small-weight gradients; then those sums and the conv / dense_0 kernels' and biases' l2 + Keras Adam
+  drx_rows_csr_adam_multi   the lookups' rows -> gradient + L2 (Keras l2(reg): 2*reg*w) + Keras Adam of item_emb, user_emb and dense_1_W
+                            (+ dense_1_b; its rows formed as score gradient x hidden row where they are summed) in one pass per table, from
+                            the lookups grouped by row on the host (drx_batch_csr); one lr_t per registered layer
 (table_update == 'scatter', for batches already on the device: drx_scatter_rows x3 into a zeroed gradient arena + drx_adam_dense x4)
 """
 import ctypes as C
@@ -282,27 +284,31 @@ class CaserEngine:
         if want_loss:                                   # Keras l2(reg) on the pre-update weights
             sq = _lib.sumsq([self.user_emb, self.item_emb, self.W1] + [self.sw[start:start + n] for _, start, n, regd, _ in self.seg if regd])
             reg_loss = self.reg * sq
-        check(L_.drx_caser_fwd_bwd(C.byref(self.D), C.byref(A), gsw.data_ptr(), stream), 'drx_caser_fwd_bwd')
         alpha = self._alphas(step_idx)
         l2c = 2.0 * self.reg
+        sg = AdamSegments()
+        sg.n = len(self.seg)
+        for i, (_, start, n, regd, layer) in enumerate(self.seg):
+            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[layer], (l2c if regd else 0.0)
+        m, v = self.state['sw']
+        # forward / backward, then the small weights' Adam in the launch that sums the workgroups' partial gradients
+        check(L_.drx_caser_step_small(C.byref(self.D), C.byref(A), gsw.data_ptr(), self.sw.data_ptr(), m.data_ptr(), v.data_ptr(), C.byref(sg),
+                                      self.beta1, self.beta2, self.eps, stream), 'drx_caser_step_small')
         if csr is not None:
+            # the three lookup tables (+ dense_1_b) in one launch: gradient rows summed per table row, l2, Keras Adam
             ptrE, ordE, ptrW, ordW, ptrU, ordU = csr
             st_ = self.state
-            for rp, od, src, src_s, ld, n_rows, name, a, sname, a_s in (
-                    (ptrU, ordU, p_dPu, None, self.ld, self.U, 'user_emb', alpha[0], None, 0.0),
-                    (ptrE, ordE, p_dE, None, self.ld, self.N, 'item_emb', alpha[1], None, 0.0),
-                    (ptrW, ordW, p_dW1, db1.data_ptr(), self.ld2, self.N, 'W1', alpha[4 + self.L], 'b1', alpha[5 + self.L])):
-                p = getattr(self, name)
-                m, v = st_[name]
-                ps = ms = vs = None
+            tabs = (_lib.CsrAdamTable * 3)()
+            for t, (rp, od, src, scale, group, ld, n_rows, name, a, sname, a_s) in zip(tabs, (
+                    (ptrU, ordU, p_dPu, None, 0, self.ld, self.U, 'user_emb', alpha[0], None, 0.0),
+                    (ptrE, ordE, p_dE, None, 0, self.ld, self.N, 'item_emb', alpha[1], None, 0.0),
+                    (ptrW, ordW, p_dW1, db1.data_ptr(), self.Tp, self.ld2, self.N, 'W1', alpha[4 + self.L], 'b1', alpha[5 + self.L]))):
+                t.row_ptr, t.order, t.src, t.scale, t.group, t.ld, t.n_rows = rp, od, src, scale, group, ld, n_rows
+                t.p, (t.m, t.v) = getattr(self, name).data_ptr(), (x.data_ptr() for x in st_[name])
                 if sname is not None:
-                    ps, (ms, vs) = getattr(self, sname).data_ptr(), (t.data_ptr() for t in st_[sname])
-                if name == 'W1':
-                    check(L_.drx_rows_csr_adam_outer(rp, od, src_s, src, self.Tp, ld, n_rows, p.data_ptr(), m.data_ptr(), v.data_ptr(), ps, ms, vs,
-                                                     a, a_s, l2c, self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam_outer')
-                else:
-                    check(L_.drx_rows_csr_adam(rp, od, src, src_s, ld, n_rows, p.data_ptr(), m.data_ptr(), v.data_ptr(), ps, ms, vs, a, a_s, l2c,
-                                               self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam')
+                    t.p_s, (t.m_s, t.v_s) = getattr(self, sname).data_ptr(), (x.data_ptr() for x in st_[sname])
+                t.alpha, t.alpha_s, t.l2_coef = a, a_s, l2c
+            check(L_.drx_rows_csr_adam_multi(tabs, 3, self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam_multi')
         else:
             self._grad_arena.zero_()
             g = self._grads
@@ -314,13 +320,6 @@ class CaserEngine:
             self._adam('item_emb', g['item_emb'], alpha[1], l2c, stream)
             self._adam('W1', g['W1'], alpha[4 + self.L], l2c, stream)
             self._adam('b1', g['b1'], alpha[5 + self.L], 0.0, stream)
-        sg = AdamSegments()
-        sg.n = len(self.seg)
-        for i, (_, start, n, regd, layer) in enumerate(self.seg):
-            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[layer], (l2c if regd else 0.0)
-        m, v = self.state['sw']
-        check(L_.drx_adam_segments(self.sw.data_ptr(), m.data_ptr(), v.data_ptr(), gsw.data_ptr(), C.byref(sg), self.beta1, self.beta2, self.eps,
-                                   stream), 'drx_adam_segments')
         if want_loss:
             return float((gsw[-1] + reg_loss).item())
         return None

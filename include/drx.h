@@ -397,6 +397,17 @@ int drx_rows_csr_adam(const int32_t *row_ptr, const int32_t *order, const float 
 int drx_rows_csr_adam_outer(const int32_t *row_ptr, const int32_t *order, const float *scale, const float *src, int32_t group, int32_t ld,
                             int32_t n_rows, float *p, float *m, float *v, float *p_s, float *m_s, float *v_s, float alpha, float alpha_s,
                             float l2_coef, float beta1, float beta2, float eps, void *stream);
+/* Several tables in ONE launch (ld <= 256 each): the arguments of drx_rows_csr_adam per table; group > 0 selects the outer-product form
+ * of drx_rows_csr_adam_outer (scale required), group == 0 the plain one (scale = the optional per-lookup scalars src_s). */
+#define DRX_MAX_CSR_TABLES 4
+typedef struct DrxCsrAdamTable {
+  const int32_t *row_ptr, *order;
+  const float *src, *scale;
+  int32_t group, ld, n_rows;
+  float *p, *m, *v, *p_s, *m_s, *v_s;
+  float alpha, alpha_s, l2_coef;
+} DrxCsrAdamTable;
+int drx_rows_csr_adam_multi(const DrxCsrAdamTable *tables, int32_t n_tables, float beta1, float beta2, float eps, void *stream);
 /* host: first[c] = first position of code c in codes[0..n), -1 when absent; returns the number of distinct codes (Dataset.unique on
  * dense integer code columns, mem_dataset.py's drop_duplicates, without a sort) */
 int64_t drx_first_occurrence(const int64_t *codes, int64_t n, int64_t n_codes, int64_t *first);
@@ -459,6 +470,11 @@ int drx_caser_grid(const DrxCaserDims *D, int32_t B);
 /* forward + Keras BCE + backward (caser.py:86-120 under the tape of recommender_abc.py:191-203): fills the lookup
  * gradient rows above and gsw_out[0..n_small) = gradient of the small weights, gsw_out[n_small] = prediction loss. */
 int drx_caser_fwd_bwd(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, void *stream);
+/* The same followed by the small weights' update in the launch that sums the workgroups' partial gradients: gsw_out as above, then
+ * sw, sw_m, sw_v <- l2 + Keras Adam per segment (drx_adam_segments' arithmetic; sw must be A->sw: the step's own weights, updated in
+ * place once the training kernel has read them). */
+int drx_caser_step_small(const DrxCaserDims *D, const DrxCaserArgs *A, float *gsw_out, float *sw, float *sw_m, float *sw_v,
+                         const DrxAdamSegments *sg, float beta1, float beta2, float eps, void *stream);
 /* inference hidden state cat_out[b] = [dense_0 output | user embedding] (caser.py:97-115 with training=False) */
 int drx_caser_hidden(const DrxCaserDims *D, const DrxCaserArgs *A, void *stream);
 

@@ -332,3 +332,114 @@ def test_caser_fit_with_the_device_sampler_matches_the_oracle_fed_the_same_draws
     g = model._engine.get_params()
     for k in po:
         np.testing.assert_allclose(g[k], po[k], rtol=0, atol=3e-5, err_msg=k)
+
+
+def test_fused_launches_equal_the_separate_ones_bit_for_bit():
+    """drx_rows_csr_adam_multi == drx_rows_csr_adam / drx_rows_csr_adam_outer table by table, and drx_caser_step_small ==
+    drx_caser_fwd_bwd + drx_adam_segments: the fused entry points run the same operations in the same order."""
+    import ctypes as C
+    import torch
+    from drecpy_amd import _lib
+    from drecpy_amd._lib import check, lib, stream_ptr
+    dev = torch.device('cuda:0')
+    L_ = lib()
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    rnd = lambda *s: torch.rand(*s, generator=gen, device=dev) - 0.5
+    st = stream_ptr(dev)
+    # (table rows, ld, lookups, group); the last one's rows are named by ~150 lookups each: their sums are split over the workgroup
+    specs = [(300, 52, 900, 0), (120, 100, 840, 12), (50, 16, 64, 0), (20, 52, 3000, 0)]
+    tabs = (_lib.CsrAdamTable * 4)()
+    keep, single = [], []
+    for t, (n_rows, ld, T, group) in zip(tabs, specs):
+        keys = torch.randint(0, n_rows, (T,), generator=gen, device=dev)
+        order = torch.argsort(keys, stable=True).to(torch.int32)
+        ptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=dev)
+        ptr[1:] = torch.cumsum(torch.bincount(keys, minlength=n_rows), 0).to(torch.int32)
+        src = rnd(T // group if group else T, ld)
+        scale = rnd(T) if (group or ld == 16) else None
+        state = [rnd(n_rows, ld), rnd(n_rows, ld), rnd(n_rows, ld).abs()]
+        sstate = [rnd(n_rows), rnd(n_rows), rnd(n_rows).abs()] if scale is not None else [None] * 3
+        copies = [x.clone() for x in state] + [x.clone() if x is not None else None for x in sstate]
+        keep += [order, ptr, src, scale, state, sstate, copies]
+        ps = lambda x: x.data_ptr() if x is not None else None
+        t.row_ptr, t.order, t.src, t.scale, t.group, t.ld, t.n_rows = ptr.data_ptr(), order.data_ptr(), src.data_ptr(), ps(scale), group, ld, n_rows
+        t.p, t.m, t.v, t.p_s, t.m_s, t.v_s = [x.data_ptr() for x in state] + [ps(x) for x in sstate]
+        t.alpha, t.alpha_s, t.l2_coef = 1e-2, 2e-2, 1e-3
+        c = copies
+        if group:
+            check(L_.drx_rows_csr_adam_outer(ptr.data_ptr(), order.data_ptr(), scale.data_ptr(), src.data_ptr(), group, ld, n_rows, c[0].data_ptr(),
+                                             c[1].data_ptr(), c[2].data_ptr(), ps(c[3]), ps(c[4]), ps(c[5]), 1e-2, 2e-2, 1e-3, 0.9, 0.999, 1e-7, st), 'outer')
+        else:
+            check(L_.drx_rows_csr_adam(ptr.data_ptr(), order.data_ptr(), src.data_ptr(), ps(scale), ld, n_rows, c[0].data_ptr(), c[1].data_ptr(),
+                                       c[2].data_ptr(), ps(c[3]), ps(c[4]), ps(c[5]), 1e-2, 2e-2, 1e-3, 0.9, 0.999, 1e-7, st), 'plain')
+        single.append((state + sstate, copies))
+    pre = [x.clone() for x in keep[7 * 3 + 4]]                      # the heavy table's p, m, v before the update
+    check(L_.drx_rows_csr_adam_multi(tabs, 4, 0.9, 0.999, 1e-7, st), 'multi')
+    torch.cuda.synchronize()
+    for fused, sep in single:
+        for a, b in zip(fused, sep):
+            if a is not None:
+                assert torch.equal(a, b)
+    # the split sums against fp64: g = sum of the lookups' rows, ApplyAdam(g + l2 p)
+    order, ptr, src, state = keep[7 * 3], keep[7 * 3 + 1], keep[7 * 3 + 2], keep[7 * 3 + 4]
+    keys = torch.empty(3000, dtype=torch.long, device=dev)
+    keys[order.long()] = torch.repeat_interleave(torch.arange(20, device=dev), (ptr[1:] - ptr[:-1]).long())
+    assert int((ptr[1:] - ptr[:-1]).min()) >= 64
+    g64 = torch.zeros(20, 52, dtype=torch.float64, device=dev).index_add_(0, keys, src.double())
+    p0, m0, v0 = (x.double() for x in pre)
+    gg = g64 + 1e-3 * p0
+    m1 = m0 + (gg - m0) * (1 - 0.9)
+    v1 = v0 + (gg * gg - v0) * (1 - 0.999)
+    p1 = p0 - m1 * 1e-2 / (v1.sqrt() + 1e-7)
+    assert torch.allclose(state[0].double(), p1, rtol=0, atol=1e-5) and torch.allclose(state[1].double(), m1, rtol=0, atol=1e-5)
+    # the outer form against the rows written out
+    n_rows, ld, T, group = specs[1]
+    order, ptr, src, scale = keep[7], keep[8], keep[9], keep[10]
+    rows = (scale[:, None] * src[torch.arange(T, device=dev) // group]).contiguous()
+    a = [rnd(n_rows, ld), rnd(n_rows, ld), rnd(n_rows, ld).abs(), rnd(n_rows), rnd(n_rows), rnd(n_rows).abs()]
+    b = [x.clone() for x in a]
+    check(L_.drx_rows_csr_adam_outer(ptr.data_ptr(), order.data_ptr(), scale.data_ptr(), src.data_ptr(), group, ld, n_rows, *[x.data_ptr() for x in a],
+                                     1e-2, 2e-2, 1e-3, 0.9, 0.999, 1e-7, st), 'outer')
+    check(L_.drx_rows_csr_adam(ptr.data_ptr(), order.data_ptr(), rows.data_ptr(), scale.data_ptr(), ld, n_rows, *[x.data_ptr() for x in b],
+                               1e-2, 2e-2, 1e-3, 0.9, 0.999, 1e-7, st), 'plain')
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=0, atol=2e-6)           # (a fused multiply-add where the written rows were rounded first)
+
+    # drx_caser_step_small against drx_caser_fwd_bwd + drx_adam_segments
+    from drecpy_amd.engine_caser import CaserEngine
+    rng = np.random.default_rng(3)
+    U, N, Lw, T_, neg, d, n_v, n_h, B = 30, 90, 4, 2, 2, 20, 3, 8, 70
+    eng = CaserEngine(U, N, Lw, T_, neg, d, n_v, n_h)
+    eng.set_params(ca.init_params(rng, U, N, Lw, d, n_v, n_h, np.float64))
+    eng.lr, eng.reg = 5e-3, 1e-4
+    uids, before, after = rng.integers(0, U, size=B), rng.integers(0, N, size=(B, Lw)), rng.integers(0, N, size=(B, T_ + T_ * neg))
+    sw0 = eng.sw.clone()
+    eng.step(0, uids, before, after, None, 0.0)
+    sw_fused, m_fused, v_fused = eng.sw.clone(), eng.state['sw'][0].clone(), eng.state['sw'][1].clone()
+    # the small-weight half by hand from the same pre-step parameters: drx_caser_fwd_bwd, then drx_adam_segments
+    eng2 = CaserEngine(U, N, Lw, T_, neg, d, n_v, n_h)
+    eng2.set_params(ca.init_params(np.random.default_rng(3), U, N, Lw, d, n_v, n_h, np.float64))
+    assert torch.equal(eng2.sw, sw0)
+    eng2.lr, eng2.reg = 5e-3, 1e-4
+    i32 = lambda x: torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32)).to(dev)
+    uid_t, bef_t, aft_t = i32(uids), i32(before), i32(after)
+    grid = L_.drx_caser_grid(C.byref(eng2.D), B)
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    dE, dW1, db1, dPu = f(B * Lw, eng2.ld), f(B * eng2.Tp, eng2.ld2), f(B * eng2.Tp), f(B, eng2.ld)
+    gpart, lpart, gsw = f(grid, eng2.D.n_small), f(grid), f(eng2.D.n_small + 1)
+    A = _lib.CaserArgs()
+    A.item_emb, A.user_emb, A.W1, A.b1, A.sw = (x.data_ptr() for x in (eng2.item_emb, eng2.user_emb, eng2.W1, eng2.b1, eng2.sw))
+    A.uid, A.before, A.after, A.keep, A.rate, A.B, A.mask_seed = uid_t.data_ptr(), bef_t.data_ptr(), aft_t.data_ptr(), None, 0.0, B, 0
+    A.dE, A.dW1, A.db1, A.dPu, A.gsw_part, A.loss_part, A.cat_out = (dE.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dPu.data_ptr(),
+                                                                      gpart.data_ptr(), lpart.data_ptr(), None)
+    check(L_.drx_caser_fwd_bwd(C.byref(eng2.D), C.byref(A), gsw.data_ptr(), st), 'drx_caser_fwd_bwd')
+    alpha, l2c = eng2._alphas(0), 2.0 * eng2.reg
+    sg = _lib.AdamSegments()
+    sg.n = len(eng2.seg)
+    for i, (_, start, n, regd, layer) in enumerate(eng2.seg):
+        sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[layer], (l2c if regd else 0.0)
+    m2, v2 = eng2.state['sw']
+    check(L_.drx_adam_segments(eng2.sw.data_ptr(), m2.data_ptr(), v2.data_ptr(), gsw.data_ptr(), C.byref(sg), eng2.beta1, eng2.beta2, eng2.eps, st),
+          'drx_adam_segments')
+    torch.cuda.synchronize()
+    assert torch.equal(eng2.sw, sw_fused) and torch.equal(m2, m_fused) and torch.equal(v2, v_fused)
