@@ -19,7 +19,7 @@ for set in "GRBM_GUI_ACTIVE GRBM_COUNT" \
   tail -2 $OUT/p$i.err | cut -c1-200
 done
 cd $ROOT
-python - <<P
+python - > $OUT/summary.txt <<P
 import csv, glob, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
@@ -28,4 +28,5 @@ for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
         a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
 for k in sorted(acc): print(f'{k:32s} {acc[k][0] / acc[k][1]:14.1f}  ({acc[k][1]} dispatches)')
 P
+cat $OUT/summary.txt
 find $OUT -name '*.csv' -size +2M -delete
