@@ -195,6 +195,7 @@ struct PySetOfInts {            // a CPython set holding non-negative ints (hash
 struct ListGroup {
   int64_t begin, end;                 // rows [begin, end) in the flattened row arrays
   std::vector<int32_t> held;          // ascending distinct negative-ids among the group's rows
+  std::vector<int32_t> gap;           // held[i] - i: how many eligible ids lie below held id i (complement_at searches it)
   std::vector<int32_t> order;         // eligible ids in set order, only when that order is not simply ascending
   bool order_built = false;
 };
@@ -209,14 +210,20 @@ struct DrxListSampler {
   std::vector<ListGroup> groups;      // in unique_groups order
   int32_t last_hint = 0;
 
-  // j-th (0-based) id of the ascending complement of `held` in [0, n_ids)
-  static int32_t complement_at(const std::vector<int32_t> &held, int64_t j) {
-    // smallest v with v - #(held <= v) == j  <=>  v = j + (number of held ids <= v); iterate to the fixed point
-    size_t lo = 0, hi = held.size();
-    while (lo < hi) {                       // count of held ids h with h - rank(h) <= j, rank = its index in held
-      const size_t mid = (lo + hi) / 2;
-      if ((int64_t)held[mid] - (int64_t)mid <= j) lo = mid + 1; else hi = mid;
+  // j-th (0-based) id of the ascending complement of `held` in [0, n_ids): the smallest v with v - #(held <= v) == j, i.e.
+  // v = j + #(held ids h with h - rank(h) <= j).  `gap` = h - rank(h) per held id (non-decreasing), built with the group; the count is
+  // a branch-free binary search (nine of them per window at examples/caser.py's 9 negatives: the sampler's stream is sequential, its
+  // cost per draw is what bounds Caser.fit() on the reference-exact stream).
+  static int32_t complement_at(const std::vector<int32_t> &gap, int64_t j) {
+    const int32_t *base = gap.data();
+    size_t n = gap.size();
+    if (n == 0) return (int32_t)j;
+    while (n > 1) {
+      const size_t half = n >> 1;
+      base = ((int64_t)base[half - 1] <= j) ? base + half : base;
+      n -= half;
     }
+    const size_t lo = (size_t)(base - gap.data()) + ((int64_t)base[0] <= j ? 1 : 0);
     return (int32_t)(j + (int64_t)lo);
   }
   int64_t eligible_count(const ListGroup &g) const { return (int64_t)n_ids - (int64_t)g.held.size(); }
@@ -224,11 +231,11 @@ struct DrxListSampler {
   int32_t eligible_at(ListGroup &g, int64_t j) {
     // set_difference (setobject.c): when len(so) >> 2 > len(other) the result is a COPY of so with the held ids discarded;
     // so's table (and the copy's, sized for 2 * len) is larger than every id, each id sits in slot == id: ascending order.
-    if (((int64_t)n_ids >> 2) > (int64_t)g.held.size()) return complement_at(g.held, j);
+    if (((int64_t)n_ids >> 2) > (int64_t)g.held.size()) return complement_at(g.gap, j);
     if (!g.order_built) {                   // otherwise a NEW set receives the surviving ids one by one (ascending), growing
       PySetOfInts so;                       // as it fills: ids beyond the table size collide and the order is the table's
       const int64_t n = eligible_count(g);
-      for (int64_t t = 0; t < n; ++t) so.add(complement_at(g.held, t));
+      for (int64_t t = 0; t < n; ++t) so.add(complement_at(g.gap, t));
       g.order.reserve((size_t)n);
       for (int64_t k : so.tab)
         if (k >= 0) g.order.push_back((int32_t)k);
@@ -261,6 +268,8 @@ DrxListSampler *drx_list_sampler_create(const int64_t *grp_indptr, const int64_t
     std::sort(G.held.begin(), G.held.end());
     G.held.erase(std::unique(G.held.begin(), G.held.end()), G.held.end());
     if (!G.held.empty() && (G.held.front() < 0 || G.held.back() >= n_ids)) { delete s; return nullptr; }
+    G.gap.resize(G.held.size());
+    for (size_t i = 0; i < G.held.size(); ++i) G.gap[i] = G.held[i] - (int32_t)i;
   }
   return s;
 }
@@ -275,6 +284,7 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
   in_off[0] = tg_off[0] = ng_off[0] = 0;
   std::vector<int32_t> pool;
   std::vector<int64_t> picked;
+  int64_t setsize_k = -1, setsize = 21;
   for (int32_t d = 0; d < n; ++d) {
     int failures = 0;
     for (;;) {
@@ -316,8 +326,11 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
       tg_off[d + 1] = tg_off[d] + (t1 - t0);
       if (n_neg > 0) {                                                                     // rng.sample(eligible, n_neg)
         const int64_t n_pop = s->eligible_count(G), k = n_neg;
-        int64_t setsize = 21;
-        if (k > 5) setsize += (int64_t)std::pow(4.0, std::ceil(std::log((double)(k * 3)) / std::log(4.0)));
+        if (k != setsize_k) {                 // (random.sample's threshold, the same for every draw of a sampler: computed once)
+          setsize_k = k;
+          setsize = 21;
+          if (k > 5) setsize += (int64_t)std::pow(4.0, std::ceil(std::log((double)(k * 3)) / std::log(4.0)));
+        }
         int32_t *out = neg_ids + ng_off[d];
         if (n_pop <= setsize) {
           pool.resize((size_t)n_pop);
