@@ -25,7 +25,8 @@ def test_caser_steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, update):
 # first 16 are fetched ahead, the rest where they are used), several tiles per workgroup (B = 4200 > 256 tiles of 16)
 @pytest.mark.parametrize('d,L,n_v,n_h,T,neg,B,drop', [(32, 8, 4, 16, 2, 3, 100, True), (20, 4, 3, 24, 2, 2, 50, True),
                                                       (16, 3, 18, 8, 2, 2, 33, False), (24, 5, 4, 16, 3, 6, 41, True),
-                                                      (16, 3, 2, 8, 1, 2, 4200, True)])
+                                                      (16, 3, 2, 8, 1, 2, 4200, True),
+                                                      (5, 1, 1, 1, 1, 0, 19, False), (7, 2, 3, 5, 1, 1, 16, True)])     # (the smallest shapes)
 def test_caser_tile_geometries(d, L, n_v, n_h, T, neg, B, drop):
     _steps_match_oracle(d, L, n_v, n_h, T, neg, B, drop, 'csr', steps=2 if B > 1000 else 3)
 
