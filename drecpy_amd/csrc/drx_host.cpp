@@ -320,9 +320,11 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
           (n_neg > 0 && (!neg_ids || ng_off[d] + n_neg > ng_cap)))
         return DRX_ESCRATCH;
       group_out[d] = gi;
-      for (int64_t r = i0; r < i1; ++r) in_rows[in_off[d] + (r - i0)] = s->rows[(size_t)(G.begin + r)];
+      // (the window's rows are copied AFTER the negatives are drawn — the copy consumes no random numbers — so that the cache lines
+      //  asked for here have arrived by then: `rows` is megabytes and the groups come in random order)
+      __builtin_prefetch(&s->rows[(size_t)(G.begin + i0)]);
+      __builtin_prefetch(&s->rows[(size_t)(G.begin + (t1 > i1 ? t1 : i1) - 1)]);
       in_off[d + 1] = in_off[d] + (i1 - i0);
-      for (int64_t r = t0; r < t1; ++r) tg_rows[tg_off[d] + (r - t0)] = s->rows[(size_t)(G.begin + r)];
       tg_off[d + 1] = tg_off[d] + (t1 - t0);
       if (n_neg > 0) {                                                                     // rng.sample(eligible, n_neg)
         const int64_t n_pop = s->eligible_count(G), k = n_neg;
@@ -351,6 +353,8 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
         }
       }
       ng_off[d + 1] = ng_off[d] + n_neg;
+      for (int64_t r = i0; r < i1; ++r) in_rows[in_off[d] + (r - i0)] = s->rows[(size_t)(G.begin + r)];
+      for (int64_t r = t0; r < t1; ++r) tg_rows[tg_off[d] + (r - t0)] = s->rows[(size_t)(G.begin + r)];
       break;
     }
   }
