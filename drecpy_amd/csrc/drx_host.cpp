@@ -7,6 +7,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cmath>
@@ -202,6 +204,59 @@ struct ListGroup {
 
 }  // namespace
 
+// A few persistent helper threads for the second phase of drx_list_sampler_sample (creating threads per call cost more than they
+// saved: 0.1 - 0.2 ms on a 256-core host).  run(n_parts, fn): fn(part) for part = 0 .. n_parts - 1, part 0 on the calling thread.
+struct PartPool {
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  const std::function<void(int)> *job = nullptr;
+  uint64_t generation = 0;
+  int pending = 0;
+  bool stop = false;
+  explicit PartPool(int n_workers) {
+    for (int w = 0; w < n_workers; ++w)
+      workers.emplace_back([this, w] {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<void(int)> *j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            j = job;
+          }
+          (*j)(w + 1);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_one();
+          }
+        }
+      });
+  }
+  void run(const std::function<void(int)> &fn) {          // parts 0 .. workers.size()
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = &fn;
+      pending = (int)workers.size();
+      ++generation;
+    }
+    cv_go.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~PartPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_go.notify_all();
+    for (auto &t : workers) t.join();
+  }
+};
+
 struct DrxListSampler {
   MT rng;
   int32_t n_groups, n_ids, neg_ratio, n_targets, min_pos, max_pos;     // n_targets / max_pos < 0: None
@@ -209,6 +264,7 @@ struct DrxListSampler {
   std::vector<int32_t> ids;           // negative_ids_col value of each of those rows
   std::vector<ListGroup> groups;      // in unique_groups order
   int32_t last_hint = 0;
+  std::unique_ptr<PartPool> pool;     // made by the first large batch
 
   // j-th (0-based) id of the ascending complement of `held` in [0, n_ids): the smallest v with v - #(held <= v) == j, i.e.
   // v = j + #(held ids h with h - rank(h) <= j).  `gap` = h - rank(h) per held id (non-decreasing), built with the group; the count is
@@ -276,6 +332,12 @@ DrxListSampler *drx_list_sampler_create(const int64_t *grp_indptr, const int64_t
 
 void drx_list_sampler_destroy(DrxListSampler *s) { delete s; }
 
+// Two phases.  (1) The draws in order, on the calling thread: everything that consumes random numbers — the group, the window's start, the
+// k indices rng.sample picks in the eligible tuple (with its own rejections) — and the offsets; the picked INDICES are parked in neg_ids.
+// (2) What consumes none, per draw and independent of the other draws: the indices turned into ids (a search in the group's gap
+// array each) and the window's rows copied — on up to four threads when the batch is large.  The stream of random numbers is the
+// reference's, one MT19937 consumed in order; only the work behind it leaves the sequential path (it was two thirds of a draw's cost,
+// and the sampler's pace is what bounds Caser.fit() on the reference-exact stream).
 int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, int64_t *in_off, int64_t *in_rows, int64_t in_cap,
                             int64_t *tg_off, int64_t *tg_rows, int64_t tg_cap, int64_t *ng_off, int32_t *neg_ids, int64_t ng_cap) {
   if (!s || n < 0 || !group_out || !in_off || !in_rows || !tg_off || !ng_off) return DRX_EINVAL;
@@ -284,6 +346,8 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
   in_off[0] = tg_off[0] = ng_off[0] = 0;
   std::vector<int32_t> pool;
   std::vector<int64_t> picked;
+  struct Window { int64_t i0, t0; bool map_negatives; };
+  std::vector<Window> win((size_t)n);
   int64_t setsize_k = -1, setsize = 21;
   for (int32_t d = 0; d < n; ++d) {
     int failures = 0;
@@ -320,12 +384,9 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
           (n_neg > 0 && (!neg_ids || ng_off[d] + n_neg > ng_cap)))
         return DRX_ESCRATCH;
       group_out[d] = gi;
-      // (the window's rows are copied AFTER the negatives are drawn — the copy consumes no random numbers — so that the cache lines
-      //  asked for here have arrived by then: `rows` is megabytes and the groups come in random order)
-      __builtin_prefetch(&s->rows[(size_t)(G.begin + i0)]);
-      __builtin_prefetch(&s->rows[(size_t)(G.begin + (t1 > i1 ? t1 : i1) - 1)]);
       in_off[d + 1] = in_off[d] + (i1 - i0);
       tg_off[d + 1] = tg_off[d] + (t1 - t0);
+      win[(size_t)d] = Window{i0, t0, false};
       if (n_neg > 0) {                                                                     // rng.sample(eligible, n_neg)
         const int64_t n_pop = s->eligible_count(G), k = n_neg;
         if (k != setsize_k) {                 // (random.sample's threshold, the same for every draw of a sampler: computed once)
@@ -334,6 +395,8 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
           if (k > 5) setsize += (int64_t)std::pow(4.0, std::ceil(std::log((double)(k * 3)) / std::log(4.0)));
         }
         int32_t *out = neg_ids + ng_off[d];
+        // ids looked up in a set ORDER (dense groups: eligible_at builds and caches it) stay on this thread
+        const bool pure = ((int64_t)s->n_ids >> 2) > (int64_t)G.held.size();
         if (n_pop <= setsize) {
           pool.resize((size_t)n_pop);
           for (int64_t j = 0; j < n_pop; ++j) pool[(size_t)j] = s->eligible_at(G, j);
@@ -348,15 +411,37 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
             int64_t j = (int64_t)s->rng.randbelow((uint64_t)n_pop);
             while (std::find(picked.begin(), picked.end(), j) != picked.end()) j = (int64_t)s->rng.randbelow((uint64_t)n_pop);
             picked.push_back(j);
-            out[i] = s->eligible_at(G, j);
+            out[i] = pure ? (int32_t)j : s->eligible_at(G, j);
           }
+          win[(size_t)d].map_negatives = pure;
         }
       }
       ng_off[d + 1] = ng_off[d] + n_neg;
-      for (int64_t r = i0; r < i1; ++r) in_rows[in_off[d] + (r - i0)] = s->rows[(size_t)(G.begin + r)];
-      for (int64_t r = t0; r < t1; ++r) tg_rows[tg_off[d] + (r - t0)] = s->rows[(size_t)(G.begin + r)];
       break;
     }
+  }
+  auto finish = [&](int32_t d0, int32_t d1) {
+    for (int32_t d = d0; d < d1; ++d) {
+      const ListGroup &G = s->groups[(size_t)group_out[d]];
+      const Window &w = win[(size_t)d];
+      if (w.map_negatives) {
+        int32_t *out = neg_ids + ng_off[d];
+        for (int64_t i = 0, k = ng_off[d + 1] - ng_off[d]; i < k; ++i) out[i] = DrxListSampler::complement_at(G.gap, out[i]);
+      }
+      const int64_t *src = s->rows.data() + G.begin;
+      for (int64_t r = 0, m = in_off[d + 1] - in_off[d]; r < m; ++r) in_rows[in_off[d] + r] = src[w.i0 + r];
+      for (int64_t r = 0, m = tg_off[d + 1] - tg_off[d]; r < m; ++r) tg_rows[tg_off[d] + r] = src[w.t0 + r];
+    }
+  };
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int n_parts = n >= 2048 ? (int)std::min<unsigned>(4u, hw > 1 ? hw : 1u) : 1;
+  if (n_parts <= 1) {
+    finish(0, n);
+  } else {
+    if (!s->pool) s->pool.reset(new PartPool(n_parts - 1));
+    const int np = (int)s->pool->workers.size() + 1;
+    const std::function<void(int)> part = [&](int p) { finish((int32_t)((int64_t)n * p / np), (int32_t)((int64_t)n * (p + 1) / np)); };
+    s->pool->run(part);
   }
   return DRX_OK;
 }

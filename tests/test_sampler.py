@@ -266,6 +266,34 @@ def test_native_list_sampler_equals_the_python_loop(cfg):
                 assert all(k == kb and va == vb for (k, va), (kb, vb) in zip(sorted(xa[0][0].items()), sorted(xb[0][0].items())))
 
 
+def test_native_list_sampler_large_batches_equal_small_ones():
+    """A batch of >= 2048 windows finishes its second phase (indices -> ids, row copies) on helper threads; the stream is sequential, so
+    one call for 3000 windows must equal six calls for 500 each (which stay on the calling thread) bit for bit — heavy users (ids
+    looked up in a set order) included."""
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Sampler import ListSampler
+    rng = np.random.default_rng(11)
+    U, N = 80, 120
+    rows = []
+    for u in range(U):
+        deg = int(rng.integers(9, 25)) if u % 9 else int(rng.integers(40, 100))
+        for i in rng.choice(N, size=deg, replace=False):
+            rows.append((u, int(i), 1, int(rng.integers(0, 10 ** 6))))
+    cols = list(zip(*rows))
+    ds = InteractionDataset.read_df({'user': np.array(cols[0]), 'item': np.array(cols[1]), 'interaction': np.array(cols[2]),
+                                     'timestamp': np.array(cols[3])}, verbose=False)
+    ds.assign_internal_ids()
+    cfg = dict(n_targets=3, min_positive_records=5, max_positive_records=5, neg_ratio=3, sort_column='timestamp', negative_ids_col='iid')
+    a, b = ListSampler(ds, ['uid'], seed=5, **cfg), ListSampler(ds, ['uid'], seed=5, **cfg)
+    assert a._native is not None
+    for _ in range(2):                                   # (the second round reuses the helper threads)
+        big = a.sample_group_arrays(3000)
+        parts = [b.sample_group_arrays(500) for _ in range(6)]
+        assert np.array_equal(big[0], np.concatenate([p[0] for p in parts]))                     # groups
+        for k in (2, 4, 6):                                                                      # input rows, target rows, negative ids
+            assert np.array_equal(big[k], np.concatenate([p[k] for p in parts])), k
+
+
 def test_native_list_sampler_gives_up_like_the_python_loop():
     from drecpy_amd.Dataset import InteractionDataset
     from drecpy_amd.Sampler import ListSampler
