@@ -3,6 +3,7 @@
 // and the N-long Python list comprehensions of DRecPy/Recommender/cdae.py:61-63 while producing bit-identical
 // streams (checked against stdlib `random.Random` and the golden vectors generated from the reference).
 #include <sched.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -265,6 +266,7 @@ struct DrxListSampler {
   std::vector<ListGroup> groups;      // in unique_groups order
   int32_t last_hint = 0;
   std::unique_ptr<PartPool> pool;     // made by the first large batch
+  long pool_pid = 0;                  // the process that made it: a forked child has the object without the threads
 
   // j-th (0-based) id of the ascending complement of `held` in [0, n_ids): the smallest v with v - #(held <= v) == j, i.e.
   // v = j + #(held ids h with h - rank(h) <= j).  `gap` = h - rank(h) per held id (non-decreasing), built with the group; the count is
@@ -438,7 +440,8 @@ int drx_list_sampler_sample(DrxListSampler *s, int32_t n, int32_t *group_out, in
   if (n_parts <= 1) {
     finish(0, n);
   } else {
-    if (!s->pool) s->pool.reset(new PartPool(n_parts - 1));
+    if (s->pool && s->pool_pid != (long)getpid()) (void)s->pool.release();     // (inherited through fork(): its threads do not exist here; not joined)
+    if (!s->pool) { s->pool.reset(new PartPool(n_parts - 1)); s->pool_pid = (long)getpid(); }
     const int np = (int)s->pool->workers.size() + 1;
     const std::function<void(int)> part = [&](int p) { finish((int32_t)((int64_t)n * p / np), (int32_t)((int64_t)n * (p + 1) / np)); };
     s->pool->run(part);

@@ -1,6 +1,7 @@
 """Host-side sampler / RNG of libdrx.so against stdlib random (CPython's MT19937) and the golden streams recorded
 from the reference (tests/golden/point_sampler.json).  No GPU needed: these entry points are host code."""
 import ctypes as C
+import os
 import random
 
 import numpy as np
@@ -292,6 +293,37 @@ def test_native_list_sampler_large_batches_equal_small_ones():
         assert np.array_equal(big[0], np.concatenate([p[0] for p in parts]))                     # groups
         for k in (2, 4, 6):                                                                      # input rows, target rows, negative ids
             assert np.array_equal(big[k], np.concatenate([p[k] for p in parts])), k
+
+
+def test_native_list_sampler_large_batch_in_a_forked_child():
+    """The helper threads of a large batch belong to the process that made them: a forked child draws its own large batch with new
+    ones instead of waiting for threads that do not exist there (a child process of its own, with a timeout)."""
+    import subprocess
+    import sys
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from drecpy_amd.Dataset import InteractionDataset
+from drecpy_amd.Sampler import ListSampler
+rng = np.random.default_rng(1)
+rows = [(u, int(i), 1, int(rng.integers(0, 10 ** 6))) for u in range(80) for i in rng.choice(120, size=20, replace=False)]
+c = list(zip(*rows))
+ds = InteractionDataset.read_df({'user': np.array(c[0]), 'item': np.array(c[1]), 'interaction': np.array(c[2]), 'timestamp': np.array(c[3])},
+                                verbose=False)
+ds.assign_internal_ids()
+s = ListSampler(ds, ['uid'], seed=5, n_targets=3, min_positive_records=5, max_positive_records=5, neg_ratio=3, sort_column='timestamp',
+                negative_ids_col='iid')
+s.sample_group_arrays(3000)
+pid = os.fork()
+if pid == 0:
+    out = s.sample_group_arrays(3000)
+    os._exit(0 if len(out[0]) == 3000 else 1)
+_, st = os.waitpid(pid, 0)
+sys.exit(os.WEXITSTATUS(st))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
 
 
 def test_native_list_sampler_gives_up_like_the_python_loop():
