@@ -89,6 +89,8 @@ def parse(argv=None):
                          '1/N of it (parts); auto = turns from 4 GPUs on (at 2 it saves nothing), else local')
     ap.add_argument('--no-self-bypass', action='store_true', help='row layout: send the rank\'s OWN rows through the collectives too (at world 1: the '
                     'whole exchange goes through the communicator — every row "remote", the link replaced by a device copy)')
+    ap.add_argument('--chunks', type=int, default=4, help='row layout: exchange chunks per owner (a power of two; every exchange is that many all-to-alls, '
+                    'pipelined with the owner apply and the next step\'s gather: drecpy_amd/dist.py); 1 = one all-to-all per exchange (r05)')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     ap.add_argument('--launch-dry-run', action='store_true', help='print the per-rank child command lines of an N-GPU run and exit (no GPU call)')
     ap.add_argument('--launch-selftest', action='store_true', help='children only rendezvous over gloo and all-reduce on the CPU (tests the launcher)')
@@ -292,17 +294,21 @@ def selftest_child():
 # measurement helpers
 # ------------------------------------------------------------------------------------------------------------------------------
 def hbm_copy_gbs(dev, gib=2, reps=8):
-    """Achievable HBM rate on this box: a device-to-device copy of `gib` GiB (read + write counted), GB/s."""
+    """Achievable HBM rate on this box: the library's own float4 copy kernel (drx_copy_f4) over `gib` GiB, read + write counted, GB/s
+    (the guide measured 6.29 TB/s for such a kernel).  r06: through r05 this timed torch's `copy_` (4.96 TB/s)."""
+    from drecpy_amd._lib import check, lib, ptr, stream_ptr
     n = gib * (1 << 30) // 4
     src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
-    dst.copy_(src)
+    run = lambda: check(lib().drx_copy_f4(ptr(dst), ptr(src), n * 4, stream_ptr(dev)), 'drx_copy_f4')
+    run()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     for _ in range(reps):
-        dst.copy_(src)
+        run()
     ev[1].record()
     torch.cuda.synchronize()
+    assert torch.equal(dst[:4096], src[:4096]) and torch.equal(dst[-4096:], src[-4096:])
     return 2.0 * n * 4 * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
 
 
@@ -427,15 +433,21 @@ def byte_model(st, k, S, fused_solo, fused_solo_w=False, n_users=None, n_items=N
             'cache_resident': not big_items and not big_users}
 
 
+# the translation units and headers the sampled step's kernels (sampler, preparation, sort, forward / backward, reduction, spans) are
+# built from: a PMC profile of those kernels is quoted for exactly this code.  (r06: through r05 the hash ran over every file of csrc/
+# and include/drx.h, so an edit to the DMF or Caser kernels, or a new declaration, silenced the headline's traffic figures.)
+SAMPLED_STEP_SOURCES = ('drx_cdae.hip', 'drx_sort.hip', 'drx_sampler.hip', 'drx_common.hpp', 'drx_rows.hpp', 'drx_segreduce.hpp',
+                        'drx_scan.hpp', 'drx_prep.hpp', 'drx_segstream.hpp')
+
+
 def kernel_source_hash():
-    """sha256 over the sources libdrx.so is built from: a PMC profile is only quoted for the code it was taken on."""
+    """sha256 over the sources the sampled step's kernels are built from: a PMC profile is only quoted for the code it was taken on."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, 'drecpy_amd', 'csrc')
-    for name in sorted(os.listdir(src)) + ['../../include/drx.h']:
-        if name.endswith(('.hip', '.hpp', '.cpp', '.h')):
-            with open(os.path.join(src, name), 'rb') as f:
-                h.update(name.encode() + b'\0' + f.read())
+    for name in sorted(SAMPLED_STEP_SOURCES):
+        with open(os.path.join(src, name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
     return h.hexdigest()[:16]
 
 
@@ -687,7 +699,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     else:
         from drecpy_amd.dist import ShardedCdae
         stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
-                              cpu_staging=debug_gloo, force_collectives=rccl1, self_bypass=not args.no_self_bypass)
+                              cpu_staging=debug_gloo, force_collectives=rccl1, self_bypass=not args.no_self_bypass, chunks=args.chunks)
         eng = stepper.engine
 
     micro = max(1, args.micro)       # > 1: micro-batches whose exchanges overlap each other's compute (measured at world 1: the split costs more than it hides)
@@ -824,14 +836,16 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     FWD = 'k_items_fwd_bwd' if shared_run else 'k_sampled_fwd_bwd'
     # lists of SHORT segments over rows of exactly 64 / 128 / 256 floats, Adagrad: the streamed reduction (csrc/drx_segstream.hpp)
     long_run = int(batches[0][3][-1].item()) + 2 * B > 8 * (2 * N + (hi - lo))              # csrc/drx_prep.hpp long_segments()
-    RED = 'k_seg_reduce_stream' if (stepper is None and args.optimizer == 'adagrad' and K in (64, 128, 256) and not long_run) else 'k_seg_reduce_planned'
+    # (the row layout's local reduction is the same kernel under LocalPolicyT: csrc/drx_shard.hip launches the streamed form on the same
+    # condition; the sharded stepper is always Adagrad here)
+    RED = 'k_seg_reduce_stream' if ((stepper is not None or args.optimizer == 'adagrad') and K in (64, 128, 256) and not long_run) else 'k_seg_reduce_planned'
     if stepper is None:
         names = [FWD, 'touch_sort(overlapped on side stream)' if overlap else 'touch_sort', RED + '(+bias partials)',
                  'k_span_planned(short | long spans | bias update)', '(unused)']
         dom, dom_ms, dom_alg = (RED, ph[2], alg_upd) if ph[2] >= ph[0] else (FWD, ph[0], alg_fwd)
     else:
-        names = (['row_gather+row_exchange', 'k_shard_fwd_bwd', 'k_seg_reduce_planned<LocalPolicy>(+bias partials)',
-                  'k_span_planned(+bias row)', 'grad_exchange+k_shard_apply(+bias update)'] if micro == 1 else
+        names = (['wait for the rows (fetched behind the previous step\'s apply)', 'k_shard_fwd_bwd', RED + '<LocalPolicy>(+bias partials)',
+                  'k_span_planned(+bias row)', 'grad_exchange+k_shard_apply(+bias update)+next step\'s row_gather+row_exchange, chunk by chunk'] if micro == 1 else
                  ['row_gather+first_row_exchange', 'fwd_bwd+local_reduce of all micro-batches', '-', '-', 'grad_exchange+k_shard_apply'])
         # forward reads one row per occurrence, the local reduce one gradient row per occurrence
         dom, dom_ms, dom_alg = 'k_shard_fwd_bwd+k_seg_reduce<LocalPolicy>', ph[1] + ph[2], 2.0 * B * 4.0 * K * rows_per_sample
@@ -893,6 +907,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                    'batches': 'fresh device-sampled batch every step (sampler running ahead on the side stream)' if (fresh or (pipe is not None and fresh_sharded))
                    else f'{args.n_batches} pre-sampled batches cycled',
                    'micro_batches': (micro if stepper is not None else None),
+                   'exchange_chunks': (stepper.chunks if stepper is not None else None),
                    'sharding': ('single GPU' if stepper is None else
                                 'row-sharded code path at world 1, ' + ('every row sent through the communicator (--no-self-bypass: all rows "remote", the link '
                                                                         'replaced by a device copy)' if args.no_self_bypass else
@@ -917,10 +932,10 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         dist_item = st_['dist_W'] + st_['dist_O']
         nb = {'k_shard_fwd_bwd': row_ * (dist_item + st_['dist_V'] + B + (B - st_['solo_O']) + st_['solo_O'] + st_['solo_V'] * (1 + 2 * S_opt))
                                  + 4.0 * st_['history_items'] + 40.0 * B,
-              'k_seg_reduce_planned': row_ * (st_['dist_W'] + (st_['dist_O'] - st_['solo_O']) + (st_['dist_V'] - st_['solo_V']) * (2 + 2 * S_opt))
+              RED: row_ * (st_['dist_W'] + (st_['dist_O'] - st_['solo_O']) + (st_['dist_V'] - st_['solo_V']) * (2 + 2 * S_opt))
                                       + 8.0 * (st_['occ_W'] + (B - st_['solo_O']) + (B - st_['solo_V'])),
               'k_shard_apply': row_ * dist_item * (3 + 2 * S_opt)}
-        tm = {'k_shard_fwd_bwd': float(ph[1]), 'k_seg_reduce_planned': float(ph[2]), 'k_shard_apply': float(ph[4])}
+        tm = {'k_shard_fwd_bwd': float(ph[1]), RED: float(ph[2]), 'k_shard_apply': float(ph[4])}
         per_kernel = {k_: {'bytes_per_launch': nb[k_], 'avg_launch_ms': tm[k_], 'achieved': nb[k_] / (tm[k_] * 1e-3) / 1e9,
                            'frac': nb[k_] / (tm[k_] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k_ in nb}
         domk = max(tm, key=lambda k_: tm[k_])

@@ -29,12 +29,20 @@ class Caser(RecommenderABC):
         supported = ('relu', 'tanh', 'sigmoid', 'linear', None)
         if act_h not in supported or act_mlp not in supported:
             raise Exception(f'drecpy_amd.Caser supports the activations {supported[:4]} (given: act_h={act_h!r}, act_mlp={act_mlp!r}).')
-        if not (1 <= L <= 64 and 1 <= d <= 1024):
-            raise Exception(f'drecpy_amd.Caser supports 1 <= L <= 64 and 1 <= d <= 1024 (given: L={L}, d={d}).')
-        # the fused kernels (drx_caser_tile.hpp: tiles of 16 samples on the matrix cores; drx_caser.hip: inference) take L <= 8 and d <= 64 — BASELINE
-        # configuration 5 and examples/caser.py (L = 5, d = 50); beyond that the reference's semantics are kept by the generic engine
-        # (engine_caser_wide.py: torch.autograd in tf.GradientTape's place, the library's Keras-Adam kernel per registered layer)
-        self._fused = L <= 8 and d <= 64
+        # The HIP kernels (drx_caser_tile.hpp: tiles of 16 samples on the matrix cores, the tile's item rows and the convolution weights in
+        # LDS; drx_caser.hip: inference) take 1 <= L <= 8 and 1 <= d <= 64 — BASELINE configuration 5 and examples/caser.py (L = 5, d = 50).
+        # Anything else is REJECTED here, as DMF rejects towers it has no kernel for: there is no second backend (through r05 a
+        # torch.autograd engine took those shapes; it is now tests/caser_torch_checker.py, a checker).
+        if not (1 <= L <= 8 and 1 <= d <= 64):
+            raise Exception(f'drecpy_amd.Caser supports 1 <= L <= 8 and 1 <= d <= 64 (given: L={L}, d={d}).')
+        # caser.py:108: tf.squeeze(tf.nn.max_pool1d(conv, n_h, n_h, 'SAME'), 1) is a max over ALL positions only while the longest
+        # convolution output (L positions) fits one pooling window; with L > n_h the pooled axis has ceil(L / n_h) > 1 entries and the
+        # reference's squeeze raises — a model the reference cannot produce is not trained here either
+        if L > n_h:
+            raise Exception(f'drecpy_amd.Caser needs L <= n_h (given: L={L}, n_h={n_h}): the reference pools windows of n_h positions and '
+                            f'squeezes the pooled axis (caser.py:108), which fails for L > n_h.')
+        if n_v < 1 or n_h < 1 or T < 1:
+            raise Exception(f'drecpy_amd.Caser needs n_v, n_h, T >= 1 (given: n_v={n_v}, n_h={n_h}, T={T}).')
         self.act_h, self.act_mlp = act_h, act_mlp
         self.L, self.T, self.d, self.n_v, self.n_h = L, T, d, n_v, n_h
         self.dropout_rate = dropout_rate
@@ -43,19 +51,10 @@ class Caser(RecommenderABC):
 
     def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):          # caser.py:45-75
         from ..engine_caser import CaserEngine
-        from ..engine_caser_wide import CaserWideEngine
         self.neg_ratio = neg_ratio
-        args = (self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v, self.n_h)
-        if self._fused:
-            from .._lib import DrxError
-            try:
-                self._engine = CaserEngine(*args, device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
-            except DrxError as e:
-                if 'LDS tiles' not in str(e):
-                    raise
-                self._fused = False               # (very many filters: the kernels' tiles do not fit the LDS — the generic engine takes it)
-        if not self._fused:
-            self._engine = CaserWideEngine(*args, device=self.device, act_h=self.act_h, act_mlp=self.act_mlp)
+        # (raises DrxError when the configuration's tiles do not fit the LDS — very many filters; no other backend takes it)
+        self._engine = CaserEngine(self.n_users, self.n_items, self.L, self.T, neg_ratio, self.d, self.n_v, self.n_h, device=self.device,
+                                   act_h=self.act_h, act_mlp=self.act_mlp)
         self._engine.lr, self._engine.reg = float(learning_rate), float(reg_rate)
         weights = kwds.get('initial_weights')
         if weights is None:

@@ -46,7 +46,7 @@ class ListGroups(C.Structure):
 
 class Shard(C.Structure):
     _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('n_items', C.c_int32), ('items_per_rank', C.c_int32),
-                ('n_users_local', C.c_int32), ('flags', C.c_uint32)]
+                ('n_users_local', C.c_int32), ('flags', C.c_uint32), ('chunks', C.c_int32)]
 
 
 MAX_SEGMENTS = 24                       # include/drx.h DRX_MAX_SEGMENTS
@@ -156,7 +156,9 @@ SIGNATURES = {
     'drx_shard_prepare': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch), C.c_void_p,
                                     C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_shard_owner_table_bytes': (C.c_size_t, [C.POINTER(Shard), C.c_int32]),
-    'drx_shard_owner_index': (C.c_int, [C.POINTER(Shard), C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
+    'drx_shard_chunks': (C.c_int32, [C.POINTER(Shard)]),
+    'drx_shard_unit_shift': (C.c_int32, [C.POINTER(Shard)]),
+    'drx_shard_owner_index': (C.c_int, [C.POINTER(Shard), C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_size_t, C.c_void_p]),
     'drx_shard_gather_rows': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                         C.c_int32, C.c_void_p, C.c_void_p]),
@@ -165,8 +167,9 @@ SIGNATURES = {
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_void_p), C.c_void_p]),
     'drx_shard_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_void_p, C.c_void_p,
-                                  C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                  C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                   C.c_void_p, C.c_void_p]),
+    'drx_copy_f4': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_adam_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_void_p]),
     'drx_scatter_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

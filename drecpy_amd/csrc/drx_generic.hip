@@ -359,7 +359,28 @@ __global__ void k_sumsq_final(const double *__restrict__ part, int n_part, doubl
   }
 }
 
+// Streaming copy, 16 bytes per lane and four loads in flight per thread: what the library uses to snapshot tables and what bench.py
+// times as "the HBM rate a plain kernel of this library reaches on this box" (report the achievable next to the nominal 8 TB/s).
+__global__ __launch_bounds__(kBlock) void k_copy_f4(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 extern "C" {
+
+int drx_copy_f4(void *dst, const void *src, size_t n_bytes, void *stream) {
+  if (!dst || !src || n_bytes < 16 || (n_bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return DRX_EINVAL;
+  const size_t n4 = n_bytes / 16;
+  const int blocks = (int)std::min<size_t>((n4 + 4 * kBlock - 1) / (4 * kBlock), 256 * 16);      // 16 workgroups per CU
+  hipLaunchKernelGGL(k_copy_f4, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n4);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
 
 int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, float alpha, float l2_coef, float beta1, float beta2,
                    float eps, void *stream) {

@@ -332,7 +332,12 @@ DrxListSampler *drx_list_sampler_create(const int64_t *grp_indptr, const int64_t
   return s;
 }
 
-void drx_list_sampler_destroy(DrxListSampler *s) { delete s; }
+void drx_list_sampler_destroy(DrxListSampler *s) {
+  if (!s) return;
+  // a forked child holds the parent's pool object without its threads: joining them would never return
+  if (s->pool && s->pool_pid != (long)getpid()) (void)s->pool.release();
+  delete s;
+}
 
 // Two phases.  (1) The draws in order, on the calling thread: everything that consumes random numbers — the group, the window's start, the
 // k indices rng.sample picks in the eligible tuple (with its own rejections) — and the offsets; the picked INDICES are parked in neg_ids.

@@ -17,16 +17,30 @@ namespace drx {
 // Also clears the sole-toucher marks of the batch (solo: [2B] bytes, or nullptr) and pads the slots beyond
 // the last sample's up to T with DRX_KEY_NONE (n_touch_slots may be an upper bound) — memsets the preparation would otherwise launch.
 // `present` (row-sharded step, or nullptr): one byte per WIRE key of an item row — owner-major, owner o = item / ipr at
-// (o << shift) + (W2T row ? ipr : 0) + item - o * ipr — set to 1 for every item row this batch touches (plain byte stores: every
+// WireGeo::wire(item, W2T row?) below — set to 1 for every item row this batch touches (plain byte stores: every
 // writer writes 1); drx_shard.hip turns the map into the batch's distinct rows, their positions in the exchange buffers and the
 // per-owner counts without waiting for the sort.
+// WIRE key of an item row (include/drx.h "row-sharded multi-GPU step"): owner o = item / ipr, local key l = 2 * (item - o * ipr) + (W2T
+// row ? 1 : 0), exchange chunk c = l >> cshift, UNIT v = c * world + o; key = (v << cshift) | (l & ((1 << cshift) - 1)) — unit-major, so a
+// rank's distinct keys are contiguous per (chunk, owner) and chunk c of the exchange is one contiguous run of `world` units.
+struct WireGeo {
+  int ipr, cshift, world;
+  __host__ __device__ __forceinline__ uint32_t wire(int item, int is_out) const {
+    const int o = item / ipr;
+    const uint32_t l = 2u * (uint32_t)(item - o * ipr) + (uint32_t)(is_out ? 1 : 0);
+    return (((l >> cshift) * (uint32_t)world + (uint32_t)o) << cshift) | (l & ((1u << cshift) - 1u));
+  }
+  // the owner's local key of a wire key (chunk bits back in front of the in-chunk bits): bit 0 = W2T row, the rest = local item
+  __host__ __device__ __forceinline__ uint32_t local(uint32_t w) const {
+    return (((w >> cshift) / (uint32_t)world) << cshift) | (w & ((1u << cshift) - 1u));
+  }
+  __host__ __device__ __forceinline__ uint32_t unit(uint32_t w) const { return w >> cshift; }
+};
+
 struct TouchPresence {
   uint8_t *present;
-  int ipr, shift;
-  __device__ __forceinline__ uint32_t wire(int item, int is_out) const {
-    const int o = item / ipr;
-    return ((uint32_t)o << shift) + (uint32_t)(is_out ? ipr : 0) + (uint32_t)(item - o * ipr);
-  }
+  WireGeo G;
+  __device__ __forceinline__ uint32_t wire(int item, int is_out) const { return G.wire(item, is_out); }
 };
 
 static __global__ __launch_bounds__(kBlock) void k_sparse_touches(int n_items, DrxHistory H, DrxBatch bt, uint32_t qthr, uint32_t *keys,
@@ -639,7 +653,7 @@ static int prepare_transposed(const DrxCdaeParams *p, const DrxHistory *hist, co
 }
 
 static int prepare_impl(const DrxCdaeParams *p, const DrxHistory *hist, const DrxBatch *bt, const PrepBufs &R, hipStream_t st,
-                        bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, 1, 0}) {
+                        bool with_marks = false, TouchPresence pres = TouchPresence{nullptr, WireGeo{1, 0, 1}}) {
   const int gpb = kBlock / 16;
   if (hist->t_rank && hist->t_users && hist->t_pos && hist->t_items && !pres.present && long_segments(R.T, *p)) {
     const int32_t *row_end = nullptr;

@@ -11,14 +11,18 @@
 // Two key spaces:
 //   * the touch list is sorted in the single-GPU step's keys ([0,N) W rows, [N,2N) W2T rows of GLOBAL item ids, 2N + local user):
 //     preparation, plan, marks and reduction are the shared code;
-//   * rows travel under WIRE keys, owner-major: item n of owner o = n / ipr is (o << shift) + (W2T ? ipr : 0) + n - o * ipr, with
-//     1 << shift >= 2 * ipr a multiple of the 8192-key tile — an owner's keys are whole tiles of the presence map.
+//   * rows travel under WIRE keys (WireGeo, drx_prep.hpp), UNIT-major: an owner's local keys l = 2 * local item + (W2T ? 1 : 0) are
+//     cut into `chunks` (a power of two) equal key ranges of 1 << cshift keys — whole 8192-key tiles of the presence map — and unit
+//     v = chunk * world + owner holds the keys of one (chunk, owner) pair.  r06: the chunks are what the exchanges are pipelined over —
+//     chunk c of an exchange is ONE all-to-all over the contiguous units c * world .. c * world + world - 1, the owner applies chunk
+//     c's gradient rows while chunk c + 1 travels and gathers chunk c's rows for the NEXT step right behind (dist.py).  chunks == 1
+//     is the r04 / r05 format (one all-to-all per direction).
 //
-// Exchange buffers (both directions, one float buffer per direction = ONE collective): destination o's chunk is n_o rows of ld floats
-// followed by n_o scalars padded to 32 floats (rows stay 128-byte aligned for ld % 32 == 0).  n_o = the distinct rows asked of o + 1:
-// the chunk's last row is a SENTINEL (key DRX_KEY_NONE) — unused on the way out, and on the way back it carries this rank's gradient
-// of the replicated hidden bias (its scalar: the rank's loss sum), so that every rank sums the same `world` rows in rank order: no
-// all-reduce, no extra collective.  The scalar of a W2T row is b2 on the way out and its gradient on the way back.
+// Exchange buffers (both directions): unit v's piece is n_v rows of ld floats followed by n_v scalars padded to 32 floats (rows stay
+// 128-byte aligned for ld % 32 == 0).  n_v = the distinct rows asked of owner v % world in chunk v / world + 1: the piece's last row
+// is a SENTINEL (key DRX_KEY_NONE) — unused on the way out; on the way back the sentinels carry this rank's gradient of the replicated
+// hidden bias (scalar: the rank's loss sum), and the owner sums those of the LAST chunk's segments in rank order — every rank the same
+// `world` rows: no all-reduce, no extra collective.  The scalar of a W2T row is b2 on the way out and its gradient on the way back.
 #include "drx_common.hpp"
 #include "drx_rows.hpp"
 #include "drx_segreduce.hpp"
@@ -33,12 +37,18 @@ constexpr int kTileWords = kTileKeys / 32;
 
 struct ShardGeo {
   int world, rank, ipr, shift, ld, bypass;      // bypass: this rank's OWN rows never pass through a collective (DRX_SHARD_SELF_BYPASS)
-  uint32_t n_words, n_tiles, tiles_per_owner;
-  __host__ __device__ uint32_t wire(int item, int is_out) const {
-    const int o = item / ipr;
-    return ((uint32_t)o << shift) + (uint32_t)(is_out ? ipr : 0) + (uint32_t)(item - o * ipr);
-  }
+  int chunks, cshift, units;                    // exchange chunks per owner, log2 of a unit's key span, world * chunks
+  uint32_t n_words, n_tiles, tiles_per_unit;
+  __host__ __device__ WireGeo wg() const { return WireGeo{ipr, cshift, world}; }
+  __host__ __device__ bool own_unit(int v) const { return bypass && v % world == rank; }
 };
+
+// chunks of a shard description: a power of two, at most what leaves every unit whole 8192-key tiles (smaller shards: fewer chunks)
+static int chunks_of(const DrxShard &sh, int shift) {
+  int c = sh.chunks < 1 ? 1 : sh.chunks;
+  while (c > 1 && (shift - __builtin_ctz((unsigned)c)) < 13) c >>= 1;
+  return c;
+}
 
 static ShardGeo geo_of(const DrxShard &sh, int ld) {
   ShardGeo g{};
@@ -46,8 +56,11 @@ static ShardGeo geo_of(const DrxShard &sh, int ld) {
   g.bypass = (sh.flags & DRX_SHARD_SELF_BYPASS) ? 1 : 0;
   g.shift = 13;
   while ((1ll << g.shift) < 2ll * sh.items_per_rank) ++g.shift;
-  g.tiles_per_owner = (uint32_t)((1ull << g.shift) / kTileKeys);
-  g.n_tiles = g.tiles_per_owner * (uint32_t)sh.world;
+  g.chunks = chunks_of(sh, g.shift);
+  g.cshift = g.shift - __builtin_ctz((unsigned)g.chunks);
+  g.units = g.world * g.chunks;
+  g.tiles_per_unit = (uint32_t)((1ull << g.cshift) / kTileKeys);
+  g.n_tiles = g.tiles_per_unit * (uint32_t)g.units;
   g.n_words = g.n_tiles * kTileWords;
   return g;
 }
@@ -57,10 +70,10 @@ __host__ __device__ inline uint32_t pad32(uint32_t n) { return (n + 31u) & ~31u;
 // Where the rows of a prepared batch sit in its exchange buffers.
 struct ShardXfer {
   const uint2 *ptab;          // [n_words]: x = the word's 32 presence bits, y = position of its first present key
-  const uint32_t *first;      // [world + 1]: position of owner o's first row (sentinels included); first[world] = all rows
-  const uint32_t *foff;       // [world + 1]: float offset of owner o's chunk in this rank's exchange buffers — the chunks in rank order;
-                              //   with the self-bypass the rank's own chunk comes LAST (it does not travel); foff[world] = all floats
-  int shift, ld;
+  const uint32_t *first;      // [units + 1]: position of unit v's first row (sentinels included); first[units] = all rows
+  const uint32_t *foff;       // [units + 1]: float offset of unit v's piece in this rank's exchange buffers — the pieces in unit order;
+                              //   with the self-bypass the rank's own units come LAST (they do not travel); foff[units] = all floats
+  int shift, ld;              // shift: log2 of a UNIT's key span (ShardGeo::cshift)
   __device__ __forceinline__ uint32_t pos_of(uint32_t w) const {
     const uint2 e = ptab[w >> 5];
     return e.y + (uint32_t)__popc(e.x & ((1u << (w & 31u)) - 1u));
@@ -73,8 +86,8 @@ struct ShardXfer {
     const uint32_t o = w >> shift;
     return (size_t)foff[o] + (size_t)(first[o + 1] - first[o]) * ld + (pos - first[o]);
   }
-  __device__ __forceinline__ size_t sentinel_row(int o) const { return (size_t)foff[o] + (size_t)(first[o + 1] - 1 - first[o]) * ld; }
-  __device__ __forceinline__ size_t sentinel_scal(int o) const { return (size_t)foff[o] + (size_t)(first[o + 1] - first[o]) * (ld + 1) - 1; }
+  __device__ __forceinline__ size_t sentinel_row(int v) const { return (size_t)foff[v] + (size_t)(first[v + 1] - 1 - first[v]) * ld; }
+  __device__ __forceinline__ size_t sentinel_scal(int v) const { return (size_t)foff[v] + (size_t)(first[v + 1] - first[v]) * (ld + 1) - 1; }
 };
 
 // ---- 1. presence map -> distinct rows, positions, per-owner counts (two small launches; independent of the sort) -----------------
@@ -104,12 +117,12 @@ static __global__ __launch_bounds__(kTileWords) void k_shard_emit(uint2 *__restr
                                                                   long long *__restrict__ counts, uint32_t *__restrict__ uniq) {
   __shared__ int lds[kScanThreads / 64];
   __shared__ uint32_t sfirst[DRX_MAX_WORLD + 1];
-  const int tpo = (int)g.tiles_per_owner, blk = (int)blockIdx.x;
+  const int tpo = (int)g.tiles_per_unit, blk = (int)blockIdx.x;
   int before = 0;
   for (int i = threadIdx.x; i < blk; i += kTileWords) before += tile_sum[i];
   int tile_off;
   (void)block_scan_incl(before, lds, tile_off);
-  tile_off += blk / tpo;                                   // the sentinels of the owners that end in front of this tile
+  tile_off += blk / tpo;                                   // the sentinels of the units that end in front of this tile
   const uint32_t w = blockIdx.x * kTileWords + threadIdx.x;
   uint32_t bits = ptab[w].x;
   const int c = (int)__popc(bits);
@@ -123,31 +136,33 @@ static __global__ __launch_bounds__(kTileWords) void k_shard_emit(uint2 *__restr
     uniq[pos++] = w * 32 + (uint32_t)i;
   }
   if (blk != 0) return;
-  if ((int)threadIdx.x <= g.world) {                       // thread o: where owner o's rows start
-    const int o = threadIdx.x;
-    int sum = o;
-    for (int i = 0; i < o * tpo; ++i) sum += tile_sum[i];
-    sfirst[o] = (uint32_t)sum;
+  if ((int)threadIdx.x <= g.units) {                       // thread v: where unit v's rows start
+    const int v = threadIdx.x;
+    int sum = v;
+    for (int i = 0; i < v * tpo; ++i) sum += tile_sum[i];
+    sfirst[v] = (uint32_t)sum;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t run = 0;
-    for (int o = 0; o <= g.world; ++o) {
-      first[o] = sfirst[o];
-      if (o == g.world) break;
-      const uint32_t n = sfirst[o + 1] - sfirst[o];
-      counts[o] = (long long)n;
-      uniq[sfirst[o + 1] - 1] = DRX_KEY_NONE;
-      if (g.bypass && o == g.rank) continue;            // the own chunk: behind all the others
-      foff[o] = run;
+    for (int v = 0; v <= g.units; ++v) {
+      first[v] = sfirst[v];
+      if (v == g.units) break;
+      const uint32_t n = sfirst[v + 1] - sfirst[v];
+      counts[(v % g.world) * g.chunks + v / g.world] = (long long)n;      // OWNER-major (what the count exchange sends: `chunks` per peer)
+      uniq[sfirst[v + 1] - 1] = DRX_KEY_NONE;
+      if (g.own_unit(v)) continue;                      // the own units: behind all the others
+      foff[v] = run;
       run += n * (uint32_t)g.ld + pad32(n);
     }
-    if (g.bypass) {
-      const uint32_t n = sfirst[g.rank + 1] - sfirst[g.rank];
-      foff[g.rank] = run;
-      run += n * (uint32_t)g.ld + pad32(n);
-    }
-    foff[g.world] = run;
+    if (g.bypass)
+      for (int c = 0; c < g.chunks; ++c) {
+        const int v = c * g.world + g.rank;
+        const uint32_t n = sfirst[v + 1] - sfirst[v];
+        foff[v] = run;
+        run += n * (uint32_t)g.ld + pad32(n);
+      }
+    foff[g.units] = run;
   }
 }
 
@@ -203,7 +218,7 @@ static __global__ void k_owner_scatter(ShardGeo g, SegOff so, const uint32_t *__
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const uint32_t k = recv_keys[j];
     if (k == DRX_KEY_NONE) continue;
-    const uint32_t lk = k - ((uint32_t)g.rank << g.shift);
+    const uint32_t lk = g.wg().local(k);
     tab[(size_t)lk * so.n_seg + source_of(so, j)] = (uint32_t)j;
   }
 }
@@ -226,9 +241,9 @@ static __global__ __launch_bounds__(kBlock) void k_shard_gather_rows(DrxCdaePara
       live[q] = false; outr[q] = false; bv[q] = 0.f; dst[q] = 0; sdst[q] = 0;
       const uint32_t k = j < n ? recv_keys[j] : DRX_KEY_NONE;
       if (k == DRX_KEY_NONE) continue;
-      const uint32_t t = k - ((uint32_t)g.rank << g.shift);            // local key in [0, 2 * ipr)
-      const bool is_out = t >= (uint32_t)g.ipr;
-      const size_t row = is_out ? t - g.ipr : t;
+      const uint32_t t = g.wg().local(k);                              // local key in [0, 2 * ipr): 2 * local item + (W2T row)
+      const bool is_out = t & 1u;
+      const size_t row = t >> 1;
       const int s = source_of(so, j);
       if (so.is_own(s)) continue;                                      // the requester reads its own rows from the tables
       dst[q] = (size_t)so.foff[s] + (size_t)(j - so.koff[s]) * P.ld;
@@ -255,6 +270,7 @@ struct ShardStep {
   const float *cache;                         // the rows this rank asked for, as they arrived
   float *gsend;                               // gradient rows on their way back: same geometry
   ShardXfer X;
+  WireGeo G;
   int ipr, b_norm, n_items;                   // n_items: GLOBAL
   int self;                                   // this rank when its own rows bypass the exchange (read from the tables), else -1
 };
@@ -291,7 +307,7 @@ static __global__ __launch_bounds__(kBlock) void k_shard_fwd_bwd(DrxCdaeParams P
           const int o = item / S.ipr;
           if (o == S.self) off[r] = 0x80000000u | (uint32_t)((item - o * S.ipr) * P.ld);        // an own row: straight from the table
           else {
-            const uint32_t w = ((uint32_t)o << S.X.shift) + (uint32_t)(item - o * S.ipr);
+            const uint32_t w = S.G.wire(item, 0);
             off[r] = (uint32_t)S.X.row_off(w, S.X.pos_of(w));
           }
         }
@@ -324,7 +340,7 @@ static __global__ __launch_bounds__(kBlock) void k_shard_fwd_bwd(DrxCdaeParams P
   hidden_act<G, J>(P, u, scale, lane, acc, h);
   const int i = bt.iid[b];
   const int oo = i / S.ipr;
-  const uint32_t wo = ((uint32_t)oo << S.X.shift) + (uint32_t)S.ipr + (uint32_t)(i - oo * S.ipr);
+  const uint32_t wo = S.G.wire(i, 1);
   const uint32_t po = S.X.pos_of(wo);
   const size_t ro = S.X.row_off(wo, po), sco = S.X.scal_off(wo, po);
   const bool own_out = oo == S.self;
@@ -381,6 +397,7 @@ struct LocalPolicyT {
   const float *dz2;
   float *gsend;
   ShardXfer X;
+  WireGeo WG;
   template <int G, int J>
   __device__ __forceinline__ void load(uint32_t key, uint32_t b, int lane, float4 (&row)[J], float &sc, float &coef) const {
     const uint32_t N = (uint32_t)n_items;
@@ -402,8 +419,7 @@ struct LocalPolicyT {
     } else {
       const bool is_out = key >= N;
       const int item = (int)(is_out ? key - N : key);
-      const int o = item / ipr;
-      const uint32_t w = ((uint32_t)o << X.shift) + (uint32_t)(is_out ? ipr : 0) + (uint32_t)(item - o * ipr);
+      const uint32_t w = WG.wire(item, is_out ? 1 : 0);
       const uint32_t pos = X.pos_of(w);
       store_row<G, J>(gsend + X.row_off(w, pos), 0, P.ld, lane, g);
       if (is_out && lane == 0) gsend[X.scal_off(w, pos)] = gs;
@@ -419,8 +435,7 @@ struct LocalPolicyT {
   }
   __device__ __forceinline__ bool stream_parked(uint32_t av) const { return av < 2u; }
   __device__ __forceinline__ void stream_park_at(uint32_t av, uint32_t item, uint32_t &roff, uint32_t &soff) const {
-    const int o = (int)item / ipr;
-    const uint32_t w = ((uint32_t)o << X.shift) + (uint32_t)(av == 1u ? ipr : 0) + (item - (uint32_t)(o * ipr));
+    const uint32_t w = WG.wire((int)item, av == 1u ? 1 : 0);
     const uint32_t pos = X.pos_of(w);
     roff = (uint32_t)X.row_off(w, pos);
     soff = (uint32_t)X.scal_off(w, pos);
@@ -440,7 +455,7 @@ struct LocalPolicyT {
 // extra workgroups left) into the sentinel row of EVERY destination, the rank's loss sum into that row's scalar.
 template <int G, int J>
 struct ShardBiasExtra {
-  int ld, world;
+  int ld, units;
   BiasArgs A;
   float *gsend;
   ShardXfer X;
@@ -482,9 +497,9 @@ struct ShardBiasExtra {
 #pragma unroll
         for (int j = 0; j < J; ++j) f4_add(g[j], v[j]);
       }
-      for (int o = 0; o < world; ++o) {                        // the sentinel closes owner o's chunk
-        store_row<G, J>(gsend + X.sentinel_row(o), 0, ld, lane, g);
-        if (threadIdx.x == 0) gsend[X.sentinel_scal(o)] = tl;
+      for (int v = 0; v < units; ++v) {                        // the sentinel closes unit v's piece (the owner reads the last chunk's)
+        store_row<G, J>(gsend + X.sentinel_row(v), 0, ld, lane, g);
+        if (threadIdx.x == 0) gsend[X.sentinel_scal(v)] = tl;
       }
     }
   }
@@ -495,13 +510,14 @@ template <int G, int J, int KIND>
 static __global__ __launch_bounds__(kBlock) void k_shard_apply(DrxCdaeParams P, DrxOptim opt, ShardGeo g, int b_norm, SegOff so,
                                                                const uint32_t *__restrict__ recv_keys, int n,
                                                                const uint32_t *__restrict__ tab, const float *__restrict__ grecv,
-                                                               int row_blocks, float *loss_out) {
+                                                               int row_blocks, float *loss_out, int do_bias) {
   const int lane = threadIdx.x % G;
   const int gpb = kBlock / G;
   const int W = so.n_seg;
   if ((int)blockIdx.x >= row_blocks) {
-    // the hidden bias: the sentinel rows of all segments in order (every rank sums the same rows: b stays identical everywhere)
-    if (threadIdx.x < G) {
+    // the hidden bias: the sentinel rows of all segments in order (every rank sums the same rows: b stays identical everywhere);
+    // only with the step's LAST exchange chunk
+    if (do_bias && threadIdx.x < G) {
       float4 gb[J], w[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) gb[j] = f4_zero();
@@ -541,7 +557,7 @@ static __global__ __launch_bounds__(kBlock) void k_shard_apply(DrxCdaeParams P, 
         const int j = j0 + q;
         const uint32_t key = j < n ? recv_keys[j] : DRX_KEY_NONE;
         live[q] = key != DRX_KEY_NONE;
-        lk[q] = key - ((uint32_t)g.rank << g.shift);
+        lk[q] = g.wg().local(key);
         gs[q] = 0.f;
 #pragma unroll
         for (int jx = 0; jx < J; ++jx) gsum[q][jx] = f4_zero();
@@ -556,7 +572,7 @@ static __global__ __launch_bounds__(kBlock) void k_shard_apply(DrxCdaeParams P, 
         const int j = j0 + q;
         const uint32_t key = j < n ? recv_keys[j] : DRX_KEY_NONE;
         live[q] = key != DRX_KEY_NONE;
-        lk[q] = key - ((uint32_t)g.rank << g.shift);
+        lk[q] = g.wg().local(key);
         gs[q] = 0.f;
 #pragma unroll
         for (int jx = 0; jx < J; ++jx) gsum[q][jx] = f4_zero();
@@ -611,15 +627,15 @@ static __global__ __launch_bounds__(kBlock) void k_shard_apply(DrxCdaeParams P, 
 #pragma unroll
       for (int jx = 0; jx < J; ++jx) w[q][jx] = f4_zero();
       if (live[q]) {
-        const bool is_out = lk[q] >= (uint32_t)g.ipr;
-        load_row<G, J>(is_out ? w2 : wt, is_out ? lk[q] - g.ipr : lk[q], P.ld, lane, w[q]);
+        const bool is_out = lk[q] & 1u;
+        load_row<G, J>(is_out ? w2 : wt, lk[q] >> 1, P.ld, lane, w[q]);
       }
     }
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
       if (!live[q]) continue;
-      const bool is_out = lk[q] >= (uint32_t)g.ipr;
-      const size_t row = is_out ? lk[q] - g.ipr : lk[q];
+      const bool is_out = lk[q] & 1u;
+      const size_t row = lk[q] >> 1;
       OptScalars o = opt_for(opt, 0, b_norm);
       o.inv_k = 1.0f / (float)P.k;
       row_update<G, J, KIND>(o, is_out ? w2 : wt, is_out ? a1 : a0, is_out ? c1 : c0, row, P.ld, lane, w[q], gsum[q]);
@@ -657,7 +673,7 @@ static ShardPrepBufs shard_prep_layout(Carver &cv, const DrxCdaeParams &p, const
   const ShardGeo g = geo_of(sh, p.ld);
   L.R = prep_layout(cv, key_params(p, sh), B, n_touch_slots);
   L.ptab = cv.take<uint2>(g.n_words);
-  L.uniq_cap = (size_t)n_touch_slots + (size_t)B + (size_t)sh.world;
+  L.uniq_cap = (size_t)n_touch_slots + (size_t)B + (size_t)g.units;
   L.off_uniq = align_up(cv.off, 256);
   L.uniq = cv.take<uint32_t>(L.uniq_cap);
   L.first = cv.take<uint32_t>(DRX_MAX_WORLD + 1);
@@ -704,8 +720,10 @@ static int check_shard(const DrxShard *sh) {
     return DRX_EINVAL;
   if ((long long)sh->items_per_rank * sh->world < (long long)sh->n_items) return DRX_EINVAL;
   if ((uint64_t)2 * sh->n_items + (uint64_t)sh->n_users_local + 1 >= 0xFFFFFFFFull) return DRX_EINVAL;
+  if (sh->chunks < 0 || sh->chunks > DRX_MAX_CHUNKS || (sh->chunks & (sh->chunks - 1))) return DRX_EINVAL;       // 0 / 1: unchunked
   const ShardGeo g = geo_of(*sh, 4);
   if (g.shift > 26 || ((uint64_t)sh->world << g.shift) >= 0x80000000ull) return DRX_EINVAL;
+  if (g.units > DRX_MAX_WORLD) return DRX_EINVAL;                  // (first / foff / counts hold DRX_MAX_WORLD + 1 entries)
   return DRX_OK;
 }
 
@@ -721,6 +739,9 @@ static int check_local_params(const DrxCdaeParams *p, const DrxShard *sh) {
 using namespace drx;
 
 extern "C" {
+
+int32_t drx_shard_chunks(const DrxShard *sh) { return check_shard(sh) ? 0 : geo_of(*sh, 4).chunks; }
+int32_t drx_shard_unit_shift(const DrxShard *sh) { return check_shard(sh) ? 0 : geo_of(*sh, 4).cshift; }
 
 size_t drx_shard_prep_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32_t B, int32_t n_touch_slots) {
   if (!p || check_shard(sh) || B < 1 || n_touch_slots < 0) return 0;
@@ -761,7 +782,7 @@ int drx_shard_prepare(const DrxCdaeParams *p, const DrxShard *sh, const DrxHisto
   uint8_t *present = (uint8_t *)work;
   int *tile_sum = (int *)((char *)work + align_up((size_t)g.n_words * 32, 256));
   const DrxCdaeParams pk = key_params(*p, *sh);
-  rc = prepare_impl(&pk, hist, bt, L.R, st, true, TouchPresence{present, g.ipr, g.shift});
+  rc = prepare_impl(&pk, hist, bt, L.R, st, true, TouchPresence{present, g.wg()});
   if (rc) return rc;
   if (p->ld <= 16) order_by_degree(bt, L.R, st, true);
   hipLaunchKernelGGL(k_shard_pack, dim3(g.n_tiles), dim3(kTileWords), 0, st, present, L.ptab, tile_sum);
@@ -776,7 +797,7 @@ size_t drx_shard_owner_table_bytes(const DrxShard *sh, int32_t n_segments) {
 }
 
 int drx_shard_owner_index(const DrxShard *sh, const uint32_t *recv_keys, int32_t n, const int32_t *recv_counts, int32_t n_segments,
-                          void *table, size_t table_bytes, void *stream) {
+                          int32_t chunk, void *table, size_t table_bytes, void *stream) {
   if (check_shard(sh) || !recv_keys || !recv_counts || !table || n < 1) return DRX_EINVAL;
   if (n_segments < sh->world || n_segments % sh->world || n_segments > sh->world * DRX_MAX_MICRO) return DRX_EINVAL;
   if (table_bytes < drx_shard_owner_table_bytes(sh, n_segments)) return DRX_ESCRATCH;
@@ -785,7 +806,12 @@ int drx_shard_owner_index(const DrxShard *sh, const uint32_t *recv_keys, int32_t
   const int rc = seg_off(g, recv_counts, n_segments, n, so);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  DRX_HIP(hipMemsetAsync(table, 0xFF, (size_t)2 * sh->items_per_rank * n_segments * sizeof(uint32_t), st));
+  // the table rows of THIS chunk's key range only (the chunks of a step share one table: their key ranges are disjoint)
+  if (chunk < 0 || chunk >= g.chunks) return DRX_EINVAL;
+  const size_t lk_lo = (size_t)chunk << g.cshift, lk_all = (size_t)2 * sh->items_per_rank;
+  const size_t lk_hi = std::min(lk_all, ((size_t)chunk + 1) << g.cshift);
+  if (lk_hi > lk_lo)
+    DRX_HIP(hipMemsetAsync((uint32_t *)table + lk_lo * n_segments, 0xFF, (lk_hi - lk_lo) * n_segments * sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_owner_scatter, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, g, so, recv_keys, n,
                      (uint32_t *)table);
   DRX_LAUNCH_CHECK();
@@ -848,9 +874,9 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
   const float scale = 1.0f / (1.0f - bt->q);
   const uint32_t qthr = q_threshold(bt->q);
   const bool marks = p->ld > 16;                               // (prepare_impl: rows of <= 16 floats carry no sole-toucher marks)
-  const ShardXfer X{L.ptab, L.first, L.foff, g.shift, p->ld};
+  const ShardXfer X{L.ptab, L.first, L.foff, g.cshift, p->ld};
   ShardStep S{B.dz1, B.g2, B.dz2, B.lossb, marks ? L.R.solo_v : nullptr, marks ? L.R.solo_o : nullptr, L.R.order, rows_cache, grad_send,
-              X, g.ipr, b_norm, sh->n_items, g.bypass ? g.rank : -1};
+              X, g.wg(), g.ipr, b_norm, sh->n_items, g.bypass ? g.rank : -1};
   SegBufs SB{L.R.keys_s, L.R.vals_s, B.phead, B.ptail, B.phs, B.pts, nullptr, nullptr, nullptr, nullptr, B.T, B.n_chunks, p->ld, nullptr};
   PlanBufs PB{B.pblock, B.pbs};
   const int rows_per_block = (bt->B + B.n_bpart - 1) / B.n_bpart;
@@ -861,9 +887,9 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
 #define REDUCE_AND_SPANS(G, J, KIND)                                                                                   \
   {                                                                                                                    \
     using POLT = LocalPolicyT<KIND>;                                                                                   \
-    POLT polk{*p, *opt, b_norm, sh->n_items, g.ipr, scale, B.dz1, (long long)(B.g2 - B.dz1), B.dz2, grad_send, X};    \
+    POLT polk{*p, *opt, b_norm, sh->n_items, g.ipr, scale, B.dz1, (long long)(B.g2 - B.dz1), B.dz2, grad_send, X, g.wg()}; \
     BiasPartialExtra<G, J> bpx{p->ld, BA};                                                                             \
-    ShardBiasExtra<G, J> bfx{p->ld, sh->world, BA, grad_send, X};                                                      \
+    ShardBiasExtra<G, J> bfx{p->ld, g.units, BA, grad_send, X};                                                        \
     const int cpb = kSegBlock / G;                                                                                     \
     const dim3 rgrid(n_bpart + (B.n_chunks + cpb - 1) / cpb);                                                          \
     const size_t lds_r = seg_reduce_lds_bytes(cpb, p->ld, long_segments);                                              \
@@ -919,7 +945,7 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
 }
 
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *grad_recv, int32_t n, const int32_t *recv_counts, int32_t n_segments, const void *table,
+                    const float *grad_recv, int32_t n, const int32_t *recv_counts, int32_t n_segments, int32_t chunk, const void *table,
                     const float *const *own_grad, const int64_t *own_off, float *loss_out, void *stream) {
   if (check_shard(sh)) return DRX_EINVAL;
   int rc = check_local_params(p, sh);
@@ -930,7 +956,9 @@ int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard 
   const ShardGeo g = geo_of(*sh, p->ld);
   rc = seg_off(g, recv_counts, n_segments, n, so);
   if (rc) return rc;
-  if (g.bypass) {                                  // the chunks this rank "sent" to itself: still in its own gradient buffers
+  if (chunk < 0 || chunk >= g.chunks) return DRX_EINVAL;
+  const int do_bias = chunk == g.chunks - 1;       // b and the loss: once per step, with the last chunk (its sentinels carry them)
+  if (g.bypass) {                                  // the pieces this rank "sent" to itself: still in its own gradient buffers
     if (!own_grad || !own_off) return DRX_EINVAL;
     for (int m = 0; m < n_segments / sh->world; ++m) {
       if (!own_grad[m] || own_off[m] < 0 || own_off[m] >= 0xFFFFFFFFll) return DRX_EINVAL;
@@ -946,10 +974,10 @@ int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard 
     if (blocks > 16384) blocks = 16384;                                                                                \
     if (opt->kind == DRX_OPT_ADAGRAD)                                                                                  \
       hipLaunchKernelGGL((k_shard_apply<G, J, DRX_OPT_ADAGRAD>), dim3(blocks + 1), dim3(kBlock), 0, st, *p, *opt, g, b_norm, so,    \
-                         recv_keys, n, (const uint32_t *)table, grad_recv, blocks, loss_out);                          \
+                         recv_keys, n, (const uint32_t *)table, grad_recv, blocks, loss_out, do_bias);                 \
     else                                                                                                               \
       hipLaunchKernelGGL((k_shard_apply<G, J, -1>), dim3(blocks + 1), dim3(kBlock), 0, st, *p, *opt, g, b_norm, so, recv_keys, n, \
-                         (const uint32_t *)table, grad_recv, blocks, loss_out);                                        \
+                         (const uint32_t *)table, grad_recv, blocks, loss_out, do_bias);                               \
   }
   DRX_DISPATCH_GEOM(p->ld, CALL);
 #undef CALL

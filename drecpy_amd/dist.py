@@ -1,5 +1,5 @@
 """Row-sharded CDAE across the GPUs of one node (BASELINE.json configuration 4): one process per GPU,
-`torch.distributed` over RCCL/xGMI (backend "nccl"); the same orchestration runs over gloo on CPU tensors in the world-size-2 tests,
+`torch.distributed` over RCCL/xGMI (backend "nccl"); the same orchestration runs over gloo on CPU tensors in the world-size-2 .. 4 tests,
 with the per-rank device work swapped for a NumPy statement (tests/dist_ops_numpy.py).
 
 Sharding
@@ -13,19 +13,26 @@ One step (every rank, its own B triples; losses / L2 are normalised by the GLOBA
 the concatenated batch).  Parameter-independent, run ahead of the step (ShardedPipeline: on a side stream, 1 - 3 steps early):
   1. prepare: sorted touch list + span plan + sole-toucher marks + launch order (the single-GPU step's preparation), and — from a
      presence map of the wire keys, without waiting for the sort — the batch's DISTINCT item rows, their places in the exchange
-     buffers and the per-owner counts                                                                        [drx_shard_prepare]
+     buffers and the per-unit counts                                                                         [drx_shard_prepare]
   2. all-to-all of the counts (results to pinned host memory), all-to-all(v) of the keys (4 B per distinct row); the owner enters
      the keys it received in its direct-address table                                                        [drx_shard_owner_index]
 Parameter-dependent, on the training stream:
-  3. owners gather the requested rows + output biases into ONE float buffer; all-to-all(v)                   [drx_shard_gather_rows]
+  3. owners gather the requested rows + output biases into float buffers; all-to-all(v)                      [drx_shard_gather_rows]
   4. forward / backward against the received rows, planned segmented reduction: ONE gradient row per distinct item row (hot Zipf
      rows are merged before they travel), V rows updated in place, bias gradient into the sentinel rows      [drx_shard_step_local]
   5. all-to-all(v) of the gradient buffer back to the owners
   6. owners sum what the ranks sent per row in rank order and apply the sparse optimizer; bias update        [drx_shard_apply]
-Four collectives per step (two of them run ahead), four library calls on the training stream's critical path.  Direct all-to-all
-drives all 7 xGMI links of a GPU at once (a ring would be bound by one link), and only distinct rows travel.
 
-Exchange buffer geometry (include/drx.h): per peer, in rank order, n rows of ld floats then n scalars padded to 32 floats;
+EXCHANGE CHUNKS (r06; include/drx.h "WIRE keys"): an owner's key range is cut into C chunks and every exchange is C all-to-alls, chunk
+c over the units c * world .. c * world + world - 1 (contiguous in every buffer).  The tail of step s and the head of step s + 1 are
+then ONE pipeline over the chunks:
+        communicator   GX_0  GX_1  GX_2  GX_3        RX'_0   RX'_1   RX'_2   RX'_3
+        training       .     A_0 G'_0 A_1 G'_1 A_2 G'_2 A_3 G'_3  .  .   forward(s + 1)
+(GX_c: gradient rows of chunk c to their owners; A_c: owner apply of chunk c; G'_c: gather of the rows step s + 1 asked for in chunk c —
+they are final once A_c has run, every row lives in exactly one chunk; RX'_c: those rows to their requesters.)  Step s + 1's forward
+kernel starts when RX'_{C-1} has landed.  Without chunks the four stages are serial: GX, A, G', RX'.
+
+Exchange buffer geometry (include/drx.h): per unit, in unit order, n rows of ld floats then n scalars padded to 32 floats;
 n = distinct rows + 1 sentinel.
 """
 import ctypes as C
@@ -51,10 +58,29 @@ def wire_shift(ipr):
     return s
 
 
-def wire_key(n, ipr, is_out):
-    """owner-major wire key of item n's W (is_out False) or W2T row (python ints)"""
+def wire_chunks(ipr, chunks):
+    """The chunk count a shard description gets: a power of two, lowered until a unit spans whole 8192-key tiles (drx_shard_chunks)."""
+    c = max(1, int(chunks))
+    assert c & (c - 1) == 0, 'exchange chunks: a power of two'
+    while c > 1 and wire_shift(ipr) - (c.bit_length() - 1) < 13:
+        c >>= 1
+    return c
+
+
+def wire_key(n, ipr, is_out, world=1, chunks=1):
+    """unit-major wire key of item n's W (is_out False) or W2T row (python ints): include/drx.h, csrc/drx_prep.hpp WireGeo"""
+    cs = wire_shift(ipr) - (wire_chunks(ipr, chunks).bit_length() - 1)
     o = n // ipr
-    return (o << wire_shift(ipr)) + (ipr if is_out else 0) + (n - o * ipr)
+    l = 2 * (n - o * ipr) + (1 if is_out else 0)
+    return ((((l >> cs) * world + o) << cs) | (l & ((1 << cs) - 1)))
+
+
+def wire_local(key, ipr, world=1, chunks=1):
+    """(owner, chunk, is W2T row, local item) of a wire key"""
+    cs = wire_shift(ipr) - (wire_chunks(ipr, chunks).bit_length() - 1)
+    v = key >> cs
+    l = ((v // world) << cs) | (key & ((1 << cs) - 1))
+    return v % world, v // world, bool(l & 1), l >> 1
 
 
 def pad32(n):
@@ -62,14 +88,14 @@ def pad32(n):
 
 
 def chunk_floats(counts, ld):
-    """float split sizes of an exchange buffer whose peers hold `counts` rows (sentinels included)"""
+    """float split sizes of an exchange among the peers that hold `counts` rows (sentinels included)"""
     return [int(c) * ld + pad32(c) for c in counts]
 
 
 class HipShardOps:
     """Per-rank device work through the C ABI (include/drx.h, drx_shard_*)."""
 
-    def __init__(self, n_users_local, n_items, k, rank, world, device, optimizer, lr, reg, self_bypass=True):
+    def __init__(self, n_users_local, n_items, k, rank, world, device, optimizer, lr, reg, self_bypass=True, chunks=1):
         from . import _lib
         from .engine import CdaeEngine
         self._lib = _lib
@@ -83,7 +109,11 @@ class HipShardOps:
         # the rank's own rows never pass through a collective (include/drx.h DRX_SHARD_SELF_BYPASS); off: every row travels (a
         # measurement aid: at world 1 it sends the whole exchange through the communicator)
         self.self_bypass = bool(self_bypass) and self.ipr * self.ld < (1 << 31)
-        self.shard = _lib.Shard(world, rank, n_items, self.ipr, n_users_local, _lib.SHARD_SELF_BYPASS if self.self_bypass else 0)
+        self.shard = _lib.Shard(world, rank, n_items, self.ipr, n_users_local, _lib.SHARD_SELF_BYPASS if self.self_bypass else 0,
+                                wire_chunks(self.ipr, chunks))
+        self.chunks = int(self.L.drx_shard_chunks(C.byref(self.shard)))
+        if self.chunks < 1:
+            raise _lib.DrxError('drx_shard_chunks: invalid shard description')
         wb = int(self.L.drx_shard_work_bytes(C.byref(self.shard)))
         if wb <= 0:
             raise _lib.DrxError('drx_shard_work_bytes: invalid shard description')
@@ -91,12 +121,22 @@ class HipShardOps:
         self._scratch = None
         self._loss = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._tables = {}
+        self._cnt = {}
 
     def _stream(self):
         return self._lib.stream_ptr(self.device)
 
     def _e(self, n, dtype=torch.float32):
         return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def _counts(self, counts):
+        """host int32 array of a count list (ctypes arrays are kept per length: building one costs more than filling it)"""
+        n = len(counts)
+        a = self._cnt.get(n)
+        if a is None:
+            a = self._cnt[n] = (C.c_int32 * n)()
+        a[:] = counts
+        return a
 
     # -- parameter-independent
     def prepare(self, bt, out=None):
@@ -111,44 +151,49 @@ class HipShardOps:
                                               out.numel(), self._lib.ptr(self._work), self._work.numel(), self._stream()),
                         'drx_shard_prepare')
         uniq = out[lay[0]:lay[0] + 4 * lay[2]].view(torch.int32)
-        counts = out[lay[1]:lay[1] + 8 * self.world].view(torch.int64)
+        counts = out[lay[1]:lay[1] + 8 * self.world * self.chunks].view(torch.int64)       # owner-major: [owner][chunk]
         return {'buf': out, 'uniq': uniq, 'counts_dev': counts}
 
-    def owner_index(self, req, recv_counts, slot=0):
-        """The owner's table of the keys it received (parameter-independent; one table per in-flight step `slot`)."""
+    def owner_index(self, req, recv_counts, slot=0, chunk=0):
+        """The owner's table of the keys it received for one chunk (parameter-independent; one table per in-flight step `slot`,
+        shared by the step's chunks)."""
         n_seg = len(recv_counts)
         nb = int(self.L.drx_shard_owner_table_bytes(C.byref(self.shard), n_seg))
         tab = self._tables.get(slot)
         if tab is None or tab.numel() < nb:
             tab = self._tables[slot] = torch.empty(nb, dtype=torch.uint8, device=self.device)
-        cnt = (C.c_int32 * n_seg)(*[int(c) for c in recv_counts])
-        self._lib.check(self.L.drx_shard_owner_index(C.byref(self.shard), self._lib.ptr(req), req.numel(), cnt, n_seg,
-                                                     self._lib.ptr(tab), tab.numel(), self._stream()), 'drx_shard_owner_index')
+        self._lib.check(self.L.drx_shard_owner_index(C.byref(self.shard), self._lib.ptr(req), req.numel(), self._counts(recv_counts), n_seg,
+                                                     int(chunk), self._lib.ptr(tab), tab.numel(), self._stream()), 'drx_shard_owner_index')
         return tab
 
     # -- parameter-dependent
     def xsplits(self, counts):
-        """float split sizes of an exchange among the peers that hold `counts` rows: nothing travels to the rank itself when its
-        own rows bypass the collectives"""
+        """float split sizes of ONE CHUNK's exchange among the peers that hold `counts` rows: nothing travels to the rank itself when
+        its own rows bypass the collectives"""
         f = chunk_floats(counts, self.ld)
         if self.self_bypass:
             f = [0 if (i % self.world) == self.rank else x for i, x in enumerate(f)]
         return f
 
-    def gather_rows(self, req, recv_counts):
-        out = self._e(max(32, sum(self.xsplits(recv_counts))))
-        cnt = (C.c_int32 * len(recv_counts))(*[int(c) for c in recv_counts])
+    def gather_rows(self, req, recv_counts, out=None):
+        """the rows one chunk's requests name, segment after segment"""
+        n = max(32, sum(self.xsplits(recv_counts)))
+        if out is None or out.numel() < n:
+            out = self._e(n)
         self._lib.check(self.L.drx_shard_gather_rows(C.byref(self.engine._params), C.byref(self.shard), self._lib.ptr(req), req.numel(),
-                                                     cnt, len(recv_counts), self._lib.ptr(out), self._stream()), 'drx_shard_gather_rows')
+                                                     self._counts(recv_counts), len(recv_counts), self._lib.ptr(out), self._stream()),
+                        'drx_shard_gather_rows')
         return out
 
-    def local_step(self, bt, prep, rows_cache, b_norm, loss_kind, opt, events=None):
-        """Forward / backward + reduction of one (micro-)batch: the gradient buffer on its way back (same geometry as rows_cache)."""
+    def local_step(self, bt, prep, rows_cache, b_norm, loss_kind, opt, events=None, out=None):
+        """Forward / backward + reduction of one (micro-)batch: the gradient buffer on its way back (same geometry as rows_cache,
+        the rank's own units — with the bypass — at its end)."""
         P = self.engine._params
         need = int(self.L.drx_shard_step_scratch_bytes(C.byref(P), bt.B, bt.n_touch_slots))
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(int(need * 1.1) + 4096, dtype=torch.uint8, device=self.device)
-        gsend = self._e(max(32, sum(chunk_floats(prep['send_counts'], self.ld))))     # (with the bypass: the own chunk at its end)
+        n = max(32, sum(sum(chunk_floats(sc, self.ld)) for sc in prep['send_counts']))
+        gsend = out if (out is not None and out.numel() >= n) else self._e(n)
         arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events]) if events is not None else None
         buf = prep['buf']
         self._lib.check(self.L.drx_shard_step_local(C.byref(P), C.byref(opt), C.byref(self.shard), C.byref(self.engine._hist), C.byref(bt),
@@ -157,17 +202,16 @@ class HipShardOps:
                                                     self._stream()), 'drx_shard_step_local')
         return gsend
 
-    def apply(self, req, grecv, recv_counts, table, b_norm, opt, want_loss=False, own=None):
-        """own: per micro-batch (its gradient buffer, the send counts it was built for) — where the rank's own chunks are"""
-        cnt = (C.c_int32 * len(recv_counts))(*[int(c) for c in recv_counts])
+    def apply(self, req, grecv, recv_counts, table, b_norm, opt, want_loss=False, own=None, chunk=0):
+        """One chunk of the owner apply.  own: per micro-batch (its gradient buffer, float offset of the rank's own piece of this chunk)"""
         og = oo = None
         if self.self_bypass:
             og = (C.c_void_p * len(own))(*[self._lib.ptr(g) for g, _ in own])
-            oo = (C.c_int64 * len(own))(*[sum(self.xsplits(sc)) for _, sc in own])
+            oo = (C.c_int64 * len(own))(*[int(o) for _, o in own])
         self._lib.check(self.L.drx_shard_apply(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), int(b_norm),
-                                               self._lib.ptr(req), self._lib.ptr(grecv), req.numel(), cnt, len(recv_counts),
-                                               self._lib.ptr(table), og, oo, self._lib.ptr(self._loss) if want_loss else None,
-                                               self._stream()), 'drx_shard_apply')
+                                               self._lib.ptr(req), self._lib.ptr(grecv), req.numel(), self._counts(recv_counts),
+                                               len(recv_counts), int(chunk), self._lib.ptr(table), og, oo,
+                                               self._lib.ptr(self._loss) if want_loss else None, self._stream()), 'drx_shard_apply')
         return self._loss if want_loss else None
 
     def optim(self, step):
@@ -184,12 +228,50 @@ class HipShardOps:
         return self.engine.get_params()
 
 
+class _Done:
+    """handle of an exchange that has already happened (or was issued in stream order)"""
+    def wait(self):
+        pass
+
+
+_DONE = _Done()
+
+
+class TorchTransport:
+    """all-to-all(v) through torch.distributed (RCCL on GPU tensors: backend "nccl"; gloo on CPU tensors or — cpu_staging — staged
+    through the host for ranks that share one GPU in tests).  a2a() returns a handle; handle.wait() makes the CURRENT stream wait for
+    the rows (a no-op for exchanges that ran synchronously)."""
+
+    def __init__(self, group, world, collectives, cpu_staging):
+        self.group, self.world, self.collectives, self.cpu_staging = group, world, collectives, cpu_staging
+
+    def a2a(self, send, send_splits, out, recv_splits, overlap=False):
+        n_s, n_r = int(sum(send_splits)), int(sum(recv_splits))
+        dst, send = out[:n_r], send[:n_s]
+        if not self.collectives:
+            dst.copy_(send)
+            return _DONE
+        if self.world == 1 and n_r == 0 and n_s == 0:
+            return _DONE                               # (a 1-rank communicator with the self-bypass: nothing to exchange)
+        if (self.cpu_staging and send.is_cuda) or not send.is_cuda:
+            o = torch.empty(n_r, dtype=send.dtype)
+            dist.all_to_all_single(o, send.contiguous().cpu(), output_split_sizes=[int(c) for c in recv_splits],
+                                   input_split_sizes=[int(c) for c in send_splits], group=self.group)
+            dst.copy_(o)
+            return _DONE
+        # async_op: the training stream keeps running kernels (another chunk's apply, another micro-batch) while the rows travel;
+        # on a single exchange the asynchronous form only adds a stream hop
+        work = dist.all_to_all_single(dst, send, output_split_sizes=[int(c) for c in recv_splits],
+                                      input_split_sizes=[int(c) for c in send_splits], group=self.group, async_op=overlap)
+        return work if overlap else _DONE
+
+
 class ShardedCdae:
     """One rank of the row-sharded sampled-mode CDAE.  `ops` = per-rank compute backend (HipShardOps on a GPU)."""
 
     def __init__(self, n_users_total, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
                  optimizer='adagrad', ops=None, group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False,
-                 self_bypass=True):
+                 self_bypass=True, chunks=1, transport=None):
         self.rank, self.world, self.group = rank, world, group
         # world 1 normally bypasses torch.distributed; `force_collectives` sends every exchange through the process group
         # anyway (a 1-rank RCCL communicator exercises the exact call sequence of the N-rank step on one GPU)
@@ -201,11 +283,13 @@ class ShardedCdae:
         self.user_hi = n_users_total * (rank + 1) // world
         self.n_users_total = n_users_total
         n_local = self.user_hi - self.user_lo
-        self.ops = ops if ops is not None else HipShardOps(n_local, n_items, k, rank, world, device, optimizer, lr, reg, self_bypass)
+        self.ops = ops if ops is not None else HipShardOps(n_local, n_items, k, rank, world, device, optimizer, lr, reg, self_bypass, chunks)
+        self.chunks = int(getattr(self.ops, 'chunks', 1))          # (what the shard's key range allows: <= the request)
         self.engine = getattr(self.ops, 'engine', None)
         self.ld = getattr(self.ops, 'ld', k)
         self.loss_kind = 0 if loss == 'bce' else 1
         self.q = q
+        self.xfer = transport if transport is not None else TorchTransport(group, world, self.collectives, cpu_staging)
         if self.engine is not None:
             # (the engine's tables are this rank's SHARD — its item rows are local, the history's item ids global: no transpose)
             self.engine.set_history(hist_indptr, hist_indices, with_transpose=False)
@@ -247,37 +331,19 @@ class ShardedCdae:
 
     # ---- exchanges ---------------------------------------------------------------------------------------
     def _a2a(self, send, send_counts, recv_counts, out=None, overlap=False):
-        """all-to-all(v) of a 1-D tensor with per-peer split sizes; returns (received tensor, wait()-able or None).  overlap: the
-        training stream keeps running kernels of another micro-batch while the rows travel.  The returned tensor is never empty
-        (at least 32 elements are allocated: an exchange may be empty when a rank's own rows bypass it, and the library wants a
-        pointer); its first sum(recv_counts) elements are the received ones."""
+        """all-to-all(v) of a 1-D tensor with per-peer split sizes; returns (received tensor, handle).  The returned tensor is never
+        empty (at least 32 elements are allocated: an exchange may be empty when a rank's own rows bypass it, and the library wants
+        a pointer); its first sum(recv_counts) elements are the received ones."""
         n = int(sum(recv_counts))
         if out is None:
             out = torch.empty(max(n, 32), dtype=send.dtype, device=send.device)
-        dst = out[:n]
-        send = send[:int(sum(send_counts))]
-        if not self.collectives:
-            dst.copy_(send)
-            return out, None
-        if self.world == 1 and n == 0 and send.numel() == 0:
-            return out, None                           # (a 1-rank communicator with the self-bypass: nothing to exchange)
-        if (self.cpu_staging and send.is_cuda) or not send.is_cuda:
-            o = torch.empty(n, dtype=send.dtype)
-            dist.all_to_all_single(o, send.contiguous().cpu(), output_split_sizes=[int(c) for c in recv_counts],
-                                   input_split_sizes=[int(c) for c in send_counts], group=self.group)
-            dst.copy_(o)
-            return out, None
-        # async_op only when there is another micro-batch to compute meanwhile (on one micro-batch the asynchronous form only
-        # adds a stream hop)
-        work = dist.all_to_all_single(dst, send, output_split_sizes=[int(c) for c in recv_counts],
-                                      input_split_sizes=[int(c) for c in send_counts], group=self.group, async_op=overlap)
-        return out, (work if overlap else None)
+        return out, self.xfer.a2a(send, send_counts, out, recv_counts, overlap)
 
     # ---- the parameter-independent stages ---------------------------------------------------------------------
     # They may run ahead of the training stream (ShardedPipeline below):
-    #   prepare(bt)            local: touch list, plan, marks, distinct rows, per-owner counts          [no collective]
-    #   exchange_counts(P)     all-to-all of the per-owner counts; the result goes to pinned host memory
-    #   exchange_keys(P)       all-to-all(v) of the distinct keys each owner is asked for (needs the counts on the host)
+    #   prepare(bt)            local: touch list, plan, marks, distinct rows, per-unit counts            [no collective]
+    #   exchange_counts(P)     all-to-all of the per-(owner, chunk) counts; the result goes to pinned host memory
+    #   exchange_keys(P)       per chunk an all-to-all(v) of the distinct keys each owner is asked for (needs the counts on the host)
     #   index_owner(Ps)        the owner's table of the keys it received for all micro-batches of a step
     # Every rank must call the stages in the same program order: they all run on one communicator.
     def prepare(self, bt, consumer_stream=None, out=None):
@@ -287,10 +353,16 @@ class ShardedCdae:
         P['event'] = None                           # recorded behind the LAST run-ahead stage (index_owner): what the step waits for
         return P
 
+    def _split_counts(self, P, send_flat, recv_flat):
+        """owner-major flat count vectors ([peer][chunk]) -> per chunk, per peer"""
+        W, Cn = self.world, self.chunks
+        P['send_counts'] = [[int(send_flat[o * Cn + c]) for o in range(W)] for c in range(Cn)]
+        P['recv_counts'] = [[int(recv_flat[s * Cn + c]) for s in range(W)] for c in range(Cn)]
+
     def exchange_counts(self, P):
-        """How many rows (sentinel included) every rank asks of every owner.  On the device path nothing here waits on the host:
-        the send counts are a view of the prepared buffer, both count vectors land in pinned memory."""
-        W = self.world
+        """How many rows (sentinel included) every rank asks of every owner in every chunk.  On the device path nothing here waits on
+        the host: the send counts are a view of the prepared buffer, both count vectors land in pinned memory."""
+        W, Cn = self.world, self.chunks
         if 'counts_dev' in P and not self.cpu_staging:
             send = P['counts_dev']
             recv = torch.empty_like(send)
@@ -298,7 +370,7 @@ class ShardedCdae:
                 dist.all_to_all_single(recv, send, group=self.group)
             else:
                 recv.copy_(send)
-            host = torch.empty(2, W, dtype=torch.int64, pin_memory=True)
+            host = torch.empty(2, W * Cn, dtype=torch.int64, pin_memory=True)
             host[0].copy_(send, non_blocking=True)
             host[1].copy_(recv, non_blocking=True)
             P['counts_host'] = host
@@ -309,18 +381,18 @@ class ShardedCdae:
                 send_counts = [int(c) for c in P['counts']]
             else:
                 send_counts = P['counts_dev'].cpu().tolist()
-            P['send_counts'] = send_counts
             if self.collectives:
                 s = torch.tensor(send_counts, dtype=torch.int64)
                 r = torch.empty_like(s)
                 dist.all_to_all_single(r, s, group=self.group)
-                P['recv_counts'] = r.tolist()
+                recv_counts = r.tolist()
             else:
-                P['recv_counts'] = list(send_counts)
+                recv_counts = list(send_counts)
+            self._split_counts(P, send_counts, recv_counts)
         return P
 
     def exchange_keys(self, P):
-        """Every owner learns which of its rows each rank wants (4 B per distinct row)."""
+        """Every owner learns which of its rows each rank wants (4 B per distinct row): one all-to-all(v) per chunk."""
         if 'send_counts' not in P:
             if 'counts_host' not in P:
                 self.exchange_counts(P)
@@ -328,92 +400,165 @@ class ShardedCdae:
                 t0 = time.perf_counter()
                 P['counts_event'].synchronize()         # the tiny count exchange, issued at least two steps earlier
                 self.wait_s += time.perf_counter() - t0
-                P['send_counts'] = P['counts_host'][0].tolist()
-                P['recv_counts'] = P['counts_host'][1].tolist()
-        P['req'], _ = self._a2a(P['uniq'], P['send_counts'], P['recv_counts'])
-        P['req'] = P['req'][:int(sum(P['recv_counts']))]
-        if P['req'].is_cuda and P.get('consumer') is not None:
-            P['req'].record_stream(P['consumer'])
+                self._split_counts(P, P['counts_host'][0].tolist(), P['counts_host'][1].tolist())
+        if 'send_counts' not in P:
+            self.exchange_counts(P)
+        P['req'], k0 = [], 0
+        for c in range(self.chunks):
+            sc, rc = P['send_counts'][c], P['recv_counts'][c]
+            req, _ = self._a2a(P['uniq'][k0:], sc, rc)
+            req = req[:int(sum(rc))]
+            if req.is_cuda and P.get('consumer') is not None:
+                req.record_stream(P['consumer'])
+            P['req'].append(req)
+            k0 += int(sum(sc))
         return P
 
     def index_owner(self, Ps, slot=0):
-        """The owner side of a step's key exchange(s): one table over the segments of all micro-batches (micro-batch-major)."""
+        """The owner side of a step's key exchange(s): per chunk one run of segments (micro-batch-major, then source), one table."""
         head = Ps[0]
-        head['req_all'] = Ps[0]['req'] if len(Ps) == 1 else torch.cat([P['req'] for P in Ps])
-        head['counts_all'] = [int(c) for P in Ps for c in P['recv_counts']]
-        head['table'] = self.ops.owner_index(head['req_all'], head['counts_all'], slot)
-        if head['req_all'].is_cuda and head.get('consumer') is not None:
+        head['req_all'], head['counts_all'] = [], []
+        for c in range(self.chunks):
+            req = Ps[0]['req'][c] if len(Ps) == 1 else torch.cat([P['req'][c] for P in Ps])
+            cnt = [int(n) for P in Ps for n in P['recv_counts'][c]]
+            head['req_all'].append(req)
+            head['counts_all'].append(cnt)
+            head['table'] = self.ops.owner_index(req, cnt, slot, c)
+            if req.is_cuda and head.get('consumer') is not None and len(Ps) > 1:
+                req.record_stream(head['consumer'])
+        if head['req_all'][0].is_cuda and head.get('consumer') is not None:
             head['event'] = torch.cuda.Event()
             head['event'].record(self._cur) if self._cur is not None else head['event'].record()
-            if len(Ps) > 1:
-                head['req_all'].record_stream(head['consumer'])
         return head
 
-    # ---- one step ------------------------------------------------------------------------------------------
-    def step(self, step, bt, events=None, want_loss=False, prepared=None, after_row_requests=None, after_apply=None):
-        """One training step of this rank.  `bt` is a DrxBatch or a list of up to DRX_MAX_MICRO micro-batches with pairwise
-        DISJOINT users (then `prepared` is the matching list): all micro-batches read the pre-step parameters and every
-        owned row is updated once with the sum of their gradients — the step still equals the single-process step on the
-        concatenated batch — but the row exchange of micro-batch m+1 and the gradient exchange of micro-batch m travel while
-        the other one computes.
-        Event slots (bench; one micro-batch): [0,1) row gather + row exchange, [1,2) forward / backward kernel, [2,3) planned
-        reduction, [3,4) span launch (+ the rank's bias row), [4,5) gradient exchange + owner apply (+ bias update) — slots 1..4 are
-        recorded by the library between its launches (drx_shard_step_local).  With several micro-batches: [1,4) = all of them.
-        after_row_requests: called once the row exchanges of this step and the kernels of its first micro-batch are queued —
-        ShardedPipeline queues the run-ahead count / key exchanges of later batches there, so that on the communicator they sit
-        behind this step's row exchange (and travel while it computes) instead of in front of it.
-        after_apply: called once the whole step is queued — the pipeline's collective-free preparation of a later batch goes there
-        (its host time would otherwise delay the issue of this step's owner apply)."""
-        ops, ld = self.ops, self.ld
-        bts = list(bt) if isinstance(bt, (list, tuple)) else [bt]
-        Ps = (list(prepared) if isinstance(prepared, (list, tuple)) else [prepared]) if prepared is not None else [None] * len(bts)
-        b_norm = sum(b.B for b in bts) * self.world
-        opt = ops.optim(step)
-        rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
-        wait = lambda w: w.wait() if w is not None else None
-        rec(0)
+    # ---- the two halves of a step's exchanges ------------------------------------------------------------------
+    def _ready(self, bts, Ps):
+        """prepared + keys exchanged + owner table built for a step's micro-batches (inline, when nothing ran ahead)"""
         for m, b in enumerate(bts):
             P = Ps[m] = Ps[m] if Ps[m] is not None else self.prepare(b)
             if 'req' not in P:
                 self.exchange_keys(P)
         if 'table' not in Ps[0]:
             self.index_owner(Ps)
+        return Ps
+
+    def _main_waits(self, Ps):
         if Ps[0]['event'] is not None:                 # the run-ahead stages of this step, all queued on one side stream
             (self._main or torch.cuda.current_stream()).wait_event(Ps[0]['event'])
-        ov = len(Ps) > 1
-        fetched = []
-        for P in Ps:                                   # owners answer every micro-batch's request from the pre-step tables
-            rows = ops.gather_rows(P['req'], P['recv_counts'])
-            fetched.append(self._a2a(rows, ops.xsplits(P['recv_counts']), ops.xsplits(P['send_counts']), overlap=ov))
-        wait(fetched[0][1])
+
+    def _fetch_chunk(self, Ps, c, overlap):
+        """owners answer chunk c of every micro-batch's request from the tables as they are NOW; the rows travel"""
+        ops = self.ops
+        for P in Ps:
+            if 'cache' not in P:
+                n = sum(sum(ops.xsplits(sc)) for sc in P['send_counts'])
+                P['cache'] = torch.empty(max(32, n), dtype=torch.float32, device=P['uniq'].device) if torch.is_tensor(P['uniq']) and P['uniq'].is_cuda \
+                    else torch.zeros(max(32, n), dtype=torch.float64)
+                P['cache_off'] = np.concatenate([[0], np.cumsum([sum(ops.xsplits(sc)) for sc in P['send_counts']])]).astype(np.int64)
+                P['rx'] = []
+            rows = ops.gather_rows(P['req'][c], P['recv_counts'][c])
+            if P['cache'].dtype != rows.dtype:
+                P['cache'] = P['cache'].to(rows.dtype)
+            o = int(P['cache_off'][c])
+            P['rx'].append(self._a2a(rows, ops.xsplits(P['recv_counts'][c]), ops.xsplits(P['send_counts'][c]), out=P['cache'][o:],
+                                     overlap=overlap)[1])
+
+    def fetch_rows(self, Ps):
+        """head of a step: gather + row exchange of all chunks (when the previous step's tail did not already do it)"""
+        ov = len(Ps) > 1 or self.chunks > 1
+        for c in range(self.chunks):
+            self._fetch_chunk(Ps, c, ov)
+
+    # ---- one step ------------------------------------------------------------------------------------------
+    def step(self, step, bt, events=None, want_loss=False, prepared=None, after_row_requests=None, after_apply=None, next_prepared=None):
+        """One training step of this rank.  `bt` is a DrxBatch or a list of up to DRX_MAX_MICRO micro-batches with pairwise
+        DISJOINT users (then `prepared` is the matching list): all micro-batches read the pre-step parameters and every
+        owned row is updated once with the sum of their gradients — the step still equals the single-process step on the
+        concatenated batch — but the row exchange of micro-batch m+1 and the gradient exchange of micro-batch m travel while
+        the other one computes.
+        next_prepared: the prepared (keys exchanged, owner table built) micro-batches of the NEXT step.  Their rows are then gathered
+        and sent chunk by chunk right behind this step's owner apply of the same chunk (the module docstring's pipeline), and the
+        next call finds them in flight instead of fetching them at its head.
+        Event slots (bench; one micro-batch): [0,1) waiting for the rows (fetched here when the previous step did not), [1,2) forward /
+        backward kernel, [2,3) reduction, [3,4) span launch (+ the rank's bias row), [4,5) gradient exchange + owner apply (+ bias
+        update) + — pipelined — the next step's gather and row exchange; slots 1..4 are recorded by the library between its launches
+        (drx_shard_step_local).  With several micro-batches: [1,4) = all of them.
+        after_row_requests: called once the kernels of this step's first micro-batch are queued — ShardedPipeline queues the
+        run-ahead count / key exchanges of later batches there (they travel while the step computes).
+        after_apply: called once the whole step is queued — the pipeline's collective-free preparation of a later batch goes there
+        (its host time would otherwise delay the issue of this step's owner apply)."""
+        ops = self.ops
+        bts = list(bt) if isinstance(bt, (list, tuple)) else [bt]
+        Ps = (list(prepared) if isinstance(prepared, (list, tuple)) else [prepared]) if prepared is not None else [None] * len(bts)
+        b_norm = sum(b.B for b in bts) * self.world
+        opt = ops.optim(step)
+        rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
+        Cn = self.chunks
+        rec(0)
+        self._ready(bts, Ps)
+        self._main_waits(Ps)
+        ov = len(Ps) > 1 or Cn > 1
+        if 'rx' not in Ps[0]:
+            self.fetch_rows(Ps)
+        for h in Ps[0]['rx']:
+            h.wait()
         inner = events[1:5] if (events is not None and len(Ps) == 1) else None
         if inner is None:
             rec(1)
-        n_recv = [sum(ops.xsplits(P['recv_counts'])) for P in Ps]
-        grecv = None
-        pushed, off = [], 0
+        # ---- forward / backward + local reduction of every micro-batch; gradient rows leave chunk by chunk
+        pushed = [[None] * len(Ps) for _ in range(Cn)]
+        gbufs = []
+        n_recv = [[sum(ops.xsplits(P['recv_counts'][c])) for P in Ps] for c in range(Cn)]
+        grecv = [None] * Cn
         for m, (b, P) in enumerate(zip(bts, Ps)):
-            cache, w1 = fetched[m]
-            wait(w1)
-            gsend = ops.local_step(b, P, cache, b_norm, self.loss_kind, opt, events=inner)
+            for h in P['rx']:
+                h.wait()
+            gsend = ops.local_step(b, P, P['cache'], b_norm, self.loss_kind, opt, events=inner)
+            gbufs.append(gsend)
             if m == 0 and after_row_requests is not None:
-                # the run-ahead stages are ISSUED here — behind this step's row exchange on the communicator (they travel while the
-                # step computes) and in front of its gradient exchange, and while the training stream has the forward / backward and
-                # the reduction of this batch queued: the host time they take is hidden behind those kernels
+                # the run-ahead stages are ISSUED here — while the training stream has the forward / backward and the reduction of
+                # this batch queued: the host time they take is hidden behind those kernels; on the communicator they sit in front
+                # of this step's gradient exchange
                 after_row_requests()
-            if grecv is None:                          # one receive buffer for all micro-batches: segments stay adjacent
-                grecv = torch.empty(max(32, sum(n_recv)), dtype=gsend.dtype, device=gsend.device)
-            pushed.append((self._a2a(gsend, ops.xsplits(P['send_counts']), ops.xsplits(P['recv_counts']),
-                                     out=grecv[off:off + max(n_recv[m], 1)], overlap=ov)[1], gsend))
-            off += n_recv[m]
+            for c in range(Cn):
+                if grecv[c] is None:                       # one receive buffer per chunk for all micro-batches: segments stay adjacent
+                    grecv[c] = torch.empty(max(32, sum(n_recv[c])), dtype=gsend.dtype, device=gsend.device)
+                off = sum(n_recv[c][:m])
+                so = int(P['cache_off'][c])                # (the gradient buffer has the cache's geometry: chunk c's units at the same place)
+                pushed[c][m] = self._a2a(gsend[so:], ops.xsplits(P['send_counts'][c]), ops.xsplits(P['recv_counts'][c]),
+                                         out=grecv[c][off:off + max(n_recv[c][m], 1)], overlap=ov)[1]
         if inner is None:
             rec(2); rec(3); rec(4)
-        for w1, _ in pushed:
-            wait(w1)
+        # ---- owner side, chunk by chunk: apply what has arrived, then answer the next step's requests for the same key range
         head = Ps[0]
-        loss = ops.apply(head['req_all'], grecv, head['counts_all'], head['table'], b_norm, opt, want_loss=want_loss,
-                         own=[(g, P['send_counts']) for (_, g), P in zip(pushed, Ps)])
+        nxt = None
+        if next_prepared is not None:
+            nxt = list(next_prepared) if isinstance(next_prepared, (list, tuple)) else [next_prepared]
+            if not nxt or 'table' not in nxt[0]:       # (not ready: the next call fetches its rows itself)
+                nxt = None
+            else:
+                self._main_waits(nxt)
+        loss = None
+        for c in range(Cn):
+            for h in pushed[c]:
+                h.wait()
+            own = None
+            if getattr(ops, 'self_bypass', False):
+                # the rank's own pieces: behind all the units that travel, in chunk order
+                own = []
+                for g, P in zip(gbufs, Ps):
+                    base = int(P['cache_off'][Cn])
+                    own.append((g, base + sum(chunk_floats([P['send_counts'][cc][self.rank]], self.ld)[0] for cc in range(c))))
+            out = ops.apply(head['req_all'][c], grecv[c], head['counts_all'][c], head['table'], b_norm, opt,
+                            want_loss=want_loss and c == Cn - 1, own=own, chunk=c)
+            if c == Cn - 1:
+                loss = out
+            if nxt is not None:
+                self._fetch_chunk(nxt, c, True)
         rec(5)
+        for P in Ps:                                    # (buffers of a finished step: the pipeline reuses the dict's prepared buffer)
+            for k_ in ('cache', 'rx', 'cache_off'):
+                P.pop(k_, None)
         if after_apply is not None:
             after_apply()
         if want_loss:
@@ -427,11 +572,12 @@ class ShardedPipeline:
 
     Iteration s issues, in this program order (identical on every rank — one communicator):
         step(batch s) up to its forward / backward + reduction  ·  exchange_keys + index_owner(batch s+1)  ·
-        exchange_counts(batch s+3)  ·  prepare(batch s+4)  ·  rest of step(batch s)
-    The run-ahead exchanges sit behind step s's row exchange on the communicator and travel while step s computes; the count
-    exchange of batch s+1 was issued two iterations before iteration s reads its host-side result: the host never waits for it.  On a GPU the run-ahead stages use a side
-    stream; on CPU (gloo tests) everything runs inline in the same order.  `batch_of(s)` must return the DrxBatch (or the list of
-    micro-batches) of step s and be callable LOOKAHEAD steps ahead."""
+        exchange_counts(batch s+3)  ·  gradient exchange, owner apply and — chunk by chunk — gather + row exchange of batch s+1  ·
+        prepare(batch s+4)
+    The run-ahead exchanges travel while step s computes; the count exchange of batch s+1 was issued two iterations before iteration s
+    reads its host-side result: the host never waits for it.  On a GPU the run-ahead stages use a side stream; on CPU (gloo tests)
+    everything runs inline in the same order.  `batch_of(s)` must return the DrxBatch (or the list of micro-batches) of step s and be
+    callable LOOKAHEAD steps ahead."""
 
     LOOKAHEAD = 4
 
@@ -503,7 +649,7 @@ class ShardedPipeline:
         t0 = time.perf_counter()
         ahead_s = [0.0]
 
-        def run_ahead():                       # queued behind this step's row exchange on the communicator
+        def run_ahead():                       # queued while this step's forward / reduction are on the training stream
             ta = time.perf_counter()
             with self._on_side():
                 if s + 1 < self.n:
@@ -518,8 +664,9 @@ class ShardedPipeline:
                 with self._on_side():
                     self._prepare(s + self.LOOKAHEAD)
             ahead_s[0] += time.perf_counter() - ta
+        nxt = _Later(lambda: self.P.get(s + 1))       # (step s + 1's keys are exchanged inside this call: looked up when the tail starts)
         out = self.m.step(s, self._micro(s), events=events, want_loss=want_loss, prepared=self.P.pop(s),
-                          after_row_requests=run_ahead, after_apply=prepare_ahead)
+                          after_row_requests=run_ahead, after_apply=prepare_ahead, next_prepared=nxt if s + 1 < self.n else None)
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(self.main)
@@ -532,6 +679,17 @@ class ShardedPipeline:
         return out
 
 
+class _Later(list):
+    """the next step's prepared micro-batches, resolved when first iterated (they are completed during the current step)"""
+
+    def __init__(self, get):
+        super().__init__()
+        self._get = get
+
+    def __iter__(self):
+        return iter(self._get() or [])
+
+
 class _SideStream:
     """Makes `side` torch's current stream for the duration of the block and tells the model which stream is current (event records
     without the current-stream lookup).  torch.cuda.set_stream on the way in and out: the `torch.cuda.stream(...)` context manager
@@ -542,13 +700,14 @@ class _SideStream:
         self.model, self.side = model, side
 
     def __enter__(self):
+        self.prev = torch.cuda.current_stream(self.side.device)      # (whatever the caller had current: engine._on_stream does the same)
         torch.cuda.set_stream(self.side)
         self.model._cur = self.side
         return self
 
     def __exit__(self, *a):
         self.model._cur = None
-        torch.cuda.set_stream(self.model._main)
+        torch.cuda.set_stream(self.prev)
         return False
 
 

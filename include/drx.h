@@ -305,35 +305,49 @@ int drx_cdae_sparse_prepare_assemble(const DrxCdaeParams *p, const DrxBatch *bt,
  * them.  Users (V, histories, samples) are sharded by uid range; item rows (W, W2T, b2) by item range of `items_per_rank` rows; in
  * this mode DrxCdaeParams describes the LOCAL tables (n_users = local users, n_items = items_per_rank).
  *
- * WIRE keys of item rows are owner-major: item n of owner o = n / ipr is (o << shift) + (W2T row ? ipr : 0) + n - o * ipr, where
- * 1 << shift is the smallest power of two >= max(2 * ipr, 8192).  A rank's distinct keys ("uniq"), ascending, are contiguous per
- * owner, each owner's run closed by one SENTINEL key DRX_KEY_NONE: counts[o] = distinct rows asked of owner o + 1.
+ * WIRE keys of item rows are UNIT-major (r06).  Item n of owner o = n / ipr has the local key l = 2 * (n - o * ipr) + (W2T row ? 1 : 0);
+ * with 1 << shift the smallest power of two >= max(2 * ipr, 8192) and C = `chunks` (a power of two; the library lowers it until
+ * cshift = shift - log2 C >= 13), the local keys are cut into C EXCHANGE CHUNKS of 1 << cshift keys, unit v = (l >> cshift) * world + o,
+ * and the wire key is (v << cshift) | (l & ((1 << cshift) - 1)).  A rank's distinct keys ("uniq"), ascending, are contiguous per unit,
+ * each unit's run closed by one SENTINEL key DRX_KEY_NONE: n_v = distinct rows asked of owner v % world in chunk v / world, + 1.
+ * Chunk c of every exchange (keys, rows, gradient rows) is ONE all-to-all over the units c * world .. c * world + world - 1, which are
+ * contiguous in `uniq` and in the float buffers: the host pipelines the chunks (gradient rows of chunk c + 1 travel while the owner
+ * applies chunk c and gathers chunk c's rows for the next step).  chunks <= 1: one all-to-all per exchange (the r04 / r05 format).
  *
- * EXCHANGE BUFFER (float32, the same geometry in both directions, ONE collective each): for every peer, in rank order, a chunk of
- * n rows of ld floats followed by n scalars padded to a multiple of 32 floats — n * ld + roundup(n, 32) floats (n = counts[o] on the
- * requester's side, the received counts on the owner's).  Row i of a chunk answers key i of the peer's run.  Owner -> requester: the
- * parameter row, scalar = b2 of a W2T row; the sentinel row is unused.  Requester -> owner: the rank's summed gradient row, scalar =
- * gradient of b2; the SENTINEL row carries the rank's gradient of the replicated hidden bias b and, as its scalar, the rank's loss
- * sum — every rank adds the same `world` rows in rank order, so b needs no all-reduce. */
-#define DRX_MAX_WORLD 64                /* ranks of one sharded job (per-segment offsets travel as a kernel argument) */
+ * EXCHANGE BUFFER (float32, the same geometry in both directions): for every unit, in unit order, a piece of n rows of ld floats
+ * followed by n scalars padded to a multiple of 32 floats — n * ld + roundup(n, 32) floats (n = n_v on the requester's side, the
+ * received counts on the owner's: one SEGMENT per source rank and chunk).  Row i of a piece answers key i of the unit's run.
+ * Owner -> requester: the parameter row, scalar = b2 of a W2T row; the sentinel row is unused.  Requester -> owner: the rank's summed
+ * gradient row, scalar = gradient of b2; the SENTINEL rows carry the rank's gradient of the replicated hidden bias b and, as their
+ * scalar, the rank's loss sum — the owner adds those of the LAST chunk's `world` segments in rank order, the same rows on every rank,
+ * so b needs no all-reduce. */
+#define DRX_MAX_WORLD 64                /* world x chunks of one sharded job (per-unit offsets: DRX_MAX_WORLD + 1 entries) */
 #define DRX_MAX_MICRO 4                 /* micro-batches of one step (their exchanges overlap each other's compute) */
+#define DRX_MAX_CHUNKS 16               /* exchange chunks per owner */
 typedef struct DrxShard {
   int32_t world, rank;
   int32_t n_items;          /* global number of items */
   int32_t items_per_rank;   /* ceil(n_items / world) */
   int32_t n_users_local;
   uint32_t flags;           /* DRX_SHARD_* */
+  int32_t chunks;           /* exchange chunks per owner: 0 / 1 = one all-to-all per exchange, else a power of two <= DRX_MAX_CHUNKS */
 } DrxShard;
+/* the chunk count the library actually uses for a description (chunks lowered until every unit spans whole 8192-key tiles), and log2
+ * of a unit's key span; 0 for an invalid description */
+int32_t drx_shard_chunks(const DrxShard *sh);
+int32_t drx_shard_unit_shift(const DrxShard *sh);
 /* The rank's OWN item rows never pass through a collective: the forward kernel reads them from the local tables, the gather skips
- * the requests the rank sent to itself, and its own gradient chunk is read by drx_shard_apply where drx_shard_step_local left it.
- * The float exchange buffers then hold the chunks of the OTHER peers in rank order (split size 0 for the rank itself), and on the
- * requester's side the own chunk follows them (rows_cache never reads it, grad_send keeps it).  The KEY exchange is unchanged. */
+ * the requests the rank sent to itself, and its own gradient pieces are read by drx_shard_apply where drx_shard_step_local left them.
+ * The float exchange buffers then hold the units of the OTHER peers in unit order (split size 0 for the rank itself), and on the
+ * requester's side the own units (one per chunk, in chunk order) follow them all (rows_cache never reads them, grad_send keeps
+ * them).  The KEY exchange is unchanged. */
 #define DRX_SHARD_SELF_BYPASS 1u
 
 /* Parameter-independent preparation of one local batch, built ahead on a side stream: the sorted touch list with its span plan,
  * sole-toucher marks and launch order (as drx_cdae_sparse_prepare), plus the batch's distinct item rows: wire keys with sentinels, their
  * positions in the exchange buffers, per-owner counts.  `prepared` (256-byte aligned, drx_shard_prep_bytes) is opaque except for the
- * two arrays drx_shard_prep_layout names: out4 = { byte offset of uniq (uint32[capacity]), byte offset of counts (int64[world]),
+ * two arrays drx_shard_prep_layout names: out4 = { byte offset of uniq (uint32[capacity]), byte offset of counts (int64[world x chunks],
+ * OWNER-major: counts[o * chunks + c] = n of unit c * world + o — what the count exchange sends, `chunks` entries per peer),
  * capacity of uniq in keys, bytes a step reads }.  `work` (drx_shard_work_bytes) must be ZERO when first handed in; the library
  * leaves it zero after every call (it may be shared by all preparations issued on one stream). */
 size_t drx_shard_prep_bytes(const DrxCdaeParams *p, const DrxShard *sh, int32_t B, int32_t n_touch_slots);
@@ -341,14 +355,15 @@ size_t drx_shard_work_bytes(const DrxShard *sh);
 int drx_shard_prep_layout(const DrxCdaeParams *p, const DrxShard *sh, int32_t B, int32_t n_touch_slots, size_t *out4);
 int drx_shard_prepare(const DrxCdaeParams *p, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt, void *prepared,
                       size_t prepared_bytes, void *work, size_t work_bytes, void *stream);
-/* Owner side.  The n keys a rank received are `n_segments` = world x (micro-batches of the step, <= DRX_MAX_MICRO) segments,
- * micro-batch-major then source rank, recv_counts[s] (HOST array, sentinel included) keys in segment s.
- * drx_shard_owner_index: parameter-independent, run when the keys arrive: table[local key][segment] = index of the key
- * (drx_shard_owner_table_bytes).  drx_shard_gather_rows: the requested rows + scalars into an exchange buffer of the geometry above
+/* Owner side, ONE EXCHANGE CHUNK per call.  The n keys a rank received for chunk `chunk` are `n_segments` = world x (micro-batches of
+ * the step, <= DRX_MAX_MICRO) segments, micro-batch-major then source rank, recv_counts[s] (HOST array, sentinel included) keys in
+ * segment s.  drx_shard_owner_index: parameter-independent, run when the keys arrive: table[local key][segment] = index of the key in
+ * the chunk's key array (drx_shard_owner_table_bytes; ONE table for all chunks of a step — a call clears and fills the rows of its
+ * chunk's key range only).  drx_shard_gather_rows: the requested rows + scalars into an exchange buffer of the geometry above
  * (segment after segment). */
 size_t drx_shard_owner_table_bytes(const DrxShard *sh, int32_t n_segments);
 int drx_shard_owner_index(const DrxShard *sh, const uint32_t *recv_keys, int32_t n, const int32_t *recv_counts, int32_t n_segments,
-                          void *table, size_t table_bytes, void *stream);
+                          int32_t chunk, void *table, size_t table_bytes, void *stream);
 int drx_shard_gather_rows(const DrxCdaeParams *p, const DrxShard *sh, const uint32_t *recv_keys, int32_t n, const int32_t *recv_counts,
                           int32_t n_segments, float *out, void *stream);
 /* Requester side, three launches: forward + backward of the local triples against the received rows (`rows_cache`; V rows and W2T
@@ -360,14 +375,19 @@ size_t drx_shard_step_scratch_bytes(const DrxCdaeParams *p, int32_t B, int32_t n
 int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt,
                          const void *prepared, size_t prepared_bytes, const float *rows_cache, float *grad_send, int32_t b_norm,
                          int32_t loss_kind, void *scratch, size_t scratch_bytes, void *const *events, void *stream);
-/* Owner side: sum the gradient rows received for each owned row in segment order and apply the optimizer ONCE per row; one extra
- * workgroup sums the sentinel rows in segment order, updates b and writes loss_out[0] = global loss sum / b_norm (loss_out may be
- * NULL).  `table` = what drx_shard_owner_index built from the same keys.  With DRX_SHARD_SELF_BYPASS: own_grad[m] = the grad_send
- * buffer of the step's micro-batch m, own_off[m] = float offset of the rank's own chunk in it (= the floats of the chunks sent to
- * the other peers); otherwise both NULL. */
+/* Owner side, one exchange chunk per call: sum the gradient rows received for each owned row of the chunk in segment order and apply
+ * the optimizer ONCE per row; with the LAST chunk (chunk == chunks - 1) one extra workgroup sums the sentinel rows in segment order,
+ * updates b and writes loss_out[0] = global loss sum / b_norm (loss_out may be NULL).  `table` = what drx_shard_owner_index built from
+ * the same keys.  With DRX_SHARD_SELF_BYPASS: own_grad[m] = the grad_send buffer of the step's micro-batch m, own_off[m] = float offset
+ * of the rank's own piece OF THIS CHUNK in it; otherwise both NULL. */
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
-                    const float *grad_recv, int32_t n, const int32_t *recv_counts, int32_t n_segments, const void *table,
+                    const float *grad_recv, int32_t n, const int32_t *recv_counts, int32_t n_segments, int32_t chunk, const void *table,
                     const float *const *own_grad, const int64_t *own_off, float *loss_out, void *stream);
+
+/* drx_copy_f4: dst[0 .. n_bytes) = src[0 .. n_bytes) on the device (16-B aligned, n_bytes a multiple of 16, no overlap): a streaming
+ *   float4 copy kernel — table snapshots (recommender_abc.py:336-352 keeps a copy of every weight per epoch), and the rate bench.py
+ *   reports as `hbm_copy_achievable` (the achievable HBM rate measured on the box next to the nominal peak). */
+int drx_copy_f4(void *dst, const void *src, size_t n_bytes, void *stream);
 
 /* ---- model-independent pieces of the dense (Keras-Adam) steps of DMF / Caser ------------------------------------
  * drx_adam_dense: p, m, v [n] (16-B aligned): g_total = g + l2_coef * p (g may be NULL); TF ApplyAdam update with the

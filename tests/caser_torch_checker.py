@@ -1,24 +1,23 @@
-"""Caser outside the fused kernel's domain (d > 64 or L > 8; caser.py:29-30 takes any L / d).
-
-drx_caser.hip gives a lane of one wavefront to every embedding channel (d <= 64) and unrolls the window over L <= 8 rows; wider or
-longer models keep the reference's semantics through this engine instead: the forward of caser.py:97-120 is written with torch
-operations on the device and differentiated by torch.autograd (where the reference has tf.GradientTape), the update is the library's
-dense Keras-Adam kernel (drx_adam_dense: one apply per registered layer, t = (6 + L) * step + j + 1, l2 on embeddings and kernels) —
-the same split as RecommenderABC._tape_do_batch.  It is the escape hatch for constructor arguments the tuned kernel does not take, not a
-measured path: BASELINE configuration 5 (d = 50, L = 5) never comes here.  Same interface as engine_caser.CaserEngine."""
+"""TEST INFRASTRUCTURE — a second checker for Caser: the forward of caser.py:97-120 written with torch operations and differentiated by
+torch.autograd (where the reference has tf.GradientTape), the update the library's dense Keras-Adam kernel (drx_adam_dense: one apply
+per registered layer, t = (6 + L) * step + j + 1, l2 on embeddings and kernels).  Through round 5 this file was a product backend
+(drecpy_amd/engine_caser_wide.py) for constructor arguments outside the fused HIP kernel's domain; the product now REJECTS those
+arguments (Recommender/caser.py) and nothing under drecpy_amd/ imports torch.autograd for a built-in model.  It stays here because it
+is an independent statement of the same arithmetic: tests hold it against oracle/caser_oracle.py and hold the HIP kernels against it.
+Same interface as drecpy_amd.engine_caser.CaserEngine."""
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import check, lib, stream_ptr
-from .engine import ADAM_B1, ADAM_B2, ADAM_EPS
+from drecpy_amd import _lib
+from drecpy_amd._lib import check, lib, stream_ptr
+from drecpy_amd.engine import ADAM_B1, ADAM_B2, ADAM_EPS
 
 
 def _act(kind):
     return {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid, 'linear': (lambda v: v), None: (lambda v: v)}[kind]
 
 
-class CaserWideEngine:
+class CaserTorchChecker:
     table_update = 'dense'
 
     def __init__(self, n_users, n_items, L=5, T=3, neg_ratio=3, d=50, n_v=4, n_h=16, device='cuda:0', act_h='relu', act_mlp='relu'):
@@ -48,7 +47,7 @@ class CaserWideEngine:
         self.n_layers = 6 + L
         self.lr, self.reg = 1e-3, 1e-3
         self.beta1, self.beta2, self.eps = ADAM_B1, ADAM_B2, ADAM_EPS
-        from .Recommender.trainables import TrainableLayer
+        from drecpy_amd.Recommender.trainables import TrainableLayer
         names = ['user_embeddings', 'item_embeddings', 'conv_v'] + [f'convs_h[{i}]' for i in range(L)] + ['dense_0', 'dense_1_W', 'dense_1_b']
         self.layers = [TrainableLayer(nm, (lambda ks=ks: [self.p[k] for k in ks])) for nm, ks in zip(names, self.order)]
 

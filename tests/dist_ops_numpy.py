@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from oracle import cdae_oracle as co
-from drecpy_amd.dist import chunk_floats, items_per_rank, pad32, wire_key, wire_shift
+from drecpy_amd.dist import chunk_floats, items_per_rank, pad32, wire_chunks, wire_key, wire_local, wire_shift
 
 NONE = 0xFFFFFFFF
 
@@ -23,8 +23,9 @@ def np_batch(uid, iid, y, indptr, q, mask_seed=0, keep=None):
 
 
 def _chunk_offsets(counts, ld, skip=None, world=1, own_last=False):
-    """(first key index, float offset of the rows, float offset of the scalars) of every chunk of an exchange buffer.  skip: the
-    rank whose chunks are NOT in the buffer (self-bypass) — entry None, or, with own_last (requester side), placed behind the others"""
+    """(first key index, float offset of the rows, float offset of the scalars) of every piece of an exchange buffer whose pieces —
+    segments on the owner's side, units on the requester's — hold `counts` rows.  skip: the rank whose pieces are NOT in the buffer
+    (self-bypass) — entry None, or, with own_last (requester side), placed behind all the others in order"""
     out, k, f = [], 0, 0
     for i, c in enumerate(counts):
         if skip is not None and i % world == skip:
@@ -34,18 +35,24 @@ def _chunk_offsets(counts, ld, skip=None, world=1, own_last=False):
             f += int(c) * ld + pad32(c)
         k += int(c)
     if own_last and skip is not None:
-        k0 = sum(int(c) for c in counts[:skip])
-        out[skip] = (k0, f, f + int(counts[skip]) * ld)
+        k = 0
+        for i, c in enumerate(counts):
+            if i % world == skip:
+                out[i] = (k, f, f + int(c) * ld)
+                f += int(c) * ld + pad32(c)
+            k += int(c)
     return out
 
 
 class NumpyShardOps:
-    def __init__(self, n_users_local, n_items, k, rank, world, indptr, indices, lr, reg, self_bypass=True):
+    def __init__(self, n_users_local, n_items, k, rank, world, indptr, indices, lr, reg, self_bypass=True, chunks=1):
         self.rank, self.world, self.k = rank, world, k
         self.self_bypass = self_bypass
         self.ld = k
         self.ipr = items_per_rank(n_items, world)
         self.shift = wire_shift(self.ipr)
+        self.chunks = wire_chunks(self.ipr, chunks)
+        self.cshift = self.shift - (self.chunks.bit_length() - 1)         # log2 of a unit's key span
         self.n_items, self.n_users_local = n_items, n_users_local
         self.indptr, self.indices = np.asarray(indptr, np.int64), np.asarray(indices, np.int64)
         self.lr, self.reg = lr, reg
@@ -72,27 +79,33 @@ class NumpyShardOps:
         return self.indices[s:e][kf]
 
     # -- parameter-independent
+    def _wire(self, n, is_out):
+        return wire_key(int(n), self.ipr, is_out, self.world, self.chunks)
+
     def prepare(self, bt):
-        """Distinct wire keys of the batch's item rows, ascending, every owner's run closed by a sentinel; counts per owner."""
+        """Distinct wire keys of the batch's item rows, ascending, every UNIT's run (chunk-major, then owner) closed by a sentinel;
+        counts owner-major ([owner][chunk]: what the count exchange sends)."""
         keys = set()
         for b in range(bt.B):
             for n in self._kept(bt, b):
-                keys.add(wire_key(int(n), self.ipr, False))
-            keys.add(wire_key(int(bt.iid[b]), self.ipr, True))
-        uniq, counts = [], []
-        for o in range(self.world):
-            mine = sorted(k for k in keys if (k >> self.shift) == o)
+                keys.add(self._wire(n, False))
+            keys.add(self._wire(bt.iid[b], True))
+        uniq, per_unit = [], []
+        for v in range(self.world * self.chunks):
+            mine = sorted(k for k in keys if (k >> self.cshift) == v)
             uniq += mine + [NONE]
-            counts.append(len(mine) + 1)
+            per_unit.append(len(mine) + 1)
+        counts = [per_unit[c * self.world + o] for o in range(self.world) for c in range(self.chunks)]
         pos = {k: i for i, k in enumerate(uniq) if k != NONE}
-        return {'uniq': torch.tensor(uniq, dtype=torch.int64), 'counts': counts, 'pos': pos}
+        return {'uniq': torch.tensor(uniq, dtype=torch.int64), 'counts': counts, 'pos': pos, 'per_unit': per_unit}
 
-    def owner_index(self, req, recv_counts, slot=0):
+    def owner_index(self, req, recv_counts, slot=0, chunk=0):
         return None
 
     def _local(self, key):
-        t = key - (self.rank << self.shift)
-        return (t >= self.ipr), (t - self.ipr if t >= self.ipr else t)
+        o, c, is_out, row = wire_local(int(key), self.ipr, self.world, self.chunks)
+        assert o == self.rank
+        return is_out, row
 
     def xsplits(self, counts):
         f = chunk_floats(counts, self.ld)
@@ -102,7 +115,7 @@ class NumpyShardOps:
         return self.rank if self.self_bypass else None
 
     # -- parameter-dependent
-    def gather_rows(self, req, recv_counts):
+    def gather_rows(self, req, recv_counts, out=None):
         r = req.numpy()
         out = np.zeros(sum(self.xsplits(recv_counts)))
         for ch, c in zip(_chunk_offsets(recv_counts, self.ld, self._skip(), self.world), recv_counts):
@@ -129,31 +142,31 @@ class NumpyShardOps:
         cache = rows_cache.numpy()
         B, K = bt.B, self.k
         dt = np.dtype(np.float64)
-        offs = _chunk_offsets(P['counts'], self.ld, self._skip(), self.world, own_last=True)
+        offs = _chunk_offsets(P['per_unit'], self.ld, self._skip(), self.world, own_last=True)
 
         def where(key):
-            o = key >> self.shift
-            k0, f0, s0 = offs[o]
+            v = key >> self.cshift
+            k0, f0, s0 = offs[v]
             i = P['pos'][key] - k0
             return f0 + i * self.ld, s0 + i
 
         def row_of(key):                       # an own row comes from the tables, any other from the cache
-            if self.self_bypass and (key >> self.shift) == self.rank:
+            if self.self_bypass and (key >> self.cshift) % self.world == self.rank:
                 is_out, row = self._local(key)
                 return (self.W2T[row], self.b2[row]) if is_out else (self.W[row], 0.0)
             r0, s0 = where(key)
             return cache[r0:r0 + K], cache[s0]
-        gsend = np.zeros(sum(chunk_floats(P['counts'], self.ld)))
+        gsend = np.zeros(sum(chunk_floats(P['per_unit'], self.ld)))
         s = 1.0 / (1.0 - bt.q)
         gv, gb, loss = {}, np.zeros(K), 0.0
         for b in range(B):
-            kept = [wire_key(int(n), self.ipr, False) for n in self._kept(bt, b)]
+            kept = [self._wire(n, False) for n in self._kept(bt, b)]
             acc = np.zeros(K)
             for key in kept:
                 acc += row_of(key)[0]
             u = int(bt.uid[b])
             h = co.sigmoid(s * acc + self.V[u] + self.b)
-            ko = wire_key(int(bt.iid[b]), self.ipr, True)
+            ko = self._wire(bt.iid[b], True)
             ro, so = where(ko)
             w2, b2v = row_of(ko)
             p = co.sigmoid(h @ w2 + b2v)
@@ -175,23 +188,23 @@ class NumpyShardOps:
             gb += dz1
         for u, g in gv.items():
             self._update('V', u, g, b_norm)
-        for (k0, f0, s0), c in zip(offs, P['counts']):              # the sentinel rows: bias gradient, loss sum
+        for (k0, f0, s0), c in zip(offs, P['per_unit']):            # the sentinel rows (every unit's): bias gradient, loss sum
             i = int(c) - 1
             gsend[f0 + i * self.ld:f0 + (i + 1) * self.ld] = gb
             gsend[s0 + i] = loss
         return torch.from_numpy(gsend)
 
-    def apply(self, req, grecv, recv_counts, table, b_norm, opt, want_loss=False, own=None):
+    def apply(self, req, grecv, recv_counts, table, b_norm, opt, want_loss=False, own=None, chunk=0):
+        """one exchange chunk: the rows of its key range; b and the loss with the LAST chunk (its sentinels)"""
         k, g = req.numpy(), grecv.numpy()
         tot, tots = {}, {}
         gb, loss = np.zeros(self.k), 0.0
         offs = _chunk_offsets(recv_counts, self.ld, self._skip(), self.world)
         k0 = 0
         for s, (ch, c) in enumerate(zip(offs, recv_counts)):       # segment order = micro-batch, then source rank
-            if ch is None:                                          # the chunk this rank "sent" to itself: still in its own buffer
-                og, sc_ = own[s // self.world]
+            if ch is None:                                          # the piece this rank "sent" to itself: still in its own buffer
+                og, f0 = own[s // self.world]
                 src = og.numpy()
-                f0 = sum(self.xsplits(sc_))
                 s0 = f0 + int(c) * self.ld
             else:
                 src, (_, f0, s0) = g, ch
@@ -209,5 +222,6 @@ class NumpyShardOps:
             self._update('W2T' if is_out else 'W', row, tot[key], b_norm)
             if is_out:
                 self._update('b2', row, tots[key], b_norm, reg=False)
-        self._update('b', slice(None), gb, b_norm, reg=False)
+        if chunk == self.chunks - 1:
+            self._update('b', slice(None), gb, b_norm, reg=False)
         return loss / b_norm if want_loss else None

@@ -68,25 +68,6 @@ def test_a_failing_layout_is_reported_not_fatal(tmp_path):
     assert out.returncode != 0 and d['value'] is None and 'error' in d['layouts']['columns']
 
 
-def test_pmc_traffic_profile_was_taken_on_these_kernel_sources():
-    """bench.py quotes profiles/pmc_traffic.json only when its kernel-source hash equals the tree's; a stale file means the driver's line
-    carries `traffic: null` (it happened in r03: the passes were re-taken on the GPU box and only the per-round copy was committed).
-    Re-run scripts/profile_round.sh and copy gpurun_out/<tag>/pmc_traffic.json to profiles/pmc_traffic.json when this fails."""
-    import json
-    import os
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, root)
-    import bench
-    with open(os.path.join(root, 'profiles', 'pmc_traffic.json')) as f:
-        meta = json.load(f)['_meta']
-    if meta['kernel_source_hash'] != bench.kernel_source_hash():
-        # (a stale file costs the line its `traffic` field, nothing else: reported, not red — the CPU suite runs with -x and a kernel edit
-        # made after the last GPU-box call of a round must not hide every test behind this one)
-        pytest.skip('profiles/pmc_traffic.json is stale: taken on kernel sources %s, the tree is %s — re-run scripts/profile_round.sh'
-                    % (meta['kernel_source_hash'], bench.kernel_source_hash()))
-
-
 def test_row_statistics_of_the_shared_form_match_a_brute_force_count():
     """bench.batch_row_stats(share=True) — the byte model's touches / row loads / work items of DRX_BATCH_SHARE_USERS lists — against a
     plain-Python count of the rule of csrc/drx_prep.hpp (k_tp_item_* / k_tp_expand<SHARE>): the samples of a user, ascending, in work

@@ -18,33 +18,44 @@ from helpers import new_rendezvous  # noqa: E402
 U, N, K, B, STEPS, Q = 40, 57, 6, 24, 3, 0.2
 
 
-def _problem(world=2):
+def _problem(world=2, n_items=N):
+    """n_items > N: the same 57 "live" items spread over a larger id range by a fixed permutation — the exchange CHUNKS cut an owner's
+    key range into pieces of at least 8192 keys, so a chunked exchange needs 2 * items_per_rank > 8192 * chunks / 2 to have more than
+    one chunk, and live items in all of them."""
     from oracle import cdae_oracle as co
     from helpers import synth_history
     rng = np.random.default_rng(11)
-    p = co.init_params(rng, U, N, K, np.float64)
+    p = co.init_params(rng, U, n_items, K, np.float64)
     indptr, indices = synth_history(rng, U, N, 7, zipf=1.1)
+    spread = np.sort(np.random.default_rng(5).choice(n_items, size=N, replace=False)) if n_items > N else np.arange(N)
+    spread = spread[np.random.default_rng(6).permutation(N)] if n_items > N else spread
+    # (columns of a history row stay ascending: re-sort every row after the spread)
+    ind2 = spread[indices].astype(np.int32)
+    for u in range(U):
+        ind2[indptr[u]:indptr[u + 1]].sort()
     batches = []
     for s in range(STEPS):
         per_rank = []
         for r in range(world):
             lo, hi = U * r // world, U * (r + 1) // world
-            per_rank.append((rng.integers(lo, hi, size=B), rng.integers(0, N, size=B), (rng.random(B) < 0.3).astype(np.float64),
+            per_rank.append((rng.integers(lo, hi, size=B), spread[rng.integers(0, N, size=B)], (rng.random(B) < 0.3).astype(np.float64),
                              1000 + 17 * s + r))
         batches.append(per_rank)
-    return p, indptr, indices, batches
+    return p, indptr, ind2, batches
 
 
-def _worker(rank, world, rdzv, out, pipelined=False, micro=1, bypass=True):
+def _worker(rank, world, rdzv, out, pipelined=False, micro=1, bypass=True, chunks=1, n_items=N):
     dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
     from drecpy_amd.dist import ShardedCdae
     from dist_ops_numpy import NumpyShardOps, np_batch
-    p, indptr, indices, batches = _problem(world)
+    p, indptr, indices, batches = _problem(world, n_items)
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
-    ops = NumpyShardOps(hi - lo, N, K, rank, world, lip, lidx, 0.05, 1e-3, self_bypass=bypass)
-    m = ShardedCdae(U, N, K, rank, world, 'cpu', lip, lidx, ops=ops, q=Q)
+    ops = NumpyShardOps(hi - lo, n_items, K, rank, world, lip, lidx, 0.05, 1e-3, self_bypass=bypass, chunks=chunks)
+    assert ops.chunks == chunks, (ops.chunks, chunks)
+    m = ShardedCdae(U, n_items, K, rank, world, 'cpu', lip, lidx, ops=ops, q=Q, chunks=chunks)
+    assert m.chunks == chunks
     m.set_params_global(**p)
     losses = []
 
@@ -67,17 +78,24 @@ def _worker(rank, world, rdzv, out, pipelined=False, micro=1, bypass=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('pipelined,micro,world,bypass', [(False, 1, 2, True), (True, 1, 2, True), (True, 2, 2, True), (False, 3, 2, False),
-                                                          (True, 1, 3, True), (True, 2, 4, True), (True, 1, 2, False), (True, 2, 3, False)])
-def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, world, bypass):
+@pytest.mark.parametrize('pipelined,micro,world,bypass,chunks,n_items', [
+    (False, 1, 2, True, 1, N), (True, 1, 2, True, 1, N), (True, 2, 2, True, 1, N), (False, 3, 2, False, 1, N),
+    (True, 1, 3, True, 1, N), (True, 2, 4, True, 1, N), (True, 1, 2, False, 1, N), (True, 2, 3, False, 1, N),
+    # the chunked schedule (r06): every exchange in `chunks` all-to-alls, the owner apply of chunk c followed by the gather + row exchange
+    # of the NEXT step's chunk c (pipelined) or every step fetching its own rows (inline)
+    (True, 1, 2, True, 2, 9000), (True, 1, 2, False, 4, 17000), (False, 1, 3, True, 2, 13000), (True, 2, 2, True, 2, 9000),
+    (True, 1, 4, True, 4, 34000), (True, 2, 3, False, 2, 13000)])
+def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, world, bypass, chunks, n_items):
     """micro > 1: every rank's batch is split into micro-batches with disjoint users whose exchanges overlap each other's
     compute; the step must still equal the single-process step on the concatenated batch.  bypass: a rank's own rows never pass
-    through the collectives (split size 0 for itself); off: every row travels."""
+    through the collectives (split size 0 for itself); off: every row travels.  chunks > 1: the exchanges cut into key-range chunks and
+    pipelined with the owner apply / the next step's gather (drecpy_amd/dist.py module docstring)."""
     from oracle import cdae_oracle as co
+    N = n_items
     out = str(tmp_path / 'shard')
     rdzv = new_rendezvous(tmp_path)
-    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro, bypass), nprocs=world, join=True)
-    p, indptr, indices, batches = _problem(world)
+    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro, bypass, chunks, n_items), nprocs=world, join=True)
+    p, indptr, indices, batches = _problem(world, n_items)
     st = co.sparse_state(p, 'adagrad')
     want_losses = []
     for s in range(STEPS):
@@ -246,3 +264,26 @@ def test_lists_built_in_turns_reach_every_rank(tmp_path, world):
         for s, (built_here, res) in enumerate(got):
             assert built_here == (s % world == r)
             assert torch.equal(res, torch.arange(_FakePrepEngine.RESULT, dtype=torch.uint8) + (3 * s + 1))
+
+
+def test_wire_keys_are_unit_major_and_invertible():
+    """include/drx.h WIRE keys: unit v = chunk * world + owner holds one (chunk, owner) key range; keys of a unit are contiguous, the
+    map (item, W2T?) -> key is injective and wire_local inverts it; chunks are lowered until a unit spans >= 8192 keys."""
+    from drecpy_amd.dist import items_per_rank, wire_chunks, wire_key, wire_local, wire_shift
+    for n_items, world, chunks in ((57, 2, 4), (9000, 2, 2), (17000, 2, 4), (34000, 4, 4), (1_000_000, 8, 8)):
+        ipr = items_per_rank(n_items, world)
+        C = wire_chunks(ipr, chunks)
+        cs = wire_shift(ipr) - (C.bit_length() - 1)
+        assert cs >= 13 and (C == chunks or wire_shift(ipr) - (chunks.bit_length() - 1) < 13)
+        rng = np.random.default_rng(n_items)
+        items = np.unique(np.concatenate([rng.integers(0, n_items, size=400), [0, n_items - 1, ipr - 1, min(ipr, n_items - 1)]]))
+        seen = set()
+        for n in items.tolist():
+            for is_out in (False, True):
+                k = wire_key(n, ipr, is_out, world, C)
+                assert k not in seen and k < (world << wire_shift(ipr))
+                seen.add(k)
+                o, c, out_, li = wire_local(k, ipr, world, C)
+                assert (o, out_, li) == (n // ipr, is_out, n - (n // ipr) * ipr)
+                assert (k >> cs) == c * world + o and c == (2 * li + int(is_out)) >> cs
+    assert wire_chunks(items_per_rank(57, 2), 4) == 1 and wire_chunks(items_per_rank(1_000_000, 8), 8) == 8

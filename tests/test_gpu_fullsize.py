@@ -1,4 +1,5 @@
-"""Size-independent properties of the sampled step at BASELINE sizes (no oracle can follow at this scale):
+"""The sampled step at BASELINE sizes: size-independent properties (the oracle cannot follow whole tables of this scale) and — r06 —
+one full-size step against the oracle on tables compacted to the rows the batch names (the last test of this file):
   * ml-1m-shaped (config 2 of BASELINE.json: U=6040, N=3706, K=128), a 1M-user slice of the 10M x 1M set, and the
     whole 10M-user x 1M-item x ~200M-interaction set of config 4 (one GPU holds all of it: 12.3 GB of tables + slots)
   * bit-reproducibility of a step sequence, `prepared` (side-stream) == inline touch lists bit for bit,
@@ -127,3 +128,73 @@ def test_pipeline_batches_are_the_draws_of_their_seeds_while_the_callers_stream_
         pipe.run_step()
     torch.cuda.synchronize()
     assert bool(torch.isfinite(eng.W).all())
+
+
+def test_one_full_size_step_matches_the_oracle_on_compacted_tables():
+    """BASELINE configuration 4 at FULL size against the oracle: one device-sampled batch of 65 536 triples on the
+    real 10M-user x 1M-item tables through (a) step_sparse on a list prepared ahead — the streamed reduction, the bench's code path —
+    and (b) ShardedCdae at world 1, against cdae_oracle.sparse_step(accumulate='matrix') (cdae.py:59-76 restricted to the sampled output
+    unit; fp64) on a copy of the tables COMPACTED to the rows the batch's users and items name (bench_cpu.py's compaction: same
+    arithmetic per triple, the untouched 99 % of the tables left out).  Touched rows to atol 2e-5, the parameters no triple touches bit-equal,
+    predictions of touched users <= 1e-5 relative after the step."""
+    from oracle import cdae_oracle as co
+    from drecpy_amd.dist import ShardedCdae
+    B, K, q, lr, reg, seed = 65536, 128, 0.2, 0.05, 1e-3, 4242
+    eng, U, N, ip, idx = _setup('synth-10m')
+    m = ShardedCdae(U, N, K, 0, 1, 'cuda:0', ip, idx, q=q, lr=lr, reg=reg)
+    for dst, src in zip(m.engine.tables(), eng.tables()):
+        dst.copy_(src)
+    uid, iid, y, ko = eng.sample_device(B, 5, seed, n_items=N)
+    torch.cuda.synchronize()
+    # ---- compaction: every history item of the batch's users (kept or dropped) + the output items; the batch's users
+    ul_, deg = uid.long(), (ip[uid.long() + 1] - ip[uid.long()])
+    T = int(deg.sum())
+    assert T == int(ko[-1].item())
+    row = torch.repeat_interleave(torch.arange(B, device='cuda'), deg)
+    j = torch.arange(T, device='cuda') - torch.repeat_interleave(torch.cumsum(deg, 0) - deg, deg)
+    items = idx[(ip[ul_][row] + j)].long()
+    keep = torch.as_tensor(co.drx_hash_u32(seed, row.cpu().numpy(), j.cpu().numpy()) >= co.q_threshold(q)).cuda()
+    il = torch.unique(torch.cat([items, iid.long()]))
+    uu = torch.unique(ul_)
+    imap = torch.full((N,), -1, dtype=torch.long, device='cuda'); imap[il] = torch.arange(il.numel(), device='cuda')
+    umap = torch.full((U,), -1, dtype=torch.long, device='cuda'); umap[uu] = torch.arange(uu.numel(), device='cuda')
+    f64 = lambda t: t.double().cpu().numpy()
+    p = {'W': f64(eng.W[il, :K]), 'W_': np.ascontiguousarray(f64(eng.W2T[il, :K]).T), 'V': f64(eng.V[uu, :K]), 'b': f64(eng.b[:K]),
+         'b_': f64(eng.b2[il])}
+    before = [t.clone() for t in eng.tables()]
+    kept_flat = imap[items[keep]].cpu().numpy()
+    kept_len = torch.zeros(B, dtype=torch.long, device='cuda').index_add_(0, row[keep], torch.ones(int(keep.sum()), dtype=torch.long, device='cuda'))
+    kept = np.split(kept_flat, np.cumsum(kept_len.cpu().numpy())[:-1])
+    cu, ci, yy = umap[ul_].cpu().numpy(), imap[iid.long()].cpu().numpy(), y.cpu().numpy().astype(np.float64)
+    # ---- the two device paths
+    bt, alive = eng.make_batch(uid, iid, y, keep_off=ko, q=q, mask_seed=seed)
+    prep = eng.prepare_sparse(bt)
+    eng.step_sparse(0, bt, prepared=prep)
+    bt2, alive2 = m.engine.make_batch(uid, iid, y, keep_off=ko, q=q, mask_seed=seed)
+    m.step(0, bt2)
+    torch.cuda.synchronize()
+    # ---- the oracle on the compacted copy
+    st = co.sparse_state(p, 'adagrad')
+    co.sparse_step(p, st, 0, cu, ci, yy, kept, float(np.float32(q)), lr, reg, 'bce', 'adagrad', accumulate='matrix')
+    for name, e in (('direct', eng), ('rows layout, world 1', m.engine)):
+        got = {'W': f64(e.W[il, :K]), 'W_': f64(e.W2T[il, :K]).T, 'V': f64(e.V[uu, :K]), 'b': f64(e.b[:K]), 'b_': f64(e.b2[il])}
+        for k_ in p:
+            np.testing.assert_allclose(got[k_], p[k_], rtol=0, atol=2e-5, err_msg=f'{name}: {k_}')
+    # ---- rows the batch does not name keep their bits
+    tw = torch.zeros(N, dtype=torch.bool, device='cuda'); tw[items[keep]] = True
+    to = torch.zeros(N, dtype=torch.bool, device='cuda'); to[iid.long()] = True
+    tu = torch.zeros(U, dtype=torch.bool, device='cuda'); tu[uu] = True
+    for e in (eng, m.engine):
+        assert torch.equal(before[0][~tw], e.W[~tw]) and torch.equal(before[1][~to], e.W2T[~to])
+        assert torch.equal(before[2][~tu], e.V[~tu]) and torch.equal(before[4][~to], e.b2[~to])
+    assert int(tw.sum()) > 200_000 and int(tu.sum()) > 60_000          # (the batch's footprint: ~260 k distinct W rows, ~65 k users)
+    # ---- predictions of touched users after the step (cdae.py:67-71: uncorrupted, unscaled input) on the compacted item columns
+    probe = uu[torch.linspace(0, uu.numel() - 1, 48, device='cuda').long()]
+    _, pred = eng.forward(probe.to(torch.int32))
+    pu = umap[probe].cpu().numpy()
+    t = np.zeros((len(pu), il.numel()))
+    for r, u in enumerate(probe.tolist()):
+        t[r, imap[idx[ip[u]:ip[u + 1]].long()].cpu().numpy()] = 1.0
+    _, po = co.forward(p, pu, t)
+    rel = np.abs(f64(pred[:, il]) - po) / np.abs(po)
+    assert rel.max() < 1e-5, rel.max()

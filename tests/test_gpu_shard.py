@@ -19,6 +19,9 @@ from helpers import new_rendezvous, retry_infra  # noqa: E402
 pytestmark = pytest.mark.gpu
 U, N, K, B, STEPS, Q = 300, 411, 50, 512, 4, 0.2
 K = int(os.environ.get('DRX_TEST_SHARD_K', K))          # (spawned ranks re-import this module: a test hands its K over this way)
+N_LIVE = N
+N = int(os.environ.get('DRX_TEST_SHARD_N', N))          # > 411: the 411 live items spread over a wider id range (room for exchange chunks)
+CHUNKS = int(os.environ.get('DRX_TEST_SHARD_CHUNKS', 1))
 
 
 def _problem(world):
@@ -26,13 +29,19 @@ def _problem(world):
     from helpers import synth_history
     rng = np.random.default_rng(5)
     p = co.init_params(rng, U, N, K, np.float32)
-    indptr, indices = synth_history(rng, U, N, 12, zipf=1.2)
+    indptr, indices = synth_history(rng, U, N_LIVE, 12, zipf=1.2)
+    spread = np.arange(N_LIVE)
+    if N > N_LIVE:          # an exchange chunk spans >= 8192 wire keys: live items in every chunk need a wide id range
+        spread = np.random.default_rng(6).permutation(np.sort(np.random.default_rng(7).choice(N, size=N_LIVE, replace=False)))
+        indices = spread[indices].astype(np.int32)
+        for u in range(U):
+            indices[indptr[u]:indptr[u + 1]].sort()
     batches = []
     for s in range(STEPS):
         per_rank = []
         for r in range(world):
             lo, hi = U * r // world, U * (r + 1) // world
-            per_rank.append((rng.integers(lo, hi, size=B), rng.integers(0, N, size=B), (rng.random(B) < 0.3).astype(np.float32),
+            per_rank.append((rng.integers(lo, hi, size=B), spread[rng.integers(0, N_LIVE, size=B)], (rng.random(B) < 0.3).astype(np.float32),
                              500 + 31 * s + r))
         batches.append(per_rank)
     return p, indptr, indices, batches
@@ -69,7 +78,9 @@ def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1, bypass
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
-    m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force, self_bypass=bypass)
+    m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force, self_bypass=bypass,
+                    chunks=CHUNKS)
+    assert m.chunks == CHUNKS, (m.chunks, CHUNKS)
     m.set_params_global(**p)
     losses, made = [], {}
 
@@ -175,3 +186,48 @@ def test_sharded_world1_other_row_geometries(k, monkeypatch):
     import sys as _sys
     monkeypatch.setattr(_sys.modules[__name__], 'K', k)
     _check(1, [_run_rank(0, 1, False, pipelined=True)])
+
+
+# ---- the chunked exchange schedule (r06): every exchange in CHUNKS all-to-alls over key ranges, owner apply of chunk c followed by the
+# gather + row exchange of the next step's chunk c -------------------------------------------------------------------------------------
+def _chunked(monkeypatch, n_items, chunks, k=None):
+    import sys as _sys
+    mod = _sys.modules[__name__]
+    monkeypatch.setenv('DRX_TEST_SHARD_N', str(n_items))
+    monkeypatch.setenv('DRX_TEST_SHARD_CHUNKS', str(chunks))
+    monkeypatch.setattr(mod, 'N', n_items)
+    monkeypatch.setattr(mod, 'CHUNKS', chunks)
+    if k is not None:
+        monkeypatch.setenv('DRX_TEST_SHARD_K', str(k))
+        monkeypatch.setattr(mod, 'K', k)
+
+
+@pytest.mark.parametrize('pipelined,micro,bypass,chunks,n_items,k', [(True, 1, False, 4, 9000, 50), (True, 1, True, 2, 5000, 50), (False, 1, False, 2, 5000, 50),
+                                                                     (True, 2, False, 2, 5000, 50), (True, 1, False, 4, 9000, 128), (True, 1, True, 8, 17000, 128)])
+def test_sharded_world1_chunked_matches_oracle(monkeypatch, pipelined, micro, bypass, chunks, n_items, k):
+    _chunked(monkeypatch, n_items, chunks, k)
+    _check(1, [_run_rank(0, 1, False, pipelined=pipelined, micro=micro, bypass=bypass)], micro)
+
+
+@pytest.mark.parametrize('pipelined,micro,world,bypass,chunks,n_items,k', [(True, 1, 2, True, 2, 9000, 50), (True, 1, 3, False, 2, 13000, 50),
+                                                                           (True, 2, 2, True, 2, 9000, 50), (True, 1, 2, False, 4, 17000, 128)])
+@retry_infra
+def test_sharded_ranks_on_one_gpu_chunked_match_oracle(tmp_path, monkeypatch, pipelined, micro, world, bypass, chunks, n_items, k):
+    """`world` processes share the GPU (gloo + host-staged exchanges); exchanges in 2 / 4 chunks; K = 128: the streamed local reduction
+    parks its sums in the units of several owners AND chunks."""
+    _chunked(monkeypatch, n_items, chunks, k)
+    out = str(tmp_path / 'shard')
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker, args=(world, rdzv, out, pipelined, micro, bypass), nprocs=world, join=True)
+    _check(world, [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)], micro)
+
+
+@pytest.mark.parametrize('pipelined,micro,bypass,chunks', [(True, 1, False, 4), (True, 2, False, 2), (True, 1, True, 4)])
+def test_sharded_step_through_rccl_world1_chunked(tmp_path, monkeypatch, pipelined, micro, bypass, chunks):
+    """The chunked call sequence on a real 1-rank RCCL communicator: asynchronous all-to-all(v) per chunk, the training stream waiting
+    chunk by chunk."""
+    _chunked(monkeypatch, 9000, chunks)
+    out = str(tmp_path / 'rccl')
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_worker_rccl, args=(rdzv, out, pipelined, micro, bypass), nprocs=1, join=True)
+    _check(1, [torch.load(f'{out}.0', weights_only=False)], micro)

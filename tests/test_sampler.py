@@ -324,6 +324,13 @@ sys.exit(os.WEXITSTATUS(st))
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
+    # ... and a child that only DROPS the sampler it inherited (drx_list_sampler_destroy joined threads that do not exist
+    # in the child); the child leaves through sys.exit, so every finaliser runs
+    drop = code.replace("    out = s.sample_group_arrays(3000)\n    os._exit(0 if len(out[0]) == 3000 else 1)\n",
+                        "    del s\n    import gc\n    gc.collect()\n    sys.exit(0)\n")
+    assert 'del s' in drop
+    out = subprocess.run([sys.executable, '-c', drop], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
 
 
 def test_native_list_sampler_gives_up_like_the_python_loop():
