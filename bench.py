@@ -91,6 +91,8 @@ def parse(argv=None):
                     'whole exchange goes through the communicator — every row "remote", the link replaced by a device copy)')
     ap.add_argument('--chunks', type=int, default=4, help='row layout: exchange chunks per owner (a power of two; every exchange is that many all-to-alls, '
                     'pipelined with the owner apply and the next step\'s gather: drecpy_amd/dist.py); 1 = one all-to-all per exchange (r05)')
+    ap.add_argument('--transport', default='rccl', choices=['rccl', 'torch'], help='row layout: who issues the all-to-all(v) exchanges — the library\'s own '
+                    'RCCL communicator (csrc/drx_comm.hip: one ncclGroup per exchange, enqueued from C) or torch.distributed')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     ap.add_argument('--launch-dry-run', action='store_true', help='print the per-rank child command lines of an N-GPU run and exit (no GPU call)')
     ap.add_argument('--launch-selftest', action='store_true', help='children only rendezvous over gloo and all-reduce on the CPU (tests the launcher)')
@@ -206,9 +208,12 @@ def coordinate(args, argv, ranks, world, rdzv_dir, local_of=None):
         return None, (1 if len(errors) == len(layouts) else 0)
     if not results:
         return {'metric': 'training samples/sec (user-item pairs)', 'value': None, 'n_gpus': world, 'layouts': errors, 'error': 'every layout failed'}, rc
-    best = max(results, key=lambda l_: results[l_].get('value') or 0.0)
+    # north_star fixes the ROW-wise shard: it is the N > 1 headline whenever it ran (r06; through r05 the faster layout was); the column
+    # layout — every rank walks the whole global batch — stays in `layouts` as an extra, and is the headline only if the row layout failed
+    best = 'rows' if 'rows' in results else max(results, key=lambda l_: results[l_].get('value') or 0.0)
     out = dict(results[best])
     out['headline_layout'] = best
+    out['headline_rule'] = 'rows (north_star) when it ran; otherwise the layout that did'
     brief = {}
     for lay, r in results.items():
         brief[lay] = {k_: r.get(k_) for k_ in ('value', 'ms_per_step', 'window_ms_min', 'window_ms_max', 'phases_ms', 'rccl_ranks', 'host_issue_ms_per_step')}
@@ -699,7 +704,8 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     else:
         from drecpy_amd.dist import ShardedCdae
         stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
-                              cpu_staging=debug_gloo, force_collectives=rccl1, self_bypass=not args.no_self_bypass, chunks=args.chunks)
+                              cpu_staging=debug_gloo, force_collectives=rccl1, self_bypass=not args.no_self_bypass, chunks=args.chunks,
+                              transport='rccl' if (args.transport == 'rccl' and not debug_gloo and (world > 1 or rccl1)) else None)
         eng = stepper.engine
 
     micro = max(1, args.micro)       # > 1: micro-batches whose exchanges overlap each other's compute (measured at world 1: the split costs more than it hides)
@@ -908,6 +914,7 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                    else f'{args.n_batches} pre-sampled batches cycled',
                    'micro_batches': (micro if stepper is not None else None),
                    'exchange_chunks': (stepper.chunks if stepper is not None else None),
+                   'transport': (type(stepper.xfer).__name__ if stepper is not None else None),
                    'sharding': ('single GPU' if stepper is None else
                                 'row-sharded code path at world 1, ' + ('every row sent through the communicator (--no-self-bypass: all rows "remote", the link '
                                                                         'replaced by a device copy)' if args.no_self_bypass else

@@ -21,8 +21,16 @@ class CDAE(RecommenderABC):
     fused_fit = True      # reference mode: fit() runs its quiet loop inside the library (_run_steps); False = always step by step
 
     def __init__(self, hidden_factors=50, corruption_level=0.2, loss='bce', mode='reference', loss_targets='reference',
-                 sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', **kwds):
+                 sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', layout='rows', exchange_chunks=4, **kwds):
         super().__init__(**kwds)
+        if layout not in ('rows', 'columns'):
+            raise Exception(f'Unknown multi-GPU layout "{layout}" (supported: "rows", "columns").')
+        # how a sampled, device-sampled fit() under a torch.distributed process group shards the model (drecpy_amd/dist.py):
+        #   'rows'    north_star / BASELINE configuration 4 — V rows, histories and samples by user range, item rows by item range, the
+        #             rows a batch needs and their merged gradients exchanged by all-to-all(v) in `exchange_chunks` pipelined chunks;
+        #             every rank draws `batch_size` triples of ITS users per step (global batch = world x batch_size);
+        #   'columns' every rank all rows x K / world columns, the same global batch on every rank, one all-reduce of B floats.
+        self.layout, self.exchange_chunks = layout, int(exchange_chunks)
         self.hidden_factors = hidden_factors
         self.corruption_level = corruption_level
         if loss not in ('mse', 'bce'):
@@ -39,9 +47,9 @@ class CDAE(RecommenderABC):
     # ---- multi-GPU: the same fit() under an initialised torch.distributed process group ------------------------------------
     def _world(self):
         """(rank, world) when this fit() is one process of a multi-GPU job, else None.  Sampled mode with the device sampler
-        trains column-sharded (drecpy_amd/dist.py, ColumnShardedCdae): every process is given the SAME dataset and seed,
-        holds K/N columns of every table and trains on the same batches; afterwards every process assembles all K columns
-        and predicts / ranks on its own like a single-GPU model."""
+        trains sharded (drecpy_amd/dist.py: ShardedCdae for layout='rows', ColumnShardedCdae for 'columns'): every process is given
+        the SAME dataset and seed; afterwards every process assembles the whole model and predicts / ranks on its own like a
+        single-GPU model."""
         import torch.distributed as dist
         if not (self.mode == 'sampled' and self.device_sampler and dist.is_available() and dist.is_initialized()):
             return None
@@ -49,6 +57,7 @@ class CDAE(RecommenderABC):
 
     def fit(self, interaction_dataset, epochs=50, batch_size=32, learning_rate=0.001, neg_ratio=5, reg_rate=0.001,
             copy_dataset=False, **kwds):
+        self._fit_epochs = int(epochs)         # (the row layout's pipeline issues exchanges for the steps to come: it must know the last one)
         out = super().fit(interaction_dataset, epochs=epochs, batch_size=batch_size, learning_rate=learning_rate, neg_ratio=neg_ratio,
                           reg_rate=reg_rate, copy_dataset=copy_dataset, **kwds)
         if getattr(self, '_dist_model', None) is not None:      # training is over: every rank keeps the whole model
@@ -60,11 +69,59 @@ class CDAE(RecommenderABC):
             self._engine.set_history(self._hist_indptr, self._hist_indices)
         return out
 
+    def _pre_fit_rows(self, rank, world, learning_rate, neg_ratio, reg_rate, **kwds):
+        """layout='rows' (recommender_abc.py:97-98 is the surface; north_star's row-wise shard behind it): this rank keeps the V rows,
+        histories and recorded pairs of users [lo, hi) and the item rows of its item range; dist.ShardedCdae + ShardedPipeline train."""
+        import torch.distributed as dist
+        from ..dist import ShardedCdae
+        ds = self.interaction_dataset
+        self._hist_indptr, self._hist_indices = ds.positives_csr(self.interaction_threshold)
+        seed = self.seed if self.seed is not None else 0
+        U = self.n_users
+        lo, hi = U * rank // world, U * (rank + 1) // world
+        ip = np.asarray(self._hist_indptr, np.int64)
+        m = ShardedCdae(U, self.n_items, self.hidden_factors, rank, world, self.device, ip[lo:hi + 1] - ip[lo],
+                        self._hist_indices[ip[lo]:ip[hi]], seed=seed, lr=learning_rate, reg=reg_rate, optimizer=self.sparse_optimizer,
+                        loss=self._loss_name, q=self.corruption_level, cpu_staging=(dist.get_backend() == 'gloo'),
+                        chunks=self.exchange_chunks)
+        weights = kwds.get('initial_weights')
+        n_params = (2 * self.n_items + U) * self.hidden_factors
+        if weights is None and n_params <= (1 << 26):                # the single-GPU initialisation, sliced (larger: drawn per shard on the device)
+            weights = self._glorot_like_single_gpu(seed)
+        if weights is not None:
+            m.set_params_global(**weights)
+        self._dist_model, self._engine = m, m.engine
+        self._row_range = (lo, hi)
+        all_ip, all_cols, _ = ds.interaction_csr()                  # (negatives avoid every recorded pair: see _pre_fit)
+        if len(all_cols) != len(self._hist_indices):
+            all_ip = np.asarray(all_ip, np.int64)
+            m.engine.set_recorded_pairs(all_ip[lo:hi + 1] - all_ip[lo], all_cols[all_ip[lo]:all_ip[hi]])
+        else:
+            m.engine.set_recorded_pairs(None, None)
+        self._pipeline = self._pending = None
+        self._register_tables()
+        self._sampler = PointSampler(ds, neg_ratio, self.interaction_threshold, self.seed)
+        self._mask_seed = int(self.seed if self.seed is not None else 0)
+        self._mask_rng = None
+
+    def _glorot_like_single_gpu(self, seed):
+        rng = np.random.default_rng(seed)
+
+        def glorot(shape):
+            fi, fo = (shape[0], shape[0]) if len(shape) == 1 else (shape[0], shape[1])
+            lim = np.sqrt(6.0 / (fi + fo))
+            return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+        k = self.hidden_factors
+        return dict(W=glorot((self.n_items, k)), W_=glorot((k, self.n_items)), V=glorot((self.n_users, k)), b=glorot((k,)),
+                    b_=glorot((self.n_items,)))
+
     def _pre_fit_distributed(self, rank, world, learning_rate, neg_ratio, reg_rate, **kwds):
         import torch.distributed as dist
         from ..dist import ColumnShardedCdae
         if kwds.get('epoch_callback_fn') is not None or kwds.get('early_stopping_rule') is not None:
-            raise Exception('epoch callbacks / early stopping need the whole model at every call: not available while it is column-sharded')
+            raise Exception('epoch callbacks / early stopping need the whole model at every call: not available while it is sharded')
+        if self.layout == 'rows':
+            return self._pre_fit_rows(rank, world, learning_rate, neg_ratio, reg_rate, **kwds)
         ds = self.interaction_dataset
         self._hist_indptr, self._hist_indices = ds.positives_csr(self.interaction_threshold)
         seed = self.seed if self.seed is not None else 0
@@ -75,15 +132,7 @@ class CDAE(RecommenderABC):
         weights = kwds.get('initial_weights')
         n_params = (2 * self.n_items + self.n_users) * self.hidden_factors
         if weights is None and n_params <= (1 << 26):                # the single-GPU initialisation, sliced
-            rng = np.random.default_rng(seed)
-
-            def glorot(shape):
-                fi, fo = (shape[0], shape[0]) if len(shape) == 1 else (shape[0], shape[1])
-                lim = np.sqrt(6.0 / (fi + fo))
-                return rng.uniform(-lim, lim, size=shape).astype(np.float32)
-            k = self.hidden_factors
-            weights = dict(W=glorot((self.n_items, k)), W_=glorot((k, self.n_items)), V=glorot((self.n_users, k)), b=glorot((k,)),
-                           b_=glorot((self.n_items,)))
+            weights = self._glorot_like_single_gpu(seed)
         if weights is not None:
             m.set_params_global(**weights)
         self._dist_model, self._engine = m, m.engine
@@ -213,8 +262,18 @@ class CDAE(RecommenderABC):
                 first = 0 if pipe is None else pipe.next
                 ms = self._mask_seed
                 seeds = (lambda s: ms * 7919 + first + s + 1, lambda s: ms + 0x9E3779B9 * (first + s + 1))
-                if getattr(self, '_dist_model', None) is not None:      # the same seeds on every rank: the same batches
-                    pipe = self._pipeline = self._dist_model.pipeline(batch_size, self._sampler.neg_ratio, *seeds)
+                dm = getattr(self, '_dist_model', None)
+                if dm is not None and self.layout == 'rows':
+                    # every rank draws ITS users' triples: the seeds differ by rank (row_seeds below; tests replay them)
+                    from ..dist import ShardedPipeline
+                    from ..engine import DeviceBatchSource
+                    rs = self.row_seeds(ms, dm.rank, dm.world, first)
+                    src = DeviceBatchSource(dm.engine, batch_size, self._sampler.neg_ratio, self.corruption_level, rs[0], rs[1],
+                                            n_items=self.n_items)
+                    pipe = self._pipeline = ShardedPipeline(dm, src, max(1, self._fit_epochs - first))
+                    pipe.B = batch_size
+                elif dm is not None:                                     # the same seeds on every rank: the same batches
+                    pipe = self._pipeline = dm.pipeline(batch_size, self._sampler.neg_ratio, *seeds)
                 else:
                     pipe = self._pipeline = SampledPipeline(self._engine, batch_size, self._sampler.neg_ratio, self.corruption_level,
                                                             *seeds, loss=self._loss_name)
@@ -224,6 +283,12 @@ class CDAE(RecommenderABC):
         if self.mode == 'reference':
             return self._reference_batch(batch_size, kwds.get('batches_after', 1 if kwds.get('more_to_come', False) else 0))
         return self._sampler.sample(batch_size)                  # list of (uid, iid, value) like the reference
+
+    @staticmethod
+    def row_seeds(mask_seed, rank, world, first=0):
+        """(sample seed, corruption-mask seed) of step s on rank `rank` of a row-sharded fit"""
+        return (lambda s: (mask_seed * 7919 + first + s + 1) * world + rank,
+                lambda s: (mask_seed + 0x9E3779B9 * (first + s + 1)) * world + rank)
 
     class _Batch:
         """What _sample_batch hands _do_batch in reference mode: the reference's list of (uid, iid, value) triples — built only

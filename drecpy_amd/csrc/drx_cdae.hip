@@ -1343,6 +1343,7 @@ const char *drx_strerror(int code) {
     case DRX_ESCRATCH: return "scratch buffer too small";
     case DRX_ENOTIMPL: return "not implemented";
     case DRX_ERETRY: return "sampler gave up after its maximum number of consecutive failed attempts";
+    case DRX_ECOMM: return "RCCL transport error (drx_comm_last_error() has the text)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown drx error";
   }
 }

@@ -266,6 +266,81 @@ class TorchTransport:
         return work if overlap else _DONE
 
 
+class _Ticket:
+    """handle of an exchange queued on the library's communicator; keeps the buffers alive until a stream has waited for it"""
+    __slots__ = ('xfer', 't', 'bufs')
+
+    def __init__(self, xfer, t, bufs):
+        self.xfer, self.t, self.bufs = xfer, t, bufs
+
+    def wait(self):
+        if self.t is not None:
+            x = self.xfer
+            x.check(x.L.drx_comm_wait(x.comm, self.t, x.stream_ptr(x.device)), 'drx_comm_wait')
+            self.bufs = None                          # (the waiting stream is behind the exchange now: its later work may reuse them)
+
+
+class RcclTransport:
+    """all-to-all(v) through the library's own RCCL communicator (include/drx.h drx_comm_*, csrc/drx_comm.hip): one ncclGroup of send /
+    recv pairs per exchange, enqueued from C on the communicator's stream, ordered with the CURRENT torch stream by events.  r06: the
+    chunked schedule issues 2 + 2 C exchanges per step; through torch.distributed each cost tens of microseconds of Python and the host
+    became the bound (profiles/r06b_*).  One rank per GPU (RCCL refuses two ranks on one device): tests with several ranks on one GPU
+    keep TorchTransport over gloo.  `group`: an initialised torch.distributed group of the same ranks, used ONCE to hand rank 0's
+    unique id to the others (world 1: nothing)."""
+
+    def __init__(self, world, rank, device, group=None):
+        from . import _lib
+        self._lib, self.L, self.check, self.stream_ptr = _lib, _lib.lib(), _lib.check, _lib.stream_ptr
+        self.world, self.rank, self.device = world, rank, torch.device(device)
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            self._ok(self.L.drx_comm_unique_id(ident), 'drx_comm_unique_id')
+        if world > 1:
+            box = [ident.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._ok(self.L.drx_comm_create(ident, world, rank, C.byref(h)), 'drx_comm_create')
+        self.comm = h
+        self._arr = [(C.c_int64 * world)() for _ in range(4)]
+        self.issued = 0
+
+    def _ok(self, rc, what):
+        if rc < 0:
+            raise self._lib.DrxError(f'{what}: {self._lib.lib().drx_comm_last_error().decode()} (code {rc})')
+
+    def a2a(self, send, send_splits, out, recv_splits, overlap=False):
+        so, sb, ro, rb = self._arr
+        es, er = send.element_size(), out.element_size()
+        a = 0
+        for p, n in enumerate(send_splits):
+            so[p], sb[p] = a * es, int(n) * es
+            a += int(n)
+        a = 0
+        for p, n in enumerate(recv_splits):
+            ro[p], rb[p] = a * er, int(n) * er
+            a += int(n)
+        t = self.L.drx_comm_alltoallv(self.comm, send.data_ptr(), so, sb, out.data_ptr(), ro, rb, self.stream_ptr(self.device))
+        self._ok(t, 'drx_comm_alltoallv')
+        self.issued += 1
+        h = _Ticket(self, t, (send, out))
+        if not overlap:
+            h.wait()
+        return h
+
+    def close(self):
+        if self.comm:
+            self.L.drx_comm_destroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedCdae:
     """One rank of the row-sharded sampled-mode CDAE.  `ops` = per-rank compute backend (HipShardOps on a GPU)."""
 
@@ -289,6 +364,10 @@ class ShardedCdae:
         self.ld = getattr(self.ops, 'ld', k)
         self.loss_kind = 0 if loss == 'bce' else 1
         self.q = q
+        # transport: an object with a2a() (TorchTransport / RcclTransport), or 'rccl' = the library's own communicator (one rank per
+        # GPU, or world 1 with force_collectives), default = torch.distributed
+        if transport == 'rccl':
+            transport = RcclTransport(world, rank, device, group) if self.collectives else None
         self.xfer = transport if transport is not None else TorchTransport(group, world, self.collectives, cpu_staging)
         if self.engine is not None:
             # (the engine's tables are this rank's SHARD — its item rows are local, the history's item ids global: no transpose)
@@ -329,6 +408,19 @@ class ShardedCdae:
         b_l = np.zeros(ipr, dt); b_l[:hi - lo] = b_[lo:hi]
         self.ops.set_params(Wl, W_l, np.asarray(V[self.user_lo:self.user_hi], dt), np.asarray(b, dt), b_l)
 
+    def gather_params_global(self):
+        """The whole model on every rank (reference orientation: W [N,K], W_ [K,N], V [U,K], b [K], b_ [N]) — for evaluation or
+        export after training; an infrequent host-side gather, not part of a step."""
+        mine = self.ops.get_params()
+        if self.world == 1:
+            parts = [mine]
+        else:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, mine, group=self.group)
+        N = self.n_items
+        return {'W': np.concatenate([p['W'] for p in parts], axis=0)[:N], 'W_': np.concatenate([p['W_'] for p in parts], axis=1)[:, :N],
+                'V': np.concatenate([p['V'] for p in parts], axis=0), 'b': parts[0]['b'], 'b_': np.concatenate([p['b_'] for p in parts])[:N]}
+
     # ---- exchanges ---------------------------------------------------------------------------------------
     def _a2a(self, send, send_counts, recv_counts, out=None, overlap=False):
         """all-to-all(v) of a 1-D tensor with per-peer split sizes; returns (received tensor, handle).  The returned tensor is never
@@ -366,10 +458,7 @@ class ShardedCdae:
         if 'counts_dev' in P and not self.cpu_staging:
             send = P['counts_dev']
             recv = torch.empty_like(send)
-            if self.collectives:
-                dist.all_to_all_single(recv, send, group=self.group)
-            else:
-                recv.copy_(send)
+            P['counts_x'] = self.xfer.a2a(send, [Cn] * W, recv, [Cn] * W)        # (waited for by the current stream inside)
             host = torch.empty(2, W * Cn, dtype=torch.int64, pin_memory=True)
             host[0].copy_(send, non_blocking=True)
             host[1].copy_(recv, non_blocking=True)

@@ -32,7 +32,8 @@ enum {
   DRX_EINVAL = -1,     /* bad argument (null pointer, k > DRX_MAX_K, ld % 4, ...) */
   DRX_ESCRATCH = -2,   /* scratch buffer too small */
   DRX_ENOTIMPL = -3,
-  DRX_ERETRY = -4      /* a sampler gave up after its maximum number of consecutive failed attempts */
+  DRX_ERETRY = -4,     /* a sampler gave up after its maximum number of consecutive failed attempts */
+  DRX_ECOMM = -5       /* the RCCL transport failed (librccl missing, or an nccl* call: drx_comm_last_error() has the text) */
 };
 
 #define DRX_MAX_K 1024
@@ -383,6 +384,26 @@ int drx_shard_step_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxS
 int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, int32_t b_norm, const uint32_t *recv_keys,
                     const float *grad_recv, int32_t n, const int32_t *recv_counts, int32_t n_segments, int32_t chunk, const void *table,
                     const float *const *own_grad, const int64_t *own_off, float *loss_out, void *stream);
+
+/* ---- RCCL transport of the row-sharded step (no reference equivalent; SURVEY §8b allows this one piece of state) ------------------------
+ * One communicator per rank (process) with a HIP stream of its own.  drx_comm_unique_id on one rank, the 128 bytes handed to the others
+ * by the host (torch.distributed's store, a file, ...), drx_comm_create on every rank with its device current.  librccl is opened at run
+ * time: without it these calls return DRX_ECOMM and everything else in the library works.
+ * drx_comm_alltoallv: peer p is sent send[send_off[p] .. + send_bytes[p]) and this rank receives recv_bytes[p] bytes from it at
+ *   recv + recv_off[p] (HOST arrays of `world` entries; zero sizes allowed, the rank itself included) — one group of ncclSend / ncclRecv
+ *   pairs on the communicator's stream, behind everything `after_stream` has queued so far.  Returns a ticket (>= 0) or a negative code.
+ * drx_comm_wait: `stream` waits for the exchange with that ticket (and, the communicator's stream being in order, all before it).
+ * The buffers must stay allocated until a stream that waited for the ticket has passed that point. */
+#define DRX_COMM_ID_BYTES 128
+typedef struct DrxComm DrxComm;
+int drx_comm_unique_id(void *id128);
+int drx_comm_create(const void *id128, int32_t world, int32_t rank, DrxComm **out);
+int drx_comm_destroy(DrxComm *c);
+void *drx_comm_stream(DrxComm *c);
+int64_t drx_comm_alltoallv(DrxComm *c, const void *send, const int64_t *send_off, const int64_t *send_bytes, void *recv,
+                           const int64_t *recv_off, const int64_t *recv_bytes, void *after_stream);
+int drx_comm_wait(DrxComm *c, int64_t ticket, void *stream);
+const char *drx_comm_last_error(void);
 
 /* drx_copy_f4: dst[0 .. n_bytes) = src[0 .. n_bytes) on the device (16-B aligned, n_bytes a multiple of 16, no overlap): a streaming
  *   float4 copy kernel — table snapshots (recommender_abc.py:336-352 keeps a copy of every weight per epoch), and the rate bench.py

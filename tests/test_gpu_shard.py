@@ -72,15 +72,17 @@ def _oracle(world, micro=1):
     return p, losses
 
 
-def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1, bypass=True):
+def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1, bypass=True, transport=None):
     from drecpy_amd.dist import ShardedCdae
     p, indptr, indices, batches = _problem(world)
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
     m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force, self_bypass=bypass,
-                    chunks=CHUNKS)
+                    chunks=CHUNKS, transport=transport)
     assert m.chunks == CHUNKS, (m.chunks, CHUNKS)
+    if transport == 'rccl':
+        assert type(m.xfer).__name__ == 'RcclTransport' 
     m.set_params_global(**p)
     losses, made = [], {}
 
@@ -231,3 +233,99 @@ def test_sharded_step_through_rccl_world1_chunked(tmp_path, monkeypatch, pipelin
     rdzv = new_rendezvous(tmp_path)
     mp.spawn(_worker_rccl, args=(rdzv, out, pipelined, micro, bypass), nprocs=1, join=True)
     _check(1, [torch.load(f'{out}.0', weights_only=False)], micro)
+
+
+# ---- the row layout behind the reference's own entry point: CDAE.fit() under a process group (recommender_abc.py:97-98) ------------------
+def _rows_frame():
+    rng = np.random.default_rng(21)
+    n_users, n_items = 240, 10000                       # 2 * items_per_rank > 8192: room for two exchange chunks at world 2
+    user = np.concatenate([rng.integers(0, n_users, size=n_items), rng.integers(0, n_users, size=14000)])
+    item = np.concatenate([rng.permutation(n_items), rng.integers(0, 300, size=14000)])        # every item once + a hot set
+    return {'user': user + 1, 'item': item + 1, 'interaction': rng.integers(1, 6, size=len(user))}
+
+
+def _fit_rows_worker(rank, world, rdzv, out, chunks):
+    dist.init_process_group('gloo', init_method=rdzv, rank=rank, world_size=world)
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    ds = InteractionDataset.read_df(_rows_frame(), verbose=False)
+    model = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False, layout='rows', exchange_chunks=chunks)
+    model.fit(ds, epochs=10, batch_size=256, learning_rate=0.05, reg_rate=1e-3, neg_ratio=5)
+    torch.cuda.synchronize()
+    frame = _rows_frame()
+    torch.save({'params': model._engine.get_params(), 'pred': float(model.predict(frame['user'][0], frame['item'][1])),
+                'rank': model.rank(frame['user'][0], list(frame['item'][:30]), n=5), 'chunks': chunks}, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('chunks', [1, 2])
+@retry_infra
+def test_public_fit_row_layout_equals_a_single_gpu_replay_of_the_same_buckets(tmp_path, chunks):
+    """CDAE(mode='sampled', device_sampler=True, layout='rows').fit() as two processes of one job — dist.ShardedCdae + ShardedPipeline
+    behind the reference's entry point — then every rank holds the whole model.  SURVEY §8e's parity: equality with a single-process run
+    that uses the SAME bucketing — every step's global batch = rank 0's draw of its users + rank 1's draw of its users (replayed here
+    with the ranks' seeds and corruption masks) through the plain single-GPU step."""
+    from oracle import cdae_oracle as co
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import CDAE
+    from drecpy_amd.engine import CdaeEngine
+    world, Kf, Bf, steps, seed = 2, 18, 256, 10, 3
+    out = str(tmp_path / 'fitrows')
+    rdzv = new_rendezvous(tmp_path)
+    mp.spawn(_fit_rows_worker, args=(world, rdzv, out, chunks), nprocs=world, join=True)
+    ds = InteractionDataset.read_df(_rows_frame(), verbose=False)
+    ds.assign_internal_ids()
+    ip, idx = ds.positives_csr(1e-3)
+    ip = np.asarray(ip, np.int64)
+    Uf, Nf = len(ip) - 1, int(ds.count_unique('iid'))
+    assert Nf == 10000
+    rng = np.random.default_rng(seed)
+
+    def glorot(shape):
+        fi, fo = (shape[0], shape[0]) if len(shape) == 1 else (shape[0], shape[1])
+        lim = np.sqrt(6.0 / (fi + fo))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+    eng = CdaeEngine(Uf, Nf, Kf)
+    eng.set_params(W=glorot((Nf, Kf)), W_=glorot((Kf, Nf)), V=glorot((Uf, Kf)), b=glorot((Kf,)), b_=glorot((Nf,)))
+    eng.set_history(ip, idx)
+    eng.init_optimizer('adagrad', 0.05, 1e-3)
+    locals_ = []
+    for r in range(world):
+        lo, hi = Uf * r // world, Uf * (r + 1) // world
+        e = CdaeEngine(hi - lo, Nf, 4)
+        e.set_history(ip[lo:hi + 1] - ip[lo], idx[ip[lo]:ip[hi]], with_transpose=False)
+        locals_.append((e, lo))
+    thr = co.q_threshold(0.2)
+    for s in range(steps):
+        us, is_, ys, keeps = [], [], [], []
+        for r, (e, lo) in enumerate(locals_):
+            ss, sm = CDAE.row_seeds(seed, r, world)
+            uid, iid, y, ko = [t.cpu().numpy() for t in e.sample_device(Bf, 5, ss(s), n_items=Nf)]
+            deg = np.diff(ko)
+            rows = np.repeat(np.arange(Bf), deg)
+            j = np.arange(int(ko[-1])) - np.repeat(ko[:-1], deg)
+            keeps.append((co.drx_hash_u32(sm(s), rows, j) >= thr).astype(np.uint8))
+            us.append(uid + lo); is_.append(iid); ys.append(y)
+        uid, iid, y, keep = np.concatenate(us), np.concatenate(is_), np.concatenate(ys), np.concatenate(keeps)
+        ko = np.zeros(len(uid) + 1, np.int32)
+        ko[1:] = np.cumsum(ip[uid + 1] - ip[uid])
+        assert ko[-1] == len(keep)
+        bt, alive = eng.make_batch(uid, iid, y, keep_off=ko, keep=keep, q=0.2)
+        eng.step_sparse(s, bt, 'bce')
+    torch.cuda.synchronize()
+    want = eng.get_params()
+    res = [torch.load(f'{out}.{r}', weights_only=False) for r in range(world)]
+    for got in res:
+        for k in want:
+            np.testing.assert_allclose(got['params'][k], want[k], rtol=0, atol=3e-6, err_msg=k)
+    assert res[0]['rank'] == res[1]['rank'] and abs(res[0]['pred'] - res[1]['pred']) < 1e-7
+
+
+@pytest.mark.parametrize('pipelined,micro,bypass,chunks', [(True, 1, False, 1), (True, 1, False, 4), (True, 2, False, 2), (False, 1, False, 2), (True, 1, True, 4)])
+def test_sharded_step_through_the_librarys_own_communicator(monkeypatch, pipelined, micro, bypass, chunks):
+    """transport='rccl' (csrc/drx_comm.hip): count / key / row / gradient exchanges as ncclGroups of send / recv pairs on the library's own
+    1-rank communicator and stream, ordered with torch's streams by events and tickets — the call sequence of the N-rank step."""
+    _chunked(monkeypatch, 9000, chunks)
+    res = _run_rank(0, 1, False, force=True, pipelined=pipelined, micro=micro, bypass=bypass, transport='rccl')
+    _check(1, [res], micro)
