@@ -89,7 +89,7 @@ def parse(argv=None):
                          '1/N of it (parts); auto = turns from 4 GPUs on (at 2 it saves nothing), else local')
     ap.add_argument('--no-self-bypass', action='store_true', help='row layout: send the rank\'s OWN rows through the collectives too (at world 1: the '
                     'whole exchange goes through the communicator — every row "remote", the link replaced by a device copy)')
-    ap.add_argument('--chunks', type=int, default=4, help='row layout: exchange chunks per owner (a power of two; every exchange is that many all-to-alls, '
+    ap.add_argument('--chunks', type=int, default=2, help='row layout: exchange chunks per owner (a power of two; every exchange is that many all-to-alls, '
                     'pipelined with the owner apply and the next step\'s gather: drecpy_amd/dist.py); 1 = one all-to-all per exchange (r05)')
     ap.add_argument('--transport', default='rccl', choices=['rccl', 'torch'], help='row layout: who issues the all-to-all(v) exchanges — the library\'s own '
                     'RCCL communicator (csrc/drx_comm.hip: one ncclGroup per exchange, enqueued from C) or torch.distributed')

@@ -1,4 +1,4 @@
-"""CPU legs of bench.py (`cpu_baseline*`): the oracle timed on the GPU box's host cores.  The ONLY place outside tests/ and
+"""CPU legs of bench.py and bench_configs.py (`cpu_baseline*`): the oracle timed on the GPU box's host cores.  The ONLY place outside tests/ and
 __graft_entry__.smoke() that touches oracle/ — as the thing timed beside the product, never as part of it."""
 import os
 import subprocess
@@ -141,3 +141,70 @@ def cpu_reference_fit(tr, budget_s=10.0, B=64, k=50, q=0.2, seed=10):
     return {'value': n * B / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
             'sample': f'{n} one-batch epochs of {B} in {dt:.1f} s: oracle PointSampler + per-item corruption draws + oracle/cdae_oracle.py:dense_step '
                       f'(fp32) on the {U} x {N} ml-100k-shaped training set of the GPU fit; numpy on 1 thread; host has {os.cpu_count()} cpus'}
+
+
+def dmf_cpu_baseline(ds, B=256, budget_s=6.0):
+    """oracle/dmf_oracle.step (the reference's dense-row formulation: X_u [B, N], X_i [B, U] densified per batch, dmf.py:76-77) on the
+    host, one numpy thread, for `budget_s` seconds."""
+    from oracle import dmf_oracle as dm
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    import scipy.sparse as sp
+    ip, cols, vals = ds.interaction_csr()
+    U, N = len(ip) - 1, int(np.max(cols)) + 1
+    R = sp.csr_matrix((np.asarray(vals, np.float32), np.asarray(cols), np.asarray(ip)), shape=(U, N))
+    Rt = R.T.tocsr()
+    rng = np.random.default_rng(0)
+    p = dm.init_params(rng, U, N)
+    st = dm.adam_state(p)
+
+    def loop():
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s:
+            u, i = rng.integers(0, U, size=B), rng.integers(0, N, size=B)
+            xu, xi = np.asarray(R[u].todense(), np.float32), np.asarray(Rt[i].todense(), np.float32)
+            y = np.asarray(R[u, i]).ravel().astype(np.float32) / 5.0
+            dm.step(p, st, n, xu, xi, y, 1e-3, 1e-4, 2, 2)
+            n += 1
+        return n, time.perf_counter() - t0
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            n, dt = loop()
+    else:
+        n, dt = loop()
+    return {'value': n * B / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} steps of {B} uniform (user, item) pairs in {dt:.1f} s: rows densified per batch + oracle/dmf_oracle.py:step (fp32) on the '
+                      f'{U} x {N} ml-1m-shaped set; numpy on 1 thread; host has {os.cpu_count()} cpus'}
+
+
+def caser_cpu_baseline(n_users, n_items, B=512, budget_s=6.0):
+    """oracle/caser_oracle.step (caser.py:97-120 under the tape; Keras Adam per layer) on the host, one numpy thread."""
+    from oracle import caser_oracle as ca
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    rng = np.random.default_rng(0)
+    L, T, d, n_v, n_h, neg = 5, 3, 50, 4, 16, 3
+    p = ca.init_params(rng, n_users, n_items, L, d, n_v, n_h, np.float32)
+    st = ca.adam_state(p)
+    nx = n_v + L * n_h
+
+    def loop():
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s:
+            uids = rng.integers(0, n_users, size=B)
+            before, after = rng.integers(0, n_items, size=(B, L)), rng.integers(0, n_items, size=(B, T + T * neg))
+            ca.step(p, st, n, uids, before, after, T, 5e-3, 1e-6, rng.random((B, nx)) >= 0.5, 0.5)
+            n += 1
+        return n, time.perf_counter() - t0
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            n, dt = loop()
+    else:
+        n, dt = loop()
+    return {'value': n * B / dt, 'unit': 'windows/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} steps of {B} random windows in {dt:.1f} s: oracle/caser_oracle.py:step (fp32, dense Keras Adam over the '
+                      f'{n_users} x {n_items} tables); numpy on 1 thread; host has {os.cpu_count()} cpus'}

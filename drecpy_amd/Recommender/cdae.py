@@ -21,7 +21,7 @@ class CDAE(RecommenderABC):
     fused_fit = True      # reference mode: fit() runs its quiet loop inside the library (_run_steps); False = always step by step
 
     def __init__(self, hidden_factors=50, corruption_level=0.2, loss='bce', mode='reference', loss_targets='reference',
-                 sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', layout='rows', exchange_chunks=4, **kwds):
+                 sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', layout='rows', exchange_chunks=2, **kwds):
         super().__init__(**kwds)
         if layout not in ('rows', 'columns'):
             raise Exception(f'Unknown multi-GPU layout "{layout}" (supported: "rows", "columns").')

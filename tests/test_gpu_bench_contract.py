@@ -84,5 +84,16 @@ def test_bench_line_has_the_contracted_fields():
     for blk, names_ in ((c3, ('DMF_B4096', 'ModifiedDMF_B4096')), (g['cfg5_caser_ml1m'], ('Caser_B4096',))):
         for name in names_:
             assert blk[name]['fit_windows']['windows'] >= 5 and blk[name]['fit_steady_ms_per_step'] >= 0.8 * blk[name]['step_ms'], (name, blk[name])
+    # r06: configurations 3 and 5 carry a roofline (necessary HBM bytes AND the cache-level reading: their tables are L2-resident) and a
+    # cpu_baseline (the oracle's step on the host, one core) like configuration 2
+    for blk, keys, unit in ((c3, ('B256', 'B4096'), 'samples/s'), (g['cfg5_caser_ml1m'], ('B4096',), 'windows/s')):
+        for k in keys:
+            rl = blk['roofline'][k]
+            assert rl['bound'] == 'hbm' and rl['peak'] == 8000.0 and 0.0 < rl['frac'] <= 1.0 and abs(rl['frac'] - rl['achieved'] / rl['peak']) < 1e-9
+            cl = rl['cache_level']
+            assert cl['requested_bytes_per_step'] > rl['bytes_per_launch'] * 0 and 0.0 < cl['frac_of_bound'] <= 1.0 and cl['bound_GBs'] == 17000.0
+            assert rl['avg_launch_ms'] >= cl['time_at_bound_ms'] > 0          # (no step is faster than its bytes at the two bounds)
+        cb = blk['cpu_baseline']
+        assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 0 and cb['unit'] == unit and cb['sample']
     c5d = g['cfg5_caser_ml1m']['Caser_B4096_device_sampler']
     assert c5d['sampler'].startswith('device') and 0 < c5d['fit_steady_ms_per_step'] < c5['fit_steady_ms_per_step']
