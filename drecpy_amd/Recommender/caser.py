@@ -32,7 +32,7 @@ class Caser(RecommenderABC):
         # The HIP kernels (drx_caser_tile.hpp: tiles of 16 samples on the matrix cores, the tile's item rows and the convolution weights in
         # LDS; drx_caser.hip: inference) take 1 <= L <= 8 and 1 <= d <= 64 — BASELINE configuration 5 and examples/caser.py (L = 5, d = 50).
         # Anything else is REJECTED here, as DMF rejects towers it has no kernel for: there is no second backend (through r05 a
-        # torch.autograd engine took those shapes; it is now tests/caser_torch_checker.py, a checker).
+        # torch-autodiff engine took those shapes; it is now tests/caser_torch_checker.py, a checker).
         if not (1 <= L <= 8 and 1 <= d <= 64):
             raise Exception(f'drecpy_amd.Caser supports 1 <= L <= 8 and 1 <= d <= 64 (given: L={L}, d={d}).')
         # caser.py:108: tf.squeeze(tf.nn.max_pool1d(conv, n_h, n_h, 'SAME'), 1) is a max over ALL positions only while the longest

@@ -10,8 +10,10 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include "drx.h"
 
 namespace {
@@ -61,6 +63,14 @@ constexpr int kRing = 256;          // events in flight: far more than the excha
 
 }  // namespace
 
+// One exchange as the caller posted it (DRX_COMM_THREAD: the issuing thread takes it from here)
+struct Request {
+  const void *send;
+  void *recv;
+  int64_t so[DRX_MAX_WORLD], sb[DRX_MAX_WORLD], ro[DRX_MAX_WORLD], rb[DRX_MAX_WORLD];
+  bool ordered;                     // wait for before[t] first
+};
+
 struct DrxComm {
   ncclComm_t comm = nullptr;
   int world = 0, rank = 0, device = 0;
@@ -68,6 +78,17 @@ struct DrxComm {
   hipEvent_t done[kRing];           // done[t % kRing]: recorded on `stream` behind exchange t
   hipEvent_t before[kRing];         // recorded on the caller's stream in front of exchange t
   int64_t next = 0;
+  // DRX_COMM_THREAD: the nccl* calls of an exchange (about 25 us of host time for one send / recv pair, more with 7 peers) are made
+  // by a thread of the communicator's own, so that the caller's thread goes on queueing kernels meanwhile — the chunked schedule
+  // issues 2 + 3 C exchanges per step and was bound by its ONE issuing thread (profiles/r06d_host_profile_*).  The caller posts a
+  // request (and records before[t] itself: events are recorded in the caller's program order); drx_comm_wait spins until the thread
+  // has recorded done[t] — in steady state it already has.
+  bool threaded = false;
+  Request *ring = nullptr;          // [kRing]
+  std::atomic<int64_t> posted{0}, issued{0};
+  std::atomic<int> failed{0};
+  std::atomic<bool> stop{false};
+  std::thread worker;
 };
 
 #define NCCL_TRY(call)                                                                                               \
@@ -84,6 +105,40 @@ struct DrxComm {
     if (e_ != hipSuccess) { snprintf(g_last_error, sizeof g_last_error, "%s: %s", #call, hipGetErrorString(e_)); return -(int)e_; } \
   } while (0)
 
+static int issue(DrxComm *c, const Request &q, int64_t t) {
+  if (q.ordered) HIP_TRY(hipStreamWaitEvent(c->stream, c->before[t % kRing], 0));
+  bool any = false;
+  for (int p = 0; p < c->world; ++p) any = any || q.sb[p] > 0 || q.rb[p] > 0;
+  if (any) {
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int p = 0; p < c->world; ++p) {
+      if (q.sb[p] > 0) NCCL_TRY(g_rccl.Send((const char *)q.send + q.so[p], (size_t)q.sb[p], ncclInt8, p, c->comm, c->stream));
+      if (q.rb[p] > 0) NCCL_TRY(g_rccl.Recv((char *)q.recv + q.ro[p], (size_t)q.rb[p], ncclInt8, p, c->comm, c->stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+  }
+  HIP_TRY(hipEventRecord(c->done[t % kRing], c->stream));
+  return DRX_OK;
+}
+
+static void comm_thread(DrxComm *c) {
+  (void)hipSetDevice(c->device);
+  int idle = 0;
+  while (!c->stop.load(std::memory_order_acquire)) {
+    const int64_t t = c->issued.load(std::memory_order_relaxed);
+    if (t < c->posted.load(std::memory_order_acquire)) {
+      if (!c->failed.load(std::memory_order_relaxed)) {
+        const int rc = issue(c, c->ring[t % kRing], t);
+        if (rc) c->failed.store(rc, std::memory_order_release);
+      }
+      c->issued.store(t + 1, std::memory_order_release);
+      idle = 0;
+    } else if (++idle > 4000) {
+      std::this_thread::yield();                  // (between steps: give the core away; inside a step the next request is microseconds off)
+    }
+  }
+}
+
 extern "C" {
 
 const char *drx_comm_last_error(void) { return g_last_error; }
@@ -99,8 +154,8 @@ int drx_comm_unique_id(void *id128) {
   return DRX_OK;
 }
 
-int drx_comm_create(const void *id128, int32_t world, int32_t rank, DrxComm **out) {
-  if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return DRX_EINVAL;
+int drx_comm_create(const void *id128, int32_t world, int32_t rank, uint32_t flags, DrxComm **out) {
+  if (!id128 || !out || world < 1 || world > DRX_MAX_WORLD || rank < 0 || rank >= world) return DRX_EINVAL;
   const int rc = load_rccl();
   if (rc) return rc;
   DrxComm *c = new DrxComm();
@@ -118,12 +173,23 @@ int drx_comm_create(const void *id128, int32_t world, int32_t rank, DrxComm **ou
     HIP_TRY(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->before[i], hipEventDisableTiming | hipEventDisableSystemFence));
   }
+  if (flags & DRX_COMM_THREAD) {
+    c->ring = new Request[kRing];
+    c->threaded = true;
+    c->worker = std::thread(comm_thread, c);
+  }
   *out = c;
   return DRX_OK;
 }
 
 int drx_comm_destroy(DrxComm *c) {
   if (!c) return DRX_OK;
+  if (c->threaded) {
+    while (c->issued.load(std::memory_order_acquire) < c->posted.load(std::memory_order_acquire)) std::this_thread::yield();
+    c->stop.store(true, std::memory_order_release);
+    c->worker.join();
+    delete[] c->ring;
+  }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   for (int i = 0; i < kRing; ++i) {
@@ -141,31 +207,36 @@ int64_t drx_comm_alltoallv(DrxComm *c, const void *send, const int64_t *send_off
                            const int64_t *recv_off, const int64_t *recv_bytes, void *after_stream) {
   if (!c || !send_off || !send_bytes || !recv_off || !recv_bytes) return DRX_EINVAL;
   const int64_t t = c->next;
-  if (after_stream != (void *)c->stream) {
-    HIP_TRY(hipEventRecord(c->before[t % kRing], (hipStream_t)after_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->before[t % kRing], 0));
+  for (int p = 0; p < c->world; ++p) {
+    if (send_bytes[p] < 0 || recv_bytes[p] < 0) return DRX_EINVAL;
+    if ((send_bytes[p] > 0 && !send) || (recv_bytes[p] > 0 && !recv)) return DRX_EINVAL;
   }
-  bool any = false;
-  for (int p = 0; p < c->world; ++p) any = any || send_bytes[p] > 0 || recv_bytes[p] > 0;
-  if (any) {
-    if (!send || !recv) return DRX_EINVAL;
-    NCCL_TRY(g_rccl.GroupStart());
-    for (int p = 0; p < c->world; ++p) {
-      if (send_bytes[p] < 0 || recv_bytes[p] < 0) { (void)g_rccl.GroupEnd(); return DRX_EINVAL; }
-      if (send_bytes[p] > 0)
-        NCCL_TRY(g_rccl.Send((const char *)send + send_off[p], (size_t)send_bytes[p], ncclInt8, p, c->comm, c->stream));
-      if (recv_bytes[p] > 0)
-        NCCL_TRY(g_rccl.Recv((char *)recv + recv_off[p], (size_t)recv_bytes[p], ncclInt8, p, c->comm, c->stream));
-    }
-    NCCL_TRY(g_rccl.GroupEnd());
+  const bool ordered = after_stream != (void *)c->stream;
+  if (c->threaded) {
+    if (c->failed.load(std::memory_order_acquire)) return c->failed.load();
+    // (slot t % kRing — request and events — is free once exchange t - kRing has been issued; the ring never fills in practice)
+    while (t - c->issued.load(std::memory_order_acquire) >= kRing - 1) std::this_thread::yield();
   }
-  HIP_TRY(hipEventRecord(c->done[t % kRing], c->stream));
+  if (ordered) HIP_TRY(hipEventRecord(c->before[t % kRing], (hipStream_t)after_stream));
+  Request local;
+  Request &q = c->threaded ? c->ring[t % kRing] : local;
+  q.send = send; q.recv = recv; q.ordered = ordered;
+  for (int p = 0; p < c->world; ++p) { q.so[p] = send_off[p]; q.sb[p] = send_bytes[p]; q.ro[p] = recv_off[p]; q.rb[p] = recv_bytes[p]; }
   c->next = t + 1;
-  return t;
+  if (c->threaded) {
+    c->posted.store(t + 1, std::memory_order_release);
+    return t;
+  }
+  const int rc = issue(c, q, t);
+  return rc ? rc : t;
 }
 
 int drx_comm_wait(DrxComm *c, int64_t ticket, void *stream) {
   if (!c || ticket < 0 || ticket >= c->next) return DRX_EINVAL;
+  if (c->threaded) {                 // done[ticket] must have been RECORDED before a stream can be told to wait for it
+    while (c->issued.load(std::memory_order_acquire) <= ticket) { }
+    if (c->failed.load(std::memory_order_acquire)) return c->failed.load();
+  }
   // (a slot that a later exchange has re-recorded since: waiting for the later one covers the earlier — the stream is in order)
   HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->done[ticket % kRing], 0));
   return DRX_OK;

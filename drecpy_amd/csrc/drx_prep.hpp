@@ -303,8 +303,10 @@ static PrepBufs prep_layout(Carver &cv, const DrxCdaeParams &P, int B, int n_tou
     // row width: a column-sharded job hands lists between ranks of different widths)
     R.plan.xstride = (R.n_chunks + 1) / 2;
     const bool placed = long_segments(R.T, P);
-    R.plan.xrank = placed ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
-    R.plan.xperm = placed ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
+    // (DRX_STREAM_PLACED: lists of short segments placing the blocks inside their hot rows too — a measured loss, off: drx_segreduce.hpp)
+    const bool placed_any = placed || DRX_STREAM_PLACED != 0;
+    R.plan.xrank = placed_any ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
+    R.plan.xperm = placed_any ? cv.take<uint32_t>((size_t)R.plan.xstride) : nullptr;
     R.usamp = placed ? cv.take<int32_t>(B) : nullptr;
     R.pitem = placed ? cv.take<int32_t>(B) : nullptr;
     R.witem = placed ? cv.take<WorkItem>((size_t)B) : nullptr;

@@ -197,6 +197,14 @@ struct SpanPlan {
   const int32_t *row_end;     // [row_end_keys] list position behind the last touch of key k
   uint32_t row_end_keys;
 };
+// r06 experiment, OFF: lists of SHORT segments (the headline) placing the blocks that lie inside a hot row by the XCD whose band of the
+// gradient rows their samples fall in.  scripts/mb/mb_l2band.hip had promised 157 -> ~145 us for the streamed reduction; built
+// (-DDRX_STREAM_PLACED=1) it measured 170 - 172 us against 160 - 161 in list order, and 163 with the placement's lookups paid but the
+// blocks left in list order (-DDRX_STREAM_PLACED=2) [profiles/r06_stream_placement_ab.log]: a 4.2 MB band does not stay in a 4 MB L2
+// that also streams the parameter / slot rows and the other 55 % of the gathers, and the binned order costs balance.
+#ifndef DRX_STREAM_PLACED
+#define DRX_STREAM_PLACED 0
+#endif
 #ifndef DRX_XBINS
 #define DRX_XBINS 8      // (64 — bins of 0.5 MB of gradient rows, taken in order — measured SLOWER at the ml-1m shape: 0.60 against 0.54 ms)
 #endif
@@ -211,7 +219,16 @@ __device__ __forceinline__ void place_block(const uint32_t *__restrict__ keys_s,
   // (a list that says how long it is — cnt[20], the transposed preparation's — places only the blocks that hold touches: the others
   // have no workgroup to wait for, and every rank taken is an atomic on one of kXBins counters)
   if (on && P.cnt[20] != 0u && (long long)blk * cpb * P.chunk >= (long long)P.cnt[20]) on = false;
-  if (on) {
+  // Lists of SHORT segments (r06; the 10M x 1M headline: 4 touches per distinct row on average, but the few hundred HOT rows collect
+  // 45 % of the touches): only the blocks that lie wholly INSIDE one segment — the middle of a hot row, whose touches are sample-
+  // ascending — read a narrow band of the gradient rows and are worth a bin; every other block mixes samples from everywhere and keeps
+  // the bin of its index (scripts/mb/mb_l2band.hip: gathers out of an XCD-sized window run at 14 - 19 TB/s instead of 7).
+  bool banded = true;
+  if (on && P.chunk == kChunk) {
+    const long long first = (long long)blk * cpb * P.chunk, last = first + (long long)cpb * P.chunk - 1;
+    banded = first > 0 && last < T && keys_s[first] != DRX_KEY_NONE && keys_s[first - 1] == keys_s[first] && keys_s[last] == keys_s[first];
+  }
+  if (on && banded) {
     const int at = blk * cpb * P.chunk;
     if (at < T && keys_s[at] != DRX_KEY_NONE) {                 // (a blanked or dropped touch carries no sample: any bin will do)
       uint32_t b = vals_s[at];

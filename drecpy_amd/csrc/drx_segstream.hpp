@@ -138,7 +138,16 @@ __global__ __launch_bounds__((kSegBlock / (LD / 4)) * 64) DRX_STREAM_SGPR_CAP vo
   // the key in front of them, the two ext bytes, and — lanes 0 .. 3 CPB - 1 — the first / last / preceding key of every chunk of the
   // block (is the block all-inner?).
   struct Meta { uint32_t key, val, bk, prevk; int e0, e1; } m;
-  const int blk = (int)blockIdx.x - extra_blocks;
+  // (the block of this workgroup: by the list's XCD placement — blocks inside a hot row go to the XCD whose band of the gradient rows
+  // their samples lie in, drx_segreduce.hpp place_block — or in list order)
+#if DRX_STREAM_PLACED == 2          // (diagnostic: the placement's lookups paid for, the blocks in list order all the same)
+  const int pb_ = placed_block(SP, (int)blockIdx.x, extra_blocks, (int)gridDim.x - extra_blocks, CPB);
+  const int blk = pb_ < -5 ? pb_ : (int)blockIdx.x - extra_blocks;
+#else
+  const int blk = DRX_STREAM_PLACED ? placed_block(SP, (int)blockIdx.x, extra_blocks, (int)gridDim.x - extra_blocks, CPB)
+                                    : (int)blockIdx.x - extra_blocks;
+#endif
+  if (blk < 0) return;
   {
     const int g = blk * CPB + wv, base = g * CH, pos = base + lane;
     const bool have = g < S.n_chunks;

@@ -288,7 +288,7 @@ class RcclTransport:
     keep TorchTransport over gloo.  `group`: an initialised torch.distributed group of the same ranks, used ONCE to hand rank 0's
     unique id to the others (world 1: nothing)."""
 
-    def __init__(self, world, rank, device, group=None):
+    def __init__(self, world, rank, device, group=None, threaded=True):
         from . import _lib
         self._lib, self.L, self.check, self.stream_ptr = _lib, _lib.lib(), _lib.check, _lib.stream_ptr
         self.world, self.rank, self.device = world, rank, torch.device(device)
@@ -301,7 +301,7 @@ class RcclTransport:
             ident = C.create_string_buffer(box[0], 128)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            self._ok(self.L.drx_comm_create(ident, world, rank, C.byref(h)), 'drx_comm_create')
+            self._ok(self.L.drx_comm_create(ident, world, rank, 1 if threaded else 0, C.byref(h)), 'drx_comm_create')
         self.comm = h
         self._arr = [(C.c_int64 * world)() for _ in range(4)]
         self.issued = 0
@@ -367,7 +367,7 @@ class ShardedCdae:
         # transport: an object with a2a() (TorchTransport / RcclTransport), or 'rccl' = the library's own communicator (one rank per
         # GPU, or world 1 with force_collectives), default = torch.distributed
         if transport == 'rccl':
-            transport = RcclTransport(world, rank, device, group) if self.collectives else None
+            transport = self._own_communicator(world, rank, device, group) if self.collectives else None
         self.xfer = transport if transport is not None else TorchTransport(group, world, self.collectives, cpu_staging)
         if self.engine is not None:
             # (the engine's tables are this rank's SHARD — its item rows are local, the history's item ids global: no transpose)
@@ -376,6 +376,24 @@ class ShardedCdae:
         self.last_loss = None
         self._cur = self._main = None         # ShardedPipeline: the stream its run-ahead stages are queued on / the training stream
         self.wait_s = 0.0                     # host time spent waiting for count exchanges (stays ~0 when pipelined)
+
+    @staticmethod
+    def _own_communicator(world, rank, device, group):
+        """RcclTransport, or None (= torch.distributed) when ANY rank cannot open librccl — the ranks agree first (a rank that raised
+        alone would leave the others waiting inside the communicator's set-up)."""
+        from . import _lib
+        probe = C.create_string_buffer(128)
+        ok = 1 if _lib.lib().drx_comm_unique_id(probe) == 0 else 0
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=torch.device(device) if dist.get_backend(group) == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = int(flag.item())
+        if not ok:
+            import warnings
+            warnings.warn('drecpy_amd: librccl could not be opened on every rank (' + _lib.lib().drx_comm_last_error().decode() +
+                          '); the exchanges go through torch.distributed')
+            return None
+        return RcclTransport(world, rank, device, group)
 
     def _init_random(self, seed):
         """GlorotUniform of the GLOBAL shapes, drawn per shard on the device (cdae.py:35-41)."""

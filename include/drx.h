@@ -393,11 +393,15 @@ int drx_shard_apply(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard 
  *   recv + recv_off[p] (HOST arrays of `world` entries; zero sizes allowed, the rank itself included) — one group of ncclSend / ncclRecv
  *   pairs on the communicator's stream, behind everything `after_stream` has queued so far.  Returns a ticket (>= 0) or a negative code.
  * drx_comm_wait: `stream` waits for the exchange with that ticket (and, the communicator's stream being in order, all before it).
- * The buffers must stay allocated until a stream that waited for the ticket has passed that point. */
+ * The buffers must stay allocated until a stream that waited for the ticket has passed that point.
+ * DRX_COMM_THREAD: the nccl* calls are made by a thread of the communicator's own (drx_comm_alltoallv only posts the request; the buffers'
+ * addresses and sizes are copied); drx_comm_wait then first waits (on the host, microseconds) until that thread has enqueued the
+ * exchange.  A failure of the issuing thread is returned by the next drx_comm_* call. */
 #define DRX_COMM_ID_BYTES 128
+#define DRX_COMM_THREAD 1u
 typedef struct DrxComm DrxComm;
 int drx_comm_unique_id(void *id128);
-int drx_comm_create(const void *id128, int32_t world, int32_t rank, DrxComm **out);
+int drx_comm_create(const void *id128, int32_t world, int32_t rank, uint32_t flags, DrxComm **out);
 int drx_comm_destroy(DrxComm *c);
 void *drx_comm_stream(DrxComm *c);
 int64_t drx_comm_alltoallv(DrxComm *c, const void *send, const int64_t *send_off, const int64_t *send_bytes, void *recv,

@@ -47,9 +47,14 @@ def glorot(rng, shape):
 
 
 def main():
+    # the script's own pieces first (they need no TensorFlow): a broken helper must not hide behind the missing module
+    f0 = frame()
+    assert len(f0['user']) == len(f0['item']) == len(f0['interaction']) > 0 and glorot(np.random.default_rng(0), (3, 4)).shape == (3, 4)
     try:
         import tensorflow as tf
-    except Exception as e:                                  # noqa: BLE001
+    except ModuleNotFoundError as e:
+        if e.name != 'tensorflow':                          # (a TensorFlow that is installed but broken is an ERROR, not "absent")
+            raise
         print(f'tensorflow is not importable here ({e!r}): nothing generated, FP parity stays "unpinned"')
         return 0
     if not os.path.isdir(REFERENCE_ROOT):

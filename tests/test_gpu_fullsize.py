@@ -187,7 +187,7 @@ def test_one_full_size_step_matches_the_oracle_on_compacted_tables():
     for e in (eng, m.engine):
         assert torch.equal(before[0][~tw], e.W[~tw]) and torch.equal(before[1][~to], e.W2T[~to])
         assert torch.equal(before[2][~tu], e.V[~tu]) and torch.equal(before[4][~to], e.b2[~to])
-    assert int(tw.sum()) > 200_000 and int(tu.sum()) > 60_000          # (the batch's footprint: ~260 k distinct W rows, ~65 k users)
+    assert int(tw.sum()) > 150_000 and int(tu.sum()) > 60_000          # (the batch's footprint: ~200 k distinct W rows, ~65 k users)
     # ---- predictions of touched users after the step (cdae.py:67-71: uncorrupted, unscaled input) on the compacted item columns
     probe = uu[torch.linspace(0, uu.numel() - 1, 48, device='cuda').long()]
     _, pred = eng.forward(probe.to(torch.int32))

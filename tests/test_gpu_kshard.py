@@ -298,7 +298,7 @@ def _fit_worker(rank, world, rdzv, out, prepare='local'):
     from drecpy_amd.Dataset import InteractionDataset
     from drecpy_amd.Recommender import CDAE
     ds = InteractionDataset.read_df(_frame(), verbose=False)
-    model = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False)
+    model = CDAE(hidden_factors=18, mode='sampled', device_sampler=True, seed=3, verbose=False, layout='columns')
     model.fit(ds, epochs=20, batch_size=384, learning_rate=0.05, reg_rate=1e-3, neg_ratio=5, prepare=prepare)
     torch.cuda.synchronize()
     frame = _frame()
@@ -311,7 +311,7 @@ def _fit_worker(rank, world, rdzv, out, prepare='local'):
 @pytest.mark.parametrize('prepare', ['local', 'turns'])
 @retry_infra
 def test_public_fit_under_a_process_group_equals_the_single_gpu_fit(tmp_path, prepare):
-    """CDAE.fit(mode='sampled', device_sampler=True) as two processes of one job (column-sharded training, then every rank
+    """CDAE.fit(mode='sampled', device_sampler=True, layout='columns') as two processes of one job (column-sharded training, then every rank
     holds the whole model): parameters, a prediction and a ranking equal the single-process fit with the same seed."""
     from test_gpu_fit import _frame
     from drecpy_amd.Dataset import InteractionDataset
