@@ -534,6 +534,168 @@ __global__ __launch_bounds__(256) void k_dmf_dense(DrxDmfDims D, DrxDmfArgs A) {
   }
 }
 
+// ---- k_dmf_dense on the matrix cores (r06; towers whose layers are all <= 64 wide — the defaults [64, 32], every BASELINE shape) -------
+// The wave-per-sample kernel above walks every dense layer as a chain of 64 v_readlane + FMA pairs per sample: 42 us for 4096 samples
+// and bound by that dependent chain, not by any pipe.  Here ONE WAVE takes a TILE OF 16 SAMPLES and every layer is a product whose M
+// dimension is the tile, on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate) out of LDS:
+//   forward   Z_l [16 x fo]   = A_{l-1} [16 x fin] . K_l [fin x fo] + b_l,  A_l = relu(Z_l)          (dmf.py:47-58 Dense layers)
+//   cosine    per sample: l2-normalise both towers' outputs, dot, clip, BCE                           (dmf.py:92-99)
+//   backward  dA_{l-1} [16 x fin] = dZ_l [16 x fo] . K_l^T,  dZ_l = dA_l where A_l > 0 (relu: A_l > 0 <=> Z_l > 0)
+// Operand layout (lane l): A[l % 16][l / 16], B[l / 16][l % 16], C register r = C[4 (l / 16) + r][l % 16].  The tile's activations of
+// every layer of both towers stay in LDS (rows of 68 floats: the 16 samples of an A fragment fall in 16 different bank quads) beside the
+// small weights; the same rows leave for k_dmf_wgrad / k_dmf_dzsum exactly as the wave kernel wrote them (act, dz, samp): the rest of
+// the step does not change.  Sums run in the MFMA's order (k ascending in steps of 4): another association than the wave kernel's —
+// same oracle, same tolerance, bit-reproducible.
+typedef float dmf_f4v __attribute__((ext_vector_type(4)));
+constexpr int kDmfTS = 68;                       // floats per sample row of a tile in LDS
+constexpr int kDmfTile = 16 * kDmfTS;
+
+__global__ __launch_bounds__(64) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs A) {
+  extern __shared__ __align__(16) float swl[];    // [n_small] weights | X[2][4][16][68] activations | G[2][16][68] gradient tiles | per-sample scalars
+  constexpr int W = 64;
+  const int lane = threadIdx.x, m16 = lane & 15, q4 = lane >> 4;
+  const int nsw = (D.n_small + 3) & ~3;
+  float *const X = swl + nsw;                                    // X[(tw * 4 + l) * kDmfTile + s * 68 + c]
+  float *const G = X + 2 * kDmfMaxLayers * kDmfTile;             // two tiles (ping-pong)
+  float *const SC = G + 2 * kDmfTile;                            // [16][4]: ds, rho_u, rho_i, s
+  for (int i = lane; i < D.n_small; i += 64) swl[i] = A.sw[i];
+  const DmfWork Wk = dmf_work(A.work, A.B, W);
+  const float inv_b = 1.0f / (float)A.B;
+  const int n_tiles = (A.B + 15) / 16;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b0 = tile * 16;
+    wave_lds_sync();                               // (one wave: orders the LDS traffic of consecutive tiles; the weights' copy)
+    // ---- forward, both towers
+#pragma unroll 1
+    for (int tw = 0; tw < 2; ++tw) {
+      const int nl = D.n_layers[tw], f0 = D.f[tw][0];
+      const int32_t *inv = tw ? A.inv_i : A.inv_u;
+      float *const X0 = X + (tw * kDmfMaxLayers) * kDmfTile;
+      // layer 0: the gathered pre-activations of the samples' ids + bias, relu -> A_0 (LDS + the act rows)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int s_ = it * 4 + q4, c4 = m16 * 4, b = b0 + s_;
+        float4 z = f4_zero();
+        if (b < A.B) z = *reinterpret_cast<const float4 *>(Wk.z0 + ((size_t)tw * A.B + inv[b]) * W + c4);
+        float a[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = (c4 + j < f0) ? fmaxf(a[j] + swl[D.off_b[tw][0] + c4 + j], 0.f) : 0.f;
+        *reinterpret_cast<float4 *>(X0 + s_ * kDmfTS + c4) = make_float4(a[0], a[1], a[2], a[3]);
+        if (b < A.B) *reinterpret_cast<float4 *>(Wk.act + ((size_t)tw * A.B + b) * kDmfMaxLayers * W + c4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+      wave_lds_sync();
+#pragma unroll 1
+      for (int l = 1; l < nl; ++l) {
+        const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
+        const float *const Kl = swl + D.off_k[tw][l], *const bl = swl + D.off_b[tw][l];
+        const float *const Xi = X0 + (l - 1) * kDmfTile;
+        float *const Xo = X0 + l * kDmfTile;
+        for (int nt = 0; nt < (fo + 15) / 16; ++nt) {
+          dmf_f4v acc = {0.f, 0.f, 0.f, 0.f};
+          const int col = nt * 16 + m16;
+          for (int ks = 0; ks < (fin + 3) / 4; ++ks) {
+            const int kk = 4 * ks + q4;
+            const float av = kk < fin ? Xi[m16 * kDmfTS + kk] : 0.f;
+            const float bv = (kk < fin && col < fo) ? Kl[kk * fo + col] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int s_ = 4 * q4 + r, b = b0 + s_;
+            const float a = col < fo ? fmaxf(acc[r] + bl[col], 0.f) : 0.f;
+            Xo[s_ * kDmfTS + col] = a;
+            if (b < A.B) Wk.act[((size_t)tw * A.B + b) * kDmfMaxLayers * W + l * W + col] = a;
+          }
+        }
+        for (int c = (fo + 15) / 16 * 16 + lane % 16, s_ = lane / 16; c < W; c += 16)       // (columns beyond the last 16-tile: zero, like the wave kernel's rows)
+          for (int r = s_; r < 16; r += 4) {
+            Xo[r * kDmfTS + c] = 0.f;
+            if (b0 + r < A.B) Wk.act[((size_t)tw * A.B + b0 + r) * kDmfMaxLayers * W + l * W + c] = 0.f;
+          }
+        wave_lds_sync();
+      }
+    }
+    // ---- per sample: cosine of the two outputs, loss, gradient wrt the outputs (lane = sample m16, quarter q4 of the columns)
+    {
+      const float *const Ru = X + (0 * kDmfMaxLayers + D.n_layers[0] - 1) * kDmfTile + m16 * kDmfTS;
+      const float *const Ri = X + (1 * kDmfMaxLayers + D.n_layers[1] - 1) * kDmfTile + m16 * kDmfTS;
+      float qu = 0.f, qi = 0.f, ui = 0.f;
+      for (int c = q4 * 16; c < q4 * 16 + 16; ++c) { const float u = Ru[c], v = Ri[c]; qu = fmaf(u, u, qu); qi = fmaf(v, v, qi); ui = fmaf(u, v, ui); }
+      qu += __shfl_xor(qu, 16); qu += __shfl_xor(qu, 32);
+      qi += __shfl_xor(qi, 16); qi += __shfl_xor(qi, 32);
+      ui += __shfl_xor(ui, 16); ui += __shfl_xor(ui, 32);
+      const float rhou = rsqrtf(fmaxf(qu, kL2NEps)), rhoi = rsqrtf(fmaxf(qi, kL2NEps));
+      const float s = ui * rhou * rhoi;
+      const float cosv = fmaxf(1e-6f, s);
+      const float wsc = D.off_scale >= 0 ? swl[D.off_scale] : 1.0f;
+      const float pred = wsc * cosv;
+      const int b = b0 + m16;
+      const float y = A.target_mode == 1 ? (A.y_mean_dev ? A.y_mean_dev[0] : A.y_mean) : (b < A.B ? A.y[b] : 0.f);
+      const float gp = bce_grad(y, pred) * inv_b;
+      if (q4 == 0 && b < A.B) { Wk.samp[(size_t)b * 2] = bce_elem(y, pred); Wk.samp[(size_t)b * 2 + 1] = gp * cosv; }
+      const float ds = (s > 1e-6f && b < A.B) ? gp * wsc : 0.f;
+      // l2_normalize backward of both towers: dr = rho * (dn - n * (n . dn)), dn_u = ds * n_i: dr_u = rho_u * ds * (n_i - n_u * s)
+      float *const Gu = G + m16 * kDmfTS, *const Gi = G + kDmfTile + m16 * kDmfTS;
+      for (int c = q4 * 16; c < q4 * 16 + 16; ++c) {
+        const float nu = Ru[c] * rhou, ni = Ri[c] * rhoi;
+        Gu[c] = qu > kL2NEps ? rhou * ds * (ni - nu * s) : rhou * ds * ni;
+        Gi[c] = qi > kL2NEps ? rhoi * ds * (nu - ni * s) : rhoi * ds * nu;
+      }
+    }
+    wave_lds_sync();
+    // ---- backward, both towers: G[tw] holds dA of the last layer; dZ_l overwrites it, dA_{l-1} goes to the scratch rows of X[tw][3]
+    //      (free: a tower of 4 layers keeps A_3 there only until its dZ_3 is taken — handled by taking the mask first)
+#pragma unroll 1
+    for (int tw = 0; tw < 2; ++tw) {
+      const int nl = D.n_layers[tw];
+      float *const X0 = X + (tw * kDmfMaxLayers) * kDmfTile;
+      float *const Gt = G + tw * kDmfTile;
+#pragma unroll 1
+      for (int l = nl - 1; l >= 0; --l) {
+        const int fo = D.f[tw][l];
+        const float *const Al = X0 + l * kDmfTile;
+        // dZ_l = dA_l where A_l > 0; rows leave for k_dmf_wgrad (l >= 1) / k_dmf_dzsum (l = 0)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int s_ = it * 4 + q4, c4 = m16 * 4, b = b0 + s_;
+          const float4 a = *reinterpret_cast<const float4 *>(Al + s_ * kDmfTS + c4);
+          float4 g = *reinterpret_cast<const float4 *>(Gt + s_ * kDmfTS + c4);
+          g.x = (c4 + 0 < fo && a.x > 0.f) ? g.x : 0.f; g.y = (c4 + 1 < fo && a.y > 0.f) ? g.y : 0.f;
+          g.z = (c4 + 2 < fo && a.z > 0.f) ? g.z : 0.f; g.w = (c4 + 3 < fo && a.w > 0.f) ? g.w : 0.f;
+          *reinterpret_cast<float4 *>(Gt + s_ * kDmfTS + c4) = g;
+          if (b < A.B) *reinterpret_cast<float4 *>(Wk.dz + ((size_t)tw * A.B + b) * kDmfMaxLayers * W + l * W + c4) = g;
+        }
+        wave_lds_sync();
+        if (l == 0) break;
+        const int fin = D.f[tw][l - 1];
+        const float *const Kl = swl + D.off_k[tw][l];
+        dmf_f4v acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {                        // (constant indices: the four accumulators stay in registers)
+          acc[nt] = dmf_f4v{0.f, 0.f, 0.f, 0.f};
+          if (nt * 16 < fin) {
+            const int row = nt * 16 + m16;                     // unit of layer l - 1
+            for (int ks = 0; ks < (fo + 3) / 4; ++ks) {
+              const int kk = 4 * ks + q4;                      // unit of layer l
+              const float av = kk < fo ? Gt[m16 * kDmfTS + kk] : 0.f;
+              const float bv = (kk < fo && row < fin) ? Kl[row * fo + kk] : 0.f;
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
+            }
+          }
+        }
+        wave_lds_sync();                                        // (every lane has read dZ_l: the tile may be overwritten)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int col = nt * 16 + m16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Gt[(4 * q4 + r) * kDmfTS + col] = col < fin ? acc[nt][r] : 0.f;
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+}
+
 // gsw_part[chunk][i] = sum over the chunk's samples (ascending b) of the gradient of small weight i:
 //   kernel element (tw, l >= 1, j, k): act[tw][b][l-1][j] * dz[tw][b][l][k];   bias (tw, l, k): dz[tw][b][l][k];   scale: samp[b][1]
 // loss_part[chunk] = sum of samp[b][0] / B.  One thread per small weight, blockIdx.y = chunk.
@@ -818,7 +980,17 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
 #undef DRX_DMF_GATHER
   const size_t lds = (size_t)D->n_small * 4;
   const int dgrid = (A->B + 3) / 4;
-  if (nu == 1) {
+  // (DRX_DMF_DENSE_WAVE: the wave-per-sample kernel for every shape — the A / B build of scripts/build_variant.sh)
+#ifndef DRX_DMF_DENSE_WAVE
+#define DRX_DMF_DENSE_WAVE 0
+#endif
+  const size_t lds_t = ((size_t)((D->n_small + 3) & ~3) + (size_t)(2 * kDmfMaxLayers + 2) * kDmfTile + 64) * 4;
+  if (nu == 1 && !DRX_DMF_DENSE_WAVE && lds_t <= 160 * 1024) {            // tiles of 16 samples on the matrix cores, one wave per tile
+    if (lds_t > 48 * 1024)
+      DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    const int tiles = (A->B + 15) / 16;
+    hipLaunchKernelGGL(k_dmf_dense_tile, dim3(tiles < 2048 ? tiles : 2048), dim3(64), lds_t, st, *D, *A);
+  } else if (nu == 1) {
     if (lds > 48 * 1024) DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_dmf_dense<1>, dim3(dgrid < 2048 ? dgrid : 2048), dim3(256), lds, st, *D, *A);
   } else {
