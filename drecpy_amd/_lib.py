@@ -170,6 +170,7 @@ SIGNATURES = {
                                   C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                   C.c_void_p, C.c_void_p]),
     'drx_copy_f4': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'drx_copy_f4_variant': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     'drx_comm_unique_id': (C.c_int, [C.c_void_p]),
     'drx_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]),
     'drx_comm_destroy': (C.c_int, [C.c_void_p]),

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void k_dmf_dense(DrxDmfDims D, DrxDmfArgs A) {
 
 // ---- k_dmf_dense on the matrix cores (r06; towers whose layers are all <= 64 wide — the defaults [64, 32], every BASELINE shape) -------
 // The wave-per-sample kernel above walks every dense layer as a chain of 64 v_readlane + FMA pairs per sample: 42 us for 4096 samples
-// and bound by that dependent chain, not by any pipe.  Here ONE WAVE takes a TILE OF 16 SAMPLES and every layer is a product whose M
+// and bound by that dependent chain, not by any pipe.  Here a workgroup of FOUR WAVES (two per tower) takes a TILE OF 16 SAMPLES and every layer is a product whose M
 // dimension is the tile, on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate) out of LDS:
 //   forward   Z_l [16 x fo]   = A_{l-1} [16 x fin] . K_l [fin x fo] + b_l,  A_l = relu(Z_l)          (dmf.py:47-58 Dense layers)
 //   cosine    per sample: l2-normalise both towers' outputs, dot, clip, BCE                           (dmf.py:92-99)
@@ -550,54 +550,61 @@ typedef float dmf_f4v __attribute__((ext_vector_type(4)));
 constexpr int kDmfTS = 68;                       // floats per sample row of a tile in LDS
 constexpr int kDmfTile = 16 * kDmfTS;
 
-__global__ __launch_bounds__(64) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs A) {
-  extern __shared__ __align__(16) float swl[];    // [n_small] weights | X[2][4][16][68] activations | G[2][16][68] gradient tiles | per-sample scalars
+__global__ __launch_bounds__(256) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs A) {
+  extern __shared__ __align__(16) float swl[];    // [n_small] weights | X[2][4][16][68] activations | G[2][16][68] gradient tiles
   constexpr int W = 64;
-  const int lane = threadIdx.x, m16 = lane & 15, q4 = lane >> 4;
+  // FOUR waves per tile: waves 2 tw and 2 tw + 1 run tower tw, splitting its 16-column tiles (and the samples of the row-wise passes)
+  // between them — a tile's life is a chain of dependent layers (27 us with one wave, the whole kernel's time: every CU holds one tile)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tw = wv >> 1, half = wv & 1;
+  const int m16 = lane & 15, q4 = lane >> 4;
   const int nsw = (D.n_small + 3) & ~3;
   float *const X = swl + nsw;                                    // X[(tw * 4 + l) * kDmfTile + s * 68 + c]
-  float *const G = X + 2 * kDmfMaxLayers * kDmfTile;             // two tiles (ping-pong)
-  float *const SC = G + 2 * kDmfTile;                            // [16][4]: ds, rho_u, rho_i, s
-  for (int i = lane; i < D.n_small; i += 64) swl[i] = A.sw[i];
+  float *const G = X + 2 * kDmfMaxLayers * kDmfTile;             // one tile per tower
+  for (int i = threadIdx.x; i < D.n_small; i += 256) swl[i] = A.sw[i];
   const DmfWork Wk = dmf_work(A.work, A.B, W);
   const float inv_b = 1.0f / (float)A.B;
   const int n_tiles = (A.B + 15) / 16;
+  const int nl = D.n_layers[tw], f0 = D.f[tw][0];
+  const int32_t *const inv = tw ? A.inv_i : A.inv_u;
+  float *const X0 = X + (tw * kDmfMaxLayers) * kDmfTile;
+  float *const Gt = G + tw * kDmfTile;
+  const int nl_max = D.n_layers[0] > D.n_layers[1] ? D.n_layers[0] : D.n_layers[1];
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b0 = tile * 16;
-    wave_lds_sync();                               // (one wave: orders the LDS traffic of consecutive tiles; the weights' copy)
-    // ---- forward, both towers
-#pragma unroll 1
-    for (int tw = 0; tw < 2; ++tw) {
-      const int nl = D.n_layers[tw], f0 = D.f[tw][0];
-      const int32_t *inv = tw ? A.inv_i : A.inv_u;
-      float *const X0 = X + (tw * kDmfMaxLayers) * kDmfTile;
-      // layer 0: the gathered pre-activations of the samples' ids + bias, relu -> A_0 (LDS + the act rows)
+    __syncthreads();                                            // (the weights' copy; the previous tile's rows are free)
+    // ---- forward.  Layer 0: the gathered pre-activations of the samples' ids + bias, relu -> A_0 (LDS + the act rows); a wave: 8 samples
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int s_ = it * 4 + q4, c4 = m16 * 4, b = b0 + s_;
-        float4 z = f4_zero();
-        if (b < A.B) z = *reinterpret_cast<const float4 *>(Wk.z0 + ((size_t)tw * A.B + inv[b]) * W + c4);
-        float a[4] = {z.x, z.y, z.z, z.w};
+    for (int it = 0; it < 2; ++it) {
+      const int s_ = half * 8 + it * 4 + q4, c4 = m16 * 4, b = b0 + s_;
+      float4 z = f4_zero();
+      if (b < A.B) z = *reinterpret_cast<const float4 *>(Wk.z0 + ((size_t)tw * A.B + inv[b]) * W + c4);
+      float a[4] = {z.x, z.y, z.z, z.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = (c4 + j < f0) ? fmaxf(a[j] + swl[D.off_b[tw][0] + c4 + j], 0.f) : 0.f;
-        *reinterpret_cast<float4 *>(X0 + s_ * kDmfTS + c4) = make_float4(a[0], a[1], a[2], a[3]);
-        if (b < A.B) *reinterpret_cast<float4 *>(Wk.act + ((size_t)tw * A.B + b) * kDmfMaxLayers * W + c4) = make_float4(a[0], a[1], a[2], a[3]);
-      }
-      wave_lds_sync();
+      for (int j = 0; j < 4; ++j) a[j] = (c4 + j < f0) ? fmaxf(a[j] + swl[D.off_b[tw][0] + c4 + j], 0.f) : 0.f;
+      *reinterpret_cast<float4 *>(X0 + s_ * kDmfTS + c4) = make_float4(a[0], a[1], a[2], a[3]);
+      if (b < A.B) *reinterpret_cast<float4 *>(Wk.act + ((size_t)tw * A.B + b) * kDmfMaxLayers * W + c4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    __syncthreads();
 #pragma unroll 1
-      for (int l = 1; l < nl; ++l) {
+    for (int l = 1; l < nl_max; ++l) {                           // (both towers walk the same number of barriers)
+      if (l < nl) {
         const int fin = D.f[tw][l - 1], fo = D.f[tw][l];
         const float *const Kl = swl + D.off_k[tw][l], *const bl = swl + D.off_b[tw][l];
         const float *const Xi = X0 + (l - 1) * kDmfTile;
         float *const Xo = X0 + l * kDmfTile;
-        for (int nt = 0; nt < (fo + 15) / 16; ++nt) {
-          dmf_f4v acc = {0.f, 0.f, 0.f, 0.f};
+        float av[16];                                            // this lane's A operands of every k-step: one batch of LDS reads
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) { const int kk = 4 * ks + q4; av[ks] = kk < fin ? Xi[m16 * kDmfTS + kk] : 0.f; }
+        for (int nt = half; nt < 4; nt += 2) {                   // all four 16-column tiles of the 64-float row: beyond fo they are zero
           const int col = nt * 16 + m16;
-          for (int ks = 0; ks < (fin + 3) / 4; ++ks) {
-            const int kk = 4 * ks + q4;
-            const float av = kk < fin ? Xi[m16 * kDmfTS + kk] : 0.f;
-            const float bv = (kk < fin && col < fo) ? Kl[kk * fo + col] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+          dmf_f4v acc = {0.f, 0.f, 0.f, 0.f};
+          if (nt * 16 < fo) {
+            float bv[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) { const int kk = 4 * ks + q4; bv[ks] = (kk < fin && col < fo) ? Kl[kk * fo + col] : 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+              if (4 * ks < fin) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -607,15 +614,11 @@ __global__ __launch_bounds__(64) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs 
             if (b < A.B) Wk.act[((size_t)tw * A.B + b) * kDmfMaxLayers * W + l * W + col] = a;
           }
         }
-        for (int c = (fo + 15) / 16 * 16 + lane % 16, s_ = lane / 16; c < W; c += 16)       // (columns beyond the last 16-tile: zero, like the wave kernel's rows)
-          for (int r = s_; r < 16; r += 4) {
-            Xo[r * kDmfTS + c] = 0.f;
-            if (b0 + r < A.B) Wk.act[((size_t)tw * A.B + b0 + r) * kDmfMaxLayers * W + l * W + c] = 0.f;
-          }
-        wave_lds_sync();
       }
+      __syncthreads();
     }
-    // ---- per sample: cosine of the two outputs, loss, gradient wrt the outputs (lane = sample m16, quarter q4 of the columns)
+    // ---- per sample: cosine of the two outputs, loss, gradient wrt the outputs (lane = sample m16, quarter q4 of the columns); every
+    //      wave computes the scalars, the leading wave of a tower writes that tower's gradient tile
     {
       const float *const Ru = X + (0 * kDmfMaxLayers + D.n_layers[0] - 1) * kDmfTile + m16 * kDmfTS;
       const float *const Ri = X + (1 * kDmfMaxLayers + D.n_layers[1] - 1) * kDmfTile + m16 * kDmfTS;
@@ -632,32 +635,28 @@ __global__ __launch_bounds__(64) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs 
       const int b = b0 + m16;
       const float y = A.target_mode == 1 ? (A.y_mean_dev ? A.y_mean_dev[0] : A.y_mean) : (b < A.B ? A.y[b] : 0.f);
       const float gp = bce_grad(y, pred) * inv_b;
-      if (q4 == 0 && b < A.B) { Wk.samp[(size_t)b * 2] = bce_elem(y, pred); Wk.samp[(size_t)b * 2 + 1] = gp * cosv; }
+      if (wv == 0 && q4 == 0 && b < A.B) { Wk.samp[(size_t)b * 2] = bce_elem(y, pred); Wk.samp[(size_t)b * 2 + 1] = gp * cosv; }
       const float ds = (s > 1e-6f && b < A.B) ? gp * wsc : 0.f;
       // l2_normalize backward of both towers: dr = rho * (dn - n * (n . dn)), dn_u = ds * n_i: dr_u = rho_u * ds * (n_i - n_u * s)
-      float *const Gu = G + m16 * kDmfTS, *const Gi = G + kDmfTile + m16 * kDmfTS;
-      for (int c = q4 * 16; c < q4 * 16 + 16; ++c) {
-        const float nu = Ru[c] * rhou, ni = Ri[c] * rhoi;
-        Gu[c] = qu > kL2NEps ? rhou * ds * (ni - nu * s) : rhou * ds * ni;
-        Gi[c] = qi > kL2NEps ? rhoi * ds * (nu - ni * s) : rhoi * ds * nu;
+      if (half == 0) {
+        float *const Gs = Gt + m16 * kDmfTS;
+        for (int c = q4 * 16; c < q4 * 16 + 16; ++c) {
+          const float nu = Ru[c] * rhou, ni = Ri[c] * rhoi;
+          Gs[c] = tw == 0 ? (qu > kL2NEps ? rhou * ds * (ni - nu * s) : rhou * ds * ni) : (qi > kL2NEps ? rhoi * ds * (nu - ni * s) : rhoi * ds * nu);
+        }
       }
     }
-    wave_lds_sync();
-    // ---- backward, both towers: G[tw] holds dA of the last layer; dZ_l overwrites it, dA_{l-1} goes to the scratch rows of X[tw][3]
-    //      (free: a tower of 4 layers keeps A_3 there only until its dZ_3 is taken — handled by taking the mask first)
+    __syncthreads();
+    // ---- backward: Gt holds dA of the tower's last layer; dZ_l overwrites it (rows leave for k_dmf_wgrad / k_dmf_dzsum), then dA_{l-1}
 #pragma unroll 1
-    for (int tw = 0; tw < 2; ++tw) {
-      const int nl = D.n_layers[tw];
-      float *const X0 = X + (tw * kDmfMaxLayers) * kDmfTile;
-      float *const Gt = G + tw * kDmfTile;
-#pragma unroll 1
-      for (int l = nl - 1; l >= 0; --l) {
-        const int fo = D.f[tw][l];
+    for (int l = nl_max - 1; l >= 0; --l) {
+      const bool on = l < nl;
+      const int fo = on ? D.f[tw][l] : 0;
+      if (on) {
         const float *const Al = X0 + l * kDmfTile;
-        // dZ_l = dA_l where A_l > 0; rows leave for k_dmf_wgrad (l >= 1) / k_dmf_dzsum (l = 0)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int s_ = it * 4 + q4, c4 = m16 * 4, b = b0 + s_;
+        for (int it = 0; it < 2; ++it) {                         // dZ_l = dA_l where A_l > 0; a wave: 8 samples
+          const int s_ = half * 8 + it * 4 + q4, c4 = m16 * 4, b = b0 + s_;
           const float4 a = *reinterpret_cast<const float4 *>(Al + s_ * kDmfTS + c4);
           float4 g = *reinterpret_cast<const float4 *>(Gt + s_ * kDmfTS + c4);
           g.x = (c4 + 0 < fo && a.x > 0.f) ? g.x : 0.f; g.y = (c4 + 1 < fo && a.y > 0.f) ? g.y : 0.f;
@@ -665,33 +664,39 @@ __global__ __launch_bounds__(64) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs 
           *reinterpret_cast<float4 *>(Gt + s_ * kDmfTS + c4) = g;
           if (b < A.B) *reinterpret_cast<float4 *>(Wk.dz + ((size_t)tw * A.B + b) * kDmfMaxLayers * W + l * W + c4) = g;
         }
-        wave_lds_sync();
-        if (l == 0) break;
-        const int fin = D.f[tw][l - 1];
+      }
+      __syncthreads();
+      if (l == 0) break;
+      dmf_f4v acc[2] = {dmf_f4v{0.f, 0.f, 0.f, 0.f}, dmf_f4v{0.f, 0.f, 0.f, 0.f}};
+      const int fin = on ? D.f[tw][l - 1] : 0;
+      if (on) {
         const float *const Kl = swl + D.off_k[tw][l];
-        dmf_f4v acc[4];
+        float av[16];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {                        // (constant indices: the four accumulators stay in registers)
-          acc[nt] = dmf_f4v{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 16; ++ks) { const int kk = 4 * ks + q4; av[ks] = kk < fo ? Gt[m16 * kDmfTS + kk] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                            // this wave's two 16-unit tiles of layer l - 1
+          const int nt = half + 2 * j, row = nt * 16 + m16;
           if (nt * 16 < fin) {
-            const int row = nt * 16 + m16;                     // unit of layer l - 1
-            for (int ks = 0; ks < (fo + 3) / 4; ++ks) {
-              const int kk = 4 * ks + q4;                      // unit of layer l
-              const float av = kk < fo ? Gt[m16 * kDmfTS + kk] : 0.f;
-              const float bv = (kk < fo && row < fin) ? Kl[row * fo + kk] : 0.f;
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
-            }
+            float bv[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) { const int kk = 4 * ks + q4; bv[ks] = (kk < fo && row < fin) ? Kl[row * fo + kk] : 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+              if (4 * ks < fo) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc[j], 0, 0, 0);
           }
         }
-        wave_lds_sync();                                        // (every lane has read dZ_l: the tile may be overwritten)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = nt * 16 + m16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Gt[(4 * q4 + r) * kDmfTS + col] = col < fin ? acc[nt][r] : 0.f;
-        }
-        wave_lds_sync();
       }
+      __syncthreads();                                          // (every wave has read dZ_l: the tile may be overwritten)
+      if (on) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = (half + 2 * j) * 16 + m16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Gt[(4 * q4 + r) * kDmfTS + col] = col < fin ? acc[j][r] : 0.f;
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -985,11 +990,11 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
 #define DRX_DMF_DENSE_WAVE 0
 #endif
   const size_t lds_t = ((size_t)((D->n_small + 3) & ~3) + (size_t)(2 * kDmfMaxLayers + 2) * kDmfTile + 64) * 4;
-  if (nu == 1 && !DRX_DMF_DENSE_WAVE && lds_t <= 160 * 1024) {            // tiles of 16 samples on the matrix cores, one wave per tile
+  if (nu == 1 && !DRX_DMF_DENSE_WAVE && lds_t <= 160 * 1024) {            // tiles of 16 samples on the matrix cores, four waves per tile
     if (lds_t > 48 * 1024)
       DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
     const int tiles = (A->B + 15) / 16;
-    hipLaunchKernelGGL(k_dmf_dense_tile, dim3(tiles < 2048 ? tiles : 2048), dim3(64), lds_t, st, *D, *A);
+    hipLaunchKernelGGL(k_dmf_dense_tile, dim3(tiles < 2048 ? tiles : 2048), dim3(256), lds_t, st, *D, *A);
   } else if (nu == 1) {
     if (lds > 48 * 1024) DRX_HIP(hipFuncSetAttribute((const void *)k_dmf_dense<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_dmf_dense<1>, dim3(dgrid < 2048 ? dgrid : 2048), dim3(256), lds, st, *D, *A);

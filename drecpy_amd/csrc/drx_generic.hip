@@ -359,28 +359,51 @@ __global__ void k_sumsq_final(const double *__restrict__ part, int n_part, doubl
   }
 }
 
-// Streaming copy, 16 bytes per lane and four loads in flight per thread: what the library uses to snapshot tables and what bench.py
-// times as "the HBM rate a plain kernel of this library reaches on this box" (report the achievable next to the nominal 8 TB/s).
-__global__ __launch_bounds__(kBlock) void k_copy_f4(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n4) {
+// Streaming copy, 16 bytes per lane: what the library uses to snapshot tables and what bench.py times as "the HBM rate a plain kernel of
+// this library reaches on this box" (report the achievable next to the nominal 8 TB/s).  Forms (drx_copy_f4_variant;
+// scripts/copy_bench.py times them side by side): 0 grid-stride, four loads in flight per thread, 16 workgroups per CU; 1 one float4 per
+// thread, as many workgroups as that takes; 2 grid-stride, eight in flight, 8 workgroups per CU; 3 = 1 with non-temporal loads / stores;
+// 4 = 0 with non-temporal loads / stores.
+typedef float copy_v4 __attribute__((ext_vector_type(4)));       // (the non-temporal builtins take native vectors, not HIP's float4 struct)
+template <int NF, bool NT>
+__global__ __launch_bounds__(kBlock) void k_copy_f4(copy_v4 *__restrict__ dst, const copy_v4 *__restrict__ src, size_t n4) {
   const size_t stride = (size_t)gridDim.x * kBlock;
   size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  for (; i + (NF - 1) * stride < n4; i += NF * stride) {
+    copy_v4 v[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) v[j] = NT ? __builtin_nontemporal_load(src + i + j * stride) : src[i + j * stride];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) { if (NT) __builtin_nontemporal_store(v[j], dst + i + j * stride); else dst[i + j * stride] = v[j]; }
   }
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 extern "C" {
 
-int drx_copy_f4(void *dst, const void *src, size_t n_bytes, void *stream) {
+int drx_copy_f4_variant(void *dst, const void *src, size_t n_bytes, int32_t variant, void *stream) {
   if (!dst || !src || n_bytes < 16 || (n_bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return DRX_EINVAL;
   const size_t n4 = n_bytes / 16;
-  const int blocks = (int)std::min<size_t>((n4 + 4 * kBlock - 1) / (4 * kBlock), 256 * 16);      // 16 workgroups per CU
-  hipLaunchKernelGGL(k_copy_f4, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n4);
+  hipStream_t st = (hipStream_t)stream;
+  copy_v4 *d = (copy_v4 *)dst;
+  const copy_v4 *sp = (const copy_v4 *)src;
+  const size_t one = (n4 + kBlock - 1) / kBlock;
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((k_copy_f4<4, false>), dim3((unsigned)std::min<size_t>((one + 3) / 4, 256 * 16)), dim3(kBlock), 0, st, d, sp, n4); break;
+    case 1: hipLaunchKernelGGL((k_copy_f4<1, false>), dim3((unsigned)std::min<size_t>(one, 0x7FFFFFFFu)), dim3(kBlock), 0, st, d, sp, n4); break;
+    case 2: hipLaunchKernelGGL((k_copy_f4<8, false>), dim3((unsigned)std::min<size_t>((one + 7) / 8, 256 * 8)), dim3(kBlock), 0, st, d, sp, n4); break;
+    case 3: hipLaunchKernelGGL((k_copy_f4<1, true>), dim3((unsigned)std::min<size_t>(one, 0x7FFFFFFFu)), dim3(kBlock), 0, st, d, sp, n4); break;
+    case 4: hipLaunchKernelGGL((k_copy_f4<4, true>), dim3((unsigned)std::min<size_t>((one + 3) / 4, 256 * 16)), dim3(kBlock), 0, st, d, sp, n4); break;
+    default: return DRX_EINVAL;
+  }
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
+
+#ifndef DRX_COPY_VARIANT
+#define DRX_COPY_VARIANT 0          // (what scripts/copy_bench.py measured fastest on an MI355X: profiles/r06_copy_variants.log)
+#endif
+int drx_copy_f4(void *dst, const void *src, size_t n_bytes, void *stream) { return drx_copy_f4_variant(dst, src, n_bytes, DRX_COPY_VARIANT, stream); }
 
 int drx_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, float alpha, float l2_coef, float beta1, float beta2,
                    float eps, void *stream) {

@@ -413,6 +413,8 @@ const char *drx_comm_last_error(void);
  *   float4 copy kernel — table snapshots (recommender_abc.py:336-352 keeps a copy of every weight per epoch), and the rate bench.py
  *   reports as `hbm_copy_achievable` (the achievable HBM rate measured on the box next to the nominal peak). */
 int drx_copy_f4(void *dst, const void *src, size_t n_bytes, void *stream);
+/* the same with the kernel's form chosen by the caller (0 .. 4: csrc/drx_generic.hip; scripts/copy_bench.py times them side by side) */
+int drx_copy_f4_variant(void *dst, const void *src, size_t n_bytes, int32_t variant, void *stream);
 
 /* ---- model-independent pieces of the dense (Keras-Adam) steps of DMF / Caser ------------------------------------
  * drx_adam_dense: p, m, v [n] (16-B aligned): g_total = g + l2_coef * p (g may be NULL); TF ApplyAdam update with the

@@ -13,3 +13,8 @@ for B in 4096 256; do
   grep "drx::" $OUT/dmf_B${B}_kernel_stats.csv | awk -F'",' '{print $1, $2, $4}' | cut -c1-60,200- | head -12
   grep "ms/step" $OUT/dmf$B.txt
 done
+cd $GRAFT_REPO_ROOT
+python scripts/sort_bench.py > $OUT/sort_bench.txt 2>&1
+for v in ipt4 ipt16 t256 t1024 t256ipt16; do DRX_HOST_SANITIZER_LIB=drecpy_amd/csrc/build/libdrx_sort_$v.so python scripts/sort_bench.py >> $OUT/sort_bench.txt 2>&1; done
+grep "sort of" $OUT/sort_bench.txt
+python scripts/copy_bench.py > $OUT/copy_bench.txt 2>&1; cat $OUT/copy_bench.txt
