@@ -401,7 +401,7 @@ int drx_copy_f4_variant(void *dst, const void *src, size_t n_bytes, int32_t vari
 }
 
 #ifndef DRX_COPY_VARIANT
-#define DRX_COPY_VARIANT 0          // (what scripts/copy_bench.py measured fastest on an MI355X: profiles/r06_copy_variants.log)
+#define DRX_COPY_VARIANT 3          // (what scripts/copy_bench.py measured fastest on an MI355X: profiles/r06_copy_variants.log)
 #endif
 int drx_copy_f4(void *dst, const void *src, size_t n_bytes, void *stream) { return drx_copy_f4_variant(dst, src, n_bytes, DRX_COPY_VARIANT, stream); }
 
