@@ -29,8 +29,9 @@ namespace drx {
 #define DRX_SORT_THREADS 512
 #endif
 #ifndef DRX_SORT_IPT
-#define DRX_SORT_IPT 8
-#endif
+#define DRX_SORT_IPT 16          // r06: tiles of 8192 pairs (8 through r05).  Alone the sort takes the same 78 - 79 us for 1.18 M pairs; beside the
+#endif                           // training kernels the step ran 0.3333 - 0.3372 ms against 0.3385 - 0.3391 (tiles of 2048: 0.350 - 0.354)
+                                 // [profiles/r06_sort_tile_variants_beside_training.log]: half as many workgroups asking for room on the CUs
 constexpr int kSortThreads = DRX_SORT_THREADS;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kSortIPT = DRX_SORT_IPT;            // items per thread
