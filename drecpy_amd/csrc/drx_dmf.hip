@@ -286,7 +286,8 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
   Tu.rho = A.rho_u; Ti.rho = A.rho_i;
   const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du, total = n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
-  for (int it = blockIdx.x; it < total; it += gridDim.x) {
+  for (int it0 = blockIdx.x; it0 < total; it0 += gridDim.x) {
+    const int it = A.work_order && !A.nd_dev ? A.work_order[it0] : it0;       // (longest rows first: include/drx.h DrxDmfArgs::work_order)
     const int tw = it < n_du ? 0 : 1, d = tw ? it - n_du : it;
     if (tw) tower_gather_q<WV, NU>(D, 1, Ti, d, k, w, part + w * W); else tower_gather_q<WV, NU>(D, 0, Tu, d, k, w, part + w * W);
     if (A.map_u && threadIdx.x == 0) {               // for k_dmf_k0_update: which distinct index this id has in THIS step
@@ -340,6 +341,7 @@ struct K0Tables {
   int rows[2];
   float alpha[2];
   float l2c, b1, b2, eps;
+  const int32_t *order;       // workgroup -> row (longest first), or nullptr
 };
 
 __global__ __launch_bounds__(256) void k_dmf_k0_update(DrxDmfDims D, DrxDmfArgs A, K0Tables U) {
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void k_dmf_k0_update(DrxDmfDims D, DrxDmfArgs 
   __shared__ float hc[4][64];
   __shared__ float4 part[4][16];
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6, r = k >> 4, c = k & 15;
-  const int row = blockIdx.x;
+  const int row = U.order ? U.order[blockIdx.x] : (int)blockIdx.x;
   const int tw = row < U.rows[0] ? 0 : 1;
   const int n = tw ? row - U.rows[0] : row;
   const int ld0 = D.ld0[tw];
@@ -1032,7 +1034,7 @@ int drx_dmf_k0_update(const DrxDmfDims *D, const DrxDmfArgs *A, const DrxDmfK0Up
        (uintptr_t)A->dz0u | (uintptr_t)A->dz0i) & 15)
     return DRX_EINVAL;
   K0Tables U{{up->K0u, up->K0i}, {up->m_u, up->m_i}, {up->v_u, up->v_i}, {up->n_items, up->n_users}, {up->alpha_u, up->alpha_i},
-             up->l2_coef, up->beta1, up->beta2, up->eps};
+             up->l2_coef, up->beta1, up->beta2, up->eps, up->row_order};
   hipLaunchKernelGGL(k_dmf_k0_update, dim3((unsigned)(up->n_items + up->n_users)), dim3(256), 0, (hipStream_t)stream, *D, *A, U);
   DRX_LAUNCH_CHECK();
   return DRX_OK;

@@ -776,6 +776,22 @@ int32_t drx_batch_distinct(const int32_t *ids, int32_t B, int32_t n_rows, const 
   return overflow ? DRX_EINVAL : nd;
 }
 
+// Work items of the DMF first-layer gather, longest first (DrxDmfArgs::work_order): item i < n_u is distinct user i with off_u[i + 1] -
+// off_u[i] non-zeros, item n_u + j distinct item j.  A counting sort over the bit length of the degree (descending), stable inside a
+// class: the few popular items whose columns hold thousands of entries come out in front — all the gather's launch needs — in O(n).
+int drx_dmf_work_order(const int32_t *off_u, int32_t n_u, const int32_t *off_i, int32_t n_i, int32_t *order) {
+  if (!off_u || !off_i || !order || n_u < 0 || n_i < 0) return DRX_EINVAL;
+  int32_t count[33] = {0}, start[33];
+  auto cls = [](int32_t d) { return d <= 0 ? 0 : 32 - __builtin_clz((uint32_t)d); };      // 0 .. 32
+  for (int32_t i = 0; i < n_u; ++i) ++count[cls(off_u[i + 1] - off_u[i])];
+  for (int32_t j = 0; j < n_i; ++j) ++count[cls(off_i[j + 1] - off_i[j])];
+  int32_t run = 0;
+  for (int c = 32; c >= 0; --c) { start[c] = run; run += count[c]; }
+  for (int32_t i = 0; i < n_u; ++i) order[start[cls(off_u[i + 1] - off_u[i])]++] = i;
+  for (int32_t j = 0; j < n_i; ++j) order[start[cls(off_i[j + 1] - off_i[j])]++] = n_u + j;
+  return DRX_OK;
+}
+
 int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out) {
   return drx_sampler_draw(s, DRX_DRAW_MIXED, n, h_uid_out, h_iid_out, h_val_out, nullptr);
 }

@@ -117,6 +117,11 @@ class DmfEngine:
         for (ip, _, vals), n, out in ((self.csr, self.U, self._rho[0]), (self.csc, self.N, self._rho[1])):
             check(lib().drx_dmf_norms(C.byref(self.D), ptr(ip), ptr(vals), n, ptr(out), stream_ptr(self.device)), 'drx_dmf_norms')
 
+        # drx_dmf_k0_update: row n of K0u (an item) walks COLUMN n of the matrix, row u of K0i (a user) walks ROW u; the longest walks
+        # first (include/drx.h DrxDmfK0Update::row_order) — static per dataset
+        walk = np.concatenate([np.diff(self._h_indptr[1]), np.diff(self._h_indptr[0])])
+        self._k0_order = torch.as_tensor(np.argsort(-walk, kind='stable').astype(np.int32)).to(d)
+
     SCAN_MAX_NNZ = 1 << 25      # 32 M non-zeros = 0.5 GB walked per step: beyond that the touches of a batch are the smaller job
 
     def set_params(self, p):
@@ -179,11 +184,11 @@ class DmfEngine:
                                      ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
 
     # what a step uploads, in this order, each array 16-byte aligned at a byte offset that depends on the batch size alone
-    _BATCH_ARRAYS = ('du', 'di', 'y', 'off_u', 'off_i', 'inv_u', 'inv_i', 'gptr_u', 'gptr_i', 'grows_u', 'grows_i')
+    _BATCH_ARRAYS = ('du', 'di', 'y', 'off_u', 'off_i', 'inv_u', 'inv_i', 'gptr_u', 'gptr_i', 'grows_u', 'grows_i', 'order')
 
     @staticmethod
     def _batch_layout(B):
-        lens = (B, B, B, B + 1, B + 1, B, B, B + 1, B + 1, B, B)
+        lens = (B, B, B, B + 1, B + 1, B, B, B + 1, B + 1, B, B, 2 * B)
         offs, total = [], 0
         for n in lens:
             offs.append(total)
@@ -214,6 +219,9 @@ class DmfEngine:
         y32[:] = y
         off_u = buf[at['off_u']:at['off_u'] + 4 * (nd[0] + 1)].view(np.int32)
         off_i = buf[at['off_i']:at['off_i'] + 4 * (nd[1] + 1)].view(np.int32)
+        # the gather's work items, LONGEST row / column first (include/drx.h DrxDmfArgs::work_order): a popular item's column has
+        # thousands of non-zeros and is the launch's critical path when its workgroup happens to start late
+        check(L_.drx_dmf_work_order(base + at['off_u'], nd[0], base + at['off_i'], nd[1], base + at['order']), 'drx_dmf_work_order')
         return {'buf': buf, 'offs': offs, 'B': B, 'n_du': nd[0], 'n_di': nd[1], 'Tu': int(off_u[-1]), 'Ti': int(off_i[-1]),
                 'y_mean': float(y32.astype(np.float64).mean())}
 
@@ -318,7 +326,7 @@ class DmfEngine:
             n_du = n_di = B                 # upper bounds: they size the launches; the kernels read nd_dev
         else:
             alive, ptrs = self._upload_batch(prep)
-            p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri = ptrs
+            p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri, p_order = ptrs
             B, Tu, Ti = prep['B'], prep['Tu'], prep['Ti']
             n_du, n_di = prep['n_du'], prep['n_di']
         ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
@@ -342,6 +350,8 @@ class DmfEngine:
         A.y, A.off_u, A.off_i = p_y, p_offu, p_offi
         A.inv_u, A.inv_i, A.gptr_u, A.gptr_i, A.grows_u, A.grows_i = p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri
         A.n_du, A.n_di = n_du, n_di
+        if not on_device:
+            A.work_order = p_order
         if on_device:
             A.nd_dev, A.y_mean_dev = prep['device']['nd'].data_ptr(), prep['device']['y_mean'].data_ptr()
         if self.broadcast_targets and self.scale_var is not None:
@@ -375,6 +385,7 @@ class DmfEngine:
             (mu, vu), (mi, vi) = self.state['K0u'], self.state['K0i']
             up.K0u, up.m_u, up.v_u, up.K0i, up.m_i, up.v_i = (t.data_ptr() for t in (self.K0u, mu, vu, self.K0i, mi, vi))
             up.n_items, up.n_users = self.N, self.U
+            up.row_order = self._k0_order.data_ptr()
             up.alpha_u, up.alpha_i, up.l2_coef, up.beta1, up.beta2, up.eps = alpha[0], alpha[1], l2c, self.beta1, self.beta2, self.eps
             check(L_.drx_dmf_k0_update(C.byref(self.D), C.byref(A), C.byref(up), stream), 'drx_dmf_k0_update')
         else:

@@ -1,6 +1,9 @@
 """The ordinary CDAE.fit() as a multi-GPU job: start one process per GPU, give every process the SAME dataset and seed; training
-runs column-sharded (every rank K/N columns of every table, same batches, one all-reduce of B floats per step), and when fit()
-returns every rank holds the whole model and can predict / rank on its own.
+runs ROW-sharded (layout='rows', the default: every rank the V rows, histories and samples of its user range and the item rows of its
+item range; the rows a batch needs and their merged gradients travel by all-to-all(v), pipelined in `exchange_chunks` chunks;
+`batch_size` triples are drawn PER RANK and step — or, with CDAE(layout='columns'), column-sharded: every rank K/N columns of every
+table, the same global batch, one all-reduce of B floats per step), and when fit() returns every rank holds the whole model and can
+predict / rank on its own.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/cdae_fit_multi_gpu.py"""
 import os
 import sys
@@ -28,9 +31,9 @@ user = np.repeat(np.arange(users, dtype=np.int64), np.diff(indptr))
 ds = InteractionDataset.from_arrays(user, indices.astype(np.int64), np.ones(len(user)))        # identical on every rank
 
 model = CDAE(hidden_factors=128, corruption_level=0.2, mode='sampled', device_sampler=True, seed=10, verbose=False,
-             device=f'cuda:{local}')
+             device=f'cuda:{local}', layout='rows', exchange_chunks=2)
 t0 = time.time()
-model.fit(ds, learning_rate=0.05, reg_rate=0.001, epochs=300, batch_size=65536 * world, neg_ratio=5)
+model.fit(ds, learning_rate=0.05, reg_rate=0.001, epochs=300, batch_size=65536, neg_ratio=5)      # 65 536 triples per rank and step
 torch.cuda.synchronize()
 if rank == 0:
     print(f'{world} GPUs: fit (set-up + 300 steps of {65536 * world}) {time.time() - t0:.2f} s; top-5 for user 0:', model.recommend(0, n=5))

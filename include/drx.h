@@ -580,7 +580,14 @@ typedef struct DrxDmfArgs {
    * there.  nd_dev [2] = {n_du, n_di} (n_du / n_di above then are upper bounds that size the launches), y_mean_dev [1]; or NULL. */
   const int32_t *nd_dev;
   const float *y_mean_dev;
+  /* r06, optional (NULL: the distinct ids in their own order): a permutation of 0 .. n_du + n_di - 1 — work item i of the first-layer
+   * gather takes distinct id work_order[i] (users 0 .. n_du - 1, items n_du ..).  LONGEST rows / columns FIRST: the gather of a popular
+   * item's column (thousands of non-zeros) is the launch's critical path when it happens to start late. */
+  const int32_t *work_order;
 } DrxDmfArgs;
+/* Host helper for DrxDmfArgs::work_order: the gather's work items (distinct users 0 .. n_u - 1 with off_u[i + 1] - off_u[i] non-zeros, then
+ * distinct items) ordered by the bit length of their degree, descending, stable inside a class — O(n). */
+int drx_dmf_work_order(const int32_t *off_u, int32_t n_u, const int32_t *off_i, int32_t n_i, int32_t *order);
 /* Host helper for the arrays above: the distinct ids of a batch, ascending.  distinct [<= B], inv [B], gptr [<= B+1], grows [B],
  * off [<= B+1] (prefix sums of indptr row lengths of the distinct ids; NULL to skip) are host arrays;
  * scratch = int32 [n_rows], all -1 on entry and again on return (the caller keeps it between steps).  Returns the number of distinct
@@ -616,6 +623,9 @@ typedef struct DrxDmfK0Update {
   int32_t n_items, n_users;
   float alpha_u, alpha_i;    /* Keras-Adam lr_t of the apply_gradients call each kernel belongs to */
   float l2_coef, beta1, beta2, eps;
+  /* r06, optional (NULL: rows in table order): a permutation of 0 .. n_items + n_users - 1 (K0u rows, then K0i rows) — workgroup i takes
+   * row row_order[i]; the rows with the longest columns / rows of the interaction matrix first (static per dataset) */
+  const int32_t *row_order;
 } DrxDmfK0Update;
 int drx_dmf_k0_update(const DrxDmfDims *D, const DrxDmfArgs *A, const DrxDmfK0Update *up, void *stream);
 /* all-pairs cosine scores on the matrix cores: out[u, n] = max(1e-6, ru[u,:kdim] . ri[n,:kdim]) with bf16 operands /

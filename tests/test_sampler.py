@@ -498,3 +498,24 @@ def test_counter_based_list_sampler_has_the_reference_samplers_distribution():
     first_ref = np.asarray(iid[in_rows], np.int64).reshape(n, L)[:, 0]
     close(first_ref, b_c[:, 0].astype(np.int64), n_ids, 'first input id (group x window start)')
     close(np.asarray(negs, np.int64), a_c[:, T:].reshape(-1).astype(np.int64), n_ids, 'negative ids')
+
+
+def test_dmf_work_order_puts_the_longest_rows_first():
+    """drx_dmf_work_order (include/drx.h DrxDmfArgs::work_order): a permutation of the gather's work items, classes of the degree's bit
+    length descending, stable inside a class."""
+    from drecpy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for n_u, n_i in ((50, 70), (1, 0), (0, 3), (4096, 3000)):
+        du, di = rng.integers(0, 3000, n_u), rng.integers(0, 7000, n_i)
+        ou, oi = np.zeros(n_u + 1, np.int32), np.zeros(n_i + 1, np.int32)
+        ou[1:], oi[1:] = np.cumsum(du), np.cumsum(di)
+        out = np.full(n_u + n_i, -1, np.int32)
+        assert L.drx_dmf_work_order(ou.ctypes.data, n_u, oi.ctypes.data, n_i, out.ctypes.data) == 0
+        deg = np.concatenate([du, di])
+        cls = [int(deg[i]).bit_length() for i in out]
+        assert sorted(out.tolist()) == list(range(n_u + n_i))
+        assert all(cls[i] >= cls[i + 1] for i in range(len(cls) - 1))
+        for c in set(cls):                                  # stable: ascending work-item index inside a class
+            idx = [int(out[i]) for i in range(len(cls)) if cls[i] == c]
+            assert idx == sorted(idx)
