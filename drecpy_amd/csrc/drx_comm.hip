@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -133,7 +134,9 @@ static void comm_thread(DrxComm *c) {
       }
       c->issued.store(t + 1, std::memory_order_release);
       idle = 0;
-    } else if (++idle > 4000) {
+    } else if (++idle > 200000) {
+      std::this_thread::sleep_for(std::chrono::microseconds(200));      // (nothing for a long while: evaluation, set-up — stop burning the core)
+    } else if (idle > 4000) {
       std::this_thread::yield();                  // (between steps: give the core away; inside a step the next request is microseconds off)
     }
   }
