@@ -54,20 +54,126 @@ __global__ __launch_bounds__(kBlock) void k_topk_lds(const float *__restrict__ s
   }
 }
 
+__device__ __forceinline__ unsigned long long topk_key(const float *scores, const uint32_t *mask, size_t row_off, int i) {
+  const size_t bit = row_off + (size_t)i;
+  const bool ok = !mask || ((mask[bit >> 5] >> (bit & 31)) & 1u);
+  return ok ? (((unsigned long long)ordered_bits(scores[bit]) << 32) | (unsigned)i) : 0ull;
+}
+
+// ---- small k of a short row (the ranking protocols: k = 10 of a MovieLens catalogue): SELECTION by one wave, no sort (r06) ----------
+// The LDS path above sorts every padded row in full whatever k is: 231 us for 2048 rows of 3706 scores at k = 10 (78 bitonic stages of
+// 4096 keys behind 78 workgroup barriers) — 25 x the 9.4 us the DMF scorer needs to produce them.  Here ONE WAVE owns a row, holds its
+// keys in registers (NPL per lane, row position lane + 64 j) and extracts the k largest one after another: the keys are unique (the
+// index is part of them), so the next winner is the largest key BELOW the last one — a lane's local maximum under that bound, then a
+// wave maximum by shuffles.  No LDS, no barrier, O(k NPL) instructions per wave; every row of the launch is resident at once.
+// maximum of a 32-bit value over the wave, in every lane: the GCN data-parallel-primitive ladder (quad swaps, half-row and row mirrors,
+// then the row broadcasts that gfx9 keeps) — six dependent v_max_u32_dpp, no LDS crossbar; the last lane holds the result
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define DRX_DPP_MAX(ctrl, rows) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, true))
+  DRX_DPP_MAX(0xB1, 0xF);          // quad_perm [1, 0, 3, 2]
+  DRX_DPP_MAX(0x4E, 0xF);          // quad_perm [2, 3, 0, 1]
+  DRX_DPP_MAX(0x141, 0xF);         // row_half_mirror
+  DRX_DPP_MAX(0x140, 0xF);         // row_mirror: every lane of a row of 16 holds the row's maximum
+  DRX_DPP_MAX(0x142, 0xA);         // row_bcast15 into rows 1 and 3
+  DRX_DPP_MAX(0x143, 0xC);         // row_bcast31 into rows 2 and 3
+#undef DRX_DPP_MAX
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// a lane's two largest keys below `bound` (a >= b; 0 = none): 11 vector instructions per key
+template <int NPL>
+__device__ __forceinline__ void lane_top2(const unsigned long long (&key)[NPL], unsigned long long bound, unsigned long long &a,
+                                          unsigned long long &b) {
+  a = 0ull; b = 0ull;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const unsigned long long c = key[j] < bound ? key[j] : 0ull;
+    const bool up = c > a;
+    const unsigned long long lo = up ? a : c;
+    a = up ? c : a;
+    b = lo > b ? lo : b;
+  }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(kBlock) void k_topk_wave(const float *__restrict__ scores, const uint32_t *__restrict__ mask, int R, int n, int k,
+                                                      int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+  const int lane = threadIdx.x & 63;
+  const size_t r = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (r >= (size_t)R) return;
+  const size_t row_off = r * (size_t)n;
+  unsigned long long key[NPL];
+  {
+    // every load of the row issued before the first is waited for: clamped positions, no branch (a conditional load per key had the
+    // compiler wait for each in turn: 58 round trips, 18 us of a wave's life whatever k)
+    float v[NPL];
+    uint32_t mw[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = min(lane + 64 * j, n - 1);
+      v[j] = scores[row_off + (size_t)i];
+    }
+    if (mask) {
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const size_t bit = row_off + (size_t)min(lane + 64 * j, n - 1);
+        mw[j] = mask[bit >> 5] >> (bit & 31);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) mw[j] = 1u;
+    }
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = lane + 64 * j;
+      key[j] = (i < n && (mw[j] & 1u)) ? (((unsigned long long)ordered_bits(v[j]) << 32) | (unsigned)i) : 0ull;
+    }
+  }
+  // Every lane keeps its TWO best keys not yet handed out (first version: the lane's maximum below the last winner recomputed over all
+  // its registers in every round — 38 us for 2048 rows of 3706 at k = 10, bound by those 6 NPL instructions per round).  A round is then
+  // a wave maximum of the lanes' heads and a pop on the winning lane; a lane that has handed out both refills from its registers below
+  // its last key — rare: k winners fall on 64 lanes.
+  unsigned long long a, b;
+  lane_top2<NPL>(key, ~0ull, a, b);                    // (a valid key is never all ones: the index is below 2^31)
+  unsigned long long last = ~0ull;                     // this lane's last winner: what a refill starts below
+  unsigned long long mine = 0ull;
+  for (int it = 0; it < k; ++it) {
+    // the largest head: its score bits first, then the largest index among the lanes that hold those bits (two 32-bit wave maxima by
+    // DPP; six shuffle rounds of a 64-bit value through the LDS crossbar had cost 0.65 us per round)
+    const uint32_t mh = wave_max_u32((uint32_t)(a >> 32));
+    const uint32_t ml = wave_max_u32((uint32_t)(a >> 32) == mh ? (uint32_t)a : 0u);
+    const unsigned long long m = ((unsigned long long)mh << 32) | ml;
+    if (lane == it) mine = m;                          // winner `it` waits on lane `it` (k <= 64): written out after the loop, all at once
+    if (m == 0ull) continue;                           // (the row is exhausted: the rest comes out "missing"; wave-uniform)
+    const bool won = a == m;                           // keys are unique: exactly one lane
+    if (won) { last = a; a = b; b = 0ull; }
+    if (__ballot(won && a == 0ull)) {                  // the winner has nothing left in hand: its next two below `last` (wave-uniform branch)
+      unsigned long long na, nb;
+      lane_top2<NPL>(key, last, na, nb);
+      if (won && a == 0ull) { a = na; b = nb; }
+    }
+  }
+  // (first version: lane 0 wrote winner `it` inside the loop — its score is a dependent load the store waits for: a round trip per
+  // round, 29 us for the launch)
+  if (lane < k) {
+    if (mine == 0ull) { out_idx[r * (size_t)k + lane] = -1; out_val[r * (size_t)k + lane] = -INFINITY; }
+    else {
+      const int idx = (int)(mine & 0xFFFFFFFFull);
+      out_idx[r * (size_t)k + lane] = idx;
+      out_val[r * (size_t)k + lane] = scores[row_off + idx];
+    }
+  }
+}
+
 // ---- rows longer than the LDS path (the 1 M-item catalogue): RADIX SELECT, not a sort ------------------------------------------
 // One workgroup per row finds the k-th largest 64-bit key by walking its digits from the top, 11 bits at a time: a 2048-bin LDS
 // histogram of the digit among the keys that match the prefix found so far, the bin where the count from the top reaches k, next
 // digit (6 passes over the row, which L2 / the Infinity Cache hold after the first).  Keys are unique (the index is part of them),
 // so exactly k keys are >= the k-th one: they are collected (in any order) and a second launch orders those k in LDS with the
 // bitonic network above.  r02 sorted every row in full with rocprim::segmented_radix_sort_keys_desc.
+constexpr int kWaveTopkMaxK = 64;       // k_topk_wave: above it the full sort in LDS costs less than k passes over the registers
 constexpr int kSelThreads = 1024;
 constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;
-
-__device__ __forceinline__ unsigned long long topk_key(const float *scores, const uint32_t *mask, size_t row_off, int i) {
-  const size_t bit = row_off + (size_t)i;
-  const bool ok = !mask || ((mask[bit >> 5] >> (bit & 31)) & 1u);
-  return ok ? (((unsigned long long)ordered_bits(scores[bit]) << 32) | (unsigned)i) : 0ull;
-}
 
 __global__ __launch_bounds__(kSelThreads) void k_topk_select(const float *__restrict__ scores, const uint32_t *__restrict__ mask, int n,
                                                              int k, unsigned long long *__restrict__ cand, int *__restrict__ n_cand) {
@@ -257,6 +363,14 @@ extern "C" int drx_topk(const float *scores, const uint32_t *cand_mask, int32_t 
                            out_idx + (size_t)r * k, out_val + (size_t)r * k);
       }
     }
+    DRX_LAUNCH_CHECK();
+    return DRX_OK;
+  }
+  if (k <= drx::kWaveTopkMaxK && n <= 64 * 64) {            // few of a short row: selection by one wave per row
+    const dim3 grid((unsigned)((R + drx::kBlock / 64 - 1) / (drx::kBlock / 64)));
+    if (n <= 64 * 16) hipLaunchKernelGGL(drx::k_topk_wave<16>, grid, dim3(drx::kBlock), 0, st, scores, cand_mask, R, n, k, out_idx, out_val);
+    else if (n <= 64 * 32) hipLaunchKernelGGL(drx::k_topk_wave<32>, grid, dim3(drx::kBlock), 0, st, scores, cand_mask, R, n, k, out_idx, out_val);
+    else hipLaunchKernelGGL(drx::k_topk_wave<64>, grid, dim3(drx::kBlock), 0, st, scores, cand_mask, R, n, k, out_idx, out_val);
     DRX_LAUNCH_CHECK();
     return DRX_OK;
   }
