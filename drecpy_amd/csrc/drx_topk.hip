@@ -171,7 +171,8 @@ __global__ __launch_bounds__(kBlock) void k_topk_wave(const float *__restrict__ 
 // digit (6 passes over the row, which L2 / the Infinity Cache hold after the first).  Keys are unique (the index is part of them),
 // so exactly k keys are >= the k-th one: they are collected (in any order) and a second launch orders those k in LDS with the
 // bitonic network above.  r02 sorted every row in full with rocprim::segmented_radix_sort_keys_desc.
-constexpr int kWaveTopkMaxK = 64;       // k_topk_wave: above it the full sort in LDS costs less than k passes over the registers
+constexpr int kWaveTopkMaxK = 64;       // k_topk_wave: one winner per lane.  (Up to 512 winners in 8 registers per lane was built: k = 100 took 214 us
+                                        // against the sort's 232 — with more winners than lanes the refills, 1 us each, take over.)
 constexpr int kSelThreads = 1024;
 constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;
 

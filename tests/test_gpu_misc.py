@@ -48,7 +48,7 @@ def test_dataset_assign_ids_on_gpu_matches_golden():
                                  (1_000_000, 100), (40_000, 20_000), (20_000, 30_000),      # long rows: radix select (+ the k > 16384 ordering)
                                  # r06: k <= 64 of rows of <= 4096 scores: selection by one wave per row (16 / 32 / 64 keys per lane), more
                                  # candidates asked for than the mask leaves, a row of one score
-                                 (3706, 10), (4096, 64), (1024, 1), (1025, 33), (2048, 64), (2049, 3), (63, 64), (5, 1), (700, 40), (130, 60)])
+                                 (3706, 10), (4096, 64), (1024, 1), (1025, 33), (2048, 64), (2049, 3), (63, 64), (5, 1), (700, 40), (130, 60), (3706, 65)])
 def test_topk_matches_heapq(n, k):
     import torch
     from drecpy_amd.engine import CdaeEngine, pack_mask_bits
