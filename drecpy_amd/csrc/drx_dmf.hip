@@ -102,12 +102,16 @@ __device__ __forceinline__ void tower_gather(const DrxDmfDims &D, int tw, const 
 // t % (4 / NU) == r; the partial sums are combined by exchanges.  Writes this wave's partial pre-activations (column k at out[k]) —
 // the training path (k_dmf_gather).
 template <int WV, int NU>
-__device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out) {
+__device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, const TowerIO &T, int b, int k, int w, float *out, int seg = 0,
+                                               int seg_len = 0) {
   constexpr int LPR = 16 * NU, RPW = 64 / LPR;      // lanes per kernel row, rows per load instruction
   const int id = T.ids[b];
-  const int64_t s = T.indptr[id], e = T.indptr[id + 1];
+  const int64_t s0 = T.indptr[id], e0 = T.indptr[id + 1];
+  // (a long row / column cut into segments of seg_len non-zeros: DrxDmfArgs::work_order — this workgroup's part of it)
+  const int64_t s = seg_len > 0 ? s0 + (int64_t)seg * seg_len : s0;
+  const int64_t e = seg_len > 0 ? (s + seg_len < e0 ? s + seg_len : e0) : e0;
   // (a popular item has thousands of non-zeros: forming the norm here, one load in flight per wave, was the kernel's tail)
-  const float rho_in = T.rho ? T.rho[id] : row_rho(D, T.values, s, e, k);
+  const float rho_in = T.rho ? T.rho[id] : row_rho(D, T.values, s0, e0, k);
   const int r = k / LPR, c = k % LPR;
   const bool ok = 4 * c < T.ld0;
   float4 acc = f4_zero();
@@ -120,7 +124,7 @@ __device__ __forceinline__ void tower_gather_q(const DrxDmfDims &D, int tw, cons
     if (j < e) {
       idx = T.indices[j];
       v = T.values[j] * rho_in;
-      if (touches) { T.tkeys[base + (j - s)] = (uint32_t)idx; T.tsrc[base + (j - s)] = (uint32_t)b; T.tcoef[base + (j - s)] = v; }
+      if (touches) { T.tkeys[base + (j - s0)] = (uint32_t)idx; T.tsrc[base + (j - s0)] = (uint32_t)b; T.tcoef[base + (j - s0)] = v; }
     }
     const int n_here = (int)((e - c0) < 64 ? (e - c0) : 64);
     for (int t = 0; t < n_here; t += 8 * RPW) {
@@ -285,12 +289,16 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
   TowerIO Tu{A.K0u, D.ld0[0], A.u_indptr, A.u_indices, A.u_values, A.uid, A.off_u, A.dz0u, A.tkeys_u, A.tsrc_u, A.tcoef_u};
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
   Tu.rho = A.rho_u; Ti.rho = A.rho_i;
-  const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du, total = n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
+  const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du;
+  const bool listed = A.work_order && !A.nd_dev;     // (longest rows first, long ones in segments: include/drx.h DrxDmfArgs::work_order)
+  const int total = listed ? A.n_work : n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
   for (int it0 = blockIdx.x; it0 < total; it0 += gridDim.x) {
-    const int it = A.work_order && !A.nd_dev ? A.work_order[it0] : it0;       // (longest rows first: include/drx.h DrxDmfArgs::work_order)
+    const int enc = listed ? A.work_order[it0] : it0;
+    const int it = enc & 0xFFFFFF, seg = listed ? (int)((unsigned)enc >> 24) : 0, seg_len = listed ? A.seg_len : 0;
     const int tw = it < n_du ? 0 : 1, d = tw ? it - n_du : it;
-    if (tw) tower_gather_q<WV, NU>(D, 1, Ti, d, k, w, part + w * W); else tower_gather_q<WV, NU>(D, 0, Tu, d, k, w, part + w * W);
-    if (A.map_u && threadIdx.x == 0) {               // for k_dmf_k0_update: which distinct index this id has in THIS step
+    if (tw) tower_gather_q<WV, NU>(D, 1, Ti, d, k, w, part + w * W, seg, seg_len);
+    else tower_gather_q<WV, NU>(D, 0, Tu, d, k, w, part + w * W, seg, seg_len);
+    if (A.map_u && threadIdx.x == 0 && seg == 0) {   // for k_dmf_k0_update: which distinct index this id has in THIS step
       const int id = tw ? A.iid[d] : A.uid[d];
       (tw ? A.map_i : A.map_u)[id] = ((unsigned long long)A.stamp << 32) | (unsigned long long)(uint32_t)d;
     }
@@ -301,7 +309,9 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
         float p = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WV; ++ww) p += part[ww * W + k + 64 * h];
-        Wk.z0[((size_t)tw * A.B + d) * W + k + 64 * h] = p;
+        // segment 0: the id's first-layer sum; a later segment: its partial row (the dense kernel adds them in segment order)
+        if (seg == 0) Wk.z0[((size_t)tw * A.B + d) * W + k + 64 * h] = p;
+        else A.zpart[((size_t)(A.zseg[it] >> 8) + seg - 1) * W + k + 64 * h] = p;
       }
     }
     __syncthreads();
@@ -494,6 +504,15 @@ __global__ __launch_bounds__(256) void k_dmf_dense(DrxDmfDims D, DrxDmfArgs A) {
       pu[h] = Wk.z0[((size_t)0 * A.B + A.inv_u[b]) * W + k + 64 * h];
       pi[h] = Wk.z0[((size_t)1 * A.B + A.inv_i[b]) * W + k + 64 * h];
     }
+    if (A.zseg && A.work_order && !A.nd_dev) {       // long rows / columns gathered in segments: their partial rows, in segment order
+      const int zu_ = A.zseg[A.inv_u[b]], zi_ = A.zseg[A.n_du + A.inv_i[b]];
+      for (int g = 0; g < (zu_ & 255); ++g)
+#pragma unroll
+        for (int h = 0; h < NU; ++h) pu[h] += A.zpart[((size_t)(zu_ >> 8) + g) * W + k + 64 * h];
+      for (int g = 0; g < (zi_ & 255); ++g)
+#pragma unroll
+        for (int h = 0; h < NU; ++h) pi[h] += A.zpart[((size_t)(zi_ >> 8) + g) * W + k + 64 * h];
+    }
     float zu[kDmfMaxLayers][NU], au[kDmfMaxLayers][NU], zi[kDmfMaxLayers][NU], ai[kDmfMaxLayers][NU], ru[NU], ri[NU];
     tower_dense<NU>(D, 0, swl, k, pu, zu, au, ru);
     tower_dense<NU>(D, 1, swl, k, pi, zi, ai, ri);
@@ -579,7 +598,13 @@ __global__ __launch_bounds__(256) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs
     for (int it = 0; it < 2; ++it) {
       const int s_ = half * 8 + it * 4 + q4, c4 = m16 * 4, b = b0 + s_;
       float4 z = f4_zero();
-      if (b < A.B) z = *reinterpret_cast<const float4 *>(Wk.z0 + ((size_t)tw * A.B + inv[b]) * W + c4);
+      if (b < A.B) {
+        z = *reinterpret_cast<const float4 *>(Wk.z0 + ((size_t)tw * A.B + inv[b]) * W + c4);
+        if (A.zseg && A.work_order && !A.nd_dev) {     // a long row / column gathered in segments: its partial rows, in segment order
+          const int zs = A.zseg[(tw ? A.n_du : 0) + inv[b]];
+          for (int g = 0; g < (zs & 255); ++g) f4_add(z, *reinterpret_cast<const float4 *>(A.zpart + ((size_t)(zs >> 8) + g) * W + c4));
+        }
+      }
       float a[4] = {z.x, z.y, z.z, z.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[j] = (c4 + j < f0) ? fmaxf(a[j] + swl[D.off_b[tw][0] + c4 + j], 0.f) : 0.f;
@@ -979,7 +1004,10 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   if (A->target_mode == 1 && A->nd_dev && !A->y_mean_dev) return DRX_EINVAL;      // a device-prepared batch knows its mean only there
   const int wv = dmf_waves(A->n_du + A->n_di);
   const int items = A->n_du + A->n_di;
-  const int ggrid = items < 8192 ? items : 8192;
+  const bool listed = A->work_order && !A->nd_dev;
+  if (listed && (A->n_work < items || A->seg_len < 0 || (A->seg_len > 0 && (!A->zseg || !A->zpart)))) return DRX_EINVAL;
+  const int gitems = listed ? A->n_work : items;            // (long rows / columns cut into segments: more work items than ids)
+  const int ggrid = gitems < 8192 ? gitems : 8192;
   const int nu = dmf_units(*D), W = 64 * nu;
 #define DRX_DMF_GATHER(WVN, NUN) hipLaunchKernelGGL((k_dmf_gather<WVN, NUN>), dim3(ggrid), dim3(64 * WVN), 0, st, *D, *A)
   if (nu == 1) { if (wv == 16) DRX_DMF_GATHER(16, 1); else if (wv == 8) DRX_DMF_GATHER(8, 1); else DRX_DMF_GATHER(4, 1); }

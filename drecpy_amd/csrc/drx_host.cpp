@@ -776,20 +776,41 @@ int32_t drx_batch_distinct(const int32_t *ids, int32_t B, int32_t n_rows, const 
   return overflow ? DRX_EINVAL : nd;
 }
 
-// Work items of the DMF first-layer gather, longest first (DrxDmfArgs::work_order): item i < n_u is distinct user i with off_u[i + 1] -
-// off_u[i] non-zeros, item n_u + j distinct item j.  A counting sort over the bit length of the degree (descending), stable inside a
-// class: the few popular items whose columns hold thousands of entries come out in front — all the gather's launch needs — in O(n).
-int drx_dmf_work_order(const int32_t *off_u, int32_t n_u, const int32_t *off_i, int32_t n_i, int32_t *order) {
-  if (!off_u || !off_i || !order || n_u < 0 || n_i < 0) return DRX_EINVAL;
+// Work items of the DMF first-layer gather (DrxDmfArgs::work_order), longest first, LONG rows / columns CUT INTO SEGMENTS: entry =
+// work index | segment << 24, work index i < n_u = distinct user i (off_u[i + 1] - off_u[i] non-zeros), n_u + j = distinct item j.  A
+// counting sort over the bit length of the degree (descending), stable inside a class, in O(n): the few popular items whose columns
+// hold thousands of entries come out in front, each as ceil(deg / seg_len) entries of at most seg_len non-zeros — segment 0 writes the
+// id's first-layer sum, segment g > 0 partial row zseg[i] >> 8 + g - 1 (zseg[i] = first partial << 8 | number of partials; 0: none).
+// seg_len = 0: no cutting.  Returns the number of entries (<= order_cap), or DRX_ESCRATCH when they do not fit; *n_part = partial rows.
+int32_t drx_dmf_work_order(const int32_t *off_u, int32_t n_u, const int32_t *off_i, int32_t n_i, int32_t seg_len, int32_t *order,
+                           int32_t order_cap, int32_t *zseg, int32_t *n_part) {
+  if (!off_u || !off_i || !order || n_u < 0 || n_i < 0 || seg_len < 0 || (int64_t)n_u + n_i >= (1 << 24)) return DRX_EINVAL;
+  if (seg_len > 0 && !zseg) return DRX_EINVAL;
   int32_t count[33] = {0}, start[33];
   auto cls = [](int32_t d) { return d <= 0 ? 0 : 32 - __builtin_clz((uint32_t)d); };      // 0 .. 32
-  for (int32_t i = 0; i < n_u; ++i) ++count[cls(off_u[i + 1] - off_u[i])];
-  for (int32_t j = 0; j < n_i; ++j) ++count[cls(off_i[j + 1] - off_i[j])];
+  auto segs = [seg_len](int32_t d) { return seg_len > 0 && d > seg_len ? (d + seg_len - 1) / seg_len : 1; };
+  int64_t entries = 0;
+  for (int32_t i = 0; i < n_u + n_i; ++i) {
+    const int32_t d = i < n_u ? off_u[i + 1] - off_u[i] : off_i[i - n_u + 1] - off_i[i - n_u];
+    const int32_t ns = segs(d);
+    if (ns > 255) return DRX_EINVAL;                  // (the caller picks seg_len >= max degree / 255)
+    count[cls(d)] += ns;
+    entries += ns;
+  }
+  if (entries > order_cap) return DRX_ESCRATCH;
   int32_t run = 0;
   for (int c = 32; c >= 0; --c) { start[c] = run; run += count[c]; }
-  for (int32_t i = 0; i < n_u; ++i) order[start[cls(off_u[i + 1] - off_u[i])]++] = i;
-  for (int32_t j = 0; j < n_i; ++j) order[start[cls(off_i[j + 1] - off_i[j])]++] = n_u + j;
-  return DRX_OK;
+  int32_t parts = 0;
+  for (int32_t i = 0; i < n_u + n_i; ++i) {
+    const int32_t d = i < n_u ? off_u[i + 1] - off_u[i] : off_i[i - n_u + 1] - off_i[i - n_u];
+    const int32_t ns = segs(d);
+    int32_t &at = start[cls(d)];
+    for (int32_t g = 0; g < ns; ++g) order[at++] = i | (g << 24);
+    if (zseg) zseg[i] = ns > 1 ? ((parts << 8) | (ns - 1)) : 0;
+    parts += ns - 1;
+  }
+  if (n_part) *n_part = parts;
+  return (int32_t)entries;
 }
 
 int drx_sampler_sample(DrxSampler *s, int32_t n, int32_t *h_uid_out, int32_t *h_iid_out, double *h_val_out) {

@@ -120,6 +120,8 @@ class DmfEngine:
         # drx_dmf_k0_update: row n of K0u (an item) walks COLUMN n of the matrix, row u of K0i (a user) walks ROW u; the longest walks
         # first (include/drx.h DrxDmfK0Update::row_order) — static per dataset
         walk = np.concatenate([np.diff(self._h_indptr[1]), np.diff(self._h_indptr[0])])
+        # segment length of the gather's work items: 1024 non-zeros, more where the longest row / column would need over 255 segments
+        self._seg_len = max(1024, -(-int(walk.max() if len(walk) else 0) // 255))
         self._k0_order = torch.as_tensor(np.argsort(-walk, kind='stable').astype(np.int32)).to(d)
 
     SCAN_MAX_NNZ = 1 << 25      # 32 M non-zeros = 0.5 GB walked per step: beyond that the touches of a batch are the smaller job
@@ -184,11 +186,12 @@ class DmfEngine:
                                      ptr(self._scratch), self._scratch.numel(), stream_ptr(self.device)), 'drx_scatter_rows')
 
     # what a step uploads, in this order, each array 16-byte aligned at a byte offset that depends on the batch size alone
-    _BATCH_ARRAYS = ('du', 'di', 'y', 'off_u', 'off_i', 'inv_u', 'inv_i', 'gptr_u', 'gptr_i', 'grows_u', 'grows_i', 'order')
+    _BATCH_ARRAYS = ('du', 'di', 'y', 'off_u', 'off_i', 'inv_u', 'inv_i', 'gptr_u', 'gptr_i', 'grows_u', 'grows_i', 'order', 'zseg')
+    _ORDER_EXTRA = 4096        # work items beyond one per distinct id (segments of long rows / columns): drx_dmf_work_order's order_cap
 
     @staticmethod
     def _batch_layout(B):
-        lens = (B, B, B, B + 1, B + 1, B, B, B + 1, B + 1, B, B, 2 * B)
+        lens = (B, B, B, B + 1, B + 1, B, B, B + 1, B + 1, B, B, 2 * B + DmfEngine._ORDER_EXTRA, 2 * B)
         offs, total = [], 0
         for n in lens:
             offs.append(total)
@@ -221,8 +224,20 @@ class DmfEngine:
         off_i = buf[at['off_i']:at['off_i'] + 4 * (nd[1] + 1)].view(np.int32)
         # the gather's work items, LONGEST row / column first (include/drx.h DrxDmfArgs::work_order): a popular item's column has
         # thousands of non-zeros and is the launch's critical path when its workgroup happens to start late
-        check(L_.drx_dmf_work_order(base + at['off_u'], nd[0], base + at['off_i'], nd[1], base + at['order']), 'drx_dmf_work_order')
+        # the gather's work items: longest rows / columns first, long ones cut into segments of _seg_len non-zeros (include/drx.h
+        # DrxDmfArgs::work_order; uncut when the segments would not fit the list: rare, correct all the same)
+        n_part = C.c_int32(0)
+        seg = self._seg_len
+        n_work = int(L_.drx_dmf_work_order(base + at['off_u'], nd[0], base + at['off_i'], nd[1], seg, base + at['order'],
+                                           2 * B + self._ORDER_EXTRA, base + at['zseg'], C.byref(n_part)))
+        if n_work < 0:
+            seg = 0
+            n_work = int(L_.drx_dmf_work_order(base + at['off_u'], nd[0], base + at['off_i'], nd[1], 0, base + at['order'],
+                                               2 * B + self._ORDER_EXTRA, base + at['zseg'], C.byref(n_part)))
+            if n_work < 0:
+                check(n_work, 'drx_dmf_work_order')
         return {'buf': buf, 'offs': offs, 'B': B, 'n_du': nd[0], 'n_di': nd[1], 'Tu': int(off_u[-1]), 'Ti': int(off_i[-1]),
+                'n_work': n_work, 'seg_len': seg, 'n_part': int(n_part.value),
                 'y_mean': float(y32.astype(np.float64).mean())}
 
     # ---- batches drawn and prepared ON THE DEVICE (DMF.fit(device_sampler=True): throughput mode) --------------------------------
@@ -326,7 +341,7 @@ class DmfEngine:
             n_du = n_di = B                 # upper bounds: they size the launches; the kernels read nd_dev
         else:
             alive, ptrs = self._upload_batch(prep)
-            p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri, p_order = ptrs
+            p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri, p_order, p_zseg = ptrs
             B, Tu, Ti = prep['B'], prep['Tu'], prep['Ti']
             n_du, n_di = prep['n_du'], prep['n_di']
         ld0u, ld0i = self.D.ld0[0], self.D.ld0[1]
@@ -351,7 +366,11 @@ class DmfEngine:
         A.inv_u, A.inv_i, A.gptr_u, A.gptr_i, A.grows_u, A.grows_i = p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri
         A.n_du, A.n_di = n_du, n_di
         if not on_device:
-            A.work_order = p_order
+            A.work_order, A.n_work, A.seg_len, A.zseg = p_order, prep['n_work'], prep['seg_len'], p_zseg
+            zp = getattr(self, '_zpart', None)
+            if zp is None:
+                zp = self._zpart = torch.empty(self._ORDER_EXTRA + 8, self.W, dtype=torch.float32, device=self.device)
+            A.zpart = zp.data_ptr()
         if on_device:
             A.nd_dev, A.y_mean_dev = prep['device']['nd'].data_ptr(), prep['device']['y_mean'].data_ptr()
         if self.broadcast_targets and self.scale_var is not None:

@@ -580,14 +580,24 @@ typedef struct DrxDmfArgs {
    * there.  nd_dev [2] = {n_du, n_di} (n_du / n_di above then are upper bounds that size the launches), y_mean_dev [1]; or NULL. */
   const int32_t *nd_dev;
   const float *y_mean_dev;
-  /* r06, optional (NULL: the distinct ids in their own order): a permutation of 0 .. n_du + n_di - 1 — work item i of the first-layer
-   * gather takes distinct id work_order[i] (users 0 .. n_du - 1, items n_du ..).  LONGEST rows / columns FIRST: the gather of a popular
-   * item's column (thousands of non-zeros) is the launch's critical path when it happens to start late. */
+  /* r06, optional (NULL: one work item per distinct id, in their own order; ignored with nd_dev): the first-layer gather's n_work work
+   * items, entry = distinct index (users 0 .. n_du - 1, items n_du ..) | segment << 24.  LONGEST rows / columns FIRST — the gather of a
+   * popular item's column (thousands of non-zeros) is the launch's critical path when it happens to start late — and long ones CUT
+   * into segments of seg_len non-zeros (0: uncut): segment 0 leaves the id's first-layer sum, segment g > 0 the partial row
+   * zpart[(zseg[i] >> 8) + g - 1] (rows of 64 floats per unit slot), which the dense kernel adds in segment order (zseg[i] & 255 of
+   * them).  drx_dmf_work_order builds order and zseg on the host. */
   const int32_t *work_order;
+  int32_t n_work, seg_len;
+  const int32_t *zseg;
+  float *zpart;
 } DrxDmfArgs;
-/* Host helper for DrxDmfArgs::work_order: the gather's work items (distinct users 0 .. n_u - 1 with off_u[i + 1] - off_u[i] non-zeros, then
- * distinct items) ordered by the bit length of their degree, descending, stable inside a class — O(n). */
-int drx_dmf_work_order(const int32_t *off_u, int32_t n_u, const int32_t *off_i, int32_t n_i, int32_t *order);
+/* Host helper for DrxDmfArgs::work_order / zseg: the gather's work items (distinct users 0 .. n_u - 1 with off_u[i + 1] - off_u[i]
+ * non-zeros, then distinct items), ordered by the bit length of their degree, descending, stable inside a class — O(n) — and cut into
+ * segments of at most seg_len non-zeros (0: uncut): entry = work index | segment << 24; zseg[i] = first partial row << 8 | number of
+ * partial rows of work index i (0: none).  Returns the number of entries, DRX_ESCRATCH when they exceed order_cap (use seg_len = 0
+ * then), DRX_EINVAL when a row would need more than 255 segments; *n_part = partial rows. */
+int32_t drx_dmf_work_order(const int32_t *off_u, int32_t n_u, const int32_t *off_i, int32_t n_i, int32_t seg_len, int32_t *order,
+                           int32_t order_cap, int32_t *zseg, int32_t *n_part);
 /* Host helper for the arrays above: the distinct ids of a batch, ascending.  distinct [<= B], inv [B], gptr [<= B+1], grows [B],
  * off [<= B+1] (prefix sums of indptr row lengths of the distinct ids; NULL to skip) are host arrays;
  * scratch = int32 [n_rows], all -1 on entry and again on return (the caller keeps it between steps).  Returns the number of distinct

@@ -500,22 +500,35 @@ def test_counter_based_list_sampler_has_the_reference_samplers_distribution():
     close(np.asarray(negs, np.int64), a_c[:, T:].reshape(-1).astype(np.int64), n_ids, 'negative ids')
 
 
-def test_dmf_work_order_puts_the_longest_rows_first():
-    """drx_dmf_work_order (include/drx.h DrxDmfArgs::work_order): a permutation of the gather's work items, classes of the degree's bit
-    length descending, stable inside a class."""
+def test_dmf_work_order_puts_the_longest_rows_first_and_cuts_them():
+    """drx_dmf_work_order (include/drx.h DrxDmfArgs::work_order / zseg): the gather's work items — every distinct id, classes of the
+    degree's bit length descending, stable inside a class, a row of more than seg_len non-zeros as ceil(deg / seg_len) entries
+    (segment << 24), its partial rows numbered consecutively in work-index order."""
+    import ctypes as C
     from drecpy_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(0)
-    for n_u, n_i in ((50, 70), (1, 0), (0, 3), (4096, 3000)):
+    for n_u, n_i, seg in ((50, 70, 1024), (1, 0, 0), (0, 3, 16), (4096, 3000, 1024), (40, 40, 0)):
         du, di = rng.integers(0, 3000, n_u), rng.integers(0, 7000, n_i)
         ou, oi = np.zeros(n_u + 1, np.int32), np.zeros(n_i + 1, np.int32)
         ou[1:], oi[1:] = np.cumsum(du), np.cumsum(di)
-        out = np.full(n_u + n_i, -1, np.int32)
-        assert L.drx_dmf_work_order(ou.ctypes.data, n_u, oi.ctypes.data, n_i, out.ctypes.data) == 0
         deg = np.concatenate([du, di])
-        cls = [int(deg[i]).bit_length() for i in out]
-        assert sorted(out.tolist()) == list(range(n_u + n_i))
+        nseg = np.where((seg > 0) & (deg > seg), -(-deg // max(seg, 1)), 1) if seg else np.ones(len(deg), np.int64)
+        if nseg.max(initial=1) > 255:
+            continue
+        cap = int(nseg.sum())
+        out, zseg, n_part = np.full(cap, -1, np.int32), np.full(n_u + n_i, -1, np.int32), C.c_int32(-1)
+        n = L.drx_dmf_work_order(ou.ctypes.data, n_u, oi.ctypes.data, n_i, seg, out.ctypes.data, cap, zseg.ctypes.data, C.byref(n_part))
+        assert n == cap and n_part.value == int((nseg - 1).sum())
+        ids, segs = out & 0xFFFFFF, out >> 24
+        cls = [int(deg[i]).bit_length() for i in ids]
         assert all(cls[i] >= cls[i + 1] for i in range(len(cls) - 1))
-        for c in set(cls):                                  # stable: ascending work-item index inside a class
-            idx = [int(out[i]) for i in range(len(cls)) if cls[i] == c]
-            assert idx == sorted(idx)
+        for i in range(n_u + n_i):                          # every id: its segments 0 .. nseg - 1, in order, adjacent
+            at = np.flatnonzero(ids == i)
+            assert segs[at].tolist() == list(range(int(nseg[i]))) and (len(at) == 1 or np.all(np.diff(at) == 1))
+        first = 0
+        for i in range(n_u + n_i):
+            assert zseg[i] == (((first << 8) | int(nseg[i] - 1)) if nseg[i] > 1 else 0)
+            first += int(nseg[i] - 1)
+        if cap > n_u + n_i:                                  # a list that is too short is refused, not truncated
+            assert L.drx_dmf_work_order(ou.ctypes.data, n_u, oi.ctypes.data, n_i, seg, out.ctypes.data, cap - 1, zseg.ctypes.data, C.byref(n_part)) < 0
