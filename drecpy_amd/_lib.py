@@ -94,7 +94,7 @@ class DmfArgs(C.Structure):
 
 class DmfK0Update(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('K0u', 'm_u', 'v_u', 'K0i', 'm_i', 'v_i')] + [('n_items', C.c_int32), ('n_users', C.c_int32)] + \
-               [(n, C.c_float) for n in ('alpha_u', 'alpha_i', 'l2_coef', 'beta1', 'beta2', 'eps')] + [('row_order', C.c_void_p)]
+               [(n, C.c_float) for n in ('alpha_u', 'alpha_i', 'l2_coef', 'beta1', 'beta2', 'eps')] + [('row_order', C.c_void_p), ('n_long', C.c_int32)]
 
 
 class Optim(C.Structure):

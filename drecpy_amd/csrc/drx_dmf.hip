@@ -352,13 +352,109 @@ struct K0Tables {
   float alpha[2];
   float l2c, b1, b2, eps;
   const int32_t *order;       // workgroup -> row (longest first), or nullptr
+  int n_long;                 // with `order`: its first n_long rows take a workgroup each, the others a WAVE each (four per workgroup)
 };
+
+// One WAVE per kernel row (r06; rows whose column / row of the interaction matrix holds at most kK0WaveMax entries: all but a few hundred).
+// A workgroup per row left four fifths of its lanes idle on the average row (193 entries against 1024 per round) and kept a CU at 8 rows
+// in flight; a wave per row keeps 32.  Same walk, the wave's own 256 entries per round, no cross-wave combine.
+constexpr int kK0WaveMax = 1024;
+__device__ __forceinline__ void k0_update_wave_row(const DrxDmfDims &D, const DrxDmfArgs &A, const K0Tables &U, int row, int (*hd)[64],
+                                                   float (*hc)[64]) {
+  const int k = threadIdx.x & 63, w = threadIdx.x >> 6, r = k >> 4, c = k & 15;
+  const int tw = row < U.rows[0] ? 0 : 1;
+  const int n = tw ? row - U.rows[0] : row;
+  const int ld0 = D.ld0[tw];
+  const int64_t *ip = tw ? A.u_indptr : A.i_indptr;
+  const int32_t *ix = tw ? A.u_indices : A.i_indices;
+  const float *vals = tw ? A.u_values : A.i_values;
+  const unsigned long long *map = tw ? A.map_i : A.map_u;
+  const float *rho = tw ? A.rho_i : A.rho_u;
+  const float *dz0 = tw ? A.dz0i : A.dz0u;
+  const bool col = 4 * c < ld0;
+  const bool upd = r == 0 && col;
+  float4 p = f4_zero(), m = f4_zero(), v = f4_zero();
+  const size_t at = (size_t)n * ld0 + 4 * c;
+  if (upd) {
+    p = *reinterpret_cast<const float4 *>(U.K0[tw] + at);
+    m = *reinterpret_cast<const float4 *>(U.m[tw] + at);
+    v = *reinterpret_cast<const float4 *>(U.v[tw] + at);
+  }
+  const int64_t s = ip[n], e = ip[n + 1];
+  float4 acc = f4_zero();
+  constexpr int UN = 4;
+  for (int64_t c0 = s; c0 < e; c0 += 64 * UN) {
+    int id[UN];
+    float val[UN];
+    unsigned long long ent[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t j = c0 + 64 * u + k;
+      id[u] = j < e ? ix[j] : -1;
+      val[u] = j < e ? vals[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      ent[u] = id[u] >= 0 ? map[id[u]] : 0ull;
+      val[u] *= id[u] >= 0 ? rho[id[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (c0 + 64 * u >= e) break;                   // (wave-uniform)
+      const bool hit = (uint32_t)(ent[u] >> 32) == A.stamp;
+      const unsigned long long mask = __ballot(hit);
+      if (!mask) continue;
+      if (hit) {
+        const int rank = __popcll(mask & ((1ull << k) - 1ull));
+        hd[w][rank] = (int)(uint32_t)ent[u];
+        hc[w][rank] = val[u];
+      }
+      wave_lds_sync();
+      const int nh = __popcll(mask);
+      int t = r;
+      for (; t + 4 < nh; t += 8) {                   // two dz0 rows in flight per quarter-wave
+        const int d0 = hd[w][t], d1 = hd[w][t + 4];
+        const float c0f = hc[w][t], c1f = hc[w][t + 4];
+        float4 x0 = f4_zero(), x1 = f4_zero();
+        if (col) {
+          x0 = *reinterpret_cast<const float4 *>(dz0 + (size_t)d0 * ld0 + 4 * c);
+          x1 = *reinterpret_cast<const float4 *>(dz0 + (size_t)d1 * ld0 + 4 * c);
+        }
+        f4_fma(acc, c0f, x0);
+        f4_fma(acc, c1f, x1);
+      }
+      if (t < nh) {
+        const int dd = hd[w][t];
+        const float cc = hc[w][t];
+        if (col) f4_fma(acc, cc, *reinterpret_cast<const float4 *>(dz0 + (size_t)dd * ld0 + 4 * c));
+      }
+      wave_lds_sync();
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+  if (upd) {
+    const OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, U.b1, U.b2, U.eps, U.alpha[tw]};
+    opt_update1(o, fmaf(U.l2c, p.x, acc.x), p.x, m.x, v.x);
+    opt_update1(o, fmaf(U.l2c, p.y, acc.y), p.y, m.y, v.y);
+    opt_update1(o, fmaf(U.l2c, p.z, acc.z), p.z, m.z, v.z);
+    opt_update1(o, fmaf(U.l2c, p.w, acc.w), p.w, m.w, v.w);
+    *reinterpret_cast<float4 *>(U.K0[tw] + at) = p;
+    *reinterpret_cast<float4 *>(U.m[tw] + at) = m;
+    *reinterpret_cast<float4 *>(U.v[tw] + at) = v;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_dmf_k0_update(DrxDmfDims D, DrxDmfArgs A, K0Tables U) {
   __shared__ int hd[4][64];
   __shared__ float hc[4][64];
   __shared__ float4 part[4][16];
   const int k = threadIdx.x & 63, w = threadIdx.x >> 6, r = k >> 4, c = k & 15;
+  if (U.order && (int)blockIdx.x >= U.n_long) {      // a workgroup of four short rows, a wave each (whole waves leave: no barrier in there)
+    const int i = U.n_long + ((int)blockIdx.x - U.n_long) * 4 + w;
+    if (i < U.rows[0] + U.rows[1]) k0_update_wave_row(D, A, U, U.order[i], hd, hc);
+    return;
+  }
   const int row = U.order ? U.order[blockIdx.x] : (int)blockIdx.x;
   const int tw = row < U.rows[0] ? 0 : 1;
   const int n = tw ? row - U.rows[0] : row;
@@ -1062,8 +1158,15 @@ int drx_dmf_k0_update(const DrxDmfDims *D, const DrxDmfArgs *A, const DrxDmfK0Up
        (uintptr_t)A->dz0u | (uintptr_t)A->dz0i) & 15)
     return DRX_EINVAL;
   K0Tables U{{up->K0u, up->K0i}, {up->m_u, up->m_i}, {up->v_u, up->v_i}, {up->n_items, up->n_users}, {up->alpha_u, up->alpha_i},
-             up->l2_coef, up->beta1, up->beta2, up->eps, up->row_order};
-  hipLaunchKernelGGL(k_dmf_k0_update, dim3((unsigned)(up->n_items + up->n_users)), dim3(256), 0, (hipStream_t)stream, *D, *A, U);
+             up->l2_coef, up->beta1, up->beta2, up->eps, up->row_order, 0};
+  const int rows = up->n_items + up->n_users;
+  int grid = rows;
+  if (up->row_order) {                               // the order's first n_long rows: a workgroup each; the others a wave each
+    if (up->n_long < 0 || up->n_long > rows) return DRX_EINVAL;
+    U.n_long = up->n_long;
+    grid = up->n_long + (rows - up->n_long + 3) / 4;
+  }
+  hipLaunchKernelGGL(k_dmf_k0_update, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *D, *A, U);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

@@ -123,6 +123,7 @@ class DmfEngine:
         # segment length of the gather's work items: 1024 non-zeros, more where the longest row / column would need over 255 segments
         self._seg_len = max(1024, -(-int(walk.max() if len(walk) else 0) // 255))
         self._k0_order = torch.as_tensor(np.argsort(-walk, kind='stable').astype(np.int32)).to(d)
+        self._k0_long = int((walk > 1024).sum())            # (csrc/drx_dmf.hip kK0WaveMax: longer walks take a workgroup, the others a wave)
 
     SCAN_MAX_NNZ = 1 << 25      # 32 M non-zeros = 0.5 GB walked per step: beyond that the touches of a batch are the smaller job
 
@@ -404,7 +405,7 @@ class DmfEngine:
             (mu, vu), (mi, vi) = self.state['K0u'], self.state['K0i']
             up.K0u, up.m_u, up.v_u, up.K0i, up.m_i, up.v_i = (t.data_ptr() for t in (self.K0u, mu, vu, self.K0i, mi, vi))
             up.n_items, up.n_users = self.N, self.U
-            up.row_order = self._k0_order.data_ptr()
+            up.row_order, up.n_long = self._k0_order.data_ptr(), self._k0_long
             up.alpha_u, up.alpha_i, up.l2_coef, up.beta1, up.beta2, up.eps = alpha[0], alpha[1], l2c, self.beta1, self.beta2, self.eps
             check(L_.drx_dmf_k0_update(C.byref(self.D), C.byref(A), C.byref(up), stream), 'drx_dmf_k0_update')
         else:

@@ -633,9 +633,11 @@ typedef struct DrxDmfK0Update {
   int32_t n_items, n_users;
   float alpha_u, alpha_i;    /* Keras-Adam lr_t of the apply_gradients call each kernel belongs to */
   float l2_coef, beta1, beta2, eps;
-  /* r06, optional (NULL: rows in table order): a permutation of 0 .. n_items + n_users - 1 (K0u rows, then K0i rows) — workgroup i takes
-   * row row_order[i]; the rows with the longest columns / rows of the interaction matrix first (static per dataset) */
+  /* r06, optional (NULL: rows in table order, a workgroup each): a permutation of 0 .. n_items + n_users - 1 (K0u rows, then K0i rows),
+   * the rows with the longest columns / rows of the interaction matrix first (static per dataset).  Its first n_long rows take a
+   * workgroup each — every row whose walk is longer than 1024 entries must be among them —, the others a WAVE each, four per workgroup. */
   const int32_t *row_order;
+  int32_t n_long;
 } DrxDmfK0Update;
 int drx_dmf_k0_update(const DrxDmfDims *D, const DrxDmfArgs *A, const DrxDmfK0Update *up, void *stream);
 /* all-pairs cosine scores on the matrix cores: out[u, n] = max(1e-6, ru[u,:kdim] . ri[n,:kdim]) with bf16 operands /
