@@ -104,9 +104,10 @@ def parse(argv=None):
 # ------------------------------------------------------------------------------------------------------------------------------
 # N-GPU launch: no GPU call anywhere in this section
 # ------------------------------------------------------------------------------------------------------------------------------
-def _child_argv(argv, layout):
-    """The command line of one rank's child for `layout`: this script with the same measurement flags."""
-    drop_with_value = {'--layout', '--child-layout', '--layout-timeout-s'}
+def _child_argv(argv, layout, override=()):
+    """The command line of one rank's child for `layout`: this script with the same measurement flags (`override`: flag, value, …
+    that replace the caller's)."""
+    drop_with_value = {'--layout', '--child-layout', '--layout-timeout-s'} | set(override[0::2])
     out, skip = [], False
     for a in argv:
         if skip:
@@ -118,7 +119,29 @@ def _child_argv(argv, layout):
         if any(a.startswith(d + '=') for d in drop_with_value) or a in ('--launch-dry-run',):
             continue
         out.append(a)
-    return [sys.executable, os.path.join(ROOT, 'bench.py')] + out + ['--child-layout', layout]
+    return [sys.executable, os.path.join(ROOT, 'bench.py')] + out + list(override) + ['--child-layout', layout]
+
+
+def _agree(rdzv_dir, name, ranks, world, ok, wait_s=120.0):
+    """Did attempt `name` succeed on EVERY rank?  Under torch.distributed.run each rank has its own coordinator: all of them must take
+    the same decision (retry / go on), or the next layout's children would wait for ranks that never come.  One small file per rank in
+    the rendezvous directory (one node: a shared file system); a rank that never reports counts as failed."""
+    for r in ranks:
+        with open(os.path.join(rdzv_dir, f'{name}.status.{r}.tmp'), 'w') as f:
+            f.write('ok' if ok else 'bad')
+        os.replace(os.path.join(rdzv_dir, f'{name}.status.{r}.tmp'), os.path.join(rdzv_dir, f'{name}.status.{r}'))
+    t0, seen = time.time(), {}
+    while len(seen) < world and time.time() - t0 < wait_s:
+        for r in range(world):
+            if r not in seen:
+                try:
+                    with open(os.path.join(rdzv_dir, f'{name}.status.{r}')) as f:
+                        seen[r] = f.read().strip()
+                except OSError:
+                    pass
+        if len(seen) < world:
+            time.sleep(0.05)
+    return len(seen) == world and all(v == 'ok' for v in seen.values())
 
 
 def _child_env(rank, local_rank, world, rdzv):
@@ -177,14 +200,24 @@ def coordinate(args, argv, ranks, world, rdzv_dir, local_of=None):
     fail or exceed the time limit is reported inside `layouts` and cannot be the headline.  The children of a layout meet through
     `file://<rdzv_dir>/<layout>`: no TCP port is chosen anywhere (a computed port inside the ephemeral range failed GPUTEST_r03)."""
     layouts = ['selftest'] if args.launch_selftest else (list(LAYOUTS) if args.layout == 'both' else [args.layout])
-    results, errors = {}, {}
+    # (name, layout, flags that replace the caller's, only if that attempt failed).  The row layout's second chance: the same step with
+    # its exchanges issued through torch.distributed — the library's own communicator has only ever run at world 1 (one-GPU boxes)
+    attempts = []
+    for lay in layouts:
+        attempts.append((lay, lay, (), None))
+        if lay == 'rows' and args.transport == 'rccl':
+            attempts.append(('rows_torch_transport', 'rows', ('--transport', 'torch'), 'rows'))
+    results, errors, failed, done_ok = {}, {}, set(), set()
     local_of = local_of or {}
-    for i, lay in enumerate(layouts):
-        rdzv = f'file://{rdzv_dir}/{lay}'
-        cmd = _child_argv(argv, lay)
+    for name, lay, override, only_after in attempts:
+        if only_after is not None and only_after not in failed and not args.launch_dry_run:
+            continue
+        rdzv = f'file://{rdzv_dir}/{name}'
+        cmd = _child_argv(argv, lay, override)
         if args.launch_dry_run:
             for r in ranks:
-                print(f'[{lay}] RANK={r} LOCAL_RANK={r} WORLD_SIZE={world} DRX_RDZV={rdzv} ' + ' '.join(cmd), flush=True)
+                print(f'[{name}{" (only if " + only_after + " fails)" if only_after else ""}] RANK={r} LOCAL_RANK={r} WORLD_SIZE={world} '
+                      f'DRX_RDZV={rdzv} ' + ' '.join(cmd), flush=True)
             continue
         t0 = time.time()
         procs = [(r, subprocess.Popen(cmd, env=_child_env(r, local_of.get(r, r), world, rdzv),
@@ -196,16 +229,23 @@ def coordinate(args, argv, ranks, world, rdzv_dir, local_of=None):
             if ln.startswith('{'):
                 line = ln
         if bad:
-            errors[lay] = {'error': f'child exit codes {bad}', 'first_failed_rank': first_bad, 'seconds': round(time.time() - t0, 1)}
+            errors[name] = {'error': f'child exit codes {bad}', 'first_failed_rank': first_bad, 'seconds': round(time.time() - t0, 1)}
         elif 0 in ranks and line is None:
-            errors[lay] = {'error': 'rank 0 printed no JSON line', 'seconds': round(time.time() - t0, 1)}
-        elif line is not None:
-            results[lay] = json.loads(line)
+            errors[name] = {'error': 'rank 0 printed no JSON line', 'seconds': round(time.time() - t0, 1)}
+        if not _agree(rdzv_dir, name, ranks, world, name not in errors):
+            failed.add(name)
+            errors.setdefault(name, {'error': 'failed on another rank', 'seconds': round(time.time() - t0, 1)})
+        else:
+            done_ok.add(lay)
+            if line is not None:
+                results[lay] = json.loads(line)
+                if name != lay:
+                    results[lay]['attempt'] = name
     if args.launch_dry_run:
         return None, 0
     rc = 0 if (results or (0 not in ranks and not errors)) else 1
     if 0 not in ranks:
-        return None, (1 if len(errors) == len(layouts) else 0)
+        return None, (0 if done_ok else 1)
     if not results:
         return {'metric': 'training samples/sec (user-item pairs)', 'value': None, 'n_gpus': world, 'layouts': errors, 'error': 'every layout failed'}, rc
     # north_star fixes the ROW-wise shard: it is the N > 1 headline whenever it ran (r06; through r05 the faster layout was); the column
@@ -216,7 +256,7 @@ def coordinate(args, argv, ranks, world, rdzv_dir, local_of=None):
     out['headline_rule'] = 'rows (north_star) when it ran; otherwise the layout that did'
     brief = {}
     for lay, r in results.items():
-        brief[lay] = {k_: r.get(k_) for k_ in ('value', 'ms_per_step', 'window_ms_min', 'window_ms_max', 'phases_ms', 'rccl_ranks', 'host_issue_ms_per_step')}
+        brief[lay] = {k_: r.get(k_) for k_ in ('value', 'ms_per_step', 'window_ms_min', 'window_ms_max', 'phases_ms', 'rccl_ranks', 'host_issue_ms_per_step', 'attempt')}
         brief[lay]['sharding'] = (r.get('config') or {}).get('sharding')
         brief[lay]['roofline'] = {k_: (r.get('roofline') or {}).get(k_) for k_ in ('kernel', 'frac', 'achieved', 'whole_step_frac', 'model_frac')}
     brief.update(errors)

@@ -15,6 +15,9 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import bench_cpu          # noqa: E402  (the CPU legs: the only importer of oracle/ outside tests and smoke)
 
 
 def frame_of(shape, seed=0):
@@ -186,7 +189,7 @@ def dmf_block(ds, dev, with_cpu=True):
                           'tflops': flops / (ms * 1e-3) / 1e12, 'bound': 'hbm (16 FLOP per output byte)'}
     ue = torch.arange(0, n_u, device=dev)
     out['score_matrix_incl_towers_ms'] = _timed(lambda: m._engine.score_matrix_bf16(ue), 10) * 1e3
-    out['cpu_baseline'] = __import__('bench_cpu').dmf_cpu_baseline(ds) if with_cpu else None
+    out['cpu_baseline'] = bench_cpu.dmf_cpu_baseline(ds) if with_cpu else None
     return out
 
 
@@ -230,7 +233,7 @@ def caser_block(ds, dev, with_cpu=True):
         out[f'Caser_B{B}_device_sampler'] = {'fit_ms_per_step_incl_setup': e2d * 1e3, 'fit_steady_ms_per_step': steady_d * 1e3,
                                              'fit_windows_per_s': B / steady_d, 'fit_windows': spread_d,
                                              'sampler': getattr(m2, '_sampler_kind', None)}
-    out['cpu_baseline'] = __import__('bench_cpu').caser_cpu_baseline(m.n_users, m.n_items) if with_cpu else None
+    out['cpu_baseline'] = bench_cpu.caser_cpu_baseline(m.n_users, m.n_items) if with_cpu else None
     return out
 
 

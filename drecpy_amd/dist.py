@@ -583,7 +583,7 @@ class ShardedCdae:
         owned row is updated once with the sum of their gradients — the step still equals the single-process step on the
         concatenated batch — but the row exchange of micro-batch m+1 and the gradient exchange of micro-batch m travel while
         the other one computes.
-        next_prepared: the prepared (keys exchanged, owner table built) micro-batches of the NEXT step.  Their rows are then gathered
+        next_prepared: the prepared (keys exchanged, owner table built) micro-batches of the NEXT step, or a callable that returns them.  Their rows are then gathered
         and sent chunk by chunk right behind this step's owner apply of the same chunk (the module docstring's pipeline), and the
         next call finds them in flight instead of fetching them at its head.
         Event slots (bench; one micro-batch): [0,1) waiting for the rows (fetched here when the previous step did not), [1,2) forward /
@@ -639,6 +639,8 @@ class ShardedCdae:
         # ---- owner side, chunk by chunk: apply what has arrived, then answer the next step's requests for the same key range
         head = Ps[0]
         nxt = None
+        if callable(next_prepared):                    # (the pipeline: the next step's keys are exchanged INSIDE this call — looked up now)
+            next_prepared = next_prepared()
         if next_prepared is not None:
             nxt = list(next_prepared) if isinstance(next_prepared, (list, tuple)) else [next_prepared]
             if not nxt or 'table' not in nxt[0]:       # (not ready: the next call fetches its rows itself)
@@ -771,9 +773,10 @@ class ShardedPipeline:
                 with self._on_side():
                     self._prepare(s + self.LOOKAHEAD)
             ahead_s[0] += time.perf_counter() - ta
-        nxt = _Later(lambda: self.P.get(s + 1))       # (step s + 1's keys are exchanged inside this call: looked up when the tail starts)
+        # (step s + 1's keys are exchanged inside this call, by run_ahead: its prepared micro-batches are looked up when the tail starts)
         out = self.m.step(s, self._micro(s), events=events, want_loss=want_loss, prepared=self.P.pop(s),
-                          after_row_requests=run_ahead, after_apply=prepare_ahead, next_prepared=nxt if s + 1 < self.n else None)
+                          after_row_requests=run_ahead, after_apply=prepare_ahead,
+                          next_prepared=(lambda: self.P.get(s + 1)) if s + 1 < self.n else None)
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(self.main)
@@ -784,17 +787,6 @@ class ShardedPipeline:
             self.batch_of.release(s)                   # e.g. engine.DeviceBatchSource: the batch's buffers may be reused
         self.next = s + 1
         return out
-
-
-class _Later(list):
-    """the next step's prepared micro-batches, resolved when first iterated (they are completed during the current step)"""
-
-    def __init__(self, get):
-        super().__init__()
-        self._get = get
-
-    def __iter__(self):
-        return iter(self._get() or [])
 
 
 class _SideStream:

@@ -18,7 +18,9 @@ def test_dry_run_prints_one_command_line_per_rank_and_layout():
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('[')]
-    assert len(lines) == 8                                        # 4 ranks x (rows, columns)
+    assert len(lines) == 12                                       # 4 ranks x (rows, its second chance, columns)
+    retry = [l for l in lines if l.startswith('[rows_torch_transport (only if rows fails)]')]
+    assert len(retry) == 4 and all(l.rstrip().endswith('--transport torch --child-layout rows') for l in retry)
     for lay in ('rows', 'columns'):
         mine = [l for l in lines if l.startswith(f'[{lay}]')]
         assert sorted(int(l.split('RANK=')[1].split()[0]) for l in mine) == [0, 1, 2, 3]
@@ -27,7 +29,7 @@ def test_dry_run_prints_one_command_line_per_rank_and_layout():
         for l in mine:
             assert 'WORLD_SIZE=4' in l and 'MASTER_PORT' not in l and l.rstrip().endswith(f'--child-layout {lay}')
             assert '--gpus 4 --steps 20 --warmup 5' in l and '--launch-dry-run' not in l
-    assert len({l.split('DRX_RDZV=')[1].split()[0] for l in lines}) == 2         # ... and the two layouts in different ones
+    assert len({l.split('DRX_RDZV=')[1].split()[0] for l in lines}) == 3         # ... and every attempt in a store of its own
 
 
 def _one_line(stdout):
@@ -66,6 +68,20 @@ def test_a_failing_layout_is_reported_not_fatal(tmp_path):
                          capture_output=True, text=True, timeout=400)
     d = _one_line(out.stdout)
     assert out.returncode != 0 and d['value'] is None and 'error' in d['layouts']['columns']
+
+
+def test_a_failing_row_layout_gets_a_second_chance_through_torch_distributed():
+    """The row layout's exchanges go through the library's own RCCL communicator by default; when that attempt fails on ANY rank every
+    coordinator starts the layout once more with --transport torch (here both die: no GPU) — and an explicit --transport torch has no
+    second attempt."""
+    env = dict(ENV, HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+    out = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '2', '--warmup', '1', '--layout', 'rows', '--layout-timeout-s', '120'],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    d = _one_line(out.stdout)
+    assert out.returncode != 0 and d['value'] is None and set(d['layouts']) == {'rows', 'rows_torch_transport'}, d
+    out = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '2', '--warmup', '1', '--layout', 'rows', '--transport', 'torch',
+                          '--layout-timeout-s', '120'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert set(_one_line(out.stdout)['layouts']) == {'rows'}
 
 
 def test_row_statistics_of_the_shared_form_match_a_brute_force_count():
