@@ -93,6 +93,8 @@ def parse(argv=None):
                     'pipelined with the owner apply and the next step\'s gather: drecpy_amd/dist.py); 1 = one all-to-all per exchange (r05)')
     ap.add_argument('--transport', default='rccl', choices=['rccl', 'torch'], help='row layout: who issues the all-to-all(v) exchanges — the library\'s own '
                     'RCCL communicator (csrc/drx_comm.hip: one ncclGroup per exchange, enqueued from C) or torch.distributed')
+    ap.add_argument('--no-phases', action='store_true', help='row layout, --transport rccl: issue the exchanges of a step call by call from Python '
+                    '(drecpy_amd/dist.py) instead of through the library\'s four phase calls (drx_shard_phase_*: A/B of the host cost)')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     ap.add_argument('--launch-dry-run', action='store_true', help='print the per-rank child command lines of an N-GPU run and exit (no GPU call)')
     ap.add_argument('--launch-selftest', action='store_true', help='children only rendezvous over gloo and all-reduce on the CPU (tests the launcher)')
@@ -745,7 +747,8 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         from drecpy_amd.dist import ShardedCdae
         stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
                               cpu_staging=debug_gloo, force_collectives=rccl1, self_bypass=not args.no_self_bypass, chunks=args.chunks,
-                              transport='rccl' if (args.transport == 'rccl' and not debug_gloo and (world > 1 or rccl1)) else None)
+                              transport='rccl' if (args.transport == 'rccl' and not debug_gloo and (world > 1 or rccl1)) else None,
+                              phases=False if args.no_phases else None)
         eng = stepper.engine
 
     micro = max(1, args.micro)       # > 1: micro-batches whose exchanges overlap each other's compute (measured at world 1: the split costs more than it hides)
@@ -955,6 +958,8 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
                    'micro_batches': (micro if stepper is not None else None),
                    'exchange_chunks': (stepper.chunks if stepper is not None else None),
                    'transport': (type(stepper.xfer).__name__ if stepper is not None else None),
+                   'exchanges_issued_by': (('library (drx_shard_phase_*)' if (stepper.phases and max(1, args.micro) == 1) else 'dist.py, call by call')
+                                           if stepper is not None else None),
                    'sharding': ('single GPU' if stepper is None else
                                 'row-sharded code path at world 1, ' + ('every row sent through the communicator (--no-self-bypass: all rows "remote", the link '
                                                                         'replaced by a device copy)' if args.no_self_bypass else

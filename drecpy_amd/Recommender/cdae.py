@@ -21,7 +21,7 @@ class CDAE(RecommenderABC):
     fused_fit = True      # reference mode: fit() runs its quiet loop inside the library (_run_steps); False = always step by step
 
     def __init__(self, hidden_factors=50, corruption_level=0.2, loss='bce', mode='reference', loss_targets='reference',
-                 sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', layout='rows', exchange_chunks=2, **kwds):
+                 sparse_optimizer='adagrad', device_sampler=False, device='cuda:0', layout='rows', exchange_chunks=2, exchange_transport='rccl', **kwds):
         super().__init__(**kwds)
         if layout not in ('rows', 'columns'):
             raise Exception(f'Unknown multi-GPU layout "{layout}" (supported: "rows", "columns").')
@@ -30,7 +30,12 @@ class CDAE(RecommenderABC):
         #             rows a batch needs and their merged gradients exchanged by all-to-all(v) in `exchange_chunks` pipelined chunks;
         #             every rank draws `batch_size` triples of ITS users per step (global batch = world x batch_size);
         #   'columns' every rank all rows x K / world columns, the same global batch on every rank, one all-reduce of B floats.
-        self.layout, self.exchange_chunks = layout, int(exchange_chunks)
+        # exchange_transport (rows): 'rccl' = the library's own RCCL communicator, the exchanges of a step issued from C
+        #             (include/drx.h drx_comm_*, drx_shard_phase_*) — under an "nccl" process group, where librccl opens on every rank;
+        #             'torch' = torch.distributed.all_to_all_single call by call (always under gloo).
+        if exchange_transport not in ('rccl', 'torch'):
+            raise Exception(f'Unknown exchange transport "{exchange_transport}" (supported: "rccl", "torch").')
+        self.layout, self.exchange_chunks, self.exchange_transport = layout, int(exchange_chunks), exchange_transport
         self.hidden_factors = hidden_factors
         self.corruption_level = corruption_level
         if loss not in ('mse', 'bce'):
@@ -83,7 +88,8 @@ class CDAE(RecommenderABC):
         m = ShardedCdae(U, self.n_items, self.hidden_factors, rank, world, self.device, ip[lo:hi + 1] - ip[lo],
                         self._hist_indices[ip[lo]:ip[hi]], seed=seed, lr=learning_rate, reg=reg_rate, optimizer=self.sparse_optimizer,
                         loss=self._loss_name, q=self.corruption_level, cpu_staging=(dist.get_backend() == 'gloo'),
-                        chunks=self.exchange_chunks)
+                        chunks=self.exchange_chunks,
+                        transport='rccl' if (self.exchange_transport == 'rccl' and dist.get_backend() == 'nccl') else None)
         weights = kwds.get('initial_weights')
         n_params = (2 * self.n_items + U) * self.hidden_factors
         if weights is None and n_params <= (1 << 26):                # the single-GPU initialisation, sliced (larger: drawn per shard on the device)

@@ -49,6 +49,16 @@ class Shard(C.Structure):
                 ('n_users_local', C.c_int32), ('flags', C.c_uint32), ('chunks', C.c_int32)]
 
 
+MAX_CHUNKS = 16                         # include/drx.h DRX_MAX_CHUNKS
+
+
+class ShardExchange(C.Structure):
+    """include/drx.h DrxShardExchange: one prepared batch's exchange state for the drx_shard_phase_* calls"""
+    _fields_ = [('send_counts', C.c_void_p), ('recv_counts', C.c_void_p), ('uniq', C.c_void_p), ('req', C.c_void_p), ('table', C.c_void_p),
+                ('table_bytes', C.c_size_t), ('rows_cache', C.c_void_p), ('rows_send', C.c_void_p), ('grad_send', C.c_void_p),
+                ('grad_recv', C.c_void_p), ('rows_ticket', C.c_int64 * MAX_CHUNKS), ('grad_ticket', C.c_int64 * MAX_CHUNKS)]
+
+
 MAX_SEGMENTS = 24                       # include/drx.h DRX_MAX_SEGMENTS
 
 
@@ -170,6 +180,14 @@ SIGNATURES = {
     'drx_shard_apply': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                   C.c_void_p, C.c_void_p]),
+    'drx_shard_exchange_sizes': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    'drx_shard_phase_keys': (C.c_int, [C.POINTER(Shard), C.c_void_p, C.POINTER(ShardExchange), C.c_void_p]),
+    'drx_shard_phase_rows': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.POINTER(ShardExchange), C.c_int32, C.c_void_p]),
+    'drx_shard_phase_local': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch),
+                                        C.c_void_p, C.POINTER(ShardExchange), C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]),
+    'drx_shard_phase_tail': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.c_void_p, C.POINTER(ShardExchange),
+                                       C.POINTER(ShardExchange), C.c_int32, C.c_void_p, C.c_void_p]),
     'drx_copy_f4': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_copy_f4_variant': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     'drx_comm_unique_id': (C.c_int, [C.c_void_p]),

@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, 'libdrx.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HOSTCXX = os.environ.get('CXX', 'g++')
 ARCH = 'gfx950'
-SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_sampler.hip', 'drx_shard.hip', 'drx_comm.hip', 'drx_generic.hip', 'drx_caser.hip', 'drx_dmf.hip', 'drx_host.cpp']
+SOURCES = ['drx_cdae.hip', 'drx_sort.hip', 'drx_topk.hip', 'drx_idmap.hip', 'drx_sampler.hip', 'drx_shard.hip', 'drx_shard_phase.cpp', 'drx_comm.hip', 'drx_generic.hip', 'drx_caser.hip', 'drx_dmf.hip', 'drx_host.cpp']
 COMMON = ['-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
 

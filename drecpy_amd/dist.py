@@ -214,6 +214,48 @@ class HipShardOps:
                                                self._lib.ptr(self._loss) if want_loss else None, self._stream()), 'drx_shard_apply')
         return self._loss if want_loss else None
 
+    # -- the exchange phases issued from C (include/drx.h drx_shard_phase_*; one micro-batch per step, the library's communicator)
+    def x_new(self, prep, counts_host):
+        """DrxShardExchange of a prepared batch whose count exchange has landed in `counts_host` (pinned int64 [2, world * chunks])"""
+        X = self._lib.ShardExchange()
+        X.send_counts, X.recv_counts = counts_host[0].data_ptr(), counts_host[1].data_ptr()
+        X.uniq = prep['uniq'].data_ptr()
+        sizes = (C.c_int64 * 4)()
+        self._lib.check(self.L.drx_shard_exchange_sizes(C.byref(self.engine._params), C.byref(self.shard), X.send_counts, X.recv_counts,
+                                                        sizes), 'drx_shard_exchange_sizes')
+        return X, tuple(int(v) for v in sizes)
+
+    def x_keys(self, comm, X, req, slot):
+        nb = int(self.L.drx_shard_owner_table_bytes(C.byref(self.shard), self.world))
+        tab = self._tables.get(slot)
+        if tab is None or tab.numel() < nb:
+            tab = self._tables[slot] = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        X.req, X.table, X.table_bytes = req.data_ptr(), tab.data_ptr(), tab.numel()
+        self._lib.check(self.L.drx_shard_phase_keys(C.byref(self.shard), comm, C.byref(X), self._stream()), 'drx_shard_phase_keys')
+        return tab
+
+    def x_rows(self, comm, X, chunk):
+        self._lib.check(self.L.drx_shard_phase_rows(C.byref(self.engine._params), C.byref(self.shard), comm, C.byref(X), int(chunk),
+                                                    self._stream()), 'drx_shard_phase_rows')
+
+    def x_local(self, comm, X, bt, prep, b_norm, loss_kind, opt, events=None):
+        P = self.engine._params
+        need = int(self.L.drx_shard_step_scratch_bytes(C.byref(P), bt.B, bt.n_touch_slots))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(int(need * 1.1) + 4096, dtype=torch.uint8, device=self.device)
+        arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events]) if events is not None else None
+        buf = prep['buf']
+        self._lib.check(self.L.drx_shard_phase_local(C.byref(P), C.byref(opt), C.byref(self.shard), C.byref(self.engine._hist), C.byref(bt),
+                                                     comm, C.byref(X), self._lib.ptr(buf), buf.numel(), int(b_norm), int(loss_kind),
+                                                     self._lib.ptr(self._scratch), self._scratch.numel(), arr, self._stream()),
+                        'drx_shard_phase_local')
+
+    def x_tail(self, comm, X, X_next, b_norm, opt, want_loss=False):
+        self._lib.check(self.L.drx_shard_phase_tail(C.byref(self.engine._params), C.byref(opt), C.byref(self.shard), comm, C.byref(X),
+                                                    C.byref(X_next) if X_next is not None else None, int(b_norm),
+                                                    self._lib.ptr(self._loss) if want_loss else None, self._stream()), 'drx_shard_phase_tail')
+        return self._loss if want_loss else None
+
     def optim(self, step):
         a = self.engine.adam_alpha(self.engine.lr, step + 1, self.engine.beta1, self.engine.beta2)
         return self.engine._optim([a] * 5)
@@ -346,7 +388,7 @@ class ShardedCdae:
 
     def __init__(self, n_users_total, n_items, k, rank, world, device, hist_indptr, hist_indices, seed=10, lr=0.05, reg=1e-3,
                  optimizer='adagrad', ops=None, group=None, loss='bce', q=0.2, cpu_staging=False, force_collectives=False,
-                 self_bypass=True, chunks=1, transport=None):
+                 self_bypass=True, chunks=1, transport=None, phases=None):
         self.rank, self.world, self.group = rank, world, group
         # world 1 normally bypasses torch.distributed; `force_collectives` sends every exchange through the process group
         # anyway (a 1-rank RCCL communicator exercises the exact call sequence of the N-rank step on one GPU)
@@ -369,6 +411,13 @@ class ShardedCdae:
         if transport == 'rccl':
             transport = self._own_communicator(world, rank, device, group) if self.collectives else None
         self.xfer = transport if transport is not None else TorchTransport(group, world, self.collectives, cpu_staging)
+        # phases: the exchanges of a step issued by the library (drx_shard_phase_*: four calls per step, split sizes read from the count
+        # exchange's pinned mailbox) instead of call by call from here.  Needs the library's communicator; steps of several micro-batches
+        # keep the call-by-call form.  Default: on with transport='rccl'
+        can = isinstance(self.xfer, RcclTransport) and isinstance(self.ops, HipShardOps)
+        if phases and not can:
+            raise ValueError("phases=True needs transport='rccl' (the library's own communicator) and the HIP shard ops")
+        self.phases = can if phases is None else bool(phases)
         if self.engine is not None:
             # (the engine's tables are this rank's SHARD — its item rows are local, the history's item ids global: no transpose)
             self.engine.set_history(hist_indptr, hist_indices, with_transpose=False)
@@ -498,8 +547,9 @@ class ShardedCdae:
             self._split_counts(P, send_counts, recv_counts)
         return P
 
-    def exchange_keys(self, P):
-        """Every owner learns which of its rows each rank wants (4 B per distinct row): one all-to-all(v) per chunk."""
+    def exchange_keys(self, P, solo=True):
+        """Every owner learns which of its rows each rank wants (4 B per distinct row): one all-to-all(v) per chunk.
+        solo: the batch is its step's only micro-batch (then — self.phases — the library issues the exchanges: drx_shard_phase_*)."""
         if 'send_counts' not in P:
             if 'counts_host' not in P:
                 self.exchange_counts(P)
@@ -507,6 +557,14 @@ class ShardedCdae:
                 t0 = time.perf_counter()
                 P['counts_event'].synchronize()         # the tiny count exchange, issued at least two steps earlier
                 self.wait_s += time.perf_counter() - t0
+                if self.phases and solo:
+                    # the library reads the mailbox itself; here only the buffer sizes.  The key exchange proper happens in
+                    # index_owner (drx_shard_phase_keys: exchange + owner table, chunk by chunk)
+                    P['x'], P['sizes'] = self.ops.x_new(P, P['counts_host'])
+                    P['req'] = torch.empty(P['sizes'][2], dtype=torch.int32, device=P['uniq'].device)
+                    if P.get('consumer') is not None:
+                        P['req'].record_stream(P['consumer'])
+                    return P
                 self._split_counts(P, P['counts_host'][0].tolist(), P['counts_host'][1].tolist())
         if 'send_counts' not in P:
             self.exchange_counts(P)
@@ -524,6 +582,14 @@ class ShardedCdae:
     def index_owner(self, Ps, slot=0):
         """The owner side of a step's key exchange(s): per chunk one run of segments (micro-batch-major, then source), one table."""
         head = Ps[0]
+        if 'x' in head:
+            if len(Ps) != 1:
+                raise ValueError('phases=True runs one micro-batch per step')
+            head['table'] = self.ops.x_keys(self.xfer.comm, head['x'], head['req'], slot)
+            if head.get('consumer') is not None:
+                head['event'] = torch.cuda.Event()
+                head['event'].record(self._cur) if self._cur is not None else head['event'].record()
+            return head
         head['req_all'], head['counts_all'] = [], []
         for c in range(self.chunks):
             req = Ps[0]['req'][c] if len(Ps) == 1 else torch.cat([P['req'][c] for P in Ps])
@@ -544,7 +610,7 @@ class ShardedCdae:
         for m, b in enumerate(bts):
             P = Ps[m] = Ps[m] if Ps[m] is not None else self.prepare(b)
             if 'req' not in P:
-                self.exchange_keys(P)
+                self.exchange_keys(P, solo=len(bts) == 1)
         if 'table' not in Ps[0]:
             self.index_owner(Ps)
         return Ps
@@ -572,9 +638,63 @@ class ShardedCdae:
 
     def fetch_rows(self, Ps):
         """head of a step: gather + row exchange of all chunks (when the previous step's tail did not already do it)"""
+        if 'x' in Ps[0]:
+            self._x_row_buffers(Ps[0])
+            for c in range(self.chunks):
+                self.ops.x_rows(self.xfer.comm, Ps[0]['x'], c)
+            Ps[0]['rx'] = True
+            return
         ov = len(Ps) > 1 or self.chunks > 1
         for c in range(self.chunks):
             self._fetch_chunk(Ps, c, ov)
+
+    def _x_row_buffers(self, P):
+        """the two row buffers of a prepared batch (allocated with the TRAINING stream current: both are read and written only by it and
+        by exchanges it has waited for when the batch's dict is dropped)"""
+        if 'rows_cache' not in P:
+            dev = P['uniq'].device
+            P['rows_cache'] = torch.empty(P['sizes'][0], dtype=torch.float32, device=dev)
+            P['rows_send'] = torch.empty(P['sizes'][1], dtype=torch.float32, device=dev)
+            P['x'].rows_cache, P['x'].rows_send = P['rows_cache'].data_ptr(), P['rows_send'].data_ptr()
+
+    def _step_phases(self, step, bt, P, events, want_loss, after_row_requests, after_apply, next_prepared):
+        """step() with the exchanges issued by the library: four calls (rows of the head only when nothing ran ahead)"""
+        ops, comm = self.ops, self.xfer.comm
+        b_norm = bt.B * self.world
+        opt = ops.optim(step)
+        rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
+        rec(0)
+        Ps = self._ready([bt], [P])
+        P = Ps[0]
+        self._main_waits(Ps)
+        if 'rx' not in P:
+            self.fetch_rows(Ps)
+        dev = P['uniq'].device
+        P['grad_send'] = torch.empty(P['sizes'][0], dtype=torch.float32, device=dev)
+        P['grad_recv'] = torch.empty(P['sizes'][1], dtype=torch.float32, device=dev)
+        X = P['x']
+        X.grad_send, X.grad_recv = P['grad_send'].data_ptr(), P['grad_recv'].data_ptr()
+        ops.x_local(comm, X, bt, P, b_norm, self.loss_kind, opt, events=events[1:5] if events is not None else None)
+        if after_row_requests is not None:
+            after_row_requests()                       # (the run-ahead exchanges: in front of this step's gradient exchange)
+        nxt = next_prepared() if callable(next_prepared) else next_prepared
+        if nxt is not None:
+            nxt = list(nxt) if isinstance(nxt, (list, tuple)) else [nxt]
+            if len(nxt) != 1 or 'table' not in nxt[0] or 'x' not in nxt[0]:
+                nxt = None
+            else:
+                self._main_waits(nxt)
+                self._x_row_buffers(nxt[0])
+        loss = ops.x_tail(comm, X, nxt[0]['x'] if nxt is not None else None, b_norm, opt, want_loss=want_loss)
+        if nxt is not None:
+            nxt[0]['rx'] = True
+        rec(5)
+        if after_apply is not None:
+            after_apply()
+        if want_loss:
+            self.last_loss = float(loss[0].item())
+            return self.last_loss
+        return None
 
     # ---- one step ------------------------------------------------------------------------------------------
     def step(self, step, bt, events=None, want_loss=False, prepared=None, after_row_requests=None, after_apply=None, next_prepared=None):
@@ -597,6 +717,8 @@ class ShardedCdae:
         ops = self.ops
         bts = list(bt) if isinstance(bt, (list, tuple)) else [bt]
         Ps = (list(prepared) if isinstance(prepared, (list, tuple)) else [prepared]) if prepared is not None else [None] * len(bts)
+        if self.phases and len(bts) == 1 and (Ps[0] is None or 'send_counts' not in Ps[0]):
+            return self._step_phases(step, bts[0], Ps[0], events, want_loss, after_row_requests, after_apply, next_prepared)
         b_norm = sum(b.B for b in bts) * self.world
         opt = ops.optim(step)
         rec = (lambda i: events[i].record()) if events is not None else (lambda i: None)
@@ -749,7 +871,7 @@ class ShardedPipeline:
 
     def _keys(self, s):
         for P in self.P[s]:
-            self.m.exchange_keys(P)
+            self.m.exchange_keys(P, solo=len(self.P[s]) == 1)
         self.m.index_owner(self.P[s], slot=s % self.RING)
 
     def run_step(self, events=None, want_loss=False):

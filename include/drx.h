@@ -409,6 +409,51 @@ int64_t drx_comm_alltoallv(DrxComm *c, const void *send, const int64_t *send_off
 int drx_comm_wait(DrxComm *c, int64_t ticket, void *stream);
 const char *drx_comm_last_error(void);
 
+/* ---- the exchange PHASES of a row-sharded step, issued from C (r06; no reference equivalent) -------------------------------------------
+ * What drecpy_amd/dist.py does between the drx_shard_* launches — offsets of every unit's piece, one drx_comm_alltoallv per chunk, the
+ * waits — as four calls per step with the split sizes READ FROM THE COUNT EXCHANGE'S PINNED MAILBOX: the chunked schedule of a step is
+ * 2 + 3 C exchanges, 2 C waits and 3 C launches, and issued from Python the host was the next wall behind the links.
+ * One micro-batch per step; one DrxShardExchange per prepared batch, filled by the caller:
+ *   send_counts / recv_counts  HOST arrays [world x chunks] as the count exchange delivers them: send_counts[o * chunks + c] = rows
+ *                              (sentinel included) this rank asks of owner o in chunk c, recv_counts[s * chunks + c] = rows rank s asks
+ *                              of this rank in chunk c
+ *   uniq                       device: the rank's distinct wire keys (drx_shard_prepare)
+ *   req                        device: the keys this rank receives, chunk after chunk, per chunk source after source (sizes[2] keys)
+ *   table                      device: drx_shard_owner_table_bytes(sh, world)
+ *   rows_cache, grad_send      device: the requester's exchange buffers (sizes[0] floats each; geometry: "EXCHANGE BUFFER" above)
+ *   rows_send, grad_recv       device: the owner's (sizes[1] floats each): chunk after chunk, per chunk one segment per source rank
+ *   rows_ticket / grad_ticket  written by the phases: the communicator tickets of the chunk's row / gradient exchange
+ * drx_shard_exchange_sizes: sizes4 = { requester floats, owner floats, keys received, keys sent } (every buffer: at least 32 elements).
+ * drx_shard_phase_keys  (parameter-independent, on the run-ahead stream): per chunk the key all-to-all, then drx_shard_owner_index.
+ * drx_shard_phase_rows  one chunk: drx_shard_gather_rows of the rows asked of this rank as they are NOW, then their all-to-all
+ *                       (-> rows_ticket[chunk]).  Head of a step for all chunks, or — pipelined — by drx_shard_phase_tail.
+ * drx_shard_phase_local `stream` waits for the row tickets, then drx_shard_step_local (events as there).
+ * drx_shard_phase_tail  posts the gradient all-to-all of every chunk; then chunk by chunk: wait, drx_shard_apply, and — `next` not NULL —
+ *                       drx_shard_phase_rows(next, chunk): the rows of a chunk leave for the NEXT step right behind their update. */
+typedef struct DrxShardExchange {
+  const int64_t *send_counts;
+  const int64_t *recv_counts;
+  const uint32_t *uniq;
+  uint32_t *req;
+  void *table;
+  size_t table_bytes;
+  float *rows_cache;
+  float *rows_send;
+  float *grad_send;
+  float *grad_recv;
+  int64_t rows_ticket[DRX_MAX_CHUNKS];
+  int64_t grad_ticket[DRX_MAX_CHUNKS];
+} DrxShardExchange;
+int drx_shard_exchange_sizes(const DrxCdaeParams *p, const DrxShard *sh, const int64_t *send_counts, const int64_t *recv_counts,
+                             int64_t *sizes4);
+int drx_shard_phase_keys(const DrxShard *sh, DrxComm *comm, DrxShardExchange *x, void *stream);
+int drx_shard_phase_rows(const DrxCdaeParams *p, const DrxShard *sh, DrxComm *comm, DrxShardExchange *x, int32_t chunk, void *stream);
+int drx_shard_phase_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt,
+                          DrxComm *comm, DrxShardExchange *x, const void *prepared, size_t prepared_bytes, int32_t b_norm,
+                          int32_t loss_kind, void *scratch, size_t scratch_bytes, void *const *events, void *stream);
+int drx_shard_phase_tail(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, DrxComm *comm, DrxShardExchange *x,
+                         DrxShardExchange *next, int32_t b_norm, float *loss_out, void *stream);
+
 /* drx_copy_f4: dst[0 .. n_bytes) = src[0 .. n_bytes) on the device (16-B aligned, n_bytes a multiple of 16, no overlap): a streaming
  *   float4 copy kernel — table snapshots (recommender_abc.py:336-352 keeps a copy of every weight per epoch), and the rate bench.py
  *   reports as `hbm_copy_achievable` (the achievable HBM rate measured on the box next to the nominal peak). */

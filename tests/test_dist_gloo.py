@@ -287,3 +287,29 @@ def test_wire_keys_are_unit_major_and_invertible():
                 assert (o, out_, li) == (n // ipr, is_out, n - (n // ipr) * ipr)
                 assert (k >> cs) == c * world + o and c == (2 * li + int(is_out)) >> cs
     assert wire_chunks(items_per_rank(57, 2), 4) == 1 and wire_chunks(items_per_rank(1_000_000, 8), 8) == 8
+
+
+def test_exchange_sizes_of_the_library_equal_the_host_statement():
+    """drx_shard_exchange_sizes (csrc/drx_shard_phase.cpp: the geometry the C-issued phases of a step use) against dist.chunk_floats /
+    the self-bypass rule stated in Python: floats of the requester's buffers (own units included, at the end), floats of the owner's
+    (nothing from the rank itself with the bypass), keys received and sent.  Host arithmetic only: no GPU call."""
+    import ctypes as C
+    from drecpy_amd import _lib
+    from drecpy_amd.dist import chunk_floats, items_per_rank, wire_chunks
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for world, rank, n_items, chunks, bypass, ld in ((1, 0, 9000, 2, True, 128), (4, 2, 40000, 4, True, 64), (4, 1, 40000, 4, False, 128),
+                                                     (8, 7, 1_000_000, 2, True, 128), (3, 0, 500, 4, True, 32)):
+        ipr = items_per_rank(n_items, world)
+        sh = _lib.Shard(world, rank, n_items, ipr, 100, _lib.SHARD_SELF_BYPASS if bypass else 0, wire_chunks(ipr, chunks))
+        Cn = int(L.drx_shard_chunks(C.byref(sh)))
+        P = _lib.CdaeParams(100, ipr, ld, ld, None, None, None, None, None)
+        send = rng.integers(1, 3000, size=world * Cn).astype(np.int64)
+        recv = rng.integers(1, 3000, size=world * Cn).astype(np.int64)
+        out = (C.c_int64 * 4)()
+        assert L.drx_shard_exchange_sizes(C.byref(P), C.byref(sh), send.ctypes.data, recv.ctypes.data, out) == 0
+        want_req = sum(chunk_floats(send.tolist(), ld))
+        want_own = sum(f for i, f in enumerate(chunk_floats(recv.tolist(), ld)) if not (bypass and i // Cn == rank))
+        assert list(out) == [max(32, want_req), max(32, want_own), max(32, int(recv.sum())), int(send.sum())], (world, rank, list(out))
+        send[0] = 0                                    # (a unit without its sentinel: rejected)
+        assert L.drx_shard_exchange_sizes(C.byref(P), C.byref(sh), send.ctypes.data, recv.ctypes.data, out) != 0

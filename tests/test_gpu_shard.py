@@ -72,17 +72,17 @@ def _oracle(world, micro=1):
     return p, losses
 
 
-def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1, bypass=True, transport=None):
+def _run_rank(rank, world, staged, force=False, pipelined=False, micro=1, bypass=True, transport=None, phases=None):
     from drecpy_amd.dist import ShardedCdae
     p, indptr, indices, batches = _problem(world)
     lo, hi = U * rank // world, U * (rank + 1) // world
     lip = indptr[lo:hi + 1] - indptr[lo]
     lidx = indices[indptr[lo]:indptr[hi]]
     m = ShardedCdae(U, N, K, rank, world, 'cuda:0', lip, lidx, q=Q, cpu_staging=staged, force_collectives=force, self_bypass=bypass,
-                    chunks=CHUNKS, transport=transport)
+                    chunks=CHUNKS, transport=transport, phases=phases)
     assert m.chunks == CHUNKS, (m.chunks, CHUNKS)
     if transport == 'rccl':
-        assert type(m.xfer).__name__ == 'RcclTransport' 
+        assert type(m.xfer).__name__ == 'RcclTransport' and m.phases == (True if phases is None else phases)
     m.set_params_global(**p)
     losses, made = [], {}
 
@@ -322,10 +322,24 @@ def test_public_fit_row_layout_equals_a_single_gpu_replay_of_the_same_buckets(tm
     assert res[0]['rank'] == res[1]['rank'] and abs(res[0]['pred'] - res[1]['pred']) < 1e-7
 
 
-@pytest.mark.parametrize('pipelined,micro,bypass,chunks', [(True, 1, False, 1), (True, 1, False, 4), (True, 2, False, 2), (False, 1, False, 2), (True, 1, True, 4)])
-def test_sharded_step_through_the_librarys_own_communicator(monkeypatch, pipelined, micro, bypass, chunks):
+@pytest.mark.parametrize('phases', [True, False])
+@pytest.mark.parametrize('pipelined,micro,bypass,chunks', [(True, 1, False, 1), (True, 1, False, 4), (True, 2, False, 2), (False, 1, False, 2), (True, 1, True, 4),
+                                                           (True, 1, True, 2), (False, 1, True, 1)])
+def test_sharded_step_through_the_librarys_own_communicator(monkeypatch, pipelined, micro, bypass, chunks, phases):
     """transport='rccl' (csrc/drx_comm.hip): count / key / row / gradient exchanges as ncclGroups of send / recv pairs on the library's own
-    1-rank communicator and stream, ordered with torch's streams by events and tickets — the call sequence of the N-rank step."""
+    1-rank communicator and stream, ordered with torch's streams by events and tickets — the call sequence of the N-rank step.
+    phases: the exchanges of a step issued by the library (drx_shard_phase_*: keys, rows, local, tail — the split sizes read from the count
+    exchange's pinned mailbox) or call by call from dist.py; steps of several micro-batches always take the second form."""
     _chunked(monkeypatch, 9000, chunks)
-    res = _run_rank(0, 1, False, force=True, pipelined=pipelined, micro=micro, bypass=bypass, transport='rccl')
+    res = _run_rank(0, 1, False, force=True, pipelined=pipelined, micro=micro, bypass=bypass, transport='rccl', phases=phases)
     _check(1, [res], micro)
+
+
+def test_the_librarys_phases_equal_the_call_by_call_step_bit_for_bit(monkeypatch):
+    """same kernels, same buffers' geometry, same order: parameters after the pipelined steps are identical, not merely close"""
+    _chunked(monkeypatch, 9000, 2)
+    a = _run_rank(0, 1, False, force=True, pipelined=True, bypass=False, transport='rccl', phases=True)
+    b = _run_rank(0, 1, False, force=True, pipelined=True, bypass=False, transport='rccl', phases=False)
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert a[1] == b[1]
