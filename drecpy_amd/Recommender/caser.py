@@ -75,6 +75,7 @@ class Caser(RecommenderABC):
             self._sampler.device_twin(self.device)
             self._host_prefetch = False
             self._draws = 0
+            self._ahead = None                            # (a batch drawn ahead by an earlier fit() belongs to its sampler)
             self._sampler_kind = 'device list sampler (drx_list_sample_device, counter-based; throughput mode)'
         else:
             self.__dict__.pop('_host_prefetch', None)
@@ -115,8 +116,7 @@ class Caser(RecommenderABC):
 
     def _sample_batch(self, batch_size, **kwds):                          # caser.py:77-84
         if getattr(self, '_device_sampler', False):
-            self._draws += 1
-            return self._sampler.sample_device(batch_size, self._drop_seed * 1000003 + self._draws)
+            return self._draw_ahead(batch_size)
         if getattr(self._sampler, '_native', None) is not None:           # array form of the same draws (C++ loop)
             ds = self.interaction_dataset
             grp, in_off, in_rows, tg_off, tg_rows, ng_off, negs = self._sampler.sample_group_arrays(batch_size)
@@ -135,6 +135,35 @@ class Caser(RecommenderABC):
             before.append([int(r['iid']) for r in pos])
             after.append([int(r['iid']) for r in targets] + [int(x) for x in negs])
         return uids, before, after
+
+    def _draw_ahead(self, batch_size):
+        """device_sampler=True: the windows of batch s + 1 are drawn — and their lookups grouped by table row (engine.prepare_device_batch)
+        — on a side stream while step s trains: neither depends on the parameters.  The draws are the ones the inline loop made (seed =
+        f(model seed, number of the draw)); one batch beyond the last step is drawn and dropped."""
+        import torch
+        eng = self._engine
+        st = self.__dict__.get('_ahead')
+        if st is None or st['B'] != batch_size:
+            st = self._ahead = {'B': batch_size, 'side': torch.cuda.Stream(eng.device, priority=-1), 'next': None}
+        main = torch.cuda.current_stream(eng.device)
+
+        def draw():
+            self._draws += 1
+            with torch.cuda.stream(st['side']):
+                grp, before, after = self._sampler.sample_device(batch_size, self._drop_seed * 1000003 + self._draws)
+                prep = eng.prepare_device_batch(grp, before, after)
+                ev = torch.cuda.Event()
+                ev.record(st['side'])
+            for t in (prep['uid'], prep['before'], prep['after']):
+                t.record_stream(main)                     # (allocated with the side stream current, read by the step on the training stream)
+            return prep, ev
+        if st['next'] is None:
+            st['side'].wait_stream(main)                  # (tables / sampler arrays set up on the training stream)
+            st['next'] = draw()
+        prep, ev = st['next']
+        main.wait_event(ev)
+        st['next'] = draw()
+        return prep['uid'], prep['before'], prep['after'], prep
 
     def _do_batch(self, batch_samples, step=0, want_loss=False, **kwds):
         uids, before, after = batch_samples[:3]

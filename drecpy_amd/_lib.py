@@ -84,6 +84,10 @@ class CsrAdamTable(C.Structure):                        # include/drx.h DrxCsrAd
                [(n, C.c_void_p) for n in ('p', 'm', 'v', 'p_s', 'm_s', 'v_s')] + [(n, C.c_float) for n in ('alpha', 'alpha_s', 'l2_coef')]
 
 
+class CsrList(C.Structure):                             # include/drx.h DrxCsrList
+    _fields_ = [('keys', C.c_void_p), ('T', C.c_int32), ('n_rows', C.c_int32), ('row_ptr', C.c_void_p), ('order', C.c_void_p)]
+
+
 class DmfDims(C.Structure):
     _fields_ = [('n_layers', C.c_int32 * 2), ('f', (C.c_int32 * 4) * 2), ('ld0', C.c_int32 * 2),
                 ('off_k', (C.c_int32 * 4) * 2), ('off_b', (C.c_int32 * 4) * 2), ('n_small', C.c_int32),
@@ -221,6 +225,8 @@ SIGNATURES = {
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
     'drx_first_occurrence': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'drx_batch_csr': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'drx_batch_csr_device_bytes': (C.c_size_t, [C.POINTER(CsrList), C.c_int32]),
+    'drx_batch_csr_device': (C.c_int, [C.POINTER(CsrList), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'drx_rows_csr_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_void_p]),

@@ -455,6 +455,98 @@ int drx_rows_csr_adam_outer(const int32_t *row_ptr, const int32_t *order, const 
   return rows_csr_adam(row_ptr, order, src, scale, group, ld, n_rows, p, m, v, p_s, m_s, v_s, alpha, alpha_s, l2_coef, beta1, beta2, eps, stream);
 }
 
+// ---- drx_batch_csr on the device: the lookups of several key lists grouped by the table row they name -----------------------------
+// One stable sort of all lists' (row, lookup) pairs — list l's rows offset by the rows of the lists before it, so the lists come out
+// one after the other and a row's lookups ascending — then row_ptr by one binary search per row.
+struct CsrLists {
+  int n;
+  const int32_t *keys[DRX_MAX_CSR_TABLES];
+  int32_t *row_ptr[DRX_MAX_CSR_TABLES], *order[DRX_MAX_CSR_TABLES];
+  uint32_t t_base[DRX_MAX_CSR_TABLES + 1], r_base[DRX_MAX_CSR_TABLES + 1];   // first lookup / first row of list l in the concatenation
+};
+
+static __global__ void k_csr_keys(CsrLists Ls, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t T = Ls.t_base[Ls.n];
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < Ls.n && j >= Ls.t_base[l + 1]) ++l;
+    const uint32_t q = j - Ls.t_base[l];
+    keys[j] = Ls.r_base[l] + (uint32_t)Ls.keys[l][q];
+    vals[j] = q;
+  }
+}
+
+static __global__ void k_csr_finish(CsrLists Ls, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals) {
+  const uint32_t T = Ls.t_base[Ls.n], R = Ls.r_base[Ls.n] + (uint32_t)Ls.n;       // (every list: n_rows + 1 row_ptr entries)
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < T + R; j += gridDim.x * blockDim.x) {
+    if (j < T) {
+      int l = 0;
+      while (l + 1 < Ls.n && j >= Ls.t_base[l + 1]) ++l;
+      Ls.order[l][j - Ls.t_base[l]] = (int32_t)vals[j];
+    } else {
+      uint32_t e = j - T;
+      int l = 0;
+      while (l + 1 < Ls.n && e >= Ls.r_base[l + 1] + (uint32_t)(l + 1)) ++l;
+      const uint32_t r = e - (Ls.r_base[l] + (uint32_t)l);                          // 0 .. n_rows of list l
+      const uint32_t want = Ls.r_base[l] + r;
+      uint32_t lo = Ls.t_base[l], hi = Ls.t_base[l + 1];                            // first pair of the list whose key is >= want
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1; else hi = mid;
+      }
+      Ls.row_ptr[l][r] = (int32_t)(lo - Ls.t_base[l]);
+    }
+  }
+}
+
+static int csr_lists(const DrxCsrList *lists, int32_t n_lists, CsrLists &Ls, int &bits) {
+  if (!lists || n_lists < 1 || n_lists > DRX_MAX_CSR_TABLES) return DRX_EINVAL;
+  Ls.n = n_lists;
+  uint64_t t = 0, r = 0;
+  for (int l = 0; l < n_lists; ++l) {
+    if (!lists[l].keys || !lists[l].row_ptr || !lists[l].order || lists[l].T < 1 || lists[l].n_rows < 1) return DRX_EINVAL;
+    Ls.keys[l] = lists[l].keys; Ls.row_ptr[l] = lists[l].row_ptr; Ls.order[l] = lists[l].order;
+    Ls.t_base[l] = (uint32_t)t; Ls.r_base[l] = (uint32_t)r;
+    t += (uint64_t)lists[l].T; r += (uint64_t)lists[l].n_rows;
+    if (t >= 0x7FFFFFFFull || r >= 0x7FFFFFFFull) return DRX_EINVAL;
+  }
+  Ls.t_base[n_lists] = (uint32_t)t; Ls.r_base[n_lists] = (uint32_t)r;
+  bits = 1;
+  while ((1ull << bits) < r) ++bits;
+  return DRX_OK;
+}
+
+size_t drx_batch_csr_device_bytes(const DrxCsrList *lists, int32_t n_lists) {
+  CsrLists Ls;
+  int bits;
+  if (csr_lists(lists, n_lists, Ls, bits)) return 0;
+  const size_t T = Ls.t_base[n_lists];
+  return 4 * ((T * 4 + 255) & ~size_t(255)) + sort_pairs_temp_bytes(T, bits) + 512;
+}
+
+int drx_batch_csr_device(const DrxCsrList *lists, int32_t n_lists, void *scratch, size_t scratch_bytes, void *stream) {
+  CsrLists Ls;
+  int bits;
+  int rc = csr_lists(lists, n_lists, Ls, bits);
+  if (rc) return rc;
+  if (!scratch || scratch_bytes < drx_batch_csr_device_bytes(lists, n_lists)) return DRX_EINVAL;
+  const size_t T = Ls.t_base[n_lists], arr = (T * 4 + 255) & ~size_t(255);
+  char *base = (char *)(((uintptr_t)scratch + 255) & ~uintptr_t(255));
+  uint32_t *k_in = (uint32_t *)base, *v_in = (uint32_t *)(base + arr), *k_out = (uint32_t *)(base + 2 * arr), *v_out = (uint32_t *)(base + 3 * arr);
+  char *temp = base + 4 * arr;
+  const size_t temp_bytes = sort_pairs_temp_bytes(T, bits);
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((T + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_csr_keys, dim3(blocks > 2048 ? 2048 : blocks), dim3(kBlock), 0, st, Ls, k_in, v_in);
+  rc = sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, T, bits, st);
+  if (rc) return rc;
+  const size_t work = T + Ls.r_base[n_lists] + (size_t)n_lists;
+  blocks = (int)((work + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_csr_finish, dim3(blocks > 4096 ? 4096 : blocks), dim3(kBlock), 0, st, Ls, k_out, v_out);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
 int drx_rows_csr_adam_multi(const DrxCsrAdamTable *tables, int32_t n_tables, float beta1, float beta2, float eps, void *stream) {
   if (!tables || n_tables < 1 || n_tables > DRX_MAX_CSR_TABLES) return DRX_EINVAL;
   CsrMulti M;

@@ -180,6 +180,53 @@ class CaserEngine:
     # a zeroed gradient arena + drx_adam_dense (the only way for batches that are already on the device)
     table_update = 'csr'
 
+    # batches already on the device: group their lookups by table row on the device (True) or take the scatter + dense-Adam update
+    device_csr = True
+
+    def prepare_device_batch(self, uid, bef, aft):
+        """A batch that is already on the device, its lookups grouped by table row on the CURRENT stream (which may be a run-ahead
+        stream: nothing here depends on the parameters) — what step() takes in place of (uids, before, after).  The three slots of the
+        ring are reused only behind the step that last read them (an event recorded by that step on ITS stream)."""
+        uid, bef, aft = self._dev_i32(uid), self._dev_i32(bef), self._dev_i32(aft)
+        prep = {'uid': uid, 'before': bef, 'after': aft, 'B': uid.numel()}
+        prep['csr_dev'] = self._csr_on_device(uid, bef, aft, prep)
+        return prep
+
+    def _csr_on_device(self, uid, bef, aft, prep=None):
+        B = uid.numel()
+        sizes = (self.N + 1, B * self.L, self.N + 1, B * self.Tp, self.U + 1, B)           # ptrE, ordE, ptrW, ordW, ptrU, ordU
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (4 * n + 15) & ~15
+        st = self.__dict__.setdefault('_dev_csr', {})
+        if st.get('key') != (B, total):
+            st['key'] = (B, total)
+            st['ring'] = [torch.empty(total, dtype=torch.uint8, device=self.device) for _ in range(3)]
+            st['free'] = [None] * 3                        # recorded by the step that read the slot, on its stream
+            st['i'] = 0
+            st['scratch'] = None
+        k = st['i'] % 3
+        buf = st['ring'][k]
+        st['i'] += 1
+        if st['free'][k] is not None:
+            torch.cuda.current_stream(self.device).wait_event(st['free'][k])
+            st['free'][k] = None
+        if prep is not None:
+            prep['slot'] = k
+        base = buf.data_ptr()
+        ls = (_lib.CsrList * 3)()
+        for l, (keys, T, n_rows, kp_, ko_) in zip(ls, ((bef, B * self.L, self.N, 0, 1), (aft, B * self.Tp, self.N, 2, 3), (uid, B, self.U, 4, 5))):
+            l.keys, l.T, l.n_rows, l.row_ptr, l.order = keys.data_ptr(), T, n_rows, base + offs[kp_], base + offs[ko_]
+        if st['scratch'] is None:
+            need = int(lib().drx_batch_csr_device_bytes(ls, 3))
+            if need <= 0:
+                raise _lib.DrxError('drx_batch_csr_device_bytes: invalid lists')
+            st['scratch'] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        check(lib().drx_batch_csr_device(ls, 3, st['scratch'].data_ptr(), st['scratch'].numel(), stream_ptr(self.device)), 'drx_batch_csr_device')
+        st['keep'] = (uid, bef, aft)                       # (alive until the next step has been queued behind this one)
+        return [base + o for o in offs]
+
     def prepare_batch(self, uids, before, after):
         """Host half of a step (Caser.fit() runs it on the sampler's worker thread): the batch as int32 arrays plus, for each of the
         three lookup lists, the lookups grouped by the table row they name (drx_batch_csr) — one host buffer for one upload."""
@@ -223,7 +270,16 @@ class CaserEngine:
         mask drx_hash_u32(mask_seed, b, j) >= rate * 2^32 itself (no 344 K host random numbers per batch of 4096)."""
         L_ = lib()
         csr = None
-        if isinstance(uids, dict) or (self.table_update == 'csr' and not any(torch.is_tensor(a) for a in (uids, before, after))):
+        slot = None
+        if isinstance(uids, dict) and 'csr_dev' in uids:           # prepare_device_batch: ids and grouped lookups already on the device
+            prep = uids
+            uid, bef, aft, B, csr, slot = prep['uid'], prep['before'], prep['after'], prep['B'], prep['csr_dev'], prep.get('slot')
+            uid_p, bef_p, aft_p = uid.data_ptr(), bef.data_ptr(), aft.data_ptr()
+            kp = None
+            if keep is not None:
+                kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
+                    else keep.to(self.device, torch.uint8).contiguous()
+        elif isinstance(uids, dict) or (self.table_update == 'csr' and not any(torch.is_tensor(a) for a in (uids, before, after))):
             prep = uids if isinstance(uids, dict) else self.prepare_batch(uids, before, after)
             dev = self._upload(prep['buf'])
             B = prep['B']
@@ -241,6 +297,10 @@ class CaserEngine:
                 if keep is not None:
                     kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
                         else keep.to(self.device, torch.uint8).contiguous()
+                if self.table_update == 'csr' and self.device_csr:
+                    # a batch that is already on the device (Caser.fit(device_sampler=True)): the lookups are grouped by table row THERE
+                    # (drx_batch_csr_device: one stable sort for the three lists) and the step takes the same two launches as a host batch
+                    csr = self._csr_on_device(uid, bef, aft)
             else:                                          # host batch: one asynchronous copy for all of it
                 if getattr(self, '_stage', None) is None:
                     from ._staging import StagedUpload
@@ -309,6 +369,10 @@ class CaserEngine:
                     t.p_s, (t.m_s, t.v_s) = getattr(self, sname).data_ptr(), (x.data_ptr() for x in st_[sname])
                 t.alpha, t.alpha_s, t.l2_coef = a, a_s, l2c
             check(L_.drx_rows_csr_adam_multi(tabs, 3, self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam_multi')
+            if slot is not None:                            # (the ring slot of a device-prepared batch may be rebuilt behind this point)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._dev_csr['free'][slot] = ev
         else:
             self._grad_arena.zero_()
             g = self._grads

@@ -505,6 +505,17 @@ int drx_rows_csr_adam_multi(const DrxCsrAdamTable *tables, int32_t n_tables, flo
 int64_t drx_first_occurrence(const int64_t *codes, int64_t n, int64_t n_codes, int64_t *first);
 /* host: keys [T] in [0, n_rows) -> row_ptr [n_rows + 1], order [T] (stable counting sort) */
 int drx_batch_csr(const int32_t *keys, int32_t T, int32_t n_rows, int32_t *row_ptr, int32_t *order);
+/* The same on the DEVICE, for up to DRX_MAX_CSR_TABLES key lists in one go (batches drawn on the device: Caser.fit(device_sampler=True)
+ * then takes the fused drx_rows_csr_adam_multi update too, instead of scatter + dense Adam per table): ONE stable sort of all lists'
+ * (row, lookup) pairs, row_ptr by a binary search per row.  keys must lie in [0, n_rows) (not checked on the device).
+ * scratch: drx_batch_csr_device_bytes (0 = invalid description). */
+typedef struct DrxCsrList {
+  const int32_t *keys;       /* device [T] */
+  int32_t T, n_rows;
+  int32_t *row_ptr, *order;  /* device [n_rows + 1], [T] */
+} DrxCsrList;
+size_t drx_batch_csr_device_bytes(const DrxCsrList *lists, int32_t n_lists);
+int drx_batch_csr_device(const DrxCsrList *lists, int32_t n_lists, void *scratch, size_t scratch_bytes, void *stream);
 int drx_scatter_rows(const uint32_t *keys, int32_t T, const float *src, const uint32_t *src_index, const float *coef,
                      const float *src_s, int32_t ld, int32_t n_rows, float *out, float *out_s, void *scratch,
                      size_t scratch_bytes, void *stream);

@@ -1,13 +1,13 @@
 #!/bin/bash
 # ThreadSanitizer / AddressSanitizer run of the HOST half of libdrx (csrc/drx_host.cpp: C++ PointSampler / ListSampler, the MT19937
 # corruption stream, the two draw-ahead worker threads with their job rings) — CPU only, never on a GPU box.
-#   bash scripts/sanitize_host.sh thread|address      -> profiles/r05_sanitize_<kind>.log
+#   bash scripts/sanitize_host.sh thread|address      -> profiles/r06_sanitize_<kind>.log
 set -u
 KIND=${1:-thread}
 cd "$(dirname "$0")/.."
 SO=$(python -m drecpy_amd.build --sanitize=$KIND | tail -1)
 RT=$(gcc -print-file-name=lib$([ $KIND = thread ] && echo tsan || echo asan).so)
-LOG=profiles/r05_sanitize_$KIND.log
+LOG=profiles/r06_sanitize_$KIND.log
 export DRX_HOST_SANITIZER_LIB=$SO
 export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66"
 export ASAN_OPTIONS="detect_leaks=0 exitcode=66"     # (CPython itself 'leaks' by design; leaks of the library show up as reports of its frames)

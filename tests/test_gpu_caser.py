@@ -472,3 +472,70 @@ def test_fused_launches_equal_the_separate_ones_bit_for_bit():
           'drx_adam_segments')
     torch.cuda.synchronize()
     assert torch.equal(eng2.sw, sw_fused) and torch.equal(m2, m_fused) and torch.equal(v2, v_fused)
+
+
+@pytest.mark.parametrize('lists', [((500, 40),), ((20480, 3706), (49152, 3706), (4096, 6040)), ((7, 3), (1, 1), (300, 100000), (64, 2))])
+def test_device_csr_of_key_lists_equals_the_host_counting_sort(lists):
+    """drx_batch_csr_device (one stable sort of all lists' (row, lookup) pairs + a binary search per row) against drx_batch_csr: the same
+    row_ptr and the same order — a row's lookups ascending — for every list, rows nobody names included."""
+    import ctypes as C
+    import torch
+    from drecpy_amd import _lib
+    L_ = _lib.lib()
+    rng = np.random.default_rng(len(lists))
+    dev = torch.device('cuda:0')
+    ls = (_lib.CsrList * len(lists))()
+    keep, want = [], []
+    for l, (T, n_rows) in zip(ls, lists):
+        keys = (rng.zipf(1.3, size=T) % n_rows).astype(np.int32) if n_rows > 3 else rng.integers(0, n_rows, size=T).astype(np.int32)
+        rp, od = np.empty(n_rows + 1, np.int32), np.empty(T, np.int32)
+        assert L_.drx_batch_csr(keys.ctypes.data, T, n_rows, rp.ctypes.data, od.ctypes.data) == 0
+        want.append((rp, od))
+        k_d = torch.as_tensor(keys).to(dev)
+        rp_d = torch.full((n_rows + 1,), -7, dtype=torch.int32, device=dev)
+        od_d = torch.full((T,), -7, dtype=torch.int32, device=dev)
+        keep.append((k_d, rp_d, od_d))
+        l.keys, l.T, l.n_rows, l.row_ptr, l.order = k_d.data_ptr(), T, n_rows, rp_d.data_ptr(), od_d.data_ptr()
+    need = int(L_.drx_batch_csr_device_bytes(ls, len(lists)))
+    assert need > 0
+    scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.check(L_.drx_batch_csr_device(ls, len(lists), scratch.data_ptr(), need, _lib.stream_ptr(dev)), 'drx_batch_csr_device')
+    assert L_.drx_batch_csr_device(ls, len(lists), scratch.data_ptr(), need - 1024, _lib.stream_ptr(dev)) != 0      # (scratch too small: refused)
+    torch.cuda.synchronize()
+    for (rp, od), (_, rp_d, od_d) in zip(want, keep):
+        assert np.array_equal(rp_d.cpu().numpy(), rp) and np.array_equal(od_d.cpu().numpy(), od)
+
+
+@pytest.mark.parametrize('drop', [False, True])
+def test_a_batch_on_the_device_takes_the_same_step_as_the_same_batch_from_the_host(drop):
+    """Device tensors in (Caser.fit(device_sampler=True)): the lookups are grouped by row on the device and the step runs the launches of
+    a host batch — the same parameters BIT FOR BIT; with device_csr off the scatter + dense-Adam update (r02 – r05) only agrees to rounding."""
+    import torch
+    from drecpy_amd.engine_caser import CaserEngine
+    d, L, n_v, n_h, T, neg, B, U, N = 50, 5, 4, 16, 3, 3, 700, 60, 90
+    rng = np.random.default_rng(4)
+    p = ca.init_params(rng, U, N, L, d, n_v, n_h, np.float64)
+    engs = []
+    for kind in ('host', 'device', 'device-scatter'):
+        e = CaserEngine(U, N, L, T, neg, d, n_v, n_h)
+        e.set_params(p)
+        e.lr, e.reg = 5e-3, 1e-4
+        e.device_csr = kind != 'device-scatter'
+        engs.append(e)
+    nx = n_v + L * n_h
+    dev = engs[0].device
+    for step in range(4):
+        uids = rng.integers(0, U, size=B)
+        before = rng.zipf(1.5, size=(B, L)) % N
+        after = rng.integers(0, N, size=(B, T + T * neg))
+        keep = (rng.random((B, nx)) >= 0.5) if drop else None
+        rate = 0.5 if drop else 0.0
+        losses = [engs[0].step(step, uids, before, after, keep, rate, want_loss=True)]
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        for e in engs[1:]:
+            losses.append(e.step(step, t(uids), t(before), t(after), keep, rate, want_loss=True))
+        assert losses[0] == losses[1] and abs(losses[2] - losses[0]) < 1e-5 * abs(losses[0])
+    a, b, c = (e.get_params() for e in engs)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        np.testing.assert_allclose(c[k], a[k], rtol=0, atol=2e-6, err_msg=k)
