@@ -783,7 +783,8 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
     # The touch list of a batch (sorted row keys) does not depend on the parameters: it is prepared ahead on a side stream
     overlap = not args.no_overlap
     main = torch.cuda.current_stream()
-    side = torch.cuda.Stream(priority=-1) if overlap else None
+    from drecpy_amd.engine import run_ahead_stream
+    side = run_ahead_stream(dev, 0) if overlap else None            # (the process-wide pool: probed for a hardware queue of its own)
     prep_bufs = [None, None]
     prep_done = [torch.cuda.Event(), torch.cuda.Event()]
     step_done = [torch.cuda.Event(), torch.cuda.Event()]

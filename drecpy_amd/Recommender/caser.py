@@ -144,7 +144,8 @@ class Caser(RecommenderABC):
         eng = self._engine
         st = self.__dict__.get('_ahead')
         if st is None or st['B'] != batch_size:
-            st = self._ahead = {'B': batch_size, 'side': torch.cuda.Stream(eng.device, priority=-1), 'next': None}
+            from ..engine import run_ahead_stream
+            st = self._ahead = {'B': batch_size, 'side': run_ahead_stream(eng.device, 0), 'next': None}
         main = torch.cuda.current_stream(eng.device)
 
         def draw():

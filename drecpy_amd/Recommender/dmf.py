@@ -87,7 +87,8 @@ class DMF(RecommenderABC):
         self._host_prefetch = False                  # nothing to draw on a host thread
         self._neg_ratio = int(neg_ratio)
         self._dev_draws, self._dev_next = 0, None
-        self._dev_side = torch.cuda.Stream(self._engine.device, priority=-1)
+        from ..engine import run_ahead_stream
+        self._dev_side = run_ahead_stream(self._engine.device, 0)          # (the process-wide pool: a stream with a hardware queue of its own)
         self._dev_side.wait_stream(torch.cuda.current_stream(self._engine.device))       # the frame uploaded a moment ago
         self._dev_done = {}                          # ring slot -> event recorded behind the step that read it
         self._sampler_kind = 'device PointSampler (drx_point_sample_valued, counter-based; throughput mode)'

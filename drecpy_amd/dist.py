@@ -823,7 +823,8 @@ class ShardedPipeline:
         # High priority: ROCm multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and a stream that
         # lands on the queue of the training or the RCCL stream inherits their barriers (measured: the count exchange then
         # completes only when the GPU drains, +0.2 ms/step); priority streams get queues of their own.
-        self.side = torch.cuda.Stream(eng.device, priority=-1) if (self.cuda and use_side_stream) else None
+        from .engine import run_ahead_stream              # (the process-wide pool: streams probed for a hardware queue of their own)
+        self.side = run_ahead_stream(eng.device, 0) if (self.cuda and use_side_stream) else None
         self.P = {}
         self.next = 0
         self.host_s = [0.0, 0.0, 0.0]

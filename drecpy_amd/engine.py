@@ -8,6 +8,7 @@ import ctypes as C
 import math
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -591,7 +592,7 @@ class DeviceBatchSource:
     def __init__(self, eng, batch_size, neg_ratio, q, sample_seed_of, mask_seed_of, n_items=None, slots=8):
         self.eng, self.B, self.neg_ratio, self.q = eng, int(batch_size), int(neg_ratio), float(q)
         self.sample_seed_of, self.mask_seed_of, self.n_items = sample_seed_of, mask_seed_of, n_items
-        self.stream = torch.cuda.Stream(eng.device, priority=-1)
+        self.stream = run_ahead_stream(eng.device, 2)
         self.stream.wait_stream(torch.cuda.current_stream(eng.device))
         self.n_slots = slots                       # a slot is reused `slots` steps later: more than any pipeline looks ahead
         self.ring = [None] * slots
@@ -661,6 +662,54 @@ _RUN_AHEAD = {}
 PREP_CUS_PER_XCD = 0
 
 
+def _ping_pong_us(main, side, rounds=40):
+    """Microseconds per round of the run-ahead pattern between two streams: `side` waits for the training stream's last event, launches,
+    records; the training stream waits for that, launches, records."""
+    dev = side.device
+    x, y = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        side.wait_event(ev)
+        with _on_stream(side, main):
+            x.add_(1)
+        e2 = torch.cuda.Event()
+        e2.record(side)
+        main.wait_event(e2)
+        y.add_(1)
+        ev = torch.cuda.Event()
+        ev.record(main)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / rounds * 1e6
+
+
+# A run-ahead stream must not SHARE A HARDWARE QUEUE with the training stream: the runtime maps the streams a process uses onto a
+# handful of queues, and a stream that lands on the training stream's queue turns every cross-stream event wait into head-of-line
+# blocking — DMF.fit(device_sampler=True) at B = 256 ran at 0.33 instead of 0.11 ms/step for every second model of a process (r06,
+# profiles/r06_stream_queues.log).  Such a stream still runs kernels beside the training stream; what gives it away is the
+# round-trip time of the run-ahead pattern itself: 33 - 45 us per round on a queue of its own, 90 - 170 us on a shared one.
+STREAM_PROBE_US = 70.0
+STREAM_PROBE = os.environ.get('DRX_STREAM_PROBE', '1') != '0'
+
+
+def _probed_stream(dev, main):
+    """a high-priority stream whose run-ahead round trip with `main` is fast (the first of up to 6 candidates under STREAM_PROBE_US,
+    else the fastest of them)"""
+    best = None
+    for _ in range(6 if STREAM_PROBE else 1):
+        st = torch.cuda.Stream(dev, priority=-1)
+        if not STREAM_PROBE:
+            return st
+        us = min(_ping_pong_us(main, st), _ping_pong_us(main, st))
+        if us < STREAM_PROBE_US:
+            return st
+        if best is None or us < best[0]:
+            best = (us, st)
+    return best[1]
+
+
 def _run_ahead_streams(dev, n, cus_per_xcd=0):
     """The n run-ahead streams of a device, created ONCE per process: every new torch stream is the next of a pool and the runtime
     spreads streams over a handful of hardware queues — the second pipeline of a process (bench.py's `configs` block after the headline
@@ -679,8 +728,15 @@ def _run_ahead_streams(dev, n, cus_per_xcd=0):
                 raise _lib.DrxError(f'drx_stream_create_cu_slice({cus_per_xcd}) failed')
             have.append(torch.cuda.ExternalStream(h, device=torch.device('cuda', index)))      # (lives as long as the process)
         else:
-            have.append(torch.cuda.Stream(dev, priority=-1))
+            have.append(_probed_stream(torch.device('cuda', index), torch.cuda.current_stream(torch.device('cuda', index))))
     return have[:n]
+
+
+def run_ahead_stream(dev, k=0):
+    """The k-th run-ahead stream of the process-wide pool (k = 0, 1: the preparation of the sampled step; 2: the device samplers' draws;
+    3: deliveries).  Pipelines of different models share them: models train one at a time, and a process that uses few streams keeps
+    every one of them on a hardware queue of its own."""
+    return _run_ahead_streams(dev, k + 1, 0)[k]
 
 
 class _on_stream:
@@ -725,7 +781,7 @@ class SampledPipeline:
         # deliver_fn(s, bt, out): second stage of a preparation, issued ONE step before the list is used on a stream of its own
         # (e.g. the broadcast of a list another rank built: issued late, so that no rank's collective waits for a sort)
         self.deliver_fn = deliver_fn
-        self.comm = torch.cuda.Stream(eng.device, priority=-1) if deliver_fn is not None else None
+        self.comm = run_ahead_stream(eng.device, 3) if deliver_fn is not None else None
         self.sample_seed_of, self.mask_seed_of = sample_seed_of, mask_seed_of
         self.n_items = n_items
         dev = eng.device
