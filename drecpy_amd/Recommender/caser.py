@@ -19,6 +19,7 @@ from ..Sampler import ListSampler
 
 class Caser(RecommenderABC):
     _host_prefetch = True      # fit() draws batch t+1 on a worker thread while batch t trains (sampler-only, engine-free hook)
+    _prefetch_from = 2048      # ... for batches of at least this many samples (smaller ones: drawn inline, recommender_abc.fit)
 
     def __init__(self, L=5, T=3, d=50, n_v=4, n_h=16, act_h='relu', act_mlp='relu', dropout_rate=0.5,
                  sort_column='timestamp', device='cuda:0', reference_rank=True, **kwds):

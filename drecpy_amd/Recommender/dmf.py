@@ -18,6 +18,7 @@ from ..Sampler import PointSampler
 
 class DMF(RecommenderABC):
     _host_prefetch = True      # fit() draws batch t+1 on a worker thread while batch t trains (sampler-only, engine-free hook)
+    _prefetch_from = 2048      # ... for batches of at least this many samples (smaller ones: drawn inline, recommender_abc.fit)
     # from this batch size on, the host-side preparation of a batch (distinct ids, groupings) runs in _do_batch on the main thread instead
     # of behind the draw on the worker: at B = 4096 the reference-exact draw (0.29 ms) plus the preparation (0.09 ms) made the worker the
     # slowest stage of fit()

@@ -26,6 +26,7 @@ ran) instead of deep-copied every step (recommender_abc.py:336-341).  The loss i
 is logged or an early-stopping rule needs it.
 """
 import logging
+import os
 import pickle
 import random
 import threading
@@ -207,7 +208,11 @@ class RecommenderABC(ABC):
             # streams end exactly where the reference's do.  Models whose _sample_batch is independent of _do_batch opt in with
             # `_host_prefetch` (the draw runs on a worker thread; ctypes calls release the GIL); CDAE handles `more_to_come`
             # itself (its corruption stream belongs to the draw).
-            if getattr(self, '_host_prefetch', False):
+            # From `_prefetch_from` samples per batch on: below it the draw is a few tens of microseconds, and two threads that both run
+            # Python hand the interpreter lock back and forth through futex wake-ups — DMF at B = 256: 0.19 - 0.25 ms per step with the
+            # worker, 0.125 inline (r06, profiles/r06_host_handover.log).
+            if getattr(self, '_host_prefetch', False) and batch_size >= getattr(self, '_prefetch_from', 0) \
+                    and os.environ.get('DRX_HOST_PREFETCH') != 'inline':
                 batch = ahead.result() if ahead is not None else self._sample_batch(batch_size, **kwds)
                 ahead = self._prefetch_pool().submit(self._sample_batch, batch_size, **kwds) if epoch < epochs else None
             else:
@@ -224,6 +229,9 @@ class RecommenderABC(ABC):
                 if ahead is not None:
                     ahead.result()                 # drawn but unused: an early stop leaves the sampler one batch further
                 break
+        if getattr(self, '_host_pool', None) is not None:      # (the prefetch worker of this fit(): the next fit() starts its own)
+            self._host_pool.close()
+            self._host_pool = None
         best = monitor.after_training(epoch)
         if best is not None and best != epochs:
             self._info(f'Reverting network weights to epoch {best} due to the evaluation of the early stopping rule '
@@ -356,8 +364,16 @@ class RecommenderABC(ABC):
 
     def _prefetch_pool(self):
         if getattr(self, '_host_pool', None) is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._host_pool = ThreadPoolExecutor(max_workers=2)
+            if os.environ.get('DRX_HOST_PREFETCH', 'spin') == 'pool':          # (A/B: concurrent.futures, r02 - r05)
+                from concurrent.futures import ThreadPoolExecutor
+
+                class _Pool(ThreadPoolExecutor):
+                    def close(self):
+                        self.shutdown(wait=True)
+                self._host_pool = _Pool(max_workers=1)
+            else:
+                from .._spinpool import SpinWorker        # (one worker; hand-overs polled without the interpreter lock)
+                self._host_pool = SpinWorker()
         return self._host_pool
 
     @abstractmethod

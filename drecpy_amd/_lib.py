@@ -224,6 +224,7 @@ SIGNATURES = {
     'drx_dmf_fwd_bwd': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p]),
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
     'drx_first_occurrence': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    'drx_spin_until': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
     'drx_batch_csr': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'drx_batch_csr_device_bytes': (C.c_size_t, [C.POINTER(CsrList), C.c_int32]),
     'drx_batch_csr_device': (C.c_int, [C.POINTER(CsrList), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -704,6 +704,22 @@ void drx_drawahead_destroy(DrxDrawAhead *d) {
   delete d;
 }
 
+// Polls *p until it is at least `at_least` or `poll_us` microseconds have passed (1 / 0): the hand-over between fit()'s issuing thread
+// and its sampling worker (drecpy_amd/_spinpool.py) — called through ctypes, i.e. WITHOUT the interpreter lock.  A batch is needed
+// every 90 - 250 us; putting either thread to sleep between two of them costs a futex wake-up on an idle core each way, and the same
+// loop ran at 0.09 or at 0.23 ms per step depending on where the scheduler had put the threads (r06, profiles/r06_host_handover.log).
+int drx_spin_until(const int64_t *p, int64_t at_least, int32_t poll_us) {
+  if (!p) return DRX_EINVAL;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(p, __ATOMIC_ACQUIRE) >= at_least) return 1;
+    __builtin_ia32_pause();
+    if ((spins & 255) == 255 &&
+        std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= poll_us)
+      return 0;
+  }
+}
+
 // first[c] = position of the first occurrence of code c in codes[0..n) (or -1): Dataset.unique() on columns of small dense integer codes
 // without a sort.  Returns the number of distinct codes, or DRX_EINVAL for a code outside [0, n_codes).
 int64_t drx_first_occurrence(const int64_t *codes, int64_t n, int64_t n_codes, int64_t *first) {

@@ -503,6 +503,9 @@ int drx_rows_csr_adam_multi(const DrxCsrAdamTable *tables, int32_t n_tables, flo
 /* host: first[c] = first position of code c in codes[0..n), -1 when absent; returns the number of distinct codes (Dataset.unique on
  * dense integer code columns, mem_dataset.py's drop_duplicates, without a sort) */
 int64_t drx_first_occurrence(const int64_t *codes, int64_t n, int64_t n_codes, int64_t *first);
+/* host: 1 as soon as *p >= at_least, 0 after poll_us microseconds of polling (the hand-over between fit()'s issuing thread and its
+ * sampling worker thread: drecpy_amd/_spinpool.py; recommender_abc.py:186-188 draws the batch inline) */
+int drx_spin_until(const int64_t *p, int64_t at_least, int32_t poll_us);
 /* host: keys [T] in [0, n_rows) -> row_ptr [n_rows + 1], order [T] (stable counting sort) */
 int drx_batch_csr(const int32_t *keys, int32_t T, int32_t n_rows, int32_t *row_ptr, int32_t *order);
 /* The same on the DEVICE, for up to DRX_MAX_CSR_TABLES key lists in one go (batches drawn on the device: Caser.fit(device_sampler=True)

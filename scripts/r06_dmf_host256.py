@@ -10,7 +10,9 @@ from drecpy_amd.Recommender import DMF                           # noqa: E402
 
 ds = InteractionDataset.read_df(bc.frame_of('ml-1m'), verbose=False)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for si in (5e-3, 1e-4, 1e-5, 5e-3, 1e-4, 1e-5):
+if os.environ.get('DRX_FORCE_WORKER') == '1':
+    DMF._prefetch_from = 0                                       # (A/B: the worker thread at every batch size)
+for si in (5e-3, 5e-3, 5e-3):
     sys.setswitchinterval(si)
     md = DMF(user_factors=[64, 32], item_factors=[64, 32], seed=10, verbose=False, device='cuda:0')
     md.fit(ds, epochs=3, batch_size=B, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=5)
