@@ -139,3 +139,23 @@ def test_scatter_rows_both_paths_against_numpy(T, n_rows, ld, indexed):
     scale = max(1.0, float(np.abs(want).max()))
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-5 * scale)
     np.testing.assert_allclose(out_s.cpu().numpy(), want_s, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want_s).max())))
+
+
+def test_run_ahead_streams_come_from_one_probed_pool():
+    """engine.run_ahead_stream: the k-th run-ahead stream of the PROCESS (DMF, Caser, the device samplers and the row layout's side stream
+    share them — a process that uses few streams keeps each on a hardware queue of its own), probed when created: the round trip of the
+    run-ahead pattern with the training stream (_ping_pong_us) is that of a stream with its own queue."""
+    import torch
+    from drecpy_amd import engine
+    dev = torch.device('cuda:0')
+    a, b = engine.run_ahead_stream(dev, 0), engine.run_ahead_stream(dev, 1)
+    assert a is engine.run_ahead_stream(dev, 0) and b is engine.run_ahead_stream(dev, 1) and a.cuda_stream != b.cuda_stream
+    main = torch.cuda.current_stream(dev)
+    assert a.cuda_stream != main.cuda_stream
+    us = min(engine._ping_pong_us(main, a), engine._ping_pong_us(main, a))
+    assert us < 2 * engine.STREAM_PROBE_US, us            # (a stream on the training stream's queue: 90 - 170 us on the boxes measured)
+    x = torch.zeros(8, device=dev)
+    with engine._on_stream(a):
+        x.add_(1)
+    torch.cuda.synchronize()
+    assert float(x.sum()) == 8.0 and torch.cuda.current_stream(dev).cuda_stream == main.cuda_stream
