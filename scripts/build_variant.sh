@@ -13,7 +13,9 @@ for s in $SRCS; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I $ROOT/include -I $ROOT/drecpy_amd/csrc $FLAGS -c $ROOT/drecpy_amd/csrc/$s -o $OBJ/$s.o &
   pids="$pids $!"
 done
-g++ -pthread -O3 -fPIC -std=c++17 -I $ROOT/include -I $ROOT/drecpy_amd/csrc -c $ROOT/drecpy_amd/csrc/drx_host.cpp -o $OBJ/drx_host.cpp.o
+for s in drx_host.cpp drx_shard_phase.cpp; do
+  g++ -pthread -O3 -fPIC -std=c++17 -I $ROOT/include -I $ROOT/drecpy_amd/csrc -c $ROOT/drecpy_amd/csrc/$s -o $OBJ/$s.o
+done
 for p in $pids; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $ROOT/drecpy_amd/csrc/build/libdrx_$NAME.so $OBJ/*.o -ldl
 echo $ROOT/drecpy_amd/csrc/build/libdrx_$NAME.so
