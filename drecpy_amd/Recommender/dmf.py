@@ -103,7 +103,8 @@ class DMF(RecommenderABC):
             self._dev_side.wait_event(self._dev_done[k])
         self._dev_draws += 1
         seed = (int(self.seed) if self.seed is not None else 0) * 1000003 + self._dev_draws
-        with torch.cuda.stream(self._dev_side):
+        from ..engine import _on_stream                 # (`with torch.cuda.stream(...)` without most of its Python layers)
+        with _on_stream(self._dev_side):
             prep = eng.prepare_batch_device(batch_size, self._neg_ratio, seed)
             prep['ready'] = torch.cuda.Event()
             prep['ready'].record(self._dev_side)

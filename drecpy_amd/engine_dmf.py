@@ -281,18 +281,27 @@ class DmfEngine:
                 'scratch': torch.empty(need, dtype=torch.uint8, device=self.device)}
         st = stream_ptr(self.device)
         uid, iid = slot['ids'][0], slot['ids'][1]
+        # everything but the seed and the stream is the same from call to call on a slot: the arguments are built once (at B = 256 the
+        # host, not the device, bounds fit(device_sampler=True): r06, profiles/r06_dmf_host_profile_B256.txt)
+        call = slot.get('call')
+        pos, rec = getattr(self, '_pos', None), getattr(self, '_rec', None)          # (set_sampler_frame; absent when only `triples` are prepared)
+        if call is None or call['pos'] is not pos or call['rec'] is not rec:
+            a = slot['arr']
+            call = slot['call'] = {
+                'pos': pos, 'rec': rec, 'draw_out': (ptr(uid), ptr(iid), ptr(slot['y'])),
+                'distinct': (ptr(uid), ptr(iid), ptr(slot['y']), B, self.U, self.N, *[ptr(a[r]) for r in range(8)], ptr(slot['nd']),
+                             ptr(slot['y_mean']), ptr(slot['scratch']), slot['scratch'].numel())}
+            if pos is not None:
+                H = History(ptr(pos[0]), ptr(pos[1]))
+                R = History(ptr(rec[0]), ptr(rec[1])) if rec is not None else None
+                call.update({'H': H, 'R': R, 'draw': (C.byref(H), C.byref(R) if R is not None else None, ptr(pos[2]), self._vstd[0], self._vstd[1],
+                                                      self.U, self.N, B)})
         if triples is not None:
             uid.copy_(triples[0]); iid.copy_(triples[1]); slot['y'].copy_(triples[2])
         else:
-            H = History(ptr(self._pos[0]), ptr(self._pos[1]))
-            R = History(ptr(self._rec[0]), ptr(self._rec[1])) if self._rec is not None else None
-            check(L_.drx_point_sample_valued(C.byref(H), C.byref(R) if R is not None else None, ptr(self._pos[2]), self._vstd[0],
-                                             self._vstd[1], self.U, self.N, B, int(neg_ratio), int(seed) & ((1 << 64) - 1), ptr(uid), ptr(iid),
-                                             ptr(slot['y']), st), 'drx_point_sample_valued')
-        a = slot['arr']
-        check(L_.drx_dmf_batch_distinct_device(ptr(uid), ptr(iid), ptr(slot['y']), B, self.U, self.N, *[ptr(a[r]) for r in range(8)],
-                                               ptr(slot['nd']), ptr(slot['y_mean']), ptr(slot['scratch']), slot['scratch'].numel(), st),
-              'drx_dmf_batch_distinct_device')
+            check(L_.drx_point_sample_valued(*call['draw'], int(neg_ratio), int(seed) & ((1 << 64) - 1), *call['draw_out'], st),
+                  'drx_point_sample_valued')
+        check(L_.drx_dmf_batch_distinct_device(*call['distinct'], st), 'drx_dmf_batch_distinct_device')
         return {'device': slot, 'B': B}
 
     def _upload_batch(self, prepared):
@@ -321,6 +330,10 @@ class DmfEngine:
         and the prediction scale among them (the registration order, recommender_abc.py:194-196); default: the reference DMF's
         (2, 0, 1), or (3, 1, 2, 0) with a bound scale."""
         L_ = lib()
+        if isinstance(uids, dict) and uids.get('device') is not None and not want_loss:
+            done = self._step_device_cached(L_, step_idx, uids, applies)
+            if done:
+                return None
         z = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
         if not isinstance(uids, dict):
@@ -428,9 +441,49 @@ class DmfEngine:
         m, v = self.state['sw']
         check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), self.beta1, self.beta2, self.eps,
                                    stream), 'drx_adam_segments')
+        if on_device and scan and prep['device'].pop('step_cache_wanted', False):
+            sg_tw = [(i, tw) for i, (_, _, _, _, tw) in enumerate(self.seg)] + ([(len(self.seg), 2)] if self.scale_var is not None else [])
+            prep['device']['step_cache'] = {
+                'applies': tuple(applies), 'key': self._step_cache_key(), 'A': A, 'up': up, 'sg': sg, 'gsw': ptr(gsw), 'D': C.byref(self.D),
+                'Aref': C.byref(A), 'upref': C.byref(up), 'sgref': C.byref(sg), 'sg_tw': sg_tw, 'sw': ptr(self.sw), 'm': ptr(m), 'v': ptr(v),
+                'keep': (gsw, gpart, lpart, dz0u, dz0i)}
         if want_loss:
             return float((gsw[-1] + reg_loss).item())
         return None
+
+    def _step_device_cached(self, L_, step_idx, prep, applies):
+        """step() for a device-prepared batch whose argument structs were built by an earlier step on the same ring slot: only the stamp
+        and the learning rates change from step to step (fit(device_sampler=True) at B = 256 is bound by the host's Python, not by the
+        75 us of kernels).  False when there is no valid cache for the slot: the caller takes the general path, which fills it."""
+        sl = prep['device']
+        c = sl.get('step_cache')
+        if applies is None:
+            applies = (3, 1, 2, 0) if self.scale_var is not None else (2, 0, 1, None)
+        if c is None or c['applies'] != applies or c['key'] != self._step_cache_key():
+            sl['step_cache_wanted'] = True
+            return False
+        A, up, sg, gsw = c['A'], c['up'], c['sg'], c['gsw']
+        stream = stream_ptr(self.device)
+        self._stamp += 1
+        A.stamp = self._stamp
+        n_app = applies[0]
+        alpha = [CdaeEngine.adam_alpha(self.lr, n_app * step_idx + j + 1, self.beta1, self.beta2) if j is not None else 0.0 for j in applies[1:]]
+        check(L_.drx_dmf_fwd_bwd(c['D'], c['Aref'], gsw, stream), 'drx_dmf_fwd_bwd')
+        up.alpha_u, up.alpha_i = alpha[0], alpha[1]
+        check(L_.drx_dmf_k0_update(c['D'], c['Aref'], c['upref'], stream), 'drx_dmf_k0_update')
+        for i, tw in c['sg_tw']:
+            sg.alpha[i] = alpha[tw]
+        check(L_.drx_adam_segments(c['sw'], c['m'], c['v'], gsw, c['sgref'], self.beta1, self.beta2, self.eps, stream), 'drx_adam_segments')
+        return True
+
+    def _step_cache_key(self):
+        """what a cached argument struct depends on besides its ring slot: the tensors a set_params / set_interactions / optimizer change
+        would replace, and the scalars baked into the structs"""
+        w = getattr(self, '_work', None)
+        return (self.K0u.data_ptr(), self.sw.data_ptr(), self._maps[0].data_ptr(), self._rho[0].data_ptr(), self.csr[0].data_ptr(),
+                self.state['sw'][0].data_ptr(), self.state['K0u'][0].data_ptr(), self._k0_order.data_ptr(), self._k0_long,
+                w.data_ptr() if w is not None else 0, id(self.D), self.D.off_scale, self.first_layer_update, self.reg, self.beta1, self.beta2,
+                self.eps, self.broadcast_targets, self.scale_var is not None, getattr(self, '_step_bufs', (None,))[0])
 
     def predict(self, uids, iids, want_reps=False, scaled=True):
         """max(1e-6, cosine) for each (uid, iid) pair (dmf.py:88-96) — times the bound prediction scale unless scaled=False;

@@ -389,6 +389,62 @@ def test_a_step_on_a_device_prepared_batch_equals_the_host_prepared_one(modified
         assert np.array_equal(ga[k], gb[k]), k
 
 
+@pytest.mark.parametrize('modified', [False, True])
+def test_the_cached_argument_structs_of_device_batches_change_nothing(modified, monkeypatch):
+    """Steps on device-prepared batches reuse the argument structs an earlier step built for the same ring slot (only the stamp and the
+    learning rates are refreshed: DmfEngine._step_device_cached): the same parameters, bit for bit, as with the cache off — over more steps
+    than the ring has slots, with a learning-rate change and a set_params (which replaces nothing the cache points to) in between."""
+    import torch
+    from drecpy_amd.engine_dmf import DmfEngine
+    from drecpy_amd.Recommender import Variable
+    rng = np.random.default_rng(23)
+    U, N, B = 150, 90, 180
+    csr, csc, _ = _problem(rng, U, N, 2800)
+    p = dm.init_params(rng, U, N, (32, 16), (24, 16), np.float64)
+    engs = []
+    for _ in range(2):
+        e = DmfEngine(U, N, (32, 16), (24, 16), True)
+        e.set_interactions(csr, csc)
+        if modified:
+            e.bind_prediction_scale(Variable([1.0]), broadcast_targets=True)
+        e.set_params(p)
+        e.lr, e.reg = 2e-3, 1e-3
+        engs.append(e)
+    monkeypatch.setattr(engs[1], '_step_device_cached', lambda *a, **k: False)          # the general path every time
+    hits = [0]
+    inner = engs[0]._step_device_cached
+
+    def counted(*a, **k):
+        r = inner(*a, **k)
+        hits[0] += bool(r)
+        return r
+    monkeypatch.setattr(engs[0], '_step_device_cached', counted)
+    for step in range(11):
+        u = rng.integers(0, U, size=B).astype(np.int32)
+        i = rng.integers(0, N // 3, size=B).astype(np.int32)
+        y = rng.random(B).astype(np.float32)
+        if step == 7:
+            for e in engs:
+                e.lr = 5e-3
+        for e in engs:
+            e.step(step, e.prepare_batch_device(B, 0, 0, triples=[torch.as_tensor(a).cuda() for a in (u, i, y)]))
+    assert hits[0] >= 4, hits                       # (3 slots: filled on their second visit, reused from the third)
+    ga, gb = engs[0].get_params(), engs[1].get_params()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+    engs[0].reg = 5e-3                              # a scalar the structs hold: the cache must notice
+    engs[1].reg = 5e-3
+    for step in range(11, 14):
+        u = rng.integers(0, U, size=B).astype(np.int32)
+        i = rng.integers(0, N // 3, size=B).astype(np.int32)
+        y = rng.random(B).astype(np.float32)
+        for e in engs:
+            e.step(step, e.prepare_batch_device(B, 0, 0, triples=[torch.as_tensor(a).cuda() for a in (u, i, y)]))
+    ga, gb = engs[0].get_params(), engs[1].get_params()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+
+
 def test_dmf_fit_with_the_device_sampler():
     """DMF.fit(device_sampler=True): the device PointSampler's triples carry the reference sampler's distribution AND values
     (two-sample chi-square against the reference-exact stream: users of positives, cells of positives, users / items of
