@@ -898,8 +898,6 @@ class SampledPipeline:
     def run_step(self, events=None, want_loss=False):
         """Queues step `self.next` (and the run-ahead work of the following steps); returns the loss tensor or None."""
         s = self.next
-        self._sample(s + self.SA)
-        self._prepare(s + self.D)
         if self.deliver_fn is not None:
             self._deliver(s + 1)
         bt = self.batch_of(s)
@@ -910,5 +908,10 @@ class SampledPipeline:
         else:
             out = self.eng.step_sparse(s, bt, self.loss, want_loss=want_loss, events=events, prepared=self.prep[k])
         self.step_ev[s % self.NE].record(self.main)
+        # The run-ahead work of later steps is queued BEHIND the step itself: everything step s needs was queued iterations ago, and after
+        # a host-side fence (an epoch callback, bench.py's timed windows) the training stream starts 50 - 60 us earlier (r06: windows of
+        # 20 steps ran 0.8 % faster); in steady state the host is several steps ahead and the order does not matter.
+        self._sample(s + self.SA)
+        self._prepare(s + self.D)
         self.next = s + 1
         return out
