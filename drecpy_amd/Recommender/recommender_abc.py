@@ -26,7 +26,6 @@ ran) instead of deep-copied every step (recommender_abc.py:336-341).  The loss i
 is logged or an early-stopping rule needs it.
 """
 import logging
-import os
 import pickle
 import random
 import threading
@@ -211,8 +210,7 @@ class RecommenderABC(ABC):
             # From `_prefetch_from` samples per batch on: below it the draw is a few tens of microseconds, and two threads that both run
             # Python hand the interpreter lock back and forth through futex wake-ups — DMF at B = 256: 0.19 - 0.25 ms per step with the
             # worker, 0.125 inline (r06, profiles/r06_host_handover.log).
-            if getattr(self, '_host_prefetch', False) and batch_size >= getattr(self, '_prefetch_from', 0) \
-                    and os.environ.get('DRX_HOST_PREFETCH') != 'inline':
+            if getattr(self, '_host_prefetch', False) and batch_size >= getattr(self, '_prefetch_from', 0) and self._prefetch_mode != 'inline':
                 batch = ahead.result() if ahead is not None else self._sample_batch(batch_size, **kwds)
                 ahead = self._prefetch_pool().submit(self._sample_batch, batch_size, **kwds) if epoch < epochs else None
             else:
@@ -362,9 +360,12 @@ class RecommenderABC(ABC):
     def _pre_fit(self, learning_rate, neg_ratio, reg_rate, **kwds):
         """Build the model state for `self.interaction_dataset` (tables on the device, sampler)."""
 
+    _prefetch_mode = 'spin'       # who draws the next batch of a `_host_prefetch` model: 'spin' (a worker with polled hand-overs),
+                                  # 'pool' (concurrent.futures: the r02 - r05 form) or 'inline' — an attribute, not an environment switch
+
     def _prefetch_pool(self):
         if getattr(self, '_host_pool', None) is None:
-            if os.environ.get('DRX_HOST_PREFETCH', 'spin') == 'pool':          # (A/B: concurrent.futures, r02 - r05)
+            if self._prefetch_mode == 'pool':          # (A/B: concurrent.futures, r02 - r05)
                 from concurrent.futures import ThreadPoolExecutor
 
                 class _Pool(ThreadPoolExecutor):

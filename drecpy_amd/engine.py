@@ -691,7 +691,7 @@ def _ping_pong_us(main, side, rounds=40):
 # profiles/r06_stream_queues.log).  Such a stream still runs kernels beside the training stream; what gives it away is the
 # round-trip time of the run-ahead pattern itself: 33 - 45 us per round on a queue of its own, 90 - 170 us on a shared one.
 STREAM_PROBE_US = 70.0
-STREAM_PROBE = os.environ.get('DRX_STREAM_PROBE', '1') != '0'
+STREAM_PROBE = True                 # (False: take the streams as they come — A/B, scripts/r06_stream_parity.py)
 
 
 def _probed_stream(dev, main):

@@ -9,6 +9,9 @@ from drecpy_amd.Dataset import InteractionDataset                # noqa: E402
 from drecpy_amd.Recommender import DMF                           # noqa: E402
 
 K, prio = int(sys.argv[1]), int(sys.argv[2])
+if os.environ.get('DRX_STREAM_PROBE') == '0':                      # (this script's own switch: the package reads no environment variable)
+    from drecpy_amd import engine
+    engine.STREAM_PROBE = False
 keep = [torch.cuda.Stream('cuda:0', priority=prio) for _ in range(K)]
 if len(sys.argv) > 3 and sys.argv[3] == 'use':                  # the dummies do some work: a stream gets its hardware queue when first used
     for st in keep:
