@@ -149,15 +149,17 @@ class Caser(RecommenderABC):
             st = self._ahead = {'B': batch_size, 'side': run_ahead_stream(eng.device, 0), 'next': None}
         main = torch.cuda.current_stream(eng.device)
 
+        from ..engine import _on_stream                 # (`with torch.cuda.stream(...)` without most of its Python layers)
+
         def draw():
             self._draws += 1
-            with torch.cuda.stream(st['side']):
-                grp, before, after = self._sampler.sample_device(batch_size, self._drop_seed * 1000003 + self._draws)
-                prep = eng.prepare_device_batch(grp, before, after)
+            with _on_stream(st['side']):
+                # a ring slot of the engine: the id tensors, the grouped lookups and every argument struct built once per slot
+                sl = eng.device_slot(batch_size)
+                self._sampler.sample_device(batch_size, self._drop_seed * 1000003 + self._draws, out=(sl['uid'], sl['before'], sl['after']))
+                prep = eng.group_slot(sl)
                 ev = torch.cuda.Event()
                 ev.record(st['side'])
-            for t in (prep['uid'], prep['before'], prep['after']):
-                t.record_stream(main)                     # (allocated with the side stream current, read by the step on the training stream)
             return prep, ev
         if st['next'] is None:
             st['side'].wait_stream(main)                  # (tables / sampler arrays set up on the training stream)

@@ -160,17 +160,21 @@ class ListSampler:
         self._twin = (G, t, torch.device(device))
         return self
 
-    def sample_device(self, n, seed):
+    def sample_device(self, n, seed, out=None):
         """n windows drawn on the device (see include/drx.h drx_list_sample_device): int32 tensors group value [n], input ids
-        [n, min_positive_records], target ids followed by negative ids [n, n_targets * (1 + neg_ratio)]."""
+        [n, min_positive_records], target ids followed by negative ids [n, n_targets * (1 + neg_ratio)].  out: the three tensors to fill."""
         import ctypes as C
         import torch
         from .. import _lib
         G, _, dev = self._twin
         L_, T, neg = int(self.min_positive_records), int(self.n_targets), int(self.neg_ratio)
-        grp = torch.empty(n, dtype=torch.int32, device=dev)
-        before = torch.empty(n, L_, dtype=torch.int32, device=dev)
-        after = torch.empty(n, T * (1 + neg), dtype=torch.int32, device=dev)
+        if out is not None:
+            grp, before, after = out
+            assert grp.numel() == n and before.shape == (n, L_) and after.shape == (n, T * (1 + neg)) and grp.dtype == torch.int32
+        else:
+            grp = torch.empty(n, dtype=torch.int32, device=dev)
+            before = torch.empty(n, L_, dtype=torch.int32, device=dev)
+            after = torch.empty(n, T * (1 + neg), dtype=torch.int32, device=dev)
         _lib.check(_lib.lib().drx_list_sample_device(C.byref(G), n, L_, T, neg, int(seed) & (2 ** 64 - 1), grp.data_ptr(), before.data_ptr(),
                                                      after.data_ptr(), _lib.stream_ptr(dev)), 'drx_list_sample_device')
         return grp, before, after

@@ -192,6 +192,118 @@ class CaserEngine:
         prep['csr_dev'] = self._csr_on_device(uid, bef, aft, prep)
         return prep
 
+    # ---- the same with the batch's id tensors OWNED by the ring (Caser.fit(device_sampler=True): the sampler writes into them) ----------
+    # Everything a draw and a step hand to the library is then the same from visit to visit of a slot: the argument structs are built
+    # once per slot (at 4096 windows the host's Python, not the 79 us of training kernels, bounded the step: r06,
+    # profiles/r06_caser_host_profile.txt).
+    def device_slot(self, B):
+        """The next ring slot for a batch of B windows drawn on the device: {'uid', 'before', 'after'} int32 tensors to fill on the CURRENT
+        stream (which has been made to wait for the step that last read the slot), then group_slot(slot)."""
+        st = self.__dict__.setdefault('_dev_slots', {})
+        if st.get('B') != B:
+            i32 = dict(dtype=torch.int32, device=self.device)
+            sizes = (self.N + 1, B * self.L, self.N + 1, B * self.Tp, self.U + 1, B)       # ptrE, ordE, ptrW, ordW, ptrU, ordU
+            offs, total = [], 0
+            for n in sizes:
+                offs.append(total)
+                total += (4 * n + 15) & ~15
+            st.clear()
+            st.update({'B': B, 'i': 0, 'slots': []})
+            for k in range(3):
+                sl = {'k': k, 'B': B, 'uid': torch.empty(B, **i32), 'before': torch.empty(B, self.L, **i32),
+                      'after': torch.empty(B, self.Tp, **i32), 'buf': torch.empty(total, dtype=torch.uint8, device=self.device), 'free': None}
+                base = sl['buf'].data_ptr()
+                ls = (_lib.CsrList * 3)()
+                for l, (keys, T, n_rows, kp_, ko_) in zip(ls, ((sl['before'], B * self.L, self.N, 0, 1), (sl['after'], B * self.Tp, self.N, 2, 3),
+                                                            (sl['uid'], B, self.U, 4, 5))):
+                    l.keys, l.T, l.n_rows, l.row_ptr, l.order = keys.data_ptr(), T, n_rows, base + offs[kp_], base + offs[ko_]
+                sl['lists'] = ls
+                sl['csr_dev'] = [base + o for o in offs]
+                st['slots'].append(sl)
+            need = int(lib().drx_batch_csr_device_bytes(st['slots'][0]['lists'], 3))
+            if need <= 0:
+                raise _lib.DrxError('drx_batch_csr_device_bytes: invalid lists')
+            st['scratch'] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            st['scratch_args'] = (st['scratch'].data_ptr(), st['scratch'].numel())
+        sl = st['slots'][st['i'] % 3]
+        st['i'] += 1
+        if sl['free'] is not None:
+            torch.cuda.current_stream(self.device).wait_event(sl['free'])
+            sl['free'] = None
+        return sl
+
+    def group_slot(self, sl):
+        """the lookups of a filled slot grouped by table row (drx_batch_csr_device) on the current stream; returns what step() takes"""
+        check(lib().drx_batch_csr_device(sl['lists'], 3, *self._dev_slots['scratch_args'], stream_ptr(self.device)), 'drx_batch_csr_device')
+        return sl
+
+    def _step_slot(self, step_idx, sl, keep, rate, mask_seed):
+        """step() on a ring slot (no loss wanted): the argument structs of the slot's earlier visit with this step's scalars"""
+        L_ = lib()
+        B = sl['B']
+        c = sl.get('step')
+        n_dE, n_dW1, n_dPu = B * self.L * self.ld, B * self.ld2, B * self.ld
+        wk = getattr(self, '_step_bufs', None)
+        if wk is None or wk[0] != (B, True):               # (the work buffers of a batch size, shared with the general path)
+            z = dict(dtype=torch.float32, device=self.device)
+            grid = L_.drx_caser_grid(C.byref(self.D), B)
+            rows = torch.zeros(n_dE + n_dW1 + n_dPu, **z)
+            wk = self._step_bufs = ((B, True), rows, torch.empty(B * self.Tp, **z), torch.empty(grid, self.D.n_small, **z), torch.empty(grid, **z),
+                                    torch.empty(self.D.n_small + 1, **z))
+        key = (self.item_emb.data_ptr(), self.sw.data_ptr(), self.state['sw'][0].data_ptr(), self.state['W1'][0].data_ptr(), self.reg, self.beta1,
+               self.beta2, self.eps, id(self.D), id(wk))
+        if c is None or c['key'] != key:
+            _, rows, db1, gpart, lpart, gsw = wk
+            base = rows.data_ptr()
+            p_dE, p_dW1, p_dPu = base, base + 4 * n_dE, base + 4 * (n_dE + n_dW1)
+            A = CaserArgs()
+            A.item_emb, A.user_emb, A.W1, A.b1, A.sw = (t.data_ptr() for t in (self.item_emb, self.user_emb, self.W1, self.b1, self.sw))
+            A.uid, A.before, A.after = sl['uid'].data_ptr(), sl['before'].data_ptr(), sl['after'].data_ptr()
+            A.B = int(B)
+            A.dE, A.db1, A.dPu, A.gsw_part, A.loss_part = p_dE, db1.data_ptr(), p_dPu, gpart.data_ptr(), lpart.data_ptr()
+            A.dW1, A.cat_out = None, p_dW1
+            l2c = 2.0 * self.reg
+            sg = AdamSegments()
+            sg.n = len(self.seg)
+            for i, (_, start, n, regd, layer) in enumerate(self.seg):
+                sg.start[i], sg.len[i], sg.l2_coef[i] = start, n, (l2c if regd else 0.0)
+            ptrE, ordE, ptrW, ordW, ptrU, ordU = sl['csr_dev']
+            st_ = self.state
+            tabs = (_lib.CsrAdamTable * 3)()
+            for t, (rp, od, src, scale, group, ld, n_rows, name, sname) in zip(tabs, (
+                    (ptrU, ordU, p_dPu, None, 0, self.ld, self.U, 'user_emb', None),
+                    (ptrE, ordE, p_dE, None, 0, self.ld, self.N, 'item_emb', None),
+                    (ptrW, ordW, p_dW1, db1.data_ptr(), self.Tp, self.ld2, self.N, 'W1', 'b1'))):
+                t.row_ptr, t.order, t.src, t.scale, t.group, t.ld, t.n_rows = rp, od, src, scale, group, ld, n_rows
+                t.p, (t.m, t.v) = getattr(self, name).data_ptr(), (x.data_ptr() for x in st_[name])
+                if sname is not None:
+                    t.p_s, (t.m_s, t.v_s) = getattr(self, sname).data_ptr(), (x.data_ptr() for x in st_[sname])
+                t.l2_coef = l2c
+            m, v = self.state['sw']
+            c = sl['step'] = {'key': key, 'A': A, 'sg': sg, 'tabs': tabs, 'keep': wk,
+                              'small': (C.byref(self.D), C.byref(A), gsw.data_ptr(), self.sw.data_ptr(), m.data_ptr(), v.data_ptr(), C.byref(sg),
+                                        self.beta1, self.beta2, self.eps),
+                              'layers': [layer for (_, _, _, _, layer) in self.seg]}
+        A, sg, tabs = c['A'], c['sg'], c['tabs']
+        kp = None
+        if keep is not None:
+            kp = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.uint8)).to(self.device) if not torch.is_tensor(keep) \
+                else keep.to(self.device, torch.uint8).contiguous()
+        A.keep = kp.data_ptr() if kp is not None else None
+        A.rate = float(rate)
+        A.mask_seed = int(mask_seed) & (2 ** 64 - 1)
+        alpha = self._alphas(step_idx)
+        for i, layer in enumerate(c['layers']):
+            sg.alpha[i] = alpha[layer]
+        tabs[0].alpha, tabs[1].alpha, tabs[2].alpha, tabs[2].alpha_s = alpha[0], alpha[1], alpha[4 + self.L], alpha[5 + self.L]
+        stream = stream_ptr(self.device)
+        check(L_.drx_caser_step_small(*c['small'], stream), 'drx_caser_step_small')
+        check(L_.drx_rows_csr_adam_multi(tabs, 3, self.beta1, self.beta2, self.eps, stream), 'drx_rows_csr_adam_multi')
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        sl['free'] = ev
+        return None
+
     def _csr_on_device(self, uid, bef, aft, prep=None):
         B = uid.numel()
         sizes = (self.N + 1, B * self.L, self.N + 1, B * self.Tp, self.U + 1, B)           # ptrE, ordE, ptrW, ordW, ptrU, ordU
@@ -271,6 +383,11 @@ class CaserEngine:
         L_ = lib()
         csr = None
         slot = None
+        if isinstance(uids, dict) and 'lists' in uids:             # a ring slot (device_slot / group_slot)
+            if not want_loss and self.table_update == 'csr':
+                return self._step_slot(step_idx, uids, keep, rate, mask_seed)
+            sl = uids                                               # (with the loss: the general path below, on the slot's tensors)
+            uids = {'uid': sl['uid'], 'before': sl['before'], 'after': sl['after'], 'B': sl['B'], 'csr_dev': sl['csr_dev'], 'ring_slot': sl}
         if isinstance(uids, dict) and 'csr_dev' in uids:           # prepare_device_batch: ids and grouped lookups already on the device
             prep = uids
             uid, bef, aft, B, csr, slot = prep['uid'], prep['before'], prep['after'], prep['B'], prep['csr_dev'], prep.get('slot')
@@ -373,6 +490,10 @@ class CaserEngine:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
                 self._dev_csr['free'][slot] = ev
+            if isinstance(uids, dict) and uids.get('ring_slot') is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                uids['ring_slot']['free'] = ev
         else:
             self._grad_arena.zero_()
             g = self._grads

@@ -539,3 +539,42 @@ def test_a_batch_on_the_device_takes_the_same_step_as_the_same_batch_from_the_ho
     for k in a:
         assert np.array_equal(a[k], b[k]), k
         np.testing.assert_allclose(c[k], a[k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_ring_slots_with_cached_argument_structs_take_the_same_steps(monkeypatch):
+    """Caser.fit(device_sampler=True) fills ring slots the engine owns (device_slot / group_slot) and steps on them with argument structs
+    built once per slot (_step_slot): the same parameters, bit for bit, as the same draws through prepare_device_batch and the general
+    step — over more steps than the ring has slots, with dropout, a learning-rate change in between."""
+    import torch
+    from drecpy_amd.engine_caser import CaserEngine
+    d, L, n_v, n_h, T, neg, B, U, N = 50, 5, 4, 16, 3, 3, 300, 70, 120
+    rng = np.random.default_rng(9)
+    p = ca.init_params(rng, U, N, L, d, n_v, n_h, np.float64)
+    engs = []
+    for _ in range(2):
+        e = CaserEngine(U, N, L, T, neg, d, n_v, n_h)
+        e.set_params(p)
+        e.lr, e.reg = 5e-3, 1e-4
+        engs.append(e)
+    dev = engs[0].device
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+    for step in range(10):
+        uids = rng.integers(0, U, size=B)
+        before = rng.zipf(1.5, size=(B, L)) % N
+        after = rng.integers(0, N, size=(B, T + T * neg))
+        if step == 6:
+            for e in engs:
+                e.lr = 1e-2
+        sl = engs[0].device_slot(B)
+        sl['uid'].copy_(t(uids)); sl['before'].copy_(t(before)); sl['after'].copy_(t(after))
+        engs[0].step(step, engs[0].group_slot(sl), rate=0.5, mask_seed=77 + step)
+        engs[1].step(step, engs[1].prepare_device_batch(t(uids), t(before), t(after)), rate=0.5, mask_seed=77 + step)
+    assert 'step' in engs[0]._dev_slots['slots'][0]                    # (the cached structs were in use)
+    la = engs[0].step(10, engs[0].group_slot(engs[0].device_slot(B)), rate=0.5, mask_seed=5, want_loss=True)      # (a slot through the general path)
+    assert np.isfinite(la)
+    a, b = engs[0].get_params(), engs[1].get_params()
+    engs[1].step(10, engs[1].prepare_device_batch(*(engs[0]._dev_slots['slots'][(engs[0]._dev_slots['i'] - 1) % 3][k] for k in ('uid', 'before', 'after'))),
+                 rate=0.5, mask_seed=5, want_loss=True)
+    a, b = engs[0].get_params(), engs[1].get_params()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
