@@ -84,6 +84,14 @@ class Caser(RecommenderABC):
         self._drop_seed = int(self.seed) if self.seed is not None else int(np.random.SeedSequence().entropy % (2 ** 62))
         self._dropout_mask_fn = kwds.get('dropout_mask_fn')
 
+    def _restore_engine(self, params):
+        """RecommenderABC.load (recommender_abc.py:517-524): the engine rebuilt from the saved weights"""
+        from ..engine_caser import CaserEngine
+        self._engine = CaserEngine(self.n_users, self.n_items, self.L, self.T, self.neg_ratio, self.d, self.n_v, self.n_h, device=self.device,
+                                   act_h=self.act_h, act_mlp=self.act_mlp)
+        self._engine.set_params(params)
+        self._layers = self._engine.layers
+
     def _fused_trainables(self):
         return self._engine.layers
 

@@ -71,6 +71,16 @@ class DMF(RecommenderABC):
         else:
             self.__dict__.pop('_host_prefetch', None)
 
+    def _restore_engine(self, params):
+        """RecommenderABC.load (recommender_abc.py:517-524): the engine rebuilt from the saved weights and the saved dataset.  A subclass
+        that bound a prediction scale in its `_pre_fit` (ModifiedDMF) binds it again in its own override before calling this."""
+        from ..engine_dmf import DmfEngine
+        ds = self.interaction_dataset
+        self._engine = DmfEngine(self.n_users, self.n_items, self.user_factors, self.item_factors, self.l2_norm_vectors, device=self.device)
+        self._engine.set_interactions(ds.interaction_csr(), ds.interaction_csr(transpose=True))
+        self._engine.set_params({k: v for k, v in params.items() if k != 'extra_w'})
+        self.user_nn, self.item_nn = self._engine.user_nn, self._engine.item_nn
+
     def _setup_device_sampler(self, ds, neg_ratio):
         import torch
         indptr, cols, vals = ds.interaction_csr()

@@ -39,7 +39,8 @@ from .loss_tracker import LossTracker
 _LOG_FORMAT = '[%(asctime)s] (%(levelname)s) %(name)s: %(message)s'
 _UNPICKLED = ('_engine', '_logger', '_file_logger', '_device_lock', '_sampler', '_mask_rng', '_mask_rngs', '_drawahead', '_L', 'epoch_weights', '_pipeline', '_pending',
               '_host_pool', '_dist_model', 'optimizer', 'trainable_vars', 'trainable_weights', 'trainable_layers', 'trainable_models',
-              '_extra_weight', 'W', 'W_', 'V', 'b', 'b_', 'user_nn', 'item_nn', '_layers')
+              '_extra_weight', 'W', 'W_', 'V', 'b', 'b_', 'user_nn', 'item_nn', '_layers',
+              '_ahead', '_dev_side', '_dev_next', '_dev_done')             # (run-ahead state of fit(device_sampler=True): streams, events, device batches)
 
 
 def _make_logger(name, handler):
@@ -199,6 +200,9 @@ class RecommenderABC(ABC):
         monitor.before_training()
         bar = self._progress_bar(epochs)
         epoch, ahead = 0, None
+        if getattr(self, '_host_pool', None) is not None:      # (left behind by a fit() that raised: its worker may hold an unclaimed job)
+            self._host_pool.close()
+            self._host_pool = None
         if not monitor.needs_loss and bar is None and self._file_logger is None:
             # nothing observes single steps (no loss, callback, rule or log line per epoch): a model may run the loop natively
             epoch = int(self._run_steps(0, epochs, batch_size, **kwds) or 0)

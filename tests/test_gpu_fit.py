@@ -320,3 +320,32 @@ def test_device_point_sampler_has_the_reference_samplers_distribution(implicit):
     close(u[pos_d] * N + i[pos_d], ru[pos_r] * N + ri[pos_r], U * N, 'cells of positives')
     close(u[~pos_d], ru[~pos_r], U, 'users of negatives')
     close(i[~pos_d], ri[~pos_r], N, 'items of negatives')
+
+
+@pytest.mark.parametrize('device_sampler', [False, True])
+def test_dmf_and_caser_survive_save_and_load(tmp_path, device_sampler):
+    """RecommenderABC.save / load (recommender_abc.py:503-524 dumps and restores the whole object) for the two models besides CDAE: the
+    loaded model ranks like the fitted one — also after fit(device_sampler=True), whose run-ahead streams and events are not saved."""
+    import pandas as pd
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import DMF, Caser, RecommenderABC
+    rng = np.random.default_rng(2)
+    rows = []
+    for u in range(40):
+        for t, i in enumerate(rng.choice(60, size=14, replace=False)):
+            rows.append((u + 1, int(i) + 1, int(rng.integers(1, 6)), t))
+    frame = pd.DataFrame(rows, columns=['user', 'item', 'interaction', 'timestamp'])
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    dmf = DMF(user_factors=[16, 8], item_factors=[16, 8], seed=10, verbose=False)
+    dmf.fit(ds, epochs=6, batch_size=64, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=3, device_sampler=device_sampler)
+    caser = Caser(L=3, T=2, d=8, n_v=2, n_h=4, dropout_rate=0.5, sort_column='timestamp', seed=10, verbose=False)
+    caser.fit(ds, epochs=6, batch_size=32, learning_rate=5e-3, reg_rate=1e-5, neg_ratio=2, device_sampler=device_sampler)
+    for name, model in (('dmf', dmf), ('caser', caser)):
+        path = str(tmp_path / f'{name}.bin')
+        model.save(path)
+        again = RecommenderABC.load(path)
+        for u in (1, 7, 40):
+            a = model.recommend(u, n=5, novelty=True)
+            b = again.recommend(u, n=5, novelty=True)
+            assert [i for _, i in a] == [i for _, i in b], (name, u)
+            np.testing.assert_allclose([s for s, _ in a], [s for s, _ in b], rtol=0, atol=1e-6)
