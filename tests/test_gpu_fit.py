@@ -349,3 +349,39 @@ def test_dmf_and_caser_survive_save_and_load(tmp_path, device_sampler):
             b = again.recommend(u, n=5, novelty=True)
             assert [i for _, i in a] == [i for _, i in b], (name, u)
             np.testing.assert_allclose([s for s, _ in a], [s for s, _ in b], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('device_sampler', [False, True])
+def test_dmf_and_caser_epoch_callbacks_early_stopping_and_revert(device_sampler):
+    """recommender_abc.py:170-256 for the two models besides CDAE: the callback runs every `epoch_callback_freq` epochs, the rule every
+    `early_stopping_freq`, and after training the weights are those of the rule's best epoch — equal to a fresh fit of that many epochs
+    from the same seed (the draws and the steps are deterministic), with the host samplers and with the device samplers."""
+    import pandas as pd
+    from drecpy_amd.Dataset import InteractionDataset
+    from drecpy_amd.Recommender import DMF, Caser, MaxValidationValueRule
+    rng = np.random.default_rng(4)
+    rows = []
+    for u in range(40):
+        for t, i in enumerate(rng.choice(60, size=14, replace=False)):
+            rows.append((u + 1, int(i) + 1, int(rng.integers(1, 6)), t))
+    frame = pd.DataFrame(rows, columns=['user', 'item', 'interaction', 'timestamp'])
+    ds = InteractionDataset.read_df(frame, verbose=False)
+    make = {'dmf': lambda: DMF(user_factors=[16, 8], item_factors=[16, 8], seed=10, verbose=False),
+            'caser': lambda: Caser(L=3, T=2, d=8, n_v=2, n_h=4, dropout_rate=0.5, sort_column='timestamp', seed=10, verbose=False)}
+    args = {'dmf': dict(batch_size=64, learning_rate=1e-3, reg_rate=1e-4, neg_ratio=3),
+            'caser': dict(batch_size=32, learning_rate=5e-3, reg_rate=1e-5, neg_ratio=2)}
+    for name in ('dmf', 'caser'):
+        calls = []
+
+        def cb(m):
+            calls.append(1)
+            return {'val': -abs(len(calls) - 2)}          # best at the 2nd callback = epoch 4
+        model = make[name]()
+        model.fit(ds, epochs=8, epoch_callback_fn=cb, epoch_callback_freq=2, early_stopping_rule=MaxValidationValueRule('val'),
+                  early_stopping_freq=2, device_sampler=device_sampler, **args[name])
+        assert len(calls) == 4 and len(model._loss_tracker.epoch_losses) == 8, (name, len(calls))
+        ref = make[name]()
+        ref.fit(ds, epochs=4, device_sampler=device_sampler, **args[name])
+        a, b = model._engine.get_params(), ref._engine.get_params()
+        for k in a:
+            np.testing.assert_allclose(a[k], b[k], rtol=0, atol=1e-6, err_msg=f'{name} {k}')
