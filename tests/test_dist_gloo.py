@@ -84,7 +84,8 @@ def _worker(rank, world, rdzv, out, pipelined=False, micro=1, bypass=True, chunk
     # the chunked schedule (r06): every exchange in `chunks` all-to-alls, the owner apply of chunk c followed by the gather + row exchange
     # of the NEXT step's chunk c (pipelined) or every step fetching its own rows (inline)
     (True, 1, 2, True, 2, 9000), (True, 1, 2, False, 4, 17000), (False, 1, 3, True, 2, 13000), (True, 2, 2, True, 2, 9000),
-    (True, 1, 4, True, 4, 34000), (True, 2, 3, False, 2, 13000)])
+    (True, 1, 4, True, 4, 34000), (True, 2, 3, False, 2, 13000),
+    (True, 1, 8, True, 2, 70000)])                                             # (the world of BASELINE configuration 4)
 def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, world, bypass, chunks, n_items):
     """micro > 1: every rank's batch is split into micro-batches with disjoint users whose exchanges overlap each other's
     compute; the step must still equal the single-process step on the concatenated batch.  bypass: a rank's own rows never pass
