@@ -212,7 +212,9 @@ def test_sharded_world1_chunked_matches_oracle(monkeypatch, pipelined, micro, by
 
 
 @pytest.mark.parametrize('pipelined,micro,world,bypass,chunks,n_items,k', [(True, 1, 2, True, 2, 9000, 50), (True, 1, 3, False, 2, 13000, 50),
-                                                                           (True, 2, 2, True, 2, 9000, 50), (True, 1, 2, False, 4, 17000, 128)])
+                                                                           (True, 2, 2, True, 2, 9000, 50), (True, 1, 2, False, 4, 17000, 128),
+                                                                           # (BASELINE configuration 4's world: eight segments per chunk in the owner's kernels)
+                                                                           (True, 1, 8, True, 2, 70000, 128), (True, 1, 8, False, 1, 70000, 50), (True, 1, 5, True, 2, 43000, 128)])
 @retry_infra
 def test_sharded_ranks_on_one_gpu_chunked_match_oracle(tmp_path, monkeypatch, pipelined, micro, world, bypass, chunks, n_items, k):
     """`world` processes share the GPU (gloo + host-staged exchanges); exchanges in 2 / 4 chunks; K = 128: the streamed local reduction
