@@ -103,7 +103,7 @@ class DmfArgs(C.Structure):
                                           'gptr_u', 'gptr_i', 'grows_u', 'grows_i')] + [('n_du', C.c_int32), ('n_di', C.c_int32)] + \
                [(n, C.c_void_p) for n in ('map_u', 'map_i', 'rho_u', 'rho_i')] + [('stamp', C.c_uint32)] + \
                [(n, C.c_void_p) for n in ('nd_dev', 'y_mean_dev', 'work_order')] + [('n_work', C.c_int32), ('seg_len', C.c_int32)] + \
-               [(n, C.c_void_p) for n in ('zseg', 'zpart')]
+               [(n, C.c_void_p) for n in ('zseg', 'zpart', 'n_work_dev')]
 
 
 class DmfK0Update(C.Structure):
@@ -234,6 +234,8 @@ SIGNATURES = {
     'drx_rows_csr_adam_outer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'drx_dmf_work_order_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     'drx_dmf_work_order': (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                        C.POINTER(C.c_int32)]),
     'drx_batch_distinct': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -290,8 +290,9 @@ __global__ __launch_bounds__(64 * WV) void k_dmf_gather(DrxDmfDims D, DrxDmfArgs
   TowerIO Ti{A.K0i, D.ld0[1], A.i_indptr, A.i_indices, A.i_values, A.iid, A.off_i, A.dz0i, A.tkeys_i, A.tsrc_i, A.tcoef_i};
   Tu.rho = A.rho_u; Ti.rho = A.rho_i;
   const int n_du = A.nd_dev ? A.nd_dev[0] : A.n_du;
-  const bool listed = A.work_order && !A.nd_dev;     // (longest rows first, long ones in segments: include/drx.h DrxDmfArgs::work_order)
-  const int total = listed ? A.n_work : n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
+  // (longest rows first, long ones in segments: include/drx.h DrxDmfArgs::work_order; a device-prepared batch brings a list built there)
+  const bool listed = A.work_order && (!A.nd_dev || A.n_work_dev);
+  const int total = listed ? (A.n_work_dev ? A.n_work_dev[0] : A.n_work) : n_du + (A.nd_dev ? A.nd_dev[1] : A.n_di);
   for (int it0 = blockIdx.x; it0 < total; it0 += gridDim.x) {
     const int enc = listed ? A.work_order[it0] : it0;
     const int it = enc & 0xFFFFFF, seg = listed ? (int)((unsigned)enc >> 24) : 0, seg_len = listed ? A.seg_len : 0;
@@ -600,8 +601,8 @@ __global__ __launch_bounds__(256) void k_dmf_dense(DrxDmfDims D, DrxDmfArgs A) {
       pu[h] = Wk.z0[((size_t)0 * A.B + A.inv_u[b]) * W + k + 64 * h];
       pi[h] = Wk.z0[((size_t)1 * A.B + A.inv_i[b]) * W + k + 64 * h];
     }
-    if (A.zseg && A.work_order && !A.nd_dev) {       // long rows / columns gathered in segments: their partial rows, in segment order
-      const int zu_ = A.zseg[A.inv_u[b]], zi_ = A.zseg[A.n_du + A.inv_i[b]];
+    if (A.zseg && A.work_order && (!A.nd_dev || A.n_work_dev)) {       // long rows / columns gathered in segments: their partial rows, in segment order
+      const int zu_ = A.zseg[A.inv_u[b]], zi_ = A.zseg[(A.nd_dev ? A.nd_dev[0] : A.n_du) + A.inv_i[b]];
       for (int g = 0; g < (zu_ & 255); ++g)
 #pragma unroll
         for (int h = 0; h < NU; ++h) pu[h] += A.zpart[((size_t)(zu_ >> 8) + g) * W + k + 64 * h];
@@ -696,8 +697,8 @@ __global__ __launch_bounds__(256) void k_dmf_dense_tile(DrxDmfDims D, DrxDmfArgs
       float4 z = f4_zero();
       if (b < A.B) {
         z = *reinterpret_cast<const float4 *>(Wk.z0 + ((size_t)tw * A.B + inv[b]) * W + c4);
-        if (A.zseg && A.work_order && !A.nd_dev) {     // a long row / column gathered in segments: its partial rows, in segment order
-          const int zs = A.zseg[(tw ? A.n_du : 0) + inv[b]];
+        if (A.zseg && A.work_order && (!A.nd_dev || A.n_work_dev)) {     // a long row / column gathered in segments: its partial rows, in segment order
+          const int zs = A.zseg[(tw ? (A.nd_dev ? A.nd_dev[0] : A.n_du) : 0) + inv[b]];
           for (int g = 0; g < (zs & 255); ++g) f4_add(z, *reinterpret_cast<const float4 *>(A.zpart + ((size_t)(zs >> 8) + g) * W + c4));
         }
       }
@@ -1065,6 +1066,70 @@ int drx_dmf_batch_distinct_device(const int32_t *uid, const int32_t *iid, const 
 }
 
 
+// drx_dmf_work_order on the device: ONE workgroup; a distinct id's entries (its segments) are consecutive, the classes — bit length of
+// the degree, descending — are filled through LDS counters (the order inside a class does not matter: a work item writes its own row)
+static __global__ __launch_bounds__(1024) void k_dmf_work_order(const int64_t *__restrict__ u_indptr, const int64_t *__restrict__ i_indptr,
+                                                                const int32_t *__restrict__ du, const int32_t *__restrict__ di,
+                                                                const int32_t *__restrict__ nd, int seg_len, int32_t *__restrict__ order,
+                                                                int order_cap, int32_t *__restrict__ zseg, int32_t *__restrict__ out2) {
+  __shared__ int count[33], start[33], parts, entries;
+  if (threadIdx.x < 33) count[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { parts = 0; entries = 0; }
+  __syncthreads();
+  const int n_u = nd[0], n = n_u + nd[1];
+  auto degree = [&](int i) {
+    const int id = i < n_u ? du[i] : di[i - n_u];
+    const int64_t *ip = i < n_u ? u_indptr : i_indptr;
+    return (int)(ip[id + 1] - ip[id]);
+  };
+  auto cls = [](int d) { return d <= 0 ? 0 : 32 - __clz(d); };
+  auto segs = [seg_len](int d) { const int ns = seg_len > 0 && d > seg_len ? (d + seg_len - 1) / seg_len : 1; return ns > 255 ? 255 : ns; };
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int d = degree(i), ns = segs(d);
+    atomicAdd(&count[cls(d)], ns);
+    atomicAdd(&entries, ns);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int c = 32; c >= 0; --c) { start[c] = run; run += count[c]; }
+  }
+  __syncthreads();
+  const bool fits = entries <= order_cap;               // (the caller's capacity rule guarantees it; if not: uncut, one entry per id)
+  if (!fits) {
+    __syncthreads();
+    if (threadIdx.x < 33) count[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&count[cls(degree(i))], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int run = 0;
+      for (int c = 32; c >= 0; --c) { start[c] = run; run += count[c]; }
+      entries = n;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int d = degree(i), ns = fits ? segs(d) : 1;
+    const int at = atomicAdd(&start[cls(d)], ns);
+    for (int g = 0; g < ns; ++g) order[at + g] = i | (g << 24);
+    int z = 0;
+    if (ns > 1) z = (atomicAdd(&parts, ns - 1) << 8) | (ns - 1);
+    zseg[i] = z;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { out2[0] = entries; out2[1] = parts; }
+}
+
+int drx_dmf_work_order_device(const int64_t *u_indptr, const int64_t *i_indptr, const int32_t *du, const int32_t *di, const int32_t *nd_dev,
+                              int32_t seg_len, int32_t *order, int32_t order_cap, int32_t *zseg, int32_t *out2, void *stream) {
+  if (!u_indptr || !i_indptr || !du || !di || !nd_dev || !order || !zseg || !out2 || seg_len < 0 || order_cap < 1) return DRX_EINVAL;
+  hipLaunchKernelGGL(k_dmf_work_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, u_indptr, i_indptr, du, di, nd_dev, seg_len, order,
+                     order_cap, zseg, out2);
+  DRX_LAUNCH_CHECK();
+  return DRX_OK;
+}
+
 // number of batch chunks of k_dmf_wgrad = rows of gsw_part / entries of loss_part the caller provides
 // (16 samples per chunk up to 256 chunks: a thread of k_dmf_wgrad walks its chunk serially, two strided loads per sample — 64-sample
 // chunks made that walk 25 us of a 130 us step)
@@ -1100,7 +1165,7 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   if (A->target_mode == 1 && A->nd_dev && !A->y_mean_dev) return DRX_EINVAL;      // a device-prepared batch knows its mean only there
   const int wv = dmf_waves(A->n_du + A->n_di);
   const int items = A->n_du + A->n_di;
-  const bool listed = A->work_order && !A->nd_dev;
+  const bool listed = A->work_order && (!A->nd_dev || A->n_work_dev);
   if (listed && (A->n_work < items || A->seg_len < 0 || (A->seg_len > 0 && (!A->zseg || !A->zpart)))) return DRX_EINVAL;
   const int gitems = listed ? A->n_work : items;            // (long rows / columns cut into segments: more work items than ids)
   const int ggrid = gitems < 8192 ? gitems : 8192;

@@ -649,6 +649,9 @@ typedef struct DrxDmfArgs {
   int32_t n_work, seg_len;
   const int32_t *zseg;
   float *zpart;
+  /* the list built on the DEVICE (drx_dmf_work_order_device, for batches prepared there: nd_dev set): n_work_dev[0] = its entries —
+   * n_work above is then the list's CAPACITY and sizes the launch; NULL: a host-built list (ignored with nd_dev), or none */
+  const int32_t *n_work_dev;
 } DrxDmfArgs;
 /* Host helper for DrxDmfArgs::work_order / zseg: the gather's work items (distinct users 0 .. n_u - 1 with off_u[i + 1] - off_u[i]
  * non-zeros, then distinct items), ordered by the bit length of their degree, descending, stable inside a class — O(n) — and cut into
@@ -657,6 +660,12 @@ typedef struct DrxDmfArgs {
  * then), DRX_EINVAL when a row would need more than 255 segments; *n_part = partial rows. */
 int32_t drx_dmf_work_order(const int32_t *off_u, int32_t n_u, const int32_t *off_i, int32_t n_i, int32_t seg_len, int32_t *order,
                            int32_t order_cap, int32_t *zseg, int32_t *n_part);
+/* The same list for a batch whose distinct ids live on the device (drx_dmf_batch_distinct_device: du / di, nd_dev = {n_du, n_di}): degrees
+ * from the interaction matrix's two index pointers, one workgroup, classes by bit length of the degree (descending; inside a class in no
+ * particular order: a work item writes its own row, the result does not depend on the order).  out2 = {entries, partial rows}.  The
+ * caller guarantees that the entries fit: order_cap >= 2 B + 2 nnz / seg_len (every distinct id brings its own row or column once). */
+int drx_dmf_work_order_device(const int64_t *u_indptr, const int64_t *i_indptr, const int32_t *du, const int32_t *di, const int32_t *nd_dev,
+                              int32_t seg_len, int32_t *order, int32_t order_cap, int32_t *zseg, int32_t *out2, void *stream);
 /* Host helper for the arrays above: the distinct ids of a batch, ascending.  distinct [<= B], inv [B], gptr [<= B+1], grows [B],
  * off [<= B+1] (prefix sums of indptr row lengths of the distinct ids; NULL to skip) are host arrays;
  * scratch = int32 [n_rows], all -1 on entry and again on return (the caller keeps it between steps).  Returns the number of distinct

@@ -357,10 +357,13 @@ def test_distinct_ids_on_the_device_equal_the_host_helper(B, U, N):
     assert abs(float(dev['y_mean'].item()) - float(y.astype(np.float64).mean())) < 1e-6
 
 
+@pytest.mark.parametrize('seg_len', [None, 8])
 @pytest.mark.parametrize('modified', [False, True])
-def test_a_step_on_a_device_prepared_batch_equals_the_host_prepared_one(modified):
+def test_a_step_on_a_device_prepared_batch_equals_the_host_prepared_one(modified, seg_len):
     """The same triples through prepare_batch (host arrays, one upload) and through prepare_batch_device (the distinct counts and the
-    batch mean stay on the device: DrxDmfArgs.nd_dev / y_mean_dev): identical parameters after three steps, bit for bit."""
+    batch mean stay on the device: DrxDmfArgs.nd_dev / y_mean_dev): identical parameters after three steps, bit for bit.
+    seg_len = 8: rows and columns longer than 8 non-zeros are gathered in segments — the work list with its partial rows built by
+    drx_dmf_work_order on the host and by drx_dmf_work_order_device on the device (the lists differ in order, the sums do not)."""
     import torch
     from drecpy_amd.engine_dmf import DmfEngine
     from drecpy_amd.Recommender import Variable
@@ -376,6 +379,9 @@ def test_a_step_on_a_device_prepared_batch_equals_the_host_prepared_one(modified
             e.bind_prediction_scale(Variable([1.0]), broadcast_targets=True)
         e.set_params(p)
         e.lr, e.reg = 2e-3, 1e-3
+        if seg_len is not None:
+            e._seg_len = seg_len
+            assert e._device_seg_len() == seg_len
         engs.append(e)
     for step in range(3):
         u = rng.integers(0, U, size=B).astype(np.int32)
@@ -384,6 +390,9 @@ def test_a_step_on_a_device_prepared_batch_equals_the_host_prepared_one(modified
         la = engs[0].step(step, u, i, y, want_loss=True)
         lb = engs[1].step(step, engs[1].prepare_batch_device(B, 0, 0, triples=[torch.as_tensor(a).cuda() for a in (u, i, y)]), want_loss=True)
         assert la == lb, (step, la, lb)
+    if seg_len is not None:                          # (the device list really held segments)
+        nw = next(iter(engs[1]._dev_ring.values()))['nw'].cpu().numpy()
+        assert nw[1] > 0 and nw[0] > nw[1]
     ga, gb = engs[0].get_params(), engs[1].get_params()
     for k in ga:
         assert np.array_equal(ga[k], gb[k]), k
