@@ -416,6 +416,72 @@ __global__ __launch_bounds__(kBlock) void k_list_sample(DrxListGroups G, int B, 
   }
 }
 
+// The same draws with SIXTEEN LANES per window (r06): a window's negatives are independent until two of them collide, so lane l forms the
+// first candidate of negatives l, l + 16, ... side by side (hash, complement search: the thread-per-window kernel's chain of ~10
+// dependent loads per negative, nine negatives deep, was 36 us for 4096 windows); the candidates are then confirmed IN ORDER — negative i
+// keeps the first attempt a = 0, 1, ... whose id none of the negatives before it took, exactly the rule above, so the two kernels return
+// the same windows — through group-wide comparisons in registers.  Up to 64 negatives per window (4 per lane).
+constexpr int kListMaxPerLane = 4;
+__global__ __launch_bounds__(kBlock) void k_list_sample16(DrxListGroups G, int B, int L, int T, int neg, uint64_t seed,
+                                                          int32_t *__restrict__ grp, int32_t *__restrict__ before, int32_t *after) {
+  const int l = threadIdx.x & 15, gbase = threadIdx.x & 48;          // lane in the window's group, the group's first lane in the wave
+  const int d_raw = (blockIdx.x * kBlock + threadIdx.x) >> 4;
+  const bool live = d_raw < B;
+  const int d = live ? d_raw : B - 1;                                 // (idle groups shadow the last window and write nothing)
+  const int g = G.eligible[scale_u32(hash_u32(seed, (uint32_t)d, 0u), (uint32_t)G.n_eligible)];
+  const int64_t r0 = G.indptr[g];
+  const int n_rows = (int)(G.indptr[g + 1] - r0);
+  const int start = (int)scale_u32(hash_u32(seed, (uint32_t)d, 1u), (uint32_t)(n_rows - L - T + 1));
+  const int Tp = T * (1 + neg), n_neg = T * neg;
+  int32_t *const out = after + (size_t)d * Tp;
+  if (live) {
+    if (l == 0) grp[d] = G.group_value[g];
+    for (int t = l; t < L; t += 16) before[(size_t)d * L + t] = G.seq_ids[r0 + start + t];
+    for (int t = l; t < T; t += 16) out[t] = G.seq_ids[r0 + start + L + t];
+  }
+  const int64_t h0 = G.held_indptr[g];
+  const int nh = (int)(G.held_indptr[g + 1] - h0);
+  const uint32_t n_pop = (uint32_t)(G.n_ids - nh);
+  int32_t fin[kListMaxPerLane];
+#pragma unroll
+  for (int c = 0; c < kListMaxPerLane; ++c) fin[c] = -1;
+  for (int c = 0; c * 16 < n_neg; ++c) {
+    const int i = c * 16 + l;
+    int a = 0;
+    uint32_t j = 0;
+    int32_t id = -1;
+    if (i < n_neg) {
+      j = scale_u32(hash_u32(seed, (uint32_t)d, (uint32_t)(2 + 16 * i)), n_pop);
+      id = complement_at(G.held + h0, nh, j);
+    }
+    for (int k = 0; k < 16; ++k) {                                    // confirm the chunk's negatives in order
+      bool need = c * 16 + k < n_neg;                                 // (uniform in the group; groups of one wave may differ)
+      while (__any(need)) {
+        const int32_t idk = __shfl(id, k, 16);
+        bool mine = false;
+        if (need) {
+#pragma unroll
+          for (int q = 0; q < kListMaxPerLane; ++q) mine |= fin[q] == idk;      // (fin holds confirmed ids only: all of them came before)
+        }
+        const unsigned long long b = __ballot(mine);
+        const bool dup = ((b >> gbase) & 0xFFFFull) != 0;
+        if (need && !dup) need = false;
+        else if (need && l == k) {                                    // taken: the next attempt of this negative
+          ++a;
+          if (a < 16) j = scale_u32(hash_u32(seed, (uint32_t)d, (uint32_t)(2 + 16 * i + a)), n_pop);
+          else j = j + 1 == n_pop ? 0u : j + 1;                       // (sixteen collisions in a row: walk the complement)
+          id = complement_at(G.held + h0, nh, j);
+        }
+      }
+      if (l == k && i < n_neg) {
+#pragma unroll
+        for (int q = 0; q < kListMaxPerLane; ++q) if (q == c) fin[q] = id;
+        if (live) out[T + i] = id;
+      }
+    }
+  }
+}
+
 }  // namespace drx
 
 extern "C" int drx_list_sample_device(const DrxListGroups *g, int32_t B, int32_t n_inputs, int32_t n_targets, int32_t neg_ratio,
@@ -424,8 +490,12 @@ extern "C" int drx_list_sample_device(const DrxListGroups *g, int32_t B, int32_t
   if (!g || !g->indptr || !g->seq_ids || !g->held_indptr || !g->held || !g->group_value || !g->eligible || g->n_eligible < 1 ||
       g->n_ids < 1 || B < 1 || n_inputs < 1 || n_targets < 1 || neg_ratio < 0 || !group_out || !before || !after)
     return DRX_EINVAL;
-  hipLaunchKernelGGL(k_list_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, *g, B, n_inputs, n_targets,
-                     neg_ratio, seed, group_out, before, after);
+  if (n_targets * neg_ratio <= 16 * kListMaxPerLane && kBlock % 64 == 0)
+    hipLaunchKernelGGL(k_list_sample16, dim3((B * 16 + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, *g, B, n_inputs,
+                       n_targets, neg_ratio, seed, group_out, before, after);
+  else
+    hipLaunchKernelGGL(k_list_sample, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, *g, B, n_inputs, n_targets,
+                       neg_ratio, seed, group_out, before, after);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }
