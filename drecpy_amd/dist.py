@@ -479,14 +479,33 @@ class ShardedCdae:
         """The whole model on every rank (reference orientation: W [N,K], W_ [K,N], V [U,K], b [K], b_ [N]) — for evaluation or
         export after training; an infrequent host-side gather, not part of a step."""
         mine = self.ops.get_params()
+        N = self.n_items
         if self.world == 1:
-            parts = [mine]
-        else:
+            return {'W': mine['W'][:N], 'W_': mine['W_'][:, :N], 'V': mine['V'], 'b': mine['b'], 'b_': mine['b_'][:N]}
+        if not all(isinstance(mine[k], np.ndarray) for k in ('W', 'W_', 'V', 'b_')):          # (test doubles with other containers)
             parts = [None] * self.world
             dist.all_gather_object(parts, mine, group=self.group)
-        N = self.n_items
-        return {'W': np.concatenate([p['W'] for p in parts], axis=0)[:N], 'W_': np.concatenate([p['W_'] for p in parts], axis=1)[:, :N],
-                'V': np.concatenate([p['V'] for p in parts], axis=0), 'b': parts[0]['b'], 'b_': np.concatenate([p['b_'] for p in parts])[:N]}
+            return {'W': np.concatenate([p['W'] for p in parts], axis=0)[:N], 'W_': np.concatenate([p['W_'] for p in parts], axis=1)[:, :N],
+                    'V': np.concatenate([p['V'] for p in parts], axis=0), 'b': parts[0]['b'], 'b_': np.concatenate([p['b_'] for p in parts])[:N]}
+        # tensors, not pickled objects: at BASELINE configuration 4 a rank's V shard alone is 640 MB (all_gather_object would serialise it,
+        # pad every rank's blob to the largest and keep both copies).  Shards enter with their sharded axis first, padded to the largest
+        # shard (user ranges differ by one row when world does not divide U; item tables are ipr rows on every rank).
+        W = self.world
+        dev = torch.device(self.engine.device) if (self.engine is not None and dist.get_backend(self.group) == 'nccl') else torch.device('cpu')
+        rows = {'W': [self.ipr] * W, 'W_': [self.ipr] * W, 'b_': [self.ipr] * W,
+                'V': [self.n_users_total * (r + 1) // W - self.n_users_total * r // W for r in range(W)]}
+        out = {'b': mine['b']}
+        for name in ('W', 'W_', 'V', 'b_'):
+            a = np.ascontiguousarray(mine[name].T if name == 'W_' else mine[name])
+            n_max = max(rows[name])
+            t = torch.zeros((n_max,) + a.shape[1:], dtype=torch.as_tensor(a[:0]).dtype, device=dev)
+            t[:a.shape[0]].copy_(torch.as_tensor(a))
+            parts = [torch.empty_like(t) for _ in range(W)]
+            dist.all_gather(parts, t, group=self.group)
+            full = torch.cat([p[:rows[name][r]] for r, p in enumerate(parts)], dim=0).cpu().numpy()
+            out[name] = full.T if name == 'W_' else full
+        out['W'], out['W_'], out['b_'] = out['W'][:N], out['W_'][:, :N], out['b_'][:N]
+        return out
 
     # ---- exchanges ---------------------------------------------------------------------------------------
     def _a2a(self, send, send_counts, recv_counts, out=None, overlap=False):

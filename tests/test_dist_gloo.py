@@ -73,7 +73,9 @@ def _worker(rank, world, rdzv, out, pipelined=False, micro=1, bypass=True, chunk
         for s in range(STEPS):
             losses.append(m.step(s, batch_of(s), want_loss=True))
     got = ops.get_params()
-    torch.save({'params': {k: np.asarray(v) for k, v in got.items()}, 'losses': losses}, f'{out}.{rank}')
+    full = m.gather_params_global()                     # every rank the whole model (tensor all-gathers of the padded shards)
+    torch.save({'params': {k: np.asarray(v) for k, v in got.items()}, 'losses': losses, 'full': {k: np.asarray(v) for k, v in full.items()}},
+               f'{out}.{rank}')
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,6 +129,10 @@ def test_sharded_step_equals_single_process_oracle(tmp_path, pipelined, micro, w
         np.testing.assert_allclose(g['V'], p['V'][ulo:uhi], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g['b'], p['b'], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(res[r]['losses'], want_losses, rtol=1e-9)
+        full = res[r]['full']                           # gather_params_global: the reference-orientation model, identical on every rank
+        assert full['W'].shape == p['W'].shape and full['W_'].shape == p['W_'].shape and full['V'].shape == p['V'].shape
+        for k in ('W', 'W_', 'V', 'b', 'b_'):
+            np.testing.assert_allclose(full[k], p[k], rtol=1e-9, atol=1e-12, err_msg=f'gathered {k}')
 
 
 # ---- column-sharded layout (dist.ColumnShardedCdae) over gloo on CPU -------------------------------------------------------------
