@@ -1023,10 +1023,27 @@ class ColumnShardedCdae:
         mine = self.get_params()
         if not self.collectives:
             return mine
-        parts = [None] * self.world
-        dist.all_gather_object(parts, mine, group=self.group)
-        return {'W': np.concatenate([p['W'] for p in parts], axis=1), 'W_': np.concatenate([p['W_'] for p in parts], axis=0),
-                'V': np.concatenate([p['V'] for p in parts], axis=1), 'b': np.concatenate([p['b'] for p in parts]), 'b_': parts[0]['b_']}
+        if not all(isinstance(mine[k], np.ndarray) for k in ('W', 'W_', 'V', 'b')) or not hasattr(self, 'k_hi'):
+            parts = [None] * self.world
+            dist.all_gather_object(parts, mine, group=self.group)
+            return {'W': np.concatenate([p['W'] for p in parts], axis=1), 'W_': np.concatenate([p['W_'] for p in parts], axis=0),
+                    'V': np.concatenate([p['V'] for p in parts], axis=1), 'b': np.concatenate([p['b'] for p in parts]), 'b_': parts[0]['b_']}
+        # tensors, not pickled objects (a rank's column slice of V is 640 MB at BASELINE configuration 4): the column axis first, padded
+        # to the widest slice (the last rank's may be narrower)
+        Wd = self.world
+        kpr = -(-self.k // Wd)
+        cols = [min(self.k, (r + 1) * kpr) - min(self.k, r * kpr) for r in range(Wd)]
+        dev = torch.device(self.engine.device) if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+        out = {'b_': mine['b_']}
+        for name in ('W', 'W_', 'V', 'b'):
+            a = np.ascontiguousarray(mine[name].T if name in ('W', 'V') else mine[name])        # [columns, ...]
+            t = torch.zeros((max(cols),) + a.shape[1:], dtype=torch.as_tensor(a[:0]).dtype, device=dev)
+            t[:a.shape[0]].copy_(torch.as_tensor(a))
+            parts = [torch.empty_like(t) for _ in range(Wd)]
+            dist.all_gather(parts, t, group=self.group)
+            full = torch.cat([p[:cols[r]] for r, p in enumerate(parts)], dim=0).cpu().numpy()
+            out[name] = np.ascontiguousarray(full.T) if name in ('W', 'V') else full
+        return out
 
     def step(self, step, bt, prepared=None, events=None, want_loss=False):
         e = self.engine
