@@ -292,9 +292,12 @@ def _caser_frame():
     return {k: v.copy() for k, v in load_frames()['ls_int_ts'].items()}
 
 
-@pytest.mark.parametrize('L,T,neg,n,seed', [(5, 3, 3, 600, 12345), (2, 1, 6, 257, 7), (3, 2, 0, 64, 99)])
+@pytest.mark.parametrize('L,T,neg,n,seed', [(5, 3, 3, 600, 12345), (2, 1, 6, 257, 7), (3, 2, 0, 64, 99),
+                                            (2, 2, 12, 300, 5), (2, 1, 40, 130, 8), (2, 2, 32, 70, 6), (2, 2, 40, 64, 3)])
 def test_device_list_sampler_equals_its_cpu_restatement(L, T, neg, n, seed):
-    """drx_list_sample_device (throughput mode of ListSampler) against oracle/data_oracle.py::list_sample_counter, bit for bit."""
+    """drx_list_sample_device (throughput mode of ListSampler) against oracle/data_oracle.py::list_sample_counter, bit for bit.
+    The kernel with sixteen lanes per window takes up to 64 negatives per window — 9, 6, 0: one chunk of 16; 24, 40, 64: several —, the
+    thread-per-window kernel the rest (80)."""
     from oracle import data_oracle as do
     from drecpy_amd.Dataset import InteractionDataset
     from drecpy_amd.Sampler import ListSampler
