@@ -550,3 +550,51 @@ def test_dmf_of_the_references_consistency_script_fits_and_ranks():
     sc = e.score_matrix_bf16(np.arange(4)).cpu().numpy()
     pr = e.predict(np.repeat(np.arange(4), e.N), np.tile(np.arange(e.N), 4)).cpu().numpy().reshape(4, e.N)
     assert np.max(np.abs(sc - pr)) < 1.5e-2
+
+
+@pytest.mark.parametrize('seg_len', [0, 8, 64])
+def test_the_device_work_list_has_the_host_lists_entries_and_classes(seg_len):
+    """drx_dmf_work_order_device against drx_dmf_work_order: the same entries (work index | segment << 24) as a SET, degree classes
+    (bit length of the degree) non-increasing along the list, every id's segments consecutive and ascending, the partial rows of
+    different ids disjoint and as many as the host counts (inside a class the two lists may differ in order: no result depends on it)."""
+    import ctypes as C
+    import torch
+    from drecpy_amd import _lib
+    L_ = _lib.lib()
+    rng = np.random.default_rng(31 + seg_len)
+    U, N, B = 300, 200, 256
+    csr, csc, _ = _problem(rng, U, N, 9000)
+    du = np.sort(rng.choice(U, size=140, replace=False)).astype(np.int32)
+    di = np.sort(rng.choice(N, size=90, replace=False)).astype(np.int32)
+    ipu, ipi = np.asarray(csr[0], np.int64), np.asarray(csc[0], np.int64)
+    off_u = np.concatenate([[0], np.cumsum(ipu[du + 1] - ipu[du])]).astype(np.int32)
+    off_i = np.concatenate([[0], np.cumsum(ipi[di + 1] - ipi[di])]).astype(np.int32)
+    cap = 2 * B + 4096
+    want, zs_h, n_part = np.zeros(cap, np.int32), np.zeros(len(du) + len(di), np.int32), C.c_int32(0)
+    n_h = L_.drx_dmf_work_order(off_u.ctypes.data, len(du), off_i.ctypes.data, len(di), seg_len, want.ctypes.data, cap, zs_h.ctypes.data, C.byref(n_part))
+    assert n_h >= len(du) + len(di)
+    dev = torch.device('cuda:0')
+    t = lambda a: torch.as_tensor(a).to(dev)
+    d_ipu, d_ipi, d_du, d_di = t(ipu), t(ipi), t(du), t(di)
+    nd = t(np.array([len(du), len(di)], np.int32))
+    order, zseg, out2 = torch.full((cap,), -1, dtype=torch.int32, device=dev), torch.zeros(2 * B, dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev)
+    _lib.check(L_.drx_dmf_work_order_device(d_ipu.data_ptr(), d_ipi.data_ptr(), d_du.data_ptr(), d_di.data_ptr(), nd.data_ptr(), seg_len,
+                                            order.data_ptr(), cap, zseg.data_ptr(), out2.data_ptr(), _lib.stream_ptr(dev)), 'drx_dmf_work_order_device')
+    torch.cuda.synchronize()
+    n_d, parts_d = out2.cpu().numpy().tolist()
+    got, zs_d = order.cpu().numpy()[:n_d], zseg.cpu().numpy()[:len(du) + len(di)]
+    assert n_d == n_h and parts_d == n_part.value and sorted(got.tolist()) == sorted(want[:n_h].tolist())
+    deg = np.concatenate([np.diff(off_u), np.diff(off_i)])
+    cls = np.array([int(d).bit_length() for d in deg])
+    along = cls[got & 0xFFFFFF]
+    assert np.all(np.diff(along) <= 0)                                   # longest classes first
+    for i in np.unique(got & 0xFFFFFF):                                  # an id's segments: consecutive, ascending from 0
+        at = np.flatnonzero((got & 0xFFFFFF) == i)
+        assert np.array_equal(at, np.arange(at[0], at[0] + len(at))) and np.array_equal(got[at] >> 24, np.arange(len(at)))
+        assert (zs_d[i] & 255) == len(at) - 1 == (zs_h[i] & 255)
+    taken = np.zeros(max(1, parts_d), bool)
+    for i in np.flatnonzero(zs_d & 255):
+        lo, n = zs_d[i] >> 8, zs_d[i] & 255
+        assert not taken[lo:lo + n].any()
+        taken[lo:lo + n] = True
+    assert taken.sum() == parts_d
