@@ -95,6 +95,7 @@ def parse(argv=None):
                     'RCCL communicator (csrc/drx_comm.hip: one ncclGroup per exchange, enqueued from C) or torch.distributed')
     ap.add_argument('--no-phases', action='store_true', help='row layout, --transport rccl: issue the exchanges of a step call by call from Python '
                     '(drecpy_amd/dist.py) instead of through the library\'s four phase calls (drx_shard_phase_*: A/B of the host cost)')
+    ap.add_argument('--no-comm-thread', action='store_true', help='row layout at world 1 (DRX_BENCH_RCCL1): the library\'s communicator without its issuing thread')
     ap.add_argument('--micro', type=int, default=1, help='micro-batches per sharded step (exchanges of one overlap the compute of the other); default 1')
     ap.add_argument('--launch-dry-run', action='store_true', help='print the per-rank child command lines of an N-GPU run and exit (no GPU call)')
     ap.add_argument('--launch-selftest', action='store_true', help='children only rendezvous over gloo and all-reduce on the CPU (tests the launcher)')
@@ -745,11 +746,13 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         eng.init_optimizer(args.optimizer, 1e-3 if args.optimizer == 'adam' else LR, REG)
         stepper = None
     else:
-        from drecpy_amd.dist import ShardedCdae
+        from drecpy_amd.dist import RcclTransport, ShardedCdae
+        transport = 'rccl' if (args.transport == 'rccl' and not debug_gloo and (world > 1 or rccl1)) else None
+        if transport and args.no_comm_thread and world == 1:        # (A/B at world 1: the nccl* calls made by the posting thread itself)
+            transport = RcclTransport(1, 0, dev, threaded=False)
         stepper = ShardedCdae(U, N, K, rank, world, dev, indptr, indices, seed=10, lr=LR, reg=REG, q=Q,
                               cpu_staging=debug_gloo, force_collectives=rccl1, self_bypass=not args.no_self_bypass, chunks=args.chunks,
-                              transport='rccl' if (args.transport == 'rccl' and not debug_gloo and (world > 1 or rccl1)) else None,
-                              phases=False if args.no_phases else None)
+                              transport=transport, phases=False if args.no_phases else None)
         eng = stepper.engine
 
     micro = max(1, args.micro)       # > 1: micro-batches whose exchanges overlap each other's compute (measured at world 1: the split costs more than it hides)
@@ -828,7 +831,8 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         if fresh_sharded:      # a new device-sampled batch of this rank's users every step, drawn ahead on its own stream
             from drecpy_amd.engine import DeviceBatchSource
             source = DeviceBatchSource(eng, B, NEG_RATIO, Q, lambda s: 5000 + 7919 * s + 104729 * rank,
-                                       lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N)
+                                       lambda s: 5000 + 7919 * s + 104729 * rank, n_items=N,
+                                       stream_slot=0)         # (the pipeline's own run-ahead stream: a rank's streams share four hardware queues)
         else:
             source = lambda s: structs[s % len(structs)][0]
         pipe = ShardedPipeline(stepper, source, total_steps)

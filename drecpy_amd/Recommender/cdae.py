@@ -275,7 +275,7 @@ class CDAE(RecommenderABC):
                     from ..engine import DeviceBatchSource
                     rs = self.row_seeds(ms, dm.rank, dm.world, first)
                     src = DeviceBatchSource(dm.engine, batch_size, self._sampler.neg_ratio, self.corruption_level, rs[0], rs[1],
-                                            n_items=self.n_items)
+                                            n_items=self.n_items, stream_slot=0)      # (the pipeline's own run-ahead stream: engine.DeviceBatchSource)
                     pipe = self._pipeline = ShardedPipeline(dm, src, max(1, self._fit_epochs - first))
                     pipe.B = batch_size
                 elif dm is not None:                                     # the same seeds on every rank: the same batches
