@@ -1149,5 +1149,8 @@ class ColumnShardedCdae:
                                                                                                          want_loss=want_loss),
                                prepare_fn={'local': None, 'turns': self.build_in_turns, 'parts': self.prepare}[self.prepare_mode],
                                deliver_fn=self.deliver_in_turns if self.prepare_mode == 'turns' else None,
-                               prep_ahead=self.TURNS_AHEAD if self.prepare_mode == 'turns' else 1)
+                               prep_ahead=self.TURNS_AHEAD if self.prepare_mode == 'turns' else 1,
+                               # a rank's streams share four hardware queues (engine._run_ahead_slot): training, torch.distributed's own,
+                               # and two more — two run-ahead streams, or one and the deliveries' stream
+                               side_streams=1 if self.prepare_mode == 'turns' else 2)
 
