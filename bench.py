@@ -978,6 +978,13 @@ def run_direct(args, rank, world, dev, dist, debug_gloo=False, rccl1=False):
         'host_issue_ms_per_step': ([round(1e3 * t / total_steps, 4) for t in pipe.host_s + [stepper.wait_s]] if pipe is not None else None),
     }
     out.update(win.fields(world * B))
+    if stepper is None and len(ph) >= 4:
+        # (i) end to end incl. the sampler = `value` (a fresh batch is drawn and prepared on the device for every step, beside
+        # the training kernels); (ii) the training launches alone, HIP events around each of them on the timed steps that carry events
+        kern_ms = float(ph[0]) + float(ph[2]) + float(ph[3])
+        out['device_only'] = {'ms_per_step': kern_ms, 'value': world * B / (kern_ms * 1e-3),
+                              'what': 'sum of the three training launches between their HIP events (forward, reduction, spans) on the timed '
+                                      'steps: the step without the launch gaps; the draw and the preparation of later batches run beside them'}
     ms_of = {'k_sampled_fwd_bwd': float(ph[0]), 'k_seg_reduce': float(ph[2])} if stepper is None else {}
     if dedup is not None and stepper is not None:
         # row layout at world 1: strictly necessary HBM bytes of its three big kernels from the same exact row counts —
