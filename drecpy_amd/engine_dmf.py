@@ -256,6 +256,9 @@ class DmfEngine:
         self._vstd = (float(vmin), float(vrange))
         self._dev_ring, self._dev_i = {}, 0
 
+    # host-prepared batches: the argument structs of a step cached per slot of the upload ring (False: built anew every step — A/B, tests)
+    host_step_cache = True
+
     # device-prepared batches: the gather's work list (longest rows first, long ones cut into segments) built on the device too — False:
     # one work item per distinct id in their own order, as through r05 (52.6 against 28 us for the gather at B = 4096)
     device_work_order = True
@@ -327,7 +330,7 @@ class DmfEngine:
     def _upload_batch(self, prepared):
         """Host batch -> device in one asynchronous copy from a pinned ring (so the host can run ahead of the device); returns the
         device buffer and the addresses of the arrays in it."""
-        st = self.__dict__.setdefault('_stage', {'i': 0, 'host': [None] * 4, 'ev': [None] * 4})
+        st = self.__dict__.setdefault('_stage', {'i': 0, 'host': [None] * 4, 'ev': [None] * 4, 'dev': [None] * 4, 'cache': [None] * 4})
         buf = prepared['buf']
         total = buf.nbytes
         k = st['i'] % 4
@@ -335,13 +338,18 @@ class DmfEngine:
         if st['host'][k] is None or st['host'][k].numel() < total:
             st['host'][k] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8, pin_memory=True)
             st['ev'][k] = torch.cuda.Event()
+            # the device side of the slot is kept too (r06): steps run in order on one stream, so a copy into it is queued behind the
+            # step that last read it — and a slot's addresses stay the same from visit to visit (the step's argument structs are cached)
+            st['dev'][k] = torch.empty(st['host'][k].numel(), dtype=torch.uint8, device=self.device)
+            st['cache'][k] = None
         else:
             st['ev'][k].synchronize()                 # the copy that last read this pinned slot has finished
         st['host'][k].numpy()[:total] = buf
-        dev = torch.empty(total, dtype=torch.uint8, device=self.device)
-        dev.copy_(st['host'][k][:total], non_blocking=True)
+        dev = st['dev'][k]
+        dev[:total].copy_(st['host'][k][:total], non_blocking=True)
         st['ev'][k].record(torch.cuda.current_stream(self.device))
         base = dev.data_ptr()
+        prepared['stage_slot'] = k
         return dev, [base + o for o in prepared['offs']]
 
     def step(self, step_idx, uids, iids=None, y=None, want_loss=False, applies=None):
@@ -375,6 +383,19 @@ class DmfEngine:
             n_du = n_di = B                 # upper bounds: they size the launches; the kernels read nd_dev
         else:
             alive, ptrs = self._upload_batch(prep)
+            if not want_loss and self.first_layer_update == 'scan' and self.host_step_cache:
+                c = self._stage['cache'][prep['stage_slot']]
+                if applies is None:
+                    applies = (3, 1, 2, 0) if self.scale_var is not None else (2, 0, 1, None)
+                if c is not None and c['B'] == prep['B'] and c['base'] == alive.data_ptr() and c['applies'] == tuple(applies) \
+                        and c['key'] == self._step_cache_key():
+                    A = c['A']                              # the slot's struct with this batch's scalars
+                    A.n_du, A.n_di, A.n_work, A.seg_len = prep['n_du'], prep['n_di'], prep['n_work'], prep['seg_len']
+                    if A.target_mode == 1:
+                        A.y_mean = prep['y_mean']
+                    self._launch_cached(L_, c, step_idx, tuple(applies))
+                    return None
+                self._stage['cache_wanted'] = (prep['stage_slot'], alive.data_ptr())
             p_du, p_di, p_y, p_offu, p_offi, p_invu, p_invi, p_gpu, p_gpi, p_gru, p_gri, p_order, p_zseg = ptrs
             B, Tu, Ti = prep['B'], prep['Tu'], prep['Ti']
             n_du, n_di = prep['n_du'], prep['n_di']
@@ -468,6 +489,13 @@ class DmfEngine:
         m, v = self.state['sw']
         check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), self.beta1, self.beta2, self.eps,
                                    stream), 'drx_adam_segments')
+        wanted_host = None if on_device else self.__dict__.get('_stage', {}).pop('cache_wanted', None)
+        if (not on_device) and scan and wanted_host is not None and not want_loss:
+            sg_tw = [(i, tw) for i, (_, _, _, _, tw) in enumerate(self.seg)] + ([(len(self.seg), 2)] if self.scale_var is not None else [])
+            self._stage['cache'][wanted_host[0]] = {
+                'B': B, 'base': wanted_host[1], 'applies': tuple(applies), 'key': self._step_cache_key(), 'A': A, 'up': up, 'sg': sg, 'gsw': ptr(gsw),
+                'D': C.byref(self.D), 'Aref': C.byref(A), 'upref': C.byref(up), 'sgref': C.byref(sg), 'sg_tw': sg_tw, 'sw': ptr(self.sw),
+                'm': ptr(m), 'v': ptr(v), 'keep': (gsw, gpart, lpart, dz0u, dz0i)}
         if on_device and scan and prep['device'].pop('step_cache_wanted', False):
             sg_tw = [(i, tw) for i, (_, _, _, _, tw) in enumerate(self.seg)] + ([(len(self.seg), 2)] if self.scale_var is not None else [])
             prep['device']['step_cache'] = {
@@ -489,6 +517,11 @@ class DmfEngine:
         if c is None or c['applies'] != applies or c['key'] != self._step_cache_key():
             sl['step_cache_wanted'] = True
             return False
+        self._launch_cached(L_, c, step_idx, applies)
+        return True
+
+    def _launch_cached(self, L_, c, step_idx, applies):
+        """the three library calls of a scan-update step from cached argument structs: stamp and learning rates refreshed"""
         A, up, sg, gsw = c['A'], c['up'], c['sg'], c['gsw']
         stream = stream_ptr(self.device)
         self._stamp += 1
@@ -501,7 +534,6 @@ class DmfEngine:
         for i, tw in c['sg_tw']:
             sg.alpha[i] = alpha[tw]
         check(L_.drx_adam_segments(c['sw'], c['m'], c['v'], gsw, c['sgref'], self.beta1, self.beta2, self.eps, stream), 'drx_adam_segments')
-        return True
 
     def _step_cache_key(self):
         """what a cached argument struct depends on besides its ring slot: the tensors a set_params / set_interactions / optimizer change

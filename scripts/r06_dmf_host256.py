@@ -11,6 +11,8 @@ from drecpy_amd.Recommender import DMF                           # noqa: E402
 ds = InteractionDataset.read_df(bc.frame_of('ml-1m'), verbose=False)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 DMF._prefetch_mode = os.environ.get('DRX_HOST_PREFETCH', 'spin')     # (this script's own switch: the package reads no environment variable)
+from drecpy_amd.engine_dmf import DmfEngine                      # noqa: E402
+DmfEngine.host_step_cache = os.environ.get('DRX_HOST_CACHE', '1') == '1'      # (A/B: the cached argument structs of host-batch steps)
 if os.environ.get('DRX_FORCE_WORKER') == '1':
     DMF._prefetch_from = 0                                       # (A/B: the worker thread at every batch size)
 for si in (5e-3, 5e-3, 5e-3):

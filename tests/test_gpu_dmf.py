@@ -598,3 +598,42 @@ def test_the_device_work_list_has_the_host_lists_entries_and_classes(seg_len):
         assert not taken[lo:lo + n].any()
         taken[lo:lo + n] = True
     assert taken.sum() == parts_d
+
+
+@pytest.mark.parametrize('modified', [False, True])
+def test_the_cached_argument_structs_of_host_batches_change_nothing(modified):
+    """Steps on host-prepared batches reuse the argument structs of the slot of the upload ring they land in (four slots; a slot's device
+    addresses are the same from visit to visit): the same parameters, bit for bit, as with the cache off — over more steps than the ring
+    has slots, with batches of different distinct-id counts, a learning-rate change, and a loss read in between (the general path)."""
+    from drecpy_amd.engine_dmf import DmfEngine
+    from drecpy_amd.Recommender import Variable
+    rng = np.random.default_rng(29)
+    U, N, B = 150, 90, 180
+    csr, csc, _ = _problem(rng, U, N, 2800)
+    p = dm.init_params(rng, U, N, (32, 16), (24, 16), np.float64)
+    engs = []
+    for cached in (True, False):
+        e = DmfEngine(U, N, (32, 16), (24, 16), True)
+        e.set_interactions(csr, csc)
+        if modified:
+            e.bind_prediction_scale(Variable([1.0]), broadcast_targets=True)
+        e.set_params(p)
+        e.lr, e.reg = 2e-3, 1e-3
+        e.host_step_cache = cached
+        e._seg_len = 8                                   # (segments in play: n_work and the partial rows differ from batch to batch)
+        engs.append(e)
+    for step in range(14):
+        hi = U if step % 3 else U // 5                    # some batches with few distinct users
+        u = rng.integers(0, hi, size=B).astype(np.int32)
+        i = rng.integers(0, N // 2, size=B).astype(np.int32)
+        y = rng.random(B).astype(np.float32)
+        if step == 8:
+            for e in engs:
+                e.lr = 5e-3
+        want_loss = step == 10
+        la = [e.step(step, u, i, y, want_loss=want_loss) for e in engs]
+        assert la[0] == la[1]
+    assert sum(c is not None for c in engs[0]._stage['cache']) == 4 and all(c is None for c in engs[1]._stage['cache'])
+    ga, gb = engs[0].get_params(), engs[1].get_params()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
