@@ -222,6 +222,8 @@ SIGNATURES = {
     'drx_dmf_grid': (C.c_int, [C.c_int32]),
     'drx_dmf_work_bytes': (C.c_size_t, [C.c_int32]),
     'drx_dmf_fwd_bwd': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p]),
+    'drx_dmf_step_small': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(AdamSegments), C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'drx_dmf_predict': (C.c_int, [C.POINTER(DmfDims), C.POINTER(DmfArgs), C.c_void_p]),
     'drx_first_occurrence': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'drx_spin_until': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),

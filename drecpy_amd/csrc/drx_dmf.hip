@@ -889,6 +889,38 @@ __global__ __launch_bounds__(1024) void k_sum_partials2(const float *__restrict_
   }
 }
 
+// k_sum_partials2 with the small weights' Keras Adam behind it (as drx_caser.hip's k_sum_partials_adam): the thread that has column j's
+// sum applies l2 + Adam of j's segment — one launch instead of two, the same operations in the same order.
+__global__ __launch_bounds__(1024) void k_sum_partials2_adam(const float *__restrict__ part, int n_rows, int n, const float *__restrict__ tail,
+                                                             float *__restrict__ out, float *p, float *m, float *v, DrxAdamSegments sg,
+                                                             float b1, float b2, float eps) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float a = 0.f;
+  if (j < n) for (int r = q; r < n_rows; r += 16) a += part[(size_t)r * n + j];
+  else if (j == n) for (int r = q; r < n_rows; r += 16) a += tail[r];
+  red[q][c] = a;
+  __syncthreads();
+  if (q == 0 && j <= n) {
+    float t = 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) t += red[qq][c];
+    out[j] = t;
+    if (j < n) {
+      int sgi = -1;
+      for (int k = 0; k < sg.n; ++k)
+        if (j >= sg.start[k] && j < sg.start[k] + sg.len[k]) sgi = k;
+      if (sgi >= 0) {
+        const OptScalars o{DRX_OPT_ADAM, 0.f, 0.f, b1, b2, eps, sg.alpha[sgi]};
+        float pp = p[j], mm = m[j], vv = v[j];
+        opt_update1(o, fmaf(sg.l2_coef[sgi], pp, t), pp, mm, vv);
+        p[j] = pp; m[j] = mm; v[j] = vv;
+      }
+    }
+  }
+}
+
 // ---- bf16 MFMA all-pairs cosine scorer: out[u, n] = max(1e-6, ru[u] . ri[n]) for l2-normalised fp32 rows of width 32 -------
 // v_mfma_f32_32x32x16_bf16 per 32x32 quarter and 16 k (K = 32: two of them).  A = users (row r = lane & 31, k = 8*(lane >> 5) + j),
 // B = items (col r, same k); C/D: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -1140,7 +1172,23 @@ size_t drx_dmf_work_bytes(int32_t B) {
   return ((size_t)2 * B * 128 + (size_t)4 * B * kDmfMaxLayers * 128 + (size_t)2 * B) * 4 + 256;      // (rows of 128: the widest towers)
 }
 
+static int dmf_fwd_bwd_impl(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, float *sw, float *sw_m, float *sw_v,
+                            const DrxAdamSegments *sg, float beta1, float beta2, float eps, void *stream);
+
 int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream) {
+  return dmf_fwd_bwd_impl(D, A, gsw_out, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, stream);
+}
+
+// drx_dmf_fwd_bwd with the small weights' Keras Adam in the launch that sums the chunks' partial gradients (drx_adam_segments' work; the
+// first-layer update — drx_dmf_k0_update — reads none of `sw` and may follow)
+int drx_dmf_step_small(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, float *sw, float *sw_m, float *sw_v,
+                       const DrxAdamSegments *sg, float beta1, float beta2, float eps, void *stream) {
+  if (!sw || !sw_m || !sw_v || !sg || sg->n < 1 || sg->n > DRX_MAX_SEGMENTS || (A && sw != A->sw)) return DRX_EINVAL;
+  return dmf_fwd_bwd_impl(D, A, gsw_out, sw, sw_m, sw_v, sg, beta1, beta2, eps, stream);
+}
+
+static int dmf_fwd_bwd_impl(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, float *sw, float *sw_m, float *sw_v,
+                            const DrxAdamSegments *sg, float beta1, float beta2, float eps, void *stream) {
   int rc = check_dims(D);
   if (rc) return rc;
   if (!A || !A->K0u || !A->K0i || !A->sw || !A->u_indptr || !A->u_indices || !A->u_values || !A->i_indptr || !A->i_indices ||
@@ -1195,8 +1243,12 @@ int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, vo
   }
   hipLaunchKernelGGL(k_dmf_dzsum, dim3((items + 3) / 4 < 2048 ? (items + 3) / 4 : 2048), dim3(256), 0, st, *D, *A, W);
   hipLaunchKernelGGL(k_dmf_wgrad, dim3((D->n_small + 1 + 255) / 256, chunks), dim3(256), 0, st, *D, *A, chunk, W);
-  hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, chunks, D->n_small,
-                     A->loss_part, gsw_out);
+  if (sg)
+    hipLaunchKernelGGL(k_sum_partials2_adam, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, chunks, D->n_small,
+                       A->loss_part, gsw_out, sw, sw_m, sw_v, *sg, beta1, beta2, eps);
+  else
+    hipLaunchKernelGGL(k_sum_partials2, dim3((D->n_small + 64) / 64), dim3(1024), 0, st, A->gsw_part, chunks, D->n_small,
+                       A->loss_part, gsw_out);
   DRX_LAUNCH_CHECK();
   return DRX_OK;
 }

@@ -455,12 +455,25 @@ class DmfEngine:
         if want_loss:
             sq = _lib.sumsq([self.K0u, self.K0i] + [self.sw[start:start + n] for _, start, n, regd, _ in self.seg if regd])
             reg_loss = self.reg * sq
-        check(L_.drx_dmf_fwd_bwd(C.byref(self.D), C.byref(A), ptr(gsw), stream), 'drx_dmf_fwd_bwd')
         if applies is None:
             applies = (3, 1, 2, 0) if self.scale_var is not None else (2, 0, 1, None)
         n_app = applies[0]
         alpha = [CdaeEngine.adam_alpha(self.lr, n_app * step_idx + j + 1, self.beta1, self.beta2) if j is not None else 0.0 for j in applies[1:]]
         l2c = 2.0 * self.reg
+        sg = AdamSegments()
+        sg.n = len(self.seg)
+        for i, (_, start, n, regd, tw) in enumerate(self.seg):
+            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[tw], (l2c if regd else 0.0)
+        if self.scale_var is not None:                     # the registered scalar: its own lr_t, no regulariser
+            i = sg.n
+            sg.n += 1
+            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = self._scale_slot, 1, alpha[2], 0.0
+        m, v = self.state['sw']
+        # forward / backward with the small weights' Keras Adam in the launch that sums their partial gradients (r06: drx_dmf_step_small
+        # — one launch less than drx_dmf_fwd_bwd + drx_adam_segments; gsw still holds the gradient and, last, the loss sum; the
+        # first-layer update below reads none of the small weights)
+        check(L_.drx_dmf_step_small(C.byref(self.D), C.byref(A), ptr(gsw), ptr(self.sw), ptr(m), ptr(v), C.byref(sg), self.beta1, self.beta2,
+                                    self.eps, stream), 'drx_dmf_step_small')
         if scan:
             up = DmfK0Update()
             (mu, vu), (mi, vi) = self.state['K0u'], self.state['K0i']
@@ -478,17 +491,6 @@ class DmfEngine:
                 m, v = self.state[name]
                 check(L_.drx_adam_dense(ptr(p), ptr(m), ptr(v), ptr(self._g[name]), p.numel(), alpha[tw], l2c, self.beta1, self.beta2,
                                         self.eps, stream), 'drx_adam_dense')
-        sg = AdamSegments()
-        sg.n = len(self.seg)
-        for i, (_, start, n, regd, tw) in enumerate(self.seg):
-            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = start, n, alpha[tw], (l2c if regd else 0.0)
-        if self.scale_var is not None:                     # the registered scalar: its own lr_t, no regulariser
-            i = sg.n
-            sg.n += 1
-            sg.start[i], sg.len[i], sg.alpha[i], sg.l2_coef[i] = self._scale_slot, 1, alpha[2], 0.0
-        m, v = self.state['sw']
-        check(L_.drx_adam_segments(ptr(self.sw), ptr(m), ptr(v), ptr(gsw), C.byref(sg), self.beta1, self.beta2, self.eps,
-                                   stream), 'drx_adam_segments')
         wanted_host = None if on_device else self.__dict__.get('_stage', {}).pop('cache_wanted', None)
         if (not on_device) and scan and wanted_host is not None and not want_loss:
             sg_tw = [(i, tw) for i, (_, _, _, _, tw) in enumerate(self.seg)] + ([(len(self.seg), 2)] if self.scale_var is not None else [])
@@ -528,12 +530,14 @@ class DmfEngine:
         A.stamp = self._stamp
         n_app = applies[0]
         alpha = [CdaeEngine.adam_alpha(self.lr, n_app * step_idx + j + 1, self.beta1, self.beta2) if j is not None else 0.0 for j in applies[1:]]
-        check(L_.drx_dmf_fwd_bwd(c['D'], c['Aref'], gsw, stream), 'drx_dmf_fwd_bwd')
-        up.alpha_u, up.alpha_i = alpha[0], alpha[1]
-        check(L_.drx_dmf_k0_update(c['D'], c['Aref'], c['upref'], stream), 'drx_dmf_k0_update')
         for i, tw in c['sg_tw']:
             sg.alpha[i] = alpha[tw]
-        check(L_.drx_adam_segments(c['sw'], c['m'], c['v'], gsw, c['sgref'], self.beta1, self.beta2, self.eps, stream), 'drx_adam_segments')
+        # (the small weights' Adam in the launch that sums their partial gradients: drx_dmf_step_small — one launch less than
+        # drx_dmf_fwd_bwd + drx_adam_segments, the same bits; the first-layer update reads none of them)
+        check(L_.drx_dmf_step_small(c['D'], c['Aref'], gsw, c['sw'], c['m'], c['v'], c['sgref'], self.beta1, self.beta2, self.eps, stream),
+              'drx_dmf_step_small')
+        up.alpha_u, up.alpha_i = alpha[0], alpha[1]
+        check(L_.drx_dmf_k0_update(c['D'], c['Aref'], c['upref'], stream), 'drx_dmf_k0_update')
 
     def _step_cache_key(self):
         """what a cached argument struct depends on besides its ring slot: the tensors a set_params / set_interactions / optimizer change

@@ -688,6 +688,10 @@ size_t drx_dmf_work_bytes(int32_t B);
 /* forward + Keras BCE + backward (dmf.py:88-99 under the tape): dz0 rows + touches for drx_scatter_rows,
  * gsw_out[0..n_small) small-weight gradients, gsw_out[n_small] = prediction loss */
 int drx_dmf_fwd_bwd(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, void *stream);
+/* The same with the small weights' Keras Adam (what drx_adam_segments does with gsw_out afterwards) in the launch that sums the chunks'
+ * partial gradients: one launch less per step (r06; drx_dmf_k0_update reads none of `sw` and may follow). */
+int drx_dmf_step_small(const DrxDmfDims *D, const DrxDmfArgs *A, float *gsw_out, float *sw, float *sw_m, float *sw_v,
+                       const DrxAdamSegments *sg, float beta1, float beta2, float eps, void *stream);
 int drx_dmf_predict(const DrxDmfDims *D, const DrxDmfArgs *A, void *stream);
 /* The update of the first-layer kernels (tf.keras Dense kernels [N, f0] of user_nn / [U, f0] of item_nn, dmf.py:44-60) after
  * drx_dmf_fwd_bwd ran with the id maps: gradient (+ l2_coef * K0, dmf.py:101-103) and dense Keras Adam in one pass over both tables —
