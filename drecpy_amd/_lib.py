@@ -185,6 +185,7 @@ SIGNATURES = {
                                   C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                   C.c_void_p, C.c_void_p]),
     'drx_shard_exchange_sizes': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    'drx_shard_phase_layout': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     'drx_shard_phase_keys': (C.c_int, [C.POINTER(Shard), C.c_void_p, C.POINTER(ShardExchange), C.c_void_p]),
     'drx_shard_phase_rows': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Shard), C.c_void_p, C.POINTER(ShardExchange), C.c_int32, C.c_void_p]),
     'drx_shard_phase_local': (C.c_int, [C.POINTER(CdaeParams), C.POINTER(Optim), C.POINTER(Shard), C.POINTER(History), C.POINTER(Batch),

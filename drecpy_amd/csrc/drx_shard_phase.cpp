@@ -99,6 +99,35 @@ int drx_shard_exchange_sizes(const DrxCdaeParams *p, const DrxShard *sh, const i
   return DRX_OK;
 }
 
+// The geometry the phases use, laid open for tests (no device call): for exchange chunk `chunk`, per peer p the BYTE offset and size of
+//   out[0 .. 4 world)   the key exchange:      send offset, send bytes, recv offset, recv bytes   (uniq -> req)
+//   out[4 .. 8 world)   the row exchange:      send (rows_send, the owner's geometry) and recv (rows_cache, the requester's)
+//   out[8 .. 12 world)  the gradient exchange: send (grad_send, requester's) and recv (grad_recv, owner's)
+// each block as four runs of `world` values; then out[12 world] = key offset of the chunk in req, out[12 world + 1] = float offset of the
+// chunk in the owner's buffers, out[12 world + 2] = float offset of the rank's OWN piece of the chunk in grad_send (0 without the bypass).
+int drx_shard_phase_layout(const DrxCdaeParams *p, const DrxShard *sh, const int64_t *send_counts, const int64_t *recv_counts, int32_t chunk,
+                           int64_t *out) {
+  Geo g;
+  if (!p || !send_counts || !recv_counts || !out || geo_of(sh, p->ld, g) || chunk < 0 || chunk >= g.chunks) return DRX_EINVAL;
+  Geo::Chunk s, r;
+  int rc = chunk_layout(g, send_counts, chunk, s);
+  if (!rc) rc = chunk_layout(g, recv_counts, chunk, r);
+  if (rc) return rc;
+  const int W = g.world;
+  for (int q = 0; q < W; ++q) {
+    out[0 * W + q] = 4 * (s.key0 + s.key_off[q]); out[1 * W + q] = 4 * s.keys[q];
+    out[2 * W + q] = 4 * (r.key0 + r.key_off[q]); out[3 * W + q] = 4 * r.keys[q];
+    out[4 * W + q] = 4 * (r.flt0 + r.flt_off[q]); out[5 * W + q] = 4 * r.flts[q];
+    out[6 * W + q] = 4 * (s.flt0 + s.flt_off[q]); out[7 * W + q] = 4 * s.flts[q];
+    out[8 * W + q] = 4 * (s.flt0 + s.flt_off[q]); out[9 * W + q] = 4 * s.flts[q];
+    out[10 * W + q] = 4 * (r.flt0 + r.flt_off[q]); out[11 * W + q] = 4 * r.flts[q];
+  }
+  out[12 * W] = r.key0;
+  out[12 * W + 1] = r.flt0;
+  out[12 * W + 2] = g.bypass ? own_offset(g, send_counts, chunk) : 0;
+  return DRX_OK;
+}
+
 int drx_shard_phase_keys(const DrxShard *sh, DrxComm *comm, DrxShardExchange *x, void *stream) {
   Geo g;
   if (!comm || check_x(x) || geo_of(sh, 4, g)) return DRX_EINVAL;

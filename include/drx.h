@@ -446,6 +446,9 @@ typedef struct DrxShardExchange {
 } DrxShardExchange;
 int drx_shard_exchange_sizes(const DrxCdaeParams *p, const DrxShard *sh, const int64_t *send_counts, const int64_t *recv_counts,
                              int64_t *sizes4);
+/* the phases' geometry for tests (host arithmetic only): out[12 world + 3], see csrc/drx_shard_phase.cpp */
+int drx_shard_phase_layout(const DrxCdaeParams *p, const DrxShard *sh, const int64_t *send_counts, const int64_t *recv_counts, int32_t chunk,
+                           int64_t *out);
 int drx_shard_phase_keys(const DrxShard *sh, DrxComm *comm, DrxShardExchange *x, void *stream);
 int drx_shard_phase_rows(const DrxCdaeParams *p, const DrxShard *sh, DrxComm *comm, DrxShardExchange *x, int32_t chunk, void *stream);
 int drx_shard_phase_local(const DrxCdaeParams *p, const DrxOptim *opt, const DrxShard *sh, const DrxHistory *hist, const DrxBatch *bt,

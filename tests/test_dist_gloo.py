@@ -320,3 +320,54 @@ def test_exchange_sizes_of_the_library_equal_the_host_statement():
         assert list(out) == [max(32, want_req), max(32, want_own), max(32, int(recv.sum())), int(send.sum())], (world, rank, list(out))
         send[0] = 0                                    # (a unit without its sentinel: rejected)
         assert L.drx_shard_exchange_sizes(C.byref(P), C.byref(sh), send.ctypes.data, recv.ctypes.data, out) != 0
+
+
+def test_the_phases_geometry_equals_the_call_by_call_steps_at_every_world():
+    """drx_shard_phase_layout (what drx_shard_phase_keys / _rows / _tail hand the communicator: csrc/drx_shard_phase.cpp) against the
+    arithmetic of dist.ShardedCdae's call-by-call step — the form the gloo tests above hold against the oracle at world 2 / 3 / 4 / 8:
+    per exchange chunk and peer the byte offset and size of the key, row and gradient exchanges in both directions, the chunk's place in
+    the owner's buffers, the rank's own piece behind everything that travels.  On one GPU the phases only ever run at world 1; this is
+    their world > 1.  Host arithmetic only."""
+    import ctypes as C
+    from drecpy_amd import _lib
+    from drecpy_amd.dist import chunk_floats, items_per_rank, wire_chunks
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for world, rank, n_items, chunks, bypass, ld in ((2, 0, 20000, 2, True, 128), (2, 1, 20000, 2, False, 128), (3, 1, 30000, 2, True, 64),
+                                                     (4, 3, 80000, 4, True, 128), (8, 5, 1_000_000, 2, True, 128), (8, 0, 1_000_000, 1, False, 128),
+                                                     (8, 7, 1_000_000, 4, True, 52)):
+        ipr = items_per_rank(n_items, world)
+        sh = _lib.Shard(world, rank, n_items, ipr, 100, _lib.SHARD_SELF_BYPASS if bypass else 0, wire_chunks(ipr, chunks))
+        Cn = int(L.drx_shard_chunks(C.byref(sh)))
+        assert Cn == chunks
+        P = _lib.CdaeParams(100, ipr, ld, ld, None, None, None, None, None)
+        send = rng.integers(1, 4000, size=world * Cn).astype(np.int64)          # [owner * Cn + chunk]
+        recv = rng.integers(1, 4000, size=world * Cn).astype(np.int64)          # [source * Cn + chunk]
+        sc = [[int(send[o * Cn + c]) for o in range(world)] for c in range(Cn)]  # as ShardedCdae._split_counts
+        rc = [[int(recv[s * Cn + c]) for s in range(world)] for c in range(Cn)]
+
+        def xs(counts):                                                          # HipShardOps.xsplits
+            f = chunk_floats(counts, ld)
+            return [0 if (bypass and i == rank) else x for i, x in enumerate(f)]
+        cache_off = np.concatenate([[0], np.cumsum([sum(xs(sc[c])) for c in range(Cn)])])     # ShardedCdae._fetch_chunk
+        own_floats = np.concatenate([[0], np.cumsum([sum(xs(rc[c])) for c in range(Cn)])])    # (the per-chunk tensors, laid end to end)
+        for c in range(Cn):
+            out = (C.c_int64 * (12 * world + 3))()
+            assert L.drx_shard_phase_layout(C.byref(P), C.byref(sh), send.ctypes.data, recv.ctypes.data, c, out) == 0
+            o = np.array(list(out)).astype(np.int64)
+            blk = lambda b: o[b * world:(b + 1) * world]
+            k0 = sum(sum(sc[cc]) for cc in range(c))
+            r0 = sum(sum(rc[cc]) for cc in range(c))
+            cum = lambda v: np.concatenate([[0], np.cumsum(v)[:-1]])
+            # keys: uniq[k0:] split by sc[c]  ->  req, chunk after chunk, split by rc[c]
+            assert np.array_equal(blk(0), 4 * (k0 + cum(sc[c]))) and np.array_equal(blk(1), 4 * np.array(sc[c]))
+            assert np.array_equal(blk(2), 4 * (r0 + cum(rc[c]))) and np.array_equal(blk(3), 4 * np.array(rc[c]))
+            # rows: the owner's gather output of the chunk split by xsplits(rc[c])  ->  cache[cache_off[c]:] split by xsplits(sc[c])
+            assert np.array_equal(blk(4), 4 * (own_floats[c] + cum(xs(rc[c])))) and np.array_equal(blk(5), 4 * np.array(xs(rc[c])))
+            assert np.array_equal(blk(6), 4 * (cache_off[c] + cum(xs(sc[c])))) and np.array_equal(blk(7), 4 * np.array(xs(sc[c])))
+            # gradient rows: gsend[cache_off[c]:] split by xsplits(sc[c])  ->  the chunk's receive buffer split by xsplits(rc[c])
+            assert np.array_equal(blk(8), blk(6)) and np.array_equal(blk(9), blk(7))
+            assert np.array_equal(blk(10), blk(4)) and np.array_equal(blk(11), blk(5))
+            assert o[12 * world] == r0 and o[12 * world + 1] == own_floats[c]
+            own = cache_off[Cn] + sum(chunk_floats([sc[cc][rank]], ld)[0] for cc in range(c)) if bypass else 0     # ShardedCdae.step
+            assert o[12 * world + 2] == own, (world, rank, c, o[12 * world + 2], own)
