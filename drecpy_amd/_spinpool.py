@@ -46,7 +46,7 @@ class SpinWorker:
             while c[0] < nxt:
                 if c[3]:
                     return
-                if self._spin(self._p_sub, nxt, self.POLL_US):
+                if self._spin(self._p_sub, nxt, self.POLL_US) > 0:         # (1: there; 0: polled long enough; < 0: a bad pointer — treated as 0)
                     break
                 c[2] = 1                                  # nothing for a while: sleep — the client sets `go` when it sees this flag
                 if c[0] < nxt and not c[3]:
@@ -76,7 +76,7 @@ class SpinWorker:
     def _result(self, n):
         if n != self._n or n == self._taken:
             raise RuntimeError('result of a job that is not the one in flight')
-        while not self._spin(self._p_done, n, self.POLL_US):
+        while self._spin(self._p_done, n, self.POLL_US) <= 0:
             if not self._th.is_alive():
                 raise RuntimeError('the prefetch worker died')
             time.sleep(50e-6)
