@@ -549,9 +549,12 @@ class Windows:
 
     def __init__(self, steps, windows, n_events, world, dist, dev):
         self.steps, self.windows, self.world, self.dist, self.dev = steps, max(1, windows), world, dist, dev
-        # six event records per step cost ~4 % of the step: only every EVERY-th timed step carries them (r06: 8, was 4 — 100 timed steps
-        # still give a dozen timed launches of every kernel)
-        self.every = max(1, int(os.environ.get('DRX_BENCH_EVENTS_EVERY', 8)))
+        # six event records per step cost ~4 % of the step: only every EVERY-th timed step carries them (r06: was 4 — each costs
+        # ~28 us: the records between launches keep the next kernel from starting early)
+        # short windows: two event-carrying steps per window, evenly (20-step windows with a cadence of 8 alternated between two and three of
+        # them: the median window was always one of the slower kind); long windows: every 16th step
+        auto = max(8, self.steps // 2) if self.steps <= 64 else 16
+        self.every = max(1, int(os.environ.get('DRX_BENCH_EVENTS_EVERY', auto)))
         total = self.steps * self.windows
         self.evs = [[torch.cuda.Event(enable_timing=True) for _ in range(n_events)] if i % self.every == 0 else None for i in range(total)]
         for es in self.evs:
